@@ -1,0 +1,392 @@
+// api.hip -- the extern "C" surface declared in include/frcnn_hip.h: argument validation,
+// the per-image context (activation ping-pong buffers + scratch, one hipMalloc slab), and the
+// fused VGG-16 forward that enqueues every kernel of FasterRCNNModel.forward
+// (reference: models/faster_rcnn.py:80-132) on one stream with no host round trip.
+#include "common.h"
+#include <cstring>
+#include <string>
+#include <vector>
+#include <new>
+
+namespace frcnn {
+
+static thread_local std::string g_hip_error;
+void set_hip_error(hipError_t e) { g_hip_error = hipGetErrorString(e); }
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct EventRec { int cls; hipEvent_t start, stop; };
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+struct frcnn_ctx {
+    int max_h = 0, max_w = 0, max_rois = 0;
+    int max_fh = 0, max_fw = 0, a_cap = 0, pre_cap = 0;
+    void* slab = nullptr;
+    size_t slab_bytes = 0;
+    // carved buffers
+    float *act_a = nullptr, *act_b = nullptr;      // ping-pong activations (NHWC)
+    float *fm = nullptr;                           // [fh][fw][512]
+    float *rpn_trunk = nullptr;                    // [fh][fw][512]
+    float *rpn_head = nullptr;                     // [fh*fw][128]
+    float *scores = nullptr;                       // [A]
+    int32_t* sorted_idx = nullptr;                 // [pre_cap]
+    float *anchor_map = nullptr, *valid_map = nullptr;
+    float *roi_out = nullptr;                      // [max_rois][7][7][512]
+    float *fc1_out = nullptr, *fc2_out = nullptr;  // [max_rois][4096]
+    float *head_logits = nullptr;                  // [max_rois][128]
+    void* lin_ws = nullptr; size_t lin_ws_bytes = 0;
+    ProposalScratch ps{};
+    // anchor cache key
+    int anc_h = -1, anc_w = -1, anc_fh = -1, anc_fw = -1;
+    // last forward's shapes (for frcnn_ctx_tensor)
+    int last_fh = 0, last_fw = 0, last_pre = 0, last_post = 0;
+    // timing
+    bool timing = false;
+    std::vector<EventRec> recs;
+    std::vector<hipEvent_t> free_events;
+    double t_ms[FRCNN_NUM_KCLASS] = {0};
+    int64_t t_cnt[FRCNN_NUM_KCLASS] = {0};
+};
+
+namespace {
+
+struct Scope {
+    frcnn_ctx* c; int cls; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
+    Scope(frcnn_ctx* c_, int cls_, hipStream_t s_) : c(c_), cls(cls_), s(s_), on(c_ && c_->timing) {
+        if (!on) return;
+        e0 = take(); e1 = take();
+        if (!e0 || !e1) { on = false; return; }
+        (void)hipEventRecord(e0, s);
+    }
+    ~Scope() {
+        if (!on) return;
+        (void)hipEventRecord(e1, s);
+        c->recs.push_back(EventRec{cls, e0, e1});
+    }
+    hipEvent_t take() {
+        if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace
+
+extern "C" {
+
+int frcnn_abi_version(void) { return FRCNN_ABI_VERSION; }
+
+const char* frcnn_error_string(int code)
+{
+    switch (code) {
+        case FRCNN_OK: return "ok";
+        case FRCNN_EINVAL: return "invalid argument";
+        case FRCNN_EHIP: return "HIP runtime error";
+        case FRCNN_ENOMEM: return "out of device memory";
+        case FRCNN_EUNSUPPORTED: return "unsupported configuration";
+        case FRCNN_ENODEVICE: return "no gfx950 device";
+        default: return "unknown error";
+    }
+}
+
+const char* frcnn_last_hip_error(void) { return g_hip_error.c_str(); }
+
+int frcnn_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int good = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++good;
+    }
+    return good;
+}
+
+int frcnn_anchors(int image_h, int image_w, int fh, int fw, int feature_pixels,
+                  float* d_anchor_map, float* d_valid_map, void* stream)
+{
+    if (!d_anchor_map || !d_valid_map || image_h < 1 || image_w < 1) return FRCNN_EINVAL;
+    return launch_anchors(image_h, image_w, fh, fw, feature_pixels, d_anchor_map, d_valid_map, as_stream(stream));
+}
+
+int frcnn_pack_conv3x3(const float* d_w, float* d_wp, int cout, int cin, void* stream)
+{
+    if (!d_w || !d_wp) return FRCNN_EINVAL;
+    return launch_pack_conv3x3(d_w, d_wp, cout, cin, as_stream(stream));
+}
+
+int frcnn_pack_conv3x3_c3(const float* d_w, float* d_wp, int cout, void* stream)
+{
+    if (!d_w || !d_wp) return FRCNN_EINVAL;
+    return launch_pack_conv3x3_c3(d_w, d_wp, cout, as_stream(stream));
+}
+
+int frcnn_pack_fc_chw_to_hwc(const float* d_w, float* d_wp, int out_features, int channels, int pooled_hw,
+                             void* stream)
+{
+    if (!d_w || !d_wp) return FRCNN_EINVAL;
+    return launch_pack_fc_chw_to_hwc(d_w, d_wp, out_features, channels, pooled_hw, as_stream(stream));
+}
+
+int frcnn_pack_stack_rows(const float* d_w1, const float* d_b1, int n1, const float* d_w2, const float* d_b2,
+                          int n2, int k, int n_pad, float* d_w_out, float* d_b_out, void* stream)
+{
+    if (!d_w1 || !d_b1 || (n2 > 0 && (!d_w2 || !d_b2)) || !d_w_out || !d_b_out) return FRCNN_EINVAL;
+    return launch_pack_stack_rows(d_w1, d_b1, n1, d_w2, d_b2, n2, k, n_pad, d_w_out, d_b_out, as_stream(stream));
+}
+
+int frcnn_conv3x3_c3(const float* d_x, const float* d_wp, const float* d_bias, float* d_y, int H, int W,
+                     int cout, unsigned flags, void* stream)
+{
+    if (!d_x || !d_wp || !d_bias || !d_y) return FRCNN_EINVAL;
+    if (flags & FRCNN_POOL2) return FRCNN_EUNSUPPORTED;
+    return launch_conv3x3_c3(d_x, d_wp, d_bias, d_y, H, W, cout, flags, as_stream(stream));
+}
+
+int frcnn_conv3x3_nhwc(const float* d_x, const float* d_wp, const float* d_bias, float* d_y, int H, int W,
+                       int cin, int cout, unsigned flags, void* stream)
+{
+    if (!d_x || !d_wp || !d_bias || !d_y) return FRCNN_EINVAL;
+    return launch_conv3x3_nhwc(d_x, d_wp, d_bias, d_y, H, W, cin, cout, flags, as_stream(stream));
+}
+
+int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream)
+{
+    if (!d_x || !d_y) return FRCNN_EINVAL;
+    return launch_maxpool2x2(d_x, d_y, H, W, c, as_stream(stream));
+}
+
+size_t frcnn_linear_workspace_bytes(int M, int N, int K) { return linear_workspace_bytes(M, N, K); }
+
+int frcnn_linear(const float* d_a, int lda, const float* d_w, const float* d_bias, float* d_y, int ldy,
+                 int M, int N, int K, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_a || !d_w || !d_bias || !d_y) return FRCNN_EINVAL;
+    return launch_linear(d_a, lda, d_w, d_bias, d_y, ldy, M, N, K, flags, d_ws, ws_bytes, as_stream(stream));
+}
+
+int frcnn_softmax_rows(const float* d_x, int ldx, float* d_y, int M, int ncls, void* stream)
+{
+    if (!d_x || !d_y) return FRCNN_EINVAL;
+    return launch_softmax_rows(d_x, ldx, d_y, M, ncls, as_stream(stream));
+}
+
+int frcnn_rpn_proposals(frcnn_ctx* ctx, const float* d_head, int ld_head, const float* d_anchor_map,
+                        const float* d_valid_map, int fh, int fw, int image_h, int image_w, int pre_nms,
+                        int post_nms, float nms_threshold, float min_side, float* d_scores,
+                        int32_t* d_sorted_idx, float* d_props, int32_t* d_counts, void* stream)
+{
+    if (!ctx || !d_head || !d_anchor_map || !d_scores || !d_sorted_idx || !d_props || !d_counts) return FRCNN_EINVAL;
+    FRCNN_HIP_TRY(hipMemsetAsync(d_counts, 0, 4 * sizeof(int32_t), as_stream(stream)));
+    return launch_rpn_proposals(ctx->ps, d_head, ld_head, d_anchor_map, d_valid_map, fh, fw, image_h, image_w,
+                                pre_nms, post_nms, nms_threshold, min_side, d_scores, d_sorted_idx, d_props,
+                                d_counts, as_stream(stream));
+}
+
+int frcnn_nms(frcnn_ctx* ctx, const float* d_boxes, const float* d_scores, int n, float threshold,
+              int max_keep, int32_t* d_keep, int32_t* d_n_keep, void* stream)
+{
+    if (!ctx || !d_boxes || !d_scores || !d_keep || !d_n_keep) return FRCNN_EINVAL;
+    return launch_nms(ctx->ps, d_boxes, d_scores, n, threshold, max_keep, d_keep, d_n_keep, as_stream(stream));
+}
+
+int frcnn_roi_pool(const float* d_fm, int fh, int fw, int c, const float* d_rois, const int32_t* d_n_rois,
+                   int max_rois, int pooled, float spatial_scale, float* d_out, void* stream)
+{
+    if (!d_fm || !d_rois || !d_n_rois || !d_out) return FRCNN_EINVAL;
+    return launch_roi_pool(d_fm, fh, fw, c, d_rois, d_n_rois, max_rois, pooled, spatial_scale, d_out,
+                           as_stream(stream));
+}
+
+int frcnn_detections(const float* d_props, const float* d_classes, const float* d_deltas,
+                     const int32_t* d_n_rois, int max_rois, int ncls, int image_h, int image_w,
+                     float score_threshold, float nms_threshold, double* d_out, int32_t* d_out_cnt, void* stream)
+{
+    if (!d_props || !d_classes || !d_deltas || !d_n_rois || !d_out || !d_out_cnt) return FRCNN_EINVAL;
+    return launch_detections(d_props, d_classes, d_deltas, d_n_rois, max_rois, ncls, image_h, image_w,
+                             score_threshold, nms_threshold, d_out, d_out_cnt, as_stream(stream));
+}
+
+// ---- context ---------------------------------------------------------------------------------
+int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_rois)
+{
+    if (!out || max_image_h < 16 || max_image_w < 16 || max_rois < 1 || max_rois > 512) return FRCNN_EINVAL;
+    frcnn_ctx* c = new (std::nothrow) frcnn_ctx();
+    if (!c) return FRCNN_ENOMEM;
+    c->max_h = max_image_h; c->max_w = max_image_w; c->max_rois = max_rois;
+    c->max_fh = cdiv(max_image_h, 16); c->max_fw = cdiv(max_image_w, 16);   // ceil covers ResNet maps too
+    c->a_cap = c->max_fh * c->max_fw * 9;
+    if (c->a_cap < 16384) c->a_cap = 16384;      // the stand-alone NMS entry borrows this scratch
+    c->pre_cap = 16384;
+
+    const size_t act = (size_t)max_image_h * max_image_w * 64 * sizeof(float);
+    const size_t fmb = (size_t)c->max_fh * c->max_fw * 512 * sizeof(float);
+    const size_t headb = (size_t)c->max_fh * c->max_fw * 128 * sizeof(float);
+    size_t lin = 0;
+    {
+        const size_t w1 = linear_workspace_bytes(max_rois, 4096, 512 * 49);
+        const size_t w2 = linear_workspace_bytes(max_rois, 4096, 4096);
+        const size_t w3 = linear_workspace_bytes(max_rois, 128, 4096);
+        const size_t w4 = linear_workspace_bytes(c->max_fh * c->max_fw, 45, 512);
+        lin = w1; if (w2 > lin) lin = w2; if (w3 > lin) lin = w3; if (w4 > lin) lin = w4;
+    }
+    struct Item { void** p; size_t bytes; };
+    void* ps_base = nullptr;
+    Item items[] = {
+        {(void**)&c->act_a, act}, {(void**)&c->act_b, act / 2},
+        {(void**)&c->fm, fmb}, {(void**)&c->rpn_trunk, fmb}, {(void**)&c->rpn_head, headb},
+        {(void**)&c->scores, (size_t)c->a_cap * 4}, {(void**)&c->sorted_idx, (size_t)c->pre_cap * 4},
+        {(void**)&c->anchor_map, (size_t)c->a_cap * 16}, {(void**)&c->valid_map, (size_t)c->a_cap * 4},
+        {(void**)&c->roi_out, (size_t)max_rois * 49 * 512 * 4},
+        {(void**)&c->fc1_out, (size_t)max_rois * 4096 * 4}, {(void**)&c->fc2_out, (size_t)max_rois * 4096 * 4},
+        {(void**)&c->head_logits, (size_t)max_rois * 128 * 4},
+        {(void**)&c->lin_ws, lin},
+        {&ps_base, proposal_scratch_bytes(c->a_cap, c->pre_cap, 2048)},
+    };
+    size_t total = 0;
+    for (auto& it : items) total += align_up(it.bytes, 256);
+    hipError_t e = hipMalloc(&c->slab, total);
+    if (e != hipSuccess) { set_hip_error(e); delete c; return FRCNN_ENOMEM; }
+    c->slab_bytes = total;
+    unsigned char* p = static_cast<unsigned char*>(c->slab);
+    for (auto& it : items) { *it.p = p; p += align_up(it.bytes, 256); }
+    c->lin_ws_bytes = lin;
+    proposal_scratch_carve(c->ps, ps_base, c->a_cap, c->pre_cap, 2048);
+    *out = c;
+    return FRCNN_OK;
+}
+
+void frcnn_ctx_destroy(frcnn_ctx* ctx)
+{
+    if (!ctx) return;
+    for (auto& r : ctx->recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+    if (ctx->slab) (void)hipFree(ctx->slab);
+    delete ctx;
+}
+
+size_t frcnn_ctx_bytes(const frcnn_ctx* ctx) { return ctx ? ctx->slab_bytes : 0; }
+
+int frcnn_ctx_timing_enable(frcnn_ctx* ctx, int enable)
+{
+    if (!ctx) return FRCNN_EINVAL;
+    ctx->timing = enable != 0;
+    return FRCNN_OK;
+}
+
+int frcnn_ctx_timing_read(frcnn_ctx* ctx, double ms[FRCNN_NUM_KCLASS], int64_t launches[FRCNN_NUM_KCLASS], int reset)
+{
+    if (!ctx || !ms || !launches) return FRCNN_EINVAL;
+    for (auto& r : ctx->recs) {
+        FRCNN_HIP_TRY(hipEventSynchronize(r.stop));
+        float t = 0.f;
+        FRCNN_HIP_TRY(hipEventElapsedTime(&t, r.start, r.stop));
+        ctx->t_ms[r.cls] += t;
+        ctx->t_cnt[r.cls] += 1;
+        ctx->free_events.push_back(r.start);
+        ctx->free_events.push_back(r.stop);
+    }
+    ctx->recs.clear();
+    for (int i = 0; i < FRCNN_NUM_KCLASS; ++i) { ms[i] = ctx->t_ms[i]; launches[i] = ctx->t_cnt[i]; }
+    if (reset) for (int i = 0; i < FRCNN_NUM_KCLASS; ++i) { ctx->t_ms[i] = 0; ctx->t_cnt[i] = 0; }
+    return FRCNN_OK;
+}
+
+int frcnn_ctx_tensor(frcnn_ctx* c, int which, void** d_ptr, size_t* bytes)
+{
+    if (!c || !d_ptr || !bytes) return FRCNN_EINVAL;
+    const size_t fmsz = (size_t)c->last_fh * c->last_fw;
+    switch (which) {
+        case 0: *d_ptr = c->fm; *bytes = fmsz * 512 * 4; break;
+        case 1: *d_ptr = c->rpn_head; *bytes = fmsz * 128 * 4; break;
+        case 2: *d_ptr = c->scores; *bytes = fmsz * 9 * 4; break;
+        case 3: *d_ptr = c->sorted_idx; *bytes = (size_t)c->last_pre * 4; break;
+        case 4: *d_ptr = c->roi_out; *bytes = (size_t)c->last_post * 49 * 512 * 4; break;
+        case 5: *d_ptr = c->fc2_out; *bytes = (size_t)c->last_post * 4096 * 4; break;
+        case 6: *d_ptr = c->anchor_map; *bytes = fmsz * 9 * 16; break;
+        case 7: *d_ptr = c->valid_map; *bytes = fmsz * 9 * 4; break;
+        case 8: *d_ptr = c->head_logits; *bytes = (size_t)c->last_post * 128 * 4; break;
+        default: return FRCNN_EINVAL;
+    }
+    return FRCNN_OK;
+}
+
+// ---- fused forward ---------------------------------------------------------------------------
+int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_forward_params* p,
+                        const float* d_image, int H, int W, const float* d_anchor_map,
+                        const float* d_valid_map, float* d_props, float* d_classes, float* d_deltas,
+                        int32_t* d_counts, void* stream)
+{
+    if (!c || !w || !p || !d_image || !d_props || !d_classes || !d_deltas || !d_counts) return FRCNN_EINVAL;
+    if (H < 16 || W < 16 || H > c->max_h || W > c->max_w) return FRCNN_EINVAL;
+    if (p->post_nms < 1 || p->post_nms > c->max_rois || p->pre_nms < 1 || p->pre_nms > c->pre_cap) return FRCNN_EINVAL;
+    if (w->num_classes < 2 || w->num_classes > 26) return FRCNN_EUNSUPPORTED;   // ncls + 4(ncls-1) <= 128
+    for (int i = 0; i < 13; ++i) if (!w->conv_w[i] || !w->conv_b[i]) return FRCNN_EINVAL;
+    if (!w->rpn_conv_w || !w->rpn_conv_b || !w->rpn_head_w || !w->rpn_head_b || !w->fc1_w || !w->fc1_b ||
+        !w->fc2_w || !w->fc2_b || !w->head_w || !w->head_b)
+        return FRCNN_EINVAL;
+    hipStream_t s = as_stream(stream);
+    const unsigned R = FRCNN_RELU, RP = FRCNN_RELU | FRCNN_POOL2;
+    int rc;
+#define STEP(cls, call) do { Scope _sc(c, cls, s); rc = (call); } while (0); if (rc) return rc
+
+    // stage 1: feature extractor (models/vgg16.py:76-96)
+    float *A = c->act_a, *B = c->act_b;
+    int h = H, wd = W;
+    STEP(1, launch_conv3x3_c3(d_image, w->conv_w[0], w->conv_b[0], A, h, wd, 64, R, s));
+    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[1], w->conv_b[1], B, h, wd, 64, 64, RP, s));   h /= 2; wd /= 2;
+    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[2], w->conv_b[2], A, h, wd, 64, 128, R, s));
+    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[3], w->conv_b[3], B, h, wd, 128, 128, RP, s)); h /= 2; wd /= 2;
+    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[4], w->conv_b[4], A, h, wd, 128, 256, R, s));
+    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[5], w->conv_b[5], B, h, wd, 256, 256, R, s));
+    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[6], w->conv_b[6], A, h, wd, 256, 256, RP, s)); h /= 2; wd /= 2;
+    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[7], w->conv_b[7], B, h, wd, 256, 512, R, s));
+    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[8], w->conv_b[8], A, h, wd, 512, 512, R, s));
+    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[9], w->conv_b[9], B, h, wd, 512, 512, RP, s)); h /= 2; wd /= 2;
+    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[10], w->conv_b[10], A, h, wd, 512, 512, R, s));
+    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[11], w->conv_b[11], B, h, wd, 512, 512, R, s));
+    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[12], w->conv_b[12], c->fm, h, wd, 512, 512, R, s));
+    const int fh = h, fw = wd;
+    c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms;
+
+    // stage 2: RPN (models/rpn.py:88-153)
+    STEP(0, launch_conv3x3_nhwc(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, 512, 512, R, s));
+    STEP(2, launch_linear(c->rpn_trunk, 512, w->rpn_head_w, w->rpn_head_b, c->rpn_head, 128, fh * fw, 45, 512,
+                          0u, c->lin_ws, c->lin_ws_bytes, s));
+    const float* amap = d_anchor_map;
+    const float* vmap = d_valid_map;
+    if (!amap || !vmap) {
+        if (c->anc_h != H || c->anc_w != W || c->anc_fh != fh || c->anc_fw != fw) {
+            STEP(5, launch_anchors(H, W, fh, fw, 16, c->anchor_map, c->valid_map, s));
+            c->anc_h = H; c->anc_w = W; c->anc_fh = fh; c->anc_fw = fw;
+        }
+        amap = c->anchor_map; vmap = c->valid_map;
+    }
+    FRCNN_HIP_TRY(hipMemsetAsync(d_counts, 0, 4 * sizeof(int32_t), s));
+    STEP(3, launch_rpn_proposals(c->ps, c->rpn_head, 128, amap, p->allow_edge_proposals ? nullptr : vmap, fh, fw,
+                                 H, W, p->pre_nms, p->post_nms, p->rpn_nms_threshold, p->min_side, c->scores,
+                                 c->sorted_idx, d_props, d_counts, s));
+
+    // stage 3: detector (models/detector.py:65-80, models/vgg16.py:129-133)
+    const int R_ = p->post_nms;
+    STEP(4, launch_roi_pool(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
+    STEP(2, launch_linear(c->roi_out, 49 * 512, w->fc1_w, w->fc1_b, c->fc1_out, 4096, R_, 4096, 49 * 512, R,
+                          c->lin_ws, c->lin_ws_bytes, s));
+    STEP(2, launch_linear(c->fc1_out, 4096, w->fc2_w, w->fc2_b, c->fc2_out, 4096, R_, 4096, 4096, R,
+                          c->lin_ws, c->lin_ws_bytes, s));
+    const int ncls = w->num_classes, nd = (ncls - 1) * 4;
+    STEP(2, launch_linear(c->fc2_out, 4096, w->head_w, w->head_b, c->head_logits, 128, R_, ncls + nd, 4096, 0u,
+                          c->lin_ws, c->lin_ws_bytes, s));
+    STEP(5, launch_head_finish(c->head_logits, 128, R_, ncls, nd, d_classes, d_deltas, s));
+#undef STEP
+    return FRCNN_OK;
+}
+
+}  // extern "C"

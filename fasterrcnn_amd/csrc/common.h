@@ -1,0 +1,89 @@
+// common.h -- shared helpers for libfrcnn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/frcnn_hip.h"
+
+typedef float f32x4  __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace frcnn {
+
+// Record the last HIP error of this thread (read by frcnn_last_hip_error()).
+void set_hip_error(hipError_t e);
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_hip_error(e); return FRCNN_EHIP; }
+    return FRCNN_OK;
+}
+
+#define FRCNN_HIP_TRY(expr)                                   \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) { ::frcnn::set_hip_error(_e); return FRCNN_EHIP; } \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Per-kernel-class event timer (see frcnn_ctx_timing_* in the header).
+struct KernelTimer;
+
+}  // namespace frcnn
+
+// ---- launchers implemented across the .hip files (internal C++ API; the C ABI in api.hip
+//      validates arguments and forwards here) ------------------------------------------------
+namespace frcnn {
+
+int launch_anchors(int image_h, int image_w, int fh, int fw, int feature_pixels,
+                   float* anchor_map, float* valid_map, hipStream_t s);
+
+int launch_pack_conv3x3(const float* w, float* wp, int cout, int cin, hipStream_t s);
+int launch_pack_conv3x3_c3(const float* w, float* wp, int cout, hipStream_t s);
+int launch_pack_fc_chw_to_hwc(const float* w, float* wp, int out_f, int c, int phw, hipStream_t s);
+int launch_pack_stack_rows(const float* w1, const float* b1, int n1, const float* w2, const float* b2,
+                           int n2, int k, int n_pad, float* wo, float* bo, hipStream_t s);
+
+int launch_conv3x3_c3(const float* x, const float* wp, const float* b, float* y, int H, int W,
+                      int cout, unsigned flags, hipStream_t s);
+int launch_conv3x3_nhwc(const float* x, const float* wp, const float* b, float* y, int H, int W,
+                        int cin, int cout, unsigned flags, hipStream_t s);
+int launch_maxpool2x2(const float* x, float* y, int H, int W, int c, hipStream_t s);
+
+size_t linear_workspace_bytes(int M, int N, int K);
+int launch_linear(const float* a, int lda, const float* w, const float* bias, float* y, int ldy,
+                  int M, int N, int K, unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_softmax_rows(const float* x, int ldx, float* y, int M, int ncls, hipStream_t s);
+int launch_head_finish(const float* x, int ldx, int M, int ncls, int ndelta, float* classes,
+                       float* deltas, hipStream_t s);
+
+// proposal scratch layout is owned by the ctx; see proposals.hip
+struct ProposalScratch {
+    unsigned long long* keys;   // [A_cap]
+    float*    boxes_all;        // [A_cap][4]
+    float*    cand_boxes;       // [pre_cap][4]  clipped+filtered, score-descending
+    float*    cand_scores;      // [pre_cap]
+    unsigned long long* mask;   // [pre_cap][pre_cap/64]
+    int32_t*  keep;             // [post_cap]
+    int       a_cap, pre_cap, post_cap;
+};
+size_t proposal_scratch_bytes(int a_cap, int pre_cap, int post_cap);
+void   proposal_scratch_carve(ProposalScratch& ps, void* base, int a_cap, int pre_cap, int post_cap);
+
+int launch_rpn_proposals(const ProposalScratch& ps, const float* head, int ld_head,
+                         const float* anchor_map, const float* valid_map, int fh, int fw,
+                         int image_h, int image_w, int pre_nms, int post_nms, float nms_thr,
+                         float min_side, float* scores, int32_t* sorted_idx, float* props,
+                         int32_t* counts, hipStream_t s);
+int launch_nms(const ProposalScratch& ps, const float* boxes, const float* scores, int n, float thr,
+               int max_keep, int32_t* keep, int32_t* n_keep, hipStream_t s);
+
+int launch_roi_pool(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
+                    int max_rois, int pooled, float scale, float* out, hipStream_t s);
+
+int launch_detections(const float* props, const float* classes, const float* deltas,
+                      const int32_t* n_rois, int max_rois, int ncls, int image_h, int image_w,
+                      float score_thr, float nms_thr, double* out, int32_t* out_cnt, hipStream_t s);
+
+}  // namespace frcnn

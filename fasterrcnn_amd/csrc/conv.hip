@@ -1,0 +1,370 @@
+// conv.hip -- 3x3 "same" convolutions of the VGG-16 feature extractor and the RPN trunk
+// (reference: models/vgg16.py:27-47,76-96 and models/rpn.py:39,88 -- there nn.Conv2d on cuDNN).
+//
+// conv3x3_mfma_kernel: implicit GEMM on the exact-f32 matrix pipe (v_mfma_f32_32x32x2_f32):
+//   M = output pixels (32 consecutive x of one image row per MFMA tile)
+//   N = output channels (32 per MFMA tile)
+//   K = 9 taps x Cin, walked as (16-channel chunk) x (tap)
+// Activations are NHWC so a pixel's 16-channel chunk is one 64-B run: the block stages the
+// (rows+2) x 34 pixel halo of the chunk in LDS once and re-reads it for all 9 taps; the
+// tap's [BN][16] weight slice is staged per (chunk, tap) stage.  Both tiles are double buffered
+// so there is ONE barrier per stage (32 MFMAs = 2048 matrix-pipe cycles per wave).
+// LDS rows are padded 16 -> 20 floats: a ds_read_b128 lane group then touches 16 distinct
+// 16-B slots (5*i mod 16 is a bijection), i.e. conflict-free for both operands.
+// K-order trick: MFMA 32x32x2 takes k = lane>>5.  The lane half h owns channels
+// [8g+4h, 8g+4h+4) of every 8-channel group g, so one ds_read_b128 feeds four MFMAs for A and
+// one for B (a dot product does not care about the order of k as long as A and B agree).
+// Epilogue: bias + ReLU (+ the 2x2/stride-2 max-pool of vgg16.py:78,82,87,92 done in
+// registers: the wave owns two image rows, and the accumulator layout puts x, x+1 in
+// adjacent registers of one lane), then NHWC stores of 128 B per half-wave.
+#include "common.h"
+
+namespace frcnn {
+
+static constexpr int LDK = 20;   // padded LDS row (floats) of a 16-channel chunk
+static constexpr int HC  = 34;   // halo columns = 32 + 2
+
+template <int WM, int WN>
+struct ConvCfg {
+    static constexpr int TR  = 2 * WM;        // image rows per block
+    static constexpr int BN  = 64 * WN;       // output channels per block
+    static constexpr int HR  = TR + 2;        // halo rows
+    static constexpr int HALO_F = HR * HC * LDK;
+    static constexpr int WT_F   = BN * LDK;
+    static constexpr int NHP = HR * HC * 4;   // 16-B halo pieces per chunk
+    static constexpr int NH  = (NHP + 255) / 256;
+    static constexpr int NW  = BN * 4 / 256;  // 16-B weight pieces per thread per stage
+    static constexpr size_t LDS_BYTES = (size_t)(2 * HALO_F + 2 * WT_F) * sizeof(float);
+};
+
+template <int WM, int WN, bool POOL>
+__global__ __launch_bounds__(256)
+void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                         const float* __restrict__ bias, float* __restrict__ y,
+                         int H, int W, int Cin, int Cout, int relu)
+{
+    using C = ConvCfg<WM, WN>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const halo0 = smem;
+    float* const wts0  = smem + 2 * C::HALO_F;
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int x0 = blockIdx.x * 32;
+    const int y0 = blockIdx.y * C::TR;
+    const int n0 = blockIdx.z * C::BN;
+
+    // ---- loop-invariant staging addresses ------------------------------------------------
+    int h_src[C::NH];   // element offset of the piece inside x for chunk 0, or -1 (zero fill)
+    int h_dst[C::NH];   // float offset inside a halo buffer, or -1 (no piece)
+#pragma unroll
+    for (int it = 0; it < C::NH; ++it) {
+        const int q = tid + 256 * it;
+        const int pix = q >> 2, p = q & 3;
+        const int hy = pix / HC, hx = pix - hy * HC;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool have = q < C::NHP;
+        const bool inb = have && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        h_dst[it] = have ? pix * LDK + 4 * p : -1;
+        h_src[it] = inb ? (gy * W + gx) * Cin + 4 * p : -1;
+    }
+    int w_src[C::NW], w_dst[C::NW];
+#pragma unroll
+    for (int it = 0; it < C::NW; ++it) {
+        const int q = tid + 256 * it;
+        const int o = q >> 2, p = q & 3;
+        w_src[it] = (n0 + o) * Cin + 4 * p;
+        w_dst[it] = o * LDK + 4 * p;
+    }
+    const int tap_stride = Cout * Cin;
+
+    f32x4 hreg[C::NH];
+    f32x4 wreg[C::NW];
+
+    auto load_halo = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < C::NH; ++it) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (h_src[it] >= 0) v = *reinterpret_cast<const f32x4*>(x + h_src[it] + chunk * 16);
+            hreg[it] = v;
+        }
+    };
+    auto store_halo = [&](float* buf) {
+#pragma unroll
+        for (int it = 0; it < C::NH; ++it)
+            if (h_dst[it] >= 0) *reinterpret_cast<f32x4*>(buf + h_dst[it]) = hreg[it];
+    };
+    auto load_w = [&](int chunk, int tap) {
+#pragma unroll
+        for (int it = 0; it < C::NW; ++it)
+            wreg[it] = *reinterpret_cast<const f32x4*>(wp + (size_t)tap * tap_stride + w_src[it] + chunk * 16);
+    };
+    auto store_w = [&](float* buf) {
+#pragma unroll
+        for (int it = 0; it < C::NW; ++it)
+            *reinterpret_cast<f32x4*>(buf + w_dst[it]) = wreg[it];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nchunks = Cin >> 4;
+    const int nstages = nchunks * 9;
+
+    // prologue: chunk 0 halo + (chunk 0, tap 0) weights
+    load_halo(0);
+    load_w(0, 0);
+    store_halo(halo0);
+    store_w(wts0);
+    __syncthreads();
+
+    // per-lane LDS read bases (floats)
+    const int a_base = ((2 * wm) * HC + li) * LDK + 4 * lh;   // + (mt + r)*HC*LDK + s*LDK + 8g
+    const int b_base = (64 * wn + li) * LDK + 4 * lh;         // + nt*32*LDK + 8g
+
+    int chunk = 0, tap = 0, tr = 0, ts = 0;
+    for (int s = 0; s < nstages; ++s) {
+        const bool has_next = (s + 1) < nstages;
+        int nchunk = chunk, ntap = tap + 1;
+        if (ntap == 9) { ntap = 0; nchunk = chunk + 1; }
+        if (has_next) {
+            load_w(nchunk, ntap);
+            if (ntap == 0) load_halo(nchunk);
+        }
+
+        const float* hal = halo0 + (chunk & 1) * C::HALO_F + a_base + (tr * HC + ts) * LDK;
+        const float* wt  = wts0 + (s & 1) * C::WT_F + b_base;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f32x4 af[2], bf[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                af[mt] = *reinterpret_cast<const f32x4*>(hal + mt * HC * LDK + 8 * g);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                bf[nt] = *reinterpret_cast<const f32x4*>(wt + nt * 32 * LDK + 8 * g);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][kk], bf[nt][kk],
+                                                                          acc[mt][nt], 0, 0, 0);
+        }
+
+        if (has_next) {
+            store_w(wts0 + ((s + 1) & 1) * C::WT_F);
+            if (ntap == 0) store_halo(halo0 + (nchunk & 1) * C::HALO_F);
+        }
+        __syncthreads();
+        chunk = nchunk; tap = ntap;
+        ts += 1; if (ts == 3) { ts = 0; tr += 1; if (tr == 3) tr = 0; }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------
+    // acc[mt][nt][r] = out[row y0+2wm+mt][col x0 + (r&3)+8(r>>2)+4lh][cout n0+64wn+32nt+li]
+    const int orow = y0 + 2 * wm;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int co = n0 + 64 * wn + 32 * nt + li;
+        const float bv = bias[co];
+        if (!POOL) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int yy = orow + mt;
+                if (yy >= H) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int xx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (xx < W) {
+                        float v = acc[mt][nt][r] + bv;
+                        if (relu) v = fmaxf(v, 0.f);
+                        y[((size_t)yy * W + xx) * Cout + co] = v;
+                    }
+                }
+            }
+        } else {
+            const int Hp = H >> 1, Wp = W >> 1;
+            const int py = orow >> 1;
+            if (py < Hp) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int px = (x0 + (r & 3) + 8 * (r >> 2) + 4 * lh) >> 1;
+                    if (px < Wp) {
+                        float v = fmaxf(fmaxf(acc[0][nt][r], acc[0][nt][r + 1]),
+                                        fmaxf(acc[1][nt][r], acc[1][nt][r + 1])) + bv;
+                        if (relu) v = fmaxf(v, 0.f);
+                        y[((size_t)py * Wp + px) * Cout + co] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// First layer (models/vgg16.py:27,76): Cin = 3, K = 27 is too thin for the matrix pipe and the
+// layer is bound by its 4*H*W*cout-byte output write.  One thread = one pixel x 16 output
+// channels; the 27 x 16 weights of the channel group are wave-uniform (scalar loads).
+__global__ __launch_bounds__(256)
+void conv3x3_c3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                       const float* __restrict__ bias, float* __restrict__ y,
+                       int H, int W, int Cout, int relu)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int og = blockIdx.y;
+    if (pix >= H * W) return;
+    const int yy = pix / W, xx = pix - yy * W;
+    float in[27];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int gy = yy + r - 1, gx = xx + s - 1;
+                const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                in[ci * 9 + r * 3 + s] = inb ? x[((size_t)ci * H + gy) * W + gx] : 0.f;
+            }
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    const float* wg = wp + og * 16;
+#pragma unroll
+    for (int k = 0; k < 27; ++k)
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = fmaf(in[k], wg[k * Cout + o], acc[o]);
+    float* out = y + (size_t)pix * Cout + og * 16;
+#pragma unroll
+    for (int o4 = 0; o4 < 4; ++o4) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = acc[o4 * 4 + j] + bias[og * 16 + o4 * 4 + j];
+            v[j] = relu ? fmaxf(t, 0.f) : t;
+        }
+        *reinterpret_cast<f32x4*>(out + 4 * o4) = v;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void maxpool2x2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C)
+{
+    const int Hp = H >> 1, Wp = W >> 1, C4 = C >> 2;
+    const size_t total = (size_t)Hp * Wp * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const size_t p = i / C4;
+        const int px = (int)(p % Wp), py = (int)(p / Wp);
+        const f32x4* r0 = reinterpret_cast<const f32x4*>(x + ((size_t)(2 * py) * W + 2 * px) * C) + c4;
+        const f32x4* r1 = reinterpret_cast<const f32x4*>(x + ((size_t)(2 * py + 1) * W + 2 * px) * C) + c4;
+        const f32x4 a = r0[0], b = r0[C4], c = r1[0], d = r1[C4];
+        f32x4 m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(c[j], d[j]));
+        reinterpret_cast<f32x4*>(y)[i] = m;
+    }
+}
+
+// ---- weight repacking ----------------------------------------------------------------------
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin)
+{
+    const size_t total = (size_t)9 * cout * cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ci = (int)(i % cin);
+        const size_t t = i / cin;
+        const int o = (int)(t % cout);
+        const int tap = (int)(t / cout);
+        wp[i] = w[((size_t)o * cin + ci) * 9 + tap];
+    }
+}
+
+__global__ void pack_conv3x3_c3_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout)
+{
+    const int total = 27 * cout;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int o = i % cout, k = i / cout;     // k = ci*9 + r*3 + s
+        wp[i] = w[o * 27 + k];
+    }
+}
+
+template <int WM, int WN, bool POOL>
+static int launch_cfg(const float* x, const float* wp, const float* b, float* y, int H, int W,
+                      int cin, int cout, int relu, hipStream_t s)
+{
+    using C = ConvCfg<WM, WN>;
+    auto kern = conv3x3_mfma_kernel<WM, WN, POOL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(W, 32), cdiv(H, C::TR), cout / C::BN);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, x, wp, b, y, H, W, cin, cout, relu);
+    return check_launch();
+}
+
+int launch_conv3x3_nhwc(const float* x, const float* wp, const float* b, float* y, int H, int W,
+                        int cin, int cout, unsigned flags, hipStream_t s)
+{
+    if (cin % 16 != 0 || cout % 64 != 0 || H < 1 || W < 1) return FRCNN_EINVAL;
+    const int relu = (flags & FRCNN_RELU) ? 1 : 0;
+    const bool pool = (flags & FRCNN_POOL2) != 0;
+    if (pool && (H < 2 || W < 2)) return FRCNN_EINVAL;
+    // Tile choice: cout = 64 -> 8 rows x 32 cols x 64 ch; otherwise 4 rows x 32 cols x 128 ch.
+    if (cout % 128 != 0) {
+        return pool ? launch_cfg<4, 1, true>(x, wp, b, y, H, W, cin, cout, relu, s)
+                    : launch_cfg<4, 1, false>(x, wp, b, y, H, W, cin, cout, relu, s);
+    }
+    return pool ? launch_cfg<2, 2, true>(x, wp, b, y, H, W, cin, cout, relu, s)
+                : launch_cfg<2, 2, false>(x, wp, b, y, H, W, cin, cout, relu, s);
+}
+
+int launch_conv3x3_c3(const float* x, const float* wp, const float* b, float* y, int H, int W,
+                      int cout, unsigned flags, hipStream_t s)
+{
+    if (cout % 16 != 0 || H < 1 || W < 1) return FRCNN_EINVAL;
+    dim3 grid(cdiv(H * W, 256), cout / 16);
+    hipLaunchKernelGGL(conv3x3_c3_kernel, grid, dim3(256), 0, s, x, wp, b, y, H, W, cout,
+                       (flags & FRCNN_RELU) ? 1 : 0);
+    return check_launch();
+}
+
+int launch_maxpool2x2(const float* x, float* y, int H, int W, int c, hipStream_t s)
+{
+    if (c % 4 != 0 || H < 2 || W < 2) return FRCNN_EINVAL;
+    const size_t total = (size_t)(H / 2) * (W / 2) * (c / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(maxpool2x2_kernel, dim3(blocks), dim3(256), 0, s, x, y, H, W, c);
+    return check_launch();
+}
+
+int launch_pack_conv3x3(const float* w, float* wp, int cout, int cin, hipStream_t s)
+{
+    if (cout < 1 || cin < 1) return FRCNN_EINVAL;
+    const size_t total = (size_t)9 * cout * cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, s, w, wp, cout, cin);
+    return check_launch();
+}
+
+int launch_pack_conv3x3_c3(const float* w, float* wp, int cout, hipStream_t s)
+{
+    if (cout < 1) return FRCNN_EINVAL;
+    hipLaunchKernelGGL(pack_conv3x3_c3_kernel, dim3(cdiv(27 * cout, 256)), dim3(256), 0, s, w, wp, cout);
+    return check_launch();
+}
+
+}  // namespace frcnn

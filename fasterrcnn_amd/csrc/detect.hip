@@ -1,0 +1,167 @@
+// detect.hip -- final detections on the device: one block per foreground class.
+// Replaces models/faster_rcnn.py:179-224, which on the reference is 3 D2H copies, a numpy
+// float64 decode per class, and 20 x (2 H2D + torchvision nms + 1 D2H).
+//
+// Arithmetic follows the reference's numpy promotion rules exactly:
+//   :181-183  anchor centre/size from the float32 proposals IN FLOAT32, then widened to float64
+//   :192-197  convert_deltas_to_boxes (math_utils.py:91-96) in float64 with stds [.1,.1,.2,.2],
+//             means 0: d*std+mean, a_hw*d_yx + a_cyx (two roundings), a_hw*exp(d_hw), +-0.5*size
+//   :200-201  clip y to [0,H-1], x to [0,W-1]
+//   :208      keep score > threshold (float32 compare)
+//   :216-220  torchvision nms on float64 boxes: stable score-descending order, suppress iff
+//             inter/(area_i+area_j-inter) > 0.3 evaluated in float64
+//   :221-224  rows (y1,x1,y2,x2,score) float64, NMS order
+// Sorting is an LDS bitonic sort of (score bits, ~index) keys; the 512x512 IoU bit matrix lives
+// in LDS; the greedy pass is one wave holding the 8 "removed" words in lanes 0-7.
+#include "common.h"
+
+namespace frcnn {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ unsigned ordered_bits32(float f)
+{
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+static constexpr int DET_MAX = 512;
+
+__global__ __launch_bounds__(512)
+void detections_kernel(const float* __restrict__ props, const float* __restrict__ classes,
+                       const float* __restrict__ deltas, const int32_t* __restrict__ n_rois,
+                       int max_rois, int ncls, double clip_h, double clip_w, float score_thr,
+                       double nms_thr, double* __restrict__ out, int32_t* __restrict__ out_cnt)
+{
+    __shared__ u64 keys[DET_MAX];
+    __shared__ double sbox[DET_MAX][4];      // boxes in sorted order
+    __shared__ u64 mask[DET_MAX][DET_MAX / 64];
+    __shared__ int keep_list[DET_MAX];
+    __shared__ int counters[2];
+
+    const int cls = blockIdx.x + 1;
+    const int t = threadIdx.x;
+    int n = *n_rois;
+    if (n > max_rois) n = max_rois;
+    if (t == 0) { counters[0] = 0; counters[1] = 0; }
+    __syncthreads();
+
+    u64 key = 0ull;
+    if (t < n) {
+        const float score = classes[(size_t)t * ncls + cls];
+        if (score > score_thr) {
+            key = ((u64)ordered_bits32(score) << 32) | (u64)(0xFFFFFFFFu - (unsigned)t);
+            atomicAdd(&counters[0], 1);
+        }
+    }
+    keys[t] = key;
+    __syncthreads();
+    const int m = counters[0];
+
+    // bitonic sort, descending, 512 keys / 512 threads (256 compare-exchanges per pass)
+    for (int k = 2; k <= DET_MAX; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (t < DET_MAX / 2) {
+                const int i = 2 * t - (t & (j - 1));
+                const int l = i + j;
+                const bool desc = (i & k) == 0;
+                const u64 a = keys[i], b = keys[l];
+                if ((a < b) == desc) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (t < m) {
+        // decode the box of the proposal that landed on rank t
+        const int idx = (int)(0xFFFFFFFFu - (unsigned)(keys[t] & 0xFFFFFFFFull));
+        const f32x4 p = reinterpret_cast<const f32x4*>(props)[idx];
+        const double acy = (double)(0.5f * (p[0] + p[2]));
+        const double acx = (double)(0.5f * (p[1] + p[3]));
+        const double ah = (double)(p[2] - p[0]);
+        const double aw = (double)(p[3] - p[1]);
+        const float* d = deltas + (size_t)idx * (ncls - 1) * 4 + (cls - 1) * 4;
+        const double dy = __dadd_rn(__dmul_rn((double)d[0], 0.1), 0.0);
+        const double dx = __dadd_rn(__dmul_rn((double)d[1], 0.1), 0.0);
+        const double dh = __dadd_rn(__dmul_rn((double)d[2], 0.2), 0.0);
+        const double dw = __dadd_rn(__dmul_rn((double)d[3], 0.2), 0.0);
+        const double cy = __dadd_rn(__dmul_rn(ah, dy), acy);
+        const double cx = __dadd_rn(__dmul_rn(aw, dx), acx);
+        const double h = __dmul_rn(ah, exp(dh));
+        const double w = __dmul_rn(aw, exp(dw));
+        double y1 = cy - 0.5 * h, x1 = cx - 0.5 * w, y2 = cy + 0.5 * h, x2 = cx + 0.5 * w;
+        y1 = fmin(fmax(y1, 0.0), clip_h); y2 = fmin(fmax(y2, 0.0), clip_h);
+        x1 = fmin(fmax(x1, 0.0), clip_w); x2 = fmin(fmax(x2, 0.0), clip_w);
+        sbox[t][0] = y1; sbox[t][1] = x1; sbox[t][2] = y2; sbox[t][3] = x2;
+    }
+    __syncthreads();
+
+    // IoU bit matrix (row t, columns > t)
+    if (t < m) {
+        const double a0 = sbox[t][0], a1 = sbox[t][1], a2 = sbox[t][2], a3 = sbox[t][3];
+        const double sa = (a2 - a0) * (a3 - a1);
+        const int nw = (m + 63) >> 6;
+        for (int wq = 0; wq < nw; ++wq) {
+            u64 bits = 0ull;
+            const int jbeg = wq * 64;
+            if (jbeg + 63 > t) {
+                for (int j = 0; j < 64; ++j) {
+                    const int jj = jbeg + j;
+                    if (jj > t && jj < m) {
+                        const double b0 = sbox[jj][0], b1 = sbox[jj][1], b2 = sbox[jj][2], b3 = sbox[jj][3];
+                        const double d0 = fmax(fmin(a2, b2) - fmax(a0, b0), 0.0);
+                        const double d1 = fmax(fmin(a3, b3) - fmax(a1, b1), 0.0);
+                        const double inter = d0 * d1;
+                        const double sb = (b2 - b0) * (b3 - b1);
+                        if (inter / (sa + sb - inter) > nms_thr) bits |= 1ull << j;
+                    }
+                }
+            }
+            mask[t][wq] = bits;
+        }
+    }
+    __syncthreads();
+
+    // greedy pass: wave 0, lane w (< 8) owns removed word w
+    if (t < 64) {
+        u64 rem = 0ull;
+        int kept = 0;
+        const int nw = (m + 63) >> 6;
+        for (int p = 0; p < m; ++p) {
+            const unsigned lo = __shfl((unsigned)(rem & 0xFFFFFFFFull), p >> 6);
+            const unsigned hi = __shfl((unsigned)(rem >> 32), p >> 6);
+            const u64 word = ((u64)hi << 32) | lo;
+            if (!((word >> (p & 63)) & 1ull)) {
+                if (t == 0) keep_list[kept] = p;
+                ++kept;
+                if (t < nw) rem |= mask[p][t];
+            }
+        }
+        if (t == 0) counters[1] = kept;
+    }
+    __syncthreads();
+    const int kept = counters[1];
+    if (t < kept) {
+        const int p = keep_list[t];
+        const u64 k = keys[p];
+        const unsigned ob = (unsigned)(k >> 32);
+        const unsigned fb = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+        double* o = out + ((size_t)(cls - 1) * max_rois + t) * 5;
+        o[0] = sbox[p][0]; o[1] = sbox[p][1]; o[2] = sbox[p][2]; o[3] = sbox[p][3];
+        o[4] = (double)__uint_as_float(fb);
+    }
+    if (t == 0) out_cnt[cls - 1] = kept;
+}
+
+int launch_detections(const float* props, const float* classes, const float* deltas,
+                      const int32_t* n_rois, int max_rois, int ncls, int image_h, int image_w,
+                      float score_thr, float nms_thr, double* out, int32_t* out_cnt, hipStream_t s)
+{
+    if (max_rois < 1 || max_rois > DET_MAX || ncls < 2 || ncls > 64) return FRCNN_EINVAL;
+    hipLaunchKernelGGL(detections_kernel, dim3(ncls - 1), dim3(512), 0, s, props, classes, deltas, n_rois,
+                       max_rois, ncls, (double)(image_h - 1), (double)(image_w - 1), score_thr,
+                       (double)nms_thr, out, out_cnt);
+    return check_launch();
+}
+
+}  // namespace frcnn

@@ -1,0 +1,428 @@
+// proposals.hip -- RPN proposal generation without host round trips.
+// Replaces, in order (reference: models/rpn.py):
+//   :89  t.sigmoid                          \
+//   :98-104,158-173 _extract_valid            >  rpn_decode_kernel (one thread per anchor)
+//   :118-123 t_convert_deltas_to_boxes      /   (models/math_utils.py:122-127, fp32, no FMA)
+//   :129-132 argsort ascending, flip, [0:N]    topk_sort_kernel: 8-pass radix select of the
+//                                              N-th largest 64-bit key, LDS bitonic sort of the
+//                                              survivors.  key = (score bits, anchor index+1):
+//                                              unique keys -> one deterministic order; ties go
+//                                              to the HIGHER anchor index, which is what a stable
+//                                              ascending sort followed by flip() produces.
+//   :135-144 clamp, >= 16 px filter            same kernel, order-preserving scan compaction
+//   :147-153 torchvision.ops.nms(0.7)[0:N]     nms_mask_kernel (64x64 IoU bit tiles) +
+//                                              nms_reduce_kernel (one wave: 64 boxes per step,
+//                                              readlane over the diagonal word, early exit)
+#include "common.h"
+
+namespace frcnn {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ unsigned ordered_bits(float f)
+{
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned o)
+{
+    const unsigned b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(b);
+}
+
+// One thread per anchor n = (y*fw + x)*9 + k  (the reference's flat order, rpn.py:162-165).
+__global__ __launch_bounds__(256)
+void rpn_decode_kernel(const float* __restrict__ head, int ld, const float* __restrict__ anchors,
+                       const float* __restrict__ valid, int A, float* __restrict__ scores,
+                       f32x4* __restrict__ boxes_all, u64* __restrict__ keys)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= A) return;
+    const int pix = n / 9, k = n - pix * 9;
+    const float* row = head + (size_t)pix * ld;
+    const float logit = row[k];
+    const float score = 1.0f / (1.0f + expf(-logit));
+    const float dy = row[9 + 4 * k + 0], dx = row[9 + 4 * k + 1];
+    const float dh = row[9 + 4 * k + 2], dw = row[9 + 4 * k + 3];
+    const f32x4 a = reinterpret_cast<const f32x4*>(anchors)[n];   // cy, cx, h, w
+    // center = anchors[:,2:4] * deltas[:,0:2] + anchors[:,0:2]  (two roundings, as torch does)
+    const float cy = __fadd_rn(__fmul_rn(a[2], dy), a[0]);
+    const float cx = __fadd_rn(__fmul_rn(a[3], dx), a[1]);
+    const float h = __fmul_rn(a[2], expf(dh));
+    const float w = __fmul_rn(a[3], expf(dw));
+    const float hh = 0.5f * h, hw = 0.5f * w;
+    f32x4 b;
+    b[0] = cy - hh; b[1] = cx - hw; b[2] = cy + hh; b[3] = cx + hw;
+    scores[n] = score;
+    boxes_all[n] = b;
+    const bool ok = (valid == nullptr) || (valid[n] > 0.f);
+    keys[n] = ok ? (((u64)ordered_bits(score) << 32) | (u64)(unsigned)(n + 1)) : 0ull;
+}
+
+// keys for the stand-alone NMS entry: stable descending (ties -> LOWER index first).
+__global__ __launch_bounds__(256)
+void nms_keys_kernel(const float* __restrict__ scores, int n, u64* __restrict__ keys)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = ((u64)ordered_bits(scores[i]) << 32) | (u64)(0xFFFFFFFFu - (unsigned)i);
+}
+
+// Single block, 1024 threads.  Selects the K largest of n_keys 64-bit keys (zero keys are
+// "absent"), sorts them descending in LDS, then emits them.
+//   MODE 0 (RPN): idx = low-1; writes sorted_idx; clips to the image, drops boxes with a side
+//                 < min_side, compacts in order into cand_boxes/cand_scores.
+//   MODE 1 (NMS): idx = 0xFFFFFFFF-low; gathers boxes in sorted order, no clip/filter.
+// counts[0] = number selected (<= K), counts[1] = number emitted to cand_*.
+template <int MODE>
+__global__ __launch_bounds__(1024)
+void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_n,
+                      const f32x4* __restrict__ boxes_src, float image_h, float image_w, float min_side,
+                      int32_t* __restrict__ sorted_idx, f32x4* __restrict__ cand_boxes,
+                      float* __restrict__ cand_scores, int32_t* __restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64* buf = reinterpret_cast<u64*>(smem_raw);                 // [sort_n]
+    int* hist = reinterpret_cast<int*>(buf + sort_n);            // [256]
+    int* misc = hist + 256;                                      // [64]
+    const int tid = threadIdx.x;
+
+    // ---- how many keys are present ----------------------------------------------------------
+    if (tid == 0) { misc[0] = 0; misc[1] = 0; }
+    __syncthreads();
+    {
+        int c = 0;
+        for (int i = tid; i < n_keys; i += 1024) c += keys[i] != 0ull;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if ((tid & 63) == 0 && c) atomicAdd(&misc[0], c);
+    }
+    __syncthreads();
+    const int present = misc[0];
+    const int want = present < K ? present : K;
+    __syncthreads();
+
+    // ---- radix select: threshold = want-th largest key --------------------------------------
+    u64 thr = 1ull;            // all present keys
+    if (present > K) {
+        u64 prefix = 0ull, pmask = 0ull;
+        int remaining = K;
+        for (int byte = 7; byte >= 0; --byte) {
+            for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+            __syncthreads();
+            const int sh = byte * 8;
+            for (int i = tid; i < n_keys; i += 1024) {
+                const u64 k = keys[i];
+                if (k != 0ull && (k & pmask) == prefix) atomicAdd(&hist[(int)((k >> sh) & 255ull)], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int c = 0, d = 255;
+                for (; d > 0; --d) {
+                    const int hcount = hist[d];
+                    if (c + hcount >= remaining) break;
+                    c += hcount;
+                }
+                misc[2] = d; misc[3] = remaining - c;
+            }
+            __syncthreads();
+            prefix |= (u64)misc[2] << sh;
+            pmask |= 255ull << sh;
+            remaining = misc[3];
+            __syncthreads();
+        }
+        thr = prefix;
+    }
+
+    // ---- gather survivors into LDS, pad, bitonic sort descending -----------------------------
+    for (int i = tid; i < sort_n; i += 1024) buf[i] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < n_keys; i += 1024) {
+        const u64 k = keys[i];
+        if (k != 0ull && k >= thr) {
+            const int pos = atomicAdd(&misc[1], 1);
+            if (pos < sort_n) buf[pos] = k;
+        }
+    }
+    __syncthreads();
+    for (int k = 2; k <= sort_n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (sort_n >> 1); t += 1024) {
+                const int i = 2 * t - (t & (j - 1));
+                const int l = i + j;
+                const bool desc = (i & k) == 0;
+                const u64 a = buf[i], b = buf[l];
+                if ((a < b) == desc) { buf[i] = b; buf[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- emit in rank order ------------------------------------------------------------------
+    // thread t owns ranks [t*per, (t+1)*per)
+    const int per = sort_n >> 10 ? sort_n >> 10 : 1;
+    int* wave_tot = misc + 8;     // [16]
+    int local = 0;
+    for (int q = 0; q < per; ++q) {
+        const int p = tid * per + q;
+        if (p < want && p < sort_n) {
+            const u64 k = buf[p];
+            const unsigned low = (unsigned)(k & 0xFFFFFFFFull);
+            const int idx = MODE == 0 ? (int)(low - 1u) : (int)(0xFFFFFFFFu - low);
+            if (sorted_idx) sorted_idx[p] = idx;
+            if (MODE == 0) {
+                f32x4 b = boxes_src[idx];
+                b[0] = fmaxf(b[0], 0.f); b[1] = fmaxf(b[1], 0.f);
+                b[2] = fminf(b[2], image_h); b[3] = fminf(b[3], image_w);
+                const bool keep = ((b[2] - b[0]) >= min_side) && ((b[3] - b[1]) >= min_side);
+                local += keep;
+            } else {
+                local += 1;
+            }
+        }
+    }
+    // block exclusive scan of `local`
+    int incl = local;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int wv = 0; wv < (tid >> 6); ++wv) wave_off += wave_tot[wv];
+    int pos = wave_off + incl - local;
+    for (int q = 0; q < per; ++q) {
+        const int p = tid * per + q;
+        if (p < want && p < sort_n) {
+            const u64 k = buf[p];
+            const unsigned low = (unsigned)(k & 0xFFFFFFFFull);
+            const int idx = MODE == 0 ? (int)(low - 1u) : (int)(0xFFFFFFFFu - low);
+            f32x4 b = boxes_src[idx];
+            bool keep = true;
+            if (MODE == 0) {
+                b[0] = fmaxf(b[0], 0.f); b[1] = fmaxf(b[1], 0.f);
+                b[2] = fminf(b[2], image_h); b[3] = fminf(b[3], image_w);
+                keep = ((b[2] - b[0]) >= min_side) && ((b[3] - b[1]) >= min_side);
+            }
+            if (keep) {
+                cand_boxes[pos] = b;
+                cand_scores[pos] = from_ordered_bits((unsigned)(k >> 32));
+                ++pos;
+            }
+        }
+    }
+    if (tid == 1023) { counts[0] = want; counts[1] = pos; }
+}
+
+// IoU exactly as torchvision's nms kernels compute it (fp32, no +1, no epsilon):
+//   inter / (area_a + area_b - inter), suppression iff iou > thr.
+__device__ __forceinline__ bool iou_gt(const f32x4 a, const f32x4 b, float thr)
+{
+    const float l0 = fmaxf(a[0], b[0]), l1 = fmaxf(a[1], b[1]);
+    const float r0 = fminf(a[2], b[2]), r1 = fminf(a[3], b[3]);
+    const float d0 = fmaxf(r0 - l0, 0.f), d1 = fmaxf(r1 - l1, 0.f);
+    const float inter = d0 * d1;
+    const float sa = (a[2] - a[0]) * (a[3] - a[1]);
+    const float sb = (b[2] - b[0]) * (b[3] - b[1]);
+    return (inter / (sa + sb - inter)) > thr;
+}
+
+// grid (nw, nw), one wave per 64x64 tile; only tiles on or above the diagonal are written.
+__global__ __launch_bounds__(64)
+void nms_mask_kernel(const f32x4* __restrict__ boxes, const int32_t* __restrict__ n_ptr, float thr,
+                     int nw_stride, u64* __restrict__ mask)
+{
+    const int n = *n_ptr;
+    const int by = blockIdx.y, bx = blockIdx.x;
+    if (bx < by || by * 64 >= n || bx * 64 >= n) return;
+    __shared__ f32x4 colb[64];
+    const int t = threadIdx.x;
+    const int jn = bx * 64 + t;
+    colb[t] = jn < n ? boxes[jn] : f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int i = by * 64 + t;
+    if (i >= n) return;
+    const f32x4 a = boxes[i];
+    u64 bits = 0ull;
+    const int jmax = (n - bx * 64) < 64 ? (n - bx * 64) : 64;
+    for (int j = 0; j < jmax; ++j) {
+        const int jj = bx * 64 + j;
+        if (jj > i && iou_gt(a, colb[j], thr)) bits |= 1ull << j;
+    }
+    mask[(size_t)i * nw_stride + bx] = bits;
+}
+
+// One wave.  removed[] lives in registers: lane l holds words l and l+64 (capacity 8192 boxes)
+// plus words l+128, l+192 (16384).  Per 64-box chunk: lane l fetches the diagonal word of box
+// 64c+l, the wave resolves the chunk serially on a uniform 64-bit "alive" word (readlane per
+// kept box), then ORs the kept rows into removed[] with independent row loads.
+__global__ __launch_bounds__(64)
+void nms_reduce_kernel(const u64* __restrict__ mask, int nw_stride, const int32_t* __restrict__ n_ptr,
+                       int max_keep, const f32x4* __restrict__ cand_boxes,
+                       const int32_t* __restrict__ order,      // optional map to input indices
+                       int32_t* __restrict__ keep, f32x4* __restrict__ props,
+                       int32_t* __restrict__ n_keep_out)
+{
+    const int n = *n_ptr;
+    const int lane = threadIdx.x;
+    const int nw = (n + 63) >> 6;
+    u64 rem[4] = {0ull, 0ull, 0ull, 0ull};
+    __shared__ int32_t kept_list[2048];
+    int kept = 0;
+    for (int c = 0; c < nw && kept < max_keep; ++c) {
+        // removed word of this chunk (uniform)
+        const u64 mine = rem[0];
+        u64 sel = (c >> 6) == 0 ? rem[0] : (c >> 6) == 1 ? rem[1] : (c >> 6) == 2 ? rem[2] : rem[3];
+        (void)mine;
+        const unsigned lo = __shfl((unsigned)(sel & 0xFFFFFFFFull), c & 63);
+        const unsigned hi = __shfl((unsigned)(sel >> 32), c & 63);
+        const u64 cur = ((u64)hi << 32) | lo;
+        const int row = c * 64 + lane;
+        const u64 diag = row < n ? mask[(size_t)row * nw_stride + c] : 0ull;
+        const int left = n - c * 64;
+        const u64 validm = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        u64 alive = ~cur & validm;
+        u64 keepbits = 0ull;
+        while (alive != 0ull && kept < max_keep) {
+            const int b = __ffsll((long long)alive) - 1;
+            keepbits |= 1ull << b;
+            if (lane == 0) kept_list[kept] = c * 64 + b;
+            ++kept;
+            const unsigned dlo = __shfl((unsigned)(diag & 0xFFFFFFFFull), b);
+            const unsigned dhi = __shfl((unsigned)(diag >> 32), b);
+            alive &= ~(((u64)dhi << 32) | dlo);
+            alive &= ~(1ull << b);
+        }
+        if (kept >= max_keep) break;
+        // OR the kept rows into removed[] for words > c
+        u64 kb = keepbits;
+        while (kb != 0ull) {
+            const int b = __ffsll((long long)kb) - 1;
+            kb &= kb - 1ull;
+            const u64* mrow = mask + (size_t)(c * 64 + b) * nw_stride;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int w = lane + 64 * q;
+                if (w > c && w < nw) rem[q] |= mrow[w];
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = lane; k < max_keep; k += 64) {
+        if (k < kept) {
+            const int ci = kept_list[k];
+            if (keep) keep[k] = order ? order[ci] : ci;
+            if (props) props[k] = cand_boxes[ci];
+        } else {
+            if (props) props[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    if (lane == 0) *n_keep_out = kept;
+}
+
+// ---- host side ------------------------------------------------------------------------------
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t proposal_scratch_bytes(int a_cap, int pre_cap, int post_cap)
+{
+    size_t b = 0;
+    b += align_up((size_t)a_cap * 8, 256);                       // keys
+    b += align_up((size_t)a_cap * 16, 256);                      // boxes_all
+    b += align_up((size_t)pre_cap * 16, 256);                    // cand_boxes
+    b += align_up((size_t)pre_cap * 4, 256);                     // cand_scores
+    b += align_up((size_t)pre_cap * (pre_cap / 64) * 8, 256);    // mask
+    b += align_up((size_t)post_cap * 4, 256);                    // keep
+    return b;
+}
+
+void proposal_scratch_carve(ProposalScratch& ps, void* base, int a_cap, int pre_cap, int post_cap)
+{
+    unsigned char* p = static_cast<unsigned char*>(base);
+    ps.keys = reinterpret_cast<u64*>(p);         p += align_up((size_t)a_cap * 8, 256);
+    ps.boxes_all = reinterpret_cast<float*>(p);  p += align_up((size_t)a_cap * 16, 256);
+    ps.cand_boxes = reinterpret_cast<float*>(p); p += align_up((size_t)pre_cap * 16, 256);
+    ps.cand_scores = reinterpret_cast<float*>(p); p += align_up((size_t)pre_cap * 4, 256);
+    ps.mask = reinterpret_cast<u64*>(p);         p += align_up((size_t)pre_cap * (pre_cap / 64) * 8, 256);
+    ps.keep = reinterpret_cast<int32_t*>(p);
+    ps.a_cap = a_cap; ps.pre_cap = pre_cap; ps.post_cap = post_cap;
+}
+
+static int pow2_at_least(int v) { int p = 1024; while (p < v) p <<= 1; return p; }
+
+template <int MODE>
+static int launch_topk(const u64* keys, int n_keys, int K, const float* boxes_src, float ih, float iw,
+                       float min_side, int32_t* sorted_idx, float* cand_boxes, float* cand_scores,
+                       int32_t* counts, hipStream_t s)
+{
+    const int sort_n = pow2_at_least(K);
+    if (sort_n > 16384) return FRCNN_EUNSUPPORTED;
+    const size_t lds = (size_t)sort_n * 8 + 256 * 4 + 64 * 4;
+    auto kern = topk_sort_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + 2048));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, s, keys, n_keys, K, sort_n,
+                       reinterpret_cast<const f32x4*>(boxes_src), ih, iw, min_side, sorted_idx,
+                       reinterpret_cast<f32x4*>(cand_boxes), cand_scores, counts);
+    return check_launch();
+}
+
+int launch_rpn_proposals(const ProposalScratch& ps, const float* head, int ld_head,
+                         const float* anchor_map, const float* valid_map, int fh, int fw,
+                         int image_h, int image_w, int pre_nms, int post_nms, float nms_thr,
+                         float min_side, float* scores, int32_t* sorted_idx, float* props,
+                         int32_t* counts, hipStream_t s)
+{
+    const int A = fh * fw * 9;
+    if (A < 1 || A > ps.a_cap || pre_nms < 1 || pre_nms > ps.pre_cap || post_nms < 1 ||
+        post_nms > ps.post_cap || post_nms > 2048 || ld_head < 45)
+        return FRCNN_EINVAL;
+    hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(A, 256)), dim3(256), 0, s, head, ld_head, anchor_map,
+                       valid_map, A, scores, reinterpret_cast<f32x4*>(ps.boxes_all), ps.keys);
+    int rc = check_launch();
+    if (rc) return rc;
+    rc = launch_topk<0>(ps.keys, A, pre_nms, ps.boxes_all, (float)image_h, (float)image_w, min_side,
+                        sorted_idx, ps.cand_boxes, ps.cand_scores, counts, s);
+    if (rc) return rc;
+    const int nw = cdiv(pre_nms, 64);
+    const int nw_stride = ps.pre_cap / 64;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, nw), dim3(64), 0, s,
+                       reinterpret_cast<const f32x4*>(ps.cand_boxes), counts + 1, nms_thr, nw_stride, ps.mask);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(64), 0, s, ps.mask, nw_stride, counts + 1, post_nms,
+                       reinterpret_cast<const f32x4*>(ps.cand_boxes), (const int32_t*)nullptr,
+                       (int32_t*)nullptr, reinterpret_cast<f32x4*>(props), counts + 2);
+    return check_launch();
+}
+
+int launch_nms(const ProposalScratch& ps, const float* boxes, const float* scores, int n, float thr,
+               int max_keep, int32_t* keep, int32_t* n_keep, hipStream_t s)
+{
+    if (n < 0 || n > ps.pre_cap || n > ps.a_cap || max_keep < 1 || max_keep > 2048) return FRCNN_EINVAL;
+    if (n == 0) {
+        FRCNN_HIP_TRY(hipMemsetAsync(n_keep, 0, sizeof(int32_t), s));
+        return FRCNN_OK;
+    }
+    hipLaunchKernelGGL(nms_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, scores, n, ps.keys);
+    int rc = check_launch();
+    if (rc) return rc;
+    // sorted order -> ps.keep is too small for n indices; reuse boxes_all's tail as int scratch
+    int32_t* order = reinterpret_cast<int32_t*>(ps.boxes_all);
+    int32_t* counts = order + ps.a_cap;          // boxes_all holds 4*a_cap floats; use [a_cap, a_cap+4)
+    rc = launch_topk<1>(ps.keys, n, n, boxes, 0.f, 0.f, 0.f, order, ps.cand_boxes, ps.cand_scores, counts, s);
+    if (rc) return rc;
+    const int nw = cdiv(n, 64);
+    const int nw_stride = ps.pre_cap / 64;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, nw), dim3(64), 0, s,
+                       reinterpret_cast<const f32x4*>(ps.cand_boxes), counts + 1, thr, nw_stride, ps.mask);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(64), 0, s, ps.mask, nw_stride, counts + 1, max_keep,
+                       reinterpret_cast<const f32x4*>(ps.cand_boxes), order, keep, (f32x4*)nullptr, n_keep);
+    return check_launch();
+}
+
+}  // namespace frcnn

@@ -1,0 +1,237 @@
+/*
+ * frcnn_hip.h -- C ABI of libfrcnn_hip.so, the MI355X (gfx950) Faster R-CNN inference hot path.
+ *
+ * The reference (trzy/FasterRCNN, pytorch tree) has no FFI: its hot path is Python calling
+ * torch / torchvision native kernels.  Each entry point below replaces one of those call sites;
+ * the reference file:line it stands in for is cited per function (paths relative to
+ * /root/reference/pytorch/FasterRCNN/).  INTEGRATION.md shows the ctypes stub a maintainer of
+ * the reference would add to bind them.
+ *
+ * Conventions (all functions):
+ *   - return int: 0 = FRCNN_OK, negative = error code below; never throws, never aborts.
+ *   - every pointer named d_* / marked "device" is a DEVICE pointer owned by the caller
+ *     (e.g. a torch allocation); nothing is allocated behind the caller's back except inside
+ *     an frcnn_ctx (frcnn_ctx_create / frcnn_ctx_destroy).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued
+ *     asynchronously on it, no host synchronisation unless stated.
+ *   - activations are float32, NHWC ("pixel-major, channel-contiguous") unless stated; the
+ *     network input is the reference's NCHW float32 image.
+ *   - box layout is the reference's (y1, x1, y2, x2) in image pixels; anchors are
+ *     (center_y, center_x, height, width).
+ */
+#ifndef FRCNN_HIP_H
+#define FRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRCNN_OK            0
+#define FRCNN_EINVAL       -1   /* bad argument (null pointer, shape not supported by the kernel) */
+#define FRCNN_EHIP         -2   /* a HIP runtime call failed; see frcnn_last_hip_error() */
+#define FRCNN_ENOMEM       -3   /* workspace allocation failed */
+#define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
+#define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
+
+#define FRCNN_ABI_VERSION 1
+
+/* flags for frcnn_conv3x3_nhwc / frcnn_linear */
+#define FRCNN_RELU   1u
+#define FRCNN_POOL2  2u   /* fuse MaxPool2d(2, stride 2, floor) into the conv epilogue */
+
+int         frcnn_abi_version(void);
+const char* frcnn_error_string(int code);
+/* hipGetErrorString of the last HIP failure seen by this thread ("" if none). */
+const char* frcnn_last_hip_error(void);
+/* Number of visible devices whose gcnArchName starts with "gfx950"; <0 on error. */
+int         frcnn_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Anchors.  Replaces models/anchors.py:43-135 generate_anchor_maps (float64 math, one final
+ * cast to float32 -- reproduced bit-exactly).
+ *   d_anchor_map : float32 [fh][fw][9*4]  (cy, cx, h, w) per anchor, k = area-major/aspect-minor
+ *   d_valid_map  : float32 [fh][fw][9]    1.0 if the anchor lies inside the image else 0.0
+ * ---------------------------------------------------------------------------------------- */
+int frcnn_anchors(int image_h, int image_w, int fh, int fw, int feature_pixels,
+                  float* d_anchor_map, float* d_valid_map, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight repacking (run once at load; device -> device).
+ * ---------------------------------------------------------------------------------------- */
+/* OIHW [cout][cin][3][3] -> tap-major [9][cout][cin] (cin contiguous) for frcnn_conv3x3_nhwc. */
+int frcnn_pack_conv3x3(const float* d_w_oihw, float* d_w_packed, int cout, int cin, void* stream);
+/* OIHW [cout][3][3][3] -> [27][cout] (k = ci*9 + r*3 + s major) for frcnn_conv3x3_c3. */
+int frcnn_pack_conv3x3_c3(const float* d_w_oihw, float* d_w_packed, int cout, void* stream);
+/* fc1 [out][c*ph*pw] (reference flatten order C,7,7: vgg16.py:129) -> [out][(p)*C + c]
+ * so that it consumes the NHWC RoI-pool output directly. */
+int frcnn_pack_fc_chw_to_hwc(const float* d_w, float* d_w_packed, int out_features, int channels,
+                             int pooled_hw, void* stream);
+/* Stack row-major matrices [n1][k] and [n2][k] into [n_pad][k] (rows >= n1+n2 zero) and the
+ * biases into [n_pad].  Used for the RPN 1x1 heads (rpn.py:40-41) and the detector heads
+ * (detector.py:29-30). */
+int frcnn_pack_stack_rows(const float* d_w1, const float* d_b1, int n1,
+                          const float* d_w2, const float* d_b2, int n2,
+                          int k, int n_pad, float* d_w_out, float* d_b_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolutions.  Replace nn.Conv2d(3x3, stride 1, "same") + F.relu (+ nn.MaxPool2d(2,2)) at
+ * models/vgg16.py:76-96 and models/rpn.py:88.
+ * ---------------------------------------------------------------------------------------- */
+/* First layer: Cin = 3, input NCHW float32 [3][H][W], output NHWC [H][W][cout]; cout % 16 == 0.
+ * d_w_packed from frcnn_pack_conv3x3_c3. */
+int frcnn_conv3x3_c3(const float* d_x_chw, const float* d_w_packed, const float* d_bias,
+                     float* d_y, int H, int W, int cout, unsigned flags, void* stream);
+/* General layer on the f32 MFMA pipe: x NHWC [H][W][cin], y NHWC [H][W][cout] or, with
+ * FRCNN_POOL2, [H/2][W/2][cout].  Requires cin % 16 == 0, cout % 64 == 0.
+ * d_w_packed from frcnn_pack_conv3x3. */
+int frcnn_conv3x3_nhwc(const float* d_x, const float* d_w_packed, const float* d_bias,
+                       float* d_y, int H, int W, int cin, int cout, unsigned flags, void* stream);
+/* Stand-alone 2x2/stride-2 floor max-pool on NHWC (vgg16.py:78,82,87,92), c % 4 == 0. */
+int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense layers on the f32 MFMA pipe.  Replace nn.Linear (+ReLU) at models/vgg16.py:130-132,
+ * models/detector.py:76,78 and the two 1x1 convolutions at models/rpn.py:89-90.
+ *   y[m][n] = act( sum_k a[m*lda + k] * w[n*k_dim + k] + bias[n] ),  m < M, n < N
+ * w is row-major [n_rows][K] with n_rows >= N rounded up to 128 (extra rows must be readable;
+ * frcnn_pack_stack_rows zero-fills them).  K % 16 == 0.  `d_ws` is split-K scratch of at least
+ * frcnn_linear_workspace_bytes(M, N, K) bytes (may be NULL if that returns 0).
+ * ---------------------------------------------------------------------------------------- */
+size_t frcnn_linear_workspace_bytes(int M, int N, int K);
+int frcnn_linear(const float* d_a, int lda, const float* d_w, const float* d_bias,
+                 float* d_y, int ldy, int M, int N, int K, unsigned flags,
+                 void* d_ws, size_t ws_bytes, void* stream);
+/* Row softmax over the first `ncls` columns of x[m*ldx ..] -> y[m*ncls ..] (detector.py:77). */
+int frcnn_softmax_rows(const float* d_x, int ldx, float* d_y, int M, int ncls, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RPN proposal generation.  Replaces models/rpn.py:89 (sigmoid), :98-104 (_extract_valid),
+ * :118-123 + models/math_utils.py:99-128 (decode), :129-132 (argsort/flip/top-N),
+ * :135-144 (clip, >=16 px filter), :147-153 (torchvision.ops.nms 0.7, first N).
+ *
+ *   d_head      : float32 [fh*fw][ld_head]; columns 0..8 objectness logits, 9..44 box deltas
+ *                 (ty,tx,th,tw per anchor) -- the fused 1x1 head output
+ *   d_anchor_map: float32 [fh*fw*9][4];  d_valid_map: float32 [fh*fw*9] or NULL
+ *                 (NULL == allow_edge_proposals=True, models/faster_rcnn.py:36)
+ * Outputs (device):
+ *   d_scores    : float32 [A]       sigmoid objectness per anchor (A = fh*fw*9), reference order
+ *   d_sorted_idx: int32   [pre_nms] flat anchor index of the top-N, score-descending; ties are
+ *                 broken by HIGHER anchor index first (what stable-ascending argsort + flip gives)
+ *   d_props     : float32 [post_nms][4] kept proposals (y1,x1,y2,x2), rows >= *d_n_props zeroed
+ *   d_counts    : int32 [4] = { n_candidates (<=pre_nms), n_after_size_filter, n_props, 0 }
+ * `ctx` supplies scratch (keys, decoded boxes, NMS mask).  pre_nms <= 16384, post_nms <= 2048.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct frcnn_ctx frcnn_ctx;
+
+int frcnn_rpn_proposals(frcnn_ctx* ctx, const float* d_head, int ld_head,
+                        const float* d_anchor_map, const float* d_valid_map,
+                        int fh, int fw, int image_h, int image_w,
+                        int pre_nms, int post_nms, float nms_threshold, float min_side,
+                        float* d_scores, int32_t* d_sorted_idx, float* d_props, int32_t* d_counts,
+                        void* stream);
+
+/* Stand-alone greedy NMS, float32 boxes (any consistent corner order), replaces
+ * torchvision.ops.nms as called at models/rpn.py:147-151: scores are sorted stably descending,
+ * box j is suppressed by an earlier kept box i iff inter/(area_i+area_j-inter) > threshold.
+ * d_keep receives up to max_keep indices into the INPUT order (score-descending), d_n_keep the
+ * count.  n <= 16384. */
+int frcnn_nms(frcnn_ctx* ctx, const float* d_boxes, const float* d_scores, int n, float threshold,
+              int max_keep, int32_t* d_keep, int32_t* d_n_keep, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RoI max pooling.  Replaces torchvision.ops.RoIPool((7,7), 1/16) at models/detector.py:27,72
+ * including the (y1,x1,y2,x2)->(x1,y1,x2,y2) column swap at :65-69.
+ *   d_fm   : float32 NHWC [fh][fw][c];   d_rois : float32 [max_rois][4] (y1,x1,y2,x2) pixels
+ *   d_n_rois: device int32, rows >= *d_n_rois produce zeros
+ *   d_out  : float32 [max_rois][pooled][pooled][c]  (NHWC per RoI)
+ * ---------------------------------------------------------------------------------------- */
+int frcnn_roi_pool(const float* d_fm, int fh, int fw, int c, const float* d_rois,
+                   const int32_t* d_n_rois, int max_rois, int pooled, float spatial_scale,
+                   float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Final detections.  Replaces models/faster_rcnn.py:179-224 (the numpy float64 decode with
+ * stds [.1,.1,.2,.2], clip to [0,H-1]/[0,W-1], score > threshold, per-class
+ * torchvision.ops.nms(0.3) on float64 boxes) without the 20 host round trips.
+ *   d_props  : float32 [max_rois][4]; d_classes: float32 [max_rois][ncls] (softmax);
+ *   d_deltas : float32 [max_rois][(ncls-1)*4]; d_n_rois: device int32
+ * Outputs:
+ *   d_out    : float64 [(ncls-1)][max_rois][5]  rows (y1,x1,y2,x2,score) in NMS (score-desc) order
+ *   d_out_cnt: int32   [(ncls-1)]               rows valid per class (class c -> index c-1)
+ * max_rois <= 512.
+ * ---------------------------------------------------------------------------------------- */
+int frcnn_detections(const float* d_props, const float* d_classes, const float* d_deltas,
+                     const int32_t* d_n_rois, int max_rois, int ncls,
+                     int image_h, int image_w, float score_threshold, float nms_threshold,
+                     double* d_out, int32_t* d_out_cnt, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Context + fused VGG-16 forward.  Replaces FasterRCNNModel.forward
+ * (models/faster_rcnn.py:80-132) for the VGG-16 backbone (models/vgg16.py:22-158): one call
+ * enqueues every kernel of stage 1-3 on `stream`, no host round trip.
+ * One ctx per in-flight image (it owns the activation ping-pong buffers and scratch);
+ * a ctx is not re-entrant, different ctxs are independent.
+ * ---------------------------------------------------------------------------------------- */
+int  frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_rois);
+void frcnn_ctx_destroy(frcnn_ctx* ctx);
+size_t frcnn_ctx_bytes(const frcnn_ctx* ctx);
+
+typedef struct frcnn_vgg16_weights {
+    const float* conv_w[13];   /* [0]: frcnn_pack_conv3x3_c3, [1..12]: frcnn_pack_conv3x3     */
+    const float* conv_b[13];
+    const float* rpn_conv_w;   /* frcnn_pack_conv3x3 of _rpn_conv1                            */
+    const float* rpn_conv_b;
+    const float* rpn_head_w;   /* frcnn_pack_stack_rows(_rpn_class, _rpn_boxes) -> [128][512] */
+    const float* rpn_head_b;   /* [128]                                                       */
+    const float* fc1_w;        /* frcnn_pack_fc_chw_to_hwc(_fc1) [4096][25088]                */
+    const float* fc1_b;
+    const float* fc2_w;        /* [4096][4096] as stored                                      */
+    const float* fc2_b;
+    const float* head_w;       /* frcnn_pack_stack_rows(_classifier, _regressor) -> [128][4096] */
+    const float* head_b;       /* [128]                                                       */
+    int32_t num_classes;       /* 21 for VOC                                                  */
+} frcnn_vgg16_weights;
+
+typedef struct frcnn_forward_params {
+    int32_t pre_nms;            /* 6000  (models/faster_rcnn.py:124) */
+    int32_t post_nms;           /* 300   (models/faster_rcnn.py:125) */
+    float   rpn_nms_threshold;  /* 0.7   (models/rpn.py:150)         */
+    float   min_side;           /* 16    (models/rpn.py:142)         */
+    int32_t allow_edge_proposals; /* 1   (models/faster_rcnn.py:36)  */
+} frcnn_forward_params;
+
+/* d_image: float32 NCHW [3][H][W] (preprocessed as models/vgg16.py:146 prescribes).
+ * d_anchor_map / d_valid_map: optional caller-provided maps (faster_rcnn.py:113-115); NULL =
+ * generate (and cache per shape) inside the ctx.
+ * Outputs (device, caller-owned): d_props [post_nms][4], d_classes [post_nms][ncls],
+ * d_deltas [post_nms][(ncls-1)*4], d_counts int32[4] as in frcnn_rpn_proposals. */
+int frcnn_vgg16_forward(frcnn_ctx* ctx, const frcnn_vgg16_weights* w, const frcnn_forward_params* p,
+                        const float* d_image, int H, int W,
+                        const float* d_anchor_map, const float* d_valid_map,
+                        float* d_props, float* d_classes, float* d_deltas, int32_t* d_counts,
+                        void* stream);
+
+/* Introspection for parity tests: device pointers of intermediate tensors of the LAST forward
+ * on this ctx.  which: 0 feature map NHWC [fh][fw][512], 1 RPN head [fh*fw][128],
+ * 2 objectness scores [A], 3 sorted anchor indices int32 [pre_nms], 4 RoI-pool out
+ * [post_nms][7][7][512], 5 fc2 output [post_nms][4096], 6 anchor map, 7 valid map,
+ * 8 head logits [post_nms][128].  Returns FRCNN_EINVAL for unknown ids. */
+int frcnn_ctx_tensor(frcnn_ctx* ctx, int which, void** d_ptr, size_t* bytes);
+
+/* Per-kernel-class HIP-event timing for bench.py's roofline block: when enabled, every launch
+ * of class `k` inside frcnn_vgg16_forward is bracketed by events on the launch stream.
+ * classes: 0 conv3x3 MFMA (backbone+RPN), 1 conv first layer, 2 linear MFMA, 3 proposals,
+ * 4 roi_pool, 5 other.  frcnn_ctx_timing_read synchronises the recorded events and returns
+ * accumulated milliseconds and launch counts since the last reset. */
+#define FRCNN_NUM_KCLASS 6
+int frcnn_ctx_timing_enable(frcnn_ctx* ctx, int enable);
+int frcnn_ctx_timing_read(frcnn_ctx* ctx, double ms[FRCNN_NUM_KCLASS], int64_t launches[FRCNN_NUM_KCLASS],
+                          int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRCNN_HIP_H */
