@@ -1,0 +1,146 @@
+"""
+ctypes binding of include/frcnn_hip.h (libfrcnn_hip.so).
+
+The library is built in-tree by `python -m fasterrcnn_amd.build` (or `__graft_entry__.build()`)
+and loaded lazily.  Loading failures are LOUD (RuntimeError with the build hint): there is no
+fallback implementation of any kernel.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfrcnn_hip.so")
+
+OK = 0
+ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
+          -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
+RELU = 1
+POOL2 = 2
+NUM_KCLASS = 6
+KCLASS_NAMES = ("conv3x3_mfma", "conv3x3_c3", "linear_mfma", "proposals", "roi_pool", "other")
+
+# Every symbol include/frcnn_hip.h declares (tests check the .so exports all of them).
+SYMBOLS = (
+    "frcnn_abi_version", "frcnn_error_string", "frcnn_last_hip_error", "frcnn_device_count",
+    "frcnn_anchors", "frcnn_pack_conv3x3", "frcnn_pack_conv3x3_c3", "frcnn_pack_fc_chw_to_hwc",
+    "frcnn_pack_stack_rows", "frcnn_conv3x3_c3", "frcnn_conv3x3_nhwc", "frcnn_maxpool2x2_nhwc",
+    "frcnn_linear_workspace_bytes", "frcnn_linear", "frcnn_softmax_rows", "frcnn_rpn_proposals",
+    "frcnn_nms", "frcnn_roi_pool", "frcnn_detections", "frcnn_ctx_create", "frcnn_ctx_destroy",
+    "frcnn_ctx_bytes", "frcnn_vgg16_forward", "frcnn_ctx_tensor", "frcnn_ctx_timing_enable",
+    "frcnn_ctx_timing_read",
+)
+
+
+class FrcnnError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__("%s failed: %s (%d)%s" % (where, ERRORS.get(code, "?"), code,
+                                                   (": " + detail) if detail else ""))
+
+
+class VGG16Weights(C.Structure):
+    _fields_ = [
+        ("conv_w", C.c_void_p * 13), ("conv_b", C.c_void_p * 13),
+        ("rpn_conv_w", C.c_void_p), ("rpn_conv_b", C.c_void_p),
+        ("rpn_head_w", C.c_void_p), ("rpn_head_b", C.c_void_p),
+        ("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p),
+        ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p),
+        ("head_w", C.c_void_p), ("head_b", C.c_void_p),
+        ("num_classes", C.c_int32),
+    ]
+
+
+class ForwardParams(C.Structure):
+    _fields_ = [("pre_nms", C.c_int32), ("post_nms", C.c_int32), ("rpn_nms_threshold", C.c_float),
+                ("min_side", C.c_float), ("allow_edge_proposals", C.c_int32)]
+
+
+_lib = None
+
+_vp, _i, _u, _f, _sz = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_size_t
+
+_SIGNATURES = {
+    "frcnn_abi_version": (C.c_int, []),
+    "frcnn_error_string": (C.c_char_p, [_i]),
+    "frcnn_last_hip_error": (C.c_char_p, []),
+    "frcnn_device_count": (C.c_int, []),
+    "frcnn_anchors": (C.c_int, [_i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "frcnn_pack_conv3x3": (C.c_int, [_vp, _vp, _i, _i, _vp]),
+    "frcnn_pack_conv3x3_c3": (C.c_int, [_vp, _vp, _i, _vp]),
+    "frcnn_pack_fc_chw_to_hwc": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "frcnn_pack_stack_rows": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "frcnn_conv3x3_c3": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp]),
+    "frcnn_conv3x3_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp]),
+    "frcnn_maxpool2x2_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "frcnn_linear_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "frcnn_linear": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_softmax_rows": (C.c_int, [_vp, _i, _vp, _i, _i, _vp]),
+    "frcnn_rpn_proposals": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f,
+                                      _vp, _vp, _vp, _vp, _vp]),
+    "frcnn_nms": (C.c_int, [_vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp]),
+    "frcnn_roi_pool": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "frcnn_detections": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "frcnn_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), _i, _i, _i]),
+    "frcnn_ctx_destroy": (None, [_vp]),
+    "frcnn_ctx_bytes": (C.c_size_t, [_vp]),
+    "frcnn_vgg16_forward": (C.c_int, [_vp, C.POINTER(VGG16Weights), C.POINTER(ForwardParams), _vp, _i, _i,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "frcnn_ctx_tensor": (C.c_int, [_vp, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "frcnn_ctx_timing_enable": (C.c_int, [_vp, _i]),
+    "frcnn_ctx_timing_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), _i]),
+}
+
+
+def lib():
+    """Returns the loaded library; raises RuntimeError (never falls back) if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "fasterrcnn_amd: %s is missing. Build it with `python -m fasterrcnn_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path." % LIB_PATH)
+    try:
+        handle = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError("fasterrcnn_amd: cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name in SYMBOLS:
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise RuntimeError("fasterrcnn_amd: %s does not export %s (stale build?)" % (LIB_PATH, name)) from e
+        restype, argtypes = _SIGNATURES[name]
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if handle.frcnn_abi_version() != 1:
+        raise RuntimeError("fasterrcnn_amd: ABI version mismatch in %s" % LIB_PATH)
+    _lib = handle
+    return _lib
+
+
+def check(rc, where):
+    if rc != OK:
+        detail = ""
+        if rc == -2:
+            detail = lib().frcnn_last_hip_error().decode("utf-8", "replace")
+        raise FrcnnError(rc, where, detail)
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return s.cuda_stream
+
+
+def require_gpu():
+    """Raises unless a gfx950 device is visible to BOTH torch and the HIP library."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("fasterrcnn_amd: no GPU visible to torch; this path only runs on MI355X (gfx950)")
+    if lib().frcnn_device_count() < 1:
+        raise RuntimeError("fasterrcnn_amd: no gfx950 device found by libfrcnn_hip.so")

@@ -1,0 +1,222 @@
+"""
+FasterRCNNModel, mirroring pytorch/FasterRCNN/models/faster_rcnn.py:27-226 (constructor,
+`forward`, `predict`).  Same constructor arguments, attribute names (`backbone`,
+`_stage1_feature_extractor`, `_stage2_region_proposal_network`, `_stage3_detector_network` ->
+identical state_dict keys), same return types.
+
+Differences that are deliberate:
+  * every stage runs as HIP kernels behind include/frcnn_hip.h; `forward` is ONE C call
+    (`frcnn_vgg16_forward`) that enqueues all kernels on the current stream, `predict` adds the
+    on-device float64 decode + per-class NMS (`frcnn_detections`) and a single D2H copy instead
+    of the reference's 3 + 20x3 host round trips (faster_rcnn.py:175-177,216-220);
+  * anchor maps are generated on the device once per image shape and cached
+    (the reference recomputes them on the CPU per call, faster_rcnn.py:113-115);
+  * `predict_async` / `Pending.result` expose the same computation with several images in flight
+    on separate streams (each image is still an independent batch-1 forward);
+  * `train_step` and the samplers (faster_rcnn.py:228-561) are outside the inference hot path.
+There is no CPU / eager fallback: parameters must live on an MI355X (`.cuda()`).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch as t
+from torch import nn
+
+from .. import _native as nv
+from .. import runtime as rt
+from .. import utils
+from . import anchors   # noqa: F401  (part of the mirrored module surface)
+from . import detector
+from . import rpn
+from . import vgg16
+
+
+class Pending:
+    """Handle of one enqueued `predict`; `result()` waits for its stream and builds the reference's dict."""
+    def __init__(self, model, slot, with_detections):
+        self._model, self._slot, self._with_detections = model, slot, with_detections
+        self._result = None
+
+    def result(self):
+        if self._result is None:
+            slot = self._slot
+            slot.done.synchronize()
+            if self._with_detections:
+                cnt = slot.h_det_cnt.numpy()
+                det = slot.h_det.numpy()
+                # copy: the pinned staging buffer is reused by the next image on this slot
+                self._result = {c + 1: det[c, : int(cnt[c])].copy() for c in range(det.shape[0])}
+            else:
+                n = int(slot.h_counts[2])
+                # fresh tensors, as the reference returns: the slot buffers are reused by the next image
+                self._result = (slot.props[:n].clone(), slot.classes[:n].clone(), slot.deltas[:n].clone())
+            slot.busy = False
+            slot.keepalive = None
+        return self._result
+
+
+class FasterRCNNModel(nn.Module):
+    @dataclass
+    class Loss:
+        rpn_class: float
+        rpn_regression: float
+        detector_class: float
+        detector_regression: float
+        total: float
+
+    def __init__(self, num_classes, backbone, rpn_minibatch_size=256, proposal_batch_size=128, allow_edge_proposals=True):
+        super().__init__()
+
+        # Constants (faster_rcnn.py:60-64)
+        self._num_classes = num_classes
+        self._rpn_minibatch_size = rpn_minibatch_size
+        self._proposal_batch_size = proposal_batch_size
+        self._detector_box_delta_means = [0, 0, 0, 0]
+        self._detector_box_delta_stds = [0.1, 0.1, 0.2, 0.2]   # baked into csrc/detect.hip
+        self._allow_edge_proposals = allow_edge_proposals
+
+        # Backbone
+        self.backbone = backbone
+        if not isinstance(backbone, vgg16.VGG16Backbone):
+            raise NotImplementedError("this build accelerates the VGG-16 backbone (models/vgg16.py); got %s" % type(backbone).__name__)
+
+        # Network stages
+        self._stage1_feature_extractor = backbone.feature_extractor
+        self._stage2_region_proposal_network = rpn.RegionProposalNetwork(
+            feature_map_channels=backbone.feature_map_channels, allow_edge_proposals=allow_edge_proposals)
+        self._stage3_detector_network = detector.DetectorNetwork(num_classes=num_classes, backbone=backbone)
+
+        # Inference hyper-parameters (test-time values, faster_rcnn.py:124-125; rpn.py:142,150; :219)
+        self.max_proposals_pre_nms = 6000
+        self.max_proposals_post_nms = 300
+        self.rpn_nms_threshold = 0.7
+        self.rpn_min_side = 16.0
+        self.detector_nms_threshold = 0.3
+
+        self._slots = {}
+        self._wstruct = None
+        self._wstruct_key = None
+        self._wkeep = None
+
+    # ------------------------------------------------------------------------------------------
+    def _device(self):
+        p = self._stage3_detector_network._classifier.weight
+        if not p.is_cuda:
+            raise RuntimeError("FasterRCNNModel runs only on an MI355X GPU: call .cuda() first "
+                               "(the reference has the same requirement, README.md:65)")
+        return p.device
+
+    def _weights(self):
+        """The frcnn_vgg16_weights struct over packed device tensors (rebuilt when parameters change)."""
+        s1 = self._stage1_feature_extractor.packed()
+        s2 = self._stage2_region_proposal_network.packed()
+        pv = self._stage3_detector_network._pool_to_feature_vector.packed()
+        hd = self._stage3_detector_network.packed()
+        tensors = [x for pair in s1 for x in pair] + list(s2) + list(pv) + list(hd)
+        key = tuple(x.data_ptr() for x in tensors)
+        if key != self._wstruct_key:
+            w = nv.VGG16Weights()
+            for i, (wp, b) in enumerate(s1):
+                w.conv_w[i] = wp.data_ptr()
+                w.conv_b[i] = b.data_ptr()
+            w.rpn_conv_w, w.rpn_conv_b, w.rpn_head_w, w.rpn_head_b = (x.data_ptr() for x in s2)
+            w.fc1_w, w.fc1_b, w.fc2_w, w.fc2_b = (x.data_ptr() for x in pv)
+            w.head_w, w.head_b = (x.data_ptr() for x in hd)
+            w.num_classes = self._num_classes
+            self._wstruct, self._wstruct_key, self._wkeep = w, key, tensors
+        return self._wstruct
+
+    def _slot(self, index, h, w, device):
+        key = (str(device), index)
+        slot = self._slots.get(key)
+        if slot is None or not slot.ctx.fits(h, w, self.max_proposals_post_nms) or slot.num_classes != self._num_classes:
+            slot = rt.Slot(device, max(h, 608), max(w, 1008), self.max_proposals_post_nms, self._num_classes,
+                           own_stream=(index > 0))
+            self._slots[key] = slot
+        return slot
+
+    def _enqueue(self, image_data, anchor_map, anchor_valid_map, score_threshold, slot_index):
+        assert image_data.shape[0] == 1, "Batch size must be 1"
+        device = self._device()
+        image = rt.as_f32_cuda(image_data, "image_data")
+        if image.device != device:
+            raise RuntimeError("image_data is on %s but the model is on %s" % (image.device, device))
+        if image.dim() != 4 or image.shape[1] != 3:
+            raise ValueError("image_data must be shaped (1, 3, H, W)")
+        h, w = int(image.shape[2]), int(image.shape[3])
+        slot = self._slot(slot_index, h, w, device)
+        if slot.busy:
+            raise RuntimeError("slot %d still has an un-collected image in flight" % slot_index)
+        amap = rt.to_device_map(anchor_map, device)
+        vmap = rt.to_device_map(anchor_valid_map, device)
+        if amap is None or vmap is None:
+            amap = vmap = None
+        weights = self._weights()
+        params = nv.ForwardParams(int(self.max_proposals_pre_nms), int(self.max_proposals_post_nms),
+                                  float(self.rpn_nms_threshold), float(self.rpn_min_side),
+                                  1 if self._allow_edge_proposals else 0)
+        lib = nv.lib()
+        with t.cuda.device(device):
+            stream = slot.use_stream()
+            if slot.stream is not None:
+                # the image (and packed weights) were produced on the caller's stream
+                stream.wait_stream(t.cuda.current_stream(device))
+            sp = stream.cuda_stream
+            nv.check(lib.frcnn_vgg16_forward(slot.ctx.handle, C.byref(weights), C.byref(params), nv.ptr(image), h, w,
+                                             nv.ptr(amap), nv.ptr(vmap), nv.ptr(slot.props), nv.ptr(slot.classes),
+                                             nv.ptr(slot.deltas), nv.ptr(slot.counts), sp), "frcnn_vgg16_forward")
+            with_det = score_threshold is not None
+            with t.cuda.stream(stream):
+                if with_det:
+                    nv.check(lib.frcnn_detections(nv.ptr(slot.props), nv.ptr(slot.classes), nv.ptr(slot.deltas),
+                                                  slot.counts.data_ptr() + 8, slot.max_rois, self._num_classes, h, w,
+                                                  float(score_threshold), float(self.detector_nms_threshold),
+                                                  nv.ptr(slot.det), nv.ptr(slot.det_cnt), sp), "frcnn_detections")
+                    slot.h_det.copy_(slot.det, non_blocking=True)
+                    slot.h_det_cnt.copy_(slot.det_cnt, non_blocking=True)
+                slot.h_counts.copy_(slot.counts, non_blocking=True)
+                slot.done.record(stream)
+        slot.busy = True
+        slot.keepalive = (image, amap, vmap)
+        return Pending(self, slot, with_det)
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, image_data, anchor_map=None, anchor_valid_map=None):
+        """
+        Forward inference (faster_rcnn.py:80-132).  image_data (1, 3, H, W) float32 CUDA, VGG-16
+        preprocessing.  Returns proposals (N, 4) (y1, x1, y2, x2), classes (N, num_classes),
+        box deltas (N, (num_classes-1)*4) as new CUDA tensors.
+        """
+        with t.no_grad():
+            return self._enqueue(image_data, anchor_map, anchor_valid_map, None, 0).result()
+
+    @utils.no_grad
+    def predict(self, image_data, score_threshold, anchor_map=None, anchor_valid_map=None):
+        """
+        Inference to final boxes (faster_rcnn.py:134-226).  Returns Dict[int, np.ndarray]: for every
+        class index 1..num_classes-1 an (n, 5) float64 array of (y1, x1, y2, x2, score) rows in
+        NMS (score-descending) order; classes without detections map to shape (0, 5).
+        """
+        self.eval()
+        assert image_data.shape[0] == 1, "Batch size must be 1"
+        return self._enqueue(image_data, anchor_map, anchor_valid_map, score_threshold, 0).result()
+
+    @utils.no_grad
+    def predict_async(self, image_data, score_threshold, slot, anchor_map=None, anchor_valid_map=None):
+        """
+        Enqueues `predict` for one image on in-flight slot `slot` (0 = current stream, >0 = the slot's
+        own stream) and returns a `Pending`; call `.result()` to obtain the dict.  A slot must be
+        collected before it is reused.
+        """
+        return self._enqueue(image_data, anchor_map, anchor_valid_map, score_threshold, int(slot))
+
+    def context(self, slot=0):
+        """The runtime.Context of an in-flight slot (parity tests read intermediate tensors from it)."""
+        for (dev, idx), s in self._slots.items():
+            if idx == slot:
+                return s.ctx
+        raise KeyError("slot %d has not been used yet" % slot)
+
+    def train_step(self, *args, **kwargs):
+        raise NotImplementedError("training (faster_rcnn.py:228-362) is outside the accelerated inference hot path")

@@ -1,0 +1,157 @@
+"""
+VGG-16 backbone, mirroring pytorch/FasterRCNN/models/vgg16.py:22-158: same class names, layer
+attribute names (-> identical state_dict keys: `_block{1..5}_conv{1..3}.{weight,bias}`,
+`_fc{1,2}.{weight,bias}`), same Backbone properties.  nn.Conv2d / nn.Linear objects are used as
+PARAMETER HOLDERS only; the arithmetic runs in csrc/conv.hip and csrc/linear.hip.
+"""
+import torch as t
+from torch import nn
+
+from .. import _native as nv
+from .. import runtime as rt
+from ..datasets import image
+from .backbone import Backbone
+
+_LAYERS = [  # (name, cin, cout, pool_after)
+    ("_block1_conv1", 3, 64, False), ("_block1_conv2", 64, 64, True),
+    ("_block2_conv1", 64, 128, False), ("_block2_conv2", 128, 128, True),
+    ("_block3_conv1", 128, 256, False), ("_block3_conv2", 256, 256, False), ("_block3_conv3", 256, 256, True),
+    ("_block4_conv1", 256, 512, False), ("_block4_conv2", 512, 512, False), ("_block4_conv3", 512, 512, True),
+    ("_block5_conv1", 512, 512, False), ("_block5_conv2", 512, 512, False), ("_block5_conv3", 512, 512, False),
+]
+
+
+def pack_conv3x3(conv):
+    """OIHW weight of a 3x3 nn.Conv2d -> tap-major [9][cout][cin] (or [27][cout] when cin == 3)."""
+    w = conv.weight.detach()
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    w = rt.as_f32_cuda(w, "conv weight")
+    out = t.empty((27, cout) if cin == 3 else (9, cout, cin), dtype=t.float32, device=w.device)
+    with t.cuda.device(w.device):
+        if cin == 3:
+            nv.check(nv.lib().frcnn_pack_conv3x3_c3(nv.ptr(w), nv.ptr(out), cout, nv.stream_ptr()), "frcnn_pack_conv3x3_c3")
+        else:
+            nv.check(nv.lib().frcnn_pack_conv3x3(nv.ptr(w), nv.ptr(out), cout, cin, nv.stream_ptr()), "frcnn_pack_conv3x3")
+    return out
+
+
+class FeatureExtractor(nn.Module):
+    def __init__(self):
+        super().__init__()
+        for name, cin, cout, _ in _LAYERS:
+            setattr(self, name, nn.Conv2d(in_channels=cin, out_channels=cout, kernel_size=(3, 3), stride=1, padding="same"))
+        # Freeze first two convolutional blocks (vgg16.py:49-58) -- no effect on inference
+        for name in ("_block1_conv1", "_block1_conv2", "_block2_conv1", "_block2_conv2"):
+            getattr(self, name).weight.requires_grad = False
+            getattr(self, name).bias.requires_grad = False
+        self._packed_key = None
+        self._packed = None
+
+    def convs(self):
+        return [getattr(self, name) for name, _, _, _ in _LAYERS]
+
+    def packed(self):
+        """[(packed_weight, bias)] x 13 on the parameters' device, rebuilt when parameters change."""
+        params = [p for c in self.convs() for p in (c.weight, c.bias)]
+        key = rt.param_key(params)
+        if key != self._packed_key:
+            self._packed = [(pack_conv3x3(c), rt.as_f32_cuda(c.bias.detach(), "conv bias")) for c in self.convs()]
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, image_data):
+        """
+        image_data (1, 3, H, W) float32 CUDA -> feature map (1, 512, H // 16, W // 16), as the
+        reference returns it (NCHW view of the NHWC result).
+        """
+        assert image_data.shape[0] == 1, "Batch size must be 1"
+        x = rt.as_f32_cuda(image_data, "image_data")
+        packed = self.packed()
+        lib = nv.lib()
+        h, w = int(x.shape[2]), int(x.shape[3])
+        with t.cuda.device(x.device):
+            s = nv.stream_ptr()
+            cur = None
+            for i, (name, cin, cout, pool) in enumerate(_LAYERS):
+                wp, b = packed[i]
+                oh, ow = (h // 2, w // 2) if pool else (h, w)
+                y = t.empty((oh, ow, cout), dtype=t.float32, device=x.device)
+                if i == 0:
+                    nv.check(lib.frcnn_conv3x3_c3(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cout, nv.RELU, s),
+                             "frcnn_conv3x3_c3")
+                else:
+                    flags = nv.RELU | (nv.POOL2 if pool else 0)
+                    nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(cur), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags, s),
+                             "frcnn_conv3x3_nhwc")
+                cur, h, w = y, oh, ow
+        return cur.permute(2, 0, 1).unsqueeze(0)
+
+
+class PoolToFeatureVector(nn.Module):
+    def __init__(self, dropout_probability):
+        super().__init__()
+        self._fc1 = nn.Linear(in_features=512 * 7 * 7, out_features=4096)
+        self._fc2 = nn.Linear(in_features=4096, out_features=4096)
+        # Dropout is identity at inference; kept so the module tree matches the reference
+        self._dropout1 = nn.Dropout(p=dropout_probability)
+        self._dropout2 = nn.Dropout(p=dropout_probability)
+        self._packed_key = None
+        self._packed = None
+
+    def packed(self):
+        """fc1 with its input dimension permuted (C,7,7) -> (7,7,C); fc2 and biases as stored."""
+        params = [self._fc1.weight, self._fc1.bias, self._fc2.weight, self._fc2.bias]
+        key = rt.param_key(params)
+        if key != self._packed_key:
+            w1 = rt.as_f32_cuda(self._fc1.weight.detach(), "fc1 weight")
+            w1p = t.empty_like(w1)
+            with t.cuda.device(w1.device):
+                nv.check(nv.lib().frcnn_pack_fc_chw_to_hwc(nv.ptr(w1), nv.ptr(w1p), 4096, 512, 49, nv.stream_ptr()),
+                         "frcnn_pack_fc_chw_to_hwc")
+            self._packed = (w1p, rt.as_f32_cuda(self._fc1.bias.detach(), "fc1 bias"),
+                            rt.as_f32_cuda(self._fc2.weight.detach(), "fc2 weight"),
+                            rt.as_f32_cuda(self._fc2.bias.detach(), "fc2 bias"))
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, rois):
+        """rois (N, 512, 7, 7) -> (N, 4096): fc1+ReLU, fc2+ReLU (dropout = identity at inference)."""
+        if self.training and (self._dropout1.p > 0 or self._dropout2.p > 0):
+            raise NotImplementedError("training-mode dropout is outside the inference hot path")
+        x = rt.as_f32_cuda(rois, "rois")
+        n = int(x.shape[0])
+        x = x.permute(0, 2, 3, 1).contiguous().reshape(n, 49 * 512)   # layout plumbing: (C,7,7) -> (7,7,C)
+        w1p, b1, w2, b2 = self.packed()
+        return linear(linear(x, w1p, b1, 4096, relu=True), w2, b2, 4096, relu=True)
+
+
+def linear(x, w, b, n_out, relu):
+    """y = act(x @ w[:n_out].T + b) through frcnn_linear; x (M,K) CUDA float32, w row-major [>=n_out][K]."""
+    m, k = int(x.shape[0]), int(x.shape[1])
+    y = t.empty((m, n_out), dtype=t.float32, device=x.device)
+    if m == 0:
+        return y
+    lib = nv.lib()
+    ws_bytes = int(lib.frcnn_linear_workspace_bytes(m, n_out, k))
+    ws = t.empty((max(ws_bytes, 4) // 4,), dtype=t.float32, device=x.device)
+    with t.cuda.device(x.device):
+        nv.check(lib.frcnn_linear(nv.ptr(x), k, nv.ptr(w), nv.ptr(b), nv.ptr(y), n_out, m, n_out, k,
+                                  nv.RELU if relu else 0, nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_linear")
+    return y
+
+
+class VGG16Backbone(Backbone):
+    def __init__(self, dropout_probability):
+        super().__init__()
+        self.feature_map_channels = 512
+        self.feature_pixels = 16
+        self.feature_vector_size = 4096
+        self.image_preprocessing_params = image.PreprocessingParams(
+            channel_order=image.ChannelOrder.BGR, scaling=1.0, means=[103.939, 116.779, 123.680], stds=[1, 1, 1])
+        self.feature_extractor = FeatureExtractor()
+        self.pool_to_feature_vector = PoolToFeatureVector(dropout_probability=dropout_probability)
+
+    def compute_feature_map_shape(self, image_shape):
+        image_width = image_shape[-1]
+        image_height = image_shape[-2]
+        return (self.feature_map_channels, image_height // self.feature_pixels, image_width // self.feature_pixels)

@@ -1,0 +1,125 @@
+"""
+Device-side plumbing shared by the model mirror: frcnn_ctx handles, per-image slots (context +
+stream + persistent output buffers + pinned host staging) and packed-weight caching.
+PyTorch is used only for memory, streams and events.
+"""
+import ctypes as C
+
+import numpy as np
+import torch as t
+
+from . import _native as nv
+
+
+class Context:
+    """Owns one frcnn_ctx (activation buffers + scratch for one in-flight image)."""
+    def __init__(self, device, max_h, max_w, max_rois):
+        nv.require_gpu()
+        self.device = t.device(device)
+        self.max_h, self.max_w, self.max_rois = int(max_h), int(max_w), int(max_rois)
+        handle = C.c_void_p()
+        with t.cuda.device(self.device):
+            nv.check(nv.lib().frcnn_ctx_create(C.byref(handle), self.max_h, self.max_w, self.max_rois),
+                     "frcnn_ctx_create")
+        self.handle = handle
+
+    def fits(self, h, w, rois):
+        return h <= self.max_h and w <= self.max_w and rois <= self.max_rois
+
+    @property
+    def nbytes(self):
+        return int(nv.lib().frcnn_ctx_bytes(self.handle))
+
+    def tensor(self, which, dtype=t.float32):
+        """Copies intermediate tensor `which` of the last forward to a new CUDA tensor (tests only)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        nv.check(nv.lib().frcnn_ctx_tensor(self.handle, which, C.byref(p), C.byref(n)), "frcnn_ctx_tensor")
+        itemsize = t.empty((), dtype=dtype).element_size()
+        out = t.empty((n.value // itemsize,), dtype=dtype, device=self.device)
+        t.cuda.current_stream(self.device).synchronize()
+        rc = _hip_memcpy_dtod(out.data_ptr(), p.value, n.value)
+        if rc != 0:
+            raise RuntimeError("hipMemcpy failed: %d" % rc)
+        return out
+
+    def timing_enable(self, on):
+        nv.check(nv.lib().frcnn_ctx_timing_enable(self.handle, 1 if on else 0), "frcnn_ctx_timing_enable")
+
+    def timing_read(self, reset=True):
+        ms = (C.c_double * nv.NUM_KCLASS)()
+        cnt = (C.c_int64 * nv.NUM_KCLASS)()
+        nv.check(nv.lib().frcnn_ctx_timing_read(self.handle, ms, cnt, 1 if reset else 0), "frcnn_ctx_timing_read")
+        return {nv.KCLASS_NAMES[i]: (ms[i], cnt[i]) for i in range(nv.NUM_KCLASS)}
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) is not None and self.handle.value:
+                nv.lib().frcnn_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_hip = None
+
+
+def _hip_memcpy_dtod(dst, src, nbytes):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.restype = C.c_int
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return _hip.hipMemcpy(dst, src, nbytes, 3)   # hipMemcpyDeviceToDevice
+
+
+class Slot:
+    """
+    Everything one in-flight image needs: a Context, a stream, device output buffers for
+    forward()/predict() and pinned host buffers for the (single) D2H copy of the detections.
+    """
+    def __init__(self, device, max_h, max_w, max_rois, num_classes, own_stream):
+        self.device = t.device(device)
+        self.ctx = Context(device, max_h, max_w, max_rois)
+        self.max_rois, self.num_classes = int(max_rois), int(num_classes)
+        self.stream = t.cuda.Stream(device=self.device) if own_stream else None
+        nfg = num_classes - 1
+        d = self.device
+        self.props = t.zeros((max_rois, 4), dtype=t.float32, device=d)
+        self.classes = t.zeros((max_rois, num_classes), dtype=t.float32, device=d)
+        self.deltas = t.zeros((max_rois, nfg * 4), dtype=t.float32, device=d)
+        self.counts = t.zeros((4,), dtype=t.int32, device=d)
+        self.det = t.zeros((nfg, max_rois, 5), dtype=t.float64, device=d)
+        self.det_cnt = t.zeros((nfg,), dtype=t.int32, device=d)
+        self.h_det = t.zeros((nfg, max_rois, 5), dtype=t.float64).pin_memory()
+        self.h_det_cnt = t.zeros((nfg,), dtype=t.int32).pin_memory()
+        self.h_counts = t.zeros((4,), dtype=t.int32).pin_memory()
+        self.done = t.cuda.Event()
+        self.busy = False
+        self.keepalive = None     # references that must outlive the enqueued work
+
+    def use_stream(self):
+        return self.stream if self.stream is not None else t.cuda.current_stream(self.device)
+
+
+def param_key(params):
+    """Cache key that changes whenever any of the tensors is replaced, moved or written in place."""
+    return tuple((p.data_ptr(), p._version, str(p.device), tuple(p.shape)) for p in params)
+
+
+def as_f32_cuda(x, what):
+    if not isinstance(x, t.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % what)
+    if not x.is_cuda:
+        raise RuntimeError("%s must be a CUDA (MI355X) tensor: this path has no CPU implementation" % what)
+    if x.dtype != t.float32:
+        raise TypeError("%s must be float32" % what)
+    return x.contiguous()
+
+
+def to_device_map(x, device):
+    """Accepts the reference's numpy anchor maps (or tensors) and returns a contiguous CUDA float32 tensor."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        x = t.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    return x.to(device=device, dtype=t.float32).contiguous()

@@ -1,0 +1,367 @@
+"""
+oracle/frcnn_oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+CPU restatement (numpy + torch-CPU) of the reference's inference hot path, used ONLY by tests/,
+__graft_entry__.smoke() and bench.py's `cpu_baseline` leg as the checker / CPU baseline.  Nothing
+under fasterrcnn_amd/ imports it; the product path has no CPU fallback.
+
+Every function cites the reference lines it follows (paths relative to
+/root/reference/pytorch/FasterRCNN/).  Dense layers use the very torch-CPU ops the reference calls
+(F.conv2d, F.linear, F.max_pool2d, softmax, sigmoid, argsort): torch core is importable here.
+torchvision is NOT vendored in the reference nor installed (pytorch/requirements.txt pins
+torchvision==0.15.0+cu117), so `nms` and `roi_pool` below restate torchvision's published
+semantics; the reference has no tests that pin them -> PARITY UNPINNED at that boundary
+(DESIGN.md section "Oracle").  Everything else is pinned by oracle/make_golden.py, which imports
+the reference itself in the build container and checks this file against it; the captured vectors
+live in tests/golden/.
+"""
+import itertools
+import math
+from collections import defaultdict
+
+import numpy as np
+import torch as t
+from torch.nn import functional as F
+
+
+# ------------------------------------------------------------------------------------------------
+# anchors  (models/anchors.py:25-135)
+# ------------------------------------------------------------------------------------------------
+def anchor_sizes():
+    """(9,2) (height,width); k = area-major, aspect-minor (anchors.py:33-41)."""
+    out = []
+    for area, aspect in itertools.product([128 * 128, 256 * 256, 512 * 512], [0.5, 1.0, 2.0]):
+        root = math.sqrt(area / aspect)
+        out.append((aspect * root, root))
+    return np.array(out, dtype=np.float64)
+
+
+def generate_anchor_maps(image_shape, feature_map_shape, feature_pixels):
+    """
+    anchors.py:43-135.  Returns anchor_map (H,W,36) float32 of (cy,cx,h,w) and valid map (H,W,9)
+    float32.  The arithmetic order matters for bit-exactness: cell centres are rounded to float32
+    (:118) and then combined with the float64 template; a single cast to float32 ends it (:135).
+    """
+    sizes = anchor_sizes()
+    height, width = int(feature_map_shape[-2]), int(feature_map_shape[-1])
+    ys = (np.arange(height) * feature_pixels + 0.5 * feature_pixels).astype(np.float32)     # :105,:118
+    xs = (np.arange(width) * feature_pixels + 0.5 * feature_pixels).astype(np.float32)
+    shape = (height, width, 9)
+    cy = np.broadcast_to(ys[:, None, None].astype(np.float64), shape)
+    cx = np.broadcast_to(xs[None, :, None].astype(np.float64), shape)
+    half_h = 0.5 * sizes[None, None, :, 0]
+    half_w = 0.5 * sizes[None, None, :, 1]
+    y1, x1 = cy + (-half_h), cx + (-half_w)                                                  # :92,:118
+    y2, x2 = cy + half_h, cx + half_w                                                        # :93,:118
+    image_height, image_width = image_shape[1], image_shape[2]
+    valid = (y1 >= 0) & (x1 >= 0) & (y2 <= image_height) & (x2 <= image_width)              # :124-125
+    amap = np.stack([0.5 * (y1 + y2), 0.5 * (x1 + x2), y2 - y1, x2 - x1], axis=-1)           # :128-130
+    return amap.reshape(height, width, 36).astype(np.float32), valid.astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# torchvision.ops restated (third-party; see module docstring)
+# ------------------------------------------------------------------------------------------------
+def nms(boxes, scores, iou_threshold):
+    """
+    torchvision.ops.nms(boxes[N,4], scores[N], thr) as called at rpn.py:147-151 and
+    faster_rcnn.py:216-220: stable score-descending order; a later box j is dropped by an earlier
+    kept box i iff inter/(area_i+area_j-inter) > thr, computed in the dtype of `boxes`; no +1, no
+    epsilon.  The threshold is a C float inside torchvision's CUDA devIoU, hence float32(thr).
+    Returns int64 indices in kept (score-descending) order.
+    """
+    boxes = np.asarray(boxes)
+    scores = np.asarray(scores)
+    n = boxes.shape[0]
+    if n == 0:
+        return np.zeros((0,), dtype=np.int64)
+    dt = boxes.dtype
+    thr = dt.type(np.float32(iou_threshold))
+    order = np.argsort(-scores.astype(np.float64), kind="stable")
+    b = boxes[order]
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    suppressed = np.zeros(n, dtype=bool)
+    keep = []
+    zero = dt.type(0)
+    for i in range(n):
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        if i + 1 >= n:
+            break
+        r = b[i + 1:]
+        d0 = np.maximum(np.minimum(b[i, 2], r[:, 2]) - np.maximum(b[i, 0], r[:, 0]), zero)
+        d1 = np.maximum(np.minimum(b[i, 3], r[:, 3]) - np.maximum(b[i, 1], r[:, 1]), zero)
+        inter = d0 * d1
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iou = inter / (area[i] + area[i + 1:] - inter)
+        suppressed[i + 1:] |= iou > thr
+    return order[np.asarray(keep, dtype=np.int64)]
+
+
+def _c_round(x):
+    """C round(): half away from zero (numpy's round is half-to-even)."""
+    return np.where(x >= 0, np.floor(x + np.float32(0.5)), np.ceil(x - np.float32(0.5)))
+
+
+def roi_pool(feature_map, rois_xyxy, output_size, spatial_scale):
+    """
+    torchvision.ops.RoIPool(output_size, spatial_scale)(input NCHW (1,C,H,W), rois (K,5) =
+    (batch, x1, y1, x2, y2)) as used at detector.py:27,72.  float32 arithmetic throughout:
+      start/end = round(coord*scale); size = max(end-start+1, 1); bin = size/out;
+      window = [floor(p*bin)+start, ceil((p+1)*bin)+start) clipped to the map; empty -> 0 else max.
+    Returns (K, C, out, out) float32.
+    """
+    fm = np.asarray(feature_map, dtype=np.float32)
+    assert fm.shape[0] == 1
+    fm = fm[0]
+    c, h, w = fm.shape
+    rois = np.asarray(rois_xyxy, dtype=np.float32)
+    k = rois.shape[0]
+    out = np.zeros((k, c, output_size, output_size), dtype=np.float32)
+    scale = np.float32(spatial_scale)
+    for r in range(k):
+        rs_w = int(_c_round(rois[r, 1] * scale)); rs_h = int(_c_round(rois[r, 2] * scale))
+        re_w = int(_c_round(rois[r, 3] * scale)); re_h = int(_c_round(rois[r, 4] * scale))
+        roi_w = max(re_w - rs_w + 1, 1); roi_h = max(re_h - rs_h + 1, 1)
+        bin_h = np.float32(roi_h) / np.float32(output_size)
+        bin_w = np.float32(roi_w) / np.float32(output_size)
+        for ph in range(output_size):
+            hs = int(np.floor(np.float32(ph) * bin_h)) + rs_h
+            he = int(np.ceil(np.float32(ph + 1) * bin_h)) + rs_h
+            hs = min(max(hs, 0), h); he = min(max(he, 0), h)
+            for pw in range(output_size):
+                ws = int(np.floor(np.float32(pw) * bin_w)) + rs_w
+                we = int(np.ceil(np.float32(pw + 1) * bin_w)) + rs_w
+                ws = min(max(ws, 0), w); we = min(max(we, 0), w)
+                if he > hs and we > ws:
+                    out[r, :, ph, pw] = fm[:, hs:he, ws:we].max(axis=(1, 2))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# network stages on torch-CPU (the same ATen ops the reference calls)
+# ------------------------------------------------------------------------------------------------
+_S1 = "_stage1_feature_extractor."
+_S2 = "_stage2_region_proposal_network."
+_S3 = "_stage3_detector_network."
+
+
+def vgg16_features(sd, image):
+    """vgg16.py:60-98: 13 x (conv3x3 same + ReLU), max-pool 2x2/2 after blocks 1-4.  image (1,3,H,W)."""
+    y = image
+    for block, convs in ((1, 2), (2, 2), (3, 3), (4, 3), (5, 3)):
+        for i in range(1, convs + 1):
+            key = "%s_block%d_conv%d" % (_S1, block, i)
+            y = F.relu(F.conv2d(y, sd[key + ".weight"], sd[key + ".bias"], stride=1, padding=1))
+        if block < 5:
+            y = F.max_pool2d(y, kernel_size=2, stride=2)
+    return y
+
+
+def decode_boxes_f32(deltas, anchors):
+    """math_utils.py:99-128 with means 0 / stds 1 (rpn.py:118-123), float32 torch ops."""
+    d = deltas * t.ones(4) + t.zeros(4)
+    center = anchors[:, 2:4] * d[:, 0:2] + anchors[:, 0:2]
+    size = anchors[:, 2:4] * t.exp(d[:, 2:4])
+    boxes = t.empty(d.shape, dtype=t.float32)
+    boxes[:, 0:2] = center - 0.5 * size
+    boxes[:, 2:4] = center + 0.5 * size
+    return boxes
+
+
+def rpn_forward(sd, feature_map, image_shape, anchor_map, anchor_valid_map, pre_nms, post_nms,
+                allow_edge_proposals=True, detail=None):
+    """
+    rpn.py:88-156.  Returns (objectness_score_map (1,H,W,9), box_deltas_map (1,H,W,36), proposals (N,4)).
+    `detail`, if a dict, receives the intermediates the parity tests compare.
+    """
+    y = F.relu(F.conv2d(feature_map, sd[_S2 + "_rpn_conv1.weight"], sd[_S2 + "_rpn_conv1.bias"], padding=1))
+    score_map = t.sigmoid(F.conv2d(y, sd[_S2 + "_rpn_class.weight"], sd[_S2 + "_rpn_class.bias"]))
+    delta_map = F.conv2d(y, sd[_S2 + "_rpn_boxes.weight"], sd[_S2 + "_rpn_boxes.bias"])
+    score_map = score_map.permute(0, 2, 3, 1).contiguous()          # :95-96
+    delta_map = delta_map.permute(0, 2, 3, 1).contiguous()
+    anchors = t.from_numpy(np.ascontiguousarray(anchor_map)).reshape(-1, 4)
+    scores = score_map.reshape(-1)
+    deltas = delta_map.reshape(-1, 4)
+    if not allow_edge_proposals:                                     # :167-173
+        idx = t.from_numpy(np.ascontiguousarray(anchor_valid_map)).reshape(-1) > 0
+        flat_index = t.nonzero(idx).reshape(-1)
+        anchors, scores, deltas = anchors[idx], scores[idx], deltas[idx]
+    else:
+        flat_index = t.arange(scores.shape[0])
+    proposals = decode_boxes_f32(deltas, anchors)                    # :118-123
+    order = t.argsort(scores, stable=True).flip(dims=(0,))           # :129-130 (ties -> higher index first)
+    top = order[0:pre_nms]
+    proposals = proposals[top]                                       # :131-132
+    top_scores = scores[top]
+    proposals[:, 0:2] = t.clamp(proposals[:, 0:2], min=0)            # :135-137
+    proposals[:, 2] = t.clamp(proposals[:, 2], max=image_shape[1])
+    proposals[:, 3] = t.clamp(proposals[:, 3], max=image_shape[2])
+    hh = proposals[:, 2] - proposals[:, 0]                           # :140-144
+    ww = proposals[:, 3] - proposals[:, 1]
+    big = t.where((hh >= 16) & (ww >= 16))[0]
+    cand = proposals[big]
+    cand_scores = top_scores[big]
+    keep = nms(cand.numpy(), cand_scores.numpy(), 0.7)[0:post_nms]   # :147-153
+    out = cand[t.from_numpy(keep)]
+    if detail is not None:
+        detail["rpn_trunk"] = y
+        detail["scores"] = scores
+        detail["decoded"] = decode_boxes_f32(deltas, anchors)
+        detail["sorted_idx"] = flat_index[top].numpy().astype(np.int64)
+        detail["n_after_filter"] = int(big.shape[0])
+        detail["candidates"] = cand
+    return score_map, delta_map, out
+
+
+def pool_to_feature_vector(sd, rois):
+    """vgg16.py:129-133 (dropout is identity at inference)."""
+    x = rois.reshape(rois.shape[0], 512 * 7 * 7)
+    p = _S3 + "_pool_to_feature_vector."
+    y = F.relu(F.linear(x, sd[p + "_fc1.weight"], sd[p + "_fc1.bias"]))
+    return F.relu(F.linear(y, sd[p + "_fc2.weight"], sd[p + "_fc2.bias"]))
+
+
+def detector_forward(sd, feature_map, proposals, detail=None):
+    """detector.py:65-80: RoIPool 7x7 @ 1/16 -> fc1, fc2 -> softmax classes, box deltas."""
+    props = proposals.numpy() if isinstance(proposals, t.Tensor) else np.asarray(proposals)
+    rois = np.zeros((props.shape[0], 5), dtype=np.float32)
+    rois[:, 1:] = props[:, [1, 0, 3, 2]]                             # (y1,x1,y2,x2) -> (x1,y1,x2,y2), :69
+    pooled = t.from_numpy(roi_pool(feature_map.numpy(), rois, 7, 1.0 / 16.0))
+    y = pool_to_feature_vector(sd, pooled)
+    logits = F.linear(y, sd[_S3 + "_classifier.weight"], sd[_S3 + "_classifier.bias"])
+    classes = F.softmax(logits, dim=1)
+    deltas = F.linear(y, sd[_S3 + "_regressor.weight"], sd[_S3 + "_regressor.bias"])
+    if detail is not None:
+        detail["pooled"] = pooled
+        detail["fc2"] = y
+        detail["class_logits"] = logits
+    return classes, deltas
+
+
+def forward(sd, image, anchor_map=None, anchor_valid_map=None, allow_edge_proposals=True,
+            pre_nms=6000, post_nms=300, detail=None):
+    """faster_rcnn.py:80-132.  image: torch float32 (1,3,H,W) on CPU."""
+    assert image.shape[0] == 1
+    image_shape = tuple(image.shape[1:])
+    with t.no_grad():
+        if anchor_map is None or anchor_valid_map is None:
+            fshape = (512, image_shape[1] // 16, image_shape[2] // 16)        # vgg16.py:155-158
+            anchor_map, anchor_valid_map = generate_anchor_maps(image_shape, fshape, 16)
+        fm = vgg16_features(sd, image)
+        _, _, proposals = rpn_forward(sd, fm, image_shape, anchor_map, anchor_valid_map, pre_nms, post_nms,
+                                      allow_edge_proposals, detail)
+        classes, deltas = detector_forward(sd, fm, proposals, detail)
+    if detail is not None:
+        detail["feature_map"] = fm
+    return proposals, classes, deltas
+
+
+def convert_deltas_to_boxes(box_deltas, anchors, box_delta_means, box_delta_stds):
+    """math_utils.py:65-97 (numpy; promotes to float64 with list-valued means/stds)."""
+    d = box_deltas * np.asarray(box_delta_stds) + np.asarray(box_delta_means)
+    center = anchors[:, 2:4] * d[:, 0:2] + anchors[:, 0:2]
+    size = anchors[:, 2:4] * np.exp(d[:, 2:4])
+    boxes = np.empty(d.shape)
+    boxes[:, 0:2] = center - 0.5 * size
+    boxes[:, 2:4] = center + 0.5 * size
+    return boxes
+
+
+def detections(proposals, classes, box_deltas, image_height, image_width, score_threshold):
+    """
+    faster_rcnn.py:175-224 on numpy inputs (float32): float32 anchor conversion stored into float64
+    (:180-183), float64 decode with stds [.1,.1,.2,.2] (:190-197), clip (:200-201), score filter
+    (:208), per-class nms 0.3 on float64 boxes (:216-220), rows (y1,x1,y2,x2,score) float64 (:221-224).
+    """
+    proposals = np.asarray(proposals, dtype=np.float32)
+    classes = np.asarray(classes, dtype=np.float32)
+    box_deltas = np.asarray(box_deltas, dtype=np.float32)
+    anchors = np.empty(proposals.shape)
+    anchors[:, 0] = 0.5 * (proposals[:, 0] + proposals[:, 2])
+    anchors[:, 1] = 0.5 * (proposals[:, 1] + proposals[:, 3])
+    anchors[:, 2:4] = proposals[:, 2:4] - proposals[:, 0:2]
+    result = {}
+    for c in range(1, classes.shape[1]):
+        j = (c - 1) * 4
+        boxes = convert_deltas_to_boxes(box_deltas[:, j:j + 4], anchors, [0, 0, 0, 0], [0.1, 0.1, 0.2, 0.2])
+        boxes[:, 0::2] = np.clip(boxes[:, 0::2], 0, image_height - 1)
+        boxes[:, 1::2] = np.clip(boxes[:, 1::2], 0, image_width - 1)
+        s = classes[:, c]
+        sel = np.where(s > score_threshold)[0]
+        boxes, s = boxes[sel], s[sel]
+        keep = nms(boxes, s, 0.3)
+        result[c] = np.hstack([boxes[keep], s[keep][:, None].astype(np.float64)]) if keep.size else np.zeros((0, 5))
+    return result
+
+
+def predict(sd, image, score_threshold, **kw):
+    """faster_rcnn.py:134-226."""
+    proposals, classes, deltas = forward(sd, image, **kw)
+    return detections(proposals.numpy(), classes.numpy(), deltas.numpy(), image.shape[2], image.shape[3],
+                      score_threshold)
+
+
+# ------------------------------------------------------------------------------------------------
+# mAP  (statistics.py:65-214), written as the reference's plain loops
+# ------------------------------------------------------------------------------------------------
+def iou_pair(a, b):
+    """math_utils.py:13-37 for one pair of (y1,x1,y2,x2) boxes."""
+    tl = np.maximum(a[0:2], b[0:2])
+    br = np.minimum(a[2:4], b[2:4])
+    ok = bool(np.all(tl < br))
+    inter = (np.prod(br - tl) if ok else 0.0) * 1.0
+    ua = np.prod(a[2:4] - a[0:2]) + np.prod(b[2:4] - b[0:2]) - inter
+    return inter / (ua + 1e-7)
+
+
+class MeanAveragePrecision:
+    def __init__(self):
+        self.preds = defaultdict(list)     # class -> [(score, is_tp)]
+        self.gt_count = defaultdict(int)
+
+    def add_image_results(self, scored_boxes_by_class_index, gt_boxes):
+        """gt_boxes: list of (class_index, corners).  statistics.py:77-156."""
+        for cls, _ in gt_boxes:
+            self.gt_count[cls] += 1
+        for cls, rows in scored_boxes_by_class_index.items():
+            gts = [corners for (c, corners) in gt_boxes if c == cls]
+            tp = [False] * len(rows)
+            found = [False] * len(gts)
+            # statistics.py:99's sort is a no-op (constant key): order stays gt-major, box-minor
+            for g in range(len(gts)):
+                for bidx in range(len(rows)):
+                    if iou_pair(np.asarray(rows[bidx][0:4]), np.asarray(gts[g])) <= 0.5:
+                        continue
+                    if tp[bidx] or found[g]:
+                        continue
+                    tp[bidx] = True
+                    found[g] = True
+            self.preds[cls] += [(rows[i][4], tp[i]) for i in range(len(rows))]
+
+    def average_precision(self, cls):
+        """statistics.py:158-197."""
+        ranked = sorted(self.preds[cls], key=lambda p: p[0], reverse=True)
+        n_pos = self.gt_count[cls]
+        recall, precision = [0.0], [0.0]
+        tps = fps = 0
+        for _, ok in ranked:
+            if ok:
+                tps += 1
+            else:
+                fps += 1
+            recall.append(tps / n_pos)
+            precision.append(tps / (tps + fps))
+        recall.append(1.0)
+        precision.append(0.0)
+        for i in range(len(precision)):
+            precision[i] = max(precision[i:])
+        ap = 0
+        for i in range(len(recall) - 1):
+            ap += (recall[i + 1] - recall[i]) * precision[i + 1]
+        return ap
+
+    def mean_average_precision(self):
+        """statistics.py:199-214: mean over classes that occur in the ground truth."""
+        return float(np.mean([self.average_precision(c) for c in self.gt_count]))

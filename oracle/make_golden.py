@@ -1,0 +1,238 @@
+"""
+oracle/make_golden.py -- TEST INFRASTRUCTURE ONLY; runs in the BUILD CONTAINER (needs /root/reference).
+
+  python oracle/make_golden.py --calibrate     prints the layer multipliers frozen in
+                                               fasterrcnn_amd/synthetic.py:CALIBRATION
+  python oracle/make_golden.py                 (1) runs the imported REFERENCE (reference_shims.py)
+                                               on the synthetic workload, (2) asserts that
+                                               oracle/frcnn_oracle.py reproduces it, (3) writes the
+                                               golden vectors to tests/golden/*.npz
+
+The fixtures hold data only (seeds -> expected outputs); weights and images are regenerated from
+the seeds by fasterrcnn_amd/synthetic.py on whichever machine runs the tests.
+"""
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch as t
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import frcnn_oracle as O          # noqa: E402
+from oracle import reference_shims            # noqa: E402
+from fasterrcnn_amd import synthetic          # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def build_reference_model(ref, sd, allow_edge=True):
+    model = ref.faster_rcnn.FasterRCNNModel(num_classes=21, backbone=ref.vgg16.VGG16Backbone(dropout_probability=0.0),
+                                            allow_edge_proposals=allow_edge)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    return model
+
+
+def calibrate(ref):
+    """Measures the five multipliers with the reference's own modules (seed 1234, image seed 0)."""
+    ones = {k: 1.0 for k in synthetic.CALIBRATION}
+    sd = synthetic.vgg16_state_dict(1234, calibration=ones)
+    img = synthetic.image(0).unsqueeze(0)
+    cal = {}
+    with t.no_grad():
+        model = build_reference_model(ref, sd)
+        fm = model._stage1_feature_extractor(image_data=img)
+        k = "_stage1_feature_extractor._block5_conv3.weight"
+        cal[k] = 1.0 / float(fm.std())
+        fm = fm * cal[k]
+        rpn = model._stage2_region_proposal_network
+        y = t.relu(rpn._rpn_conv1(fm))
+        cal["_stage2_region_proposal_network._rpn_class.weight"] = 1.0 / float(rpn._rpn_class(y).std())
+        cal["_stage2_region_proposal_network._rpn_boxes.weight"] = 0.3 / float(rpn._rpn_boxes(y).std())
+        # detector statistics on the proposals of the calibrated RPN
+        sd2 = synthetic.vgg16_state_dict(1234, calibration={**ones, **cal})
+        model = build_reference_model(ref, sd2)
+        detail = {}
+        O.forward(sd2, img, detail=detail)
+        fc2 = detail["fc2"]
+        det = model._stage3_detector_network
+        cal["_stage3_detector_network._classifier.weight"] = 3.0 / float(det._classifier(fc2).std())
+        cal["_stage3_detector_network._regressor.weight"] = 1.0 / float(det._regressor(fc2).std())
+    print("CALIBRATION = {")
+    for k, v in cal.items():
+        print('    "%s": %.9g,' % (k, v))
+    print("}")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def flatten_detections(d):
+    rows = [np.hstack([np.full((v.shape[0], 1), float(c)), v]) for c, v in sorted(d.items()) if v.shape[0]]
+    return np.vstack(rows) if rows else np.zeros((0, 6))
+
+
+def assert_equal(name, a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape or not np.array_equal(a, b):
+        diff = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) if a.shape == b.shape else float("nan")
+        raise AssertionError("oracle != reference for %s (shapes %s %s, max|d| %g)" % (name, a.shape, b.shape, diff))
+    print("  oracle == reference: %-28s %s %s" % (name, a.shape, a.dtype))
+
+
+def run_case(ref, tag, sd, seed, height, width, allow_edge, score_threshold):
+    print("case %s: image seed %d, %dx%d, allow_edge=%s" % (tag, seed, height, width, allow_edge))
+    img = synthetic.image(seed, height, width).unsqueeze(0)
+    model = build_reference_model(ref, sd, allow_edge)
+    t0 = time.time()
+    with t.no_grad():
+        ref_props, ref_classes, ref_deltas = model(image_data=img)
+    t_fwd = time.time() - t0
+    ref_det = model.predict(image_data=img, score_threshold=score_threshold)
+    print("  reference forward %.2f s; %d proposals; %d detections over %d classes" % (
+        t_fwd, ref_props.shape[0], sum(v.shape[0] for v in ref_det.values()),
+        sum(1 for v in ref_det.values() if v.shape[0])))
+
+    detail = {}
+    o_props, o_classes, o_deltas = O.forward(sd, img, allow_edge_proposals=allow_edge, detail=detail)
+    o_det = O.detections(o_props.numpy(), o_classes.numpy(), o_deltas.numpy(), height, width, score_threshold)
+    assert_equal("proposals", o_props.numpy(), ref_props.numpy())
+    assert_equal("classes", o_classes.numpy(), ref_classes.numpy())
+    assert_equal("box_deltas", o_deltas.numpy(), ref_deltas.numpy())
+    assert sorted(o_det.keys()) == sorted(ref_det.keys()) == list(range(1, 21))
+    for c in ref_det:
+        assert ref_det[c].dtype == np.float64 and ref_det[c].shape[1:] == (5,)
+    assert_equal("detections", flatten_detections(o_det), flatten_detections(ref_det))
+
+    # the reference's own intermediate tensors, for stage-level parity
+    with t.no_grad():
+        fm = model._stage1_feature_extractor(image_data=img)
+        am, vm = ref.anchors.generate_anchor_maps(tuple(img.shape[1:]), model.backbone.compute_feature_map_shape(tuple(img.shape[1:])), 16)
+        smap, dmap, _ = model._stage2_region_proposal_network(
+            feature_map=fm, image_shape=tuple(img.shape[1:]), anchor_map=am, anchor_valid_map=vm,
+            max_proposals_pre_nms=6000, max_proposals_post_nms=300)
+    assert_equal("feature_map", detail["feature_map"].numpy(), fm.numpy())
+    scores = smap.reshape(-1).numpy()
+    if allow_edge:
+        assert_equal("objectness", detail["scores"].numpy(), scores)
+    sorted_idx = detail["sorted_idx"]
+    top_scores = (scores if allow_edge else scores[vm.reshape(-1) > 0])
+    n_unique_top = len(np.unique(np.sort(detail["scores"].numpy())[::-1][: len(sorted_idx)]))
+    # margin between consecutive sorted scores (how robust the order is to fp32 noise)
+    ss = np.sort(detail["scores"].numpy().astype(np.float64))[::-1][: len(sorted_idx)]
+    print("  top-%d: %d unique scores, min gap %.3g, median gap %.3g" % (
+        len(sorted_idx), n_unique_top, float(np.min(-np.diff(ss))) if len(ss) > 1 else 0.0,
+        float(np.median(-np.diff(ss))) if len(ss) > 1 else 0.0))
+
+    fm_np = fm.numpy()[0]
+    out = {
+        "seed": np.int64(seed), "height": np.int64(height), "width": np.int64(width),
+        "allow_edge": np.int64(1 if allow_edge else 0), "score_threshold": np.float64(score_threshold),
+        "weights_seed": np.int64(1234),
+        "proposals": ref_props.numpy(), "classes": ref_classes.numpy(), "box_deltas": ref_deltas.numpy(),
+        "detections": flatten_detections(ref_det),
+        "sorted_idx": sorted_idx.astype(np.int32),
+        "n_after_filter": np.int64(detail["n_after_filter"]),
+        "scores_sample": scores[::7].copy(), "scores_sha": np.array(sha(scores)),
+        "feature_map_sample": fm_np[::16, :, :].copy(),          # 32 of 512 channels
+        "feature_map_absmean": np.float64(np.abs(fm_np).mean()),
+        "rpn_deltas_sample": dmap.reshape(-1, 4).numpy()[::11].copy(),
+        "fc2_sample": detail["fc2"].numpy()[:, ::64].copy(),
+        "class_logits": detail["class_logits"].numpy(),
+    }
+    np.savez_compressed(os.path.join(GOLDEN, "vgg16_%s.npz" % tag), **out)
+    print("  wrote tests/golden/vgg16_%s.npz" % tag)
+
+
+def golden_small_ops(ref):
+    """Reference-side known answers for the pieces that are cheap to pin exactly."""
+    out = {}
+    for tag, ishape, fshape in (("vgg", (3, 600, 1000), (512, 37, 62)), ("resnet", (3, 600, 1000), (1024, 38, 63)),
+                                ("small", (3, 224, 320), (512, 14, 20)), ("odd", (3, 333, 517), (512, 20, 32))):
+        am, vm = ref.anchors.generate_anchor_maps(ishape, fshape, 16)
+        am2, vm2 = O.generate_anchor_maps(ishape, fshape, 16)
+        assert_equal("anchors[%s]" % tag, am2, am)
+        assert_equal("valid[%s]" % tag, vm2, vm)
+        out["anchors_%s_shape" % tag] = np.array(list(ishape) + list(fshape), dtype=np.int64)
+        out["anchors_%s_sha" % tag] = np.array([sha(am), sha(vm)])
+        out["anchors_%s_nvalid" % tag] = np.int64(vm.sum())
+        if tag in ("small", "odd"):
+            out["anchors_%s_map" % tag] = am
+            out["anchors_%s_valid" % tag] = vm
+
+    # numpy float64 decode (math_utils.py:65-97) on seeded inputs
+    rng = np.random.RandomState(5)
+    anchors = np.abs(rng.randn(64, 4)) * 100 + 20
+    deltas = (rng.randn(64, 4) * 0.5).astype(np.float32)
+    r = ref.math_utils.convert_deltas_to_boxes(deltas, anchors, [0, 0, 0, 0], [0.1, 0.1, 0.2, 0.2])
+    o = O.convert_deltas_to_boxes(deltas, anchors, [0, 0, 0, 0], [0.1, 0.1, 0.2, 0.2])
+    assert_equal("convert_deltas_to_boxes", o, r)
+
+    # mAP: the SURVEY's known answer + a seeded random accumulation through the reference's class
+    Box = ref.training_sample.Box
+    calc = ref.statistics.PrecisionRecallCurveCalculator()
+    gts = [(7, np.array([100, 200, 400, 700], dtype=np.float32)), (15, np.array([50, 50, 300, 180], dtype=np.float32))]
+    preds = {7: np.array([[100, 200, 400, 700, .9], [110, 210, 390, 690, .8], [0, 0, 50, 50, .7]], dtype=np.float64),
+             15: np.array([[50, 50, 300, 180, .6]], dtype=np.float64)}
+    calc.add_image_results(preds, [Box(c, "x", k) for c, k in gts])
+    known = float(calc.compute_mean_average_precision())
+    assert known == 1.0, known
+    rng = np.random.RandomState(11)
+    calc = ref.statistics.PrecisionRecallCurveCalculator()
+    mine = O.MeanAveragePrecision()
+    stream = []
+    for img_i in range(12):
+        g = []
+        for _ in range(rng.randint(1, 5)):
+            y1, x1 = rng.uniform(0, 400), rng.uniform(0, 700)
+            g.append((int(rng.randint(1, 6)), np.array([y1, x1, y1 + rng.uniform(40, 200), x1 + rng.uniform(40, 300)], dtype=np.float32)))
+        p = {}
+        for c in range(1, 21):
+            rows = []
+            for cls, k in g:
+                if cls == c and rng.rand() < 0.8:
+                    rows.append(np.concatenate([k + rng.randn(4) * rng.choice([3, 40]), [rng.uniform(0.05, 1)]]))
+            for _ in range(rng.randint(0, 3)):
+                y1, x1 = rng.uniform(0, 400), rng.uniform(0, 700)
+                rows.append(np.array([y1, x1, y1 + 80, x1 + 120, rng.uniform(0.05, 1)]))
+            rows.sort(key=lambda r_: -r_[4])
+            p[c] = np.array(rows, dtype=np.float64).reshape(-1, 5)
+        calc.add_image_results(p, [Box(c, "x", k) for c, k in g])
+        mine.add_image_results(p, g)
+        stream.append((g, p))
+    ref_map = float(calc.compute_mean_average_precision())
+    assert mine.mean_average_precision() == ref_map, (mine.mean_average_precision(), ref_map)
+    print("  oracle == reference: mAP stream  %.12f" % ref_map)
+    out["map_known_answer"] = np.float64(known)
+    out["map_stream_value"] = np.float64(ref_map)
+    out["map_stream_gt"] = np.array([[i, c] + k.tolist() for i, (g, _) in enumerate(stream) for c, k in g], dtype=np.float64)
+    out["map_stream_pred"] = np.array([[i, c] + row.tolist() for i, (_, p) in enumerate(stream) for c in p for row in p[c]], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLDEN, "small_ops.npz"), **out)
+    print("  wrote tests/golden/small_ops.npz")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--calibrate", action="store_true")
+    args = ap.parse_args()
+    t.manual_seed(0)
+    ref = reference_shims.install(O)
+    if args.calibrate:
+        calibrate(ref)
+        return
+    os.makedirs(GOLDEN, exist_ok=True)
+    golden_small_ops(ref)
+    sd = synthetic.vgg16_state_dict(1234)
+    run_case(ref, "600x1000_s0", sd, 0, 600, 1000, True, 0.05)
+    run_case(ref, "224x320_s3", sd, 3, 224, 320, True, 0.05)           # A = 2520 < 6000 anchors
+    run_case(ref, "333x517_s5_noedge", sd, 5, 333, 517, False, 0.05)   # ragged size, valid-anchor filter
+
+
+if __name__ == "__main__":
+    main()
