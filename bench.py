@@ -1,0 +1,203 @@
+"""
+bench.py -- images/sec of Faster R-CNN VGG-16 inference (600x1000, 300 proposals) on N x MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one `predict()` of one synthetic, already-preprocessed float32 3x600x1000 image that is
+resident in HBM when the timed region starts: VGG-16 backbone, RPN (6000 pre- / 300 post-NMS),
+RoI pooling, FC head, on-device float64 decode + per-class NMS, one D2H copy of the detections.
+Every image is an independent batch-1 forward (BASELINE.json configs[1]); `--inflight` of them
+are in flight on separate HIP streams.  fp32 end to end (the reference's dtype), exact-f32 MFMA.
+
+Multi-GPU: image-parallel, rank r owns its own images, no data-path collective; weak scaling
+(K steps per rank).  The mAP@0.5 bookkeeping runs after the timed region on a small labelled
+subset and is merged across ranks with the single all-gather of fasterrcnn_amd/evaluate.py.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+import torch.distributed as dist   # noqa: E402
+
+H, W = 600, 1000
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+# (cin, cout, h, w) of the 3x3 convolutions that run on the MFMA kernel (conv1_1 is the VALU kernel)
+_MFMA_CONVS = [(64, 64, 600, 1000), (64, 128, 300, 500), (128, 128, 300, 500), (128, 256, 150, 250),
+               (256, 256, 150, 250), (256, 256, 150, 250), (256, 512, 75, 125), (512, 512, 75, 125),
+               (512, 512, 75, 125), (512, 512, 37, 62), (512, 512, 37, 62), (512, 512, 37, 62),
+               (512, 512, 37, 62)]   # last = RPN trunk (models/rpn.py:88)
+
+
+def conv_mfma_flops_per_image():
+    return float(sum(2.0 * 9 * ci * co * h * w for ci, co, h, w in _MFMA_CONVS))
+
+
+def total_flops_per_image(n_rois=300):
+    conv1_1 = 2.0 * 27 * 64 * H * W
+    rpn_heads = 2.0 * 512 * 45 * 37 * 62
+    det = n_rois * 2.0 * (25088 * 4096 + 4096 * 4096 + 4096 * 101)
+    return conv1_1 + conv_mfma_flops_per_image() + rpn_heads + det
+
+
+def planted_ground_truth(seed, det, num_classes=21):
+    """Synthetic GT for image `seed`: seeded random boxes plus up to 3 of the image's own top
+    detections jittered by a few pixels (so mAP@0.5 is neither 0 nor 1)."""
+    from fasterrcnn_amd import synthetic
+    from fasterrcnn_amd.datasets.training_sample import Box
+    rng = np.random.RandomState(104729 * int(seed) + 1)
+    boxes = [Box(c, str(c), k) for c, k in synthetic.ground_truth(seed, H, W, num_classes)]
+    rows = [(c, r) for c, v in det.items() for r in v[:2]]
+    rows.sort(key=lambda cr: -cr[1][4])
+    for c, r in rows[:3]:
+        boxes.append(Box(int(c), str(c), (r[:4] + rng.randn(4) * 4.0).astype(np.float32)))
+    return boxes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--inflight", type=int, default=4, help="images in flight per GPU (separate HIP streams)")
+    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic images resident per GPU")
+    ap.add_argument("--map-images", type=int, default=8, help="labelled images per rank for the mAP@0.5 leg")
+    ap.add_argument("--cpu-images", type=int, default=3, help="images timed on the host CPU (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-images", type=int, default=10)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if world > 1 else args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from fasterrcnn_amd import _native, synthetic
+    from fasterrcnn_amd.evaluate import ImageRecords, merged_calculator
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    from fasterrcnn_amd.models.vgg16 import VGG16Backbone
+    _native.require_gpu()
+
+    sd = synthetic.vgg16_state_dict(1234)
+    model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda(dev).eval()
+
+    # synthetic image pool, resident in HBM before timing; per-image seed = global index
+    seeds = [rank * args.pool + i for i in range(args.pool)]
+    pool = [synthetic.image(s).unsqueeze(0).to(dev) for s in seeds]
+    nslots = max(1, args.inflight)
+
+    def run(n_steps):
+        pending = []
+        for i in range(n_steps):
+            if len(pending) == nslots:
+                pending.pop(0).result()
+            pending.append(model.predict_async(pool[i % len(pool)], 0.05, slot=1 + (i % nslots)))
+        last = None
+        while pending:
+            last = pending.pop(0).result()
+        return last
+
+    run(max(args.warmup, nslots))
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    value = n_gpus * args.steps / elapsed if world > 1 or args.gpus == 1 else args.steps / elapsed
+
+    # ---- mAP@0.5 leg (outside the timed region): labelled subset, merged across ranks -------------
+    records = ImageRecords()
+    for i in range(min(args.map_images, len(pool))):
+        det = model.predict(pool[i], score_threshold=0.05)
+        records.add(seeds[i], det, planted_ground_truth(seeds[i], det))
+    calc = merged_calculator(records)
+    mean_ap = float(calc.compute_mean_average_precision()) if calc._object_count_by_class_index else None
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: HIP events around every conv3x3 MFMA launch, one stream
+        model.predict(pool[0], score_threshold=0.05)
+        ctx = model.context(0)
+        ctx.timing_enable(True)
+        for i in range(args.roofline_images):
+            model.predict(pool[i % len(pool)], score_threshold=0.05)
+        torch.cuda.synchronize(dev)
+        timing = ctx.timing_read(reset=True)
+        ctx.timing_enable(False)
+        conv_ms, conv_launches = timing["conv3x3_mfma"]
+        flops_per_launch = conv_mfma_flops_per_image() / len(_MFMA_CONVS)
+        avg_launch_s = (conv_ms / 1e3) / max(conv_launches, 1)
+        achieved = flops_per_launch / avg_launch_s / 1e12 if conv_launches else 0.0
+        roofline = {
+            "kernel": "conv3x3_mfma_kernel (12 backbone layers + RPN trunk)",
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "flops_per_launch": flops_per_launch, "avg_launch_us": round(avg_launch_s * 1e6, 2),
+            "launches": int(conv_launches),
+            "per_class_ms_per_image": {k: round(v[0] / args.roofline_images, 4) for k, v in timing.items()},
+        }
+
+        cpu = None
+        if not args.no_cpu_baseline and n_gpus == 1:
+            from oracle import frcnn_oracle as O       # CPU baseline leg only (checker, never the product)
+            cores = os.cpu_count() or 1
+            torch.set_num_threads(cores)
+            img0 = synthetic.image(seeds[0]).unsqueeze(0)
+            O.predict(sd, img0, 0.05)                    # warm-up
+            tc = time.perf_counter()
+            for i in range(args.cpu_images):
+                O.predict(sd, synthetic.image(seeds[i % len(seeds)]).unsqueeze(0), 0.05)
+            dt = time.perf_counter() - tc
+            cpu = {"value": round(args.cpu_images / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+                   "sample": "%d x predict() of the 600x1000 workload through oracle/frcnn_oracle.py "
+                             "(torch-CPU conv/linear, %d threads), %.1f s" % (args.cpu_images, cores, dt)}
+
+        out = {
+            "metric": "images/sec (600x1000) Faster-RCNN VGG-16 inference", "value": round(value, 3),
+            "unit": "images/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "VGG-16 Faster R-CNN predict(), 3x600x1000 float32, batch=1 per forward, "
+                                   "6000 pre-/300 post-NMS proposals, score_threshold 0.05",
+                       "images_in_flight_per_gpu": nslots, "parallelism": "image-parallel x%d" % n_gpus,
+                       "flops_per_image": total_flops_per_image()},
+            "tflops_per_gpu": round(value / n_gpus * total_flops_per_image() / 1e12, 2),
+            "map_at_0.5": mean_ap, "map_images": int(args.map_images * world),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

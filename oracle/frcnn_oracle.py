@@ -170,17 +170,12 @@ def decode_boxes_f32(deltas, anchors):
     return boxes
 
 
-def rpn_forward(sd, feature_map, image_shape, anchor_map, anchor_valid_map, pre_nms, post_nms,
-                allow_edge_proposals=True, detail=None):
+def proposals_from_maps(score_map, delta_map, image_shape, anchor_map, anchor_valid_map, pre_nms, post_nms,
+                        allow_edge_proposals=True, detail=None):
     """
-    rpn.py:88-156.  Returns (objectness_score_map (1,H,W,9), box_deltas_map (1,H,W,36), proposals (N,4)).
-    `detail`, if a dict, receives the intermediates the parity tests compare.
+    rpn.py:98-153 from the permuted head outputs: score_map (1,H,W,9) (already sigmoid-ed),
+    delta_map (1,H,W,36).  Returns proposals (N,4).
     """
-    y = F.relu(F.conv2d(feature_map, sd[_S2 + "_rpn_conv1.weight"], sd[_S2 + "_rpn_conv1.bias"], padding=1))
-    score_map = t.sigmoid(F.conv2d(y, sd[_S2 + "_rpn_class.weight"], sd[_S2 + "_rpn_class.bias"]))
-    delta_map = F.conv2d(y, sd[_S2 + "_rpn_boxes.weight"], sd[_S2 + "_rpn_boxes.bias"])
-    score_map = score_map.permute(0, 2, 3, 1).contiguous()          # :95-96
-    delta_map = delta_map.permute(0, 2, 3, 1).contiguous()
     anchors = t.from_numpy(np.ascontiguousarray(anchor_map)).reshape(-1, 4)
     scores = score_map.reshape(-1)
     deltas = delta_map.reshape(-1, 4)
@@ -206,12 +201,31 @@ def rpn_forward(sd, feature_map, image_shape, anchor_map, anchor_valid_map, pre_
     keep = nms(cand.numpy(), cand_scores.numpy(), 0.7)[0:post_nms]   # :147-153
     out = cand[t.from_numpy(keep)]
     if detail is not None:
-        detail["rpn_trunk"] = y
         detail["scores"] = scores
         detail["decoded"] = decode_boxes_f32(deltas, anchors)
         detail["sorted_idx"] = flat_index[top].numpy().astype(np.int64)
         detail["n_after_filter"] = int(big.shape[0])
         detail["candidates"] = cand
+        detail["candidate_scores"] = cand_scores
+    return out
+
+
+def rpn_forward(sd, feature_map, image_shape, anchor_map, anchor_valid_map, pre_nms, post_nms,
+                allow_edge_proposals=True, detail=None):
+    """
+    rpn.py:88-156.  Returns (objectness_score_map (1,H,W,9), box_deltas_map (1,H,W,36), proposals (N,4)).
+    `detail`, if a dict, receives the intermediates the parity tests compare.
+    """
+    y = F.relu(F.conv2d(feature_map, sd[_S2 + "_rpn_conv1.weight"], sd[_S2 + "_rpn_conv1.bias"], padding=1))
+    score_map = t.sigmoid(F.conv2d(y, sd[_S2 + "_rpn_class.weight"], sd[_S2 + "_rpn_class.bias"]))
+    delta_map = F.conv2d(y, sd[_S2 + "_rpn_boxes.weight"], sd[_S2 + "_rpn_boxes.bias"])
+    score_map = score_map.permute(0, 2, 3, 1).contiguous()          # :95-96
+    delta_map = delta_map.permute(0, 2, 3, 1).contiguous()
+    out = proposals_from_maps(score_map, delta_map, image_shape, anchor_map, anchor_valid_map, pre_nms, post_nms,
+                              allow_edge_proposals, detail)
+    if detail is not None:
+        detail["rpn_trunk"] = y
+        detail["delta_map"] = delta_map
     return score_map, delta_map, out
 
 

@@ -1,0 +1,53 @@
+"""The C-ABI library loads, exports every symbol include/frcnn_hip.h declares, and validates
+arguments without touching a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+from fasterrcnn_amd import _native as nv
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "frcnn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(frcnn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    syms = header_symbols()
+    assert len(syms) >= 20
+    assert sorted(nv.SYMBOLS) == syms
+
+
+def test_library_exports_every_header_symbol():
+    lib = nv.lib()
+    raw = C.CDLL(nv.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(raw, name), name
+    assert lib.frcnn_abi_version() == 1
+    assert lib.frcnn_error_string(0) == b"ok"
+    assert lib.frcnn_error_string(-1) == b"invalid argument"
+
+
+def test_argument_validation_without_gpu():
+    lib = nv.lib()
+    assert lib.frcnn_anchors(600, 1000, 37, 62, 16, None, None, None) == -1
+    assert lib.frcnn_conv3x3_nhwc(None, None, None, None, 8, 8, 16, 64, 0, None) == -1
+    assert lib.frcnn_linear(None, 16, None, None, None, 16, 1, 1, 16, 0, None, 0, None) == -1
+    assert lib.frcnn_roi_pool(None, 1, 1, 4, None, None, 1, 7, 0.0625, None, None) == -1
+    assert lib.frcnn_detections(None, None, None, None, 300, 21, 600, 1000, 0.05, 0.3, None, None, None) == -1
+    handle = C.c_void_p()
+    assert lib.frcnn_ctx_create(C.byref(handle), 4, 4, 300) == -1          # image too small
+    assert lib.frcnn_ctx_create(C.byref(handle), 600, 1000, 100000) == -1  # too many rois
+    assert lib.frcnn_ctx_bytes(None) == 0
+    lib.frcnn_ctx_destroy(None)                                            # must be a no-op
+
+
+def test_linear_workspace_plan_is_deterministic():
+    lib = nv.lib()
+    # fc1 of one image's 300 RoIs: all rows in one block tile, 32 column blocks, split-K 8
+    assert lib.frcnn_linear_workspace_bytes(300, 4096, 25088) == 8 * 300 * 4096 * 4
+    assert lib.frcnn_linear_workspace_bytes(300, 4096, 4096) == 8 * 300 * 4096 * 4
+    assert lib.frcnn_linear_workspace_bytes(1, 1, 16) == 0

@@ -1,0 +1,115 @@
+"""Host-side logic of the product package on CPU: model surface, error behaviour, mAP mirror."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fasterrcnn_amd import statistics, synthetic
+from fasterrcnn_amd.datasets.training_sample import Box
+from fasterrcnn_amd.models import math_utils
+from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+from fasterrcnn_amd.models.vgg16 import VGG16Backbone
+from oracle import frcnn_oracle as O
+
+
+@pytest.fixture(scope="module")
+def cpu_model():
+    return FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+
+
+def test_state_dict_keys_match_reference(cpu_model, sd_cpu):
+    keys = list(cpu_model.state_dict().keys())
+    assert len(keys) == 40
+    assert sorted(keys) == sorted(sd_cpu.keys())                      # names captured from the reference
+    assert sum(p.numel() for p in cpu_model.parameters()) == 137057234
+    cpu_model.load_state_dict(sd_cpu, strict=True)
+    assert cpu_model.state_dict()["_stage3_detector_network._pool_to_feature_vector._fc1.weight"].shape == (4096, 25088)
+
+
+def test_backbone_contract(cpu_model):
+    b = cpu_model.backbone
+    assert (b.feature_map_channels, b.feature_pixels, b.feature_vector_size) == (512, 16, 4096)
+    assert b.compute_feature_map_shape((3, 600, 1000)) == (512, 37, 62)
+    assert b.image_preprocessing_params.means == [103.939, 116.779, 123.680]
+    assert b.image_preprocessing_params.channel_order.value == "BGR"
+
+
+def test_no_cpu_fallback(cpu_model):
+    img = torch.zeros((1, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="MI355X"):
+        cpu_model.predict(img, score_threshold=0.05)
+    with pytest.raises(AssertionError, match="Batch size must be 1"):
+        cpu_model.predict(torch.zeros((2, 3, 64, 64)), score_threshold=0.05)
+    with pytest.raises(NotImplementedError):
+        cpu_model.train_step()
+
+
+def test_product_does_not_import_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "fasterrcnn_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_iou_matches_oracle_pairwise():
+    rng = np.random.RandomState(0)
+    a = np.sort(rng.rand(7, 2, 2) * 100, axis=1).reshape(7, 4)[:, [0, 1, 2, 3]]
+    b = np.sort(rng.rand(5, 2, 2) * 100, axis=1).reshape(5, 4)
+    m = math_utils.intersection_over_union(a, b)
+    for i in range(7):
+        for j in range(5):
+            assert m[i, j] == O.iou_pair(a[i], b[j])
+
+
+def _stream(golden_dir):
+    g = np.load(os.path.join(golden_dir, "small_ops.npz"))
+    gts, preds = g["map_stream_gt"], g["map_stream_pred"]
+    for i in range(int(gts[:, 0].max()) + 1):
+        gt = [(int(r[1]), r[2:6].astype(np.float32)) for r in gts[gts[:, 0] == i]]
+        p = {c: preds[(preds[:, 0] == i) & (preds[:, 1] == c)][:, 2:7] for c in range(1, 21)}
+        yield gt, p
+    return
+
+
+def test_map_mirror_equals_reference_values(golden_dir):
+    g = np.load(os.path.join(golden_dir, "small_ops.npz"))
+    calc = statistics.PrecisionRecallCurveCalculator()
+    for gt, p in _stream(golden_dir):
+        calc.add_image_results(p, [Box(c, "x", k) for c, k in gt])
+    assert float(calc.compute_mean_average_precision()) == float(g["map_stream_value"])
+    # SURVEY 8(a14) known answer
+    calc = statistics.PrecisionRecallCurveCalculator()
+    preds = {7: np.array([[100, 200, 400, 700, .9], [110, 210, 390, 690, .8], [0, 0, 50, 50, .7]]),
+             15: np.array([[50, 50, 300, 180, .6]])}
+    for c in range(1, 21):
+        preds.setdefault(c, np.zeros((0, 5)))
+    calc.add_image_results(preds, [Box(7, "car", np.array([100, 200, 400, 700], np.float32)),
+                                   Box(15, "person", np.array([50, 50, 300, 180], np.float32))])
+    assert [tp for _, tp in calc._unsorted_predictions_by_class_index[7]] == [True, False, False]
+    assert float(calc.compute_mean_average_precision()) == 1.0
+
+
+def test_map_state_roundtrip_is_exact(golden_dir):
+    whole = statistics.PrecisionRecallCurveCalculator()
+    parts = [statistics.PrecisionRecallCurveCalculator() for _ in range(3)]
+    for i, (gt, p) in enumerate(_stream(golden_dir)):
+        boxes = [Box(c, "x", k) for c, k in gt]
+        whole.add_image_results(p, boxes)
+        parts[i % 3].add_image_results(p, boxes)
+    merged = statistics.PrecisionRecallCurveCalculator()
+    for part in parts:
+        merged.merge_state(part.state())
+    # image-interleaved sharding changes the insertion order of equal-score records only;
+    # scores here are continuous, so mAP must agree to the last bit
+    assert float(merged.compute_mean_average_precision()) == float(whole.compute_mean_average_precision())
+
+
+def test_synthetic_workload_is_reproducible():
+    a, b = synthetic.image(4), synthetic.image(4)
+    assert a.shape == (3, 600, 1000) and torch.equal(a, b)
+    assert not torch.equal(a, synthetic.image(5))
+    gt = synthetic.ground_truth(4)
+    assert 1 <= len(gt) <= 5 and all(1 <= c <= 20 and k.dtype == np.float32 for c, k in gt)

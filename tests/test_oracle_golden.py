@@ -1,0 +1,113 @@
+"""Pins oracle/frcnn_oracle.py against the golden vectors captured from the imported reference
+(oracle/make_golden.py).  CPU only."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fasterrcnn_amd import synthetic
+from oracle import frcnn_oracle as O
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def flat(d):
+    rows = [np.hstack([np.full((v.shape[0], 1), float(c)), v]) for c, v in sorted(d.items()) if v.shape[0]]
+    return np.vstack(rows) if rows else np.zeros((0, 6))
+
+
+@pytest.fixture(scope="module")
+def small_ops(golden_dir):
+    return np.load(os.path.join(golden_dir, "small_ops.npz"))
+
+
+@pytest.mark.parametrize("tag", ["vgg", "resnet", "small", "odd"])
+def test_anchor_maps_bit_exact(small_ops, tag):
+    s = small_ops["anchors_%s_shape" % tag]
+    am, vm = O.generate_anchor_maps(tuple(s[:3]), tuple(s[3:]), 16)
+    assert [sha(am), sha(vm)] == list(small_ops["anchors_%s_sha" % tag])
+    assert int(vm.sum()) == int(small_ops["anchors_%s_nvalid" % tag])
+    if tag in ("small", "odd"):
+        assert np.array_equal(am, small_ops["anchors_%s_map" % tag])
+        assert np.array_equal(vm, small_ops["anchors_%s_valid" % tag])
+
+
+def test_survey_probe_hashes(small_ops):
+    # hashes measured on the reference at survey time
+    assert list(small_ops["anchors_vgg_sha"]) == ["bc0ded16d198f63e", "0e397daf862a5ca2"]
+    assert list(small_ops["anchors_resnet_sha"]) == ["0cb76c8d833871ed", "b2cbea43c58fb086"]
+    assert int(small_ops["anchors_vgg_nvalid"]) == 8044
+
+
+def test_map_known_answer_and_stream(small_ops):
+    gts = small_ops["map_stream_gt"]
+    preds = small_ops["map_stream_pred"]
+    acc = O.MeanAveragePrecision()
+    for i in range(int(gts[:, 0].max()) + 1):
+        g = [(int(r[1]), r[2:6].astype(np.float32)) for r in gts[gts[:, 0] == i]]
+        p = {c: preds[(preds[:, 0] == i) & (preds[:, 1] == c)][:, 2:7] for c in range(1, 21)}
+        acc.add_image_results(p, g)
+    assert acc.mean_average_precision() == float(small_ops["map_stream_value"])
+    assert float(small_ops["map_known_answer"]) == 1.0
+
+
+def test_nms_edge_cases():
+    assert O.nms(np.zeros((0, 4), np.float32), np.zeros((0,), np.float32), 0.7).shape == (0,)
+    b = np.array([[0, 0, 10, 10], [0, 0, 10, 10], [20, 20, 30, 30], [0, 0, 10, 9.9]], np.float32)
+    s = np.array([0.5, 0.5, 0.9, 0.4], np.float32)
+    # ties keep input order (stable); identical boxes suppress each other; IoU 0.99 > 0.7
+    assert O.nms(b, s, 0.7).tolist() == [2, 0]
+    # degenerate zero-area boxes: 0/0 -> nan, never > thr -> kept
+    z = np.zeros((3, 4), np.float32)
+    assert O.nms(z, np.array([3, 2, 1], np.float32), 0.5).tolist() == [0, 1, 2]
+
+
+def test_roi_pool_semantics():
+    fm = np.arange(1 * 2 * 6 * 8, dtype=np.float32).reshape(1, 2, 6, 8)
+    # roi covering columns 0..3, rows 0..1 at scale 1: (b, x1, y1, x2, y2)
+    out = O.roi_pool(fm, np.array([[0, 0, 0, 3, 1]], np.float32), 2, 1.0)
+    assert out.shape == (1, 2, 2, 2)
+    assert out[0, 0].tolist() == [[1.0, 3.0], [9.0, 11.0]]
+    # half-away-from-zero rounding: 2.5 -> 3 (numpy's rint would give 2)
+    out = O.roi_pool(fm, np.array([[0, 2.5, 0, 2.5, 0]], np.float32), 1, 1.0)
+    assert out[0, 0, 0, 0] == 3.0
+    # roi entirely outside the map -> empty bins -> zeros
+    out = O.roi_pool(fm, np.array([[0, 100, 100, 120, 120]], np.float32), 2, 1.0)
+    assert not out.any()
+
+
+@pytest.mark.parametrize("tag,allow_edge", [("224x320_s3", True), ("333x517_s5_noedge", False)])
+def test_oracle_reproduces_reference_small(golden_dir, sd_cpu, tag, allow_edge):
+    g = np.load(os.path.join(golden_dir, "vgg16_%s.npz" % tag))
+    img = synthetic.image(int(g["seed"]), int(g["height"]), int(g["width"])).unsqueeze(0)
+    detail = {}
+    props, classes, deltas = O.forward(sd_cpu, img, allow_edge_proposals=allow_edge, detail=detail)
+    assert np.array_equal(props.numpy(), g["proposals"])
+    assert np.array_equal(classes.numpy(), g["classes"])
+    assert np.array_equal(deltas.numpy(), g["box_deltas"])
+    assert np.array_equal(detail["sorted_idx"].astype(np.int32), g["sorted_idx"])
+    det = O.detections(props.numpy(), classes.numpy(), deltas.numpy(), int(g["height"]), int(g["width"]),
+                       float(g["score_threshold"]))
+    assert sorted(det.keys()) == list(range(1, 21))
+    assert np.array_equal(flat(det), g["detections"])
+
+
+def test_oracle_reproduces_reference_full_size(golden_dir, sd_cpu):
+    g = np.load(os.path.join(golden_dir, "vgg16_600x1000_s0.npz"))
+    img = synthetic.image(0).unsqueeze(0)
+    assert tuple(img.shape) == (1, 3, 600, 1000)
+    detail = {}
+    props, classes, deltas = O.forward(sd_cpu, img, detail=detail)
+    fm = detail["feature_map"].numpy()[0]
+    assert np.array_equal(fm[::16], g["feature_map_sample"])
+    assert sha(detail["scores"].numpy()) == str(g["scores_sha"])
+    assert np.array_equal(detail["sorted_idx"].astype(np.int32), g["sorted_idx"])
+    assert np.array_equal(props.numpy(), g["proposals"])
+    assert np.array_equal(classes.numpy(), g["classes"])
+    assert np.array_equal(deltas.numpy(), g["box_deltas"])
+    det = O.detections(props.numpy(), classes.numpy(), deltas.numpy(), 600, 1000, 0.05)
+    assert np.array_equal(flat(det), g["detections"])
