@@ -23,7 +23,8 @@ KCLASS_NAMES = ("conv3x3_mfma", "conv3x3_c3", "linear_mfma", "proposals", "roi_p
 SYMBOLS = (
     "frcnn_abi_version", "frcnn_error_string", "frcnn_last_hip_error", "frcnn_device_count",
     "frcnn_anchors", "frcnn_pack_conv3x3", "frcnn_pack_conv3x3_c3", "frcnn_pack_fc_chw_to_hwc",
-    "frcnn_pack_stack_rows", "frcnn_conv3x3_c3", "frcnn_conv3x3_nhwc", "frcnn_maxpool2x2_nhwc",
+    "frcnn_pack_stack_rows", "frcnn_conv3x3_c3", "frcnn_conv3x3_workspace_bytes", "frcnn_conv3x3_nhwc",
+    "frcnn_maxpool2x2_nhwc",
     "frcnn_linear_workspace_bytes", "frcnn_linear", "frcnn_softmax_rows", "frcnn_rpn_proposals",
     "frcnn_nms", "frcnn_roi_pool", "frcnn_detections", "frcnn_ctx_create", "frcnn_ctx_destroy",
     "frcnn_ctx_bytes", "frcnn_vgg16_forward", "frcnn_ctx_tensor", "frcnn_ctx_timing_enable",
@@ -70,7 +71,8 @@ _SIGNATURES = {
     "frcnn_pack_fc_chw_to_hwc": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "frcnn_pack_stack_rows": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "frcnn_conv3x3_c3": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp]),
-    "frcnn_conv3x3_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp]),
+    "frcnn_conv3x3_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "frcnn_conv3x3_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_maxpool2x2_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "frcnn_linear_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "frcnn_linear": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),

@@ -38,6 +38,7 @@ struct frcnn_ctx {
     float *fc1_out = nullptr, *fc2_out = nullptr;  // [max_rois][4096]
     float *head_logits = nullptr;                  // [max_rois][128]
     void* lin_ws = nullptr; size_t lin_ws_bytes = 0;
+    void* conv_ws = nullptr; size_t conv_ws_bytes = 0;   // split-K partials of under-filled conv layers
     ProposalScratch ps{};
     // anchor cache key
     int anc_h = -1, anc_w = -1, anc_fh = -1, anc_fw = -1;
@@ -150,11 +151,13 @@ int frcnn_conv3x3_c3(const float* d_x, const float* d_wp, const float* d_bias, f
     return launch_conv3x3_c3(d_x, d_wp, d_bias, d_y, H, W, cout, flags, as_stream(stream));
 }
 
+size_t frcnn_conv3x3_workspace_bytes(int H, int W, int cin, int cout) { return conv3x3_workspace_bytes(H, W, cin, cout); }
+
 int frcnn_conv3x3_nhwc(const float* d_x, const float* d_wp, const float* d_bias, float* d_y, int H, int W,
-                       int cin, int cout, unsigned flags, void* stream)
+                       int cin, int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
 {
     if (!d_x || !d_wp || !d_bias || !d_y) return FRCNN_EINVAL;
-    return launch_conv3x3_nhwc(d_x, d_wp, d_bias, d_y, H, W, cin, cout, flags, as_stream(stream));
+    return launch_conv3x3_nhwc(d_x, d_wp, d_bias, d_y, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
 }
 
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream)
@@ -237,6 +240,25 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         const size_t w4 = linear_workspace_bytes(c->max_fh * c->max_fw, 45, 512);
         lin = w1; if (w2 > lin) lin = w2; if (w3 > lin) lin = w3; if (w4 > lin) lin = w4;
     }
+    size_t cws = 0;
+    {
+        // the layers that may split: every VGG-16 shape at the largest image this ctx accepts
+        const int dims[5][2] = {{max_image_h, max_image_w}, {max_image_h / 2, max_image_w / 2},
+                                {max_image_h / 4, max_image_w / 4}, {max_image_h / 8, max_image_w / 8},
+                                {max_image_h / 16, max_image_w / 16}};
+        const int chans[5][2] = {{64, 64}, {128, 128}, {256, 256}, {512, 512}, {512, 512}};
+        for (int i = 0; i < 5; ++i) {
+            size_t b = conv3x3_workspace_bytes(dims[i][0], dims[i][1], chans[i][0], chans[i][1]);
+            if (i > 0) {
+                const size_t b2 = conv3x3_workspace_bytes(dims[i][0], dims[i][1], chans[i - 1][1], chans[i][1]);
+                if (b2 > b) b = b2;
+            }
+            if (b > cws) cws = b;
+        }
+        // smaller images of the same ctx can pick a larger split factor: size for the worst case
+        const size_t generous = (size_t)16 * c->max_fh * c->max_fw * 512 * sizeof(float);
+        if (generous > cws) cws = generous;
+    }
     struct Item { void** p; size_t bytes; };
     void* ps_base = nullptr;
     Item items[] = {
@@ -247,7 +269,7 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         {(void**)&c->roi_out, (size_t)max_rois * 49 * 512 * 4},
         {(void**)&c->fc1_out, (size_t)max_rois * 4096 * 4}, {(void**)&c->fc2_out, (size_t)max_rois * 4096 * 4},
         {(void**)&c->head_logits, (size_t)max_rois * 128 * 4},
-        {(void**)&c->lin_ws, lin},
+        {(void**)&c->lin_ws, lin}, {(void**)&c->conv_ws, cws},
         {&ps_base, proposal_scratch_bytes(c->a_cap, c->pre_cap, 2048)},
     };
     size_t total = 0;
@@ -258,6 +280,7 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
     unsigned char* p = static_cast<unsigned char*>(c->slab);
     for (auto& it : items) { *it.p = p; p += align_up(it.bytes, 256); }
     c->lin_ws_bytes = lin;
+    c->conv_ws_bytes = cws;
     proposal_scratch_carve(c->ps, ps_base, c->a_cap, c->pre_cap, 2048);
     *out = c;
     return FRCNN_OK;
@@ -341,23 +364,23 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     float *A = c->act_a, *B = c->act_b;
     int h = H, wd = W;
     STEP(1, launch_conv3x3_c3(d_image, w->conv_w[0], w->conv_b[0], A, h, wd, 64, R, s));
-    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[1], w->conv_b[1], B, h, wd, 64, 64, RP, s));   h /= 2; wd /= 2;
-    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[2], w->conv_b[2], A, h, wd, 64, 128, R, s));
-    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[3], w->conv_b[3], B, h, wd, 128, 128, RP, s)); h /= 2; wd /= 2;
-    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[4], w->conv_b[4], A, h, wd, 128, 256, R, s));
-    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[5], w->conv_b[5], B, h, wd, 256, 256, R, s));
-    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[6], w->conv_b[6], A, h, wd, 256, 256, RP, s)); h /= 2; wd /= 2;
-    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[7], w->conv_b[7], B, h, wd, 256, 512, R, s));
-    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[8], w->conv_b[8], A, h, wd, 512, 512, R, s));
-    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[9], w->conv_b[9], B, h, wd, 512, 512, RP, s)); h /= 2; wd /= 2;
-    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[10], w->conv_b[10], A, h, wd, 512, 512, R, s));
-    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[11], w->conv_b[11], B, h, wd, 512, 512, R, s));
-    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[12], w->conv_b[12], c->fm, h, wd, 512, 512, R, s));
+    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[1], w->conv_b[1], B, h, wd, 64, 64, RP, c->conv_ws, c->conv_ws_bytes, s));   h /= 2; wd /= 2;
+    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[2], w->conv_b[2], A, h, wd, 64, 128, R, c->conv_ws, c->conv_ws_bytes, s));
+    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[3], w->conv_b[3], B, h, wd, 128, 128, RP, c->conv_ws, c->conv_ws_bytes, s)); h /= 2; wd /= 2;
+    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[4], w->conv_b[4], A, h, wd, 128, 256, R, c->conv_ws, c->conv_ws_bytes, s));
+    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[5], w->conv_b[5], B, h, wd, 256, 256, R, c->conv_ws, c->conv_ws_bytes, s));
+    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[6], w->conv_b[6], A, h, wd, 256, 256, RP, c->conv_ws, c->conv_ws_bytes, s)); h /= 2; wd /= 2;
+    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[7], w->conv_b[7], B, h, wd, 256, 512, R, c->conv_ws, c->conv_ws_bytes, s));
+    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[8], w->conv_b[8], A, h, wd, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
+    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[9], w->conv_b[9], B, h, wd, 512, 512, RP, c->conv_ws, c->conv_ws_bytes, s)); h /= 2; wd /= 2;
+    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[10], w->conv_b[10], A, h, wd, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
+    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[11], w->conv_b[11], B, h, wd, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
+    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[12], w->conv_b[12], c->fm, h, wd, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
     const int fh = h, fw = wd;
     c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms;
 
     // stage 2: RPN (models/rpn.py:88-153)
-    STEP(0, launch_conv3x3_nhwc(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, 512, 512, R, s));
+    STEP(0, launch_conv3x3_nhwc(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
     STEP(2, launch_linear(c->rpn_trunk, 512, w->rpn_head_w, w->rpn_head_b, c->rpn_head, 128, fh * fw, 45, 512,
                           0u, c->lin_ws, c->lin_ws_bytes, s));
     const float* amap = d_anchor_map;

@@ -47,8 +47,9 @@ int launch_pack_stack_rows(const float* w1, const float* b1, int n1, const float
 
 int launch_conv3x3_c3(const float* x, const float* wp, const float* b, float* y, int H, int W,
                       int cout, unsigned flags, hipStream_t s);
+size_t conv3x3_workspace_bytes(int H, int W, int cin, int cout);
 int launch_conv3x3_nhwc(const float* x, const float* wp, const float* b, float* y, int H, int W,
-                        int cin, int cout, unsigned flags, hipStream_t s);
+                        int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_maxpool2x2(const float* x, float* y, int H, int W, int c, hipStream_t s);
 
 size_t linear_workspace_bytes(int M, int N, int K);

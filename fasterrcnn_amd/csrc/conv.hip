@@ -18,6 +18,7 @@
 // registers: the wave owns two image rows, and the accumulator layout puts x, x+1 in
 // adjacent registers of one lane), then NHWC stores of 128 B per half-wave.
 #include "common.h"
+#include <cstdlib>
 
 namespace frcnn {
 
@@ -41,7 +42,8 @@ template <int WM, int WN, bool POOL>
 __global__ __launch_bounds__(256)
 void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                          const float* __restrict__ bias, float* __restrict__ y,
-                         int H, int W, int Cin, int Cout, int relu)
+                         int H, int W, int Cin, int Cout, int relu, int cout_tiles, int chunks_per_split,
+                         float* __restrict__ ws)
 {
     using C = ConvCfg<WM, WN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -56,7 +58,9 @@ void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ 
 
     const int x0 = blockIdx.x * 32;
     const int y0 = blockIdx.y * C::TR;
-    const int n0 = blockIdx.z * C::BN;
+    // blockIdx.z = cout tile + cout_tiles * k-split index (split-K over 16-channel chunks)
+    const int ksplit_idx = blockIdx.z / cout_tiles;
+    const int n0 = (blockIdx.z - ksplit_idx * cout_tiles) * C::BN;
 
     // ---- loop-invariant staging addresses ------------------------------------------------
     int h_src[C::NH];   // element offset of the piece inside x for chunk 0, or -1 (zero fill)
@@ -117,13 +121,15 @@ void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nchunks = Cin >> 4;
-    const int nstages = nchunks * 9;
+    const int chunk_begin = ksplit_idx * chunks_per_split;
+    int chunk_end = chunk_begin + chunks_per_split;
+    if (chunk_end > (Cin >> 4)) chunk_end = Cin >> 4;
+    const int nstages = (chunk_end - chunk_begin) * 9;
 
-    // prologue: chunk 0 halo + (chunk 0, tap 0) weights
-    load_halo(0);
-    load_w(0, 0);
-    store_halo(halo0);
+    // prologue: first chunk's halo + (first chunk, tap 0) weights
+    load_halo(chunk_begin);
+    load_w(chunk_begin, 0);
+    store_halo(halo0 + (chunk_begin & 1) * C::HALO_F);
     store_w(wts0);
     __syncthreads();
 
@@ -131,7 +137,7 @@ void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ 
     const int a_base = ((2 * wm) * HC + li) * LDK + 4 * lh;   // + (mt + r)*HC*LDK + s*LDK + 8g
     const int b_base = (64 * wn + li) * LDK + 4 * lh;         // + nt*32*LDK + 8g
 
-    int chunk = 0, tap = 0, tr = 0, ts = 0;
+    int chunk = chunk_begin, tap = 0, tr = 0, ts = 0;
     for (int s = 0; s < nstages; ++s) {
         const bool has_next = (s + 1) < nstages;
         int nchunk = chunk, ntap = tap + 1;
@@ -174,6 +180,25 @@ void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ 
     // ---- epilogue ------------------------------------------------------------------------
     // acc[mt][nt][r] = out[row y0+2wm+mt][col x0 + (r&3)+8(r>>2)+4lh][cout n0+64wn+32nt+li]
     const int orow = y0 + 2 * wm;
+    if (ws != nullptr) {
+        // split-K: raw partial sums [ksplit][H][W][Cout]; bias/ReLU/pool happen in the finish kernel
+        float* part = ws + (size_t)ksplit_idx * H * W * Cout;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = n0 + 64 * wn + 32 * nt + li;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int yy = orow + mt;
+                if (yy >= H) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int xx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (xx < W) part[((size_t)yy * W + xx) * Cout + co] = acc[mt][nt][r];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int co = n0 + 64 * wn + 32 * nt + li;
@@ -209,6 +234,46 @@ void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ 
                 }
             }
         }
+    }
+}
+
+// Split-K finish: y = act(bias + sum_k part[k]) (+ 2x2 max-pool), fixed summation order.
+__global__ __launch_bounds__(256)
+void conv_splitk_finish_kernel(const float* __restrict__ ws, int ksplit, const float* __restrict__ bias,
+                               float* __restrict__ y, int H, int W, int Cout, int relu, int pool)
+{
+    const int C4 = Cout >> 2;
+    const int Ho = pool ? H >> 1 : H, Wo = pool ? W >> 1 : W;
+    const size_t total = (size_t)Ho * Wo * C4;
+    const size_t plane = (size_t)H * W * Cout;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const size_t p = i / C4;
+        const int ox = (int)(p % Wo), oy = (int)(p / Wo);
+        const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[c4];
+        f32x4 best;
+        const int np = pool ? 4 : 1;
+        for (int q = 0; q < np; ++q) {
+            const int iy = pool ? 2 * oy + (q >> 1) : oy, ix = pool ? 2 * ox + (q & 1) : ox;
+            const size_t off = ((size_t)iy * W + ix) * Cout + 4 * c4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(ws + off);
+            for (int k = 1; k < ksplit; ++k) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(ws + k * plane + off);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += t[j];
+            }
+            if (q == 0) best = v;
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) best[j] = fmaxf(best[j], v[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = best[j] + bv[j];
+            best[j] = relu ? fmaxf(t, 0.f) : t;
+        }
+        reinterpret_cast<f32x4*>(y)[i] = best;
     }
 }
 
@@ -299,7 +364,7 @@ __global__ void pack_conv3x3_c3_kernel(const float* __restrict__ w, float* __res
 
 template <int WM, int WN, bool POOL>
 static int launch_cfg(const float* x, const float* wp, const float* b, float* y, int H, int W,
-                      int cin, int cout, int relu, hipStream_t s)
+                      int cin, int cout, int relu, int ksplit, float* ws, hipStream_t s)
 {
     using C = ConvCfg<WM, WN>;
     auto kern = conv3x3_mfma_kernel<WM, WN, POOL>;
@@ -309,25 +374,77 @@ static int launch_cfg(const float* x, const float* wp, const float* b, float* y,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_set = true;
     }
-    dim3 grid(cdiv(W, 32), cdiv(H, C::TR), cout / C::BN);
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, x, wp, b, y, H, W, cin, cout, relu);
+    const int cout_tiles = cout / C::BN;
+    const int nchunks = cin / 16;
+    dim3 grid(cdiv(W, 32), cdiv(H, C::TR), cout_tiles * ksplit);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, x, wp, b, y, H, W, cin, cout, relu, cout_tiles,
+                       cdiv(nchunks, ksplit), ksplit > 1 ? ws : (float*)nullptr);
     return check_launch();
 }
 
+// Split-K factor for a layer whose (rows x 32-col segments x cout tiles) grid cannot fill the
+// chip: the 37x62 maps of block 5 / the RPN trunk give 80 blocks for 256 CUs.  Power of two,
+// at least two 16-channel chunks per split.  FRCNN_CONV_BLOCKS_TARGET overrides the fill target.
+static int conv_blocks_target()
+{
+    static int target = -1;
+    if (target < 0) {
+        const char* e = getenv("FRCNN_CONV_BLOCKS_TARGET");
+        target = e ? atoi(e) : 640;
+        if (target < 1) target = 1;
+    }
+    return target;
+}
+
+static int choose_ksplit(int H, int W, int cin, int cout)
+{
+    const bool narrow = (cout % 128) != 0;
+    const int tr = narrow ? 8 : 4, bn = narrow ? 64 : 128;
+    const int blocks = cdiv(W, 32) * cdiv(H, tr) * (cout / bn);
+    const int nchunks = cin / 16;
+    const int target = conv_blocks_target();
+    if (blocks * 2 > target) return 1;
+    int k = 1;
+    while (k * 2 * blocks <= target && nchunks % (k * 2) == 0 && nchunks / (k * 2) >= 2) k *= 2;
+    return k;
+}
+
+size_t conv3x3_workspace_bytes(int H, int W, int cin, int cout)
+{
+    if (cin % 16 != 0 || cout % 64 != 0 || H < 1 || W < 1) return 0;
+    const int k = choose_ksplit(H, W, cin, cout);
+    return k > 1 ? (size_t)k * H * W * cout * sizeof(float) : 0;
+}
+
 int launch_conv3x3_nhwc(const float* x, const float* wp, const float* b, float* y, int H, int W,
-                        int cin, int cout, unsigned flags, hipStream_t s)
+                        int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, hipStream_t s)
 {
     if (cin % 16 != 0 || cout % 64 != 0 || H < 1 || W < 1) return FRCNN_EINVAL;
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
     const bool pool = (flags & FRCNN_POOL2) != 0;
     if (pool && (H < 2 || W < 2)) return FRCNN_EINVAL;
+    int ksplit = choose_ksplit(H, W, cin, cout);
+    if (ksplit > 1 && (ws == nullptr || ws_bytes < (size_t)ksplit * H * W * cout * sizeof(float))) ksplit = 1;
+    float* wsf = static_cast<float*>(ws);
+    int rc;
     // Tile choice: cout = 64 -> 8 rows x 32 cols x 64 ch; otherwise 4 rows x 32 cols x 128 ch.
-    if (cout % 128 != 0) {
-        return pool ? launch_cfg<4, 1, true>(x, wp, b, y, H, W, cin, cout, relu, s)
-                    : launch_cfg<4, 1, false>(x, wp, b, y, H, W, cin, cout, relu, s);
+    if (ksplit > 1) {
+        rc = (cout % 128 != 0) ? launch_cfg<4, 1, false>(x, wp, b, y, H, W, cin, cout, relu, ksplit, wsf, s)
+                               : launch_cfg<2, 2, false>(x, wp, b, y, H, W, cin, cout, relu, ksplit, wsf, s);
+        if (rc) return rc;
+        const size_t total = (size_t)(pool ? H / 2 : H) * (pool ? W / 2 : W) * (cout / 4);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, (const float*)wsf, ksplit, b, y,
+                           H, W, cout, relu, pool ? 1 : 0);
+        return check_launch();
     }
-    return pool ? launch_cfg<2, 2, true>(x, wp, b, y, H, W, cin, cout, relu, s)
-                : launch_cfg<2, 2, false>(x, wp, b, y, H, W, cin, cout, relu, s);
+    if (cout % 128 != 0) {
+        return pool ? launch_cfg<4, 1, true>(x, wp, b, y, H, W, cin, cout, relu, 1, nullptr, s)
+                    : launch_cfg<4, 1, false>(x, wp, b, y, H, W, cin, cout, relu, 1, nullptr, s);
+    }
+    return pool ? launch_cfg<2, 2, true>(x, wp, b, y, H, W, cin, cout, relu, 1, nullptr, s)
+                : launch_cfg<2, 2, false>(x, wp, b, y, H, W, cin, cout, relu, 1, nullptr, s);
 }
 
 int launch_conv3x3_c3(const float* x, const float* wp, const float* b, float* y, int H, int W,

@@ -128,8 +128,9 @@ void detections_kernel(const float* __restrict__ props, const float* __restrict_
         int kept = 0;
         const int nw = (m + 63) >> 6;
         for (int p = 0; p < m; ++p) {
-            const unsigned lo = __shfl((unsigned)(rem & 0xFFFFFFFFull), p >> 6);
-            const unsigned hi = __shfl((unsigned)(rem >> 32), p >> 6);
+            const int src = __builtin_amdgcn_readfirstlane(p >> 6);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rem & 0xFFFFFFFFull), src);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rem >> 32), src);
             const u64 word = ((u64)hi << 32) | lo;
             if (!((word >> (p & 63)) & 1ull)) {
                 if (t == 0) keep_list[kept] = p;

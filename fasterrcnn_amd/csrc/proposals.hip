@@ -106,22 +106,36 @@ void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_
         u64 prefix = 0ull, pmask = 0ull;
         int remaining = K;
         for (int byte = 7; byte >= 0; --byte) {
+            const int sh = byte * 8;
+            if (MODE == 0 && (byte == 3 || byte == 2) && n_keys < 65535) {   // index+1 < 2^16: digits are 0 in every key
+                pmask |= 255ull << sh;
+                continue;
+            }
             for (int i = tid; i < 256; i += 1024) hist[i] = 0;
             __syncthreads();
-            const int sh = byte * 8;
             for (int i = tid; i < n_keys; i += 1024) {
                 const u64 k = keys[i];
                 if (k != 0ull && (k & pmask) == prefix) atomicAdd(&hist[(int)((k >> sh) & 255ull)], 1);
             }
             __syncthreads();
-            if (tid == 0) {
-                int c = 0, d = 255;
-                for (; d > 0; --d) {
-                    const int hcount = hist[d];
-                    if (c + hcount >= remaining) break;
-                    c += hcount;
+            if (tid < 64) {
+                // lane l owns bins 255-4l .. 252-4l; suffix counts from the top digit down
+                const int top = 255 - 4 * tid;
+                const int h0 = hist[top], h1 = hist[top - 1], h2 = hist[top - 2], h3 = hist[top - 3];
+                const int sum = h0 + h1 + h2 + h3;
+                int incl = sum;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (tid >= o) incl += v;
                 }
-                misc[2] = d; misc[3] = remaining - c;
+                const int excl = incl - sum;
+                if (excl < remaining && incl >= remaining) {       // exactly one lane
+                    int c = excl, d = top;
+                    if (c + h0 < remaining) { c += h0; d = top - 1;
+                        if (c + h1 < remaining) { c += h1; d = top - 2;
+                            if (c + h2 < remaining) { c += h2; d = top - 3; } } }
+                    misc[2] = d; misc[3] = remaining - c;
+                }
             }
             __syncthreads();
             prefix |= (u64)misc[2] << sh;
@@ -251,10 +265,19 @@ void nms_mask_kernel(const f32x4* __restrict__ boxes, const int32_t* __restrict_
     mask[(size_t)i * nw_stride + bx] = bits;
 }
 
-// One wave.  removed[] lives in registers: lane l holds words l and l+64 (capacity 8192 boxes)
-// plus words l+128, l+192 (16384).  Per 64-box chunk: lane l fetches the diagonal word of box
-// 64c+l, the wave resolves the chunk serially on a uniform 64-bit "alive" word (readlane per
-// kept box), then ORs the kept rows into removed[] with independent row loads.
+__device__ __forceinline__ u64 readlane64(u64 v, int lane_uniform)
+{
+    const int l = __builtin_amdgcn_readfirstlane(lane_uniform);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xFFFFFFFFull), l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+// One wave.  removed[] lives in registers: lane l holds words l, l+64 (capacity 8192 boxes) and
+// l+128, l+192 (16384).  Per 64-box chunk: lane l holds the diagonal word of box 64c+l (prefetched
+// one chunk ahead), the chunk is resolved serially on a wave-uniform 64-bit "alive" word in
+// SGPRs (s_ff1 + v_readlane per kept box, no LDS), then the kept rows are OR-ed into removed[]
+// with independent row loads issued four rows at a time.
 __global__ __launch_bounds__(64)
 void nms_reduce_kernel(const u64* __restrict__ mask, int nw_stride, const int32_t* __restrict__ n_ptr,
                        int max_keep, const f32x4* __restrict__ cand_boxes,
@@ -268,16 +291,16 @@ void nms_reduce_kernel(const u64* __restrict__ mask, int nw_stride, const int32_
     u64 rem[4] = {0ull, 0ull, 0ull, 0ull};
     __shared__ int32_t kept_list[2048];
     int kept = 0;
+    u64 diag_next = (lane < n) ? mask[(size_t)lane * nw_stride] : 0ull;
     for (int c = 0; c < nw && kept < max_keep; ++c) {
-        // removed word of this chunk (uniform)
-        const u64 mine = rem[0];
-        u64 sel = (c >> 6) == 0 ? rem[0] : (c >> 6) == 1 ? rem[1] : (c >> 6) == 2 ? rem[2] : rem[3];
-        (void)mine;
-        const unsigned lo = __shfl((unsigned)(sel & 0xFFFFFFFFull), c & 63);
-        const unsigned hi = __shfl((unsigned)(sel >> 32), c & 63);
-        const u64 cur = ((u64)hi << 32) | lo;
-        const int row = c * 64 + lane;
-        const u64 diag = row < n ? mask[(size_t)row * nw_stride + c] : 0ull;
+        const u64 diag = diag_next;
+        {
+            const int nrow = (c + 1) * 64 + lane;
+            diag_next = (c + 1 < nw && nrow < n) ? mask[(size_t)nrow * nw_stride + (c + 1)] : 0ull;
+        }
+        const int cq = c >> 6;
+        const u64 sel = cq == 0 ? rem[0] : cq == 1 ? rem[1] : cq == 2 ? rem[2] : rem[3];
+        const u64 cur = readlane64(sel, c & 63);
         const int left = n - c * 64;
         const u64 validm = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
         u64 alive = ~cur & validm;
@@ -287,23 +310,38 @@ void nms_reduce_kernel(const u64* __restrict__ mask, int nw_stride, const int32_
             keepbits |= 1ull << b;
             if (lane == 0) kept_list[kept] = c * 64 + b;
             ++kept;
-            const unsigned dlo = __shfl((unsigned)(diag & 0xFFFFFFFFull), b);
-            const unsigned dhi = __shfl((unsigned)(diag >> 32), b);
-            alive &= ~(((u64)dhi << 32) | dlo);
+            alive &= ~readlane64(diag, b);
             alive &= ~(1ull << b);
         }
         if (kept >= max_keep) break;
-        // OR the kept rows into removed[] for words > c
+        // OR the kept rows into removed[] for words > c, four independent rows per step
         u64 kb = keepbits;
+        const bool wide = nw > 128;
         while (kb != 0ull) {
-            const int b = __ffsll((long long)kb) - 1;
-            kb &= kb - 1ull;
-            const u64* mrow = mask + (size_t)(c * 64 + b) * nw_stride;
+            const u64* rows[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int w = lane + 64 * q;
-                if (w > c && w < nw) rem[q] |= mrow[w];
+            for (int u = 0; u < 4; ++u) {
+                if (kb != 0ull) {
+                    const int b = __ffsll((long long)kb) - 1;
+                    kb &= kb - 1ull;
+                    rows[u] = mask + (size_t)(c * 64 + b) * nw_stride;
+                } else {
+                    rows[u] = nullptr;
+                }
             }
+            u64 v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int w = lane + 64 * q;
+                    const bool need = rows[u] != nullptr && w > c && w < nw && (q < 2 || wide);
+                    v[u][q] = need ? rows[u][w] : 0ull;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rem[q] |= v[u][q];
         }
     }
     __syncthreads();

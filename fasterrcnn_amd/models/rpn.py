@@ -10,7 +10,7 @@ from torch import nn
 
 from .. import _native as nv
 from .. import runtime as rt
-from .vgg16 import pack_conv3x3
+from .vgg16 import conv3x3, pack_conv3x3
 
 
 def pack_stack_rows(m1, m2, n_pad=128):
@@ -87,9 +87,7 @@ class RegionProposalNetwork(nn.Module):
         a = fh * fw * 9
         with t.cuda.device(dev):
             s = nv.stream_ptr()
-            trunk = t.empty((fh, fw, c), dtype=t.float32, device=dev)
-            nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(x), nv.ptr(wc), nv.ptr(bc), nv.ptr(trunk), fh, fw, c, c, nv.RELU, s),
-                     "frcnn_conv3x3_nhwc")
+            trunk = conv3x3(x, wc, bc, c, c, relu=True, pool=False)
             head = t.zeros((fh * fw, 128), dtype=t.float32, device=dev)
             ws_bytes = int(lib.frcnn_linear_workspace_bytes(fh * fw, 45, c))
             ws = t.empty((max(ws_bytes, 4) // 4,), dtype=t.float32, device=dev)

@@ -35,6 +35,21 @@ def pack_conv3x3(conv):
     return out
 
 
+def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False):
+    """One 3x3 'same' convolution (+ReLU, + fused 2x2 max-pool) on an NHWC CUDA tensor via frcnn_conv3x3_nhwc."""
+    h, w = int(x_hwc.shape[0]), int(x_hwc.shape[1])
+    oh, ow = (h // 2, w // 2) if pool else (h, w)
+    y = t.empty((oh, ow, cout), dtype=t.float32, device=x_hwc.device)
+    lib = nv.lib()
+    ws_bytes = int(lib.frcnn_conv3x3_workspace_bytes(h, w, cin, cout))
+    ws = t.empty((max(ws_bytes, 4) // 4,), dtype=t.float32, device=x_hwc.device)
+    flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
+    with t.cuda.device(x_hwc.device):
+        nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
+                                        nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc")
+    return y
+
+
 class FeatureExtractor(nn.Module):
     def __init__(self):
         super().__init__()
@@ -69,21 +84,16 @@ class FeatureExtractor(nn.Module):
         packed = self.packed()
         lib = nv.lib()
         h, w = int(x.shape[2]), int(x.shape[3])
-        with t.cuda.device(x.device):
-            s = nv.stream_ptr()
-            cur = None
-            for i, (name, cin, cout, pool) in enumerate(_LAYERS):
-                wp, b = packed[i]
-                oh, ow = (h // 2, w // 2) if pool else (h, w)
-                y = t.empty((oh, ow, cout), dtype=t.float32, device=x.device)
-                if i == 0:
-                    nv.check(lib.frcnn_conv3x3_c3(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cout, nv.RELU, s),
-                             "frcnn_conv3x3_c3")
-                else:
-                    flags = nv.RELU | (nv.POOL2 if pool else 0)
-                    nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(cur), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags, s),
-                             "frcnn_conv3x3_nhwc")
-                cur, h, w = y, oh, ow
+        cur = None
+        for i, (name, cin, cout, pool) in enumerate(_LAYERS):
+            wp, b = packed[i]
+            if i == 0:
+                cur = t.empty((h, w, cout), dtype=t.float32, device=x.device)
+                with t.cuda.device(x.device):
+                    nv.check(lib.frcnn_conv3x3_c3(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(cur), h, w, cout, nv.RELU,
+                                                  nv.stream_ptr()), "frcnn_conv3x3_c3")
+            else:
+                cur = conv3x3(cur, wp, b, cin, cout, relu=True, pool=pool)
         return cur.permute(2, 0, 1).unsqueeze(0)
 
 

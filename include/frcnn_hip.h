@@ -86,9 +86,14 @@ int frcnn_conv3x3_c3(const float* d_x_chw, const float* d_w_packed, const float*
                      float* d_y, int H, int W, int cout, unsigned flags, void* stream);
 /* General layer on the f32 MFMA pipe: x NHWC [H][W][cin], y NHWC [H][W][cout] or, with
  * FRCNN_POOL2, [H/2][W/2][cout].  Requires cin % 16 == 0, cout % 64 == 0.
- * d_w_packed from frcnn_pack_conv3x3. */
+ * d_w_packed from frcnn_pack_conv3x3.  Layers whose output grid cannot fill the chip (the 37x62
+ * maps of block 5 / the RPN trunk) run split-K over input channels with a deterministic
+ * fixed-order finish; `d_ws` is scratch of at least frcnn_conv3x3_workspace_bytes() bytes
+ * (NULL or too small = no split, same results up to fp32 summation order). */
+size_t frcnn_conv3x3_workspace_bytes(int H, int W, int cin, int cout);
 int frcnn_conv3x3_nhwc(const float* d_x, const float* d_w_packed, const float* d_bias,
-                       float* d_y, int H, int W, int cin, int cout, unsigned flags, void* stream);
+                       float* d_y, int H, int W, int cin, int cout, unsigned flags,
+                       void* d_ws, size_t ws_bytes, void* stream);
 /* Stand-alone 2x2/stride-2 floor max-pool on NHWC (vgg16.py:78,82,87,92), c % 4 == 0. */
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream);
 

@@ -34,7 +34,7 @@ def test_library_exports_every_header_symbol():
 def test_argument_validation_without_gpu():
     lib = nv.lib()
     assert lib.frcnn_anchors(600, 1000, 37, 62, 16, None, None, None) == -1
-    assert lib.frcnn_conv3x3_nhwc(None, None, None, None, 8, 8, 16, 64, 0, None) == -1
+    assert lib.frcnn_conv3x3_nhwc(None, None, None, None, 8, 8, 16, 64, 0, None, 0, None) == -1
     assert lib.frcnn_linear(None, 16, None, None, None, 16, 1, 1, 16, 0, None, 0, None) == -1
     assert lib.frcnn_roi_pool(None, 1, 1, 4, None, None, 1, 7, 0.0625, None, None) == -1
     assert lib.frcnn_detections(None, None, None, None, 300, 21, 600, 1000, 0.05, 0.3, None, None, None) == -1
@@ -51,3 +51,6 @@ def test_linear_workspace_plan_is_deterministic():
     assert lib.frcnn_linear_workspace_bytes(300, 4096, 25088) == 8 * 300 * 4096 * 4
     assert lib.frcnn_linear_workspace_bytes(300, 4096, 4096) == 8 * 300 * 4096 * 4
     assert lib.frcnn_linear_workspace_bytes(1, 1, 16) == 0
+    # conv: the 37x62 block-5 / RPN-trunk layers split 8-way, the 600x1000 layer does not
+    assert lib.frcnn_conv3x3_workspace_bytes(37, 62, 512, 512) == 8 * 37 * 62 * 512 * 4
+    assert lib.frcnn_conv3x3_workspace_bytes(600, 1000, 64, 64) == 0

@@ -84,9 +84,10 @@ def test_conv3x3_c3(H, W):
     w = torch.randn((64, 3, 3, 3), generator=g) * 0.2
     b = torch.randn((64,), generator=g)
     wp = torch.empty((27, 64), device=DEV)
-    nv.check(nv.lib().frcnn_pack_conv3x3_c3(nv.ptr(gpu(w)), nv.ptr(wp), 64, S()), "pack")
+    dw, dx, db = gpu(w), gpu(x), gpu(b)          # keep device inputs alive across the async launches
+    nv.check(nv.lib().frcnn_pack_conv3x3_c3(nv.ptr(dw), nv.ptr(wp), 64, S()), "pack")
     y = torch.empty((H, W, 64), device=DEV)
-    nv.check(nv.lib().frcnn_conv3x3_c3(nv.ptr(gpu(x)), nv.ptr(wp), nv.ptr(gpu(b)), nv.ptr(y), H, W, 64, nv.RELU, S()), "conv_c3")
+    nv.check(nv.lib().frcnn_conv3x3_c3(nv.ptr(dx), nv.ptr(wp), nv.ptr(db), nv.ptr(y), H, W, 64, nv.RELU, S()), "conv_c3")
     check_conv(y, x, w, b, True, False, "conv_c3 %dx%d" % (H, W))
 
 
@@ -107,23 +108,34 @@ def test_conv3x3_nhwc(H, W, cin, cout, pool, relu):
     w = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
     b = torch.randn((cout,), generator=g) * 0.1
     wp = torch.empty((9, cout, cin), device=DEV)
-    nv.check(nv.lib().frcnn_pack_conv3x3(nv.ptr(gpu(w)), nv.ptr(wp), cout, cin, S()), "pack")
+    dw, db = gpu(w), gpu(b)
+    nv.check(nv.lib().frcnn_pack_conv3x3(nv.ptr(dw), nv.ptr(wp), cout, cin, S()), "pack")
     # pack layout: [tap][cout][cin]
     assert torch.equal(wp.cpu(), w.permute(2, 3, 0, 1).reshape(9, cout, cin))
     xh = gpu(x.permute(1, 2, 0))
     oh, ow = (H // 2, W // 2) if pool else (H, W)
     y = torch.full((oh, ow, cout), float("nan"), device=DEV)
     flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
-    nv.check(nv.lib().frcnn_conv3x3_nhwc(nv.ptr(xh), nv.ptr(wp), nv.ptr(gpu(b)), nv.ptr(y), H, W, cin, cout, flags, S()), "conv")
+    lib = nv.lib()
+    ws_bytes = int(lib.frcnn_conv3x3_workspace_bytes(H, W, cin, cout))
+    ws = torch.empty((max(ws_bytes, 4) // 4,), device=DEV)
+    nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(xh), nv.ptr(wp), nv.ptr(db), nv.ptr(y), H, W, cin, cout, flags,
+                                    nv.ptr(ws), ws_bytes, S()), "conv")
     assert not torch.isnan(y).any()
-    check_conv(y, x, w, b, relu, pool, "conv %dx%d %d->%d pool=%d" % (H, W, cin, cout, pool))
+    check_conv(y, x, w, b, relu, pool, "conv %dx%d %d->%d pool=%d (split-K ws %d B)" % (H, W, cin, cout, pool, ws_bytes))
+    # without scratch the layer runs un-split: same result up to fp32 summation order
+    y1 = torch.full((oh, ow, cout), float("nan"), device=DEV)
+    nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(xh), nv.ptr(wp), nv.ptr(db), nv.ptr(y1), H, W, cin, cout, flags, None, 0, S()), "conv")
+    check_conv(y1, x, w, b, relu, pool, "   un-split")
+    if ws_bytes == 0:
+        assert torch.equal(y, y1)
 
 
 def test_conv_rejects_unsupported_shapes():
     d = torch.zeros(16, device=DEV)
     lib = nv.lib()
-    assert lib.frcnn_conv3x3_nhwc(nv.ptr(d), nv.ptr(d), nv.ptr(d), nv.ptr(d), 4, 4, 3, 64, 0, S()) == -1    # cin % 16
-    assert lib.frcnn_conv3x3_nhwc(nv.ptr(d), nv.ptr(d), nv.ptr(d), nv.ptr(d), 4, 4, 16, 32, 0, S()) == -1   # cout % 64
+    assert lib.frcnn_conv3x3_nhwc(nv.ptr(d), nv.ptr(d), nv.ptr(d), nv.ptr(d), 4, 4, 3, 64, 0, None, 0, S()) == -1    # cin % 16
+    assert lib.frcnn_conv3x3_nhwc(nv.ptr(d), nv.ptr(d), nv.ptr(d), nv.ptr(d), 4, 4, 16, 32, 0, None, 0, S()) == -1   # cout % 64
     assert lib.frcnn_conv3x3_c3(nv.ptr(d), nv.ptr(d), nv.ptr(d), nv.ptr(d), 4, 4, 64, nv.POOL2, S()) == -4
 
 
@@ -131,7 +143,8 @@ def test_maxpool_exact():
     g = torch.Generator().manual_seed(3)
     x = torch.randn((64, 75, 125), generator=g)
     y = torch.empty((37, 62, 64), device=DEV)
-    nv.check(nv.lib().frcnn_maxpool2x2_nhwc(nv.ptr(gpu(x.permute(1, 2, 0))), nv.ptr(y), 75, 125, 64, S()), "maxpool")
+    dx = gpu(x.permute(1, 2, 0))
+    nv.check(nv.lib().frcnn_maxpool2x2_nhwc(nv.ptr(dx), nv.ptr(y), 75, 125, 64, S()), "maxpool")
     assert torch.equal(y.cpu().permute(2, 0, 1), F.max_pool2d(x.unsqueeze(0), 2, 2)[0])
 
 
@@ -155,7 +168,8 @@ def test_linear(M, N, K, relu):
     ws = torch.empty((max(ws_bytes, 4) // 4,), device=DEV)
     ldy = N + 3
     y = torch.full((M, ldy), 7.0, device=DEV)
-    nv.check(lib.frcnn_linear(nv.ptr(gpu(a)), K, nv.ptr(gpu(w)), nv.ptr(gpu(b)), nv.ptr(y), ldy, M, N, K,
+    da, dw, db = gpu(a), gpu(w), gpu(b)
+    nv.check(lib.frcnn_linear(nv.ptr(da), K, nv.ptr(dw), nv.ptr(db), nv.ptr(y), ldy, M, N, K,
                               nv.RELU if relu else 0, nv.ptr(ws), ws_bytes, S()), "linear")
     out = y.cpu()
     assert (out[:, N:] == 7.0).all()                                  # nothing written past N
@@ -171,7 +185,7 @@ def test_linear(M, N, K, relu):
     assert e_ours <= 4e-6 * np.sqrt(K)
     # deterministic split-K: a second run is bit-identical
     y2 = torch.full((M, ldy), 7.0, device=DEV)
-    nv.check(lib.frcnn_linear(nv.ptr(gpu(a)), K, nv.ptr(gpu(w)), nv.ptr(gpu(b)), nv.ptr(y2), ldy, M, N, K,
+    nv.check(lib.frcnn_linear(nv.ptr(da), K, nv.ptr(dw), nv.ptr(db), nv.ptr(y2), ldy, M, N, K,
                               nv.RELU if relu else 0, nv.ptr(ws), ws_bytes, S()), "linear")
     assert torch.equal(y2.cpu(), out)
 
@@ -180,12 +194,14 @@ def test_fc_weight_permutation_and_stack_rows():
     g = torch.Generator().manual_seed(9)
     w = torch.randn((8, 512 * 49), generator=g)
     wp = torch.empty((8, 512 * 49), device=DEV)
-    nv.check(nv.lib().frcnn_pack_fc_chw_to_hwc(nv.ptr(gpu(w)), nv.ptr(wp), 8, 512, 49, S()), "pack_fc")
+    dw = gpu(w)
+    nv.check(nv.lib().frcnn_pack_fc_chw_to_hwc(nv.ptr(dw), nv.ptr(wp), 8, 512, 49, S()), "pack_fc")
     assert torch.equal(wp.cpu(), w.reshape(8, 512, 49).permute(0, 2, 1).reshape(8, -1))
     w1, b1 = torch.randn((9, 64), generator=g), torch.randn((9,), generator=g)
     w2, b2 = torch.randn((36, 64), generator=g), torch.randn((36,), generator=g)
     wo, bo = torch.empty((128, 64), device=DEV), torch.empty((128,), device=DEV)
-    nv.check(nv.lib().frcnn_pack_stack_rows(nv.ptr(gpu(w1)), nv.ptr(gpu(b1)), 9, nv.ptr(gpu(w2)), nv.ptr(gpu(b2)), 36,
+    d1, e1, d2, e2 = gpu(w1), gpu(b1), gpu(w2), gpu(b2)
+    nv.check(nv.lib().frcnn_pack_stack_rows(nv.ptr(d1), nv.ptr(e1), 9, nv.ptr(d2), nv.ptr(e2), 36,
                                             64, 128, nv.ptr(wo), nv.ptr(bo), S()), "stack")
     assert torch.equal(wo.cpu()[:45], torch.cat([w1, w2])) and not wo.cpu()[45:].any()
     assert torch.equal(bo.cpu()[:45], torch.cat([b1, b2])) and not bo.cpu()[45:].any()
@@ -195,7 +211,8 @@ def test_softmax_rows():
     g = torch.Generator().manual_seed(4)
     x = torch.randn((300, 128), generator=g) * 3
     y = torch.empty((300, 21), device=DEV)
-    nv.check(nv.lib().frcnn_softmax_rows(nv.ptr(gpu(x)), 128, nv.ptr(y), 300, 21, S()), "softmax")
+    dx = gpu(x)
+    nv.check(nv.lib().frcnn_softmax_rows(nv.ptr(dx), 128, nv.ptr(y), 300, 21, S()), "softmax")
     ref = F.softmax(x[:, :21], dim=1)
     assert float((y.cpu() - ref).abs().max()) <= 2e-7         # a few ulp of values <= 1
 
@@ -225,7 +242,8 @@ def test_rpn_proposals_vs_oracle(ctx, ih, iw, pre, post, allow_edge, seed):
     head[:, 0:9] = torch.randn((fh * fw, 9), generator=g) * 1.5
     head[:, 9:45] = torch.randn((fh * fw, 36), generator=g) * 0.3
     am, vm = O.generate_anchor_maps((3, ih, iw), (512, fh, fw), 16)
-    scores, sidx, props, counts = run_proposals(ctx, gpu(head), gpu(am), gpu(vm), fh, fw, ih, iw, pre, post, allow_edge)
+    dh, dam, dvm = gpu(head), gpu(am), gpu(vm)
+    scores, sidx, props, counts = run_proposals(ctx, dh, dam, dvm, fh, fw, ih, iw, pre, post, allow_edge)
 
     score_map = torch.sigmoid(head[:, 0:9]).reshape(1, fh, fw, 9)
     delta_map = head[:, 9:45].reshape(1, fh, fw, 36)
@@ -258,7 +276,8 @@ def test_rpn_proposals_score_ties_break_to_higher_index(ctx):
     head = torch.zeros((fh * fw, 128))
     head[:, 0:9] = 20.0                     # sigmoid saturates to exactly 1.0 everywhere: all tied
     am, vm = O.generate_anchor_maps((3, ih, iw), (512, fh, fw), 16)
-    scores, sidx, props, counts = run_proposals(ctx, gpu(head), gpu(am), gpu(vm), fh, fw, ih, iw, 500, 300, True)
+    dh, dam, dvm = gpu(head), gpu(am), gpu(vm)
+    scores, sidx, props, counts = run_proposals(ctx, dh, dam, dvm, fh, fw, ih, iw, 500, 300, True)
     a = fh * fw * 9
     assert (scores == 1.0).all()
     assert sidx[:500].tolist() == list(range(a - 1, a - 501, -1))
@@ -313,7 +332,8 @@ def test_roi_pool_bit_exact(c, fh, fw, n):
     r = torch.zeros((maxr, 4)); r[:n] = torch.from_numpy(rois)
     out = torch.full((maxr, 7, 7, c), float("nan"), device=DEV)
     cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
-    nv.check(nv.lib().frcnn_roi_pool(nv.ptr(gpu(fm[0].permute(1, 2, 0))), fh, fw, c, nv.ptr(gpu(r)), nv.ptr(cnt), maxr, 7,
+    dfm, dr = gpu(fm[0].permute(1, 2, 0)), gpu(r)
+    nv.check(nv.lib().frcnn_roi_pool(nv.ptr(dfm), fh, fw, c, nv.ptr(dr), nv.ptr(cnt), maxr, 7,
                                      1.0 / 16.0, nv.ptr(out), S()), "roi_pool")
     rois5 = np.zeros((n, 5), np.float32); rois5[:, 1:] = rois[:, [1, 0, 3, 2]]
     ref = O.roi_pool(fm.numpy(), rois5, 7, 1.0 / 16.0)               # (n, c, 7, 7)
@@ -341,7 +361,8 @@ def test_detections_vs_oracle(n, thr, seed):
     out = torch.zeros((20, maxr, 5), dtype=torch.float64, device=DEV)
     cnt = torch.full((20,), -1, dtype=torch.int32, device=DEV)
     nr = torch.tensor([n], dtype=torch.int32, device=DEV)
-    nv.check(nv.lib().frcnn_detections(nv.ptr(gpu(props)), nv.ptr(gpu(classes)), nv.ptr(gpu(deltas)), nv.ptr(nr), maxr, ncls,
+    dp, dc, dd = gpu(props), gpu(classes), gpu(deltas)
+    nv.check(nv.lib().frcnn_detections(nv.ptr(dp), nv.ptr(dc), nv.ptr(dd), nv.ptr(nr), maxr, ncls,
                                        600, 1000, thr, 0.3, nv.ptr(out), nv.ptr(cnt), S()), "detections")
     ref = O.detections(props[:n], classes[:n], deltas[:n], 600, 1000, thr)
     got_cnt = cnt.cpu().numpy()

@@ -195,7 +195,7 @@ def test_predict_matches_reference_golden(gpu_model, model_edge_off, golden_dir,
 
 
 def test_predict_on_oracle_forward_outputs_is_exact(golden_dir, oracle_runs):
-    """frcnn_detections fed the oracle's own forward outputs must reproduce the reference's dict."""
+    """frcnn_detections fed the oracle's own forward outputs must reproduce the oracle's dict exactly."""
     from fasterrcnn_amd import _native as nv
     for tag, _ in CASES:
         g, img = load_case(golden_dir, tag)
@@ -205,17 +205,24 @@ def test_predict_on_oracle_forward_outputs_is_exact(golden_dir, oracle_runs):
         out = torch.zeros((20, 300, 5), dtype=torch.float64, device="cuda:0")
         cnt = torch.zeros((20,), dtype=torch.int32, device="cuda:0")
         nr = torch.tensor([n], dtype=torch.int32, device="cuda:0")
-        nv.check(nv.lib().frcnn_detections(nv.ptr(pad(props, 4)), nv.ptr(pad(classes, 21)), nv.ptr(pad(deltas, 80)), nv.ptr(nr),
+        dp, dc, dd = pad(props, 4), pad(classes, 21), pad(deltas, 80)      # held: kernels run asynchronously
+        nv.check(nv.lib().frcnn_detections(nv.ptr(dp), nv.ptr(dc), nv.ptr(dd), nv.ptr(nr),
                                            300, 21, int(g["height"]), int(g["width"]), float(g["score_threshold"]), 0.3,
                                            nv.ptr(out), nv.ptr(cnt), nv.stream_ptr()), "detections")
-        ref = g["detections"]
+        # the oracle's detections for the SAME forward outputs (computed on this host's CPU; the golden
+        # file was produced on another CPU model whose torch-CPU GEMMs differ in the last bits)
+        ref = O.detections(props.numpy(), classes.numpy(), deltas.numpy(), int(g["height"]), int(g["width"]),
+                           float(g["score_threshold"]))
         o, k = out.cpu().numpy(), cnt.cpu().numpy()
         for c in range(1, 21):
-            r = ref[ref[:, 0] == c][:, 1:]
+            r = ref[c]
             assert k[c - 1] == len(r)
             if len(r):
                 assert np.array_equal(o[c - 1, :len(r), 4], r[:, 4])
                 assert np.abs(o[c - 1, :len(r), :4] - r[:, :4]).max() <= 1e-9
+        # and it agrees with the reference's golden dict up to that CPU-to-CPU noise
+        gref = g["detections"]
+        assert abs(int(k.sum()) - len(gref)) <= max(2, 0.02 * len(gref))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,92 @@
+"""
+tools/layer_bench.py -- per-layer timing of the HIP kernels through the C ABI (development aid).
+
+  python tools/layer_bench.py [--reps 20]
+
+Times every VGG-16 conv layer shape (600x1000 input), the FC layers and the proposal kernels in
+isolation with events on torch's current stream (the kernels are launched on that stream) and
+prints microseconds and TFLOP/s per layer.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from fasterrcnn_amd import _native as nv  # noqa: E402
+
+LAYERS = [("conv1_2", 64, 64, 600, 1000, True), ("conv2_1", 64, 128, 300, 500, False),
+          ("conv2_2", 128, 128, 300, 500, True), ("conv3_1", 128, 256, 150, 250, False),
+          ("conv3_2", 256, 256, 150, 250, False), ("conv3_3", 256, 256, 150, 250, True),
+          ("conv4_1", 256, 512, 75, 125, False), ("conv4_2", 512, 512, 75, 125, False),
+          ("conv4_3", 512, 512, 75, 125, True), ("conv5_x", 512, 512, 37, 62, False)]
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps   # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", type=str, default="")
+    args = ap.parse_args()
+    nv.require_gpu()
+    lib = nv.lib()
+    dev = "cuda:0"
+    s = nv.stream_ptr()
+    total_us, total_fl = 0.0, 0.0
+    mult = {"conv5_x": 4}
+    for name, cin, cout, h, w, pool in LAYERS:
+        if args.only and args.only not in name:
+            continue
+        x = torch.randn((h, w, cin), device=dev)
+        wp = torch.randn((9, cout, cin), device=dev) * 0.02
+        b = torch.zeros((cout,), device=dev)
+        oh, ow = (h // 2, w // 2) if pool else (h, w)
+        y = torch.empty((oh, ow, cout), device=dev)
+        wsb = int(lib.frcnn_conv3x3_workspace_bytes(h, w, cin, cout))
+        ws = torch.empty((max(wsb, 4) // 4,), device=dev)
+        flags = nv.RELU | (nv.POOL2 if pool else 0)
+
+        def run():
+            nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
+                                            nv.ptr(ws), wsb, s), "conv")
+        us = timeit(run, args.reps)
+        fl = 2.0 * 9 * cin * cout * h * w
+        k = mult.get(name, 1)
+        total_us += us * k
+        total_fl += fl * k
+        print("%-8s %4d->%4d %4dx%-4d pool=%d splitws=%9d  %8.1f us  %6.1f TF" % (name, cin, cout, h, w, pool, wsb, us, fl / us / 1e6))
+    if not args.only:
+        print("all MFMA convs of one image (conv5_x x4 incl. RPN trunk): %.1f us, %.1f TF" % (total_us, total_fl / total_us / 1e6))
+    # FC layers
+    for name, m, n, k in (("fc1", 300, 4096, 25088), ("fc2", 300, 4096, 4096), ("heads", 300, 101, 4096), ("rpn1x1", 2294, 45, 512)):
+        if args.only and args.only not in name:
+            continue
+        a = torch.randn((m, k), device=dev)
+        wt = torch.randn(((n + 127) // 128 * 128, k), device=dev) * 0.01
+        b = torch.zeros((n,), device=dev)
+        y = torch.empty((m, n), device=dev)
+        wsb = int(lib.frcnn_linear_workspace_bytes(m, n, k))
+        ws = torch.empty((max(wsb, 4) // 4,), device=dev)
+
+        def run():
+            nv.check(lib.frcnn_linear(nv.ptr(a), k, nv.ptr(wt), nv.ptr(b), nv.ptr(y), n, m, n, k, nv.RELU, nv.ptr(ws), wsb, s), "linear")
+        us = timeit(run, args.reps)
+        print("%-8s M=%d N=%d K=%d  %8.1f us  %6.1f TF" % (name, m, n, k, us, 2.0 * m * n * k / us / 1e6))
+
+
+if __name__ == "__main__":
+    main()
