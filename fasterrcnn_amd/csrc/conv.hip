@@ -382,15 +382,19 @@ static int launch_cfg(const float* x, const float* wp, const float* b, float* y,
     return check_launch();
 }
 
-// Split-K factor for a layer whose (rows x 32-col segments x cout tiles) grid cannot fill the
-// chip: the 37x62 maps of block 5 / the RPN trunk give 80 blocks for 256 CUs.  Power of two,
-// at least two 16-channel chunks per split.  FRCNN_CONV_BLOCKS_TARGET overrides the fill target.
+// Split-K factor.  Two reasons to split: (1) a layer whose (rows x 32-col segments x cout tiles)
+// grid cannot fill the chip -- the 37x62 maps of block 5 / the RPN trunk give 80 blocks for 256
+// CUs; (2) block-count quantisation -- the dispatcher packs the tail of a grid 3 blocks per CU
+// onto a subset of CUs (measured: 1200 blocks on 768 slots run as two full rounds = 78 % MFMA
+// busy), so work units must be small against blocks/slots.  Power of two, at least two 16-channel
+// chunks per split; the target of ~5 blocks per CU was the measured optimum (profiles/r01).
+// FRCNN_CONV_BLOCKS_TARGET overrides it (tuning knob).
 static int conv_blocks_target()
 {
     static int target = -1;
     if (target < 0) {
         const char* e = getenv("FRCNN_CONV_BLOCKS_TARGET");
-        target = e ? atoi(e) : 640;
+        target = e ? atoi(e) : 1280;
         if (target < 1) target = 1;
     }
     return target;
@@ -404,8 +408,10 @@ static int choose_ksplit(int H, int W, int cin, int cout)
     const int nchunks = cin / 16;
     const int target = conv_blocks_target();
     if (blocks * 2 > target) return 1;
+    // partial sums cost 2 x ksplit x output bytes of HBM traffic: not worth it on the big early maps
+    if ((size_t)H * W * cout * sizeof(float) > ((size_t)40 << 20)) return 1;
     int k = 1;
-    while (k * 2 * blocks <= target && nchunks % (k * 2) == 0 && nchunks / (k * 2) >= 2) k *= 2;
+    while (k * 2 * blocks <= target && nchunks % (k * 2) == 0 && nchunks / (k * 2) >= 4) k *= 2;
     return k;
 }
 

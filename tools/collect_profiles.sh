@@ -1,0 +1,21 @@
+#!/bin/bash
+# tools/collect_profiles.sh <tag> -- runs on the GPU box (via gpurun); writes gpurun_out/<tag>/...
+# 1. the default bench line; 2. rocprofv3 kernel trace + stats of a bench run; 3. PMC passes
+# (counters in their own runs, kernel-trace only, as the pool requires).
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+B="python bench.py --steps 60 --warmup 10 --no-cpu-baseline"
+timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench exit $?"
+tail -c 2500 $OUT/bench_default.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/trace.log 2>&1; echo "trace exit $?"
+P="python bench.py --steps 12 --warmup 4 --no-cpu-baseline --inflight 1 --roofline-images 2 --map-images 0"
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_mfma -o p -- $P > $OUT/pmc_mfma.log 2>&1; echo "pmc mfma exit $?"
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $P > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?"
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $P > $OUT/pmc_write.log 2>&1; echo "pmc write exit $?"
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL --output-format csv -d $OUT/pmc_lds -o p -- $P > $OUT/pmc_lds.log 2>&1; echo "pmc lds exit $?"
+ls -la $OUT $OUT/trace | head -40
+# keep the merged output small: drop the raw per-dispatch traces beyond what the summary needs
+python tools/summarize_profiles.py $OUT > $OUT/summary.md 2> $OUT/summary.err; echo "summary exit $?"; head -60 $OUT/summary.md

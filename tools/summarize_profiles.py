@@ -1,0 +1,84 @@
+"""tools/summarize_profiles.py <dir> -- condenses the rocprofv3 CSVs written by collect_profiles.sh
+into a markdown summary (per-kernel time, MFMA busy, HBM bytes per launch)."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "").replace("frcnn::", "")
+    return n[:60]
+
+
+def load(pattern):
+    files = glob.glob(pattern)
+    return list(csv.DictReader(open(files[0]))) if files else []
+
+
+def main(d):
+    print("# rocprofv3 summary (%s)\n" % os.path.basename(d.rstrip("/")))
+    bench = os.path.join(d, "bench_default.json")
+    if os.path.exists(bench):
+        lines = [l for l in open(bench).read().splitlines() if l.startswith("{")]
+        if lines:
+            print("## bench.py (default flags)\n\n```json\n%s\n```\n" % lines[-1])
+    stats = load(os.path.join(d, "trace", "*kernel_stats.csv"))
+    if stats:
+        print("## kernel trace + stats (bench.py --steps 60 --warmup 10 --no-cpu-baseline, 4 images in flight)\n")
+        print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+        for r in stats[:24]:
+            print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                     float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+        print()
+    # per-layer conv durations by grid
+    kt = load(os.path.join(d, "trace", "*kernel_trace.csv"))
+    if kt:
+        agg = collections.defaultdict(list)
+        for r in kt:
+            if "conv3x3_mfma" in r["Kernel_Name"] or "linear_mfma" in r["Kernel_Name"]:
+                key = (short(r["Kernel_Name"]), r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
+                agg[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        print("## MFMA kernels by grid (threads x, blocks y, z), multi-stream run\n")
+        print("| kernel | grid | launches | avg us |\n|---|---|---|---|")
+        for k, v in sorted(agg.items()):
+            print("| %s | %s x %s x %s | %d | %.1f |" % (k[0], k[1], k[2], k[3], len(v), sum(v) / len(v)))
+        print()
+    for tag, title in (("pmc_mfma", "MFMA / wave-state counters"), ("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"),
+                       ("pmc_lds", "LDS counters")):
+        rows = load(os.path.join(d, tag, "*counter_collection.csv"))
+        if not rows:
+            continue
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        cnt = collections.defaultdict(set)
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            if not any(x in k for x in ("conv3x3", "linear_mfma", "roi_pool", "topk", "nms_", "detections", "splitk", "conv_splitk")):
+                continue
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[k].add(r["Dispatch_Id"])
+        print("## %s (single stream, per launch averages)\n" % title)
+        names = sorted({c for v in agg.values() for c in v})
+        print("| kernel | launches | " + " | ".join(names) + " |\n|---|---|" + "---|" * len(names))
+        for k, v in sorted(agg.items()):
+            n = max(len(cnt[k]), 1)
+            print("| %s | %d | " % (k, n) + " | ".join("%.4g" % (v.get(c, 0.0) / n) for c in names) + " |")
+        print()
+        if tag == "pmc_mfma":
+            print("derived (per kernel, summed over its launches): MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCD * 1024 SIMD); "
+                  "clock = GRBM_GUI_ACTIVE/8 / duration\n")
+            print("| kernel | MFMA busy | waves/SIMD avg (SQ_WAVE_CYCLES*4 / (1024 * GUI/8)) | WAIT_INST_ANY | WAIT_ANY | ACTIVE |\n|---|---|---|---|---|---|")
+            for k, v in sorted(agg.items()):
+                g = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+                wc = v.get("SQ_WAVE_CYCLES", 0.0)
+                if g <= 0 or wc <= 0:
+                    continue
+                print("| %s | %.3f | %.2f | %.3f | %.3f | %.3f |" % (
+                    k, v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (g * 1024), wc * 4 / (1024 * g),
+                    v.get("SQ_WAIT_INST_ANY", 0.0) / wc, v.get("SQ_WAIT_ANY", 0.0) / wc, v.get("SQ_ACTIVE_INST_ANY", 0.0) / wc))
+            print()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
