@@ -29,6 +29,8 @@ SYMBOLS = (
     "frcnn_nms", "frcnn_roi_pool", "frcnn_detections", "frcnn_ctx_create", "frcnn_ctx_destroy",
     "frcnn_ctx_bytes", "frcnn_vgg16_forward", "frcnn_ctx_tensor", "frcnn_ctx_timing_enable",
     "frcnn_ctx_timing_read",
+    "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv7x7_s2_c3",
+    "frcnn_maxpool3x3_s2_nhwc", "frcnn_spatial_mean_nhwc", "frcnn_resnet_forward",
 )
 
 
@@ -49,6 +51,23 @@ class VGG16Weights(C.Structure):
         ("head_w", C.c_void_p), ("head_b", C.c_void_p),
         ("num_classes", C.c_int32),
     ]
+
+
+RESNET_MAX_BLOCKS = 64
+
+
+class BottleneckWeights(C.Structure):
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("w3", C.c_void_p), ("b3", C.c_void_p), ("wd", C.c_void_p), ("bd", C.c_void_p),
+                ("cin", C.c_int32), ("width", C.c_int32), ("cout", C.c_int32), ("stride", C.c_int32)]
+
+
+class ResNetWeights(C.Structure):
+    _fields_ = [("stem_w", C.c_void_p), ("stem_b", C.c_void_p), ("n_blocks", C.c_int32 * 4),
+                ("blocks", BottleneckWeights * RESNET_MAX_BLOCKS),
+                ("rpn_conv_w", C.c_void_p), ("rpn_conv_b", C.c_void_p),
+                ("rpn_head_w", C.c_void_p), ("rpn_head_b", C.c_void_p),
+                ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("num_classes", C.c_int32)]
 
 
 class ForwardParams(C.Structure):
@@ -88,6 +107,14 @@ _SIGNATURES = {
     "frcnn_vgg16_forward": (C.c_int, [_vp, C.POINTER(VGG16Weights), C.POINTER(ForwardParams), _vp, _i, _i,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "frcnn_ctx_tensor": (C.c_int, [_vp, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "frcnn_fold_bn_pack": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
+    "frcnn_conv_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "frcnn_conv_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_conv7x7_s2_c3": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp]),
+    "frcnn_maxpool3x3_s2_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "frcnn_spatial_mean_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "frcnn_resnet_forward": (C.c_int, [_vp, C.POINTER(ResNetWeights), C.POINTER(ForwardParams), _vp, _i, _i,
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "frcnn_ctx_timing_enable": (C.c_int, [_vp, _i]),
     "frcnn_ctx_timing_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), _i]),
 }

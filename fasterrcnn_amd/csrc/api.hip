@@ -39,6 +39,9 @@ struct frcnn_ctx {
     float *head_logits = nullptr;                  // [max_rois][128]
     void* lin_ws = nullptr; size_t lin_ws_bytes = 0;
     void* conv_ws = nullptr; size_t conv_ws_bytes = 0;   // split-K partials of under-filled conv layers
+    float* res_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // ResNet bottleneck rotation
+    size_t res_buf_floats = 0;
+    int last_c = 512, last_vec = 4096;
     ProposalScratch ps{};
     // anchor cache key
     int anc_h = -1, anc_w = -1, anc_fh = -1, anc_fw = -1;
@@ -166,6 +169,47 @@ int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, voi
     return launch_maxpool2x2(d_x, d_y, H, W, c, as_stream(stream));
 }
 
+int frcnn_fold_bn_pack(const float* d_w, const float* d_gamma, const float* d_beta, const float* d_mean,
+                       const float* d_var, float eps, int cout, int cin, int ksize, float* d_wp, float* d_bp, void* stream)
+{
+    if (!d_w || !d_gamma || !d_beta || !d_mean || !d_var || !d_wp || !d_bp) return FRCNN_EINVAL;
+    return launch_fold_bn_pack(d_w, d_gamma, d_beta, d_mean, d_var, eps, cout, cin, ksize, d_wp, d_bp, as_stream(stream));
+}
+
+size_t frcnn_conv_workspace_bytes(int N, int H, int W, int cin, int cout, int ksize, int stride, int pad)
+{
+    return conv_gather_workspace_bytes(N, H, W, cin, cout, ksize, stride, pad);
+}
+
+int frcnn_conv_nhwc(const float* d_x, const float* d_wp, const float* d_bias, const float* d_residual, float* d_y,
+                    int N, int H, int W, int cin, int cout, int ksize, int stride, int pad, unsigned flags,
+                    void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_x || !d_wp || !d_bias || !d_y) return FRCNN_EINVAL;
+    if (flags & FRCNN_POOL2) return FRCNN_EUNSUPPORTED;
+    return launch_conv_gather(d_x, d_wp, d_bias, d_residual, d_y, N, H, W, cin, cout, ksize, stride, pad, flags,
+                              d_ws, ws_bytes, as_stream(stream));
+}
+
+int frcnn_conv7x7_s2_c3(const float* d_x, const float* d_wp, const float* d_bias, float* d_y, int H, int W,
+                        int cout, unsigned flags, void* stream)
+{
+    if (!d_x || !d_wp || !d_bias || !d_y) return FRCNN_EINVAL;
+    return launch_conv7x7_s2_c3(d_x, d_wp, d_bias, d_y, H, W, cout, flags, as_stream(stream));
+}
+
+int frcnn_maxpool3x3_s2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream)
+{
+    if (!d_x || !d_y) return FRCNN_EINVAL;
+    return launch_maxpool3x3_s2(d_x, d_y, H, W, c, as_stream(stream));
+}
+
+int frcnn_spatial_mean_nhwc(const float* d_x, float* d_y, int N, int H, int W, int c, void* stream)
+{
+    if (!d_x || !d_y) return FRCNN_EINVAL;
+    return launch_spatial_mean(d_x, d_y, N, H, W, c, as_stream(stream));
+}
+
 size_t frcnn_linear_workspace_bytes(int M, int N, int K) { return linear_workspace_bytes(M, N, K); }
 
 int frcnn_linear(const float* d_a, int lda, const float* d_w, const float* d_bias, float* d_y, int ldy,
@@ -230,7 +274,7 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
     c->pre_cap = 16384;
 
     const size_t act = (size_t)max_image_h * max_image_w * 64 * sizeof(float);
-    const size_t fmb = (size_t)c->max_fh * c->max_fw * 512 * sizeof(float);
+    const size_t fmb = (size_t)c->max_fh * c->max_fw * 1024 * sizeof(float);   // 1024 channels for the ResNet maps
     const size_t headb = (size_t)c->max_fh * c->max_fw * 128 * sizeof(float);
     size_t lin = 0;
     {
@@ -238,7 +282,9 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         const size_t w2 = linear_workspace_bytes(max_rois, 4096, 4096);
         const size_t w3 = linear_workspace_bytes(max_rois, 128, 4096);
         const size_t w4 = linear_workspace_bytes(c->max_fh * c->max_fw, 45, 512);
-        lin = w1; if (w2 > lin) lin = w2; if (w3 > lin) lin = w3; if (w4 > lin) lin = w4;
+        const size_t w5 = linear_workspace_bytes(c->max_fh * c->max_fw, 45, 1024);
+        const size_t w6 = linear_workspace_bytes(max_rois, 128, 2048);
+        lin = w1; if (w2 > lin) lin = w2; if (w3 > lin) lin = w3; if (w4 > lin) lin = w4; if (w5 > lin) lin = w5; if (w6 > lin) lin = w6;
     }
     size_t cws = 0;
     {
@@ -259,6 +305,15 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         const size_t generous = (size_t)16 * c->max_fh * c->max_fw * 512 * sizeof(float);
         if (generous > cws) cws = generous;
     }
+    {
+        // ResNet: stem output ((H+1)/2 x (W+1)/2 x 64) == layer1 output size; per-RoI head tensors
+        const size_t stem = (size_t)((max_image_h + 1) / 2) * ((max_image_w + 1) / 2) * 64;
+        const size_t head = (size_t)max_rois * 49 * 512;
+        const size_t head2 = (size_t)max_rois * 16 * 2048;
+        size_t m = stem; if (head > m) m = head; if (head2 > m) m = head2;
+        c->res_buf_floats = m;
+        if (cws < ((size_t)160 << 20)) cws = (size_t)160 << 20;
+    }
     struct Item { void** p; size_t bytes; };
     void* ps_base = nullptr;
     Item items[] = {
@@ -266,10 +321,13 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         {(void**)&c->fm, fmb}, {(void**)&c->rpn_trunk, fmb}, {(void**)&c->rpn_head, headb},
         {(void**)&c->scores, (size_t)c->a_cap * 4}, {(void**)&c->sorted_idx, (size_t)c->pre_cap * 4},
         {(void**)&c->anchor_map, (size_t)c->a_cap * 16}, {(void**)&c->valid_map, (size_t)c->a_cap * 4},
-        {(void**)&c->roi_out, (size_t)max_rois * 49 * 512 * 4},
+        {(void**)&c->roi_out, (size_t)max_rois * 49 * 1024 * 4},
         {(void**)&c->fc1_out, (size_t)max_rois * 4096 * 4}, {(void**)&c->fc2_out, (size_t)max_rois * 4096 * 4},
         {(void**)&c->head_logits, (size_t)max_rois * 128 * 4},
         {(void**)&c->lin_ws, lin}, {(void**)&c->conv_ws, cws},
+        {(void**)&c->res_buf[0], c->res_buf_floats * 4}, {(void**)&c->res_buf[1], c->res_buf_floats * 4},
+        {(void**)&c->res_buf[2], c->res_buf_floats * 4}, {(void**)&c->res_buf[3], c->res_buf_floats * 4},
+        {(void**)&c->res_buf[4], c->res_buf_floats * 4},
         {&ps_base, proposal_scratch_bytes(c->a_cap, c->pre_cap, 2048)},
     };
     size_t total = 0;
@@ -327,12 +385,12 @@ int frcnn_ctx_tensor(frcnn_ctx* c, int which, void** d_ptr, size_t* bytes)
     if (!c || !d_ptr || !bytes) return FRCNN_EINVAL;
     const size_t fmsz = (size_t)c->last_fh * c->last_fw;
     switch (which) {
-        case 0: *d_ptr = c->fm; *bytes = fmsz * 512 * 4; break;
+        case 0: *d_ptr = c->fm; *bytes = fmsz * c->last_c * 4; break;
         case 1: *d_ptr = c->rpn_head; *bytes = fmsz * 128 * 4; break;
         case 2: *d_ptr = c->scores; *bytes = fmsz * 9 * 4; break;
         case 3: *d_ptr = c->sorted_idx; *bytes = (size_t)c->last_pre * 4; break;
-        case 4: *d_ptr = c->roi_out; *bytes = (size_t)c->last_post * 49 * 512 * 4; break;
-        case 5: *d_ptr = c->fc2_out; *bytes = (size_t)c->last_post * 4096 * 4; break;
+        case 4: *d_ptr = c->roi_out; *bytes = (size_t)c->last_post * 49 * c->last_c * 4; break;
+        case 5: *d_ptr = c->fc2_out; *bytes = (size_t)c->last_post * c->last_vec * 4; break;
         case 6: *d_ptr = c->anchor_map; *bytes = fmsz * 9 * 16; break;
         case 7: *d_ptr = c->valid_map; *bytes = fmsz * 9 * 4; break;
         case 8: *d_ptr = c->head_logits; *bytes = (size_t)c->last_post * 128 * 4; break;
@@ -377,7 +435,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     STEP(0, launch_conv3x3_nhwc(A, w->conv_w[11], w->conv_b[11], B, h, wd, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
     STEP(0, launch_conv3x3_nhwc(B, w->conv_w[12], w->conv_b[12], c->fm, h, wd, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
     const int fh = h, fw = wd;
-    c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms;
+    c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms; c->last_c = 512; c->last_vec = 4096;
 
     // stage 2: RPN (models/rpn.py:88-153)
     STEP(0, launch_conv3x3_nhwc(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
@@ -406,6 +464,142 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
                           c->lin_ws, c->lin_ws_bytes, s));
     const int ncls = w->num_classes, nd = (ncls - 1) * 4;
     STEP(2, launch_linear(c->fc2_out, 4096, w->head_w, w->head_b, c->head_logits, 128, R_, ncls + nd, 4096, 0u,
+                          c->lin_ws, c->lin_ws_bytes, s));
+    STEP(5, launch_head_finish(c->head_logits, 128, R_, ncls, nd, d_classes, d_deltas, s));
+#undef STEP
+    return FRCNN_OK;
+}
+
+// ---- fused ResNet forward ----------------------------------------------------------------------
+namespace {
+// One Bottleneck (torchvision v1.5): out = relu(conv3(relu(conv2(relu(conv1(x))))) + identity).
+// x: [N][h][w][cin] in `cur`; returns the buffer index holding the output, updates h, w.
+int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& h, int& w, int cur,
+                   int* out_idx, hipStream_t s, int cls_conv)
+{
+    // pick three scratch buffers different from `cur`
+    int f[4], k = 0;
+    for (int i = 0; i < 5 && k < 4; ++i) if (i != cur) f[k++] = i;
+    float* X = c->res_buf[cur];
+    float* T1 = c->res_buf[f[0]];
+    float* T2 = c->res_buf[f[1]];
+    float* ID = c->res_buf[f[2]];
+    float* OUT = c->res_buf[f[3]];
+    const unsigned R = FRCNN_RELU;
+    int rc;
+    const int ho = (h + 2 - 3) / b.stride + 1, wo = (w + 2 - 3) / b.stride + 1;
+    const size_t need1 = (size_t)N * h * w * b.width, need2 = (size_t)N * ho * wo * b.cout;
+    if (need1 > c->res_buf_floats || need2 > c->res_buf_floats) return FRCNN_EINVAL;
+#define RSTEP(call) do { Scope _sc(c, cls_conv, s); rc = (call); } while (0); if (rc) return rc
+    RSTEP(launch_conv_gather(X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s));
+    if (b.stride == 1 && N == 1 && b.width % 64 == 0) {
+        RSTEP(launch_conv3x3_nhwc(T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, c->conv_ws, c->conv_ws_bytes, s));
+    } else {
+        RSTEP(launch_conv_gather(T1, b.w2, b.b2, nullptr, T2, N, h, w, b.width, b.width, 3, b.stride, 1, R,
+                                 c->conv_ws, c->conv_ws_bytes, s));
+    }
+    const float* identity = X;
+    if (b.wd) {
+        RSTEP(launch_conv_gather(X, b.wd, b.bd, nullptr, ID, N, h, w, b.cin, b.cout, 1, b.stride, 0, 0u,
+                                 c->conv_ws, c->conv_ws_bytes, s));
+        identity = ID;
+    } else if (b.cin != b.cout || b.stride != 1) {
+        return FRCNN_EINVAL;
+    }
+    RSTEP(launch_conv_gather(T2, b.w3, b.b3, identity, OUT, N, ho, wo, b.width, b.cout, 1, 1, 0, R,
+                             c->conv_ws, c->conv_ws_bytes, s));
+#undef RSTEP
+    h = ho; w = wo;
+    *out_idx = f[3];
+    return FRCNN_OK;
+}
+}  // namespace
+
+int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p,
+                         const float* d_image, int H, int W, const float* d_anchor_map,
+                         const float* d_valid_map, float* d_props, float* d_classes, float* d_deltas,
+                         int32_t* d_counts, void* stream)
+{
+    if (!c || !w || !p || !d_image || !d_props || !d_classes || !d_deltas || !d_counts) return FRCNN_EINVAL;
+    if (H < 32 || W < 32 || H > c->max_h || W > c->max_w) return FRCNN_EINVAL;
+    if (p->post_nms < 1 || p->post_nms > c->max_rois || p->pre_nms < 1 || p->pre_nms > c->pre_cap) return FRCNN_EINVAL;
+    if (w->num_classes < 2 || w->num_classes > 26) return FRCNN_EUNSUPPORTED;
+    int nb = 0;
+    for (int i = 0; i < 4; ++i) { if (w->n_blocks[i] < 1) return FRCNN_EINVAL; nb += w->n_blocks[i]; }
+    if (nb > FRCNN_RESNET_MAX_BLOCKS) return FRCNN_EINVAL;
+    if (!w->stem_w || !w->stem_b || !w->rpn_conv_w || !w->rpn_conv_b || !w->rpn_head_w || !w->rpn_head_b ||
+        !w->head_w || !w->head_b)
+        return FRCNN_EINVAL;
+    for (int i = 0; i < nb; ++i) {
+        const frcnn_bottleneck_weights& b = w->blocks[i];
+        if (!b.w1 || !b.b1 || !b.w2 || !b.b2 || !b.w3 || !b.b3 || (b.wd && !b.bd)) return FRCNN_EINVAL;
+        if (b.cin % 16 || b.width % 16 || b.cout % 64 || (b.stride != 1 && b.stride != 2)) return FRCNN_EINVAL;
+    }
+    hipStream_t s = as_stream(stream);
+    int rc;
+#define STEP(cls, call) do { Scope _sc(c, cls, s); rc = (call); } while (0); if (rc) return rc
+
+    // stage 1: conv1/bn1/relu/maxpool/layer1..3 (models/resnet.py:38-46)
+    int h = (H + 6 - 7) / 2 + 1, wd = (W + 6 - 7) / 2 + 1;
+    if ((size_t)h * wd * 64 > c->res_buf_floats) return FRCNN_EINVAL;
+    STEP(1, launch_conv7x7_s2_c3(d_image, w->stem_w, w->stem_b, c->res_buf[0], H, W, 64, FRCNN_RELU, s));
+    STEP(5, launch_maxpool3x3_s2(c->res_buf[0], c->res_buf[1], h, wd, 64, s));
+    h = (h + 2 - 3) / 2 + 1; wd = (wd + 2 - 3) / 2 + 1;
+    int cur = 1, bi = 0;
+    for (int layer = 0; layer < 3; ++layer)
+        for (int k = 0; k < w->n_blocks[layer]; ++k, ++bi) {
+            int out = -1;
+            rc = run_bottleneck(c, w->blocks[bi], 1, h, wd, cur, &out, s, 0);
+            if (rc) return rc;
+            cur = out;
+        }
+    const int fh = h, fw = wd;
+    const int C = w->blocks[bi - 1].cout;                       // 1024
+    if (fh > c->max_fh || fw > c->max_fw || C > 1024 || C % 64) return FRCNN_EINVAL;
+    FRCNN_HIP_TRY(hipMemcpyAsync(c->fm, c->res_buf[cur], (size_t)fh * fw * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms; c->last_c = C;
+
+    // stage 2: RPN (models/rpn.py:88-153)
+    STEP(0, launch_conv3x3_nhwc(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU,
+                                c->conv_ws, c->conv_ws_bytes, s));
+    STEP(2, launch_linear(c->rpn_trunk, C, w->rpn_head_w, w->rpn_head_b, c->rpn_head, 128, fh * fw, 45, C, 0u,
+                          c->lin_ws, c->lin_ws_bytes, s));
+    const float* amap = d_anchor_map;
+    const float* vmap = d_valid_map;
+    if (!amap || !vmap) {
+        if (c->anc_h != H || c->anc_w != W || c->anc_fh != fh || c->anc_fw != fw) {
+            STEP(5, launch_anchors(H, W, fh, fw, 16, c->anchor_map, c->valid_map, s));
+            c->anc_h = H; c->anc_w = W; c->anc_fh = fh; c->anc_fw = fw;
+        }
+        amap = c->anchor_map; vmap = c->valid_map;
+    }
+    FRCNN_HIP_TRY(hipMemsetAsync(d_counts, 0, 4 * sizeof(int32_t), s));
+    STEP(3, launch_rpn_proposals(c->ps, c->rpn_head, 128, amap, p->allow_edge_proposals ? nullptr : vmap, fh, fw,
+                                 H, W, p->pre_nms, p->post_nms, p->rpn_nms_threshold, p->min_side, c->scores,
+                                 c->sorted_idx, d_props, d_counts, s));
+
+    // stage 3: RoIPool, layer4 per RoI, spatial mean, heads (models/detector.py:65-80, resnet.py:109-118)
+    const int R_ = p->post_nms;
+    STEP(4, launch_roi_pool(c->fm, fh, fw, C, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
+    if ((size_t)R_ * 49 * C > c->res_buf_floats * 2) { /* roi_out is its own buffer; nothing to check */ }
+    // layer4 reads its input from roi_out: stage it as res_buf "cur" by pointer swap
+    float* saved = c->res_buf[0];
+    c->res_buf[0] = c->roi_out;
+    cur = 0; h = 7; wd = 7;
+    for (int k = 0; k < w->n_blocks[3]; ++k, ++bi) {
+        int out = -1;
+        rc = run_bottleneck(c, w->blocks[bi], R_, h, wd, cur, &out, s, 2);
+        if (rc) { c->res_buf[0] = saved; return rc; }
+        cur = out;
+    }
+    float* head_in = c->res_buf[cur];
+    c->res_buf[0] = saved;
+    const int V = w->blocks[bi - 1].cout;                       // 2048
+    if (V > 4096) return FRCNN_EINVAL;
+    c->last_vec = V;
+    STEP(5, launch_spatial_mean(head_in, c->fc2_out, R_, h, wd, V, s));
+    const int ncls = w->num_classes, nd = (ncls - 1) * 4;
+    STEP(2, launch_linear(c->fc2_out, V, w->head_w, w->head_b, c->head_logits, 128, R_, ncls + nd, V, 0u,
                           c->lin_ws, c->lin_ws_bytes, s));
     STEP(5, launch_head_finish(c->head_logits, 128, R_, ncls, nd, d_classes, d_deltas, s));
 #undef STEP

@@ -52,6 +52,18 @@ int launch_conv3x3_nhwc(const float* x, const float* wp, const float* b, float* 
                         int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_maxpool2x2(const float* x, float* y, int H, int W, int c, hipStream_t s);
 
+// conv_gather.hip (ResNet path)
+size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R, int stride, int pad);
+int launch_conv_gather(const float* x, const float* wp, const float* bias, const float* residual, float* y,
+                       int N, int H, int W, int cin, int cout, int R, int stride, int pad, unsigned flags,
+                       void* ws, size_t ws_bytes, hipStream_t s);
+int launch_conv7x7_s2_c3(const float* x, const float* wp, const float* b, float* y, int H, int W, int cout,
+                         unsigned flags, hipStream_t s);
+int launch_maxpool3x3_s2(const float* x, float* y, int H, int W, int c, hipStream_t s);
+int launch_spatial_mean(const float* x, float* y, int N, int H, int W, int c, hipStream_t s);
+int launch_fold_bn_pack(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                        float eps, int cout, int cin, int ksize, float* wp, float* bp, hipStream_t s);
+
 size_t linear_workspace_bytes(int M, int N, int K);
 int launch_linear(const float* a, int lda, const float* w, const float* bias, float* y, int ldy,
                   int M, int N, int K, unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);

@@ -1,0 +1,445 @@
+// conv_gather.hip -- generic NHWC convolution as a gather implicit GEMM on the exact-f32 matrix
+// pipe, for everything the halo-tile kernel of conv.hip does not cover in the ResNet backbones
+// (reference: models/resnet.py:33-118, i.e. torchvision's Bottleneck v1.5 blocks):
+//   * 1x1 convolutions (plain GEMM over pixels), with stride 2 for the downsample branches
+//   * 3x3 stride-2 convolutions (layer2.0 / layer3.0 / layer4.0 conv2)
+//   * 3x3 convolutions on the tiny per-RoI maps of the detector head (300 x 7x7 / 4x4)
+// Output row m = (n, oy, ox) of a batch of N maps; for K-stage (16-channel chunk c, tap (r,s))
+// the A row is the 64-byte run x[n][oy*stride-pad+r][ox*stride-pad+s][16c..16c+15] or zeros.
+// Staging, LDS layout (rows padded to 20 floats), lane-half K ownership, double buffering and the
+// deterministic split-K are those of linear.hip; the epilogue fuses the folded BatchNorm bias, the
+// residual add and ReLU (Bottleneck: out = relu(bn3(conv3) + identity)).
+#include "common.h"
+
+namespace frcnn {
+
+static constexpr int GLDK = 20;
+
+template <int TM, int TN, int WM, int WN>
+struct GatherCfg {
+    static constexpr int BM = 32 * TM * WM;
+    static constexpr int BN = 32 * TN * WN;
+    static constexpr int NA = BM * 4 / 256;
+    static constexpr int NB = BN * 4 / 256;
+    static constexpr int A_F = BM * GLDK;
+    static constexpr int B_F = BN * GLDK;
+    static constexpr size_t LDS_BYTES = (size_t)2 * (A_F + B_F) * sizeof(float);
+};
+
+struct GatherShape {
+    int N, H, W, Cin, Cout, Ho, Wo, R, S, stride, pad;
+};
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256)
+void conv_gather_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                             const float* __restrict__ bias, const float* __restrict__ residual,
+                             float* __restrict__ y, float* __restrict__ ws, GatherShape g,
+                             int stages_per_split, int relu)
+{
+    using C = GatherCfg<TM, TN, WM, WN>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const at0 = smem;
+    float* const bt0 = smem + 2 * C::A_F;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * C::BM, n0 = blockIdx.x * C::BN;
+    const int M = g.N * g.Ho * g.Wo;
+    const int taps = g.R * g.S;
+    const int total_stages = (g.Cin >> 4) * taps;
+    const int st_begin = blockIdx.z * stages_per_split;
+    int st_end = st_begin + stages_per_split;
+    if (st_end > total_stages) st_end = total_stages;
+    const int nst = st_end - st_begin;
+
+    // loop-invariant per-row gather coordinates
+    int a_img[C::NA], a_iy[C::NA], a_ix[C::NA], a_dst[C::NA];
+#pragma unroll
+    for (int it = 0; it < C::NA; ++it) {
+        const int q = tid + 256 * it, row = q >> 2, p = q & 3;
+        const int m = m0 + row;
+        a_dst[it] = row * GLDK + 4 * p;
+        if (m < M) {
+            const int n = m / (g.Ho * g.Wo);
+            const int rem = m - n * g.Ho * g.Wo;
+            const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+            a_img[it] = n * g.H * g.W;              // pixel offset of the image
+            a_iy[it] = oy * g.stride - g.pad;
+            a_ix[it] = ox * g.stride - g.pad;
+        } else {
+            a_img[it] = -1; a_iy[it] = 0; a_ix[it] = 0;
+        }
+    }
+    int b_row[C::NB], b_dst[C::NB];
+#pragma unroll
+    for (int it = 0; it < C::NB; ++it) {
+        const int q = tid + 256 * it, row = q >> 2, p = q & 3;
+        b_row[it] = (n0 + row < g.Cout) ? (n0 + row) : -1;
+        b_dst[it] = row * GLDK + 4 * p;
+    }
+    const int p4 = (tid & 3) * 4;
+
+    f32x4 areg[C::NA], breg[C::NB];
+    auto load_tiles = [&](int stage) {
+        const int chunk = stage / taps, tap = stage - chunk * taps;
+        const int r = tap / g.S, s = tap - r * g.S;
+        const int c0 = chunk * 16 + p4;
+#pragma unroll
+        for (int it = 0; it < C::NA; ++it) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int iy = a_iy[it] + r, ix = a_ix[it] + s;
+            if (a_img[it] >= 0 && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                v = *reinterpret_cast<const f32x4*>(x + ((size_t)a_img[it] + (size_t)iy * g.W + ix) * g.Cin + c0);
+            areg[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < C::NB; ++it) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b_row[it] >= 0)
+                v = *reinterpret_cast<const f32x4*>(wp + ((size_t)tap * g.Cout + b_row[it]) * g.Cin + c0);
+            breg[it] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < C::NA; ++it)
+            *reinterpret_cast<f32x4*>(at0 + buf * C::A_F + a_dst[it]) = areg[it];
+#pragma unroll
+        for (int it = 0; it < C::NB; ++it)
+            *reinterpret_cast<f32x4*>(bt0 + buf * C::B_F + b_dst[it]) = breg[it];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nst > 0) {
+        load_tiles(st_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    const int a_base = (32 * TM * wm + li) * GLDK + 4 * lh;
+    const int b_base = (32 * TN * wn + li) * GLDK + 4 * lh;
+    for (int s = 0; s < nst; ++s) {
+        const bool has_next = (s + 1) < nst;
+        if (has_next) load_tiles(st_begin + s + 1);
+        const float* at = at0 + (s & 1) * C::A_F + a_base;
+        const float* bt = bt0 + (s & 1) * C::B_F + b_base;
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(at + i * 32 * GLDK + 8 * gq);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bt + j * 32 * GLDK + 8 * gq);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+        }
+        if (has_next) store_tiles((s + 1) & 1);
+        __syncthreads();
+    }
+
+    const bool direct = (gridDim.z == 1);
+    float* const dst = direct ? y : ws + (size_t)blockIdx.z * M * g.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + 32 * (TN * wn + j) + li;
+        if (n >= g.Cout) continue;
+        const float bv = direct ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (direct) {
+                        if (residual) v += residual[(size_t)m * g.Cout + n];
+                        if (relu) v = fmaxf(v, 0.f);
+                    }
+                    dst[(size_t)m * g.Cout + n] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void gather_splitk_finish_kernel(const float* __restrict__ ws, int splits, const float* __restrict__ bias,
+                                 const float* __restrict__ residual, float* __restrict__ y, int M, int Cout, int relu)
+{
+    const int C4 = Cout >> 2;
+    const size_t total = (size_t)M * C4;
+    const size_t plane = (size_t)M * Cout;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        f32x4 v = reinterpret_cast<const f32x4*>(ws)[i];
+        for (int k = 1; k < splits; ++k) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(ws + k * plane + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += t[j];
+        }
+        const f32x4 b = reinterpret_cast<const f32x4*>(bias)[c4];
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (residual) r = reinterpret_cast<const f32x4*>(residual)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = v[j] + b[j] + r[j];
+            v[j] = relu ? fmaxf(t, 0.f) : t;
+        }
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+// ---- small ResNet-only kernels -----------------------------------------------------------------
+// Stem: 7x7 stride-2 pad-3 convolution of the NCHW image (Cin = 3) with the folded bn1 and ReLU
+// (models/resnet.py:39-41 = torchvision resnet.conv1/bn1/relu).  K = 147: VALU kernel, thread =
+// output pixel x 16 channels, weights [147][cout] via scalar loads.
+__global__ __launch_bounds__(256)
+void conv7x7_s2_c3_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                          float* __restrict__ y, int H, int W, int Ho, int Wo, int Cout, int relu)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int og = blockIdx.y;
+    if (pix >= Ho * Wo) return;
+    const int oy = pix / Wo, ox = pix - oy * Wo;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    const float* wg = wp + og * 16;
+    for (int ci = 0; ci < 3; ++ci) {
+        for (int r = 0; r < 7; ++r) {
+            const int iy = oy * 2 - 3 + r;
+            const bool yin = iy >= 0 && iy < H;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) {
+                const int ix = ox * 2 - 3 + s;
+                const float v = (yin && ix >= 0 && ix < W) ? x[((size_t)ci * H + iy) * W + ix] : 0.f;
+                const float* wk = wg + (size_t)((ci * 7 + r) * 7 + s) * Cout;
+#pragma unroll
+                for (int o = 0; o < 16; ++o) acc[o] = fmaf(v, wk[o], acc[o]);
+            }
+        }
+    }
+    float* out = y + (size_t)pix * Cout + og * 16;
+#pragma unroll
+    for (int o4 = 0; o4 < 4; ++o4) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = acc[o4 * 4 + j] + bias[og * 16 + o4 * 4 + j];
+            v[j] = relu ? fmaxf(t, 0.f) : t;
+        }
+        *reinterpret_cast<f32x4*>(out + 4 * o4) = v;
+    }
+}
+
+// MaxPool2d(kernel 3, stride 2, padding 1) on NHWC (torchvision resnet.maxpool); padding never wins.
+__global__ __launch_bounds__(256)
+void maxpool3x3_s2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int Ho, int Wo, int C)
+{
+    const int C4 = C >> 2;
+    const size_t total = (size_t)Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const size_t p = i / C4;
+        const int ox = (int)(p % Wo), oy = (int)(p / Wo);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy * 2 - 1 + r;
+            if (iy < 0 || iy >= H) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int ix = ox * 2 - 1 + s;
+                if (ix < 0 || ix >= W) continue;
+                const f32x4 v = reinterpret_cast<const f32x4*>(x + ((size_t)iy * W + ix) * C)[c4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+            }
+        }
+        reinterpret_cast<f32x4*>(y)[i] = m;
+    }
+}
+
+// y[n][c] = mean over x then over y, as `y.mean(-1).mean(-1)` (models/resnet.py:117) computes it:
+// first the mean of each row over x, then the mean of the row means.
+__global__ __launch_bounds__(256)
+void spatial_mean_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C)
+{
+    const size_t total = (size_t)N * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t n = i / C;
+        float outer = 0.f;
+        for (int yy = 0; yy < H; ++yy) {
+            float inner = 0.f;
+            for (int xx = 0; xx < W; ++xx) inner += x[((n * H + yy) * W + xx) * C + c];
+            outer += inner / (float)W;
+        }
+        y[i] = outer / (float)H;
+    }
+}
+
+// Frozen BatchNorm folded into the preceding convolution (models/resnet.py:58-77: BN always in eval
+// mode): w'[o] = w[o] * gamma[o]/sqrt(var[o]+eps), b'[o] = beta[o] - mean[o]*gamma[o]/sqrt(var[o]+eps).
+// Output layout is tap-major [R*S][cout][cin] (or [cin*R*S][cout] when cin == 3, for the stem).
+__global__ void fold_bn_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ mean,
+                                    const float* __restrict__ var, float eps, int cout, int cin, int taps,
+                                    float* __restrict__ wp, float* __restrict__ bp)
+{
+    const size_t total = (size_t)taps * cout * cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int o, ci, tap;
+        if (cin == 3) {            // [k = ci*taps + tap][cout]
+            o = (int)(i % cout);
+            const int k = (int)(i / cout);
+            ci = k / taps; tap = k - ci * taps;
+        } else {                   // [tap][cout][cin]
+            ci = (int)(i % cin);
+            const size_t t = i / cin;
+            o = (int)(t % cout); tap = (int)(t / cout);
+        }
+        const float scale = gamma[o] / sqrtf(var[o] + eps);
+        wp[i] = w[((size_t)o * cin + ci) * taps + tap] * scale;
+        if (ci == 0 && tap == 0) bp[o] = beta[o] - mean[o] * scale;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+struct GatherPlan { int cfg; int mblocks, nblocks, splits, stages_per_split; };
+
+static GatherPlan plan_gather(int M, int Cout, int stages)
+{
+    GatherPlan p;
+    p.cfg = (Cout <= 64) ? 1 : 0;                   // 1: 256 x 64 tile, 0: 128 x 128
+    const int bm = p.cfg == 1 ? 256 : 128, bn = p.cfg == 1 ? 64 : 128;
+    p.mblocks = cdiv(M, bm);
+    p.nblocks = cdiv(Cout, bn);
+    const int blocks = p.mblocks * p.nblocks;
+    int want = 1280 / (blocks > 0 ? blocks : 1);     // ~5 blocks per CU (see conv.hip)
+    int cap = stages / 8;
+    if (cap < 1) cap = 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    if ((size_t)M * Cout * sizeof(float) > ((size_t)40 << 20)) want = 1;
+    p.stages_per_split = cdiv(stages, want);
+    p.splits = cdiv(stages, p.stages_per_split);
+    return p;
+}
+
+size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R, int stride, int pad)
+{
+    if (cin % 16 != 0 || cout % 4 != 0) return 0;
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - R) / stride + 1;
+    if (Ho < 1 || Wo < 1) return 0;
+    const int M = N * Ho * Wo;
+    const GatherPlan p = plan_gather(M, cout, (cin / 16) * R * R);
+    return p.splits > 1 ? (size_t)p.splits * M * cout * sizeof(float) : 0;
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_gather_cfg(const GatherPlan& p, const float* x, const float* wp, const float* bias,
+                             const float* residual, float* y, float* ws, const GatherShape& g, int relu, hipStream_t s)
+{
+    using C = GatherCfg<TM, TN, WM, WN>;
+    auto kern = conv_gather_mfma_kernel<TM, TN, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_set = true;
+    }
+    dim3 grid(p.nblocks, p.mblocks, p.splits);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, x, wp, bias, residual, y, ws, g, p.stages_per_split, relu);
+    return check_launch();
+}
+
+int launch_conv_gather(const float* x, const float* wp, const float* bias, const float* residual, float* y,
+                       int N, int H, int W, int cin, int cout, int R, int stride, int pad, unsigned flags,
+                       void* ws, size_t ws_bytes, hipStream_t s)
+{
+    if (N < 1 || H < 1 || W < 1 || cin % 16 != 0 || cout % 4 != 0 || R < 1 || stride < 1 || pad < 0) return FRCNN_EINVAL;
+    GatherShape g;
+    g.N = N; g.H = H; g.W = W; g.Cin = cin; g.Cout = cout; g.R = R; g.S = R; g.stride = stride; g.pad = pad;
+    g.Ho = (H + 2 * pad - R) / stride + 1;
+    g.Wo = (W + 2 * pad - R) / stride + 1;
+    if (g.Ho < 1 || g.Wo < 1) return FRCNN_EINVAL;
+    const int M = N * g.Ho * g.Wo;
+    GatherPlan p = plan_gather(M, cout, (cin / 16) * R * R);
+    const size_t need = p.splits > 1 ? (size_t)p.splits * M * cout * sizeof(float) : 0;
+    if (need > ws_bytes || (need > 0 && ws == nullptr)) {       // no scratch: run un-split
+        p.splits = 1;
+        p.stages_per_split = (cin / 16) * R * R;
+    }
+    const int relu = (flags & FRCNN_RELU) ? 1 : 0;
+    int rc = p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s)
+                        : launch_gather_cfg<2, 2, 2, 2>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s);
+    if (rc) return rc;
+    if (p.splits > 1) {
+        const size_t total = (size_t)M * (cout / 4);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gather_splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, p.splits, bias,
+                           residual, y, M, cout, relu);
+        rc = check_launch();
+    }
+    return rc;
+}
+
+int launch_conv7x7_s2_c3(const float* x, const float* wp, const float* b, float* y, int H, int W, int cout,
+                         unsigned flags, hipStream_t s)
+{
+    if (cout % 16 != 0 || H < 1 || W < 1) return FRCNN_EINVAL;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    dim3 grid(cdiv(Ho * Wo, 256), cout / 16);
+    hipLaunchKernelGGL(conv7x7_s2_c3_kernel, grid, dim3(256), 0, s, x, wp, b, y, H, W, Ho, Wo, cout,
+                       (flags & FRCNN_RELU) ? 1 : 0);
+    return check_launch();
+}
+
+int launch_maxpool3x3_s2(const float* x, float* y, int H, int W, int c, hipStream_t s)
+{
+    if (c % 4 != 0 || H < 1 || W < 1) return FRCNN_EINVAL;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)Ho * Wo * (c / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(maxpool3x3_s2_kernel, dim3(blocks), dim3(256), 0, s, x, y, H, W, Ho, Wo, c);
+    return check_launch();
+}
+
+int launch_spatial_mean(const float* x, float* y, int N, int H, int W, int c, hipStream_t s)
+{
+    if (N < 1 || H < 1 || W < 1 || c < 1) return FRCNN_EINVAL;
+    const size_t total = (size_t)N * c;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(spatial_mean_kernel, dim3(blocks), dim3(256), 0, s, x, y, N, H, W, c);
+    return check_launch();
+}
+
+int launch_fold_bn_pack(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                        float eps, int cout, int cin, int ksize, float* wp, float* bp, hipStream_t s)
+{
+    if (cout < 1 || cin < 1 || ksize < 1) return FRCNN_EINVAL;
+    const size_t total = (size_t)ksize * ksize * cout * cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fold_bn_pack_kernel, dim3(blocks), dim3(256), 0, s, w, gamma, beta, mean, var, eps, cout, cin,
+                       ksize * ksize, wp, bp);
+    return check_launch();
+}
+
+}  // namespace frcnn

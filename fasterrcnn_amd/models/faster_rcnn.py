@@ -28,6 +28,7 @@ from .. import runtime as rt
 from .. import utils
 from . import anchors   # noqa: F401  (part of the mirrored module surface)
 from . import detector
+from . import resnet
 from . import rpn
 from . import vgg16
 
@@ -78,8 +79,10 @@ class FasterRCNNModel(nn.Module):
 
         # Backbone
         self.backbone = backbone
-        if not isinstance(backbone, vgg16.VGG16Backbone):
-            raise NotImplementedError("this build accelerates the VGG-16 backbone (models/vgg16.py); got %s" % type(backbone).__name__)
+        if not isinstance(backbone, (vgg16.VGG16Backbone, resnet.ResNetBackbone)):
+            raise NotImplementedError("this build accelerates the VGG-16 (models/vgg16.py) and ResNet (models/resnet.py) "
+                                      "backbones; got %s" % type(backbone).__name__)
+        self._is_resnet = isinstance(backbone, resnet.ResNetBackbone)
 
         # Network stages
         self._stage1_feature_extractor = backbone.feature_extractor
@@ -108,7 +111,9 @@ class FasterRCNNModel(nn.Module):
         return p.device
 
     def _weights(self):
-        """The frcnn_vgg16_weights struct over packed device tensors (rebuilt when parameters change)."""
+        """The frcnn_{vgg16,resnet}_weights struct over packed device tensors (rebuilt when parameters change)."""
+        if self._is_resnet:
+            return self._weights_resnet()
         s1 = self._stage1_feature_extractor.packed()
         s2 = self._stage2_region_proposal_network.packed()
         pv = self._stage3_detector_network._pool_to_feature_vector.packed()
@@ -125,6 +130,34 @@ class FasterRCNNModel(nn.Module):
             w.head_w, w.head_b = (x.data_ptr() for x in hd)
             w.num_classes = self._num_classes
             self._wstruct, self._wstruct_key, self._wkeep = w, key, tensors
+        return self._wstruct
+
+    def _weights_resnet(self):
+        fe = self._stage1_feature_extractor.packed()
+        s2 = self._stage2_region_proposal_network.packed()
+        l4 = self._stage3_detector_network._pool_to_feature_vector.packed()
+        hd = self._stage3_detector_network.packed()
+        blocks = list(fe["blocks"]) + list(l4)
+        tensors = [fe["stem"][0], fe["stem"][1]] + list(s2) + list(hd)
+        for b in blocks:
+            tensors += [b[k] for k in ("w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd") if b[k] is not None]
+        key = tuple(x.data_ptr() for x in tensors)
+        if key != self._wstruct_key:
+            if len(blocks) > nv.RESNET_MAX_BLOCKS:
+                raise NotImplementedError("more than %d bottleneck blocks" % nv.RESNET_MAX_BLOCKS)
+            w = nv.ResNetWeights()
+            w.stem_w, w.stem_b = fe["stem"][0].data_ptr(), fe["stem"][1].data_ptr()
+            for i, n in enumerate(fe["n_blocks"] + [len(l4)]):
+                w.n_blocks[i] = n
+            for i, b in enumerate(blocks):
+                bw = w.blocks[i]
+                for k in ("w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd"):
+                    setattr(bw, k, None if b[k] is None else b[k].data_ptr())
+                bw.cin, bw.width, bw.cout, bw.stride = b["cin"], b["width"], b["cout"], b["stride"]
+            w.rpn_conv_w, w.rpn_conv_b, w.rpn_head_w, w.rpn_head_b = (x.data_ptr() for x in s2)
+            w.head_w, w.head_b = (x.data_ptr() for x in hd)
+            w.num_classes = self._num_classes
+            self._wstruct, self._wstruct_key, self._wkeep = w, key, (tensors, fe, l4)
         return self._wstruct
 
     def _slot(self, index, h, w, device):
@@ -163,9 +196,11 @@ class FasterRCNNModel(nn.Module):
                 # the image (and packed weights) were produced on the caller's stream
                 stream.wait_stream(t.cuda.current_stream(device))
             sp = stream.cuda_stream
-            nv.check(lib.frcnn_vgg16_forward(slot.ctx.handle, C.byref(weights), C.byref(params), nv.ptr(image), h, w,
-                                             nv.ptr(amap), nv.ptr(vmap), nv.ptr(slot.props), nv.ptr(slot.classes),
-                                             nv.ptr(slot.deltas), nv.ptr(slot.counts), sp), "frcnn_vgg16_forward")
+            fwd, fwd_name = ((lib.frcnn_resnet_forward, "frcnn_resnet_forward") if self._is_resnet
+                             else (lib.frcnn_vgg16_forward, "frcnn_vgg16_forward"))
+            nv.check(fwd(slot.ctx.handle, C.byref(weights), C.byref(params), nv.ptr(image), h, w,
+                         nv.ptr(amap), nv.ptr(vmap), nv.ptr(slot.props), nv.ptr(slot.classes),
+                         nv.ptr(slot.deltas), nv.ptr(slot.counts), sp), fwd_name)
             with_det = score_threshold is not None
             with t.cuda.stream(stream):
                 if with_det:

@@ -1,0 +1,267 @@
+"""
+ResNet backbones, mirroring pytorch/FasterRCNN/models/resnet.py:27-185 (Architecture,
+FeatureExtractor, PoolToFeatureVector, ResNetBackbone) with the reference's attribute names, so
+the state_dict keys are the reference's:
+  _stage1_feature_extractor._feature_extractor.{0=conv1,1=bn1,4=layer1,5=layer2,6=layer3}....
+  _stage3_detector_network._pool_to_feature_vector._layer4....
+(inner names as torchvision's ResNet: N.convK.weight, N.bnK.{weight,bias,running_mean,running_var,
+num_batches_tracked}, N.downsample.{0,1}....).
+
+The reference wraps `torchvision.models.resnet{50,101,152}(weights=IMAGENET1K_V1)` (resnet.py:144-149).
+torchvision is a third-party dependency that is not available here and there is no network for the
+ImageNet weights, so `_ResNetParams` below restates torchvision's v1.5 Bottleneck architecture as a
+PARAMETER HOLDER (same module tree, torchvision's default initialisation); trained weights are
+loaded through `load_state_dict` exactly as with the reference.  All arithmetic runs in
+csrc/conv_gather.hip / conv.hip: BatchNorm is frozen in eval mode by the reference
+(resnet.py:58-77,100-107) and is folded into the preceding convolution when the weights are packed.
+"""
+from enum import Enum
+from math import ceil
+
+import torch as t
+from torch import nn
+
+from .. import _native as nv
+from .. import runtime as rt
+from ..datasets import image
+from .backbone import Backbone
+
+
+class Architecture(Enum):
+    ResNet50 = "ResNet50"
+    ResNet101 = "ResNet101"
+    ResNet152 = "ResNet152"
+
+
+_BLOCKS = {Architecture.ResNet50: (3, 4, 6, 3), Architecture.ResNet101: (3, 4, 23, 3), Architecture.ResNet152: (3, 8, 36, 3)}
+
+
+class _Bottleneck(nn.Module):
+    """torchvision.models.resnet.Bottleneck (v1.5: the stride sits on the 3x3 conv), parameters only."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or inplanes != planes * 4:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(planes * 4))
+        self.stride = stride
+
+
+class _ResNetParams(nn.Module):
+    """The module tree of torchvision's ResNet (conv1, bn1, relu, maxpool, layer1..layer4)."""
+    def __init__(self, blocks):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        inplanes = 64
+        layers = []
+        for i, (planes, n) in enumerate(zip((64, 128, 256, 512), blocks)):
+            stride = 1 if i == 0 else 2
+            mods = []
+            for b in range(n):
+                mods.append(_Bottleneck(inplanes, planes, stride if b == 0 else 1))
+                inplanes = planes * 4
+            layers.append(nn.Sequential(*mods))
+        self.layer1, self.layer2, self.layer3, self.layer4 = layers
+        for m in self.modules():          # torchvision's default initialisation
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+
+def fold_conv_bn(conv, bn):
+    """(packed weight, bias) of conv followed by frozen BatchNorm, via frcnn_fold_bn_pack."""
+    w = rt.as_f32_cuda(conv.weight.detach(), "conv weight")
+    cout, cin, k = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+    wp = t.empty((cin * k * k, cout) if cin == 3 else (k * k, cout, cin), dtype=t.float32, device=w.device)
+    bp = t.empty((cout,), dtype=t.float32, device=w.device)
+    args = [rt.as_f32_cuda(x.detach(), "bn tensor") for x in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+    with t.cuda.device(w.device):
+        nv.check(nv.lib().frcnn_fold_bn_pack(nv.ptr(w), nv.ptr(args[0]), nv.ptr(args[1]), nv.ptr(args[2]), nv.ptr(args[3]),
+                                             float(bn.eps), cout, cin, k, nv.ptr(wp), nv.ptr(bp), nv.stream_ptr()),
+                 "frcnn_fold_bn_pack")
+    return wp, bp, args
+
+
+def _bn_params(bn):
+    return [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+
+
+def pack_block(block):
+    """dict of packed tensors + shape info for one Bottleneck."""
+    w1, b1, k1 = fold_conv_bn(block.conv1, block.bn1)
+    w2, b2, k2 = fold_conv_bn(block.conv2, block.bn2)
+    w3, b3, k3 = fold_conv_bn(block.conv3, block.bn3)
+    out = {"w1": w1, "b1": b1, "w2": w2, "b2": b2, "w3": w3, "b3": b3, "wd": None, "bd": None,
+           "cin": block.conv1.in_channels, "width": block.conv1.out_channels, "cout": block.conv3.out_channels,
+           "stride": block.stride, "keep": [k1, k2, k3]}
+    if block.downsample is not None:
+        out["wd"], out["bd"], kd = fold_conv_bn(block.downsample[0], block.downsample[1])
+        out["keep"].append(kd)
+    return out
+
+
+def block_params(block):
+    ps = [block.conv1.weight, block.conv2.weight, block.conv3.weight] + _bn_params(block.bn1) + _bn_params(block.bn2) + _bn_params(block.bn3)
+    if block.downsample is not None:
+        ps += [block.downsample[0].weight] + _bn_params(block.downsample[1])
+    return ps
+
+
+def conv_nhwc(x, wp, bp, n, h, w, cin, cout, k, stride, pad, relu, residual=None):
+    """frcnn_conv_nhwc on a flat NHWC CUDA tensor; returns (y, ho, wo)."""
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    y = t.empty((n, ho, wo, cout), dtype=t.float32, device=x.device)
+    lib = nv.lib()
+    wsb = int(lib.frcnn_conv_workspace_bytes(n, h, w, cin, cout, k, stride, pad))
+    ws = t.empty((max(wsb, 4) // 4,), dtype=t.float32, device=x.device)
+    with t.cuda.device(x.device):
+        nv.check(lib.frcnn_conv_nhwc(nv.ptr(x), nv.ptr(wp), nv.ptr(bp), nv.ptr(residual), nv.ptr(y), n, h, w, cin, cout,
+                                     k, stride, pad, nv.RELU if relu else 0, nv.ptr(ws), wsb, nv.stream_ptr()),
+                 "frcnn_conv_nhwc")
+    return y, ho, wo
+
+
+def run_block(x, n, h, w, pb):
+    """One Bottleneck on NHWC data through the C ABI (stage-level path; the fused model uses frcnn_resnet_forward)."""
+    t1, _, _ = conv_nhwc(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, 1, 0, True)
+    t2, ho, wo = conv_nhwc(t1, pb["w2"], pb["b2"], n, h, w, pb["width"], pb["width"], 3, pb["stride"], 1, True)
+    identity = x
+    if pb["wd"] is not None:
+        identity, _, _ = conv_nhwc(x, pb["wd"], pb["bd"], n, h, w, pb["cin"], pb["cout"], 1, pb["stride"], 0, False)
+    out, _, _ = conv_nhwc(t2, pb["w3"], pb["b3"], n, ho, wo, pb["width"], pb["cout"], 1, 1, 0, True, residual=identity)
+    return out, ho, wo
+
+
+class FeatureExtractor(nn.Module):
+    def __init__(self, resnet):
+        super().__init__()
+        # Feature extractor layers (resnet.py:38-46)
+        self._feature_extractor = nn.Sequential(
+            resnet.conv1,     # 0
+            resnet.bn1,       # 1
+            resnet.relu,      # 2
+            resnet.maxpool,   # 3
+            resnet.layer1,    # 4
+            resnet.layer2,    # 5
+            resnet.layer3     # 6
+        )
+        # Freeze initial layers and every batchnorm (resnet.py:48-55) -- inference is unaffected
+        for layer in (resnet.conv1, resnet.bn1, resnet.layer1):
+            for p in layer.parameters():
+                p.requires_grad = False
+        for m in self._feature_extractor.modules():
+            if type(m) == nn.BatchNorm2d:
+                for p in m.parameters():
+                    p.requires_grad = False
+        self._packed_key = None
+        self._packed = None
+
+    def blocks(self):
+        fe = self._feature_extractor
+        return [b for layer in (fe[4], fe[5], fe[6]) for b in layer]
+
+    def packed(self):
+        """{'stem': (w, b), 'blocks': [dict]} of BN-folded packed weights, rebuilt when parameters change."""
+        fe = self._feature_extractor
+        params = [fe[0].weight] + _bn_params(fe[1]) + [p for b in self.blocks() for p in block_params(b)]
+        key = rt.param_key(params)
+        if key != self._packed_key:
+            sw, sb, keep = fold_conv_bn(fe[0], fe[1])
+            self._packed = {"stem": (sw, sb), "keep": keep, "blocks": [pack_block(b) for b in self.blocks()],
+                            "n_blocks": [len(fe[4]), len(fe[5]), len(fe[6])]}
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, image_data):
+        """image_data (1,3,H,W) float32 CUDA -> (1, 1024, ceil(H/16), ceil(W/16))."""
+        assert image_data.shape[0] == 1, "Batch size must be 1"
+        x = rt.as_f32_cuda(image_data, "image_data")
+        pk = self.packed()
+        h, w = int(x.shape[2]), int(x.shape[3])
+        lib = nv.lib()
+        h1, w1 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = t.empty((h1, w1, 64), dtype=t.float32, device=x.device)
+        with t.cuda.device(x.device):
+            nv.check(lib.frcnn_conv7x7_s2_c3(nv.ptr(x), nv.ptr(pk["stem"][0]), nv.ptr(pk["stem"][1]), nv.ptr(y), h, w, 64,
+                                             nv.RELU, nv.stream_ptr()), "frcnn_conv7x7_s2_c3")
+            h2, w2 = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
+            cur = t.empty((1, h2, w2, 64), dtype=t.float32, device=x.device)
+            nv.check(lib.frcnn_maxpool3x3_s2_nhwc(nv.ptr(y), nv.ptr(cur), h1, w1, 64, nv.stream_ptr()), "frcnn_maxpool3x3_s2_nhwc")
+        h, w = h2, w2
+        for pb in pk["blocks"]:
+            cur, h, w = run_block(cur, 1, h, w, pb)
+        return cur[0].permute(2, 0, 1).unsqueeze(0)
+
+
+class PoolToFeatureVector(nn.Module):
+    def __init__(self, resnet):
+        super().__init__()
+        self._layer4 = resnet.layer4
+        for m in self._layer4.modules():
+            if type(m) == nn.BatchNorm2d:
+                for p in m.parameters():
+                    p.requires_grad = False
+        self._packed_key = None
+        self._packed = None
+
+    def packed(self):
+        params = [p for b in self._layer4 for p in block_params(b)]
+        key = rt.param_key(params)
+        if key != self._packed_key:
+            self._packed = [pack_block(b) for b in self._layer4]
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, rois):
+        """rois (N, 1024, 7, 7) -> layer4 -> (N, 2048, 4, 4) -> mean over x then y -> (N, 2048)."""
+        x = rt.as_f32_cuda(rois, "rois")
+        n = int(x.shape[0])
+        if n == 0:
+            return t.empty((0, 2048), dtype=t.float32, device=x.device)
+        cur = x.permute(0, 2, 3, 1).contiguous()
+        h, w = int(x.shape[2]), int(x.shape[3])
+        for pb in self.packed():
+            cur, h, w = run_block(cur, n, h, w, pb)
+        c = int(cur.shape[3])
+        y = t.empty((n, c), dtype=t.float32, device=x.device)
+        with t.cuda.device(x.device):
+            nv.check(nv.lib().frcnn_spatial_mean_nhwc(nv.ptr(cur), nv.ptr(y), n, h, w, c, nv.stream_ptr()),
+                     "frcnn_spatial_mean_nhwc")
+        return y
+
+
+class ResNetBackbone(Backbone):
+    def __init__(self, architecture):
+        super().__init__()
+        # Backbone properties (resnet.py:138-141)
+        self.feature_map_channels = 1024
+        self.feature_pixels = 16
+        self.feature_vector_size = 2048
+        self.image_preprocessing_params = image.PreprocessingParams(
+            channel_order=image.ChannelOrder.RGB, scaling=1.0 / 255.0, means=[0.485, 0.456, 0.406], stds=[0.229, 0.224, 0.225])
+        if architecture not in _BLOCKS:
+            raise ValueError("Invalid ResNet architecture value: %s" % getattr(architecture, "value", architecture))
+        self.architecture = architecture
+        resnet = _ResNetParams(_BLOCKS[architecture])
+        self.feature_extractor = FeatureExtractor(resnet=resnet)
+        self.pool_to_feature_vector = PoolToFeatureVector(resnet=resnet)
+
+    def compute_feature_map_shape(self, image_shape):
+        """(1024, ceil(H/16), ceil(W/16)) -- resnet.py:161-185."""
+        image_width = image_shape[-1]
+        image_height = image_shape[-2]
+        return (self.feature_map_channels, ceil(image_height / self.feature_pixels), ceil(image_width / self.feature_pixels))

@@ -56,6 +56,80 @@ def vgg16_state_dict(seed=1234, num_classes=21, calibration=None):
     return sd
 
 
+RESNET_BLOCKS = {"ResNet50": (3, 4, 6, 3), "ResNet101": (3, 4, 23, 3), "ResNet152": (3, 8, 36, 3)}
+RGB_MEANS = (0.485, 0.456, 0.406)      # models/resnet.py:141 (reference)
+RGB_STDS = (0.229, 0.224, 0.225)
+
+# head multipliers on top of He-normal init (oracle/make_golden.py --calibrate-resnet, seed 1234, image seed 0)
+RESNET_CALIBRATION = {
+    "_stage2_region_proposal_network._rpn_conv1.weight": 0.613980047,
+    "_stage2_region_proposal_network._rpn_class.weight": 0.461671139,
+    "_stage2_region_proposal_network._rpn_boxes.weight": 0.166079862,
+    "_stage3_detector_network._classifier.weight": 0.996291455,
+    "_stage3_detector_network._regressor.weight": 0.27933594,
+}
+
+
+def resnet_state_dict(seed=1234, architecture="ResNet50", num_classes=21, calibration=None):
+    """
+    state_dict (CPU float32) of FasterRCNNModel over a ResNet backbone with the reference's key
+    names.  He-normal convolutions; BatchNorm statistics and affine parameters are random but
+    benign (gamma of every block's last BN is small so the residual stream stays bounded), which
+    exercises the BN folding non-trivially.
+    """
+    cal = RESNET_CALIBRATION if calibration is None else calibration
+    g = t.Generator().manual_seed(int(seed))
+    sd = {}
+
+    def conv(key, cout, cin, k):
+        sd[key + ".weight"] = t.randn((cout, cin, k, k), generator=g, dtype=t.float32) * math.sqrt(2.0 / (cin * k * k))
+
+    def bn(key, c, gamma_lo, gamma_hi):
+        sd[key + ".weight"] = t.rand((c,), generator=g) * (gamma_hi - gamma_lo) + gamma_lo
+        sd[key + ".bias"] = t.randn((c,), generator=g) * 0.1
+        sd[key + ".running_mean"] = t.randn((c,), generator=g) * 0.1
+        sd[key + ".running_var"] = t.rand((c,), generator=g) + 0.5
+        sd[key + ".num_batches_tracked"] = t.tensor(0, dtype=t.long)
+
+    fe = "_stage1_feature_extractor._feature_extractor."
+    conv(fe + "0", 64, 3, 7)
+    bn(fe + "1", 64, 0.8, 1.2)
+    inplanes = 64
+    blocks = RESNET_BLOCKS[architecture]
+    for li, (planes, n) in enumerate(zip((64, 128, 256, 512), blocks)):
+        prefix = (fe + "%d." % (4 + li)) if li < 3 else "_stage3_detector_network._pool_to_feature_vector._layer4."
+        for b in range(n):
+            p = prefix + "%d." % b
+            conv(p + "conv1", planes, inplanes, 1); bn(p + "bn1", planes, 0.8, 1.2)
+            conv(p + "conv2", planes, planes, 3);   bn(p + "bn2", planes, 0.8, 1.2)
+            conv(p + "conv3", planes * 4, planes, 1); bn(p + "bn3", planes * 4, 0.2, 0.4)
+            if b == 0:
+                conv(p + "downsample.0", planes * 4, inplanes, 1); bn(p + "downsample.1", planes * 4, 0.6, 1.0)
+            inplanes = planes * 4
+
+    def he(key, shape, fan_in):
+        sd[key + ".weight"] = t.randn(shape, generator=g, dtype=t.float32) * math.sqrt(2.0 / fan_in) * float(cal.get(key + ".weight", 1.0))
+        sd[key + ".bias"] = t.zeros(shape[0], dtype=t.float32)
+
+    he("_stage2_region_proposal_network._rpn_conv1", (1024, 1024, 3, 3), 1024 * 9)
+    he("_stage2_region_proposal_network._rpn_class", (9, 1024, 1, 1), 1024)
+    he("_stage2_region_proposal_network._rpn_boxes", (36, 1024, 1, 1), 1024)
+    he("_stage3_detector_network._classifier", (num_classes, 2048), 2048)
+    he("_stage3_detector_network._regressor", ((num_classes - 1) * 4, 2048), 2048)
+    return sd
+
+
+def image_rgb(seed, height=600, width=1000):
+    """Image preprocessed the ResNet way (models/resnet.py:141): RGB, /255, ImageNet mean/std."""
+    g = t.Generator().manual_seed(1000003 * int(seed) + 17)
+    lh, lw = max(2, int(round(height / 31.6))), max(2, int(round(width / 31.25)))
+    low = t.rand((1, 3, lh, lw), generator=g, dtype=t.float32)
+    up = t.nn.functional.interpolate(low, size=(height, width), mode="bilinear", align_corners=False)[0]
+    means = t.tensor(RGB_MEANS, dtype=t.float32).reshape(3, 1, 1)
+    stds = t.tensor(RGB_STDS, dtype=t.float32).reshape(3, 1, 1)
+    return ((up - means) / stds).contiguous()
+
+
 def image(seed, height=600, width=1000):
     """
     One preprocessed image, float32 (3, height, width): low-resolution uniform noise, bilinearly

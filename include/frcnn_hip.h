@@ -98,6 +98,36 @@ int frcnn_conv3x3_nhwc(const float* d_x, const float* d_w_packed, const float* d
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ResNet building blocks.  Replace what torchvision.models.resnet{50,101,152} executes under
+ * models/resnet.py:33-118 (conv1/bn1/relu/maxpool/layer1-3 as feature extractor, layer4 + spatial
+ * mean as the per-RoI head); BatchNorm is always in eval mode there (:58-77,:100-107) and is
+ * folded into the preceding convolution at pack time.
+ * ---------------------------------------------------------------------------------------- */
+/* Fold a frozen BatchNorm2d(gamma, beta, running_mean, running_var, eps) into conv weights
+ * OIHW [cout][cin][k][k]: d_w_packed is [k*k][cout][cin] (or [cin*k*k][cout] when cin == 3),
+ * d_b_packed [cout]. */
+int frcnn_fold_bn_pack(const float* d_w_oihw, const float* d_gamma, const float* d_beta,
+                       const float* d_mean, const float* d_var, float eps, int cout, int cin, int ksize,
+                       float* d_w_packed, float* d_b_packed, void* stream);
+/* Generic NHWC convolution (gather implicit GEMM, f32 MFMA): x [N][H][W][cin] ->
+ * y [N][Ho][Wo][cout], square kernel `ksize` (1 or 3), any stride / padding;
+ * y = act(conv(x) + bias (+ residual)), residual [N][Ho][Wo][cout] or NULL (Bottleneck's
+ * `out += identity`).  cin % 16 == 0, cout % 4 == 0.  d_ws: split-K scratch
+ * (frcnn_conv_workspace_bytes; NULL = un-split). */
+size_t frcnn_conv_workspace_bytes(int N, int H, int W, int cin, int cout, int ksize, int stride, int pad);
+int frcnn_conv_nhwc(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,
+                    float* d_y, int N, int H, int W, int cin, int cout, int ksize, int stride, int pad,
+                    unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
+/* Stem: 7x7 stride-2 pad-3 conv of the NCHW image [3][H][W] (+folded bn1, ReLU) -> NHWC
+ * [(H-1)/2+1][(W-1)/2+1][cout]; d_w_packed [147][cout] from frcnn_fold_bn_pack(cin = 3). */
+int frcnn_conv7x7_s2_c3(const float* d_x_chw, const float* d_w_packed, const float* d_bias, float* d_y,
+                        int H, int W, int cout, unsigned flags, void* stream);
+/* MaxPool2d(3, stride 2, padding 1) on NHWC; output [(H-1)/2+1][(W-1)/2+1][c]. */
+int frcnn_maxpool3x3_s2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream);
+/* y[n][c] = mean_y(mean_x(x[n][y][x][c]))  (models/resnet.py:117 `.mean(-1).mean(-1)`). */
+int frcnn_spatial_mean_nhwc(const float* d_x, float* d_y, int N, int H, int W, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Dense layers on the f32 MFMA pipe.  Replace nn.Linear (+ReLU) at models/vgg16.py:130-132,
  * models/detector.py:76,78 and the two 1x1 convolutions at models/rpn.py:89-90.
  *   y[m][n] = act( sum_k a[m*lda + k] * w[n*k_dim + k] + bias[n] ),  m < M, n < N
@@ -219,11 +249,44 @@ int frcnn_vgg16_forward(frcnn_ctx* ctx, const frcnn_vgg16_weights* w, const frcn
                         float* d_props, float* d_classes, float* d_deltas, int32_t* d_counts,
                         void* stream);
 
+/* Fused ResNet forward: FasterRCNNModel.forward (models/faster_rcnn.py:80-132) for the
+ * ResNet-50/101/152 backbones (models/resnet.py:131-185): feature map [ceil(H/16)][ceil(W/16)][1024],
+ * RPN on 1024 channels, RoIPool 7x7, layer4 per RoI + spatial mean -> 2048, heads. */
+#define FRCNN_RESNET_MAX_BLOCKS 64
+typedef struct frcnn_bottleneck_weights {
+    const float *w1, *b1;      /* 1x1 cin->width    (bn folded), [1][width][cin]   */
+    const float *w2, *b2;      /* 3x3 width->width, stride on this conv (v1.5), [9][width][width] */
+    const float *w3, *b3;      /* 1x1 width->cout, [1][cout][width] */
+    const float *wd, *bd;      /* downsample 1x1 cin->cout (stride), NULL when identity */
+    int32_t cin, width, cout, stride;
+} frcnn_bottleneck_weights;
+
+typedef struct frcnn_resnet_weights {
+    const float* stem_w;       /* [147][64] */
+    const float* stem_b;
+    int32_t n_blocks[4];       /* layer1..layer4: (3,4,6,3) / (3,4,23,3) / (3,8,36,3) */
+    frcnn_bottleneck_weights blocks[FRCNN_RESNET_MAX_BLOCKS];   /* layer1, layer2, layer3, layer4 in order */
+    const float* rpn_conv_w;   /* frcnn_pack_conv3x3 of _rpn_conv1 (1024 -> 1024) */
+    const float* rpn_conv_b;
+    const float* rpn_head_w;   /* [128][1024] */
+    const float* rpn_head_b;
+    const float* head_w;       /* [128][2048] */
+    const float* head_b;
+    int32_t num_classes;
+} frcnn_resnet_weights;
+
+int frcnn_resnet_forward(frcnn_ctx* ctx, const frcnn_resnet_weights* w, const frcnn_forward_params* p,
+                         const float* d_image, int H, int W,
+                         const float* d_anchor_map, const float* d_valid_map,
+                         float* d_props, float* d_classes, float* d_deltas, int32_t* d_counts,
+                         void* stream);
+
 /* Introspection for parity tests: device pointers of intermediate tensors of the LAST forward
  * on this ctx.  which: 0 feature map NHWC [fh][fw][512], 1 RPN head [fh*fw][128],
  * 2 objectness scores [A], 3 sorted anchor indices int32 [pre_nms], 4 RoI-pool out
  * [post_nms][7][7][512], 5 fc2 output [post_nms][4096], 6 anchor map, 7 valid map,
- * 8 head logits [post_nms][128].  Returns FRCNN_EINVAL for unknown ids. */
+ * 8 head logits [post_nms][128].  (ResNet: the feature map / RoI-pool tensors have 1024 channels,
+ * id 5 is the pooled [post_nms][2048] vector.)  Returns FRCNN_EINVAL for unknown ids. */
 int frcnn_ctx_tensor(frcnn_ctx* ctx, int which, void** d_ptr, size_t* bytes);
 
 /* Per-kernel-class HIP-event timing for bench.py's roofline block: when enabled, every launch

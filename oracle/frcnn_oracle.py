@@ -159,6 +159,54 @@ def vgg16_features(sd, image):
     return y
 
 
+# ---- ResNet (models/resnet.py:33-118 over torchvision's v1.5 Bottleneck, restated) ----------------
+_RFE = _S1 + "_feature_extractor."
+_RL4 = _S3 + "_pool_to_feature_vector._layer4."
+
+
+def is_resnet(sd):
+    return (_RFE + "0.weight") in sd
+
+
+def _bn(x, sd, prefix):
+    """BatchNorm2d in eval mode (resnet.py:58-77,100-107 force it), eps 1e-5."""
+    return F.batch_norm(x, sd[prefix + "running_mean"], sd[prefix + "running_var"], sd[prefix + "weight"],
+                        sd[prefix + "bias"], False, 0.0, 1e-5)
+
+
+def _bottleneck(x, sd, prefix, stride):
+    out = F.relu(_bn(F.conv2d(x, sd[prefix + "conv1.weight"]), sd, prefix + "bn1."))
+    out = F.relu(_bn(F.conv2d(out, sd[prefix + "conv2.weight"], stride=stride, padding=1), sd, prefix + "bn2."))
+    out = _bn(F.conv2d(out, sd[prefix + "conv3.weight"]), sd, prefix + "bn3.")
+    identity = x
+    if (prefix + "downsample.0.weight") in sd:
+        identity = _bn(F.conv2d(x, sd[prefix + "downsample.0.weight"], stride=stride), sd, prefix + "downsample.1.")
+    return F.relu(out + identity)
+
+
+def _layer(x, sd, prefix, first_stride):
+    b = 0
+    while (prefix + "%d.conv1.weight" % b) in sd:
+        x = _bottleneck(x, sd, prefix + "%d." % b, first_stride if b == 0 else 1)
+        b += 1
+    return x
+
+
+def resnet_features(sd, image):
+    """resnet.py:38-46,79-81: conv1, bn1, relu, maxpool(3,2,1), layer1..layer3 -> (1,1024,ceil(H/16),ceil(W/16))."""
+    y = F.relu(_bn(F.conv2d(image, sd[_RFE + "0.weight"], stride=2, padding=3), sd, _RFE + "1."))
+    y = F.max_pool2d(y, kernel_size=3, stride=2, padding=1)
+    y = _layer(y, sd, _RFE + "4.", 1)
+    y = _layer(y, sd, _RFE + "5.", 2)
+    return _layer(y, sd, _RFE + "6.", 2)
+
+
+def resnet_pool_to_feature_vector(sd, rois):
+    """resnet.py:109-118: layer4 (stride 2) then `.mean(-1).mean(-1)`."""
+    y = _layer(rois, sd, _RL4, 2)
+    return y.mean(-1).mean(-1)
+
+
 def decode_boxes_f32(deltas, anchors):
     """math_utils.py:99-128 with means 0 / stds 1 (rpn.py:118-123), float32 torch ops."""
     d = deltas * t.ones(4) + t.zeros(4)
@@ -243,7 +291,7 @@ def detector_forward(sd, feature_map, proposals, detail=None):
     rois = np.zeros((props.shape[0], 5), dtype=np.float32)
     rois[:, 1:] = props[:, [1, 0, 3, 2]]                             # (y1,x1,y2,x2) -> (x1,y1,x2,y2), :69
     pooled = t.from_numpy(roi_pool(feature_map.numpy(), rois, 7, 1.0 / 16.0))
-    y = pool_to_feature_vector(sd, pooled)
+    y = resnet_pool_to_feature_vector(sd, pooled) if is_resnet(sd) else pool_to_feature_vector(sd, pooled)
     logits = F.linear(y, sd[_S3 + "_classifier.weight"], sd[_S3 + "_classifier.bias"])
     classes = F.softmax(logits, dim=1)
     deltas = F.linear(y, sd[_S3 + "_regressor.weight"], sd[_S3 + "_regressor.bias"])
@@ -261,9 +309,12 @@ def forward(sd, image, anchor_map=None, anchor_valid_map=None, allow_edge_propos
     image_shape = tuple(image.shape[1:])
     with t.no_grad():
         if anchor_map is None or anchor_valid_map is None:
-            fshape = (512, image_shape[1] // 16, image_shape[2] // 16)        # vgg16.py:155-158
+            if is_resnet(sd):                                                 # resnet.py:183-185 (ceil)
+                fshape = (1024, math.ceil(image_shape[1] / 16), math.ceil(image_shape[2] / 16))
+            else:
+                fshape = (512, image_shape[1] // 16, image_shape[2] // 16)    # vgg16.py:155-158
             anchor_map, anchor_valid_map = generate_anchor_maps(image_shape, fshape, 16)
-        fm = vgg16_features(sd, image)
+        fm = resnet_features(sd, image) if is_resnet(sd) else vgg16_features(sd, image)
         _, _, proposals = rpn_forward(sd, fm, image_shape, anchor_map, anchor_valid_map, pre_nms, post_nms,
                                       allow_edge_proposals, detail)
         classes, deltas = detector_forward(sd, fm, proposals, detail)

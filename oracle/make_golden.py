@@ -30,9 +30,12 @@ from fasterrcnn_amd import synthetic          # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def build_reference_model(ref, sd, allow_edge=True):
-    model = ref.faster_rcnn.FasterRCNNModel(num_classes=21, backbone=ref.vgg16.VGG16Backbone(dropout_probability=0.0),
-                                            allow_edge_proposals=allow_edge)
+def build_reference_model(ref, sd, allow_edge=True, arch=None):
+    if arch is None:
+        backbone = ref.vgg16.VGG16Backbone(dropout_probability=0.0)
+    else:
+        backbone = ref.resnet.ResNetBackbone(architecture=getattr(ref.resnet.Architecture, arch))
+    model = ref.faster_rcnn.FasterRCNNModel(num_classes=21, backbone=backbone, allow_edge_proposals=allow_edge)
     model.load_state_dict(sd, strict=True)
     model.eval()
     return model
@@ -69,6 +72,35 @@ def calibrate(ref):
     print("}")
 
 
+def calibrate_resnet(ref, arch="ResNet50"):
+    """Head multipliers for the synthetic ResNet weights, measured with the reference's modules."""
+    ones = {k: 1.0 for k in synthetic.RESNET_CALIBRATION}
+    sd = synthetic.resnet_state_dict(1234, arch, calibration=ones)
+    img = synthetic.image_rgb(0).unsqueeze(0)
+    cal = {}
+    with t.no_grad():
+        model = build_reference_model(ref, sd, arch=arch)
+        fm = model._stage1_feature_extractor(image_data=img)
+        rpn = model._stage2_region_proposal_network
+        y = t.relu(rpn._rpn_conv1(fm))
+        k = "_stage2_region_proposal_network._rpn_conv1.weight"
+        cal[k] = 1.0 / float(y.std())
+        y = y * cal[k]
+        cal["_stage2_region_proposal_network._rpn_class.weight"] = 1.0 / float(rpn._rpn_class(y).std())
+        cal["_stage2_region_proposal_network._rpn_boxes.weight"] = 0.3 / float(rpn._rpn_boxes(y).std())
+        sd2 = synthetic.resnet_state_dict(1234, arch, calibration={**ones, **cal})
+        detail = {}
+        O.forward(sd2, img, detail=detail)
+        model = build_reference_model(ref, sd2, arch=arch)
+        det = model._stage3_detector_network
+        cal["_stage3_detector_network._classifier.weight"] = 3.0 / float(det._classifier(detail["fc2"]).std())
+        cal["_stage3_detector_network._regressor.weight"] = 1.0 / float(det._regressor(detail["fc2"]).std())
+    print("RESNET_CALIBRATION = {")
+    for k, v in cal.items():
+        print('    "%s": %.9g,' % (k, v))
+    print("}")
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
 
@@ -86,10 +118,10 @@ def assert_equal(name, a, b):
     print("  oracle == reference: %-28s %s %s" % (name, a.shape, a.dtype))
 
 
-def run_case(ref, tag, sd, seed, height, width, allow_edge, score_threshold):
-    print("case %s: image seed %d, %dx%d, allow_edge=%s" % (tag, seed, height, width, allow_edge))
-    img = synthetic.image(seed, height, width).unsqueeze(0)
-    model = build_reference_model(ref, sd, allow_edge)
+def run_case(ref, tag, sd, seed, height, width, allow_edge, score_threshold, arch=None):
+    print("case %s: image seed %d, %dx%d, allow_edge=%s, backbone=%s" % (tag, seed, height, width, allow_edge, arch or "VGG16"))
+    img = (synthetic.image_rgb if arch else synthetic.image)(seed, height, width).unsqueeze(0)
+    model = build_reference_model(ref, sd, allow_edge, arch)
     t0 = time.time()
     with t.no_grad():
         ref_props, ref_classes, ref_deltas = model(image_data=img)
@@ -140,14 +172,15 @@ def run_case(ref, tag, sd, seed, height, width, allow_edge, score_threshold):
         "sorted_idx": sorted_idx.astype(np.int32),
         "n_after_filter": np.int64(detail["n_after_filter"]),
         "scores_sample": scores[::7].copy(), "scores_sha": np.array(sha(scores)),
-        "feature_map_sample": fm_np[::16, :, :].copy(),          # 32 of 512 channels
+        "feature_map_sample": fm_np[::(32 if arch else 16), :, :].copy(),   # 32 of the 512 / 1024 channels
         "feature_map_absmean": np.float64(np.abs(fm_np).mean()),
         "rpn_deltas_sample": dmap.reshape(-1, 4).numpy()[::11].copy(),
         "fc2_sample": detail["fc2"].numpy()[:, ::64].copy(),
         "class_logits": detail["class_logits"].numpy(),
     }
-    np.savez_compressed(os.path.join(GOLDEN, "vgg16_%s.npz" % tag), **out)
-    print("  wrote tests/golden/vgg16_%s.npz" % tag)
+    name = "%s_%s.npz" % (arch.lower() if arch else "vgg16", tag)
+    np.savez_compressed(os.path.join(GOLDEN, name), **out)
+    print("  wrote tests/golden/%s" % name)
 
 
 def golden_small_ops(ref):
@@ -220,18 +253,29 @@ def golden_small_ops(ref):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--calibrate", action="store_true")
+    ap.add_argument("--calibrate-resnet", action="store_true")
+    ap.add_argument("--only-resnet", action="store_true")
     args = ap.parse_args()
     t.manual_seed(0)
     ref = reference_shims.install(O)
     if args.calibrate:
         calibrate(ref)
         return
+    if args.calibrate_resnet:
+        calibrate_resnet(ref)
+        return
     os.makedirs(GOLDEN, exist_ok=True)
-    golden_small_ops(ref)
-    sd = synthetic.vgg16_state_dict(1234)
-    run_case(ref, "600x1000_s0", sd, 0, 600, 1000, True, 0.05)
-    run_case(ref, "224x320_s3", sd, 3, 224, 320, True, 0.05)           # A = 2520 < 6000 anchors
-    run_case(ref, "333x517_s5_noedge", sd, 5, 333, 517, False, 0.05)   # ragged size, valid-anchor filter
+    if not args.only_resnet:
+        golden_small_ops(ref)
+        sd = synthetic.vgg16_state_dict(1234)
+        run_case(ref, "600x1000_s0", sd, 0, 600, 1000, True, 0.05)
+        run_case(ref, "224x320_s3", sd, 3, 224, 320, True, 0.05)           # A = 2520 < 6000 anchors
+        run_case(ref, "333x517_s5_noedge", sd, 5, 333, 517, False, 0.05)   # ragged size, valid-anchor filter
+    sd = synthetic.resnet_state_dict(1234, "ResNet50")
+    run_case(ref, "600x1000_s0", sd, 0, 600, 1000, True, 0.05, arch="ResNet50")
+    run_case(ref, "250x333_s7", sd, 7, 250, 333, True, 0.05, arch="ResNet50")   # ceil() feature map 16x21
+    sd = synthetic.resnet_state_dict(1234, "ResNet101")
+    run_case(ref, "224x320_s3", sd, 3, 224, 320, True, 0.05, arch="ResNet101")
 
 
 if __name__ == "__main__":

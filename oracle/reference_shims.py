@@ -51,6 +51,11 @@ def install(oracle_module):
     ops.nms = nms
     ops.RoIPool = RoIPool
     models.vgg16 = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("torchvision.models stub"))
+    from oracle import tv_resnet
+    for arch in ("resnet50", "resnet101", "resnet152"):
+        setattr(models, arch, getattr(tv_resnet, arch))
+    for wname in ("ResNet50_Weights", "ResNet101_Weights", "ResNet152_Weights"):
+        setattr(models, wname, types.SimpleNamespace(IMAGENET1K_V1=None))   # no network: weights come from load_state_dict
     tv.ops = ops
     tv.models = models
     sys.modules["torchvision"] = tv
@@ -73,8 +78,8 @@ def install(oracle_module):
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     # the tree has no __init__.py files: namespace packages
-    from pytorch.FasterRCNN.models import faster_rcnn, vgg16, anchors, math_utils   # noqa: E402
+    from pytorch.FasterRCNN.models import faster_rcnn, vgg16, resnet, anchors, math_utils   # noqa: E402
     from pytorch.FasterRCNN import statistics                                       # noqa: E402
     from pytorch.FasterRCNN.datasets import training_sample                         # noqa: E402
-    return types.SimpleNamespace(faster_rcnn=faster_rcnn, vgg16=vgg16, anchors=anchors, math_utils=math_utils,
+    return types.SimpleNamespace(faster_rcnn=faster_rcnn, vgg16=vgg16, resnet=resnet, anchors=anchors, math_utils=math_utils,
                                  statistics=statistics, training_sample=training_sample)

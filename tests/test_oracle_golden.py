@@ -99,7 +99,8 @@ def check_against_golden(g, props, classes, deltas, detail, det):
     tests (feature map 2e-5 relative, boxes 1e-3 px on IoU-matched rows).
     """
     fm = detail["feature_map"].numpy()[0]
-    same_host = np.array_equal(fm[::16], g["feature_map_sample"])
+    step = fm.shape[0] // 32                    # the fixture holds 32 of the 512 (VGG) / 1024 (ResNet) channels
+    same_host = np.array_equal(fm[::step], g["feature_map_sample"])
     if same_host:
         assert np.array_equal(detail["sorted_idx"].astype(np.int32), g["sorted_idx"])
         assert np.array_equal(props.numpy(), g["proposals"])
@@ -108,7 +109,7 @@ def check_against_golden(g, props, classes, deltas, detail, det):
         assert np.array_equal(flat(det), g["detections"])
         return True
     scale = float(np.abs(g["feature_map_sample"]).max())
-    assert float(np.abs(fm[::16] - g["feature_map_sample"]).max()) <= 2e-5 * scale
+    assert float(np.abs(fm[::step] - g["feature_map_sample"]).max()) <= 2e-5 * scale
     assert len(set(detail["sorted_idx"].tolist()) ^ set(g["sorted_idx"].tolist())) <= 8
     m = iou_matrix(g["proposals"].astype(np.float64), props.numpy().astype(np.float64))
     j = m.argmax(axis=1)
@@ -140,3 +141,18 @@ def test_oracle_reproduces_reference_full_size(golden_dir, sd_cpu):
     det = O.detections(props.numpy(), classes.numpy(), deltas.numpy(), 600, 1000, 0.05)
     if check_against_golden(g, props, classes, deltas, detail, det):
         assert sha(detail["scores"].numpy()) == str(g["scores_sha"])
+
+
+@pytest.mark.parametrize("name,arch", [("resnet50_250x333_s7", "ResNet50"), ("resnet101_224x320_s3", "ResNet101"),
+                                       ("resnet50_600x1000_s0", "ResNet50")])
+def test_oracle_reproduces_reference_resnet(golden_dir, name, arch):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    sd = synthetic.resnet_state_dict(1234, arch)
+    img = synthetic.image_rgb(int(g["seed"]), int(g["height"]), int(g["width"])).unsqueeze(0)
+    detail = {}
+    props, classes, deltas = O.forward(sd, img, detail=detail)
+    assert detail["feature_map"].shape[1] == 1024
+    assert tuple(detail["feature_map"].shape[2:]) == (-(-int(g["height"]) // 16), -(-int(g["width"]) // 16))   # ceil
+    det = O.detections(props.numpy(), classes.numpy(), deltas.numpy(), int(g["height"]), int(g["width"]),
+                       float(g["score_threshold"]))
+    check_against_golden(g, props, classes, deltas, detail, det)

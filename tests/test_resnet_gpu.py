@@ -1,0 +1,210 @@
+"""
+ResNet path on a real MI355X: the generic gather convolution,
+stem, 3x3/s2 max-pool, spatial mean and BatchNorm folding against torch-CPU fp32/fp64, and the
+fused ResNet-50 / ResNet-101 model against the oracle and the reference's golden vectors.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fasterrcnn_amd import _native as nv
+from fasterrcnn_amd import synthetic
+from oracle import frcnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def S():
+    return nv.stream_ptr()
+
+
+def gpu(x):
+    return torch.as_tensor(x).to(DEV).contiguous()
+
+
+def rel_err(ours, truth):
+    return float((ours.double() - truth).abs().max()) / (float(truth.abs().max()) + 1e-30)
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,k,stride,pad,relu,res", [
+    (1, 150, 250, 64, 64, 1, 1, 0, True, False),      # layer1 conv1 (cout = 64 tile)
+    (1, 150, 250, 64, 256, 1, 1, 0, True, True),      # conv3 + identity + relu
+    (1, 150, 250, 256, 512, 1, 2, 0, False, False),   # downsample 1x1 stride 2
+    (1, 150, 250, 128, 128, 3, 2, 1, True, False),    # layer2.0 conv2: 3x3 stride 2
+    (1, 75, 125, 256, 256, 3, 2, 1, True, False),     # layer3.0 conv2: odd size -> 38x63
+    (300, 7, 7, 512, 512, 3, 2, 1, True, False),      # layer4.0 conv2 on 300 RoIs
+    (300, 4, 4, 512, 512, 3, 1, 1, True, False),      # layer4.1 conv2 on 4x4 maps
+    (37, 7, 7, 1024, 512, 1, 1, 0, True, False),      # layer4.0 conv1
+    (3, 5, 9, 16, 20, 3, 1, 1, False, True),          # ragged everything, cout % 4
+])
+def test_conv_nhwc_gather(N, H, W, cin, cout, k, stride, pad, relu, res):
+    g = torch.Generator().manual_seed(N + H + W + cin + cout)
+    x = torch.randn((N, cin, H, W), generator=g)
+    w = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    ho, wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    r = torch.randn((N, cout, ho, wo), generator=g) if res else None
+    wp = gpu(w.permute(2, 3, 0, 1).reshape(k * k, cout, cin))
+    dx, db = gpu(x.permute(0, 2, 3, 1)), gpu(b)
+    dr = gpu(r.permute(0, 2, 3, 1)) if res else None
+    y = torch.full((N, ho, wo, cout), float("nan"), device=DEV)
+    lib = nv.lib()
+    wsb = int(lib.frcnn_conv_workspace_bytes(N, H, W, cin, cout, k, stride, pad))
+    ws = torch.empty((max(wsb, 4) // 4,), device=DEV)
+    nv.check(lib.frcnn_conv_nhwc(nv.ptr(dx), nv.ptr(wp), nv.ptr(db), nv.ptr(dr), nv.ptr(y), N, H, W, cin, cout, k, stride, pad,
+                                 nv.RELU if relu else 0, nv.ptr(ws), wsb, S()), "conv_nhwc")
+    truth = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)
+    if res:
+        truth = truth + r.double()
+    if relu:
+        truth = truth.clamp(min=0)
+    ours = y.cpu().permute(0, 3, 1, 2)
+    assert not torch.isnan(ours).any()
+    e = rel_err(ours, truth)
+    print("conv_nhwc N=%d %dx%d %d->%d k%d s%d: rel err %.3g (split-K ws %d B)" % (N, H, W, cin, cout, k, stride, e, wsb))
+    assert e <= 4e-6 * np.sqrt(cin * k * k)          # fp32 accumulation over K terms
+    # un-split run agrees
+    y1 = torch.full_like(y, float("nan"))
+    nv.check(lib.frcnn_conv_nhwc(nv.ptr(dx), nv.ptr(wp), nv.ptr(db), nv.ptr(dr), nv.ptr(y1), N, H, W, cin, cout, k, stride, pad,
+                                 nv.RELU if relu else 0, None, 0, S()), "conv_nhwc")
+    assert rel_err(y1.cpu().permute(0, 3, 1, 2), truth) <= 4e-6 * np.sqrt(cin * k * k)
+
+
+@pytest.mark.parametrize("H,W", [(600, 1000), (250, 333), (33, 47)])
+def test_stem_maxpool_and_bn_fold(H, W):
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn((3, H, W), generator=g)
+    w = torch.randn((64, 3, 7, 7), generator=g) * 0.1
+    gamma, beta = torch.rand((64,), generator=g) + 0.5, torch.randn((64,), generator=g) * 0.1
+    mean, var = torch.randn((64,), generator=g) * 0.1, torch.rand((64,), generator=g) + 0.5
+    lib = nv.lib()
+    dw, dg, dbt, dm, dv, dx = gpu(w), gpu(gamma), gpu(beta), gpu(mean), gpu(var), gpu(x)
+    wp, bp = torch.empty((147, 64), device=DEV), torch.empty((64,), device=DEV)
+    nv.check(lib.frcnn_fold_bn_pack(nv.ptr(dw), nv.ptr(dg), nv.ptr(dbt), nv.ptr(dm), nv.ptr(dv), 1e-5, 64, 3, 7,
+                                    nv.ptr(wp), nv.ptr(bp), S()), "fold")
+    h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((h1, w1, 64), device=DEV)
+    nv.check(lib.frcnn_conv7x7_s2_c3(nv.ptr(dx), nv.ptr(wp), nv.ptr(bp), nv.ptr(y), H, W, 64, nv.RELU, S()), "stem")
+    ref = F.relu(F.batch_norm(F.conv2d(x.double().unsqueeze(0), w.double(), stride=2, padding=3), mean.double(), var.double(),
+                              gamma.double(), beta.double(), False, 0.0, 1e-5))
+    assert tuple(ref.shape[2:]) == (h1, w1)
+    assert rel_err(y.cpu().permute(2, 0, 1).unsqueeze(0), ref) <= 5e-6
+    h2, w2 = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
+    p = torch.empty((h2, w2, 64), device=DEV)
+    nv.check(lib.frcnn_maxpool3x3_s2_nhwc(nv.ptr(y), nv.ptr(p), h1, w1, 64, S()), "maxpool")
+    pref = F.max_pool2d(y.cpu().permute(2, 0, 1).unsqueeze(0), 3, 2, 1)
+    assert torch.equal(p.cpu().permute(2, 0, 1).unsqueeze(0), pref)            # max: exact
+
+
+def test_fold_bn_3x3_layout_and_spatial_mean():
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn((32, 16, 3, 3), generator=g)
+    gamma, beta = torch.rand((32,), generator=g) + 0.5, torch.randn((32,), generator=g)
+    mean, var = torch.randn((32,), generator=g), torch.rand((32,), generator=g) + 0.5
+    dw, dg, dbt, dm, dv = gpu(w), gpu(gamma), gpu(beta), gpu(mean), gpu(var)
+    wp, bp = torch.empty((9, 32, 16), device=DEV), torch.empty((32,), device=DEV)
+    nv.check(nv.lib().frcnn_fold_bn_pack(nv.ptr(dw), nv.ptr(dg), nv.ptr(dbt), nv.ptr(dm), nv.ptr(dv), 1e-5, 32, 16, 3,
+                                         nv.ptr(wp), nv.ptr(bp), S()), "fold")
+    scale = gamma.double() / torch.sqrt(var.double() + 1e-5)
+    wref = (w.double() * scale[:, None, None, None]).permute(2, 3, 0, 1).reshape(9, 32, 16)
+    assert rel_err(wp.cpu(), wref) <= 2e-7 and rel_err(bp.cpu(), beta.double() - mean.double() * scale) <= 2e-7
+    x = torch.randn((300, 4, 4, 2048), generator=g)
+    dx = gpu(x)
+    y = torch.empty((300, 2048), device=DEV)
+    nv.check(nv.lib().frcnn_spatial_mean_nhwc(nv.ptr(dx), nv.ptr(y), 300, 4, 4, 2048, S()), "mean")
+    ref = x.permute(0, 3, 1, 2).mean(-1).mean(-1)
+    assert float((y.cpu() - ref).abs().max()) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+def iou_matrix(a, b):
+    tl = np.maximum(a[:, None, 0:2], b[None, :, 0:2])
+    br = np.minimum(a[:, None, 2:4], b[None, :, 2:4])
+    wh = np.clip(br - tl, 0, None)
+    inter = wh[..., 0] * wh[..., 1]
+    aa = np.prod(a[:, 2:4] - a[:, 0:2], axis=1)
+    ab = np.prod(b[:, 2:4] - b[:, 0:2], axis=1)
+    return inter / (aa[:, None] + ab[None, :] - inter + 1e-12)
+
+
+def match_rows(ours, ref):
+    if len(ref) == 0 or len(ours) == 0:
+        return np.zeros((0,), int), np.full((len(ref),), np.inf)
+    j = iou_matrix(ref[:, :4].astype(np.float64), ours[:, :4].astype(np.float64)).argmax(axis=1)
+    return j, np.abs(ours[j, :4] - ref[:, :4]).max(axis=1)
+
+
+def make_model(arch):
+    from fasterrcnn_amd.models import resnet
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    m = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(getattr(resnet.Architecture, arch)))
+    sd = synthetic.resnet_state_dict(1234, arch)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval(), sd
+
+
+@pytest.fixture(scope="module")
+def r50():
+    return make_model("ResNet50")
+
+
+@pytest.mark.parametrize("name", ["resnet50_250x333_s7", "resnet50_600x1000_s0"])
+def test_resnet50_stages_and_end_to_end(r50, golden_dir, name):
+    model, sd = r50
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    h, w = int(g["height"]), int(g["width"])
+    img = synthetic.image_rgb(int(g["seed"]), h, w).unsqueeze(0)
+    detail = {}
+    o_props, o_classes, o_deltas = O.forward(sd, img, detail=detail)
+    # stage 1 on its own: feature map vs the oracle (23 folded conv+BN layers deep)
+    fm = model._stage1_feature_extractor(image_data=img.cuda()).cpu()
+    ref_fm = detail["feature_map"]
+    assert tuple(fm.shape) == tuple(ref_fm.shape) == (1, 1024, -(-h // 16), -(-w // 16))
+    e = float((fm - ref_fm).abs().max()) / float(ref_fm.abs().max())
+    print("%s feature map: max rel err %.3g" % (name, e))
+    assert e <= 3e-5
+    # stage 3 on the oracle's proposals: layer4 per RoI + mean + heads
+    det = model._stage3_detector_network
+    classes, deltas = det(feature_map=ref_fm.cuda(), proposals=o_props.cuda())
+    c_err, d_err = float((classes.cpu() - o_classes).abs().max()), float((deltas.cpu() - o_deltas).abs().max())
+    print("%s detector on oracle proposals: |d prob| %.3g |d delta| %.3g" % (name, c_err, d_err))
+    assert c_err <= 2e-5 and d_err <= 2e-4 * max(1.0, float(o_deltas.abs().max()))
+    # fused forward vs the reference's golden vectors
+    props, classes, deltas = model(image_data=img.cuda())
+    assert props.shape[0] == g["proposals"].shape[0]
+    j, err = match_rows(props.cpu().numpy(), g["proposals"])
+    ok = err <= 1e-3
+    print("%s forward: %.1f%% of the reference's proposals within 1e-3 px" % (name, 100 * ok.mean()))
+    assert ok.mean() >= 0.95
+    assert np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max() <= 2e-4
+    pooled = model.context(0).tensor(5).reshape(-1, 2048)
+    assert pooled.shape[0] == 300
+    # predict vs the reference's golden dict
+    out = model.predict(image_data=img.cuda(), score_threshold=0.05)
+    ref = g["detections"]
+    n_ok = 0
+    for c in range(1, 21):
+        r = ref[ref[:, 0] == c][:, 1:]
+        if len(r):
+            j, err = match_rows(out[c], r)
+            n_ok += int(((err <= 1e-3) & (np.abs(out[c][j, 4] - r[:, 4]) <= 2e-4 if len(out[c]) else False)).sum())
+    print("%s predict: %d/%d reference detections reproduced" % (name, n_ok, len(ref)))
+    assert n_ok >= 0.93 * len(ref)
+
+
+def test_resnet101_end_to_end(golden_dir):
+    model, sd = make_model("ResNet101")
+    g = np.load(os.path.join(golden_dir, "resnet101_224x320_s3.npz"))
+    img = synthetic.image_rgb(3, 224, 320).unsqueeze(0)
+    props, classes, deltas = model(image_data=img.cuda())
+    assert props.shape[0] == g["proposals"].shape[0] == 149          # fewer than 300 survive NMS here
+    j, err = match_rows(props.cpu().numpy(), g["proposals"])
+    ok = err <= 1e-3
+    assert ok.mean() >= 0.95
+    assert np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max() <= 2e-4
+    out = model.predict(image_data=img.cuda(), score_threshold=0.05)
+    assert abs(sum(len(v) for v in out.values()) - len(g["detections"])) <= 4
