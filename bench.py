@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=3, help="images timed on the host CPU (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-images", type=int, default=10)
+    ap.add_argument("--backbone", type=str, default="vgg16", choices=["vgg16", "resnet50", "resnet101", "resnet152"],
+                    help="vgg16 is the BASELINE.json metric; the ResNets are informational (configs[2])")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,14 +129,22 @@ def main():
     from fasterrcnn_amd.models.vgg16 import VGG16Backbone
     _native.require_gpu()
 
-    sd = synthetic.vgg16_state_dict(1234)
-    model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+    is_resnet = args.backbone != "vgg16"
+    if is_resnet:
+        from fasterrcnn_amd.models import resnet
+        arch = {"resnet50": "ResNet50", "resnet101": "ResNet101", "resnet152": "ResNet152"}[args.backbone]
+        sd = synthetic.resnet_state_dict(1234, arch)
+        model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(getattr(resnet.Architecture, arch)))
+    else:
+        sd = synthetic.vgg16_state_dict(1234)
+        model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
     model.load_state_dict(sd, strict=True)
     model = model.cuda(dev).eval()
+    make_image = synthetic.image_rgb if is_resnet else synthetic.image
 
     # synthetic image pool, resident in HBM before timing; per-image seed = global index
     seeds = [rank * args.pool + i for i in range(args.pool)]
-    pool = [synthetic.image(s).unsqueeze(0).to(dev) for s in seeds]
+    pool = [make_image(s).unsqueeze(0).to(dev) for s in seeds]
     nslots = max(1, args.inflight)
 
     def run(n_steps):
@@ -197,7 +207,7 @@ def main():
         }
 
         cpu = None
-        if not args.no_cpu_baseline and n_gpus == 1:
+        if not args.no_cpu_baseline and n_gpus == 1 and not is_resnet:
             from oracle import frcnn_oracle as O       # CPU baseline leg only (checker, never the product)
             img0 = synthetic.image(seeds[0]).unsqueeze(0)
             cores = cpu_threads_for_baseline(sd, img0, O)
@@ -211,16 +221,22 @@ def main():
                              "(torch-CPU conv/linear; best of several thread counts = %d of %d host cores), %.1f s" % (
                                  args.cpu_images, cores, os.cpu_count() or 1, dt)}
 
+        # algorithmic FLOP per image: VGG-16 from the layer shapes, ResNets from BASELINE.md section 3
+        flops_img = {"vgg16": total_flops_per_image(), "resnet50": 2.7845e11, "resnet101": 3.6913e11,
+                     "resnet152": 4.5937e11}[args.backbone]
+        if is_resnet:
+            roofline = {"note": "roofline block is defined for the VGG-16 headline workload only",
+                        "per_class_ms_per_image": roofline["per_class_ms_per_image"]}
         out = {
-            "metric": "images/sec (600x1000) Faster-RCNN VGG-16 inference", "value": round(value, 3),
+            "metric": "images/sec (600x1000) Faster-RCNN %s inference" % ("VGG-16" if not is_resnet else args.backbone), "value": round(value, 3),
             "unit": "images/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "VGG-16 Faster R-CNN predict(), 3x600x1000 float32, batch=1 per forward, "
+            "config": {"workload": ("VGG-16" if not is_resnet else args.backbone) + " Faster R-CNN predict(), 3x600x1000 float32, batch=1 per forward, "
                                    "6000 pre-/300 post-NMS proposals, score_threshold 0.05",
                        "images_in_flight_per_gpu": nslots, "parallelism": "image-parallel x%d" % n_gpus,
-                       "flops_per_image": total_flops_per_image()},
-            "tflops_per_gpu": round(value / n_gpus * total_flops_per_image() / 1e12, 2),
+                       "flops_per_image": flops_img},
+            "tflops_per_gpu": round(value / n_gpus * flops_img / 1e12, 2),
             "map_at_0.5": mean_ap, "map_images": int(args.map_images * world),
             "roofline": roofline, "cpu_baseline": cpu,
         }

