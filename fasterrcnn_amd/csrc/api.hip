@@ -120,6 +120,17 @@ int frcnn_anchors(int image_h, int image_w, int fh, int fw, int feature_pixels,
     return launch_anchors(image_h, image_w, fh, fw, feature_pixels, d_anchor_map, d_valid_map, as_stream(stream));
 }
 
+int frcnn_rpn_targets(const float* d_anchor_map, const float* d_valid_map, int n_anchors, const float* d_gt_boxes,
+                      int n_gt, double object_thr, double background_thr, float* d_rpn_map, int32_t* d_object_idx,
+                      int32_t* d_background_idx, int32_t* d_counts, void* d_ws, void* stream)
+{
+    if (!d_anchor_map || !d_valid_map || !d_gt_boxes || !d_rpn_map || !d_object_idx || !d_background_idx ||
+        !d_counts || !d_ws)
+        return FRCNN_EINVAL;
+    return launch_rpn_targets(d_anchor_map, d_valid_map, n_anchors, d_gt_boxes, n_gt, object_thr, background_thr,
+                              d_rpn_map, d_object_idx, d_background_idx, d_counts, d_ws, as_stream(stream));
+}
+
 int frcnn_pack_conv3x3(const float* d_w, float* d_wp, int cout, int cin, void* stream)
 {
     if (!d_w || !d_wp) return FRCNN_EINVAL;

@@ -95,6 +95,10 @@ int launch_nms(const ProposalScratch& ps, const float* boxes, const float* score
 int launch_roi_pool(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
                     int max_rois, int pooled, float scale, float* out, hipStream_t s);
 
+int launch_rpn_targets(const float* anchor_map, const float* valid_map, int A, const float* gt, int M,
+                       double obj_thr, double bg_thr, float* rpn_map, int32_t* obj_idx, int32_t* bg_idx,
+                       int32_t* counts, void* ws, hipStream_t s);
+
 int launch_detections(const float* props, const float* classes, const float* deltas,
                       const int32_t* n_rois, int max_rois, int ncls, int image_h, int image_w,
                       float score_thr, float nms_thr, double* out, int32_t* out_cnt, hipStream_t s);

@@ -58,6 +58,21 @@ int         frcnn_device_count(void);
 int frcnn_anchors(int image_h, int image_w, int fh, int fw, int feature_pixels,
                   float* d_anchor_map, float* d_valid_map, void* stream);
 
+/* RPN ground-truth labelling (anchor <-> GT IoU matching).  Replaces models/anchors.py:137-262
+ * generate_rpn_map: float64 IoU of every anchor with every ground-truth box (float32 corners
+ * (y1,x1,y2,x2)), invalid anchors excluded; object if IoU >= object_thr or the anchor attains a
+ * GT box's maximum IoU, background if max IoU < background_thr, ignored otherwise; float32
+ * regression targets of the best-IoU box.
+ *   d_rpn_map        : float32 [A][6] = (trainable, object, ty, tx, th, tw), A = fh*fw*9
+ *   d_object_idx     : int32 [A] flat anchor indices of object anchors, ascending; d_counts[0] of them
+ *   d_background_idx : int32 [A] likewise for background anchors; d_counts[1]
+ *   d_ws             : scratch, at least 8*n_gt bytes.  n_gt >= 1 (the reference cannot label an
+ *                      image without boxes either). */
+int frcnn_rpn_targets(const float* d_anchor_map, const float* d_valid_map, int n_anchors,
+                      const float* d_gt_boxes, int n_gt, double object_thr, double background_thr,
+                      float* d_rpn_map, int32_t* d_object_idx, int32_t* d_background_idx, int32_t* d_counts,
+                      void* d_ws, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Weight repacking (run once at load; device -> device).
  * ---------------------------------------------------------------------------------------- */

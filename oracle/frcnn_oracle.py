@@ -59,6 +59,52 @@ def generate_anchor_maps(image_shape, feature_map_shape, feature_pixels):
     return amap.reshape(height, width, 36).astype(np.float32), valid.astype(np.float32)
 
 
+def generate_rpn_map(anchor_map, anchor_valid_map, gt_corners, object_iou_threshold=0.7, background_iou_threshold=0.3):
+    """
+    anchors.py:137-262.  gt_corners: (M,4) float32 (y1,x1,y2,x2).  Returns (rpn_map float32
+    (H,W,9,6), object indices (N,3), background indices (M,3)) with the reference's dtype flow:
+    anchor corners float32 -> float64 (:186-190), IoU float64 (:199), targets float32 (:244-246).
+    """
+    height, width, k = anchor_valid_map.shape
+    gt = np.asarray(gt_corners)
+    am = anchor_map.reshape(-1, 4)
+    corners = np.empty(am.shape)                                             # float64
+    corners[:, 0:2] = am[:, 0:2] - 0.5 * am[:, 2:4]
+    corners[:, 2:4] = am[:, 0:2] + 0.5 * am[:, 2:4]
+    n = corners.shape[0]
+    tl = np.maximum(corners[:, None, 0:2], gt[None, :, 0:2])                 # math_utils.py:29-37
+    br = np.minimum(corners[:, None, 2:4], gt[None, :, 2:4])
+    ok = np.all(tl < br, axis=2)
+    inter = ok * np.prod(br - tl, axis=2)
+    a1 = np.prod(corners[:, 2:4] - corners[:, 0:2], axis=1)
+    a2 = np.prod(gt[:, 2:4] - gt[:, 0:2], axis=1)
+    ious = inter / (a1[:, None] + a2[None, :] - inter + 1e-7)
+    ious[anchor_valid_map.reshape(-1) == 0, :] = -1.0                        # :204
+    best = ious.max(axis=1)
+    best_m = ious.argmax(axis=1)
+    gt_best = ious.max(axis=0)
+    top_anchor = np.where(ious == gt_best)[0]                                # :218
+    label = np.full(n, -1)
+    label[best < background_iou_threshold] = 0
+    label[best >= object_iou_threshold] = 1
+    label[top_anchor] = 1
+    enable = (label >= 0).astype(np.float32)
+    label[label < 0] = 0
+    centers = 0.5 * (gt[:, 0:2] + gt[:, 2:4])
+    sides = gt[:, 2:4] - gt[:, 0:2]
+    targets = np.empty((n, 4))
+    targets[:, 0:2] = (centers[best_m] - am[:, 0:2]) / am[:, 2:4]
+    targets[:, 2:4] = np.log(sides[best_m] / am[:, 2:4])
+    rpn_map = np.zeros((height, width, k, 6))
+    rpn_map[..., 0] = anchor_valid_map * enable.reshape(height, width, k)
+    rpn_map[..., 1] = label.reshape(height, width, k)
+    rpn_map[..., 2:6] = targets.reshape(height, width, k, 4)
+    coords = np.stack(np.meshgrid(np.arange(height), np.arange(width), np.arange(k), indexing="ij"), axis=-1)
+    obj = coords[(rpn_map[..., 1] > 0) & (rpn_map[..., 0] > 0)]
+    bg = coords[(rpn_map[..., 1] == 0) & (rpn_map[..., 0] > 0)]
+    return rpn_map.astype(np.float32), obj, bg
+
+
 # ------------------------------------------------------------------------------------------------
 # torchvision.ops restated (third-party; see module docstring)
 # ------------------------------------------------------------------------------------------------

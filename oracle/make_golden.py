@@ -199,6 +199,31 @@ def golden_small_ops(ref):
             out["anchors_%s_map" % tag] = am
             out["anchors_%s_valid" % tag] = vm
 
+    # RPN ground-truth labelling (anchors.py:137-262): SURVEY's known answer + seeded box sets
+    Box_ = ref.training_sample.Box
+    gt_sets = {"known": np.array([[100, 200, 400, 700], [50, 50, 300, 180]], dtype=np.float32)}
+    rng = np.random.RandomState(21)
+    for name, m in (("one", 1), ("five", 5), ("many", 17)):
+        y1 = rng.uniform(0, 500, m); x1 = rng.uniform(0, 850, m)
+        gt_sets[name] = np.stack([y1, x1, y1 + rng.uniform(20, 99, m) * rng.choice([1, 4], m),
+                                  x1 + rng.uniform(20, 149, m) * rng.choice([1, 4], m)], axis=1).astype(np.float32)
+    am, vm = ref.anchors.generate_anchor_maps((3, 600, 1000), (512, 37, 62), 16)
+    for name, gtc in gt_sets.items():
+        rmap, obj, bg = ref.anchors.generate_rpn_map(am, vm, [Box_(1, "x", c) for c in gtc])
+        omap, oobj, obg = O.generate_rpn_map(am, vm, gtc)
+        assert_equal("rpn_map[%s]" % name, omap, rmap)
+        assert_equal("rpn_obj[%s]" % name, oobj, obj)
+        assert_equal("rpn_bg[%s]" % name, obg, bg)
+        out["rpn_gt_%s" % name] = gtc
+        out["rpn_obj_%s" % name] = obj.astype(np.int32)
+        out["rpn_nbg_%s" % name] = np.int64(len(bg))
+        out["rpn_bg_head_%s" % name] = bg[:64].astype(np.int32)
+        out["rpn_map_sha_%s" % name] = np.array(sha(rmap))
+        trainable = rmap[..., 0] > 0
+        out["rpn_targets_obj_%s" % name] = rmap[(rmap[..., 1] > 0) & trainable][:, 2:6]
+    assert len(out["rpn_obj_known"]) == 10 and int(out["rpn_nbg_known"]) == 6847          # SURVEY 8(f2) probe
+    assert out["rpn_obj_known"][0].tolist() == [9, 7, 2]
+
     # numpy float64 decode (math_utils.py:65-97) on seeded inputs
     rng = np.random.RandomState(5)
     anchors = np.abs(rng.randn(64, 4)) * 100 + 20

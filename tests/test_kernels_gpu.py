@@ -377,3 +377,34 @@ def test_detections_vs_oracle(n, thr, seed):
             # boxes: float64 arithmetic identical except exp() ulp -> 1e-9 px
             assert np.abs(got[c - 1, :k, :4] - ref[c][:, :4]).max() <= 1e-9
     print("detections: %d rows over 20 classes (thr %.3g)" % (total, thr))
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["known", "one", "five", "many"])
+def test_rpn_targets_vs_oracle_and_reference(golden_dir, name):
+    """anchor <-> GT IoU matching (anchors.py:137-262): labels and anchor lists bit-exact, float32 targets to 1e-6."""
+    from fasterrcnn_amd.datasets.training_sample import Box
+    from fasterrcnn_amd.models import anchors as A
+    g = np.load(os.path.join(golden_dir, "small_ops.npz"))
+    gt = g["rpn_gt_%s" % name]
+    am, vm = O.generate_anchor_maps((3, 600, 1000), (512, 37, 62), 16)
+    rmap, obj, bg = A.generate_rpn_map(am, vm, [Box(1, "x", c) for c in gt])
+    omap, oobj, obg = O.generate_rpn_map(am, vm, gt)
+    assert rmap.shape == (37, 62, 9, 6) and rmap.dtype == np.float32
+    assert np.array_equal(rmap[..., 0:2], omap[..., 0:2])                       # trainable / object flags: exact
+    assert np.array_equal(obj, oobj) and np.array_equal(bg, obg)                # (y,x,k) lists in the same order
+    assert np.array_equal(obj.astype(np.int32), g["rpn_obj_%s" % name]) and len(bg) == int(g["rpn_nbg_%s" % name])
+    assert np.array_equal(rmap[..., 2:4], omap[..., 2:4])                       # (gt_c - a_c)/a: float32 IEEE ops
+    assert np.abs(rmap[..., 4:6] - omap[..., 4:6]).max() <= 1e-6                # logf: a few ulp
+
+
+def test_rpn_targets_ragged_map_and_errors():
+    from fasterrcnn_amd.datasets.training_sample import Box
+    from fasterrcnn_amd.models import anchors as A
+    am, vm = O.generate_anchor_maps((3, 333, 517), (512, 20, 32), 16)
+    gt = np.array([[10, 20, 300, 400], [100, 100, 180, 260], [0, 0, 332, 516]], dtype=np.float32)
+    rmap, obj, bg = A.generate_rpn_map(am, vm, [Box(1, "x", c) for c in gt])
+    omap, oobj, obg = O.generate_rpn_map(am, vm, gt)
+    assert np.array_equal(rmap[..., 0:4], omap[..., 0:4]) and np.array_equal(obj, oobj) and np.array_equal(bg, obg)
+    with pytest.raises(ValueError):
+        A.generate_rpn_map(am, vm, [])

@@ -156,3 +156,15 @@ def test_oracle_reproduces_reference_resnet(golden_dir, name, arch):
     det = O.detections(props.numpy(), classes.numpy(), deltas.numpy(), int(g["height"]), int(g["width"]),
                        float(g["score_threshold"]))
     check_against_golden(g, props, classes, deltas, detail, det)
+
+
+@pytest.mark.parametrize("name", ["known", "one", "five", "many"])
+def test_rpn_ground_truth_map_matches_reference(small_ops, name):
+    am, vm = O.generate_anchor_maps((3, 600, 1000), (512, 37, 62), 16)
+    rmap, obj, bg = O.generate_rpn_map(am, vm, small_ops["rpn_gt_%s" % name])
+    assert sha(rmap) == str(small_ops["rpn_map_sha_%s" % name])
+    assert np.array_equal(obj.astype(np.int32), small_ops["rpn_obj_%s" % name])
+    assert len(bg) == int(small_ops["rpn_nbg_%s" % name])
+    assert np.array_equal(bg[:64].astype(np.int32), small_ops["rpn_bg_head_%s" % name])
+    if name == "known":        # probe values measured on the reference
+        assert len(obj) == 10 and len(bg) == 6847 and obj[0].tolist() == [9, 7, 2]
