@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=3, help="images timed on the host CPU (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-images", type=int, default=10)
+    ap.add_argument("--math", type=str, default="f32", choices=["f32", "f32x6"],
+                    help="3x3 conv arithmetic: exact f32 MFMA (default) or exactly split bf16x3 operands (six bf16 MFMAs per product)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the informational f32x6 throughput leg")
     ap.add_argument("--backbone", type=str, default="vgg16", choices=["vgg16", "resnet50", "resnet101", "resnet152"],
                     help="vgg16 is the BASELINE.json metric; the ResNets are informational (configs[2])")
     args = ap.parse_args()
@@ -140,6 +143,8 @@ def main():
         model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
     model.load_state_dict(sd, strict=True)
     model = model.cuda(dev).eval()
+    if args.math != "f32":
+        model.math_mode = args.math
     make_image = synthetic.image_rgb if is_resnet else synthetic.image
 
     # synthetic image pool, resident in HBM before timing; per-image seed = global index
@@ -173,6 +178,28 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     value = n_gpus * args.steps / elapsed if world > 1 or args.gpus == 1 else args.steps / elapsed
+
+    # ---- informational: the same workload in the f32x6 math mode (not the headline value) -----------
+    secondary = None
+    if not is_resnet and args.math == "f32" and not args.no_secondary:
+        model.math_mode = "f32x6"
+        run(max(args.warmup, nslots))
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        ts = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - ts
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        secondary = {"math": "f32x6 (operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, f32 accumulate)",
+                     "value": round(n_gpus * args.steps / dt, 3), "unit": "images/sec"}
+        model.math_mode = "f32"
 
     # ---- mAP@0.5 leg (outside the timed region): labelled subset, merged across ranks -------------
     records = ImageRecords()
@@ -237,6 +264,7 @@ def main():
                        "images_in_flight_per_gpu": nslots, "parallelism": "image-parallel x%d" % n_gpus,
                        "flops_per_image": flops_img},
             "tflops_per_gpu": round(value / n_gpus * flops_img / 1e12, 2),
+            "math": args.math, "secondary_f32x6": secondary,
             "map_at_0.5": mean_ap, "map_images": int(args.map_images * world),
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfrcnn_hip.so")
+LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
@@ -31,6 +31,7 @@ SYMBOLS = (
     "frcnn_ctx_timing_read",
     "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv7x7_s2_c3",
     "frcnn_maxpool3x3_s2_nhwc", "frcnn_spatial_mean_nhwc", "frcnn_resnet_forward", "frcnn_rpn_targets",
+    "frcnn_pack_conv3x3_x6", "frcnn_conv3x3_nhwc_x6",
 )
 
 
@@ -72,7 +73,12 @@ class ResNetWeights(C.Structure):
 
 class ForwardParams(C.Structure):
     _fields_ = [("pre_nms", C.c_int32), ("post_nms", C.c_int32), ("rpn_nms_threshold", C.c_float),
-                ("min_side", C.c_float), ("allow_edge_proposals", C.c_int32)]
+                ("min_side", C.c_float), ("allow_edge_proposals", C.c_int32), ("math_mode", C.c_int32)]
+
+
+MATH_F32 = 0      # exact f32 MFMA
+MATH_F32X6 = 1    # bf16x3 split operands, six bf16 MFMAs per product, f32 accumulate
+MATH_MODES = {"f32": MATH_F32, "f32x6": MATH_F32X6}
 
 
 _lib = None
@@ -93,6 +99,8 @@ _SIGNATURES = {
     "frcnn_conv3x3_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "frcnn_conv3x3_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_maxpool2x2_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "frcnn_pack_conv3x3_x6": (C.c_int, [_vp, _vp, _i, _i, _vp]),
+    "frcnn_conv3x3_nhwc_x6": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_linear_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "frcnn_linear": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_softmax_rows": (C.c_int, [_vp, _i, _vp, _i, _i, _vp]),

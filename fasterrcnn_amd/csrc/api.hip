@@ -174,6 +174,19 @@ int frcnn_conv3x3_nhwc(const float* d_x, const float* d_wp, const float* d_bias,
     return launch_conv3x3_nhwc(d_x, d_wp, d_bias, d_y, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
 }
 
+int frcnn_pack_conv3x3_x6(const float* d_w, void* d_wq, int cout, int cin, void* stream)
+{
+    if (!d_w || !d_wq) return FRCNN_EINVAL;
+    return launch_pack_conv3x3_x6(d_w, d_wq, cout, cin, as_stream(stream));
+}
+
+int frcnn_conv3x3_nhwc_x6(const float* d_x, const void* d_wq, const float* d_bias, float* d_y, int H, int W,
+                          int cin, int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_x || !d_wq || !d_bias || !d_y) return FRCNN_EINVAL;
+    return launch_conv3x3_x6(d_x, d_wq, d_bias, d_y, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
+}
+
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream)
 {
     if (!d_x || !d_y) return FRCNN_EINVAL;
@@ -427,29 +440,36 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     hipStream_t s = as_stream(stream);
     const unsigned R = FRCNN_RELU, RP = FRCNN_RELU | FRCNN_POOL2;
     int rc;
+    if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32X6) return FRCNN_EINVAL;
+    const bool x6 = p->math_mode == FRCNN_MATH_F32X6;
+    auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
+                     unsigned fl) -> int {
+        return x6 ? launch_conv3x3_x6(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s)
+                  : launch_conv3x3_nhwc(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s);
+    };
 #define STEP(cls, call) do { Scope _sc(c, cls, s); rc = (call); } while (0); if (rc) return rc
 
     // stage 1: feature extractor (models/vgg16.py:76-96)
     float *A = c->act_a, *B = c->act_b;
     int h = H, wd = W;
     STEP(1, launch_conv3x3_c3(d_image, w->conv_w[0], w->conv_b[0], A, h, wd, 64, R, s));
-    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[1], w->conv_b[1], B, h, wd, 64, 64, RP, c->conv_ws, c->conv_ws_bytes, s));   h /= 2; wd /= 2;
-    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[2], w->conv_b[2], A, h, wd, 64, 128, R, c->conv_ws, c->conv_ws_bytes, s));
-    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[3], w->conv_b[3], B, h, wd, 128, 128, RP, c->conv_ws, c->conv_ws_bytes, s)); h /= 2; wd /= 2;
-    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[4], w->conv_b[4], A, h, wd, 128, 256, R, c->conv_ws, c->conv_ws_bytes, s));
-    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[5], w->conv_b[5], B, h, wd, 256, 256, R, c->conv_ws, c->conv_ws_bytes, s));
-    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[6], w->conv_b[6], A, h, wd, 256, 256, RP, c->conv_ws, c->conv_ws_bytes, s)); h /= 2; wd /= 2;
-    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[7], w->conv_b[7], B, h, wd, 256, 512, R, c->conv_ws, c->conv_ws_bytes, s));
-    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[8], w->conv_b[8], A, h, wd, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
-    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[9], w->conv_b[9], B, h, wd, 512, 512, RP, c->conv_ws, c->conv_ws_bytes, s)); h /= 2; wd /= 2;
-    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[10], w->conv_b[10], A, h, wd, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
-    STEP(0, launch_conv3x3_nhwc(A, w->conv_w[11], w->conv_b[11], B, h, wd, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
-    STEP(0, launch_conv3x3_nhwc(B, w->conv_w[12], w->conv_b[12], c->fm, h, wd, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
+    STEP(0, conv3(A, w->conv_w[1], w->conv_b[1], B, h, wd, 64, 64, RP));   h /= 2; wd /= 2;
+    STEP(0, conv3(B, w->conv_w[2], w->conv_b[2], A, h, wd, 64, 128, R));
+    STEP(0, conv3(A, w->conv_w[3], w->conv_b[3], B, h, wd, 128, 128, RP)); h /= 2; wd /= 2;
+    STEP(0, conv3(B, w->conv_w[4], w->conv_b[4], A, h, wd, 128, 256, R));
+    STEP(0, conv3(A, w->conv_w[5], w->conv_b[5], B, h, wd, 256, 256, R));
+    STEP(0, conv3(B, w->conv_w[6], w->conv_b[6], A, h, wd, 256, 256, RP)); h /= 2; wd /= 2;
+    STEP(0, conv3(A, w->conv_w[7], w->conv_b[7], B, h, wd, 256, 512, R));
+    STEP(0, conv3(B, w->conv_w[8], w->conv_b[8], A, h, wd, 512, 512, R));
+    STEP(0, conv3(A, w->conv_w[9], w->conv_b[9], B, h, wd, 512, 512, RP)); h /= 2; wd /= 2;
+    STEP(0, conv3(B, w->conv_w[10], w->conv_b[10], A, h, wd, 512, 512, R));
+    STEP(0, conv3(A, w->conv_w[11], w->conv_b[11], B, h, wd, 512, 512, R));
+    STEP(0, conv3(B, w->conv_w[12], w->conv_b[12], c->fm, h, wd, 512, 512, R));
     const int fh = h, fw = wd;
     c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms; c->last_c = 512; c->last_vec = 4096;
 
     // stage 2: RPN (models/rpn.py:88-153)
-    STEP(0, launch_conv3x3_nhwc(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, 512, 512, R, c->conv_ws, c->conv_ws_bytes, s));
+    STEP(0, conv3(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, 512, 512, R));
     STEP(2, launch_linear(c->rpn_trunk, 512, w->rpn_head_w, w->rpn_head_b, c->rpn_head, 128, fh * fw, 45, 512,
                           0u, c->lin_ws, c->lin_ws_bytes, s));
     const float* amap = d_anchor_map;
@@ -535,6 +555,7 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     if (H < 32 || W < 32 || H > c->max_h || W > c->max_w) return FRCNN_EINVAL;
     if (p->post_nms < 1 || p->post_nms > c->max_rois || p->pre_nms < 1 || p->pre_nms > c->pre_cap) return FRCNN_EINVAL;
     if (w->num_classes < 2 || w->num_classes > 26) return FRCNN_EUNSUPPORTED;
+    if (p->math_mode != FRCNN_MATH_F32) return FRCNN_EUNSUPPORTED;     // the ResNet path is exact-f32 only for now
     int nb = 0;
     for (int i = 0; i < 4; ++i) { if (w->n_blocks[i] < 1) return FRCNN_EINVAL; nb += w->n_blocks[i]; }
     if (nb > FRCNN_RESNET_MAX_BLOCKS) return FRCNN_EINVAL;

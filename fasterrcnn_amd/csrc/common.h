@@ -51,6 +51,10 @@ size_t conv3x3_workspace_bytes(int H, int W, int cin, int cout);
 int launch_conv3x3_nhwc(const float* x, const float* wp, const float* b, float* y, int H, int W,
                         int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_maxpool2x2(const float* x, float* y, int H, int W, int c, hipStream_t s);
+// conv_x6.hip: same layer on the bf16 pipe with exactly split operands ("f32x6" math mode)
+int launch_pack_conv3x3_x6(const float* w, void* wq, int cout, int cin, hipStream_t s);
+int launch_conv3x3_x6(const float* x, const void* wq, const float* b, float* y, int H, int W, int cin, int cout,
+                      unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 
 // conv_gather.hip (ResNet path)
 size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R, int stride, int pad);

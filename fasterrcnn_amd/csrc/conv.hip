@@ -415,6 +415,18 @@ static int choose_ksplit(int H, int W, int cin, int cout)
     return k;
 }
 
+int conv3x3_choose_ksplit(int H, int W, int cin, int cout) { return choose_ksplit(H, W, cin, cout); }
+
+int launch_conv_splitk_finish(const float* ws, int ksplit, const float* b, float* y, int H, int W, int cout, int relu,
+                              int pool, hipStream_t s)
+{
+    const size_t total = (size_t)(pool ? H / 2 : H) * (pool ? W / 2 : W) * (cout / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, ws, ksplit, b, y, H, W, cout, relu, pool);
+    return check_launch();
+}
+
 size_t conv3x3_workspace_bytes(int H, int W, int cin, int cout)
 {
     if (cin % 16 != 0 || cout % 64 != 0 || H < 1 || W < 1) return 0;
@@ -438,12 +450,7 @@ int launch_conv3x3_nhwc(const float* x, const float* wp, const float* b, float* 
         rc = (cout % 128 != 0) ? launch_cfg<4, 1, false>(x, wp, b, y, H, W, cin, cout, relu, ksplit, wsf, s)
                                : launch_cfg<2, 2, false>(x, wp, b, y, H, W, cin, cout, relu, ksplit, wsf, s);
         if (rc) return rc;
-        const size_t total = (size_t)(pool ? H / 2 : H) * (pool ? W / 2 : W) * (cout / 4);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, (const float*)wsf, ksplit, b, y,
-                           H, W, cout, relu, pool ? 1 : 0);
-        return check_launch();
+        return launch_conv_splitk_finish(wsf, ksplit, b, y, H, W, cout, relu, pool ? 1 : 0, s);
     }
     if (cout % 128 != 0) {
         return pool ? launch_cfg<4, 1, true>(x, wp, b, y, H, W, cin, cout, relu, 1, nullptr, s)

@@ -97,10 +97,28 @@ class FasterRCNNModel(nn.Module):
         self.rpn_min_side = 16.0
         self.detector_nms_threshold = 0.3
 
+        # arithmetic of the 3x3 convolutions: "f32" = exact f32 MFMA, "f32x6" = exactly split bf16x3
+        # operands, six bf16 MFMAs per product with f32 accumulation (same accuracy class)
+        self._math_mode = "f32"
+
         self._slots = {}
         self._wstruct = None
         self._wstruct_key = None
         self._wkeep = None
+
+    @property
+    def math_mode(self):
+        return self._math_mode
+
+    @math_mode.setter
+    def math_mode(self, mode):
+        if mode not in nv.MATH_MODES:
+            raise ValueError("math_mode must be one of %s" % sorted(nv.MATH_MODES))
+        if mode != "f32" and self._is_resnet:
+            raise NotImplementedError("the ResNet path runs in the exact-f32 math mode only")
+        self._math_mode = mode
+        self._stage1_feature_extractor.math_mode = mode
+        self._stage2_region_proposal_network.math_mode = mode
 
     # ------------------------------------------------------------------------------------------
     def _device(self):
@@ -188,7 +206,7 @@ class FasterRCNNModel(nn.Module):
         weights = self._weights()
         params = nv.ForwardParams(int(self.max_proposals_pre_nms), int(self.max_proposals_post_nms),
                                   float(self.rpn_nms_threshold), float(self.rpn_min_side),
-                                  1 if self._allow_edge_proposals else 0)
+                                  1 if self._allow_edge_proposals else 0, nv.MATH_MODES[self._math_mode])
         lib = nv.lib()
         with t.cuda.device(device):
             stream = slot.use_stream()

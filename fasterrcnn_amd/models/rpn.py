@@ -56,13 +56,14 @@ class RegionProposalNetwork(nn.Module):
             m.bias.data.zero_()
         self._packed_key = None
         self._packed = None
+        self.math_mode = "f32"
 
     def packed(self):
         params = [p for m in (self._rpn_conv1, self._rpn_class, self._rpn_boxes) for p in (m.weight, m.bias)]
-        key = rt.param_key(params)
+        key = (self.math_mode,) + rt.param_key(params)
         if key != self._packed_key:
             head_w, head_b = pack_stack_rows(self._rpn_class, self._rpn_boxes)
-            self._packed = (pack_conv3x3(self._rpn_conv1), rt.as_f32_cuda(self._rpn_conv1.bias.detach(), "bias"),
+            self._packed = (pack_conv3x3(self._rpn_conv1, self.math_mode), rt.as_f32_cuda(self._rpn_conv1.bias.detach(), "bias"),
                             head_w, head_b)
             self._packed_key = key
         return self._packed

@@ -21,11 +21,19 @@ _LAYERS = [  # (name, cin, cout, pool_after)
 ]
 
 
-def pack_conv3x3(conv):
-    """OIHW weight of a 3x3 nn.Conv2d -> tap-major [9][cout][cin] (or [27][cout] when cin == 3)."""
+def pack_conv3x3(conv, math_mode="f32"):
+    """
+    OIHW weight of a 3x3 nn.Conv2d -> tap-major [9][cout][cin] (or [27][cout] when cin == 3); in the
+    "f32x6" math mode -> the exactly split [9][cout][cin/16][hi,mid,lo][16] bf16 layout.
+    """
     w = conv.weight.detach()
     cout, cin = int(w.shape[0]), int(w.shape[1])
     w = rt.as_f32_cuda(w, "conv weight")
+    if math_mode == "f32x6" and cin != 3:
+        out = t.empty((9 * cout * cin * 3,), dtype=t.int16, device=w.device)
+        with t.cuda.device(w.device):
+            nv.check(nv.lib().frcnn_pack_conv3x3_x6(nv.ptr(w), nv.ptr(out), cout, cin, nv.stream_ptr()), "frcnn_pack_conv3x3_x6")
+        return out
     out = t.empty((27, cout) if cin == 3 else (9, cout, cin), dtype=t.float32, device=w.device)
     with t.cuda.device(w.device):
         if cin == 3:
@@ -36,7 +44,8 @@ def pack_conv3x3(conv):
 
 
 def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False):
-    """One 3x3 'same' convolution (+ReLU, + fused 2x2 max-pool) on an NHWC CUDA tensor via frcnn_conv3x3_nhwc."""
+    """One 3x3 'same' convolution (+ReLU, + fused 2x2 max-pool) on an NHWC CUDA tensor via frcnn_conv3x3_nhwc
+    (or frcnn_conv3x3_nhwc_x6 when `wp` is a split int16 weight buffer)."""
     h, w = int(x_hwc.shape[0]), int(x_hwc.shape[1])
     oh, ow = (h // 2, w // 2) if pool else (h, w)
     y = t.empty((oh, ow, cout), dtype=t.float32, device=x_hwc.device)
@@ -45,8 +54,9 @@ def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False):
     ws = t.empty((max(ws_bytes, 4) // 4,), dtype=t.float32, device=x_hwc.device)
     flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
     with t.cuda.device(x_hwc.device):
-        nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
-                                        nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc")
+        fn = lib.frcnn_conv3x3_nhwc_x6 if wp.dtype == t.int16 else lib.frcnn_conv3x3_nhwc
+        nv.check(fn(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
+                    nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc")
     return y
 
 
@@ -61,6 +71,7 @@ class FeatureExtractor(nn.Module):
             getattr(self, name).bias.requires_grad = False
         self._packed_key = None
         self._packed = None
+        self.math_mode = "f32"
 
     def convs(self):
         return [getattr(self, name) for name, _, _, _ in _LAYERS]
@@ -68,9 +79,9 @@ class FeatureExtractor(nn.Module):
     def packed(self):
         """[(packed_weight, bias)] x 13 on the parameters' device, rebuilt when parameters change."""
         params = [p for c in self.convs() for p in (c.weight, c.bias)]
-        key = rt.param_key(params)
+        key = (self.math_mode,) + rt.param_key(params)
         if key != self._packed_key:
-            self._packed = [(pack_conv3x3(c), rt.as_f32_cuda(c.bias.detach(), "conv bias")) for c in self.convs()]
+            self._packed = [(pack_conv3x3(c, self.math_mode), rt.as_f32_cuda(c.bias.detach(), "conv bias")) for c in self.convs()]
             self._packed_key = key
         return self._packed
 

@@ -109,6 +109,16 @@ size_t frcnn_conv3x3_workspace_bytes(int H, int W, int cin, int cout);
 int frcnn_conv3x3_nhwc(const float* d_x, const float* d_w_packed, const float* d_bias,
                        float* d_y, int H, int W, int cin, int cout, unsigned flags,
                        void* d_ws, size_t ws_bytes, void* stream);
+/* The same layer in the "f32x6" math mode: every fp32 operand is split exactly into three bf16
+ * terms and the product is formed from the six largest bf16 x bf16 partial products on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms <= 2^-24 relative: fp32-rounding
+ * class), 2.67x the matrix-pipe rate of the exact-f32 kernel.  d_w_split from
+ * frcnn_pack_conv3x3_x6 (54*cout*cin bytes: [tap][cout][cin/16][hi,mid,lo][16] bf16); inputs,
+ * outputs, bias and scratch are the same fp32 tensors as for frcnn_conv3x3_nhwc. */
+int frcnn_pack_conv3x3_x6(const float* d_w_oihw, void* d_w_split, int cout, int cin, void* stream);
+int frcnn_conv3x3_nhwc_x6(const float* d_x, const void* d_w_split, const float* d_bias,
+                          float* d_y, int H, int W, int cin, int cout, unsigned flags,
+                          void* d_ws, size_t ws_bytes, void* stream);
 /* Stand-alone 2x2/stride-2 floor max-pool on NHWC (vgg16.py:78,82,87,92), c % 4 == 0. */
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream);
 
@@ -251,7 +261,12 @@ typedef struct frcnn_forward_params {
     float   rpn_nms_threshold;  /* 0.7   (models/rpn.py:150)         */
     float   min_side;           /* 16    (models/rpn.py:142)         */
     int32_t allow_edge_proposals; /* 1   (models/faster_rcnn.py:36)  */
+    int32_t math_mode;          /* FRCNN_MATH_F32 (exact f32 MFMA) or FRCNN_MATH_F32X6; selects how the
+                                   3x3 conv weight pointers of the weights struct are interpreted
+                                   (frcnn_pack_conv3x3 vs frcnn_pack_conv3x3_x6) */
 } frcnn_forward_params;
+#define FRCNN_MATH_F32   0
+#define FRCNN_MATH_F32X6 1
 
 /* d_image: float32 NCHW [3][H][W] (preprocessed as models/vgg16.py:146 prescribes).
  * d_anchor_map / d_valid_map: optional caller-provided maps (faster_rcnn.py:113-115); NULL =

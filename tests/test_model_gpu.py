@@ -289,3 +289,40 @@ def test_state_dict_roundtrip_repacks(gpu_model, sd_cpu):
     gpu_model.load_state_dict(sd_cpu, strict=True)
     after = gpu_model(image_data=img)
     assert torch.equal(before[2], after[2])
+
+
+# ---------------------------------------------------------------------------------------------
+# "f32x6" math mode (bf16x3-split operands, six bf16 MFMAs per product): the SAME end-to-end
+# thresholds as the exact-f32 mode
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,allow_edge", CASES[:2])
+def test_f32x6_math_mode_end_to_end(gpu_model, golden_dir, oracle_runs, tag, allow_edge):
+    g, img = load_case(golden_dir, tag)
+    assert gpu_model.math_mode == "f32"
+    gpu_model.math_mode = "f32x6"
+    try:
+        fm = gpu_model._stage1_feature_extractor(image_data=img.cuda()).cpu()
+        ref = oracle_runs[tag][3]["feature_map"]
+        err = float((fm - ref).abs().max()) / float(ref.abs().max())
+        print("f32x6 feature map %s: max rel err %.3g" % (tag, err))
+        assert err <= 2e-5
+        props, classes, deltas = gpu_model(image_data=img.cuda())
+        j, e = match_rows(props.cpu().numpy(), g["proposals"])
+        ok = e <= 1e-3
+        print("f32x6 forward %s: %.1f%% of the reference's proposals within 1e-3 px" % (tag, 100 * ok.mean()))
+        assert props.shape[0] == g["proposals"].shape[0] and ok.mean() >= 0.95
+        assert np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max() <= 1e-4
+        det = gpu_model.predict(image_data=img.cuda(), score_threshold=float(g["score_threshold"]))
+        refd = g["detections"]
+        n_ok = 0
+        for c in range(1, 21):
+            r = refd[refd[:, 0] == c][:, 1:]
+            if len(r) and len(det[c]):
+                jj, ee = match_rows(det[c], r)
+                n_ok += int(((ee <= 1e-3) & (np.abs(det[c][jj, 4] - r[:, 4]) <= 1e-4)).sum())
+        print("f32x6 predict %s: %d/%d reference detections reproduced" % (tag, n_ok, len(refd)))
+        assert n_ok >= 0.95 * len(refd)
+    finally:
+        gpu_model.math_mode = "f32"
+    with pytest.raises(ValueError):
+        gpu_model.math_mode = "bf16"

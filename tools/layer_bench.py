@@ -41,6 +41,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--x6", action="store_true", help="time the f32x6 (bf16x3 split) conv kernels")
     args = ap.parse_args()
     nv.require_gpu()
     lib = nv.lib()
@@ -53,16 +54,24 @@ def main():
             continue
         x = torch.randn((h, w, cin), device=dev)
         wp = torch.randn((9, cout, cin), device=dev) * 0.02
+        if args.x6:
+            w_oihw = torch.randn((cout, cin, 3, 3), device=dev) * 0.02
+            wq = torch.empty((9 * cout * cin * 3,), dtype=torch.int16, device=dev)
+            nv.check(lib.frcnn_pack_conv3x3_x6(nv.ptr(w_oihw), nv.ptr(wq), cout, cin, s), "pack_x6")
         b = torch.zeros((cout,), device=dev)
         oh, ow = (h // 2, w // 2) if pool else (h, w)
         y = torch.empty((oh, ow, cout), device=dev)
-        wsb = int(lib.frcnn_conv3x3_workspace_bytes(h, w, cin, cout))
+        wsb = (160 << 20) if args.x6 else int(lib.frcnn_conv3x3_workspace_bytes(h, w, cin, cout))
         ws = torch.empty((max(wsb, 4) // 4,), device=dev)
         flags = nv.RELU | (nv.POOL2 if pool else 0)
 
         def run():
-            nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
-                                            nv.ptr(ws), wsb, s), "conv")
+            if args.x6:
+                nv.check(lib.frcnn_conv3x3_nhwc_x6(nv.ptr(x), nv.ptr(wq), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
+                                                   nv.ptr(ws), wsb, s), "conv_x6")
+            else:
+                nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
+                                                nv.ptr(ws), wsb, s), "conv")
         us = timeit(run, args.reps)
         fl = 2.0 * 9 * cin * cout * h * w
         k = mult.get(name, 1)
