@@ -31,7 +31,7 @@ SYMBOLS = (
     "frcnn_ctx_timing_read",
     "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv7x7_s2_c3",
     "frcnn_maxpool3x3_s2_nhwc", "frcnn_spatial_mean_nhwc", "frcnn_resnet_forward", "frcnn_rpn_targets",
-    "frcnn_pack_conv3x3_x6", "frcnn_conv3x3_nhwc_x6",
+    "frcnn_pack_conv3x3_x6", "frcnn_conv3x3_nhwc_x6", "frcnn_preprocess_workspace_bytes", "frcnn_preprocess",
 )
 
 
@@ -116,6 +116,9 @@ _SIGNATURES = {
                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "frcnn_ctx_tensor": (C.c_int, [_vp, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "frcnn_rpn_targets": (C.c_int, [_vp, _vp, _i, _vp, _i, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "frcnn_preprocess_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "frcnn_preprocess": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _f, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp,
+                                   _vp, _sz, _vp]),
     "frcnn_fold_bn_pack": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     "frcnn_conv_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "frcnn_conv_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),

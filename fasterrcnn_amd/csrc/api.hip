@@ -120,6 +120,17 @@ int frcnn_anchors(int image_h, int image_w, int fh, int fw, int feature_pixels,
     return launch_anchors(image_h, image_w, fh, fw, feature_pixels, d_anchor_map, d_valid_map, as_stream(stream));
 }
 
+size_t frcnn_preprocess_workspace_bytes(int H, int W, int out_h, int out_w) { return preprocess_workspace_bytes(H, W, out_h, out_w); }
+
+int frcnn_preprocess(const unsigned char* d_rgb, int H, int W, int out_h, int out_w, int bgr_order, int horizontal_flip,
+                     float scaling, const float* means, const float* stds, float* d_out, unsigned char* d_out_u8,
+                     void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_rgb || !d_out || !d_ws || !means || !stds) return FRCNN_EINVAL;
+    return launch_preprocess(d_rgb, H, W, out_h, out_w, bgr_order, horizontal_flip, scaling, means, stds, d_out, d_out_u8,
+                             d_ws, ws_bytes, as_stream(stream));
+}
+
 int frcnn_rpn_targets(const float* d_anchor_map, const float* d_valid_map, int n_anchors, const float* d_gt_boxes,
                       int n_gt, double object_thr, double background_thr, float* d_rpn_map, int32_t* d_object_idx,
                       int32_t* d_background_idx, int32_t* d_counts, void* d_ws, void* stream)

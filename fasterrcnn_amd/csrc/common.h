@@ -103,6 +103,11 @@ int launch_rpn_targets(const float* anchor_map, const float* valid_map, int A, c
                        double obj_thr, double bg_thr, float* rpn_map, int32_t* obj_idx, int32_t* bg_idx,
                        int32_t* counts, void* ws, hipStream_t s);
 
+size_t preprocess_workspace_bytes(int H, int W, int Ho, int Wo);
+int launch_preprocess(const unsigned char* rgb, int H, int W, int Ho, int Wo, int bgr, int flip, float scaling,
+                      const float* means, const float* stds, float* out, unsigned char* out_u8, void* ws,
+                      size_t ws_bytes, hipStream_t s);
+
 int launch_detections(const float* props, const float* classes, const float* deltas,
                       const int32_t* n_rois, int max_rois, int ncls, int image_h, int image_w,
                       float score_thr, float nms_thr, double* out, int32_t* out_cnt, hipStream_t s);

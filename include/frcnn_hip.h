@@ -58,6 +58,19 @@ int         frcnn_device_count(void);
 int frcnn_anchors(int image_h, int image_w, int fh, int fw, int feature_pixels,
                   float* d_anchor_map, float* d_valid_map, void* stream);
 
+/* Image preprocessing.  Replaces datasets/image.py:92-100 and :43-57: PIL
+ * `Image.resize((out_w, out_h), BILINEAR)` of the decoded 8-bit RGB image (optionally after
+ * FLIP_LEFT_RIGHT), reproduced bit for bit (22-bit fixed-point two-pass resampler), then channel
+ * order / scaling / (x - mean) / std in float32 into the CHW tensor the model consumes.
+ *   d_rgb    : uint8 [H][W][3] RGB (what imageio / PIL decode to)
+ *   means, stds: HOST float[3] in OUTPUT channel order (PreprocessingParams.means / .stds)
+ *   d_out    : float32 [3][out_h][out_w];  d_out_u8: optional uint8 [out_h][out_w][3] resized RGB
+ *   d_ws     : scratch of frcnn_preprocess_workspace_bytes(H, W, out_h, out_w) bytes */
+size_t frcnn_preprocess_workspace_bytes(int H, int W, int out_h, int out_w);
+int frcnn_preprocess(const unsigned char* d_rgb, int H, int W, int out_h, int out_w, int bgr_order,
+                     int horizontal_flip, float scaling, const float* means, const float* stds,
+                     float* d_out, unsigned char* d_out_u8, void* d_ws, size_t ws_bytes, void* stream);
+
 /* RPN ground-truth labelling (anchor <-> GT IoU matching).  Replaces models/anchors.py:137-262
  * generate_rpn_map: float64 IoU of every anchor with every ground-truth box (float32 corners
  * (y1,x1,y2,x2)), invalid anchors excluded; object if IoU >= object_thr or the anchor attains a

@@ -25,6 +25,68 @@ from torch.nn import functional as F
 
 
 # ------------------------------------------------------------------------------------------------
+# preprocessing  (datasets/image.py:34-101; PIL's 8-bit BILINEAR resampler restated)
+# ------------------------------------------------------------------------------------------------
+def _pil_coeffs(in_size, out_size):
+    """libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc for the bilinear (triangle) filter."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds, kk = [], []
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        ss = 1.0 / filterscale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [max(0.0, 1.0 - abs((x + xmin - center + 0.5) * ss)) for x in range(xmax)]
+        ww = sum(w[:0], 0.0)
+        for v in w:
+            ww += v
+        w = [(v / ww if ww != 0.0 else v) for v in w] + [0.0] * (ksize - xmax)
+        kk.append([int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22)) for v in w])
+        bounds.append((xmin, xmax))
+    return bounds, np.asarray(kk, dtype=np.int64)
+
+
+def pil_resize_bilinear(rgb, out_h, out_w):
+    """Image.resize((out_w, out_h), Image.BILINEAR) of a uint8 (H,W,3) image: horizontal pass, then vertical."""
+    src = np.asarray(rgb, dtype=np.int64)
+    h, w, _ = src.shape
+    bx, kx = _pil_coeffs(w, out_w)
+    tmp = np.empty((h, out_w, 3), dtype=np.int64)
+    for xx, (x0, n) in enumerate(bx):
+        acc = (src[:, x0:x0 + n, :] * kx[xx, :n][None, :, None]).sum(axis=1) + (1 << 21)
+        tmp[:, xx, :] = np.clip(acc >> 22, 0, 255)
+    by, ky = _pil_coeffs(h, out_h)
+    out = np.empty((out_h, out_w, 3), dtype=np.int64)
+    for yy, (y0, n) in enumerate(by):
+        acc = (tmp[y0:y0 + n, :, :] * ky[yy, :n][:, None, None]).sum(axis=0) + (1 << 21)
+        out[yy] = np.clip(acc >> 22, 0, 255)
+    return out.astype(np.uint8)
+
+
+def preprocess_image(rgb, bgr, scaling, means, stds, min_dimension_pixels=None, horizontal_flip=False):
+    """image.py:89-100 + :43-57 from the decoded uint8 RGB array to the float32 (3,h,w) tensor."""
+    rgb = np.asarray(rgb, dtype=np.uint8)
+    h0, w0 = rgb.shape[0], rgb.shape[1]
+    if horizontal_flip:
+        rgb = rgb[:, ::-1, :]
+    if min_dimension_pixels is not None:
+        sf = min_dimension_pixels / h0 if w0 > h0 else min_dimension_pixels / w0          # :34-41
+        rgb = pil_resize_bilinear(rgb, int(h0 * sf), int(w0 * sf))                       # :94-96
+    data = rgb.astype(np.float32)
+    if bgr:
+        data = data[:, :, ::-1]
+    data = data.copy()
+    for c in range(3):
+        data[:, :, c] *= scaling
+    for c in range(3):
+        data[:, :, c] = (data[:, :, c] - means[c]) / stds[c]
+    return data.transpose([2, 0, 1]).copy()
+
+
+# ------------------------------------------------------------------------------------------------
 # anchors  (models/anchors.py:25-135)
 # ------------------------------------------------------------------------------------------------
 def anchor_sizes():

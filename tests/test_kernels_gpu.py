@@ -442,3 +442,30 @@ def test_rpn_targets_ragged_map_and_errors():
     assert np.array_equal(rmap[..., 0:4], omap[..., 0:4]) and np.array_equal(obj, oobj) and np.array_equal(bg, obg)
     with pytest.raises(ValueError):
         A.generate_rpn_map(am, vm, [])
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("h,w,min_side,flip,bgr", [(375, 500, 600, False, True), (500, 375, 600, True, True),
+                                                   (1200, 1600, 600, False, False), (333, 517, None, False, True),
+                                                   (97, 211, 600, True, False)])
+def test_preprocess_vs_pil_and_oracle(h, w, min_side, flip, bgr):
+    """datasets/image.py:89-100 + :43-57: resized 8-bit pixels == PIL bit for bit, float tensor == oracle."""
+    from PIL import Image
+    from fasterrcnn_amd.datasets import image as I
+    rng = np.random.RandomState(h * 3 + w)
+    img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    params = (I.PreprocessingParams(I.ChannelOrder.BGR, 1.0, [103.939, 116.779, 123.680], [1, 1, 1]) if bgr else
+              I.PreprocessingParams(I.ChannelOrder.RGB, 1.0 / 255.0, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]))
+    out, sf, shape, resized = I.preprocess_image(img, params, min_side, flip, return_resized=True)
+    pil = Image.fromarray(img, mode="RGB")
+    if flip:
+        pil = pil.transpose(method=Image.FLIP_LEFT_RIGHT)
+    if min_side is not None:
+        f = I._compute_scale_factor(pil.width, pil.height, min_side)
+        pil = pil.resize((int(pil.width * f), int(pil.height * f)), resample=Image.BILINEAR)
+        assert sf == f
+    assert shape == (3, h, w)
+    assert np.array_equal(resized.cpu().numpy(), np.array(pil))                         # PIL itself: bit-exact
+    ref = O.preprocess_image(img, bgr, params.scaling, params.means, params.stds, min_side, flip)
+    assert tuple(out.shape) == ref.shape
+    assert np.array_equal(out.cpu().numpy(), ref)                                       # float32 sequence: exact

@@ -168,3 +168,28 @@ def test_rpn_ground_truth_map_matches_reference(small_ops, name):
     assert np.array_equal(bg[:64].astype(np.int32), small_ops["rpn_bg_head_%s" % name])
     if name == "known":        # probe values measured on the reference
         assert len(obj) == 10 and len(bg) == 6847 and obj[0].tolist() == [9, 7, 2]
+
+
+@pytest.mark.parametrize("h,w,oh,ow", [(375, 500, 600, 800), (500, 375, 800, 600), (1200, 1600, 600, 800),
+                                       (333, 517, 333, 517), (100, 37, 163, 60), (720, 1280, 600, 1066)])
+def test_pil_bilinear_resample_restatement_is_bit_exact(h, w, oh, ow):
+    """datasets/image.py:96 calls PIL's resize; PIL IS installed, so the restatement is pinned on the real thing."""
+    from PIL import Image
+    rng = np.random.RandomState(h + w)
+    img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    ref = np.array(Image.fromarray(img, mode="RGB").resize((ow, oh), resample=Image.BILINEAR))
+    assert np.array_equal(O.pil_resize_bilinear(img, oh, ow), ref)
+
+
+def test_preprocess_restatement_matches_reference_sequence():
+    """image.py:43-57 on PIL-resized pixels: float32 scale, mean/std, BGR flip, CHW."""
+    from PIL import Image
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 256, (375, 500, 3)).astype(np.uint8)
+    pil = Image.fromarray(img, mode="RGB").resize((800, 600), resample=Image.BILINEAR)
+    x = np.array(pil).astype(np.float32)[:, :, ::-1].copy()
+    for c, m in enumerate([103.939, 116.779, 123.680]):
+        x[:, :, c] = (x[:, :, c] * 1.0 - m) / 1
+    out = O.preprocess_image(img, True, 1.0, [103.939, 116.779, 123.680], [1, 1, 1], 600)
+    assert out.dtype == np.float32 and out.shape == (3, 600, 800)
+    assert np.array_equal(out, x.transpose(2, 0, 1))
