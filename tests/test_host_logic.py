@@ -130,3 +130,40 @@ def test_resnet_state_dict_keys_match_reference():
         resnet.ResNetBackbone("ResNet18")
     m101 = resnet.ResNetBackbone(resnet.Architecture.ResNet101)
     assert len(m101.feature_extractor._feature_extractor[6]) == 23
+
+
+def test_checkpoint_formats(tmp_path, cpu_model, sd_cpu):
+    from fasterrcnn_amd import state
+    # 1. the reference's own checkpoint format
+    path = str(tmp_path / "fasterrcnn.pth")
+    torch.save({"epoch": 3, "model_state_dict": sd_cpu}, path)
+    fresh = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+    assert state.load(fresh, path) == []
+    for k, v in fresh.state_dict().items():
+        assert torch.equal(v, sd_cpu[k]), k
+    state.save(fresh, path, epoch=4)
+    assert torch.load(path)["epoch"] == 4
+    with pytest.raises(KeyError):
+        bad = str(tmp_path / "bad.pth")
+        torch.save({"something": 1}, bad)
+        state.load(fresh, bad)
+    # 2. Caffe / torchvision-style VGG-16 file: conv blocks + fc1/fc2 land on the LIVE keys
+    names = {"features.%d" % n: k for n, k in zip((0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28),
+             ["_stage1_feature_extractor._block%d_conv%d" % (b, c) for b, n in ((1, 2), (2, 2), (3, 3), (4, 3), (5, 3)) for c in range(1, n + 1)])}
+    caffe = {}
+    for src, dst in names.items():
+        caffe[src + ".weight"], caffe[src + ".bias"] = sd_cpu[dst + ".weight"] * 2, sd_cpu[dst + ".bias"] + 1
+    p = "_stage3_detector_network._pool_to_feature_vector."
+    caffe["classifier.0.weight"], caffe["classifier.0.bias"] = sd_cpu[p + "_fc1.weight"] * 2, sd_cpu[p + "_fc1.bias"] + 1
+    caffe["classifier.3.weight"], caffe["classifier.3.bias"] = sd_cpu[p + "_fc2.weight"] * 2, sd_cpu[p + "_fc2.bias"] + 1
+    cpath = str(tmp_path / "vgg16_caffe.pth")
+    torch.save(caffe, cpath)
+    left = state.load(fresh, cpath)
+    assert sorted(left) == sorted(k for k in sd_cpu if "_rpn_" in k or "_classifier" in k or "_regressor" in k)
+    assert torch.equal(fresh.state_dict()[p + "_fc1.weight"], sd_cpu[p + "_fc1.weight"] * 2)
+    assert torch.equal(fresh.state_dict()["_stage1_feature_extractor._block3_conv2.bias"], sd_cpu["_stage1_feature_extractor._block3_conv2.bias"] + 1)
+    tracker = state.BestWeightsTracker(str(tmp_path / "best.pth"))
+    tracker.on_epoch_end(fresh, 1, 10.0)
+    tracker.on_epoch_end(fresh, 2, 5.0)
+    tracker.save_best_weights(fresh)
+    assert torch.load(str(tmp_path / "best.pth"))["epoch"] == 1
