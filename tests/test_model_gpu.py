@@ -326,3 +326,56 @@ def test_f32x6_math_mode_end_to_end(gpu_model, golden_dir, oracle_runs, tag, all
         gpu_model.math_mode = "f32"
     with pytest.raises(ValueError):
         gpu_model.math_mode = "bf16"
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases
+# ---------------------------------------------------------------------------------------------
+def test_zero_proposals_survive(gpu_model, sd_cpu):
+    """Every RPN box smaller than 16 px -> the size filter removes all candidates: forward returns empty
+    tensors and predict a dict of 20 empty (0,5) arrays (what the reference's tensor code yields for N = 0)."""
+    sd2 = {k: v.clone() for k, v in sd_cpu.items()}
+    sd2["_stage2_region_proposal_network._rpn_boxes.weight"].zero_()
+    bias = torch.zeros(36)
+    bias[2::4] = -6.0            # th = tw = -6 -> sizes anchor * e^-6 < 2 px
+    bias[3::4] = -6.0
+    sd2["_stage2_region_proposal_network._rpn_boxes.bias"] = bias
+    gpu_model.load_state_dict(sd2, strict=True)
+    try:
+        img = synthetic.image(1, 224, 320).unsqueeze(0).cuda()
+        props, classes, deltas = gpu_model(image_data=img)
+        assert tuple(props.shape) == (0, 4) and tuple(classes.shape) == (0, 21) and tuple(deltas.shape) == (0, 80)
+        det = gpu_model.predict(image_data=img, score_threshold=0.05)
+        assert sorted(det.keys()) == list(range(1, 21)) and all(v.shape == (0, 5) and v.dtype == np.float64 for v in det.values())
+        ref = O.forward(sd2, img.cpu())
+        assert ref[0].shape[0] == 0
+    finally:
+        gpu_model.load_state_dict(sd_cpu, strict=True)
+
+
+def test_larger_image_grows_the_context(gpu_model, sd_cpu):
+    """A 720x1280 image (larger than the default 608x1008 context) re-creates the slot; results match the oracle."""
+    img = synthetic.image(9, 720, 1280).unsqueeze(0)
+    detail = {}
+    o_props, o_classes, o_deltas = O.forward(sd_cpu, img, detail=detail)
+    props, classes, deltas = gpu_model(image_data=img.cuda())
+    assert props.shape[0] == o_props.shape[0]
+    j, err = match_rows(props.cpu().numpy(), o_props.numpy())
+    assert (err <= 1e-3).mean() >= 0.95
+    fm = gpu_model.context(0).tensor(0).reshape(45, 80, 512).permute(2, 0, 1).cpu()
+    ref = detail["feature_map"][0]
+    assert float((fm - ref).abs().max()) / float(ref.abs().max()) <= 2e-5
+    # and the next small image still works on the grown context
+    small = synthetic.image(3, 224, 320).unsqueeze(0).cuda()
+    assert gpu_model(image_data=small)[0].shape[1] == 4
+
+
+def test_smallest_supported_image(gpu_model, sd_cpu):
+    """32x48 -> a 2x3 feature map, 54 anchors; everything still lines up with the oracle."""
+    img = synthetic.image(4, 32, 48).unsqueeze(0)
+    o = O.forward(sd_cpu, img)
+    g = gpu_model(image_data=img.cuda())
+    assert g[0].shape[0] == o[0].shape[0]
+    if o[0].shape[0]:
+        j, err = match_rows(g[0].cpu().numpy(), o[0].numpy())
+        assert (err <= 1e-3).mean() >= 0.9
