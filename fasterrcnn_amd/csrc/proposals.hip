@@ -67,6 +67,71 @@ void nms_keys_kernel(const float* __restrict__ scores, int n, u64* __restrict__ 
     if (i < n) keys[i] = ((u64)ordered_bits(scores[i]) << 32) | (u64)(0xFFFFFFFFu - (unsigned)i);
 }
 
+// ---- register-resident bitonic sort (descending) of 1024*PER keys held PER-per-thread ---------------
+// thread t owns global positions [PER*t, PER*t+PER).  Sub-passes with partner distance j < PER are
+// in-thread, PER <= j < 64*PER go through __shfl_xor (same wave), j >= 64*PER through LDS.
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int lane_mask)
+{
+    const unsigned lo = __shfl_xor((unsigned)(v & 0xFFFFFFFFull), lane_mask);
+    const unsigned hi = __shfl_xor((unsigned)(v >> 32), lane_mask);
+    return ((u64)hi << 32) | lo;
+}
+
+// element at global index g, partner at g ^ j, run length k: keep max iff (descending run) == (lower index)
+__device__ __forceinline__ u64 bitonic_pick(u64 mine, u64 other, int g, int j, int k)
+{
+    const bool keep_max = (((g & k) == 0) == ((g & j) == 0));
+    const bool other_bigger = other > mine;
+    return (keep_max == other_bigger) ? other : mine;
+}
+
+template <int PER, int J>
+__device__ __forceinline__ void bitonic_inthread(u64 (&e)[PER], int base, int k)
+{
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        if ((r & J) == 0) {
+            const u64 a = e[r], b = e[r | J];
+            e[r] = bitonic_pick(a, b, base + r, J, k);
+            e[r | J] = bitonic_pick(b, a, base + (r | J), J, k);
+        }
+    }
+}
+
+template <int PER>
+__device__ void bitonic_sort_regs(u64* buf, int tid)
+{
+    constexpr int N = 1024 * PER;
+    u64 e[PER];
+    const int base = tid * PER;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) e[r] = buf[base + r];
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64 * PER) {
+#pragma unroll
+                for (int r = 0; r < PER; ++r) buf[base + r] = e[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < PER; ++r) e[r] = bitonic_pick(e[r], buf[(base + r) ^ j], base + r, j, k);
+                __syncthreads();
+            } else if (j >= PER) {
+                const int lane_mask = j / PER;
+#pragma unroll
+                for (int r = 0; r < PER; ++r) e[r] = bitonic_pick(e[r], shfl_xor_u64(e[r], lane_mask), base + r, j, k);
+            } else {
+                if (PER > 8 && j == 8) bitonic_inthread<PER, (PER > 8 ? 8 : 1)>(e, base, k);
+                else if (PER > 4 && j == 4) bitonic_inthread<PER, (PER > 4 ? 4 : 1)>(e, base, k);
+                else if (PER > 2 && j == 2) bitonic_inthread<PER, (PER > 2 ? 2 : 1)>(e, base, k);
+                else if (PER > 1 && j == 1) bitonic_inthread<PER, 1>(e, base, k);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) buf[base + r] = e[r];
+    __syncthreads();
+}
+
 // Single block, 1024 threads.  Selects the K largest of n_keys 64-bit keys (zero keys are
 // "absent"), sorts them descending in LDS, then emits them.
 //   MODE 0 (RPN): idx = low-1; writes sorted_idx; clips to the image, drops boxes with a side
@@ -86,12 +151,27 @@ void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_
     int* misc = hist + 256;                                      // [64]
     const int tid = threadIdx.x;
 
+    // each thread keeps its keys (i = tid + 1024*it) in registers when they fit: the select reads them 8 times
+    constexpr int KPT = 24;
+    const bool in_regs = n_keys <= 1024 * KPT;
+    u64 kreg[KPT];
+#pragma unroll
+    for (int it = 0; it < KPT; ++it) {
+        const int i = tid + 1024 * it;
+        kreg[it] = (in_regs && i < n_keys) ? keys[i] : 0ull;
+    }
+
     // ---- how many keys are present ----------------------------------------------------------
     if (tid == 0) { misc[0] = 0; misc[1] = 0; }
     __syncthreads();
     {
         int c = 0;
-        for (int i = tid; i < n_keys; i += 1024) c += keys[i] != 0ull;
+        if (in_regs) {
+#pragma unroll
+            for (int it = 0; it < KPT; ++it) c += kreg[it] != 0ull;
+        } else {
+            for (int i = tid; i < n_keys; i += 1024) c += keys[i] != 0ull;
+        }
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
         if ((tid & 63) == 0 && c) atomicAdd(&misc[0], c);
     }
@@ -113,9 +193,17 @@ void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_
             }
             for (int i = tid; i < 256; i += 1024) hist[i] = 0;
             __syncthreads();
-            for (int i = tid; i < n_keys; i += 1024) {
-                const u64 k = keys[i];
-                if (k != 0ull && (k & pmask) == prefix) atomicAdd(&hist[(int)((k >> sh) & 255ull)], 1);
+            if (in_regs) {
+#pragma unroll
+                for (int it = 0; it < KPT; ++it) {
+                    const u64 k = kreg[it];
+                    if (k != 0ull && (k & pmask) == prefix) atomicAdd(&hist[(int)((k >> sh) & 255ull)], 1);
+                }
+            } else {
+                for (int i = tid; i < n_keys; i += 1024) {
+                    const u64 k = keys[i];
+                    if (k != 0ull && (k & pmask) == prefix) atomicAdd(&hist[(int)((k >> sh) & 255ull)], 1);
+                }
             }
             __syncthreads();
             if (tid < 64) {
@@ -149,24 +237,41 @@ void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_
     // ---- gather survivors into LDS, pad, bitonic sort descending -----------------------------
     for (int i = tid; i < sort_n; i += 1024) buf[i] = 0ull;
     __syncthreads();
-    for (int i = tid; i < n_keys; i += 1024) {
-        const u64 k = keys[i];
-        if (k != 0ull && k >= thr) {
-            const int pos = atomicAdd(&misc[1], 1);
-            if (pos < sort_n) buf[pos] = k;
+    if (in_regs) {
+#pragma unroll
+        for (int it = 0; it < KPT; ++it) {
+            const u64 k = kreg[it];
+            if (k != 0ull && k >= thr) {
+                const int pos = atomicAdd(&misc[1], 1);
+                if (pos < sort_n) buf[pos] = k;
+            }
+        }
+    } else {
+        for (int i = tid; i < n_keys; i += 1024) {
+            const u64 k = keys[i];
+            if (k != 0ull && k >= thr) {
+                const int pos = atomicAdd(&misc[1], 1);
+                if (pos < sort_n) buf[pos] = k;
+            }
         }
     }
     __syncthreads();
-    for (int k = 2; k <= sort_n; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (sort_n >> 1); t += 1024) {
-                const int i = 2 * t - (t & (j - 1));
-                const int l = i + j;
-                const bool desc = (i & k) == 0;
-                const u64 a = buf[i], b = buf[l];
-                if ((a < b) == desc) { buf[i] = b; buf[l] = a; }
+    if (sort_n == 8192) {
+        bitonic_sort_regs<8>(buf, tid);          // the 6000-of-20646 case: 81 of 91 sub-passes barrier-free
+    } else if (sort_n == 16384) {
+        bitonic_sort_regs<16>(buf, tid);
+    } else {
+        for (int k = 2; k <= sort_n; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (sort_n >> 1); t += 1024) {
+                    const int i = 2 * t - (t & (j - 1));
+                    const int l = i + j;
+                    const bool desc = (i & k) == 0;
+                    const u64 a = buf[i], b = buf[l];
+                    if ((a < b) == desc) { buf[i] = b; buf[l] = a; }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
 

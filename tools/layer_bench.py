@@ -80,6 +80,16 @@ def main():
         print("%-8s %4d->%4d %4dx%-4d pool=%d splitws=%9d  %8.1f us  %6.1f TF" % (name, cin, cout, h, w, pool, wsb, us, fl / us / 1e6))
     if not args.only:
         print("all MFMA convs of one image (conv5_x x4 incl. RPN trunk): %.1f us, %.1f TF" % (total_us, total_fl / total_us / 1e6))
+    if not args.only or "c3" in args.only:
+        x = torch.randn((3, 600, 1000), device=dev)
+        wp = torch.randn((27, 64), device=dev) * 0.1
+        b = torch.zeros((64,), device=dev)
+        y = torch.empty((600, 1000, 64), device=dev)
+
+        def run_c3():
+            nv.check(lib.frcnn_conv3x3_c3(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(y), 600, 1000, 64, nv.RELU, s), "c3")
+        us = timeit(run_c3, args.reps)
+        print("conv1_1 (c3) 600x1000: %8.1f us  %.2f TB/s of output writes" % (us, 153.6e6 / us / 1e6))
     # FC layers
     for name, m, n, k in (("fc1", 300, 4096, 25088), ("fc2", 300, 4096, 4096), ("heads", 300, 101, 4096), ("rpn1x1", 2294, 45, 512)):
         if args.only and args.only not in name:
