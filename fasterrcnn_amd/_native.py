@@ -32,6 +32,11 @@ SYMBOLS = (
     "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv7x7_s2_c3",
     "frcnn_maxpool3x3_s2_nhwc", "frcnn_spatial_mean_nhwc", "frcnn_resnet_forward", "frcnn_rpn_targets",
     "frcnn_pack_conv3x3_x6", "frcnn_conv3x3_nhwc_x6", "frcnn_preprocess_workspace_bytes", "frcnn_preprocess",
+    # training path
+    "frcnn_label_proposals", "frcnn_gather_rows", "frcnn_rpn_loss", "frcnn_detector_loss",
+    "frcnn_gemm_tn_workspace_bytes", "frcnn_gemm_tn", "frcnn_conv3x3_wgrad_workspace_bytes", "frcnn_conv3x3_wgrad",
+    "frcnn_pack_conv3x3_dgrad", "frcnn_relu_backward", "frcnn_add_inplace", "frcnn_maxpool2x2_backward",
+    "frcnn_roi_pool_backward_workspace_bytes", "frcnn_roi_pool_backward", "frcnn_transpose", "frcnn_sgd_step",
 )
 
 
@@ -127,6 +132,23 @@ _SIGNATURES = {
     "frcnn_spatial_mean_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "frcnn_resnet_forward": (C.c_int, [_vp, C.POINTER(ResNetWeights), C.POINTER(ForwardParams), _vp, _i, _i,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "frcnn_label_proposals": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        _vp, _vp, _vp, _vp, _vp, _vp]),
+    "frcnn_gather_rows": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp]),
+    "frcnn_rpn_loss": (C.c_int, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "frcnn_detector_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "frcnn_gemm_tn_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "frcnn_gemm_tn": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "frcnn_conv3x3_wgrad_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "frcnn_conv3x3_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "frcnn_pack_conv3x3_dgrad": (C.c_int, [_vp, _vp, _i, _i, _vp]),
+    "frcnn_relu_backward": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "frcnn_add_inplace": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "frcnn_maxpool2x2_backward": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "frcnn_roi_pool_backward_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "frcnn_roi_pool_backward": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _vp, _i, _vp, _sz, _vp]),
+    "frcnn_transpose": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    "frcnn_sgd_step": (C.c_int, [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _vp]),
     "frcnn_ctx_timing_enable": (C.c_int, [_vp, _i]),
     "frcnn_ctx_timing_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), _i]),
 }

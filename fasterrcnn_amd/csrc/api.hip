@@ -296,6 +296,117 @@ int frcnn_detections(const float* d_props, const float* d_classes, const float* 
                              score_threshold, nms_threshold, d_out, d_out_cnt, as_stream(stream));
 }
 
+// ---- training path -----------------------------------------------------------------------------
+int frcnn_label_proposals(const float* d_props, const int32_t* d_n_props, int max_props,
+                          const float* d_gt_boxes, const int32_t* d_gt_class_idx, int n_gt, int num_classes,
+                          float min_background_iou, float min_object_iou,
+                          const float box_delta_means[4], const float box_delta_stds[4],
+                          float* d_out_props, int32_t* d_out_class_idx, float* d_out_gt_classes,
+                          float* d_out_gt_box_deltas, int32_t* d_out_count, void* stream)
+{
+    if ((!d_props && max_props > 0) || !d_n_props || !d_gt_boxes || !d_gt_class_idx || !box_delta_means || !box_delta_stds ||
+        !d_out_props || !d_out_class_idx || !d_out_gt_classes || !d_out_gt_box_deltas || !d_out_count)
+        return FRCNN_EINVAL;
+    if (!(min_background_iou < min_object_iou)) return FRCNN_EINVAL;      // faster_rcnn.py:421 assert
+    return launch_label_proposals(d_props, d_n_props, max_props, d_gt_boxes, d_gt_class_idx, n_gt, num_classes,
+                                  min_background_iou, min_object_iou, box_delta_means, box_delta_stds, d_out_props,
+                                  d_out_class_idx, d_out_gt_classes, d_out_gt_box_deltas, d_out_count, as_stream(stream));
+}
+
+int frcnn_gather_rows(const float* d_src, const int32_t* d_idx, int n, int row_floats, float* d_dst, void* stream)
+{
+    if (n > 0 && (!d_src || !d_idx || !d_dst)) return FRCNN_EINVAL;
+    return launch_gather_rows(d_src, d_idx, n, row_floats, d_dst, as_stream(stream));
+}
+
+int frcnn_rpn_loss(const float* d_head, int ld_head, int cells, const int32_t* d_sample, int n_sample,
+                   const float* d_rpn_map, float* d_losses, float* d_grad_head, void* stream)
+{
+    if (!d_head || (n_sample > 0 && !d_sample) || !d_rpn_map || !d_losses) return FRCNN_EINVAL;
+    return launch_rpn_loss(d_head, ld_head, cells, d_sample, n_sample, d_rpn_map, d_losses, d_grad_head, as_stream(stream));
+}
+
+int frcnn_detector_loss(const float* d_classes, const float* d_deltas, const float* d_gt_classes,
+                        const float* d_gt_box_deltas, int n, int num_classes, float* d_losses,
+                        float* d_grad_logits, int ld_grad, void* stream)
+{
+    if (!d_losses || (n > 0 && (!d_classes || !d_deltas || !d_gt_classes || !d_gt_box_deltas))) return FRCNN_EINVAL;
+    return launch_detector_loss(d_classes, d_deltas, d_gt_classes, d_gt_box_deltas, n, num_classes, d_losses,
+                                d_grad_logits, ld_grad, as_stream(stream));
+}
+
+size_t frcnn_gemm_tn_workspace_bytes(int M, int N, int R) { return M > 0 && N > 0 && R > 0 ? gemm_tn_workspace_bytes(M, N, R, 1) : 0; }
+
+int frcnn_gemm_tn(const float* d_a, int lda, const float* d_b, int ldb, float* d_c, int ldc,
+                  int M, int N, int R, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_a || !d_b || !d_c) return FRCNN_EINVAL;
+    return launch_gemm_tn(d_a, lda, d_b, ldb, d_c, ldc, M, N, R, d_ws, ws_bytes, as_stream(stream));
+}
+
+size_t frcnn_conv3x3_wgrad_workspace_bytes(int H, int W, int cin, int cout)
+{
+    return H > 0 && W > 0 && cin > 0 && cout > 0 ? gemm_tn_workspace_bytes(cout, cin, H * W, 9) : 0;
+}
+
+int frcnn_conv3x3_wgrad(const float* d_x, const float* d_dz, float* d_dwp, int H, int W, int cin, int cout,
+                        void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_x || !d_dz || !d_dwp) return FRCNN_EINVAL;
+    return launch_conv3x3_wgrad(d_x, d_dz, d_dwp, H, W, cin, cout, d_ws, ws_bytes, as_stream(stream));
+}
+
+int frcnn_pack_conv3x3_dgrad(const float* d_wp, float* d_wd, int cout, int cin, void* stream)
+{
+    if (!d_wp || !d_wd) return FRCNN_EINVAL;
+    return launch_pack_conv3x3_dgrad(d_wp, d_wd, cout, cin, as_stream(stream));
+}
+
+int frcnn_relu_backward(float* d_dy, const float* d_y, size_t n, void* stream)
+{
+    if (n > 0 && (!d_dy || !d_y)) return FRCNN_EINVAL;
+    return launch_relu_backward(d_dy, d_y, n, as_stream(stream));
+}
+
+int frcnn_add_inplace(float* d_a, const float* d_b, size_t n, void* stream)
+{
+    if (n > 0 && (!d_a || !d_b)) return FRCNN_EINVAL;
+    return launch_add_inplace(d_a, d_b, n, as_stream(stream));
+}
+
+int frcnn_maxpool2x2_backward(const float* d_x, const float* d_dy, float* d_dx, int H, int W, int c, void* stream)
+{
+    if (!d_x || !d_dy || !d_dx) return FRCNN_EINVAL;
+    return launch_maxpool2x2_backward(d_x, d_dy, d_dx, H, W, c, as_stream(stream));
+}
+
+size_t frcnn_roi_pool_backward_workspace_bytes(int n_rois, int pooled, int c)
+{
+    return n_rois > 0 && pooled > 0 && c > 0 ? roi_pool_backward_workspace_bytes(n_rois, pooled, c) : 0;
+}
+
+int frcnn_roi_pool_backward(const float* d_fm, int fh, int fw, int c, const float* d_rois, int n_rois, int pooled,
+                            float spatial_scale, const float* d_dout, float* d_dfm, int accumulate,
+                            void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_fm || !d_dfm || (n_rois > 0 && (!d_rois || !d_dout))) return FRCNN_EINVAL;
+    return launch_roi_pool_backward(d_fm, fh, fw, c, d_rois, n_rois, pooled, spatial_scale, d_dout, d_dfm, accumulate,
+                                    d_ws, ws_bytes, as_stream(stream));
+}
+
+int frcnn_transpose(const float* d_x, int ldi, float* d_y, int ldo, int rows, int cols, void* stream)
+{
+    if (!d_x || !d_y) return FRCNN_EINVAL;
+    return launch_transpose(d_x, ldi, d_y, ldo, rows, cols, as_stream(stream));
+}
+
+int frcnn_sgd_step(float* d_w, const float* d_grad, float* d_momentum_buf, size_t n, float lr, float momentum,
+                   float weight_decay, int first_step, void* stream)
+{
+    if (n > 0 && (!d_w || !d_grad)) return FRCNN_EINVAL;
+    return launch_sgd(d_w, d_grad, d_momentum_buf, n, lr, momentum, weight_decay, first_step, as_stream(stream));
+}
+
 // ---- context ---------------------------------------------------------------------------------
 int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_rois)
 {

@@ -112,4 +112,31 @@ int launch_detections(const float* props, const float* classes, const float* del
                       const int32_t* n_rois, int max_rois, int ncls, int image_h, int image_w,
                       float score_thr, float nms_thr, double* out, int32_t* out_cnt, hipStream_t s);
 
+// gemm_tn.hip / train.hip (train step)
+size_t gemm_tn_workspace_bytes(int M, int N, int R, int taps);
+int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int R,
+                   void* ws, size_t ws_bytes, hipStream_t s);
+int launch_conv3x3_wgrad(const float* x, const float* dz, float* dwp, int H, int W, int cin, int cout,
+                         void* ws, size_t ws_bytes, hipStream_t s);
+int launch_label_proposals(const float* props, const int32_t* n_props, int max_props, const float* gt,
+                           const int32_t* gt_cls, int M, int ncls, float bg_thr, float obj_thr,
+                           const float means[4], const float stds[4], float* out_props, int32_t* out_cls,
+                           float* out_onehot, float* out_deltas, int32_t* out_count, hipStream_t s);
+int launch_gather_rows(const float* src, const int32_t* idx, int n, int row_floats, float* dst, hipStream_t s);
+int launch_rpn_loss(const float* head, int ld, int cells, const int32_t* sample, int n_sample, const float* rpn_map,
+                    float* losses, float* d_head, hipStream_t s);
+int launch_detector_loss(const float* classes, const float* deltas, const float* gt_onehot, const float* gt_deltas,
+                         int S, int ncls, float* losses, float* d_logits, int ld, hipStream_t s);
+int launch_relu_backward(float* dy, const float* y, size_t n, hipStream_t s);
+int launch_add_inplace(float* a, const float* b, size_t n, hipStream_t s);
+int launch_maxpool2x2_backward(const float* x, const float* dy, float* dx, int H, int W, int C, hipStream_t s);
+size_t roi_pool_backward_workspace_bytes(int n_rois, int pooled, int C);
+int launch_roi_pool_backward(const float* fm, int fh, int fw, int C, const float* rois, int n_rois, int pooled,
+                             float scale, const float* dout, float* dfm, int accumulate, void* ws, size_t ws_bytes,
+                             hipStream_t s);
+int launch_transpose(const float* x, int ldi, float* y, int ldo, int rows, int cols, hipStream_t s);
+int launch_pack_conv3x3_dgrad(const float* wp, float* wd, int cout, int cin, hipStream_t s);
+int launch_sgd(float* w, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay, int first,
+               hipStream_t s);
+
 }  // namespace frcnn

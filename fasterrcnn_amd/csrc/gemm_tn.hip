@@ -1,0 +1,236 @@
+// gemm_tn.hip -- the one matrix kernel of the backward pass (SURVEY.md section 8 row f3;
+// reference: total_loss.backward() at models/faster_rcnn.py:355, i.e. autograd's conv2d / linear
+// backward on cuDNN / cuBLAS).
+//
+//   C[m][n] = sum_r A[r][m] * B[r][n]          ("TN": both operands are stored reduction-major)
+//
+// Every gradient GEMM of the train step has this shape once the small operand is transposed:
+//   linear weight gradient  dW[out][in]  = sum_sample dY[sample][out] * X[sample][in]
+//   linear data gradient    dX[sample][in] = sum_out dY^T[out][sample] * W[out][in]
+//   conv3x3 weight gradient dW[tap][co][ci] = sum_pixel dZ[pixel][co] * X[pixel + tap offset][ci]
+// The conv form is the same kernel with the B row of reduction index r taken from the shifted
+// pixel (zero outside the image) and blockIdx.z selecting the tap, so the result lands directly in
+// the tap-major packed layout the forward kernel consumes (csrc/conv.hip) -- no im2col, no repack.
+//
+// Exact-f32 matrix pipe (v_mfma_f32_32x32x2_f32).  Block = 128 x 128 output tile, 4 waves of
+// 64 x 64.  Both operands are staged as [16 reduction rows][128] floats in LDS (coalesced 512-B
+// global rows, double buffered, one barrier per 32 MFMAs/wave).  The MFMA wants one A value per lane
+// (m = lane & 31, k = lane >> 5); the wave's 64 m-values are assigned as m = 2*(lane&31) + mt so a
+// single ds_read_b64 feeds both m-tiles (likewise n), and the half-waves read two different LDS rows
+// -> conflict-free without padding.  The accumulator's column index is then n = 2*(lane&31) + nt:
+// the two n-tiles of a lane are adjacent floats and leave as one 8-byte store.
+// Split-R (deterministic): blockIdx.z also enumerates reduction ranges; partials go to a dense
+// [split][tap][M][N] workspace and are summed in fixed order by gemm_tn_reduce_kernel.
+#include "common.h"
+
+namespace frcnn {
+
+static constexpr int GT_T  = 128;   // tile edge (both m and n)
+static constexpr int GT_RK = 16;    // reduction rows per stage
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool CONV>
+__global__ __launch_bounds__(256)
+void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                    float* __restrict__ C, int ldc, int M, int N, int R,
+                    int rows_per_split, int splits, float* __restrict__ ws,
+                    int img_h, int img_w)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][GT_RK][GT_T];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GT_RK][GT_T];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * GT_T, m0 = blockIdx.y * GT_T;
+    const int tap = blockIdx.z / splits, split = blockIdx.z - tap * splits;
+    const int r_begin = split * rows_per_split;
+    int r_end = r_begin + rows_per_split;
+    if (r_end > R) r_end = R;
+    const int dy = CONV ? tap / 3 - 1 : 0, dx = CONV ? tap % 3 - 1 : 0;
+
+    // this thread's two 16-B pieces per operand per stage: row = q >> 5, column = (q & 31) * 4
+    const int prow0 = tid >> 5, pcol = (tid & 31) * 4;      // second piece: row + 8
+    const bool a_col_ok = m0 + pcol + 4 <= lda;
+    const bool b_col_ok = n0 + pcol + 4 <= ldb;
+
+    f32x4 areg[2], breg[2];
+    auto load_stage = [&](int r0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int r = r0 + prow0 + 8 * it;
+            const bool r_ok = r < r_end;
+            const bool a_ok = r_ok && a_col_ok;
+            const size_t a_off = a_ok ? (size_t)r * lda + m0 + pcol : 0;
+            f32x4 av = *reinterpret_cast<const f32x4*>(A + a_off);
+            if (!a_ok) av = f32x4{0.f, 0.f, 0.f, 0.f};
+            areg[it] = av;
+            bool b_ok = r_ok && b_col_ok;
+            size_t b_row = (size_t)r;
+            if (CONV) {
+                const int py = r / img_w, px = r - py * img_w;
+                const int sy = py + dy, sx = px + dx;
+                b_ok = b_ok && sy >= 0 && sy < img_h && sx >= 0 && sx < img_w;
+                b_row = (size_t)(sy * img_w + sx);
+            }
+            const size_t b_off = b_ok ? b_row * ldb + n0 + pcol : 0;
+            f32x4 bv = *reinterpret_cast<const f32x4*>(B + b_off);
+            if (!b_ok) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            breg[it] = bv;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            *reinterpret_cast<f32x4*>(&As[buf][prow0 + 8 * it][pcol]) = areg[it];
+            *reinterpret_cast<f32x4*>(&Bs[buf][prow0 + 8 * it][pcol]) = breg[it];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nstages = (r_end - r_begin + GT_RK - 1) / GT_RK;
+    if (nstages > 0) {
+        load_stage(r_begin);
+        store_stage(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        const bool has_next = s + 1 < nstages;
+        if (has_next) load_stage(r_begin + (s + 1) * GT_RK);
+        const int buf = s & 1;
+#pragma unroll
+        for (int kk = 0; kk < GT_RK / 2; ++kk) {
+            const f32x2 a2 = *reinterpret_cast<const f32x2*>(&As[buf][2 * kk + lh][wm * 64 + 2 * li]);
+            const f32x2 b2 = *reinterpret_cast<const f32x2*>(&Bs[buf][2 * kk + lh][wn * 64 + 2 * li]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt], b2[nt], acc[mt][nt], 0, 0, 0);
+        }
+        if (has_next) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // acc[mt][nt][reg] = C[m0 + 64 wm + 2 i + mt][n0 + 64 wn + 2 li + nt],  i = (reg&3) + 8 (reg>>2) + 4 lh
+    float* out;
+    int ld_out;
+    if (ws != nullptr) {
+        out = ws + ((size_t)split * gridDim.z / splits + tap) * (size_t)M * N;   // [split][tap][M][N]
+        ld_out = N;
+    } else {
+        out = C + (size_t)tap * M * ldc;
+        ld_out = ldc;
+    }
+    const int n = n0 + 64 * wn + 2 * li;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            const int m = m0 + 64 * wm + 2 * i + mt;
+            if (m >= M) continue;
+            float* p = out + (size_t)m * ld_out + n;
+            if (n + 1 < N) *reinterpret_cast<f32x2*>(p) = f32x2{acc[mt][0][reg], acc[mt][1][reg]};
+            else if (n < N) *p = acc[mt][0][reg];
+        }
+}
+
+// C[tap][m][n] (row stride ldc) = sum over splits of ws[split][tap][m][n], ascending split order.
+__global__ __launch_bounds__(256)
+void gemm_tn_reduce_kernel(const float* __restrict__ ws, int splits, int taps, int M, int N,
+                           float* __restrict__ C, int ldc)
+{
+    const size_t per = (size_t)taps * M * N;
+    const int N2 = N >> 1;                     // N is even on this path
+    const size_t total = (size_t)taps * M * N2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int n2 = (int)(i % N2);
+        const size_t row = i / N2;             // tap * M + m
+        const size_t src = row * N + 2 * n2;
+        f32x2 v = *reinterpret_cast<const f32x2*>(ws + src);
+        for (int s = 1; s < splits; ++s) {
+            const f32x2 t = *reinterpret_cast<const f32x2*>(ws + s * per + src);
+            v[0] += t[0]; v[1] += t[1];
+        }
+        *reinterpret_cast<f32x2*>(C + row * ldc + 2 * n2) = v;
+    }
+}
+
+namespace {
+// Reduction ranges so that the launch has ~1024+ blocks, each range >= 64 rows, partials fit in ws.
+void choose_split(int M, int N, int R, int taps, size_t ws_bytes, bool have_ws, int* splits, int* rows_per_split)
+{
+    const long tiles = (long)cdiv(M, GT_T) * cdiv(N, GT_T) * taps;
+    int s = 1;
+    if (have_ws && (N % 2 == 0) && tiles < 768) {
+        s = (int)((1024 + tiles - 1) / tiles);
+        const int max_by_rows = R / 64 > 0 ? R / 64 : 1;
+        if (s > max_by_rows) s = max_by_rows;
+        const size_t per = (size_t)taps * M * N * sizeof(float);
+        const size_t max_by_ws = per ? ws_bytes / per : 1;
+        if ((size_t)s > max_by_ws) s = (int)max_by_ws;
+        if (s < 1) s = 1;
+    }
+    int rps = cdiv(cdiv(R, s), GT_RK) * GT_RK;
+    if (rps < GT_RK) rps = GT_RK;
+    *splits = cdiv(R, rps) > 0 ? cdiv(R, rps) : 1;
+    *rows_per_split = rps;
+}
+
+template <bool CONV>
+int launch_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int R, int taps,
+              int img_h, int img_w, void* ws, size_t ws_bytes, hipStream_t s)
+{
+    int splits, rps;
+    choose_split(M, N, R, taps, ws_bytes, ws != nullptr, &splits, &rps);
+    if (cdiv(N, GT_T) > 65535 || cdiv(M, GT_T) > 65535 || taps * splits > 65535) return FRCNN_EINVAL;
+    float* part = splits > 1 ? static_cast<float*>(ws) : nullptr;
+    dim3 grid(cdiv(N, GT_T), cdiv(M, GT_T), taps * splits);
+    hipLaunchKernelGGL((gemm_tn_kernel<CONV>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, R, rps, splits,
+                       part, img_h, img_w);
+    int rc = check_launch();
+    if (rc || splits == 1) return rc;
+    const size_t total = (size_t)taps * M * (N / 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, splits, taps, M, N, C, ldc);
+    return check_launch();
+}
+}  // namespace
+
+size_t gemm_tn_workspace_bytes(int M, int N, int R, int taps)
+{
+    int splits, rps;
+    choose_split(M, N, R, taps, (size_t)1 << 40, true, &splits, &rps);
+    return splits > 1 ? (size_t)splits * taps * M * N * sizeof(float) : 0;
+}
+
+int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int R,
+                   void* ws, size_t ws_bytes, hipStream_t s)
+{
+    if (M < 1 || N < 1 || R < 1 || lda < M || ldb < N || ldc < N || (lda & 3) || (ldb & 3) || (ldc & 1)) return FRCNN_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return FRCNN_EINVAL;
+    if (reinterpret_cast<uintptr_t>(C) & 7) return FRCNN_EINVAL;
+    return launch_tn<false>(A, lda, B, ldb, C, ldc, M, N, R, 1, 0, 0, ws, ws_bytes, s);
+}
+
+int launch_conv3x3_wgrad(const float* x, const float* dz, float* dwp, int H, int W, int cin, int cout,
+                         void* ws, size_t ws_bytes, hipStream_t s)
+{
+    if (H < 1 || W < 1 || cin < 4 || cout < 4 || (cin & 3) || (cout & 3)) return FRCNN_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dz)) & 15) return FRCNN_EINVAL;
+    if ((long)H * W > (1L << 30)) return FRCNN_EINVAL;
+    // A = dz [pixel][cout], B = x [pixel (shifted)][cin], C = dwp [tap][cout][cin]
+    return launch_tn<true>(dz, cout, x, cin, dwp, cin, cout, cin, H * W, 9, H, W, ws, ws_bytes, s);
+}
+
+}  // namespace frcnn

@@ -1,6 +1,6 @@
 """
-Detector stage, mirroring pytorch/FasterRCNN/models/detector.py:20-80 (losses at :83-155 are
-training-only and out of scope).  `_classifier` / `_regressor` keep their names and
+Detector stage, mirroring pytorch/FasterRCNN/models/detector.py:20-80 (losses at :83-155: csrc/train.hip
+`frcnn_detector_loss`, driven by fasterrcnn_amd/training.py).  `_classifier` / `_regressor` keep their names and
 initialisation; RoI pooling is csrc/roipool.hip, the heads one stacked GEMM (csrc/linear.hip)
 followed by the softmax/split epilogue.
 """

@@ -13,7 +13,9 @@ Differences that are deliberate:
     (the reference recomputes them on the CPU per call, faster_rcnn.py:113-115);
   * `predict_async` / `Pending.result` expose the same computation with several images in flight
     on separate streams (each image is still an independent batch-1 forward);
-  * `train_step` and the samplers (faster_rcnn.py:228-561) are outside the inference hot path.
+  * `train_step` (faster_rcnn.py:228-362, VGG-16 backbone) is written out as explicit forward + backward
+    + SGD over the C ABI in fasterrcnn_amd/training.py; the trained weights live in the kernels' packed
+    layouts and are written back to the nn.Parameters lazily (before state_dict / predict / forward).
 There is no CPU / eager fallback: parameters must live on an MI355X (`.cuda()`).
 """
 import ctypes as C
@@ -101,6 +103,7 @@ class FasterRCNNModel(nn.Module):
         # operands, six bf16 MFMAs per product with f32 accumulation (same accuracy class)
         self._math_mode = "f32"
 
+        self._train_state = None
         self._slots = {}
         self._wstruct = None
         self._wstruct_key = None
@@ -189,6 +192,7 @@ class FasterRCNNModel(nn.Module):
 
     def _enqueue(self, image_data, anchor_map, anchor_valid_map, score_threshold, slot_index):
         assert image_data.shape[0] == 1, "Batch size must be 1"
+        self.sync_parameters()
         device = self._device()
         image = rt.as_f32_cuda(image_data, "image_data")
         if image.device != device:
@@ -271,5 +275,35 @@ class FasterRCNNModel(nn.Module):
                 return s.ctx
         raise KeyError("slot %d has not been used yet" % slot)
 
-    def train_step(self, *args, **kwargs):
-        raise NotImplementedError("training (faster_rcnn.py:228-362) is outside the accelerated inference hot path")
+    # ------------------------------------------------------------------------------------------
+    def _training_state(self):
+        from .. import training
+        if self._train_state is None:
+            self._device()
+            self._train_state = training.TrainState(self)
+        return self._train_state
+
+    def sync_parameters(self):
+        """Writes weights updated by `train_step` back into the nn.Parameters (no-op when nothing is pending)."""
+        if self._train_state is not None:
+            self._train_state.sync_to_parameters()
+
+    def state_dict(self, *args, **kwargs):
+        self.sync_parameters()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._train_state = None          # packed training masters and momentum buffers belong to the old weights
+        return super().load_state_dict(*args, **kwargs)
+
+    def train_step(self, optimizer, image_data, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_object_indices,
+                   gt_rpn_background_indices, gt_boxes):
+        """
+        One training step on one sample (faster_rcnn.py:228-362): forward, the four losses, backward, SGD.
+        `optimizer` supplies lr / momentum / weight_decay through `param_groups` (a torch.optim.SGD built as
+        __main__.py:98-105 does, or fasterrcnn_amd.training.create_optimizer); its state lives with the model.
+        Returns FasterRCNNModel.Loss.
+        """
+        from .. import training
+        return training.train_step(self, optimizer, image_data, anchor_map, anchor_valid_map, gt_rpn_map,
+                                   gt_rpn_object_indices, gt_rpn_background_indices, gt_boxes)

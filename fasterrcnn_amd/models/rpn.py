@@ -1,6 +1,6 @@
 """
 Region proposal network, mirroring pytorch/FasterRCNN/models/rpn.py:29-173 (inference part;
-the losses at :176-272 are training-only and out of scope).  Layer names `_rpn_conv1`,
+the losses at :176-272 and their gradients are csrc/train.hip `frcnn_rpn_loss`, driven by fasterrcnn_amd/training.py).  Layer names `_rpn_conv1`,
 `_rpn_class`, `_rpn_boxes` and their initialisation follow the reference; the arithmetic is
 csrc/conv.hip (3x3 trunk), csrc/linear.hip (both 1x1 heads as ONE GEMM, output already NHWC)
 and csrc/proposals.hip (sigmoid, decode, top-N, clip, size filter, NMS).

@@ -324,6 +324,85 @@ int frcnn_resnet_forward(frcnn_ctx* ctx, const frcnn_resnet_weights* w, const fr
                          float* d_props, float* d_classes, float* d_deltas, int32_t* d_counts,
                          void* stream);
 
+/* ==========================================================================================
+ * Training path (SURVEY.md section 8 rows f2 + f3): FasterRCNNModel.train_step,
+ * models/faster_rcnn.py:228-362.  The reference relies on autograd over cuDNN/cuBLAS; here every
+ * backward operator is an explicit entry point and fasterrcnn_amd/models/faster_rcnn.py chains them.
+ * All arithmetic is float32 on the exact-f32 matrix pipe; loss sums are float64, rounded once.
+ * ======================================================================================== */
+
+/* models/faster_rcnn.py:421-510 _label_proposals.  Rows 0..n_props-1 are the RPN proposals
+ * (n_props read from the device, clamped to max_props), followed by the n_gt ground-truth boxes
+ * (:433).  For every row whose best IoU >= min_background_iou (order preserved, :476-480):
+ *   d_out_props         float32 [K][4]
+ *   d_out_class_idx     int32   [K]       0 = background (best IoU < min_object_iou, :483)
+ *   d_out_gt_classes    float32 [K][num_classes]            one-hot (:486-488)
+ *   d_out_gt_box_deltas float32 [K][2][4*(num_classes-1)]   [:,0,:] mask, [:,1,:] (ty,tx,th,tw) tiled (:497-510)
+ *   d_out_count         int32   K
+ * Output buffers hold max_props + n_gt rows.  IoU as math_utils.py:39-63 in float32 (eps 1e-7). */
+int frcnn_label_proposals(const float* d_props, const int32_t* d_n_props, int max_props,
+                          const float* d_gt_boxes, const int32_t* d_gt_class_idx, int n_gt, int num_classes,
+                          float min_background_iou, float min_object_iou,
+                          const float box_delta_means[4], const float box_delta_stds[4],
+                          float* d_out_props, int32_t* d_out_class_idx, float* d_out_gt_classes,
+                          float* d_out_gt_box_deltas, int32_t* d_out_count, void* stream);
+
+/* dst[i][:] = src[idx[i]][:] -- the index selects of faster_rcnn.py:557-561 (_sample_proposals; the
+ * random permutation itself is drawn on the host exactly as the reference draws it). */
+int frcnn_gather_rows(const float* d_src, const int32_t* d_idx, int n, int row_floats, float* d_dst, void* stream);
+
+/* models/rpn.py:176-272 class_loss + regression_loss over the anchor mini-batch, and the gradient of
+ * (class_loss + regression_loss) with respect to the RPN head output.
+ *   d_head    float32 [cells][ld_head]: [9 objectness logits | 36 box deltas | pad] per feature-map cell
+ *   d_sample  int32 [n_sample]: flat anchor indices (y*fw + x)*9 + k marked trainable by
+ *             faster_rcnn.py:364-419 _sample_rpn_minibatch (no duplicates)
+ *   d_rpn_map float32 [A][6] (trainable, object, ty, tx, th, tw)  (frcnn_rpn_targets layout)
+ *   d_losses  float32 [2] = (class, regression);  d_grad_head [cells][ld_head] or NULL (fully written). */
+int frcnn_rpn_loss(const float* d_head, int ld_head, int cells, const int32_t* d_sample, int n_sample,
+                   const float* d_rpn_map, float* d_losses, float* d_grad_head, void* stream);
+
+/* models/detector.py:83-155 class_loss + regression_loss and the gradient with respect to the stacked
+ * head output [class logits (num_classes) | regressor outputs (4*(num_classes-1)) | pad to ld_grad].
+ *   d_classes [n][num_classes] softmax output, d_deltas [n][4*(num_classes-1)],
+ *   d_gt_classes / d_gt_box_deltas as produced by frcnn_label_proposals. */
+int frcnn_detector_loss(const float* d_classes, const float* d_deltas, const float* d_gt_classes,
+                        const float* d_gt_box_deltas, int n, int num_classes, float* d_losses,
+                        float* d_grad_logits, int ld_grad, void* stream);
+
+/* C[m][n] = sum_r A[r][m] * B[r][n]  (m < M, n < N, r < R): autograd's linear backward
+ * (weight gradient dY^T X; data gradient with A = dY^T).  lda, ldb multiples of 4, ldc even,
+ * A/B 16-byte aligned; rows may be read up to their leading dimension.  Deterministic split-R
+ * through d_ws (frcnn_gemm_tn_workspace_bytes; NULL = no split). */
+size_t frcnn_gemm_tn_workspace_bytes(int M, int N, int R);
+int frcnn_gemm_tn(const float* d_a, int lda, const float* d_b, int ldb, float* d_c, int ldc,
+                  int M, int N, int R, void* d_ws, size_t ws_bytes, void* stream);
+
+/* conv2d backward of the 3x3 "same" layers (vgg16.py:76-96, rpn.py:88):
+ *   weight gradient  d_dwp [9][cout][cin] (the frcnn_pack_conv3x3 layout) from x [H][W][cin], dz [H][W][cout];
+ *   data gradient    dx = frcnn_conv3x3_nhwc(dz, frcnn_pack_conv3x3_dgrad(wp), zero bias, flags 0). */
+size_t frcnn_conv3x3_wgrad_workspace_bytes(int H, int W, int cin, int cout);
+int frcnn_conv3x3_wgrad(const float* d_x, const float* d_dz, float* d_dwp, int H, int W, int cin, int cout,
+                        void* d_ws, size_t ws_bytes, void* stream);
+int frcnn_pack_conv3x3_dgrad(const float* d_wp, float* d_wd, int cout, int cin, void* stream);
+
+/* dy[i] = y[i] > 0 ? dy[i] : 0 (ReLU backward, in place); a[i] += b[i]. */
+int frcnn_relu_backward(float* d_dy, const float* d_y, size_t n, void* stream);
+int frcnn_add_inplace(float* d_a, const float* d_b, size_t n, void* stream);
+/* MaxPool2d(2,2) backward: x [H][W][c] pool input, dy [H/2][W/2][c] -> dx [H][W][c] (first maximum wins). */
+int frcnn_maxpool2x2_backward(const float* d_x, const float* d_dy, float* d_dx, int H, int W, int c, void* stream);
+/* torchvision RoIPool backward (detector.py:72): dout [n][pooled][pooled][c] -> dfm [fh][fw][c] (gradient to
+ * each bin's argmax cell).  Deterministic gather formulation; accumulate != 0 adds to dfm. */
+size_t frcnn_roi_pool_backward_workspace_bytes(int n_rois, int pooled, int c);
+int frcnn_roi_pool_backward(const float* d_fm, int fh, int fw, int c, const float* d_rois, int n_rois, int pooled,
+                            float spatial_scale, const float* d_dout, float* d_dfm, int accumulate,
+                            void* d_ws, size_t ws_bytes, void* stream);
+/* y[c][r] = x[r][c]; y rows are ldo >= rows wide, the tail is zero filled. */
+int frcnn_transpose(const float* d_x, int ldi, float* d_y, int ldo, int rows, int cols, void* stream);
+/* torch.optim.SGD.step as built at __main__.py:98-105: g += weight_decay*w; buf = first_step ? g :
+ * momentum*buf + g; w -= lr*buf (layout agnostic: applied to the packed weights). */
+int frcnn_sgd_step(float* d_w, const float* d_grad, float* d_momentum_buf, size_t n, float lr, float momentum,
+                   float weight_decay, int first_step, void* stream);
+
 /* Introspection for parity tests: device pointers of intermediate tensors of the LAST forward
  * on this ctx.  which: 0 feature map NHWC [fh][fw][512], 1 RPN head [fh*fw][128],
  * 2 objectness scores [A], 3 sorted anchor indices int32 [pre_nms], 4 RoI-pool out

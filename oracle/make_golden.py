@@ -3,6 +3,7 @@ oracle/make_golden.py -- TEST INFRASTRUCTURE ONLY; runs in the BUILD CONTAINER (
 
   python oracle/make_golden.py --calibrate     prints the layer multipliers frozen in
                                                fasterrcnn_amd/synthetic.py:CALIBRATION
+  python oracle/make_golden.py --train         reference train_step vs oracle/train_oracle.py -> tests/golden/train_*.npz
   python oracle/make_golden.py                 (1) runs the imported REFERENCE (reference_shims.py)
                                                on the synthetic workload, (2) asserts that
                                                oracle/frcnn_oracle.py reproduces it, (3) writes the
@@ -275,11 +276,118 @@ def golden_small_ops(ref):
     print("  wrote tests/golden/small_ops.npz")
 
 
+
+def sample_positions(n, count=2048):
+    return np.unique(np.linspace(0, n - 1, min(count, n)).astype(np.int64))
+
+
+def golden_train(ref, tag, seed, height, width, steps=2, lr=1e-6, momentum=0.9, weight_decay=5e-4):
+    """
+    Runs the REFERENCE's train_step (faster_rcnn.py:228-362) with torch.optim.SGD built as __main__.py:98-105 does,
+    asserts oracle/train_oracle.py reproduces losses / gradients / updated weights bit for bit under the same RNG
+    seeds, and writes the fixture the GPU parity test compares against.
+    """
+    import random
+    from oracle import train_oracle as TO
+    print("train case %s: image seed %d, %dx%d, %d steps" % (tag, seed, height, width, steps))
+    sd0 = synthetic.vgg16_state_dict(1234)
+    img = synthetic.image(seed, height, width).unsqueeze(0)
+    gts = synthetic.ground_truth(seed, height, width)
+    Box = ref.training_sample.Box
+    boxes = [Box(c, "x", k) for c, k in gts]
+    backbone = ref.vgg16.VGG16Backbone(dropout_probability=0.0)
+    model = ref.faster_rcnn.FasterRCNNModel(num_classes=21, backbone=backbone, allow_edge_proposals=True)
+    model.load_state_dict(sd0, strict=True)
+    ishape = tuple(img.shape[1:])
+    am, vm = ref.anchors.generate_anchor_maps(ishape, backbone.compute_feature_map_shape(ishape), 16)
+    rmap, obj, bg = ref.anchors.generate_rpn_map(am, vm, boxes)
+    print("  %d gt boxes, %d object / %d background anchors" % (len(gts), len(obj), len(bg)))
+    params = []
+    for key, value in dict(model.named_parameters()).items():          # __main__.py:98-105
+        if not value.requires_grad:
+            continue
+        if "weight" in key:
+            params += [{"params": [value], "weight_decay": weight_decay}]
+    optimizer = t.optim.SGD(params, lr=lr, momentum=momentum)
+    gt_corners = np.stack([k for _, k in gts]).astype(np.float32)
+    gt_cls = np.array([c for c, _ in gts], dtype=np.int64)
+
+    out = {"seed": np.int64(seed), "height": np.int64(height), "width": np.int64(width), "weights_seed": np.int64(1234),
+           "steps": np.int64(steps), "lr": np.float64(lr), "momentum": np.float64(momentum),
+           "weight_decay": np.float64(weight_decay), "rng_seed": np.int64(100 + seed)}
+    sd = {k: v.clone() for k, v in sd0.items()}
+    bufs = None
+    keys = TO.trainable_weight_keys(sd0)
+    out["train_keys"] = np.array(keys)
+    random.seed(100 + seed); t.manual_seed(100 + seed)
+    rng_py, rng_t = random.getstate(), t.get_rng_state()
+    for step in range(steps):
+        # reference
+        random.setstate(rng_py); t.set_rng_state(rng_t)
+        t0 = time.time()
+        loss = model.train_step(optimizer=optimizer, image_data=img, anchor_map=am, anchor_valid_map=vm,
+                                gt_rpn_map=t.from_numpy(rmap).unsqueeze(dim=0), gt_rpn_object_indices=[obj],
+                                gt_rpn_background_indices=[bg], gt_boxes=[boxes])
+        ref_after_py, ref_after_t = random.getstate(), t.get_rng_state()
+        print("  step %d reference %.1f s: %s" % (step, time.time() - t0, loss))
+        ref_grads = {k: v.grad.detach().clone() for k, v in model.named_parameters() if k in keys}
+        ref_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        # oracle, same RNG state
+        random.setstate(rng_py); t.set_rng_state(rng_t)
+        detail = {}
+        losses, grads, new_sd, bufs = TO.train_step(sd, img, am, vm, t.from_numpy(rmap).unsqueeze(dim=0), obj, bg,
+                                                    gt_corners, gt_cls, 21, lr, momentum, weight_decay, bufs, detail=detail)
+        for name in ("rpn_class", "rpn_regression", "detector_class", "detector_regression", "total"):
+            assert_equal("step%d loss.%s" % (step, name), np.float64(losses[name]), np.float64(getattr(loss, name)))
+        # step 0 is bit-identical.  From step 1 on the detector branch's softmax gradient involves cancellation of
+        # 1/(p+eps)-sized terms and the CPU BLAS the linear backward runs on does not fix its summation order
+        # across buffer alignments: the two runs agree to ~1e-7 of each tensor's largest entry, not bitwise.
+        for k in keys:
+            if step == 0:
+                assert_equal("step%d grad %s" % (step, k[-40:]), grads[k].numpy(), ref_grads[k].numpy())
+                assert_equal("step%d new  %s" % (step, k[-40:]), new_sd[k].numpy(), ref_sd[k].numpy())
+            else:
+                gscale = max(float(v.abs().max()) for v in ref_grads.values())
+                for what, a, b in (("grad", grads[k], ref_grads[k]), ("new", new_sd[k], ref_sd[k])):
+                    floor = 1e-6 * gscale if what == "grad" else 1e-30      # a tensor of pure rounding noise is not compared
+                    d = float((a - b).abs().max()) / max(float(b.abs().max()), floor)
+                    assert d < 1e-5, (step, what, k, d)
+                    print("  oracle ~= reference: step%d %s %-44s rel max|d| %.2g" % (step, what, k[-44:], d))
+        rng_same = random.getstate() == ref_after_py and bool((t.get_rng_state() == ref_after_t).all())
+        print("  RNG state after step %d identical: %s" % (step, rng_same))
+        for k in sd0:
+            if k not in keys:
+                assert_equal("step%d frozen %s" % (step, k[-40:]), new_sd[k].numpy(), sd0[k].numpy())
+        pre = "s%d_" % step
+        out[pre + "losses"] = np.array([losses[n] for n in ("rpn_class", "rpn_regression", "detector_class",
+                                                             "detector_regression", "total")], dtype=np.float64)
+        out[pre + "rpn_sample_flat"] = detail["rpn_sample_flat"]
+        out[pre + "proposal_sample_indices"] = detail["proposal_sample_indices"].astype(np.int32)
+        out[pre + "n_rpn_proposals"] = np.int64(detail["rpn_proposals"].shape[0])
+        out[pre + "n_labelled"] = np.int64(detail["labelled"][0].shape[0])
+        out[pre + "sampled_props"] = detail["sampled"][0].numpy()
+        out[pre + "sampled_class_idx"] = detail["sampled"][1].numpy().argmax(axis=1).astype(np.int32)
+        for k in keys:
+            g = grads[k].numpy().reshape(-1).astype(np.float64)
+            pos = sample_positions(g.shape[0])
+            out[pre + "gnorm/" + k] = np.float64(np.sqrt((g * g).sum()))
+            out[pre + "gsample/" + k] = g[pos].astype(np.float32)
+            dw = (new_sd[k].numpy().reshape(-1).astype(np.float64) - sd[k].numpy().reshape(-1).astype(np.float64))
+            out[pre + "dwnorm/" + k] = np.float64(np.sqrt((dw * dw).sum()))
+            out[pre + "dwsample/" + k] = dw[pos].astype(np.float32)
+        sd = new_sd
+        rng_py, rng_t = ref_after_py, ref_after_t
+    name = "train_vgg16_%s.npz" % tag
+    np.savez_compressed(os.path.join(GOLDEN, name), **out)
+    print("  wrote tests/golden/%s" % name)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--calibrate", action="store_true")
     ap.add_argument("--calibrate-resnet", action="store_true")
     ap.add_argument("--only-resnet", action="store_true")
+    ap.add_argument("--train", action="store_true", help="only the train-step fixtures (tests/golden/train_*.npz)")
     args = ap.parse_args()
     t.manual_seed(0)
     ref = reference_shims.install(O)
@@ -290,6 +398,10 @@ def main():
         calibrate_resnet(ref)
         return
     os.makedirs(GOLDEN, exist_ok=True)
+    if args.train:
+        golden_train(ref, "352x480_s4", 4, 352, 480)
+        golden_train(ref, "416x544_s6", 6, 416, 544)
+        return
     if not args.only_resnet:
         golden_small_ops(ref)
         sd = synthetic.vgg16_state_dict(1234)

@@ -8,7 +8,7 @@ imported in place.  What the reference needs but this image lacks is stubbed at 
 
   * torchvision (pytorch/requirements.txt:8, not installed, not vendored): a stub package whose
     ops.nms / ops.RoIPool forward to oracle/frcnn_oracle.py's restatements of torchvision's
-    documented semantics -- so the golden vectors pin the reference's OWN code around those two
+    documented semantics (RoIPool's backward: oracle/train_oracle.py RoIPoolFunction) -- so the golden vectors pin the reference's OWN code around those two
     calls, not torchvision itself (parity unpinned there, see DESIGN.md);
   * imageio (datasets/image.py:11): empty stub, never called;
   * `.cuda()` / device="cuda" (rpn.py:120-122, math_utils.py:125, detector.py:65,
@@ -44,6 +44,9 @@ def install(oracle_module):
             self.spatial_scale = spatial_scale
 
         def forward(self, input, rois):
+            if input.requires_grad:       # train_step: forward + backward restated in oracle/train_oracle.py
+                from oracle import train_oracle
+                return train_oracle.RoIPoolFunction.apply(input, rois, self.output_size[0], self.spatial_scale)
             out = oracle_module.roi_pool(input.detach().numpy(), rois.detach().numpy(), self.output_size[0],
                                          self.spatial_scale)
             return t.from_numpy(out)

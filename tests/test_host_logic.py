@@ -4,8 +4,9 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch as t
 
-from fasterrcnn_amd import statistics, synthetic
+from fasterrcnn_amd import statistics, synthetic, training
 from fasterrcnn_amd.datasets.training_sample import Box
 from fasterrcnn_amd.models import math_utils
 from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
@@ -41,8 +42,9 @@ def test_no_cpu_fallback(cpu_model):
         cpu_model.predict(img, score_threshold=0.05)
     with pytest.raises(AssertionError, match="Batch size must be 1"):
         cpu_model.predict(torch.zeros((2, 3, 64, 64)), score_threshold=0.05)
-    with pytest.raises(NotImplementedError):
-        cpu_model.train_step()
+    # training has no CPU path either: the packed masters are built on the device
+    with pytest.raises(RuntimeError, match="MI355X"):
+        cpu_model.train_step(training.create_optimizer(cpu_model), img, None, None, torch.zeros((1, 4, 4, 9, 6)), [np.zeros((1, 3))], [np.zeros((1, 3))], [[]])
 
 
 def test_product_does_not_import_oracle():
@@ -167,3 +169,34 @@ def test_checkpoint_formats(tmp_path, cpu_model, sd_cpu):
     tracker.on_epoch_end(fresh, 2, 5.0)
     tracker.save_best_weights(fresh)
     assert torch.load(str(tmp_path / "best.pth"))["epoch"] == 1
+
+
+def test_proposal_sampler_draws_like_the_reference():
+    """training._sample_proposal_indices consumes torch's CPU generator exactly as faster_rcnn.py:512-561 does."""
+    from fasterrcnn_amd import training
+    from oracle import train_oracle as TO
+    rng = np.random.RandomState(3)
+    cls = t.from_numpy((rng.rand(900) < 0.08).astype(np.int64) * rng.randint(1, 21, 900))
+    onehot = t.nn.functional.one_hot(cls, 21).float()
+    props = t.arange(900, dtype=t.float32).reshape(-1, 1).repeat(1, 4)
+    deltas = t.zeros((900, 2, 80))
+    for max_props in (128, 2000, 0):
+        t.manual_seed(77)
+        idx = training._sample_proposal_indices(cls, max_props, 0.25)
+        t.manual_seed(77)
+        rp, rc, _ = TO.sample_proposals(props, onehot, deltas, max_props, 0.25)
+        assert t.equal(props[idx], rp) and t.equal(onehot[idx], rc)
+    # no positives -> empty batch (faster_rcnn.py:552-553)
+    assert training._sample_proposal_indices(t.zeros((50,), dtype=t.int64), 128, 0.25).shape[0] == 0
+
+
+def test_optimizer_hyper_parameters_from_torch_sgd():
+    from fasterrcnn_amd import training
+    p = t.nn.Parameter(t.zeros(3))
+    q = t.nn.Parameter(t.zeros(3))
+    opt = t.optim.SGD([{"params": [p], "weight_decay": 5e-4}, {"params": [q], "weight_decay": 5e-4}], lr=1e-3, momentum=0.9)
+    assert training.sgd_hyper_parameters(opt) == (1e-3, 0.9, 5e-4)
+    assert training.sgd_hyper_parameters(training.create_optimizer(None)) == (1e-3, 0.9, 5e-4)
+    bad = t.optim.SGD([{"params": [p], "weight_decay": 0.0}, {"params": [q], "weight_decay": 5e-4}], lr=1e-3, momentum=0.9)
+    with pytest.raises(NotImplementedError):
+        training.sgd_hyper_parameters(bad)

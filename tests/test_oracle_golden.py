@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch as t
 
 from fasterrcnn_amd import synthetic
 from oracle import frcnn_oracle as O
@@ -193,3 +194,54 @@ def test_preprocess_restatement_matches_reference_sequence():
     out = O.preprocess_image(img, True, 1.0, [103.939, 116.779, 123.680], [1, 1, 1], 600)
     assert out.dtype == np.float32 and out.shape == (3, 600, 800)
     assert np.array_equal(out, x.transpose(2, 0, 1))
+
+
+# ---- training step: oracle/train_oracle.py vs the fixtures captured from the reference's train_step ----
+def test_train_oracle_reproduces_reference_step(golden_dir, sd_cpu):
+    import random
+    from oracle import train_oracle as TO
+    g = np.load(os.path.join(golden_dir, "train_vgg16_352x480_s4.npz"))
+    seed, h, w = int(g["seed"]), int(g["height"]), int(g["width"])
+    img = synthetic.image(seed, h, w).unsqueeze(0)
+    gts = synthetic.ground_truth(seed, h, w)
+    am, vm = O.generate_anchor_maps((3, h, w), (512, h // 16, w // 16), 16)
+    gc = np.stack([k for _, k in gts])
+    gcls = np.array([c for c, _ in gts])
+    rmap, obj, bg = O.generate_rpn_map(am, vm, gc)
+    random.seed(int(g["rng_seed"])); t.manual_seed(int(g["rng_seed"]))
+    detail = {}
+    losses, grads, new_sd, bufs = TO.train_step(sd_cpu, img, am, vm, t.from_numpy(rmap).unsqueeze(0), obj, bg, gc, gcls, 21,
+                                                float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), None, detail=detail)
+    # host RNG use is platform independent: the sampled anchors must be the reference's
+    assert np.array_equal(detail["rpn_sample_flat"], g["s0_rpn_sample_flat"])
+    want = g["s0_losses"]
+    got = np.array([losses[n] for n in ("rpn_class", "rpn_regression", "detector_class", "detector_regression", "total")])
+    if detail["rpn_proposals"].shape[0] == int(g["s0_n_rpn_proposals"]) and \
+            np.array_equal(detail["proposal_sample_indices"].astype(np.int32), g["s0_proposal_sample_indices"]):
+        # same discrete selections as on the machine that wrote the fixture: float results agree to rounding
+        assert np.all(np.abs(got - want) <= 1e-5 * np.abs(want)), (got, want)
+        keys = [str(k) for k in g["train_keys"]]
+        for k in keys:
+            gk = grads[k].numpy().reshape(-1).astype(np.float64)
+            pos = np.unique(np.linspace(0, gk.shape[0] - 1, min(2048, gk.shape[0])).astype(np.int64))
+            ws = g["s0_gsample/" + k].astype(np.float64)
+            assert np.abs(gk[pos] - ws).max() <= 1e-4 * max(np.abs(ws).max(), 1e-12), k
+        for k in sd_cpu:
+            if k not in keys:
+                assert t.equal(new_sd[k], sd_cpu[k]), k            # frozen blocks and all biases untouched
+    else:
+        # a different CPU rounds the 13-layer forward differently and an RPN rank may flip: only coarse agreement
+        assert np.all(np.abs(got - want) <= 0.2 * np.abs(want) + 0.05), (got, want)
+
+
+def test_train_oracle_roi_pool_backward_routes_to_first_maximum():
+    from oracle import train_oracle as TO
+    fm = t.zeros((1, 2, 8, 8))
+    fm[0, 0, 2, 3] = 5.0                    # unique maximum of the whole map for channel 0; channel 1 all ties (zeros)
+    x = fm.clone().requires_grad_(True)
+    out = TO.roi_pool_autograd(x, t.tensor([[0.0, 0.0, 127.0, 127.0]]))
+    assert t.equal(out.detach(), t.from_numpy(O.roi_pool(fm.numpy(), np.array([[0, 0, 0, 127, 127]], dtype=np.float32), 7, 1 / 16.0)))
+    out.sum().backward()
+    gx = x.grad[0]
+    assert float(gx[0, 2, 3]) == float((out[0, 0] == 5.0).sum())      # every bin whose window holds (2,3) routes there
+    assert float(gx[1].sum()) == 49.0 and float(gx[1, 0, 0]) >= 1.0   # ties -> first cell of each window
