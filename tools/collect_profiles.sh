@@ -16,6 +16,10 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_IN
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $P > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?"
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $P > $OUT/pmc_write.log 2>&1; echo "pmc write exit $?"
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL --output-format csv -d $OUT/pmc_lds -o p -- $P > $OUT/pmc_lds.log 2>&1; echo "pmc lds exit $?"
+# train step: wall time per step + per-kernel stats
+timeout 600 python tools/train_bench.py --steps 20 --warmup 3 > $OUT/train_bench.json 2> $OUT/train_bench.err; echo "train bench exit $?"; cat $OUT/train_bench.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -o t -- python tools/train_bench.py --steps 8 --warmup 2 > $OUT/trace_train.log 2>&1; echo "train trace exit $?"
+rm -f $OUT/trace_train/t_kernel_trace.csv
 ls -la $OUT $OUT/trace | head -40
 # keep the merged output small: drop the raw per-dispatch traces beyond what the summary needs
 python tools/summarize_profiles.py $OUT > $OUT/summary.md 2> $OUT/summary.err; echo "summary exit $?"; head -60 $OUT/summary.md

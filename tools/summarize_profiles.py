@@ -32,6 +32,19 @@ def main(d):
             print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                      float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
         print()
+    tb = os.path.join(d, "train_bench.json")
+    if os.path.exists(tb):
+        lines = [l for l in open(tb).read().splitlines() if l.startswith("{")]
+        if lines:
+            print("## tools/train_bench.py (train step, SURVEY section 8 row f3)\n\n```json\n%s\n```\n" % lines[-1])
+    tstats = load(os.path.join(d, "trace_train", "*kernel_stats.csv"))
+    if tstats:
+        print("## train step: kernel stats (tools/train_bench.py --steps 8 --warmup 2 = 10 steps)\n")
+        print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+        for r in tstats[:24]:
+            print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                     float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+        print()
     # per-layer conv durations by grid
     kt = load(os.path.join(d, "trace", "*kernel_trace.csv"))
     if kt:
@@ -80,5 +93,30 @@ def main(d):
             print()
 
 
+def traffic(d):
+    """
+    HBM bytes per conv3x3_mfma launch from the separate FETCH_SIZE / WRITE_SIZE passes (KiB per dispatch), with the
+    gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE reports half of the bytes of
+    wide coalesced reads -> doubled; WRITE_SIZE taken as is.  Written to <dir>/traffic.json (bench.py reads the copy
+    committed under profiles/rNN/).
+    """
+    import json
+    out = {}
+    for tag, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        rows = [r for r in load(os.path.join(d, tag, "*counter_collection.csv"))
+                if "conv3x3_mfma" in r["Kernel_Name"] and r["Counter_Name"] == name]
+        if not rows:
+            return
+        disp = {r["Dispatch_Id"] for r in rows}
+        out[name] = (sum(float(r["Counter_Value"]) for r in rows) / len(disp), len(disp))
+    f, w = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
+    rec = {"source": "%s (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, single stream)" % d,
+           "kernel": "conv3x3_mfma_kernel (all instantiations)", "launches": out["FETCH_SIZE"][1],
+           "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w, "fetch_correction": 2.0,
+           "hbm_bytes_per_launch": f * 1024 * 2.0 + w * 1024}
+    json.dump(rec, open(os.path.join(d, "traffic.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    traffic(sys.argv[1])

@@ -1,0 +1,67 @@
+"""
+Times FasterRCNNModel.train_step (VGG-16, one 600x1000 synthetic sample per step) on cuda:0 and prints one JSON line.
+Informational: BASELINE.json's headline metric is inference throughput (bench.py); this reports the cost of
+SURVEY.md section 8 row f3 on the same hardware.
+  python tools/train_bench.py [--steps 20] [--warmup 3] [--height 600 --width 1000] [--lr 1e-6]
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fasterrcnn_amd import synthetic, training                                   # noqa: E402
+from fasterrcnn_amd.datasets.training_sample import Box                          # noqa: E402
+from fasterrcnn_amd.models import anchors                                        # noqa: E402
+from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel                    # noqa: E402
+from fasterrcnn_amd.models.vgg16 import VGG16Backbone                            # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=600)
+    ap.add_argument("--width", type=int, default=1000)
+    ap.add_argument("--lr", type=float, default=1e-6)
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic samples cycled through")
+    args = ap.parse_args()
+    h, w = args.height, args.width
+    model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+    model.load_state_dict(synthetic.vgg16_state_dict(1234), strict=True)
+    model = model.cuda()
+    am, vm = anchors.generate_anchor_maps((3, h, w), (512, h // 16, w // 16), 16)
+    samples = []
+    for seed in range(args.pool):
+        gts = synthetic.ground_truth(seed, h, w)
+        boxes = [Box(c, "x", k) for c, k in gts]
+        rmap, obj, bg = anchors.generate_rpn_map(am, vm, boxes)
+        samples.append((synthetic.image(seed, h, w).unsqueeze(0).cuda(), torch.from_numpy(rmap).unsqueeze(0).cuda(), obj, bg, boxes))
+    opt = training.create_optimizer(model, learning_rate=args.lr)
+    random.seed(0); torch.manual_seed(0)
+    losses = []
+
+    def step(i):
+        img, rmap, obj, bg, boxes = samples[i % len(samples)]
+        return model.train_step(opt, img, am, vm, rmap, [obj], [bg], [boxes])
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses.append(step(i).total)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "train_step (VGG-16 Faster R-CNN, %dx%d, batch 1)" % (h, w), "ms_per_step": 1e3 * dt / args.steps,
+                      "steps_per_sec": args.steps / dt, "steps": args.steps, "warmup": args.warmup, "dtype": "f32",
+                      "first_total_loss": losses[0], "last_total_loss": losses[-1], "data": "synthetic"}))
+
+
+if __name__ == "__main__":
+    main()
