@@ -42,7 +42,13 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--x6", action="store_true", help="time the f32x6 (bf16x3 split) conv kernels")
+    ap.add_argument("--shape", type=str, action="append", default=[], help="extra layer: cin,cout,h,w,pool (repeatable)")
     args = ap.parse_args()
+    for i, sh in enumerate(args.shape):
+        cin, cout, h, w, pool = (int(v) for v in sh.split(","))
+        LAYERS.append(("custom%d" % i, cin, cout, h, w, bool(pool)))
+    if args.shape and not args.only:
+        args.only = "custom"
     nv.require_gpu()
     lib = nv.lib()
     dev = "cuda:0"
