@@ -19,6 +19,7 @@
 // adjacent registers of one lane), then NHWC stores of 128 B per half-wave.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace frcnn {
 
@@ -237,6 +238,256 @@ void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ 
     }
 }
 
+// ---- software-pipelined variant ------------------------------------------------------------------
+// Same tiles, same LDS layout, same arithmetic order per accumulator; only the instruction schedule of
+// the K loop differs.  Measured on the skeletons in tools/micro/: a wave that has MFMAs ready starves
+// the younger waves of its SIMD, so the staging instructions of a wave are NOT hidden by the other
+// resident waves -- they must be issued in the shadow of the wave's own MFMAs.  Per stage (chunk c, tap t):
+//   F0(s) is in registers | read F1(s) | LDS-write the tile of stage s+1 | global-load the tile of stage s+2 |
+//   16 MFMAs on F0 with those instructions interleaved one per MFMA | barrier |
+//   read F0(s+1) interleaved with the 16 MFMAs on F1
+// One barrier per stage still suffices: every read of a buffer happens before the barrier of the stage
+// that owns it, every write to it after the barrier of the previous stage.  The 9 taps are unrolled so each
+// stage is one basic block (the halo is loaded in tap 7 and written in tap 8 of the previous chunk).
+template <int WM, int WN, bool POOL>
+__global__ __launch_bounds__(256)
+void conv3x3_mfma2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                          const float* __restrict__ bias, float* __restrict__ y,
+                          int H, int W, int Cin, int Cout, int relu, int cout_tiles, int chunks_per_split,
+                          float* __restrict__ ws, const float* __restrict__ zeros)
+{
+    using C = ConvCfg<WM, WN>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const halo0 = smem;
+    float* const wts0  = smem + 2 * C::HALO_F;
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int x0 = blockIdx.x * 32;
+    const int y0 = blockIdx.y * C::TR;
+    const int ksplit_idx = blockIdx.z / cout_tiles;
+    const int n0 = (blockIdx.z - ksplit_idx * cout_tiles) * C::BN;
+
+    // staging addresses (32-bit element offsets, as in conv3x3_mfma_kernel).  Out-of-image halo pieces are loaded from
+    // offset 0 (always valid) and zeroed by a select before the LDS write: no predicated loads in the pipelined loop.
+    int h_src[C::NH], h_dst[C::NH];
+    unsigned h_inb = 0;
+#pragma unroll
+    for (int it = 0; it < C::NH; ++it) {
+        int q = tid + 256 * it;
+        if (q >= C::NHP) q = C::NHP - 1;                       // surplus threads duplicate the last piece (same value, same slot)
+        const int pix = q >> 2, p = q & 3;
+        const int hy = pix / HC, hx = pix - hy * HC;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        h_dst[it] = pix * LDK + 4 * p;
+        h_src[it] = inb ? ((gy * W + gx) * Cin + 4 * p) * 4 : 0;       // BYTE offset from the (uniform) chunk base
+        h_inb |= (inb ? 1u : 0u) << it;
+    }
+    int w_src[C::NW], w_dst[C::NW];
+#pragma unroll
+    for (int it = 0; it < C::NW; ++it) {
+        const int q = tid + 256 * it;
+        const int o = q >> 2, p = q & 3;
+        w_src[it] = ((n0 + o) * Cin + 4 * p) * 4;                       // BYTE offset from the (uniform) tap/chunk base
+        w_dst[it] = o * LDK + 4 * p;
+    }
+    const int tap_stride = Cout * Cin;
+
+    f32x4 hreg[C::NH];
+    f32x4 wreg[C::NW];
+    auto load_halo = [&](int chunk) {
+        // uniform base in SGPRs + one 32-bit per-lane byte offset (global_load saddr form: no 64-bit address VGPRs)
+        const char* base = reinterpret_cast<const char*>(x + chunk * 16);
+#pragma unroll
+        for (int it = 0; it < C::NH; ++it) hreg[it] = *reinterpret_cast<const f32x4*>(base + (unsigned)h_src[it]);
+    };
+    auto store_halo = [&](float* buf) {
+#pragma unroll
+        for (int it = 0; it < C::NH; ++it) {
+            f32x4 v = hreg[it];
+            if (!((h_inb >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(buf + h_dst[it]) = v;
+        }
+    };
+    auto load_w = [&](int chunk, int tap) {
+        const char* base = reinterpret_cast<const char*>(wp + (size_t)tap * tap_stride + chunk * 16);
+#pragma unroll
+        for (int it = 0; it < C::NW; ++it) wreg[it] = *reinterpret_cast<const f32x4*>(base + (unsigned)w_src[it]);
+    };
+    auto store_w = [&](float* buf) {
+#pragma unroll
+        for (int it = 0; it < C::NW; ++it) *reinterpret_cast<f32x4*>(buf + w_dst[it]) = wreg[it];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int chunk_begin = ksplit_idx * chunks_per_split;
+    int chunk_end = chunk_begin + chunks_per_split;
+    if (chunk_end > (Cin >> 4)) chunk_end = Cin >> 4;
+    const int last_chunk = chunk_end - 1;
+
+    const int a_base = ((2 * wm) * HC + li) * LDK + 4 * lh;
+    const int b_base = (64 * wn + li) * LDK + 4 * lh;
+
+    // prologue: tile of stage 0 in LDS, weights of stage 1 in registers, F0 of stage 0 in registers
+    load_halo(chunk_begin);
+    load_w(chunk_begin, 0);
+    store_halo(halo0 + (chunk_begin & 1) * C::HALO_F);
+    store_w(wts0);
+    load_w(chunk_begin, 1);
+    __syncthreads();
+    f32x4 a0[2], b0[2], a1[2], b1[2];
+    {
+        const float* hal = halo0 + (chunk_begin & 1) * C::HALO_F + a_base;
+        const float* wt = wts0 + b_base;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a0[mt] = *reinterpret_cast<const f32x4*>(hal + mt * HC * LDK);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b0[nt] = *reinterpret_cast<const f32x4*>(wt + nt * 32 * LDK);
+    }
+
+    int wpar = 0;                                    // weight buffer of the current stage
+    for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+        const int nchunk = chunk < last_chunk ? chunk + 1 : last_chunk;      // clamped: surplus prefetches are harmless
+        float* const hal_cur = halo0 + (chunk & 1) * C::HALO_F;
+        float* const hal_nxt = halo0 + ((chunk + 1) & 1) * C::HALO_F;
+        auto stage = [&](auto tap_c) {
+            constexpr int tap = decltype(tap_c)::value;
+            constexpr int tr = tap / 3, ts = tap % 3;
+            const float* hal = hal_cur + a_base + (tr * HC + ts) * LDK;
+            const float* wt = wts0 + wpar * C::WT_F + b_base;
+            float* const wt_nxt = wts0 + (wpar ^ 1) * C::WT_F;
+            // b. second-half fragments of this stage
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a1[mt] = *reinterpret_cast<const f32x4*>(hal + mt * HC * LDK + 8);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) b1[nt] = *reinterpret_cast<const f32x4*>(wt + nt * 32 * LDK + 8);
+            // c. tile of stage s+1 -> LDS (weights every stage; the next chunk's halo in tap 8)
+            store_w(wt_nxt);
+            if (tap == 8) store_halo(hal_nxt);
+            // d. global loads for stage s+2
+            if (tap <= 6) load_w(chunk, tap + 2); else load_w(nchunk, tap - 7);
+            if (tap == 7) load_halo(nchunk);
+            // e. first half: 16 MFMAs on F0
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt][kk], b0[nt][kk], acc[mt][nt], 0, 0, 0);
+            // one staging instruction in the shadow of each MFMA
+            {
+                constexpr int n_wr = C::NW + (tap == 8 ? C::NH : 0);
+                constexpr int n_ld = C::NW + (tap == 7 ? C::NH : 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+                for (int q = 0; q < n_wr; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+#pragma unroll
+                for (int q = 0; q < n_ld; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // f. the tile of stage s+1 is complete; nobody reads this stage's buffers any more
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            // g. first-half fragments of stage s+1
+            {
+                constexpr int ntr = (tap + 1) % 9 / 3, nts = (tap + 1) % 3;
+                const float* nhal = (tap == 8 ? hal_nxt : hal_cur) + a_base + (ntr * HC + nts) * LDK;
+                const float* nwt = wt_nxt + b_base;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) a0[mt] = *reinterpret_cast<const f32x4*>(nhal + mt * HC * LDK);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) b0[nt] = *reinterpret_cast<const f32x4*>(nwt + nt * 32 * LDK);
+            }
+            // h. second half: 16 MFMAs on F1
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][kk], b1[nt][kk], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            wpar ^= 1;
+        };
+        stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{}); stage(std::integral_constant<int, 2>{});
+        stage(std::integral_constant<int, 3>{}); stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
+        stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{}); stage(std::integral_constant<int, 8>{});
+    }
+
+    // ---- epilogue (identical to conv3x3_mfma_kernel) -------------------------------------------
+    const int orow = y0 + 2 * wm;
+    if (ws != nullptr) {
+        float* part = ws + (size_t)ksplit_idx * H * W * Cout;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = n0 + 64 * wn + 32 * nt + li;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int yy = orow + mt;
+                if (yy >= H) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int xx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (xx < W) part[((size_t)yy * W + xx) * Cout + co] = acc[mt][nt][r];
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int co = n0 + 64 * wn + 32 * nt + li;
+        const float bv = bias[co];
+        if (!POOL) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int yy = orow + mt;
+                if (yy >= H) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int xx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (xx < W) {
+                        float v = acc[mt][nt][r] + bv;
+                        if (relu) v = fmaxf(v, 0.f);
+                        y[((size_t)yy * W + xx) * Cout + co] = v;
+                    }
+                }
+            }
+        } else {
+            const int Hp = H >> 1, Wp = W >> 1;
+            const int py = orow >> 1;
+            if (py < Hp) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int px = (x0 + (r & 3) + 8 * (r >> 2) + 4 * lh) >> 1;
+                    if (px < Wp) {
+                        float v = fmaxf(fmaxf(acc[0][nt][r], acc[0][nt][r + 1]),
+                                        fmaxf(acc[1][nt][r], acc[1][nt][r + 1])) + bv;
+                        if (relu) v = fmaxf(v, 0.f);
+                        y[((size_t)py * Wp + px) * Cout + co] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Split-K finish: y = act(bias + sum_k part[k]) (+ 2x2 max-pool), fixed summation order.
 __global__ __launch_bounds__(256)
 void conv_splitk_finish_kernel(const float* __restrict__ ws, int ksplit, const float* __restrict__ bias,
@@ -371,6 +622,28 @@ static int launch_cfg(const float* x, const float* wp, const float* b, float* y,
                       int cin, int cout, int relu, int ksplit, float* ws, hipStream_t s)
 {
     using C = ConvCfg<WM, WN>;
+    const int cout_tiles = cout / C::BN;
+    const int nchunks = cin / 16;
+    dim3 grid(cdiv(W, 32), cdiv(H, C::TR), cout_tiles * ksplit);
+    static int v2 = -1;
+    if (v2 < 0) { const char* e = getenv("FRCNN_CONV_V2"); v2 = e ? atoi(e) : 1; }
+    if (v2) {
+        auto kern2 = conv3x3_mfma2_kernel<WM, WN, POOL>;
+        static bool attr2_set = false;
+        static float* zeros = nullptr;
+        if (!attr2_set) {
+            FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+            attr2_set = true;
+        }
+        if (!zeros) {
+            FRCNN_HIP_TRY(hipMalloc(&zeros, 256));
+            FRCNN_HIP_TRY(hipMemset(zeros, 0, 256));
+        }
+        hipLaunchKernelGGL(kern2, grid, dim3(256), C::LDS_BYTES, s, x, wp, b, y, H, W, cin, cout, relu, cout_tiles,
+                           cdiv(nchunks, ksplit), ksplit > 1 ? ws : (float*)nullptr, (const float*)zeros);
+        return check_launch();
+    }
     auto kern = conv3x3_mfma_kernel<WM, WN, POOL>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -378,9 +651,6 @@ static int launch_cfg(const float* x, const float* wp, const float* b, float* y,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_set = true;
     }
-    const int cout_tiles = cout / C::BN;
-    const int nchunks = cin / 16;
-    dim3 grid(cdiv(W, 32), cdiv(H, C::TR), cout_tiles * ksplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, x, wp, b, y, H, W, cin, cout, relu, cout_tiles,
                        cdiv(nchunks, ksplit), ksplit > 1 ? ws : (float*)nullptr);
     return check_launch();

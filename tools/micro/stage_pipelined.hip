@@ -11,7 +11,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
-template <int V>
+template <int V, int IL>
 __global__ __launch_bounds__(256) void skel(float* out, int stages, const float* gsrc)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -35,23 +35,32 @@ __global__ __launch_bounds__(256) void skel(float* out, int stages, const float*
             a1[j] = *reinterpret_cast<const f32x4*>(&lds[cur + ((ra + (j + 2) * 1280) & 4092)]);
             b1[j] = *reinterpret_cast<const f32x4*>(&lds[cur + ((rb + (j + 2) * 1280) & 4092)]);
         }
-        SB();
+        if (!IL) SB();
         // c. stage s+1 tile -> LDS
 #pragma unroll
         for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(&lds[nxt + ((tid * 4 + j * 1024) & 4092)]) = g[j];
-        SB();
+        if (!IL) SB();
         // d. global loads for stage s+2
         if (V & 8) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) g[j] = *reinterpret_cast<const f32x4*>(gsrc + ((tid * 4 + j * 1024 + (s & 31) * 8192) & 0xFFFFC));
         }
-        SB();
+        if (!IL) SB();
         // e. 16 MFMAs on F0
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i >> 1][kk], b0[i & 1][kk], acc[i], 0, 0, 0);
+        if (IL) {
+            // one staging instruction in the shadow of each MFMA: 4 ds_read, 6 ds_write, 6 global loads under 16 MFMAs
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        }
         SB();
         // f. barrier
         __syncthreads();
@@ -60,13 +69,17 @@ __global__ __launch_bounds__(256) void skel(float* out, int stages, const float*
 #pragma unroll
         for (int j = 0; j < 2; ++j) { a0[j] = *reinterpret_cast<const f32x4*>(&lds[nxt + ra + j * 1280 - (ra + j * 1280 > 4092 ? 4096 : 0)]);
                                       b0[j] = *reinterpret_cast<const f32x4*>(&lds[nxt + ((rb + j * 1280) & 4092)]); }
-        SB();
+        if (!IL) SB();
         // h. 16 MFMAs on F1
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i >> 1][kk], b1[i & 1][kk], acc[i], 0, 0, 0);
+        if (IL) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        }
         SB();
     }
     float sum = 0.f;
@@ -74,21 +87,21 @@ __global__ __launch_bounds__(256) void skel(float* out, int stages, const float*
     out[blockIdx.x * 256 + tid] = sum + g[0][0];
 }
 
-template <int V>
+template <int V, int IL>
 void run(int per_cu, int cus, const char* what)
 {
     const int blocks = per_cu * cus, stages = 2000;
     float *out, *gsrc;
     hipMalloc(&out, (size_t)blocks * 256 * 4); hipMalloc(&gsrc, 4 << 20); hipMemset(gsrc, 0, 4 << 20);
     const int lds_bytes = 53 * 1024;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(skel<V>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(skel<V, IL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     int occ = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, skel<V>, 256, lds_bytes);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (skel<V, IL>), 256, lds_bytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(skel<V>, dim3(blocks), dim3(256), lds_bytes, 0, out, stages, gsrc);
+        hipLaunchKernelGGL((skel<V, IL>), dim3(blocks), dim3(256), lds_bytes, 0, out, stages, gsrc);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
@@ -103,7 +116,10 @@ int main()
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
-    run<8>(3, cus, "warm-up");
-    for (int per_cu = 1; per_cu <= 3; ++per_cu) { run<0>(per_cu, cus, "pipelined, no global"); run<8>(per_cu, cus, "pipelined, with global"); }
+    run<8, 0>(3, cus, "warm-up");
+    for (int per_cu = 1; per_cu <= 3; ++per_cu) {
+        run<0, 0>(per_cu, cus, "grouped, no global"); run<8, 0>(per_cu, cus, "grouped, with global");
+        run<0, 1>(per_cu, cus, "interleaved, no global"); run<8, 1>(per_cu, cus, "interleaved, with global");
+    }
     return 0;
 }
