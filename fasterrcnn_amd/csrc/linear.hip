@@ -8,7 +8,7 @@
 // Both operands are K-contiguous, so they are staged exactly like the conv kernel's tiles:
 // [rows][16 k] chunks in LDS, rows padded to 20 floats (conflict-free ds_read_b128), the lane
 // half h owning k in [8g+4h, 8g+4h+4) so one b128 read feeds four MFMAs.  One barrier per
-// 16-k stage, double-buffered.
+// 16-k stage, double-buffered; the K loop is software pipelined (see the comment in the kernel).
 // The detector GEMMs have M = 300 rows only (one image's RoIs) against K = 25088 / 4096: the
 // block tile spans ALL rows (320 x 128) so the 411 MB fc1 weight matrix is streamed exactly
 // once, and the grid is filled by deterministic split-K (partials to scratch, fixed-order
@@ -53,42 +53,44 @@ void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __res
     if (st_end > total_stages) st_end = total_stages;
     const int nst = st_end - st_begin;
 
-    size_t a_src[C::NA]; bool a_ok[C::NA]; int a_dst[C::NA];
+    // staging addresses: byte offsets from the uniform k-stage base (saddr-form loads).  Rows beyond M re-read row M-1:
+    // they only feed output rows that the epilogue never stores, so no predication is needed.
+    unsigned a_src[C::NA]; int a_dst[C::NA];
 #pragma unroll
     for (int it = 0; it < C::NA; ++it) {
         const int q = tid + 256 * it, row = q >> 2, p = q & 3;
-        a_ok[it] = (m0 + row) < M;
-        a_src[it] = (size_t)(m0 + row) * lda + 4 * p;
+        const int gr = (m0 + row) < M ? (m0 + row) : M - 1;
+        a_src[it] = (unsigned)(((size_t)(gr - m0) * lda + 4 * p) * sizeof(float));
         a_dst[it] = row * LLDK + 4 * p;
     }
-    size_t b_src[C::NB]; int b_dst[C::NB];
+    unsigned b_src[C::NB]; int b_dst[C::NB];
 #pragma unroll
     for (int it = 0; it < C::NB; ++it) {
         const int q = tid + 256 * it, row = q >> 2, p = q & 3;
-        b_src[it] = (size_t)(n0 + row) * K + 4 * p;
+        b_src[it] = (unsigned)(((size_t)row * K + 4 * p) * sizeof(float));
         b_dst[it] = row * LLDK + 4 * p;
     }
+    const float* const a_blk = a + (size_t)m0 * lda;
+    const float* const w_blk = w + (size_t)n0 * K;
 
-    f32x4 areg[C::NA], breg[C::NB];
-    auto load_tiles = [&](int stage) {
-        const int k0 = stage << 4;
+    // two register sets: the tile of stage s+1 and the tile of stage s+2 are in flight at the same time (the weights
+    // of fc1 stream from HBM, one 2 us stage of prefetch distance is not enough with one wave per SIMD)
+    f32x4 areg[2][C::NA], breg[2][C::NB];
+    auto load_tiles = [&](int stage, f32x4 (&ar)[C::NA], f32x4 (&br)[C::NB]) {
+        const char* ab = reinterpret_cast<const char*>(a_blk + (stage << 4));
+        const char* wb = reinterpret_cast<const char*>(w_blk + (stage << 4));
 #pragma unroll
-        for (int it = 0; it < C::NA; ++it) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a_ok[it]) v = *reinterpret_cast<const f32x4*>(a + a_src[it] + k0);
-            areg[it] = v;
-        }
+        for (int it = 0; it < C::NA; ++it) ar[it] = *reinterpret_cast<const f32x4*>(ab + a_src[it]);
 #pragma unroll
-        for (int it = 0; it < C::NB; ++it)
-            breg[it] = *reinterpret_cast<const f32x4*>(w + b_src[it] + k0);
+        for (int it = 0; it < C::NB; ++it) br[it] = *reinterpret_cast<const f32x4*>(wb + b_src[it]);
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const f32x4 (&ar)[C::NA], const f32x4 (&br)[C::NB]) {
 #pragma unroll
         for (int it = 0; it < C::NA; ++it)
-            *reinterpret_cast<f32x4*>(at0 + buf * C::A_F + a_dst[it]) = areg[it];
+            *reinterpret_cast<f32x4*>(at0 + buf * C::A_F + a_dst[it]) = ar[it];
 #pragma unroll
         for (int it = 0; it < C::NB; ++it)
-            *reinterpret_cast<f32x4*>(bt0 + buf * C::B_F + b_dst[it]) = breg[it];
+            *reinterpret_cast<f32x4*>(bt0 + buf * C::B_F + b_dst[it]) = br[it];
     };
 
     f32x16 acc[TM][TN];
@@ -99,37 +101,84 @@ void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __res
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nst > 0) {
-        load_tiles(st_begin);
-        store_tiles(0);
-    }
-    __syncthreads();
-
     const int a_base = (32 * TM * wm + li) * LLDK + 4 * lh;
     const int b_base = (32 * TN * wn + li) * LLDK + 4 * lh;
 
-    for (int s = 0; s < nst; ++s) {
-        const bool has_next = (s + 1) < nst;
-        if (has_next) load_tiles(st_begin + s + 1);
-        const float* at = at0 + (s & 1) * C::A_F + a_base;
-        const float* bt = bt0 + (s & 1) * C::B_F + b_base;
+    // Software-pipelined K loop (same schedule as conv3x3_mfma2_kernel, csrc/conv.hip): per 16-k stage
+    //   F0(s) in registers | read F1(s) | LDS-write tile s+1 | global-load tile s+2 | MFMAs on F0, one staging
+    //   instruction per MFMA | barrier | read F0(s+1) under the MFMAs on F1.
+    // Prefetches past the last stage are clamped to it (harmless re-reads / re-writes of unused buffers).
+    f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
+    if (nst > 0) {
+        const int last = st_end - 1;
+        load_tiles(st_begin, areg[0], breg[0]);
+        store_tiles(0, areg[0], breg[0]);
+        load_tiles(st_begin + 1 < st_end ? st_begin + 1 : last, areg[0], breg[0]);     // tile 1 -> set 0
+        load_tiles(st_begin + 2 < st_end ? st_begin + 2 : last, areg[1], breg[1]);     // tile 2 -> set 1
+        __syncthreads();
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            f32x4 af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i) a0[i] = *reinterpret_cast<const f32x4*>(at0 + a_base + i * 32 * LLDK);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(at + i * 32 * LLDK + 8 * g);
+        for (int j = 0; j < TN; ++j) b0[j] = *reinterpret_cast<const f32x4*>(bt0 + b_base + j * 32 * LLDK);
+        constexpr int N_RD = TM + TN, N_ST = C::NA + C::NB;
+        // stage s: writes the tile of stage s+1 from register set (s & 1), then refills that set with the tile of stage s+3
+        auto stage = [&](int s, f32x4 (&ar)[C::NA], f32x4 (&br)[C::NB]) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            const float* at = at0 + cur * C::A_F + a_base;
+            const float* bt = bt0 + cur * C::B_F + b_base;
+            // b. second-half fragments
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bt + j * 32 * LLDK + 8 * g);
+            for (int i = 0; i < TM; ++i) a1[i] = *reinterpret_cast<const f32x4*>(at + i * 32 * LLDK + 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b1[j] = *reinterpret_cast<const f32x4*>(bt + j * 32 * LLDK + 8);
+            // c. tile s+1 -> LDS; d. tile s+2 -> registers
+            store_tiles(nxt, ar, br);
+            {
+                const int s3 = st_begin + s + 3;
+                load_tiles(s3 < st_end ? s3 : last, ar, br);
+            }
+            // e. first half
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
-        }
-        if (has_next) store_tiles((s + 1) & 1);
-        __syncthreads();
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], b0[j][kk], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < N_RD; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+            for (int q = 0; q < N_ST; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+#pragma unroll
+            for (int q = 0; q < N_ST; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            // f.
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            // g. first-half fragments of stage s+1
+            {
+                const float* nat = at0 + nxt * C::A_F + a_base;
+                const float* nbt = bt0 + nxt * C::B_F + b_base;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a0[i] = *reinterpret_cast<const f32x4*>(nat + i * 32 * LLDK);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b0[j] = *reinterpret_cast<const f32x4*>(nbt + j * 32 * LLDK);
+            }
+            // h. second half
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[j][kk], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < N_RD; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int s = 0;
+        for (; s + 1 < nst; s += 2) { stage(s, areg[0], breg[0]); stage(s + 1, areg[1], breg[1]); }
+        if (s < nst) stage(s, areg[0], breg[0]);
     }
 
     // epilogue: acc[i][j][r] = out[m0 + 32(TM wm + i) + (r&3)+8(r>>2)+4lh][n0 + 32(TN wn + j) + li]
