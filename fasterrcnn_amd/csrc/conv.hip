@@ -39,210 +39,12 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = (size_t)(2 * HALO_F + 2 * WT_F) * sizeof(float);
 };
 
-template <int WM, int WN, bool POOL>
-__global__ __launch_bounds__(256)
-void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                         const float* __restrict__ bias, float* __restrict__ y,
-                         int H, int W, int Cin, int Cout, int relu, int cout_tiles, int chunks_per_split,
-                         float* __restrict__ ws)
-{
-    using C = ConvCfg<WM, WN>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const halo0 = smem;
-    float* const wts0  = smem + 2 * C::HALO_F;
-
-    const int tid  = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, lh = lane >> 5;
-
-    const int x0 = blockIdx.x * 32;
-    const int y0 = blockIdx.y * C::TR;
-    // blockIdx.z = cout tile + cout_tiles * k-split index (split-K over 16-channel chunks)
-    const int ksplit_idx = blockIdx.z / cout_tiles;
-    const int n0 = (blockIdx.z - ksplit_idx * cout_tiles) * C::BN;
-
-    // ---- loop-invariant staging addresses ------------------------------------------------
-    int h_src[C::NH];   // element offset of the piece inside x for chunk 0, or -1 (zero fill)
-    int h_dst[C::NH];   // float offset inside a halo buffer, or -1 (no piece)
-#pragma unroll
-    for (int it = 0; it < C::NH; ++it) {
-        const int q = tid + 256 * it;
-        const int pix = q >> 2, p = q & 3;
-        const int hy = pix / HC, hx = pix - hy * HC;
-        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool have = q < C::NHP;
-        const bool inb = have && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        h_dst[it] = have ? pix * LDK + 4 * p : -1;
-        h_src[it] = inb ? (gy * W + gx) * Cin + 4 * p : -1;
-    }
-    int w_src[C::NW], w_dst[C::NW];
-#pragma unroll
-    for (int it = 0; it < C::NW; ++it) {
-        const int q = tid + 256 * it;
-        const int o = q >> 2, p = q & 3;
-        w_src[it] = (n0 + o) * Cin + 4 * p;
-        w_dst[it] = o * LDK + 4 * p;
-    }
-    const int tap_stride = Cout * Cin;
-
-    f32x4 hreg[C::NH];
-    f32x4 wreg[C::NW];
-
-    auto load_halo = [&](int chunk) {
-#pragma unroll
-        for (int it = 0; it < C::NH; ++it) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (h_src[it] >= 0) v = *reinterpret_cast<const f32x4*>(x + h_src[it] + chunk * 16);
-            hreg[it] = v;
-        }
-    };
-    auto store_halo = [&](float* buf) {
-#pragma unroll
-        for (int it = 0; it < C::NH; ++it)
-            if (h_dst[it] >= 0) *reinterpret_cast<f32x4*>(buf + h_dst[it]) = hreg[it];
-    };
-    auto load_w = [&](int chunk, int tap) {
-#pragma unroll
-        for (int it = 0; it < C::NW; ++it)
-            wreg[it] = *reinterpret_cast<const f32x4*>(wp + (size_t)tap * tap_stride + w_src[it] + chunk * 16);
-    };
-    auto store_w = [&](float* buf) {
-#pragma unroll
-        for (int it = 0; it < C::NW; ++it)
-            *reinterpret_cast<f32x4*>(buf + w_dst[it]) = wreg[it];
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int chunk_begin = ksplit_idx * chunks_per_split;
-    int chunk_end = chunk_begin + chunks_per_split;
-    if (chunk_end > (Cin >> 4)) chunk_end = Cin >> 4;
-    const int nstages = (chunk_end - chunk_begin) * 9;
-
-    // prologue: first chunk's halo + (first chunk, tap 0) weights
-    load_halo(chunk_begin);
-    load_w(chunk_begin, 0);
-    store_halo(halo0 + (chunk_begin & 1) * C::HALO_F);
-    store_w(wts0);
-    __syncthreads();
-
-    // per-lane LDS read bases (floats)
-    const int a_base = ((2 * wm) * HC + li) * LDK + 4 * lh;   // + (mt + r)*HC*LDK + s*LDK + 8g
-    const int b_base = (64 * wn + li) * LDK + 4 * lh;         // + nt*32*LDK + 8g
-
-    int chunk = chunk_begin, tap = 0, tr = 0, ts = 0;
-    for (int s = 0; s < nstages; ++s) {
-        const bool has_next = (s + 1) < nstages;
-        int nchunk = chunk, ntap = tap + 1;
-        if (ntap == 9) { ntap = 0; nchunk = chunk + 1; }
-        if (has_next) {
-            load_w(nchunk, ntap);
-            if (ntap == 0) load_halo(nchunk);
-        }
-
-        const float* hal = halo0 + (chunk & 1) * C::HALO_F + a_base + (tr * HC + ts) * LDK;
-        const float* wt  = wts0 + (s & 1) * C::WT_F + b_base;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            f32x4 af[2], bf[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                af[mt] = *reinterpret_cast<const f32x4*>(hal + mt * HC * LDK + 8 * g);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                bf[nt] = *reinterpret_cast<const f32x4*>(wt + nt * 32 * LDK + 8 * g);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][kk], bf[nt][kk],
-                                                                          acc[mt][nt], 0, 0, 0);
-        }
-
-        if (has_next) {
-            store_w(wts0 + ((s + 1) & 1) * C::WT_F);
-            if (ntap == 0) store_halo(halo0 + (nchunk & 1) * C::HALO_F);
-        }
-        __syncthreads();
-        chunk = nchunk; tap = ntap;
-        ts += 1; if (ts == 3) { ts = 0; tr += 1; if (tr == 3) tr = 0; }
-    }
-
-    // ---- epilogue ------------------------------------------------------------------------
-    // acc[mt][nt][r] = out[row y0+2wm+mt][col x0 + (r&3)+8(r>>2)+4lh][cout n0+64wn+32nt+li]
-    const int orow = y0 + 2 * wm;
-    if (ws != nullptr) {
-        // split-K: raw partial sums [ksplit][H][W][Cout]; bias/ReLU/pool happen in the finish kernel
-        float* part = ws + (size_t)ksplit_idx * H * W * Cout;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int co = n0 + 64 * wn + 32 * nt + li;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int yy = orow + mt;
-                if (yy >= H) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int xx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (xx < W) part[((size_t)yy * W + xx) * Cout + co] = acc[mt][nt][r];
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int co = n0 + 64 * wn + 32 * nt + li;
-        const float bv = bias[co];
-        if (!POOL) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int yy = orow + mt;
-                if (yy >= H) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int xx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (xx < W) {
-                        float v = acc[mt][nt][r] + bv;
-                        if (relu) v = fmaxf(v, 0.f);
-                        y[((size_t)yy * W + xx) * Cout + co] = v;
-                    }
-                }
-            }
-        } else {
-            const int Hp = H >> 1, Wp = W >> 1;
-            const int py = orow >> 1;
-            if (py < Hp) {
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int px = (x0 + (r & 3) + 8 * (r >> 2) + 4 * lh) >> 1;
-                    if (px < Wp) {
-                        float v = fmaxf(fmaxf(acc[0][nt][r], acc[0][nt][r + 1]),
-                                        fmaxf(acc[1][nt][r], acc[1][nt][r + 1])) + bv;
-                        if (relu) v = fmaxf(v, 0.f);
-                        y[((size_t)py * Wp + px) * Cout + co] = v;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ---- software-pipelined variant ------------------------------------------------------------------
-// Same tiles, same LDS layout, same arithmetic order per accumulator; only the instruction schedule of
-// the K loop differs.  Measured on the skeletons in tools/micro/: a wave that has MFMAs ready starves
-// the younger waves of its SIMD, so the staging instructions of a wave are NOT hidden by the other
-// resident waves -- they must be issued in the shadow of the wave's own MFMAs.  Per stage (chunk c, tap t):
+// ---- the K loop is software pipelined ------------------------------------------------------------
+// Measured on the skeletons in tools/micro/: a wave that has MFMAs ready starves the younger waves of
+// its SIMD, so the staging instructions of a wave are NOT hidden by the other resident waves -- they
+// must be issued in the shadow of the wave's own MFMAs (a loop that does staging, then 32 MFMAs, then
+// a barrier tops out at 85 % of the pipe however many waves are resident; this order reaches 99 % in
+// the loop, 146 TFLOP/s on a long-K layer).  Per stage (chunk c, tap t):
 //   F0(s) is in registers | read F1(s) | LDS-write the tile of stage s+1 | global-load the tile of stage s+2 |
 //   16 MFMAs on F0 with those instructions interleaved one per MFMA | barrier |
 //   read F0(s+1) interleaved with the 16 MFMAs on F1
@@ -251,10 +53,10 @@ void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ 
 // stage is one basic block (the halo is loaded in tap 7 and written in tap 8 of the previous chunk).
 template <int WM, int WN, bool POOL>
 __global__ __launch_bounds__(256)
-void conv3x3_mfma2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                          const float* __restrict__ bias, float* __restrict__ y,
-                          int H, int W, int Cin, int Cout, int relu, int cout_tiles, int chunks_per_split,
-                          float* __restrict__ ws, const float* __restrict__ zeros)
+void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                         const float* __restrict__ bias, float* __restrict__ y,
+                         int H, int W, int Cin, int Cout, int relu, int cout_tiles, int chunks_per_split,
+                         float* __restrict__ ws)
 {
     using C = ConvCfg<WM, WN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -430,7 +232,8 @@ void conv3x3_mfma2_kernel(const float* __restrict__ x, const float* __restrict__
         stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{}); stage(std::integral_constant<int, 8>{});
     }
 
-    // ---- epilogue (identical to conv3x3_mfma_kernel) -------------------------------------------
+    // ---- epilogue ------------------------------------------------------------------------------
+    // acc[mt][nt][r] = out[row y0+2wm+mt][col x0 + (r&3)+8(r>>2)+4lh][cout n0+64wn+32nt+li]
     const int orow = y0 + 2 * wm;
     if (ws != nullptr) {
         float* part = ws + (size_t)ksplit_idx * H * W * Cout;
@@ -625,25 +428,6 @@ static int launch_cfg(const float* x, const float* wp, const float* b, float* y,
     const int cout_tiles = cout / C::BN;
     const int nchunks = cin / 16;
     dim3 grid(cdiv(W, 32), cdiv(H, C::TR), cout_tiles * ksplit);
-    static int v2 = -1;
-    if (v2 < 0) { const char* e = getenv("FRCNN_CONV_V2"); v2 = e ? atoi(e) : 1; }
-    if (v2) {
-        auto kern2 = conv3x3_mfma2_kernel<WM, WN, POOL>;
-        static bool attr2_set = false;
-        static float* zeros = nullptr;
-        if (!attr2_set) {
-            FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-            attr2_set = true;
-        }
-        if (!zeros) {
-            FRCNN_HIP_TRY(hipMalloc(&zeros, 256));
-            FRCNN_HIP_TRY(hipMemset(zeros, 0, 256));
-        }
-        hipLaunchKernelGGL(kern2, grid, dim3(256), C::LDS_BYTES, s, x, wp, b, y, H, W, cin, cout, relu, cout_tiles,
-                           cdiv(nchunks, ksplit), ksplit > 1 ? ws : (float*)nullptr, (const float*)zeros);
-        return check_launch();
-    }
     auto kern = conv3x3_mfma_kernel<WM, WN, POOL>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -14,7 +14,7 @@
 //
 // Exact-f32 matrix pipe (v_mfma_f32_32x32x2_f32).  Block = 128 x 128 output tile, 4 waves of
 // 64 x 64.  Both operands are staged as [16 reduction rows][128] floats in LDS (coalesced 512-B
-// global rows, double buffered, one barrier per 32 MFMAs/wave).  The MFMA wants one A value per lane
+// global rows, double buffered, one barrier per 32 MFMAs/wave, software-pipelined like the conv kernel).  The MFMA wants one A value per lane
 // (m = lane & 31, k = lane >> 5); the wave's 64 m-values are assigned as m = 2*(lane&31) + mt so a
 // single ds_read_b64 feeds both m-tiles (likewise n), and the half-waves read two different LDS rows
 // -> conflict-free without padding.  The accumulator's column index is then n = 2*(lane&31) + nt:
@@ -54,6 +54,7 @@ void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restric
     const int prow0 = tid >> 5, pcol = (tid & 31) * 4;      // second piece: row + 8
     const bool a_col_ok = m0 + pcol + 4 <= lda;
     const bool b_col_ok = n0 + pcol + 4 <= ldb;
+    unsigned ok_bits = 0;      // per piece: bit 0 = A piece valid, bit 1 = B piece valid (set by load_stage)
 
     f32x4 areg[2], breg[2];
     auto load_stage = [&](int r0) {
@@ -63,9 +64,7 @@ void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restric
             const bool r_ok = r < r_end;
             const bool a_ok = r_ok && a_col_ok;
             const size_t a_off = a_ok ? (size_t)r * lda + m0 + pcol : 0;
-            f32x4 av = *reinterpret_cast<const f32x4*>(A + a_off);
-            if (!a_ok) av = f32x4{0.f, 0.f, 0.f, 0.f};
-            areg[it] = av;
+            areg[it] = *reinterpret_cast<const f32x4*>(A + a_off);
             bool b_ok = r_ok && b_col_ok;
             size_t b_row = (size_t)r;
             if (CONV) {
@@ -75,16 +74,19 @@ void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restric
                 b_row = (size_t)(sy * img_w + sx);
             }
             const size_t b_off = b_ok ? b_row * ldb + n0 + pcol : 0;
-            f32x4 bv = *reinterpret_cast<const f32x4*>(B + b_off);
-            if (!b_ok) bv = f32x4{0.f, 0.f, 0.f, 0.f};
-            breg[it] = bv;
+            breg[it] = *reinterpret_cast<const f32x4*>(B + b_off);
+            ok_bits = (ok_bits & ~(3u << (2 * it))) | ((a_ok ? 1u : 0u) << (2 * it)) | ((b_ok ? 2u : 0u) << (2 * it));
         }
     };
-    auto store_stage = [&](int buf) {
+    // invalid pieces were loaded from offset 0 (always readable); they are zeroed here, on the way into LDS
+    auto store_stage = [&](int buf, unsigned ok) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            *reinterpret_cast<f32x4*>(&As[buf][prow0 + 8 * it][pcol]) = areg[it];
-            *reinterpret_cast<f32x4*>(&Bs[buf][prow0 + 8 * it][pcol]) = breg[it];
+            f32x4 av = areg[it], bv = breg[it];
+            if (!((ok >> (2 * it)) & 1u)) av = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!((ok >> (2 * it)) & 2u)) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&As[buf][prow0 + 8 * it][pcol]) = av;
+            *reinterpret_cast<f32x4*>(&Bs[buf][prow0 + 8 * it][pcol]) = bv;
         }
     };
 
@@ -96,28 +98,66 @@ void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // Software-pipelined reduction loop (the schedule of conv3x3_mfma_kernel, csrc/conv.hip): per 16-row stage
+    //   F0(s) = fragments of reduction rows 0..7 in registers | read F1(s) (rows 8..15) | LDS-write stage s+1 |
+    //   global-load stage s+2 | 16 MFMAs on F0, one staging instruction per MFMA | barrier | read F0(s+1) under the
+    //   16 MFMAs on F1.  Loads past the range are clamped by the validity bits (zero contribution).
     const int nstages = (r_end - r_begin + GT_RK - 1) / GT_RK;
     if (nstages > 0) {
+        unsigned ok_w;                                // validity of the tile currently held in areg / breg
         load_stage(r_begin);
-        store_stage(0);
-    }
-    __syncthreads();
-    for (int s = 0; s < nstages; ++s) {
-        const bool has_next = s + 1 < nstages;
-        if (has_next) load_stage(r_begin + (s + 1) * GT_RK);
-        const int buf = s & 1;
-#pragma unroll
-        for (int kk = 0; kk < GT_RK / 2; ++kk) {
-            const f32x2 a2 = *reinterpret_cast<const f32x2*>(&As[buf][2 * kk + lh][wm * 64 + 2 * li]);
-            const f32x2 b2 = *reinterpret_cast<const f32x2*>(&Bs[buf][2 * kk + lh][wn * 64 + 2 * li]);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt], b2[nt], acc[mt][nt], 0, 0, 0);
-        }
-        if (has_next) store_stage(buf ^ 1);
+        store_stage(0, ok_bits);
+        load_stage(r_begin + GT_RK);
+        ok_w = ok_bits;
         __syncthreads();
+        f32x2 a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            a0[kk] = *reinterpret_cast<const f32x2*>(&As[0][2 * kk + lh][wm * 64 + 2 * li]);
+            b0[kk] = *reinterpret_cast<const f32x2*>(&Bs[0][2 * kk + lh][wn * 64 + 2 * li]);
+        }
+        for (int s = 0; s < nstages; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                a1[kk] = *reinterpret_cast<const f32x2*>(&As[cur][8 + 2 * kk + lh][wm * 64 + 2 * li]);
+                b1[kk] = *reinterpret_cast<const f32x2*>(&Bs[cur][8 + 2 * kk + lh][wn * 64 + 2 * li]);
+            }
+            store_stage(nxt, ok_w);
+            load_stage(r_begin + (s + 2) * GT_RK);
+            ok_w = ok_bits;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk][mt], b0[kk][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                a0[kk] = *reinterpret_cast<const f32x2*>(&As[nxt][2 * kk + lh][wm * 64 + 2 * li]);
+                b0[kk] = *reinterpret_cast<const f32x2*>(&Bs[nxt][2 * kk + lh][wn * 64 + 2 * li]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk][mt], b1[kk][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // acc[mt][nt][reg] = C[m0 + 64 wm + 2 i + mt][n0 + 64 wn + 2 li + nt],  i = (reg&3) + 8 (reg>>2) + 4 lh
