@@ -81,34 +81,45 @@ void conv_gather_mfma_kernel(const float* __restrict__ x, const float* __restric
     }
     const int p4 = (tid & 3) * 4;
 
+    // Loads are never predicated (a predicated load costs an immediate vmcnt(0)): an invalid piece is read from offset 0
+    // and zeroed by a select on its way into LDS.  `ok` carries one validity bit per piece of the tile held in registers.
     f32x4 areg[C::NA], breg[C::NB];
+    unsigned ok_bits = 0;
     auto load_tiles = [&](int stage) {
         const int chunk = stage / taps, tap = stage - chunk * taps;
         const int r = tap / g.S, s = tap - r * g.S;
         const int c0 = chunk * 16 + p4;
+        unsigned ok = 0;
 #pragma unroll
         for (int it = 0; it < C::NA; ++it) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int iy = a_iy[it] + r, ix = a_ix[it] + s;
-            if (a_img[it] >= 0 && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
-                v = *reinterpret_cast<const f32x4*>(x + ((size_t)a_img[it] + (size_t)iy * g.W + ix) * g.Cin + c0);
-            areg[it] = v;
+            const bool v_ok = a_img[it] >= 0 && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            const size_t off = v_ok ? ((size_t)a_img[it] + (size_t)iy * g.W + ix) * g.Cin + c0 : 0;
+            areg[it] = *reinterpret_cast<const f32x4*>(x + off);
+            ok |= (v_ok ? 1u : 0u) << it;
         }
 #pragma unroll
         for (int it = 0; it < C::NB; ++it) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b_row[it] >= 0)
-                v = *reinterpret_cast<const f32x4*>(wp + ((size_t)tap * g.Cout + b_row[it]) * g.Cin + c0);
-            breg[it] = v;
+            const bool v_ok = b_row[it] >= 0;
+            const size_t off = v_ok ? ((size_t)tap * g.Cout + b_row[it]) * g.Cin + c0 : 0;
+            breg[it] = *reinterpret_cast<const f32x4*>(wp + off);
+            ok |= (v_ok ? 1u : 0u) << (16 + it);
         }
+        ok_bits = ok;
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, unsigned ok) {
 #pragma unroll
-        for (int it = 0; it < C::NA; ++it)
-            *reinterpret_cast<f32x4*>(at0 + buf * C::A_F + a_dst[it]) = areg[it];
+        for (int it = 0; it < C::NA; ++it) {
+            f32x4 v = areg[it];
+            if (!((ok >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(at0 + buf * C::A_F + a_dst[it]) = v;
+        }
 #pragma unroll
-        for (int it = 0; it < C::NB; ++it)
-            *reinterpret_cast<f32x4*>(bt0 + buf * C::B_F + b_dst[it]) = breg[it];
+        for (int it = 0; it < C::NB; ++it) {
+            f32x4 v = breg[it];
+            if (!((ok >> (16 + it)) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(bt0 + buf * C::B_F + b_dst[it]) = v;
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -119,36 +130,74 @@ void conv_gather_mfma_kernel(const float* __restrict__ x, const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nst > 0) {
-        load_tiles(st_begin);
-        store_tiles(0);
-    }
-    __syncthreads();
-
     const int a_base = (32 * TM * wm + li) * GLDK + 4 * lh;
     const int b_base = (32 * TN * wn + li) * GLDK + 4 * lh;
-    for (int s = 0; s < nst; ++s) {
-        const bool has_next = (s + 1) < nst;
-        if (has_next) load_tiles(st_begin + s + 1);
-        const float* at = at0 + (s & 1) * C::A_F + a_base;
-        const float* bt = bt0 + (s & 1) * C::B_F + b_base;
+
+    // Software-pipelined K loop (the schedule of conv3x3_mfma_kernel, csrc/conv.hip): F0(s) in registers | read F1(s) |
+    // LDS-write tile s+1 | gather-load tile s+2 | MFMAs on F0 with one staging instruction per MFMA | barrier |
+    // read F0(s+1) under the MFMAs on F1.  Prefetches past the last stage are clamped to it.
+    if (nst > 0) {
+        const int last = st_end - 1;
+        load_tiles(st_begin);
+        store_tiles(0, ok_bits);
+        load_tiles(st_begin + 1 < st_end ? st_begin + 1 : last);
+        unsigned ok_w = ok_bits;
+        __syncthreads();
+        f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
 #pragma unroll
-        for (int gq = 0; gq < 2; ++gq) {
-            f32x4 af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i) a0[i] = *reinterpret_cast<const f32x4*>(at0 + a_base + i * 32 * GLDK);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(at + i * 32 * GLDK + 8 * gq);
+        for (int j = 0; j < TN; ++j) b0[j] = *reinterpret_cast<const f32x4*>(bt0 + b_base + j * 32 * GLDK);
+        constexpr int N_RD = TM + TN, N_ST = C::NA + C::NB;
+        for (int s = 0; s < nst; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            const float* at = at0 + cur * C::A_F + a_base;
+            const float* bt = bt0 + cur * C::B_F + b_base;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bt + j * 32 * GLDK + 8 * gq);
+            for (int i = 0; i < TM; ++i) a1[i] = *reinterpret_cast<const f32x4*>(at + i * 32 * GLDK + 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b1[j] = *reinterpret_cast<const f32x4*>(bt + j * 32 * GLDK + 8);
+            store_tiles(nxt, ok_w);
+            {
+                const int s2 = st_begin + s + 2;
+                load_tiles(s2 < st_end ? s2 : last);
+                ok_w = ok_bits;
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], b0[j][kk], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < N_RD; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+            for (int q = 0; q < N_ST; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+#pragma unroll
+            for (int q = 0; q < N_ST; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float* nat = at0 + nxt * C::A_F + a_base;
+                const float* nbt = bt0 + nxt * C::B_F + b_base;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a0[i] = *reinterpret_cast<const f32x4*>(nat + i * 32 * GLDK);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b0[j] = *reinterpret_cast<const f32x4*>(nbt + j * 32 * GLDK);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[j][kk], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < N_RD; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (has_next) store_tiles((s + 1) & 1);
-        __syncthreads();
     }
 
     const bool direct = (gridDim.z == 1);
