@@ -23,16 +23,17 @@ template <int TM, int TN, int WM, int WN>
 struct GemmCfg {
     static constexpr int BM = 32 * TM * WM;
     static constexpr int BN = 32 * TN * WN;
-    static constexpr int NA = BM * 4 / 256;
-    static constexpr int NB = BN * 4 / 256;
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int NA = (BM * 4 + THREADS - 1) / THREADS;      // 16-B pieces per thread per stage (surplus ones duplicate the last)
+    static constexpr int NB = (BN * 4 + THREADS - 1) / THREADS;
     static constexpr int A_F = BM * LLDK;
     static constexpr int B_F = BN * LLDK;
     static constexpr size_t LDS_BYTES = (size_t)2 * (A_F + B_F) * sizeof(float);
-    static_assert((BM * 4) % 256 == 0 && (BN * 4) % 256 == 0, "tile rows must be multiples of 64");
+    static_assert(THREADS == 256 || THREADS == 512, "4 or 8 waves per block");
 };
 
 template <int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64 * WM * WN)
 void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __restrict__ w,
                         const float* __restrict__ bias, float* __restrict__ y, int ldy,
                         float* __restrict__ ws, int M, int N, int K, int stages_per_split, int relu)
@@ -58,7 +59,9 @@ void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __res
     unsigned a_src[C::NA]; int a_dst[C::NA];
 #pragma unroll
     for (int it = 0; it < C::NA; ++it) {
-        const int q = tid + 256 * it, row = q >> 2, p = q & 3;
+        int q = tid + C::THREADS * it;
+        if (q >= C::BM * 4) q = C::BM * 4 - 1;
+        const int row = q >> 2, p = q & 3;
         const int gr = (m0 + row) < M ? (m0 + row) : M - 1;
         a_src[it] = (unsigned)(((size_t)(gr - m0) * lda + 4 * p) * sizeof(float));
         a_dst[it] = row * LLDK + 4 * p;
@@ -66,7 +69,9 @@ void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __res
     unsigned b_src[C::NB]; int b_dst[C::NB];
 #pragma unroll
     for (int it = 0; it < C::NB; ++it) {
-        const int q = tid + 256 * it, row = q >> 2, p = q & 3;
+        int q = tid + C::THREADS * it;
+        if (q >= C::BN * 4) q = C::BN * 4 - 1;
+        const int row = q >> 2, p = q & 3;
         b_src[it] = (unsigned)(((size_t)row * K + 4 * p) * sizeof(float));
         b_dst[it] = row * LLDK + 4 * p;
     }
@@ -332,7 +337,7 @@ static int launch_linear_cfg(const LinearPlan& p, const float* a, int lda, const
         attr_set = true;
     }
     dim3 grid(p.nblocks, p.mblocks, p.splits);
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, a, lda, w, bias, y, ldy, ws, M, N, K,
+    hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), C::LDS_BYTES, s, a, lda, w, bias, y, ldy, ws, M, N, K,
                        p.stages_per_split, relu);
     return check_launch();
 }
@@ -345,7 +350,8 @@ int launch_linear(const float* a, int lda, const float* w, const float* bias, fl
     const size_t need = p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
     if (need > ws_bytes || (need > 0 && ws == nullptr)) return FRCNN_EINVAL;
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
-    int rc = p.big ? launch_linear_cfg<5, 2, 2, 2>(p, a, lda, w, bias, y, ldy, (float*)ws, M, N, K, relu, s)
+    // big: 8 waves (2 x 4) of 5 x 1 MFMA tiles -- two waves per SIMD instead of one wave of 5 x 2 tiles
+    int rc = p.big ? launch_linear_cfg<5, 1, 2, 4>(p, a, lda, w, bias, y, ldy, (float*)ws, M, N, K, relu, s)
                    : launch_linear_cfg<2, 2, 2, 2>(p, a, lda, w, bias, y, ldy, (float*)ws, M, N, K, relu, s);
     if (rc != FRCNN_OK) return rc;
     if (p.splits > 1) {
