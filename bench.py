@@ -9,7 +9,7 @@ A "step" is one `predict()` of one synthetic, already-preprocessed float32 3x600
 resident in HBM when the timed region starts: VGG-16 backbone, RPN (6000 pre- / 300 post-NMS),
 RoI pooling, FC head, on-device float64 decode + per-class NMS, one D2H copy of the detections.
 Every image is an independent batch-1 forward (BASELINE.json configs[1]); `--inflight` of them
-are in flight on separate HIP streams.  fp32 end to end (the reference's dtype), exact-f32 MFMA.
+are in flight on separate HIP streams (GPU_MAX_HW_QUEUES=16 unless the environment says otherwise).  fp32 end to end (the reference's dtype), exact-f32 MFMA.
 
 Multi-GPU: image-parallel, rank r owns its own images, no data-path collective; weak scaling
 (K steps per rank).  The mAP@0.5 bookkeeping runs after the timed region on a small labelled
@@ -26,6 +26,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+# One HIP hardware queue per two in-flight streams: the ROCm default of 4 queues serialises 8+ streams pairwise
+# (measured: 271 img/s with 4 queues / 8 images in flight, 288 with 16 / 24; more than 16 queues is slower).
+# Read by the HIP runtime at initialisation, so it must be set before torch creates the device context.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
@@ -103,7 +108,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--inflight", type=int, default=8, help="images in flight per GPU (separate HIP streams)")
+    ap.add_argument("--inflight", type=int, default=24, help="images in flight per GPU (separate HIP streams)")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic images resident per GPU")
     ap.add_argument("--map-images", type=int, default=8, help="labelled images per rank for the mAP@0.5 leg")
     ap.add_argument("--cpu-images", type=int, default=3, help="images timed on the host CPU (rank 0, N=1 only)")
@@ -267,7 +272,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("VGG-16" if not is_resnet else args.backbone) + " Faster R-CNN predict(), 3x600x1000 float32, batch=1 per forward, "
                                    "6000 pre-/300 post-NMS proposals, score_threshold 0.05",
-                       "images_in_flight_per_gpu": nslots, "parallelism": "image-parallel x%d" % n_gpus,
+                       "images_in_flight_per_gpu": nslots, "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "image-parallel x%d" % n_gpus,
                        "flops_per_image": flops_img},
             "tflops_per_gpu": round(value / n_gpus * flops_img / 1e12, 2),
             "math": args.math, "secondary_f32x6": secondary,

@@ -12,6 +12,9 @@ timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err;
 tail -c 2500 $OUT/bench_default.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/trace.log 2>&1; echo "trace exit $?"
 P="python bench.py --steps 12 --warmup 4 --no-cpu-baseline --inflight 1 --roofline-images 2 --map-images 0"
+# single-stream kernel durations (what bench.py's roofline block times with HIP events): kernel trace + stats, no counters
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_single -o t -- python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-secondary --inflight 1 --roofline-images 10 --map-images 0 > $OUT/trace_single.log 2>&1; echo "single-stream trace exit $?"
+rm -f $OUT/trace_single/t_kernel_trace.csv
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_mfma -o p -- $P > $OUT/pmc_mfma.log 2>&1; echo "pmc mfma exit $?"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $P > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?"
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $P > $OUT/pmc_write.log 2>&1; echo "pmc write exit $?"

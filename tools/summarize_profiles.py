@@ -26,12 +26,28 @@ def main(d):
             print("## bench.py (default flags)\n\n```json\n%s\n```\n" % lines[-1])
     stats = load(os.path.join(d, "trace", "*kernel_stats.csv"))
     if stats:
-        print("## kernel trace + stats (bench.py --steps 60 --warmup 10 --no-cpu-baseline, 4 images in flight)\n")
+        print("## kernel trace + stats (bench.py --steps 60 --warmup 10 --no-cpu-baseline, default images in flight)\n")
         print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
         for r in stats[:24]:
             print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                      float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
         print()
+    sstats = load(os.path.join(d, "trace_single", "*kernel_stats.csv"))
+    if sstats:
+        print("## single stream: kernel stats (bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-secondary --inflight 1 "
+              "--roofline-images 10 --map-images 0)\n")
+        print("One image at a time, so a kernel's duration is its own: this is the regime bench.py's `roofline` block times with "
+              "HIP events (`avg_launch_us` = mean over the conv3x3_mfma_kernel launches of all instantiations).\n")
+        print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+        tot_ns, tot_calls = 0.0, 0
+        for r in sstats[:20]:
+            print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                     float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+        for r in sstats:
+            if "conv3x3_mfma_kernel" in r["Name"]:
+                tot_ns += float(r["TotalDurationNs"]); tot_calls += int(r["Calls"])
+        if tot_calls:
+            print("\nconv3x3_mfma_kernel, all instantiations: %d launches, mean %.1f us\n" % (tot_calls, tot_ns / tot_calls / 1e3))
     tb = os.path.join(d, "train_bench.json")
     if os.path.exists(tb):
         lines = [l for l in open(tb).read().splitlines() if l.startswith("{")]
