@@ -483,3 +483,35 @@ def test_train_step_matches_reference_fixture(tag, golden_dir, sd_cpu):
     # the trained model still predicts (weights are re-packed from the synced parameters)
     det = model.predict(img, score_threshold=0.05)
     assert sorted(det.keys()) == list(range(1, 21))
+
+
+def test_train_step_full_size_is_deterministic_and_learns(sd_cpu):
+    """BASELINE's 600x1000 size: three steps on one sample, run twice from the same seeds -> bit-identical losses and weights
+    (split reductions and the RoI-pool backward are fixed-order), finite, and the loss falls."""
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    from fasterrcnn_amd.models.vgg16 import VGG16Backbone
+    h, w, seed = 600, 1000, 2
+    img = synthetic.image(seed, h, w).unsqueeze(0).cuda()
+    gts = synthetic.ground_truth(seed, h, w)
+    boxes = [Box(class_index=c, class_name="x", corners=k) for c, k in gts]
+    am, vm = O.generate_anchor_maps((3, h, w), (512, h // 16, w // 16), 16)
+    rmap, obj, bg = O.generate_rpn_map(am, vm, np.stack([k for _, k in gts]))
+    rmap_t = torch.from_numpy(rmap).unsqueeze(0).cuda()
+    runs = []
+    for _ in range(2):
+        model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+        model.load_state_dict(sd_cpu, strict=True)
+        model = model.cuda()
+        opt = T.create_optimizer(model, learning_rate=1e-6)
+        random.seed(5); torch.manual_seed(5)
+        losses = [model.train_step(opt, img, am, vm, rmap_t, [obj], [bg], [boxes]) for _ in range(3)]
+        sd = model.state_dict()
+        runs.append((losses, {k: v.clone() for k, v in sd.items()}))
+    (l0, s0), (l1, s1) = runs
+    assert [x.total for x in l0] == [x.total for x in l1]
+    assert all(np.isfinite([x.rpn_class, x.rpn_regression, x.detector_class, x.detector_regression, x.total]).all() for x in l0)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+    assert l0[-1].total < l0[0].total
+    changed = [k for k in s0 if not torch.equal(s0[k].cpu(), sd_cpu[k])]
+    assert len(changed) == 16 and all("weight" in k for k in changed)        # 9 convs + 3 RPN + fc1 fc2 + 2 heads; no bias
