@@ -37,6 +37,8 @@ SYMBOLS = (
     "frcnn_gemm_tn_workspace_bytes", "frcnn_gemm_tn", "frcnn_conv3x3_wgrad_workspace_bytes", "frcnn_conv3x3_wgrad",
     "frcnn_pack_conv3x3_dgrad", "frcnn_relu_backward", "frcnn_add_inplace", "frcnn_maxpool2x2_backward",
     "frcnn_roi_pool_backward_workspace_bytes", "frcnn_roi_pool_backward", "frcnn_transpose", "frcnn_sgd_step",
+    "frcnn_conv_wgrad_workspace_bytes", "frcnn_conv_wgrad", "frcnn_conv_dgrad_workspace_bytes", "frcnn_conv_dgrad",
+    "frcnn_pack_conv_dgrad", "frcnn_scale_rows", "frcnn_bn_scale_shift", "frcnn_spatial_mean_backward",
 )
 
 
@@ -142,6 +144,14 @@ _SIGNATURES = {
     "frcnn_conv3x3_wgrad_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "frcnn_conv3x3_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "frcnn_pack_conv3x3_dgrad": (C.c_int, [_vp, _vp, _i, _i, _vp]),
+    "frcnn_conv_wgrad_workspace_bytes": (C.c_size_t, [_i] * 8),
+    "frcnn_conv_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "frcnn_conv_dgrad_workspace_bytes": (C.c_size_t, [_i] * 8),
+    "frcnn_conv_dgrad": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "frcnn_pack_conv_dgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "frcnn_scale_rows": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "frcnn_bn_scale_shift": (C.c_int, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "frcnn_spatial_mean_backward": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "frcnn_relu_backward": (C.c_int, [_vp, _vp, _sz, _vp]),
     "frcnn_add_inplace": (C.c_int, [_vp, _vp, _sz, _vp]),
     "frcnn_maxpool2x2_backward": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -362,6 +362,58 @@ int frcnn_pack_conv3x3_dgrad(const float* d_wp, float* d_wd, int cout, int cin, 
     return launch_pack_conv3x3_dgrad(d_wp, d_wd, cout, cin, as_stream(stream));
 }
 
+size_t frcnn_conv_wgrad_workspace_bytes(int N, int H, int W, int cin, int cout, int ksize, int stride, int pad)
+{
+    if (N < 1 || H < 1 || W < 1 || cin < 1 || cout < 1 || ksize < 1 || stride < 1 || pad < 0) return 0;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    return Ho > 0 && Wo > 0 ? gemm_tn_workspace_bytes(cout, cin, N * Ho * Wo, ksize * ksize) : 0;
+}
+
+int frcnn_conv_wgrad(const float* d_x, const float* d_dz, float* d_dwp, int N, int H, int W, int cin, int cout,
+                     int ksize, int stride, int pad, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_x || !d_dz || !d_dwp) return FRCNN_EINVAL;
+    return launch_conv_wgrad(d_x, d_dz, d_dwp, N, H, W, cin, cout, ksize, stride, pad, d_ws, ws_bytes, as_stream(stream));
+}
+
+size_t frcnn_conv_dgrad_workspace_bytes(int N, int H, int W, int cin, int cout, int ksize, int stride, int pad)
+{
+    return conv_dgrad_workspace_bytes(N, H, W, cin, cout, ksize, stride, pad);
+}
+
+int frcnn_conv_dgrad(const float* d_dz, const float* d_wd, const float* d_residual, float* d_dx, int N, int H, int W,
+                     int cin, int cout, int ksize, int stride, int pad, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_dz || !d_wd || !d_dx) return FRCNN_EINVAL;
+    return launch_conv_dgrad(d_dz, d_wd, d_residual, d_dx, N, H, W, cin, cout, ksize, stride, pad, d_ws, ws_bytes,
+                             as_stream(stream));
+}
+
+int frcnn_pack_conv_dgrad(const float* d_wp, float* d_wd, int taps, int cout, int cin, void* stream)
+{
+    if (!d_wp || !d_wd) return FRCNN_EINVAL;
+    return launch_pack_conv_dgrad(d_wp, d_wd, taps, cout, cin, as_stream(stream));
+}
+
+int frcnn_scale_rows(const float* d_src, const float* d_scale, float* d_dst, int taps, int cout, int cin, void* stream)
+{
+    if (!d_src || !d_scale || !d_dst) return FRCNN_EINVAL;
+    return launch_scale_rows(d_src, d_scale, d_dst, taps, cout, cin, as_stream(stream));
+}
+
+int frcnn_bn_scale_shift(const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_var, float eps,
+                         int c, float* d_scale, float* d_shift, void* stream)
+{
+    if (!d_gamma || !d_beta || !d_mean || !d_var || !d_scale || !d_shift) return FRCNN_EINVAL;
+    return launch_bn_scale_shift(d_gamma, d_beta, d_mean, d_var, eps, c, d_scale, d_shift, as_stream(stream));
+}
+
+int frcnn_spatial_mean_backward(const float* d_dy, float* d_dx, int N, int H, int W, int c, void* stream)
+{
+    if (!d_dy || !d_dx) return FRCNN_EINVAL;
+    return launch_spatial_mean_backward(d_dy, d_dx, N, H, W, c, as_stream(stream));
+}
+
 int frcnn_relu_backward(float* d_dy, const float* d_y, size_t n, void* stream)
 {
     if (n > 0 && (!d_dy || !d_y)) return FRCNN_EINVAL;

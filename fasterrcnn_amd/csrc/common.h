@@ -136,6 +136,16 @@ int launch_roi_pool_backward(const float* fm, int fh, int fw, int C, const float
                              hipStream_t s);
 int launch_transpose(const float* x, int ldi, float* y, int ldo, int rows, int cols, hipStream_t s);
 int launch_pack_conv3x3_dgrad(const float* wp, float* wd, int cout, int cin, hipStream_t s);
+int launch_conv_wgrad(const float* x, const float* dz, float* dwp, int N, int H, int W, int cin, int cout, int ks, int stride,
+                      int pad, void* ws, size_t ws_bytes, hipStream_t s);
+size_t conv_dgrad_workspace_bytes(int N, int H, int W, int cin, int cout, int R, int stride, int pad);
+int launch_conv_dgrad(const float* dz, const float* wd, const float* residual, float* dx, int N, int H, int W, int cin,
+                      int cout, int R, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_pack_conv_dgrad(const float* wp, float* wd, int taps, int cout, int cin, hipStream_t s);
+int launch_scale_rows(const float* src, const float* scale, float* dst, int taps, int cout, int cin, hipStream_t s);
+int launch_bn_scale_shift(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
+                          float* scale, float* shift, hipStream_t s);
+int launch_spatial_mean_backward(const float* dy, float* dx, int N, int H, int W, int c, hipStream_t s);
 int launch_sgd(float* w, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay, int first,
                hipStream_t s);
 

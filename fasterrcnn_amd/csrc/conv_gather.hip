@@ -28,6 +28,10 @@ struct GatherCfg {
 
 struct GatherShape {
     int N, H, W, Cin, Cout, Ho, Wo, R, S, stride, pad;
+    // transposed != 0: the data-gradient form.  Destination rows are the pixels (n, oy, ox) of the forward conv's INPUT
+    // (Ho x Wo = that input's size), the source (H x W) is the gradient of the forward output, and tap (r, s) reads source
+    // pixel ((oy + pad - r) / stride, (ox + pad - s) / stride) when both divisions are exact and in range.
+    int transposed;
 };
 
 template <int TM, int TN, int WM, int WN>
@@ -66,8 +70,8 @@ void conv_gather_mfma_kernel(const float* __restrict__ x, const float* __restric
             const int rem = m - n * g.Ho * g.Wo;
             const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
             a_img[it] = n * g.H * g.W;              // pixel offset of the image
-            a_iy[it] = oy * g.stride - g.pad;
-            a_ix[it] = ox * g.stride - g.pad;
+            a_iy[it] = g.transposed ? oy + g.pad : oy * g.stride - g.pad;
+            a_ix[it] = g.transposed ? ox + g.pad : ox * g.stride - g.pad;
         } else {
             a_img[it] = -1; a_iy[it] = 0; a_ix[it] = 0;
         }
@@ -92,8 +96,14 @@ void conv_gather_mfma_kernel(const float* __restrict__ x, const float* __restric
         unsigned ok = 0;
 #pragma unroll
         for (int it = 0; it < C::NA; ++it) {
-            const int iy = a_iy[it] + r, ix = a_ix[it] + s;
-            const bool v_ok = a_img[it] >= 0 && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            int iy = a_iy[it] + r, ix = a_ix[it] + s;
+            bool v_ok = a_img[it] >= 0;
+            if (g.transposed) {
+                const int ty = a_iy[it] - r, tx = a_ix[it] - s;
+                iy = ty / g.stride; ix = tx / g.stride;
+                v_ok = v_ok && ty >= 0 && tx >= 0 && iy * g.stride == ty && ix * g.stride == tx;
+            }
+            v_ok = v_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
             const size_t off = v_ok ? ((size_t)a_img[it] + (size_t)iy * g.W + ix) * g.Cin + c0 : 0;
             areg[it] = *reinterpret_cast<const f32x4*>(x + off);
             ok |= (v_ok ? 1u : 0u) << it;
@@ -206,7 +216,7 @@ void conv_gather_mfma_kernel(const float* __restrict__ x, const float* __restric
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + 32 * (TN * wn + j) + li;
         if (n >= g.Cout) continue;
-        const float bv = direct ? bias[n] : 0.f;
+        const float bv = (direct && bias) ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -240,7 +250,8 @@ void gather_splitk_finish_kernel(const float* __restrict__ ws, int splits, const
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += t[j];
         }
-        const f32x4 b = reinterpret_cast<const f32x4*>(bias)[c4];
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (bias) b = reinterpret_cast<const f32x4*>(bias)[c4];
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
         if (residual) r = reinterpret_cast<const f32x4*>(residual)[i];
 #pragma unroll
@@ -421,6 +432,7 @@ int launch_conv_gather(const float* x, const float* wp, const float* bias, const
 {
     if (N < 1 || H < 1 || W < 1 || cin % 16 != 0 || cout % 4 != 0 || R < 1 || stride < 1 || pad < 0) return FRCNN_EINVAL;
     GatherShape g;
+    g.transposed = 0;
     g.N = N; g.H = H; g.W = W; g.Cin = cin; g.Cout = cout; g.R = R; g.S = R; g.stride = stride; g.pad = pad;
     g.Ho = (H + 2 * pad - R) / stride + 1;
     g.Wo = (W + 2 * pad - R) / stride + 1;
@@ -445,6 +457,50 @@ int launch_conv_gather(const float* x, const float* wp, const float* bias, const
         rc = check_launch();
     }
     return rc;
+}
+
+// Data gradient of y = conv(x, w) (k x k, stride, pad; x [N][H][W][cin], y [N][Ho][Wo][cout]):
+//   dx[n][iy][ix][ci] = residual + sum_{tap, co} dz[n][(iy+pad-r)/stride][(ix+pad-s)/stride][co] * wd[tap][ci][co]
+// as the gather kernel in its transposed mode (wd = per-tap transpose of the forward pack, frcnn_pack_conv_dgrad).
+int launch_conv_dgrad(const float* dz, const float* wd, const float* residual, float* dx, int N, int H, int W, int cin,
+                      int cout, int R, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t s)
+{
+    if (N < 1 || H < 1 || W < 1 || cout % 16 != 0 || cin % 4 != 0 || R < 1 || stride < 1 || pad < 0) return FRCNN_EINVAL;
+    GatherShape g;
+    g.transposed = 1;
+    g.N = N; g.R = R; g.S = R; g.stride = stride; g.pad = pad;
+    g.H = (H + 2 * pad - R) / stride + 1;           // source = dz
+    g.W = (W + 2 * pad - R) / stride + 1;
+    g.Ho = H; g.Wo = W;                             // destination = dx
+    g.Cin = cout; g.Cout = cin;
+    if (g.H < 1 || g.W < 1) return FRCNN_EINVAL;
+    const int M = N * H * W;
+    GatherPlan p = plan_gather(M, cin, (cout / 16) * R * R);
+    const size_t need = p.splits > 1 ? (size_t)p.splits * M * cin * sizeof(float) : 0;
+    if (need > ws_bytes || (need > 0 && ws == nullptr)) {
+        p.splits = 1;
+        p.stages_per_split = (cout / 16) * R * R;
+    }
+    int rc = p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, dz, wd, nullptr, residual, dx, (float*)ws, g, 0, s)
+                        : launch_gather_cfg<2, 2, 2, 2>(p, dz, wd, nullptr, residual, dx, (float*)ws, g, 0, s);
+    if (rc) return rc;
+    if (p.splits > 1) {
+        const size_t total = (size_t)M * (cin / 4);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gather_splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, p.splits,
+                           (const float*)nullptr, residual, dx, M, cin, 0);
+        rc = check_launch();
+    }
+    return rc;
+}
+
+size_t conv_dgrad_workspace_bytes(int N, int H, int W, int cin, int cout, int R, int stride, int pad)
+{
+    if (N < 1 || H < 1 || W < 1 || cout % 16 != 0 || R < 1 || stride < 1) return 0;
+    const int M = N * H * W;
+    const GatherPlan p = plan_gather(M, cin, (cout / 16) * R * R);
+    return p.splits > 1 ? (size_t)p.splits * M * cin * sizeof(float) : 0;
 }
 
 int launch_conv7x7_s2_c3(const float* x, const float* wp, const float* b, float* y, int H, int W, int cout,

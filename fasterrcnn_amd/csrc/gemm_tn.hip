@@ -30,12 +30,14 @@ static constexpr int GT_RK = 16;    // reduction rows per stage
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// geometry of the convolution whose weight gradient is computed (CONV mode): reduction row r = output pixel (n, oy, ox)
+struct WgradGeom { int H, W, Ho, Wo, ks, stride, pad; };
+
 template <bool CONV>
 __global__ __launch_bounds__(256)
 void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                     float* __restrict__ C, int ldc, int M, int N, int R,
-                    int rows_per_split, int splits, float* __restrict__ ws,
-                    int img_h, int img_w)
+                    int rows_per_split, int splits, float* __restrict__ ws, WgradGeom cg)
 {
     __shared__ __attribute__((aligned(16))) float As[2][GT_RK][GT_T];
     __shared__ __attribute__((aligned(16))) float Bs[2][GT_RK][GT_T];
@@ -48,7 +50,7 @@ void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restric
     const int r_begin = split * rows_per_split;
     int r_end = r_begin + rows_per_split;
     if (r_end > R) r_end = R;
-    const int dy = CONV ? tap / 3 - 1 : 0, dx = CONV ? tap % 3 - 1 : 0;
+    const int dy = CONV ? tap / cg.ks - cg.pad : 0, dx = CONV ? tap % cg.ks - cg.pad : 0;
 
     // this thread's two 16-B pieces per operand per stage: row = q >> 5, column = (q & 31) * 4
     const int prow0 = tid >> 5, pcol = (tid & 31) * 4;      // second piece: row + 8
@@ -68,10 +70,12 @@ void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restric
             bool b_ok = r_ok && b_col_ok;
             size_t b_row = (size_t)r;
             if (CONV) {
-                const int py = r / img_w, px = r - py * img_w;
-                const int sy = py + dy, sx = px + dx;
-                b_ok = b_ok && sy >= 0 && sy < img_h && sx >= 0 && sx < img_w;
-                b_row = (size_t)(sy * img_w + sx);
+                const int hw = cg.Ho * cg.Wo;
+                const int n = r / hw, rem = r - n * hw;
+                const int oy = rem / cg.Wo, ox = rem - oy * cg.Wo;
+                const int sy = oy * cg.stride + dy, sx = ox * cg.stride + dx;
+                b_ok = b_ok && sy >= 0 && sy < cg.H && sx >= 0 && sx < cg.W;
+                b_row = (size_t)n * cg.H * cg.W + (size_t)(sy * cg.W + sx);
             }
             const size_t b_off = b_ok ? b_row * ldb + n0 + pcol : 0;
             breg[it] = *reinterpret_cast<const f32x4*>(B + b_off);
@@ -228,7 +232,7 @@ void choose_split(int M, int N, int R, int taps, size_t ws_bytes, bool have_ws, 
 
 template <bool CONV>
 int launch_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int R, int taps,
-              int img_h, int img_w, void* ws, size_t ws_bytes, hipStream_t s)
+              WgradGeom cg, void* ws, size_t ws_bytes, hipStream_t s)
 {
     int splits, rps;
     choose_split(M, N, R, taps, ws_bytes, ws != nullptr, &splits, &rps);
@@ -236,7 +240,7 @@ int launch_tn(const float* A, int lda, const float* B, int ldb, float* C, int ld
     float* part = splits > 1 ? static_cast<float*>(ws) : nullptr;
     dim3 grid(cdiv(N, GT_T), cdiv(M, GT_T), taps * splits);
     hipLaunchKernelGGL((gemm_tn_kernel<CONV>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, R, rps, splits,
-                       part, img_h, img_w);
+                       part, cg);
     int rc = check_launch();
     if (rc || splits == 1) return rc;
     const size_t total = (size_t)taps * M * (N / 2);
@@ -260,7 +264,7 @@ int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, i
     if (M < 1 || N < 1 || R < 1 || lda < M || ldb < N || ldc < N || (lda & 3) || (ldb & 3) || (ldc & 1)) return FRCNN_EINVAL;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return FRCNN_EINVAL;
     if (reinterpret_cast<uintptr_t>(C) & 7) return FRCNN_EINVAL;
-    return launch_tn<false>(A, lda, B, ldb, C, ldc, M, N, R, 1, 0, 0, ws, ws_bytes, s);
+    return launch_tn<false>(A, lda, B, ldb, C, ldc, M, N, R, 1, WgradGeom{0, 0, 0, 0, 1, 1, 0}, ws, ws_bytes, s);
 }
 
 int launch_conv3x3_wgrad(const float* x, const float* dz, float* dwp, int H, int W, int cin, int cout,
@@ -270,7 +274,20 @@ int launch_conv3x3_wgrad(const float* x, const float* dz, float* dwp, int H, int
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dz)) & 15) return FRCNN_EINVAL;
     if ((long)H * W > (1L << 30)) return FRCNN_EINVAL;
     // A = dz [pixel][cout], B = x [pixel (shifted)][cin], C = dwp [tap][cout][cin]
-    return launch_tn<true>(dz, cout, x, cin, dwp, cin, cout, cin, H * W, 9, H, W, ws, ws_bytes, s);
+    return launch_tn<true>(dz, cout, x, cin, dwp, cin, cout, cin, H * W, 9, WgradGeom{H, W, H, W, 3, 1, 1}, ws, ws_bytes, s);
+}
+
+// general form (ResNet bottlenecks): x [N][H][W][cin], dz [N][Ho][Wo][cout] -> dwp [k*k][cout][cin]
+int launch_conv_wgrad(const float* x, const float* dz, float* dwp, int N, int H, int W, int cin, int cout, int ks, int stride,
+                      int pad, void* ws, size_t ws_bytes, hipStream_t s)
+{
+    if (N < 1 || H < 1 || W < 1 || cin < 4 || cout < 4 || (cin & 3) || (cout & 3) || ks < 1 || ks > 7 || stride < 1 || pad < 0)
+        return FRCNN_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dz)) & 15) return FRCNN_EINVAL;
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+    if (Ho < 1 || Wo < 1 || (long)N * H * W > (1L << 30)) return FRCNN_EINVAL;
+    return launch_tn<true>(dz, cout, x, cin, dwp, cin, cout, cin, N * Ho * Wo, ks * ks, WgradGeom{H, W, Ho, Wo, ks, stride, pad},
+                           ws, ws_bytes, s);
 }
 
 }  // namespace frcnn

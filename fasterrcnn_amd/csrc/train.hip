@@ -393,6 +393,56 @@ void pack_conv3x3_dgrad_kernel(const float* __restrict__ wp, float* __restrict__
     }
 }
 
+// wd[tap][ci][co] = wp[tap][co][ci]: the weight pack of the gather kernel's transposed (data-gradient) mode
+__global__ __launch_bounds__(256)
+void pack_conv_dgrad_kernel(const float* __restrict__ wp, float* __restrict__ wd, int taps, int cout, int cin)
+{
+    const size_t per = (size_t)cout * cin, total = (size_t)taps * per;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int tap = (int)(i / per);
+        const size_t rem = i - tap * per;
+        const int ci = (int)(rem / cout), co = (int)(rem % cout);
+        wd[i] = wp[(size_t)tap * per + (size_t)co * cin + ci];
+    }
+}
+
+// dst[tap][co][ci] = src[tap][co][ci] * scale[co]: folding a frozen BatchNorm's scale into a weight pack, and the
+// chain rule back from the folded weight's gradient to the raw weight's (same factor)
+__global__ __launch_bounds__(256)
+void scale_rows_kernel(const float* __restrict__ src, const float* __restrict__ scale, float* __restrict__ dst,
+                       int taps, int cout, int cin)
+{
+    const size_t total = (size_t)taps * cout * cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int co = (int)((i / cin) % cout);
+        dst[i] = __fmul_rn(src[i], scale[co]);
+    }
+}
+
+// frozen BatchNorm (eval mode) as y = x * scale + shift: scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+__global__ void bn_scale_shift_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ mean, const float* __restrict__ var, float eps, int c,
+                                      float* __restrict__ scale, float* __restrict__ shift)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c) return;
+    const float sc = gamma[i] / sqrtf(var[i] + eps);
+    scale[i] = sc;
+    shift[i] = beta[i] - mean[i] * sc;
+}
+
+// backward of y = x.mean(-1).mean(-1) (models/resnet.py:117): dx[n][y][x][c] = (dy[n][c] / H) / W
+__global__ __launch_bounds__(256)
+void spatial_mean_backward_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C)
+{
+    const size_t total = (size_t)N * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t n = i / ((size_t)H * W * C);
+        dx[i] = (dy[n * C + c] / (float)H) / (float)W;
+    }
+}
+
 // torch.optim.SGD.step: g += wd * w; buf = first ? g : momentum * buf + g; w -= lr * buf
 __global__ __launch_bounds__(256)
 void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ buf, size_t n,
@@ -517,6 +567,35 @@ int launch_pack_conv3x3_dgrad(const float* wp, float* wd, int cout, int cin, hip
 {
     if (cout < 1 || cin < 1) return FRCNN_EINVAL;
     hipLaunchKernelGGL(pack_conv3x3_dgrad_kernel, dim3(grid_for((size_t)9 * cout * cin)), dim3(256), 0, s, wp, wd, cout, cin);
+    return check_launch();
+}
+
+int launch_pack_conv_dgrad(const float* wp, float* wd, int taps, int cout, int cin, hipStream_t s)
+{
+    if (taps < 1 || cout < 1 || cin < 1) return FRCNN_EINVAL;
+    hipLaunchKernelGGL(pack_conv_dgrad_kernel, dim3(grid_for((size_t)taps * cout * cin)), dim3(256), 0, s, wp, wd, taps, cout, cin);
+    return check_launch();
+}
+
+int launch_scale_rows(const float* src, const float* scale, float* dst, int taps, int cout, int cin, hipStream_t s)
+{
+    if (taps < 1 || cout < 1 || cin < 1) return FRCNN_EINVAL;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for((size_t)taps * cout * cin)), dim3(256), 0, s, src, scale, dst, taps, cout, cin);
+    return check_launch();
+}
+
+int launch_bn_scale_shift(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
+                          float* scale, float* shift, hipStream_t s)
+{
+    if (c < 1) return FRCNN_EINVAL;
+    hipLaunchKernelGGL(bn_scale_shift_kernel, dim3(cdiv(c, 256)), dim3(256), 0, s, gamma, beta, mean, var, eps, c, scale, shift);
+    return check_launch();
+}
+
+int launch_spatial_mean_backward(const float* dy, float* dx, int N, int H, int W, int c, hipStream_t s)
+{
+    if (N < 1 || H < 1 || W < 1 || c < 1) return FRCNN_EINVAL;
+    hipLaunchKernelGGL(spatial_mean_backward_kernel, dim3(grid_for((size_t)N * H * W * c)), dim3(256), 0, s, dy, dx, N, H, W, c);
     return check_launch();
 }
 

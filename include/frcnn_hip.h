@@ -385,6 +385,26 @@ int frcnn_conv3x3_wgrad(const float* d_x, const float* d_dz, float* d_dwp, int H
                         void* d_ws, size_t ws_bytes, void* stream);
 int frcnn_pack_conv3x3_dgrad(const float* d_wp, float* d_wd, int cout, int cin, void* stream);
 
+/* General forms for the ResNet bottlenecks (models/resnet.py:38-46,110; BatchNorm frozen, so each conv+BN is one conv with a
+ * folded weight): x [N][H][W][cin], y = conv(x) [N][Ho][Wo][cout], k x k taps, stride, pad.
+ *   frcnn_conv_wgrad : d_dwp [k*k][cout][cin] = gradient with respect to the (folded) weight pack
+ *   frcnn_conv_dgrad : d_dx [N][H][W][cin] = d_residual (or 0 if NULL) + gradient with respect to x, from d_dz [N][Ho][Wo][cout]
+ *                      and d_wd = frcnn_pack_conv_dgrad(weight pack) ([tap][cin][cout]); cout % 16 == 0, cin % 4 == 0
+ *   frcnn_scale_rows : dst[tap][co][ci] = src[tap][co][ci] * scale[co] (fold a frozen BN scale into a pack; chain rule back)
+ *   frcnn_bn_scale_shift : scale = gamma / sqrt(var + eps), shift = beta - mean * scale (the eval-mode BatchNorm affine)
+ *   frcnn_spatial_mean_backward : backward of `y.mean(-1).mean(-1)` (resnet.py:117). */
+size_t frcnn_conv_wgrad_workspace_bytes(int N, int H, int W, int cin, int cout, int ksize, int stride, int pad);
+int frcnn_conv_wgrad(const float* d_x, const float* d_dz, float* d_dwp, int N, int H, int W, int cin, int cout,
+                     int ksize, int stride, int pad, void* d_ws, size_t ws_bytes, void* stream);
+size_t frcnn_conv_dgrad_workspace_bytes(int N, int H, int W, int cin, int cout, int ksize, int stride, int pad);
+int frcnn_conv_dgrad(const float* d_dz, const float* d_wd, const float* d_residual, float* d_dx, int N, int H, int W,
+                     int cin, int cout, int ksize, int stride, int pad, void* d_ws, size_t ws_bytes, void* stream);
+int frcnn_pack_conv_dgrad(const float* d_wp, float* d_wd, int taps, int cout, int cin, void* stream);
+int frcnn_scale_rows(const float* d_src, const float* d_scale, float* d_dst, int taps, int cout, int cin, void* stream);
+int frcnn_bn_scale_shift(const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_var, float eps,
+                         int c, float* d_scale, float* d_shift, void* stream);
+int frcnn_spatial_mean_backward(const float* d_dy, float* d_dx, int N, int H, int W, int c, void* stream);
+
 /* dy[i] = y[i] > 0 ? dy[i] : 0 (ReLU backward, in place); a[i] += b[i]. */
 int frcnn_relu_backward(float* d_dy, const float* d_y, size_t n, void* stream);
 int frcnn_add_inplace(float* d_a, const float* d_b, size_t n, void* stream);

@@ -515,3 +515,81 @@ def test_train_step_full_size_is_deterministic_and_learns(sd_cpu):
     assert l0[-1].total < l0[0].total
     changed = [k for k in s0 if not torch.equal(s0[k].cpu(), sd_cpu[k])]
     assert len(changed) == 16 and all("weight" in k for k in changed)        # 9 convs + 3 RPN + fc1 fc2 + 2 heads; no bias
+
+
+# ---- general conv backward (ResNet bottlenecks) -------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,cin,cout,k,stride,pad", [(1, 20, 33, 64, 128, 1, 1, 0), (1, 21, 33, 64, 256, 1, 2, 0),
+                                                         (1, 20, 33, 64, 64, 3, 2, 1), (5, 7, 7, 128, 64, 3, 2, 1),
+                                                         (3, 4, 4, 64, 64, 3, 1, 1), (1, 38, 63, 256, 64, 3, 1, 1),
+                                                         (128, 4, 4, 64, 256, 1, 1, 0)])
+def test_conv_wgrad_and_dgrad_general(N, H, W, cin, cout, k, stride, pad):
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + k + stride)
+    x = torch.randn((N, cin, H, W), generator=g)
+    w = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (k * k * cin)) ** 0.5
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dz = torch.randn((N, cout, Ho, Wo), generator=g)
+    res = torch.randn((N, cin, H, W), generator=g)
+
+    def grads(dtype):
+        xx = x.to(dtype).requires_grad_(True)
+        ww = w.to(dtype).requires_grad_(True)
+        F.conv2d(xx, ww, None, stride=stride, padding=pad).backward(dz.to(dtype))
+        return xx.grad.detach(), ww.grad.detach()
+    dx64, dw64 = grads(torch.float64)
+    dx32, dw32 = grads(torch.float32)
+    lib = nv.lib()
+    x_n = gpu(x.permute(0, 2, 3, 1))
+    dz_n = gpu(dz.permute(0, 2, 3, 1))
+    dwp = torch.full((k * k, cout, cin), float("nan"), device=DEV)
+    wsb = int(lib.frcnn_conv_wgrad_workspace_bytes(N, H, W, cin, cout, k, stride, pad))
+    ws = torch.empty((wsb // 4 + 1,), device=DEV)
+    nv.check(lib.frcnn_conv_wgrad(nv.ptr(x_n), nv.ptr(dz_n), nv.ptr(dwp), N, H, W, cin, cout, k, stride, pad, nv.ptr(ws), wsb, S()),
+             "conv_wgrad")
+    got_dw = dwp.permute(1, 2, 0).reshape(cout, cin, k, k).cpu().numpy()
+    e, ey = err_vs_f64(got_dw, dw64.numpy(), dw32.numpy())
+    assert e <= max(4 * ey, 2e-6), ("wgrad", e, ey)
+    # data gradient (+ fused residual)
+    wp = gpu(w.permute(2, 3, 0, 1).reshape(k * k, cout, cin))
+    wd = torch.empty((k * k, cin, cout), device=DEV)
+    nv.check(lib.frcnn_pack_conv_dgrad(nv.ptr(wp), nv.ptr(wd), k * k, cout, cin, S()), "pack_conv_dgrad")
+    assert torch.equal(wd.cpu(), wp.cpu().permute(0, 2, 1))
+    res_n = gpu(res.permute(0, 2, 3, 1))
+    dx = torch.full((N, H, W, cin), float("nan"), device=DEV)
+    wsb = int(lib.frcnn_conv_dgrad_workspace_bytes(N, H, W, cin, cout, k, stride, pad))
+    ws = torch.empty((wsb // 4 + 1,), device=DEV)
+    for residual in (None, res_n):
+        nv.check(lib.frcnn_conv_dgrad(nv.ptr(dz_n), nv.ptr(wd), nv.ptr(residual), nv.ptr(dx), N, H, W, cin, cout, k, stride, pad,
+                                      nv.ptr(ws), wsb, S()), "conv_dgrad")
+        want64 = dx64 + (res.double() if residual is not None else 0)
+        want32 = dx32 + (res if residual is not None else 0)
+        e, ey = err_vs_f64(dx.permute(0, 3, 1, 2).cpu().numpy(), want64.numpy(), want32.numpy())
+        assert e <= max(4 * ey, 2e-6), ("dgrad", residual is not None, e, ey)
+
+
+def test_scale_rows_bn_affine_and_mean_backward():
+    g = torch.Generator().manual_seed(8)
+    lib = nv.lib()
+    taps, cout, cin = 9, 64, 32
+    src = torch.randn((taps, cout, cin), generator=g)
+    sc = torch.rand((cout,), generator=g) + 0.5
+    d_src, d_sc = gpu(src), gpu(sc)
+    dst = torch.empty_like(d_src)
+    nv.check(lib.frcnn_scale_rows(nv.ptr(d_src), nv.ptr(d_sc), nv.ptr(dst), taps, cout, cin, S()), "scale_rows")
+    assert torch.equal(dst.cpu(), src * sc.reshape(1, cout, 1))
+    gamma, beta = torch.rand((300,), generator=g) + 0.5, torch.randn((300,), generator=g)
+    mean, var = torch.randn((300,), generator=g), torch.rand((300,), generator=g) + 0.5
+    dg, db, dm, dv = gpu(gamma), gpu(beta), gpu(mean), gpu(var)
+    scale, shift = torch.empty((300,), device=DEV), torch.empty((300,), device=DEV)
+    nv.check(lib.frcnn_bn_scale_shift(nv.ptr(dg), nv.ptr(db), nv.ptr(dm), nv.ptr(dv), 1e-5, 300, nv.ptr(scale), nv.ptr(shift), S()),
+             "bn_scale_shift")
+    want_scale = gamma / torch.sqrt(var + 1e-5)
+    assert float((scale.cpu() - want_scale).abs().max()) <= 1.2e-7 * float(want_scale.abs().max())
+    assert float((shift.cpu() - (beta - mean * want_scale)).abs().max()) <= 1e-6
+    x = torch.randn((6, 32, 4, 4), generator=g, requires_grad=True)
+    y = x.mean(-1).mean(-1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    d_dy = gpu(dy)
+    dx = torch.empty((6, 4, 4, 32), device=DEV)
+    nv.check(lib.frcnn_spatial_mean_backward(nv.ptr(d_dy), nv.ptr(dx), 6, 4, 4, 32, S()), "spatial_mean_backward")
+    assert torch.equal(dx.permute(0, 3, 1, 2).cpu(), x.grad)
