@@ -13,7 +13,7 @@ Differences that are deliberate:
     (the reference recomputes them on the CPU per call, faster_rcnn.py:113-115);
   * `predict_async` / `Pending.result` expose the same computation with several images in flight
     on separate streams (each image is still an independent batch-1 forward);
-  * `train_step` (faster_rcnn.py:228-362, VGG-16 backbone) is written out as explicit forward + backward
+  * `train_step` (faster_rcnn.py:228-362, VGG-16 and ResNet backbones) is written out as explicit forward + backward
     + SGD over the C ABI in fasterrcnn_amd/training.py; the trained weights live in the kernels' packed
     layouts and are written back to the nn.Parameters lazily (before state_dict / predict / forward).
 There is no CPU / eager fallback: parameters must live on an MI355X (`.cuda()`).
@@ -280,7 +280,7 @@ class FasterRCNNModel(nn.Module):
         from .. import training
         if self._train_state is None:
             self._device()
-            self._train_state = training.TrainState(self)
+            self._train_state = training.make_train_state(self)
         return self._train_state
 
     def sync_parameters(self):

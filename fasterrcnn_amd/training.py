@@ -1,7 +1,7 @@
 """
 The train step of FasterRCNNModel (reference: models/faster_rcnn.py:228-362 `train_step`, the samplers at
 :364-561, the losses at models/rpn.py:176-272 and models/detector.py:83-155, torch.optim.SGD built at
-__main__.py:98-105) for the VGG-16 backbone -- SURVEY.md section 8 rows f2 + f3.
+__main__.py:98-105) for the VGG-16 and ResNet-50/101/152 backbones -- SURVEY.md section 8 rows f2 + f3.
 
 The reference leans on autograd; here the backward pass is written out operator by operator over the
 C ABI (include/frcnn_hip.h, "Training path"): every gradient GEMM is `frcnn_gemm_tn` /
@@ -14,7 +14,9 @@ kernel with a flipped/transposed weight pack.  Design points:
     `TrainState.sync_to_parameters()` writes them back to the nn.Parameters (reference key names/layouts)
     lazily -- before state_dict(), predict() or forward();
   * what the reference trains is reproduced exactly: only parameters with "weight" in their name and
-    requires_grad (blocks 1-2 of VGG-16 frozen, biases never updated);
+    requires_grad (VGG-16: blocks 1-2 frozen; ResNet: conv1, bn1, layer1 and every BatchNorm frozen, resnet.py:48-55,
+    86, 123 -- biases are never updated).  A frozen BatchNorm is folded into its convolution: the kernels run the
+    folded weight, SGD and weight decay act on the raw weight (gradient = BN scale x folded gradient);
   * host-side randomness is drawn exactly as the reference draws it (python `random.sample` for the anchor
     mini-batch, `torch.randperm` on the CPU generator for the proposal batch), so a seeded run selects the
     same samples;
@@ -129,37 +131,61 @@ def create_optimizer(model, learning_rate=1e-3, momentum=0.9, weight_decay=5e-4)
     return SGD(learning_rate, momentum, weight_decay)
 
 
+def conv_wgrad(x, dz, n, h, w, cin, cout, k, stride, pad):
+    """Weight-pack gradient [k*k][cout][cin] of a general NHWC convolution (frcnn_conv_wgrad)."""
+    lib = _lib()
+    dwp = t.empty((k * k, cout, cin), dtype=t.float32, device=x.device)
+    wsb = int(lib.frcnn_conv_wgrad_workspace_bytes(n, h, w, cin, cout, k, stride, pad))
+    ws = _ws(wsb, x.device) if wsb else None
+    nv.check(lib.frcnn_conv_wgrad(nv.ptr(x), nv.ptr(dz), nv.ptr(dwp), n, h, w, cin, cout, k, stride, pad, nv.ptr(ws), wsb,
+                                  nv.stream_ptr()), "frcnn_conv_wgrad")
+    return dwp
+
+
+def conv_dgrad(dz, wf, residual, n, h, w, cin, cout, k, stride, pad):
+    """Input gradient [n][h][w][cin] (+ residual) of a general NHWC convolution with (folded) weight pack wf."""
+    lib = _lib()
+    wd = t.empty((k * k, cin, cout), dtype=t.float32, device=dz.device)
+    nv.check(lib.frcnn_pack_conv_dgrad(nv.ptr(wf), nv.ptr(wd), k * k, cout, cin, nv.stream_ptr()), "frcnn_pack_conv_dgrad")
+    dx = t.empty((n, h, w, cin), dtype=t.float32, device=dz.device)
+    wsb = int(lib.frcnn_conv_dgrad_workspace_bytes(n, h, w, cin, cout, k, stride, pad))
+    ws = _ws(wsb, dz.device) if wsb else None
+    nv.check(lib.frcnn_conv_dgrad(nv.ptr(dz), nv.ptr(wd), nv.ptr(residual), nv.ptr(dx), n, h, w, cin, cout, k, stride, pad,
+                                  nv.ptr(ws), wsb, nv.stream_ptr()), "frcnn_conv_dgrad")
+    return dx
+
+
 class TrainState:
-    """Packed master weights + momentum buffers of one FasterRCNNModel (VGG-16)."""
+    """
+    Packed master weights + momentum buffers of one FasterRCNNModel, and the backbone-specific halves of the step:
+    `features_forward/backward` (stage 1) and `head_forward/backward` (RoI features -> feature vector).  The RPN and
+    the detector heads are common: `rpn_conv`, `rpn_head`, `head` (+ biases).
+    """
+    C = 0          # feature-map channels
+    V = 0          # feature-vector size
+
     def __init__(self, model):
         self.model = model
-        fe = model._stage1_feature_extractor
-        rp = model._stage2_region_proposal_network
-        dn = model._stage3_detector_network
-        pv = dn._pool_to_feature_vector
         if model.math_mode != "f32":
             raise NotImplementedError("training runs in the exact-f32 math mode")
-        if pv._dropout1.p > 0 or pv._dropout2.p > 0:
-            raise NotImplementedError("dropout > 0 is not implemented in the train step (reference default: 0.0)")
-        # clones: the inference-side packed caches are rebuilt from the parameters, these are the training masters
-        self.conv = [(wp.clone(), b.clone()) for wp, b in fe.packed()]
+        rp = model._stage2_region_proposal_network
+        dn = model._stage3_detector_network
         wc, bc, wh, bh = rp.packed()
         self.rpn_conv, self.rpn_conv_b, self.rpn_head, self.rpn_head_b = wc.clone(), bc.clone(), wh.clone(), bh.clone()
-        w1p, b1, w2, b2 = pv.packed()
-        self.fc1, self.fc1_b, self.fc2, self.fc2_b = w1p.clone(), b1.clone(), w2.clone(), b2.clone()
         hw, hb = dn.packed()
         self.head, self.head_b = hw.clone(), hb.clone()
-        self.device = self.fc1.device
-        self.zero_bias = t.zeros((1024,), dtype=t.float32, device=self.device)
+        self.device = self.head.device
+        self.zero_bias = t.zeros((2048,), dtype=t.float32, device=self.device)
         self.momentum = {}
         self.steps = 0
         self.dirty = False
 
     def trainable(self):
         """name -> packed master tensor, for everything SGD updates."""
-        out = {"conv%d" % i: self.conv[i][0] for i in _TRAINABLE_CONVS}
-        out.update(rpn_conv=self.rpn_conv, rpn_head=self.rpn_head, fc1=self.fc1, fc2=self.fc2, head=self.head)
-        return out
+        raise NotImplementedError
+
+    def after_update(self):
+        """Hook: derived packs (BN-folded weights) are rebuilt from the masters after SGD."""
 
     def apply_sgd(self, grads, lr, momentum, weight_decay):
         lib = _lib()
@@ -177,33 +203,303 @@ class TrainState:
                     first = 1
             nv.check(lib.frcnn_sgd_step(nv.ptr(w), nv.ptr(g), nv.ptr(buf), w.numel(), lr, momentum, weight_decay, first,
                                         nv.stream_ptr()), "frcnn_sgd_step")
+        self.after_update()
         self.steps += 1
         self.dirty = True
 
     @t.no_grad()
     def sync_to_parameters(self):
-        """Writes the packed masters back into the nn.Parameters (OIHW convs, (C,7,7)-ordered fc1, separate heads)."""
+        """Writes the packed masters back into the nn.Parameters (reference layouts and key names)."""
         if not self.dirty:
             return
         m = self.model
-        fe = m._stage1_feature_extractor
-        for i in _TRAINABLE_CONVS:
-            conv = fe.convs()[i]
-            co, ci = int(conv.weight.shape[0]), int(conv.weight.shape[1])
-            conv.weight.copy_(self.conv[i][0].permute(1, 2, 0).reshape(co, ci, 3, 3))
         rp = m._stage2_region_proposal_network
         c = int(rp._rpn_conv1.weight.shape[0])
         rp._rpn_conv1.weight.copy_(self.rpn_conv.permute(1, 2, 0).reshape(c, c, 3, 3))
         rp._rpn_class.weight.copy_(self.rpn_head[0:9].reshape(9, c, 1, 1))
         rp._rpn_boxes.weight.copy_(self.rpn_head[9:45].reshape(36, c, 1, 1))
         dn = m._stage3_detector_network
-        pv = dn._pool_to_feature_vector
-        pv._fc1.weight.copy_(self.fc1.reshape(4096, 49, 512).permute(0, 2, 1).reshape(4096, 512 * 49))
-        pv._fc2.weight.copy_(self.fc2)
         ncls = m._num_classes
         dn._classifier.weight.copy_(self.head[0:ncls])
         dn._regressor.weight.copy_(self.head[ncls:ncls + 4 * (ncls - 1)])
+        self._sync_backbone()
         self.dirty = False
+
+    def _sync_backbone(self):
+        raise NotImplementedError
+
+
+class VGG16TrainState(TrainState):
+    """VGG-16: blocks 1-2 frozen (vgg16.py:49-58); conv3_1..conv5_3, fc1, fc2 train."""
+    C, V = 512, 4096
+
+    def __init__(self, model):
+        super().__init__(model)
+        fe = model._stage1_feature_extractor
+        pv = model._stage3_detector_network._pool_to_feature_vector
+        if pv._dropout1.p > 0 or pv._dropout2.p > 0:
+            raise NotImplementedError("dropout > 0 is not implemented in the train step (reference default: 0.0)")
+        # clones: the inference-side packed caches are rebuilt from the parameters, these are the training masters
+        self.conv = [(wp.clone(), b.clone()) for wp, b in fe.packed()]
+        w1p, b1, w2, b2 = pv.packed()
+        self.fc1, self.fc1_b, self.fc2, self.fc2_b = w1p.clone(), b1.clone(), w2.clone(), b2.clone()
+
+    def trainable(self):
+        out = {"conv%d" % i: self.conv[i][0] for i in _TRAINABLE_CONVS}
+        out.update(rpn_conv=self.rpn_conv, rpn_head=self.rpn_head, fc1=self.fc1, fc2=self.fc2, head=self.head)
+        return out
+
+    def _sync_backbone(self):
+        m = self.model
+        fe = m._stage1_feature_extractor
+        for i in _TRAINABLE_CONVS:
+            conv = fe.convs()[i]
+            co, ci = int(conv.weight.shape[0]), int(conv.weight.shape[1])
+            conv.weight.copy_(self.conv[i][0].permute(1, 2, 0).reshape(co, ci, 3, 3))
+        pv = m._stage3_detector_network._pool_to_feature_vector
+        pv._fc1.weight.copy_(self.fc1.reshape(4096, 49, 512).permute(0, 2, 1).reshape(4096, 512 * 49))
+        pv._fc2.weight.copy_(self.fc2)
+
+    # ---- stage 1 (vgg16.py:76-96) -------------------------------------------------------------------------
+    def features_forward(self, image):
+        lib = _lib()
+        H, W = int(image.shape[2]), int(image.shape[3])
+        x_in, y_out = {}, {}
+        cur = t.empty((H, W, 64), dtype=t.float32, device=self.device)
+        nv.check(lib.frcnn_conv3x3_c3(nv.ptr(image), nv.ptr(self.conv[0][0]), nv.ptr(self.conv[0][1]), nv.ptr(cur), H, W, 64,
+                                      nv.RELU, nv.stream_ptr()), "frcnn_conv3x3_c3")
+        for i in range(1, 13):
+            _, cin, cout, pool = vgg16._LAYERS[i]
+            wp, b = self.conv[i]
+            if i in _TRAINABLE_CONVS:
+                x_in[i] = cur
+                y = vgg16.conv3x3(cur, wp, b, cin, cout, relu=True, pool=False)
+                y_out[i] = y
+                cur = maxpool2x2(y) if pool else y
+            else:
+                cur = vgg16.conv3x3(cur, wp, b, cin, cout, relu=True, pool=pool)      # frozen: pool fused
+        return cur, (x_in, y_out)
+
+    def features_backward(self, g, saved, grads):
+        """autograd of vgg16.py:84-96; `g` = gradient with respect to the (post-ReLU) feature map."""
+        x_in, y_out = saved
+        for i in range(12, 3, -1):
+            _, cin, cout, _ = vgg16._LAYERS[i]
+            relu_backward(g, y_out[i])
+            grads["conv%d" % i] = conv3x3_wgrad(x_in[i], g, cin, cout)
+            if i > 4:
+                gx = conv3x3_dgrad(g, self.conv[i][0], cin, cout, self.zero_bias)
+                g = maxpool2x2_backward(y_out[i - 1], gx) if (i - 1) in _POOL_AFTER else gx
+
+    # ---- RoI features -> feature vector (vgg16.py:129-133) ------------------------------------------------
+    def head_forward(self, roi_out):
+        h1 = vgg16.linear(roi_out, self.fc1, self.fc1_b, 4096, relu=True)
+        h2 = vgg16.linear(h1, self.fc2, self.fc2_b, 4096, relu=True)
+        return h2, (roi_out, h1, h2)
+
+    def head_backward(self, dh2, saved, grads, detail=None):
+        roi_out, h1, h2 = saved
+        S = int(h2.shape[0])
+        if detail is not None:
+            detail["dh2"] = dh2.clone()
+        relu_backward(dh2, h2)
+        grads["fc2"] = gemm_tn(dh2, 4096, h1, 4096, 4096, 4096, S)
+        dh2_t, sp = transpose(dh2, S, 4096, 4096)
+        dh1 = gemm_tn(dh2_t, sp, self.fc2, 4096, S, 4096, 4096)
+        if detail is not None:
+            detail["dh1"] = dh1.clone()
+            detail.update(h1=h1, h2=h2)
+        relu_backward(dh1, h1)
+        grads["fc1"] = gemm_tn(dh1, 4096, roi_out, 49 * 512, 4096, 49 * 512, S)
+        dh1_t, sp = transpose(dh1, S, 4096, 4096)
+        return gemm_tn(dh1_t, sp, self.fc1, 49 * 512, S, 49 * 512, 4096)
+
+    def zero_head_grads(self, grads):
+        for name in ("fc2", "fc1"):
+            grads[name] = t.zeros_like(self.trainable()[name])
+
+
+class _TrainConv:
+    """One conv + frozen BatchNorm of a trainable Bottleneck: raw master pack, BN scale/shift, folded pack."""
+    def __init__(self, conv, bn):
+        lib = _lib()
+        w = rt.as_f32_cuda(conv.weight.detach(), "conv weight")
+        self.cout, self.cin, self.k = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+        self.stride, self.pad = int(conv.stride[0]), int(conv.padding[0])
+        self.conv = conv
+        # [tap][co][ci]; clone: for a 1x1 conv the permuted view IS the parameter's storage
+        self.raw = w.permute(2, 3, 0, 1).reshape(self.k * self.k, self.cout, self.cin).clone(memory_format=t.contiguous_format)
+        self.scale = t.empty((self.cout,), dtype=t.float32, device=w.device)
+        self.shift = t.empty((self.cout,), dtype=t.float32, device=w.device)
+        args = [rt.as_f32_cuda(x.detach(), "bn tensor") for x in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+        nv.check(lib.frcnn_bn_scale_shift(nv.ptr(args[0]), nv.ptr(args[1]), nv.ptr(args[2]), nv.ptr(args[3]), float(bn.eps),
+                                          self.cout, nv.ptr(self.scale), nv.ptr(self.shift), nv.stream_ptr()), "frcnn_bn_scale_shift")
+        self.folded = t.empty_like(self.raw)
+        self.refold()
+
+    def refold(self):
+        nv.check(_lib().frcnn_scale_rows(nv.ptr(self.raw), nv.ptr(self.scale), nv.ptr(self.folded), self.k * self.k, self.cout,
+                                         self.cin, nv.stream_ptr()), "frcnn_scale_rows")
+
+    def forward(self, x, n, h, w, relu, residual=None):
+        from .models import resnet
+        return resnet.conv_nhwc(x, self.folded, self.shift, n, h, w, self.cin, self.cout, self.k, self.stride, self.pad, relu,
+                                residual=residual)
+
+    def wgrad(self, x, dz, n, h, w):
+        """Gradient with respect to the RAW weight: the folded weight's gradient times the BN scale of its output channel."""
+        g = conv_wgrad(x, dz, n, h, w, self.cin, self.cout, self.k, self.stride, self.pad)
+        nv.check(_lib().frcnn_scale_rows(nv.ptr(g), nv.ptr(self.scale), nv.ptr(g), self.k * self.k, self.cout, self.cin,
+                                         nv.stream_ptr()), "frcnn_scale_rows")
+        return g
+
+    def dgrad(self, dz, residual, n, h, w):
+        return conv_dgrad(dz, self.folded, residual, n, h, w, self.cin, self.cout, self.k, self.stride, self.pad)
+
+    def sync(self):
+        self.conv.weight.copy_(self.raw.permute(1, 2, 0).reshape(self.cout, self.cin, self.k, self.k))
+
+
+class _TrainBlock:
+    """A trainable Bottleneck (torchvision v1.5): out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + identity)."""
+    def __init__(self, block, name):
+        self.name = name
+        self.c1 = _TrainConv(block.conv1, block.bn1)
+        self.c2 = _TrainConv(block.conv2, block.bn2)
+        self.c3 = _TrainConv(block.conv3, block.bn3)
+        self.cd = _TrainConv(block.downsample[0], block.downsample[1]) if block.downsample is not None else None
+
+    def convs(self):
+        out = {"conv1": self.c1, "conv2": self.c2, "conv3": self.c3}
+        if self.cd is not None:
+            out["downsample"] = self.cd
+        return out
+
+    def forward(self, x, n, h, w):
+        t1, _, _ = self.c1.forward(x, n, h, w, True)
+        t2, ho, wo = self.c2.forward(t1, n, h, w, True)
+        identity = x
+        if self.cd is not None:
+            identity, _, _ = self.cd.forward(x, n, h, w, False)
+        out, _, _ = self.c3.forward(t2, n, ho, wo, True, residual=identity)
+        return out, ho, wo, (x, t1, t2, out, n, h, w, ho, wo)
+
+    def backward(self, g, saved, grads, need_dx):
+        """`g` = gradient with respect to the block output (consumed); returns the gradient with respect to x or None."""
+        x, t1, t2, out, n, h, w, ho, wo = saved
+        relu_backward(g, out)
+        grads[self.name + ".conv3"] = self.c3.wgrad(t2, g, n, ho, wo)
+        d_t2 = self.c3.dgrad(g, None, n, ho, wo)
+        relu_backward(d_t2, t2)
+        grads[self.name + ".conv2"] = self.c2.wgrad(t1, d_t2, n, h, w)
+        d_t1 = self.c2.dgrad(d_t2, None, n, h, w)
+        relu_backward(d_t1, t1)
+        grads[self.name + ".conv1"] = self.c1.wgrad(x, d_t1, n, h, w)
+        if self.cd is not None:
+            grads[self.name + ".downsample"] = self.cd.wgrad(x, g, n, h, w)
+        if not need_dx:
+            return None
+        dx_id = self.cd.dgrad(g, None, n, h, w) if self.cd is not None else g
+        return self.c1.dgrad(d_t1, dx_id, n, h, w)
+
+
+class ResNetTrainState(TrainState):
+    """
+    ResNet-50/101/152: conv1, bn1, layer1 and every BatchNorm frozen (resnet.py:48-55,86,123); the convolutions of layer2,
+    layer3 (feature extractor) and layer4 (per-RoI head) train.  A frozen BatchNorm is an affine map per channel, so each
+    conv+BN runs as ONE convolution with the folded weight W * scale[co]; the master (what SGD and weight decay act on) is
+    the raw weight, its gradient = scale[co] * the folded weight's gradient, and the folded pack is rebuilt after every update.
+    """
+    C, V = 1024, 2048
+
+    def __init__(self, model):
+        super().__init__(model)
+        fe = model._stage1_feature_extractor
+        seq = fe._feature_extractor
+        pk = fe.packed()
+        n1 = len(seq[4])
+        self.stem = (pk["stem"][0], pk["stem"][1])
+        self.frozen_blocks = pk["blocks"][:n1]                      # layer1: folded inference packs
+        with t.cuda.device(self.device):
+            self.blocks = [_TrainBlock(b, "layer2.%d" % i) for i, b in enumerate(seq[5])] + \
+                          [_TrainBlock(b, "layer3.%d" % i) for i, b in enumerate(seq[6])]
+            l4 = model._stage3_detector_network._pool_to_feature_vector._layer4
+            self.head_blocks = [_TrainBlock(b, "layer4.%d" % i) for i, b in enumerate(l4)]
+
+    def trainable(self):
+        out = {}
+        for blk in self.blocks + self.head_blocks:
+            for cname, c in blk.convs().items():
+                out[blk.name + "." + cname] = c.raw
+        out.update(rpn_conv=self.rpn_conv, rpn_head=self.rpn_head, head=self.head)
+        return out
+
+    def after_update(self):
+        for blk in self.blocks + self.head_blocks:
+            for c in blk.convs().values():
+                c.refold()
+
+    def _sync_backbone(self):
+        for blk in self.blocks + self.head_blocks:
+            for c in blk.convs().values():
+                c.sync()
+
+    # ---- stage 1 (resnet.py:38-46) ------------------------------------------------------------------------
+    def features_forward(self, image):
+        from .models import resnet
+        lib = _lib()
+        h, w = int(image.shape[2]), int(image.shape[3])
+        h1, w1 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = t.empty((h1, w1, 64), dtype=t.float32, device=self.device)
+        nv.check(lib.frcnn_conv7x7_s2_c3(nv.ptr(image), nv.ptr(self.stem[0]), nv.ptr(self.stem[1]), nv.ptr(y), h, w, 64, nv.RELU,
+                                         nv.stream_ptr()), "frcnn_conv7x7_s2_c3")
+        h2, w2 = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
+        cur = t.empty((1, h2, w2, 64), dtype=t.float32, device=self.device)
+        nv.check(lib.frcnn_maxpool3x3_s2_nhwc(nv.ptr(y), nv.ptr(cur), h1, w1, 64, nv.stream_ptr()), "frcnn_maxpool3x3_s2_nhwc")
+        h, w = h2, w2
+        for pb in self.frozen_blocks:
+            cur, h, w = resnet.run_block(cur, 1, h, w, pb)
+        saved = []
+        for blk in self.blocks:
+            cur, h, w, sv = blk.forward(cur, 1, h, w)
+            saved.append(sv)
+        return cur[0], saved                                        # [fh][fw][1024]
+
+    def features_backward(self, g, saved, grads):
+        g = g.reshape(1, g.shape[0], g.shape[1], g.shape[2])
+        for i in range(len(self.blocks) - 1, -1, -1):
+            g = self.blocks[i].backward(g, saved[i], grads, need_dx=(i > 0))      # layer1 below is frozen: no dx for block 0
+
+    # ---- RoI features -> feature vector (resnet.py:109-118) -----------------------------------------------
+    def head_forward(self, roi_out):
+        S = int(roi_out.shape[0])
+        cur = roi_out.reshape(S, 7, 7, 1024)
+        h = w = 7
+        saved = []
+        for blk in self.head_blocks:
+            cur, h, w, sv = blk.forward(cur, S, h, w)
+            saved.append(sv)
+        vec = t.empty((S, 2048), dtype=t.float32, device=self.device)
+        nv.check(_lib().frcnn_spatial_mean_nhwc(nv.ptr(cur), nv.ptr(vec), S, h, w, 2048, nv.stream_ptr()), "frcnn_spatial_mean_nhwc")
+        return vec, (saved, S, h, w)
+
+    def head_backward(self, dvec, saved, grads, detail=None):
+        blocks_saved, S, h, w = saved
+        g = t.empty((S, h, w, 2048), dtype=t.float32, device=self.device)
+        nv.check(_lib().frcnn_spatial_mean_backward(nv.ptr(dvec), nv.ptr(g), S, h, w, 2048, nv.stream_ptr()),
+                 "frcnn_spatial_mean_backward")
+        for i in range(len(self.head_blocks) - 1, -1, -1):
+            g = self.head_blocks[i].backward(g, blocks_saved[i], grads, need_dx=True)
+        return g.reshape(S, 49 * 1024)
+
+    def zero_head_grads(self, grads):
+        for blk in self.head_blocks:
+            for cname, c in blk.convs().items():
+                grads[blk.name + "." + cname] = t.zeros_like(c.raw)
+
+
+def make_train_state(model):
+    return ResNetTrainState(model) if model._is_resnet else VGG16TrainState(model)
 
 
 def _flat_anchor_indices(index_map, fw):
@@ -224,8 +520,6 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
     assert len(gt_rpn_object_indices) == 1, "Batch size must be 1"
     assert len(gt_rpn_background_indices) == 1, "Batch size must be 1"
     assert len(gt_boxes) == 1, "Batch size must be 1"
-    if model._is_resnet:
-        raise NotImplementedError("train_step is implemented for the VGG-16 backbone")
     lr, momentum, weight_decay = sgd_hyper_parameters(optimizer)
     st = model._training_state()
     dev = st.device
@@ -234,32 +528,19 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
     H, W = int(image.shape[2]), int(image.shape[3])
     ncls = model._num_classes
     nd = 4 * (ncls - 1)
+    C, V = st.C, st.V
     with t.no_grad(), t.cuda.device(dev):
         s = nv.stream_ptr()
-        # ---- stage 1 forward, keeping what the backward needs (vgg16.py:76-96) -----------------------
-        x_in, y_out = {}, {}
-        cur = t.empty((H, W, 64), dtype=t.float32, device=dev)
-        nv.check(lib.frcnn_conv3x3_c3(nv.ptr(image), nv.ptr(st.conv[0][0]), nv.ptr(st.conv[0][1]), nv.ptr(cur), H, W, 64,
-                                      nv.RELU, s), "frcnn_conv3x3_c3")
-        for i in range(1, 13):
-            _, cin, cout, pool = vgg16._LAYERS[i]
-            wp, b = st.conv[i]
-            if i in _TRAINABLE_CONVS:
-                x_in[i] = cur
-                y = vgg16.conv3x3(cur, wp, b, cin, cout, relu=True, pool=False)
-                y_out[i] = y
-                cur = maxpool2x2(y) if pool else y
-            else:
-                cur = vgg16.conv3x3(cur, wp, b, cin, cout, relu=True, pool=pool)      # frozen: pool fused
-        fm = cur                                                                       # [fh][fw][512]
+        # ---- stage 1 forward, keeping what the backward needs ------------------------------------------
+        fm, fsaved = st.features_forward(image)                                        # [fh][fw][C]
         fh, fw = int(fm.shape[0]), int(fm.shape[1])
         P = fh * fw
         # ---- stage 2 forward (rpn.py:88-156, 12000 / 2000 in training: faster_rcnn.py:301-302) --------
-        trunk = vgg16.conv3x3(fm, st.rpn_conv, st.rpn_conv_b, 512, 512, relu=True, pool=False)
+        trunk = vgg16.conv3x3(fm, st.rpn_conv, st.rpn_conv_b, C, C, relu=True, pool=False)
         head = t.zeros((P, 128), dtype=t.float32, device=dev)
-        wsb = int(lib.frcnn_linear_workspace_bytes(P, 45, 512))
+        wsb = int(lib.frcnn_linear_workspace_bytes(P, 45, C))
         ws = _ws(wsb, dev)
-        nv.check(lib.frcnn_linear(nv.ptr(trunk), 512, nv.ptr(st.rpn_head), nv.ptr(st.rpn_head_b), nv.ptr(head), 128, P, 45, 512,
+        nv.check(lib.frcnn_linear(nv.ptr(trunk), C, nv.ptr(st.rpn_head), nv.ptr(st.rpn_head_b), nv.ptr(head), 128, P, 45, C,
                                   0, nv.ptr(ws), wsb, s), "frcnn_linear")
         amap = rt.to_device_map(anchor_map, dev)
         vmap = rt.to_device_map(anchor_valid_map, dev)
@@ -318,13 +599,12 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
             for src, dst, rf in ((lab_props, s_props, 4), (lab_onehot, s_onehot, ncls), (lab_deltas, s_deltas, 2 * nd)):
                 nv.check(lib.frcnn_gather_rows(nv.ptr(src), nv.ptr(idx_dev), S, rf, nv.ptr(dst), s), "frcnn_gather_rows")
             # ---- stage 3 forward (detector.py:65-80) ------------------------------------------------
-            roi_out = t.empty((S, 49 * 512), dtype=t.float32, device=dev)
+            roi_out = t.empty((S, 49 * C), dtype=t.float32, device=dev)
             cnt = t.tensor([S], dtype=t.int32, device=dev)
-            nv.check(lib.frcnn_roi_pool(nv.ptr(fm), fh, fw, 512, nv.ptr(s_props), nv.ptr(cnt), S, 7, 1.0 / 16.0,
+            nv.check(lib.frcnn_roi_pool(nv.ptr(fm), fh, fw, C, nv.ptr(s_props), nv.ptr(cnt), S, 7, 1.0 / 16.0,
                                         nv.ptr(roi_out), s), "frcnn_roi_pool")
-            h1 = vgg16.linear(roi_out, st.fc1, st.fc1_b, 4096, relu=True)
-            h2 = vgg16.linear(h1, st.fc2, st.fc2_b, 4096, relu=True)
-            logits = vgg16.linear(h2, st.head, st.head_b, ncls + nd, relu=False)
+            vec, hsaved = st.head_forward(roi_out)
+            logits = vgg16.linear(vec, st.head, st.head_b, ncls + nd, relu=False)
             classes = t.empty((S, ncls), dtype=t.float32, device=dev)
             nv.check(lib.frcnn_softmax_rows(nv.ptr(logits), ncls + nd, nv.ptr(classes), S, ncls, s), "frcnn_softmax_rows")
             deltas = logits[:, ncls:].contiguous()
@@ -332,56 +612,39 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
             nv.check(lib.frcnn_detector_loss(nv.ptr(classes), nv.ptr(deltas), nv.ptr(s_onehot), nv.ptr(s_deltas), S, ncls,
                                              losses.data_ptr() + 8, nv.ptr(dlogits), 128, s), "frcnn_detector_loss")
             # ---- stage 3 backward ---------------------------------------------------------------------
-            grads["head"] = gemm_tn(dlogits, 128, h2, 4096, 128, 4096, S)
+            grads["head"] = gemm_tn(dlogits, 128, vec, V, 128, V, S)
             dl_t, sp = transpose(dlogits, S, 128, 128)
-            dh2 = gemm_tn(dl_t, sp, st.head, 4096, S, 4096, 128)
-            if detail is not None:
-                detail["dh2"] = dh2.clone()
-            relu_backward(dh2, h2)
-            grads["fc2"] = gemm_tn(dh2, 4096, h1, 4096, 4096, 4096, S)
-            dh2_t, sp = transpose(dh2, S, 4096, 4096)
-            dh1 = gemm_tn(dh2_t, sp, st.fc2, 4096, S, 4096, 4096)
-            if detail is not None:
-                detail["dh1"] = dh1.clone()
-            relu_backward(dh1, h1)
-            grads["fc1"] = gemm_tn(dh1, 4096, roi_out, 49 * 512, 4096, 49 * 512, S)
-            dh1_t, sp = transpose(dh1, S, 4096, 4096)
-            droi = gemm_tn(dh1_t, sp, st.fc1, 49 * 512, S, 49 * 512, 4096)
-            dfm = t.empty((fh, fw, 512), dtype=t.float32, device=dev)
-            wsb = int(lib.frcnn_roi_pool_backward_workspace_bytes(S, 7, 512))
+            dvec = gemm_tn(dl_t, sp, st.head, V, S, V, 128)
+            droi = st.head_backward(dvec, hsaved, grads, detail)
+            dfm = t.empty((fh, fw, C), dtype=t.float32, device=dev)
+            wsb = int(lib.frcnn_roi_pool_backward_workspace_bytes(S, 7, C))
             ws = _ws(wsb, dev)
-            nv.check(lib.frcnn_roi_pool_backward(nv.ptr(fm), fh, fw, 512, nv.ptr(s_props), S, 7, 1.0 / 16.0, nv.ptr(droi),
+            nv.check(lib.frcnn_roi_pool_backward(nv.ptr(fm), fh, fw, C, nv.ptr(s_props), S, 7, 1.0 / 16.0, nv.ptr(droi),
                                                  nv.ptr(dfm), 0, nv.ptr(ws), wsb, s), "frcnn_roi_pool_backward")
             if detail is not None:
                 detail.update(sampled_props=s_props, sampled_onehot=s_onehot, sampled_deltas=s_deltas, classes=classes,
-                              deltas=deltas, dlogits=dlogits, h1=h1, h2=h2, roi_out=roi_out, dfm_roi=dfm.clone(), droi=droi)
+                              deltas=deltas, dlogits=dlogits, vec=vec, roi_out=roi_out, dfm_roi=dfm.clone(), droi=droi)
         else:
-            for name in ("head", "fc2", "fc1"):
-                grads[name] = t.zeros_like(st.trainable()[name])
+            grads["head"] = t.zeros_like(st.head)
+            st.zero_head_grads(grads)
         # ---- RPN losses + backward (rpn.py:176-272) ---------------------------------------------------
         dhead = t.empty((P, 128), dtype=t.float32, device=dev)
         nv.check(lib.frcnn_rpn_loss(nv.ptr(head), 128, P, nv.ptr(rpn_sample), int(rpn_sample.shape[0]), nv.ptr(rpn_map),
                                     nv.ptr(losses), nv.ptr(dhead), s), "frcnn_rpn_loss")
-        grads["rpn_head"] = gemm_tn(dhead, 128, trunk, 512, 128, 512, P)
+        grads["rpn_head"] = gemm_tn(dhead, 128, trunk, C, 128, C, P)
         dhead_t, pp = transpose(dhead, P, 128, 128)
-        dtrunk = gemm_tn(dhead_t, pp, st.rpn_head, 512, P, 512, 128).reshape(fh, fw, 512)
+        dtrunk = gemm_tn(dhead_t, pp, st.rpn_head, C, P, C, 128).reshape(fh, fw, C)
         relu_backward(dtrunk, trunk)
-        grads["rpn_conv"] = conv3x3_wgrad(fm, dtrunk, 512, 512)
-        g = conv3x3_dgrad(dtrunk, st.rpn_conv, 512, 512, st.zero_bias)
+        grads["rpn_conv"] = conv3x3_wgrad(fm, dtrunk, C, C)
+        g = conv3x3_dgrad(dtrunk, st.rpn_conv, C, C, st.zero_bias)
         if dfm is not None:
             nv.check(lib.frcnn_add_inplace(nv.ptr(g), nv.ptr(dfm), g.numel(), s), "frcnn_add_inplace")
         if detail is not None:
             detail.update(dfm=g.clone(), dhead=dhead, head=head, trunk=trunk, fm=fm, rpn_sample=rpn_sample,
                           proposals=props, counts=counts, labelled=(lab_props[:K], lab_cls[:K], lab_onehot[:K], lab_deltas[:K]),
                           sample_idx=sample_idx)
-        # ---- stage 1 backward (autograd of vgg16.py:84-96; blocks 1-2 are frozen) ----------------------
-        for i in range(12, 3, -1):
-            _, cin, cout, _ = vgg16._LAYERS[i]
-            relu_backward(g, y_out[i])
-            grads["conv%d" % i] = conv3x3_wgrad(x_in[i], g, cin, cout)
-            if i > 4:
-                gx = conv3x3_dgrad(g, st.conv[i][0], cin, cout, st.zero_bias)
-                g = maxpool2x2_backward(y_out[i - 1], gx) if (i - 1) in _POOL_AFTER else gx
+        # ---- stage 1 backward ---------------------------------------------------------------------------
+        st.features_backward(g, fsaved, grads)
         # ---- SGD (torch.optim.SGD.step, __main__.py:98-105) --------------------------------------------
         if detail is not None:
             detail["grads"] = {k: v.clone() for k, v in grads.items()}

@@ -281,7 +281,7 @@ def sample_positions(n, count=2048):
     return np.unique(np.linspace(0, n - 1, min(count, n)).astype(np.int64))
 
 
-def golden_train(ref, tag, seed, height, width, steps=2, lr=1e-6, momentum=0.9, weight_decay=5e-4):
+def golden_train(ref, tag, seed, height, width, steps=2, lr=1e-6, momentum=0.9, weight_decay=5e-4, arch=None):
     """
     Runs the REFERENCE's train_step (faster_rcnn.py:228-362) with torch.optim.SGD built as __main__.py:98-105 does,
     asserts oracle/train_oracle.py reproduces losses / gradients / updated weights bit for bit under the same RNG
@@ -290,12 +290,15 @@ def golden_train(ref, tag, seed, height, width, steps=2, lr=1e-6, momentum=0.9, 
     import random
     from oracle import train_oracle as TO
     print("train case %s: image seed %d, %dx%d, %d steps" % (tag, seed, height, width, steps))
-    sd0 = synthetic.vgg16_state_dict(1234)
-    img = synthetic.image(seed, height, width).unsqueeze(0)
+    sd0 = synthetic.resnet_state_dict(1234, arch) if arch else synthetic.vgg16_state_dict(1234)
+    img = (synthetic.image_rgb if arch else synthetic.image)(seed, height, width).unsqueeze(0)
     gts = synthetic.ground_truth(seed, height, width)
     Box = ref.training_sample.Box
     boxes = [Box(c, "x", k) for c, k in gts]
-    backbone = ref.vgg16.VGG16Backbone(dropout_probability=0.0)
+    if arch:
+        backbone = ref.resnet.ResNetBackbone(architecture=getattr(ref.resnet.Architecture, arch))
+    else:
+        backbone = ref.vgg16.VGG16Backbone(dropout_probability=0.0)
     model = ref.faster_rcnn.FasterRCNNModel(num_classes=21, backbone=backbone, allow_edge_proposals=True)
     model.load_state_dict(sd0, strict=True)
     ishape = tuple(img.shape[1:])
@@ -377,7 +380,7 @@ def golden_train(ref, tag, seed, height, width, steps=2, lr=1e-6, momentum=0.9, 
             out[pre + "dwsample/" + k] = dw[pos].astype(np.float32)
         sd = new_sd
         rng_py, rng_t = ref_after_py, ref_after_t
-    name = "train_vgg16_%s.npz" % tag
+    name = "train_%s_%s.npz" % (arch.lower() if arch else "vgg16", tag)
     np.savez_compressed(os.path.join(GOLDEN, name), **out)
     print("  wrote tests/golden/%s" % name)
 
@@ -399,8 +402,10 @@ def main():
         return
     os.makedirs(GOLDEN, exist_ok=True)
     if args.train:
-        golden_train(ref, "352x480_s4", 4, 352, 480)
-        golden_train(ref, "416x544_s6", 6, 416, 544)
+        if not args.only_resnet:
+            golden_train(ref, "352x480_s4", 4, 352, 480)
+            golden_train(ref, "416x544_s6", 6, 416, 544)
+        golden_train(ref, "352x480_s4", 4, 352, 480, arch="ResNet50")
         return
     if not args.only_resnet:
         golden_small_ops(ref)

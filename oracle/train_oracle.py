@@ -34,12 +34,23 @@ FROZEN = ("_block1_conv1", "_block1_conv2", "_block2_conv1", "_block2_conv2")   
 
 
 def trainable_weight_keys(sd):
-    """The parameters __main__.py:98-105 hands to SGD: requires_grad and "weight" in the key (biases are NOT trained)."""
+    """
+    The parameters __main__.py:98-105 hands to SGD: requires_grad and "weight" in the key (biases are NOT trained).
+    VGG-16: blocks 1-2 frozen (vgg16.py:49-58).  ResNet: conv1, bn1, layer1 and EVERY BatchNorm frozen
+    (resnet.py:48-55,86,123), so the conv weights of layer2, layer3 and layer4 train.
+    """
     keys = []
+    resnet = orc.is_resnet(sd)
+    rfe = _S1 + "_feature_extractor."
     for k in sd:
         if "weight" not in k:
             continue
-        if any((_S1 + f + ".") in k for f in FROZEN):
+        if resnet:
+            if k.startswith(rfe + "0.") or k.startswith(rfe + "1.") or k.startswith(rfe + "4."):
+                continue
+            if ".bn" in k or ".downsample.1." in k:            # BatchNorm affine weights are frozen
+                continue
+        elif any((_S1 + f + ".") in k for f in FROZEN):
             continue
         keys.append(k)
     return keys
@@ -257,7 +268,8 @@ def train_step(sd, image, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_objec
     train_keys = trainable_weight_keys(sd)
     p = {k: v.clone().requires_grad_(k in train_keys) for k, v in sd.items()}
     image_shape = tuple(image.shape[1:])
-    fm = vgg16_features_train(p, image, detail)
+    resnet = orc.is_resnet(sd)
+    fm = orc.resnet_features(p, image) if resnet else vgg16_features_train(p, image, detail)
     # stage 2 (rpn.py:88-156) with 12000 / 2000
     y = F.relu(F.conv2d(fm, p[_S2 + "_rpn_conv1.weight"], p[_S2 + "_rpn_conv1.bias"], padding=1))
     score_map = t.sigmoid(F.conv2d(y, p[_S2 + "_rpn_class.weight"], p[_S2 + "_rpn_class.bias"]))
@@ -278,10 +290,14 @@ def train_step(sd, image, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_objec
         detail["sampled"] = (props.clone(), gt_classes.clone(), gt_box_deltas.clone())
     # stage 3 (detector.py:65-80)
     pooled = roi_pool_autograd(fm, props)
-    x = pooled.reshape(pooled.shape[0], 512 * 7 * 7)
-    pv = _S3 + "_pool_to_feature_vector."
-    h1 = F.relu(F.linear(x, p[pv + "_fc1.weight"], p[pv + "_fc1.bias"]))
-    h2 = F.relu(F.linear(h1, p[pv + "_fc2.weight"], p[pv + "_fc2.bias"]))
+    if resnet:
+        h1 = None
+        h2 = orc.resnet_pool_to_feature_vector(p, pooled)                     # layer4 + mean (resnet.py:109-118)
+    else:
+        x = pooled.reshape(pooled.shape[0], 512 * 7 * 7)
+        pv = _S3 + "_pool_to_feature_vector."
+        h1 = F.relu(F.linear(x, p[pv + "_fc1.weight"], p[pv + "_fc1.bias"]))
+        h2 = F.relu(F.linear(h1, p[pv + "_fc2.weight"], p[pv + "_fc2.bias"]))
     classes = F.softmax(F.linear(h2, p[_S3 + "_classifier.weight"], p[_S3 + "_classifier.bias"]), dim=1)
     deltas = F.linear(h2, p[_S3 + "_regressor.weight"], p[_S3 + "_regressor.bias"])
     l_rc = rpn_class_loss(score_map, minibatch)
@@ -291,9 +307,11 @@ def train_step(sd, image, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_objec
     total = l_rc + l_rr + l_dc + l_dr
     watched = {}
     if detail is not None:          # gradients of intermediates, for stage-by-stage parity reports
-        watched = dict(feature_map=fm, rpn_trunk=y, pooled=pooled, fc1=h1, fc2=h2, score_map=score_map, delta_map=delta_map,
+        watched = dict(feature_map=fm, rpn_trunk=y, pooled=pooled, fc2=h2, score_map=score_map, delta_map=delta_map,
                        classes=classes, deltas=deltas)
-        watched.update({name: detail[name] for name, _ in VGG_LAYERS[4:]})
+        if not resnet:
+            watched["fc1"] = h1
+            watched.update({name: detail[name] for name, _ in VGG_LAYERS[4:]})
         for v in watched.values():
             v.retain_grad()
     total.backward()
@@ -318,6 +336,6 @@ def train_step(sd, image, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_objec
         new_sd[k] = sd[k].add(g, alpha=-lr)
     if detail is not None:
         detail.update(feature_map=fm.detach(), rpn_trunk=y.detach(), score_map=score_map.detach(),
-                      delta_map=delta_map.detach(), pooled=pooled.detach(), fc1=h1.detach(), fc2=h2.detach(),
+                      delta_map=delta_map.detach(), pooled=pooled.detach(), fc1=None if h1 is None else h1.detach(), fc2=h2.detach(),
                       classes=classes.detach(), deltas=deltas.detach(), minibatch=minibatch)
     return losses, grads, new_sd, bufs

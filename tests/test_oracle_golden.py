@@ -197,14 +197,21 @@ def test_preprocess_restatement_matches_reference_sequence():
 
 
 # ---- training step: oracle/train_oracle.py vs the fixtures captured from the reference's train_step ----
-def test_train_oracle_reproduces_reference_step(golden_dir, sd_cpu):
+@pytest.mark.parametrize("backbone", ["vgg16", "resnet50"])
+def test_train_oracle_reproduces_reference_step(golden_dir, sd_cpu, backbone):
     import random
     from oracle import train_oracle as TO
-    g = np.load(os.path.join(golden_dir, "train_vgg16_352x480_s4.npz"))
+    g = np.load(os.path.join(golden_dir, "train_%s_352x480_s4.npz" % backbone))
     seed, h, w = int(g["seed"]), int(g["height"]), int(g["width"])
-    img = synthetic.image(seed, h, w).unsqueeze(0)
+    if backbone == "resnet50":
+        sd_cpu = synthetic.resnet_state_dict(1234, "ResNet50")
+        img = synthetic.image_rgb(seed, h, w).unsqueeze(0)
+        fshape = (1024, -(-h // 16), -(-w // 16))
+    else:
+        img = synthetic.image(seed, h, w).unsqueeze(0)
+        fshape = (512, h // 16, w // 16)
     gts = synthetic.ground_truth(seed, h, w)
-    am, vm = O.generate_anchor_maps((3, h, w), (512, h // 16, w // 16), 16)
+    am, vm = O.generate_anchor_maps((3, h, w), fshape, 16)
     gc = np.stack([k for _, k in gts])
     gcls = np.array([c for c, _ in gts])
     rmap, obj, bg = O.generate_rpn_map(am, vm, gc)

@@ -376,19 +376,50 @@ def canonical_grads(packed, ncls=21):
     return out
 
 
-@pytest.mark.parametrize("tag", ["352x480_s4", "416x544_s6"])
-def test_train_step_matches_reference_fixture(tag, golden_dir, sd_cpu):
+def canonical_grads_resnet(packed, ncls=21):
+    """packed-layout gradients of the ResNet train step -> the reference's parameter layouts / key names."""
+    out = {}
+    fe = "_stage1_feature_extractor._feature_extractor."
+    l4 = "_stage3_detector_network._pool_to_feature_vector._layer4."
+    for name, g in packed.items():
+        if not name.startswith("layer"):
+            continue
+        layer, blk, conv = name.split(".")
+        prefix = {"layer2": fe + "5.", "layer3": fe + "6.", "layer4": l4}[layer] + blk + "."
+        key = prefix + ("downsample.0.weight" if conv == "downsample" else conv + ".weight")
+        k = int(round(g.shape[0] ** 0.5))
+        out[key] = g.permute(1, 2, 0).reshape(g.shape[1], g.shape[2], k, k)
+    out["_stage2_region_proposal_network._rpn_conv1.weight"] = packed["rpn_conv"].permute(1, 2, 0).reshape(1024, 1024, 3, 3)
+    out["_stage2_region_proposal_network._rpn_class.weight"] = packed["rpn_head"][0:9].reshape(9, 1024, 1, 1)
+    out["_stage2_region_proposal_network._rpn_boxes.weight"] = packed["rpn_head"][9:45].reshape(36, 1024, 1, 1)
+    out["_stage3_detector_network._classifier.weight"] = packed["head"][0:ncls]
+    out["_stage3_detector_network._regressor.weight"] = packed["head"][ncls:ncls + 4 * (ncls - 1)]
+    return out
+
+
+@pytest.mark.parametrize("backbone,tag", [("vgg16", "352x480_s4"), ("vgg16", "416x544_s6"), ("resnet50", "352x480_s4")])
+def test_train_step_matches_reference_fixture(backbone, tag, golden_dir, sd_cpu):
     from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
     from fasterrcnn_amd.models.vgg16 import VGG16Backbone
-    gold = np.load(os.path.join(golden_dir, "train_vgg16_%s.npz" % tag))
+    from fasterrcnn_amd.models import resnet
+    gold = np.load(os.path.join(golden_dir, "train_%s_%s.npz" % (backbone, tag)))
     seed, h, w = int(gold["seed"]), int(gold["height"]), int(gold["width"])
-    model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
-    model.load_state_dict(sd_cpu, strict=True)
+    if backbone == "vgg16":
+        model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+        model.load_state_dict(sd_cpu, strict=True)
+        img = synthetic.image(seed, h, w).unsqueeze(0).cuda()
+        fshape = (512, h // 16, w // 16)
+        canon = canonical_grads
+    else:
+        model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet50))
+        model.load_state_dict(synthetic.resnet_state_dict(1234, "ResNet50"), strict=True)
+        img = synthetic.image_rgb(seed, h, w).unsqueeze(0).cuda()
+        fshape = (1024, -(-h // 16), -(-w // 16))
+        canon = canonical_grads_resnet
     model = model.cuda()
-    img = synthetic.image(seed, h, w).unsqueeze(0).cuda()
     gts = synthetic.ground_truth(seed, h, w)
     boxes = [Box(class_index=c, class_name="x", corners=k) for c, k in gts]
-    am, vm = O.generate_anchor_maps((3, h, w), (512, h // 16, w // 16), 16)
+    am, vm = O.generate_anchor_maps((3, h, w), fshape, 16)
     rmap, obj, bg = O.generate_rpn_map(am, vm, np.stack([k for _, k in gts]))
     opt = T.create_optimizer(model, learning_rate=float(gold["lr"]), momentum=float(gold["momentum"]),
                              weight_decay=float(gold["weight_decay"]))
@@ -448,7 +479,7 @@ def test_train_step_matches_reference_fixture(tag, golden_dir, sd_cpu):
         # by up to ~1e-3 of the tensor's largest entry while the bulk agrees to ~1e-6.  Hence: a tight bound on
         # the MEDIAN error, looser bounds on the L2 error and the norm.  The backward operators themselves are
         # held to float32 accuracy on identical inputs by the per-operator tests above.
-        grads = canonical_grads(detail["grads"])
+        grads = canon(detail["grads"])
         gscale = max(float(gold[pre + "gnorm/" + k]) for k in keys)
         for k in keys:
             gk = grads[k].reshape(-1)

@@ -30,18 +30,27 @@ def main():
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--lr", type=float, default=1e-6)
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic samples cycled through")
+    ap.add_argument("--backbone", type=str, default="vgg16", choices=["vgg16", "resnet50", "resnet101", "resnet152"])
     args = ap.parse_args()
     h, w = args.height, args.width
-    model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
-    model.load_state_dict(synthetic.vgg16_state_dict(1234), strict=True)
+    if args.backbone == "vgg16":
+        model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+        model.load_state_dict(synthetic.vgg16_state_dict(1234), strict=True)
+        make_image = synthetic.image
+    else:
+        from fasterrcnn_amd.models import resnet
+        arch = {"resnet50": "ResNet50", "resnet101": "ResNet101", "resnet152": "ResNet152"}[args.backbone]
+        model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(getattr(resnet.Architecture, arch)))
+        model.load_state_dict(synthetic.resnet_state_dict(1234, arch), strict=True)
+        make_image = synthetic.image_rgb
     model = model.cuda()
-    am, vm = anchors.generate_anchor_maps((3, h, w), (512, h // 16, w // 16), 16)
+    am, vm = anchors.generate_anchor_maps((3, h, w), model.backbone.compute_feature_map_shape((3, h, w)), 16)
     samples = []
     for seed in range(args.pool):
         gts = synthetic.ground_truth(seed, h, w)
         boxes = [Box(c, "x", k) for c, k in gts]
         rmap, obj, bg = anchors.generate_rpn_map(am, vm, boxes)
-        samples.append((synthetic.image(seed, h, w).unsqueeze(0).cuda(), torch.from_numpy(rmap).unsqueeze(0).cuda(), obj, bg, boxes))
+        samples.append((make_image(seed, h, w).unsqueeze(0).cuda(), torch.from_numpy(rmap).unsqueeze(0).cuda(), obj, bg, boxes))
     opt = training.create_optimizer(model, learning_rate=args.lr)
     random.seed(0); torch.manual_seed(0)
     losses = []
@@ -58,7 +67,7 @@ def main():
         losses.append(step(i).total)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"metric": "train_step (VGG-16 Faster R-CNN, %dx%d, batch 1)" % (h, w), "ms_per_step": 1e3 * dt / args.steps,
+    print(json.dumps({"metric": "train_step (%s Faster R-CNN, %dx%d, batch 1)" % (args.backbone, h, w), "ms_per_step": 1e3 * dt / args.steps,
                       "steps_per_sec": args.steps / dt, "steps": args.steps, "warmup": args.warmup, "dtype": "f32",
                       "first_total_loss": losses[0], "last_total_loss": losses[-1], "data": "synthetic"}))
 
