@@ -597,6 +597,13 @@ int frcnn_ctx_tensor(frcnn_ctx* c, int which, void** d_ptr, size_t* bytes)
     return FRCNN_OK;
 }
 
+namespace {
+struct BlocksTargetScope {
+    explicit BlocksTargetScope(int t) { conv3x3_set_blocks_target(t); }
+    ~BlocksTargetScope() { conv3x3_set_blocks_target(0); }
+};
+}  // namespace
+
 // ---- fused forward ---------------------------------------------------------------------------
 int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_forward_params* p,
                         const float* d_image, int H, int W, const float* d_anchor_map,
@@ -615,6 +622,8 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     const unsigned R = FRCNN_RELU, RP = FRCNN_RELU | FRCNN_POOL2;
     int rc;
     if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32X6) return FRCNN_EINVAL;
+    if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
+    BlocksTargetScope target_scope(p->conv_blocks_target);
     const bool x6 = p->math_mode == FRCNN_MATH_F32X6;
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
@@ -743,6 +752,8 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     }
     hipStream_t s = as_stream(stream);
     int rc;
+    if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
+    BlocksTargetScope target_scope(p->conv_blocks_target);
 #define STEP(cls, call) do { Scope _sc(c, cls, s); rc = (call); } while (0); if (rc) return rc
 
     // stage 1: conv1/bn1/relu/maxpool/layer1..3 (models/resnet.py:38-46)

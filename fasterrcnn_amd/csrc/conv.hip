@@ -446,16 +446,23 @@ static int launch_cfg(const float* x, const float* wp, const float* b, float* y,
 // onto a subset of CUs (measured: 1200 blocks on 768 slots run as two full rounds = 78 % MFMA
 // busy), so work units must be small against blocks/slots.  Power of two, at least two 16-channel
 // chunks per split; the target of ~5 blocks per CU was the measured optimum (profiles/r01).
-// FRCNN_CONV_BLOCKS_TARGET overrides it (tuning knob).
+// That optimum is for ONE image on the chip (latency).  With many images in flight on separate streams the
+// other images' kernels fill the tail, and fewer, longer work units win (measured, 24 in flight: target 320 ->
+// 293 img/s, 1280 -> 286, 2560 -> 281): frcnn_forward_params.conv_blocks_target lets the caller say which regime
+// it is in; 0 = this default.  FRCNN_CONV_BLOCKS_TARGET overrides both (tuning knob).
+static thread_local int g_blocks_target_override = 0;
+void conv3x3_set_blocks_target(int target) { g_blocks_target_override = target > 0 ? target : 0; }
+
 static int conv_blocks_target()
 {
-    static int target = -1;
-    if (target < 0) {
+    static int env_target = -1;
+    if (env_target < 0) {
         const char* e = getenv("FRCNN_CONV_BLOCKS_TARGET");
-        target = e ? atoi(e) : 1280;
-        if (target < 1) target = 1;
+        env_target = e ? atoi(e) : 0;
+        if (env_target < 0) env_target = 0;
     }
-    return target;
+    if (env_target > 0) return env_target;
+    return g_blocks_target_override > 0 ? g_blocks_target_override : 1280;
 }
 
 static int choose_ksplit(int H, int W, int cin, int cout)

@@ -98,6 +98,7 @@ class FasterRCNNModel(nn.Module):
         self.rpn_nms_threshold = 0.7
         self.rpn_min_side = 16.0
         self.detector_nms_threshold = 0.3
+        self.inflight_conv_blocks_target = 320      # frcnn_forward_params.conv_blocks_target used by predict_async slots
 
         # arithmetic of the 3x3 convolutions: "f32" = exact f32 MFMA, "f32x6" = exactly split bf16x3
         # operands, six bf16 MFMAs per product with f32 accumulation (same accuracy class)
@@ -210,7 +211,10 @@ class FasterRCNNModel(nn.Module):
         weights = self._weights()
         params = nv.ForwardParams(int(self.max_proposals_pre_nms), int(self.max_proposals_post_nms),
                                   float(self.rpn_nms_threshold), float(self.rpn_min_side),
-                                  1 if self._allow_edge_proposals else 0, nv.MATH_MODES[self._math_mode])
+                                  1 if self._allow_edge_proposals else 0, nv.MATH_MODES[self._math_mode],
+                                  # slot 0 = one image at a time (latency); slots > 0 = many images in flight on their own
+                                  # streams, where longer split-K work units give more throughput (csrc/conv.hip)
+                                  0 if slot_index == 0 else self.inflight_conv_blocks_target)
         lib = nv.lib()
         with t.cuda.device(device):
             stream = slot.use_stream()

@@ -277,6 +277,9 @@ typedef struct frcnn_forward_params {
     int32_t math_mode;          /* FRCNN_MATH_F32 (exact f32 MFMA) or FRCNN_MATH_F32X6; selects how the
                                    3x3 conv weight pointers of the weights struct are interpreted
                                    (frcnn_pack_conv3x3 vs frcnn_pack_conv3x3_x6) */
+    int32_t conv_blocks_target; /* split-K granularity of the 3x3 layers: blocks per launch to aim for.  0 = 1280 (best
+                                   latency for one image on the chip); ~320 when many images are in flight on separate
+                                   streams (other images' kernels fill the tail, longer work units win) */
 } frcnn_forward_params;
 #define FRCNN_MATH_F32   0
 #define FRCNN_MATH_F32X6 1
