@@ -481,6 +481,7 @@ static int choose_ksplit(int H, int W, int cin, int cout)
 }
 
 int conv3x3_choose_ksplit(int H, int W, int cin, int cout) { return choose_ksplit(H, W, cin, cout); }
+int conv3x3_blocks_target() { return conv_blocks_target(); }
 
 int launch_conv_splitk_finish(const float* ws, int ksplit, const float* b, float* y, int H, int W, int cout, int relu,
                               int pool, hipStream_t s)

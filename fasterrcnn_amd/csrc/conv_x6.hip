@@ -335,12 +335,14 @@ static int x6_ksplit(int H, int W, int cin, int cout)
     const int rows = narrow ? 8 : 4;
     const int blocks = cdiv(W, 32) * cdiv(H, rows) * (cout / bn);
     const int nchunks = cin / 16;
-    static int target = -1;
-    if (target < 0) {
+    static int env_target = -1;
+    if (env_target < 0) {
         const char* e = getenv("FRCNN_X6_BLOCKS_TARGET");       // tuning knob
-        target = e ? atoi(e) : 1280;
-        if (target < 1) target = 1;
+        env_target = e ? atoi(e) : 0;
+        if (env_target < 0) env_target = 0;
     }
+    // otherwise the regime-dependent target of conv.hip (frcnn_forward_params.conv_blocks_target; 1280 by default)
+    const int target = env_target > 0 ? env_target : conv3x3_blocks_target();
     if (blocks * 2 > target) return 1;
     if ((size_t)H * W * cout * sizeof(float) > ((size_t)40 << 20)) return 1;
     int k = 1;

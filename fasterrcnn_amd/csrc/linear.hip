@@ -14,6 +14,7 @@
 // once, and the grid is filled by deterministic split-K (partials to scratch, fixed-order
 // reduce fused with bias+ReLU) -- no atomics, results are run-to-run identical.
 #include "common.h"
+#include <cstdlib>
 
 namespace frcnn {
 
@@ -306,7 +307,9 @@ static LinearPlan plan_linear(int M, int N, int K)
     p.mblocks = cdiv(M, bm);
     p.nblocks = cdiv(N, 128);
     const int stages = K / 16;
-    int want = 256 / (p.mblocks * p.nblocks);       // fill 256 CUs
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("FRCNN_LINEAR_BLOCKS_TARGET"); target = e ? atoi(e) : 256; if (target < 1) target = 1; }
+    int want = target / (p.mblocks * p.nblocks);    // fill 256 CUs
     int cap = stages / 8;                           // >= 8 stages (128 k) per split
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
