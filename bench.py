@@ -165,7 +165,8 @@ def main():
         for i in range(n_steps):
             if len(pending) == nslots:
                 pending.pop(0).result()
-            pending.append(model.predict_async(pool[i % len(pool)], 0.05, slot=1 + (i % nslots)))
+            # one image at a time = slot 0 (the latency configuration of predict()); otherwise the in-flight slots 1..n
+            pending.append(model.predict_async(pool[i % len(pool)], 0.05, slot=0 if nslots == 1 else 1 + (i % nslots)))
         last = None
         while pending:
             last = pending.pop(0).result()
