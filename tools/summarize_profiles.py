@@ -133,6 +133,26 @@ def traffic(d):
     json.dump(rec, open(os.path.join(d, "traffic.json"), "w"), indent=1)
 
 
+def condense_pmc(d):
+    """Per-dispatch counter dumps -> <dir>/pmc_counters_by_kernel.csv (pass, kernel, counter, dispatches, sum): what gets committed."""
+    out = []
+    for tag in ("mfma", "fetch", "write", "lds"):
+        rows = load(os.path.join(d, "pmc_" + tag, "*counter_collection.csv"))
+        agg = collections.defaultdict(float)
+        cnt = collections.defaultdict(set)
+        for r in rows:
+            key = (tag, short(r["Kernel_Name"]), r["Counter_Name"])
+            agg[key] += float(r["Counter_Value"])
+            cnt[key].add(r["Dispatch_Id"])
+        out += [(k[0], k[1], k[2], len(cnt[k]), v) for k, v in sorted(agg.items())]
+    if out:
+        with open(os.path.join(d, "pmc_counters_by_kernel.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["pass", "kernel", "counter", "dispatches", "sum_over_dispatches"])
+            w.writerows(out)
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
     traffic(sys.argv[1])
+    condense_pmc(sys.argv[1])
