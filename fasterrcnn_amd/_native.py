@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
+ABI_VERSION = 2     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
@@ -186,7 +187,7 @@ def lib():
         restype, argtypes = _SIGNATURES[name]
         fn.restype = restype
         fn.argtypes = argtypes
-    if handle.frcnn_abi_version() != 1:
+    if handle.frcnn_abi_version() != ABI_VERSION:
         raise RuntimeError("fasterrcnn_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = handle
     return _lib

@@ -1,5 +1,6 @@
 /*
- * frcnn_hip.h -- C ABI of libfrcnn_hip.so, the MI355X (gfx950) Faster R-CNN inference hot path.
+ * frcnn_hip.h -- C ABI of libfrcnn_hip.so, the MI355X (gfx950) Faster R-CNN hot path: inference (forward / predict),
+ * and the operators of the train step (section "Training path" below).
  *
  * The reference (trzy/FasterRCNN, pytorch tree) has no FFI: its hot path is Python calling
  * torch / torchvision native kernels.  Each entry point below replaces one of those call sites;
@@ -36,7 +37,7 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 1
+#define FRCNN_ABI_VERSION 2   /* 2: training entry points, frcnn_forward_params.conv_blocks_target */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u

@@ -26,7 +26,7 @@ def test_library_exports_every_header_symbol():
     raw = C.CDLL(nv.LIB_PATH)
     for name in header_symbols():
         assert hasattr(raw, name), name
-    assert lib.frcnn_abi_version() == 1
+    assert lib.frcnn_abi_version() == nv.ABI_VERSION
     assert lib.frcnn_error_string(0) == b"ok"
     assert lib.frcnn_error_string(-1) == b"invalid argument"
 
