@@ -105,6 +105,7 @@ class FasterRCNNModel(nn.Module):
         self._math_mode = "f32"
 
         self._train_state = None
+        self._gradient_sync = None          # training.enable_data_parallel
         self._slots = {}
         self._wstruct = None
         self._wstruct_key = None

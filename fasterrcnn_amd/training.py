@@ -498,6 +498,53 @@ class ResNetTrainState(TrainState):
                 grads[blk.name + "." + cname] = t.zeros_like(c.raw)
 
 
+class GradientAverager:
+    """
+    Data-parallel training (beyond the reference, which trains on one GPU): every rank runs `train_step` on its own sample
+    and the weight gradients are averaged over the ranks before the SGD update -- ONE exchange step per training step,
+    `torch.distributed.all_reduce` over RCCL/xGMI (backend "nccl") or gloo.  The gradients of a step are packed into a few
+    large flat buckets (`bucket_bytes`, default 256 MB: xGMI rings are per-link bound, so few large messages) in a fixed
+    name order, reduced, divided by the world size and scattered back in place.  Attach with `enable_data_parallel(model)`.
+    """
+    def __init__(self, group=None, bucket_bytes=256 << 20):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("GradientAverager needs an initialised torch.distributed process group")
+        self.dist, self.group, self.bucket_bytes = dist, group, int(bucket_bytes)
+        self.world = dist.get_world_size(group)
+
+    def buckets(self, grads):
+        """[[name, ...], ...]: names in sorted order, greedily packed up to bucket_bytes (identical on every rank)."""
+        out, cur, size = [], [], 0
+        for name in sorted(grads):
+            nbytes = grads[name].numel() * grads[name].element_size()
+            if cur and size + nbytes > self.bucket_bytes:
+                out.append(cur)
+                cur, size = [], 0
+            cur.append(name)
+            size += nbytes
+        if cur:
+            out.append(cur)
+        return out
+
+    def __call__(self, grads):
+        for names in self.buckets(grads):
+            flat = t.cat([grads[n].reshape(-1) for n in names])
+            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+            flat /= float(self.world)
+            off = 0
+            for n in names:
+                k = grads[n].numel()
+                grads[n].copy_(flat[off:off + k].view_as(grads[n]))
+                off += k
+
+
+def enable_data_parallel(model, group=None, bucket_bytes=256 << 20):
+    """Average the weight gradients of every `train_step` over the ranks of `group` (see GradientAverager)."""
+    model._gradient_sync = GradientAverager(group, bucket_bytes)
+    return model
+
+
 def make_train_state(model):
     return ResNetTrainState(model) if model._is_resnet else VGG16TrainState(model)
 
@@ -646,6 +693,9 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
         # ---- stage 1 backward ---------------------------------------------------------------------------
         st.features_backward(g, fsaved, grads)
         # ---- SGD (torch.optim.SGD.step, __main__.py:98-105) --------------------------------------------
+        sync = getattr(model, "_gradient_sync", None)
+        if sync is not None:
+            sync(grads)                                               # data parallel: average over the ranks
         if detail is not None:
             detail["grads"] = {k: v.clone() for k, v in grads.items()}
         st.apply_sgd(grads, lr, momentum, weight_decay)

@@ -68,3 +68,44 @@ def test_sharded_map_equals_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results == {0: expected, 1: expected}
+
+
+# ---- data-parallel training: the gradient exchange of fasterrcnn_amd/training.py ---------------------------------
+def _grad_worker(rank, world, port, result_queue):
+    import torch
+    from fasterrcnn_amd import training
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = {"conv4": torch.randn((9, 8, 4), generator=g), "head": torch.randn((16, 32), generator=g),
+             "fc1": torch.randn((64, 100), generator=g), "rpn_conv": torch.randn((9, 4, 4), generator=g)}
+    mine = {k: v.clone() for k, v in grads.items()}
+    avg = training.GradientAverager(bucket_bytes=8 * 1024)          # small buckets: several messages
+    nb = len(avg.buckets(grads))
+    avg(grads)
+    result_queue.put((rank, nb, {k: v.numpy() for k, v in mine.items()}, {k: v.numpy() for k, v in grads.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_averager_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, nb, mine, out = q.get(timeout=120)
+        res[rank] = (nb, mine, out)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] and res[0][0] >= 2                 # same bucketing on both ranks, more than one bucket
+    for k in res[0][1]:
+        want = (res[0][1][k] + res[1][1][k]) / 2.0
+        assert np.array_equal(res[0][2][k], res[1][2][k])            # every rank ends with the same gradients
+        assert np.allclose(res[0][2][k], want, rtol=1e-6, atol=1e-7)

@@ -624,3 +624,43 @@ def test_scale_rows_bn_affine_and_mean_backward():
     dx = torch.empty((6, 4, 4, 32), device=DEV)
     nv.check(lib.frcnn_spatial_mean_backward(nv.ptr(d_dy), nv.ptr(dx), 6, 4, 4, 32, S()), "spatial_mean_backward")
     assert torch.equal(dx.permute(0, 3, 1, 2).cpu(), x.grad)
+
+
+def test_data_parallel_gradient_exchange_single_rank(sd_cpu):
+    """The RCCL exchange of training.GradientAverager on a one-rank group must leave the step bit-identical
+    (average of one); the world-2 arithmetic is covered on CPU by tests/test_distributed_gloo.py."""
+    import socket
+    import torch.distributed as dist
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    from fasterrcnn_amd.models.vgg16 import VGG16Backbone
+    h, w, seed = 352, 480, 4
+    img = synthetic.image(seed, h, w).unsqueeze(0).cuda()
+    gts = synthetic.ground_truth(seed, h, w)
+    boxes = [Box(class_index=c, class_name="x", corners=k) for c, k in gts]
+    am, vm = O.generate_anchor_maps((3, h, w), (512, h // 16, w // 16), 16)
+    rmap, obj, bg = O.generate_rpn_map(am, vm, np.stack([k for _, k in gts]))
+    rmap_t = torch.from_numpy(rmap).unsqueeze(0)
+
+    def run(parallel):
+        model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+        model.load_state_dict(sd_cpu, strict=True)
+        model = model.cuda()
+        if parallel:
+            T.enable_data_parallel(model, bucket_bytes=64 << 20)
+        opt = T.create_optimizer(model, learning_rate=1e-6)
+        random.seed(9); torch.manual_seed(9)
+        loss = model.train_step(opt, img, am, vm, rmap_t, [obj], [bg], [boxes])
+        return loss, {k: v.clone() for k, v in model.state_dict().items()}
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    l0, s0 = run(False)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        l1, s1 = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert l0 == l1
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
