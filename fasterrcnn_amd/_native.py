@@ -171,6 +171,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64: load it FIRST so that libfrcnn_hip.so binds to the same runtime copy.  Loaded the
+    # other way round the process holds two HIP runtimes and the second one to initialise sees no device.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "fasterrcnn_amd: %s is missing. Build it with `python -m fasterrcnn_amd.build` "

@@ -54,3 +54,13 @@ def test_linear_workspace_plan_is_deterministic():
     # conv: the 37x62 block-5 / RPN-trunk layers split 8-way, the 600x1000 layer does not
     assert lib.frcnn_conv3x3_workspace_bytes(37, 62, 512, 512) == 8 * 37 * 62 * 512 * 4
     assert lib.frcnn_conv3x3_workspace_bytes(600, 1000, 64, 64) == 0
+
+
+def test_library_load_puts_torchs_hip_runtime_first():
+    """libfrcnn_hip.so must bind to the HIP runtime torch bundles (one runtime per process): loading it imports torch first."""
+    import subprocess
+    import sys
+    code = ("import sys; from fasterrcnn_amd import _native as nv; assert 'torch' not in sys.modules; nv.lib(); "
+            "assert 'torch' in sys.modules; print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
