@@ -238,6 +238,8 @@ def main():
         achieved = flops_per_launch / avg_launch_s / 1e12 if conv_launches else 0.0
         roofline = {
             "kernel": "conv3x3_mfma_kernel (12 backbone layers + RPN trunk)",
+            "regime": "HIP events around every launch, one image at a time on one stream (after the timed region: with 24 images "
+                      "in flight concurrent kernels share the CUs and a launch's wall duration is not its own)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(),
             "flops_per_launch": flops_per_launch, "avg_launch_us": round(avg_launch_s * 1e6, 2),
