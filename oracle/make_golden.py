@@ -281,7 +281,7 @@ def sample_positions(n, count=2048):
     return np.unique(np.linspace(0, n - 1, min(count, n)).astype(np.int64))
 
 
-def golden_train(ref, tag, seed, height, width, steps=2, lr=1e-6, momentum=0.9, weight_decay=5e-4, arch=None):
+def golden_train(ref, tag, seed, height, width, steps=2, lr=1e-6, momentum=0.9, weight_decay=5e-4, arch=None, sample_count=2048):
     """
     Runs the REFERENCE's train_step (faster_rcnn.py:228-362) with torch.optim.SGD built as __main__.py:98-105 does,
     asserts oracle/train_oracle.py reproduces losses / gradients / updated weights bit for bit under the same RNG
@@ -317,7 +317,7 @@ def golden_train(ref, tag, seed, height, width, steps=2, lr=1e-6, momentum=0.9, 
 
     out = {"seed": np.int64(seed), "height": np.int64(height), "width": np.int64(width), "weights_seed": np.int64(1234),
            "steps": np.int64(steps), "lr": np.float64(lr), "momentum": np.float64(momentum),
-           "weight_decay": np.float64(weight_decay), "rng_seed": np.int64(100 + seed)}
+           "weight_decay": np.float64(weight_decay), "rng_seed": np.int64(100 + seed), "sample_count": np.int64(sample_count)}
     sd = {k: v.clone() for k, v in sd0.items()}
     bufs = None
     keys = TO.trainable_weight_keys(sd0)
@@ -372,7 +372,7 @@ def golden_train(ref, tag, seed, height, width, steps=2, lr=1e-6, momentum=0.9, 
         out[pre + "sampled_class_idx"] = detail["sampled"][1].numpy().argmax(axis=1).astype(np.int32)
         for k in keys:
             g = grads[k].numpy().reshape(-1).astype(np.float64)
-            pos = sample_positions(g.shape[0])
+            pos = sample_positions(g.shape[0], sample_count)
             out[pre + "gnorm/" + k] = np.float64(np.sqrt((g * g).sum()))
             out[pre + "gsample/" + k] = g[pos].astype(np.float32)
             dw = (new_sd[k].numpy().reshape(-1).astype(np.float64) - sd[k].numpy().reshape(-1).astype(np.float64))
@@ -391,6 +391,7 @@ def main():
     ap.add_argument("--calibrate-resnet", action="store_true")
     ap.add_argument("--only-resnet", action="store_true")
     ap.add_argument("--train", action="store_true", help="only the train-step fixtures (tests/golden/train_*.npz)")
+    ap.add_argument("--only-resnet101", action="store_true", help="with --train: only the ResNet-101 fixture")
     args = ap.parse_args()
     t.manual_seed(0)
     ref = reference_shims.install(O)
@@ -401,11 +402,15 @@ def main():
         calibrate_resnet(ref)
         return
     os.makedirs(GOLDEN, exist_ok=True)
+    if args.train and args.only_resnet101:
+        golden_train(ref, "320x416_s6", 6, 320, 416, arch="ResNet101", sample_count=512)
+        return
     if args.train:
         if not args.only_resnet:
             golden_train(ref, "352x480_s4", 4, 352, 480)
             golden_train(ref, "416x544_s6", 6, 416, 544)
         golden_train(ref, "352x480_s4", 4, 352, 480, arch="ResNet50")
+        golden_train(ref, "320x416_s6", 6, 320, 416, arch="ResNet101", sample_count=512)
         return
     if not args.only_resnet:
         golden_small_ops(ref)
