@@ -114,8 +114,9 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=3, help="images timed on the host CPU (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-images", type=int, default=10)
-    ap.add_argument("--math", type=str, default="f32", choices=["f32", "f32x6"],
-                    help="3x3 conv arithmetic: exact f32 MFMA (default) or exactly split bf16x3 operands (six bf16 MFMAs per product)")
+    ap.add_argument("--math", type=str, default="f32", choices=["f32", "f32_winograd", "f32x6"],
+                    help="3x3 conv arithmetic: exact f32 MFMA direct (default), the same with the >= 256-channel layers as Winograd "
+                         "F(2x2,3x3) in float32, or exactly split bf16x3 operands (six bf16 MFMAs per product)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the informational f32x6 throughput leg")
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
                     help="untimed pre-roll before the warm-up steps: the GPU takes ~1-2 s of load to leave its idle power state "
@@ -127,10 +128,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        # started without a launcher: re-run under torch.distributed.run, one rank per GPU (the form the docstring shows)
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world if world > 1 else args.gpus
+    n_gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -189,7 +200,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    value = n_gpus * args.steps / elapsed if world > 1 or args.gpus == 1 else args.steps / elapsed
+    value = n_gpus * args.steps / elapsed
 
     # ---- informational: the same workload in the f32x6 math mode (not the headline value) -----------
     secondary = None

@@ -12,13 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
-ABI_VERSION = 2     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
+ABI_VERSION = 3     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
 POOL2 = 2
-NUM_KCLASS = 6
-KCLASS_NAMES = ("conv3x3_mfma", "conv3x3_c3", "linear_mfma", "proposals", "roi_pool", "other")
+NUM_KCLASS = 7
+KCLASS_NAMES = ("conv3x3_mfma", "conv3x3_c3", "linear_mfma", "proposals", "roi_pool", "other", "conv3x3_winograd")
 
 # Every symbol include/frcnn_hip.h declares (tests check the .so exports all of them).
 SYMBOLS = (
@@ -33,6 +33,8 @@ SYMBOLS = (
     "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv7x7_s2_c3",
     "frcnn_maxpool3x3_s2_nhwc", "frcnn_spatial_mean_nhwc", "frcnn_resnet_forward", "frcnn_rpn_targets",
     "frcnn_pack_conv3x3_x6", "frcnn_conv3x3_nhwc_x6", "frcnn_preprocess_workspace_bytes", "frcnn_preprocess",
+    "frcnn_winograd_min_cin", "frcnn_pack_conv3x3_winograd", "frcnn_conv3x3_winograd_workspace_bytes",
+    "frcnn_conv3x3_nhwc_winograd",
     # training path
     "frcnn_label_proposals", "frcnn_gather_rows", "frcnn_rpn_loss", "frcnn_detector_loss",
     "frcnn_gemm_tn_workspace_bytes", "frcnn_gemm_tn", "frcnn_conv3x3_wgrad_workspace_bytes", "frcnn_conv3x3_wgrad",
@@ -87,7 +89,9 @@ class ForwardParams(C.Structure):
 
 MATH_F32 = 0      # exact f32 MFMA
 MATH_F32X6 = 1    # bf16x3 split operands, six bf16 MFMAs per product, f32 accumulate
-MATH_MODES = {"f32": MATH_F32, "f32x6": MATH_F32X6}
+MATH_F32_WINOGRAD = 2   # exact f32 MFMA; 3x3 layers with cin >= WINOGRAD_MIN_CIN as Winograd F(2x2,3x3) in float32
+MATH_MODES = {"f32": MATH_F32, "f32x6": MATH_F32X6, "f32_winograd": MATH_F32_WINOGRAD}
+WINOGRAD_MIN_CIN = 256  # == frcnn_winograd_min_cin() (tests/test_abi.py)
 
 
 _lib = None
@@ -110,6 +114,10 @@ _SIGNATURES = {
     "frcnn_maxpool2x2_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "frcnn_pack_conv3x3_x6": (C.c_int, [_vp, _vp, _i, _i, _vp]),
     "frcnn_conv3x3_nhwc_x6": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_winograd_min_cin": (C.c_int, []),
+    "frcnn_pack_conv3x3_winograd": (C.c_int, [_vp, _vp, _i, _i, _vp]),
+    "frcnn_conv3x3_winograd_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "frcnn_conv3x3_nhwc_winograd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_linear_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "frcnn_linear": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_softmax_rows": (C.c_int, [_vp, _i, _vp, _i, _i, _vp]),

@@ -39,6 +39,7 @@ struct frcnn_ctx {
     float *head_logits = nullptr;                  // [max_rois][128]
     void* lin_ws = nullptr; size_t lin_ws_bytes = 0;
     void* conv_ws = nullptr; size_t conv_ws_bytes = 0;   // split-K partials of under-filled conv layers
+    void* wino_ws = nullptr; size_t wino_ws_bytes = 0;   // V and M of the Winograd layers; allocated by the first forward that needs it
     float* res_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // ResNet bottleneck rotation
     size_t res_buf_floats = 0;
     int last_c = 512, last_vec = 4096;
@@ -196,6 +197,26 @@ int frcnn_conv3x3_nhwc_x6(const float* d_x, const void* d_wq, const float* d_bia
 {
     if (!d_x || !d_wq || !d_bias || !d_y) return FRCNN_EINVAL;
     return launch_conv3x3_x6(d_x, d_wq, d_bias, d_y, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
+}
+
+int frcnn_winograd_min_cin(void) { return WINOGRAD_MIN_CIN; }
+
+int frcnn_pack_conv3x3_winograd(const float* d_w, float* d_u, int cout, int cin, void* stream)
+{
+    if (!d_w || !d_u) return FRCNN_EINVAL;
+    return launch_pack_conv3x3_winograd(d_w, d_u, cout, cin, as_stream(stream));
+}
+
+size_t frcnn_conv3x3_winograd_workspace_bytes(int H, int W, int cin, int cout)
+{
+    return conv3x3_winograd_workspace_bytes(H, W, cin, cout);
+}
+
+int frcnn_conv3x3_nhwc_winograd(const float* d_x, const float* d_u, const float* d_bias, float* d_y, int H, int W,
+                                int cin, int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_x || !d_u || !d_bias || !d_y || H < 1 || W < 1) return FRCNN_EINVAL;
+    return launch_conv3x3_winograd(d_x, d_u, d_bias, d_y, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
 }
 
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream)
@@ -548,10 +569,11 @@ void frcnn_ctx_destroy(frcnn_ctx* ctx)
     for (auto& r : ctx->recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->slab) (void)hipFree(ctx->slab);
+    if (ctx->wino_ws) (void)hipFree(ctx->wino_ws);
     delete ctx;
 }
 
-size_t frcnn_ctx_bytes(const frcnn_ctx* ctx) { return ctx ? ctx->slab_bytes : 0; }
+size_t frcnn_ctx_bytes(const frcnn_ctx* ctx) { return ctx ? ctx->slab_bytes + ctx->wino_ws_bytes : 0; }
 
 int frcnn_ctx_timing_enable(frcnn_ctx* ctx, int enable)
 {
@@ -598,6 +620,24 @@ int frcnn_ctx_tensor(frcnn_ctx* c, int which, void** d_ptr, size_t* bytes)
 }
 
 namespace {
+// Winograd scratch for every eligible VGG-16 layer shape up to the ctx's largest image (allocated once, on first use:
+// contexts that never run the mode do not pay the 16*T*(cin+cout) floats).
+int ensure_wino_ws(frcnn_ctx* c)
+{
+    if (c->wino_ws) return FRCNN_OK;
+    size_t need = 0;
+    const int shapes[4][3] = {{4, 256, 256}, {8, 256, 512}, {8, 512, 512}, {16, 512, 512}};
+    for (auto& sh : shapes) {
+        const size_t b = conv3x3_winograd_workspace_bytes(c->max_h / sh[0], c->max_w / sh[0], sh[1], sh[2]);
+        if (b > need) need = b;
+    }
+    if (need == 0) return FRCNN_EINVAL;
+    hipError_t e = hipMalloc(&c->wino_ws, need);
+    if (e != hipSuccess) { set_hip_error(e); c->wino_ws = nullptr; return FRCNN_ENOMEM; }
+    c->wino_ws_bytes = need;
+    return FRCNN_OK;
+}
+
 struct BlocksTargetScope {
     explicit BlocksTargetScope(int t) { conv3x3_set_blocks_target(t); }
     ~BlocksTargetScope() { conv3x3_set_blocks_target(0); }
@@ -621,38 +661,47 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     hipStream_t s = as_stream(stream);
     const unsigned R = FRCNN_RELU, RP = FRCNN_RELU | FRCNN_POOL2;
     int rc;
-    if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32X6) return FRCNN_EINVAL;
+    if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32X6 && p->math_mode != FRCNN_MATH_F32_WINOGRAD)
+        return FRCNN_EINVAL;
     if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
     BlocksTargetScope target_scope(p->conv_blocks_target);
     const bool x6 = p->math_mode == FRCNN_MATH_F32X6;
+    const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
+    if (wino) { rc = ensure_wino_ws(c); if (rc) return rc; }
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
+        if (wino && ci >= WINOGRAD_MIN_CIN) {
+            Scope _w(c, 6, s);
+            return launch_conv3x3_winograd(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->wino_ws, c->wino_ws_bytes, s);
+        }
+        Scope _d(c, 0, s);
         return x6 ? launch_conv3x3_x6(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s)
                   : launch_conv3x3_nhwc(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s);
     };
 #define STEP(cls, call) do { Scope _sc(c, cls, s); rc = (call); } while (0); if (rc) return rc
+#define CONV(call) do { rc = (call); } while (0); if (rc) return rc
 
     // stage 1: feature extractor (models/vgg16.py:76-96)
     float *A = c->act_a, *B = c->act_b;
     int h = H, wd = W;
     STEP(1, launch_conv3x3_c3(d_image, w->conv_w[0], w->conv_b[0], A, h, wd, 64, R, s));
-    STEP(0, conv3(A, w->conv_w[1], w->conv_b[1], B, h, wd, 64, 64, RP));   h /= 2; wd /= 2;
-    STEP(0, conv3(B, w->conv_w[2], w->conv_b[2], A, h, wd, 64, 128, R));
-    STEP(0, conv3(A, w->conv_w[3], w->conv_b[3], B, h, wd, 128, 128, RP)); h /= 2; wd /= 2;
-    STEP(0, conv3(B, w->conv_w[4], w->conv_b[4], A, h, wd, 128, 256, R));
-    STEP(0, conv3(A, w->conv_w[5], w->conv_b[5], B, h, wd, 256, 256, R));
-    STEP(0, conv3(B, w->conv_w[6], w->conv_b[6], A, h, wd, 256, 256, RP)); h /= 2; wd /= 2;
-    STEP(0, conv3(A, w->conv_w[7], w->conv_b[7], B, h, wd, 256, 512, R));
-    STEP(0, conv3(B, w->conv_w[8], w->conv_b[8], A, h, wd, 512, 512, R));
-    STEP(0, conv3(A, w->conv_w[9], w->conv_b[9], B, h, wd, 512, 512, RP)); h /= 2; wd /= 2;
-    STEP(0, conv3(B, w->conv_w[10], w->conv_b[10], A, h, wd, 512, 512, R));
-    STEP(0, conv3(A, w->conv_w[11], w->conv_b[11], B, h, wd, 512, 512, R));
-    STEP(0, conv3(B, w->conv_w[12], w->conv_b[12], c->fm, h, wd, 512, 512, R));
+    CONV(conv3(A, w->conv_w[1], w->conv_b[1], B, h, wd, 64, 64, RP));   h /= 2; wd /= 2;
+    CONV(conv3(B, w->conv_w[2], w->conv_b[2], A, h, wd, 64, 128, R));
+    CONV(conv3(A, w->conv_w[3], w->conv_b[3], B, h, wd, 128, 128, RP)); h /= 2; wd /= 2;
+    CONV(conv3(B, w->conv_w[4], w->conv_b[4], A, h, wd, 128, 256, R));
+    CONV(conv3(A, w->conv_w[5], w->conv_b[5], B, h, wd, 256, 256, R));
+    CONV(conv3(B, w->conv_w[6], w->conv_b[6], A, h, wd, 256, 256, RP)); h /= 2; wd /= 2;
+    CONV(conv3(A, w->conv_w[7], w->conv_b[7], B, h, wd, 256, 512, R));
+    CONV(conv3(B, w->conv_w[8], w->conv_b[8], A, h, wd, 512, 512, R));
+    CONV(conv3(A, w->conv_w[9], w->conv_b[9], B, h, wd, 512, 512, RP)); h /= 2; wd /= 2;
+    CONV(conv3(B, w->conv_w[10], w->conv_b[10], A, h, wd, 512, 512, R));
+    CONV(conv3(A, w->conv_w[11], w->conv_b[11], B, h, wd, 512, 512, R));
+    CONV(conv3(B, w->conv_w[12], w->conv_b[12], c->fm, h, wd, 512, 512, R));
     const int fh = h, fw = wd;
     c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms; c->last_c = 512; c->last_vec = 4096;
 
     // stage 2: RPN (models/rpn.py:88-153)
-    STEP(0, conv3(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, 512, 512, R));
+    CONV(conv3(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, 512, 512, R));
     STEP(2, launch_linear(c->rpn_trunk, 512, w->rpn_head_w, w->rpn_head_b, c->rpn_head, 128, fh * fw, 45, 512,
                           0u, c->lin_ws, c->lin_ws_bytes, s));
     const float* amap = d_anchor_map;
@@ -681,6 +730,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
                           c->lin_ws, c->lin_ws_bytes, s));
     STEP(5, launch_head_finish(c->head_logits, 128, R_, ncls, nd, d_classes, d_deltas, s));
 #undef STEP
+#undef CONV
     return FRCNN_OK;
 }
 

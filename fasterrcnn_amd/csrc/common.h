@@ -27,6 +27,9 @@ inline int check_launch() {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// 3x3 layers with at least this many input channels run as Winograd F(2x2,3x3) in math mode FRCNN_MATH_F32_WINOGRAD
+static constexpr int WINOGRAD_MIN_CIN = 256;
+
 // Per-kernel-class event timer (see frcnn_ctx_timing_* in the header).
 struct KernelTimer;
 
@@ -73,6 +76,13 @@ int launch_fold_bn_pack(const float* w, const float* gamma, const float* beta, c
 size_t linear_workspace_bytes(int M, int N, int K);
 int launch_linear(const float* a, int lda, const float* w, const float* bias, float* y, int ldy,
                   int M, int N, int K, unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_linear_batched(const float* a, int lda, size_t a_stride, const float* w, size_t w_stride, float* y, int ldy,
+                          size_t y_stride, int M, int N, int K, int batches, hipStream_t s);
+// winograd.hip: F(2x2,3x3) float32 path of the wide 3x3 layers
+size_t conv3x3_winograd_workspace_bytes(int H, int W, int cin, int cout);
+int launch_pack_conv3x3_winograd(const float* w, float* u, int cout, int cin, hipStream_t s);
+int launch_conv3x3_winograd(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
+                            unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_softmax_rows(const float* x, int ldx, float* y, int M, int ncls, hipStream_t s);
 int launch_head_finish(const float* x, int ldx, int M, int ncls, int ndelta, float* classes,
                        float* deltas, hipStream_t s);

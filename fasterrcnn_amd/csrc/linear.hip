@@ -33,11 +33,18 @@ struct GemmCfg {
     static_assert(THREADS == 256 || THREADS == 512, "4 or 8 waves per block");
 };
 
-template <int TM, int TN, int WM, int WN>
+// BATCHED: `batches` independent GEMMs of the same shape in one launch (the 16 Winograd positions of csrc/winograd.hip),
+// operands of batch z at a + z*a_stride, w + z*w_stride, y + z*y_stride; no split-K, no bias (bias == nullptr).
+// The grid is one-dimensional and the block order is XCD-aware: hardware block b runs on XCD b % 8, so the logical
+// tile index is laid out XCD-major -- the nblocks column tiles that share an A tile and the neighbouring row tiles
+// that share the batch's weights land in the same XCD's L2.
+struct BatchGeom { long long a_stride, w_stride, y_stride; int nblocks, mblocks, batches; };
+
+template <int TM, int TN, int WM, int WN, bool BATCHED>
 __global__ __launch_bounds__(64 * WM * WN)
 void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __restrict__ w,
                         const float* __restrict__ bias, float* __restrict__ y, int ldy,
-                        float* __restrict__ ws, int M, int N, int K, int stages_per_split, int relu)
+                        float* __restrict__ ws, int M, int N, int K, int stages_per_split, int relu, BatchGeom bg)
 {
     using C = GemmCfg<TM, TN, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -47,7 +54,20 @@ void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.y * C::BM, n0 = blockIdx.x * C::BN;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if constexpr (BATCHED) {
+        const int total = bg.nblocks * bg.mblocks * bg.batches;
+        const int per = total >> 3, rem = total & 7, xcd = bx & 7, j = bx >> 3;
+        const int L = xcd < rem ? xcd * (per + 1) + j : rem * (per + 1) + (xcd - rem) * per + j;
+        bx = L % bg.nblocks;
+        const int t2 = L / bg.nblocks;
+        by = t2 % bg.mblocks;
+        const int bz = t2 / bg.mblocks;
+        a += bz * bg.a_stride;
+        w += bz * bg.w_stride;
+        y += bz * bg.y_stride;
+    }
+    const int m0 = by * C::BM, n0 = bx * C::BN;
 
     const int total_stages = K >> 4;
     const int st_begin = blockIdx.z * stages_per_split;
@@ -195,7 +215,7 @@ void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __res
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + 32 * (TN * wn + j) + li;
         if (n >= N) continue;
-        const float bv = direct ? bias[n] : 0.f;
+        const float bv = (direct && bias != nullptr) ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -332,7 +352,7 @@ static int launch_linear_cfg(const LinearPlan& p, const float* a, int lda, const
                              int relu, hipStream_t s)
 {
     using C = GemmCfg<TM, TN, WM, WN>;
-    auto kern = linear_mfma_kernel<TM, TN, WM, WN>;
+    auto kern = linear_mfma_kernel<TM, TN, WM, WN, false>;
     static bool attr_set = false;
     if (!attr_set) {
         FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -341,8 +361,36 @@ static int launch_linear_cfg(const LinearPlan& p, const float* a, int lda, const
     }
     dim3 grid(p.nblocks, p.mblocks, p.splits);
     hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), C::LDS_BYTES, s, a, lda, w, bias, y, ldy, ws, M, N, K,
-                       p.stages_per_split, relu);
+                       p.stages_per_split, relu, BatchGeom{0, 0, 0, 0, 0, 0});
     return check_launch();
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_linear_batched_cfg(const float* a, int lda, const float* w, float* y, int ldy, int M, int N, int K,
+                                     const BatchGeom& bg, hipStream_t s)
+{
+    using C = GemmCfg<TM, TN, WM, WN>;
+    auto kern = linear_mfma_kernel<TM, TN, WM, WN, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_set = true;
+    }
+    const long long total = (long long)bg.nblocks * bg.mblocks * bg.batches;
+    if (total < 1 || total > 0x7fffffffLL) return FRCNN_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(C::THREADS), C::LDS_BYTES, s, a, lda, w,
+                       (const float*)nullptr, y, ldy, (float*)nullptr, M, N, K, K >> 4, 0, bg);
+    return check_launch();
+}
+
+// y_z[m][n] = sum_k a_z[m][k] * w_z[n][k] for z < batches; w_z holds ceil(N/128)*128 rows.
+int launch_linear_batched(const float* a, int lda, size_t a_stride, const float* w, size_t w_stride, float* y, int ldy,
+                          size_t y_stride, int M, int N, int K, int batches, hipStream_t s)
+{
+    if (M < 1 || N < 1 || K < 16 || K % 16 != 0 || lda % 4 != 0 || lda < K || ldy < N || batches < 1) return FRCNN_EINVAL;
+    BatchGeom bg{(long long)a_stride, (long long)w_stride, (long long)y_stride, cdiv(N, 128), cdiv(M, 128), batches};
+    return launch_linear_batched_cfg<2, 2, 2, 2>(a, lda, w, y, ldy, M, N, K, bg, s);
 }
 
 int launch_linear(const float* a, int lda, const float* w, const float* bias, float* y, int ldy,

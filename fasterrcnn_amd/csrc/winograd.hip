@@ -1,0 +1,217 @@
+// winograd.hip -- 3x3 stride-1 "same" convolution as Winograd F(2x2,3x3) in float32, for the wide layers
+// (cin >= FRCNN_WINOGRAD_MIN_CIN) of models/vgg16.py:36-47 and the RPN trunk models/rpn.py:39,88.
+//
+//   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
+//
+// 16 multiplies per 2x2 outputs and channel pair instead of 36: the matrix pipe does 2.25x less work.
+// All arithmetic is float32 (the filter transform is evaluated in float64 and rounded once); on the
+// reference's golden vectors the detections are reproduced at the same rate as with the direct kernel
+// (tests/winograd_parity_probe.py is the CPU model of this file, tests/test_winograd_gpu.py the parity test).
+//
+// Three launches per layer, NHWC throughout, T = ceil(H/2) * ceil(W/2) tiles:
+//   1. wino_input_kernel   x [H][W][cin]        -> V [16][T][cin]     (B^T d B, zero padding folded in)
+//   2. linear_mfma_kernel  batched over the 16 positions: M_p [T][cout] = V_p [T][cin] . U_p [cout][cin]^T
+//                          (csrc/linear.hip, exact-f32 MFMA, XCD-aware block order)
+//   3. wino_output_kernel  M [16][T][cout]      -> y (A^T M A + bias, ReLU, optional fused 2x2 max-pool:
+//                          a 2x2 output tile IS one pooling window)
+// V and M are scratch (16 T (cin + cout) floats); they are HBM / Infinity-Cache traffic that the direct
+// kernel does not have, which is why the narrow, large layers stay on csrc/conv.hip.
+#include "common.h"
+
+namespace frcnn {
+
+// U[p = 4 i + j][k][c] = (G g G^T)[i][j],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]];  g: OIHW [cout][cin][3][3]
+__global__ __launch_bounds__(256)
+void wino_pack_kernel(const float* __restrict__ g, float* __restrict__ u, int cout, int cin)
+{
+    const size_t total = (size_t)cout * cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float* gp = g + i * 9;
+        double w[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) w[a][b] = (double)gp[a * 3 + b];
+        double r[4][3];                      // G g
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            r[0][b] = w[0][b];
+            r[1][b] = 0.5 * (w[0][b] + w[1][b] + w[2][b]);
+            r[2][b] = 0.5 * (w[0][b] - w[1][b] + w[2][b]);
+            r[3][b] = w[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {        // (G g) G^T
+            const double q0 = r[a][0];
+            const double q1 = 0.5 * (r[a][0] + r[a][1] + r[a][2]);
+            const double q2 = 0.5 * (r[a][0] - r[a][1] + r[a][2]);
+            const double q3 = r[a][2];
+            u[(size_t)(4 * a + 0) * total + i] = (float)q0;
+            u[(size_t)(4 * a + 1) * total + i] = (float)q1;
+            u[(size_t)(4 * a + 2) * total + i] = (float)q2;
+            u[(size_t)(4 * a + 3) * total + i] = (float)q3;
+        }
+    }
+}
+
+// One thread = one tile x 4 channels.  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].
+__global__ __launch_bounds__(256)
+void wino_input_kernel(const float* __restrict__ x, float* __restrict__ v, int H, int W, int cin, int tw, int T)
+{
+    const int c4n = cin >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)T * c4n) return;
+    const int tile = (int)(idx / c4n), c = (int)(idx % c4n) * 4;
+    const int ty = tile / tw, tx = tile % tw;
+    const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+    f32x4 d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = y0 + a;
+        const bool yok = yy >= 0 && yy < H;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int xx = x0 + b;
+            const bool ok = yok && xx >= 0 && xx < W;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            d[a][b] = ok ? *reinterpret_cast<const f32x4*>(x + ((size_t)yy * W + xx) * cin + c) : zero;
+        }
+    }
+    f32x4 r[4][4];                           // B^T d
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        r[0][b] = d[0][b] - d[2][b];
+        r[1][b] = d[1][b] + d[2][b];
+        r[2][b] = d[2][b] - d[1][b];
+        r[3][b] = d[1][b] - d[3][b];
+    }
+    const size_t plane = (size_t)T * cin;
+    float* vp = v + (size_t)tile * cin + c;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {            // (B^T d) B
+        *reinterpret_cast<f32x4*>(vp + (size_t)(4 * a + 0) * plane) = r[a][0] - r[a][2];
+        *reinterpret_cast<f32x4*>(vp + (size_t)(4 * a + 1) * plane) = r[a][1] + r[a][2];
+        *reinterpret_cast<f32x4*>(vp + (size_t)(4 * a + 2) * plane) = r[a][2] - r[a][1];
+        *reinterpret_cast<f32x4*>(vp + (size_t)(4 * a + 3) * plane) = r[a][1] - r[a][3];
+    }
+}
+
+// One thread = one tile x 4 output channels.  A^T = [[1,1,1,0],[0,1,-1,-1]].
+template <bool POOL>
+__global__ __launch_bounds__(256)
+void wino_output_kernel(const float* __restrict__ m, const float* __restrict__ bias, float* __restrict__ y,
+                        int H, int W, int cout, int tw, int T, int relu)
+{
+    const int k4n = cout >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)T * k4n) return;
+    const int tile = (int)(idx / k4n), k = (int)(idx % k4n) * 4;
+    const int ty = tile / tw, tx = tile % tw;
+    const int Ho = H >> 1, Wo = W >> 1;
+    if (POOL && (ty >= Ho || tx >= Wo)) return;      // floor pooling drops the odd last row / column
+    const size_t plane = (size_t)T * cout;
+    const float* mp = m + (size_t)tile * cout + k;
+    f32x4 s[2][4];                           // A^T M
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(mp + (size_t)(0 + j) * plane);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(mp + (size_t)(4 + j) * plane);
+        const f32x4 m2 = *reinterpret_cast<const f32x4*>(mp + (size_t)(8 + j) * plane);
+        const f32x4 m3 = *reinterpret_cast<const f32x4*>(mp + (size_t)(12 + j) * plane);
+        s[0][j] = (m0 + m1) + m2;
+        s[1][j] = (m1 - m2) - m3;
+    }
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + k);
+    f32x4 o[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {            // (A^T M) A
+        o[a][0] = ((s[a][0] + s[a][1]) + s[a][2]) + bv;
+        o[a][1] = ((s[a][1] - s[a][2]) - s[a][3]) + bv;
+    }
+    if (relu) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[a][b][e] = fmaxf(o[a][b][e], 0.f);
+    }
+    if (POOL) {
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
+        *reinterpret_cast<f32x4*>(y + ((size_t)ty * Wo + tx) * cout + k) = r;
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int yy = 2 * ty + a;
+            if (yy >= H) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int xx = 2 * tx + b;
+                if (xx < W) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * cout + k) = o[a][b];
+            }
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+static inline bool wino_shape_ok(int H, int W, int cin, int cout)
+{
+    return H >= 1 && W >= 1 && cin >= 16 && cin % 16 == 0 && cout >= 128 && cout % 128 == 0 &&
+           (size_t)cdiv(H, 2) * cdiv(W, 2) * 16 * (size_t)(cin > cout ? cin : cout) < ((size_t)1 << 31);
+}
+
+size_t conv3x3_winograd_workspace_bytes(int H, int W, int cin, int cout)
+{
+    if (!wino_shape_ok(H, W, cin, cout)) return 0;
+    const size_t T = (size_t)cdiv(H, 2) * cdiv(W, 2);
+    return 16 * T * ((size_t)cin + cout) * sizeof(float);
+}
+
+int launch_pack_conv3x3_winograd(const float* w, float* u, int cout, int cin, hipStream_t s)
+{
+    if (cout < 1 || cin < 1) return FRCNN_EINVAL;
+    const size_t total = (size_t)cout * cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, s, w, u, cout, cin);
+    return check_launch();
+}
+
+int launch_conv3x3_winograd(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
+                            unsigned flags, void* ws, size_t ws_bytes, hipStream_t s)
+{
+    if (!wino_shape_ok(H, W, cin, cout)) return FRCNN_EUNSUPPORTED;
+    const bool pool = (flags & FRCNN_POOL2) != 0;
+    if (pool && (H < 2 || W < 2)) return FRCNN_EINVAL;
+    const size_t need = conv3x3_winograd_workspace_bytes(H, W, cin, cout);
+    if (ws == nullptr || ws_bytes < need) return FRCNN_EINVAL;
+    const int th = cdiv(H, 2), tw = cdiv(W, 2), T = th * tw;
+    float* V = static_cast<float*>(ws);
+    float* M = V + (size_t)16 * T * cin;
+    {
+        const size_t n = (size_t)T * (cin / 4);
+        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, V, H, W, cin, tw, T);
+        int rc = check_launch();
+        if (rc) return rc;
+    }
+    {
+        int rc = launch_linear_batched(V, cin, (size_t)T * cin, u, (size_t)cout * cin, M, cout, (size_t)T * cout,
+                                       T, cout, cin, 16, s);
+        if (rc) return rc;
+    }
+    {
+        const size_t n = (size_t)T * (cout / 4);
+        const int relu = (flags & FRCNN_RELU) ? 1 : 0;
+        if (pool)
+            hipLaunchKernelGGL(wino_output_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                               (const float*)M, b, y, H, W, cout, tw, T, relu);
+        else
+            hipLaunchKernelGGL(wino_output_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                               (const float*)M, b, y, H, W, cout, tw, T, relu);
+        return check_launch();
+    }
+}
+
+}  // namespace frcnn

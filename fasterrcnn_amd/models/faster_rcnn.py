@@ -100,8 +100,9 @@ class FasterRCNNModel(nn.Module):
         self.detector_nms_threshold = 0.3
         self.inflight_conv_blocks_target = 320      # frcnn_forward_params.conv_blocks_target used by predict_async slots
 
-        # arithmetic of the 3x3 convolutions: "f32" = exact f32 MFMA, "f32x6" = exactly split bf16x3
-        # operands, six bf16 MFMAs per product with f32 accumulation (same accuracy class)
+        # arithmetic of the 3x3 convolutions: "f32" = exact f32 MFMA, direct; "f32_winograd" = exact f32 MFMA with the
+        # >= 256-channel layers as Winograd F(2x2,3x3) in float32 (2.25x fewer multiplies, fp32 rounding differences
+        # only); "f32x6" = exactly split bf16x3 operands, six bf16 MFMAs per product with f32 accumulation
         self._math_mode = "f32"
 
         self._train_state = None

@@ -24,11 +24,18 @@ _LAYERS = [  # (name, cin, cout, pool_after)
 def pack_conv3x3(conv, math_mode="f32"):
     """
     OIHW weight of a 3x3 nn.Conv2d -> tap-major [9][cout][cin] (or [27][cout] when cin == 3); in the
-    "f32x6" math mode -> the exactly split [9][cout][cin/16][hi,mid,lo][16] bf16 layout.
+    "f32x6" math mode -> the exactly split [9][cout][cin/16][hi,mid,lo][16] bf16 layout; in the
+    "f32_winograd" mode, for cin >= 256 -> the transformed filters G g G^T as [16][cout][cin].
     """
     w = conv.weight.detach()
     cout, cin = int(w.shape[0]), int(w.shape[1])
     w = rt.as_f32_cuda(w, "conv weight")
+    if math_mode == "f32_winograd" and cin >= nv.WINOGRAD_MIN_CIN:
+        out = t.empty((16, cout, cin), dtype=t.float32, device=w.device)
+        with t.cuda.device(w.device):
+            nv.check(nv.lib().frcnn_pack_conv3x3_winograd(nv.ptr(w), nv.ptr(out), cout, cin, nv.stream_ptr()),
+                     "frcnn_pack_conv3x3_winograd")
+        return out
     if math_mode == "f32x6" and cin != 3:
         out = t.empty((9 * cout * cin * 3,), dtype=t.int16, device=w.device)
         with t.cuda.device(w.device):
@@ -45,16 +52,21 @@ def pack_conv3x3(conv, math_mode="f32"):
 
 def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False):
     """One 3x3 'same' convolution (+ReLU, + fused 2x2 max-pool) on an NHWC CUDA tensor via frcnn_conv3x3_nhwc
-    (or frcnn_conv3x3_nhwc_x6 when `wp` is a split int16 weight buffer)."""
+    (frcnn_conv3x3_nhwc_x6 when `wp` is a split int16 weight buffer, frcnn_conv3x3_nhwc_winograd when it is a
+    [16][cout][cin] transformed filter bank)."""
     h, w = int(x_hwc.shape[0]), int(x_hwc.shape[1])
     oh, ow = (h // 2, w // 2) if pool else (h, w)
     y = t.empty((oh, ow, cout), dtype=t.float32, device=x_hwc.device)
     lib = nv.lib()
-    ws_bytes = int(lib.frcnn_conv3x3_workspace_bytes(h, w, cin, cout))
+    winograd = wp.dtype == t.float32 and wp.dim() == 3 and int(wp.shape[0]) == 16
+    if winograd:
+        ws_bytes = int(lib.frcnn_conv3x3_winograd_workspace_bytes(h, w, cin, cout))
+    else:
+        ws_bytes = int(lib.frcnn_conv3x3_workspace_bytes(h, w, cin, cout))
     ws = t.empty((max(ws_bytes, 4) // 4,), dtype=t.float32, device=x_hwc.device)
     flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
     with t.cuda.device(x_hwc.device):
-        fn = lib.frcnn_conv3x3_nhwc_x6 if wp.dtype == t.int16 else lib.frcnn_conv3x3_nhwc
+        fn = lib.frcnn_conv3x3_nhwc_x6 if wp.dtype == t.int16 else (lib.frcnn_conv3x3_nhwc_winograd if winograd else lib.frcnn_conv3x3_nhwc)
         nv.check(fn(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
                     nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc")
     return y

@@ -37,7 +37,7 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 2   /* 2: training entry points, frcnn_forward_params.conv_blocks_target */
+#define FRCNN_ABI_VERSION 3   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -133,6 +133,22 @@ int frcnn_pack_conv3x3_x6(const float* d_w_oihw, void* d_w_split, int cout, int 
 int frcnn_conv3x3_nhwc_x6(const float* d_x, const void* d_w_split, const float* d_bias,
                           float* d_y, int H, int W, int cin, int cout, unsigned flags,
                           void* d_ws, size_t ws_bytes, void* stream);
+/* The same layer (models/vgg16.py:36-47, models/rpn.py:39) as Winograd F(2x2,3x3) in float32: three launches
+ * (input transform, 16 batched exact-f32 MFMA GEMMs over the channels, output transform + bias + ReLU +
+ * optional 2x2 max-pool), 2.25x fewer multiplies than the direct form.  No reduced-precision operands: every
+ * value is float32 (the filter transform G g G^T is evaluated in float64 and rounded once); results differ
+ * from the direct kernel by fp32 rounding only (a few 1e-7 relative per layer).
+ *   d_u    : float32 [16][cout][cin] from frcnn_pack_conv3x3_winograd (OIHW weights in)
+ *   d_ws   : scratch of frcnn_conv3x3_winograd_workspace_bytes() = 16*ceil(H/2)*ceil(W/2)*(cin+cout)*4 bytes
+ * Requires cin % 16 == 0 and cout % 128 == 0 (FRCNN_EUNSUPPORTED otherwise).  The fused forward uses it in
+ * math mode FRCNN_MATH_F32_WINOGRAD for the layers with cin >= frcnn_winograd_min_cin() (= 256: below that the
+ * transformed tensors cost more HBM traffic than the matrix pipe saves). */
+int frcnn_winograd_min_cin(void);
+int frcnn_pack_conv3x3_winograd(const float* d_w_oihw, float* d_u, int cout, int cin, void* stream);
+size_t frcnn_conv3x3_winograd_workspace_bytes(int H, int W, int cin, int cout);
+int frcnn_conv3x3_nhwc_winograd(const float* d_x, const float* d_u, const float* d_bias,
+                                float* d_y, int H, int W, int cin, int cout, unsigned flags,
+                                void* d_ws, size_t ws_bytes, void* stream);
 /* Stand-alone 2x2/stride-2 floor max-pool on NHWC (vgg16.py:78,82,87,92), c % 4 == 0. */
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream);
 
@@ -275,15 +291,17 @@ typedef struct frcnn_forward_params {
     float   rpn_nms_threshold;  /* 0.7   (models/rpn.py:150)         */
     float   min_side;           /* 16    (models/rpn.py:142)         */
     int32_t allow_edge_proposals; /* 1   (models/faster_rcnn.py:36)  */
-    int32_t math_mode;          /* FRCNN_MATH_F32 (exact f32 MFMA) or FRCNN_MATH_F32X6; selects how the
-                                   3x3 conv weight pointers of the weights struct are interpreted
-                                   (frcnn_pack_conv3x3 vs frcnn_pack_conv3x3_x6) */
+    int32_t math_mode;          /* FRCNN_MATH_F32 (exact f32 MFMA, direct), FRCNN_MATH_F32X6 or FRCNN_MATH_F32_WINOGRAD;
+                                   selects how the 3x3 conv weight pointers of the weights struct are interpreted:
+                                   frcnn_pack_conv3x3 / frcnn_pack_conv3x3_x6 / (layers with cin >=
+                                   frcnn_winograd_min_cin()) frcnn_pack_conv3x3_winograd, frcnn_pack_conv3x3 otherwise */
     int32_t conv_blocks_target; /* split-K granularity of the 3x3 layers: blocks per launch to aim for.  0 = 1280 (best
                                    latency for one image on the chip); ~320 when many images are in flight on separate
                                    streams (other images' kernels fill the tail, longer work units win) */
 } frcnn_forward_params;
 #define FRCNN_MATH_F32   0
 #define FRCNN_MATH_F32X6 1
+#define FRCNN_MATH_F32_WINOGRAD 2
 
 /* d_image: float32 NCHW [3][H][W] (preprocessed as models/vgg16.py:146 prescribes).
  * d_anchor_map / d_valid_map: optional caller-provided maps (faster_rcnn.py:113-115); NULL =
@@ -438,9 +456,10 @@ int frcnn_ctx_tensor(frcnn_ctx* ctx, int which, void** d_ptr, size_t* bytes);
 /* Per-kernel-class HIP-event timing for bench.py's roofline block: when enabled, every launch
  * of class `k` inside frcnn_vgg16_forward is bracketed by events on the launch stream.
  * classes: 0 conv3x3 MFMA (backbone+RPN), 1 conv first layer, 2 linear MFMA, 3 proposals,
- * 4 roi_pool, 5 other.  frcnn_ctx_timing_read synchronises the recorded events and returns
+ * 4 roi_pool, 5 other, 6 Winograd 3x3 layer (its three launches as one unit; math mode
+ * FRCNN_MATH_F32_WINOGRAD).  frcnn_ctx_timing_read synchronises the recorded events and returns
  * accumulated milliseconds and launch counts since the last reset. */
-#define FRCNN_NUM_KCLASS 6
+#define FRCNN_NUM_KCLASS 7
 int frcnn_ctx_timing_enable(frcnn_ctx* ctx, int enable);
 int frcnn_ctx_timing_read(frcnn_ctx* ctx, double ms[FRCNN_NUM_KCLASS], int64_t launches[FRCNN_NUM_KCLASS],
                           int reset);

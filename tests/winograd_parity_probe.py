@@ -1,0 +1,125 @@
+"""
+tests/winograd_parity_probe.py -- development probe (CPU only, not collected by pytest).
+
+Question: would an fp32 Winograd F(2x2,3x3) convolution for the wide VGG-16 layers (2.25x fewer
+multiplies) keep the parity the exact-f32 direct kernel has against the reference's golden vectors
+(boxes within 1e-3 px)?  The probe swaps the oracle's 3x3 convolutions with cin >= MIN_CIN for an fp32
+Winograd emulation (transforms and channel reduction in float32, as a GPU kernel would do them) and
+scores the final detections with the criterion of tests/test_model_gpu.py.  The control replaces the same
+layers with a direct convolution summed in a different order (per-tap GEMMs), i.e. the kind of
+difference two correct fp32 implementations always have.
+
+  python tests/winograd_parity_probe.py [--min-cin 256] [--cases 600x1000_s0,224x320_s3]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch as t
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from fasterrcnn_amd import synthetic          # noqa: E402
+from oracle import frcnn_oracle as O          # noqa: E402
+
+BT = t.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=t.float32)
+G = t.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=t.float32)
+AT = t.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=t.float32)
+
+
+def winograd_conv3x3(x, w, b):
+    """x (1,C,H,W), w (K,C,3,3), b (K,) -> (1,K,H,W); everything in float32."""
+    _, C, H, W = x.shape
+    K = w.shape[0]
+    He, We = (H + 1) // 2 * 2, (W + 1) // 2 * 2
+    xp = F.pad(x, (1, 1 + We - W, 1, 1 + He - H))
+    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)[0]                     # (C, th, tw, 4, 4)
+    th, tw = d.shape[1], d.shape[2]
+    V = t.einsum("ij,cabjk,lk->cabil", BT, d, BT)                 # B^T d B
+    U = t.einsum("ij,kcjl,ml->kcim", G, w, G)                     # G g G^T  (K,C,4,4)
+    M = t.empty((K, th * tw, 4, 4), dtype=t.float32)
+    Vf = V.reshape(C, th * tw, 4, 4)
+    for i in range(4):
+        for j in range(4):
+            M[:, :, i, j] = U[:, :, i, j] @ Vf[:, :, i, j]        # (K,C) @ (C,tiles)
+    Y = t.einsum("ij,knjl,ml->knim", AT, M, AT)                   # (K, tiles, 2, 2)
+    y = Y.reshape(K, th, tw, 2, 2).permute(0, 1, 3, 2, 4).reshape(K, He, We)[:, :H, :W]
+    return (y + b[:, None, None]).unsqueeze(0)
+
+
+def pertap_conv3x3(x, w, b):
+    """Direct convolution as nine per-tap GEMMs accumulated in float32 (a different summation order)."""
+    _, C, H, W = x.shape
+    K = w.shape[0]
+    xp = F.pad(x, (1, 1, 1, 1))[0]
+    y = t.zeros((K, H * W), dtype=t.float32)
+    for dy in range(3):
+        for dx in range(3):
+            y += w[:, :, dy, dx] @ xp[:, dy:dy + H, dx:dx + W].reshape(C, H * W)
+    return (y.reshape(K, H, W) + b[:, None, None]).unsqueeze(0)
+
+
+def iou_matrix(a, b):
+    tl = np.maximum(a[:, None, 0:2], b[None, :, 0:2])
+    br = np.minimum(a[:, None, 2:4], b[None, :, 2:4])
+    wh = np.clip(br - tl, 0, None)
+    inter = wh[..., 0] * wh[..., 1]
+    aa = np.prod(a[:, 2:4] - a[:, 0:2], axis=1)
+    ab = np.prod(b[:, 2:4] - b[:, 0:2], axis=1)
+    return inter / (aa[:, None] + ab[None, :] - inter + 1e-12)
+
+
+def score(det, ref):
+    n_ref = n_ok = 0
+    errs = []
+    for c in range(1, 21):
+        r = ref[ref[:, 0] == c][:, 1:]
+        n_ref += len(r)
+        if len(r) == 0 or len(det[c]) == 0:
+            continue
+        j = iou_matrix(r[:, :4].astype(np.float64), det[c][:, :4]).argmax(axis=1)
+        err = np.abs(det[c][j, :4] - r[:, :4]).max(axis=1)
+        ok = (err <= 1e-3) & (np.abs(det[c][j, 4] - r[:, 4]) <= 1e-4)
+        errs.extend(err[err < 1.0].tolist())
+        n_ok += int(ok.sum())
+    return n_ok, n_ref, (np.median(errs) if errs else float("nan")), (np.percentile(errs, 95) if errs else float("nan"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--min-cin", type=int, default=256)
+    ap.add_argument("--cases", type=str, default="600x1000_s0,224x320_s3")
+    args = ap.parse_args()
+    sd = synthetic.vgg16_state_dict(1234)
+    real_conv = F.conv2d
+    for tag in args.cases.split(","):
+        g = np.load(os.path.join(ROOT, "tests", "golden", "vgg16_%s.npz" % tag))
+        img = synthetic.image(int(g["seed"]), int(g["height"]), int(g["width"])).unsqueeze(0)
+        for name, impl in (("oracle (MKL direct)", None), ("per-tap direct", pertap_conv3x3), ("winograd F(2x2,3x3)", winograd_conv3x3)):
+            def patched(x, w, b=None, stride=1, padding=0, **kw):
+                if impl is not None and w.shape[2] == 3 and w.shape[1] >= args.min_cin and stride == 1:
+                    return impl(x, w, b)
+                return real_conv(x, w, b, stride=stride, padding=padding, **kw)
+            O.F.conv2d = patched
+            try:
+                detail = {}
+                with t.no_grad():
+                    props, classes, deltas = O.forward(sd, img, allow_edge_proposals=bool(g["allow_edge"]), detail=detail)
+                det = O.detections(props.numpy(), classes.numpy(), deltas.numpy(), int(g["height"]), int(g["width"]),
+                                   float(g["score_threshold"]))
+            finally:
+                O.F.conv2d = real_conv
+            n_ok, n_ref, med, p95 = score(det, g["detections"])
+            fm = detail["feature_map"].numpy()[0]
+            fm_err = np.abs(fm[:32] - g["feature_map_sample"]).max() / max(float(g["feature_map_absmean"]), 1e-30)
+            pr = props.numpy()
+            same_props = (np.abs(pr[:, None, :] - g["proposals"][None, :, :]).max(axis=2) <= 1e-3).any(axis=0).mean() if len(pr) else 0.0
+            print("%-16s %-20s detections %3d/%3d within 1e-3 px (median %.2e, p95 %.2e)  proposals %.1f%%  feature-map max err / mean|x| %.2e"
+                  % (tag, name, n_ok, n_ref, med, p95, 100 * same_props, fm_err), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--x6", action="store_true", help="time the f32x6 (bf16x3 split) conv kernels")
+    ap.add_argument("--winograd", action="store_true", help="time the Winograd F(2x2,3x3) path for layers with cout %% 128 == 0 "
+                    "(TF column = direct-convolution FLOP / time)")
     ap.add_argument("--shape", type=str, action="append", default=[], help="extra layer: cin,cout,h,w,pool (repeatable)")
     args = ap.parse_args()
     for i, sh in enumerate(args.shape):
@@ -67,12 +69,22 @@ def main():
         b = torch.zeros((cout,), device=dev)
         oh, ow = (h // 2, w // 2) if pool else (h, w)
         y = torch.empty((oh, ow, cout), device=dev)
-        wsb = (160 << 20) if args.x6 else int(lib.frcnn_conv3x3_workspace_bytes(h, w, cin, cout))
+        wino = args.winograd and cout % 128 == 0
+        if wino:
+            w_oihw = torch.randn((cout, cin, 3, 3), device=dev) * 0.02
+            wu = torch.empty((16, cout, cin), device=dev)
+            nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w_oihw), nv.ptr(wu), cout, cin, s), "pack_winograd")
+            wsb = int(lib.frcnn_conv3x3_winograd_workspace_bytes(h, w, cin, cout))
+        else:
+            wsb = (160 << 20) if args.x6 else int(lib.frcnn_conv3x3_workspace_bytes(h, w, cin, cout))
         ws = torch.empty((max(wsb, 4) // 4,), device=dev)
         flags = nv.RELU | (nv.POOL2 if pool else 0)
 
         def run():
-            if args.x6:
+            if wino:
+                nv.check(lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x), nv.ptr(wu), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
+                                                         nv.ptr(ws), wsb, s), "conv_winograd")
+            elif args.x6:
                 nv.check(lib.frcnn_conv3x3_nhwc_x6(nv.ptr(x), nv.ptr(wq), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
                                                    nv.ptr(ws), wsb, s), "conv_x6")
             else:
