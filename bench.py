@@ -46,8 +46,34 @@ _MFMA_CONVS = [(64, 64, 600, 1000), (64, 128, 300, 500), (128, 128, 300, 500), (
                (512, 512, 37, 62)]   # last = RPN trunk (models/rpn.py:88)
 
 
+WINOGRAD_MIN_CIN = 256           # fasterrcnn_amd/_native.py WINOGRAD_MIN_CIN
+
+
 def conv_mfma_flops_per_image():
     return float(sum(2.0 * 9 * ci * co * h * w for ci, co, h, w in _MFMA_CONVS))
+
+
+def direct_layers(math):
+    """The 3x3 layers that run on conv3x3_mfma_kernel in this math mode."""
+    return [l for l in _MFMA_CONVS if not (math == "f32_winograd" and l[0] >= WINOGRAD_MIN_CIN)]
+
+
+def winograd_layers(math):
+    return [l for l in _MFMA_CONVS if math == "f32_winograd" and l[0] >= WINOGRAD_MIN_CIN]
+
+
+def winograd_gemm_flops(ci, co, h, w):
+    """FLOP the 16 batched GEMMs of one Winograd F(2x2,3x3) layer execute: 16 positions x tiles x cin x cout x 2."""
+    return 2.0 * 16 * ((h + 1) // 2) * ((w + 1) // 2) * ci * co
+
+
+def executed_mfma_flops_per_image(math, n_rois=300):
+    """Matrix-pipe FLOP actually executed per image (Winograd layers count their GEMM FLOP, not the direct-form FLOP)."""
+    conv = sum(2.0 * 9 * ci * co * h * w for ci, co, h, w in direct_layers(math))
+    wino = sum(winograd_gemm_flops(*l) for l in winograd_layers(math))
+    rpn_heads = 2.0 * 512 * 45 * 37 * 62
+    det = n_rois * 2.0 * (25088 * 4096 + 4096 * 4096 + 4096 * 101)
+    return conv + wino + rpn_heads + det
 
 
 def total_flops_per_image(n_rois=300):
@@ -114,10 +140,11 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=3, help="images timed on the host CPU (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-images", type=int, default=10)
-    ap.add_argument("--math", type=str, default="f32", choices=["f32", "f32_winograd", "f32x6"],
-                    help="3x3 conv arithmetic: exact f32 MFMA direct (default), the same with the >= 256-channel layers as Winograd "
-                         "F(2x2,3x3) in float32, or exactly split bf16x3 operands (six bf16 MFMAs per product)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the informational f32x6 throughput leg")
+    ap.add_argument("--math", type=str, default=None, choices=["f32", "f32_winograd", "f32x6"],
+                    help="3x3 conv arithmetic: f32_winograd (VGG-16 default: exact f32 MFMA, the >= 256-channel layers as Winograd "
+                         "F(2x2,3x3) in float32), f32 (every layer on the direct exact-f32 kernel; the only mode of the ResNets), "
+                         "or f32x6 (exactly split bf16x3 operands, six bf16 MFMAs per product)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the informational legs in the other math modes")
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
                     help="untimed pre-roll before the warm-up steps: the GPU takes ~1-2 s of load to leave its idle power state "
                          "(sclk 157 MHz -> 2.4 GHz), far longer than a 20-step warm-up")
@@ -162,8 +189,9 @@ def main():
         model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
     model.load_state_dict(sd, strict=True)
     model = model.cuda(dev).eval()
-    if args.math != "f32":
-        model.math_mode = args.math
+    if args.math is None:
+        args.math = model.math_mode                 # the model's default: f32_winograd (VGG-16) / f32 (ResNet)
+    model.math_mode = args.math
     make_image = synthetic.image_rgb if is_resnet else synthetic.image
 
     # synthetic image pool, resident in HBM before timing; per-image seed = global index
@@ -202,27 +230,29 @@ def main():
         elapsed = float(tt.item())
     value = n_gpus * args.steps / elapsed
 
-    # ---- informational: the same workload in the f32x6 math mode (not the headline value) -----------
-    secondary = None
-    if not is_resnet and args.math == "f32" and not args.no_secondary:
-        model.math_mode = "f32x6"
-        run(max(args.warmup, nslots))
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        ts = time.perf_counter()
-        run(args.steps)
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - ts
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        secondary = {"math": "f32x6 (operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, f32 accumulate)",
-                     "value": round(n_gpus * args.steps / dt, 3), "unit": "images/sec"}
-        model.math_mode = "f32"
+    # ---- informational: the same workload in the other math modes (not the headline value) -----------
+    secondary = {}
+    if not is_resnet and not args.no_secondary:
+        for mode in ("f32", "f32_winograd", "f32x6"):
+            if mode == args.math:
+                continue
+            model.math_mode = mode
+            run(max(args.warmup, nslots))
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            ts = time.perf_counter()
+            run(args.steps)
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            dt = time.perf_counter() - ts
+            if world > 1:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            secondary[mode] = round(n_gpus * args.steps / dt, 3)
+        model.math_mode = args.math
 
     # ---- mAP@0.5 leg (outside the timed region): labelled subset, merged across ranks -------------
     records = ImageRecords()
@@ -243,20 +273,36 @@ def main():
         torch.cuda.synchronize(dev)
         timing = ctx.timing_read(reset=True)
         ctx.timing_enable(False)
-        conv_ms, conv_launches = timing["conv3x3_mfma"]
-        flops_per_launch = conv_mfma_flops_per_image() / len(_MFMA_CONVS)
-        avg_launch_s = (conv_ms / 1e3) / max(conv_launches, 1)
-        achieved = flops_per_launch / avg_launch_s / 1e12 if conv_launches else 0.0
-        roofline = {
-            "kernel": "conv3x3_mfma_kernel (12 backbone layers + RPN trunk)",
-            "regime": "HIP events around every launch, one image at a time on one stream (after the timed region: with 24 images "
-                      "in flight concurrent kernels share the CUs and a launch's wall duration is not its own)",
-            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(),
-            "flops_per_launch": flops_per_launch, "avg_launch_us": round(avg_launch_s * 1e6, 2),
-            "launches": int(conv_launches),
-            "per_class_ms_per_image": {k: round(v[0] / max(args.roofline_images, 1), 4) for k, v in timing.items()},
-        }
+        def mfma_roofline(kernel, cls, layer_flops, note):
+            ms, launches = timing[cls]
+            if not launches:
+                return None
+            per_launch = float(sum(layer_flops)) / len(layer_flops)
+            avg_s = (ms / 1e3) / launches
+            ach = per_launch / avg_s / 1e12
+            return {"kernel": kernel, "regime": regime, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "flops_per_launch": per_launch,
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(launches), "ms_per_image": round(ms / max(args.roofline_images, 1), 4),
+                    "note": note}
+
+        regime = ("HIP events around every launch, one image at a time on one stream (after the timed region: with 24 images "
+                  "in flight concurrent kernels share the CUs and a launch's wall duration is not its own)")
+        dl, wl = direct_layers(args.math), winograd_layers(args.math)
+        r_direct = mfma_roofline("conv3x3_mfma_kernel (direct 3x3 layers: %d per image)" % len(dl), "conv3x3_mfma",
+                                 [2.0 * 9 * ci * co * h * w for ci, co, h, w in dl], "FLOP = direct-convolution FLOP of the layers")
+        if r_direct is not None:
+            r_direct["traffic"] = measured_traffic()
+        r_wino = mfma_roofline("linear_mfma_kernel<2,2,2,2,batched> (16-position Winograd GEMM: %d layers per image)" % len(wl),
+                               "winograd_gemm", [winograd_gemm_flops(*l) for l in wl],
+                               "FLOP = the FLOP the GEMMs execute (16 x tiles x cin x cout x 2), NOT the 2.25x larger "
+                               "direct-convolution FLOP they replace") if wl else None
+        # `roofline` = the kernel with the most GPU time per image, the other one rides along
+        both = [r for r in (r_direct, r_wino) if r is not None]
+        both.sort(key=lambda r: -r["ms_per_image"])
+        roofline = dict(both[0]) if both else {"note": "timing disabled"}
+        if len(both) > 1:
+            roofline["second_kernel"] = both[1]
+        roofline["per_class_ms_per_image"] = {k: round(v[0] / max(args.roofline_images, 1), 4) for k, v in timing.items()}
 
         cpu = None
         if not args.no_cpu_baseline and n_gpus == 1 and not is_resnet:
@@ -289,7 +335,10 @@ def main():
                        "images_in_flight_per_gpu": nslots, "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "image-parallel x%d" % n_gpus,
                        "flops_per_image": flops_img},
             "tflops_per_gpu": round(value / n_gpus * flops_img / 1e12, 2),
-            "math": args.math, "secondary_f32x6": secondary,
+            "tflops_per_gpu_note": "direct-convolution FLOP of the workload x images/sec (BASELINE.md's 4.4922e11 per image); "
+                                   "in the f32_winograd mode the matrix pipe executes fewer: see mfma_tflops_executed_per_gpu",
+            "mfma_tflops_executed_per_gpu": None if is_resnet else round(value / n_gpus * executed_mfma_flops_per_image(args.math) / 1e12, 2),
+            "math": args.math, "other_math_modes_images_per_sec": secondary,
             "map_at_0.5": mean_ap, "map_images": int(args.map_images * world),
             "roofline": roofline, "cpu_baseline": cpu,
         }

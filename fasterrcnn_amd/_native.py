@@ -17,8 +17,9 @@ ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
 POOL2 = 2
-NUM_KCLASS = 7
-KCLASS_NAMES = ("conv3x3_mfma", "conv3x3_c3", "linear_mfma", "proposals", "roi_pool", "other", "conv3x3_winograd")
+NUM_KCLASS = 8
+KCLASS_NAMES = ("conv3x3_mfma", "conv3x3_c3", "linear_mfma", "proposals", "roi_pool", "other", "winograd_transforms",
+                "winograd_gemm")
 
 # Every symbol include/frcnn_hip.h declares (tests check the .so exports all of them).
 SYMBOLS = (

@@ -671,8 +671,15 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
         if (wino && ci >= WINOGRAD_MIN_CIN) {
-            Scope _w(c, 6, s);
-            return launch_conv3x3_winograd(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->wino_ws, c->wino_ws_bytes, s);
+            float *V = nullptr, *M = nullptr;
+            int r = winograd_plan(hh, ww, ci, co, fl, c->wino_ws, c->wino_ws_bytes, &V, &M);
+            if (r) return r;
+            { Scope _t(c, 6, s); r = launch_winograd_input(xin, V, hh, ww, ci, s); }
+            if (r) return r;
+            { Scope _g(c, 7, s); r = launch_winograd_gemm(V, wgt, M, hh, ww, ci, co, s); }
+            if (r) return r;
+            Scope _o(c, 6, s);
+            return launch_winograd_output(M, bs, yout, hh, ww, co, fl, s);
         }
         Scope _d(c, 0, s);
         return x6 ? launch_conv3x3_x6(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s)

@@ -83,6 +83,10 @@ size_t conv3x3_winograd_workspace_bytes(int H, int W, int cin, int cout);
 int launch_pack_conv3x3_winograd(const float* w, float* u, int cout, int cin, hipStream_t s);
 int launch_conv3x3_winograd(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
                             unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
+int winograd_plan(int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, float** V, float** M);
+int launch_winograd_input(const float* x, float* V, int H, int W, int cin, hipStream_t s);
+int launch_winograd_gemm(const float* V, const float* u, float* M, int H, int W, int cin, int cout, hipStream_t s);
+int launch_winograd_output(const float* M, const float* b, float* y, int H, int W, int cout, unsigned flags, hipStream_t s);
 int launch_softmax_rows(const float* x, int ldx, float* y, int M, int ncls, hipStream_t s);
 int launch_head_finish(const float* x, int ldx, int M, int ncls, int ndelta, float* classes,
                        float* deltas, hipStream_t s);

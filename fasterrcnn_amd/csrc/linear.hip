@@ -40,7 +40,7 @@ struct GemmCfg {
 // that share the batch's weights land in the same XCD's L2.
 struct BatchGeom { long long a_stride, w_stride, y_stride; int nblocks, mblocks, batches; };
 
-template <int TM, int TN, int WM, int WN, bool BATCHED>
+template <int TM, int TN, int WM, int WN, bool BATCHED, int NSETS = 2>
 __global__ __launch_bounds__(64 * WM * WN)
 void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __restrict__ w,
                         const float* __restrict__ bias, float* __restrict__ y, int ldy,
@@ -101,7 +101,9 @@ void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __res
 
     // two register sets: the tile of stage s+1 and the tile of stage s+2 are in flight at the same time (the weights
     // of fc1 stream from HBM, one 2 us stage of prefetch distance is not enough with one wave per SIMD)
-    f32x4 areg[2][C::NA], breg[2][C::NB];
+    // (NSETS = 1: one tile of prefetch distance, 16 registers fewer -- the batched Winograd GEMMs read L2 / Infinity-Cache
+    // resident operands and gain more from a third resident block per CU than from the second tile in flight)
+    f32x4 areg[NSETS][C::NA], breg[NSETS][C::NB];
     auto load_tiles = [&](int stage, f32x4 (&ar)[C::NA], f32x4 (&br)[C::NB]) {
         const char* ab = reinterpret_cast<const char*>(a_blk + (stage << 4));
         const char* wb = reinterpret_cast<const char*>(w_blk + (stage << 4));
@@ -140,7 +142,8 @@ void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __res
         load_tiles(st_begin, areg[0], breg[0]);
         store_tiles(0, areg[0], breg[0]);
         load_tiles(st_begin + 1 < st_end ? st_begin + 1 : last, areg[0], breg[0]);     // tile 1 -> set 0
-        load_tiles(st_begin + 2 < st_end ? st_begin + 2 : last, areg[1], breg[1]);     // tile 2 -> set 1
+        if constexpr (NSETS == 2)
+            load_tiles(st_begin + 2 < st_end ? st_begin + 2 : last, areg[1], breg[1]); // tile 2 -> set 1
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TM; ++i) a0[i] = *reinterpret_cast<const f32x4*>(at0 + a_base + i * 32 * LLDK);
@@ -160,7 +163,7 @@ void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __res
             // c. tile s+1 -> LDS; d. tile s+2 -> registers
             store_tiles(nxt, ar, br);
             {
-                const int s3 = st_begin + s + 3;
+                const int s3 = st_begin + s + 1 + NSETS;
                 load_tiles(s3 < st_end ? s3 : last, ar, br);
             }
             // e. first half
@@ -202,9 +205,13 @@ void linear_mfma_kernel(const float* __restrict__ a, int lda, const float* __res
             for (int q = 0; q < N_RD; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
             __builtin_amdgcn_sched_barrier(0);
         };
-        int s = 0;
-        for (; s + 1 < nst; s += 2) { stage(s, areg[0], breg[0]); stage(s + 1, areg[1], breg[1]); }
-        if (s < nst) stage(s, areg[0], breg[0]);
+        if constexpr (NSETS == 2) {
+            int s = 0;
+            for (; s + 1 < nst; s += 2) { stage(s, areg[0], breg[0]); stage(s + 1, areg[1], breg[1]); }
+            if (s < nst) stage(s, areg[0], breg[0]);
+        } else {
+            for (int s = 0; s < nst; ++s) stage(s, areg[0], breg[0]);
+        }
     }
 
     // epilogue: acc[i][j][r] = out[m0 + 32(TM wm + i) + (r&3)+8(r>>2)+4lh][n0 + 32(TN wn + j) + li]
@@ -365,12 +372,12 @@ static int launch_linear_cfg(const LinearPlan& p, const float* a, int lda, const
     return check_launch();
 }
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int NSETS>
 static int launch_linear_batched_cfg(const float* a, int lda, const float* w, float* y, int ldy, int M, int N, int K,
                                      const BatchGeom& bg, hipStream_t s)
 {
     using C = GemmCfg<TM, TN, WM, WN>;
-    auto kern = linear_mfma_kernel<TM, TN, WM, WN, true>;
+    auto kern = linear_mfma_kernel<TM, TN, WM, WN, true, NSETS>;
     static bool attr_set = false;
     if (!attr_set) {
         FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -390,7 +397,16 @@ int launch_linear_batched(const float* a, int lda, size_t a_stride, const float*
 {
     if (M < 1 || N < 1 || K < 16 || K % 16 != 0 || lda % 4 != 0 || lda < K || ldy < N || batches < 1) return FRCNN_EINVAL;
     BatchGeom bg{(long long)a_stride, (long long)w_stride, (long long)y_stride, cdiv(N, 128), cdiv(M, 128), batches};
-    return launch_linear_batched_cfg<2, 2, 2, 2>(a, lda, w, y, ldy, M, N, K, bg, s);
+    static int nsets = -1, bm64_below = -1;
+    if (nsets < 0) { const char* e = getenv("FRCNN_WINO_NSETS"); nsets = e ? atoi(e) : 1; }
+    if (bm64_below < 0) { const char* e = getenv("FRCNN_WINO_BM64_BELOW"); bm64_below = e ? atoi(e) : 1536; }
+    // few 128 x 128 tiles (the 37 x 62 maps: 320) leave CUs idle or unevenly loaded: 64-row tiles double the block count
+    if ((long long)bg.nblocks * bg.mblocks * batches < bm64_below) {
+        bg.mblocks = cdiv(M, 64);
+        return launch_linear_batched_cfg<1, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
+    }
+    return nsets == 2 ? launch_linear_batched_cfg<2, 2, 2, 2, 2>(a, lda, w, y, ldy, M, N, K, bg, s)
+                      : launch_linear_batched_cfg<2, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
 }
 
 int launch_linear(const float* a, int lda, const float* w, const float* bias, float* y, int ldy,

@@ -179,39 +179,53 @@ int launch_pack_conv3x3_winograd(const float* w, float* u, int cout, int cin, hi
     return check_launch();
 }
 
+// The three launches of one layer, separately callable so that the fused forward can time them per class.
+int launch_winograd_input(const float* x, float* V, int H, int W, int cin, hipStream_t s)
+{
+    const int tw = cdiv(W, 2), T = cdiv(H, 2) * tw;
+    const size_t n = (size_t)T * (cin / 4);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, V, H, W, cin, tw, T);
+    return check_launch();
+}
+
+int launch_winograd_gemm(const float* V, const float* u, float* M, int H, int W, int cin, int cout, hipStream_t s)
+{
+    const int T = cdiv(H, 2) * cdiv(W, 2);
+    return launch_linear_batched(V, cin, (size_t)T * cin, u, (size_t)cout * cin, M, cout, (size_t)T * cout, T, cout, cin, 16, s);
+}
+
+int launch_winograd_output(const float* M, const float* b, float* y, int H, int W, int cout, unsigned flags, hipStream_t s)
+{
+    const int tw = cdiv(W, 2), T = cdiv(H, 2) * tw;
+    const size_t n = (size_t)T * (cout / 4);
+    const int relu = (flags & FRCNN_RELU) ? 1 : 0;
+    if (flags & FRCNN_POOL2)
+        hipLaunchKernelGGL(wino_output_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, b, y, H, W, cout, tw, T, relu);
+    else
+        hipLaunchKernelGGL(wino_output_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, b, y, H, W, cout, tw, T, relu);
+    return check_launch();
+}
+
+// Validates shape and scratch; V = ws, M = ws + 16 T cin floats.
+int winograd_plan(int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, float** V, float** M)
+{
+    if (!wino_shape_ok(H, W, cin, cout)) return FRCNN_EUNSUPPORTED;
+    if ((flags & FRCNN_POOL2) && (H < 2 || W < 2)) return FRCNN_EINVAL;
+    if (ws == nullptr || ws_bytes < conv3x3_winograd_workspace_bytes(H, W, cin, cout)) return FRCNN_EINVAL;
+    *V = static_cast<float*>(ws);
+    *M = *V + (size_t)16 * cdiv(H, 2) * cdiv(W, 2) * cin;
+    return FRCNN_OK;
+}
+
 int launch_conv3x3_winograd(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
                             unsigned flags, void* ws, size_t ws_bytes, hipStream_t s)
 {
-    if (!wino_shape_ok(H, W, cin, cout)) return FRCNN_EUNSUPPORTED;
-    const bool pool = (flags & FRCNN_POOL2) != 0;
-    if (pool && (H < 2 || W < 2)) return FRCNN_EINVAL;
-    const size_t need = conv3x3_winograd_workspace_bytes(H, W, cin, cout);
-    if (ws == nullptr || ws_bytes < need) return FRCNN_EINVAL;
-    const int th = cdiv(H, 2), tw = cdiv(W, 2), T = th * tw;
-    float* V = static_cast<float*>(ws);
-    float* M = V + (size_t)16 * T * cin;
-    {
-        const size_t n = (size_t)T * (cin / 4);
-        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, V, H, W, cin, tw, T);
-        int rc = check_launch();
-        if (rc) return rc;
-    }
-    {
-        int rc = launch_linear_batched(V, cin, (size_t)T * cin, u, (size_t)cout * cin, M, cout, (size_t)T * cout,
-                                       T, cout, cin, 16, s);
-        if (rc) return rc;
-    }
-    {
-        const size_t n = (size_t)T * (cout / 4);
-        const int relu = (flags & FRCNN_RELU) ? 1 : 0;
-        if (pool)
-            hipLaunchKernelGGL(wino_output_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                               (const float*)M, b, y, H, W, cout, tw, T, relu);
-        else
-            hipLaunchKernelGGL(wino_output_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                               (const float*)M, b, y, H, W, cout, tw, T, relu);
-        return check_launch();
-    }
+    float *V = nullptr, *M = nullptr;
+    int rc = winograd_plan(H, W, cin, cout, flags, ws, ws_bytes, &V, &M);
+    if (rc) return rc;
+    if ((rc = launch_winograd_input(x, V, H, W, cin, s)) != FRCNN_OK) return rc;
+    if ((rc = launch_winograd_gemm(V, u, M, H, W, cin, cout, s)) != FRCNN_OK) return rc;
+    return launch_winograd_output(M, b, y, H, W, cout, flags, s);
 }
 
 }  // namespace frcnn

@@ -68,6 +68,11 @@ class RegionProposalNetwork(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def packed_direct(self):
+        """Fresh direct-kernel packs whatever the inference math mode is (the train step's masters)."""
+        head_w, head_b = pack_stack_rows(self._rpn_class, self._rpn_boxes)
+        return (pack_conv3x3(self._rpn_conv1, "f32"), rt.as_f32_cuda(self._rpn_conv1.bias.detach(), "bias").clone(), head_w, head_b)
+
     def forward(self, feature_map, image_shape, anchor_map, anchor_valid_map, max_proposals_pre_nms, max_proposals_post_nms):
         """
         Same contract as rpn.py:51-156.  feature_map (1, C, H, W) CUDA float32 ->

@@ -97,6 +97,10 @@ class FeatureExtractor(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def packed_direct(self):
+        """Fresh tap-major [9][cout][cin] packs whatever the inference math mode is (the train step's masters)."""
+        return [(pack_conv3x3(c, "f32"), rt.as_f32_cuda(c.bias.detach(), "conv bias").clone()) for c in self.convs()]
+
     def forward(self, image_data):
         """
         image_data (1, 3, H, W) float32 CUDA -> feature map (1, 512, H // 16, W // 16), as the

@@ -166,12 +166,12 @@ class TrainState:
 
     def __init__(self, model):
         self.model = model
-        if model.math_mode != "f32":
-            raise NotImplementedError("training runs in the exact-f32 math mode")
+        if model.math_mode not in ("f32", "f32_winograd"):
+            raise NotImplementedError("training runs on the exact-f32 direct kernels (inference math mode f32 or f32_winograd)")
         rp = model._stage2_region_proposal_network
         dn = model._stage3_detector_network
-        wc, bc, wh, bh = rp.packed()
-        self.rpn_conv, self.rpn_conv_b, self.rpn_head, self.rpn_head_b = wc.clone(), bc.clone(), wh.clone(), bh.clone()
+        # masters in the direct kernels' layout, whatever layout the inference mode packs
+        self.rpn_conv, self.rpn_conv_b, self.rpn_head, self.rpn_head_b = rp.packed_direct()
         hw, hb = dn.packed()
         self.head, self.head_b = hw.clone(), hb.clone()
         self.device = self.head.device
@@ -240,7 +240,7 @@ class VGG16TrainState(TrainState):
         if pv._dropout1.p > 0 or pv._dropout2.p > 0:
             raise NotImplementedError("dropout > 0 is not implemented in the train step (reference default: 0.0)")
         # clones: the inference-side packed caches are rebuilt from the parameters, these are the training masters
-        self.conv = [(wp.clone(), b.clone()) for wp, b in fe.packed()]
+        self.conv = fe.packed_direct()
         w1p, b1, w2, b2 = pv.packed()
         self.fc1, self.fc1_b, self.fc2, self.fc2_b = w1p.clone(), b1.clone(), w2.clone(), b2.clone()
 

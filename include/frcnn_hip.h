@@ -456,10 +456,10 @@ int frcnn_ctx_tensor(frcnn_ctx* ctx, int which, void** d_ptr, size_t* bytes);
 /* Per-kernel-class HIP-event timing for bench.py's roofline block: when enabled, every launch
  * of class `k` inside frcnn_vgg16_forward is bracketed by events on the launch stream.
  * classes: 0 conv3x3 MFMA (backbone+RPN), 1 conv first layer, 2 linear MFMA, 3 proposals,
- * 4 roi_pool, 5 other, 6 Winograd 3x3 layer (its three launches as one unit; math mode
+ * 4 roi_pool, 5 other, 6 Winograd input / output transforms, 7 Winograd batched MFMA GEMM (math mode
  * FRCNN_MATH_F32_WINOGRAD).  frcnn_ctx_timing_read synchronises the recorded events and returns
  * accumulated milliseconds and launch counts since the last reset. */
-#define FRCNN_NUM_KCLASS 7
+#define FRCNN_NUM_KCLASS 8
 int frcnn_ctx_timing_enable(frcnn_ctx* ctx, int enable);
 int frcnn_ctx_timing_read(frcnn_ctx* ctx, double ms[FRCNN_NUM_KCLASS], int64_t launches[FRCNN_NUM_KCLASS],
                           int reset);

@@ -310,24 +310,26 @@ def test_state_dict_roundtrip_repacks(gpu_model, sd_cpu):
 
 
 # ---------------------------------------------------------------------------------------------
-# "f32x6" math mode (bf16x3-split operands, six bf16 MFMAs per product): the SAME end-to-end
-# thresholds as the exact-f32 mode
+# The other math modes -- "f32" (every 3x3 layer on the direct exact-f32 kernel; the default is
+# "f32_winograd", which the tests above exercise) and "f32x6" (bf16x3-split operands, six bf16 MFMAs
+# per product): the SAME end-to-end thresholds as the default mode
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["f32", "f32x6"])
 @pytest.mark.parametrize("tag,allow_edge", CASES[:2])
-def test_f32x6_math_mode_end_to_end(gpu_model, golden_dir, oracle_runs, tag, allow_edge):
+def test_other_math_modes_end_to_end(gpu_model, golden_dir, oracle_runs, tag, allow_edge, mode):
     g, img = load_case(golden_dir, tag)
-    assert gpu_model.math_mode == "f32"
-    gpu_model.math_mode = "f32x6"
+    assert gpu_model.math_mode == "f32_winograd"
+    gpu_model.math_mode = mode
     try:
         fm = gpu_model._stage1_feature_extractor(image_data=img.cuda()).cpu()
         ref = oracle_runs[tag][3]["feature_map"]
         err = float((fm - ref).abs().max()) / float(ref.abs().max())
-        print("f32x6 feature map %s: max rel err %.3g" % (tag, err))
+        print("%s feature map %s: max rel err %.3g" % (mode, tag, err))
         assert err <= 2e-5
         props, classes, deltas = gpu_model(image_data=img.cuda())
         j, e = match_rows(props.cpu().numpy(), g["proposals"])
         ok = e <= 1e-3
-        print("f32x6 forward %s: %.1f%% of the reference's proposals within 1e-3 px" % (tag, 100 * ok.mean()))
+        print("%s forward %s: %.1f%% of the reference's proposals within 1e-3 px" % (mode, tag, 100 * ok.mean()))
         assert props.shape[0] == g["proposals"].shape[0] and ok.mean() >= 0.95
         assert np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max() <= 1e-4
         det = gpu_model.predict(image_data=img.cuda(), score_threshold=float(g["score_threshold"]))
@@ -338,10 +340,10 @@ def test_f32x6_math_mode_end_to_end(gpu_model, golden_dir, oracle_runs, tag, all
             if len(r) and len(det[c]):
                 jj, ee = match_rows(det[c], r)
                 n_ok += int(((ee <= 1e-3) & (np.abs(det[c][jj, 4] - r[:, 4]) <= 1e-4)).sum())
-        print("f32x6 predict %s: %d/%d reference detections reproduced" % (tag, n_ok, len(refd)))
+        print("%s predict %s: %d/%d reference detections reproduced" % (mode, tag, n_ok, len(refd)))
         assert n_ok >= 0.95 * len(refd)
     finally:
-        gpu_model.math_mode = "f32"
+        gpu_model.math_mode = "f32_winograd"
     with pytest.raises(ValueError):
         gpu_model.math_mode = "bf16"
 
