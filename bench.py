@@ -46,7 +46,8 @@ _MFMA_CONVS = [(64, 64, 600, 1000), (64, 128, 300, 500), (128, 128, 300, 500), (
                (512, 512, 37, 62)]   # last = RPN trunk (models/rpn.py:88)
 
 
-WINOGRAD_MIN_CIN = 256           # fasterrcnn_amd/_native.py WINOGRAD_MIN_CIN
+def uses_winograd(cin, cout):       # fasterrcnn_amd/_native.py uses_winograd
+    return cin >= 128 and cout >= 256
 
 
 def conv_mfma_flops_per_image():
@@ -55,11 +56,11 @@ def conv_mfma_flops_per_image():
 
 def direct_layers(math):
     """The 3x3 layers that run on conv3x3_mfma_kernel in this math mode."""
-    return [l for l in _MFMA_CONVS if not (math == "f32_winograd" and l[0] >= WINOGRAD_MIN_CIN)]
+    return [l for l in _MFMA_CONVS if not (math == "f32_winograd" and uses_winograd(l[0], l[1]))]
 
 
 def winograd_layers(math):
-    return [l for l in _MFMA_CONVS if math == "f32_winograd" and l[0] >= WINOGRAD_MIN_CIN]
+    return [l for l in _MFMA_CONVS if math == "f32_winograd" and uses_winograd(l[0], l[1])]
 
 
 def winograd_gemm_flops(ci, co, h, w):

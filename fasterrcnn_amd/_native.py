@@ -34,7 +34,7 @@ SYMBOLS = (
     "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv7x7_s2_c3",
     "frcnn_maxpool3x3_s2_nhwc", "frcnn_spatial_mean_nhwc", "frcnn_resnet_forward", "frcnn_rpn_targets",
     "frcnn_pack_conv3x3_x6", "frcnn_conv3x3_nhwc_x6", "frcnn_preprocess_workspace_bytes", "frcnn_preprocess",
-    "frcnn_winograd_min_cin", "frcnn_pack_conv3x3_winograd", "frcnn_conv3x3_winograd_workspace_bytes",
+    "frcnn_conv3x3_uses_winograd", "frcnn_pack_conv3x3_winograd", "frcnn_conv3x3_winograd_workspace_bytes",
     "frcnn_conv3x3_nhwc_winograd",
     # training path
     "frcnn_label_proposals", "frcnn_gather_rows", "frcnn_rpn_loss", "frcnn_detector_loss",
@@ -90,9 +90,13 @@ class ForwardParams(C.Structure):
 
 MATH_F32 = 0      # exact f32 MFMA
 MATH_F32X6 = 1    # bf16x3 split operands, six bf16 MFMAs per product, f32 accumulate
-MATH_F32_WINOGRAD = 2   # exact f32 MFMA; 3x3 layers with cin >= WINOGRAD_MIN_CIN as Winograd F(2x2,3x3) in float32
+MATH_F32_WINOGRAD = 2   # exact f32 MFMA; 3x3 layers with uses_winograd(cin, cout) as Winograd F(2x2,3x3) in float32
 MATH_MODES = {"f32": MATH_F32, "f32x6": MATH_F32X6, "f32_winograd": MATH_F32_WINOGRAD}
-WINOGRAD_MIN_CIN = 256  # == frcnn_winograd_min_cin() (tests/test_abi.py)
+
+
+def uses_winograd(cin, cout):
+    """== frcnn_conv3x3_uses_winograd(cin, cout) (tests/test_abi.py): the 3x3 layers the f32_winograd mode transforms."""
+    return cin >= 128 and cout >= 256 and cin % 16 == 0 and cout % 128 == 0
 
 
 _lib = None
@@ -115,7 +119,7 @@ _SIGNATURES = {
     "frcnn_maxpool2x2_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "frcnn_pack_conv3x3_x6": (C.c_int, [_vp, _vp, _i, _i, _vp]),
     "frcnn_conv3x3_nhwc_x6": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
-    "frcnn_winograd_min_cin": (C.c_int, []),
+    "frcnn_conv3x3_uses_winograd": (C.c_int, [_i, _i]),
     "frcnn_pack_conv3x3_winograd": (C.c_int, [_vp, _vp, _i, _i, _vp]),
     "frcnn_conv3x3_winograd_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "frcnn_conv3x3_nhwc_winograd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),

@@ -199,7 +199,7 @@ int frcnn_conv3x3_nhwc_x6(const float* d_x, const void* d_wq, const float* d_bia
     return launch_conv3x3_x6(d_x, d_wq, d_bias, d_y, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
 }
 
-int frcnn_winograd_min_cin(void) { return WINOGRAD_MIN_CIN; }
+int frcnn_conv3x3_uses_winograd(int cin, int cout) { return conv3x3_uses_winograd(cin, cout) ? 1 : 0; }
 
 int frcnn_pack_conv3x3_winograd(const float* d_w, float* d_u, int cout, int cin, void* stream)
 {
@@ -626,7 +626,7 @@ int ensure_wino_ws(frcnn_ctx* c)
 {
     if (c->wino_ws) return FRCNN_OK;
     size_t need = 0;
-    const int shapes[4][3] = {{4, 256, 256}, {8, 256, 512}, {8, 512, 512}, {16, 512, 512}};
+    const int shapes[5][3] = {{4, 128, 256}, {4, 256, 256}, {8, 256, 512}, {8, 512, 512}, {16, 512, 512}};
     for (auto& sh : shapes) {
         const size_t b = conv3x3_winograd_workspace_bytes(c->max_h / sh[0], c->max_w / sh[0], sh[1], sh[2]);
         if (b > need) need = b;
@@ -670,7 +670,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     if (wino) { rc = ensure_wino_ws(c); if (rc) return rc; }
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
-        if (wino && ci >= WINOGRAD_MIN_CIN) {
+        if (wino && conv3x3_uses_winograd(ci, co)) {
             float *V = nullptr, *M = nullptr;
             int r = winograd_plan(hh, ww, ci, co, fl, c->wino_ws, c->wino_ws_bytes, &V, &M);
             if (r) return r;

@@ -27,8 +27,8 @@ inline int check_launch() {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// 3x3 layers with at least this many input channels run as Winograd F(2x2,3x3) in math mode FRCNN_MATH_F32_WINOGRAD
-static constexpr int WINOGRAD_MIN_CIN = 256;
+// 3x3 layers that run as Winograd F(2x2,3x3) in math mode FRCNN_MATH_F32_WINOGRAD (VGG-16: conv3_1 ... conv5_3 and the RPN trunk)
+static inline bool conv3x3_uses_winograd(int cin, int cout) { return cin >= 128 && cout >= 256 && cin % 16 == 0 && cout % 128 == 0; }
 
 // Per-kernel-class event timer (see frcnn_ctx_timing_* in the header).
 struct KernelTimer;

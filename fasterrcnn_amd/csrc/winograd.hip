@@ -1,5 +1,5 @@
 // winograd.hip -- 3x3 stride-1 "same" convolution as Winograd F(2x2,3x3) in float32, for the wide layers
-// (cin >= FRCNN_WINOGRAD_MIN_CIN) of models/vgg16.py:36-47 and the RPN trunk models/rpn.py:39,88.
+// (cin >= 128, cout >= 256: conv3x3_uses_winograd, common.h) of models/vgg16.py:36-47 and the RPN trunk models/rpn.py:39,88.
 //
 //   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
 //

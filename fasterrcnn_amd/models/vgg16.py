@@ -25,12 +25,12 @@ def pack_conv3x3(conv, math_mode="f32"):
     """
     OIHW weight of a 3x3 nn.Conv2d -> tap-major [9][cout][cin] (or [27][cout] when cin == 3); in the
     "f32x6" math mode -> the exactly split [9][cout][cin/16][hi,mid,lo][16] bf16 layout; in the
-    "f32_winograd" mode, for cin >= 256 -> the transformed filters G g G^T as [16][cout][cin].
+    "f32_winograd" mode, for cin >= 128 and cout >= 256 -> the transformed filters G g G^T as [16][cout][cin].
     """
     w = conv.weight.detach()
     cout, cin = int(w.shape[0]), int(w.shape[1])
     w = rt.as_f32_cuda(w, "conv weight")
-    if math_mode == "f32_winograd" and cin >= nv.WINOGRAD_MIN_CIN:
+    if math_mode == "f32_winograd" and nv.uses_winograd(cin, cout):
         out = t.empty((16, cout, cin), dtype=t.float32, device=w.device)
         with t.cuda.device(w.device):
             nv.check(nv.lib().frcnn_pack_conv3x3_winograd(nv.ptr(w), nv.ptr(out), cout, cin, nv.stream_ptr()),

@@ -141,9 +141,10 @@ int frcnn_conv3x3_nhwc_x6(const float* d_x, const void* d_w_split, const float* 
  *   d_u    : float32 [16][cout][cin] from frcnn_pack_conv3x3_winograd (OIHW weights in)
  *   d_ws   : scratch of frcnn_conv3x3_winograd_workspace_bytes() = 16*ceil(H/2)*ceil(W/2)*(cin+cout)*4 bytes
  * Requires cin % 16 == 0 and cout % 128 == 0 (FRCNN_EUNSUPPORTED otherwise).  The fused forward uses it in
- * math mode FRCNN_MATH_F32_WINOGRAD for the layers with cin >= frcnn_winograd_min_cin() (= 256: below that the
- * transformed tensors cost more HBM traffic than the matrix pipe saves). */
-int frcnn_winograd_min_cin(void);
+ * math mode FRCNN_MATH_F32_WINOGRAD for the layers where frcnn_conv3x3_uses_winograd(cin, cout) != 0
+ * (cin >= 128 and cout >= 256: for narrower layers the transformed tensors cost more HBM traffic than the
+ * matrix pipe saves -- measured per VGG-16 layer). */
+int frcnn_conv3x3_uses_winograd(int cin, int cout);
 int frcnn_pack_conv3x3_winograd(const float* d_w_oihw, float* d_u, int cout, int cin, void* stream);
 size_t frcnn_conv3x3_winograd_workspace_bytes(int H, int W, int cin, int cout);
 int frcnn_conv3x3_nhwc_winograd(const float* d_x, const float* d_u, const float* d_bias,
@@ -293,8 +294,8 @@ typedef struct frcnn_forward_params {
     int32_t allow_edge_proposals; /* 1   (models/faster_rcnn.py:36)  */
     int32_t math_mode;          /* FRCNN_MATH_F32 (exact f32 MFMA, direct), FRCNN_MATH_F32X6 or FRCNN_MATH_F32_WINOGRAD;
                                    selects how the 3x3 conv weight pointers of the weights struct are interpreted:
-                                   frcnn_pack_conv3x3 / frcnn_pack_conv3x3_x6 / (layers with cin >=
-                                   frcnn_winograd_min_cin()) frcnn_pack_conv3x3_winograd, frcnn_pack_conv3x3 otherwise */
+                                   frcnn_pack_conv3x3 / frcnn_pack_conv3x3_x6 / (layers with
+                                   frcnn_conv3x3_uses_winograd(cin, cout)) frcnn_pack_conv3x3_winograd, frcnn_pack_conv3x3 otherwise */
     int32_t conv_blocks_target; /* split-K granularity of the 3x3 layers: blocks per launch to aim for.  0 = 1280 (best
                                    latency for one image on the chip); ~320 when many images are in flight on separate
                                    streams (other images' kernels fill the tail, longer work units win) */

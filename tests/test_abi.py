@@ -64,3 +64,12 @@ def test_library_load_puts_torchs_hip_runtime_first():
             "assert 'torch' in sys.modules; print('ok')")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_winograd_layer_rule_matches_binding():
+    lib = nv.lib()
+    for cin in (3, 16, 64, 120, 128, 256, 512, 1024):
+        for cout in (64, 128, 200, 256, 512, 1024):
+            assert bool(lib.frcnn_conv3x3_uses_winograd(cin, cout)) == nv.uses_winograd(cin, cout), (cin, cout)
+    # VGG-16: conv3_1 .. conv5_3 and the RPN trunk, not blocks 1-2
+    assert nv.uses_winograd(128, 256) and nv.uses_winograd(512, 512) and not nv.uses_winograd(128, 128) and not nv.uses_winograd(64, 128)
