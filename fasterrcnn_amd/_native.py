@@ -85,7 +85,7 @@ class ResNetWeights(C.Structure):
 class ForwardParams(C.Structure):
     _fields_ = [("pre_nms", C.c_int32), ("post_nms", C.c_int32), ("rpn_nms_threshold", C.c_float),
                 ("min_side", C.c_float), ("allow_edge_proposals", C.c_int32), ("math_mode", C.c_int32),
-                ("conv_blocks_target", C.c_int32)]
+                ("conv_blocks_target", C.c_int32), ("winograd_tile_rows", C.c_int32)]
 
 
 MATH_F32 = 0      # exact f32 MFMA

@@ -639,8 +639,8 @@ int ensure_wino_ws(frcnn_ctx* c)
 }
 
 struct BlocksTargetScope {
-    explicit BlocksTargetScope(int t) { conv3x3_set_blocks_target(t); }
-    ~BlocksTargetScope() { conv3x3_set_blocks_target(0); }
+    explicit BlocksTargetScope(int t, int wino_rows = 0) { conv3x3_set_blocks_target(t); linear_batched_set_tile(wino_rows); }
+    ~BlocksTargetScope() { conv3x3_set_blocks_target(0); linear_batched_set_tile(0); }
 };
 }  // namespace
 
@@ -664,7 +664,8 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32X6 && p->math_mode != FRCNN_MATH_F32_WINOGRAD)
         return FRCNN_EINVAL;
     if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
-    BlocksTargetScope target_scope(p->conv_blocks_target);
+    if (p->winograd_tile_rows != 0 && p->winograd_tile_rows != 64 && p->winograd_tile_rows != 128) return FRCNN_EINVAL;
+    BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows);
     const bool x6 = p->math_mode == FRCNN_MATH_F32X6;
     const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
     if (wino) { rc = ensure_wino_ws(c); if (rc) return rc; }

@@ -78,6 +78,7 @@ int launch_linear(const float* a, int lda, const float* w, const float* bias, fl
                   int M, int N, int K, unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_linear_batched(const float* a, int lda, size_t a_stride, const float* w, size_t w_stride, float* y, int ldy,
                           size_t y_stride, int M, int N, int K, int batches, hipStream_t s);
+void linear_batched_set_tile(int rows);        // 64 | 128: tile rows of the calling thread's next batched launches (0 = default)
 // winograd.hip: F(2x2,3x3) float32 path of the wide 3x3 layers
 size_t conv3x3_winograd_workspace_bytes(int H, int W, int cin, int cout);
 int launch_pack_conv3x3_winograd(const float* w, float* u, int cout, int cin, hipStream_t s);

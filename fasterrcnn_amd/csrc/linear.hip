@@ -391,24 +391,31 @@ static int launch_linear_batched_cfg(const float* a, int lda, const float* w, fl
     return check_launch();
 }
 
-// y_z[m][n] = sum_k a_z[m][k] * w_z[n][k] for z < batches; w_z holds ceil(N/128)*128 rows.
+// y_z[m][n] = sum_k a_z[m][k] * w_z[n][k] for z < batches; w_z holds N rounded up to the tile's columns (128 or 256) rows.
+// Tile of the calling thread's next launches: 64 = 64 x 128 (84 registers, five blocks per CU: lowest latency for one
+// image on the chip: never slower than 128 x 128 on the VGG-16 shapes, 20 % faster where 128-row tiles are few -- the
+// 37 x 62 maps -- or short -- cin = 128), 128 = 128 x 128 (fewer LDS / L2 operand bytes per MFMA: with many images in flight
+// the chip runs at its power limit and the cheaper tile wins, 372 -> 380 img/s).  0 = default (64).
+static thread_local int g_batched_tile = 0;
+void linear_batched_set_tile(int rows) { g_batched_tile = rows; }
+
 int launch_linear_batched(const float* a, int lda, size_t a_stride, const float* w, size_t w_stride, float* y, int ldy,
                           size_t y_stride, int M, int N, int K, int batches, hipStream_t s)
 {
     if (M < 1 || N < 1 || K < 16 || K % 16 != 0 || lda % 4 != 0 || lda < K || ldy < N || batches < 1) return FRCNN_EINVAL;
+    static int env_tile = -1;
+    if (env_tile < 0) { const char* e = getenv("FRCNN_WINO_TILE"); env_tile = e ? atoi(e) : 0; }
+    int tile = env_tile ? env_tile : (g_batched_tile ? g_batched_tile : 64);
+    if ((tile == 1256 || tile == 2256) && N % 256 != 0) tile = 128;
     BatchGeom bg{(long long)a_stride, (long long)w_stride, (long long)y_stride, cdiv(N, 128), cdiv(M, 128), batches};
-    static int nsets = -1, bm64_below = -1;
-    if (nsets < 0) { const char* e = getenv("FRCNN_WINO_NSETS"); nsets = e ? atoi(e) : 1; }
-    if (bm64_below < 0) { const char* e = getenv("FRCNN_WINO_BM64_BELOW"); bm64_below = e ? atoi(e) : 0x7fffffff; }
-    // 64 x 128 tiles (84 registers, five blocks per CU) are never slower than 128 x 128 on the VGG-16 shapes and 20 % faster
-    // where 128-row tiles are few (the 37 x 62 maps: 320) or short (cin = 128: 8 stages); FRCNN_WINO_BM64_BELOW=0 selects
-    // the 128 x 128 variants for experiments
-    if ((long long)bg.nblocks * bg.mblocks * batches < bm64_below) {
-        bg.mblocks = cdiv(M, 64);
-        return launch_linear_batched_cfg<1, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
+    switch (tile) {
+        case 64:   bg.mblocks = cdiv(M, 64);  return launch_linear_batched_cfg<1, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
+        case 256:  bg.mblocks = cdiv(M, 256); return launch_linear_batched_cfg<4, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);   // experiments
+        case 2568: bg.mblocks = cdiv(M, 256); return launch_linear_batched_cfg<2, 2, 4, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
+        case 1256: bg.nblocks = cdiv(N, 256); return launch_linear_batched_cfg<2, 4, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
+        case 1282: return launch_linear_batched_cfg<2, 2, 2, 2, 2>(a, lda, w, y, ldy, M, N, K, bg, s);
+        default:   return launch_linear_batched_cfg<2, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
     }
-    return nsets == 2 ? launch_linear_batched_cfg<2, 2, 2, 2, 2>(a, lda, w, y, ldy, M, N, K, bg, s)
-                      : launch_linear_batched_cfg<2, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
 }
 
 int launch_linear(const float* a, int lda, const float* w, const float* bias, float* y, int ldy,

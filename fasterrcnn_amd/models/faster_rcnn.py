@@ -99,6 +99,7 @@ class FasterRCNNModel(nn.Module):
         self.rpn_min_side = 16.0
         self.detector_nms_threshold = 0.3
         self.inflight_conv_blocks_target = 320      # frcnn_forward_params.conv_blocks_target used by predict_async slots
+        self.inflight_winograd_tile_rows = 128      # frcnn_forward_params.winograd_tile_rows used by predict_async slots
 
         # arithmetic of the 3x3 convolutions: "f32" = exact f32 MFMA, direct; "f32_winograd" = exact f32 MFMA with the
         # >= 256-channel layers as Winograd F(2x2,3x3) in float32 (2.25x fewer multiplies, fp32 rounding differences
@@ -220,7 +221,8 @@ class FasterRCNNModel(nn.Module):
                                   1 if self._allow_edge_proposals else 0, nv.MATH_MODES[self._math_mode],
                                   # slot 0 = one image at a time (latency); slots > 0 = many images in flight on their own
                                   # streams, where longer split-K work units give more throughput (csrc/conv.hip)
-                                  0 if slot_index == 0 else self.inflight_conv_blocks_target)
+                                  0 if slot_index == 0 else self.inflight_conv_blocks_target,
+                                  0 if slot_index == 0 else self.inflight_winograd_tile_rows)
         lib = nv.lib()
         with t.cuda.device(device):
             stream = slot.use_stream()

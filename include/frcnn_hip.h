@@ -299,6 +299,9 @@ typedef struct frcnn_forward_params {
     int32_t conv_blocks_target; /* split-K granularity of the 3x3 layers: blocks per launch to aim for.  0 = 1280 (best
                                    latency for one image on the chip); ~320 when many images are in flight on separate
                                    streams (other images' kernels fill the tail, longer work units win) */
+    int32_t winograd_tile_rows; /* FRCNN_MATH_F32_WINOGRAD: row count of the batched GEMM's block tile.  0 = 64 (64 x 128 tiles, five
+                                   blocks per CU: best latency for one image on the chip); 128 with many images in flight (the chip
+                                   is then at its power limit and the tile with fewer operand bytes per MFMA wins) */
 } frcnn_forward_params;
 #define FRCNN_MATH_F32   0
 #define FRCNN_MATH_F32X6 1
