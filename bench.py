@@ -84,8 +84,8 @@ def total_flops_per_image(n_rois=300):
     return conv1_1 + conv_mfma_flops_per_image() + rpn_heads + det
 
 
-def measured_traffic():
-    """HBM bytes per conv3x3 MFMA launch from the newest committed PMC passes (profiles/rNN/traffic.json:
+def measured_traffic(family="conv3x3_mfma_kernel"):
+    """HBM bytes per launch of a kernel family from the newest committed PMC passes (profiles/rNN/traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs, FETCH_SIZE doubled per the gfx950
     note in MI355X_MICROARCH.md).  bench.py cannot run rocprofv3 on itself, so this is the recorded value."""
     import glob
@@ -93,7 +93,10 @@ def measured_traffic():
     if not files:
         return None
     try:
-        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+        rec = json.load(open(files[-1]))
+        if "by_kernel" in rec:
+            return float(rec["by_kernel"][family]["hbm_bytes_per_launch"])
+        return float(rec["hbm_bytes_per_launch"]) if family == "conv3x3_mfma_kernel" else None
     except Exception:
         return None
 
@@ -297,6 +300,8 @@ def main():
                                "winograd_gemm", [winograd_gemm_flops(*l) for l in wl],
                                "FLOP = the FLOP the GEMMs execute (16 x tiles x cin x cout x 2), NOT the 2.25x larger "
                                "direct-convolution FLOP they replace") if wl else None
+        if r_wino is not None:
+            r_wino["traffic"] = measured_traffic("winograd_gemm")
         # `roofline` = the kernel with the most GPU time per image, the other one rides along
         both = [r for r in (r_direct, r_wino) if r is not None]
         both.sort(key=lambda r: -r["ms_per_image"])

@@ -7,11 +7,11 @@ TAG=${1:-r01}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 60 --warmup 10 --no-cpu-baseline"
+B="python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-secondary"
 timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench exit $?"
 tail -c 2500 $OUT/bench_default.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/trace.log 2>&1; echo "trace exit $?"
-P="python bench.py --steps 12 --warmup 4 --ramp-seconds 0 --no-cpu-baseline --inflight 1 --roofline-images 2 --map-images 0"
+P="python bench.py --steps 12 --warmup 4 --ramp-seconds 0 --no-cpu-baseline --no-secondary --inflight 1 --roofline-images 2 --map-images 0"
 # single-stream kernel durations (what bench.py's roofline block times with HIP events): kernel trace + stats, no counters
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_single -o t -- python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-secondary --inflight 1 --roofline-images 10 --map-images 0 > $OUT/trace_single.log 2>&1; echo "single-stream trace exit $?"
 rm -f $OUT/trace_single/t_kernel_trace.csv

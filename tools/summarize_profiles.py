@@ -26,7 +26,7 @@ def main(d):
             print("## bench.py (default flags)\n\n```json\n%s\n```\n" % lines[-1])
     stats = load(os.path.join(d, "trace", "*kernel_stats.csv"))
     if stats:
-        print("## kernel trace + stats (bench.py --steps 60 --warmup 10 --no-cpu-baseline, default images in flight)\n")
+        print("## kernel trace + stats (bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-secondary, default images in flight)\n")
         print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
         for r in stats[:24]:
             print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
@@ -47,7 +47,14 @@ def main(d):
             if "conv3x3_mfma_kernel" in r["Name"]:
                 tot_ns += float(r["TotalDurationNs"]); tot_calls += int(r["Calls"])
         if tot_calls:
-            print("\nconv3x3_mfma_kernel, all instantiations: %d launches, mean %.1f us\n" % (tot_calls, tot_ns / tot_calls / 1e3))
+            print("\nconv3x3_mfma_kernel, all instantiations: %d launches, mean %.1f us" % (tot_calls, tot_ns / tot_calls / 1e3))
+        g_ns, g_calls = 0.0, 0
+        for r in sstats:
+            if "linear_mfma_kernel" in r["Name"] and "true" in r["Name"]:
+                g_ns += float(r["TotalDurationNs"]); g_calls += int(r["Calls"])
+        if g_calls:
+            print("batched Winograd GEMM (linear_mfma_kernel<..., true, 1>), all tiles: %d launches, mean %.1f us" % (g_calls, g_ns / g_calls / 1e3))
+        print()
     tb = os.path.join(d, "train_bench.json")
     if os.path.exists(tb):
         lines = [l for l in open(tb).read().splitlines() if l.startswith("{")]
@@ -83,7 +90,7 @@ def main(d):
         cnt = collections.defaultdict(set)
         for r in rows:
             k = short(r["Kernel_Name"])
-            if not any(x in k for x in ("conv3x3", "linear_mfma", "roi_pool", "topk", "nms_", "detections", "splitk", "conv_splitk")):
+            if not any(x in k for x in ("conv3x3", "linear_mfma", "wino_", "roi_pool", "topk", "nms_", "detections", "splitk", "conv_splitk")):
                 continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k].add(r["Dispatch_Id"])
@@ -111,25 +118,40 @@ def main(d):
 
 def traffic(d):
     """
-    HBM bytes per conv3x3_mfma launch from the separate FETCH_SIZE / WRITE_SIZE passes (KiB per dispatch), with the
-    gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE reports half of the bytes of
-    wide coalesced reads -> doubled; WRITE_SIZE taken as is.  Written to <dir>/traffic.json (bench.py reads the copy
-    committed under profiles/rNN/).
+    HBM bytes per launch from the separate FETCH_SIZE / WRITE_SIZE passes (KiB per dispatch), with the gfx950 correction of
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE reports half of the bytes of wide coalesced reads ->
+    doubled; WRITE_SIZE taken as is.  Written to <dir>/traffic.json (bench.py reads the copy committed under profiles/rNN/):
+    `hbm_bytes_per_launch` = conv3x3_mfma_kernel (all instantiations), `by_kernel` = the same figure per kernel family.
     """
     import json
-    out = {}
+    families = (("conv3x3_mfma_kernel", lambda n: "conv3x3_mfma" in n),
+                ("winograd_gemm", lambda n: "linear_mfma_kernel" in n and "true" in n.split("(")[0]),
+                ("wino_input_kernel", lambda n: "wino_input" in n), ("wino_output_kernel", lambda n: "wino_output" in n),
+                ("linear_mfma_kernel", lambda n: "linear_mfma_kernel" in n and "true" not in n.split("(")[0]))
+    raw = {}
     for tag, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        rows = [r for r in load(os.path.join(d, tag, "*counter_collection.csv"))
-                if "conv3x3_mfma" in r["Kernel_Name"] and r["Counter_Name"] == name]
-        if not rows:
-            return
-        disp = {r["Dispatch_Id"] for r in rows}
-        out[name] = (sum(float(r["Counter_Value"]) for r in rows) / len(disp), len(disp))
-    f, w = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
+        raw[name] = [r for r in load(os.path.join(d, tag, "*counter_collection.csv")) if r["Counter_Name"] == name]
+    if not raw["FETCH_SIZE"] or not raw["WRITE_SIZE"]:
+        return
+    by = {}
+    for fam, pred in families:
+        vals = {}
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            rows = [r for r in raw[name] if pred(r["Kernel_Name"])]
+            disp = {r["Dispatch_Id"] for r in rows}
+            vals[name] = (sum(float(r["Counter_Value"]) for r in rows) / max(len(disp), 1), len(disp))
+        if vals["FETCH_SIZE"][1] == 0:
+            continue
+        f, w = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+        by[fam] = {"launches": vals["FETCH_SIZE"][1], "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
+                   "hbm_bytes_per_launch": f * 1024 * 2.0 + w * 1024}
+    if "conv3x3_mfma_kernel" not in by:
+        return
+    c = by["conv3x3_mfma_kernel"]
     rec = {"source": "%s (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, single stream)" % d,
-           "kernel": "conv3x3_mfma_kernel (all instantiations)", "launches": out["FETCH_SIZE"][1],
-           "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w, "fetch_correction": 2.0,
-           "hbm_bytes_per_launch": f * 1024 * 2.0 + w * 1024}
+           "kernel": "conv3x3_mfma_kernel (all instantiations)", "launches": c["launches"],
+           "FETCH_SIZE_KiB_per_launch": c["FETCH_SIZE_KiB_per_launch"], "WRITE_SIZE_KiB_per_launch": c["WRITE_SIZE_KiB_per_launch"],
+           "fetch_correction": 2.0, "hbm_bytes_per_launch": c["hbm_bytes_per_launch"], "by_kernel": by}
     json.dump(rec, open(os.path.join(d, "traffic.json"), "w"), indent=1)
 
 
