@@ -200,23 +200,24 @@ int frcnn_conv3x3_nhwc_x6(const float* d_x, const void* d_wq, const float* d_bia
 }
 
 int frcnn_conv3x3_uses_winograd(int cin, int cout) { return conv3x3_uses_winograd(cin, cout) ? 1 : 0; }
+int frcnn_resnet_block_uses_winograd(int width, int stride) { return resnet_block_uses_winograd(width, stride) ? 1 : 0; }
 
-int frcnn_pack_conv3x3_winograd(const float* d_w, float* d_u, int cout, int cin, void* stream)
+int frcnn_pack_conv3x3_winograd(const float* d_w, const float* d_row_scale, float* d_u, int cout, int cin, void* stream)
 {
     if (!d_w || !d_u) return FRCNN_EINVAL;
-    return launch_pack_conv3x3_winograd(d_w, d_u, cout, cin, as_stream(stream));
+    return launch_pack_conv3x3_winograd(d_w, d_row_scale, d_u, cout, cin, as_stream(stream));
 }
 
-size_t frcnn_conv3x3_winograd_workspace_bytes(int H, int W, int cin, int cout)
+size_t frcnn_conv3x3_winograd_workspace_bytes(int n_maps, int H, int W, int cin, int cout)
 {
-    return conv3x3_winograd_workspace_bytes(H, W, cin, cout);
+    return conv3x3_winograd_workspace_bytes(n_maps, H, W, cin, cout);
 }
 
-int frcnn_conv3x3_nhwc_winograd(const float* d_x, const float* d_u, const float* d_bias, float* d_y, int H, int W,
+int frcnn_conv3x3_nhwc_winograd(const float* d_x, const float* d_u, const float* d_bias, float* d_y, int n_maps, int H, int W,
                                 int cin, int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
 {
-    if (!d_x || !d_u || !d_bias || !d_y || H < 1 || W < 1) return FRCNN_EINVAL;
-    return launch_conv3x3_winograd(d_x, d_u, d_bias, d_y, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
+    if (!d_x || !d_u || !d_bias || !d_y || n_maps < 1 || H < 1 || W < 1) return FRCNN_EINVAL;
+    return launch_conv3x3_winograd(d_x, d_u, d_bias, d_y, n_maps, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
 }
 
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream)
@@ -620,22 +621,43 @@ int frcnn_ctx_tensor(frcnn_ctx* c, int which, void** d_ptr, size_t* bytes)
 }
 
 namespace {
-// Winograd scratch for every eligible VGG-16 layer shape up to the ctx's largest image (allocated once, on first use:
-// contexts that never run the mode do not pay the 16*T*(cin+cout) floats).
+// Winograd scratch (V and M of the largest eligible layer up to the ctx's largest image), allocated once, on first use:
+// contexts that never run the mode do not pay the 16*T*(cin+cout) floats.
 int ensure_wino_ws(frcnn_ctx* c)
 {
     if (c->wino_ws) return FRCNN_OK;
     size_t need = 0;
+    // VGG-16 layer shapes (image / 4, / 8, / 16)
     const int shapes[5][3] = {{4, 128, 256}, {4, 256, 256}, {8, 256, 512}, {8, 512, 512}, {16, 512, 512}};
     for (auto& sh : shapes) {
-        const size_t b = conv3x3_winograd_workspace_bytes(c->max_h / sh[0], c->max_w / sh[0], sh[1], sh[2]);
+        const size_t b = conv3x3_winograd_workspace_bytes(1, c->max_h / sh[0], c->max_w / sh[0], sh[1], sh[2]);
         if (b > need) need = b;
     }
+    // ResNet: the RPN trunk on the 1024-channel map, layer4's 512-wide 3x3 on max_rois 4x4 maps
+    const size_t b1 = conv3x3_winograd_workspace_bytes(1, c->max_fh, c->max_fw, 1024, 1024);
+    const size_t b2 = conv3x3_winograd_workspace_bytes(c->max_rois, 4, 4, 512, 512);
+    if (b1 > need) need = b1;
+    if (b2 > need) need = b2;
     if (need == 0) return FRCNN_EINVAL;
     hipError_t e = hipMalloc(&c->wino_ws, need);
     if (e != hipSuccess) { set_hip_error(e); c->wino_ws = nullptr; return FRCNN_ENOMEM; }
     c->wino_ws_bytes = need;
     return FRCNN_OK;
+}
+
+// One Winograd layer inside a fused forward, its three launches timed as classes 6 (transforms) and 7 (GEMM).
+int run_winograd_layer(frcnn_ctx* c, const float* x, const float* u, const float* b, float* y, int N, int h, int w, int ci, int co,
+                       unsigned flags, hipStream_t s)
+{
+    float *V = nullptr, *M = nullptr;
+    int r = winograd_plan(N, h, w, ci, co, flags, c->wino_ws, c->wino_ws_bytes, &V, &M);
+    if (r) return r;
+    { Scope _t(c, 6, s); r = launch_winograd_input(x, V, N, h, w, ci, s); }
+    if (r) return r;
+    { Scope _g(c, 7, s); r = launch_winograd_gemm(V, u, M, N, h, w, ci, co, s); }
+    if (r) return r;
+    Scope _o(c, 6, s);
+    return launch_winograd_output(M, b, y, N, h, w, co, flags, s);
 }
 
 struct BlocksTargetScope {
@@ -671,17 +693,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     if (wino) { rc = ensure_wino_ws(c); if (rc) return rc; }
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
-        if (wino && conv3x3_uses_winograd(ci, co)) {
-            float *V = nullptr, *M = nullptr;
-            int r = winograd_plan(hh, ww, ci, co, fl, c->wino_ws, c->wino_ws_bytes, &V, &M);
-            if (r) return r;
-            { Scope _t(c, 6, s); r = launch_winograd_input(xin, V, hh, ww, ci, s); }
-            if (r) return r;
-            { Scope _g(c, 7, s); r = launch_winograd_gemm(V, wgt, M, hh, ww, ci, co, s); }
-            if (r) return r;
-            Scope _o(c, 6, s);
-            return launch_winograd_output(M, bs, yout, hh, ww, co, fl, s);
-        }
+        if (wino && conv3x3_uses_winograd(ci, co)) return run_winograd_layer(c, xin, wgt, bs, yout, 1, hh, ww, ci, co, fl, s);
         Scope _d(c, 0, s);
         return x6 ? launch_conv3x3_x6(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s)
                   : launch_conv3x3_nhwc(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s);
@@ -747,7 +759,7 @@ namespace {
 // One Bottleneck (torchvision v1.5): out = relu(conv3(relu(conv2(relu(conv1(x))))) + identity).
 // x: [N][h][w][cin] in `cur`; returns the buffer index holding the output, updates h, w.
 int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& h, int& w, int cur,
-                   int* out_idx, hipStream_t s, int cls_conv)
+                   int* out_idx, hipStream_t s, int cls_conv, bool wino)
 {
     // pick three scratch buffers different from `cur`
     int f[4], k = 0;
@@ -764,7 +776,10 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
     if (need1 > c->res_buf_floats || need2 > c->res_buf_floats) return FRCNN_EINVAL;
 #define RSTEP(call) do { Scope _sc(c, cls_conv, s); rc = (call); } while (0); if (rc) return rc
     RSTEP(launch_conv_gather(X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s));
-    if (b.stride == 1 && N == 1 && b.width % 64 == 0) {
+    if (wino && resnet_block_uses_winograd(b.width, b.stride)) {
+        rc = run_winograd_layer(c, T1, b.w2, b.b2, T2, N, h, w, b.width, b.width, R, s);
+        if (rc) return rc;
+    } else if (b.stride == 1 && N == 1 && b.width % 64 == 0) {
         RSTEP(launch_conv3x3_nhwc(T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, c->conv_ws, c->conv_ws_bytes, s));
     } else {
         RSTEP(launch_conv_gather(T1, b.w2, b.b2, nullptr, T2, N, h, w, b.width, b.width, 3, b.stride, 1, R,
@@ -796,7 +811,8 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     if (H < 32 || W < 32 || H > c->max_h || W > c->max_w) return FRCNN_EINVAL;
     if (p->post_nms < 1 || p->post_nms > c->max_rois || p->pre_nms < 1 || p->pre_nms > c->pre_cap) return FRCNN_EINVAL;
     if (w->num_classes < 2 || w->num_classes > 26) return FRCNN_EUNSUPPORTED;
-    if (p->math_mode != FRCNN_MATH_F32) return FRCNN_EUNSUPPORTED;     // the ResNet path is exact-f32 only for now
+    if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32_WINOGRAD) return FRCNN_EUNSUPPORTED;   // no f32x6 ResNet path
+    const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
     int nb = 0;
     for (int i = 0; i < 4; ++i) { if (w->n_blocks[i] < 1) return FRCNN_EINVAL; nb += w->n_blocks[i]; }
     if (nb > FRCNN_RESNET_MAX_BLOCKS) return FRCNN_EINVAL;
@@ -811,7 +827,9 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     hipStream_t s = as_stream(stream);
     int rc;
     if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
-    BlocksTargetScope target_scope(p->conv_blocks_target);
+    if (p->winograd_tile_rows != 0 && p->winograd_tile_rows != 64 && p->winograd_tile_rows != 128) return FRCNN_EINVAL;
+    BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows);
+    if (wino) { rc = ensure_wino_ws(c); if (rc) return rc; }
 #define STEP(cls, call) do { Scope _sc(c, cls, s); rc = (call); } while (0); if (rc) return rc
 
     // stage 1: conv1/bn1/relu/maxpool/layer1..3 (models/resnet.py:38-46)
@@ -824,7 +842,7 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     for (int layer = 0; layer < 3; ++layer)
         for (int k = 0; k < w->n_blocks[layer]; ++k, ++bi) {
             int out = -1;
-            rc = run_bottleneck(c, w->blocks[bi], 1, h, wd, cur, &out, s, 0);
+            rc = run_bottleneck(c, w->blocks[bi], 1, h, wd, cur, &out, s, 0, wino);
             if (rc) return rc;
             cur = out;
         }
@@ -835,8 +853,13 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms; c->last_c = C;
 
     // stage 2: RPN (models/rpn.py:88-153)
-    STEP(0, launch_conv3x3_nhwc(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU,
-                                c->conv_ws, c->conv_ws_bytes, s));
+    if (wino && conv3x3_uses_winograd(C, C)) {
+        rc = run_winograd_layer(c, c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, 1, fh, fw, C, C, FRCNN_RELU, s);
+        if (rc) return rc;
+    } else {
+        STEP(0, launch_conv3x3_nhwc(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU,
+                                    c->conv_ws, c->conv_ws_bytes, s));
+    }
     STEP(2, launch_linear(c->rpn_trunk, C, w->rpn_head_w, w->rpn_head_b, c->rpn_head, 128, fh * fw, 45, C, 0u,
                           c->lin_ws, c->lin_ws_bytes, s));
     const float* amap = d_anchor_map;
@@ -863,7 +886,7 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     cur = 0; h = 7; wd = 7;
     for (int k = 0; k < w->n_blocks[3]; ++k, ++bi) {
         int out = -1;
-        rc = run_bottleneck(c, w->blocks[bi], R_, h, wd, cur, &out, s, 2);
+        rc = run_bottleneck(c, w->blocks[bi], R_, h, wd, cur, &out, s, 2, wino);
         if (rc) { c->res_buf[0] = saved; return rc; }
         cur = out;
     }

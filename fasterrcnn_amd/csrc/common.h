@@ -29,6 +29,9 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // 3x3 layers that run as Winograd F(2x2,3x3) in math mode FRCNN_MATH_F32_WINOGRAD (VGG-16: conv3_1 ... conv5_3 and the RPN trunk)
 static inline bool conv3x3_uses_winograd(int cin, int cout) { return cin >= 128 && cout >= 256 && cin % 16 == 0 && cout % 128 == 0; }
+// ResNet bottlenecks (3x3 width -> width): only the stride-1 blocks of layer4 (width 512, 300 RoIs x 4x4 maps); the 256-wide
+// 38 x 63 layers of layer3 are 2.8 GFLOP each and do not pay for two extra launches
+static inline bool resnet_block_uses_winograd(int width, int stride) { return stride == 1 && width >= 512 && width % 128 == 0; }
 
 // Per-kernel-class event timer (see frcnn_ctx_timing_* in the header).
 struct KernelTimer;
@@ -80,14 +83,14 @@ int launch_linear_batched(const float* a, int lda, size_t a_stride, const float*
                           size_t y_stride, int M, int N, int K, int batches, hipStream_t s);
 void linear_batched_set_tile(int rows);        // 64 | 128: tile rows of the calling thread's next batched launches (0 = default)
 // winograd.hip: F(2x2,3x3) float32 path of the wide 3x3 layers
-size_t conv3x3_winograd_workspace_bytes(int H, int W, int cin, int cout);
-int launch_pack_conv3x3_winograd(const float* w, float* u, int cout, int cin, hipStream_t s);
-int launch_conv3x3_winograd(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
+size_t conv3x3_winograd_workspace_bytes(int N, int H, int W, int cin, int cout);
+int launch_pack_conv3x3_winograd(const float* w, const float* scale, float* u, int cout, int cin, hipStream_t s);
+int launch_conv3x3_winograd(const float* x, const float* u, const float* b, float* y, int N, int H, int W, int cin, int cout,
                             unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
-int winograd_plan(int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, float** V, float** M);
-int launch_winograd_input(const float* x, float* V, int H, int W, int cin, hipStream_t s);
-int launch_winograd_gemm(const float* V, const float* u, float* M, int H, int W, int cin, int cout, hipStream_t s);
-int launch_winograd_output(const float* M, const float* b, float* y, int H, int W, int cout, unsigned flags, hipStream_t s);
+int winograd_plan(int N, int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, float** V, float** M);
+int launch_winograd_input(const float* x, float* V, int N, int H, int W, int cin, hipStream_t s);
+int launch_winograd_gemm(const float* V, const float* u, float* M, int N, int H, int W, int cin, int cout, hipStream_t s);
+int launch_winograd_output(const float* M, const float* b, float* y, int N, int H, int W, int cout, unsigned flags, hipStream_t s);
 int launch_softmax_rows(const float* x, int ldx, float* y, int M, int ncls, hipStream_t s);
 int launch_head_finish(const float* x, int ldx, int M, int ncls, int ndelta, float* classes,
                        float* deltas, hipStream_t s);

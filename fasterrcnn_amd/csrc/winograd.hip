@@ -8,7 +8,8 @@
 // reference's golden vectors the detections are reproduced at the same rate as with the direct kernel
 // (tests/winograd_parity_probe.py is the CPU model of this file, tests/test_winograd_gpu.py the parity test).
 //
-// Three launches per layer, NHWC throughout, T = ceil(H/2) * ceil(W/2) tiles:
+// Three launches per layer, NHWC throughout (optionally a batch of N maps: the per-RoI 4 x 4 maps of ResNet's layer4),
+// T = N * ceil(H/2) * ceil(W/2) tiles:
 //   1. wino_input_kernel   x [H][W][cin]        -> V [16][T][cin]     (B^T d B, zero padding folded in)
 //   2. linear_mfma_kernel  batched over the 16 positions: M_p [T][cout] = V_p [T][cin] . U_p [cout][cin]^T
 //                          (csrc/linear.hip, exact-f32 MFMA, XCD-aware block order)
@@ -21,17 +22,20 @@
 namespace frcnn {
 
 // U[p = 4 i + j][k][c] = (G g G^T)[i][j],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]];  g: OIHW [cout][cin][3][3]
+// `scale` (per cout, may be NULL): the frozen-BatchNorm fold of the ResNet layers -- the filter is first multiplied in float32
+// exactly as fold_bn_pack_kernel does (csrc/conv_gather.hip), so both packs describe the same folded weights.
 __global__ __launch_bounds__(256)
-void wino_pack_kernel(const float* __restrict__ g, float* __restrict__ u, int cout, int cin)
+void wino_pack_kernel(const float* __restrict__ g, const float* __restrict__ scale, float* __restrict__ u, int cout, int cin)
 {
     const size_t total = (size_t)cout * cin;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const float* gp = g + i * 9;
+        const float sc = scale ? scale[i / cin] : 1.0f;
         double w[3][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) w[a][b] = (double)gp[a * 3 + b];
+            for (int b = 0; b < 3; ++b) w[a][b] = (double)(scale ? gp[a * 3 + b] * sc : gp[a * 3 + b]);
         double r[4][3];                      // G g
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
@@ -55,15 +59,18 @@ void wino_pack_kernel(const float* __restrict__ g, float* __restrict__ u, int co
 }
 
 // One thread = one tile x 4 channels.  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].
+// x: [N][H][W][cin]; tiles are numbered image-major (tpi = th * tw per image), T = N * tpi.
 __global__ __launch_bounds__(256)
-void wino_input_kernel(const float* __restrict__ x, float* __restrict__ v, int H, int W, int cin, int tw, int T)
+void wino_input_kernel(const float* __restrict__ x, float* __restrict__ v, int H, int W, int cin, int tw, int tpi, int T)
 {
     const int c4n = cin >> 2;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)T * c4n) return;
     const int tile = (int)(idx / c4n), c = (int)(idx % c4n) * 4;
-    const int ty = tile / tw, tx = tile % tw;
+    const int img = tile / tpi, tin = tile - img * tpi;
+    const int ty = tin / tw, tx = tin % tw;
     const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+    x += (size_t)img * H * W * cin;
     f32x4 d[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -100,15 +107,17 @@ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ v, int H
 template <bool POOL>
 __global__ __launch_bounds__(256)
 void wino_output_kernel(const float* __restrict__ m, const float* __restrict__ bias, float* __restrict__ y,
-                        int H, int W, int cout, int tw, int T, int relu)
+                        int H, int W, int cout, int tw, int tpi, int T, int relu)
 {
     const int k4n = cout >> 2;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)T * k4n) return;
     const int tile = (int)(idx / k4n), k = (int)(idx % k4n) * 4;
-    const int ty = tile / tw, tx = tile % tw;
+    const int img = tile / tpi, tin = tile - img * tpi;
+    const int ty = tin / tw, tx = tin % tw;
     const int Ho = H >> 1, Wo = W >> 1;
     if (POOL && (ty >= Ho || tx >= Wo)) return;      // floor pooling drops the odd last row / column
+    y += (size_t)img * (POOL ? (size_t)Ho * Wo : (size_t)H * W) * cout;
     const size_t plane = (size_t)T * cout;
     const float* mp = m + (size_t)tile * cout + k;
     f32x4 s[2][4];                           // A^T M
@@ -156,76 +165,76 @@ void wino_output_kernel(const float* __restrict__ m, const float* __restrict__ b
 }
 
 // ---- host side ------------------------------------------------------------------------------
-static inline bool wino_shape_ok(int H, int W, int cin, int cout)
+static inline bool wino_shape_ok(int N, int H, int W, int cin, int cout)
 {
-    return H >= 1 && W >= 1 && cin >= 16 && cin % 16 == 0 && cout >= 128 && cout % 128 == 0 &&
-           (size_t)cdiv(H, 2) * cdiv(W, 2) * 16 * (size_t)(cin > cout ? cin : cout) < ((size_t)1 << 31);
+    return N >= 1 && H >= 1 && W >= 1 && cin >= 16 && cin % 16 == 0 && cout >= 128 && cout % 128 == 0 &&
+           (size_t)N * cdiv(H, 2) * cdiv(W, 2) * 16 * (size_t)(cin > cout ? cin : cout) < ((size_t)1 << 31);
 }
 
-size_t conv3x3_winograd_workspace_bytes(int H, int W, int cin, int cout)
+size_t conv3x3_winograd_workspace_bytes(int N, int H, int W, int cin, int cout)
 {
-    if (!wino_shape_ok(H, W, cin, cout)) return 0;
-    const size_t T = (size_t)cdiv(H, 2) * cdiv(W, 2);
+    if (!wino_shape_ok(N, H, W, cin, cout)) return 0;
+    const size_t T = (size_t)N * cdiv(H, 2) * cdiv(W, 2);
     return 16 * T * ((size_t)cin + cout) * sizeof(float);
 }
 
-int launch_pack_conv3x3_winograd(const float* w, float* u, int cout, int cin, hipStream_t s)
+int launch_pack_conv3x3_winograd(const float* w, const float* scale, float* u, int cout, int cin, hipStream_t s)
 {
     if (cout < 1 || cin < 1) return FRCNN_EINVAL;
     const size_t total = (size_t)cout * cin;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, s, w, u, cout, cin);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, s, w, scale, u, cout, cin);
     return check_launch();
 }
 
 // The three launches of one layer, separately callable so that the fused forward can time them per class.
-int launch_winograd_input(const float* x, float* V, int H, int W, int cin, hipStream_t s)
+int launch_winograd_input(const float* x, float* V, int N, int H, int W, int cin, hipStream_t s)
 {
-    const int tw = cdiv(W, 2), T = cdiv(H, 2) * tw;
+    const int tw = cdiv(W, 2), tpi = cdiv(H, 2) * tw, T = N * tpi;
     const size_t n = (size_t)T * (cin / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, V, H, W, cin, tw, T);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, V, H, W, cin, tw, tpi, T);
     return check_launch();
 }
 
-int launch_winograd_gemm(const float* V, const float* u, float* M, int H, int W, int cin, int cout, hipStream_t s)
+int launch_winograd_gemm(const float* V, const float* u, float* M, int N, int H, int W, int cin, int cout, hipStream_t s)
 {
-    const int T = cdiv(H, 2) * cdiv(W, 2);
+    const int T = N * cdiv(H, 2) * cdiv(W, 2);
     return launch_linear_batched(V, cin, (size_t)T * cin, u, (size_t)cout * cin, M, cout, (size_t)T * cout, T, cout, cin, 16, s);
 }
 
-int launch_winograd_output(const float* M, const float* b, float* y, int H, int W, int cout, unsigned flags, hipStream_t s)
+int launch_winograd_output(const float* M, const float* b, float* y, int N, int H, int W, int cout, unsigned flags, hipStream_t s)
 {
-    const int tw = cdiv(W, 2), T = cdiv(H, 2) * tw;
+    const int tw = cdiv(W, 2), tpi = cdiv(H, 2) * tw, T = N * tpi;
     const size_t n = (size_t)T * (cout / 4);
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
     if (flags & FRCNN_POOL2)
-        hipLaunchKernelGGL(wino_output_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, b, y, H, W, cout, tw, T, relu);
+        hipLaunchKernelGGL(wino_output_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, b, y, H, W, cout, tw, tpi, T, relu);
     else
-        hipLaunchKernelGGL(wino_output_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, b, y, H, W, cout, tw, T, relu);
+        hipLaunchKernelGGL(wino_output_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, b, y, H, W, cout, tw, tpi, T, relu);
     return check_launch();
 }
 
 // Validates shape and scratch; V = ws, M = ws + 16 T cin floats.
-int winograd_plan(int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, float** V, float** M)
+int winograd_plan(int N, int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, float** V, float** M)
 {
-    if (!wino_shape_ok(H, W, cin, cout)) return FRCNN_EUNSUPPORTED;
+    if (!wino_shape_ok(N, H, W, cin, cout)) return FRCNN_EUNSUPPORTED;
     if ((flags & FRCNN_POOL2) && (H < 2 || W < 2)) return FRCNN_EINVAL;
-    if (ws == nullptr || ws_bytes < conv3x3_winograd_workspace_bytes(H, W, cin, cout)) return FRCNN_EINVAL;
+    if (ws == nullptr || ws_bytes < conv3x3_winograd_workspace_bytes(N, H, W, cin, cout)) return FRCNN_EINVAL;
     *V = static_cast<float*>(ws);
-    *M = *V + (size_t)16 * cdiv(H, 2) * cdiv(W, 2) * cin;
+    *M = *V + (size_t)16 * N * cdiv(H, 2) * cdiv(W, 2) * cin;
     return FRCNN_OK;
 }
 
-int launch_conv3x3_winograd(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
+int launch_conv3x3_winograd(const float* x, const float* u, const float* b, float* y, int N, int H, int W, int cin, int cout,
                             unsigned flags, void* ws, size_t ws_bytes, hipStream_t s)
 {
     float *V = nullptr, *M = nullptr;
-    int rc = winograd_plan(H, W, cin, cout, flags, ws, ws_bytes, &V, &M);
+    int rc = winograd_plan(N, H, W, cin, cout, flags, ws, ws_bytes, &V, &M);
     if (rc) return rc;
-    if ((rc = launch_winograd_input(x, V, H, W, cin, s)) != FRCNN_OK) return rc;
-    if ((rc = launch_winograd_gemm(V, u, M, H, W, cin, cout, s)) != FRCNN_OK) return rc;
-    return launch_winograd_output(M, b, y, H, W, cout, flags, s);
+    if ((rc = launch_winograd_input(x, V, N, H, W, cin, s)) != FRCNN_OK) return rc;
+    if ((rc = launch_winograd_gemm(V, u, M, N, H, W, cin, cout, s)) != FRCNN_OK) return rc;
+    return launch_winograd_output(M, b, y, N, H, W, cout, flags, s);
 }
 
 }  // namespace frcnn

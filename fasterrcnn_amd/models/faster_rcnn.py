@@ -105,10 +105,10 @@ class FasterRCNNModel(nn.Module):
         # >= 256-channel layers as Winograd F(2x2,3x3) in float32 (2.25x fewer multiplies, fp32 rounding differences
         # only); "f32x6" = exactly split bf16x3 operands, six bf16 MFMAs per product with f32 accumulation
         # Default: the fastest mode that reproduces the reference's golden vectors at the exact-f32 rate
-        # (tests/test_winograd_gpu.py, tests/test_model_gpu.py); the ResNet path has direct kernels only.
+        # (tests/test_winograd_gpu.py, tests/test_model_gpu.py, tests/test_resnet_gpu.py).  ResNet: the RPN trunk and the
+        # stride-1 3x3 convolutions of layer4 are the Winograd layers; there is no f32x6 ResNet path.
         self._math_mode = "f32"
-        if not self._is_resnet:
-            self.math_mode = "f32_winograd"
+        self.math_mode = "f32_winograd"
 
         self._train_state = None
         self._gradient_sync = None          # training.enable_data_parallel
@@ -125,11 +125,13 @@ class FasterRCNNModel(nn.Module):
     def math_mode(self, mode):
         if mode not in nv.MATH_MODES:
             raise ValueError("math_mode must be one of %s" % sorted(nv.MATH_MODES))
-        if mode != "f32" and self._is_resnet:
-            raise NotImplementedError("the ResNet path runs in the exact-f32 math mode only")
+        if mode == "f32x6" and self._is_resnet:
+            raise NotImplementedError("the ResNet path has no f32x6 kernels (math modes: f32, f32_winograd)")
         self._math_mode = mode
         self._stage1_feature_extractor.math_mode = mode
         self._stage2_region_proposal_network.math_mode = mode
+        if self._is_resnet:
+            self._stage3_detector_network._pool_to_feature_vector.math_mode = mode
 
     # ------------------------------------------------------------------------------------------
     def _device(self):

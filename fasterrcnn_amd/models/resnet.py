@@ -100,10 +100,31 @@ def _bn_params(bn):
     return [bn.weight, bn.bias, bn.running_mean, bn.running_var]
 
 
-def pack_block(block):
+def fold_conv_bn_winograd(conv, bn):
+    """(transformed filter bank [16][cout][cin], bias) of a 3x3 conv followed by frozen BatchNorm: the same float32 fold as
+    frcnn_fold_bn_pack (scale = gamma / sqrt(var + eps) applied to the filter rows, bias = beta - mean * scale), then G g G^T."""
+    w = rt.as_f32_cuda(conv.weight.detach(), "conv weight")
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    args = [rt.as_f32_cuda(x.detach(), "bn tensor") for x in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+    scale = t.empty((cout,), dtype=t.float32, device=w.device)
+    shift = t.empty((cout,), dtype=t.float32, device=w.device)
+    u = t.empty((16, cout, cin), dtype=t.float32, device=w.device)
+    with t.cuda.device(w.device):
+        lib = nv.lib()
+        nv.check(lib.frcnn_bn_scale_shift(nv.ptr(args[0]), nv.ptr(args[1]), nv.ptr(args[2]), nv.ptr(args[3]), float(bn.eps), cout,
+                                          nv.ptr(scale), nv.ptr(shift), nv.stream_ptr()), "frcnn_bn_scale_shift")
+        nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w), nv.ptr(scale), nv.ptr(u), cout, cin, nv.stream_ptr()),
+                 "frcnn_pack_conv3x3_winograd")
+    return u, shift, args + [scale]
+
+
+def pack_block(block, math_mode="f32"):
     """dict of packed tensors + shape info for one Bottleneck."""
     w1, b1, k1 = fold_conv_bn(block.conv1, block.bn1)
-    w2, b2, k2 = fold_conv_bn(block.conv2, block.bn2)
+    if math_mode == "f32_winograd" and nv.resnet_block_uses_winograd(block.conv2.out_channels, block.stride):
+        w2, b2, k2 = fold_conv_bn_winograd(block.conv2, block.bn2)
+    else:
+        w2, b2, k2 = fold_conv_bn(block.conv2, block.bn2)
     w3, b3, k3 = fold_conv_bn(block.conv3, block.bn3)
     out = {"w1": w1, "b1": b1, "w2": w2, "b2": b2, "w3": w3, "b3": b3, "wd": None, "bd": None,
            "cin": block.conv1.in_channels, "width": block.conv1.out_channels, "cout": block.conv3.out_channels,
@@ -138,7 +159,18 @@ def conv_nhwc(x, wp, bp, n, h, w, cin, cout, k, stride, pad, relu, residual=None
 def run_block(x, n, h, w, pb):
     """One Bottleneck on NHWC data through the C ABI (stage-level path; the fused model uses frcnn_resnet_forward)."""
     t1, _, _ = conv_nhwc(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, 1, 0, True)
-    t2, ho, wo = conv_nhwc(t1, pb["w2"], pb["b2"], n, h, w, pb["width"], pb["width"], 3, pb["stride"], 1, True)
+    if pb["w2"].dim() == 3 and int(pb["w2"].shape[0]) == 16:          # Winograd filter bank (f32_winograd mode)
+        width = pb["width"]
+        ho, wo = h, w
+        t2 = t.empty((n, h, w, width), dtype=t.float32, device=x.device)
+        lib = nv.lib()
+        wsb = int(lib.frcnn_conv3x3_winograd_workspace_bytes(n, h, w, width, width))
+        ws = t.empty((max(wsb, 4) // 4,), dtype=t.float32, device=x.device)
+        with t.cuda.device(x.device):
+            nv.check(lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(t1), nv.ptr(pb["w2"]), nv.ptr(pb["b2"]), nv.ptr(t2), n, h, w, width, width,
+                                                     nv.RELU, nv.ptr(ws), wsb, nv.stream_ptr()), "frcnn_conv3x3_nhwc_winograd")
+    else:
+        t2, ho, wo = conv_nhwc(t1, pb["w2"], pb["b2"], n, h, w, pb["width"], pb["width"], 3, pb["stride"], 1, True)
     identity = x
     if pb["wd"] is not None:
         identity, _, _ = conv_nhwc(x, pb["wd"], pb["bd"], n, h, w, pb["cin"], pb["cout"], 1, pb["stride"], 0, False)
@@ -169,6 +201,7 @@ class FeatureExtractor(nn.Module):
                     p.requires_grad = False
         self._packed_key = None
         self._packed = None
+        self.math_mode = "f32"
 
     def blocks(self):
         fe = self._feature_extractor
@@ -178,10 +211,10 @@ class FeatureExtractor(nn.Module):
         """{'stem': (w, b), 'blocks': [dict]} of BN-folded packed weights, rebuilt when parameters change."""
         fe = self._feature_extractor
         params = [fe[0].weight] + _bn_params(fe[1]) + [p for b in self.blocks() for p in block_params(b)]
-        key = rt.param_key(params)
+        key = (self.math_mode,) + rt.param_key(params)
         if key != self._packed_key:
             sw, sb, keep = fold_conv_bn(fe[0], fe[1])
-            self._packed = {"stem": (sw, sb), "keep": keep, "blocks": [pack_block(b) for b in self.blocks()],
+            self._packed = {"stem": (sw, sb), "keep": keep, "blocks": [pack_block(b, self.math_mode) for b in self.blocks()],
                             "n_blocks": [len(fe[4]), len(fe[5]), len(fe[6])]}
             self._packed_key = key
         return self._packed
@@ -217,12 +250,13 @@ class PoolToFeatureVector(nn.Module):
                     p.requires_grad = False
         self._packed_key = None
         self._packed = None
+        self.math_mode = "f32"
 
     def packed(self):
         params = [p for b in self._layer4 for p in block_params(b)]
-        key = rt.param_key(params)
+        key = (self.math_mode,) + rt.param_key(params)
         if key != self._packed_key:
-            self._packed = [pack_block(b) for b in self._layer4]
+            self._packed = [pack_block(b, self.math_mode) for b in self._layer4]
             self._packed_key = key
         return self._packed
 

@@ -33,7 +33,7 @@ def pack_conv3x3(conv, math_mode="f32"):
     if math_mode == "f32_winograd" and nv.uses_winograd(cin, cout):
         out = t.empty((16, cout, cin), dtype=t.float32, device=w.device)
         with t.cuda.device(w.device):
-            nv.check(nv.lib().frcnn_pack_conv3x3_winograd(nv.ptr(w), nv.ptr(out), cout, cin, nv.stream_ptr()),
+            nv.check(nv.lib().frcnn_pack_conv3x3_winograd(nv.ptr(w), None, nv.ptr(out), cout, cin, nv.stream_ptr()),
                      "frcnn_pack_conv3x3_winograd")
         return out
     if math_mode == "f32x6" and cin != 3:
@@ -60,13 +60,17 @@ def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False):
     lib = nv.lib()
     winograd = wp.dtype == t.float32 and wp.dim() == 3 and int(wp.shape[0]) == 16
     if winograd:
-        ws_bytes = int(lib.frcnn_conv3x3_winograd_workspace_bytes(h, w, cin, cout))
+        ws_bytes = int(lib.frcnn_conv3x3_winograd_workspace_bytes(1, h, w, cin, cout))
     else:
         ws_bytes = int(lib.frcnn_conv3x3_workspace_bytes(h, w, cin, cout))
     ws = t.empty((max(ws_bytes, 4) // 4,), dtype=t.float32, device=x_hwc.device)
     flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
     with t.cuda.device(x_hwc.device):
-        fn = lib.frcnn_conv3x3_nhwc_x6 if wp.dtype == t.int16 else (lib.frcnn_conv3x3_nhwc_winograd if winograd else lib.frcnn_conv3x3_nhwc)
+        if winograd:
+            nv.check(lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
+                                                     nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc_winograd")
+            return y
+        fn = lib.frcnn_conv3x3_nhwc_x6 if wp.dtype == t.int16 else lib.frcnn_conv3x3_nhwc
         nv.check(fn(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
                     nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc")
     return y

@@ -133,22 +133,27 @@ int frcnn_pack_conv3x3_x6(const float* d_w_oihw, void* d_w_split, int cout, int 
 int frcnn_conv3x3_nhwc_x6(const float* d_x, const void* d_w_split, const float* d_bias,
                           float* d_y, int H, int W, int cin, int cout, unsigned flags,
                           void* d_ws, size_t ws_bytes, void* stream);
-/* The same layer (models/vgg16.py:36-47, models/rpn.py:39) as Winograd F(2x2,3x3) in float32: three launches
+/* The same layer (models/vgg16.py:36-47, models/rpn.py:39; with n_maps > 1 also the stride-1 3x3 of a ResNet
+ * bottleneck on the per-RoI maps, models/resnet.py:110) as Winograd F(2x2,3x3) in float32: three launches
  * (input transform, 16 batched exact-f32 MFMA GEMMs over the channels, output transform + bias + ReLU +
  * optional 2x2 max-pool), 2.25x fewer multiplies than the direct form.  No reduced-precision operands: every
  * value is float32 (the filter transform G g G^T is evaluated in float64 and rounded once); results differ
  * from the direct kernel by fp32 rounding only (a few 1e-7 relative per layer).
- *   d_u    : float32 [16][cout][cin] from frcnn_pack_conv3x3_winograd (OIHW weights in)
- *   d_ws   : scratch of frcnn_conv3x3_winograd_workspace_bytes() = 16*ceil(H/2)*ceil(W/2)*(cin+cout)*4 bytes
- * Requires cin % 16 == 0 and cout % 128 == 0 (FRCNN_EUNSUPPORTED otherwise).  The fused forward uses it in
- * math mode FRCNN_MATH_F32_WINOGRAD for the layers where frcnn_conv3x3_uses_winograd(cin, cout) != 0
+ *   d_x    : float32 NHWC [n_maps][H][W][cin];  d_y : [n_maps][H][W][cout] ([n_maps][H/2][W/2][cout] with FRCNN_POOL2)
+ *   d_u    : float32 [16][cout][cin] from frcnn_pack_conv3x3_winograd (OIHW weights in; d_row_scale, optional,
+ *            multiplies filter row `cout` in float32 first = the frozen-BatchNorm fold of frcnn_fold_bn_pack)
+ *   d_ws   : scratch of frcnn_conv3x3_winograd_workspace_bytes() = 16*n_maps*ceil(H/2)*ceil(W/2)*(cin+cout)*4 bytes
+ * Requires cin % 16 == 0 and cout % 128 == 0 (FRCNN_EUNSUPPORTED otherwise).  The fused forwards use it in
+ * math mode FRCNN_MATH_F32_WINOGRAD: VGG-16 / RPN trunk layers where frcnn_conv3x3_uses_winograd(cin, cout) != 0
  * (cin >= 128 and cout >= 256: for narrower layers the transformed tensors cost more HBM traffic than the
- * matrix pipe saves -- measured per VGG-16 layer). */
+ * matrix pipe saves -- measured per VGG-16 layer) and ResNet bottlenecks where
+ * frcnn_resnet_block_uses_winograd(width, stride) != 0 (the stride-1 blocks of layer4). */
 int frcnn_conv3x3_uses_winograd(int cin, int cout);
-int frcnn_pack_conv3x3_winograd(const float* d_w_oihw, float* d_u, int cout, int cin, void* stream);
-size_t frcnn_conv3x3_winograd_workspace_bytes(int H, int W, int cin, int cout);
+int frcnn_resnet_block_uses_winograd(int width, int stride);
+int frcnn_pack_conv3x3_winograd(const float* d_w_oihw, const float* d_row_scale, float* d_u, int cout, int cin, void* stream);
+size_t frcnn_conv3x3_winograd_workspace_bytes(int n_maps, int H, int W, int cin, int cout);
 int frcnn_conv3x3_nhwc_winograd(const float* d_x, const float* d_u, const float* d_bias,
-                                float* d_y, int H, int W, int cin, int cout, unsigned flags,
+                                float* d_y, int n_maps, int H, int W, int cin, int cout, unsigned flags,
                                 void* d_ws, size_t ws_bytes, void* stream);
 /* Stand-alone 2x2/stride-2 floor max-pool on NHWC (vgg16.py:78,82,87,92), c % 4 == 0. */
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream);
@@ -324,7 +329,9 @@ int frcnn_vgg16_forward(frcnn_ctx* ctx, const frcnn_vgg16_weights* w, const frcn
 #define FRCNN_RESNET_MAX_BLOCKS 64
 typedef struct frcnn_bottleneck_weights {
     const float *w1, *b1;      /* 1x1 cin->width    (bn folded), [1][width][cin]   */
-    const float *w2, *b2;      /* 3x3 width->width, stride on this conv (v1.5), [9][width][width] */
+    const float *w2, *b2;      /* 3x3 width->width, stride on this conv (v1.5), [9][width][width]; in math mode
+                                  FRCNN_MATH_F32_WINOGRAD the blocks with frcnn_resnet_block_uses_winograd(width, stride)
+                                  carry frcnn_pack_conv3x3_winograd's [16][width][width] instead */
     const float *w3, *b3;      /* 1x1 width->cout, [1][cout][width] */
     const float *wd, *bd;      /* downsample 1x1 cin->cout (stride), NULL when identity */
     int32_t cin, width, cout, stride;
@@ -335,7 +342,8 @@ typedef struct frcnn_resnet_weights {
     const float* stem_b;
     int32_t n_blocks[4];       /* layer1..layer4: (3,4,6,3) / (3,4,23,3) / (3,8,36,3) */
     frcnn_bottleneck_weights blocks[FRCNN_RESNET_MAX_BLOCKS];   /* layer1, layer2, layer3, layer4 in order */
-    const float* rpn_conv_w;   /* frcnn_pack_conv3x3 of _rpn_conv1 (1024 -> 1024) */
+    const float* rpn_conv_w;   /* frcnn_pack_conv3x3 (FRCNN_MATH_F32) / frcnn_pack_conv3x3_winograd (FRCNN_MATH_F32_WINOGRAD) of
+                                  _rpn_conv1 (1024 -> 1024) */
     const float* rpn_conv_b;
     const float* rpn_head_w;   /* [128][1024] */
     const float* rpn_head_b;

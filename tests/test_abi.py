@@ -71,5 +71,9 @@ def test_winograd_layer_rule_matches_binding():
     for cin in (3, 16, 64, 120, 128, 256, 512, 1024):
         for cout in (64, 128, 200, 256, 512, 1024):
             assert bool(lib.frcnn_conv3x3_uses_winograd(cin, cout)) == nv.uses_winograd(cin, cout), (cin, cout)
+    for width in (64, 128, 256, 512):
+        for stride in (1, 2):
+            assert bool(lib.frcnn_resnet_block_uses_winograd(width, stride)) == nv.resnet_block_uses_winograd(width, stride)
+    assert nv.resnet_block_uses_winograd(512, 1) and not nv.resnet_block_uses_winograd(512, 2) and not nv.resnet_block_uses_winograd(256, 1)
     # VGG-16: conv3_1 .. conv5_3 and the RPN trunk, not blocks 1-2
     assert nv.uses_winograd(128, 256) and nv.uses_winograd(512, 512) and not nv.uses_winograd(128, 128) and not nv.uses_winograd(64, 128)

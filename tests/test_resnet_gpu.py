@@ -210,3 +210,27 @@ def test_resnet101_end_to_end(golden_dir):
     assert np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max() <= 2e-4
     out = model.predict(image_data=img.cuda(), score_threshold=0.05)
     assert abs(sum(len(v) for v in out.values()) - len(g["detections"])) <= 4
+
+
+def test_resnet50_direct_mode_agrees_with_default_winograd_mode(r50):
+    """Default = f32_winograd (RPN trunk + the stride-1 3x3 convolutions of layer4 as Winograd F(2x2,3x3)); "f32" keeps every
+    layer on the direct kernels.  Both must give the same proposals / class scores up to float32 rounding."""
+    model, _ = r50
+    assert model.math_mode == "f32_winograd"
+    img = synthetic.image_rgb(5, 352, 480).unsqueeze(0).cuda()
+    a = model(image_data=img)
+    model.math_mode = "f32"
+    try:
+        b = model(image_data=img)
+    finally:
+        model.math_mode = "f32_winograd"
+    a2 = model(image_data=img)
+    for u, v in zip(a, a2):
+        assert torch.equal(u, v)                                         # deterministic, packs restored
+    j, err = match_rows(a[0].cpu().numpy(), b[0].cpu().numpy())
+    ok = err <= 1e-3
+    print("ResNet-50 f32 vs f32_winograd: %.1f%% of proposals within 1e-3 px" % (100 * ok.mean()))
+    assert ok.mean() >= 0.95
+    assert np.abs(a[1].cpu().numpy()[j[ok]] - b[1].cpu().numpy()[ok]).max() <= 2e-4
+    with pytest.raises(NotImplementedError):
+        model.math_mode = "f32x6"

@@ -48,22 +48,23 @@ def match_rows(ours, ref):
     return j, np.abs(ours[j, :4] - ref[:, :4]).max(axis=1)
 
 
-def run_layer(kind, x, w_oihw, b, relu, pool):
-    """kind: 'direct' | 'winograd'; x NHWC CUDA, returns NHWC CUDA."""
+def run_layer(kind, x, w_oihw, b, relu, pool, scale=None):
+    """kind: 'direct' | 'winograd'; x NHWC CUDA ([H][W][C] or [N][H][W][C] for winograd), returns NHWC CUDA."""
     lib = nv.lib()
-    h, wd, cin = (int(v) for v in x.shape)
+    n = int(x.shape[0]) if x.dim() == 4 else 1
+    h, wd, cin = (int(v) for v in x.shape[-3:])
     cout = int(w_oihw.shape[0])
     s = nv.stream_ptr()
     oh, ow = (h // 2, wd // 2) if pool else (h, wd)
-    y = torch.full((oh, ow, cout), float("nan"), device=x.device)
+    y = torch.full(((n, oh, ow, cout) if x.dim() == 4 else (oh, ow, cout)), float("nan"), device=x.device)
     flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
     if kind == "winograd":
         u = torch.empty((16, cout, cin), device=x.device)
-        nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w_oihw), nv.ptr(u), cout, cin, s), "pack_winograd")
-        wsb = int(lib.frcnn_conv3x3_winograd_workspace_bytes(h, wd, cin, cout))
-        assert wsb == 16 * ((h + 1) // 2) * ((wd + 1) // 2) * (cin + cout) * 4
+        nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w_oihw), nv.ptr(scale), nv.ptr(u), cout, cin, s), "pack_winograd")
+        wsb = int(lib.frcnn_conv3x3_winograd_workspace_bytes(n, h, wd, cin, cout))
+        assert wsb == 16 * n * ((h + 1) // 2) * ((wd + 1) // 2) * (cin + cout) * 4
         ws = torch.empty((wsb // 4,), device=x.device)
-        nv.check(lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), h, wd, cin, cout, flags,
+        nv.check(lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), n, h, wd, cin, cout, flags,
                                                  nv.ptr(ws), wsb, s), "conv_winograd")
     else:
         wp = torch.empty((9, cout, cin), device=x.device)
@@ -82,7 +83,7 @@ def test_filter_transform_matches_numpy():
     g = rng.randn(128, 48, 3, 3).astype(np.float32)
     gd = torch.from_numpy(g).cuda()
     u = torch.empty((16, 128, 48), device="cuda")
-    nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(gd), nv.ptr(u), 128, 48, nv.stream_ptr()), "pack_winograd")
+    nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(gd), None, nv.ptr(u), 128, 48, nv.stream_ptr()), "pack_winograd")
     torch.cuda.synchronize()
     ref = np.einsum("ia,kcab,jb->ijkc", G, g.astype(np.float64), G).reshape(16, 128, 48)
     got = u.cpu().numpy().astype(np.float64)
@@ -130,22 +131,47 @@ def test_layer_against_float64_and_direct(h, w, cin, cout, relu, pool):
     assert np.array_equal(yw, yw2)
 
 
+def test_batched_maps_with_folded_batchnorm_scale():
+    """The ResNet layer4 use: 3x3 512->512 on a batch of per-RoI 4x4 maps, filter rows pre-multiplied by the frozen-BN scale."""
+    gen = torch.Generator().manual_seed(77)
+    n, h, w, cin, cout = 7, 4, 4, 512, 512
+    x = torch.randn((n, h, w, cin), generator=gen)
+    wt = torch.randn((cout, cin, 3, 3), generator=gen) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn((cout,), generator=gen) * 0.1
+    scale = torch.rand((cout,), generator=gen) + 0.5
+    folded = (wt * scale[:, None, None, None]).double()               # the float32 product, as the pack forms it
+    ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), folded, b.double(), padding=1)).permute(0, 2, 3, 1).numpy()
+    y = run_layer("winograd", x.cuda(), wt.cuda(), b.cuda(), True, False, scale=scale.cuda()).cpu().numpy().astype(np.float64)
+    assert y.shape == ref.shape and np.isfinite(y).all()
+    err = float(np.abs(y - ref).max()) / float(np.abs(ref).max())
+    print("winograd batched %dx%dx%d %d->%d with BN scale: max err / max|y| = %.3g" % (n, h, w, cin, cout, err))
+    assert err <= 3e-6
+    # odd map size in a batch (7x7), pooled output
+    x2 = torch.randn((3, 7, 7, 128), generator=gen)
+    w2 = torch.randn((256, 128, 3, 3), generator=gen) * 0.03
+    b2 = torch.zeros((256,))
+    ref2 = F.max_pool2d(F.conv2d(x2.permute(0, 3, 1, 2).double(), w2.double(), None, padding=1), 2, 2).permute(0, 2, 3, 1).numpy()
+    y2 = run_layer("winograd", x2.cuda(), w2.cuda(), b2.cuda(), False, True).cpu().numpy().astype(np.float64)
+    assert y2.shape == ref2.shape == (3, 3, 3, 256)
+    assert float(np.abs(y2 - ref2).max()) / float(np.abs(ref2).max()) <= 3e-6
+
+
 def test_rejects_unsupported_shapes():
     lib = nv.lib()
-    assert lib.frcnn_conv3x3_winograd_workspace_bytes(8, 8, 24, 128) == 0        # cin % 16
-    assert lib.frcnn_conv3x3_winograd_workspace_bytes(8, 8, 32, 64) == 0         # cout % 128
+    assert lib.frcnn_conv3x3_winograd_workspace_bytes(1, 8, 8, 24, 128) == 0        # cin % 16
+    assert lib.frcnn_conv3x3_winograd_workspace_bytes(1, 8, 8, 32, 64) == 0         # cout % 128
     x = torch.zeros((8, 8, 32), device="cuda")
     u = torch.zeros((16, 64, 32), device="cuda")
     b = torch.zeros((64,), device="cuda")
     y = torch.zeros((8, 8, 64), device="cuda")
     ws = torch.zeros((1 << 16,), device="cuda")
-    rc = lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 8, 8, 32, 64, 0, nv.ptr(ws), 1 << 18,
+    rc = lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, 8, 8, 32, 64, 0, nv.ptr(ws), 1 << 18,
                                          nv.stream_ptr())
     assert rc == -4
     u2 = torch.zeros((16, 128, 32), device="cuda")
     b2 = torch.zeros((128,), device="cuda")
     y2 = torch.zeros((8, 8, 128), device="cuda")
-    rc = lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x), nv.ptr(u2), nv.ptr(b2), nv.ptr(y2), 8, 8, 32, 128, 0, nv.ptr(ws), 64,
+    rc = lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x), nv.ptr(u2), nv.ptr(b2), nv.ptr(y2), 1, 8, 8, 32, 128, 0, nv.ptr(ws), 64,
                                          nv.stream_ptr())
     assert rc == -1                                                                # scratch too small
 

@@ -73,8 +73,8 @@ def main():
         if wino:
             w_oihw = torch.randn((cout, cin, 3, 3), device=dev) * 0.02
             wu = torch.empty((16, cout, cin), device=dev)
-            nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w_oihw), nv.ptr(wu), cout, cin, s), "pack_winograd")
-            wsb = int(lib.frcnn_conv3x3_winograd_workspace_bytes(h, w, cin, cout))
+            nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w_oihw), None, nv.ptr(wu), cout, cin, s), "pack_winograd")
+            wsb = int(lib.frcnn_conv3x3_winograd_workspace_bytes(1, h, w, cin, cout))
         else:
             wsb = (160 << 20) if args.x6 else int(lib.frcnn_conv3x3_workspace_bytes(h, w, cin, cout))
         ws = torch.empty((max(wsb, 4) // 4,), device=dev)
@@ -82,7 +82,7 @@ def main():
 
         def run():
             if wino:
-                nv.check(lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x), nv.ptr(wu), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
+                nv.check(lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x), nv.ptr(wu), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
                                                          nv.ptr(ws), wsb, s), "conv_winograd")
             elif args.x6:
                 nv.check(lib.frcnn_conv3x3_nhwc_x6(nv.ptr(x), nv.ptr(wq), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
