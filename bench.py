@@ -269,14 +269,24 @@ def main():
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events around every conv3x3 MFMA launch, one stream
-        model.predict(pool[0], score_threshold=0.05)
+        # Per image: read + reset the per-class event sums, then keep the MEDIAN image per class (times its launch count), so
+        # that one image hit by a clock ramp after the idle gap of the previous leg does not skew the mean.
+        for i in range(3):
+            model.predict(pool[i % len(pool)], score_threshold=0.05)
         ctx = model.context(0)
         ctx.timing_enable(True)
-        for i in range(args.roofline_images):
+        per_image = []
+        for i in range(max(args.roofline_images, 1)):
             model.predict(pool[i % len(pool)], score_threshold=0.05)
-        torch.cuda.synchronize(dev)
-        timing = ctx.timing_read(reset=True)
+            torch.cuda.synchronize(dev)
+            per_image.append(ctx.timing_read(reset=True))
         ctx.timing_enable(False)
+        n_img = len(per_image)
+        timing = {}
+        for k in per_image[0]:
+            ms = sorted(t[k][0] for t in per_image)
+            med = ms[n_img // 2] if n_img % 2 else 0.5 * (ms[n_img // 2 - 1] + ms[n_img // 2])
+            timing[k] = (med * n_img, sum(t[k][1] for t in per_image))     # (median image x images, launches)
         def mfma_roofline(kernel, cls, layer_flops, note):
             ms, launches = timing[cls]
             if not launches:
@@ -289,8 +299,8 @@ def main():
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(launches), "ms_per_image": round(ms / max(args.roofline_images, 1), 4),
                     "note": note}
 
-        regime = ("HIP events around every launch, one image at a time on one stream (after the timed region: with 24 images "
-                  "in flight concurrent kernels share the CUs and a launch's wall duration is not its own)")
+        regime = ("HIP events around every launch, one image at a time on one stream, median image of %d (after the timed region: with "
+                  "24 images in flight concurrent kernels share the CUs and a launch's wall duration is not its own)" % n_img)
         dl, wl = direct_layers(args.math), winograd_layers(args.math)
         r_direct = mfma_roofline("conv3x3_mfma_kernel (direct 3x3 layers: %d per image)" % len(dl), "conv3x3_mfma",
                                  [2.0 * 9 * ci * co * h * w for ci, co, h, w in dl], "FLOP = direct-convolution FLOP of the layers")
