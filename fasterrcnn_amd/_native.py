@@ -34,7 +34,8 @@ SYMBOLS = (
     "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv7x7_s2_c3",
     "frcnn_maxpool3x3_s2_nhwc", "frcnn_spatial_mean_nhwc", "frcnn_resnet_forward", "frcnn_rpn_targets",
     "frcnn_pack_conv3x3_x6", "frcnn_conv3x3_nhwc_x6", "frcnn_preprocess_workspace_bytes", "frcnn_preprocess",
-    "frcnn_conv3x3_uses_winograd", "frcnn_resnet_block_uses_winograd", "frcnn_pack_conv3x3_winograd", "frcnn_conv3x3_winograd_workspace_bytes",
+    "frcnn_conv3x3_uses_winograd", "frcnn_resnet_block_uses_winograd", "frcnn_pack_conv3x3_winograd",
+    "frcnn_pack_conv3x3_winograd_taps", "frcnn_conv3x3_winograd_workspace_bytes",
     "frcnn_conv3x3_nhwc_winograd",
     # training path
     "frcnn_label_proposals", "frcnn_gather_rows", "frcnn_rpn_loss", "frcnn_detector_loss",
@@ -127,6 +128,7 @@ _SIGNATURES = {
     "frcnn_conv3x3_uses_winograd": (C.c_int, [_i, _i]),
     "frcnn_resnet_block_uses_winograd": (C.c_int, [_i, _i]),
     "frcnn_pack_conv3x3_winograd": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
+    "frcnn_pack_conv3x3_winograd_taps": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "frcnn_conv3x3_winograd_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "frcnn_conv3x3_nhwc_winograd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_linear_workspace_bytes": (C.c_size_t, [_i, _i, _i]),

@@ -208,6 +208,12 @@ int frcnn_pack_conv3x3_winograd(const float* d_w, const float* d_row_scale, floa
     return launch_pack_conv3x3_winograd(d_w, d_row_scale, d_u, cout, cin, as_stream(stream));
 }
 
+int frcnn_pack_conv3x3_winograd_taps(const float* d_wp, float* d_u, int cout, int cin, int data_gradient, void* stream)
+{
+    if (!d_wp || !d_u) return FRCNN_EINVAL;
+    return launch_pack_conv3x3_winograd_taps(d_wp, d_u, cout, cin, data_gradient, as_stream(stream));
+}
+
 size_t frcnn_conv3x3_winograd_workspace_bytes(int n_maps, int H, int W, int cin, int cout)
 {
     return conv3x3_winograd_workspace_bytes(n_maps, H, W, cin, cout);

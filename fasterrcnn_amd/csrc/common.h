@@ -85,6 +85,7 @@ void linear_batched_set_tile(int rows);        // 64 | 128: tile rows of the cal
 // winograd.hip: F(2x2,3x3) float32 path of the wide 3x3 layers
 size_t conv3x3_winograd_workspace_bytes(int N, int H, int W, int cin, int cout);
 int launch_pack_conv3x3_winograd(const float* w, const float* scale, float* u, int cout, int cin, hipStream_t s);
+int launch_pack_conv3x3_winograd_taps(const float* wp, float* u, int cout, int cin, int data_gradient, hipStream_t s);
 int launch_conv3x3_winograd(const float* x, const float* u, const float* b, float* y, int N, int H, int W, int cin, int cout,
                             unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int winograd_plan(int N, int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, float** V, float** M);

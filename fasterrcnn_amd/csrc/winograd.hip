@@ -58,6 +58,42 @@ void wino_pack_kernel(const float* __restrict__ g, const float* __restrict__ sca
     }
 }
 
+// The same transform from the direct kernels' tap-major pack wp[tap][cout][cin] (the train step's master weights):
+//   data_gradient == 0: U[p][k][c] of the layer's own filter (forward);
+//   data_gradient == 1: the bank of the data-gradient convolution dz (cout channels) -> dx (cin channels), whose filter is
+//                       the 180-degree rotated, channel-transposed one: g'[ci][co][tap] = wp[8 - tap][co][ci]; output [16][cin][cout].
+__global__ __launch_bounds__(256)
+void wino_pack_taps_kernel(const float* __restrict__ wp, float* __restrict__ u, int cout, int cin, int data_gradient)
+{
+    const size_t total = (size_t)cout * cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        double w[3][3];
+        if (!data_gradient) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) w[tp / 3][tp % 3] = (double)wp[(size_t)tp * total + i];
+        } else {
+            const size_t ci = i / cout, co = i % cout;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) w[tp / 3][tp % 3] = (double)wp[(size_t)(8 - tp) * total + co * cin + ci];
+        }
+        double r[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            r[0][b] = w[0][b];
+            r[1][b] = 0.5 * (w[0][b] + w[1][b] + w[2][b]);
+            r[2][b] = 0.5 * (w[0][b] - w[1][b] + w[2][b]);
+            r[3][b] = w[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            u[(size_t)(4 * a + 0) * total + i] = (float)r[a][0];
+            u[(size_t)(4 * a + 1) * total + i] = (float)(0.5 * (r[a][0] + r[a][1] + r[a][2]));
+            u[(size_t)(4 * a + 2) * total + i] = (float)(0.5 * (r[a][0] - r[a][1] + r[a][2]));
+            u[(size_t)(4 * a + 3) * total + i] = (float)r[a][2];
+        }
+    }
+}
+
 // One thread = one tile x 4 channels.  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].
 // x: [N][H][W][cin]; tiles are numbered image-major (tpi = th * tw per image), T = N * tpi.
 __global__ __launch_bounds__(256)
@@ -185,6 +221,16 @@ int launch_pack_conv3x3_winograd(const float* w, const float* scale, float* u, i
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, s, w, scale, u, cout, cin);
+    return check_launch();
+}
+
+int launch_pack_conv3x3_winograd_taps(const float* wp, float* u, int cout, int cin, int data_gradient, hipStream_t s)
+{
+    if (cout < 1 || cin < 1) return FRCNN_EINVAL;
+    const size_t total = (size_t)cout * cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wino_pack_taps_kernel, dim3(blocks), dim3(256), 0, s, wp, u, cout, cin, data_gradient ? 1 : 0);
     return check_launch();
 }
 

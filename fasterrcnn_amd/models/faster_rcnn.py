@@ -128,6 +128,10 @@ class FasterRCNNModel(nn.Module):
         if mode == "f32x6" and self._is_resnet:
             raise NotImplementedError("the ResNet path has no f32x6 kernels (math modes: f32, f32_winograd)")
         self._math_mode = mode
+        if getattr(self, "_train_state", None) is not None:
+            if mode == "f32x6":
+                raise NotImplementedError("a model with a live train state runs in the f32 or f32_winograd math mode")
+            self._train_state.winograd = mode == "f32_winograd"
         self._stage1_feature_extractor.math_mode = mode
         self._stage2_region_proposal_network.math_mode = mode
         if self._is_resnet:

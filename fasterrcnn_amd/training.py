@@ -81,8 +81,27 @@ def conv3x3_wgrad(x_hwc, dz_hwc, cin, cout):
     return dwp
 
 
-def conv3x3_dgrad(dz_hwc, wp, cin, cout, zero_bias):
+def winograd_bank(wp, cout, cin, data_gradient=False):
+    """Direct pack [9][cout][cin] -> Winograd F(2x2,3x3) filter bank: [16][cout][cin], or for the data gradient [16][cin][cout]
+    of the rotated, channel-transposed filter (frcnn_pack_conv3x3_winograd_taps).  Rebuilt from the master weights at every use:
+    ten 16 MB writes per step at most."""
+    u = t.empty((16, cin, cout) if data_gradient else (16, cout, cin), dtype=t.float32, device=wp.device)
+    nv.check(_lib().frcnn_pack_conv3x3_winograd_taps(nv.ptr(wp), nv.ptr(u), cout, cin, 1 if data_gradient else 0, nv.stream_ptr()),
+             "frcnn_pack_conv3x3_winograd_taps")
+    return u
+
+
+def conv3x3_forward(x_hwc, wp, b, cin, cout, winograd):
+    """y = relu(conv3x3(x) + b) without pooling, on the direct kernel or (wide layers of the f32_winograd mode) as a Winograd layer."""
+    if winograd and nv.uses_winograd(cin, cout):
+        wp = winograd_bank(wp, cout, cin)
+    return vgg16.conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False)
+
+
+def conv3x3_dgrad(dz_hwc, wp, cin, cout, zero_bias, winograd=False):
     """Gradient with respect to the input of y = conv3x3(x, wp): a 3x3 conv of dz (cout channels) to cin channels."""
+    if winograd and nv.uses_winograd(cout, cin):
+        return vgg16.conv3x3(dz_hwc, winograd_bank(wp, cout, cin, data_gradient=True), zero_bias, cout, cin, relu=False, pool=False)
     wd = t.empty((9, cin, cout), dtype=t.float32, device=dz_hwc.device)
     nv.check(_lib().frcnn_pack_conv3x3_dgrad(nv.ptr(wp), nv.ptr(wd), cout, cin, nv.stream_ptr()), "frcnn_pack_conv3x3_dgrad")
     return vgg16.conv3x3(dz_hwc, wd, zero_bias, cout, cin, relu=False, pool=False)
@@ -167,7 +186,9 @@ class TrainState:
     def __init__(self, model):
         self.model = model
         if model.math_mode not in ("f32", "f32_winograd"):
-            raise NotImplementedError("training runs on the exact-f32 direct kernels (inference math mode f32 or f32_winograd)")
+            raise NotImplementedError("training runs in the f32 or f32_winograd math mode")
+        # forward and data-gradient 3x3 convolutions of the wide VGG-16 / RPN layers as Winograd layers, weight gradients always direct
+        self.winograd = model.math_mode == "f32_winograd"
         rp = model._stage2_region_proposal_network
         dn = model._stage3_detector_network
         # masters in the direct kernels' layout, whatever layout the inference mode packs
@@ -273,7 +294,7 @@ class VGG16TrainState(TrainState):
             wp, b = self.conv[i]
             if i in _TRAINABLE_CONVS:
                 x_in[i] = cur
-                y = vgg16.conv3x3(cur, wp, b, cin, cout, relu=True, pool=False)
+                y = conv3x3_forward(cur, wp, b, cin, cout, self.winograd)
                 y_out[i] = y
                 cur = maxpool2x2(y) if pool else y
             else:
@@ -288,7 +309,7 @@ class VGG16TrainState(TrainState):
             relu_backward(g, y_out[i])
             grads["conv%d" % i] = conv3x3_wgrad(x_in[i], g, cin, cout)
             if i > 4:
-                gx = conv3x3_dgrad(g, self.conv[i][0], cin, cout, self.zero_bias)
+                gx = conv3x3_dgrad(g, self.conv[i][0], cin, cout, self.zero_bias, self.winograd)
                 g = maxpool2x2_backward(y_out[i - 1], gx) if (i - 1) in _POOL_AFTER else gx
 
     # ---- RoI features -> feature vector (vgg16.py:129-133) ------------------------------------------------
@@ -583,7 +604,7 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
         fh, fw = int(fm.shape[0]), int(fm.shape[1])
         P = fh * fw
         # ---- stage 2 forward (rpn.py:88-156, 12000 / 2000 in training: faster_rcnn.py:301-302) --------
-        trunk = vgg16.conv3x3(fm, st.rpn_conv, st.rpn_conv_b, C, C, relu=True, pool=False)
+        trunk = conv3x3_forward(fm, st.rpn_conv, st.rpn_conv_b, C, C, st.winograd)
         head = t.zeros((P, 128), dtype=t.float32, device=dev)
         wsb = int(lib.frcnn_linear_workspace_bytes(P, 45, C))
         ws = _ws(wsb, dev)
@@ -683,7 +704,7 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
         dtrunk = gemm_tn(dhead_t, pp, st.rpn_head, C, P, C, 128).reshape(fh, fw, C)
         relu_backward(dtrunk, trunk)
         grads["rpn_conv"] = conv3x3_wgrad(fm, dtrunk, C, C)
-        g = conv3x3_dgrad(dtrunk, st.rpn_conv, C, C, st.zero_bias)
+        g = conv3x3_dgrad(dtrunk, st.rpn_conv, C, C, st.zero_bias, st.winograd)
         if dfm is not None:
             nv.check(lib.frcnn_add_inplace(nv.ptr(g), nv.ptr(dfm), g.numel(), s), "frcnn_add_inplace")
         if detail is not None:

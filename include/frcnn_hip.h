@@ -151,6 +151,11 @@ int frcnn_conv3x3_nhwc_x6(const float* d_x, const void* d_w_split, const float* 
 int frcnn_conv3x3_uses_winograd(int cin, int cout);
 int frcnn_resnet_block_uses_winograd(int width, int stride);
 int frcnn_pack_conv3x3_winograd(const float* d_w_oihw, const float* d_row_scale, float* d_u, int cout, int cin, void* stream);
+/* The same filter bank from the direct kernels' tap-major pack [9][cout][cin] (frcnn_pack_conv3x3: the train step's master
+ * weights).  data_gradient = 0: the layer's own bank [16][cout][cin]; data_gradient = 1: the bank [16][cin][cout] of the
+ * convolution that maps the output gradient (cout channels) to the input gradient (cin channels), i.e. of the 180-degree rotated,
+ * channel-transposed filter that frcnn_pack_conv3x3_dgrad builds for the direct kernel (autograd of models/vgg16.py:84-96). */
+int frcnn_pack_conv3x3_winograd_taps(const float* d_w_packed, float* d_u, int cout, int cin, int data_gradient, void* stream);
 size_t frcnn_conv3x3_winograd_workspace_bytes(int n_maps, int H, int W, int cin, int cout);
 int frcnn_conv3x3_nhwc_winograd(const float* d_x, const float* d_u, const float* d_bias,
                                 float* d_y, int n_maps, int H, int W, int cin, int cout, unsigned flags,

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-6)
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic samples cycled through")
     ap.add_argument("--backbone", type=str, default="vgg16", choices=["vgg16", "resnet50", "resnet101", "resnet152"])
+    ap.add_argument("--math", type=str, default=None, choices=["f32", "f32_winograd"],
+                    help="default: the model's (f32_winograd: forward / data-gradient convolutions of the wide layers as Winograd layers)")
     args = ap.parse_args()
     h, w = args.height, args.width
     if args.backbone == "vgg16":
@@ -44,6 +46,8 @@ def main():
         model.load_state_dict(synthetic.resnet_state_dict(1234, arch), strict=True)
         make_image = synthetic.image_rgb
     model = model.cuda()
+    if args.math is not None:
+        model.math_mode = args.math
     am, vm = anchors.generate_anchor_maps((3, h, w), model.backbone.compute_feature_map_shape((3, h, w)), 16)
     samples = []
     for seed in range(args.pool):
@@ -68,7 +72,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"metric": "train_step (%s Faster R-CNN, %dx%d, batch 1)" % (args.backbone, h, w), "ms_per_step": 1e3 * dt / args.steps,
-                      "steps_per_sec": args.steps / dt, "steps": args.steps, "warmup": args.warmup, "dtype": "f32",
+                      "steps_per_sec": args.steps / dt, "steps": args.steps, "warmup": args.warmup, "dtype": "f32", "math": model.math_mode,
                       "first_total_loss": losses[0], "last_total_loss": losses[-1], "data": "synthetic"}))
 
 
