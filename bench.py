@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=24, help="images in flight per GPU (separate HIP streams)")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic images resident per GPU")
     ap.add_argument("--map-images", type=int, default=8, help="labelled images per rank for the mAP@0.5 leg")
-    ap.add_argument("--cpu-images", type=int, default=3, help="images timed on the host CPU (rank 0, N=1 only)")
+    ap.add_argument("--cpu-images", type=int, default=12, help="images timed on the host CPU (rank 0, N=1 only): ~12 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-images", type=int, default=10)
     ap.add_argument("--math", type=str, default=None, choices=["f32", "f32_winograd", "f32x6"],
@@ -306,7 +306,7 @@ def main():
                                  [2.0 * 9 * ci * co * h * w for ci, co, h, w in dl], "FLOP = direct-convolution FLOP of the layers")
         if r_direct is not None:
             r_direct["traffic"] = measured_traffic()
-        r_wino = mfma_roofline("linear_mfma_kernel<2,2,2,2,batched> (16-position Winograd GEMM: %d layers per image)" % len(wl),
+        r_wino = mfma_roofline("linear_mfma_kernel<1,2,2,2,BATCHED> (16-position Winograd GEMM, 64x128 tiles: %d layers per image)" % len(wl),
                                "winograd_gemm", [winograd_gemm_flops(*l) for l in wl],
                                "FLOP = the FLOP the GEMMs execute (16 x tiles x cin x cout x 2), NOT the 2.25x larger "
                                "direct-convolution FLOP they replace") if wl else None
