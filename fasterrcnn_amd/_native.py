@@ -102,7 +102,7 @@ def uses_winograd(cin, cout):
 
 def resnet_block_uses_winograd(width, stride):
     """== frcnn_resnet_block_uses_winograd(width, stride): the bottleneck 3x3 convolutions the f32_winograd mode transforms."""
-    return stride == 1 and width >= 512 and width % 128 == 0
+    return stride == 1 and width >= int(os.environ.get("FRCNN_RESNET_WINO_MIN_WIDTH", "256")) and width % 128 == 0
 
 
 _lib = None

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include "../../include/frcnn_hip.h"
 
 typedef float f32x4  __attribute__((ext_vector_type(4)));
@@ -29,9 +30,16 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // 3x3 layers that run as Winograd F(2x2,3x3) in math mode FRCNN_MATH_F32_WINOGRAD (VGG-16: conv3_1 ... conv5_3 and the RPN trunk)
 static inline bool conv3x3_uses_winograd(int cin, int cout) { return cin >= 128 && cout >= 256 && cin % 16 == 0 && cout % 128 == 0; }
-// ResNet bottlenecks (3x3 width -> width): only the stride-1 blocks of layer4 (width 512, 300 RoIs x 4x4 maps); the 256-wide
-// 38 x 63 layers of layer3 are 2.8 GFLOP each and do not pay for two extra launches
-static inline bool resnet_block_uses_winograd(int width, int stride) { return stride == 1 && width >= 512 && width % 128 == 0; }
+// ResNet bottlenecks (3x3 width -> width): the stride-1 blocks of layer3 (width 256, one 38 x 63 map) and layer4 (width 512,
+// 300 RoIs x 4 x 4 maps).  Measured: layer4 alone ResNet-50 311 -> 360 / ResNet-101 228 -> 258 img/s, with layer3 364 / 267;
+// the 128-wide blocks of layer2 are below the width where the transforms pay (FRCNN_RESNET_WINO_MIN_WIDTH overrides, experiments)
+static inline int resnet_winograd_min_width()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FRCNN_RESNET_WINO_MIN_WIDTH"); v = e ? atoi(e) : 256; }
+    return v;
+}
+static inline bool resnet_block_uses_winograd(int width, int stride) { return stride == 1 && width >= resnet_winograd_min_width() && width % 128 == 0; }
 
 // Per-kernel-class event timer (see frcnn_ctx_timing_* in the header).
 struct KernelTimer;

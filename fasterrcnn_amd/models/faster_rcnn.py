@@ -106,7 +106,7 @@ class FasterRCNNModel(nn.Module):
         # only); "f32x6" = exactly split bf16x3 operands, six bf16 MFMAs per product with f32 accumulation
         # Default: the fastest mode that reproduces the reference's golden vectors at the exact-f32 rate
         # (tests/test_winograd_gpu.py, tests/test_model_gpu.py, tests/test_resnet_gpu.py).  ResNet: the RPN trunk and the
-        # stride-1 3x3 convolutions of layer4 are the Winograd layers; there is no f32x6 ResNet path.
+        # stride-1 3x3 convolutions of layer3 / layer4 are the Winograd layers; there is no f32x6 ResNet path.
         self._math_mode = "f32"
         self.math_mode = "f32_winograd"
 

@@ -147,7 +147,7 @@ int frcnn_conv3x3_nhwc_x6(const float* d_x, const void* d_w_split, const float* 
  * math mode FRCNN_MATH_F32_WINOGRAD: VGG-16 / RPN trunk layers where frcnn_conv3x3_uses_winograd(cin, cout) != 0
  * (cin >= 128 and cout >= 256: for narrower layers the transformed tensors cost more HBM traffic than the
  * matrix pipe saves -- measured per VGG-16 layer) and ResNet bottlenecks where
- * frcnn_resnet_block_uses_winograd(width, stride) != 0 (the stride-1 blocks of layer4). */
+ * frcnn_resnet_block_uses_winograd(width, stride) != 0 (the stride-1 blocks of layer3 and layer4: width >= 256). */
 int frcnn_conv3x3_uses_winograd(int cin, int cout);
 int frcnn_resnet_block_uses_winograd(int width, int stride);
 int frcnn_pack_conv3x3_winograd(const float* d_w_oihw, const float* d_row_scale, float* d_u, int cout, int cin, void* stream);

@@ -74,6 +74,7 @@ def test_winograd_layer_rule_matches_binding():
     for width in (64, 128, 256, 512):
         for stride in (1, 2):
             assert bool(lib.frcnn_resnet_block_uses_winograd(width, stride)) == nv.resnet_block_uses_winograd(width, stride)
-    assert nv.resnet_block_uses_winograd(512, 1) and not nv.resnet_block_uses_winograd(512, 2) and not nv.resnet_block_uses_winograd(256, 1)
+    assert nv.resnet_block_uses_winograd(512, 1) and not nv.resnet_block_uses_winograd(512, 2) and nv.resnet_block_uses_winograd(256, 1) \
+        and not nv.resnet_block_uses_winograd(128, 1)
     # VGG-16: conv3_1 .. conv5_3 and the RPN trunk, not blocks 1-2
     assert nv.uses_winograd(128, 256) and nv.uses_winograd(512, 512) and not nv.uses_winograd(128, 128) and not nv.uses_winograd(64, 128)
