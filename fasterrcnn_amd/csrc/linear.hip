@@ -395,7 +395,9 @@ static int launch_linear_batched_cfg(const float* a, int lda, const float* w, fl
 // Tile of the calling thread's next launches: 64 = 64 x 128 (84 registers, five blocks per CU: lowest latency for one
 // image on the chip: never slower than 128 x 128 on the VGG-16 shapes, 20 % faster where 128-row tiles are few -- the
 // 37 x 62 maps -- or short -- cin = 128), 128 = 128 x 128 (fewer LDS / L2 operand bytes per MFMA: with many images in flight
-// the chip runs at its power limit and the cheaper tile wins, 372 -> 380 img/s).  0 = default (64).
+// the chip runs at its power limit and the cheaper tile wins, 372 -> 380 img/s).  0 = default (64).  FRCNN_WINO_TILE=64|128
+// overrides for experiments; 256-row / 256-column tiles and a second register set of prefetch were measured slower or equal
+// (tools/micro/README.md) and are not instantiated.
 static thread_local int g_batched_tile = 0;
 void linear_batched_set_tile(int rows) { g_batched_tile = rows; }
 
@@ -405,17 +407,11 @@ int launch_linear_batched(const float* a, int lda, size_t a_stride, const float*
     if (M < 1 || N < 1 || K < 16 || K % 16 != 0 || lda % 4 != 0 || lda < K || ldy < N || batches < 1) return FRCNN_EINVAL;
     static int env_tile = -1;
     if (env_tile < 0) { const char* e = getenv("FRCNN_WINO_TILE"); env_tile = e ? atoi(e) : 0; }
-    int tile = env_tile ? env_tile : (g_batched_tile ? g_batched_tile : 64);
-    if ((tile == 1256 || tile == 2256) && N % 256 != 0) tile = 128;
+    const int tile = env_tile ? env_tile : (g_batched_tile ? g_batched_tile : 64);
     BatchGeom bg{(long long)a_stride, (long long)w_stride, (long long)y_stride, cdiv(N, 128), cdiv(M, 128), batches};
-    switch (tile) {
-        case 64:   bg.mblocks = cdiv(M, 64);  return launch_linear_batched_cfg<1, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
-        case 256:  bg.mblocks = cdiv(M, 256); return launch_linear_batched_cfg<4, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);   // experiments
-        case 2568: bg.mblocks = cdiv(M, 256); return launch_linear_batched_cfg<2, 2, 4, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
-        case 1256: bg.nblocks = cdiv(N, 256); return launch_linear_batched_cfg<2, 4, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
-        case 1282: return launch_linear_batched_cfg<2, 2, 2, 2, 2>(a, lda, w, y, ldy, M, N, K, bg, s);
-        default:   return launch_linear_batched_cfg<2, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
-    }
+    if (tile == 128) return launch_linear_batched_cfg<2, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
+    bg.mblocks = cdiv(M, 64);
+    return launch_linear_batched_cfg<1, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);
 }
 
 int launch_linear(const float* a, int lda, const float* w, const float* bias, float* y, int ldy,
