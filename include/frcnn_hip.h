@@ -274,7 +274,10 @@ int frcnn_detections(const float* d_props, const float* d_classes, const float* 
  * (models/faster_rcnn.py:80-132) for the VGG-16 backbone (models/vgg16.py:22-158): one call
  * enqueues every kernel of stage 1-3 on `stream`, no host round trip.
  * One ctx per in-flight image (it owns the activation ping-pong buffers and scratch);
- * a ctx is not re-entrant, different ctxs are independent.
+ * a ctx is not re-entrant, different ctxs are independent.  The slab is allocated by
+ * frcnn_ctx_create; the V / M scratch of the Winograd layers (FRCNN_MATH_F32_WINOGRAD) is added by the
+ * first forward of the ctx that runs in that mode (one hipMalloc, sized for the ctx's largest image:
+ * 307 MB at 600x1000) and counted by frcnn_ctx_bytes from then on.
  * ---------------------------------------------------------------------------------------- */
 int  frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_rois);
 void frcnn_ctx_destroy(frcnn_ctx* ctx);
