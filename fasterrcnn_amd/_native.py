@@ -89,6 +89,11 @@ class ForwardParams(C.Structure):
                 ("conv_blocks_target", C.c_int32), ("winograd_tile_rows", C.c_int32)]
 
 
+# capacity limits of the kernels (validated by FasterRCNNModel with a message; the C entry points return FRCNN_EINVAL / EUNSUPPORTED)
+MAX_NUM_CLASSES = 26        # classifier (n) + regressor (4n-4) rows stacked into one 128-row operand (csrc/api.hip)
+MAX_POST_NMS_DETECT = 512   # DET_MAX of csrc/detect.hip (per-class NMS bit matrix in LDS)
+MAX_PRE_NMS = 16384         # frcnn_ctx pre_cap (csrc/api.hip): one-block radix select + sort
+
 MATH_F32 = 0      # exact f32 MFMA
 MATH_F32X6 = 1    # bf16x3 split operands, six bf16 MFMAs per product, f32 accumulate
 MATH_F32_WINOGRAD = 2   # exact f32 MFMA; 3x3 layers with uses_winograd(cin, cout) as Winograd F(2x2,3x3) in float32

@@ -57,14 +57,15 @@ def _all_gather_rows(x, device):
     return t.cat([b[:k] for b, k in zip(bufs, sizes)], dim=0).cpu()
 
 
-def merged_calculator(records, device=None):
+def merged_calculator(records, device=None, force_gather=False):
     """
     Builds the global PrecisionRecallCurveCalculator from this rank's ImageRecords.  With an
-    initialised process group the records of all ranks are exchanged first (every rank gets the
-    full result); without one it is the local accumulation.
+    initialised process group of more than one rank the records of all ranks are exchanged first
+    (every rank gets the full result); without one it is the local accumulation.
+    `force_gather` runs the exchange also in a one-rank group (the RCCL path on a single GPU).
     """
     pred, gt = records.arrays()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_gather):
         if device is None:
             device = t.device("cuda", t.cuda.current_device()) if dist.get_backend() == "nccl" else t.device("cpu")
         pred = _all_gather_rows(t.from_numpy(pred), device).numpy()
@@ -121,3 +122,60 @@ def evaluate_stream(model, samples, score_threshold=0.05, inflight=4, rank=0, wo
     while pending:
         collect(pending.pop(0))
     return records
+
+
+def evaluate(model, eval_data, num_samples=None, print_average_precisions=False, class_index_to_name=None,
+             inflight=8, score_threshold=0.05, force_gather=False):
+    """
+    The reference's evaluate() (pytorch/FasterRCNN/__main__.py:62-96): `model.predict(score_threshold=0.05)` per
+    sample of `eval_data`, `PrecisionRecallCurveCalculator.add_image_results`, returns 100 x mAP.
+    `eval_data` iterates samples that carry `.image_data` (numpy or tensor (3, H, W), preprocessed) and `.gt_boxes`
+    (the reference's TrainingSample); the dataset itself (voc.Dataset) stays the caller's.  Images are uploaded and
+    predicted `inflight` at a time; under an initialised process group each rank takes every world-th sample and the
+    records are merged with one all-gather (merged_calculator), so every rank returns the same value.
+    """
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    device = model._device()
+
+    def stream():
+        for i, sample in enumerate(eval_data):
+            if num_samples is not None and i >= num_samples:
+                break
+            if i % world != rank:
+                yield i, None, None           # evaluate_stream skips it without touching the image
+                continue
+            data = sample.image_data
+            if not isinstance(data, t.Tensor):
+                data = t.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
+            yield i, data.unsqueeze(dim=0).to(device), sample.gt_boxes
+
+    records = evaluate_stream(model, stream(), score_threshold=score_threshold, inflight=inflight, rank=rank, world=world)
+    calc = merged_calculator(records, force_gather=force_gather)
+    if print_average_precisions:
+        calc.print_average_precisions(class_index_to_name=class_index_to_name or {})
+    return 100.0 * calc.compute_mean_average_precision()
+
+
+def predict(model, image_data, score_threshold=0.7):
+    """__main__.py:226-228 without the drawing: (3, H, W) preprocessed numpy image -> predict() dict."""
+    if not isinstance(image_data, t.Tensor):
+        image_data = t.from_numpy(np.ascontiguousarray(image_data, dtype=np.float32))
+    return model.predict(image_data=image_data.unsqueeze(dim=0).to(model._device()), score_threshold=score_threshold)
+
+
+def predict_one(model, url, score_threshold=0.7, min_dimension_pixels=600):
+    """
+    __main__.py:237-240 (`run_one_image` of the north star): load_image with the backbone's preprocessing at a
+    600-pixel minimum side, then predict at score threshold 0.7.  Returns (scored_boxes_by_class_index, PIL image,
+    scale_factor); visualisation (visualize.show_detections) is outside this build's scope.
+    Decode on the host, resize + normalise on the device (datasets/image.py) -- the tensor never leaves the GPU.
+    """
+    from PIL import Image
+    from .datasets import image as I
+    with Image.open(url) as im:
+        rgb = np.array(im.convert("RGB"))
+    image_data, scale_factor, _, resized = I.preprocess_image(rgb, model.backbone.image_preprocessing_params,
+                                                              min_dimension_pixels, False, return_resized=True)
+    det = model.predict(image_data=image_data.unsqueeze(dim=0), score_threshold=score_threshold)
+    return det, Image.fromarray(resized.cpu().numpy(), mode="RGB"), scale_factor

@@ -70,6 +70,11 @@ class FasterRCNNModel(nn.Module):
 
     def __init__(self, num_classes, backbone, rpn_minibatch_size=256, proposal_batch_size=128, allow_edge_proposals=True):
         super().__init__()
+        # capacity limits of the kernels behind this class (csrc/api.hip, csrc/detect.hip); the reference has none, so
+        # they are refused here with their reason instead of as a bare error code from the first forward
+        if not 2 <= int(num_classes) <= nv.MAX_NUM_CLASSES:
+            raise ValueError("num_classes must be in [2, %d]: classifier + regressor rows are stacked into one 128-row GEMM "
+                             "operand (5 x num_classes - 4 <= 128); got %r" % (nv.MAX_NUM_CLASSES, num_classes))
 
         # Constants (faster_rcnn.py:60-64)
         self._num_classes = num_classes
@@ -195,6 +200,36 @@ class FasterRCNNModel(nn.Module):
             self._wstruct, self._wstruct_key, self._wkeep = w, key, (tensors, fe, l4)
         return self._wstruct
 
+    def _check_limits(self):
+        if not 1 <= int(self.max_proposals_post_nms) <= nv.MAX_POST_NMS_DETECT:
+            raise ValueError("max_proposals_post_nms must be in [1, %d] for predict() (the per-class NMS of csrc/detect.hip keeps "
+                             "its IoU bit matrix in LDS); got %r" % (nv.MAX_POST_NMS_DETECT, self.max_proposals_post_nms))
+        if not 1 <= int(self.max_proposals_pre_nms) <= nv.MAX_PRE_NMS:
+            raise ValueError("max_proposals_pre_nms must be in [1, %d] (one-block sort of csrc/proposals.hip); got %r" % (
+                nv.MAX_PRE_NMS, self.max_proposals_pre_nms))
+
+    def invalidate_packed(self):
+        """
+        Drops every packed / folded / transformed weight cache so that the next forward rebuilds them from the
+        nn.Parameters.  The caches are keyed on (data_ptr, _version) of the parameters, which `load_state_dict`, `copy_`
+        and optimizers bump -- writes through `.data` (p.data.normal_(), p.data.copy_()) do NOT: call this after them.
+        """
+        self.sync_parameters()
+        for m in self.modules():
+            if hasattr(m, "_packed_key"):
+                m._packed_key = None
+        self._wstruct_key = None
+        self._train_state = None
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float(): trained weights go back into the parameters first, masters and slots belong to the old device
+        self.sync_parameters()
+        out = super()._apply(fn, *args, **kwargs)
+        self._train_state = None
+        self._slots = {}
+        self._wstruct_key = None
+        return out
+
     def _slot(self, index, h, w, device):
         key = (str(device), index)
         slot = self._slots.get(key)
@@ -206,6 +241,7 @@ class FasterRCNNModel(nn.Module):
 
     def _enqueue(self, image_data, anchor_map, anchor_valid_map, score_threshold, slot_index):
         assert image_data.shape[0] == 1, "Batch size must be 1"
+        self._check_limits()
         self.sync_parameters()
         device = self._device()
         image = rt.as_f32_cuda(image_data, "image_data")
@@ -296,10 +332,20 @@ class FasterRCNNModel(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _training_state(self):
         from .. import training
-        if self._train_state is None:
+        st = self._train_state
+        if st is not None and st.parameters_changed():
+            # somebody wrote the nn.Parameters since the masters were cloned (sub-module load_state_dict, manual re-init,
+            # a real torch optimizer step): the parameters are the truth, the masters are rebuilt; momentum buffers stay
+            if st.dirty:
+                raise RuntimeError("parameters were modified while weights trained by train_step were still pending in the packed "
+                                   "masters; call model.sync_parameters() before writing parameters directly")
+            fresh = training.make_train_state(self)
+            fresh.momentum, fresh.steps = st.momentum, st.steps
+            self._train_state = st = fresh
+        if st is None:
             self._device()
-            self._train_state = training.make_train_state(self)
-        return self._train_state
+            self._train_state = st = training.make_train_state(self)
+        return st
 
     def sync_parameters(self):
         """Writes weights updated by `train_step` back into the nn.Parameters (no-op when nothing is pending)."""

@@ -200,6 +200,11 @@ class TrainState:
         self.momentum = {}
         self.steps = 0
         self.dirty = False
+        self._param_key = rt.param_key(list(model.parameters()))
+
+    def parameters_changed(self):
+        """True when any nn.Parameter was replaced or written (version bump) since the masters were cloned / last synced."""
+        return rt.param_key(list(self.model.parameters())) != self._param_key
 
     def trainable(self):
         """name -> packed master tensor, for everything SGD updates."""
@@ -234,6 +239,9 @@ class TrainState:
         if not self.dirty:
             return
         m = self.model
+        if self.parameters_changed():
+            raise RuntimeError("parameters were modified while weights trained by train_step were still pending in the packed "
+                               "masters; the write-back would silently overwrite them")
         rp = m._stage2_region_proposal_network
         c = int(rp._rpn_conv1.weight.shape[0])
         rp._rpn_conv1.weight.copy_(self.rpn_conv.permute(1, 2, 0).reshape(c, c, 3, 3))
@@ -245,6 +253,7 @@ class TrainState:
         dn._regressor.weight.copy_(self.head[ncls:ncls + 4 * (ncls - 1)])
         self._sync_backbone()
         self.dirty = False
+        self._param_key = rt.param_key(list(m.parameters()))
 
     def _sync_backbone(self):
         raise NotImplementedError
