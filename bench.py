@@ -119,6 +119,85 @@ def cpu_threads_for_baseline(sd, img, O):
     return best
 
 
+def sample_rocm_smi(load_fn, device_index, seconds=1.2):
+    """sclk / mclk / socket power of this GPU from `rocm-smi --json`, sampled while `load_fn()` keeps the headline load running
+    (the tool takes a few hundred ms to start, so it is launched first and read after ~`seconds` of load).  None when unavailable."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        proc = subprocess.Popen([exe, "-d", str(device_index), "--showclocks", "--showpower", "--json"],
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end or proc.poll() is None:
+            load_fn()
+            if time.perf_counter() > t_end + 10:
+                proc.kill()
+                return None
+        raw = json.loads(proc.stdout.read().decode() or "{}")
+        card = next(iter(raw.values())) if raw else {}
+        out = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl:
+                out["sclk"] = v
+            elif "mclk" in kl:
+                out["mclk"] = v
+            elif "power" in kl and "socket" in kl:
+                out["socket_power_w"] = v
+        return out or None
+    except Exception:
+        return None
+
+
+def train_step_leg(backbone, dev, steps=10, warmup=3, lr=1e-6, pool=2):
+    """ms per FasterRCNNModel.train_step (one 600x1000 synthetic sample per step, batch 1 as the reference trains: forward, four
+    losses, backward, SGD with momentum) -- SURVEY section 8 row f3 / BASELINE configs[4]'s single-GPU fp32 RoIPool form."""
+    import random
+    from fasterrcnn_amd import synthetic, training
+    from fasterrcnn_amd.datasets.training_sample import Box
+    from fasterrcnn_amd.models import anchors, resnet
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    from fasterrcnn_amd.models.vgg16 import VGG16Backbone
+    if backbone == "vgg16":
+        model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+        model.load_state_dict(synthetic.vgg16_state_dict(1234), strict=True)
+        make_image = synthetic.image
+    else:
+        arch = {"resnet50": "ResNet50", "resnet101": "ResNet101", "resnet152": "ResNet152"}[backbone]
+        model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(getattr(resnet.Architecture, arch)))
+        model.load_state_dict(synthetic.resnet_state_dict(1234, arch), strict=True)
+        make_image = synthetic.image_rgb
+    model = model.cuda(dev)
+    am, vm = anchors.generate_anchor_maps((3, H, W), model.backbone.compute_feature_map_shape((3, H, W)), 16)
+    samples = []
+    for seed in range(pool):
+        boxes = [Box(c, "x", k) for c, k in synthetic.ground_truth(seed, H, W)]
+        rmap, obj, bg = anchors.generate_rpn_map(am, vm, boxes)
+        samples.append((make_image(seed, H, W).unsqueeze(0).to(dev), torch.from_numpy(rmap).unsqueeze(0).to(dev), obj, bg, boxes))
+    opt = training.create_optimizer(model, learning_rate=lr)
+    random.seed(0)
+    torch.manual_seed(0)
+    losses = []
+
+    def step(i):
+        img, rmap, obj, bg, boxes = samples[i % len(samples)]
+        return model.train_step(opt, img, am, vm, rmap, [obj], [bg], [boxes])
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        losses.append(step(i).total)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return {"ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "math": model.math_mode, "dtype": "f32",
+            "first_total_loss": round(float(losses[0]), 5), "last_total_loss": round(float(losses[-1]), 5)}
+
+
 def planted_ground_truth(seed, det, num_classes=21):
     """Synthetic GT for image `seed`: seeded random boxes plus up to 3 of the image's own top
     detections jittered by a few pixels (so mAP@0.5 is neither 0 nor 1)."""
@@ -152,6 +231,12 @@ def main():
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
                     help="untimed pre-roll before the warm-up steps: the GPU takes ~1-2 s of load to leave its idle power state "
                          "(sclk 157 MHz -> 2.4 GHz), far longer than a 20-step warm-up")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run every barrier / all-reduce / all-gather also with ONE rank "
+                         "(so the multi-GPU code path can be exercised on a one-GPU box)")
+    ap.add_argument("--min-timed-seconds", type=float, default=1.0,
+                    help="the timed burst of --steps steps is repeated until this much has been timed; the MEDIAN burst is reported")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the single-stream / ResNet-50 / train-step legs")
     ap.add_argument("--backbone", type=str, default="vgg16", choices=["vgg16", "resnet50", "resnet101", "resnet152"],
                     help="vgg16 is the BASELINE.json metric; the ResNets are informational (configs[2])")
     args = ap.parse_args()
@@ -169,8 +254,11 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_ADDR" not in os.environ:          # --force-dist without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29531"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world
     torch.cuda.set_device(local_rank)
@@ -215,24 +303,44 @@ def main():
             last = pending.pop(0).result()
         return last
 
+    def timed_burst(fn, n_steps):
+        """EXACTLY n_steps steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        ts = time.perf_counter()
+        fn(n_steps)
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        dt = time.perf_counter() - ts
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def timed_median(fn, n_steps, min_seconds):
+        """Repeats the K-step burst until `min_seconds` have been timed (at least once, at most 64 times; every rank takes
+        the same decision because the burst time is already the max over ranks) and returns (median burst, all bursts)."""
+        bursts, total = [], 0.0
+        while not bursts or (total < min_seconds and len(bursts) < 64):
+            bursts.append(timed_burst(fn, n_steps))
+            total += bursts[-1]
+        srt = sorted(bursts)
+        return srt[(len(srt) - 1) // 2], bursts
+
     t_ramp = time.perf_counter() + max(args.ramp_seconds, 0.0)
     while time.perf_counter() < t_ramp:
         run(nslots)
     run(max(args.warmup, nslots))
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, bursts = timed_median(run, args.steps, args.min_timed_seconds)
     value = n_gpus * args.steps / elapsed
+
+    # clocks / power under the headline load (rocm-smi sampled in the middle of one more, untimed, second of the same load)
+    smi = None
+    if rank == 0:
+        smi = sample_rocm_smi(lambda: run(nslots), local_rank)
 
     # ---- informational: the same workload in the other math modes (not the headline value) -----------
     secondary = {}
@@ -242,28 +350,55 @@ def main():
                 continue
             model.math_mode = mode
             run(max(args.warmup, nslots))
-            torch.cuda.synchronize(dev)
-            if world > 1:
-                dist.barrier()
-            ts = time.perf_counter()
-            run(args.steps)
-            torch.cuda.synchronize(dev)
-            if world > 1:
-                dist.barrier()
-            dt = time.perf_counter() - ts
-            if world > 1:
-                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt = float(tt.item())
+            dt, _ = timed_median(run, args.steps, min(args.min_timed_seconds, 0.5))
             secondary[mode] = round(n_gpus * args.steps / dt, 3)
         model.math_mode = args.math
+
+    # ---- driver-timed secondary legs (rank 0 of a one-GPU run; none of them is the headline value) -------------------
+    extra = {}
+    if rank == 0 and n_gpus == 1 and not args.no_extra_legs and not is_resnet:
+        # (1) configs[1] taken literally: ONE image on the chip at a time (slot 0 = the latency configuration of predict())
+        def run_single(n_steps):
+            for i in range(n_steps):
+                model.predict(pool[i % len(pool)], score_threshold=0.05)
+        run_single(5)
+        dt, _ = timed_median(run_single, args.steps, min(args.min_timed_seconds, 0.5))
+        extra["single_stream_images_per_sec"] = round(args.steps / dt, 3)
+        # (2) configs[2]: ResNet-50 backbone, 8 independent batch-1 images in flight (the reference asserts batch 1)
+        from fasterrcnn_amd.models import resnet as _resnet
+        m50 = FasterRCNNModel(num_classes=21, backbone=_resnet.ResNetBackbone(_resnet.Architecture.ResNet50))
+        m50.load_state_dict(synthetic.resnet_state_dict(1234, "ResNet50"), strict=True)
+        m50 = m50.cuda(dev).eval()
+        pool50 = [synthetic.image_rgb(s_).unsqueeze(0).to(dev) for s_ in seeds[:8]]
+
+        def run50(n_steps):
+            pend = []
+            for i in range(n_steps):
+                if len(pend) == 8:
+                    pend.pop(0).result()
+                pend.append(m50.predict_async(pool50[i % len(pool50)], 0.05, slot=1 + (i % 8)))
+            while pend:
+                pend.pop(0).result()
+        run50(16)
+        dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
+        extra["resnet50_images_per_sec"] = round(args.steps / dt, 3)
+        extra["resnet50_config"] = "ResNet-50 predict(), 3x600x1000, 8 batch-1 images in flight, math %s" % m50.math_mode
+        del m50, pool50
+        # (3) the train step (row f3; configs[4]'s single-GPU fp32 RoIPool form)
+        extra["train_step_ms"] = {}
+        for bb in ("vgg16", "resnet101"):
+            try:
+                extra["train_step_ms"][bb] = train_step_leg(bb, dev)
+            except Exception as e:     # a secondary leg must never take the headline line down with it
+                extra["train_step_ms"][bb] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
 
     # ---- mAP@0.5 leg (outside the timed region): labelled subset, merged across ranks -------------
     records = ImageRecords()
     for i in range(min(args.map_images, len(pool))):
         det = model.predict(pool[i], score_threshold=0.05)
         records.add(seeds[i], det, planted_ground_truth(seeds[i], det))
-    calc = merged_calculator(records)
+    calc = merged_calculator(records, force_gather=use_dist)       # ONE all-gather over RCCL when a process group is up
     mean_ap = float(calc.compute_mean_average_precision()) if calc._object_count_by_class_index else None
 
     out = None
@@ -344,7 +479,10 @@ def main():
         out = {
             "metric": "images/sec (600x1000) Faster-RCNN %s inference" % ("VGG-16" if not is_resnet else args.backbone), "value": round(value, 3),
             "unit": "images/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ramp_seconds": args.ramp_seconds,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "timed_bursts": {"count": len(bursts), "reported": "median burst of `steps` steps", "min_ms": round(1e3 * min(bursts), 3),
+                             "max_ms": round(1e3 * max(bursts), 3), "total_timed_s": round(sum(bursts), 3)},
+            "rocm_smi_under_load": smi, "process_group": ("nccl x%d" % world) if use_dist else None, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("VGG-16" if not is_resnet else args.backbone) + " Faster R-CNN predict(), 3x600x1000 float32, batch=1 per forward, "
                                    "6000 pre-/300 post-NMS proposals, score_threshold 0.05",
@@ -355,11 +493,12 @@ def main():
                                    "in the f32_winograd mode the matrix pipe executes fewer: see mfma_tflops_executed_per_gpu",
             "mfma_tflops_executed_per_gpu": None if is_resnet else round(value / n_gpus * executed_mfma_flops_per_image(args.math) / 1e12, 2),
             "math": args.math, "other_math_modes_images_per_sec": secondary,
+            **extra,
             "map_at_0.5": mean_ap, "map_images": int(args.map_images * world),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -729,3 +729,82 @@ def test_data_parallel_gradient_exchange_single_rank(sd_cpu):
     assert l0 == l1
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+
+
+def test_direct_parameter_writes_between_steps_are_honoured(sd_cpu):
+    """the packed training masters are cloned once.  A parameter written directly between two steps (sub-module
+    load_state_dict, manual re-init, a torch optimizer) must reach the next step instead of being overwritten by stale masters;
+    `.data` writes (no version bump) need invalidate_packed(); a conflicting write while trained weights are pending raises."""
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    from fasterrcnn_amd.models.vgg16 import VGG16Backbone
+    h, w, seed = 224, 320, 4
+    img = synthetic.image(seed, h, w).unsqueeze(0).cuda()
+    gts = synthetic.ground_truth(seed, h, w)
+    boxes = [Box(class_index=c, class_name="x", corners=k) for c, k in gts]
+    am, vm = O.generate_anchor_maps((3, h, w), (512, h // 16, w // 16), 16)
+    rmap, obj, bg = O.generate_rpn_map(am, vm, np.stack([k for _, k in gts]))
+    rmap_t = torch.from_numpy(rmap).unsqueeze(0)
+
+    def fresh():
+        m = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+        m.load_state_dict(sd_cpu, strict=True)
+        return m.cuda()
+
+    def step(m, opt, s):
+        random.seed(s); torch.manual_seed(s)
+        return m.train_step(opt, img, am, vm, rmap_t, [obj], [bg], [boxes])
+
+    key = "_stage3_detector_network._regressor.weight"
+    # run A: step, then the regressor is re-initialised through the parameter API, then a second step
+    a = fresh()
+    oa = T.create_optimizer(a, learning_rate=1e-6)
+    step(a, oa, 1)
+    a.sync_parameters()
+    with torch.no_grad():
+        a._stage3_detector_network._regressor.weight.mul_(0.5)          # in-place, bumps _version
+    la = step(a, oa, 2)
+    sa = a.state_dict()
+    # run B: the same, but the write goes through a state_dict round trip of the whole model (the path that always worked)
+    b = fresh()
+    ob = T.create_optimizer(b, learning_rate=1e-6)
+    step(b, ob, 1)
+    sd_mid = {k: v.clone() for k, v in b.state_dict().items()}
+    sd_mid[key] = sd_mid[key] * 0.5
+    momentum = b._train_state.momentum
+    b.load_state_dict(sd_mid, strict=True)
+    b._training_state().momentum = momentum                               # load_state_dict drops the optimizer state; keep it comparable
+    lb = step(b, ob, 2)
+    sb = b.state_dict()
+    assert la == lb
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    # the halved regressor really was used: the detector regression loss differs from an un-modified second step
+    c = fresh()
+    oc = T.create_optimizer(c, learning_rate=1e-6)
+    step(c, oc, 1)
+    lc = step(c, oc, 2)
+    assert lc.detector_regression != la.detector_regression
+    # a write while trained weights are still pending in the masters is refused, not silently lost
+    with torch.no_grad():
+        c._stage3_detector_network._regressor.weight.mul_(2.0)
+    with pytest.raises(RuntimeError):
+        c.state_dict()
+    # .data writes bypass the version counter: invalidate_packed() is the documented hook
+    d = fresh().eval()
+    im = synthetic.image(2, 224, 320).unsqueeze(0).cuda()
+    before = d(image_data=im)
+    d._stage3_detector_network._regressor.weight.data.mul_(2.0)
+    d.invalidate_packed()
+    after = d(image_data=im)
+    assert torch.allclose(after[2], before[2] * 2.0, rtol=1e-5, atol=1e-6)
+
+
+def test_constructor_refuses_unsupported_capacities():
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    from fasterrcnn_amd.models.vgg16 import VGG16Backbone
+    with pytest.raises(ValueError, match="num_classes"):
+        FasterRCNNModel(num_classes=81, backbone=VGG16Backbone(dropout_probability=0.0))
+    m = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0)).cuda().eval()
+    m.max_proposals_post_nms = 1000
+    with pytest.raises(ValueError, match="max_proposals_post_nms"):
+        m.predict(synthetic.image(1, 64, 64).unsqueeze(0).cuda(), 0.05)
