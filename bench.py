@@ -138,15 +138,7 @@ def sample_rocm_smi(load_fn, device_index, seconds=1.2):
                 return None
         raw = json.loads(proc.stdout.read().decode() or "{}")
         card = next(iter(raw.values())) if raw else {}
-        out = {}
-        for k, v in card.items():
-            kl = k.lower()
-            if "sclk" in kl:
-                out["sclk"] = v
-            elif "mclk" in kl:
-                out["mclk"] = v
-            elif "power" in kl and "socket" in kl:
-                out["socket_power_w"] = v
+        out = {k: v for k, v in card.items() if any(x in k.lower() for x in ("sclk", "mclk", "power"))}
         return out or None
     except Exception:
         return None

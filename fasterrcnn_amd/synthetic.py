@@ -102,7 +102,10 @@ def resnet_state_dict(seed=1234, architecture="ResNet50", num_classes=21, calibr
             p = prefix + "%d." % b
             conv(p + "conv1", planes, inplanes, 1); bn(p + "bn1", planes, 0.8, 1.2)
             conv(p + "conv2", planes, planes, 3);   bn(p + "bn2", planes, 0.8, 1.2)
-            conv(p + "conv3", planes * 4, planes, 1); bn(p + "bn3", planes * 4, 0.2, 0.4)
+            # the residual stream grows with depth: ResNet-152's 50 blocks get a smaller last-BN gamma so that its feature map
+            # stays in the range the (ResNet-50-calibrated) heads were tuned for (std ~6 instead of ~30, where the RPN saturates)
+            g3 = (0.12, 0.24) if architecture == "ResNet152" else (0.2, 0.4)
+            conv(p + "conv3", planes * 4, planes, 1); bn(p + "bn3", planes * 4, g3[0], g3[1])
             if b == 0:
                 conv(p + "downsample.0", planes * 4, inplanes, 1); bn(p + "downsample.1", planes * 4, 0.6, 1.0)
             inplanes = planes * 4

@@ -392,6 +392,7 @@ def main():
     ap.add_argument("--only-resnet", action="store_true")
     ap.add_argument("--train", action="store_true", help="only the train-step fixtures (tests/golden/train_*.npz)")
     ap.add_argument("--only-resnet101", action="store_true", help="with --train: only the ResNet-101 fixture")
+    ap.add_argument("--only-resnet152", action="store_true", help="only the ResNet-152 inference fixture")
     args = ap.parse_args()
     t.manual_seed(0)
     ref = reference_shims.install(O)
@@ -402,6 +403,10 @@ def main():
         calibrate_resnet(ref)
         return
     os.makedirs(GOLDEN, exist_ok=True)
+    if args.only_resnet152:
+        sd = synthetic.resnet_state_dict(1234, "ResNet152")
+        run_case(ref, "250x333_s7", sd, 7, 250, 333, True, 0.05, arch="ResNet152")
+        return
     if args.train and args.only_resnet101:
         golden_train(ref, "320x416_s6", 6, 320, 416, arch="ResNet101", sample_count=512)
         return
@@ -423,6 +428,8 @@ def main():
     run_case(ref, "250x333_s7", sd, 7, 250, 333, True, 0.05, arch="ResNet50")   # ceil() feature map 16x21
     sd = synthetic.resnet_state_dict(1234, "ResNet101")
     run_case(ref, "224x320_s3", sd, 3, 224, 320, True, 0.05, arch="ResNet101")
+    sd = synthetic.resnet_state_dict(1234, "ResNet152")
+    run_case(ref, "250x333_s7", sd, 7, 250, 333, True, 0.05, arch="ResNet152")
 
 
 if __name__ == "__main__":

@@ -145,6 +145,7 @@ def test_oracle_reproduces_reference_full_size(golden_dir, sd_cpu):
 
 
 @pytest.mark.parametrize("name,arch", [("resnet50_250x333_s7", "ResNet50"), ("resnet101_224x320_s3", "ResNet101"),
+                                       ("resnet152_250x333_s7", "ResNet152"),
                                        ("resnet50_600x1000_s0", "ResNet50")])
 def test_oracle_reproduces_reference_resnet(golden_dir, name, arch):
     g = np.load(os.path.join(golden_dir, name + ".npz"))

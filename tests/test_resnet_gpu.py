@@ -212,6 +212,36 @@ def test_resnet101_end_to_end(golden_dir):
     assert abs(sum(len(v) for v in out.values()) - len(g["detections"])) <= 4
 
 
+def test_resnet152_end_to_end(golden_dir):
+    """models/resnet.py:144-149 ResNet152 ([3, 8, 36, 3] bottlenecks, 155 convolutions): golden vectors of the reference."""
+    model, sd = make_model("ResNet152")
+    g = np.load(os.path.join(golden_dir, "resnet152_250x333_s7.npz"))
+    img = synthetic.image_rgb(7, 250, 333).unsqueeze(0)
+    detail = {}
+    O.forward(sd, img, detail=detail)
+    fm = model._stage1_feature_extractor(image_data=img.cuda()).cpu()
+    e = float((fm - detail["feature_map"]).abs().max()) / float(detail["feature_map"].abs().max())
+    print("ResNet-152 feature map (46 bottlenecks deep): max rel err %.3g" % e)
+    assert e <= 5e-5
+    props, classes, deltas = model(image_data=img.cuda())
+    assert props.shape[0] == g["proposals"].shape[0] == 300
+    j, err = match_rows(props.cpu().numpy(), g["proposals"])
+    ok = err <= 1e-3
+    print("ResNet-152 forward: %.1f%% of the reference's proposals within 1e-3 px" % (100 * ok.mean()))
+    assert ok.mean() >= 0.95
+    assert np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max() <= 2e-4
+    out = model.predict(image_data=img.cuda(), score_threshold=0.05)
+    ref = g["detections"]
+    n_ok = 0
+    for c in range(1, 21):
+        r = ref[ref[:, 0] == c][:, 1:]
+        if len(r) and len(out[c]):
+            jj, ee = match_rows(out[c], r)
+            n_ok += int(((ee <= 1e-3) & (np.abs(out[c][jj, 4] - r[:, 4]) <= 2e-4)).sum())
+    print("ResNet-152 predict: %d/%d reference detections reproduced" % (n_ok, len(ref)))
+    assert n_ok >= 0.93 * len(ref)
+
+
 def test_resnet50_direct_mode_agrees_with_default_winograd_mode(r50):
     """Default = f32_winograd (RPN trunk + the stride-1 3x3 convolutions of layer4 as Winograd F(2x2,3x3)); "f32" keeps every
     layer on the direct kernels.  Both must give the same proposals / class scores up to float32 rounding."""
