@@ -46,8 +46,8 @@ _MFMA_CONVS = [(64, 64, 600, 1000), (64, 128, 300, 500), (128, 128, 300, 500), (
                (512, 512, 37, 62)]   # last = RPN trunk (models/rpn.py:88)
 
 
-def uses_winograd(cin, cout):       # fasterrcnn_amd/_native.py uses_winograd
-    return cin >= 128 and cout >= 256
+def uses_winograd(cin, cout):       # fasterrcnn_amd/_native.py uses_winograd_fused: every single-map 3x3 layer from conv1_2 on
+    return cin >= 64 and cin % 16 == 0 and cout >= 64 and cout % 32 == 0
 
 
 def conv_mfma_flops_per_image():
@@ -64,7 +64,8 @@ def winograd_layers(math):
 
 
 def winograd_gemm_flops(ci, co, h, w):
-    """FLOP the 16 batched GEMMs of one Winograd F(2x2,3x3) layer execute: 16 positions x tiles x cin x cout x 2."""
+    """FLOP the matrix pipe executes for one Winograd F(2x2,3x3) layer: 16 positions x tiles x cin x cout x 2 (tiles = the image's
+    ceil(h/2) x ceil(w/2); the padding of the kernel's 4 x 16-tile blocks is NOT counted -- it is waste, not work)."""
     return 2.0 * 16 * ((h + 1) // 2) * ((w + 1) // 2) * ci * co
 
 
@@ -95,7 +96,7 @@ def measured_traffic(family="conv3x3_mfma_kernel"):
     try:
         rec = json.load(open(files[-1]))
         if "by_kernel" in rec:
-            return float(rec["by_kernel"][family]["hbm_bytes_per_launch"])
+            return float(rec["by_kernel"][family]["hbm_bytes_per_launch"]) if family in rec["by_kernel"] else None
         return float(rec["hbm_bytes_per_launch"]) if family == "conv3x3_mfma_kernel" else None
     except Exception:
         return None
@@ -216,8 +217,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-images", type=int, default=10)
     ap.add_argument("--math", type=str, default=None, choices=["f32", "f32_winograd", "f32x6"],
-                    help="3x3 conv arithmetic: f32_winograd (VGG-16 default: exact f32 MFMA, the >= 256-channel layers as Winograd "
-                         "F(2x2,3x3) in float32), f32 (every layer on the direct exact-f32 kernel; the only mode of the ResNets), "
+                    help="3x3 conv arithmetic: f32_winograd (default: exact f32 MFMA, every 3x3 layer from conv1_2 on as a one-launch Winograd "
+                         "F(2x2,3x3) layer in float32), f32 (every layer on the direct exact-f32 kernel; the only mode of the ResNets), "
                          "or f32x6 (exactly split bf16x3 operands, six bf16 MFMAs per product)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the informational legs in the other math modes")
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
@@ -433,12 +434,14 @@ def main():
                                  [2.0 * 9 * ci * co * h * w for ci, co, h, w in dl], "FLOP = direct-convolution FLOP of the layers")
         if r_direct is not None:
             r_direct["traffic"] = measured_traffic()
-        r_wino = mfma_roofline("linear_mfma_kernel<1,2,2,2,BATCHED> (16-position Winograd GEMM, 64x128 tiles: %d layers per image)" % len(wl),
-                               "winograd_gemm", [winograd_gemm_flops(*l) for l in wl],
-                               "FLOP = the FLOP the GEMMs execute (16 x tiles x cin x cout x 2), NOT the 2.25x larger "
-                               "direct-convolution FLOP they replace") if wl else None
+        r_wino = mfma_roofline("wino_fused_kernel (one-launch Winograd F(2x2,3x3) layer, all 16 positions in MFMA accumulators: %d layers "
+                               "per image)" % len(wl), "winograd_gemm", [winograd_gemm_flops(*l) for l in wl],
+                               "FLOP = the FLOP the matrix pipe executes (16 x tiles x cin x cout x 2), NOT the 2.25x larger "
+                               "direct-convolution FLOP the layers replace") if wl else None
         if r_wino is not None:
-            r_wino["traffic"] = measured_traffic("winograd_gemm")
+            r_wino["traffic"] = measured_traffic("wino_fused_kernel")
+            r_wino["algorithmic_bytes_per_launch"] = float(sum(4.0 * (h * w * ci + 16 * ci * co + (h // (2 if i in (0, 2, 5, 8) else 1)) * (w // (2 if i in (0, 2, 5, 8) else 1)) * co)
+                                                               for i, (ci, co, h, w) in enumerate(wl))) / len(wl)
         # `roofline` = the kernel with the most GPU time per image, the other one rides along
         both = [r for r in (r_direct, r_wino) if r is not None]
         both.sort(key=lambda r: -r["ms_per_image"])

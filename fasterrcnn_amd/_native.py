@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
-ABI_VERSION = 3     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
+ABI_VERSION = 4     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
@@ -37,6 +37,8 @@ SYMBOLS = (
     "frcnn_conv3x3_uses_winograd", "frcnn_resnet_block_uses_winograd", "frcnn_pack_conv3x3_winograd",
     "frcnn_pack_conv3x3_winograd_taps", "frcnn_conv3x3_winograd_workspace_bytes",
     "frcnn_conv3x3_nhwc_winograd",
+    "frcnn_conv3x3_uses_winograd_fused", "frcnn_resnet_block_uses_winograd_fused", "frcnn_pack_conv3x3_winograd_fused", "frcnn_pack_conv3x3_winograd_fused_taps",
+    "frcnn_conv3x3_nhwc_winograd_fused",
     # training path
     "frcnn_label_proposals", "frcnn_gather_rows", "frcnn_rpn_loss", "frcnn_detector_loss",
     "frcnn_gemm_tn_workspace_bytes", "frcnn_gemm_tn", "frcnn_conv3x3_wgrad_workspace_bytes", "frcnn_conv3x3_wgrad",
@@ -105,6 +107,16 @@ def uses_winograd(cin, cout):
     return cin >= 128 and cout >= 256 and cin % 16 == 0 and cout % 128 == 0
 
 
+def uses_winograd_fused(cin, cout):
+    """== frcnn_conv3x3_uses_winograd_fused(cin, cout): single-map 3x3 stride-1 layers that run as ONE-launch Winograd layers."""
+    return cin >= 64 and cin % 16 == 0 and cout >= 64 and cout % 32 == 0
+
+
+def resnet_block_uses_winograd_fused(n_maps, width, stride):
+    """== frcnn_resnet_block_uses_winograd_fused: bottleneck 3x3 convolutions on ONE map (layer1..3 at inference)."""
+    return n_maps == 1 and stride == 1 and uses_winograd_fused(width, width)
+
+
 def resnet_block_uses_winograd(width, stride):
     """== frcnn_resnet_block_uses_winograd(width, stride): the bottleneck 3x3 convolutions the f32_winograd mode transforms."""
     return stride == 1 and width >= int(os.environ.get("FRCNN_RESNET_WINO_MIN_WIDTH", "256")) and width % 128 == 0
@@ -136,6 +148,11 @@ _SIGNATURES = {
     "frcnn_pack_conv3x3_winograd_taps": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "frcnn_conv3x3_winograd_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "frcnn_conv3x3_nhwc_winograd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_conv3x3_uses_winograd_fused": (C.c_int, [_i, _i]),
+    "frcnn_resnet_block_uses_winograd_fused": (C.c_int, [_i, _i, _i]),
+    "frcnn_pack_conv3x3_winograd_fused": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
+    "frcnn_pack_conv3x3_winograd_fused_taps": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "frcnn_conv3x3_nhwc_winograd_fused": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp]),
     "frcnn_linear_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "frcnn_linear": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_softmax_rows": (C.c_int, [_vp, _i, _vp, _i, _i, _vp]),

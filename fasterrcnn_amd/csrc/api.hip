@@ -226,6 +226,28 @@ int frcnn_conv3x3_nhwc_winograd(const float* d_x, const float* d_u, const float*
     return launch_conv3x3_winograd(d_x, d_u, d_bias, d_y, n_maps, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
 }
 
+int frcnn_conv3x3_uses_winograd_fused(int cin, int cout) { return conv3x3_uses_winograd_fused(cin, cout) ? 1 : 0; }
+int frcnn_resnet_block_uses_winograd_fused(int n_maps, int width, int stride) { return resnet_block_uses_winograd_fused(n_maps, width, stride) ? 1 : 0; }
+
+int frcnn_pack_conv3x3_winograd_fused(const float* d_w, const float* d_row_scale, float* d_u, int cout, int cin, void* stream)
+{
+    if (!d_w || !d_u) return FRCNN_EINVAL;
+    return launch_pack_conv3x3_winograd_fused(d_w, d_row_scale, d_u, cout, cin, as_stream(stream));
+}
+
+int frcnn_pack_conv3x3_winograd_fused_taps(const float* d_wp, float* d_u, int cout, int cin, int data_gradient, void* stream)
+{
+    if (!d_wp || !d_u) return FRCNN_EINVAL;
+    return launch_pack_conv3x3_winograd_fused_taps(d_wp, d_u, cout, cin, data_gradient, as_stream(stream));
+}
+
+int frcnn_conv3x3_nhwc_winograd_fused(const float* d_x, const float* d_u, const float* d_bias, float* d_y, int H, int W,
+                                      int cin, int cout, unsigned flags, void* stream)
+{
+    if (!d_x || !d_u || !d_bias || !d_y || H < 1 || W < 1) return FRCNN_EINVAL;
+    return launch_conv3x3_winograd_fused(d_x, d_u, d_bias, d_y, H, W, cin, cout, flags, as_stream(stream));
+}
+
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream)
 {
     if (!d_x || !d_y) return FRCNN_EINVAL;
@@ -696,10 +718,12 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows);
     const bool x6 = p->math_mode == FRCNN_MATH_F32X6;
     const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
-    if (wino) { rc = ensure_wino_ws(c); if (rc) return rc; }
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
-        if (wino && conv3x3_uses_winograd(ci, co)) return run_winograd_layer(c, xin, wgt, bs, yout, 1, hh, ww, ci, co, fl, s);
+        if (wino && conv3x3_uses_winograd_fused(ci, co)) {     // one launch, no scratch (csrc/winofused.hip); timed as class 7
+            Scope _w(c, 7, s);
+            return launch_conv3x3_winograd_fused(xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
+        }
         Scope _d(c, 0, s);
         return x6 ? launch_conv3x3_x6(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s)
                   : launch_conv3x3_nhwc(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s);
@@ -782,7 +806,10 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
     if (need1 > c->res_buf_floats || need2 > c->res_buf_floats) return FRCNN_EINVAL;
 #define RSTEP(call) do { Scope _sc(c, cls_conv, s); rc = (call); } while (0); if (rc) return rc
     RSTEP(launch_conv_gather(X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s));
-    if (wino && resnet_block_uses_winograd(b.width, b.stride)) {
+    if (wino && resnet_block_uses_winograd_fused(N, b.width, b.stride)) {
+        { Scope _w(c, 7, s); rc = launch_conv3x3_winograd_fused(T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s); }
+        if (rc) return rc;
+    } else if (wino && resnet_block_uses_winograd(b.width, b.stride)) {
         rc = run_winograd_layer(c, T1, b.w2, b.b2, T2, N, h, w, b.width, b.width, R, s);
         if (rc) return rc;
     } else if (b.stride == 1 && N == 1 && b.width % 64 == 0) {
@@ -859,8 +886,8 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms; c->last_c = C;
 
     // stage 2: RPN (models/rpn.py:88-153)
-    if (wino && conv3x3_uses_winograd(C, C)) {
-        rc = run_winograd_layer(c, c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, 1, fh, fw, C, C, FRCNN_RELU, s);
+    if (wino && conv3x3_uses_winograd_fused(C, C)) {
+        { Scope _w(c, 7, s); rc = launch_conv3x3_winograd_fused(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU, s); }
         if (rc) return rc;
     } else {
         STEP(0, launch_conv3x3_nhwc(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU,

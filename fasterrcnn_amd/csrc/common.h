@@ -100,6 +100,19 @@ int winograd_plan(int N, int H, int W, int cin, int cout, unsigned flags, void* 
 int launch_winograd_input(const float* x, float* V, int N, int H, int W, int cin, hipStream_t s);
 int launch_winograd_gemm(const float* V, const float* u, float* M, int N, int H, int W, int cin, int cout, hipStream_t s);
 int launch_winograd_output(const float* M, const float* b, float* y, int N, int H, int W, int cout, unsigned flags, hipStream_t s);
+// winofused.hip: the same layer for one map as ONE launch (all 16 positions in accumulators, no V / M scratch)
+static inline bool conv3x3_uses_winograd_fused(int cin, int cout) { return cin >= 64 && cin % 16 == 0 && cout >= 64 && cout % 32 == 0; }
+// ResNet bottleneck 3x3 (width -> width) on ONE map (the feature extractor's layer1..3 at inference): every stride-1 block;
+// the per-RoI 4 x 4 maps of layer4 (n_maps = RoIs) stay on the three-launch batched form (resnet_block_uses_winograd)
+static inline bool resnet_block_uses_winograd_fused(int n_maps, int width, int stride)
+{
+    return n_maps == 1 && stride == 1 && conv3x3_uses_winograd_fused(width, width);
+}
+bool conv3x3_winograd_fused_ok(int H, int W, int cin, int cout);
+int launch_pack_conv3x3_winograd_fused(const float* w, const float* scale, float* u, int cout, int cin, hipStream_t s);
+int launch_pack_conv3x3_winograd_fused_taps(const float* wp, float* u, int cout, int cin, int data_gradient, hipStream_t s);
+int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
+                                  unsigned flags, hipStream_t s);
 int launch_softmax_rows(const float* x, int ldx, float* y, int M, int ncls, hipStream_t s);
 int launch_head_finish(const float* x, int ldx, int M, int ncls, int ndelta, float* classes,
                        float* deltas, hipStream_t s);

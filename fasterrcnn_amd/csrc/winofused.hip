@@ -1,0 +1,443 @@
+// winofused.hip -- 3x3 stride-1 "same" convolution as Winograd F(2x2,3x3) in float32, ONE launch per layer.
+// Replaces the three launches of csrc/winograd.hip (input transform -> 16 batched GEMMs -> output transform) for a single
+// map: models/vgg16.py:77-96 (conv1_2 ... conv5_3), models/rpn.py:88 (RPN trunk), the stride-1 3x3 convolutions of ResNet's
+// layer2 / layer3 (models/resnet.py:38-46 over torchvision's Bottleneck).
+//
+//   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
+//
+// No V / M scratch: HBM traffic of a layer is its input, its filter bank and its output.
+//
+// Work decomposition.  A block owns 4 x 16 Winograd tiles (8 x 32 output pixels) x 32 output channels and ALL 16 Winograd
+// positions of that slab: wave w owns tile row w, its accumulators are acc[position][cout half] = 16 x 2 MFMA 16x16 tiles
+// (v_mfma_f32_16x16x4_f32, exact f32, 4 registers each = 128 registers).  Because every position's accumulator is live, the
+// output transform A^T M A (+ bias, ReLU, 2x2 max-pool: a Winograd tile IS a pooling window) runs on registers in the epilogue.
+//
+// K loop over 16-channel chunks; per chunk
+//   * the (8+2) x (32+2) pixel input halo of the block's tiles is staged ONCE in LDS (zero padding folded in).  The B^T d B
+//     input transform is evaluated when the MFMA operand is formed: for position row i the wave reads the two patch rows
+//     that B^T combines (8 ds_read_b128), r_i[b] = d[a1][b] +- d[a2][b], and the four operands of the row are
+//     V[i][j] = r_i[b1] +- r_i[b2] -- the same float32 operation order as wino_input_kernel;
+//   * the filter bank arrives in four slabs (one per position row i: 4 positions x 32 couts x 16 channels = 8 KB, contiguous
+//     in the [chunk][cout block][position][32][16] layout of wino_pack_fused_kernel), double buffered;
+//   * MFMA roles: A = U (rows = couts), B = V (columns = tiles), so a lane's four accumulator registers are four CONSECUTIVE
+//     output channels of one tile -> 16-byte stores.
+// A "stage" is (chunk, i): 32 MFMAs per wave (1024 matrix-pipe cycles), 16 ds_read_b128, 32 VALU adds, 2 global loads +
+// 2 LDS writes for the next filter slab, 2 global loads of the next chunk's halo; one barrier per stage, a second one at the
+// chunk seam (the halo is single buffered: 32.6 + 2 x 8 KB of LDS per block, two blocks per CU).
+//
+// LDS layouts (both conflict-free for ds_read_b128 with lane = row + 16 * k-quad, checked against the lane groups of
+// MI355X_MICROARCH.md): halo pixel = 16 channels padded to 24 floats, pixels de-interleaved by column parity so that the 16
+// tiles of a wave read 16 consecutive pixels; filter rows = 16 floats, the k-quad slot XOR-swizzled by {0,2,3,1}[(row >> 2) & 3].
+#include "common.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace frcnn {
+
+static constexpr int WF_TR = 4, WF_TC = 16;              // tile rows / columns per block (one tile row per wave)
+static constexpr int WF_HR = 2 * WF_TR + 2;              // 10 halo rows
+static constexpr int WF_HC = 2 * WF_TC + 2;              // 34 halo columns
+static constexpr int WF_HP = WF_HC / 2;                  // 17 pixels per parity plane of a halo row
+static constexpr int WF_PS = 24;                         // floats per halo pixel in LDS
+static constexpr int WF_NPIX = WF_HR * WF_HC;            // 340
+static constexpr int WF_HALO_F = WF_NPIX * WF_PS;        // 8160 floats
+static constexpr int WF_BN = 32;                         // output channels per block
+static constexpr int WF_U_F = 4 * WF_BN * 16;            // floats per filter slab (4 positions x 32 couts x 16 channels)
+static constexpr int WF_NHP = WF_NPIX * 4;               // 16-byte halo pieces per chunk
+static constexpr int WF_NH = (WF_NHP + 255) / 256;       // 6 per thread
+#ifndef WF_ABLATE
+#define WF_ABLATE 0                                      // timing experiments only (tools/build_ablate.sh): 1 no halo LDS writes, 2 no filter
+#endif                                                   // LDS writes, 4 no halo LDS reads, 8 no filter LDS reads (after the prologue); results wrong
+#ifndef WF_HALO_BUFS
+#define WF_HALO_BUFS 2                                   // 2: no barrier at the chunk seam, 81,664 B of LDS per block (two blocks fill a CU's 160 KB)
+#endif
+static constexpr size_t WF_LDS_BYTES = (size_t)(WF_HALO_BUFS * WF_HALO_F + 2 * WF_U_F) * sizeof(float);
+static_assert(WF_NH == 6, "halo pieces are spread over the first three stages of a chunk, two per stage");
+
+// B^T rows: r_i = d[A1] (-|+) d[A2];  the same table gives the column combination V[i][j] = r_i[A1_j] (-|+) r_i[A2_j]
+__device__ __forceinline__ constexpr int wf_a1(int i) { return i == 0 ? 0 : (i == 1 ? 1 : (i == 2 ? 2 : 1)); }
+__device__ __forceinline__ constexpr int wf_a2(int i) { return i == 0 ? 2 : (i == 1 ? 2 : (i == 2 ? 1 : 3)); }
+__device__ __forceinline__ constexpr bool wf_sub(int i) { return i != 1; }
+
+// U'[chunk][cout block][p = 4 i + j][32][16] = (G g G^T)[i][j] of filter (cout, cin);  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+// g: OIHW [cout][cin][3][3]; `scale` (per cout, may be NULL) = the frozen-BatchNorm fold of the ResNet layers, multiplied in
+// float32 first exactly as fold_bn_pack_kernel does.  Values are identical to wino_pack_kernel's bank (float64, rounded once).
+__global__ __launch_bounds__(256)
+void wino_pack_fused_kernel(const float* __restrict__ g, const float* __restrict__ scale, float* __restrict__ u, int cout, int cin)
+{
+    const size_t total = (size_t)cout * cin;
+    const int ncb = cout / WF_BN;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int co = (int)(idx / cin), ci = (int)(idx % cin);
+        const float* gp = g + idx * 9;
+        const float sc = scale ? scale[co] : 1.0f;
+        double w[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) w[a][b] = (double)(scale ? gp[a * 3 + b] * sc : gp[a * 3 + b]);
+        double r[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            r[0][b] = w[0][b];
+            r[1][b] = 0.5 * (w[0][b] + w[1][b] + w[2][b]);
+            r[2][b] = 0.5 * (w[0][b] - w[1][b] + w[2][b]);
+            r[3][b] = w[2][b];
+        }
+        const size_t base = ((size_t)(ci >> 4) * ncb + (co / WF_BN)) * 16 * (WF_BN * 16) + (size_t)(co % WF_BN) * 16 + (ci & 15);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double q[4] = {r[a][0], 0.5 * (r[a][0] + r[a][1] + r[a][2]), 0.5 * (r[a][0] - r[a][1] + r[a][2]), r[a][2]};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) u[base + (size_t)(4 * a + b) * (WF_BN * 16)] = (float)q[b];
+        }
+    }
+}
+
+// The same bank from the direct kernels' tap-major pack wp[tap][cout][cin] (the train step's master weights):
+//   data_gradient == 0: the layer's own filter;  == 1: the data-gradient convolution dz (cout channels) -> dx (cin channels),
+//   filter g'[ci][co][tap] = wp[8 - tap][co][ci] (180-degree rotation, channels transposed); output channels = cin then.
+__global__ __launch_bounds__(256)
+void wino_pack_fused_taps_kernel(const float* __restrict__ wp, float* __restrict__ u, int cout, int cin, int data_gradient)
+{
+    const size_t total = (size_t)cout * cin;
+    const int oc = data_gradient ? cin : cout, ic = data_gradient ? cout : cin;     // channels of the convolution that is packed
+    const int ncb = oc / WF_BN;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int o = (int)(idx / ic), c = (int)(idx % ic);
+        double w[3][3];
+        if (!data_gradient) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) w[tp / 3][tp % 3] = (double)wp[(size_t)tp * total + idx];
+        } else {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) w[tp / 3][tp % 3] = (double)wp[(size_t)(8 - tp) * total + (size_t)c * cin + o];
+        }
+        double r[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            r[0][b] = w[0][b];
+            r[1][b] = 0.5 * (w[0][b] + w[1][b] + w[2][b]);
+            r[2][b] = 0.5 * (w[0][b] - w[1][b] + w[2][b]);
+            r[3][b] = w[2][b];
+        }
+        const size_t base = ((size_t)(c >> 4) * ncb + (o / WF_BN)) * 16 * (WF_BN * 16) + (size_t)(o % WF_BN) * 16 + (c & 15);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double q[4] = {r[a][0], 0.5 * (r[a][0] + r[a][1] + r[a][2]), 0.5 * (r[a][0] - r[a][1] + r[a][2]), r[a][2]};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) u[base + (size_t)(4 * a + b) * (WF_BN * 16)] = (float)q[b];
+        }
+    }
+}
+
+struct WfGeom { int tbx, tby, ncb, total; };
+
+#define WF_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define WF_MFMA 0x008
+#define WF_VALU 0x002
+#define WF_DSR  0x100
+#define WF_DSW  0x200
+
+template <bool POOL>
+__global__ __launch_bounds__(256, 2)
+void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ bias,
+                       float* __restrict__ y, int H, int W, int Cin, int Cout, int relu, WfGeom gm)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_wf[];
+    float* const halo0 = smem_wf;                           // WF_HALO_BUFS halo buffers
+    float* const ub0 = smem_wf + WF_HALO_BUFS * WF_HALO_F;  // 2 filter slab buffers
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, kq = lane >> 4;
+
+    // XCD-aware block order: hardware block b runs on XCD b % 8; the logical index is laid out XCD-major so that the cout
+    // blocks of one tile block (same halo) and neighbouring tile blocks (same filter slabs) share an XCD's L2
+    int L;
+    {
+        const int b = blockIdx.x, per = gm.total >> 3, rem = gm.total & 7, xcd = b & 7, j = b >> 3;
+        L = xcd < rem ? xcd * (per + 1) + j : rem * (per + 1) + (xcd - rem) * per + j;
+    }
+    const int cb = L % gm.ncb;
+    const int tb = L / gm.ncb;
+    const int bx = tb % gm.tbx, by = tb / gm.tbx;
+    const int n0 = cb * WF_BN;
+    const int y0 = 2 * WF_TR * by - 1, x0 = 2 * WF_TC * bx - 1;
+    const int nchunks = Cin >> 4;
+
+    // ---- halo staging: piece = (pixel, k-quad); out-of-image pieces load offset 0 and are zeroed by a select ----------
+    unsigned h_src[WF_NH];
+    int h_dst[WF_NH];
+    unsigned h_inb = 0;
+#pragma unroll
+    for (int it = 0; it < WF_NH; ++it) {
+        const int q = tid + 256 * it;
+        const int qq = q < WF_NHP ? q : q - WF_NHP;       // surplus threads duplicate the first pieces (same data, same address): no branch in the loop
+        const int px = qq >> 2, pk = qq & 3;
+        const int hr = px / WF_HC, hc = px - hr * WF_HC;
+        const int gy = y0 + hr, gx = x0 + hc;
+        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        h_src[it] = inb ? (unsigned)((((size_t)gy * W + gx) * Cin + 4 * pk) * sizeof(float)) : 0u;
+        h_dst[it] = ((hr * 2 + (hc & 1)) * WF_HP + (hc >> 1)) * WF_PS + 4 * pk;
+        if (inb) h_inb |= 1u << it;
+    }
+    // ---- filter slab staging: 512 pieces of 16 B per slab, two per thread ------------------------------------------------
+    int u_dst[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int q = tid + 256 * it;
+        const int row = q >> 2, pk = q & 3;
+        u_dst[it] = row * 16 + 4 * (pk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3));
+    }
+    const float* const u_blk = u + (size_t)cb * 16 * (WF_BN * 16) + 4 * tid;        // + chunk * ncb * 8192 + i * 2048 + 1024 * it
+    const size_t u_chunk_stride = (size_t)gm.ncb * 16 * (WF_BN * 16);
+
+    f32x4 hreg[2][2];            // two pieces in flight + two waiting for their LDS write
+    f32x4 ureg[2];
+    auto load_halo_piece = [&](f32x4& dst, int it, int chunk) {
+        if ((WF_ABLATE & 32) && chunk > 0) return;
+        dst = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(x + (chunk << 4)) + h_src[it]);
+    };
+    bool past_prologue = false;
+    auto store_halo_piece = [&](float* hb, const f32x4& src, int it) {
+        if ((WF_ABLATE & 1) && past_prologue) { asm volatile("" :: "v"(src)); return; }
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(hb + h_dst[it]) = ((h_inb >> it) & 1u) ? src : zero;
+    };
+    auto load_u = [&](int chunk, int i) {
+        if ((WF_ABLATE & 16) && (chunk > 0 || i > 0)) return;
+        const float* p = u_blk + (size_t)chunk * u_chunk_stride + i * WF_U_F;
+        ureg[0] = *reinterpret_cast<const f32x4*>(p);
+        ureg[1] = *reinterpret_cast<const f32x4*>(p + 1024);
+    };
+    auto store_u = [&](int buf) {
+        if ((WF_ABLATE & 2) && past_prologue) { asm volatile("" :: "v"(ureg[0]), "v"(ureg[1])); return; }
+        *reinterpret_cast<f32x4*>(ub0 + buf * WF_U_F + u_dst[0]) = ureg[0];
+        *reinterpret_cast<f32x4*>(ub0 + buf * WF_U_F + u_dst[1]) = ureg[1];
+    };
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // operand addresses: V from patch pixel (a, b) of tile (wave, l16): halo row 2 wave + a, plane b & 1, index l16 + (b >> 1)
+    const int v_off = ((4 * wave) * WF_HP + l16) * WF_PS + 4 * kq;
+    // U of position j (within the stage's row), cout half c: row = 32 j + 16 c + l16
+    const int u_off = l16 * 16 + 4 * (kq ^ ((0x78 >> (2 * ((l16 >> 2) & 3))) & 3));
+
+    // state carried from stage to stage: r_i of the current stage, the fragments of its first position
+    f32x4 r[4], ua[2], uc[2], v[2];
+    auto read_r = [&](const float* hb, int i) {           // r_i[b] = d[a1][b] -+ d[a2][b]
+        if ((WF_ABLATE & 4) && past_prologue) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) r[b] = wf_sub(i) ? r[b] - r[(b + 1) & 3] : r[b] + r[(b + 1) & 3];
+            return;
+        }
+        const float* vb = hb + v_off;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(vb + ((2 * wf_a1(i) + (b & 1)) * WF_HP + (b >> 1)) * WF_PS);
+            const f32x4 d2 = *reinterpret_cast<const f32x4*>(vb + ((2 * wf_a2(i) + (b & 1)) * WF_HP + (b >> 1)) * WF_PS);
+            r[b] = wf_sub(i) ? d1 - d2 : d1 + d2;
+        }
+    };
+    auto make_v = [&](int j) -> f32x4 { return wf_sub(j) ? r[wf_a1(j)] - r[wf_a2(j)] : r[wf_a1(j)] + r[wf_a2(j)]; };
+    auto read_u = [&](int buf, int j, f32x4& a, f32x4& c) {
+        if ((WF_ABLATE & 8) && past_prologue) { a = a + c; c = c - a; return; }
+        const float* ub = ub0 + buf * WF_U_F + u_off + (32 * j) * 16;
+        a = *reinterpret_cast<const f32x4*>(ub);
+        c = *reinterpret_cast<const f32x4*>(ub + 16 * 16);
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------------------------------------
+    {
+        f32x4 h0[WF_NH];
+#pragma unroll
+        for (int it = 0; it < WF_NH; ++it) load_halo_piece(h0[it], it, 0);
+        load_u(0, 0);
+#pragma unroll
+        for (int it = 0; it < WF_NH; ++it) store_halo_piece(halo0, h0[it], it);
+        store_u(0);
+    }
+    __syncthreads();
+    read_r(halo0, 0);
+    read_u(0, 0, ua[0], uc[0]);
+    v[0] = make_v(0);
+    past_prologue = true;
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int cn = (c + 1) < nchunks ? c + 1 : c;    // clamped: the last chunk re-loads itself, harmlessly
+        float* const hcur = halo0 + (WF_HALO_BUFS == 2 ? (c & 1) * WF_HALO_F : 0);
+        float* const hnxt = halo0 + (WF_HALO_BUFS == 2 ? ((c + 1) & 1) * WF_HALO_F : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int buf = i & 1;                       // 4 stages per chunk: the slab buffer parity repeats every chunk
+            // next filter slab and (stages 0..2) a third of the next chunk's halo: in flight under this stage's MFMAs
+            if (i < 3) load_u(c, i + 1); else load_u(cn, 0);
+            if (i < 3) { load_halo_piece(hreg[i & 1][0], 2 * i, cn); load_halo_piece(hreg[i & 1][1], 2 * i + 1, cn); }
+            __builtin_amdgcn_sched_barrier(0);           // the loads stay at the top of the stage (hipcc sinks them to their use otherwise)
+            if (WF_HALO_BUFS == 1 && i == 3) __syncthreads();     // single halo buffer: every wave is past its last read of this chunk
+            // phases 0..2: MFMAs of position j under the fragment reads / operand arithmetic of position j + 1
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int cur = j & 1, nxt = cur ^ 1;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc[4 * i + j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[cur][s], v[cur][s], acc[4 * i + j][0], 0, 0, 0);
+                    acc[4 * i + j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uc[cur][s], v[cur][s], acc[4 * i + j][1], 0, 0, 0);
+                }
+                read_u(buf, j + 1, ua[nxt], uc[nxt]);
+                v[nxt] = make_v(j + 1);
+                if (j == 2) {
+                    store_u(buf ^ 1);
+                    if (i >= 1) {
+                        store_halo_piece(hnxt, hreg[(i - 1) & 1][0], 2 * (i - 1));
+                        store_halo_piece(hnxt, hreg[(i - 1) & 1][1], 2 * (i - 1) + 1);
+                    }
+                }
+                WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 1); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 1);
+                WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2);
+                if (j == 2) {
+                    WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1);
+                    if (i >= 1) { WF_SGB(WF_VALU, 8); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1); }
+                    else { WF_SGB(WF_MFMA, 2); }
+                } else {
+                    WF_SGB(WF_MFMA, 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!(WF_ABLATE & 64)) __syncthreads();
+            // phase 3: MFMAs of position 3 under the reads that open the next stage (first fragments of the next slab, the
+            // two patch rows of the next position row)
+            {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc[4 * i + 3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[1][s], v[1][s], acc[4 * i + 3][0], 0, 0, 0);
+                    acc[4 * i + 3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uc[1][s], v[1][s], acc[4 * i + 3][1], 0, 0, 0);
+                }
+                read_u(buf ^ 1, 0, ua[0], uc[0]);
+                read_r(i == 3 ? hnxt : hcur, (i + 1) & 3);
+                v[0] = make_v(0);
+                WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 2);
+                WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 2);
+                WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 8); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 8); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue: Y = A^T M A on registers; lane = tile (wave, l16) x couts n0 + 16 c + 4 kq .. + 3 -----------------------
+    const int ty = WF_TR * by + wave, tx = WF_TC * bx + l16;
+    const int th = (H + 1) >> 1, tw = (W + 1) >> 1;
+    if (ty >= th || tx >= tw) return;
+    const int Ho = H >> 1, Wo = W >> 1;
+    if (POOL && (ty >= Ho || tx >= Wo)) return;          // floor pooling drops the odd last row / column
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int co = n0 + 16 * c + 4 * kq;
+        f32x4 s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = (acc[0 + j][c] + acc[4 + j][c]) + acc[8 + j][c];
+            s[1][j] = (acc[4 + j][c] - acc[8 + j][c]) - acc[12 + j][c];
+        }
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
+        f32x4 o[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            o[a][0] = ((s[a][0] + s[a][1]) + s[a][2]) + bv;
+            o[a][1] = ((s[a][1] - s[a][2]) - s[a][3]) + bv;
+        }
+        if (relu) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[a][b][e] = fmaxf(o[a][b][e], 0.f);
+        }
+        if (POOL) {
+            f32x4 m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
+            *reinterpret_cast<f32x4*>(y + ((size_t)ty * Wo + tx) * Cout + co) = m;
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int yy = 2 * ty + a;
+                if (yy >= H) continue;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int xx = 2 * tx + b;
+                    if (xx < W) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * Cout + co) = o[a][b];
+                }
+            }
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+bool conv3x3_winograd_fused_ok(int H, int W, int cin, int cout)
+{
+    return H >= 1 && W >= 1 && cin >= 16 && cin % 16 == 0 && cout >= WF_BN && cout % WF_BN == 0 &&
+           (size_t)H * W * cin * sizeof(float) < ((size_t)1 << 32);
+}
+
+int launch_pack_conv3x3_winograd_fused(const float* w, const float* scale, float* u, int cout, int cin, hipStream_t s)
+{
+    if (cout < WF_BN || cout % WF_BN != 0 || cin < 16 || cin % 16 != 0) return FRCNN_EUNSUPPORTED;
+    const size_t total = (size_t)cout * cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wino_pack_fused_kernel, dim3(blocks), dim3(256), 0, s, w, scale, u, cout, cin);
+    return check_launch();
+}
+
+int launch_pack_conv3x3_winograd_fused_taps(const float* wp, float* u, int cout, int cin, int data_gradient, hipStream_t s)
+{
+    const int oc = data_gradient ? cin : cout, ic = data_gradient ? cout : cin;
+    if (oc < WF_BN || oc % WF_BN != 0 || ic < 16 || ic % 16 != 0) return FRCNN_EUNSUPPORTED;
+    const size_t total = (size_t)cout * cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wino_pack_fused_taps_kernel, dim3(blocks), dim3(256), 0, s, wp, u, cout, cin, data_gradient ? 1 : 0);
+    return check_launch();
+}
+
+int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
+                                  unsigned flags, hipStream_t s)
+{
+    if (!conv3x3_winograd_fused_ok(H, W, cin, cout)) return FRCNN_EUNSUPPORTED;
+    if ((flags & FRCNN_POOL2) && (H < 2 || W < 2)) return FRCNN_EINVAL;
+    const int th = cdiv(H, 2), tw = cdiv(W, 2);
+    WfGeom gm;
+    gm.tbx = cdiv(tw, WF_TC);
+    gm.tby = cdiv(th, WF_TR);
+    gm.ncb = cout / WF_BN;
+    const long long total = (long long)gm.tbx * gm.tby * gm.ncb;
+    if (total > 0x7fffffffLL) return FRCNN_EINVAL;
+    gm.total = (int)total;
+    const int relu = (flags & FRCNN_RELU) ? 1 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WF_LDS_BYTES));
+        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WF_LDS_BYTES));
+        attr_set = true;
+        if (getenv("FRCNN_DEBUG_OCCUPANCY")) {
+            int nb = -1;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(wino_fused_kernel<false>), 256, WF_LDS_BYTES);
+            fprintf(stderr, "wino_fused_kernel: %d blocks per CU at %zu B of LDS\n", nb, WF_LDS_BYTES);
+        }
+    }
+    if (flags & FRCNN_POOL2)
+        hipLaunchKernelGGL(wino_fused_kernel<true>, dim3((unsigned)gm.total), dim3(256), WF_LDS_BYTES, s, x, u, b, y, H, W, cin, cout, relu, gm);
+    else
+        hipLaunchKernelGGL(wino_fused_kernel<false>, dim3((unsigned)gm.total), dim3(256), WF_LDS_BYTES, s, x, u, b, y, H, W, cin, cout, relu, gm);
+    return check_launch();
+}
+
+}  // namespace frcnn

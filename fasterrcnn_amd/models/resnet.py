@@ -100,28 +100,33 @@ def _bn_params(bn):
     return [bn.weight, bn.bias, bn.running_mean, bn.running_var]
 
 
-def fold_conv_bn_winograd(conv, bn):
-    """(transformed filter bank [16][cout][cin], bias) of a 3x3 conv followed by frozen BatchNorm: the same float32 fold as
+def fold_conv_bn_winograd(conv, bn, fused=False):
+    """fused=True: the one-launch kernel's flat bank (frcnn_pack_conv3x3_winograd_fused), else
+    (transformed filter bank [16][cout][cin], bias) of a 3x3 conv followed by frozen BatchNorm: the same float32 fold as
     frcnn_fold_bn_pack (scale = gamma / sqrt(var + eps) applied to the filter rows, bias = beta - mean * scale), then G g G^T."""
     w = rt.as_f32_cuda(conv.weight.detach(), "conv weight")
     cout, cin = int(w.shape[0]), int(w.shape[1])
     args = [rt.as_f32_cuda(x.detach(), "bn tensor") for x in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
     scale = t.empty((cout,), dtype=t.float32, device=w.device)
     shift = t.empty((cout,), dtype=t.float32, device=w.device)
-    u = t.empty((16, cout, cin), dtype=t.float32, device=w.device)
+    u = t.empty((16 * cout * cin,) if fused else (16, cout, cin), dtype=t.float32, device=w.device)
     with t.cuda.device(w.device):
         lib = nv.lib()
         nv.check(lib.frcnn_bn_scale_shift(nv.ptr(args[0]), nv.ptr(args[1]), nv.ptr(args[2]), nv.ptr(args[3]), float(bn.eps), cout,
                                           nv.ptr(scale), nv.ptr(shift), nv.stream_ptr()), "frcnn_bn_scale_shift")
-        nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w), nv.ptr(scale), nv.ptr(u), cout, cin, nv.stream_ptr()),
-                 "frcnn_pack_conv3x3_winograd")
+        pack = lib.frcnn_pack_conv3x3_winograd_fused if fused else lib.frcnn_pack_conv3x3_winograd
+        nv.check(pack(nv.ptr(w), nv.ptr(scale), nv.ptr(u), cout, cin, nv.stream_ptr()), "frcnn_pack_conv3x3_winograd")
     return u, shift, args + [scale]
 
 
-def pack_block(block, math_mode="f32"):
-    """dict of packed tensors + shape info for one Bottleneck."""
+def pack_block(block, math_mode="f32", single_map=False):
+    """dict of packed tensors + shape info for one Bottleneck.  single_map: the block runs on ONE map (layer1..3 of the feature
+    extractor) -> its 3x3 is a one-launch Winograd layer in the f32_winograd mode; the per-RoI maps of layer4 use the batched form."""
     w1, b1, k1 = fold_conv_bn(block.conv1, block.bn1)
-    if math_mode == "f32_winograd" and nv.resnet_block_uses_winograd(block.conv2.out_channels, block.stride):
+    width = block.conv2.out_channels
+    if math_mode == "f32_winograd" and nv.resnet_block_uses_winograd_fused(1 if single_map else 2, width, block.stride):
+        w2, b2, k2 = fold_conv_bn_winograd(block.conv2, block.bn2, fused=True)
+    elif math_mode == "f32_winograd" and nv.resnet_block_uses_winograd(width, block.stride):
         w2, b2, k2 = fold_conv_bn_winograd(block.conv2, block.bn2)
     else:
         w2, b2, k2 = fold_conv_bn(block.conv2, block.bn2)
@@ -159,7 +164,15 @@ def conv_nhwc(x, wp, bp, n, h, w, cin, cout, k, stride, pad, relu, residual=None
 def run_block(x, n, h, w, pb):
     """One Bottleneck on NHWC data through the C ABI (stage-level path; the fused model uses frcnn_resnet_forward)."""
     t1, _, _ = conv_nhwc(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, 1, 0, True)
-    if pb["w2"].dim() == 3 and int(pb["w2"].shape[0]) == 16:          # Winograd filter bank (f32_winograd mode)
+    if pb["w2"].dim() == 1:                                             # one-launch Winograd bank (f32_winograd mode, one map)
+        assert n == 1
+        width = pb["width"]
+        ho, wo = h, w
+        t2 = t.empty((n, h, w, width), dtype=t.float32, device=x.device)
+        with t.cuda.device(x.device):
+            nv.check(nv.lib().frcnn_conv3x3_nhwc_winograd_fused(nv.ptr(t1), nv.ptr(pb["w2"]), nv.ptr(pb["b2"]), nv.ptr(t2), h, w, width, width,
+                                                                nv.RELU, nv.stream_ptr()), "frcnn_conv3x3_nhwc_winograd_fused")
+    elif pb["w2"].dim() == 3 and int(pb["w2"].shape[0]) == 16:        # Winograd filter bank (f32_winograd mode)
         width = pb["width"]
         ho, wo = h, w
         t2 = t.empty((n, h, w, width), dtype=t.float32, device=x.device)
@@ -214,7 +227,7 @@ class FeatureExtractor(nn.Module):
         key = (self.math_mode,) + rt.param_key(params)
         if key != self._packed_key:
             sw, sb, keep = fold_conv_bn(fe[0], fe[1])
-            self._packed = {"stem": (sw, sb), "keep": keep, "blocks": [pack_block(b, self.math_mode) for b in self.blocks()],
+            self._packed = {"stem": (sw, sb), "keep": keep, "blocks": [pack_block(b, self.math_mode, single_map=True) for b in self.blocks()],
                             "n_blocks": [len(fe[4]), len(fe[5]), len(fe[6])]}
             self._packed_key = key
         return self._packed

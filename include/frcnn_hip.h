@@ -37,7 +37,7 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 3   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers */
+#define FRCNN_ABI_VERSION 4   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -160,6 +160,27 @@ size_t frcnn_conv3x3_winograd_workspace_bytes(int n_maps, int H, int W, int cin,
 int frcnn_conv3x3_nhwc_winograd(const float* d_x, const float* d_u, const float* d_bias,
                                 float* d_y, int n_maps, int H, int W, int cin, int cout, unsigned flags,
                                 void* d_ws, size_t ws_bytes, void* stream);
+/* The same Winograd F(2x2,3x3) float32 layer for ONE map as ONE launch with no V / M scratch (csrc/winofused.hip): a
+ * block owns 4 x 16 tiles x 32 output channels and all 16 Winograd positions in MFMA accumulators
+ * (v_mfma_f32_16x16x4_f32); the input transform B^T d B is evaluated on the LDS-staged halo when the operand is formed
+ * (same float32 operation order as the three-launch form), the output transform A^T M A + bias + ReLU + optional
+ * 2x2 max-pool runs on the accumulators.  HBM traffic of a layer = its input, filter bank and output, so the form pays for
+ * every 3x3 stride-1 layer with cin % 16 == 0 and cout % 32 == 0 (FRCNN_EUNSUPPORTED otherwise; H*W*cin*4 < 2^32).
+ *   d_u : float32 [cin/16][cout/32][16][32][16] from frcnn_pack_conv3x3_winograd_fused (OIHW in; optional per-cout
+ *         d_row_scale as above) or frcnn_pack_conv3x3_winograd_fused_taps (tap-major [9][cout][cin] in; data_gradient = 1
+ *         packs the bank of the data-gradient convolution cout -> cin channels).  16*cout*cin floats, the values of
+ *         frcnn_pack_conv3x3_winograd's bank in another order.
+ * The fused forwards use it in math mode FRCNN_MATH_F32_WINOGRAD for every single-map 3x3 stride-1 layer
+ * (frcnn_conv3x3_uses_winograd_fused(cin, cout) != 0); the three-launch form stays for ResNet's per-RoI 4 x 4 maps. */
+int frcnn_conv3x3_uses_winograd_fused(int cin, int cout);
+/* ResNet bottleneck 3x3 (width -> width, n_maps maps in one call): != 0 for ONE map, stride 1, width >= 64 -- the blocks of
+ * layer1..3 at inference; frcnn_resnet_forward then expects frcnn_pack_conv3x3_winograd_fused's bank in w2 (frozen-BatchNorm
+ * scale as d_row_scale).  The per-RoI maps of layer4 keep frcnn_resnet_block_uses_winograd / the three-launch form. */
+int frcnn_resnet_block_uses_winograd_fused(int n_maps, int width, int stride);
+int frcnn_pack_conv3x3_winograd_fused(const float* d_w_oihw, const float* d_row_scale, float* d_u, int cout, int cin, void* stream);
+int frcnn_pack_conv3x3_winograd_fused_taps(const float* d_w_packed, float* d_u, int cout, int cin, int data_gradient, void* stream);
+int frcnn_conv3x3_nhwc_winograd_fused(const float* d_x, const float* d_u, const float* d_bias, float* d_y,
+                                      int H, int W, int cin, int cout, unsigned flags, void* stream);
 /* Stand-alone 2x2/stride-2 floor max-pool on NHWC (vgg16.py:78,82,87,92), c % 4 == 0. */
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream);
 

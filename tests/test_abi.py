@@ -76,5 +76,12 @@ def test_winograd_layer_rule_matches_binding():
             assert bool(lib.frcnn_resnet_block_uses_winograd(width, stride)) == nv.resnet_block_uses_winograd(width, stride)
     assert nv.resnet_block_uses_winograd(512, 1) and not nv.resnet_block_uses_winograd(512, 2) and nv.resnet_block_uses_winograd(256, 1) \
         and not nv.resnet_block_uses_winograd(128, 1)
-    # VGG-16: conv3_1 .. conv5_3 and the RPN trunk, not blocks 1-2
+    for n_maps in (1, 300):
+        for width in (32, 64, 128, 256, 512):
+            for stride in (1, 2):
+                assert bool(lib.frcnn_resnet_block_uses_winograd_fused(n_maps, width, stride)) == \
+                    nv.resnet_block_uses_winograd_fused(n_maps, width, stride)
+    assert nv.resnet_block_uses_winograd_fused(1, 64, 1) and not nv.resnet_block_uses_winograd_fused(300, 512, 1) \
+        and not nv.resnet_block_uses_winograd_fused(1, 256, 2)
+    # three-launch form (round 1; still used for ResNet's per-RoI maps and by the train step): conv3_1 .. conv5_3 and the RPN trunk
     assert nv.uses_winograd(128, 256) and nv.uses_winograd(512, 512) and not nv.uses_winograd(128, 128) and not nv.uses_winograd(64, 128)

@@ -25,16 +25,27 @@ LAYERS = [("conv1_2", 64, 64, 600, 1000, True), ("conv2_1", 64, 128, 300, 500, F
           ("conv4_3", 512, 512, 75, 125, True), ("conv5_x", 512, 512, 37, 62, False)]
 
 
-def timeit(fn, reps):
+def timeit(fn, reps, ramp_s=1.0):
+    """Median of 5 batches of `reps` launches after `ramp_s` seconds of the same load (the GPU needs ~1.5 s to leave its idle
+    power state; a cold 20-launch measurement reads 10-20 % slow and noisy)."""
+    import time
     fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps   # us
+    t_end = time.perf_counter() + ramp_s
+    while time.perf_counter() < t_end:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+    out = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) * 1e3 / reps)   # us
+    return sorted(out)[2]
 
 
 def main():
@@ -44,6 +55,8 @@ def main():
     ap.add_argument("--x6", action="store_true", help="time the f32x6 (bf16x3 split) conv kernels")
     ap.add_argument("--winograd", action="store_true", help="time the Winograd F(2x2,3x3) path for layers with cout %% 128 == 0 "
                     "(TF column = direct-convolution FLOP / time)")
+    ap.add_argument("--fused", action="store_true", help="time the ONE-launch Winograd layer (csrc/winofused.hip); TF column = "
+                    "direct-convolution FLOP / time, second figure = executed Winograd GEMM FLOP / time")
     ap.add_argument("--shape", type=str, action="append", default=[], help="extra layer: cin,cout,h,w,pool (repeatable)")
     args = ap.parse_args()
     for i, sh in enumerate(args.shape):
@@ -70,7 +83,13 @@ def main():
         oh, ow = (h // 2, w // 2) if pool else (h, w)
         y = torch.empty((oh, ow, cout), device=dev)
         wino = args.winograd and cout % 128 == 0
-        if wino:
+        fused = args.fused and cout % 32 == 0 and cin % 16 == 0
+        if fused:
+            w_oihw = torch.randn((cout, cin, 3, 3), device=dev) * 0.02
+            wf = torch.empty((16 * cout * cin,), device=dev)
+            nv.check(lib.frcnn_pack_conv3x3_winograd_fused(nv.ptr(w_oihw), None, nv.ptr(wf), cout, cin, s), "pack_winograd_fused")
+            wsb = 0
+        elif wino:
             w_oihw = torch.randn((cout, cin, 3, 3), device=dev) * 0.02
             wu = torch.empty((16, cout, cin), device=dev)
             nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w_oihw), None, nv.ptr(wu), cout, cin, s), "pack_winograd")
@@ -81,7 +100,10 @@ def main():
         flags = nv.RELU | (nv.POOL2 if pool else 0)
 
         def run():
-            if wino:
+            if fused:
+                nv.check(lib.frcnn_conv3x3_nhwc_winograd_fused(nv.ptr(x), nv.ptr(wf), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags, s),
+                         "conv_winograd_fused")
+            elif wino:
                 nv.check(lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x), nv.ptr(wu), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
                                                          nv.ptr(ws), wsb, s), "conv_winograd")
             elif args.x6:
@@ -95,7 +117,11 @@ def main():
         k = mult.get(name, 1)
         total_us += us * k
         total_fl += fl * k
-        print("%-8s %4d->%4d %4dx%-4d pool=%d splitws=%9d  %8.1f us  %6.1f TF" % (name, cin, cout, h, w, pool, wsb, us, fl / us / 1e6))
+        extra = ""
+        if fused:
+            gfl = 2.0 * 16 * ((h + 1) // 2) * ((w + 1) // 2) * cin * cout
+            extra = "  (executed %.1f TF = %.3f of 157.3)" % (gfl / us / 1e6, gfl / us / 1e6 / 157.3)
+        print("%-8s %4d->%4d %4dx%-4d pool=%d splitws=%9d  %8.1f us  %6.1f TF%s" % (name, cin, cout, h, w, pool, wsb, us, fl / us / 1e6, extra))
     if not args.only:
         print("all MFMA convs of one image (conv5_x x4 incl. RPN trunk): %.1f us, %.1f TF" % (total_us, total_fl / total_us / 1e6))
     if not args.only or "c3" in args.only:
