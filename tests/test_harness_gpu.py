@@ -167,12 +167,14 @@ try:
     assert tuple(z.shape) == (0, 4)
 finally:
     dist.destroy_process_group()
-print(json.dumps({"local": local, "merged": merged}))
+print("RESULT " + json.dumps({"local": local, "merged": merged}), flush=True)
 ''' % ROOT
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    r = json.loads(out.stdout.strip().splitlines()[-1])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]        # RCCL prints its own banner lines
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0][len("RESULT "):])
     assert r["local"] == r["merged"] and 0.0 < r["local"] <= 1.0
 
 

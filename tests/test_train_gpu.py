@@ -737,7 +737,7 @@ def test_direct_parameter_writes_between_steps_are_honoured(sd_cpu):
     `.data` writes (no version bump) need invalidate_packed(); a conflicting write while trained weights are pending raises."""
     from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
     from fasterrcnn_amd.models.vgg16 import VGG16Backbone
-    h, w, seed = 224, 320, 4
+    h, w, seed = 352, 480, 4
     img = synthetic.image(seed, h, w).unsqueeze(0).cuda()
     gts = synthetic.ground_truth(seed, h, w)
     boxes = [Box(class_index=c, class_name="x", corners=k) for c, k in gts]
