@@ -36,6 +36,7 @@ struct frcnn_ctx {
     float *anchor_map = nullptr, *valid_map = nullptr;
     float *roi_out = nullptr;                      // [max_rois][7][7][512]
     float *fc1_out = nullptr, *fc2_out = nullptr;  // [max_rois][4096]
+    void *roi_rec = nullptr, *fc1_rec = nullptr;   // x6 records of roi_out ([max_rois][25088]) and fc1_out (FRCNN_FC_F32X6)
     float *head_logits = nullptr;                  // [max_rois][128]
     void* lin_ws = nullptr; size_t lin_ws_bytes = 0;
     void* conv_ws = nullptr; size_t conv_ws_bytes = 0;   // split-K partials of under-filled conv layers
@@ -246,6 +247,21 @@ int frcnn_conv3x3_nhwc_winograd_fused(const float* d_x, const float* d_u, const 
 {
     if (!d_x || !d_u || !d_bias || !d_y || H < 1 || W < 1) return FRCNN_EINVAL;
     return launch_conv3x3_winograd_fused(d_x, d_u, d_bias, d_y, H, W, cin, cout, flags, as_stream(stream));
+}
+
+int frcnn_split_rows_x6(const float* d_a, int lda, void* d_rec, int rows, int rows_out, int K, void* stream)
+{
+    if (!d_a || !d_rec) return FRCNN_EINVAL;
+    return launch_split_rows_x6(d_a, lda, d_rec, rows, rows_out, K, as_stream(stream));
+}
+
+size_t frcnn_linear_x6_workspace_bytes(int M, int N, int K) { return linear_x6_workspace_bytes(M, N, K); }
+
+int frcnn_linear_x6(const void* d_a_rec, const void* d_w_rec, const float* d_bias, float* d_y, int ldy, void* d_y_rec,
+                    int M, int N, int K, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_a_rec || !d_w_rec || !d_bias) return FRCNN_EINVAL;
+    return launch_linear_x6(d_a_rec, d_w_rec, d_bias, d_y, ldy, d_y_rec, M, N, K, flags, d_ws, ws_bytes, as_stream(stream));
 }
 
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream)
@@ -533,6 +549,10 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         const size_t w5 = linear_workspace_bytes(c->max_fh * c->max_fw, 45, 1024);
         const size_t w6 = linear_workspace_bytes(max_rois, 128, 2048);
         lin = w1; if (w2 > lin) lin = w2; if (w3 > lin) lin = w3; if (w4 > lin) lin = w4; if (w5 > lin) lin = w5; if (w6 > lin) lin = w6;
+        const size_t x1 = linear_x6_workspace_bytes(max_rois > 320 ? 320 : max_rois, 4096, 512 * 49);
+        const size_t x2 = linear_x6_workspace_bytes(max_rois > 320 ? 320 : max_rois, 4096, 4096);
+        if (x1 > lin) lin = x1;
+        if (x2 > lin) lin = x2;
     }
     size_t cws = 0;
     {
@@ -571,6 +591,7 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         {(void**)&c->anchor_map, (size_t)c->a_cap * 16}, {(void**)&c->valid_map, (size_t)c->a_cap * 4},
         {(void**)&c->roi_out, (size_t)max_rois * 49 * 1024 * 4},
         {(void**)&c->fc1_out, (size_t)max_rois * 4096 * 4}, {(void**)&c->fc2_out, (size_t)max_rois * 4096 * 4},
+        {(void**)&c->roi_rec, (size_t)max_rois * 49 * 512 * 6}, {(void**)&c->fc1_rec, (size_t)max_rois * 4096 * 6},
         {(void**)&c->head_logits, (size_t)max_rois * 128 * 4},
         {(void**)&c->lin_ws, lin}, {(void**)&c->conv_ws, cws},
         {(void**)&c->res_buf[0], c->res_buf_floats * 4}, {(void**)&c->res_buf[1], c->res_buf_floats * 4},
@@ -714,6 +735,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32X6 && p->math_mode != FRCNN_MATH_F32_WINOGRAD)
         return FRCNN_EINVAL;
     if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
+    if (p->fc_math_mode != FRCNN_FC_F32 && p->fc_math_mode != FRCNN_FC_F32X6) return FRCNN_EINVAL;
     if (p->winograd_tile_rows != 0 && p->winograd_tile_rows != 64 && p->winograd_tile_rows != 128) return FRCNN_EINVAL;
     BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows);
     const bool x6 = p->math_mode == FRCNN_MATH_F32X6;
@@ -771,10 +793,21 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     // stage 3: detector (models/detector.py:65-80, models/vgg16.py:129-133)
     const int R_ = p->post_nms;
     STEP(4, launch_roi_pool(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
-    STEP(2, launch_linear(c->roi_out, 49 * 512, w->fc1_w, w->fc1_b, c->fc1_out, 4096, R_, 4096, 49 * 512, R,
-                          c->lin_ws, c->lin_ws_bytes, s));
-    STEP(2, launch_linear(c->fc1_out, 4096, w->fc2_w, w->fc2_b, c->fc2_out, 4096, R_, 4096, 4096, R,
-                          c->lin_ws, c->lin_ws_bytes, s));
+    if (p->fc_math_mode == FRCNN_FC_F32X6) {
+        // fc1 / fc2 on the bf16 pipe with exactly split operands: the RoI-pool output is split once, fc1's reduction emits the
+        // records fc2 consumes, fc2's the float32 rows the (exact-f32) heads consume
+        if (R_ > 320) return FRCNN_EUNSUPPORTED;
+        STEP(2, launch_split_rows_x6(c->roi_out, 49 * 512, c->roi_rec, R_, R_, 49 * 512, s));
+        STEP(2, launch_linear_x6(c->roi_rec, w->fc1_w, w->fc1_b, c->fc1_out, 4096, c->fc1_rec, R_, 4096, 49 * 512, R,
+                                 c->lin_ws, c->lin_ws_bytes, s));
+        STEP(2, launch_linear_x6(c->fc1_rec, w->fc2_w, w->fc2_b, c->fc2_out, 4096, nullptr, R_, 4096, 4096, R,
+                                 c->lin_ws, c->lin_ws_bytes, s));
+    } else {
+        STEP(2, launch_linear(c->roi_out, 49 * 512, w->fc1_w, w->fc1_b, c->fc1_out, 4096, R_, 4096, 49 * 512, R,
+                              c->lin_ws, c->lin_ws_bytes, s));
+        STEP(2, launch_linear(c->fc1_out, 4096, w->fc2_w, w->fc2_b, c->fc2_out, 4096, R_, 4096, 4096, R,
+                              c->lin_ws, c->lin_ws_bytes, s));
+    }
     const int ncls = w->num_classes, nd = (ncls - 1) * 4;
     STEP(2, launch_linear(c->fc2_out, 4096, w->head_w, w->head_b, c->head_logits, 128, R_, ncls + nd, 4096, 0u,
                           c->lin_ws, c->lin_ws_bytes, s));

@@ -113,6 +113,12 @@ int launch_pack_conv3x3_winograd_fused(const float* w, const float* scale, float
 int launch_pack_conv3x3_winograd_fused_taps(const float* wp, float* u, int cout, int cin, int data_gradient, hipStream_t s);
 int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
                                   unsigned flags, hipStream_t s);
+// linear_x6.hip: fc1 / fc2 on the bf16 pipe with exactly split operands
+bool linear_x6_shape_ok(int M, int N, int K);
+size_t linear_x6_workspace_bytes(int M, int N, int K);
+int launch_split_rows_x6(const float* a, int lda, void* rec, int R, int rows_out, int K, hipStream_t s);
+int launch_linear_x6(const void* a_rec, const void* w_rec, const float* bias, float* y, int ldy, void* y_rec, int M, int N, int K,
+                     unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_softmax_rows(const float* x, int ldx, float* y, int M, int ncls, hipStream_t s);
 int launch_head_finish(const float* x, int ldx, int M, int ncls, int ndelta, float* classes,
                        float* deltas, hipStream_t s);

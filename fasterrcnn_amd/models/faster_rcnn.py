@@ -114,6 +114,11 @@ class FasterRCNNModel(nn.Module):
         # stride-1 3x3 convolutions of layer3 / layer4 are the Winograd layers; there is no f32x6 ResNet path.
         self._math_mode = "f32"
         self.math_mode = "f32_winograd"
+        # arithmetic of the VGG-16 detector's fc1 / fc2 (models/vgg16.py:130-132): "f32" = exact f32 MFMA; "f32x6" = exactly split
+        # bf16x3 operands, six bf16 MFMAs per product, f32 accumulation (csrc/linear_x6.hip) -- fp32-class accuracy (dropped terms
+        # <= 2^-24 relative) at 2.67x the matrix-pipe rate; the default wherever it applies (ResNet heads have no fc1 / fc2)
+        self._fc_math_mode = "f32"
+        self.fc_math_mode = "f32" if self._is_resnet else "f32x6"
 
         self._train_state = None
         self._gradient_sync = None          # training.enable_data_parallel
@@ -141,6 +146,20 @@ class FasterRCNNModel(nn.Module):
         self._stage2_region_proposal_network.math_mode = mode
         if self._is_resnet:
             self._stage3_detector_network._pool_to_feature_vector.math_mode = mode
+
+    @property
+    def fc_math_mode(self):
+        return self._fc_math_mode
+
+    @fc_math_mode.setter
+    def fc_math_mode(self, mode):
+        if mode not in nv.FC_MATH_MODES:
+            raise ValueError("fc_math_mode must be one of %s" % sorted(nv.FC_MATH_MODES))
+        if mode == "f32x6" and self._is_resnet:
+            raise NotImplementedError("the ResNet detector head (layer4 + mean) has no fc1 / fc2")
+        self._fc_math_mode = mode
+        if not self._is_resnet:
+            self._stage3_detector_network._pool_to_feature_vector.fc_math_mode = mode
 
     # ------------------------------------------------------------------------------------------
     def _device(self):
@@ -264,6 +283,7 @@ class FasterRCNNModel(nn.Module):
                                   # slot 0 = one image at a time (latency); slots > 0 = many images in flight on their own
                                   # streams, where longer split-K work units give more throughput (csrc/conv.hip)
                                   0 if slot_index == 0 else self.inflight_conv_blocks_target,
+                                  0 if self._is_resnet else nv.FC_MATH_MODES[self._fc_math_mode],
                                   0 if slot_index == 0 else self.inflight_winograd_tile_rows)
         lib = nv.lib()
         with t.cuda.device(device):

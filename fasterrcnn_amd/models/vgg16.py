@@ -153,20 +153,30 @@ class PoolToFeatureVector(nn.Module):
         self._dropout2 = nn.Dropout(p=dropout_probability)
         self._packed_key = None
         self._packed = None
+        self.fc_math_mode = "f32"
+
+    def packed_direct(self):
+        """float32 packs whatever the inference arithmetic is (the train step's masters): fc1 with its input dimension permuted
+        (C,7,7) -> (7,7,C); fc2 and biases as stored."""
+        w1 = rt.as_f32_cuda(self._fc1.weight.detach(), "fc1 weight")
+        w1p = t.empty_like(w1)
+        with t.cuda.device(w1.device):
+            nv.check(nv.lib().frcnn_pack_fc_chw_to_hwc(nv.ptr(w1), nv.ptr(w1p), 4096, 512, 49, nv.stream_ptr()),
+                     "frcnn_pack_fc_chw_to_hwc")
+        return (w1p, rt.as_f32_cuda(self._fc1.bias.detach(), "fc1 bias"),
+                rt.as_f32_cuda(self._fc2.weight.detach(), "fc2 weight"),
+                rt.as_f32_cuda(self._fc2.bias.detach(), "fc2 bias"))
 
     def packed(self):
-        """fc1 with its input dimension permuted (C,7,7) -> (7,7,C); fc2 and biases as stored."""
+        """(fc1 weight, fc1 bias, fc2 weight, fc2 bias) in the layout of `fc_math_mode`: float32 matrices ("f32") or their x6
+        records (uint8 tensors of 96 B per (row, 16-k chunk): frcnn_split_rows_x6)."""
         params = [self._fc1.weight, self._fc1.bias, self._fc2.weight, self._fc2.bias]
-        key = rt.param_key(params)
+        key = (self.fc_math_mode,) + rt.param_key(params)
         if key != self._packed_key:
-            w1 = rt.as_f32_cuda(self._fc1.weight.detach(), "fc1 weight")
-            w1p = t.empty_like(w1)
-            with t.cuda.device(w1.device):
-                nv.check(nv.lib().frcnn_pack_fc_chw_to_hwc(nv.ptr(w1), nv.ptr(w1p), 4096, 512, 49, nv.stream_ptr()),
-                         "frcnn_pack_fc_chw_to_hwc")
-            self._packed = (w1p, rt.as_f32_cuda(self._fc1.bias.detach(), "fc1 bias"),
-                            rt.as_f32_cuda(self._fc2.weight.detach(), "fc2 weight"),
-                            rt.as_f32_cuda(self._fc2.bias.detach(), "fc2 bias"))
+            w1p, b1, w2, b2 = self.packed_direct()
+            if self.fc_math_mode == "f32x6":
+                w1p, w2 = split_rows_x6(w1p, rows_out=4096), split_rows_x6(w2, rows_out=4096)
+            self._packed = (w1p, b1, w2, b2)
             self._packed_key = key
         return self._packed
 
@@ -178,7 +188,38 @@ class PoolToFeatureVector(nn.Module):
         n = int(x.shape[0])
         x = x.permute(0, 2, 3, 1).contiguous().reshape(n, 49 * 512)   # layout plumbing: (C,7,7) -> (7,7,C)
         w1p, b1, w2, b2 = self.packed()
+        if w1p.dtype == t.uint8:
+            h1_rec = linear_x6(split_rows_x6(x), w1p, b1, n, 4096, 49 * 512, relu=True, want="records")
+            return linear_x6(h1_rec, w2, b2, n, 4096, 4096, relu=True, want="float32")
         return linear(linear(x, w1p, b1, 4096, relu=True), w2, b2, 4096, relu=True)
+
+
+def split_rows_x6(a, rows_out=None):
+    """float32 (R, K) CUDA matrix -> its x6 records (uint8, 96 B per (row, 16-k chunk); rows R .. rows_out-1 zero)."""
+    r, k = int(a.shape[0]), int(a.shape[1])
+    rows_out = r if rows_out is None else max(int(rows_out), r)
+    rows_out = (rows_out + 127) // 128 * 128 if rows_out != r else rows_out
+    rec = t.empty((rows_out * (k // 16) * 96,), dtype=t.uint8, device=a.device)
+    a = a.contiguous()
+    with t.cuda.device(a.device):
+        nv.check(nv.lib().frcnn_split_rows_x6(nv.ptr(a), k, nv.ptr(rec), r, rows_out, k, nv.stream_ptr()), "frcnn_split_rows_x6")
+    return rec
+
+
+def linear_x6(a_rec, w_rec, b, m, n_out, k, relu, want="float32"):
+    """y = act(a @ w.T + b) through frcnn_linear_x6 on x6 records; returns the float32 (m, n_out) tensor or y's records."""
+    dev = a_rec.device
+    if m == 0:
+        return t.empty((0, n_out), dtype=t.float32, device=dev) if want == "float32" else t.empty((0,), dtype=t.uint8, device=dev)
+    lib = nv.lib()
+    y = t.empty((m, n_out), dtype=t.float32, device=dev) if want == "float32" else None
+    y_rec = t.empty((m * (n_out // 16) * 96,), dtype=t.uint8, device=dev) if want == "records" else None
+    ws_bytes = int(lib.frcnn_linear_x6_workspace_bytes(m, n_out, k))
+    ws = t.empty((max(ws_bytes, 4) // 4,), dtype=t.float32, device=dev)
+    with t.cuda.device(dev):
+        nv.check(lib.frcnn_linear_x6(nv.ptr(a_rec), nv.ptr(w_rec), nv.ptr(b), nv.ptr(y), n_out, nv.ptr(y_rec), m, n_out, k,
+                                     nv.RELU if relu else 0, nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_linear_x6")
+    return y if want == "float32" else y_rec
 
 
 def linear(x, w, b, n_out, relu):

@@ -271,8 +271,8 @@ class VGG16TrainState(TrainState):
             raise NotImplementedError("dropout > 0 is not implemented in the train step (reference default: 0.0)")
         # clones: the inference-side packed caches are rebuilt from the parameters, these are the training masters
         self.conv = fe.packed_direct()
-        w1p, b1, w2, b2 = pv.packed()
-        self.fc1, self.fc1_b, self.fc2, self.fc2_b = w1p.clone(), b1.clone(), w2.clone(), b2.clone()
+        w1p, b1, w2, b2 = pv.packed_direct()      # float32 masters whatever arithmetic inference uses for fc1 / fc2
+        self.fc1, self.fc1_b, self.fc2, self.fc2_b = w1p, b1.clone(), w2.clone(), b2.clone()
 
     def trainable(self):
         out = {"conv%d" % i: self.conv[i][0] for i in _TRAINABLE_CONVS}

@@ -181,6 +181,18 @@ int frcnn_pack_conv3x3_winograd_fused(const float* d_w_oihw, const float* d_row_
 int frcnn_pack_conv3x3_winograd_fused_taps(const float* d_w_packed, float* d_u, int cout, int cin, int data_gradient, void* stream);
 int frcnn_conv3x3_nhwc_winograd_fused(const float* d_x, const float* d_u, const float* d_bias, float* d_y,
                                       int H, int W, int cin, int cout, unsigned flags, void* stream);
+/* Dense layer with ReLU (models/vgg16.py:130-132) in the "f32x6" arithmetic (csrc/linear_x6.hip): both operands as "x6 records"
+ * -- for a row-major float32 matrix [R][K] the record of (row, 16-k chunk) is 96 contiguous bytes [hi 16 | mid 16 | lo 16] bf16 with
+ * x = hi + mid + lo exactly -- six bf16 MFMAs per product, f32 accumulation (dropped terms <= 2^-24 relative: fp32-rounding class).
+ *   frcnn_split_rows_x6 : float32 [rows][lda] (K used columns, K % 16 == 0) -> records [rows_out][K/16][3][16]; rows beyond `rows`
+ *                         are zero (weight matrices: rows_out = N rounded up to 128).  96 * rows_out * K / 16 bytes.
+ *   frcnn_linear_x6     : y[m][n] = act(bias[n] + sum_k a[m][k] w[n][k]),  M <= 320, N % 4 == 0, K % 16 == 0, K >= 32.
+ *                         d_y float32 [M][ldy] and / or d_y_rec = the records of y for the next layer (N % 16 == 0); either may be
+ *                         NULL.  Deterministic split-K; d_ws >= frcnn_linear_x6_workspace_bytes(M, N, K). */
+int frcnn_split_rows_x6(const float* d_a, int lda, void* d_rec, int rows, int rows_out, int K, void* stream);
+size_t frcnn_linear_x6_workspace_bytes(int M, int N, int K);
+int frcnn_linear_x6(const void* d_a_rec, const void* d_w_rec, const float* d_bias, float* d_y, int ldy, void* d_y_rec,
+                    int M, int N, int K, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
 /* Stand-alone 2x2/stride-2 floor max-pool on NHWC (vgg16.py:78,82,87,92), c % 4 == 0. */
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream);
 
@@ -311,9 +323,9 @@ typedef struct frcnn_vgg16_weights {
     const float* rpn_conv_b;
     const float* rpn_head_w;   /* frcnn_pack_stack_rows(_rpn_class, _rpn_boxes) -> [128][512] */
     const float* rpn_head_b;   /* [128]                                                       */
-    const float* fc1_w;        /* frcnn_pack_fc_chw_to_hwc(_fc1) [4096][25088]                */
+    const float* fc1_w;        /* frcnn_pack_fc_chw_to_hwc(_fc1) [4096][25088]; with fc_math_mode FRCNN_FC_F32X6 its x6 records */
     const float* fc1_b;
-    const float* fc2_w;        /* [4096][4096] as stored                                      */
+    const float* fc2_w;        /* [4096][4096] as stored; with FRCNN_FC_F32X6 its x6 records  */
     const float* fc2_b;
     const float* head_w;       /* frcnn_pack_stack_rows(_classifier, _regressor) -> [128][4096] */
     const float* head_b;       /* [128]                                                       */
@@ -333,6 +345,9 @@ typedef struct frcnn_forward_params {
     int32_t conv_blocks_target; /* split-K granularity of the 3x3 layers: blocks per launch to aim for.  0 = 1280 (best
                                    latency for one image on the chip); ~320 when many images are in flight on separate
                                    streams (other images' kernels fill the tail, longer work units win) */
+    int32_t fc_math_mode;       /* VGG-16 detector fc1 / fc2: FRCNN_FC_F32 (exact f32 MFMA, fc1_w / fc2_w = float32 matrices) or FRCNN_FC_F32X6
+                                   (exactly split bf16x3 operands, six bf16 MFMAs per product, f32 accumulate: fc1_w / fc2_w = the x6
+                                   records of frcnn_split_rows_x6 over the same matrices, rows padded to a multiple of 128) */
     int32_t winograd_tile_rows; /* FRCNN_MATH_F32_WINOGRAD: row count of the batched GEMM's block tile.  0 = 64 (64 x 128 tiles, five
                                    blocks per CU: best latency for one image on the chip); 128 with many images in flight (the chip
                                    is then at its power limit and the tile with fewer operand bytes per MFMA wins) */
@@ -340,6 +355,8 @@ typedef struct frcnn_forward_params {
 #define FRCNN_MATH_F32   0
 #define FRCNN_MATH_F32X6 1
 #define FRCNN_MATH_F32_WINOGRAD 2
+#define FRCNN_FC_F32   0
+#define FRCNN_FC_F32X6 1
 
 /* d_image: float32 NCHW [3][H][W] (preprocessed as models/vgg16.py:146 prescribes).
  * d_anchor_map / d_valid_map: optional caller-provided maps (faster_rcnn.py:113-115); NULL =

@@ -149,6 +149,22 @@ def main():
             nv.check(lib.frcnn_linear(nv.ptr(a), k, nv.ptr(wt), nv.ptr(b), nv.ptr(y), n, m, n, k, nv.RELU, nv.ptr(ws), wsb, s), "linear")
         us = timeit(run, args.reps)
         print("%-8s M=%d N=%d K=%d  %8.1f us  %6.1f TF" % (name, m, n, k, us, 2.0 * m * n * k / us / 1e6))
+        if m <= 320 and n % 16 == 0 and name.startswith("fc"):
+            from fasterrcnn_amd.models import vgg16 as V
+            a_rec, w_rec = V.split_rows_x6(a), V.split_rows_x6(wt)
+            y_rec = torch.empty((m * (n // 16) * 96,), dtype=torch.uint8, device=dev)
+            wsb6 = int(lib.frcnn_linear_x6_workspace_bytes(m, n, k))
+            ws6 = torch.empty((wsb6 // 4,), device=dev)
+
+            def run6():
+                nv.check(lib.frcnn_linear_x6(nv.ptr(a_rec), nv.ptr(w_rec), nv.ptr(b), nv.ptr(y), n, nv.ptr(y_rec), m, n, k, nv.RELU,
+                                             nv.ptr(ws6), wsb6, s), "linear_x6")
+            us = timeit(run6, args.reps)
+            print("%-8s x6 (bf16x3 split, six MFMAs per product)  %8.1f us  %6.1f TF fp32-equivalent" % (name, us, 2.0 * m * n * k / us / 1e6))
+
+            def run_split():
+                nv.check(lib.frcnn_split_rows_x6(nv.ptr(a), k, nv.ptr(a_rec), m, m, k, s), "split")
+            print("%-8s split of the activations  %8.1f us" % (name, timeit(run_split, args.reps)))
 
 
 if __name__ == "__main__":
