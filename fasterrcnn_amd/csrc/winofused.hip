@@ -41,16 +41,18 @@ static constexpr int WF_HP = WF_HC / 2;                  // 17 pixels per parity
 static constexpr int WF_PS = 24;                         // floats per halo pixel in LDS
 static constexpr int WF_NPIX = WF_HR * WF_HC;            // 340
 static constexpr int WF_HALO_F = WF_NPIX * WF_PS;        // 8160 floats
-static constexpr int WF_BN = 32;                         // output channels per block
-static constexpr int WF_U_F = 4 * WF_BN * 16;            // floats per filter slab (4 positions x 32 couts x 16 channels)
+#ifndef WF_NT
+#define WF_NT 2                                          // 16-cout MFMA tiles per wave: 2 = 128 accumulator registers, two blocks per CU
+#endif
+static constexpr int WF_BN = 16 * WF_NT;                 // output channels per block
+static constexpr int WF_U_F = 4 * WF_BN * 16;            // floats per filter slab (4 positions x WF_BN couts x 16 channels)
+static constexpr int WF_NU = WF_U_F / 4 / 256;           // 16-byte filter pieces per thread per slab
 static constexpr int WF_NHP = WF_NPIX * 4;               // 16-byte halo pieces per chunk
 static constexpr int WF_NH = (WF_NHP + 255) / 256;       // 6 per thread
 #ifndef WF_ABLATE
 #define WF_ABLATE 0                                      // timing experiments only (tools/build_ablate.sh): 1 no halo LDS writes, 2 no filter
 #endif                                                   // LDS writes, 4 no halo LDS reads, 8 no filter LDS reads (after the prologue); results wrong
-#ifndef WF_HALO_BUFS
-#define WF_HALO_BUFS 2                                   // 2: no barrier at the chunk seam, 81,664 B of LDS per block (two blocks fill a CU's 160 KB)
-#endif
+#define WF_HALO_BUFS 2                                   // no barrier at the chunk seam; 81,664 B of LDS per block (two blocks fill a CU's 160 KB)
 static constexpr size_t WF_LDS_BYTES = (size_t)(WF_HALO_BUFS * WF_HALO_F + 2 * WF_U_F) * sizeof(float);
 static_assert(WF_NH == 6, "halo pieces are spread over the first three stages of a chunk, two per stage");
 
@@ -140,7 +142,7 @@ struct WfGeom { int tbx, tby, ncb, total; };
 #define WF_DSW  0x200
 
 template <bool POOL>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, WF_NT <= 2 ? 2 : 1)
 void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ bias,
                        float* __restrict__ y, int H, int W, int Cin, int Cout, int relu, WfGeom gm)
 {
@@ -182,9 +184,9 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         if (inb) h_inb |= 1u << it;
     }
     // ---- filter slab staging: 512 pieces of 16 B per slab, two per thread ------------------------------------------------
-    int u_dst[2];
+    int u_dst[WF_NU];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < WF_NU; ++it) {
         const int q = tid + 256 * it;
         const int row = q >> 2, pk = q & 3;
         u_dst[it] = row * 16 + 4 * (pk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3));
@@ -193,7 +195,7 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
     const size_t u_chunk_stride = (size_t)gm.ncb * 16 * (WF_BN * 16);
 
     f32x4 hreg[2][2];            // two pieces in flight + two waiting for their LDS write
-    f32x4 ureg[2];
+    f32x4 ureg[2][WF_NU];        // filter slab t travels in set t & 1: loaded two stages ahead, written to LDS one stage ahead
     auto load_halo_piece = [&](f32x4& dst, int it, int chunk) {
         if ((WF_ABLATE & 32) && chunk > 0) return;
         dst = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(x + (chunk << 4)) + h_src[it]);
@@ -204,23 +206,23 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(hb + h_dst[it]) = ((h_inb >> it) & 1u) ? src : zero;
     };
-    auto load_u = [&](int chunk, int i) {
+    auto load_u = [&](f32x4 (&ur)[WF_NU], int chunk, int i) {
         if ((WF_ABLATE & 16) && (chunk > 0 || i > 0)) return;
         const float* p = u_blk + (size_t)chunk * u_chunk_stride + i * WF_U_F;
-        ureg[0] = *reinterpret_cast<const f32x4*>(p);
-        ureg[1] = *reinterpret_cast<const f32x4*>(p + 1024);
+#pragma unroll
+        for (int it = 0; it < WF_NU; ++it) ur[it] = *reinterpret_cast<const f32x4*>(p + 1024 * it);
     };
-    auto store_u = [&](int buf) {
-        if ((WF_ABLATE & 2) && past_prologue) { asm volatile("" :: "v"(ureg[0]), "v"(ureg[1])); return; }
-        *reinterpret_cast<f32x4*>(ub0 + buf * WF_U_F + u_dst[0]) = ureg[0];
-        *reinterpret_cast<f32x4*>(ub0 + buf * WF_U_F + u_dst[1]) = ureg[1];
+    auto store_u = [&](int buf, const f32x4 (&ur)[WF_NU]) {
+        if ((WF_ABLATE & 2) && past_prologue) { asm volatile("" :: "v"(ur[0]), "v"(ur[1])); return; }
+#pragma unroll
+        for (int it = 0; it < WF_NU; ++it) *reinterpret_cast<f32x4*>(ub0 + buf * WF_U_F + u_dst[it]) = ur[it];
     };
 
-    f32x4 acc[16][2];
+    f32x4 acc[16][WF_NT];
 #pragma unroll
     for (int p = 0; p < 16; ++p)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < WF_NT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // operand addresses: V from patch pixel (a, b) of tile (wave, l16): halo row 2 wave + a, plane b & 1, index l16 + (b >> 1)
     const int v_off = ((4 * wave) * WF_HP + l16) * WF_PS + 4 * kq;
@@ -228,7 +230,7 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
     const int u_off = l16 * 16 + 4 * (kq ^ ((0x78 >> (2 * ((l16 >> 2) & 3))) & 3));
 
     // state carried from stage to stage: r_i of the current stage, the fragments of its first position
-    f32x4 r[4], ua[2], uc[2], v[2];
+    f32x4 r[4], uf[2][WF_NT], v[2];
     auto read_r = [&](const float* hb, int i) {           // r_i[b] = d[a1][b] -+ d[a2][b]
         if ((WF_ABLATE & 4) && past_prologue) {
 #pragma unroll
@@ -244,11 +246,11 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         }
     };
     auto make_v = [&](int j) -> f32x4 { return wf_sub(j) ? r[wf_a1(j)] - r[wf_a2(j)] : r[wf_a1(j)] + r[wf_a2(j)]; };
-    auto read_u = [&](int buf, int j, f32x4& a, f32x4& c) {
-        if ((WF_ABLATE & 8) && past_prologue) { a = a + c; c = c - a; return; }
-        const float* ub = ub0 + buf * WF_U_F + u_off + (32 * j) * 16;
-        a = *reinterpret_cast<const f32x4*>(ub);
-        c = *reinterpret_cast<const f32x4*>(ub + 16 * 16);
+    auto read_u = [&](int buf, int j, f32x4 (&f)[WF_NT]) {
+        if ((WF_ABLATE & 8) && past_prologue) { f[0] = f[0] + f[1]; f[1] = f[1] - f[0]; return; }
+        const float* ub = ub0 + buf * WF_U_F + u_off + (WF_BN * j) * 16;
+#pragma unroll
+        for (int c = 0; c < WF_NT; ++c) f[c] = *reinterpret_cast<const f32x4*>(ub + c * 16 * 16);
     };
 
     // ---- prologue ---------------------------------------------------------------------------------------------------------
@@ -256,73 +258,100 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         f32x4 h0[WF_NH];
 #pragma unroll
         for (int it = 0; it < WF_NH; ++it) load_halo_piece(h0[it], it, 0);
-        load_u(0, 0);
+        load_u(ureg[0], 0, 0);
 #pragma unroll
         for (int it = 0; it < WF_NH; ++it) store_halo_piece(halo0, h0[it], it);
-        store_u(0);
+        store_u(0, ureg[0]);
+        load_u(ureg[1], 0, 1);                           // slab 1: written to LDS in stage 0
     }
     __syncthreads();
     read_r(halo0, 0);
-    read_u(0, 0, ua[0], uc[0]);
+    read_u(0, 0, uf[0]);
     v[0] = make_v(0);
     past_prologue = true;
 
+    // the first third of chunk 1's halo (the slot of "stage 3 of the previous chunk")
+    {
+        const int c1 = nchunks > 1 ? 1 : 0;
+        load_halo_piece(hreg[1][0], 0, c1);
+        load_halo_piece(hreg[1][1], 1, c1);
+    }
+
     for (int c = 0; c < nchunks; ++c) {
-        const int cn = (c + 1) < nchunks ? c + 1 : c;    // clamped: the last chunk re-loads itself, harmlessly
+        const int cn = (c + 1) < nchunks ? c + 1 : c;    // clamped: past the last chunk the loads re-read it, harmlessly
+        const int cnn = (c + 2) < nchunks ? c + 2 : cn;
         float* const hcur = halo0 + (WF_HALO_BUFS == 2 ? (c & 1) * WF_HALO_F : 0);
         float* const hnxt = halo0 + (WF_HALO_BUFS == 2 ? ((c + 1) & 1) * WF_HALO_F : 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int buf = i & 1;                       // 4 stages per chunk: the slab buffer parity repeats every chunk
-            // next filter slab and (stages 0..2) a third of the next chunk's halo: in flight under this stage's MFMAs
-            if (i < 3) load_u(c, i + 1); else load_u(cn, 0);
-            if (i < 3) { load_halo_piece(hreg[i & 1][0], 2 * i, cn); load_halo_piece(hreg[i & 1][1], 2 * i + 1, cn); }
+            // Loads of the stage.  Filter slab s+2 (one stage of prefetch is shorter than the L2 latency when the block runs alone
+            // on its CU).  Halo of chunk c+1 in thirds: pieces (0,1) were loaded in stage 3 of the previous chunk, (2,3) and (4,5)
+            // are loaded in stages 0 and 1, each third is written to LDS one stage after its load -- so the whole halo is in LDS
+            // before the barrier of stage 2 and the rows of the NEXT position row can always be read before a stage's barrier.
+            if (i < 2) load_u(ureg[i & 1], c, i + 2); else load_u(ureg[i & 1], cn, i - 2);
+            if (i < 2) { load_halo_piece(hreg[i & 1][0], 2 * i + 2, cn); load_halo_piece(hreg[i & 1][1], 2 * i + 3, cn); }
+            if (i == 3) { load_halo_piece(hreg[1][0], 0, cnn); load_halo_piece(hreg[1][1], 1, cnn); }
             __builtin_amdgcn_sched_barrier(0);           // the loads stay at the top of the stage (hipcc sinks them to their use otherwise)
-            if (WF_HALO_BUFS == 1 && i == 3) __syncthreads();     // single halo buffer: every wave is past its last read of this chunk
             // phases 0..2: MFMAs of position j under the fragment reads / operand arithmetic of position j + 1
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int cur = j & 1, nxt = cur ^ 1;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc[4 * i + j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[cur][s], v[cur][s], acc[4 * i + j][0], 0, 0, 0);
-                    acc[4 * i + j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uc[cur][s], v[cur][s], acc[4 * i + j][1], 0, 0, 0);
-                }
-                read_u(buf, j + 1, ua[nxt], uc[nxt]);
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int cc = 0; cc < WF_NT; ++cc)
+                        acc[4 * i + j][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][cc][s], v[cur][s], acc[4 * i + j][cc], 0, 0, 0);
+                read_u(buf, j + 1, uf[nxt]);
                 v[nxt] = make_v(j + 1);
-                if (j == 2) {
-                    store_u(buf ^ 1);
-                    if (i >= 1) {
-                        store_halo_piece(hnxt, hreg[(i - 1) & 1][0], 2 * (i - 1));
-                        store_halo_piece(hnxt, hreg[(i - 1) & 1][1], 2 * (i - 1) + 1);
+                constexpr int NM = 4 * WF_NT;
+                if (j == 0) {
+                    // LDS writes early in the stage: by the barrier they have long completed
+                    store_u(buf ^ 1, ureg[(i + 1) & 1]);
+                    if (i < 3) {
+                        const int third = i;             // stage 0 writes pieces (0,1) [loaded in the previous chunk's stage 3], 1: (2,3), 2: (4,5)
+                        store_halo_piece(hnxt, hreg[(i + 1) & 1][0], 2 * third);
+                        store_halo_piece(hnxt, hreg[(i + 1) & 1][1], 2 * third + 1);
                     }
-                }
-                WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 1); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 1);
-                WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2);
-                if (j == 2) {
-                    WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1);
-                    if (i >= 1) { WF_SGB(WF_VALU, 8); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1); }
-                    else { WF_SGB(WF_MFMA, 2); }
+#pragma unroll
+                    for (int q = 0; q < WF_NT; ++q) { WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 1); }
+                    WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2);
+#pragma unroll
+                    for (int q = 0; q < WF_NU; ++q) { WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1); }
+                    if (i < 3) { WF_SGB(WF_VALU, 8); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1); }
+                    WF_SGB(WF_MFMA, NM);                 // whatever is left of the phase's MFMAs
+                } else if (j == 1) {
+#pragma unroll
+                    for (int q = 0; q < WF_NT; ++q) { WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 1); }
+                    WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2);
+                    WF_SGB(WF_MFMA, NM);
                 } else {
-                    WF_SGB(WF_MFMA, 4);
+                    // the two patch rows of the NEXT stage's position row (r is dead once V of position 3 exists)
+                    read_r(i == 3 ? hnxt : hcur, (i + 1) & 3);
+                    WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 4);
+#pragma unroll
+                    for (int q = 0; q < WF_NT; ++q) { WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 1); }
+                    WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 4); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 4);
+                    WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 8); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 8);
+                    WF_SGB(WF_MFMA, NM);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (!(WF_ABLATE & 64)) __syncthreads();
-            // phase 3: MFMAs of position 3 under the reads that open the next stage (first fragments of the next slab, the
-            // two patch rows of the next position row)
+            // phase 3: MFMAs of position 3 under the first fragments of the next filter slab and the next stage's first operand
             {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc[4 * i + 3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[1][s], v[1][s], acc[4 * i + 3][0], 0, 0, 0);
-                    acc[4 * i + 3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uc[1][s], v[1][s], acc[4 * i + 3][1], 0, 0, 0);
-                }
-                read_u(buf ^ 1, 0, ua[0], uc[0]);
-                read_r(i == 3 ? hnxt : hcur, (i + 1) & 3);
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int cc = 0; cc < WF_NT; ++cc)
+                        acc[4 * i + 3][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[1][cc][s], v[1][s], acc[4 * i + 3][cc], 0, 0, 0);
+                read_u(buf ^ 1, 0, uf[0]);
                 v[0] = make_v(0);
-                WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 2);
-                WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 2);
-                WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 8); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 8); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 4);
+                constexpr int NM = 4 * WF_NT;
+#pragma unroll
+                for (int q = 0; q < WF_NT; ++q) { WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 1); }
+                WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2);
+                WF_SGB(WF_MFMA, NM);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -335,7 +364,7 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
     const int Ho = H >> 1, Wo = W >> 1;
     if (POOL && (ty >= Ho || tx >= Wo)) return;          // floor pooling drops the odd last row / column
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < WF_NT; ++c) {
         const int co = n0 + 16 * c + 4 * kq;
         f32x4 s[2][4];
 #pragma unroll

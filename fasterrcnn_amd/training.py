@@ -81,10 +81,16 @@ def conv3x3_wgrad(x_hwc, dz_hwc, cin, cout):
     return dwp
 
 
-def winograd_bank(wp, cout, cin, data_gradient=False):
-    """Direct pack [9][cout][cin] -> Winograd F(2x2,3x3) filter bank: [16][cout][cin], or for the data gradient [16][cin][cout]
-    of the rotated, channel-transposed filter (frcnn_pack_conv3x3_winograd_taps).  Rebuilt from the master weights at every use:
-    ten 16 MB writes per step at most."""
+def winograd_bank(wp, cout, cin, data_gradient=False, fused=True):
+    """Direct pack [9][cout][cin] -> Winograd F(2x2,3x3) filter bank of the layer, or (data_gradient) of the convolution that maps
+    the output gradient to the input gradient (rotated, channel-transposed filter).  fused: the one-launch kernel's flat layout
+    (frcnn_pack_conv3x3_winograd_fused_taps), else round 1's [16][cout][cin] / [16][cin][cout] of the three-launch form.
+    Rebuilt from the master weights at every use: ten 16 MB writes per step at most."""
+    if fused:
+        u = t.empty((16 * cin * cout,), dtype=t.float32, device=wp.device)
+        nv.check(_lib().frcnn_pack_conv3x3_winograd_fused_taps(nv.ptr(wp), nv.ptr(u), cout, cin, 1 if data_gradient else 0,
+                                                               nv.stream_ptr()), "frcnn_pack_conv3x3_winograd_fused_taps")
+        return u
     u = t.empty((16, cin, cout) if data_gradient else (16, cout, cin), dtype=t.float32, device=wp.device)
     nv.check(_lib().frcnn_pack_conv3x3_winograd_taps(nv.ptr(wp), nv.ptr(u), cout, cin, 1 if data_gradient else 0, nv.stream_ptr()),
              "frcnn_pack_conv3x3_winograd_taps")
@@ -92,15 +98,15 @@ def winograd_bank(wp, cout, cin, data_gradient=False):
 
 
 def conv3x3_forward(x_hwc, wp, b, cin, cout, winograd):
-    """y = relu(conv3x3(x) + b) without pooling, on the direct kernel or (wide layers of the f32_winograd mode) as a Winograd layer."""
-    if winograd and nv.uses_winograd(cin, cout):
+    """y = relu(conv3x3(x) + b) without pooling, on the direct kernel or (f32_winograd mode) as a one-launch Winograd layer."""
+    if winograd and nv.uses_winograd_fused(cin, cout):
         wp = winograd_bank(wp, cout, cin)
     return vgg16.conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False)
 
 
 def conv3x3_dgrad(dz_hwc, wp, cin, cout, zero_bias, winograd=False):
     """Gradient with respect to the input of y = conv3x3(x, wp): a 3x3 conv of dz (cout channels) to cin channels."""
-    if winograd and nv.uses_winograd(cout, cin):
+    if winograd and nv.uses_winograd_fused(cout, cin):
         return vgg16.conv3x3(dz_hwc, winograd_bank(wp, cout, cin, data_gradient=True), zero_bias, cout, cin, relu=False, pool=False)
     wd = t.empty((9, cin, cout), dtype=t.float32, device=dz_hwc.device)
     nv.check(_lib().frcnn_pack_conv3x3_dgrad(nv.ptr(wp), nv.ptr(wd), cout, cin, nv.stream_ptr()), "frcnn_pack_conv3x3_dgrad")

@@ -147,15 +147,16 @@ def test_winograd_forward_and_data_gradient_from_the_master_pack(H, W, cin, cout
     # filter banks == numpy G g G^T of the filter / of the rotated, channel-transposed filter
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
     w64 = w.double().numpy()
-    u = T.winograd_bank(wp, cout, cin).cpu().numpy().astype(np.float64)
+    u = T.winograd_bank(wp, cout, cin, fused=False).cpu().numpy().astype(np.float64)
     ref_u = np.einsum("ia,kcab,jb->ijkc", G, w64, G).reshape(16, cout, cin)
     assert np.abs(u - ref_u).max() <= 1e-7 * np.abs(ref_u).max()
-    ud = T.winograd_bank(wp, cout, cin, data_gradient=True).cpu().numpy().astype(np.float64)
+    ud = T.winograd_bank(wp, cout, cin, data_gradient=True, fused=False).cpu().numpy().astype(np.float64)
     wrot = np.flip(w64, axis=(2, 3)).transpose(1, 0, 2, 3)                       # [cin][cout][3][3]
     ref_ud = np.einsum("ia,kcab,jb->ijkc", G, wrot, G).reshape(16, cin, cout)
     assert np.abs(ud - ref_ud).max() <= 1e-7 * np.abs(ref_ud).max()
     # forward (bias + ReLU) and data gradient against float64 / the direct kernels
-    assert nv.uses_winograd(cin, cout) and nv.uses_winograd(cout, cin) == (cin >= 256)
+    # (the one-launch kernel's banks, which the step uses, are permutations of these two: tests/test_winofused_gpu.py)
+    assert nv.uses_winograd_fused(cin, cout) and nv.uses_winograd_fused(cout, cin)
     b = torch.randn((cout,)) * 0.1
     x_hwc, dz_hwc = gpu(x[0].permute(1, 2, 0)), gpu(dz[0].permute(1, 2, 0))
     y64 = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))[0].permute(1, 2, 0).numpy()
