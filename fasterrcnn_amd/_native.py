@@ -39,6 +39,7 @@ SYMBOLS = (
     "frcnn_conv3x3_nhwc_winograd",
     "frcnn_conv3x3_uses_winograd_fused", "frcnn_resnet_block_uses_winograd_fused", "frcnn_pack_conv3x3_winograd_fused", "frcnn_pack_conv3x3_winograd_fused_taps",
     "frcnn_conv3x3_nhwc_winograd_fused", "frcnn_split_rows_x6", "frcnn_linear_x6_workspace_bytes", "frcnn_linear_x6",
+    "frcnn_roi_align", "frcnn_roi_align_backward",
     # training path
     "frcnn_label_proposals", "frcnn_gather_rows", "frcnn_rpn_loss", "frcnn_detector_loss",
     "frcnn_gemm_tn_workspace_bytes", "frcnn_gemm_tn", "frcnn_conv3x3_wgrad_workspace_bytes", "frcnn_conv3x3_wgrad",
@@ -88,7 +89,8 @@ class ResNetWeights(C.Structure):
 class ForwardParams(C.Structure):
     _fields_ = [("pre_nms", C.c_int32), ("post_nms", C.c_int32), ("rpn_nms_threshold", C.c_float),
                 ("min_side", C.c_float), ("allow_edge_proposals", C.c_int32), ("math_mode", C.c_int32),
-                ("conv_blocks_target", C.c_int32), ("fc_math_mode", C.c_int32), ("winograd_tile_rows", C.c_int32)]
+                ("conv_blocks_target", C.c_int32), ("fc_math_mode", C.c_int32), ("roi_op", C.c_int32), ("roi_sampling_ratio", C.c_int32),
+                ("winograd_tile_rows", C.c_int32)]
 
 
 # capacity limits of the kernels (validated by FasterRCNNModel with a message; the C entry points return FRCNN_EINVAL / EUNSUPPORTED)
@@ -100,6 +102,7 @@ MATH_F32 = 0      # exact f32 MFMA
 MATH_F32X6 = 1    # bf16x3 split operands, six bf16 MFMAs per product, f32 accumulate
 MATH_F32_WINOGRAD = 2   # exact f32 MFMA; 3x3 layers with uses_winograd(cin, cout) as Winograd F(2x2,3x3) in float32
 MATH_MODES = {"f32": MATH_F32, "f32x6": MATH_F32X6, "f32_winograd": MATH_F32_WINOGRAD}
+ROI_OPS = {"pool": 0, "align": 1}          # FRCNN_ROI_POOL (the reference) / FRCNN_ROI_ALIGN (torchvision roi_align semantics)
 FC_MATH_MODES = {"f32": 0, "f32x6": 1}   # FRCNN_FC_F32 / FRCNN_FC_F32X6: arithmetic of the VGG-16 detector's fc1 / fc2
 
 
@@ -149,6 +152,8 @@ _SIGNATURES = {
     "frcnn_pack_conv3x3_winograd_taps": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "frcnn_conv3x3_winograd_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "frcnn_conv3x3_nhwc_winograd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_roi_align": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i, _i, C.c_float, _i, _i, _vp, _vp]),
+    "frcnn_roi_align_backward": (C.c_int, [_vp, _i, _i, _i, _i, _i, C.c_float, _i, _i, _vp, _vp, _i, _vp]),
     "frcnn_split_rows_x6": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "frcnn_linear_x6_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "frcnn_linear_x6": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _u, _vp, _sz, _vp]),

@@ -353,6 +353,22 @@ int frcnn_roi_pool(const float* d_fm, int fh, int fw, int c, const float* d_rois
                            as_stream(stream));
 }
 
+int frcnn_roi_align(const float* d_fm, int fh, int fw, int c, const float* d_rois, const int32_t* d_n_rois, int max_rois,
+                    int pooled, float spatial_scale, int sampling_ratio, int aligned, float* d_out, void* stream)
+{
+    if (!d_fm || !d_rois || !d_n_rois || !d_out) return FRCNN_EINVAL;
+    return launch_roi_align(d_fm, fh, fw, c, d_rois, d_n_rois, max_rois, pooled, spatial_scale, sampling_ratio, aligned, d_out,
+                            as_stream(stream));
+}
+
+int frcnn_roi_align_backward(const float* d_rois, int n_rois, int fh, int fw, int c, int pooled, float spatial_scale,
+                             int sampling_ratio, int aligned, const float* d_dout, float* d_dfm, int accumulate, void* stream)
+{
+    if (!d_dfm || (n_rois > 0 && (!d_rois || !d_dout))) return FRCNN_EINVAL;
+    return launch_roi_align_backward(d_rois, n_rois, fh, fw, c, pooled, spatial_scale, sampling_ratio, aligned, d_dout, d_dfm,
+                                     accumulate, as_stream(stream));
+}
+
 int frcnn_detections(const float* d_props, const float* d_classes, const float* d_deltas,
                      const int32_t* d_n_rois, int max_rois, int ncls, int image_h, int image_w,
                      float score_threshold, float nms_threshold, double* d_out, int32_t* d_out_cnt, void* stream)
@@ -736,6 +752,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
         return FRCNN_EINVAL;
     if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
     if (p->fc_math_mode != FRCNN_FC_F32 && p->fc_math_mode != FRCNN_FC_F32X6) return FRCNN_EINVAL;
+    if ((p->roi_op != FRCNN_ROI_POOL && p->roi_op != FRCNN_ROI_ALIGN) || p->roi_sampling_ratio > 2) return FRCNN_EINVAL;
     if (p->winograd_tile_rows != 0 && p->winograd_tile_rows != 64 && p->winograd_tile_rows != 128) return FRCNN_EINVAL;
     BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows);
     const bool x6 = p->math_mode == FRCNN_MATH_F32X6;
@@ -792,7 +809,11 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
 
     // stage 3: detector (models/detector.py:65-80, models/vgg16.py:129-133)
     const int R_ = p->post_nms;
-    STEP(4, launch_roi_pool(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
+    if (p->roi_op == FRCNN_ROI_ALIGN) {
+        STEP(4, launch_roi_align(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, p->roi_sampling_ratio, 0, c->roi_out, s));
+    } else {
+        STEP(4, launch_roi_pool(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
+    }
     if (p->fc_math_mode == FRCNN_FC_F32X6) {
         // fc1 / fc2 on the bf16 pipe with exactly split operands: the RoI-pool output is split once, fc1's reduction emits the
         // records fc2 consumes, fc2's the float32 rows the (exact-f32) heads consume
@@ -879,6 +900,7 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     if (w->num_classes < 2 || w->num_classes > 26) return FRCNN_EUNSUPPORTED;
     if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32_WINOGRAD) return FRCNN_EUNSUPPORTED;   // no f32x6 ResNet path
     const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
+    if ((p->roi_op != FRCNN_ROI_POOL && p->roi_op != FRCNN_ROI_ALIGN) || p->roi_sampling_ratio > 2) return FRCNN_EINVAL;
     int nb = 0;
     for (int i = 0; i < 4; ++i) { if (w->n_blocks[i] < 1) return FRCNN_EINVAL; nb += w->n_blocks[i]; }
     if (nb > FRCNN_RESNET_MAX_BLOCKS) return FRCNN_EINVAL;
@@ -944,7 +966,11 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
 
     // stage 3: RoIPool, layer4 per RoI, spatial mean, heads (models/detector.py:65-80, resnet.py:109-118)
     const int R_ = p->post_nms;
-    STEP(4, launch_roi_pool(c->fm, fh, fw, C, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
+    if (p->roi_op == FRCNN_ROI_ALIGN) {
+        STEP(4, launch_roi_align(c->fm, fh, fw, C, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, p->roi_sampling_ratio, 0, c->roi_out, s));
+    } else {
+        STEP(4, launch_roi_pool(c->fm, fh, fw, C, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
+    }
     if ((size_t)R_ * 49 * C > c->res_buf_floats * 2) { /* roi_out is its own buffer; nothing to check */ }
     // layer4 reads its input from roi_out: stage it as res_buf "cur" by pointer swap
     float* saved = c->res_buf[0];

@@ -147,6 +147,12 @@ int launch_nms(const ProposalScratch& ps, const float* boxes, const float* score
 int launch_roi_pool(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
                     int max_rois, int pooled, float scale, float* out, hipStream_t s);
 
+// roialign.hip
+int launch_roi_align(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois, int max_rois, int pooled,
+                     float scale, int sampling_ratio, int aligned, float* out, hipStream_t s);
+int launch_roi_align_backward(const float* rois, int n_rois, int fh, int fw, int c, int pooled, float scale, int sampling_ratio,
+                              int aligned, const float* dout, float* dfm, int accumulate, hipStream_t s);
+
 int launch_rpn_targets(const float* anchor_map, const float* valid_map, int A, const float* gt, int M,
                        double obj_thr, double bg_thr, float* rpn_map, int32_t* obj_idx, int32_t* bg_idx,
                        int32_t* counts, void* ws, hipStream_t s);

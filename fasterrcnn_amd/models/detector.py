@@ -14,8 +14,17 @@ from .vgg16 import linear
 
 
 class DetectorNetwork(nn.Module):
-    def __init__(self, num_classes, backbone):
+    def __init__(self, num_classes, backbone, pooling="pool", sampling_ratio=2):
+        """pooling: "pool" = torchvision RoIPool 7x7 @ 1/16, what the reference uses (detector.py:27); "align" = RoIAlign with
+        torchvision.ops.roi_align's semantics (aligned=False, `sampling_ratio` samples per bin and axis), beyond the reference:
+        BASELINE.json's north_star names it."""
         super().__init__()
+        if pooling not in nv.ROI_OPS:
+            raise ValueError("pooling must be one of %s" % sorted(nv.ROI_OPS))
+        if pooling == "align" and int(sampling_ratio) > 2:
+            raise ValueError("sampling_ratio must be 1, 2 or <= 0 (adaptive)")
+        self.pooling = pooling
+        self.sampling_ratio = int(sampling_ratio)
         self._input_features = 7 * 7 * backbone.feature_map_channels
         self._num_classes = num_classes
         self._spatial_scale = 1.0 / backbone.feature_pixels
@@ -40,7 +49,7 @@ class DetectorNetwork(nn.Module):
         return self._packed
 
     def roi_pool(self, feature_map, proposals):
-        """RoIPool 7x7 of proposals (N,4) (y1,x1,y2,x2) over feature_map (1,C,H,W) -> (N, C, 7, 7)."""
+        """RoIPool (or, pooling="align", RoIAlign) 7x7 of proposals (N,4) (y1,x1,y2,x2) over feature_map (1,C,H,W) -> (N, C, 7, 7)."""
         fm = rt.as_f32_cuda(feature_map, "feature_map")
         props = rt.as_f32_cuda(proposals, "proposals")
         c, fh, fw = int(fm.shape[1]), int(fm.shape[2]), int(fm.shape[3])
@@ -50,8 +59,12 @@ class DetectorNetwork(nn.Module):
         if n > 0:
             cnt = t.tensor([n], dtype=t.int32, device=fm.device)
             with t.cuda.device(fm.device):
-                nv.check(nv.lib().frcnn_roi_pool(nv.ptr(x), fh, fw, c, nv.ptr(props), nv.ptr(cnt), n, 7,
-                                                 float(self._spatial_scale), nv.ptr(out), nv.stream_ptr()), "frcnn_roi_pool")
+                if self.pooling == "align":
+                    nv.check(nv.lib().frcnn_roi_align(nv.ptr(x), fh, fw, c, nv.ptr(props), nv.ptr(cnt), n, 7, float(self._spatial_scale),
+                                                      self.sampling_ratio, 0, nv.ptr(out), nv.stream_ptr()), "frcnn_roi_align")
+                else:
+                    nv.check(nv.lib().frcnn_roi_pool(nv.ptr(x), fh, fw, c, nv.ptr(props), nv.ptr(cnt), n, 7,
+                                                     float(self._spatial_scale), nv.ptr(out), nv.stream_ptr()), "frcnn_roi_pool")
         return out[:n].permute(0, 3, 1, 2)
 
     def forward(self, feature_map, proposals):

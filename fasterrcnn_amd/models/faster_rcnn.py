@@ -68,7 +68,11 @@ class FasterRCNNModel(nn.Module):
         detector_regression: float
         total: float
 
-    def __init__(self, num_classes, backbone, rpn_minibatch_size=256, proposal_batch_size=128, allow_edge_proposals=True):
+    def __init__(self, num_classes, backbone, rpn_minibatch_size=256, proposal_batch_size=128, allow_edge_proposals=True,
+                 roi_pooling="pool", roi_sampling_ratio=2):
+        """The reference's arguments (faster_rcnn.py:36) plus, keyword-only in spirit, the pooling operator of the detector stage:
+        roi_pooling="pool" is the reference's RoIPool; "align" is RoIAlign (torchvision.ops.roi_align semantics, aligned=False,
+        roi_sampling_ratio samples per bin and axis) for inference AND the train step -- BASELINE.json configs[4]."""
         super().__init__()
         # capacity limits of the kernels behind this class (csrc/api.hip, csrc/detect.hip); the reference has none, so
         # they are refused here with their reason instead of as a bare error code from the first forward
@@ -95,7 +99,8 @@ class FasterRCNNModel(nn.Module):
         self._stage1_feature_extractor = backbone.feature_extractor
         self._stage2_region_proposal_network = rpn.RegionProposalNetwork(
             feature_map_channels=backbone.feature_map_channels, allow_edge_proposals=allow_edge_proposals)
-        self._stage3_detector_network = detector.DetectorNetwork(num_classes=num_classes, backbone=backbone)
+        self._stage3_detector_network = detector.DetectorNetwork(num_classes=num_classes, backbone=backbone, pooling=roi_pooling,
+                                                                 sampling_ratio=roi_sampling_ratio)
 
         # Inference hyper-parameters (test-time values, faster_rcnn.py:124-125; rpn.py:142,150; :219)
         self.max_proposals_pre_nms = 6000
@@ -284,6 +289,7 @@ class FasterRCNNModel(nn.Module):
                                   # streams, where longer split-K work units give more throughput (csrc/conv.hip)
                                   0 if slot_index == 0 else self.inflight_conv_blocks_target,
                                   0 if self._is_resnet else nv.FC_MATH_MODES[self._fc_math_mode],
+                                  nv.ROI_OPS[self._stage3_detector_network.pooling], self._stage3_detector_network.sampling_ratio,
                                   0 if slot_index == 0 else self.inflight_winograd_tile_rows)
         lib = nv.lib()
         with t.cuda.device(device):

@@ -684,8 +684,13 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
             # ---- stage 3 forward (detector.py:65-80) ------------------------------------------------
             roi_out = t.empty((S, 49 * C), dtype=t.float32, device=dev)
             cnt = t.tensor([S], dtype=t.int32, device=dev)
-            nv.check(lib.frcnn_roi_pool(nv.ptr(fm), fh, fw, C, nv.ptr(s_props), nv.ptr(cnt), S, 7, 1.0 / 16.0,
-                                        nv.ptr(roi_out), s), "frcnn_roi_pool")
+            dn = model._stage3_detector_network
+            if dn.pooling == "align":
+                nv.check(lib.frcnn_roi_align(nv.ptr(fm), fh, fw, C, nv.ptr(s_props), nv.ptr(cnt), S, 7, 1.0 / 16.0, dn.sampling_ratio, 0,
+                                             nv.ptr(roi_out), s), "frcnn_roi_align")
+            else:
+                nv.check(lib.frcnn_roi_pool(nv.ptr(fm), fh, fw, C, nv.ptr(s_props), nv.ptr(cnt), S, 7, 1.0 / 16.0,
+                                            nv.ptr(roi_out), s), "frcnn_roi_pool")
             vec, hsaved = st.head_forward(roi_out)
             logits = vgg16.linear(vec, st.head, st.head_b, ncls + nd, relu=False)
             classes = t.empty((S, ncls), dtype=t.float32, device=dev)
@@ -700,10 +705,14 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
             dvec = gemm_tn(dl_t, sp, st.head, V, S, V, 128)
             droi = st.head_backward(dvec, hsaved, grads, detail)
             dfm = t.empty((fh, fw, C), dtype=t.float32, device=dev)
-            wsb = int(lib.frcnn_roi_pool_backward_workspace_bytes(S, 7, C))
-            ws = _ws(wsb, dev)
-            nv.check(lib.frcnn_roi_pool_backward(nv.ptr(fm), fh, fw, C, nv.ptr(s_props), S, 7, 1.0 / 16.0, nv.ptr(droi),
-                                                 nv.ptr(dfm), 0, nv.ptr(ws), wsb, s), "frcnn_roi_pool_backward")
+            if dn.pooling == "align":
+                nv.check(lib.frcnn_roi_align_backward(nv.ptr(s_props), S, fh, fw, C, 7, 1.0 / 16.0, dn.sampling_ratio, 0, nv.ptr(droi),
+                                                      nv.ptr(dfm), 0, s), "frcnn_roi_align_backward")
+            else:
+                wsb = int(lib.frcnn_roi_pool_backward_workspace_bytes(S, 7, C))
+                ws = _ws(wsb, dev)
+                nv.check(lib.frcnn_roi_pool_backward(nv.ptr(fm), fh, fw, C, nv.ptr(s_props), S, 7, 1.0 / 16.0, nv.ptr(droi),
+                                                     nv.ptr(dfm), 0, nv.ptr(ws), wsb, s), "frcnn_roi_pool_backward")
             if detail is not None:
                 detail.update(sampled_props=s_props, sampled_onehot=s_onehot, sampled_deltas=s_deltas, classes=classes,
                               deltas=deltas, dlogits=dlogits, vec=vec, roi_out=roi_out, dfm_roi=dfm.clone(), droi=droi)

@@ -285,6 +285,16 @@ int frcnn_nms(frcnn_ctx* ctx, const float* d_boxes, const float* d_scores, int n
 int frcnn_roi_pool(const float* d_fm, int fh, int fw, int c, const float* d_rois,
                    const int32_t* d_n_rois, int max_rois, int pooled, float spatial_scale,
                    float* d_out, void* stream);
+/* RoIAlign with torchvision.ops.roi_align's semantics (csrc/roialign.hip) -- the pooling BASELINE.json's north_star names; the
+ * reference pools with RoIPool (models/detector.py:16,27), so this is an option beyond it (DetectorNetwork(pooling="align")).
+ * Same tensors as frcnn_roi_pool; sampling_ratio = samples per bin and axis (1 or 2; <= 0: adaptive ceil(roi_size / pooled)),
+ * aligned = the half-pixel shift of torchvision's `aligned=True`.  float32, the operation order of torchvision's kernel.
+ * frcnn_roi_align_backward: d_dfm [fh][fw][c] (+)= gradient of d_dout [n_rois][pooled][pooled][c] with respect to the feature
+ * map, gathered per cell in a fixed order (deterministic; torchvision scatters with atomicAdd).  pooled <= 14. */
+int frcnn_roi_align(const float* d_fm, int fh, int fw, int c, const float* d_rois, const int32_t* d_n_rois, int max_rois,
+                    int pooled, float spatial_scale, int sampling_ratio, int aligned, float* d_out, void* stream);
+int frcnn_roi_align_backward(const float* d_rois, int n_rois, int fh, int fw, int c, int pooled, float spatial_scale,
+                             int sampling_ratio, int aligned, const float* d_dout, float* d_dfm, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Final detections.  Replaces models/faster_rcnn.py:179-224 (the numpy float64 decode with
@@ -348,6 +358,9 @@ typedef struct frcnn_forward_params {
     int32_t fc_math_mode;       /* VGG-16 detector fc1 / fc2: FRCNN_FC_F32 (exact f32 MFMA, fc1_w / fc2_w = float32 matrices) or FRCNN_FC_F32X6
                                    (exactly split bf16x3 operands, six bf16 MFMAs per product, f32 accumulate: fc1_w / fc2_w = the x6
                                    records of frcnn_split_rows_x6 over the same matrices, rows padded to a multiple of 128) */
+    int32_t roi_op;             /* FRCNN_ROI_POOL (the reference: torchvision RoIPool, models/detector.py:27) or FRCNN_ROI_ALIGN
+                                   (torchvision roi_align semantics, aligned = 0) */
+    int32_t roi_sampling_ratio; /* FRCNN_ROI_ALIGN: samples per bin and axis (1 or 2; <= 0 adaptive); ignored for FRCNN_ROI_POOL */
     int32_t winograd_tile_rows; /* FRCNN_MATH_F32_WINOGRAD: row count of the batched GEMM's block tile.  0 = 64 (64 x 128 tiles, five
                                    blocks per CU: best latency for one image on the chip); 128 with many images in flight (the chip
                                    is then at its power limit and the tile with fewer operand bytes per MFMA wins) */
@@ -355,6 +368,8 @@ typedef struct frcnn_forward_params {
 #define FRCNN_MATH_F32   0
 #define FRCNN_MATH_F32X6 1
 #define FRCNN_MATH_F32_WINOGRAD 2
+#define FRCNN_ROI_POOL  0
+#define FRCNN_ROI_ALIGN 1
 #define FRCNN_FC_F32   0
 #define FRCNN_FC_F32X6 1
 

@@ -247,6 +247,104 @@ def roi_pool(feature_map, rois_xyxy, output_size, spatial_scale):
     return out
 
 
+def roi_align_weights(h, w, roi_xyxy, output_size, spatial_scale, sampling_ratio=2, aligned=False):
+    """
+    The sampling plan of torchvision.ops.roi_align for ONE roi (x1, y1, x2, y2) on an h x w map, float32 arithmetic in the
+    operation order of torchvision 0.15's roi_align_kernel.cpp (third party, absent here: restated from its published
+    algorithm -- parity unpinned, like nms / RoIPool):
+      offset = 0.5 if aligned else 0;  start = coord * scale - offset;  size = end - start (clamped to >= 1 unless aligned);
+      bin = size / out;  grid = sampling_ratio if > 0 else ceil(size / out);  count = max(grid_h * grid_w, 1);
+      sample (ph, pw, iy, ix) at y = start_h + ph * bin_h + (iy + .5) * bin_h / grid_h (x alike);
+      bilinear_interpolate: outside [-1, H] x [-1, W] -> 0; clamp to >= 0; low = int(y); at the last row / column low = high = H - 1
+      and y = low; weights hy hx, hy lx, ly hx, ly lx.
+    Returns (grid_h, grid_w, count, list over (ph, pw) of lists of (y_low, x_low, y_high, x_high, w1, w2, w3, w4)).
+    """
+    f = np.float32
+    scale = f(spatial_scale)
+    offset = f(0.5) if aligned else f(0.0)
+    x1, y1, x2, y2 = (f(v) for v in roi_xyxy)
+    start_w, start_h = x1 * scale - offset, y1 * scale - offset
+    end_w, end_h = x2 * scale - offset, y2 * scale - offset
+    roi_w, roi_h = end_w - start_w, end_h - start_h
+    if not aligned:
+        roi_w, roi_h = max(roi_w, f(1.0)), max(roi_h, f(1.0))
+    bin_h, bin_w = roi_h / f(output_size), roi_w / f(output_size)
+    grid_h = int(sampling_ratio) if sampling_ratio > 0 else int(np.ceil(roi_h / f(output_size)))
+    grid_w = int(sampling_ratio) if sampling_ratio > 0 else int(np.ceil(roi_w / f(output_size)))
+    count = max(grid_h * grid_w, 1)
+    plan = []
+    for ph in range(output_size):
+        for pw in range(output_size):
+            samples = []
+            for iy in range(grid_h):
+                y = start_h + f(ph) * bin_h + (f(iy) + f(0.5)) * bin_h / f(grid_h)
+                for ix in range(grid_w):
+                    x = start_w + f(pw) * bin_w + (f(ix) + f(0.5)) * bin_w / f(grid_w)
+                    yy, xx = y, x
+                    if yy < f(-1.0) or yy > f(h) or xx < f(-1.0) or xx > f(w):
+                        continue                                  # contributes 0
+                    yy, xx = max(yy, f(0.0)), max(xx, f(0.0))
+                    y_low, x_low = int(yy), int(xx)
+                    if y_low >= h - 1:
+                        y_high = y_low = h - 1
+                        yy = f(y_low)
+                    else:
+                        y_high = y_low + 1
+                    if x_low >= w - 1:
+                        x_high = x_low = w - 1
+                        xx = f(x_low)
+                    else:
+                        x_high = x_low + 1
+                    ly, lx = yy - f(y_low), xx - f(x_low)
+                    hy, hx = f(1.0) - ly, f(1.0) - lx
+                    samples.append((y_low, x_low, y_high, x_high, hy * hx, hy * lx, ly * hx, ly * lx))
+            plan.append(samples)
+    return grid_h, grid_w, count, plan
+
+
+def roi_align(feature_map, rois_xyxy, output_size, spatial_scale, sampling_ratio=2, aligned=False):
+    """
+    torchvision.ops.roi_align(input NCHW (1,C,H,W), rois (K,5) = (batch, x1, y1, x2, y2), output_size, spatial_scale,
+    sampling_ratio, aligned) restated (see roi_align_weights).  float32: per bin the samples' values
+    w1 v1 + w2 v2 + w3 v3 + w4 v4 are summed in (iy, ix) order and divided by count.  Returns (K, C, out, out) float32.
+    Beyond the reference, which uses RoIPool (models/detector.py:16,27): BASELINE.json's north_star names RoIAlign.
+    """
+    fm = np.asarray(feature_map, dtype=np.float32)
+    assert fm.shape[0] == 1
+    fm = fm[0]
+    c, h, w = fm.shape
+    rois = np.asarray(rois_xyxy, dtype=np.float32)
+    k = rois.shape[0]
+    out = np.zeros((k, c, output_size, output_size), dtype=np.float32)
+    for r in range(k):
+        _, _, count, plan = roi_align_weights(h, w, rois[r, 1:5], output_size, spatial_scale, sampling_ratio, aligned)
+        for b, samples in enumerate(plan):
+            acc = np.zeros((c,), dtype=np.float32)
+            for (yl, xl, yh, xh, w1, w2, w3, w4) in samples:
+                acc = acc + (w1 * fm[:, yl, xl] + w2 * fm[:, yl, xh] + w3 * fm[:, yh, xl] + w4 * fm[:, yh, xh])
+            out[r, :, b // output_size, b % output_size] = acc / np.float32(count)
+    return out
+
+
+def roi_align_backward(grad_out, fm_shape, rois_xyxy, output_size, spatial_scale, sampling_ratio=2, aligned=False):
+    """Gradient of roi_align with respect to the feature map (float64 accumulation: the truth the kernel's float32 sum is held to).
+    grad_out (K, C, out, out) -> (1, C, H, W)."""
+    _, c, h, w = fm_shape
+    g = np.asarray(grad_out, dtype=np.float64)
+    rois = np.asarray(rois_xyxy, dtype=np.float32)
+    d = np.zeros((c, h, w), dtype=np.float64)
+    for r in range(rois.shape[0]):
+        _, _, count, plan = roi_align_weights(h, w, rois[r, 1:5], output_size, spatial_scale, sampling_ratio, aligned)
+        for b, samples in enumerate(plan):
+            gb = g[r, :, b // output_size, b % output_size] / count
+            for (yl, xl, yh, xh, w1, w2, w3, w4) in samples:
+                d[:, yl, xl] += float(w1) * gb
+                d[:, yl, xh] += float(w2) * gb
+                d[:, yh, xl] += float(w3) * gb
+                d[:, yh, xh] += float(w4) * gb
+    return d[None]
+
+
 # ------------------------------------------------------------------------------------------------
 # network stages on torch-CPU (the same ATen ops the reference calls)
 # ------------------------------------------------------------------------------------------------
@@ -393,12 +491,16 @@ def pool_to_feature_vector(sd, rois):
     return F.relu(F.linear(y, sd[p + "_fc2.weight"], sd[p + "_fc2.bias"]))
 
 
-def detector_forward(sd, feature_map, proposals, detail=None):
-    """detector.py:65-80: RoIPool 7x7 @ 1/16 -> fc1, fc2 -> softmax classes, box deltas."""
+def detector_forward(sd, feature_map, proposals, detail=None, roi_pooling="pool", sampling_ratio=2):
+    """detector.py:65-80: RoIPool 7x7 @ 1/16 -> fc1, fc2 -> softmax classes, box deltas.
+    roi_pooling="align" (beyond the reference): torchvision roi_align semantics instead of RoIPool."""
     props = proposals.numpy() if isinstance(proposals, t.Tensor) else np.asarray(proposals)
     rois = np.zeros((props.shape[0], 5), dtype=np.float32)
     rois[:, 1:] = props[:, [1, 0, 3, 2]]                             # (y1,x1,y2,x2) -> (x1,y1,x2,y2), :69
-    pooled = t.from_numpy(roi_pool(feature_map.numpy(), rois, 7, 1.0 / 16.0))
+    if roi_pooling == "align":
+        pooled = t.from_numpy(roi_align(feature_map.numpy(), rois, 7, 1.0 / 16.0, sampling_ratio, False))
+    else:
+        pooled = t.from_numpy(roi_pool(feature_map.numpy(), rois, 7, 1.0 / 16.0))
     y = resnet_pool_to_feature_vector(sd, pooled) if is_resnet(sd) else pool_to_feature_vector(sd, pooled)
     logits = F.linear(y, sd[_S3 + "_classifier.weight"], sd[_S3 + "_classifier.bias"])
     classes = F.softmax(logits, dim=1)
@@ -411,7 +513,7 @@ def detector_forward(sd, feature_map, proposals, detail=None):
 
 
 def forward(sd, image, anchor_map=None, anchor_valid_map=None, allow_edge_proposals=True,
-            pre_nms=6000, post_nms=300, detail=None):
+            pre_nms=6000, post_nms=300, detail=None, roi_pooling="pool", sampling_ratio=2):
     """faster_rcnn.py:80-132.  image: torch float32 (1,3,H,W) on CPU."""
     assert image.shape[0] == 1
     image_shape = tuple(image.shape[1:])
@@ -425,7 +527,7 @@ def forward(sd, image, anchor_map=None, anchor_valid_map=None, allow_edge_propos
         fm = resnet_features(sd, image) if is_resnet(sd) else vgg16_features(sd, image)
         _, _, proposals = rpn_forward(sd, fm, image_shape, anchor_map, anchor_valid_map, pre_nms, post_nms,
                                       allow_edge_proposals, detail)
-        classes, deltas = detector_forward(sd, fm, proposals, detail)
+        classes, deltas = detector_forward(sd, fm, proposals, detail, roi_pooling, sampling_ratio)
     if detail is not None:
         detail["feature_map"] = fm
     return proposals, classes, deltas

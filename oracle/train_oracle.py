@@ -245,6 +245,28 @@ def roi_pool_autograd(feature_map, proposals):
     return RoIPoolFunction.apply(feature_map, rois, 7, 1.0 / 16.0)
 
 
+class RoIAlignFunction(t.autograd.Function):
+    """torchvision.ops.roi_align(input (1,C,H,W), rois (K,5), 7, scale, sampling_ratio, aligned=False): forward and the gradient
+    with respect to the input through the oracle's restatement (orc.roi_align / orc.roi_align_backward; float64 accumulation in
+    the backward).  Beyond the reference, which trains with RoIPool."""
+    @staticmethod
+    def forward(ctx, inp, rois, output_size, spatial_scale, sampling_ratio):
+        ctx.meta = (tuple(inp.shape), rois.numpy().copy(), output_size, spatial_scale, sampling_ratio)
+        return t.from_numpy(orc.roi_align(inp.detach().numpy(), rois.numpy(), output_size, spatial_scale, sampling_ratio, False))
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        shape, rois, output_size, spatial_scale, sampling_ratio = ctx.meta
+        d = orc.roi_align_backward(grad_out.numpy(), shape, rois, output_size, spatial_scale, sampling_ratio, False)
+        return t.from_numpy(d.astype(np.float32)), None, None, None, None
+
+
+def roi_align_autograd(feature_map, proposals, sampling_ratio=2):
+    rois = t.zeros((proposals.shape[0], 5), dtype=t.float32)
+    rois[:, 1:] = proposals[:, [1, 0, 3, 2]]
+    return RoIAlignFunction.apply(feature_map, rois, 7, 1.0 / 16.0, sampling_ratio)
+
+
 # ---- the step ---------------------------------------------------------------------------------------
 def vgg16_features_train(p, image, detail=None):
     y = image
@@ -259,7 +281,8 @@ def vgg16_features_train(p, image, detail=None):
 
 def train_step(sd, image, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_object_indices, gt_rpn_background_indices,
                gt_corners, gt_class_idx, num_classes, lr, momentum, weight_decay, momentum_buffers=None,
-               rpn_minibatch_size=256, proposal_batch_size=128, allow_edge_proposals=True, detail=None):
+               rpn_minibatch_size=256, proposal_batch_size=128, allow_edge_proposals=True, detail=None, roi_pooling="pool",
+               sampling_ratio=2):
     """
     faster_rcnn.py:228-362 for the VGG-16 backbone (dropout 0) followed by SGD.step().
     sd: state_dict of float32 CPU tensors (not modified).  Returns (losses dict, grads dict, new_sd, buffers).
@@ -289,7 +312,7 @@ def train_step(sd, image, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_objec
     if detail is not None:
         detail["sampled"] = (props.clone(), gt_classes.clone(), gt_box_deltas.clone())
     # stage 3 (detector.py:65-80)
-    pooled = roi_pool_autograd(fm, props)
+    pooled = roi_align_autograd(fm, props, sampling_ratio) if roi_pooling == "align" else roi_pool_autograd(fm, props)
     if resnet:
         h1 = None
         h2 = orc.resnet_pool_to_feature_vector(p, pooled)                     # layer4 + mean (resnet.py:109-118)
