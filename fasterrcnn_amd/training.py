@@ -297,10 +297,13 @@ class VGG16TrainState(TrainState):
         pv._fc2.weight.copy_(self.fc2)
 
     # ---- stage 1 (vgg16.py:76-96) -------------------------------------------------------------------------
-    def features_forward(self, image):
+    def features_forward(self, image, inject=None):
+        """inject (parity tests only): {"conv<i>": HWC tensor} replaces the post-ReLU output of trainable conv i by the given
+        activations (an oracle's), "conv4_in" the input of conv3_1: the backward then runs on prescribed ReLU / max-pool masks."""
         lib = _lib()
         H, W = int(image.shape[2]), int(image.shape[3])
         x_in, y_out = {}, {}
+        inject = inject or {}
         cur = t.empty((H, W, 64), dtype=t.float32, device=self.device)
         nv.check(lib.frcnn_conv3x3_c3(nv.ptr(image), nv.ptr(self.conv[0][0]), nv.ptr(self.conv[0][1]), nv.ptr(cur), H, W, 64,
                                       nv.RELU, nv.stream_ptr()), "frcnn_conv3x3_c3")
@@ -308,8 +311,11 @@ class VGG16TrainState(TrainState):
             _, cin, cout, pool = vgg16._LAYERS[i]
             wp, b = self.conv[i]
             if i in _TRAINABLE_CONVS:
+                if ("conv%d_in" % i) in inject:
+                    cur = inject["conv%d_in" % i]
                 x_in[i] = cur
                 y = conv3x3_forward(cur, wp, b, cin, cout, self.winograd)
+                y = inject.get("conv%d" % i, y)
                 y_out[i] = y
                 cur = maxpool2x2(y) if pool else y
             else:
@@ -328,9 +334,14 @@ class VGG16TrainState(TrainState):
                 g = maxpool2x2_backward(y_out[i - 1], gx) if (i - 1) in _POOL_AFTER else gx
 
     # ---- RoI features -> feature vector (vgg16.py:129-133) ------------------------------------------------
-    def head_forward(self, roi_out):
-        h1 = vgg16.linear(roi_out, self.fc1, self.fc1_b, 4096, relu=True)
-        h2 = vgg16.linear(h1, self.fc2, self.fc2_b, 4096, relu=True)
+    def head_forward(self, roi_out, inject=None):
+        inject = inject or {}
+        h1 = inject.get("fc1", None)
+        if h1 is None:
+            h1 = vgg16.linear(roi_out, self.fc1, self.fc1_b, 4096, relu=True)
+        h2 = inject.get("fc2", None)
+        if h2 is None:
+            h2 = vgg16.linear(h1, self.fc2, self.fc2_b, 4096, relu=True)
         return h2, (roi_out, h1, h2)
 
     def head_backward(self, dh2, saved, grads, detail=None):
@@ -615,11 +626,16 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
     with t.no_grad(), t.cuda.device(dev):
         s = nv.stream_ptr()
         # ---- stage 1 forward, keeping what the backward needs ------------------------------------------
-        fm, fsaved = st.features_forward(image)                                        # [fh][fw][C]
+        # parity-test hook: detail["inject"] prescribes forward activations (see VGG16TrainState.features_forward)
+        inject = (detail or {}).get("inject") or {}
+        if inject and not isinstance(st, VGG16TrainState):
+            raise NotImplementedError("activation injection is implemented for the VGG-16 train state")
+        fm, fsaved = st.features_forward(image, inject) if inject else st.features_forward(image)   # [fh][fw][C]
         fh, fw = int(fm.shape[0]), int(fm.shape[1])
         P = fh * fw
         # ---- stage 2 forward (rpn.py:88-156, 12000 / 2000 in training: faster_rcnn.py:301-302) --------
         trunk = conv3x3_forward(fm, st.rpn_conv, st.rpn_conv_b, C, C, st.winograd)
+        trunk = inject.get("rpn_trunk", trunk)
         head = t.zeros((P, 128), dtype=t.float32, device=dev)
         wsb = int(lib.frcnn_linear_workspace_bytes(P, 45, C))
         ws = _ws(wsb, dev)
@@ -691,7 +707,8 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
             else:
                 nv.check(lib.frcnn_roi_pool(nv.ptr(fm), fh, fw, C, nv.ptr(s_props), nv.ptr(cnt), S, 7, 1.0 / 16.0,
                                             nv.ptr(roi_out), s), "frcnn_roi_pool")
-            vec, hsaved = st.head_forward(roi_out)
+            roi_out = inject.get("roi_out", roi_out)
+            vec, hsaved = st.head_forward(roi_out, inject) if inject else st.head_forward(roi_out)
             logits = vgg16.linear(vec, st.head, st.head_b, ncls + nd, relu=False)
             classes = t.empty((S, ncls), dtype=t.float32, device=dev)
             nv.check(lib.frcnn_softmax_rows(nv.ptr(logits), ncls + nd, nv.ptr(classes), S, ncls, s), "frcnn_softmax_rows")

@@ -153,7 +153,9 @@ def test_forward_matches_reference_golden(gpu_model, model_edge_off, golden_dir,
     j, err = match_rows(ours, g["proposals"])
     ok = err <= 1e-3
     print("forward %s: %.1f%% of the reference's proposals reproduced within 1e-3 px" % (tag, 100 * ok.mean()))
-    assert ok.mean() >= 0.95
+    # the gate is what is observed: every proposal of the two smaller cases, 299 of 300 at 600x1000 (one pair of
+    # RPN scores closer than two float32 implementations can resolve swaps at the NMS cut)
+    assert ok.mean() >= (0.996 if tag == "600x1000_s0" else 1.0)
     # on the matched rows the detector outputs agree
     c_err = np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max()
     d_err = np.abs(deltas.cpu().numpy()[j[ok]] - g["box_deltas"][ok]).max()
@@ -191,7 +193,8 @@ def test_predict_matches_reference_golden(gpu_model, model_edge_off, golden_dir,
     n_ours = sum(len(v) for v in det.values())
     print("predict %s: %d/%d reference detections reproduced within 1e-3 px / 1e-4 score (ours: %d rows, worst %.3g px)" % (
         tag, n_ok, n_ref, n_ours, worst))
-    assert n_ok >= 0.95 * n_ref and abs(n_ours - n_ref) <= max(3, 0.05 * n_ref)
+    # observed and therefore required in the default mode: EVERY reference detection (194 / 163 / 155), no extra rows
+    assert n_ok == n_ref and n_ours == n_ref
 
 
 def test_predict_on_oracle_forward_outputs_is_exact(golden_dir, oracle_runs):
@@ -330,7 +333,7 @@ def test_other_math_modes_end_to_end(gpu_model, golden_dir, oracle_runs, tag, al
         j, e = match_rows(props.cpu().numpy(), g["proposals"])
         ok = e <= 1e-3
         print("%s forward %s: %.1f%% of the reference's proposals within 1e-3 px" % (mode, tag, 100 * ok.mean()))
-        assert props.shape[0] == g["proposals"].shape[0] and ok.mean() >= 0.95
+        assert props.shape[0] == g["proposals"].shape[0] and ok.mean() >= 0.985
         assert np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max() <= 1e-4
         det = gpu_model.predict(image_data=img.cuda(), score_threshold=float(g["score_threshold"]))
         refd = g["detections"]
@@ -341,7 +344,9 @@ def test_other_math_modes_end_to_end(gpu_model, golden_dir, oracle_runs, tag, al
                 jj, ee = match_rows(det[c], r)
                 n_ok += int(((ee <= 1e-3) & (np.abs(det[c][jj, 4] - r[:, 4]) <= 1e-4)).sum())
         print("%s predict %s: %d/%d reference detections reproduced" % (mode, tag, n_ok, len(refd)))
-        assert n_ok >= 0.95 * len(refd)
+        # f32x6 reproduces every detection; the all-direct f32 mode is allowed the 3 of 194 that round 1 documented as its
+        # inherent RPN-rank flips at 600x1000 (194/194 with the round-2 kernels, 191/194 with round 1's)
+        assert n_ok >= len(refd) - (3 if mode == "f32" else 0)
     finally:
         gpu_model.math_mode = "f32_winograd"
     with pytest.raises(ValueError):

@@ -614,6 +614,42 @@ def test_train_step_full_size_is_deterministic_and_learns(sd_cpu):
     assert len(changed) == 16 and all("weight" in k for k in changed)        # 9 convs + 3 RPN + fc1 fc2 + 2 heads; no bias
 
 
+@pytest.mark.parametrize("roi_pooling", ["pool", "align"])
+def test_resnet101_train_step_full_size_is_deterministic_and_learns(roi_pooling):
+    """BASELINE configs[4]'s model at its size: ResNet-101, 600x1000, batch 1 (fp32; RoIPool as the reference trains, and RoIAlign):
+    four steps run twice from the same seeds -> bit-identical losses and weights, finite; the loss falls; exactly the conv weights
+    of layer2-4 + RPN + heads move (every BatchNorm and conv1 / layer1 frozen: resnet.py:48-55,86,123)."""
+    from fasterrcnn_amd.models import resnet
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    h, w, seed = 600, 1000, 2
+    sd0 = synthetic.resnet_state_dict(1234, "ResNet101")
+    img = synthetic.image_rgb(seed, h, w).unsqueeze(0).cuda()
+    gts = synthetic.ground_truth(seed, h, w)
+    boxes = [Box(class_index=c, class_name="x", corners=k) for c, k in gts]
+    am, vm = O.generate_anchor_maps((3, h, w), (1024, -(-h // 16), -(-w // 16)), 16)
+    rmap, obj, bg = O.generate_rpn_map(am, vm, np.stack([k for _, k in gts]))
+    rmap_t = torch.from_numpy(rmap).unsqueeze(0).cuda()
+    runs = []
+    for _ in range(2):
+        model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet101), roi_pooling=roi_pooling)
+        model.load_state_dict(sd0, strict=True)
+        model = model.cuda()
+        opt = T.create_optimizer(model, learning_rate=3e-6)
+        random.seed(5); torch.manual_seed(5)
+        losses = [model.train_step(opt, img, am, vm, rmap_t, [obj], [bg], [boxes]) for _ in range(4)]
+        runs.append((losses, {k: v.clone() for k, v in model.state_dict().items()}))
+    (l0, s0), (l1, s1) = runs
+    assert [x.total for x in l0] == [x.total for x in l1]
+    assert all(np.isfinite([x.rpn_class, x.rpn_regression, x.detector_class, x.detector_regression, x.total]).all() for x in l0)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+    print("ResNet-101 600x1000 %s: total loss %s" % (roi_pooling, ["%.4f" % x.total for x in l0]))
+    assert l0[-1].total < l0[0].total
+    changed = sorted(k for k in s0 if not torch.equal(s0[k].cpu(), sd0[k]))
+    from oracle import train_oracle as TO
+    assert changed == sorted(TO.trainable_weight_keys(sd0)) and len(changed) == 98
+
+
 # ---- general conv backward (ResNet bottlenecks) -------------------------------------------------------------------
 @pytest.mark.parametrize("N,H,W,cin,cout,k,stride,pad", [(1, 20, 33, 64, 128, 1, 1, 0), (1, 21, 33, 64, 256, 1, 2, 0),
                                                          (1, 20, 33, 64, 64, 3, 2, 1), (5, 7, 7, 128, 64, 3, 2, 1),
@@ -809,3 +845,64 @@ def test_constructor_refuses_unsupported_capacities():
     m.max_proposals_post_nms = 1000
     with pytest.raises(ValueError, match="max_proposals_post_nms"):
         m.predict(synthetic.image(1, 64, 64).unsqueeze(0).cuda(), 0.05)
+
+
+def test_backward_chain_elementwise_on_injected_oracle_activations(sd_cpu):
+    """the statistical gradient bounds above come from ReLU / max-pool / RoI-argmax decisions that two float32
+    forwards take differently near ties.  Here the decisions are PRESCRIBED: the oracle's forward activations (post-ReLU conv
+    outputs, RPN trunk, RoI-pooled features, fc1, fc2) are injected into the train step, so the whole backward chain -- loss
+    gradients, every GEMM / conv weight and data gradient, ReLU / max-pool / RoI-pool backward -- runs on identical inputs and
+    masks, and EVERY gradient tensor must agree elementwise to float32 summation-order accuracy (models/faster_rcnn.py:355)."""
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    from fasterrcnn_amd.models.vgg16 import VGG16Backbone
+    from oracle import train_oracle as TO
+    h, w, seed = 352, 480, 4
+    img = synthetic.image(seed, h, w).unsqueeze(0)
+    gts = synthetic.ground_truth(seed, h, w)
+    boxes = [Box(class_index=c, class_name="x", corners=k) for c, k in gts]
+    am, vm = O.generate_anchor_maps((3, h, w), (512, h // 16, w // 16), 16)
+    rmap, obj, bg = O.generate_rpn_map(am, vm, np.stack([k for _, k in gts]))
+    random.seed(5); torch.manual_seed(5)
+    od = {}
+    o_losses, o_grads, _, _ = TO.train_step(sd_cpu, img, am, vm, torch.from_numpy(rmap).unsqueeze(0), obj, bg,
+                                            np.stack([k for _, k in gts]), np.array([c for c, _ in gts]), 21, 1e-6, 0.9, 5e-4, detail=od)
+    hwc = lambda x: x.detach()[0].permute(1, 2, 0).contiguous().cuda()
+    names = [n for n, _ in TO.VGG_LAYERS]
+    inject = {"conv%d" % i: hwc(od[names[i]]) for i in range(4, 13)}
+    inject["conv4_in"] = hwc(torch.nn.functional.max_pool2d(od[names[3]], 2, 2))
+    # the oracle keeps the watched activations only as gradients; recompute the three that are not in `od` from its tensors
+    p = {k: v for k, v in sd_cpu.items()}
+    fm_o = od[names[12]].detach()
+    trunk_o = torch.relu(torch.nn.functional.conv2d(fm_o, p["_stage2_region_proposal_network._rpn_conv1.weight"],
+                                                    p["_stage2_region_proposal_network._rpn_conv1.bias"], padding=1))
+    inject["rpn_trunk"] = hwc(trunk_o)
+    sprops = od["sampled"][0]
+    pooled_o = TO.roi_pool_autograd(fm_o, sprops).detach()                                  # (S, 512, 7, 7)
+    S = pooled_o.shape[0]
+    inject["roi_out"] = pooled_o.permute(0, 2, 3, 1).contiguous().reshape(S, 49 * 512).cuda()
+    pv = "_stage3_detector_network._pool_to_feature_vector."
+    h1_o = torch.relu(torch.nn.functional.linear(pooled_o.reshape(S, -1), p[pv + "_fc1.weight"], p[pv + "_fc1.bias"]))
+    h2_o = torch.relu(torch.nn.functional.linear(h1_o, p[pv + "_fc2.weight"], p[pv + "_fc2.bias"]))
+    inject["fc1"], inject["fc2"] = h1_o.cuda().contiguous(), h2_o.cuda().contiguous()
+    model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+    model.load_state_dict(sd_cpu, strict=True)
+    model = model.cuda()
+    for mode in ("f32_winograd", "f32"):
+        model.load_state_dict(sd_cpu, strict=True)
+        model.math_mode = mode
+        opt = T.create_optimizer(model, learning_rate=1e-6)
+        random.seed(5); torch.manual_seed(5)
+        detail = {"inject": inject}
+        loss = T.train_step(model, opt, img.cuda(), am, vm, torch.from_numpy(rmap).unsqueeze(0), [obj], [bg], [boxes], detail=detail)
+        assert np.array_equal(detail["sample_idx"].numpy(), od["proposal_sample_indices"])
+        got = np.array([loss.rpn_class, loss.rpn_regression, loss.detector_class, loss.detector_regression])
+        want = np.array([o_losses[k] for k in ("rpn_class", "rpn_regression", "detector_class", "detector_regression")])
+        assert np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 1e-7), (got, want)
+        grads = canonical_grads(detail["grads"])
+        worst = (0.0, "")
+        for k, g_ref in o_grads.items():
+            e = float((grads[k].cpu() - g_ref).abs().max()) / float(g_ref.abs().max())
+            if e > worst[0]:
+                worst = (e, k)
+            assert e <= 1e-5, (mode, k, e)
+        print("injected-activation backward (%s): worst elementwise gradient error / max|g| = %.2e (%s)" % (mode, worst[0], worst[1]))
