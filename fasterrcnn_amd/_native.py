@@ -28,7 +28,7 @@ SYMBOLS = (
     "frcnn_pack_stack_rows", "frcnn_conv3x3_c3", "frcnn_conv3x3_workspace_bytes", "frcnn_conv3x3_nhwc",
     "frcnn_maxpool2x2_nhwc",
     "frcnn_linear_workspace_bytes", "frcnn_linear", "frcnn_softmax_rows", "frcnn_rpn_proposals",
-    "frcnn_nms", "frcnn_roi_pool", "frcnn_detections", "frcnn_ctx_create", "frcnn_ctx_destroy",
+    "frcnn_nms", "frcnn_roi_pool", "frcnn_detections", "frcnn_ctx_create", "frcnn_ctx_create_proposals", "frcnn_ctx_destroy",
     "frcnn_ctx_bytes", "frcnn_vgg16_forward", "frcnn_ctx_tensor", "frcnn_ctx_timing_enable",
     "frcnn_ctx_timing_read",
     "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv7x7_s2_c3",
@@ -171,6 +171,7 @@ _SIGNATURES = {
     "frcnn_roi_pool": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "frcnn_detections": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "frcnn_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), _i, _i, _i]),
+    "frcnn_ctx_create_proposals": (C.c_int, [C.POINTER(C.c_void_p), _i, _i]),
     "frcnn_ctx_destroy": (None, [_vp]),
     "frcnn_ctx_bytes": (C.c_size_t, [_vp]),
     "frcnn_vgg16_forward": (C.c_int, [_vp, C.POINTER(VGG16Weights), C.POINTER(ForwardParams), _vp, _i, _i,

@@ -629,6 +629,27 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
     return FRCNN_OK;
 }
 
+int frcnn_ctx_create_proposals(frcnn_ctx** out, int max_image_h, int max_image_w)
+{
+    // the ~50 MB proposal scratch only (keys, decoded boxes, NMS bit matrix): what frcnn_rpn_proposals / frcnn_nms use.  The fused
+    // forwards refuse such a ctx (max_rois == 0 < post_nms).
+    if (!out || max_image_h < 16 || max_image_w < 16) return FRCNN_EINVAL;
+    frcnn_ctx* c = new (std::nothrow) frcnn_ctx();
+    if (!c) return FRCNN_ENOMEM;
+    c->max_h = max_image_h; c->max_w = max_image_w; c->max_rois = 0;
+    c->max_fh = cdiv(max_image_h, 16); c->max_fw = cdiv(max_image_w, 16);
+    c->a_cap = c->max_fh * c->max_fw * 9;
+    if (c->a_cap < 16384) c->a_cap = 16384;
+    c->pre_cap = 16384;
+    const size_t total = align_up(proposal_scratch_bytes(c->a_cap, c->pre_cap, 2048), 256);
+    hipError_t e = hipMalloc(&c->slab, total);
+    if (e != hipSuccess) { set_hip_error(e); delete c; return FRCNN_ENOMEM; }
+    c->slab_bytes = total;
+    proposal_scratch_carve(c->ps, c->slab, c->a_cap, c->pre_cap, 2048);
+    *out = c;
+    return FRCNN_OK;
+}
+
 void frcnn_ctx_destroy(frcnn_ctx* ctx)
 {
     if (!ctx) return;
@@ -725,6 +746,17 @@ int run_winograd_layer(frcnn_ctx* c, const float* x, const float* u, const float
     return launch_winograd_output(M, b, y, N, h, w, co, flags, s);
 }
 
+// One one-launch Winograd layer inside a fused forward (timed as class 7).
+// (A channel split of the small maps over more blocks -- partial outputs, arrival tickets, the last arriver sums in part order --
+//  was built and measured for one image on the chip: conv5_x 87 -> 84-87 us, conv4_2 227 -> 222 us with 2 parts, slower with 4.
+//  The per-block prologue / epilogue and the partial traffic cost what the shorter serial chain wins, so it is not in the tree.)
+int run_wino_fused_layer(frcnn_ctx* c, bool /*latency*/, const float* x, const float* u, const float* b, float* y, int h, int w, int ci,
+                         int co, unsigned flags, hipStream_t s)
+{
+    Scope _w(c, 7, s);
+    return launch_conv3x3_winograd_fused(x, u, b, y, h, w, ci, co, flags, s);
+}
+
 struct BlocksTargetScope {
     explicit BlocksTargetScope(int t, int wino_rows = 0) { conv3x3_set_blocks_target(t); linear_batched_set_tile(wino_rows); }
     ~BlocksTargetScope() { conv3x3_set_blocks_target(0); linear_batched_set_tile(0); }
@@ -760,8 +792,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
         if (wino && conv3x3_uses_winograd_fused(ci, co)) {     // one launch, no scratch (csrc/winofused.hip); timed as class 7
-            Scope _w(c, 7, s);
-            return launch_conv3x3_winograd_fused(xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
+            return run_wino_fused_layer(c, p->conv_blocks_target == 0, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
         }
         Scope _d(c, 0, s);
         return x6 ? launch_conv3x3_x6(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s)
@@ -843,7 +874,7 @@ namespace {
 // One Bottleneck (torchvision v1.5): out = relu(conv3(relu(conv2(relu(conv1(x))))) + identity).
 // x: [N][h][w][cin] in `cur`; returns the buffer index holding the output, updates h, w.
 int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& h, int& w, int cur,
-                   int* out_idx, hipStream_t s, int cls_conv, bool wino)
+                   int* out_idx, hipStream_t s, int cls_conv, bool wino, bool latency)
 {
     // pick three scratch buffers different from `cur`
     int f[4], k = 0;
@@ -861,7 +892,7 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
 #define RSTEP(call) do { Scope _sc(c, cls_conv, s); rc = (call); } while (0); if (rc) return rc
     RSTEP(launch_conv_gather(X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s));
     if (wino && resnet_block_uses_winograd_fused(N, b.width, b.stride)) {
-        { Scope _w(c, 7, s); rc = launch_conv3x3_winograd_fused(T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s); }
+        rc = run_wino_fused_layer(c, latency, T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s);
         if (rc) return rc;
     } else if (wino && resnet_block_uses_winograd(b.width, b.stride)) {
         rc = run_winograd_layer(c, T1, b.w2, b.b2, T2, N, h, w, b.width, b.width, R, s);
@@ -930,7 +961,7 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     for (int layer = 0; layer < 3; ++layer)
         for (int k = 0; k < w->n_blocks[layer]; ++k, ++bi) {
             int out = -1;
-            rc = run_bottleneck(c, w->blocks[bi], 1, h, wd, cur, &out, s, 0, wino);
+            rc = run_bottleneck(c, w->blocks[bi], 1, h, wd, cur, &out, s, 0, wino, p->conv_blocks_target == 0);
             if (rc) return rc;
             cur = out;
         }
@@ -942,7 +973,7 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
 
     // stage 2: RPN (models/rpn.py:88-153)
     if (wino && conv3x3_uses_winograd_fused(C, C)) {
-        { Scope _w(c, 7, s); rc = launch_conv3x3_winograd_fused(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU, s); }
+        rc = run_wino_fused_layer(c, p->conv_blocks_target == 0, c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU, s);
         if (rc) return rc;
     } else {
         STEP(0, launch_conv3x3_nhwc(c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU,
@@ -978,7 +1009,7 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     cur = 0; h = 7; wd = 7;
     for (int k = 0; k < w->n_blocks[3]; ++k, ++bi) {
         int out = -1;
-        rc = run_bottleneck(c, w->blocks[bi], R_, h, wd, cur, &out, s, 2, wino);
+        rc = run_bottleneck(c, w->blocks[bi], R_, h, wd, cur, &out, s, 2, wino, p->conv_blocks_target == 0);
         if (rc) { c->res_buf[0] = saved; return rc; }
         cur = out;
     }

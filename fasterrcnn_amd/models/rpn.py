@@ -32,11 +32,14 @@ _scratch = {}
 
 
 def scratch_context(device, h=1024, w=1024, rois=512):
-    """A shared frcnn_ctx used as scratch by the stage-level entry points (not by the fused model)."""
-    key = str(t.device(device))
+    """Proposal scratch for the stage-level entry points (RegionProposalNetwork.forward, the train step): one proposals-only
+    frcnn_ctx (~50 MB, frcnn_ctx_create_proposals) per (device, stream) -- a ctx is not re-entrant, and ctypes calls drop the GIL,
+    so two streams / threads must never share one.  The fused model owns its own per-slot contexts."""
+    dev = t.device(device)
+    key = (str(dev), int(t.cuda.current_stream(dev).cuda_stream))
     ctx = _scratch.get(key)
-    if ctx is None or not ctx.fits(h, w, rois):
-        ctx = rt.Context(device, max(h, 1024), max(w, 1024), 512)
+    if ctx is None or h > ctx.max_h or w > ctx.max_w:
+        ctx = rt.Context(dev, max(h, 1024), max(w, 1024), 0, proposals_only=True)
         _scratch[key] = ctx
     return ctx
 

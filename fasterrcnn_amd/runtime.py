@@ -13,14 +13,18 @@ from . import _native as nv
 
 class Context:
     """Owns one frcnn_ctx (activation buffers + scratch for one in-flight image)."""
-    def __init__(self, device, max_h, max_w, max_rois):
+    def __init__(self, device, max_h, max_w, max_rois, proposals_only=False):
+        """proposals_only: just the ~50 MB proposal scratch (frcnn_ctx_create_proposals) for the stage-level RPN / NMS entry points."""
         nv.require_gpu()
         self.device = t.device(device)
-        self.max_h, self.max_w, self.max_rois = int(max_h), int(max_w), int(max_rois)
+        self.max_h, self.max_w, self.max_rois = int(max_h), int(max_w), 0 if proposals_only else int(max_rois)
         handle = C.c_void_p()
         with t.cuda.device(self.device):
-            nv.check(nv.lib().frcnn_ctx_create(C.byref(handle), self.max_h, self.max_w, self.max_rois),
-                     "frcnn_ctx_create")
+            if proposals_only:
+                nv.check(nv.lib().frcnn_ctx_create_proposals(C.byref(handle), self.max_h, self.max_w), "frcnn_ctx_create_proposals")
+            else:
+                nv.check(nv.lib().frcnn_ctx_create(C.byref(handle), self.max_h, self.max_w, self.max_rois),
+                         "frcnn_ctx_create")
         self.handle = handle
 
     def fits(self, h, w, rois):

@@ -323,6 +323,9 @@ int frcnn_detections(const float* d_props, const float* d_classes, const float* 
  * 307 MB at 600x1000) and counted by frcnn_ctx_bytes from then on.
  * ---------------------------------------------------------------------------------------- */
 int  frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_rois);
+/* A ctx that owns ONLY the proposal scratch (~50 MB: keys, decoded boxes, NMS bit matrix) for the stage-level entry points
+ * frcnn_rpn_proposals / frcnn_nms; the fused forwards return FRCNN_EINVAL on it.  Not re-entrant: one per stream. */
+int  frcnn_ctx_create_proposals(frcnn_ctx** out, int max_image_h, int max_image_w);
 void frcnn_ctx_destroy(frcnn_ctx* ctx);
 size_t frcnn_ctx_bytes(const frcnn_ctx* ctx);
 

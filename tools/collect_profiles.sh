@@ -3,17 +3,17 @@
 # 1. the default bench line; 2. rocprofv3 kernel trace + stats of a bench run; 3. PMC passes
 # (counters in their own runs, kernel-trace only, as the pool requires).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-secondary"
+B="python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-secondary --no-extra-legs"
 timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench exit $?"
 tail -c 2500 $OUT/bench_default.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/trace.log 2>&1; echo "trace exit $?"
-P="python bench.py --steps 12 --warmup 4 --ramp-seconds 0 --no-cpu-baseline --no-secondary --inflight 1 --roofline-images 2 --map-images 0"
+P="python bench.py --steps 12 --warmup 4 --ramp-seconds 0 --no-cpu-baseline --no-secondary --no-extra-legs --inflight 1 --roofline-images 2 --map-images 0 --min-timed-seconds 0"
 # single-stream kernel durations (what bench.py's roofline block times with HIP events): kernel trace + stats, no counters
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_single -o t -- python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-secondary --inflight 1 --roofline-images 10 --map-images 0 > $OUT/trace_single.log 2>&1; echo "single-stream trace exit $?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_single -o t -- python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-secondary --inflight 1 --roofline-images 10 --map-images 0 --no-extra-legs > $OUT/trace_single.log 2>&1; echo "single-stream trace exit $?"
 rm -f $OUT/trace_single/t_kernel_trace.csv
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_mfma -o p -- $P > $OUT/pmc_mfma.log 2>&1; echo "pmc mfma exit $?"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $P > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?"

@@ -37,23 +37,17 @@ def main(d):
         print("## single stream: kernel stats (bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-secondary --inflight 1 "
               "--roofline-images 10 --map-images 0)\n")
         print("One image at a time, so a kernel's duration is its own: this is the regime bench.py's `roofline` block times with "
-              "HIP events (`avg_launch_us` = mean over the conv3x3_mfma_kernel launches of all instantiations).\n")
+              "HIP events (`avg_launch_us` = mean over the wino_fused_kernel launches of both instantiations).\n")
         print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
         tot_ns, tot_calls = 0.0, 0
         for r in sstats[:20]:
             print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                      float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
-        for r in sstats:
-            if "conv3x3_mfma_kernel" in r["Name"]:
-                tot_ns += float(r["TotalDurationNs"]); tot_calls += int(r["Calls"])
-        if tot_calls:
-            print("\nconv3x3_mfma_kernel, all instantiations: %d launches, mean %.1f us" % (tot_calls, tot_ns / tot_calls / 1e3))
-        g_ns, g_calls = 0.0, 0
-        for r in sstats:
-            if "linear_mfma_kernel" in r["Name"] and "true" in r["Name"]:
-                g_ns += float(r["TotalDurationNs"]); g_calls += int(r["Calls"])
-        if g_calls:
-            print("batched Winograd GEMM (linear_mfma_kernel<..., true, 1>), all tiles: %d launches, mean %.1f us" % (g_calls, g_ns / g_calls / 1e3))
+        for fam in ("wino_fused_kernel", "linear_x6_kernel", "linear_mfma_kernel", "conv3x3_mfma_kernel"):
+            f_ns = sum(float(r["TotalDurationNs"]) for r in sstats if fam in r["Name"])
+            f_calls = sum(int(r["Calls"]) for r in sstats if fam in r["Name"])
+            if f_calls:
+                print("\n%s, all instantiations: %d launches, mean %.1f us" % (fam, f_calls, f_ns / f_calls / 1e3))
         print()
     tb = os.path.join(d, "train_bench.json")
     if os.path.exists(tb):
@@ -73,7 +67,7 @@ def main(d):
     if kt:
         agg = collections.defaultdict(list)
         for r in kt:
-            if "conv3x3_mfma" in r["Kernel_Name"] or "linear_mfma" in r["Kernel_Name"]:
+            if any(x in r["Kernel_Name"] for x in ("conv3x3_mfma", "linear_mfma", "wino_fused", "linear_x6")):
                 key = (short(r["Kernel_Name"]), r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
                 agg[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         print("## MFMA kernels by grid (threads x, blocks y, z), multi-stream run\n")
@@ -90,7 +84,7 @@ def main(d):
         cnt = collections.defaultdict(set)
         for r in rows:
             k = short(r["Kernel_Name"])
-            if not any(x in k for x in ("conv3x3", "linear_mfma", "wino_", "roi_pool", "topk", "nms_", "detections", "splitk", "conv_splitk")):
+            if not any(x in k for x in ("conv3x3", "linear_", "wino_", "roi_", "topk", "nms_", "detections", "splitk", "conv_splitk", "split_rows")):
                 continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k].add(r["Dispatch_Id"])
@@ -124,9 +118,10 @@ def traffic(d):
     `hbm_bytes_per_launch` = conv3x3_mfma_kernel (all instantiations), `by_kernel` = the same figure per kernel family.
     """
     import json
-    families = (("conv3x3_mfma_kernel", lambda n: "conv3x3_mfma" in n),
-                ("winograd_gemm", lambda n: "linear_mfma_kernel" in n and "true" in n.split("(")[0]),
-                ("wino_input_kernel", lambda n: "wino_input" in n), ("wino_output_kernel", lambda n: "wino_output" in n),
+    families = (("wino_fused_kernel", lambda n: "wino_fused_kernel" in n),
+                ("linear_x6_kernel", lambda n: "linear_x6_kernel" in n),
+                ("conv3x3_mfma_kernel", lambda n: "conv3x3_mfma" in n),
+                ("conv3x3_c3_kernel", lambda n: "conv3x3_c3" in n),
                 ("linear_mfma_kernel", lambda n: "linear_mfma_kernel" in n and "true" not in n.split("(")[0]))
     raw = {}
     for tag, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
@@ -145,11 +140,12 @@ def traffic(d):
         f, w = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
         by[fam] = {"launches": vals["FETCH_SIZE"][1], "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
                    "hbm_bytes_per_launch": f * 1024 * 2.0 + w * 1024}
-    if "conv3x3_mfma_kernel" not in by:
+    head = "wino_fused_kernel" if "wino_fused_kernel" in by else ("conv3x3_mfma_kernel" if "conv3x3_mfma_kernel" in by else None)
+    if head is None:
         return
-    c = by["conv3x3_mfma_kernel"]
+    c = by[head]
     rec = {"source": "%s (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, single stream)" % d,
-           "kernel": "conv3x3_mfma_kernel (all instantiations)", "launches": c["launches"],
+           "kernel": "%s (all instantiations)" % head, "launches": c["launches"],
            "FETCH_SIZE_KiB_per_launch": c["FETCH_SIZE_KiB_per_launch"], "WRITE_SIZE_KiB_per_launch": c["WRITE_SIZE_KiB_per_launch"],
            "fetch_correction": 2.0, "hbm_bytes_per_launch": c["hbm_bytes_per_launch"], "by_kernel": by}
     json.dump(rec, open(os.path.join(d, "traffic.json"), "w"), indent=1)
