@@ -353,8 +353,11 @@ typedef struct frcnn_forward_params {
     int32_t allow_edge_proposals; /* 1   (models/faster_rcnn.py:36)  */
     int32_t math_mode;          /* FRCNN_MATH_F32 (exact f32 MFMA, direct), FRCNN_MATH_F32X6 or FRCNN_MATH_F32_WINOGRAD;
                                    selects how the 3x3 conv weight pointers of the weights struct are interpreted:
-                                   frcnn_pack_conv3x3 / frcnn_pack_conv3x3_x6 / (layers with
-                                   frcnn_conv3x3_uses_winograd(cin, cout)) frcnn_pack_conv3x3_winograd, frcnn_pack_conv3x3 otherwise */
+                                   frcnn_pack_conv3x3 / frcnn_pack_conv3x3_x6 / FRCNN_MATH_F32_WINOGRAD: layers with
+                                   frcnn_conv3x3_uses_winograd_fused(cin, cout) (every 3x3 layer from conv1_2 on, the RPN trunk;
+                                   ResNet: frcnn_resnet_block_uses_winograd_fused blocks) frcnn_pack_conv3x3_winograd_fused,
+                                   ResNet layer4 blocks with frcnn_resnet_block_uses_winograd: frcnn_pack_conv3x3_winograd,
+                                   frcnn_pack_conv3x3 otherwise */
     int32_t conv_blocks_target; /* split-K granularity of the 3x3 layers: blocks per launch to aim for.  0 = 1280 (best
                                    latency for one image on the chip); ~320 when many images are in flight on separate
                                    streams (other images' kernels fill the tail, longer work units win) */
@@ -364,7 +367,7 @@ typedef struct frcnn_forward_params {
     int32_t roi_op;             /* FRCNN_ROI_POOL (the reference: torchvision RoIPool, models/detector.py:27) or FRCNN_ROI_ALIGN
                                    (torchvision roi_align semantics, aligned = 0) */
     int32_t roi_sampling_ratio; /* FRCNN_ROI_ALIGN: samples per bin and axis (1 or 2; <= 0 adaptive); ignored for FRCNN_ROI_POOL */
-    int32_t winograd_tile_rows; /* FRCNN_MATH_F32_WINOGRAD: row count of the batched GEMM's block tile.  0 = 64 (64 x 128 tiles, five
+    int32_t winograd_tile_rows; /* three-launch Winograd form only (ResNet layer4): row count of the batched GEMM's block tile.  0 = 64 (64 x 128 tiles, five
                                    blocks per CU: best latency for one image on the chip); 128 with many images in flight (the chip
                                    is then at its power limit and the tile with fewer operand bytes per MFMA wins) */
 } frcnn_forward_params;
