@@ -8,7 +8,7 @@ bench.py -- images/sec of Faster R-CNN VGG-16 inference (600x1000, 300 proposals
 A "step" is one `predict()` of one synthetic, already-preprocessed float32 3x600x1000 image that is
 resident in HBM when the timed region starts: VGG-16 backbone, RPN (6000 pre- / 300 post-NMS),
 RoI pooling, FC head, on-device float64 decode + per-class NMS, one D2H copy of the detections.
-Every image is an independent batch-1 forward (BASELINE.json configs[1]); `--inflight` of them
+Every image is an independent batch-1 forward (BASELINE.json configs[1]); `--inflight` of them (default 3)
 are in flight on separate HIP streams (GPU_MAX_HW_QUEUES=16 unless the environment says otherwise).  fp32 end to end (the reference's dtype), exact-f32 MFMA.
 
 Multi-GPU: image-parallel, rank r owns its own images, no data-path collective; weak scaling
@@ -197,7 +197,7 @@ def train_step_leg(backbone, dev, steps=10, warmup=3, lr=1e-6, pool=2):
 
 
 def winograd_chip_full_leg(layers, dev, streams=8, reps=6):
-    """The dominant kernel with the chip FULL -- the regime of the headline number (24 images in flight): every Winograd layer of one
+    """The dominant kernel with the chip FULL -- the regime of the headline number (several images in flight): every Winograd layer of one
     image launched back to back on each of `streams` HIP streams (own buffers per stream, random operands), wall time by events.
     achieved = streams x reps x sum of executed Winograd FLOP / wall.  A single stream (the `roofline` block) leaves the tail of every
     launch to an emptying chip: 640 work units on 512 resident-block slots (conv4_x) or 160 on 256 CUs (conv5_x)."""
@@ -264,7 +264,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--inflight", type=int, default=24, help="images in flight per GPU (separate HIP streams)")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="images in flight per GPU (separate HIP streams).  Round 2: the one-launch Winograd layers fill the chip with two "
+                         "long-running blocks per CU, so three images (one in its serial proposal / detection tail, two convolving) "
+                         "are enough -- measured 473-476 img/s at 3, 463-467 at 6-12, 455-460 at 24 (round 1's default)")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic images resident per GPU")
     ap.add_argument("--map-images", type=int, default=8, help="labelled images per rank for the mAP@0.5 leg")
     ap.add_argument("--cpu-images", type=int, default=12, help="images timed on the host CPU (rank 0, N=1 only): ~12 s of CPU work")
@@ -482,7 +485,7 @@ def main():
                     "note": note}
 
         regime = ("HIP events around every launch, one image at a time on one stream, median image of %d (after the timed region: with "
-                  "24 images in flight concurrent kernels share the CUs and a launch's wall duration is not its own)" % n_img)
+                  "several images in flight concurrent kernels share the CUs and a launch's wall duration is not its own)" % n_img)
         dl, wl = direct_layers(args.math), winograd_layers(args.math)
         r_direct = mfma_roofline("conv3x3_mfma_kernel (direct 3x3 layers: %d per image)" % len(dl), "conv3x3_mfma",
                                  [2.0 * 9 * ci * co * h * w for ci, co, h, w in dl], "FLOP = direct-convolution FLOP of the layers")
