@@ -125,6 +125,13 @@ class FasterRCNNModel(nn.Module):
         self._fc_math_mode = "f32"
         self.fc_math_mode = "f32" if self._is_resnet else "f32x6"
 
+        # hipGraph replay of one image's ~33 launches (forward + detections + the D2H copies): the second consecutive call of a slot with
+        # the same (shape, thresholds, weights, modes) captures them into a graph on the slot's stream, later calls copy the image
+        # into the graph's static input and replay it.  Any other call on the slot (different shape, caller-provided anchor maps,
+        # timing enabled) runs eagerly and drops the slot's graph (a ctx caches ONE shape's anchors).
+        # Off by default: measured on the MI355X box it changes nothing (one image at a time: 333.3 img/s with graphs, 334.2
+        # eager) -- the kernels are 20-230 us long and the eager launch path already keeps their boundaries at ~2 us.
+        self.use_hip_graphs = False
         self._train_state = None
         self._gradient_sync = None          # training.enable_data_parallel
         self._slots = {}
@@ -292,27 +299,53 @@ class FasterRCNNModel(nn.Module):
                                   nv.ROI_OPS[self._stage3_detector_network.pooling], self._stage3_detector_network.sampling_ratio,
                                   0 if slot_index == 0 else self.inflight_winograd_tile_rows)
         lib = nv.lib()
+        with_det = score_threshold is not None
+        fwd, fwd_name = ((lib.frcnn_resnet_forward, "frcnn_resnet_forward") if self._is_resnet
+                         else (lib.frcnn_vgg16_forward, "frcnn_vgg16_forward"))
+
+        def body(img, sp):
+            """Enqueues everything of one image on the stream `sp` (the current torch stream)."""
+            nv.check(fwd(slot.ctx.handle, C.byref(weights), C.byref(params), nv.ptr(img), h, w,
+                         nv.ptr(amap), nv.ptr(vmap), nv.ptr(slot.props), nv.ptr(slot.classes),
+                         nv.ptr(slot.deltas), nv.ptr(slot.counts), sp), fwd_name)
+            if with_det:
+                nv.check(lib.frcnn_detections(nv.ptr(slot.props), nv.ptr(slot.classes), nv.ptr(slot.deltas),
+                                              slot.counts.data_ptr() + 8, slot.max_rois, self._num_classes, h, w,
+                                              float(score_threshold), float(self.detector_nms_threshold),
+                                              nv.ptr(slot.det), nv.ptr(slot.det_cnt), sp), "frcnn_detections")
+                slot.h_det.copy_(slot.det, non_blocking=True)
+                slot.h_det_cnt.copy_(slot.det_cnt, non_blocking=True)
+            slot.h_counts.copy_(slot.counts, non_blocking=True)
+
+        gkey = None
+        if self.use_hip_graphs and amap is None and not slot.ctx.timing:
+            gkey = (h, w, None if score_threshold is None else float(score_threshold), float(self.detector_nms_threshold),
+                    tuple(getattr(params, f) for f, _ in params._fields_), self._wstruct_key)
         with t.cuda.device(device):
             stream = slot.use_stream()
             if slot.stream is not None:
                 # the image (and packed weights) were produced on the caller's stream
                 stream.wait_stream(t.cuda.current_stream(device))
-            sp = stream.cuda_stream
-            fwd, fwd_name = ((lib.frcnn_resnet_forward, "frcnn_resnet_forward") if self._is_resnet
-                             else (lib.frcnn_vgg16_forward, "frcnn_vgg16_forward"))
-            nv.check(fwd(slot.ctx.handle, C.byref(weights), C.byref(params), nv.ptr(image), h, w,
-                         nv.ptr(amap), nv.ptr(vmap), nv.ptr(slot.props), nv.ptr(slot.classes),
-                         nv.ptr(slot.deltas), nv.ptr(slot.counts), sp), fwd_name)
-            with_det = score_threshold is not None
             with t.cuda.stream(stream):
-                if with_det:
-                    nv.check(lib.frcnn_detections(nv.ptr(slot.props), nv.ptr(slot.classes), nv.ptr(slot.deltas),
-                                                  slot.counts.data_ptr() + 8, slot.max_rois, self._num_classes, h, w,
-                                                  float(score_threshold), float(self.detector_nms_threshold),
-                                                  nv.ptr(slot.det), nv.ptr(slot.det_cnt), sp), "frcnn_detections")
-                    slot.h_det.copy_(slot.det, non_blocking=True)
-                    slot.h_det_cnt.copy_(slot.det_cnt, non_blocking=True)
-                slot.h_counts.copy_(slot.counts, non_blocking=True)
+                if gkey is not None and slot.graph_key == gkey and slot.graph is not None:
+                    slot.graph_input.copy_(image)
+                    slot.graph.replay()
+                elif gkey is not None and slot.graph_key == gkey:
+                    # second consecutive call with this key: capture (on a side stream, as stream capture requires), then replay
+                    if slot.capture_stream is None:
+                        slot.capture_stream = t.cuda.Stream(device=device)
+                    slot.graph_input = t.empty_like(image)
+                    slot.graph_input.copy_(image)
+                    graph = t.cuda.CUDAGraph()
+                    slot.capture_stream.wait_stream(stream)
+                    with t.cuda.graph(graph, stream=slot.capture_stream, capture_error_mode="thread_local"):
+                        body(slot.graph_input, t.cuda.current_stream(device).cuda_stream)
+                    stream.wait_stream(slot.capture_stream)
+                    slot.graph = graph
+                    graph.replay()
+                else:
+                    slot.graph, slot.graph_input, slot.graph_key = None, None, gkey
+                    body(image, stream.cuda_stream)
                 slot.done.record(stream)
         slot.busy = True
         slot.keepalive = (image, amap, vmap)

@@ -26,6 +26,7 @@ class Context:
                 nv.check(nv.lib().frcnn_ctx_create(C.byref(handle), self.max_h, self.max_w, self.max_rois),
                          "frcnn_ctx_create")
         self.handle = handle
+        self.timing = False          # per-kernel event timing on: the model then launches eagerly (events are not captured)
 
     def fits(self, h, w, rois):
         return h <= self.max_h and w <= self.max_w and rois <= self.max_rois
@@ -47,6 +48,7 @@ class Context:
         return out
 
     def timing_enable(self, on):
+        self.timing = bool(on)
         nv.check(nv.lib().frcnn_ctx_timing_enable(self.handle, 1 if on else 0), "frcnn_ctx_timing_enable")
 
     def timing_read(self, reset=True):
@@ -98,6 +100,7 @@ class Slot:
         self.h_det_cnt = t.zeros((nfg,), dtype=t.int32).pin_memory()
         self.h_counts = t.zeros((4,), dtype=t.int32).pin_memory()
         self.done = t.cuda.Event()
+        self.graph, self.graph_key, self.graph_input, self.capture_stream = None, None, None, None    # hipGraph of the last call shape
         self.busy = False
         self.keepalive = None     # references that must outlive the enqueued work
 

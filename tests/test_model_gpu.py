@@ -298,6 +298,37 @@ def test_anchor_maps_argument_and_async_slots(gpu_model):
     p.result()
 
 
+def test_hip_graph_replay_equals_eager(gpu_model):
+    """use_hip_graphs: the second call of a shape captures the image's launches, later calls replay them -- bit-identical to the
+    eager launches, also after a different shape ran in between (the graph is dropped and re-captured) and on an in-flight slot."""
+    imgs = [synthetic.image(60 + i).unsqueeze(0).cuda() for i in range(3)]
+    small = synthetic.image(63, 224, 320).unsqueeze(0).cuda()
+    eager = [gpu_model.predict(image_data=im, score_threshold=0.05) for im in imgs]
+    eager_small = gpu_model.predict(image_data=small, score_threshold=0.05)
+    eager_fwd = gpu_model(image_data=imgs[0])
+    gpu_model.use_hip_graphs = True
+    try:
+        for rep in range(3):                                   # eager, capture + replay, replay
+            for i, im in enumerate(imgs):
+                got = gpu_model.predict(image_data=im, score_threshold=0.05)
+                for c in eager[i]:
+                    assert np.array_equal(got[c], eager[i][c]), (rep, i, c)
+        assert gpu_model._slots[(str(imgs[0].device), 0)].graph is not None
+        got = gpu_model.predict(image_data=small, score_threshold=0.05)              # other shape: eager, graph dropped
+        assert all(np.array_equal(got[c], eager_small[c]) for c in got)
+        assert gpu_model._slots[(str(imgs[0].device), 0)].graph is None
+        for rep in range(3):
+            fwd = gpu_model(image_data=imgs[0])                                      # forward(): its own key (no detections)
+            assert all(torch.equal(a, b) for a, b in zip(fwd, eager_fwd))
+        for rep in range(3):
+            pend = [gpu_model.predict_async(im, 0.05, slot=i + 1) for i, im in enumerate(imgs)]
+            for i, p in enumerate(pend):
+                res = p.result()
+                assert sum(len(v) for v in res.values()) == sum(len(v) for v in eager[i].values())
+    finally:
+        gpu_model.use_hip_graphs = False
+
+
 def test_state_dict_roundtrip_repacks(gpu_model, sd_cpu):
     img = synthetic.image(2, 224, 320).unsqueeze(0).cuda()
     before = gpu_model(image_data=img)
