@@ -31,6 +31,7 @@
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace frcnn {
 
@@ -50,8 +51,11 @@ static constexpr int WF_NU = WF_U_F / 4 / 256;           // 16-byte filter piece
 static constexpr int WF_NHP = WF_NPIX * 4;               // 16-byte halo pieces per chunk
 static constexpr int WF_NH = (WF_NHP + 255) / 256;       // 6 per thread
 #ifndef WF_ABLATE
-#define WF_ABLATE 0                                      // timing experiments only (tools/build_ablate.sh): 1 no halo LDS writes, 2 no filter
-#endif                                                   // LDS writes, 4 no halo LDS reads, 8 no filter LDS reads (after the prologue); results wrong
+#define WF_ABLATE 0                                      // timing experiments only (tools/build_ablate.sh), results wrong: 16 no filter loads,
+#endif                                                   // 32 no halo loads inside the K loop
+#ifndef WF_PRIO
+#define WF_PRIO 1
+#endif
 #define WF_HALO_BUFS 2                                   // no barrier at the chunk seam; 81,664 B of LDS per block (two blocks fill a CU's 160 KB)
 static constexpr size_t WF_LDS_BYTES = (size_t)(WF_HALO_BUFS * WF_HALO_F + 2 * WF_U_F) * sizeof(float);
 static_assert(WF_NH == 6, "halo pieces are spread over the first three stages of a chunk, two per stage");
@@ -141,11 +145,29 @@ struct WfGeom { int tbx, tby, ncb, total; };
 #define WF_DSR  0x100
 #define WF_DSW  0x200
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 wf_lo(const f32x4& a) { return __builtin_shufflevector(a, a, 0, 1); }
+__device__ __forceinline__ f32x2 wf_hi(const f32x4& a) { return __builtin_shufflevector(a, a, 2, 3); }
+// a -+ b on a register pair in one instruction (the neg modifiers make it a - b: the same IEEE result as v_sub_f32)
+__device__ __forceinline__ f32x2 wf_pk(bool sub, f32x2 a, f32x2 b)
+{
+    f32x2 o;
+    if (sub) asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b));
+    else asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+
 template <bool POOL>
 __global__ __launch_bounds__(256, WF_NT <= 2 ? 2 : 1)
 void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ bias,
                        float* __restrict__ y, int H, int W, int Cin, int Cout, int relu, WfGeom gm)
 {
+#ifdef WF_CLOCKS
+    const unsigned long long real_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+#if WF_PRIO
+    __builtin_amdgcn_s_setprio(3);                       // prologue and epilogue ahead of the co-resident block's K loop
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem_wf[];
     float* const halo0 = smem_wf;                           // WF_HALO_BUFS halo buffers
     float* const ub0 = smem_wf + WF_HALO_BUFS * WF_HALO_F;  // 2 filter slab buffers
@@ -167,10 +189,11 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
     const int y0 = 2 * WF_TR * by - 1, x0 = 2 * WF_TC * bx - 1;
     const int nchunks = Cin >> 4;
 
-    // ---- halo staging: piece = (pixel, k-quad); out-of-image pieces load offset 0 and are zeroed by a select ----------
-    unsigned h_src[WF_NH];
+    // ---- halo staging: piece = (pixel, k-quad).  Buffer loads: an out-of-image piece carries an offset past the descriptor's
+    // size and the hardware returns zeros for it (the "same" padding costs no instruction) -------------------------------
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, H * W * Cin * (int)sizeof(float), 0x00020000);
+    int h_src[WF_NH];
     int h_dst[WF_NH];
-    unsigned h_inb = 0;
 #pragma unroll
     for (int it = 0; it < WF_NH; ++it) {
         const int q = tid + 256 * it;
@@ -179,9 +202,8 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         const int hr = px / WF_HC, hc = px - hr * WF_HC;
         const int gy = y0 + hr, gx = x0 + hc;
         const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        h_src[it] = inb ? (unsigned)((((size_t)gy * W + gx) * Cin + 4 * pk) * sizeof(float)) : 0u;
+        h_src[it] = inb ? (int)((((unsigned)gy * W + gx) * Cin + 4 * pk) * sizeof(float)) : (int)0xFFFFFFF0u;
         h_dst[it] = ((hr * 2 + (hc & 1)) * WF_HP + (hc >> 1)) * WF_PS + 4 * pk;
-        if (inb) h_inb |= 1u << it;
     }
     // ---- filter slab staging: 512 pieces of 16 B per slab, two per thread ------------------------------------------------
     int u_dst[WF_NU];
@@ -191,32 +213,25 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         const int row = q >> 2, pk = q & 3;
         u_dst[it] = row * 16 + 4 * (pk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3));
     }
-    const float* const u_blk = u + (size_t)cb * 16 * (WF_BN * 16) + 4 * tid;        // + chunk * ncb * 8192 + i * 2048 + 1024 * it
-    const size_t u_chunk_stride = (size_t)gm.ncb * 16 * (WF_BN * 16);
+    // filter loads: buffer loads too -- lane offset 16 tid, everything else (cout block, chunk, slab, piece) in the scalar offset
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(u), 0, 16 * Cin * Cout * (int)sizeof(float), 0x00020000);
+    const int u_voff = 16 * tid;
+    const int u_blk = cb * 16 * (WF_BN * 16) * (int)sizeof(float);                  // + chunk * u_chunk_stride + (i * 2048 + 1024 * it) * 4
+    const int u_chunk_stride = gm.ncb * 16 * (WF_BN * 16) * (int)sizeof(float);
 
     f32x4 hreg[2][2];            // two pieces in flight + two waiting for their LDS write
     f32x4 ureg[2][WF_NU];        // filter slab t travels in set t & 1: loaded two stages ahead, written to LDS one stage ahead
+    bool in_loop = false;
     auto load_halo_piece = [&](f32x4& dst, int it, int chunk) {
-        if ((WF_ABLATE & 32) && chunk > 0) return;
-        dst = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(x + (chunk << 4)) + h_src[it]);
+        if ((WF_ABLATE & 32) && in_loop) return;
+        dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, h_src[it], chunk * 64, 0));
     };
-    bool past_prologue = false;
-    auto store_halo_piece = [&](float* hb, const f32x4& src, int it) {
-        if ((WF_ABLATE & 1) && past_prologue) { asm volatile("" :: "v"(src)); return; }
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(hb + h_dst[it]) = ((h_inb >> it) & 1u) ? src : zero;
+    auto store_halo_piece = [&](float* hb, const f32x4& src, int it) { *reinterpret_cast<f32x4*>(hb + h_dst[it]) = src; };
+    auto load_u_piece = [&](f32x4& dst, int chunk, int i, int it) {
+        if ((WF_ABLATE & 16) && in_loop) return;
+        dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, u_voff, u_blk + chunk * u_chunk_stride + (i * WF_U_F + 1024 * it) * (int)sizeof(float), 0));
     };
-    auto load_u = [&](f32x4 (&ur)[WF_NU], int chunk, int i) {
-        if ((WF_ABLATE & 16) && (chunk > 0 || i > 0)) return;
-        const float* p = u_blk + (size_t)chunk * u_chunk_stride + i * WF_U_F;
-#pragma unroll
-        for (int it = 0; it < WF_NU; ++it) ur[it] = *reinterpret_cast<const f32x4*>(p + 1024 * it);
-    };
-    auto store_u = [&](int buf, const f32x4 (&ur)[WF_NU]) {
-        if ((WF_ABLATE & 2) && past_prologue) { asm volatile("" :: "v"(ur[0]), "v"(ur[1])); return; }
-#pragma unroll
-        for (int it = 0; it < WF_NU; ++it) *reinterpret_cast<f32x4*>(ub0 + buf * WF_U_F + u_dst[it]) = ur[it];
-    };
+    auto store_u_piece = [&](int buf, const f32x4& src, int it) { *reinterpret_cast<f32x4*>(ub0 + buf * WF_U_F + u_dst[it]) = src; };
 
     f32x4 acc[16][WF_NT];
 #pragma unroll
@@ -229,28 +244,24 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
     // U of position j (within the stage's row), cout half c: row = 32 j + 16 c + l16
     const int u_off = l16 * 16 + 4 * (kq ^ ((0x78 >> (2 * ((l16 >> 2) & 3))) & 3));
 
-    // state carried from stage to stage: r_i of the current stage, the fragments of its first position
-    f32x4 r[4], uf[2][WF_NT], v[2];
-    auto read_r = [&](const float* hb, int i) {           // r_i[b] = d[a1][b] -+ d[a2][b]
-        if ((WF_ABLATE & 4) && past_prologue) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) r[b] = wf_sub(i) ? r[b] - r[(b + 1) & 3] : r[b] + r[(b + 1) & 3];
-            return;
-        }
-        const float* vb = hb + v_off;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const f32x4 d1 = *reinterpret_cast<const f32x4*>(vb + ((2 * wf_a1(i) + (b & 1)) * WF_HP + (b >> 1)) * WF_PS);
-            const f32x4 d2 = *reinterpret_cast<const f32x4*>(vb + ((2 * wf_a2(i) + (b & 1)) * WF_HP + (b >> 1)) * WF_PS);
-            r[b] = wf_sub(i) ? d1 - d2 : d1 + d2;
-        }
+    // state carried from stage to stage: r_i of the current stage (as register pairs: the transform adds are v_pk_add_f32),
+    // the fragments of its first position
+    f32x2 r[4][2], v[2][2];
+    f32x4 uf[2][WF_NT], d[8];
+    // the 8 patch-row reads of position row i: n = 2 b + (0: row a1, 1: row a2)
+    auto read_d = [&](const float* hb, int i, int n) {
+        const int b = n >> 1, a = (n & 1) ? wf_a2(i) : wf_a1(i);
+        d[n] = *reinterpret_cast<const f32x4*>(hb + v_off + ((2 * a + (b & 1)) * WF_HP + (b >> 1)) * WF_PS);
     };
-    auto make_v = [&](int j) -> f32x4 { return wf_sub(j) ? r[wf_a1(j)] - r[wf_a2(j)] : r[wf_a1(j)] + r[wf_a2(j)]; };
-    auto read_u = [&](int buf, int j, f32x4 (&f)[WF_NT]) {
-        if ((WF_ABLATE & 8) && past_prologue) { f[0] = f[0] + f[1]; f[1] = f[1] - f[0]; return; }
-        const float* ub = ub0 + buf * WF_U_F + u_off + (WF_BN * j) * 16;
-#pragma unroll
-        for (int c = 0; c < WF_NT; ++c) f[c] = *reinterpret_cast<const f32x4*>(ub + c * 16 * 16);
+    // r_i[b] = d[a1][b] -+ d[a2][b], one register pair (m = 2 b + half) per instruction
+    auto make_r = [&](int i, int m) {
+        const int b = m >> 1;
+        r[b][m & 1] = (m & 1) ? wf_pk(wf_sub(i), wf_hi(d[2 * b]), wf_hi(d[2 * b + 1])) : wf_pk(wf_sub(i), wf_lo(d[2 * b]), wf_lo(d[2 * b + 1]));
+    };
+    // V[i][j] = r_i[a1(j)] -+ r_i[a2(j)]
+    auto make_v = [&](int j, int slot, int h) { v[slot][h] = wf_pk(wf_sub(j), r[wf_a1(j)][h], r[wf_a2(j)][h]); };
+    auto read_u = [&](int buf, int j, int slot, int cc) {
+        uf[slot][cc] = *reinterpret_cast<const f32x4*>(ub0 + buf * WF_U_F + u_off + (WF_BN * j + 16 * cc) * 16);
     };
 
     // ---- prologue ---------------------------------------------------------------------------------------------------------
@@ -258,17 +269,24 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         f32x4 h0[WF_NH];
 #pragma unroll
         for (int it = 0; it < WF_NH; ++it) load_halo_piece(h0[it], it, 0);
-        load_u(ureg[0], 0, 0);
+#pragma unroll
+        for (int it = 0; it < WF_NU; ++it) load_u_piece(ureg[0][it], 0, 0, it);
 #pragma unroll
         for (int it = 0; it < WF_NH; ++it) store_halo_piece(halo0, h0[it], it);
-        store_u(0, ureg[0]);
-        load_u(ureg[1], 0, 1);                           // slab 1: written to LDS in stage 0
+#pragma unroll
+        for (int it = 0; it < WF_NU; ++it) store_u_piece(0, ureg[0][it], it);
+#pragma unroll
+        for (int it = 0; it < WF_NU; ++it) load_u_piece(ureg[1][it], 0, 1, it);       // slab 1: written to LDS in stage 0
     }
     __syncthreads();
-    read_r(halo0, 0);
-    read_u(0, 0, uf[0]);
-    v[0] = make_v(0);
-    past_prologue = true;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) read_d(halo0, 0, n);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) make_r(0, m);
+    read_u(0, 0, 0, 0);
+    read_u(0, 0, 0, 1);
+    make_v(0, 0, 0);
+    make_v(0, 0, 1);
 
     // the first third of chunk 1's halo (the slot of "stage 3 of the previous chunk")
     {
@@ -277,90 +295,98 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         load_halo_piece(hreg[1][1], 1, c1);
     }
 
-    for (int c = 0; c < nchunks; ++c) {
+    // The K loop is scheduled BY HAND: every statement group below is one MFMA plus at most two other instructions, fenced
+    // with sched_barrier(0) so that hipcc keeps the order.  A batch of non-MFMA instructions between two MFMAs holds the
+    // wave's issue slot while the matrix pipe drains (measured: ~5 pipe cycles per instruction); one or two of them right
+    // behind an MFMA issue are hidden under its 32 cycles.
+#define WF_GAP() __builtin_amdgcn_sched_barrier(0)
+    in_loop = true;
+#if WF_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef WF_CLOCKS
+    const unsigned long long clk0 = __builtin_readcyclecounter(), real0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // one chunk; PAR = chunk parity = halo buffer, a compile-time constant so that every LDS address of the loop is an
+    // instruction immediate (address arithmetic on the vector ALU costs matrix-pipe time like any other vector instruction)
+    auto chunk_body = [&](const int c, auto par) {
+        constexpr int PAR = decltype(par)::value;
         const int cn = (c + 1) < nchunks ? c + 1 : c;    // clamped: past the last chunk the loads re-read it, harmlessly
         const int cnn = (c + 2) < nchunks ? c + 2 : cn;
-        float* const hcur = halo0 + (WF_HALO_BUFS == 2 ? (c & 1) * WF_HALO_F : 0);
-        float* const hnxt = halo0 + (WF_HALO_BUFS == 2 ? ((c + 1) & 1) * WF_HALO_F : 0);
+        float* const hcur = halo0 + PAR * WF_HALO_F;
+        float* const hnxt = halo0 + (PAR ^ 1) * WF_HALO_F;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int buf = i & 1;                       // 4 stages per chunk: the slab buffer parity repeats every chunk
-            // Loads of the stage.  Filter slab s+2 (one stage of prefetch is shorter than the L2 latency when the block runs alone
-            // on its CU).  Halo of chunk c+1 in thirds: pieces (0,1) were loaded in stage 3 of the previous chunk, (2,3) and (4,5)
-            // are loaded in stages 0 and 1, each third is written to LDS one stage after its load -- so the whole halo is in LDS
-            // before the barrier of stage 2 and the rows of the NEXT position row can always be read before a stage's barrier.
-            if (i < 2) load_u(ureg[i & 1], c, i + 2); else load_u(ureg[i & 1], cn, i - 2);
-            if (i < 2) { load_halo_piece(hreg[i & 1][0], 2 * i + 2, cn); load_halo_piece(hreg[i & 1][1], 2 * i + 3, cn); }
-            if (i == 3) { load_halo_piece(hreg[1][0], 0, cnn); load_halo_piece(hreg[1][1], 1, cnn); }
-            __builtin_amdgcn_sched_barrier(0);           // the loads stay at the top of the stage (hipcc sinks them to their use otherwise)
-            // phases 0..2: MFMAs of position j under the fragment reads / operand arithmetic of position j + 1
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int cur = j & 1, nxt = cur ^ 1;
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int cc = 0; cc < WF_NT; ++cc)
-                        acc[4 * i + j][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][cc][s], v[cur][s], acc[4 * i + j][cc], 0, 0, 0);
-                read_u(buf, j + 1, uf[nxt]);
-                v[nxt] = make_v(j + 1);
-                constexpr int NM = 4 * WF_NT;
-                if (j == 0) {
-                    // LDS writes early in the stage: by the barrier they have long completed
-                    store_u(buf ^ 1, ureg[(i + 1) & 1]);
-                    if (i < 3) {
-                        const int third = i;             // stage 0 writes pieces (0,1) [loaded in the previous chunk's stage 3], 1: (2,3), 2: (4,5)
-                        store_halo_piece(hnxt, hreg[(i + 1) & 1][0], 2 * third);
-                        store_halo_piece(hnxt, hreg[(i + 1) & 1][1], 2 * third + 1);
-                    }
-#pragma unroll
-                    for (int q = 0; q < WF_NT; ++q) { WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 1); }
-                    WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2);
-#pragma unroll
-                    for (int q = 0; q < WF_NU; ++q) { WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1); }
-                    if (i < 3) { WF_SGB(WF_VALU, 8); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSW, 1); }
-                    WF_SGB(WF_MFMA, NM);                 // whatever is left of the phase's MFMAs
-                } else if (j == 1) {
-#pragma unroll
-                    for (int q = 0; q < WF_NT; ++q) { WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 1); }
-                    WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2);
-                    WF_SGB(WF_MFMA, NM);
-                } else {
-                    // the two patch rows of the NEXT stage's position row (r is dead once V of position 3 exists)
-                    read_r(i == 3 ? hnxt : hcur, (i + 1) & 3);
-                    WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 4);
-#pragma unroll
-                    for (int q = 0; q < WF_NT; ++q) { WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 1); }
-                    WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 4); WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 4);
-                    WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 8); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 8);
-                    WF_SGB(WF_MFMA, NM);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (!(WF_ABLATE & 64)) __syncthreads();
-            // phase 3: MFMAs of position 3 under the first fragments of the next filter slab and the next stage's first operand
-            {
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int cc = 0; cc < WF_NT; ++cc)
-                        acc[4 * i + 3][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[1][cc][s], v[1][s], acc[4 * i + 3][cc], 0, 0, 0);
-                read_u(buf ^ 1, 0, uf[0]);
-                v[0] = make_v(0);
-                constexpr int NM = 4 * WF_NT;
-#pragma unroll
-                for (int q = 0; q < WF_NT; ++q) { WF_SGB(WF_MFMA, 1); WF_SGB(WF_DSR, 1); }
-                WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2); WF_SGB(WF_MFMA, 1); WF_SGB(WF_VALU, 2);
-                WF_SGB(WF_MFMA, NM);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            const int ls = i & 1, ss = (i + 1) & 1;      // register sets: loaded in this stage / written to LDS in this stage
+            const float* const hrow = i == 3 ? hnxt : hcur;
+            const int inext = (i + 1) & 3;
+            auto mfma = [&](int j, int slot, int k) {
+                const int s = k >> 1, cc = k & 1;
+                acc[4 * i + j][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[slot][cc][s], v[slot][s >> 1][s & 1], acc[4 * i + j][cc], 0, 0, 0);
+            };
+            // Data movement of the stage.  Filter slab s+2 is loaded (one stage of prefetch is shorter than the L2 latency when
+            // the block runs alone on its CU), slab s+1 is written to LDS.  Halo of chunk c+1 in thirds: pieces (0,1) were loaded
+            // in stage 3 of the previous chunk, (2,3) and (4,5) are loaded in stages 0 and 1, each third is written to LDS one
+            // stage after its load -- the whole halo is in LDS before the barrier of stage 2.
+            // phase 0: position 0 | fragments + operand of position 1, the stage's global loads
+            mfma(0, 0, 0); read_u(buf, 1, 1, 0); WF_GAP();
+            mfma(0, 0, 1); read_u(buf, 1, 1, 1); WF_GAP();
+            mfma(0, 0, 2); make_v(1, 1, 0); WF_GAP();
+            mfma(0, 0, 3); make_v(1, 1, 1); WF_GAP();
+            mfma(0, 0, 4); if (i < 2) load_u_piece(ureg[ls][0], c, i + 2, 0); else load_u_piece(ureg[ls][0], cn, i - 2, 0); WF_GAP();
+            mfma(0, 0, 5); if (i < 2) load_u_piece(ureg[ls][1], c, i + 2, 1); else load_u_piece(ureg[ls][1], cn, i - 2, 1); WF_GAP();
+            mfma(0, 0, 6); if (i < 2) load_halo_piece(hreg[ls][0], 2 * i + 2, cn); if (i == 3) load_halo_piece(hreg[1][0], 0, cnn); WF_GAP();
+            mfma(0, 0, 7); if (i < 2) load_halo_piece(hreg[ls][1], 2 * i + 3, cn); if (i == 3) load_halo_piece(hreg[1][1], 1, cnn); WF_GAP();
+            // phase 1: position 1 | position 2's fragments + operand, the LDS writes (long done by the barrier)
+            mfma(1, 1, 0); read_u(buf, 2, 0, 0); WF_GAP();
+            mfma(1, 1, 1); read_u(buf, 2, 0, 1); WF_GAP();
+            mfma(1, 1, 2); make_v(2, 0, 0); WF_GAP();
+            mfma(1, 1, 3); make_v(2, 0, 1); WF_GAP();
+            mfma(1, 1, 4); store_u_piece(buf ^ 1, ureg[ss][0], 0); WF_GAP();
+            mfma(1, 1, 5); store_u_piece(buf ^ 1, ureg[ss][1], 1); WF_GAP();
+            mfma(1, 1, 6); if (i < 3) store_halo_piece(hnxt, hreg[ss][0], 2 * i); WF_GAP();
+            mfma(1, 1, 7); if (i < 3) store_halo_piece(hnxt, hreg[ss][1], 2 * i + 1); WF_GAP();
+            // phase 2: position 2 | position 3's fragments + operand (r is dead after it), the patch rows of the NEXT position row
+            mfma(2, 0, 0); read_u(buf, 3, 1, 0); WF_GAP();
+            mfma(2, 0, 1); read_u(buf, 3, 1, 1); WF_GAP();
+            mfma(2, 0, 2); make_v(3, 1, 0); WF_GAP();
+            mfma(2, 0, 3); make_v(3, 1, 1); WF_GAP();
+            mfma(2, 0, 4); read_d(hrow, inext, 0); read_d(hrow, inext, 1); WF_GAP();
+            mfma(2, 0, 5); read_d(hrow, inext, 2); read_d(hrow, inext, 3); WF_GAP();
+            mfma(2, 0, 6); read_d(hrow, inext, 4); read_d(hrow, inext, 5); WF_GAP();
+            mfma(2, 0, 7); read_d(hrow, inext, 6); read_d(hrow, inext, 7); WF_GAP();
+            __syncthreads();
+            WF_GAP();
+            // phase 3: position 3 | the next stage's first fragments (next slab), its r and first operand
+            mfma(3, 1, 0); read_u(buf ^ 1, 0, 0, 0); WF_GAP();
+            mfma(3, 1, 1); read_u(buf ^ 1, 0, 0, 1); WF_GAP();
+            mfma(3, 1, 2); make_r(inext, 0); make_r(inext, 1); WF_GAP();
+            mfma(3, 1, 3); make_r(inext, 2); make_r(inext, 3); WF_GAP();
+            mfma(3, 1, 4); make_r(inext, 4); make_r(inext, 5); WF_GAP();
+            mfma(3, 1, 5); make_r(inext, 6); make_r(inext, 7); WF_GAP();
+            mfma(3, 1, 6); make_v(0, 0, 0); WF_GAP();
+            mfma(3, 1, 7); make_v(0, 0, 1); WF_GAP();
         }
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk_body(c, std::integral_constant<int, 0>());
+        if (c + 1 < nchunks) chunk_body(c + 1, std::integral_constant<int, 1>());
     }
+#undef WF_GAP
+#if WF_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef WF_CLOCKS
+    const unsigned long long clk1 = __builtin_readcyclecounter(), real1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- epilogue: Y = A^T M A on registers; lane = tile (wave, l16) x couts n0 + 16 c + 4 kq .. + 3 -----------------------
     const int ty = WF_TR * by + wave, tx = WF_TC * bx + l16;
     const int th = (H + 1) >> 1, tw = (W + 1) >> 1;
+#ifndef WF_CLOCKS
     if (ty >= th || tx >= tw) return;
+#endif
     const int Ho = H >> 1, Wo = W >> 1;
     if (POOL && (ty >= Ho || tx >= Wo)) return;          // floor pooling drops the odd last row / column
 #pragma unroll
@@ -405,6 +431,17 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
             }
         }
     }
+#ifdef WF_CLOCKS
+    // timing experiment: per wave, written BEHIND the output map (the caller of this build allocates H * W * Cout + 32 * blocks
+    // floats: tools/wf_clocks.py): shader cycles and 100 MHz ticks of the K loop, ticks before and after it, entry time
+    if (lane == 0) {
+        const unsigned long long real_exit = __builtin_amdgcn_s_memrealtime();
+        float* o = y + (size_t)(POOL ? (H >> 1) * (W >> 1) : H * W) * Cout + ((size_t)blockIdx.x * 4 + wave) * 8;
+        o[0] = (float)(clk1 - clk0); o[1] = (float)(real1 - real0); o[2] = (float)(real0 - real_entry); o[3] = (float)(real_exit - real1);
+        o[4] = (float)(real_entry & 0xFFFFFF); o[5] = (float)(real_exit & 0xFFFFFF); o[6] = (float)nchunks;
+        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); o[7] = (float)(hwid & 0xFFFFFF);
+    }
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
