@@ -51,8 +51,9 @@ static constexpr int WF_NU = WF_U_F / 4 / 256;           // 16-byte filter piece
 static constexpr int WF_NHP = WF_NPIX * 4;               // 16-byte halo pieces per chunk
 static constexpr int WF_NH = (WF_NHP + 255) / 256;       // 6 per thread
 #ifndef WF_ABLATE
-#define WF_ABLATE 0                                      // timing experiments only (tools/build_ablate.sh), results wrong: 16 no filter loads,
-#endif                                                   // 32 no halo loads inside the K loop
+#define WF_ABLATE 0                                      // timing experiments only (tools/build_ablate.sh), results wrong.  Inside the K loop:
+#endif                                                   // 1 no operand adds, 2 no patch-row reads, 4 no filter fragment reads, 8 no LDS writes,
+                                                         // 16 no filter loads, 32 no halo loads, 64 no barrier
 #ifndef WF_PRIO
 #define WF_PRIO 1
 #endif
@@ -226,12 +227,18 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         if ((WF_ABLATE & 32) && in_loop) return;
         dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, h_src[it], chunk * 64, 0));
     };
-    auto store_halo_piece = [&](float* hb, const f32x4& src, int it) { *reinterpret_cast<f32x4*>(hb + h_dst[it]) = src; };
+    auto store_halo_piece = [&](float* hb, const f32x4& src, int it) {
+        if ((WF_ABLATE & 8) && in_loop) { asm volatile("" :: "v"(src)); return; }
+        *reinterpret_cast<f32x4*>(hb + h_dst[it]) = src;
+    };
     auto load_u_piece = [&](f32x4& dst, int chunk, int i, int it) {
         if ((WF_ABLATE & 16) && in_loop) return;
         dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, u_voff, u_blk + chunk * u_chunk_stride + (i * WF_U_F + 1024 * it) * (int)sizeof(float), 0));
     };
-    auto store_u_piece = [&](int buf, const f32x4& src, int it) { *reinterpret_cast<f32x4*>(ub0 + buf * WF_U_F + u_dst[it]) = src; };
+    auto store_u_piece = [&](int buf, const f32x4& src, int it) {
+        if ((WF_ABLATE & 8) && in_loop) { asm volatile("" :: "v"(src)); return; }
+        *reinterpret_cast<f32x4*>(ub0 + buf * WF_U_F + u_dst[it]) = src;
+    };
 
     f32x4 acc[16][WF_NT];
 #pragma unroll
@@ -251,16 +258,19 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
     // the 8 patch-row reads of position row i: n = 2 b + (0: row a1, 1: row a2)
     auto read_d = [&](const float* hb, int i, int n) {
         const int b = n >> 1, a = (n & 1) ? wf_a2(i) : wf_a1(i);
+        if ((WF_ABLATE & 2) && in_loop) return;
         d[n] = *reinterpret_cast<const f32x4*>(hb + v_off + ((2 * a + (b & 1)) * WF_HP + (b >> 1)) * WF_PS);
     };
     // r_i[b] = d[a1][b] -+ d[a2][b], one register pair (m = 2 b + half) per instruction
     auto make_r = [&](int i, int m) {
         const int b = m >> 1;
+        if ((WF_ABLATE & 1) && in_loop) return;
         r[b][m & 1] = (m & 1) ? wf_pk(wf_sub(i), wf_hi(d[2 * b]), wf_hi(d[2 * b + 1])) : wf_pk(wf_sub(i), wf_lo(d[2 * b]), wf_lo(d[2 * b + 1]));
     };
     // V[i][j] = r_i[a1(j)] -+ r_i[a2(j)]
-    auto make_v = [&](int j, int slot, int h) { v[slot][h] = wf_pk(wf_sub(j), r[wf_a1(j)][h], r[wf_a2(j)][h]); };
+    auto make_v = [&](int j, int slot, int h) { if ((WF_ABLATE & 1) && in_loop) return; v[slot][h] = wf_pk(wf_sub(j), r[wf_a1(j)][h], r[wf_a2(j)][h]); };
     auto read_u = [&](int buf, int j, int slot, int cc) {
+        if ((WF_ABLATE & 4) && in_loop) return;
         uf[slot][cc] = *reinterpret_cast<const f32x4*>(ub0 + buf * WF_U_F + u_off + (WF_BN * j + 16 * cc) * 16);
     };
 
@@ -329,44 +339,44 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
             // the block runs alone on its CU), slab s+1 is written to LDS.  Halo of chunk c+1 in thirds: pieces (0,1) were loaded
             // in stage 3 of the previous chunk, (2,3) and (4,5) are loaded in stages 0 and 1, each third is written to LDS one
             // stage after its load -- the whole halo is in LDS before the barrier of stage 2.
-            // phase 0: position 0 | fragments + operand of position 1, the stage's global loads
-            mfma(0, 0, 0); read_u(buf, 1, 1, 0); WF_GAP();
-            mfma(0, 0, 1); read_u(buf, 1, 1, 1); WF_GAP();
-            mfma(0, 0, 2); make_v(1, 1, 0); WF_GAP();
-            mfma(0, 0, 3); make_v(1, 1, 1); WF_GAP();
-            mfma(0, 0, 4); if (i < 2) load_u_piece(ureg[ls][0], c, i + 2, 0); else load_u_piece(ureg[ls][0], cn, i - 2, 0); WF_GAP();
-            mfma(0, 0, 5); if (i < 2) load_u_piece(ureg[ls][1], c, i + 2, 1); else load_u_piece(ureg[ls][1], cn, i - 2, 1); WF_GAP();
-            mfma(0, 0, 6); if (i < 2) load_halo_piece(hreg[ls][0], 2 * i + 2, cn); if (i == 3) load_halo_piece(hreg[1][0], 0, cnn); WF_GAP();
-            mfma(0, 0, 7); if (i < 2) load_halo_piece(hreg[ls][1], 2 * i + 3, cn); if (i == 3) load_halo_piece(hreg[1][1], 1, cnn); WF_GAP();
-            // phase 1: position 1 | position 2's fragments + operand, the LDS writes (long done by the barrier)
+            // phase 0: position 0 | fragments + operand of position 1, the stage's global loads and LDS writes
+            mfma(0, 0, 0); read_u(buf, 1, 1, 0); if (i < 2) load_u_piece(ureg[ls][0], c, i + 2, 0); else load_u_piece(ureg[ls][0], cn, i - 2, 0); WF_GAP();
+            mfma(0, 0, 1); read_u(buf, 1, 1, 1); if (i < 2) load_u_piece(ureg[ls][1], c, i + 2, 1); else load_u_piece(ureg[ls][1], cn, i - 2, 1); WF_GAP();
+            mfma(0, 0, 2); make_v(1, 1, 0); if (i < 2) load_halo_piece(hreg[ls][0], 2 * i + 2, cn); if (i == 3) load_halo_piece(hreg[1][0], 0, cnn); WF_GAP();
+            mfma(0, 0, 3); make_v(1, 1, 1); if (i < 2) load_halo_piece(hreg[ls][1], 2 * i + 3, cn); if (i == 3) load_halo_piece(hreg[1][1], 1, cnn); WF_GAP();
+            mfma(0, 0, 4); store_u_piece(buf ^ 1, ureg[ss][0], 0); WF_GAP();
+            mfma(0, 0, 5); store_u_piece(buf ^ 1, ureg[ss][1], 1); WF_GAP();
+            mfma(0, 0, 6); if (i < 3) store_halo_piece(hnxt, hreg[ss][0], 2 * i); WF_GAP();
+            mfma(0, 0, 7); if (i < 3) store_halo_piece(hnxt, hreg[ss][1], 2 * i + 1); WF_GAP();
+            // phase 1: position 1 | position 2's fragments + operand, the patch rows of the NEXT position row (long landed by the barrier)
             mfma(1, 1, 0); read_u(buf, 2, 0, 0); WF_GAP();
             mfma(1, 1, 1); read_u(buf, 2, 0, 1); WF_GAP();
             mfma(1, 1, 2); make_v(2, 0, 0); WF_GAP();
             mfma(1, 1, 3); make_v(2, 0, 1); WF_GAP();
-            mfma(1, 1, 4); store_u_piece(buf ^ 1, ureg[ss][0], 0); WF_GAP();
-            mfma(1, 1, 5); store_u_piece(buf ^ 1, ureg[ss][1], 1); WF_GAP();
-            mfma(1, 1, 6); if (i < 3) store_halo_piece(hnxt, hreg[ss][0], 2 * i); WF_GAP();
-            mfma(1, 1, 7); if (i < 3) store_halo_piece(hnxt, hreg[ss][1], 2 * i + 1); WF_GAP();
-            // phase 2: position 2 | position 3's fragments + operand (r is dead after it), the patch rows of the NEXT position row
+            mfma(1, 1, 4); read_d(hrow, inext, 0); read_d(hrow, inext, 1); WF_GAP();
+            mfma(1, 1, 5); read_d(hrow, inext, 2); read_d(hrow, inext, 3); WF_GAP();
+            mfma(1, 1, 6); read_d(hrow, inext, 4); read_d(hrow, inext, 5); WF_GAP();
+            mfma(1, 1, 7); read_d(hrow, inext, 6); read_d(hrow, inext, 7); WF_GAP();
+            // phase 2: position 2 | position 3's fragments + operand (r is dead after it), then the next row's r
             mfma(2, 0, 0); read_u(buf, 3, 1, 0); WF_GAP();
             mfma(2, 0, 1); read_u(buf, 3, 1, 1); WF_GAP();
             mfma(2, 0, 2); make_v(3, 1, 0); WF_GAP();
             mfma(2, 0, 3); make_v(3, 1, 1); WF_GAP();
-            mfma(2, 0, 4); read_d(hrow, inext, 0); read_d(hrow, inext, 1); WF_GAP();
-            mfma(2, 0, 5); read_d(hrow, inext, 2); read_d(hrow, inext, 3); WF_GAP();
-            mfma(2, 0, 6); read_d(hrow, inext, 4); read_d(hrow, inext, 5); WF_GAP();
-            mfma(2, 0, 7); read_d(hrow, inext, 6); read_d(hrow, inext, 7); WF_GAP();
-            __syncthreads();
+            mfma(2, 0, 4); make_r(inext, 0); make_r(inext, 1); WF_GAP();
+            mfma(2, 0, 5); make_r(inext, 2); make_r(inext, 3); WF_GAP();
+            mfma(2, 0, 6); make_r(inext, 4); make_r(inext, 5); WF_GAP();
+            mfma(2, 0, 7); make_r(inext, 6); make_r(inext, 7); WF_GAP();
+            if (!(WF_ABLATE & 64)) __syncthreads();
             WF_GAP();
-            // phase 3: position 3 | the next stage's first fragments (next slab), its r and first operand
+            // phase 3: position 3 | the next stage's first fragments (next slab) and first operand
             mfma(3, 1, 0); read_u(buf ^ 1, 0, 0, 0); WF_GAP();
             mfma(3, 1, 1); read_u(buf ^ 1, 0, 0, 1); WF_GAP();
-            mfma(3, 1, 2); make_r(inext, 0); make_r(inext, 1); WF_GAP();
-            mfma(3, 1, 3); make_r(inext, 2); make_r(inext, 3); WF_GAP();
-            mfma(3, 1, 4); make_r(inext, 4); make_r(inext, 5); WF_GAP();
-            mfma(3, 1, 5); make_r(inext, 6); make_r(inext, 7); WF_GAP();
-            mfma(3, 1, 6); make_v(0, 0, 0); WF_GAP();
-            mfma(3, 1, 7); make_v(0, 0, 1); WF_GAP();
+            mfma(3, 1, 2); make_v(0, 0, 0); WF_GAP();
+            mfma(3, 1, 3); make_v(0, 0, 1); WF_GAP();
+            mfma(3, 1, 4); WF_GAP();
+            mfma(3, 1, 5); WF_GAP();
+            mfma(3, 1, 6); WF_GAP();
+            mfma(3, 1, 7); WF_GAP();
         }
     };
     for (int c = 0; c < nchunks; c += 2) {
