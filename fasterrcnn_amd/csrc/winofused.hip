@@ -310,6 +310,11 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
     // wave's issue slot while the matrix pipe drains (measured: ~5 pipe cycles per instruction); one or two of them right
     // behind an MFMA issue are hidden under its 32 cycles.
 #define WF_GAP() __builtin_amdgcn_sched_barrier(0)
+    if (WF_ABLATE) {                                     // ablated loops still multiply real data (MFMA timing of junk / zero operands differs)
+        v[1][0] = v[0][0]; v[1][1] = v[0][1]; uf[1][0] = uf[0][1]; uf[1][1] = uf[0][0];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) d[n] = uf[n & 1][n >> 2 & 1];
+    }
     in_loop = true;
 #if WF_PRIO
     __builtin_amdgcn_s_setprio(0);

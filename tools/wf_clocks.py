@@ -35,9 +35,10 @@ def run(h, w, cin, cout, reps=30):
     flop = nblk * stages * 4 * 32 * 2048.0
     print("%4dx%-4d %3d->%3d  blocks %5d | launch %.1f us (events), first entry -> last exit %.1f us | sclk %.0f MHz | K loop %.0f cycles/stage "
           "(p10 %.0f, p90 %.0f; 2048 = both waves of a SIMD back to back) | per block: before the loop %.2f us, loop %.2f us, after %.2f us | "
-          "slot occupancy %.2f of 512 | executed %.1f TF"
+          "(sum %.2f us = %.0f cycles per stage pair) | slot occupancy %.2f of 512 | executed %.1f TF"
           % (h, w, cin, cout, nblk, us, span, mhz.mean(), (cyc / stages).mean(), np.percentile(cyc / stages, 10), np.percentile(cyc / stages, 90),
-             pro.mean() / 100.0, real.mean() / 100.0, epi.mean() / 100.0, busy / (512.0 * span), flop / us / 1e6))
+             pro.mean() / 100.0, real.mean() / 100.0, epi.mean() / 100.0, (pro + real + epi).mean() / 100.0,
+             (pro + real + epi).mean() / 100.0 * mhz.mean() / stages, busy / (512.0 * span), flop / us / 1e6))
     return o
 
 
