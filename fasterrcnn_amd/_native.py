@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
-ABI_VERSION = 4     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
+ABI_VERSION = 5     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
@@ -42,6 +42,7 @@ SYMBOLS = (
     "frcnn_roi_align", "frcnn_roi_align_backward",
     # training path
     "frcnn_label_proposals", "frcnn_gather_rows", "frcnn_rpn_loss", "frcnn_detector_loss",
+    "frcnn_gemm_tn_math", "frcnn_conv3x3_wgrad_math", "frcnn_conv_wgrad_math",
     "frcnn_gemm_tn_workspace_bytes", "frcnn_gemm_tn", "frcnn_conv3x3_wgrad_workspace_bytes", "frcnn_conv3x3_wgrad",
     "frcnn_pack_conv3x3_dgrad", "frcnn_relu_backward", "frcnn_add_inplace", "frcnn_maxpool2x2_backward",
     "frcnn_roi_pool_backward_workspace_bytes", "frcnn_roi_pool_backward", "frcnn_transpose", "frcnn_sgd_step",
@@ -102,6 +103,7 @@ MATH_F32 = 0      # exact f32 MFMA
 MATH_F32X6 = 1    # bf16x3 split operands, six bf16 MFMAs per product, f32 accumulate
 MATH_F32_WINOGRAD = 2   # exact f32 MFMA; 3x3 layers with uses_winograd(cin, cout) as Winograd F(2x2,3x3) in float32
 MATH_MODES = {"f32": MATH_F32, "f32x6": MATH_F32X6, "f32_winograd": MATH_F32_WINOGRAD}
+GRAD_MATHS = {"f32": 0, "bf16": 1}         # FRCNN_GRAD_F32 / FRCNN_GRAD_BF16: arithmetic of the train step's gradient GEMMs
 ROI_OPS = {"pool": 0, "align": 1}          # FRCNN_ROI_POOL (the reference) / FRCNN_ROI_ALIGN (torchvision roi_align semantics)
 FC_MATH_MODES = {"f32": 0, "f32x6": 1}   # FRCNN_FC_F32 / FRCNN_FC_F32X6: arithmetic of the VGG-16 detector's fc1 / fc2
 
@@ -196,6 +198,9 @@ _SIGNATURES = {
     "frcnn_detector_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "frcnn_gemm_tn_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "frcnn_gemm_tn": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "frcnn_gemm_tn_math": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "frcnn_conv3x3_wgrad_math": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "frcnn_conv_wgrad_math": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "frcnn_conv3x3_wgrad_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "frcnn_conv3x3_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "frcnn_pack_conv3x3_dgrad": (C.c_int, [_vp, _vp, _i, _i, _vp]),

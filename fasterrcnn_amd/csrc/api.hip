@@ -426,6 +426,13 @@ int frcnn_gemm_tn(const float* d_a, int lda, const float* d_b, int ldb, float* d
     return launch_gemm_tn(d_a, lda, d_b, ldb, d_c, ldc, M, N, R, d_ws, ws_bytes, as_stream(stream));
 }
 
+int frcnn_gemm_tn_math(const float* d_a, int lda, const float* d_b, int ldb, float* d_c, int ldc,
+                       int M, int N, int R, int grad_math, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_a || !d_b || !d_c) return FRCNN_EINVAL;
+    return launch_gemm_tn(d_a, lda, d_b, ldb, d_c, ldc, M, N, R, d_ws, ws_bytes, as_stream(stream), grad_math);
+}
+
 size_t frcnn_conv3x3_wgrad_workspace_bytes(int H, int W, int cin, int cout)
 {
     return H > 0 && W > 0 && cin > 0 && cout > 0 ? gemm_tn_workspace_bytes(cout, cin, H * W, 9) : 0;
@@ -436,6 +443,13 @@ int frcnn_conv3x3_wgrad(const float* d_x, const float* d_dz, float* d_dwp, int H
 {
     if (!d_x || !d_dz || !d_dwp) return FRCNN_EINVAL;
     return launch_conv3x3_wgrad(d_x, d_dz, d_dwp, H, W, cin, cout, d_ws, ws_bytes, as_stream(stream));
+}
+
+int frcnn_conv3x3_wgrad_math(const float* d_x, const float* d_dz, float* d_dwp, int H, int W, int cin, int cout,
+                             int grad_math, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_x || !d_dz || !d_dwp) return FRCNN_EINVAL;
+    return launch_conv3x3_wgrad(d_x, d_dz, d_dwp, H, W, cin, cout, d_ws, ws_bytes, as_stream(stream), grad_math);
 }
 
 int frcnn_pack_conv3x3_dgrad(const float* d_wp, float* d_wd, int cout, int cin, void* stream)
@@ -456,6 +470,13 @@ int frcnn_conv_wgrad(const float* d_x, const float* d_dz, float* d_dwp, int N, i
 {
     if (!d_x || !d_dz || !d_dwp) return FRCNN_EINVAL;
     return launch_conv_wgrad(d_x, d_dz, d_dwp, N, H, W, cin, cout, ksize, stride, pad, d_ws, ws_bytes, as_stream(stream));
+}
+
+int frcnn_conv_wgrad_math(const float* d_x, const float* d_dz, float* d_dwp, int N, int H, int W, int cin, int cout,
+                          int ksize, int stride, int pad, int grad_math, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_x || !d_dz || !d_dwp) return FRCNN_EINVAL;
+    return launch_conv_wgrad(d_x, d_dz, d_dwp, N, H, W, cin, cout, ksize, stride, pad, d_ws, ws_bytes, as_stream(stream), grad_math);
 }
 
 size_t frcnn_conv_dgrad_workspace_bytes(int N, int H, int W, int cin, int cout, int ksize, int stride, int pad)

@@ -169,9 +169,9 @@ int launch_detections(const float* props, const float* classes, const float* del
 // gemm_tn.hip / train.hip (train step)
 size_t gemm_tn_workspace_bytes(int M, int N, int R, int taps);
 int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int R,
-                   void* ws, size_t ws_bytes, hipStream_t s);
+                   void* ws, size_t ws_bytes, hipStream_t s, int math = FRCNN_GRAD_F32);
 int launch_conv3x3_wgrad(const float* x, const float* dz, float* dwp, int H, int W, int cin, int cout,
-                         void* ws, size_t ws_bytes, hipStream_t s);
+                         void* ws, size_t ws_bytes, hipStream_t s, int math = FRCNN_GRAD_F32);
 int launch_label_proposals(const float* props, const int32_t* n_props, int max_props, const float* gt,
                            const int32_t* gt_cls, int M, int ncls, float bg_thr, float obj_thr,
                            const float means[4], const float stds[4], float* out_props, int32_t* out_cls,
@@ -191,7 +191,7 @@ int launch_roi_pool_backward(const float* fm, int fh, int fw, int C, const float
 int launch_transpose(const float* x, int ldi, float* y, int ldo, int rows, int cols, hipStream_t s);
 int launch_pack_conv3x3_dgrad(const float* wp, float* wd, int cout, int cin, hipStream_t s);
 int launch_conv_wgrad(const float* x, const float* dz, float* dwp, int N, int H, int W, int cin, int cout, int ks, int stride,
-                      int pad, void* ws, size_t ws_bytes, hipStream_t s);
+                      int pad, void* ws, size_t ws_bytes, hipStream_t s, int math = FRCNN_GRAD_F32);
 size_t conv_dgrad_workspace_bytes(int N, int H, int W, int cin, int cout, int R, int stride, int pad);
 int launch_conv_dgrad(const float* dz, const float* wd, const float* residual, float* dx, int N, int H, int W, int cin,
                       int cout, int R, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t s);

@@ -188,6 +188,149 @@ void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restric
         }
 }
 
+// ---- bf16 operands (BASELINE configs[4]: the reduced-precision train step) --------------------------
+// The same GEMM with both operands rounded to bfloat16 (round to nearest even: v_cvt_pk_bf16_f32, what torch's .bfloat16() does)
+// on their way into LDS and multiplied on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the f32 pipe's rate), float32
+// accumulation.  Products of bf16 values are exact in f32, so the result differs from the f32 GEMM of the ROUNDED operands only
+// by the accumulation order -- the oracle (oracle/train_oracle.py, grad_math="bf16") states exactly that.
+//
+// The MFMA wants 8 consecutive reduction indices of one m per lane while the operands are reduction-major in memory, so the
+// staging transposes: a thread loads the same four columns of 8 consecutive reduction rows (8 x 16 B, each a coalesced row
+// segment across the wave), converts, and writes four 16-byte LDS pieces [m][8 r].  LDS rows are 32 bf16 + 8 pad (80 B: the
+// fragment reads of the 32 x 2 lane map are conflict-free).  Out-of-range rows / shifted pixels outside the image are buffer
+// loads past the descriptor: the hardware returns zeros.
+static constexpr int GB_RK = 32;     // reduction rows per stage (two MFMA k-steps)
+static constexpr int GB_ROW = 40;    // bf16 per LDS row
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <bool CONV>
+__global__ __launch_bounds__(256)
+void gemm_tn_bf16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                         float* __restrict__ C, int ldc, int M, int N, int R,
+                         int rows_per_split, int splits, float* __restrict__ ws, WgradGeom cg, unsigned a_bytes, unsigned b_bytes)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][GT_T][GB_ROW];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][GT_T][GB_ROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * GT_T, m0 = blockIdx.y * GT_T;
+    const int tap = blockIdx.z / splits, split = blockIdx.z - tap * splits;
+    const int r_begin = split * rows_per_split;
+    int r_end = r_begin + rows_per_split;
+    if (r_end > R) r_end = R;
+    const int dy = CONV ? tap / cg.ks - cg.pad : 0, dx = CONV ? tap % cg.ks - cg.pad : 0;
+
+    // staging task of this thread: waves 0,1 stage A, waves 2,3 stage B; columns 4 mq .. + 3 of reduction rows 8 ro .. + 7
+    const bool is_b = tid >= 128;
+    const int q = tid & 127, mq = q & 31, ro = q >> 5;
+    const int ld = is_b ? ldb : lda;
+    const int col = (is_b ? n0 : m0) + 4 * mq;
+    const bool col_ok = col + 4 <= ld;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(is_b ? B : A), 0, (int)(is_b ? b_bytes : a_bytes), 0x00020000);
+    unsigned short (*const dst0)[GB_ROW] = is_b ? Bs[0] : As[0];
+
+    f32x4 reg[8];
+    auto load_stage = [&](int r0) {
+        const int r = r0 + 8 * ro;
+        int n_ = 0, oy = 0, ox = 0;
+        if (CONV && is_b) {
+            const int hw = cg.Ho * cg.Wo;
+            n_ = r / hw;
+            const int rem = r - n_ * hw;
+            oy = rem / cg.Wo;
+            ox = rem - oy * cg.Wo;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bool ok = (r + j) < r_end && col_ok;
+            unsigned row = (unsigned)(r + j);
+            if (CONV && is_b) {
+                const int sy = oy * cg.stride + dy, sx = ox * cg.stride + dx;
+                ok = ok && sy >= 0 && sy < cg.H && sx >= 0 && sx < cg.W;
+                row = (unsigned)((n_ * cg.H + sy) * cg.W + sx);
+                if (++ox == cg.Wo) { ox = 0; if (++oy == cg.Ho) { oy = 0; ++n_; } }
+            }
+            const unsigned off = ok ? (row * (unsigned)ld + (unsigned)col) * 4u : 0xFFFFFFF0u;
+            reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8_t v;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const bf16x2_t pr = __builtin_convertvector(f32x2{reg[j][c], reg[j + 1][c]}, bf16x2_t);
+                v[j] = pr[0];
+                v[j + 1] = pr[1];
+            }
+            *reinterpret_cast<bf16x8_t*>(&dst0[buf * GT_T + 4 * mq + c][8 * ro]) = v;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nstages = (r_end - r_begin + GB_RK - 1) / GB_RK;
+    if (nstages > 0) {
+        load_stage(r_begin);
+        store_stage(0);
+        __syncthreads();
+        for (int s = 0; s < nstages; ++s) {
+            const int cur = s & 1;
+            load_stage(r_begin + (s + 1) * GB_RK);           // past the range: zeros
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t af[2], bf[2];
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    af[tl] = *reinterpret_cast<const bf16x8_t*>(&As[cur][wm * 64 + tl * 32 + li][ks * 16 + lh * 8]);
+                    bf[tl] = *reinterpret_cast<const bf16x8_t*>(&Bs[cur][wn * 64 + tl * 32 + li][ks * 16 + lh * 8]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+            }
+            store_stage(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // acc[mt][nt][reg] = C[m0 + 64 wm + 32 mt + i][n0 + 64 wn + 32 nt + li],  i = (reg&3) + 8 (reg>>2) + 4 lh
+    float* out;
+    int ld_out;
+    if (ws != nullptr) {
+        out = ws + ((size_t)split * gridDim.z / splits + tap) * (size_t)M * N;   // [split][tap][M][N]
+        ld_out = N;
+    } else {
+        out = C + (size_t)tap * M * ldc;
+        ld_out = ldc;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + 64 * wn + 32 * nt + li;
+            if (n >= N) continue;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + 64 * wm + 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                if (m < M) out[(size_t)m * ld_out + n] = acc[mt][nt][reg];
+            }
+        }
+}
+
 // C[tap][m][n] (row stride ldc) = sum over splits of ws[split][tap][m][n], ascending split order.
 __global__ __launch_bounds__(256)
 void gemm_tn_reduce_kernel(const float* __restrict__ ws, int splits, int taps, int M, int N,
@@ -211,7 +354,7 @@ void gemm_tn_reduce_kernel(const float* __restrict__ ws, int splits, int taps, i
 
 namespace {
 // Reduction ranges so that the launch has ~1024+ blocks, each range >= 64 rows, partials fit in ws.
-void choose_split(int M, int N, int R, int taps, size_t ws_bytes, bool have_ws, int* splits, int* rows_per_split)
+void choose_split(int M, int N, int R, int taps, size_t ws_bytes, bool have_ws, int* splits, int* rows_per_split, int rk)
 {
     const long tiles = (long)cdiv(M, GT_T) * cdiv(N, GT_T) * taps;
     int s = 1;
@@ -224,23 +367,32 @@ void choose_split(int M, int N, int R, int taps, size_t ws_bytes, bool have_ws, 
         if ((size_t)s > max_by_ws) s = (int)max_by_ws;
         if (s < 1) s = 1;
     }
-    int rps = cdiv(cdiv(R, s), GT_RK) * GT_RK;
-    if (rps < GT_RK) rps = GT_RK;
+    int rps = cdiv(cdiv(R, s), rk) * rk;           // multiples of the bf16 kernel's 32-row stage (the f32 kernel's is 16)
+    if (rps < rk) rps = rk;
     *splits = cdiv(R, rps) > 0 ? cdiv(R, rps) : 1;
     *rows_per_split = rps;
 }
 
 template <bool CONV>
 int launch_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int R, int taps,
-              WgradGeom cg, void* ws, size_t ws_bytes, hipStream_t s)
+              WgradGeom cg, void* ws, size_t ws_bytes, hipStream_t s, int math = FRCNN_GRAD_F32, size_t b_rows = 0)
 {
     int splits, rps;
-    choose_split(M, N, R, taps, ws_bytes, ws != nullptr, &splits, &rps);
+    choose_split(M, N, R, taps, ws_bytes, ws != nullptr, &splits, &rps, math == FRCNN_GRAD_BF16 ? GB_RK : GT_RK);
     if (cdiv(N, GT_T) > 65535 || cdiv(M, GT_T) > 65535 || taps * splits > 65535) return FRCNN_EINVAL;
     float* part = splits > 1 ? static_cast<float*>(ws) : nullptr;
     dim3 grid(cdiv(N, GT_T), cdiv(M, GT_T), taps * splits);
-    hipLaunchKernelGGL((gemm_tn_kernel<CONV>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, R, rps, splits,
-                       part, cg);
+    if (math == FRCNN_GRAD_BF16) {
+        const size_t a_bytes = (size_t)R * lda * sizeof(float), b_bytes = (CONV ? b_rows : (size_t)R) * ldb * sizeof(float);
+        if (a_bytes >= 0xFFFFFFF0u || b_bytes >= 0xFFFFFFF0u) return FRCNN_EINVAL;      // 32-bit buffer offsets
+        hipLaunchKernelGGL((gemm_tn_bf16_kernel<CONV>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, R, rps, splits,
+                           part, cg, (unsigned)a_bytes, (unsigned)b_bytes);
+    } else if (math == FRCNN_GRAD_F32) {
+        hipLaunchKernelGGL((gemm_tn_kernel<CONV>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, R, rps, splits,
+                           part, cg);
+    } else {
+        return FRCNN_EINVAL;
+    }
     int rc = check_launch();
     if (rc || splits == 1) return rc;
     const size_t total = (size_t)taps * M * (N / 2);
@@ -253,33 +405,36 @@ int launch_tn(const float* A, int lda, const float* B, int ldb, float* C, int ld
 
 size_t gemm_tn_workspace_bytes(int M, int N, int R, int taps)
 {
-    int splits, rps;
-    choose_split(M, N, R, taps, (size_t)1 << 40, true, &splits, &rps);
+    int s16, s32, rps;                      // enough for either arithmetic (their stage lengths round the ranges differently)
+    choose_split(M, N, R, taps, (size_t)1 << 40, true, &s16, &rps, GT_RK);
+    choose_split(M, N, R, taps, (size_t)1 << 40, true, &s32, &rps, GB_RK);
+    const int splits = s16 > s32 ? s16 : s32;
     return splits > 1 ? (size_t)splits * taps * M * N * sizeof(float) : 0;
 }
 
 int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int R,
-                   void* ws, size_t ws_bytes, hipStream_t s)
+                   void* ws, size_t ws_bytes, hipStream_t s, int math)
 {
     if (M < 1 || N < 1 || R < 1 || lda < M || ldb < N || ldc < N || (lda & 3) || (ldb & 3) || (ldc & 1)) return FRCNN_EINVAL;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return FRCNN_EINVAL;
     if (reinterpret_cast<uintptr_t>(C) & 7) return FRCNN_EINVAL;
-    return launch_tn<false>(A, lda, B, ldb, C, ldc, M, N, R, 1, WgradGeom{0, 0, 0, 0, 1, 1, 0}, ws, ws_bytes, s);
+    return launch_tn<false>(A, lda, B, ldb, C, ldc, M, N, R, 1, WgradGeom{0, 0, 0, 0, 1, 1, 0}, ws, ws_bytes, s, math);
 }
 
 int launch_conv3x3_wgrad(const float* x, const float* dz, float* dwp, int H, int W, int cin, int cout,
-                         void* ws, size_t ws_bytes, hipStream_t s)
+                         void* ws, size_t ws_bytes, hipStream_t s, int math)
 {
     if (H < 1 || W < 1 || cin < 4 || cout < 4 || (cin & 3) || (cout & 3)) return FRCNN_EINVAL;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dz)) & 15) return FRCNN_EINVAL;
     if ((long)H * W > (1L << 30)) return FRCNN_EINVAL;
     // A = dz [pixel][cout], B = x [pixel (shifted)][cin], C = dwp [tap][cout][cin]
-    return launch_tn<true>(dz, cout, x, cin, dwp, cin, cout, cin, H * W, 9, WgradGeom{H, W, H, W, 3, 1, 1}, ws, ws_bytes, s);
+    return launch_tn<true>(dz, cout, x, cin, dwp, cin, cout, cin, H * W, 9, WgradGeom{H, W, H, W, 3, 1, 1}, ws, ws_bytes, s, math,
+                           (size_t)H * W);
 }
 
 // general form (ResNet bottlenecks): x [N][H][W][cin], dz [N][Ho][Wo][cout] -> dwp [k*k][cout][cin]
 int launch_conv_wgrad(const float* x, const float* dz, float* dwp, int N, int H, int W, int cin, int cout, int ks, int stride,
-                      int pad, void* ws, size_t ws_bytes, hipStream_t s)
+                      int pad, void* ws, size_t ws_bytes, hipStream_t s, int math)
 {
     if (N < 1 || H < 1 || W < 1 || cin < 4 || cout < 4 || (cin & 3) || (cout & 3) || ks < 1 || ks > 7 || stride < 1 || pad < 0)
         return FRCNN_EINVAL;
@@ -287,7 +442,7 @@ int launch_conv_wgrad(const float* x, const float* dz, float* dwp, int N, int H,
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
     if (Ho < 1 || Wo < 1 || (long)N * H * W > (1L << 30)) return FRCNN_EINVAL;
     return launch_tn<true>(dz, cout, x, cin, dwp, cin, cout, cin, N * Ho * Wo, ks * ks, WgradGeom{H, W, Ho, Wo, ks, stride, pad},
-                           ws, ws_bytes, s);
+                           ws, ws_bytes, s, math, (size_t)N * H * W);
 }
 
 }  // namespace frcnn

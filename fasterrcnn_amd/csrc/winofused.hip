@@ -510,7 +510,7 @@ int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b
         attr_set = true;
         if (getenv("FRCNN_DEBUG_OCCUPANCY")) {
             int nb = -1;
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(wino_fused_kernel<false>), 256, WF_LDS_BYTES);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(wino_fused_kernel<false>), 256, WF_LDS_BYTES);
             fprintf(stderr, "wino_fused_kernel: %d blocks per CU at %zu B of LDS\n", nb, WF_LDS_BYTES);
         }
     }

@@ -132,6 +132,10 @@ class FasterRCNNModel(nn.Module):
         # Off by default: measured on the MI355X box it changes nothing (one image at a time: 333.3 img/s with graphs, 334.2
         # eager) -- the kernels are 20-230 us long and the eager launch path already keeps their boundaries at ~2 us.
         self.use_hip_graphs = False
+        # arithmetic of the train step's gradient GEMMs (every weight gradient, the data gradients of the dense layers):
+        # "f32" (the reference's precision) or "bf16" (operands rounded to bfloat16, bf16 matrix pipe, f32 accumulation;
+        # master weights, optimizer, losses and the convolutions' forward / data gradients stay float32) -- BASELINE.json configs[4]
+        self._grad_math = "f32"
         self._train_state = None
         self._gradient_sync = None          # training.enable_data_parallel
         self._slots = {}
@@ -158,6 +162,16 @@ class FasterRCNNModel(nn.Module):
         self._stage2_region_proposal_network.math_mode = mode
         if self._is_resnet:
             self._stage3_detector_network._pool_to_feature_vector.math_mode = mode
+
+    @property
+    def grad_math(self):
+        return self._grad_math
+
+    @grad_math.setter
+    def grad_math(self, mode):
+        if mode not in nv.GRAD_MATHS:
+            raise ValueError("grad_math must be one of %s" % sorted(nv.GRAD_MATHS))
+        self._grad_math = mode
 
     @property
     def fc_math_mode(self):

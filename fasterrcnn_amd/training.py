@@ -45,16 +45,21 @@ def _ws(nbytes, device):
     return t.empty((max(int(nbytes), 4) // 4 + 1,), dtype=t.float32, device=device)
 
 
+# Arithmetic of the gradient GEMMs of the step in progress (FasterRCNNModel.grad_math, set by train_step): "f32" = the exact-f32
+# matrix pipe, "bf16" = operands rounded to bfloat16, bf16 matrix pipe, f32 accumulation (csrc/gemm_tn.hip).
+_GRAD_MATH = 0
+
+
 def gemm_tn(a, lda, b, ldb, m, n, r, out=None, ldc=None):
-    """C[m][n] = sum_r A[r][m] B[r][n] (frcnn_gemm_tn)."""
+    """C[m][n] = sum_r A[r][m] B[r][n] (frcnn_gemm_tn_math)."""
     dev = a.device
     ldc = n if ldc is None else ldc
     c = t.empty((m, ldc), dtype=t.float32, device=dev) if out is None else out
     lib = _lib()
     wsb = int(lib.frcnn_gemm_tn_workspace_bytes(m, n, r))
     ws = _ws(wsb, dev) if wsb else None
-    nv.check(lib.frcnn_gemm_tn(nv.ptr(a), lda, nv.ptr(b), ldb, nv.ptr(c), ldc, m, n, r, nv.ptr(ws), wsb, nv.stream_ptr()),
-             "frcnn_gemm_tn")
+    nv.check(lib.frcnn_gemm_tn_math(nv.ptr(a), lda, nv.ptr(b), ldb, nv.ptr(c), ldc, m, n, r, _GRAD_MATH, nv.ptr(ws), wsb,
+                                    nv.stream_ptr()), "frcnn_gemm_tn_math")
     return c
 
 
@@ -76,8 +81,8 @@ def conv3x3_wgrad(x_hwc, dz_hwc, cin, cout):
     dwp = t.empty((9, cout, cin), dtype=t.float32, device=x_hwc.device)
     wsb = int(lib.frcnn_conv3x3_wgrad_workspace_bytes(h, w, cin, cout))
     ws = _ws(wsb, x_hwc.device) if wsb else None
-    nv.check(lib.frcnn_conv3x3_wgrad(nv.ptr(x_hwc), nv.ptr(dz_hwc), nv.ptr(dwp), h, w, cin, cout, nv.ptr(ws), wsb,
-                                     nv.stream_ptr()), "frcnn_conv3x3_wgrad")
+    nv.check(lib.frcnn_conv3x3_wgrad_math(nv.ptr(x_hwc), nv.ptr(dz_hwc), nv.ptr(dwp), h, w, cin, cout, _GRAD_MATH, nv.ptr(ws), wsb,
+                                          nv.stream_ptr()), "frcnn_conv3x3_wgrad_math")
     return dwp
 
 
@@ -162,8 +167,8 @@ def conv_wgrad(x, dz, n, h, w, cin, cout, k, stride, pad):
     dwp = t.empty((k * k, cout, cin), dtype=t.float32, device=x.device)
     wsb = int(lib.frcnn_conv_wgrad_workspace_bytes(n, h, w, cin, cout, k, stride, pad))
     ws = _ws(wsb, x.device) if wsb else None
-    nv.check(lib.frcnn_conv_wgrad(nv.ptr(x), nv.ptr(dz), nv.ptr(dwp), n, h, w, cin, cout, k, stride, pad, nv.ptr(ws), wsb,
-                                  nv.stream_ptr()), "frcnn_conv_wgrad")
+    nv.check(lib.frcnn_conv_wgrad_math(nv.ptr(x), nv.ptr(dz), nv.ptr(dwp), n, h, w, cin, cout, k, stride, pad, _GRAD_MATH,
+                                       nv.ptr(ws), wsb, nv.stream_ptr()), "frcnn_conv_wgrad_math")
     return dwp
 
 
@@ -608,6 +613,8 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
     `gt_boxes` is [[Box]] (objects with .class_index and .corners, datasets/training_sample.py) .
     `detail`, if a dict, receives gradients and intermediates for the parity tests.
     """
+    global _GRAD_MATH
+    _GRAD_MATH = nv.GRAD_MATHS[model.grad_math]
     model.train()
     assert image_data.shape[0] == 1, "Batch size must be 1"
     assert len(gt_rpn_map.shape) == 5 and gt_rpn_map.shape[0] == 1, "Batch size must be 1"

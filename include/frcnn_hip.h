@@ -37,7 +37,8 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 4   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers */
+#define FRCNN_ABI_VERSION 5   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
+                                 5: bf16 gradient GEMMs (the *_math entry points) */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -477,6 +478,22 @@ int frcnn_detector_loss(const float* d_classes, const float* d_deltas, const flo
 size_t frcnn_gemm_tn_workspace_bytes(int M, int N, int R);
 int frcnn_gemm_tn(const float* d_a, int lda, const float* d_b, int ldb, float* d_c, int ldc,
                   int M, int N, int R, void* d_ws, size_t ws_bytes, void* stream);
+
+/* The reduced-precision train step (BASELINE configs[4]; the reference trains in float32: faster_rcnn.py:355, so this is
+ * beyond it): the same three gradient GEMMs with `grad_math`
+ *   FRCNN_GRAD_F32  : the entry points without the suffix (exact-f32 matrix pipe)
+ *   FRCNN_GRAD_BF16 : both operands rounded to bfloat16 (round to nearest even) on their way to the bf16 matrix pipe, float32
+ *                     accumulation; result = f32 GEMM of the rounded operands up to the accumulation order
+ *                     (oracle/train_oracle.py grad_math="bf16").  Operand arrays < 4 GiB.
+ * Workspace sizes: the functions without the suffix cover both. */
+#define FRCNN_GRAD_F32  0
+#define FRCNN_GRAD_BF16 1
+int frcnn_gemm_tn_math(const float* d_a, int lda, const float* d_b, int ldb, float* d_c, int ldc,
+                       int M, int N, int R, int grad_math, void* d_ws, size_t ws_bytes, void* stream);
+int frcnn_conv3x3_wgrad_math(const float* d_x, const float* d_dz, float* d_dwp, int H, int W, int cin, int cout,
+                             int grad_math, void* d_ws, size_t ws_bytes, void* stream);
+int frcnn_conv_wgrad_math(const float* d_x, const float* d_dz, float* d_dwp, int N, int H, int W, int cin, int cout,
+                          int ksize, int stride, int pad, int grad_math, void* d_ws, size_t ws_bytes, void* stream);
 
 /* conv2d backward of the 3x3 "same" layers (vgg16.py:76-96, rpn.py:88):
  *   weight gradient  d_dwp [9][cout][cin] (the frcnn_pack_conv3x3 layout) from x [H][W][cin], dz [H][W][cout];

@@ -380,13 +380,24 @@ def _bn(x, sd, prefix):
                         sd[prefix + "bias"], False, 0.0, 1e-5)
 
 
+# conv + frozen BatchNorm of a Bottleneck.  oracle/train_oracle.py swaps this for a function with a bf16 weight gradient while it
+# restates the reduced-precision train step (grad_math="bf16"); the forward value is the same.
+CONV_BN = None
+
+
+def _conv_bn(x, sd, wkey, bn_prefix, stride=1, padding=0):
+    if CONV_BN is not None:
+        return CONV_BN(x, sd, wkey, bn_prefix, stride, padding)
+    return _bn(F.conv2d(x, sd[wkey], stride=stride, padding=padding), sd, bn_prefix)
+
+
 def _bottleneck(x, sd, prefix, stride):
-    out = F.relu(_bn(F.conv2d(x, sd[prefix + "conv1.weight"]), sd, prefix + "bn1."))
-    out = F.relu(_bn(F.conv2d(out, sd[prefix + "conv2.weight"], stride=stride, padding=1), sd, prefix + "bn2."))
-    out = _bn(F.conv2d(out, sd[prefix + "conv3.weight"]), sd, prefix + "bn3.")
+    out = F.relu(_conv_bn(x, sd, prefix + "conv1.weight", prefix + "bn1."))
+    out = F.relu(_conv_bn(out, sd, prefix + "conv2.weight", prefix + "bn2.", stride=stride, padding=1))
+    out = _conv_bn(out, sd, prefix + "conv3.weight", prefix + "bn3.")
     identity = x
     if (prefix + "downsample.0.weight") in sd:
-        identity = _bn(F.conv2d(x, sd[prefix + "downsample.0.weight"], stride=stride), sd, prefix + "downsample.1.")
+        identity = _conv_bn(x, sd, prefix + "downsample.0.weight", prefix + "downsample.1.", stride=stride)
     return F.relu(out + identity)
 
 

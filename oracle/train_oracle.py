@@ -267,11 +267,93 @@ def roi_align_autograd(feature_map, proposals, sampling_ratio=2):
     return RoIAlignFunction.apply(feature_map, rois, 7, 1.0 / 16.0, sampling_ratio)
 
 
+# ---- reduced-precision gradient GEMMs (grad_math="bf16"; beyond the reference, which trains in float32) ------------------
+# What csrc/gemm_tn.hip's bf16 kernel computes, restated: every gradient GEMM of the step -- the weight gradient of every
+# convolution and dense layer, the data gradient of the dense layers and of the RPN's 1x1 heads -- multiplies operands rounded to
+# bfloat16 (round to nearest even: torch's .bfloat16()) and accumulates in float32.  Forward passes, the data gradient of the
+# k > 1 convolutions, bias gradients, losses and the optimizer are float32 as before.
+def _bf16r(x):
+    return x.to(t.bfloat16).to(t.float32)
+
+
+class _ConvGradBf16(t.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding, dense):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, dense, b is not None)
+        return F.conv2d(x, w, b, stride=stride, padding=padding)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        stride, padding, dense, has_b = ctx.cfg
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (t.nn.grad.conv2d_input(x.shape, _bf16r(w), _bf16r(g), stride=stride, padding=padding) if dense
+                  else t.nn.grad.conv2d_input(x.shape, w, g, stride=stride, padding=padding))
+        if ctx.needs_input_grad[1]:
+            gw = t.nn.grad.conv2d_weight(_bf16r(x), w.shape, _bf16r(g), stride=stride, padding=padding)
+        if has_b and ctx.needs_input_grad[2]:
+            gb = g.sum(dim=(0, 2, 3))
+        return gx, gw, gb, None, None, None
+
+
+class _LinearGradBf16(t.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gr = _bf16r(g)
+        gx = gr @ _bf16r(w) if ctx.needs_input_grad[0] else None
+        gw = gr.t() @ _bf16r(x) if ctx.needs_input_grad[1] else None
+        gb = g.sum(dim=0) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+class _ConvBnGradBf16(t.autograd.Function):
+    """conv + frozen BatchNorm (fasterrcnn_amd/training.py _TrainConv: one convolution with the folded weight w * scale[co]; the raw
+    weight's gradient is the folded weight's bf16 gradient GEMM times scale[co]; the data gradient is a float32 convolution)."""
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, mean, var, stride, padding):
+        scale = gamma / t.sqrt(var + 1e-5)
+        ctx.save_for_backward(x, w, scale)
+        ctx.cfg = (stride, padding)
+        return F.batch_norm(F.conv2d(x, w, stride=stride, padding=padding), mean, var, gamma, beta, False, 0.0, 1e-5)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, scale = ctx.saved_tensors
+        stride, padding = ctx.cfg
+        sc = scale.reshape(-1, 1, 1, 1)
+        gx = t.nn.grad.conv2d_input(x.shape, w * sc, g, stride=stride, padding=padding) if ctx.needs_input_grad[0] else None
+        gw = sc * t.nn.grad.conv2d_weight(_bf16r(x), w.shape, _bf16r(g), stride=stride, padding=padding) if ctx.needs_input_grad[1] else None
+        return gx, gw, None, None, None, None, None, None
+
+
+def _conv_bn_bf16(x, sd, wkey, bn_prefix, stride, padding):
+    return _ConvBnGradBf16.apply(x, sd[wkey], sd[bn_prefix + "weight"], sd[bn_prefix + "bias"], sd[bn_prefix + "running_mean"],
+                                 sd[bn_prefix + "running_var"], stride, padding)
+
+
+def _conv2d(x, w, b, padding, grad_math, dense=False):
+    if grad_math == "bf16":
+        return _ConvGradBf16.apply(x, w, b, 1, padding, dense)
+    return F.conv2d(x, w, b, padding=padding)
+
+
+def _linear(x, w, b, grad_math):
+    return _LinearGradBf16.apply(x, w, b) if grad_math == "bf16" else F.linear(x, w, b)
+
+
 # ---- the step ---------------------------------------------------------------------------------------
-def vgg16_features_train(p, image, detail=None):
+def vgg16_features_train(p, image, detail=None, grad_math="f32"):
     y = image
     for name, pool in VGG_LAYERS:
-        y = F.relu(F.conv2d(y, p[_S1 + name + ".weight"], p[_S1 + name + ".bias"], padding=1))
+        y = F.relu(_conv2d(y, p[_S1 + name + ".weight"], p[_S1 + name + ".bias"], 1, grad_math))
         if detail is not None:
             detail[name] = y
         if pool:
@@ -282,21 +364,37 @@ def vgg16_features_train(p, image, detail=None):
 def train_step(sd, image, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_object_indices, gt_rpn_background_indices,
                gt_corners, gt_class_idx, num_classes, lr, momentum, weight_decay, momentum_buffers=None,
                rpn_minibatch_size=256, proposal_batch_size=128, allow_edge_proposals=True, detail=None, roi_pooling="pool",
-               sampling_ratio=2):
+               sampling_ratio=2, grad_math="f32"):
     """
     faster_rcnn.py:228-362 for the VGG-16 backbone (dropout 0) followed by SGD.step().
     sd: state_dict of float32 CPU tensors (not modified).  Returns (losses dict, grads dict, new_sd, buffers).
     RNG use (python `random`, then torch's CPU generator) is in the reference's order.
+    grad_math="bf16": the gradient GEMMs on bfloat16-rounded operands (see above); "f32" is the reference.
     """
+    if grad_math not in ("f32", "bf16"):
+        raise ValueError("grad_math")
     train_keys = trainable_weight_keys(sd)
     p = {k: v.clone().requires_grad_(k in train_keys) for k, v in sd.items()}
     image_shape = tuple(image.shape[1:])
     resnet = orc.is_resnet(sd)
-    fm = orc.resnet_features(p, image) if resnet else vgg16_features_train(p, image, detail)
+    orc.CONV_BN = _conv_bn_bf16 if grad_math == "bf16" else None
+    try:
+        return _train_step(sd, p, train_keys, image, image_shape, resnet, anchor_map, anchor_valid_map, gt_rpn_map,
+                           gt_rpn_object_indices, gt_rpn_background_indices, gt_corners, gt_class_idx, num_classes, lr, momentum,
+                           weight_decay, momentum_buffers, rpn_minibatch_size, proposal_batch_size, allow_edge_proposals, detail,
+                           roi_pooling, sampling_ratio, grad_math)
+    finally:
+        orc.CONV_BN = None
+
+
+def _train_step(sd, p, train_keys, image, image_shape, resnet, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_object_indices,
+                gt_rpn_background_indices, gt_corners, gt_class_idx, num_classes, lr, momentum, weight_decay, momentum_buffers,
+                rpn_minibatch_size, proposal_batch_size, allow_edge_proposals, detail, roi_pooling, sampling_ratio, grad_math):
+    fm = orc.resnet_features(p, image) if resnet else vgg16_features_train(p, image, detail, grad_math)
     # stage 2 (rpn.py:88-156) with 12000 / 2000
-    y = F.relu(F.conv2d(fm, p[_S2 + "_rpn_conv1.weight"], p[_S2 + "_rpn_conv1.bias"], padding=1))
-    score_map = t.sigmoid(F.conv2d(y, p[_S2 + "_rpn_class.weight"], p[_S2 + "_rpn_class.bias"]))
-    delta_map = F.conv2d(y, p[_S2 + "_rpn_boxes.weight"], p[_S2 + "_rpn_boxes.bias"])
+    y = F.relu(_conv2d(fm, p[_S2 + "_rpn_conv1.weight"], p[_S2 + "_rpn_conv1.bias"], 1, grad_math))
+    score_map = t.sigmoid(_conv2d(y, p[_S2 + "_rpn_class.weight"], p[_S2 + "_rpn_class.bias"], 0, grad_math, dense=True))
+    delta_map = _conv2d(y, p[_S2 + "_rpn_boxes.weight"], p[_S2 + "_rpn_boxes.bias"], 0, grad_math, dense=True)
     score_map = score_map.permute(0, 2, 3, 1).contiguous()
     delta_map = delta_map.permute(0, 2, 3, 1).contiguous()
     with t.no_grad():
@@ -319,10 +417,10 @@ def train_step(sd, image, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_objec
     else:
         x = pooled.reshape(pooled.shape[0], 512 * 7 * 7)
         pv = _S3 + "_pool_to_feature_vector."
-        h1 = F.relu(F.linear(x, p[pv + "_fc1.weight"], p[pv + "_fc1.bias"]))
-        h2 = F.relu(F.linear(h1, p[pv + "_fc2.weight"], p[pv + "_fc2.bias"]))
-    classes = F.softmax(F.linear(h2, p[_S3 + "_classifier.weight"], p[_S3 + "_classifier.bias"]), dim=1)
-    deltas = F.linear(h2, p[_S3 + "_regressor.weight"], p[_S3 + "_regressor.bias"])
+        h1 = F.relu(_linear(x, p[pv + "_fc1.weight"], p[pv + "_fc1.bias"], grad_math))
+        h2 = F.relu(_linear(h1, p[pv + "_fc2.weight"], p[pv + "_fc2.bias"], grad_math))
+    classes = F.softmax(_linear(h2, p[_S3 + "_classifier.weight"], p[_S3 + "_classifier.bias"], grad_math), dim=1)
+    deltas = _linear(h2, p[_S3 + "_regressor.weight"], p[_S3 + "_regressor.bias"], grad_math)
     l_rc = rpn_class_loss(score_map, minibatch)
     l_rr = rpn_regression_loss(delta_map, minibatch)
     l_dc = detector_class_loss(classes, gt_classes)
