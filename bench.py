@@ -150,9 +150,10 @@ def sample_rocm_smi(load_fn, device_index, seconds=1.2):
         return None
 
 
-def train_step_leg(backbone, dev, steps=10, warmup=3, lr=1e-6, pool=2):
+def train_step_leg(backbone, dev, steps=10, warmup=3, lr=1e-6, pool=2, grad_math="f32", roi_pooling="pool"):
     """ms per FasterRCNNModel.train_step (one 600x1000 synthetic sample per step, batch 1 as the reference trains: forward, four
-    losses, backward, SGD with momentum) -- SURVEY section 8 row f3 / BASELINE configs[4]'s single-GPU fp32 RoIPool form."""
+    losses, backward, SGD with momentum) -- SURVEY section 8 row f3.  grad_math="f32", RoIPool is the reference's step;
+    grad_math="bf16" + roi_pooling="align" on ResNet-101 is BASELINE configs[4]'s single-GPU form."""
     import random
     from fasterrcnn_amd import synthetic, training
     from fasterrcnn_amd.datasets.training_sample import Box
@@ -160,15 +161,16 @@ def train_step_leg(backbone, dev, steps=10, warmup=3, lr=1e-6, pool=2):
     from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
     from fasterrcnn_amd.models.vgg16 import VGG16Backbone
     if backbone == "vgg16":
-        model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+        model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0), roi_pooling=roi_pooling)
         model.load_state_dict(synthetic.vgg16_state_dict(1234), strict=True)
         make_image = synthetic.image
     else:
         arch = {"resnet50": "ResNet50", "resnet101": "ResNet101", "resnet152": "ResNet152"}[backbone]
-        model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(getattr(resnet.Architecture, arch)))
+        model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(getattr(resnet.Architecture, arch)), roi_pooling=roi_pooling)
         model.load_state_dict(synthetic.resnet_state_dict(1234, arch), strict=True)
         make_image = synthetic.image_rgb
     model = model.cuda(dev)
+    model.grad_math = grad_math
     am, vm = anchors.generate_anchor_maps((3, H, W), model.backbone.compute_feature_map_shape((3, H, W)), 16)
     samples = []
     for seed in range(pool):
@@ -192,8 +194,9 @@ def train_step_leg(backbone, dev, steps=10, warmup=3, lr=1e-6, pool=2):
         losses.append(step(i).total)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    return {"ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "math": model.math_mode, "dtype": "f32",
-            "first_total_loss": round(float(losses[0]), 5), "last_total_loss": round(float(losses[-1]), 5)}
+    return {"ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "math": model.math_mode,
+            "dtype": "f32" if grad_math == "f32" else "f32 forward / data gradients, bf16 gradient GEMMs (f32 accumulation, f32 master weights)",
+            "roi": roi_pooling, "first_total_loss": round(float(losses[0]), 5), "last_total_loss": round(float(losses[-1]), 5)}
 
 
 def winograd_chip_full_leg(layers, dev, streams=8, reps=6):
@@ -434,13 +437,15 @@ def main():
         extra["resnet50_images_per_sec"] = round(args.steps / dt, 3)
         extra["resnet50_config"] = "ResNet-50 predict(), 3x600x1000, 8 batch-1 images in flight, math %s" % m50.math_mode
         del m50, pool50
-        # (3) the train step (row f3; configs[4]'s single-GPU fp32 RoIPool form)
+        # (3) the train step (row f3): the reference's fp32 RoIPool step, and configs[4]'s single-GPU form (bf16 gradient GEMMs, RoIAlign)
         extra["train_step_ms"] = {}
-        for bb in ("vgg16", "resnet101"):
+        for name, bb, kw in (("vgg16", "vgg16", {}), ("resnet101", "resnet101", {}),
+                             ("vgg16_bf16", "vgg16", {"grad_math": "bf16"}),
+                             ("resnet101_bf16_roialign", "resnet101", {"grad_math": "bf16", "roi_pooling": "align"})):
             try:
-                extra["train_step_ms"][bb] = train_step_leg(bb, dev)
+                extra["train_step_ms"][name] = train_step_leg(bb, dev, **kw)
             except Exception as e:     # a secondary leg must never take the headline line down with it
-                extra["train_step_ms"][bb] = {"error": "%s: %s" % (type(e).__name__, e)}
+                extra["train_step_ms"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
 
     # ---- mAP@0.5 leg (outside the timed region): labelled subset, merged across ranks -------------

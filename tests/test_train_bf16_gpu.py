@@ -220,3 +220,98 @@ def test_bf16_train_step_full_size_is_deterministic_and_learns(sd_cpu):
     print("600x1000 VGG-16 train step: grad_math bf16 %.2f ms, f32 %.2f ms; total loss %.4f -> %.4f (f32: %.4f)"
           % (ms_bf16, ms_f32, l1[0], l1[-1], lf[-1]))
     assert ms_bf16 < ms_f32
+
+
+def test_bf16_resnet50_train_step_matches_the_bf16_oracle():
+    """ResNet-50 (frozen BatchNorm folded into each convolution: training.py _TrainConv), one step at 352x480 against the oracle's
+    bf16 restatement run here on the same seeds: identical selections and losses; gradients under the float32 step's criteria
+    (tests/test_train_gpu.py: a tight median, looser L2 / norm bounds because two float32 forwards flip a few ReLU decisions) --
+    and closer to the bf16 oracle than to the float32 oracle, which is what shows the arithmetic is the restated one."""
+    from fasterrcnn_amd.models import resnet
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    h, w, seed = 352, 480, 4
+    sd0 = synthetic.resnet_state_dict(1234, "ResNet50")
+    img = synthetic.image_rgb(seed, h, w).unsqueeze(0)
+    gts = synthetic.ground_truth(seed, h, w)
+    boxes = [Box(class_index=c, class_name="x", corners=k) for c, k in gts]
+    am, vm = O.generate_anchor_maps((3, h, w), (1024, -(-h // 16), -(-w // 16)), 16)
+    rmap, obj, bg = O.generate_rpn_map(am, vm, np.stack([k for _, k in gts]))
+    ref = {}
+    for gm in ("bf16", "f32"):
+        random.seed(5); torch.manual_seed(5)
+        od = {}
+        ref[gm] = TO.train_step(sd0, img, am, vm, torch.from_numpy(rmap).unsqueeze(0), obj, bg, np.stack([k for _, k in gts]),
+                                np.array([c for c, _ in gts]), 21, 1e-6, 0.9, 5e-4, detail=od, grad_math=gm) + (od,)
+    o_losses, o_grads, _, _, od = ref["bf16"]
+    model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet50))
+    model.load_state_dict(sd0, strict=True)
+    model = model.cuda()
+    model.grad_math = "bf16"
+    opt = T.create_optimizer(model, learning_rate=1e-6)
+    random.seed(5); torch.manual_seed(5)
+    detail = {}
+    loss = T.train_step(model, opt, img.cuda(), am, vm, torch.from_numpy(rmap).unsqueeze(0), [obj], [bg], [boxes], detail=detail)
+    assert np.array_equal(detail["sample_idx"].numpy(), od["proposal_sample_indices"])
+    got = np.array([loss.rpn_class, loss.rpn_regression, loss.detector_class, loss.detector_regression])
+    want = np.array([o_losses[k] for k in ("rpn_class", "rpn_regression", "detector_class", "detector_regression")])
+    assert np.all(np.abs(got - want) <= 2e-5 * np.abs(want) + 1e-7), (got, want)
+    grads = canonical_grads_resnet(detail["grads"])
+    assert sorted(grads) == sorted(o_grads)
+    gscale = max(float(g.norm()) for g in o_grads.values())
+    worst = {"median": (0.0, ""), "L2": (0.0, ""), "norm": (0.0, "")}
+    closer = 0
+    for k, g_ref in o_grads.items():
+        g = grads[k].cpu().double().reshape(-1)
+        r = g_ref.double().reshape(-1)
+        r32 = ref["f32"][1][k].double().reshape(-1)
+        ref_max = max(float(r.abs().max()), 1e-7 * gscale)
+        med = float((g - r).abs().median()) / ref_max
+        l2 = float((g - r).norm()) / max(float(r.norm()), 1e-7 * gscale)
+        nrm = abs(float(g.norm()) - float(r.norm())) / max(float(r.norm()), 1e-7 * gscale)
+        for name, val in (("median", med), ("L2", l2), ("norm", nrm)):
+            worst[name] = max(worst[name], (val, k.split(".")[-3] + "." + k.split(".")[-2]))
+        assert med <= 1e-4 and l2 <= 1e-2 and nrm <= 5e-3, (k, med, l2, nrm)
+        closer += float((g - r).norm()) < float((g - r32).norm())
+    print("bf16 ResNet-50 step vs the bf16 oracle: worst gradient errors %s; closer to the bf16 than to the f32 oracle on %d of %d tensors"
+          % (", ".join("%s %.2e (%s)" % (n, v[0], v[1]) for n, v in worst.items()), closer, len(o_grads)))
+    assert closer >= 0.9 * len(o_grads)
+
+
+def test_bf16_resnet101_roialign_train_step_full_size():
+    """BASELINE configs[4] on one GPU: ResNet-101, 600x1000, RoIAlign, bf16 gradient GEMMs: deterministic, finite, the loss falls
+    along the float32 trajectory, and the step is faster than the float32 one."""
+    import time
+    from fasterrcnn_amd.models import resnet
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    h, w, seed = 600, 1000, 2
+    sd0 = synthetic.resnet_state_dict(1234, "ResNet101")
+    img = synthetic.image_rgb(seed, h, w).unsqueeze(0).cuda()
+    gts = synthetic.ground_truth(seed, h, w)
+    boxes = [Box(class_index=c, class_name="x", corners=k) for c, k in gts]
+    am, vm = O.generate_anchor_maps((3, h, w), (1024, -(-h // 16), -(-w // 16)), 16)
+    rmap, obj, bg = O.generate_rpn_map(am, vm, np.stack([k for _, k in gts]))
+    rmap_t = torch.from_numpy(rmap).unsqueeze(0).cuda()
+
+    def run(gm, steps=6):
+        model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet101), roi_pooling="align")
+        model.load_state_dict(sd0, strict=True)
+        model = model.cuda()
+        model.grad_math = gm
+        opt = T.create_optimizer(model, learning_rate=3e-6)
+        random.seed(5); torch.manual_seed(5)
+        losses = []
+        for i in range(steps):
+            if i == 2:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            losses.append(model.train_step(opt, img, am, vm, rmap_t, [obj], [bg], [boxes]).total)
+        torch.cuda.synchronize()
+        return losses, {k: v.clone() for k, v in model.state_dict().items()}, (time.perf_counter() - t0) / (steps - 2) * 1e3
+    l1, s1, ms_bf16 = run("bf16")
+    l2, s2, _ = run("bf16")
+    lf, _, ms_f32 = run("f32")
+    assert l1 == l2 and all(torch.equal(s1[k], s2[k]) for k in s1), "deterministic"
+    assert all(np.isfinite(l1)) and l1[-1] < l1[0]
+    assert l1[0] == pytest.approx(lf[0], rel=1e-6) and abs(l1[-1] - lf[-1]) <= 0.05 * abs(lf[-1]), (l1, lf)
+    print("ResNet-101 600x1000 RoIAlign train step: grad_math bf16 %.2f ms, f32 %.2f ms; total loss %s (f32: %s)"
+          % (ms_bf16, ms_f32, ["%.4f" % x for x in l1], ["%.4f" % x for x in lf]))
+    assert ms_bf16 < ms_f32
