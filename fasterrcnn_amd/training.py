@@ -545,55 +545,98 @@ class ResNetTrainState(TrainState):
         return g.reshape(S, 49 * 1024)
 
     def zero_head_grads(self, grads):
-        for blk in self.head_blocks:
-            for cname, c in blk.convs().items():
-                grads[blk.name + "." + cname] = t.zeros_like(c.raw)
+        # in the backward pass's production order: a rank without a proposal batch must exchange the same messages as the others
+        for blk in reversed(self.head_blocks):
+            convs = blk.convs()
+            for cname in ("conv3", "conv2", "conv1", "downsample"):
+                if cname in convs:
+                    grads[blk.name + "." + cname] = t.zeros_like(convs[cname].raw)
 
 
 class GradientAverager:
     """
     Data-parallel training (beyond the reference, which trains on one GPU): every rank runs `train_step` on its own sample
-    and the weight gradients are averaged over the ranks before the SGD update -- ONE exchange step per training step,
-    `torch.distributed.all_reduce` over RCCL/xGMI (backend "nccl") or gloo.  The gradients of a step are packed into a few
-    large flat buckets (`bucket_bytes`, default 256 MB: xGMI rings are per-link bound, so few large messages) in a fixed
-    name order, reduced, divided by the world size and scattered back in place.  Attach with `enable_data_parallel(model)`.
+    and the weight gradients are averaged over the ranks before the SGD update, `torch.distributed.all_reduce` over RCCL/xGMI
+    (backend "nccl") or gloo.
+
+    OVERLAPPED with the backward pass: `train_step` collects its gradients in `track()`'s dict, which hands every tensor to
+    `ready()` the moment the kernel producing it has been enqueued.  A tensor of `direct_bytes` or more (fc1's 411 MB gradient
+    is produced FIRST, before the RPN and the whole backbone backward) is all-reduced in place right away with `async_op=True`:
+    the process group's own stream waits for the producing kernel and the exchange runs under the rest of the backward.
+    Smaller tensors are coalesced, in production order (the same on every rank), into flat buckets of `bucket_bytes` that are
+    sent as soon as they fill (xGMI rings are per-link bound: few large messages).  `finish()` sends the last bucket, waits for
+    every exchange (a stream-level wait on the GPU), divides by the world size and scatters the buckets back.
+    Attach with `enable_data_parallel(model)`.  `__call__(grads)` is the one-shot form (all tensors at once, same arithmetic).
     """
-    def __init__(self, group=None, bucket_bytes=256 << 20):
+    def __init__(self, group=None, bucket_bytes=64 << 20, direct_bytes=8 << 20):
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("GradientAverager needs an initialised torch.distributed process group")
-        self.dist, self.group, self.bucket_bytes = dist, group, int(bucket_bytes)
+        self.dist, self.group, self.bucket_bytes, self.direct_bytes = dist, group, int(bucket_bytes), int(direct_bytes)
         self.world = dist.get_world_size(group)
+        self._pending, self._pending_bytes, self._inflight = [], 0, []
+        self.messages = 0                                # all-reduce calls of the last step (tests / reports)
 
-    def buckets(self, grads):
-        """[[name, ...], ...]: names in sorted order, greedily packed up to bucket_bytes (identical on every rank)."""
-        out, cur, size = [], [], 0
-        for name in sorted(grads):
-            nbytes = grads[name].numel() * grads[name].element_size()
-            if cur and size + nbytes > self.bucket_bytes:
-                out.append(cur)
-                cur, size = [], 0
-            cur.append(name)
-            size += nbytes
-        if cur:
-            out.append(cur)
-        return out
+    class _Tracked(dict):
+        def __init__(self, owner):
+            super().__init__()
+            self._owner = owner
+
+        def __setitem__(self, name, tensor):
+            super().__setitem__(name, tensor)
+            self._owner.ready(name, tensor)
+
+    def track(self):
+        """The gradient dict of one step: assigning grads[name] = tensor hands the (final) tensor to the exchange."""
+        self._pending, self._pending_bytes, self._inflight, self.messages = [], 0, [], 0
+        return GradientAverager._Tracked(self)
+
+    def _send(self, flat, parts):
+        work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._inflight.append((work, flat, parts))
+        self.messages += 1
+
+    def _flush(self):
+        if self._pending:
+            parts = self._pending
+            self._send(t.cat([g.reshape(-1) for _, g in parts]), parts)
+            self._pending, self._pending_bytes = [], 0
+
+    def ready(self, name, g):
+        nbytes = g.numel() * g.element_size()
+        if nbytes >= self.direct_bytes and g.is_contiguous():
+            self._send(g.view(-1), None)                 # in place, no staging copy
+            return
+        self._pending.append((name, g))
+        self._pending_bytes += nbytes
+        if self._pending_bytes >= self.bucket_bytes:
+            self._flush()
+
+    def finish(self):
+        self._flush()
+        inv = 1.0 / float(self.world)
+        for work, flat, parts in self._inflight:
+            work.wait()
+            flat.mul_(inv)
+            if parts is not None:
+                off = 0
+                for _, g in parts:
+                    k = g.numel()
+                    g.copy_(flat[off:off + k].view_as(g))
+                    off += k
+        self._inflight = []
 
     def __call__(self, grads):
-        for names in self.buckets(grads):
-            flat = t.cat([grads[n].reshape(-1) for n in names])
-            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
-            flat /= float(self.world)
-            off = 0
-            for n in names:
-                k = grads[n].numel()
-                grads[n].copy_(flat[off:off + k].view_as(grads[n]))
-                off += k
+        tracked = self.track()
+        for name in sorted(grads):
+            tracked[name] = grads[name]
+        self.finish()
 
 
-def enable_data_parallel(model, group=None, bucket_bytes=256 << 20):
-    """Average the weight gradients of every `train_step` over the ranks of `group` (see GradientAverager)."""
-    model._gradient_sync = GradientAverager(group, bucket_bytes)
+def enable_data_parallel(model, group=None, bucket_bytes=64 << 20, direct_bytes=8 << 20):
+    """Average the weight gradients of every `train_step` over the ranks of `group`, overlapped with the backward pass
+    (see GradientAverager)."""
+    model._gradient_sync = GradientAverager(group, bucket_bytes, direct_bytes)
     return model
 
 
@@ -695,7 +738,8 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
         sample_idx = _sample_proposal_indices(class_indices, model._proposal_batch_size, 0.25)
         S = int(sample_idx.shape[0])
         losses = t.zeros((4,), dtype=t.float32, device=dev)
-        grads = {}
+        sync = getattr(model, "_gradient_sync", None)
+        grads = sync.track() if sync is not None else {}              # data parallel: every gradient is exchanged as soon as it exists
         dfm = None
         if S > 0:
             idx_dev = sample_idx.to(t.int32).to(dev)
@@ -762,9 +806,8 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
         # ---- stage 1 backward ---------------------------------------------------------------------------
         st.features_backward(g, fsaved, grads)
         # ---- SGD (torch.optim.SGD.step, __main__.py:98-105) --------------------------------------------
-        sync = getattr(model, "_gradient_sync", None)
         if sync is not None:
-            sync(grads)                                               # data parallel: average over the ranks
+            sync.finish()                                             # data parallel: the exchanges started during the backward complete
         if detail is not None:
             detail["grads"] = {k: v.clone() for k, v in grads.items()}
         st.apply_sgd(grads, lr, momentum, weight_decay)

@@ -78,13 +78,22 @@ def _grad_worker(rank, world, port, result_queue):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = torch.Generator().manual_seed(100 + rank)
-    grads = {"conv4": torch.randn((9, 8, 4), generator=g), "head": torch.randn((16, 32), generator=g),
-             "fc1": torch.randn((64, 100), generator=g), "rpn_conv": torch.randn((9, 4, 4), generator=g)}
-    mine = {k: v.clone() for k, v in grads.items()}
-    avg = training.GradientAverager(bucket_bytes=8 * 1024)          # small buckets: several messages
-    nb = len(avg.buckets(grads))
-    avg(grads)
-    result_queue.put((rank, nb, {k: v.numpy() for k, v in mine.items()}, {k: v.numpy() for k, v in grads.items()}))
+    shapes = [("head", (16, 32)), ("fc2", (64, 64)), ("fc1", (64, 100)), ("rpn_head", (16, 8)), ("rpn_conv", (9, 4, 4)), ("conv12", (9, 8, 4)),
+              ("conv11", (9, 8, 8))]
+    mine = {k: torch.randn(shp, generator=g) for k, shp in shapes}
+    # (a) the overlapped form train_step uses: tensors handed over one by one in production order; fc1 / fc2 (>= direct_bytes) are
+    #     reduced in place, the rest coalesced into 2 KB buckets
+    avg = training.GradientAverager(bucket_bytes=2 * 1024, direct_bytes=16 * 1024)
+    grads = avg.track()
+    for k, _ in shapes:
+        grads[k] = mine[k].clone()
+    avg.finish()
+    nmsg = avg.messages
+    # (b) the one-shot form
+    again = {k: v.clone() for k, v in mine.items()}
+    training.GradientAverager(bucket_bytes=8 * 1024, direct_bytes=1 << 30)(again)
+    result_queue.put((rank, nmsg, {k: v.numpy() for k, v in mine.items()}, {k: v.numpy() for k, v in grads.items()},
+                      {k: v.numpy() for k, v in again.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -99,13 +108,14 @@ def test_gradient_averager_world2():
         p.start()
     res = {}
     for _ in range(world):
-        rank, nb, mine, out = q.get(timeout=120)
-        res[rank] = (nb, mine, out)
+        rank, nmsg, mine, out, again = q.get(timeout=120)
+        res[rank] = (nmsg, mine, out, again)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res[0][0] == res[1][0] and res[0][0] >= 2                 # same bucketing on both ranks, more than one bucket
+    assert res[0][0] == res[1][0] and res[0][0] >= 4                 # same messages on both ranks: 2 in place + several buckets
     for k in res[0][1]:
         want = (res[0][1][k] + res[1][1][k]) / 2.0
-        assert np.array_equal(res[0][2][k], res[1][2][k])            # every rank ends with the same gradients
-        assert np.allclose(res[0][2][k], want, rtol=1e-6, atol=1e-7)
+        for form in (2, 3):
+            assert np.array_equal(res[0][form][k], res[1][form][k])  # every rank ends with the same gradients
+            assert np.allclose(res[0][form][k], want, rtol=1e-6, atol=1e-7)

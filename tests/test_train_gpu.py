@@ -729,8 +729,9 @@ def test_scale_rows_bn_affine_and_mean_backward():
 
 
 def test_data_parallel_gradient_exchange_single_rank(sd_cpu):
-    """The RCCL exchange of training.GradientAverager on a one-rank group must leave the step bit-identical
-    (average of one); the world-2 arithmetic is covered on CPU by tests/test_distributed_gloo.py."""
+    """The RCCL exchange of training.GradientAverager (asynchronous all-reduces started during the backward pass, completed before
+    the SGD update) on a one-rank group must leave the step bit-identical (average of one); the world-2 arithmetic is covered on
+    CPU by tests/test_distributed_gloo.py."""
     import socket
     import torch.distributed as dist
     from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
@@ -752,6 +753,9 @@ def test_data_parallel_gradient_exchange_single_rank(sd_cpu):
         opt = T.create_optimizer(model, learning_rate=1e-6)
         random.seed(9); torch.manual_seed(9)
         loss = model.train_step(opt, img, am, vm, rmap_t, [obj], [bg], [boxes])
+        if parallel:
+            # fc1, fc2, rpn_conv and the 512-channel conv gradients (>= 8 MB) travel in place as they are produced, the rest in buckets
+            assert model._gradient_sync.messages >= 8 and not model._gradient_sync._inflight
         return loss, {k: v.clone() for k, v in model.state_dict().items()}
 
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
