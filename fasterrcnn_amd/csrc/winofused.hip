@@ -53,7 +53,10 @@ static constexpr int WF_NH = (WF_NHP + 255) / 256;       // 6 per thread
 #ifndef WF_ABLATE
 #define WF_ABLATE 0                                      // timing experiments only (tools/build_ablate.sh), results wrong.  Inside the K loop:
 #endif                                                   // 1 no operand adds, 2 no patch-row reads, 4 no filter fragment reads, 8 no LDS writes,
-                                                         // 16 no filter loads, 32 no halo loads, 64 no barrier
+                                                         // 16 no filter loads, 32 no halo loads, 64 no barrier, 128 half of the operand adds
+#ifndef WF_SCALAR_ADDS
+#define WF_SCALAR_ADDS 0
+#endif
 #ifndef WF_PRIO
 #define WF_PRIO 1
 #endif
@@ -153,8 +156,15 @@ __device__ __forceinline__ f32x2 wf_hi(const f32x4& a) { return __builtin_shuffl
 __device__ __forceinline__ f32x2 wf_pk(bool sub, f32x2 a, f32x2 b)
 {
     f32x2 o;
+#if WF_SCALAR_ADDS
+    float o0, o1;
+    if (sub) { asm volatile("v_sub_f32 %0, %1, %2" : "=v"(o0) : "v"(a[0]), "v"(b[0])); asm volatile("v_sub_f32 %0, %1, %2" : "=v"(o1) : "v"(a[1]), "v"(b[1])); }
+    else { asm volatile("v_add_f32 %0, %1, %2" : "=v"(o0) : "v"(a[0]), "v"(b[0])); asm volatile("v_add_f32 %0, %1, %2" : "=v"(o1) : "v"(a[1]), "v"(b[1])); }
+    o[0] = o0; o[1] = o1;
+#else
     if (sub) asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b));
     else asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+#endif
     return o;
 }
 
@@ -265,10 +275,11 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
     auto make_r = [&](int i, int m) {
         const int b = m >> 1;
         if ((WF_ABLATE & 1) && in_loop) return;
+        if ((WF_ABLATE & 128) && in_loop && (i & 1)) return;
         r[b][m & 1] = (m & 1) ? wf_pk(wf_sub(i), wf_hi(d[2 * b]), wf_hi(d[2 * b + 1])) : wf_pk(wf_sub(i), wf_lo(d[2 * b]), wf_lo(d[2 * b + 1]));
     };
     // V[i][j] = r_i[a1(j)] -+ r_i[a2(j)]
-    auto make_v = [&](int j, int slot, int h) { if ((WF_ABLATE & 1) && in_loop) return; v[slot][h] = wf_pk(wf_sub(j), r[wf_a1(j)][h], r[wf_a2(j)][h]); };
+    auto make_v = [&](int j, int slot, int h) { if ((WF_ABLATE & 1) && in_loop) return; if ((WF_ABLATE & 128) && in_loop && (j & 1)) return; v[slot][h] = wf_pk(wf_sub(j), r[wf_a1(j)][h], r[wf_a2(j)][h]); };
     auto read_u = [&](int buf, int j, int slot, int cc) {
         if ((WF_ABLATE & 4) && in_loop) return;
         uf[slot][cc] = *reinterpret_cast<const f32x4*>(ub0 + buf * WF_U_F + u_off + (WF_BN * j + 16 * cc) * 16);
