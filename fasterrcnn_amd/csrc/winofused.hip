@@ -141,7 +141,7 @@ void wino_pack_fused_taps_kernel(const float* __restrict__ wp, float* __restrict
     }
 }
 
-struct WfGeom { int tbx, tby, ncb, total; };
+struct WfGeom { int tbx, tby, ncb, total, xcl; };        // xcl: log2 of the number of XCD groups the cout blocks are split over
 
 #define WF_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #define WF_MFMA 0x008
@@ -186,15 +186,23 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kq = lane >> 4;
 
-    // XCD-aware block order: hardware block b runs on XCD b % 8; the logical index is laid out XCD-major so that the cout
-    // blocks of one tile block (same halo) and neighbouring tile blocks (same filter slabs) share an XCD's L2
-    int L;
+    // XCD-aware block order.  Hardware block b runs on XCD b % 8 and every XCD has its own 4 MB L2.  The 8 XCDs form a
+    // (8 >> xcl) x (1 << xcl) grid: XCD (xti, xci) owns the cout blocks of group xci and a contiguous range of that group's
+    // (tile block, cout block) pairs, cout block fastest -- the blocks resident on an XCD at one time share halos (same tile
+    // block) and filter slabs (same cout block).  xcl = 0: every XCD streams the whole filter bank once per tile-block
+    // generation (fine while the bank fits the L2); larger xcl keeps a bank slice of 1 / 2^xcl resident at the price of
+    // 2^xcl XCDs reading every input tile (the launcher chooses per layer).
+    int cb, tb;
     {
-        const int b = blockIdx.x, per = gm.total >> 3, rem = gm.total & 7, xcd = b & 7, j = b >> 3;
-        L = xcd < rem ? xcd * (per + 1) + j : rem * (per + 1) + (xcd - rem) * per + j;
+        const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+        const int xt = 8 >> gm.xcl, xti = xcd >> gm.xcl, xci = xcd & ((1 << gm.xcl) - 1);
+        const int ncbx = gm.ncb >> gm.xcl, totx = gm.total >> gm.xcl;
+        const int per = totx / xt, rem = totx - per * xt;
+        if (j >= per + (xti < rem ? 1 : 0)) return;      // the grid is padded to 8 x the largest range
+        const int L = (xti < rem ? xti * (per + 1) : rem * (per + 1) + (xti - rem) * per) + j;
+        tb = L / ncbx;
+        cb = xci * ncbx + (L - tb * ncbx);
     }
-    const int cb = L % gm.ncb;
-    const int tb = L / gm.ncb;
     const int bx = tb % gm.tbx, by = tb / gm.tbx;
     const int n0 = cb * WF_BN;
     const int y0 = 2 * WF_TR * by - 1, x0 = 2 * WF_TC * bx - 1;
@@ -498,6 +506,26 @@ int launch_pack_conv3x3_winograd_fused_taps(const float* wp, float* u, int cout,
     return check_launch();
 }
 
+// How many XCD groups share the cout blocks (log2), by the size of the filter bank.  Measured with FETCH_SIZE on the VGG-16 layers
+// (tools/wf_traffic.py, MB fetched through the fabric per launch for xcl = 0 / 1 / 2 / 3): conv2_2 (1 MB bank) 108 / 182 / 348 / 348,
+// conv3_2 (4.2 MB) 207 / 166 / 210 / 345, conv4_1 (8.4 MB) 202 / 110 / 84 / 101, conv4_2 (16.8 MB) 416 / 239 / 181 / 209,
+// conv5_x (16.8 MB, 37x62) 144 / 80 / 54 / 55.  The layer times do not move (+-0.5 %: the Infinity Cache serves the re-fetches and
+// the loads are hidden), the traffic of one image's 13 layers falls from 2.4 GB to 1.4 GB.  Experiments: FRCNN_WF_XCL=0..3 overrides.
+static int wf_choose_xcl(int cin, int cout, int ncb)
+{
+    int maxl = 0;
+    while (maxl < 3 && (ncb % (2 << maxl)) == 0) ++maxl;
+    static const char* env = getenv("FRCNN_WF_XCL");
+    int want;
+    if (env) {
+        want = atoi(env);
+    } else {
+        const size_t bank = (size_t)64 * cin * cout;     // 16 positions x 4 bytes
+        want = bank <= (size_t)5 << 19 ? 0 : (bank <= (size_t)5 << 20 ? 1 : 2);
+    }
+    return want < 0 ? 0 : (want > maxl ? maxl : want);
+}
+
 int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
                                   unsigned flags, hipStream_t s)
 {
@@ -511,6 +539,9 @@ int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b
     const long long total = (long long)gm.tbx * gm.tby * gm.ncb;
     if (total > 0x7fffffffLL) return FRCNN_EINVAL;
     gm.total = (int)total;
+    gm.xcl = wf_choose_xcl(cin, cout, gm.ncb);
+    const int xt = 8 >> gm.xcl, totx = gm.total >> gm.xcl;
+    const unsigned grid = 8u * (unsigned)cdiv(totx, xt);
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
@@ -526,9 +557,9 @@ int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b
         }
     }
     if (flags & FRCNN_POOL2)
-        hipLaunchKernelGGL(wino_fused_kernel<true>, dim3((unsigned)gm.total), dim3(256), WF_LDS_BYTES, s, x, u, b, y, H, W, cin, cout, relu, gm);
+        hipLaunchKernelGGL(wino_fused_kernel<true>, dim3(grid), dim3(256), WF_LDS_BYTES, s, x, u, b, y, H, W, cin, cout, relu, gm);
     else
-        hipLaunchKernelGGL(wino_fused_kernel<false>, dim3((unsigned)gm.total), dim3(256), WF_LDS_BYTES, s, x, u, b, y, H, W, cin, cout, relu, gm);
+        hipLaunchKernelGGL(wino_fused_kernel<false>, dim3(grid), dim3(256), WF_LDS_BYTES, s, x, u, b, y, H, W, cin, cout, relu, gm);
     return check_launch();
 }
 
