@@ -103,6 +103,7 @@ MATH_F32 = 0      # exact f32 MFMA
 MATH_F32X6 = 1    # bf16x3 split operands, six bf16 MFMAs per product, f32 accumulate
 MATH_F32_WINOGRAD = 2   # exact f32 MFMA; 3x3 layers with uses_winograd(cin, cout) as Winograd F(2x2,3x3) in float32
 MATH_MODES = {"f32": MATH_F32, "f32x6": MATH_F32X6, "f32_winograd": MATH_F32_WINOGRAD}
+LINEAR_X6_ROWS = 320                      # FRCNN_LINEAR_X6_ROWS: row count of an activation record array (csrc/linear_x6.hip's row tile)
 GRAD_MATHS = {"f32": 0, "bf16": 1}         # FRCNN_GRAD_F32 / FRCNN_GRAD_BF16: arithmetic of the train step's gradient GEMMs
 ROI_OPS = {"pool": 0, "align": 1}          # FRCNN_ROI_POOL (the reference) / FRCNN_ROI_ALIGN (torchvision roi_align semantics)
 FC_MATH_MODES = {"f32": 0, "f32x6": 1}   # FRCNN_FC_F32 / FRCNN_FC_F32X6: arithmetic of the VGG-16 detector's fc1 / fc2

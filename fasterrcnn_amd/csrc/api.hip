@@ -628,7 +628,7 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         {(void**)&c->anchor_map, (size_t)c->a_cap * 16}, {(void**)&c->valid_map, (size_t)c->a_cap * 4},
         {(void**)&c->roi_out, (size_t)max_rois * 49 * 1024 * 4},
         {(void**)&c->fc1_out, (size_t)max_rois * 4096 * 4}, {(void**)&c->fc2_out, (size_t)max_rois * 4096 * 4},
-        {(void**)&c->roi_rec, (size_t)max_rois * 49 * 512 * 6}, {(void**)&c->fc1_rec, (size_t)max_rois * 4096 * 6},
+        {(void**)&c->roi_rec, (size_t)FRCNN_LINEAR_X6_ROWS * 49 * 512 * 6}, {(void**)&c->fc1_rec, (size_t)FRCNN_LINEAR_X6_ROWS * 4096 * 6},
         {(void**)&c->head_logits, (size_t)max_rois * 128 * 4},
         {(void**)&c->lin_ws, lin}, {(void**)&c->conv_ws, cws},
         {(void**)&c->res_buf[0], c->res_buf_floats * 4}, {(void**)&c->res_buf[1], c->res_buf_floats * 4},
@@ -870,7 +870,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
         // fc1 / fc2 on the bf16 pipe with exactly split operands: the RoI-pool output is split once, fc1's reduction emits the
         // records fc2 consumes, fc2's the float32 rows the (exact-f32) heads consume
         if (R_ > 320) return FRCNN_EUNSUPPORTED;
-        STEP(2, launch_split_rows_x6(c->roi_out, 49 * 512, c->roi_rec, R_, R_, 49 * 512, s));
+        STEP(2, launch_split_rows_x6(c->roi_out, 49 * 512, c->roi_rec, R_, FRCNN_LINEAR_X6_ROWS, 49 * 512, s));
         STEP(2, launch_linear_x6(c->roi_rec, w->fc1_w, w->fc1_b, c->fc1_out, 4096, c->fc1_rec, R_, 4096, 49 * 512, R,
                                  c->lin_ws, c->lin_ws_bytes, s));
         STEP(2, launch_linear_x6(c->fc1_rec, w->fc2_w, w->fc2_b, c->fc2_out, 4096, nullptr, R_, 4096, 4096, R,

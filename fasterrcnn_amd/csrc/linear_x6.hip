@@ -8,7 +8,10 @@
 // fp32 accumulation.  The three dropped terms are <= 2^-24 |a*w| each -- the size of one fp32 rounding of the product.
 //
 // Both operands arrive PRE-SPLIT as "x6 records": for a row-major matrix [R][K] the record of (row, 16-k chunk) is 96 contiguous
-// bytes [hi 16 | mid 16 | lo 16] bf16 (split_rows_x6_kernel).  Weights are split once at pack time (fc1: 411 MB fp32 -> 617 MB of
+// bytes [hi 16 | mid 16 | lo 16] bf16 (split_rows_x6_kernel), stored CHUNK-MAJOR -- [K/16][rows][96 B] -- so that the tile a
+// block stages per 16-k step (all 320 activation rows; its 128 weight rows) is ONE contiguous run of bytes: a wave's
+// global_load_dwordx4 covers 8 full 128-byte lines.  (Row-major records made it 11 row segments of 96 B = ~16 lines per
+// instruction and kept the CU's L1 / address path 70 % busy: fc1 355 us.)  Weights are split once at pack time (fc1: 411 MB fp32 -> 617 MB of
 // records, streamed once per image); activations are split by the kernel that produces them (the RoI-pool output by
 // split_rows_x6_kernel, fc1's output by the split-K reduction's epilogue), so the GEMM's staging is pure copying.
 //
@@ -53,8 +56,9 @@ __device__ __forceinline__ void lx_split3(float x, lx_u16& hi, lx_u16& mid, lx_u
     lo = lx_bf16_rne(r2);
 }
 
-// [R][ld] fp32 (K used columns, K % 16 == 0) -> records [R][K/16][3][16] bf16.  One thread = 4 consecutive floats.
-// rows_out >= R: the rows R .. rows_out-1 of the output are zero filled (weight matrices padded to the column tile).
+// [R][ld] fp32 (K used columns, K % 16 == 0) -> records [K/16][rows_out][3][16] bf16.  One thread = 4 consecutive floats.
+// rows_out >= R is the row count of the record array: the rows R .. rows_out-1 are zero filled (weight matrices padded to the
+// column tile, activations to the 320-row tile).
 __global__ __launch_bounds__(256)
 void split_rows_x6_kernel(const float* __restrict__ a, int lda, unsigned char* __restrict__ rec, int R, int rows_out, int K)
 {
@@ -67,7 +71,7 @@ void split_rows_x6_kernel(const float* __restrict__ a, int lda, unsigned char* _
         lx_u16 hi[4], mid[4], lo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) lx_split3(v[j], hi[j], mid[j], lo[j]);
-        unsigned char* p = rec + ((size_t)row * (K >> 4) + (k >> 4)) * 96 + (k & 15) * 2;
+        unsigned char* p = rec + ((size_t)(k >> 4) * rows_out + row) * 96 + (k & 15) * 2;
         uint2 ph, pm, pl;
         ph.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16);   ph.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
         pm.x = (unsigned)mid[0] | ((unsigned)mid[1] << 16); pm.y = (unsigned)mid[2] | ((unsigned)mid[3] << 16);
@@ -81,7 +85,7 @@ void split_rows_x6_kernel(const float* __restrict__ a, int lda, unsigned char* _
 __global__ __launch_bounds__(LX_THREADS, 1)
 void linear_x6_kernel(const unsigned char* __restrict__ a_rec, const unsigned char* __restrict__ w_rec,
                       const float* __restrict__ bias, float* __restrict__ y, int ldy, float* __restrict__ ws,
-                      int M, int N, int nchunks, int chunks_per_split, int relu)
+                      int M, int N, int nchunks, int chunks_per_split, int relu, int w_rows)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_lx[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -94,17 +98,17 @@ void linear_x6_kernel(const unsigned char* __restrict__ a_rec, const unsigned ch
     if (c_end > nchunks) c_end = nchunks;
     const int nst = c_end - c_begin;
 
-    // staging: piece q -> (row q / 6, slot q % 6); A rows beyond M re-read row M-1 (they feed output rows that are never stored)
-    const size_t row_bytes = (size_t)nchunks * 96;
-    size_t a_src[LX_NA], b_src[LX_NB];
+    // staging: the tile of a 16-k chunk is contiguous in the chunk-major record arrays (LX_BM activation rows: the caller pads;
+    // this block's LX_BN weight rows); piece q = 16 bytes -> LDS (row q / 6, slot q % 6)
+    const size_t a_chunk_bytes = (size_t)LX_BM * 96, b_chunk_bytes = (size_t)w_rows * 96;
+    int a_src[LX_NA], b_src[LX_NB];
     int a_dst[LX_NA], b_dst[LX_NB];
 #pragma unroll
     for (int it = 0; it < LX_NA; ++it) {
         int q = tid + LX_THREADS * it;
         if (q >= LX_BM * 6) q -= LX_BM * 6 / 2;           // surplus threads duplicate an earlier piece (same data, same address)
         const int row = q / 6, j = q - row * 6;
-        const int gr = row < M ? row : M - 1;
-        a_src[it] = (size_t)gr * row_bytes + j * 16;
+        a_src[it] = q * 16;
         a_dst[it] = row * LX_ROW + j * 16;
     }
 #pragma unroll
@@ -112,7 +116,7 @@ void linear_x6_kernel(const unsigned char* __restrict__ a_rec, const unsigned ch
         int q = tid + LX_THREADS * it;
         if (q >= LX_BN * 6) q -= LX_BN * 6 / 2;
         const int row = q / 6, j = q - row * 6;
-        b_src[it] = (size_t)(n0 + row) * row_bytes + j * 16;
+        b_src[it] = n0 * 96 + q * 16;
         b_dst[it] = LX_BM * LX_ROW + row * LX_ROW + j * 16;
     }
     // Register staging.  A (the activations' records, L2 resident) one tile ahead; B (the weight records, streamed from HBM exactly
@@ -122,13 +126,13 @@ void linear_x6_kernel(const unsigned char* __restrict__ a_rec, const unsigned ch
     bool past_prologue = false;
     auto load_a = [&](int chunk) {
         if ((LX_ABLATE & 1) && past_prologue) return;
-        const unsigned char* ab = a_rec + (size_t)chunk * 96;
+        const unsigned char* ab = a_rec + (size_t)chunk * a_chunk_bytes;
 #pragma unroll
         for (int it = 0; it < LX_NA; ++it) areg[it] = *reinterpret_cast<const f32x4*>(ab + a_src[it]);
     };
     auto load_b = [&](int chunk, f32x4 (&br)[LX_NB]) {
         if ((LX_ABLATE & 2) && past_prologue) return;
-        const unsigned char* wb = w_rec + (size_t)chunk * 96;
+        const unsigned char* wb = w_rec + (size_t)chunk * b_chunk_bytes;
 #pragma unroll
         for (int it = 0; it < LX_NB; ++it) br[it] = *reinterpret_cast<const f32x4*>(wb + b_src[it]);
     };
@@ -254,15 +258,23 @@ void linear_x6_kernel(const unsigned char* __restrict__ a_rec, const unsigned ch
 }
 
 // y[m][n] = act(bias[n] + sum_z ws[z][m][n]) in fixed z order (deterministic); y_rec (optional): the x6 records of y for the next
-// layer's GEMM ([M][N/16][3][16] bf16, N % 16 == 0).  One thread = 4 consecutive n.
+// layer's GEMM ([N/16][LX_BM][3][16] bf16, N % 16 == 0; rows M .. LX_BM-1 zero).  One thread = 4 consecutive n.
 __global__ __launch_bounds__(256)
 void splitk_reduce_x6_kernel(const float* __restrict__ ws, const float* __restrict__ bias, float* __restrict__ y, int ldy,
                              unsigned char* __restrict__ y_rec, int M, int N, int splits, int relu)
 {
     const int q4 = N >> 2;
-    const size_t total = (size_t)M * q4, plane = (size_t)M * N;
+    const size_t total = (size_t)(y_rec != nullptr ? LX_BM : M) * q4, plane = (size_t)M * N;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int m = (int)(idx / q4), n = (int)(idx % q4) * 4;
+        if (m >= M) {                                    // padding rows of the record array
+            unsigned char* p = y_rec + ((size_t)(n >> 4) * LX_BM + m) * 96 + (n & 15) * 2;
+            const uint2 z = {0u, 0u};
+            *reinterpret_cast<uint2*>(p) = z;
+            *reinterpret_cast<uint2*>(p + 32) = z;
+            *reinterpret_cast<uint2*>(p + 64) = z;
+            continue;
+        }
         const size_t off = (size_t)m * N + n;
         f32x4 v = *reinterpret_cast<const f32x4*>(ws + off);
         for (int z = 1; z < splits; ++z) v = v + *reinterpret_cast<const f32x4*>(ws + (size_t)z * plane + off);
@@ -276,7 +288,7 @@ void splitk_reduce_x6_kernel(const float* __restrict__ ws, const float* __restri
             lx_u16 hi[4], mid[4], lo[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) lx_split3(v[j], hi[j], mid[j], lo[j]);
-            unsigned char* p = y_rec + ((size_t)m * (N >> 4) + (n >> 4)) * 96 + (n & 15) * 2;
+            unsigned char* p = y_rec + ((size_t)(n >> 4) * LX_BM + m) * 96 + (n & 15) * 2;
             uint2 ph, pm, pl;
             ph.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16);   ph.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
             pm.x = (unsigned)mid[0] | ((unsigned)mid[1] << 16); pm.y = (unsigned)mid[2] | ((unsigned)mid[3] << 16);
@@ -326,8 +338,9 @@ int launch_split_rows_x6(const float* a, int lda, void* rec, int R, int rows_out
     return check_launch();
 }
 
-// a_rec: records of [M][K]; w_rec: records of [ceil(N / 128) * 128][K] (rows beyond N zero);  y fp32 [M][ldy] and / or
-// y_rec records of [M][N] (either may be NULL, not both); ws >= linear_x6_workspace_bytes.
+// a_rec: records of [M][K] in a 320-row record array (split_rows_x6 with rows_out = 320); w_rec: records of a
+// ceil(N / 128) * 128-row array (rows beyond N zero);  y fp32 [M][ldy] and / or y_rec = the records of [M][N] in a 320-row array
+// (either may be NULL, not both); ws >= linear_x6_workspace_bytes.
 int launch_linear_x6(const void* a_rec, const void* w_rec, const float* bias, float* y, int ldy, void* y_rec, int M, int N, int K,
                      unsigned flags, void* ws, size_t ws_bytes, hipStream_t s)
 {
@@ -345,10 +358,10 @@ int launch_linear_x6(const void* a_rec, const void* w_rec, const float* bias, fl
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
     hipLaunchKernelGGL(linear_x6_kernel, dim3(p.nblocks, 1, p.splits), dim3(LX_THREADS), LX_LDS_BYTES, s,
                        static_cast<const unsigned char*>(a_rec), static_cast<const unsigned char*>(w_rec), bias, y, ldy,
-                       static_cast<float*>(ws), M, N, K / 16, p.chunks_per_split, relu);
+                       static_cast<float*>(ws), M, N, K / 16, p.chunks_per_split, relu, cdiv(N, LX_BN) * LX_BN);
     int rc = check_launch();
     if (rc) return rc;
-    const size_t total = (size_t)M * (N / 4);
+    const size_t total = (size_t)(y_rec != nullptr ? LX_BM : M) * (N / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_x6_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(ws), bias, y, ldy,

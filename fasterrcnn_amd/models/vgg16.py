@@ -195,10 +195,16 @@ class PoolToFeatureVector(nn.Module):
 
 
 def split_rows_x6(a, rows_out=None):
-    """float32 (R, K) CUDA matrix -> its x6 records (uint8, 96 B per (row, 16-k chunk); rows R .. rows_out-1 zero)."""
+    """float32 (R, K) CUDA matrix -> its x6 record array (uint8, chunk-major [K/16][rows_out][96 B]; rows R .. rows_out-1 zero).
+    rows_out: None = an activation matrix (the 320-row tile of frcnn_linear_x6); a weight matrix passes its row count, which is
+    rounded up to the 128-column tile."""
     r, k = int(a.shape[0]), int(a.shape[1])
-    rows_out = r if rows_out is None else max(int(rows_out), r)
-    rows_out = (rows_out + 127) // 128 * 128 if rows_out != r else rows_out
+    if rows_out is None:
+        if r > nv.LINEAR_X6_ROWS:
+            raise ValueError("frcnn_linear_x6 multiplies at most %d rows" % nv.LINEAR_X6_ROWS)
+        rows_out = nv.LINEAR_X6_ROWS
+    else:
+        rows_out = (max(int(rows_out), r) + 127) // 128 * 128
     rec = t.empty((rows_out * (k // 16) * 96,), dtype=t.uint8, device=a.device)
     a = a.contiguous()
     with t.cuda.device(a.device):
@@ -213,7 +219,7 @@ def linear_x6(a_rec, w_rec, b, m, n_out, k, relu, want="float32"):
         return t.empty((0, n_out), dtype=t.float32, device=dev) if want == "float32" else t.empty((0,), dtype=t.uint8, device=dev)
     lib = nv.lib()
     y = t.empty((m, n_out), dtype=t.float32, device=dev) if want == "float32" else None
-    y_rec = t.empty((m * (n_out // 16) * 96,), dtype=t.uint8, device=dev) if want == "records" else None
+    y_rec = t.empty((nv.LINEAR_X6_ROWS * (n_out // 16) * 96,), dtype=t.uint8, device=dev) if want == "records" else None
     ws_bytes = int(lib.frcnn_linear_x6_workspace_bytes(m, n_out, k))
     ws = t.empty((max(ws_bytes, 4) // 4,), dtype=t.float32, device=dev)
     with t.cuda.device(dev):

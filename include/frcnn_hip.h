@@ -185,11 +185,15 @@ int frcnn_conv3x3_nhwc_winograd_fused(const float* d_x, const float* d_u, const 
 /* Dense layer with ReLU (models/vgg16.py:130-132) in the "f32x6" arithmetic (csrc/linear_x6.hip): both operands as "x6 records"
  * -- for a row-major float32 matrix [R][K] the record of (row, 16-k chunk) is 96 contiguous bytes [hi 16 | mid 16 | lo 16] bf16 with
  * x = hi + mid + lo exactly -- six bf16 MFMAs per product, f32 accumulation (dropped terms <= 2^-24 relative: fp32-rounding class).
- *   frcnn_split_rows_x6 : float32 [rows][lda] (K used columns, K % 16 == 0) -> records [rows_out][K/16][3][16]; rows beyond `rows`
- *                         are zero (weight matrices: rows_out = N rounded up to 128).  96 * rows_out * K / 16 bytes.
- *   frcnn_linear_x6     : y[m][n] = act(bias[n] + sum_k a[m][k] w[n][k]),  M <= 320, N % 4 == 0, K % 16 == 0, K >= 32.
- *                         d_y float32 [M][ldy] and / or d_y_rec = the records of y for the next layer (N % 16 == 0); either may be
- *                         NULL.  Deterministic split-K; d_ws >= frcnn_linear_x6_workspace_bytes(M, N, K). */
+ * A record array is CHUNK-MAJOR: [K/16][rows_out][96 B] (the tile a block stages per 16-k step is one contiguous run).
+ *   frcnn_split_rows_x6 : float32 [rows][lda] (K used columns, K % 16 == 0) -> a record array of `rows_out` >= rows rows; rows beyond
+ *                         `rows` are zero.  96 * rows_out * K / 16 bytes.  Weight matrices: rows_out = N rounded up to 128;
+ *                         activations: rows_out = FRCNN_LINEAR_X6_ROWS.
+ *   frcnn_linear_x6     : y[m][n] = act(bias[n] + sum_k a[m][k] w[n][k]),  M <= FRCNN_LINEAR_X6_ROWS, N % 4 == 0, K % 16 == 0,
+ *                         K >= 32.  d_a_rec: a FRCNN_LINEAR_X6_ROWS-row record array; d_y float32 [M][ldy] and / or d_y_rec = the
+ *                         records of y for the next layer (N % 16 == 0, a FRCNN_LINEAR_X6_ROWS-row array, rows beyond M zeroed);
+ *                         either may be NULL.  Deterministic split-K; d_ws >= frcnn_linear_x6_workspace_bytes(M, N, K). */
+#define FRCNN_LINEAR_X6_ROWS 320
 int frcnn_split_rows_x6(const float* d_a, int lda, void* d_rec, int rows, int rows_out, int K, void* stream);
 size_t frcnn_linear_x6_workspace_bytes(int M, int N, int K);
 int frcnn_linear_x6(const void* d_a_rec, const void* d_w_rec, const float* d_bias, float* d_y, int ldy, void* d_y_rec,

@@ -20,8 +20,8 @@ pytestmark = pytest.mark.gpu
 
 
 def records_to_planes(rec, rows, k):
-    """uint8 records -> three float32 (rows, k) matrices (hi, mid, lo)."""
-    r = rec.cpu().numpy().view(np.uint16).reshape(rows, k // 16, 3, 16)
+    """uint8 record array (chunk-major: [k/16][rows][hi, mid, lo][16] bf16) -> three float32 (rows, k) matrices (hi, mid, lo)."""
+    r = rec.cpu().numpy().view(np.uint16).reshape(k // 16, rows, 3, 16).transpose(1, 0, 2, 3)
     f = (r.astype(np.uint32) << 16).view(np.float32)
     return [f[:, :, p, :].reshape(rows, k) for p in range(3)]
 

@@ -151,8 +151,8 @@ def main():
         print("%-8s M=%d N=%d K=%d  %8.1f us  %6.1f TF" % (name, m, n, k, us, 2.0 * m * n * k / us / 1e6))
         if m <= 320 and n % 16 == 0 and name.startswith("fc"):
             from fasterrcnn_amd.models import vgg16 as V
-            a_rec, w_rec = V.split_rows_x6(a), V.split_rows_x6(wt)
-            y_rec = torch.empty((m * (n // 16) * 96,), dtype=torch.uint8, device=dev)
+            a_rec, w_rec = V.split_rows_x6(a), V.split_rows_x6(wt, rows_out=n)
+            y_rec = torch.empty((nv.LINEAR_X6_ROWS * (n // 16) * 96,), dtype=torch.uint8, device=dev)
             wsb6 = int(lib.frcnn_linear_x6_workspace_bytes(m, n, k))
             ws6 = torch.empty((wsb6 // 4,), device=dev)
 
@@ -163,7 +163,7 @@ def main():
             print("%-8s x6 (bf16x3 split, six MFMAs per product)  %8.1f us  %6.1f TF fp32-equivalent" % (name, us, 2.0 * m * n * k / us / 1e6))
 
             def run_split():
-                nv.check(lib.frcnn_split_rows_x6(nv.ptr(a), k, nv.ptr(a_rec), m, m, k, s), "split")
+                nv.check(lib.frcnn_split_rows_x6(nv.ptr(a), k, nv.ptr(a_rec), m, nv.LINEAR_X6_ROWS, k, s), "split")
             print("%-8s split of the activations  %8.1f us" % (name, timeit(run_split, args.reps)))
 
 
