@@ -116,7 +116,7 @@ def uses_winograd(cin, cout):
 
 def uses_winograd_fused(cin, cout):
     """== frcnn_conv3x3_uses_winograd_fused(cin, cout): single-map 3x3 stride-1 layers that run as ONE-launch Winograd layers."""
-    return cin >= 64 and cin % 16 == 0 and cout >= 64 and cout % 32 == 0
+    return cin >= 64 and cin % 16 == 0 and cout >= 64 and cout % 64 == 0
 
 
 def resnet_block_uses_winograd_fused(n_maps, width, stride):

@@ -101,7 +101,7 @@ int launch_winograd_input(const float* x, float* V, int N, int H, int W, int cin
 int launch_winograd_gemm(const float* V, const float* u, float* M, int N, int H, int W, int cin, int cout, hipStream_t s);
 int launch_winograd_output(const float* M, const float* b, float* y, int N, int H, int W, int cout, unsigned flags, hipStream_t s);
 // winofused.hip: the same layer for one map as ONE launch (all 16 positions in accumulators, no V / M scratch)
-static inline bool conv3x3_uses_winograd_fused(int cin, int cout) { return cin >= 64 && cin % 16 == 0 && cout >= 64 && cout % 32 == 0; }
+static inline bool conv3x3_uses_winograd_fused(int cin, int cout) { return cin >= 64 && cin % 16 == 0 && cout >= 64 && cout % 64 == 0; }
 // ResNet bottleneck 3x3 (width -> width) on ONE map (the feature extractor's layer1..3 at inference): every stride-1 block;
 // the per-RoI 4 x 4 maps of layer4 (n_maps = RoIs) stay on the three-launch batched form (resnet_block_uses_winograd)
 static inline bool resnet_block_uses_winograd_fused(int n_maps, int width, int stride)

@@ -7,27 +7,33 @@
 //
 // No V / M scratch: HBM traffic of a layer is its input, its filter bank and its output.
 //
-// Work decomposition.  A block owns 4 x 16 Winograd tiles (8 x 32 output pixels) x 32 output channels and ALL 16 Winograd
-// positions of that slab: wave w owns tile row w, its accumulators are acc[position][cout half] = 16 x 2 MFMA 16x16 tiles
-// (v_mfma_f32_16x16x4_f32, exact f32, 4 registers each = 128 registers).  Because every position's accumulator is live, the
-// output transform A^T M A (+ bias, ReLU, 2x2 max-pool: a Winograd tile IS a pooling window) runs on registers in the epilogue.
+// Work decomposition.  A block owns 2 x 16 Winograd tiles (4 x 32 output pixels) x 64 output channels and ALL 16 Winograd
+// positions of that slab.  Its four waves are (tile row tr, position-row pair h): wave (tr, h) owns the tiles of row tr, the
+// position rows i = 2 h, 2 h + 1 and all 64 couts: accumulators acc[8 positions][4 cout tiles] = 32 MFMA 16x16 tiles
+// (v_mfma_f32_16x16x4_f32, exact f32, 4 registers each = 128 registers).  The position rows are split over the wave PAIR rather
+// than the cout tiles so that each wave forms the transformed operand of only its own two rows: every vector instruction costs
+// matrix-pipe time (measured: ~9 cycles per packed add) and a block of 64 couts needs half the adds per
+// MFMA of the 32-cout block it replaces.  Because every position's accumulator is live, the output transform A^T M A (+ bias,
+// ReLU, 2x2 max-pool: a Winograd tile IS a pooling window) runs on registers in the epilogue: column pass per wave, the
+// partner's two rows arrive through LDS, row pass, store.
 //
 // K loop over 16-channel chunks; per chunk
-//   * the (8+2) x (32+2) pixel input halo of the block's tiles is staged ONCE in LDS (zero padding folded in).  The B^T d B
-//     input transform is evaluated when the MFMA operand is formed: for position row i the wave reads the two patch rows
-//     that B^T combines (8 ds_read_b128), r_i[b] = d[a1][b] +- d[a2][b], and the four operands of the row are
+//   * the (4+2) x (32+2) pixel input halo of the block's tiles is staged ONCE in LDS (zero padding = buffer loads past the
+//     descriptor).  The B^T d B input transform is evaluated when the MFMA operand is formed: for position row i the wave reads
+//     the two patch rows that B^T combines (8 ds_read_b128), r_i[b] = d[a1][b] +- d[a2][b], and the four operands of the row are
 //     V[i][j] = r_i[b1] +- r_i[b2] -- the same float32 operation order as wino_input_kernel;
-//   * the filter bank arrives in four slabs (one per position row i: 4 positions x 32 couts x 16 channels = 8 KB, contiguous
-//     in the [chunk][cout block][position][32][16] layout of wino_pack_fused_kernel), double buffered;
+//   * the filter bank arrives in four slabs of 16 KB (half a position row of BOTH wave groups: 4 positions x 64 couts x 16
+//     channels, contiguous in the [chunk][cout block][slab][h][jj][64][16] layout of wino_pack_fused_kernel), double buffered;
 //   * MFMA roles: A = U (rows = couts), B = V (columns = tiles), so a lane's four accumulator registers are four CONSECUTIVE
 //     output channels of one tile -> 16-byte stores.
-// A "stage" is (chunk, i): 32 MFMAs per wave (1024 matrix-pipe cycles), 16 ds_read_b128, 32 VALU adds, 2 global loads +
-// 2 LDS writes for the next filter slab, 2 global loads of the next chunk's halo; one barrier per stage, a second one at the
-// chunk seam (the halo is single buffered: 32.6 + 2 x 8 KB of LDS per block, two blocks per CU).
+// A "stage" is (chunk, slab): 32 MFMAs per wave (2 positions x 4 cout tiles x 4 k-steps = 1024 matrix-pipe cycles), 8 fragment
+// reads, on average 8 packed adds and 4 patch-row reads, 4 global loads + 4 LDS writes of the next filter slab, one barrier.
+// The loop is ordered by hand (one MFMA + at most two other instructions between sched_barrier fences).
 //
 // LDS layouts (both conflict-free for ds_read_b128 with lane = row + 16 * k-quad, checked against the lane groups of
 // MI355X_MICROARCH.md): halo pixel = 16 channels padded to 24 floats, pixels de-interleaved by column parity so that the 16
 // tiles of a wave read 16 consecutive pixels; filter rows = 16 floats, the k-quad slot XOR-swizzled by {0,2,3,1}[(row >> 2) & 3].
+// 71,936 B per block: two blocks per CU.
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -35,41 +41,34 @@
 
 namespace frcnn {
 
-static constexpr int WF_TR = 4, WF_TC = 16;              // tile rows / columns per block (one tile row per wave)
-static constexpr int WF_HR = 2 * WF_TR + 2;              // 10 halo rows
+static constexpr int WF_TR = 2, WF_TC = 16;              // tile rows / columns per block (a wave pair per tile row)
+static constexpr int WF_HR = 2 * WF_TR + 2;              // 6 halo rows
 static constexpr int WF_HC = 2 * WF_TC + 2;              // 34 halo columns
 static constexpr int WF_HP = WF_HC / 2;                  // 17 pixels per parity plane of a halo row
 static constexpr int WF_PS = 24;                         // floats per halo pixel in LDS
-static constexpr int WF_NPIX = WF_HR * WF_HC;            // 340
-static constexpr int WF_HALO_F = WF_NPIX * WF_PS;        // 8160 floats
-#ifndef WF_NT
-#define WF_NT 2                                          // 16-cout MFMA tiles per wave: 2 = 128 accumulator registers, two blocks per CU
-#endif
-static constexpr int WF_BN = 16 * WF_NT;                 // output channels per block
-static constexpr int WF_U_F = 4 * WF_BN * 16;            // floats per filter slab (4 positions x WF_BN couts x 16 channels)
-static constexpr int WF_NU = WF_U_F / 4 / 256;           // 16-byte filter pieces per thread per slab
-static constexpr int WF_NHP = WF_NPIX * 4;               // 16-byte halo pieces per chunk
-static constexpr int WF_NH = (WF_NHP + 255) / 256;       // 6 per thread
-#ifndef WF_ABLATE
-#define WF_ABLATE 0                                      // timing experiments only (tools/build_ablate.sh), results wrong.  Inside the K loop:
-#endif                                                   // 1 no operand adds, 2 no patch-row reads, 4 no filter fragment reads, 8 no LDS writes,
-                                                         // 16 no filter loads, 32 no halo loads, 64 no barrier, 128 half of the operand adds
-#ifndef WF_SCALAR_ADDS
-#define WF_SCALAR_ADDS 0
-#endif
+static constexpr int WF_NPIX = WF_HR * WF_HC;            // 204
+static constexpr int WF_HALO_F = WF_NPIX * WF_PS;        // 4896 floats
+static constexpr int WF_BN = 64;                         // output channels per block (4 MFMA tiles of 16)
+static constexpr int WF_U_F = 4 * WF_BN * 16;            // floats per filter slab (4 positions x 64 couts x 16 channels)
+static constexpr int WF_NU = WF_U_F / 4 / 256;           // 4 16-byte filter pieces per thread per slab
+static constexpr int WF_NHP = WF_NPIX * 4;               // 816 16-byte halo pieces per chunk
+static constexpr int WF_NH = (WF_NHP + 255) / 256;       // 4 per thread
 #ifndef WF_PRIO
-#define WF_PRIO 1
+#define WF_PRIO 1                                        // s_setprio 3 outside the K loop (prologue 4.4 -> 2.3 us; the total does not move)
 #endif
-#define WF_HALO_BUFS 2                                   // no barrier at the chunk seam; 81,664 B of LDS per block (two blocks fill a CU's 160 KB)
-static constexpr size_t WF_LDS_BYTES = (size_t)(WF_HALO_BUFS * WF_HALO_F + 2 * WF_U_F) * sizeof(float);
-static_assert(WF_NH == 6, "halo pieces are spread over the first three stages of a chunk, two per stage");
+static constexpr size_t WF_LDS_BYTES = (size_t)(2 * WF_HALO_F + 2 * WF_U_F) * sizeof(float);   // 71,936
+static_assert(WF_NH == 4 && WF_NU == 4, "the stage schedule places exactly these pieces");
 
 // B^T rows: r_i = d[A1] (-|+) d[A2];  the same table gives the column combination V[i][j] = r_i[A1_j] (-|+) r_i[A2_j]
 __device__ __forceinline__ constexpr int wf_a1(int i) { return i == 0 ? 0 : (i == 1 ? 1 : (i == 2 ? 2 : 1)); }
 __device__ __forceinline__ constexpr int wf_a2(int i) { return i == 0 ? 2 : (i == 1 ? 2 : (i == 2 ? 1 : 3)); }
 __device__ __forceinline__ constexpr bool wf_sub(int i) { return i != 1; }
 
-// U'[chunk][cout block][p = 4 i + j][32][16] = (G g G^T)[i][j] of filter (cout, cin);  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+// storage slot of Winograd position (i, j) inside a (chunk, cout block): slab = (i & 1) * 2 + (j >> 1) [the stage that uses it],
+// then the wave group h = i >> 1, then jj = j & 1
+__device__ __forceinline__ constexpr int wf_slot(int i, int j) { return (((i & 1) * 2 + (j >> 1)) * 2 + (i >> 1)) * 2 + (j & 1); }
+
+// U'[chunk][cout block][wf_slot(i, j)][64][16] = (G g G^T)[i][j] of filter (cout, cin);  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 // g: OIHW [cout][cin][3][3]; `scale` (per cout, may be NULL) = the frozen-BatchNorm fold of the ResNet layers, multiplied in
 // float32 first exactly as fold_bn_pack_kernel does.  Values are identical to wino_pack_kernel's bank (float64, rounded once).
 __global__ __launch_bounds__(256)
@@ -99,7 +98,7 @@ void wino_pack_fused_kernel(const float* __restrict__ g, const float* __restrict
         for (int a = 0; a < 4; ++a) {
             const double q[4] = {r[a][0], 0.5 * (r[a][0] + r[a][1] + r[a][2]), 0.5 * (r[a][0] - r[a][1] + r[a][2]), r[a][2]};
 #pragma unroll
-            for (int b = 0; b < 4; ++b) u[base + (size_t)(4 * a + b) * (WF_BN * 16)] = (float)q[b];
+            for (int b = 0; b < 4; ++b) u[base + (size_t)wf_slot(a, b) * (WF_BN * 16)] = (float)q[b];
         }
     }
 }
@@ -136,40 +135,28 @@ void wino_pack_fused_taps_kernel(const float* __restrict__ wp, float* __restrict
         for (int a = 0; a < 4; ++a) {
             const double q[4] = {r[a][0], 0.5 * (r[a][0] + r[a][1] + r[a][2]), 0.5 * (r[a][0] - r[a][1] + r[a][2]), r[a][2]};
 #pragma unroll
-            for (int b = 0; b < 4; ++b) u[base + (size_t)(4 * a + b) * (WF_BN * 16)] = (float)q[b];
+            for (int b = 0; b < 4; ++b) u[base + (size_t)wf_slot(a, b) * (WF_BN * 16)] = (float)q[b];
         }
     }
 }
 
 struct WfGeom { int tbx, tby, ncb, total, xcl; };        // xcl: log2 of the number of XCD groups the cout blocks are split over
 
-#define WF_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#define WF_MFMA 0x008
-#define WF_VALU 0x002
-#define WF_DSR  0x100
-#define WF_DSW  0x200
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 wf_lo(const f32x4& a) { return __builtin_shufflevector(a, a, 0, 1); }
 __device__ __forceinline__ f32x2 wf_hi(const f32x4& a) { return __builtin_shufflevector(a, a, 2, 3); }
-// a -+ b on a register pair in one instruction (the neg modifiers make it a - b: the same IEEE result as v_sub_f32)
+// a -+ b on a register pair in one instruction (the neg modifiers make it a - b: the same IEEE result as v_sub_f32).
+// Two scalar adds instead cost the same matrix-pipe time (measured).
 __device__ __forceinline__ f32x2 wf_pk(bool sub, f32x2 a, f32x2 b)
 {
     f32x2 o;
-#if WF_SCALAR_ADDS
-    float o0, o1;
-    if (sub) { asm volatile("v_sub_f32 %0, %1, %2" : "=v"(o0) : "v"(a[0]), "v"(b[0])); asm volatile("v_sub_f32 %0, %1, %2" : "=v"(o1) : "v"(a[1]), "v"(b[1])); }
-    else { asm volatile("v_add_f32 %0, %1, %2" : "=v"(o0) : "v"(a[0]), "v"(b[0])); asm volatile("v_add_f32 %0, %1, %2" : "=v"(o1) : "v"(a[1]), "v"(b[1])); }
-    o[0] = o0; o[1] = o1;
-#else
     if (sub) asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b));
     else asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
-#endif
     return o;
 }
 
 template <bool POOL>
-__global__ __launch_bounds__(256, WF_NT <= 2 ? 2 : 1)
+__global__ __launch_bounds__(256, 2)
 void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ bias,
                        float* __restrict__ y, int H, int W, int Cin, int Cout, int relu, WfGeom gm)
 {
@@ -180,11 +167,12 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
     __builtin_amdgcn_s_setprio(3);                       // prologue and epilogue ahead of the co-resident block's K loop
 #endif
     extern __shared__ __attribute__((aligned(16))) float smem_wf[];
-    float* const halo0 = smem_wf;                           // WF_HALO_BUFS halo buffers
-    float* const ub0 = smem_wf + WF_HALO_BUFS * WF_HALO_F;  // 2 filter slab buffers
+    float* const halo0 = smem_wf;                           // 2 halo buffers
+    float* const ub0 = smem_wf + 2 * WF_HALO_F;             // 2 filter slab buffers
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kq = lane >> 4;
+    const int tr = wave >> 1;                               // tile row of the wave; its position rows: 2 h, 2 h + 1 with h = wave & 1
 
     // XCD-aware block order.  Hardware block b runs on XCD b % 8 and every XCD has its own 4 MB L2.  The 8 XCDs form a
     // (8 >> xcl) x (1 << xcl) grid: XCD (xti, xci) owns the cout blocks of group xci and a contiguous range of that group's
@@ -224,7 +212,8 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         h_src[it] = inb ? (int)((((unsigned)gy * W + gx) * Cin + 4 * pk) * sizeof(float)) : (int)0xFFFFFFF0u;
         h_dst[it] = ((hr * 2 + (hc & 1)) * WF_HP + (hc >> 1)) * WF_PS + 4 * pk;
     }
-    // ---- filter slab staging: 512 pieces of 16 B per slab, two per thread ------------------------------------------------
+    // ---- filter slab staging: 1024 pieces of 16 B per slab, four per thread; buffer loads too -- lane offset 16 tid, everything
+    // else (cout block, chunk, slab, piece) in the scalar offset ------------------------------------------------------------
     int u_dst[WF_NU];
 #pragma unroll
     for (int it = 0; it < WF_NU; ++it) {
@@ -232,65 +221,185 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         const int row = q >> 2, pk = q & 3;
         u_dst[it] = row * 16 + 4 * (pk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3));
     }
-    // filter loads: buffer loads too -- lane offset 16 tid, everything else (cout block, chunk, slab, piece) in the scalar offset
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(u), 0, 16 * Cin * Cout * (int)sizeof(float), 0x00020000);
     const int u_voff = 16 * tid;
-    const int u_blk = cb * 16 * (WF_BN * 16) * (int)sizeof(float);                  // + chunk * u_chunk_stride + (i * 2048 + 1024 * it) * 4
+    const int u_blk = cb * 16 * (WF_BN * 16) * (int)sizeof(float);                  // + chunk * u_chunk_stride + (slab * 4096 + 1024 * it) * 4
     const int u_chunk_stride = gm.ncb * 16 * (WF_BN * 16) * (int)sizeof(float);
 
-    f32x4 hreg[2][2];            // two pieces in flight + two waiting for their LDS write
-    f32x4 ureg[2][WF_NU];        // filter slab t travels in set t & 1: loaded two stages ahead, written to LDS one stage ahead
-    bool in_loop = false;
+    f32x4 hreg[2][2];            // halo pieces (0,1) and (2,3) of the next chunk on their way to LDS
+    f32x4 ureg[2][WF_NU];        // filter slab s travels in set s & 1: loaded two stages ahead, written to LDS one stage ahead
     auto load_halo_piece = [&](f32x4& dst, int it, int chunk) {
-        if ((WF_ABLATE & 32) && in_loop) return;
         dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, h_src[it], chunk * 64, 0));
     };
-    auto store_halo_piece = [&](float* hb, const f32x4& src, int it) {
-        if ((WF_ABLATE & 8) && in_loop) { asm volatile("" :: "v"(src)); return; }
-        *reinterpret_cast<f32x4*>(hb + h_dst[it]) = src;
+    auto store_halo_piece = [&](float* hb, const f32x4& src, int it) { *reinterpret_cast<f32x4*>(hb + h_dst[it]) = src; };
+    auto load_u_piece = [&](f32x4& dst, int chunk, int slab, int it) {
+        dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, u_voff, u_blk + chunk * u_chunk_stride + (slab * WF_U_F + 1024 * it) * (int)sizeof(float), 0));
     };
-    auto load_u_piece = [&](f32x4& dst, int chunk, int i, int it) {
-        if ((WF_ABLATE & 16) && in_loop) return;
-        dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, u_voff, u_blk + chunk * u_chunk_stride + (i * WF_U_F + 1024 * it) * (int)sizeof(float), 0));
-    };
-    auto store_u_piece = [&](int buf, const f32x4& src, int it) {
-        if ((WF_ABLATE & 8) && in_loop) { asm volatile("" :: "v"(src)); return; }
-        *reinterpret_cast<f32x4*>(ub0 + buf * WF_U_F + u_dst[it]) = src;
-    };
+    auto store_u_piece = [&](int buf, const f32x4& src, int it) { *reinterpret_cast<f32x4*>(ub0 + buf * WF_U_F + u_dst[it]) = src; };
 
-    f32x4 acc[16][WF_NT];
+    f32x4 acc[8][4];             // [2 t + ... position (t, j) = 4 t + j][cout tile]
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
-        for (int c = 0; c < WF_NT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 4; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // operand addresses: V from patch pixel (a, b) of tile (wave, l16): halo row 2 wave + a, plane b & 1, index l16 + (b >> 1)
-    const int v_off = ((4 * wave) * WF_HP + l16) * WF_PS + 4 * kq;
-    // U of position j (within the stage's row), cout half c: row = 32 j + 16 c + l16
+    // operand addresses: V from patch pixel (a, b) of tile (tr, l16): halo row 2 tr + a, plane b & 1, index l16 + (b >> 1)
+    const int v_off = ((4 * tr) * WF_HP + l16) * WF_PS + 4 * kq;
+    // U of slab slot sl (= 2 h + jj), cout tile c: row = 64 sl + 16 c + l16
     const int u_off = l16 * 16 + 4 * (kq ^ ((0x78 >> (2 * ((l16 >> 2) & 3))) & 3));
 
-    // state carried from stage to stage: r_i of the current stage (as register pairs: the transform adds are v_pk_add_f32),
-    // the fragments of its first position
-    f32x2 r[4][2], v[2][2];
-    f32x4 uf[2][WF_NT], d[8];
-    // the 8 patch-row reads of position row i: n = 2 b + (0: row a1, 1: row a2)
-    auto read_d = [&](const float* hb, int i, int n) {
-        const int b = n >> 1, a = (n & 1) ? wf_a2(i) : wf_a1(i);
-        if ((WF_ABLATE & 2) && in_loop) return;
-        d[n] = *reinterpret_cast<const f32x4*>(hb + v_off + ((2 * a + (b & 1)) * WF_HP + (b >> 1)) * WF_PS);
-    };
-    // r_i[b] = d[a1][b] -+ d[a2][b], one register pair (m = 2 b + half) per instruction
-    auto make_r = [&](int i, int m) {
-        const int b = m >> 1;
-        if ((WF_ABLATE & 1) && in_loop) return;
-        if ((WF_ABLATE & 128) && in_loop && (i & 1)) return;
-        r[b][m & 1] = (m & 1) ? wf_pk(wf_sub(i), wf_hi(d[2 * b]), wf_hi(d[2 * b + 1])) : wf_pk(wf_sub(i), wf_lo(d[2 * b]), wf_lo(d[2 * b + 1]));
-    };
-    // V[i][j] = r_i[a1(j)] -+ r_i[a2(j)]
-    auto make_v = [&](int j, int slot, int h) { if ((WF_ABLATE & 1) && in_loop) return; if ((WF_ABLATE & 128) && in_loop && (j & 1)) return; v[slot][h] = wf_pk(wf_sub(j), r[wf_a1(j)][h], r[wf_a2(j)][h]); };
-    auto read_u = [&](int buf, int j, int slot, int cc) {
-        if ((WF_ABLATE & 4) && in_loop) return;
-        uf[slot][cc] = *reinterpret_cast<const f32x4*>(ub0 + buf * WF_U_F + u_off + (WF_BN * j + 16 * cc) * 16);
+#ifdef WF_CLOCKS
+    unsigned long long clk0 = 0, real0 = 0, clk1 = 0, real1 = 0;
+#endif
+    f32x4 M[16][2];              // epilogue: all 16 positions of the two cout tiles this wave finishes
+    // Everything that depends on the wave group h (which patch rows B^T combines, with which sign, which filter slots) must be a
+    // compile-time constant of the loop: the K loop exists once per h.
+    auto run = [&](auto hsel) {
+        constexpr int HG = decltype(hsel)::value;
+        // state carried from stage to stage: r of the current position row (as register pairs: the adds are v_pk_add_f32), the two
+        // operands in flight, two fragment sets of two cout tiles each
+        f32x2 r[4][2], v[2][2];
+        f32x4 uf[2][2], d[8];
+        // the 8 patch-row reads of position row i: n = 2 b + (0: row a1, 1: row a2)
+        auto read_d = [&](const float* hb, int i, int n) {
+            const int b = n >> 1, a = (n & 1) ? wf_a2(i) : wf_a1(i);
+            d[n] = *reinterpret_cast<const f32x4*>(hb + v_off + ((2 * a + (b & 1)) * WF_HP + (b >> 1)) * WF_PS);
+        };
+        // r_i[b] = d[a1][b] -+ d[a2][b], one register pair (m = 2 b + half) per instruction
+        auto make_r = [&](int i, int m) {
+            const int b = m >> 1;
+            r[b][m & 1] = (m & 1) ? wf_pk(wf_sub(i), wf_hi(d[2 * b]), wf_hi(d[2 * b + 1])) : wf_pk(wf_sub(i), wf_lo(d[2 * b]), wf_lo(d[2 * b + 1]));
+        };
+        // V[i][j] = r_i[a1(j)] -+ r_i[a2(j)]
+        auto make_v = [&](int j, int slot, int hf) { v[slot][hf] = wf_pk(wf_sub(j), r[wf_a1(j)][hf], r[wf_a2(j)][hf]); };
+        // fragment of filter slot (HG, jj), cout tile c of the slab in buffer `buf`
+        auto read_u = [&](int buf, int jj, int c, int set, int e) {
+            uf[set][e] = *reinterpret_cast<const f32x4*>(ub0 + buf * WF_U_F + u_off + ((2 * HG + jj) * WF_BN + 16 * c) * 16);
+        };
+
+        // ---- prologue of the group: row 2 HG of chunk 0, its first operand, the first fragments ---------------------------------
+#pragma unroll
+        for (int n = 0; n < 8; ++n) read_d(halo0, 2 * HG, n);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) make_r(2 * HG, m);
+        read_u(0, 0, 0, 0, 0);
+        read_u(0, 0, 1, 0, 1);
+        make_v(0, 0, 0);
+        make_v(0, 0, 1);
+
+#define WF_GAP() __builtin_amdgcn_sched_barrier(0)
+#if WF_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef WF_CLOCKS
+        clk0 = __builtin_readcyclecounter(); real0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        // one chunk; PAR = chunk parity = halo buffer, a compile-time constant so that every LDS address of the loop is an
+        // instruction immediate (address arithmetic on the vector ALU costs matrix-pipe time like any other vector instruction)
+        auto chunk_body = [&](const int c, auto par) {
+            constexpr int PAR = decltype(par)::value;
+            const int cn = (c + 1) < nchunks ? c + 1 : c;    // clamped: past the last chunk the loads re-read it, harmlessly
+            const int cnn = (c + 2) < nchunks ? c + 2 : cn;
+            float* const hcur = halo0 + PAR * WF_HALO_F;
+            float* const hnxt = halo0 + (PAR ^ 1) * WF_HALO_F;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // stage (chunk c, slab q): position row i = 2 HG + t of the wave, positions j = 2 hf and 2 hf + 1
+                const int t = q >> 1, hf = q & 1;
+                const int buf = q & 1;                       // 4 slabs per chunk: the slab buffer parity repeats every chunk
+                const int ls = q & 1, ss = (q + 1) & 1;      // filter register sets: loaded in this stage (slab s + 2) / written to LDS (slab s + 1)
+                const int pa = 4 * t + 2 * hf, pb = pa + 1;  // accumulator rows of the two positions
+                const int jn = (2 * hf + 2) & 3;             // the next stage's first position
+                const int in_ = 2 * HG + (t ^ 1);            // the position row after this one (next chunk's when t == 1)
+                const float* const hrow = t == 1 ? hnxt : hcur;
+                auto mfma = [&](int p, int cbase, int set, int vs, int k) {
+                    const int s = k >> 1, e = k & 1;
+                    acc[p][cbase + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[set][e][s], v[vs][s >> 1][s & 1], acc[p][cbase + e], 0, 0, 0);
+                };
+                // group 0: position a, cout tiles 0,1 | fragments of (a, tiles 2,3), operand of position b, the stage's filter loads
+                mfma(pa, 0, 0, 0, 0); read_u(buf, 0, 2, 1, 0); WF_GAP();
+                mfma(pa, 0, 0, 0, 1); read_u(buf, 0, 3, 1, 1); WF_GAP();
+                mfma(pa, 0, 0, 0, 2); make_v(2 * hf + 1, 1, 0); WF_GAP();
+                mfma(pa, 0, 0, 0, 3); make_v(2 * hf + 1, 1, 1); WF_GAP();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    mfma(pa, 0, 0, 0, 4 + it);
+                    if (q < 2) load_u_piece(ureg[ls][it], c, q + 2, it); else load_u_piece(ureg[ls][it], cn, q - 2, it);
+                    WF_GAP();
+                }
+                // group 1: position a, cout tiles 2,3 | fragments of (b, tiles 0,1); second half of a row: the next row's r
+                // (r is dead once the row's last operand exists); first stage / last stage of a chunk: halo loads of the next chunk
+                mfma(pa, 2, 1, 0, 0); read_u(buf, 1, 0, 0, 0); WF_GAP();
+                mfma(pa, 2, 1, 0, 1); read_u(buf, 1, 1, 0, 1); WF_GAP();
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    mfma(pa, 2, 1, 0, 2 + g);
+                    if (hf == 1) { make_r(in_, 2 * g); make_r(in_, 2 * g + 1); }
+                    WF_GAP();
+                }
+                mfma(pa, 2, 1, 0, 6); if (q == 0) load_halo_piece(hreg[1][0], 2, cn); if (q == 3) load_halo_piece(hreg[0][0], 0, cnn); WF_GAP();
+                mfma(pa, 2, 1, 0, 7); if (q == 0) load_halo_piece(hreg[1][1], 3, cn); if (q == 3) load_halo_piece(hreg[0][1], 1, cnn); WF_GAP();
+                // group 2: position b, cout tiles 0,1 | fragments of (b, tiles 2,3), the LDS writes (long done by the barrier)
+                mfma(pb, 0, 0, 1, 0); read_u(buf, 1, 2, 1, 0); WF_GAP();
+                mfma(pb, 0, 0, 1, 1); read_u(buf, 1, 3, 1, 1); WF_GAP();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    mfma(pb, 0, 0, 1, 2 + it);
+                    store_u_piece(buf ^ 1, ureg[ss][it], it);
+                    WF_GAP();
+                }
+                mfma(pb, 0, 0, 1, 6); if (q < 2) store_halo_piece(hnxt, hreg[q][0], 2 * q); WF_GAP();
+                mfma(pb, 0, 0, 1, 7); if (q < 2) store_halo_piece(hnxt, hreg[q][1], 2 * q + 1); WF_GAP();
+                __syncthreads();
+                WF_GAP();
+                // group 3: position b, cout tiles 2,3 | the next stage's first fragments (next slab) and first operand; first half
+                // of a row: the patch rows of the NEXT position row
+                mfma(pb, 2, 1, 1, 0); read_u(buf ^ 1, 0, 0, 0, 0); WF_GAP();
+                mfma(pb, 2, 1, 1, 1); read_u(buf ^ 1, 0, 1, 0, 1); WF_GAP();
+                mfma(pb, 2, 1, 1, 2); make_v(jn, 0, 0); WF_GAP();
+                mfma(pb, 2, 1, 1, 3); make_v(jn, 0, 1); WF_GAP();
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    mfma(pb, 2, 1, 1, 4 + g);
+                    if (hf == 0) { read_d(hrow, in_, 2 * g); read_d(hrow, in_, 2 * g + 1); }
+                    WF_GAP();
+                }
+            }
+        };
+        for (int c = 0; c < nchunks; c += 2) {
+            chunk_body(c, std::integral_constant<int, 0>());
+            if (c + 1 < nchunks) chunk_body(c + 1, std::integral_constant<int, 1>());
+        }
+#undef WF_GAP
+#ifdef WF_CLOCKS
+        clk1 = __builtin_readcyclecounter(); real1 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if WF_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        // The pair (tr, 0) / (tr, 1) holds the position rows {0, 1} / {2, 3} of all four cout tiles.  Wave h finishes the tiles 2 h and
+        // 2 h + 1 and needs the partner's two rows of them: 16 accumulators per lane travel through LDS (16 KB per wave, in the
+        // staging buffers).  Static indices only: a select between accumulator registers by a run-time h puts them in scratch.
+        __syncthreads();                                 // every wave has left the K loop: the staging buffers are free
+        {
+            float* const mine = smem_wf + (size_t)wave * 16 * 64 * 4 + lane * 4;
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    *reinterpret_cast<f32x4*>(mine + (p * 2 + e) * 64 * 4) = acc[p][2 * (1 - HG) + e];      // the partner's tiles
+        }
+        __syncthreads();
+        {
+            const float* const theirs = smem_wf + (size_t)(wave ^ 1) * 16 * 64 * 4 + lane * 4;
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    M[8 * HG + p][e] = acc[p][2 * HG + e];
+                    M[8 * (1 - HG) + p][e] = *reinterpret_cast<const f32x4*>(theirs + (p * 2 + e) * 64 * 4);
+                }
+        }
     };
 
     // ---- prologue ---------------------------------------------------------------------------------------------------------
@@ -306,138 +415,49 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         for (int it = 0; it < WF_NU; ++it) store_u_piece(0, ureg[0][it], it);
 #pragma unroll
         for (int it = 0; it < WF_NU; ++it) load_u_piece(ureg[1][it], 0, 1, it);       // slab 1: written to LDS in stage 0
+        // the first half of chunk 1's halo (the slot of "stage 3 of the previous chunk")
+        const int c1 = nchunks > 1 ? 1 : 0;
+        load_halo_piece(hreg[0][0], 0, c1);
+        load_halo_piece(hreg[0][1], 1, c1);
     }
     __syncthreads();
-#pragma unroll
-    for (int n = 0; n < 8; ++n) read_d(halo0, 0, n);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) make_r(0, m);
-    read_u(0, 0, 0, 0);
-    read_u(0, 0, 0, 1);
-    make_v(0, 0, 0);
-    make_v(0, 0, 1);
+    if (wave & 1) run(std::integral_constant<int, 1>());
+    else run(std::integral_constant<int, 0>());
 
-    // the first third of chunk 1's halo (the slot of "stage 3 of the previous chunk")
-    {
-        const int c1 = nchunks > 1 ? 1 : 0;
-        load_halo_piece(hreg[1][0], 0, c1);
-        load_halo_piece(hreg[1][1], 1, c1);
-    }
-
-    // The K loop is scheduled BY HAND: every statement group below is one MFMA plus at most two other instructions, fenced
-    // with sched_barrier(0) so that hipcc keeps the order.  A batch of non-MFMA instructions between two MFMAs holds the
-    // wave's issue slot while the matrix pipe drains (measured: ~5 pipe cycles per instruction); one or two of them right
-    // behind an MFMA issue are hidden under its 32 cycles.
-#define WF_GAP() __builtin_amdgcn_sched_barrier(0)
-    if (WF_ABLATE) {                                     // ablated loops still multiply real data (MFMA timing of junk / zero operands differs)
-        v[1][0] = v[0][0]; v[1][1] = v[0][1]; uf[1][0] = uf[0][1]; uf[1][1] = uf[0][0];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) d[n] = uf[n & 1][n >> 2 & 1];
-    }
-    in_loop = true;
-#if WF_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
+    // ---- epilogue: Y = A^T M A; lane = tile (tr, l16) x couts n0 + 16 c + 4 kq .. + 3 ----------------------------------------
+    // M (filled at the end of `run`) holds all 16 positions of the wave's two cout tiles; the transform runs in the row-then-column
+    // order of wino_output_kernel.
+    const int h = wave & 1;
 #ifdef WF_CLOCKS
-    const unsigned long long clk0 = __builtin_readcyclecounter(), real0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // one chunk; PAR = chunk parity = halo buffer, a compile-time constant so that every LDS address of the loop is an
-    // instruction immediate (address arithmetic on the vector ALU costs matrix-pipe time like any other vector instruction)
-    auto chunk_body = [&](const int c, auto par) {
-        constexpr int PAR = decltype(par)::value;
-        const int cn = (c + 1) < nchunks ? c + 1 : c;    // clamped: past the last chunk the loads re-read it, harmlessly
-        const int cnn = (c + 2) < nchunks ? c + 2 : cn;
-        float* const hcur = halo0 + PAR * WF_HALO_F;
-        float* const hnxt = halo0 + (PAR ^ 1) * WF_HALO_F;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int buf = i & 1;                       // 4 stages per chunk: the slab buffer parity repeats every chunk
-            const int ls = i & 1, ss = (i + 1) & 1;      // register sets: loaded in this stage / written to LDS in this stage
-            const float* const hrow = i == 3 ? hnxt : hcur;
-            const int inext = (i + 1) & 3;
-            auto mfma = [&](int j, int slot, int k) {
-                const int s = k >> 1, cc = k & 1;
-                acc[4 * i + j][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[slot][cc][s], v[slot][s >> 1][s & 1], acc[4 * i + j][cc], 0, 0, 0);
-            };
-            // Data movement of the stage.  Filter slab s+2 is loaded (one stage of prefetch is shorter than the L2 latency when
-            // the block runs alone on its CU), slab s+1 is written to LDS.  Halo of chunk c+1 in thirds: pieces (0,1) were loaded
-            // in stage 3 of the previous chunk, (2,3) and (4,5) are loaded in stages 0 and 1, each third is written to LDS one
-            // stage after its load -- the whole halo is in LDS before the barrier of stage 2.
-            // phase 0: position 0 | fragments + operand of position 1, the stage's global loads and LDS writes
-            mfma(0, 0, 0); read_u(buf, 1, 1, 0); if (i < 2) load_u_piece(ureg[ls][0], c, i + 2, 0); else load_u_piece(ureg[ls][0], cn, i - 2, 0); WF_GAP();
-            mfma(0, 0, 1); read_u(buf, 1, 1, 1); if (i < 2) load_u_piece(ureg[ls][1], c, i + 2, 1); else load_u_piece(ureg[ls][1], cn, i - 2, 1); WF_GAP();
-            mfma(0, 0, 2); make_v(1, 1, 0); if (i < 2) load_halo_piece(hreg[ls][0], 2 * i + 2, cn); if (i == 3) load_halo_piece(hreg[1][0], 0, cnn); WF_GAP();
-            mfma(0, 0, 3); make_v(1, 1, 1); if (i < 2) load_halo_piece(hreg[ls][1], 2 * i + 3, cn); if (i == 3) load_halo_piece(hreg[1][1], 1, cnn); WF_GAP();
-            mfma(0, 0, 4); store_u_piece(buf ^ 1, ureg[ss][0], 0); WF_GAP();
-            mfma(0, 0, 5); store_u_piece(buf ^ 1, ureg[ss][1], 1); WF_GAP();
-            mfma(0, 0, 6); if (i < 3) store_halo_piece(hnxt, hreg[ss][0], 2 * i); WF_GAP();
-            mfma(0, 0, 7); if (i < 3) store_halo_piece(hnxt, hreg[ss][1], 2 * i + 1); WF_GAP();
-            // phase 1: position 1 | position 2's fragments + operand, the patch rows of the NEXT position row (long landed by the barrier)
-            mfma(1, 1, 0); read_u(buf, 2, 0, 0); WF_GAP();
-            mfma(1, 1, 1); read_u(buf, 2, 0, 1); WF_GAP();
-            mfma(1, 1, 2); make_v(2, 0, 0); WF_GAP();
-            mfma(1, 1, 3); make_v(2, 0, 1); WF_GAP();
-            mfma(1, 1, 4); read_d(hrow, inext, 0); read_d(hrow, inext, 1); WF_GAP();
-            mfma(1, 1, 5); read_d(hrow, inext, 2); read_d(hrow, inext, 3); WF_GAP();
-            mfma(1, 1, 6); read_d(hrow, inext, 4); read_d(hrow, inext, 5); WF_GAP();
-            mfma(1, 1, 7); read_d(hrow, inext, 6); read_d(hrow, inext, 7); WF_GAP();
-            // phase 2: position 2 | position 3's fragments + operand (r is dead after it), then the next row's r
-            mfma(2, 0, 0); read_u(buf, 3, 1, 0); WF_GAP();
-            mfma(2, 0, 1); read_u(buf, 3, 1, 1); WF_GAP();
-            mfma(2, 0, 2); make_v(3, 1, 0); WF_GAP();
-            mfma(2, 0, 3); make_v(3, 1, 1); WF_GAP();
-            mfma(2, 0, 4); make_r(inext, 0); make_r(inext, 1); WF_GAP();
-            mfma(2, 0, 5); make_r(inext, 2); make_r(inext, 3); WF_GAP();
-            mfma(2, 0, 6); make_r(inext, 4); make_r(inext, 5); WF_GAP();
-            mfma(2, 0, 7); make_r(inext, 6); make_r(inext, 7); WF_GAP();
-            if (!(WF_ABLATE & 64)) __syncthreads();
-            WF_GAP();
-            // phase 3: position 3 | the next stage's first fragments (next slab) and first operand
-            mfma(3, 1, 0); read_u(buf ^ 1, 0, 0, 0); WF_GAP();
-            mfma(3, 1, 1); read_u(buf ^ 1, 0, 0, 1); WF_GAP();
-            mfma(3, 1, 2); make_v(0, 0, 0); WF_GAP();
-            mfma(3, 1, 3); make_v(0, 0, 1); WF_GAP();
-            mfma(3, 1, 4); WF_GAP();
-            mfma(3, 1, 5); WF_GAP();
-            mfma(3, 1, 6); WF_GAP();
-            mfma(3, 1, 7); WF_GAP();
-        }
-    };
-    for (int c = 0; c < nchunks; c += 2) {
-        chunk_body(c, std::integral_constant<int, 0>());
-        if (c + 1 < nchunks) chunk_body(c + 1, std::integral_constant<int, 1>());
+    // timing experiment: per wave, written BEHIND the output map (the caller of this build allocates H * W * Cout + 32 * gridDim.x
+    // floats: tools/wf_clocks.py): shader cycles and 100 MHz ticks of the K loop, ticks before and after it, entry time
+    if (lane == 0) {
+        const unsigned long long real_exit = __builtin_amdgcn_s_memrealtime();
+        float* o = y + (size_t)(POOL ? (H >> 1) * (W >> 1) : H * W) * Cout + ((size_t)blockIdx.x * 4 + wave) * 8;
+        o[0] = (float)(clk1 - clk0); o[1] = (float)(real1 - real0); o[2] = (float)(real0 - real_entry); o[3] = (float)(real_exit - real1);
+        o[4] = (float)(real_entry & 0xFFFFFF); o[5] = (float)(real_exit & 0xFFFFFF); o[6] = (float)nchunks; o[7] = 1.f;
     }
-#undef WF_GAP
-#if WF_PRIO
-    __builtin_amdgcn_s_setprio(3);
 #endif
-#ifdef WF_CLOCKS
-    const unsigned long long clk1 = __builtin_readcyclecounter(), real1 = __builtin_amdgcn_s_memrealtime();
-#endif
-
-    // ---- epilogue: Y = A^T M A on registers; lane = tile (wave, l16) x couts n0 + 16 c + 4 kq .. + 3 -----------------------
-    const int ty = WF_TR * by + wave, tx = WF_TC * bx + l16;
+    const int ty = WF_TR * by + tr, tx = WF_TC * bx + l16;
     const int th = (H + 1) >> 1, tw = (W + 1) >> 1;
-#ifndef WF_CLOCKS
     if (ty >= th || tx >= tw) return;
-#endif
     const int Ho = H >> 1, Wo = W >> 1;
     if (POOL && (ty >= Ho || tx >= Wo)) return;          // floor pooling drops the odd last row / column
 #pragma unroll
-    for (int c = 0; c < WF_NT; ++c) {
-        const int co = n0 + 16 * c + 4 * kq;
-        f32x4 s[2][4];
+    for (int e = 0; e < 2; ++e) {
+        const int co = n0 + 16 * (2 * h + e) + 4 * kq;
+        f32x4 sr[2][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            s[0][j] = (acc[0 + j][c] + acc[4 + j][c]) + acc[8 + j][c];
-            s[1][j] = (acc[4 + j][c] - acc[8 + j][c]) - acc[12 + j][c];
+            sr[0][j] = (M[0 + j][e] + M[4 + j][e]) + M[8 + j][e];
+            sr[1][j] = (M[4 + j][e] - M[8 + j][e]) - M[12 + j][e];
         }
         const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
         f32x4 o[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            o[a][0] = ((s[a][0] + s[a][1]) + s[a][2]) + bv;
-            o[a][1] = ((s[a][1] - s[a][2]) - s[a][3]) + bv;
+            o[a][0] = ((sr[a][0] + sr[a][1]) + sr[a][2]) + bv;
+            o[a][1] = ((sr[a][1] - sr[a][2]) - sr[a][3]) + bv;
         }
         if (relu) {
 #pragma unroll
@@ -445,12 +465,12 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[a][b][e] = fmaxf(o[a][b][e], 0.f);
+                    for (int q = 0; q < 4; ++q) o[a][b][q] = fmaxf(o[a][b][q], 0.f);
         }
         if (POOL) {
             f32x4 m;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
+            for (int q = 0; q < 4; ++q) m[q] = fmaxf(fmaxf(o[0][0][q], o[0][1][q]), fmaxf(o[1][0][q], o[1][1][q]));
             *reinterpret_cast<f32x4*>(y + ((size_t)ty * Wo + tx) * Cout + co) = m;
         } else {
 #pragma unroll
@@ -465,17 +485,6 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
             }
         }
     }
-#ifdef WF_CLOCKS
-    // timing experiment: per wave, written BEHIND the output map (the caller of this build allocates H * W * Cout + 32 * blocks
-    // floats: tools/wf_clocks.py): shader cycles and 100 MHz ticks of the K loop, ticks before and after it, entry time
-    if (lane == 0) {
-        const unsigned long long real_exit = __builtin_amdgcn_s_memrealtime();
-        float* o = y + (size_t)(POOL ? (H >> 1) * (W >> 1) : H * W) * Cout + ((size_t)blockIdx.x * 4 + wave) * 8;
-        o[0] = (float)(clk1 - clk0); o[1] = (float)(real1 - real0); o[2] = (float)(real0 - real_entry); o[3] = (float)(real_exit - real1);
-        o[4] = (float)(real_entry & 0xFFFFFF); o[5] = (float)(real_exit & 0xFFFFFF); o[6] = (float)nchunks;
-        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); o[7] = (float)(hwid & 0xFFFFFF);
-    }
-#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------

@@ -25,15 +25,15 @@ def pack_conv3x3(conv, math_mode="f32"):
     """
     OIHW weight of a 3x3 nn.Conv2d -> tap-major [9][cout][cin] (or [27][cout] when cin == 3); in the
     "f32x6" math mode -> the exactly split [9][cout][cin/16][hi,mid,lo][16] bf16 layout; in the
-    "f32_winograd" mode, for cin >= 64 (% 16) and cout >= 64 (% 32) -> the transformed filters G g G^T in the one-launch
-    kernel's [cin/16][cout/32][16][32][16] order (flat); "f32_winograd_3launch" (tests / experiments) keeps round 1's
+    "f32_winograd" mode, for cin >= 64 (% 16) and cout >= 64 (% 64) -> the transformed filters G g G^T in the one-launch
+    kernel's [cin/16][cout/64][16][64][16] order (flat); "f32_winograd_3launch" (tests / experiments) keeps round 1's
     [16][cout][cin] bank of the three-launch form for cin >= 128 and cout >= 256.
     """
     w = conv.weight.detach()
     cout, cin = int(w.shape[0]), int(w.shape[1])
     w = rt.as_f32_cuda(w, "conv weight")
     if math_mode == "f32_winograd" and nv.uses_winograd_fused(cin, cout):
-        # one-launch Winograd layer (csrc/winofused.hip): [cin/16][cout/32][16][32][16], kept flat (dim() == 1 marks it)
+        # one-launch Winograd layer (csrc/winofused.hip): [cin/16][cout/64][16][64][16], kept flat (dim() == 1 marks it)
         out = t.empty((16 * cout * cin,), dtype=t.float32, device=w.device)
         with t.cuda.device(w.device):
             nv.check(nv.lib().frcnn_pack_conv3x3_winograd_fused(nv.ptr(w), None, nv.ptr(out), cout, cin, nv.stream_ptr()),

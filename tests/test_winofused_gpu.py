@@ -68,22 +68,25 @@ def run_other(kind, x, w_oihw, b, relu, pool):
 def test_fused_bank_is_a_permutation_of_the_three_launch_bank():
     lib = nv.lib()
     gen = torch.Generator().manual_seed(3)
-    cout, cin = 96, 48
+    cout, cin = 192, 48
     w = torch.randn((cout, cin, 3, 3), generator=gen).cuda()
     scale = (torch.rand((cout,), generator=gen) + 0.5).cuda()
     for sc in (None, scale):
         u3 = torch.empty((16, cout, cin), device="cuda")
         # (the three-launch pack itself has no cout % 128 restriction; only its GEMM has)
         nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w), nv.ptr(sc), nv.ptr(u3), cout, cin, nv.stream_ptr()), "pack_winograd")
-        uf = fused_bank(w, sc).reshape(cin // 16, cout // 32, 16, 32, 16)      # [chunk][cout block][p][32][16]
-        want = u3.reshape(16, cout // 32, 32, cin // 16, 16).permute(3, 1, 0, 2, 4)
-        assert torch.equal(uf, want)
+        # [chunk][cout block][slot][64][16]; slot of position (i, j) = its stage (i & 1, j >> 1), then the wave group i >> 1, then j & 1
+        uf = fused_bank(w, sc).reshape(cin // 16, cout // 64, 16, 64, 16)
+        slot = [(((i & 1) * 2 + (j >> 1)) * 2 + (i >> 1)) * 2 + (j & 1) for i in range(4) for j in range(4)]
+        want = torch.empty_like(uf)
+        want[:, :, slot] = u3.reshape(16, cout // 64, 64, cin // 16, 16).permute(3, 1, 0, 2, 4)
+        assert sorted(slot) == list(range(16)) and torch.equal(uf, want)
     # from the tap-major master pack (train step): the same bank; data-gradient bank = bank of the rotated, transposed filter
     wp = w.permute(2, 3, 0, 1).reshape(9, cout, cin).contiguous()
     ut = torch.full((16 * cout * cin,), float("nan"), device="cuda")
     nv.check(lib.frcnn_pack_conv3x3_winograd_fused_taps(nv.ptr(wp), nv.ptr(ut), cout, cin, 0, nv.stream_ptr()), "pack_taps")
     assert torch.equal(ut, fused_bank(w))
-    cout2, cin2 = 64, 96                                                       # dgrad: output channels = cin2 (% 32), input = cout2 (% 16)
+    cout2, cin2 = 64, 128                                                      # dgrad: output channels = cin2 (% 64), input = cout2 (% 16)
     w2 = torch.randn((cout2, cin2, 3, 3), generator=gen).cuda()
     wp2 = w2.permute(2, 3, 0, 1).reshape(9, cout2, cin2).contiguous()
     ud = torch.full((16 * cout2 * cin2,), float("nan"), device="cuda")
@@ -104,10 +107,11 @@ def test_fused_bank_is_a_permutation_of_the_three_launch_bank():
     (300, 500, 64, 128, True, False),     # conv2_1: four chunks only
     (120, 200, 64, 64, True, True),       # conv1_2's channel shape, two cout blocks
     (9, 11, 256, 128, False, False),      # tiny, odd, no ReLU (negative values must survive)
-    (2, 2, 16, 32, True, True),           # a single tile, a single pooled pixel, one chunk, one cout block
+    (2, 2, 16, 64, True, True),           # a single tile, a single pooled pixel, one chunk, one cout block
     (1, 5, 32, 64, True, False),          # one row
-    (8, 32, 48, 96, False, True),         # exactly one block of tiles, three chunks, three cout blocks
-    (9, 33, 16, 32, True, False),         # one pixel more than a block in both directions
+    (4, 32, 48, 192, False, True),        # exactly one block of tiles, three chunks (odd), three cout blocks
+    (5, 33, 16, 64, True, False),         # one pixel more than a block in both directions
+    (38, 63, 1024, 1024, True, False),    # ResNet's RPN trunk: 64 chunks, 16 cout blocks on four XCD groups
 ])
 def test_layer_against_float64_direct_and_three_launch_form(h, w, cin, cout, relu, pool):
     gen = torch.Generator().manual_seed(h * 1000 + w + cin)
@@ -145,11 +149,11 @@ def test_zero_padding_and_locality():
     """A single non-zero input pixel only reaches its 3x3 output neighbourhood, at every image corner / block seam; the
     response equals the (flipped) filter taps up to the Winograd rounding."""
     gen = torch.Generator().manual_seed(11)
-    h, w, cin, cout = 19, 41, 16, 32
+    h, w, cin, cout = 19, 41, 16, 64
     wt = (torch.randn((cout, cin, 3, 3), generator=gen) * 0.2).cuda()
     b = torch.zeros((cout,), device="cuda")
     u = fused_bank(wt)
-    for (py, px) in [(0, 0), (0, 40), (18, 0), (18, 40), (7, 31), (8, 32), (9, 33), (3, 16)]:
+    for (py, px) in [(0, 0), (0, 40), (18, 0), (18, 40), (3, 31), (4, 32), (5, 33), (3, 16), (7, 0)]:
         x = torch.zeros((h, w, cin), device="cuda")
         x[py, px, 5] = 1.0
         y = run_fused(x, wt, b, False, False, u=u).cpu()
@@ -170,11 +174,11 @@ def test_unsupported_shapes_and_arguments():
     y = torch.zeros((8, 8, 64), device="cuda")
     s = nv.stream_ptr()
     assert lib.frcnn_conv3x3_nhwc_winograd_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 8, 8, 24, 64, 0, s) == -4    # cin % 16
-    assert lib.frcnn_conv3x3_nhwc_winograd_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 8, 8, 32, 48, 0, s) == -4    # cout % 32
+    assert lib.frcnn_conv3x3_nhwc_winograd_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 8, 8, 32, 96, 0, s) == -4    # cout % 64
     assert lib.frcnn_conv3x3_nhwc_winograd_fused(None, nv.ptr(u), nv.ptr(b), nv.ptr(y), 8, 8, 32, 64, 0, s) == -1
     assert lib.frcnn_conv3x3_nhwc_winograd_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, 8, 32, 64, nv.POOL2, s) == -1
     assert bool(lib.frcnn_conv3x3_uses_winograd_fused(64, 64)) and bool(lib.frcnn_conv3x3_uses_winograd_fused(512, 512))
     assert not lib.frcnn_conv3x3_uses_winograd_fused(3, 64) and not lib.frcnn_conv3x3_uses_winograd_fused(64, 48)
     for cin in (3, 16, 64, 120, 128, 1024):
-        for cout in (32, 64, 80, 96, 512):
+        for cout in (32, 64, 80, 96, 128, 512):
             assert bool(lib.frcnn_conv3x3_uses_winograd_fused(cin, cout)) == nv.uses_winograd_fused(cin, cout)
