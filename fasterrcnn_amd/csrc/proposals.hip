@@ -419,13 +419,16 @@ void nms_reduce_kernel(const u64* __restrict__ mask, int nw_stride, const int32_
             alive &= ~(1ull << b);
         }
         if (kept >= max_keep) break;
-        // OR the kept rows into removed[] for words > c, four independent rows per step
+        // OR the kept rows into removed[] for words > c.  The next chunk cannot be resolved before these loads are back, so as many
+        // of them as registers allow are in flight at once: 16 rows per step (one row per step was the kernel's latency chain:
+        // 300 kept boxes x ~1 us; four rows per step 84 us)
         u64 kb = keepbits;
         const bool wide = nw > 128;
+        constexpr int NR = 16;
         while (kb != 0ull) {
-            const u64* rows[4];
+            const u64* rows[NR];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NR; ++u) {
                 if (kb != 0ull) {
                     const int b = __ffsll((long long)kb) - 1;
                     kb &= kb - 1ull;
@@ -434,19 +437,33 @@ void nms_reduce_kernel(const u64* __restrict__ mask, int nw_stride, const int32_
                     rows[u] = nullptr;
                 }
             }
-            u64 v[4][4];
+            u64 v[NR][2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NR; ++u)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 2; ++q) {
                     const int w = lane + 64 * q;
-                    const bool need = rows[u] != nullptr && w > c && w < nw && (q < 2 || wide);
+                    const bool need = rows[u] != nullptr && w > c && w < nw;
                     v[u][q] = need ? rows[u][w] : 0ull;
                 }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NR; ++u)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rem[q] |= v[u][q];
+                for (int q = 0; q < 2; ++q) rem[q] |= v[u][q];
+            if (wide) {                                  // more than 8192 candidates: words 128 .. 255
+#pragma unroll
+                for (int u = 0; u < NR; ++u)
+#pragma unroll
+                    for (int q = 2; q < 4; ++q) {
+                        const int w = lane + 64 * q;
+                        const bool need = rows[u] != nullptr && w > c && w < nw;
+                        v[u][q - 2] = need ? rows[u][w] : 0ull;
+                    }
+#pragma unroll
+                for (int u = 0; u < NR; ++u)
+#pragma unroll
+                    for (int q = 2; q < 4; ++q) rem[q] |= v[u][q - 2];
+            }
         }
     }
     __syncthreads();
