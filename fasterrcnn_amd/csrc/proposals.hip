@@ -14,6 +14,7 @@
 //                                              nms_reduce_kernel (one wave: 64 boxes per step,
 //                                              readlane over the diagonal word, early exit)
 #include "common.h"
+#include <type_traits>
 
 namespace frcnn {
 
@@ -147,8 +148,8 @@ void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64* buf = reinterpret_cast<u64*>(smem_raw);                 // [sort_n]
-    int* hist = reinterpret_cast<int*>(buf + sort_n);            // [256]
-    int* misc = hist + 256;                                      // [64]
+    int* hist = reinterpret_cast<int*>(buf + sort_n);            // [4096]
+    int* misc = hist + 4096;                                     // [64]
     const int tid = threadIdx.x;
 
     // each thread keeps its keys (i = tid + 1024*it) in registers when they fit: the select reads them 8 times
@@ -161,6 +162,9 @@ void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_
         kreg[it] = (in_regs && i < n_keys) ? keys[i] : 0ull;
     }
 
+#ifdef TOPK_CLOCKS
+    unsigned long long tk[6]; tk[0] = __builtin_readcyclecounter();
+#endif
     // ---- how many keys are present ----------------------------------------------------------
     if (tid == 0) { misc[0] = 0; misc[1] = 0; }
     __syncthreads();
@@ -180,70 +184,96 @@ void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_
     const int want = present < K ? present : K;
     __syncthreads();
 
+#ifdef TOPK_CLOCKS
+    tk[1] = __builtin_readcyclecounter();
+#endif
     // ---- radix select: threshold = want-th largest key --------------------------------------
+    // 12-bit digits (4096 bins): four histogram passes over the 48 significant bits of an RPN key instead of six 8-bit ones, and
+    // the scores' clustered high bits spread over 16x more bins -- the LDS atomics of a pass serialise per address.
     u64 thr = 1ull;            // all present keys
     if (present > K) {
         u64 prefix = 0ull, pmask = 0ull;
         int remaining = K;
-        for (int byte = 7; byte >= 0; --byte) {
-            const int sh = byte * 8;
-            if (MODE == 0 && (byte == 3 || byte == 2) && n_keys < 65535) {   // index+1 < 2^16: digits are 0 in every key
-                pmask |= 255ull << sh;
-                continue;
-            }
-            for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+        const bool short_idx = MODE == 0 && n_keys < 65535;        // index + 1 < 2^16: bits 31..16 are 0 in every key
+        // digit d covers bits [sh, sh + bits)
+        const int nd = short_idx ? 5 : 6;
+        for (int d = 0; d < nd; ++d) {
+            int sh, bits;
+            if (short_idx) { sh = d == 0 ? 52 : d == 1 ? 40 : d == 2 ? 32 : d == 3 ? 4 : 0; bits = d == 2 ? 8 : d == 4 ? 4 : 12; }
+            else { sh = d == 0 ? 52 : d == 1 ? 40 : d == 2 ? 28 : d == 3 ? 16 : d == 4 ? 4 : 0; bits = d == 5 ? 4 : 12; }
+            const int nb = 1 << bits;
+            const u64 dmask = (u64)(nb - 1);
+            for (int i = tid; i < nb; i += 1024) hist[i] = 0;
             __syncthreads();
             if (in_regs) {
 #pragma unroll
                 for (int it = 0; it < KPT; ++it) {
                     const u64 k = kreg[it];
-                    if (k != 0ull && (k & pmask) == prefix) atomicAdd(&hist[(int)((k >> sh) & 255ull)], 1);
+                    if (k != 0ull && (k & pmask) == prefix) atomicAdd(&hist[(int)((k >> sh) & dmask)], 1);
                 }
             } else {
                 for (int i = tid; i < n_keys; i += 1024) {
                     const u64 k = keys[i];
-                    if (k != 0ull && (k & pmask) == prefix) atomicAdd(&hist[(int)((k >> sh) & 255ull)], 1);
+                    if (k != 0ull && (k & pmask) == prefix) atomicAdd(&hist[(int)((k >> sh) & dmask)], 1);
                 }
             }
             __syncthreads();
-            if (tid < 64) {
-                // lane l owns bins 255-4l .. 252-4l; suffix counts from the top digit down
-                const int top = 255 - 4 * tid;
-                const int h0 = hist[top], h1 = hist[top - 1], h2 = hist[top - 2], h3 = hist[top - 3];
+            {
+                // thread t owns bins top .. top - 3 (descending); block-wide inclusive scan of the counts from the top bin down
+                const int top = nb - 1 - 4 * tid;
+                const bool own = top >= 3;
+                const int h0 = own ? hist[top] : 0, h1 = own ? hist[top - 1] : 0, h2 = own ? hist[top - 2] : 0, h3 = own ? hist[top - 3] : 0;
                 const int sum = h0 + h1 + h2 + h3;
                 int incl = sum;
                 for (int o = 1; o < 64; o <<= 1) {
                     const int v = __shfl_up(incl, o);
-                    if (tid >= o) incl += v;
+                    if ((tid & 63) >= o) incl += v;
                 }
+                if ((tid & 63) == 63) misc[8 + (tid >> 6)] = incl;
+                __syncthreads();
+                int off = 0;
+                for (int wv = 0; wv < (tid >> 6); ++wv) off += misc[8 + wv];
+                incl += off;
                 const int excl = incl - sum;
-                if (excl < remaining && incl >= remaining) {       // exactly one lane
-                    int c = excl, d = top;
-                    if (c + h0 < remaining) { c += h0; d = top - 1;
-                        if (c + h1 < remaining) { c += h1; d = top - 2;
-                            if (c + h2 < remaining) { c += h2; d = top - 3; } } }
-                    misc[2] = d; misc[3] = remaining - c;
+                if (excl < remaining && incl >= remaining) {       // exactly one thread
+                    int c = excl, dg = top;
+                    if (c + h0 < remaining) { c += h0; dg = top - 1;
+                        if (c + h1 < remaining) { c += h1; dg = top - 2;
+                            if (c + h2 < remaining) { c += h2; dg = top - 3; } } }
+                    misc[2] = dg; misc[3] = remaining - c;
                 }
             }
             __syncthreads();
             prefix |= (u64)misc[2] << sh;
-            pmask |= 255ull << sh;
+            pmask |= dmask << sh;
             remaining = misc[3];
             __syncthreads();
         }
+        if (short_idx) pmask |= 0xFFFF0000ull;                      // (all zero)
         thr = prefix;
     }
 
+#ifdef TOPK_CLOCKS
+    tk[2] = __builtin_readcyclecounter();
+#endif
     // ---- gather survivors into LDS, pad, bitonic sort descending -----------------------------
     for (int i = tid; i < sort_n; i += 1024) buf[i] = 0ull;
     __syncthreads();
     if (in_regs) {
+        // one returning atomic per wave and round instead of one per survivor (6000 on one address); the order inside buf is
+        // irrelevant, it is sorted next
 #pragma unroll
         for (int it = 0; it < KPT; ++it) {
             const u64 k = kreg[it];
-            if (k != 0ull && k >= thr) {
-                const int pos = atomicAdd(&misc[1], 1);
-                if (pos < sort_n) buf[pos] = k;
+            const bool take = k != 0ull && k >= thr;
+            const unsigned long long m = __ballot(take);
+            if (m != 0ull) {
+                const int lead = __ffsll((long long)m) - 1;
+                int base = 0;
+                if ((tid & 63) == lead) base = atomicAdd(&misc[1], __popcll(m));
+                base = __shfl(base, lead);
+                const int pos = base + __popcll(m & ((1ull << (tid & 63)) - 1ull));
+                if (take && pos < sort_n) buf[pos] = k;
             }
         }
     } else {
@@ -256,6 +286,9 @@ void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_
         }
     }
     __syncthreads();
+#ifdef TOPK_CLOCKS
+    tk[3] = __builtin_readcyclecounter();
+#endif
     if (sort_n == 8192) {
         bitonic_sort_regs<8>(buf, tid);          // the 6000-of-20646 case: 81 of 91 sub-passes barrier-free
     } else if (sort_n == 16384) {
@@ -275,61 +308,125 @@ void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_
         }
     }
 
+#ifdef TOPK_CLOCKS
+    tk[4] = __builtin_readcyclecounter();
+#endif
     // ---- emit in rank order ------------------------------------------------------------------
-    // thread t owns ranks [t*per, (t+1)*per)
+    // thread t owns ranks [t*per, (t+1)*per).  With `per` a compile-time constant the box gathers of a thread are issued together
+    // and kept for the second pass (they were 2 x per dependent global round trips).
     const int per = sort_n >> 10 ? sort_n >> 10 : 1;
     int* wave_tot = misc + 8;     // [16]
-    int local = 0;
-    for (int q = 0; q < per; ++q) {
-        const int p = tid * per + q;
-        if (p < want && p < sort_n) {
-            const u64 k = buf[p];
-            const unsigned low = (unsigned)(k & 0xFFFFFFFFull);
+    int pos = 0;
+    auto emit = [&](auto perc) {
+        constexpr int PERC = decltype(perc)::value;
+        u64 kk[PERC];
+        f32x4 bb[PERC];
+        bool kp[PERC];
+        int local = 0;
+#pragma unroll
+        for (int q = 0; q < PERC; ++q) {
+            const int p = tid * PERC + q;
+            kp[q] = p < want && p < sort_n;
+            kk[q] = kp[q] ? buf[p] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < PERC; ++q) {
+            const unsigned low = (unsigned)(kk[q] & 0xFFFFFFFFull);
             const int idx = MODE == 0 ? (int)(low - 1u) : (int)(0xFFFFFFFFu - low);
-            if (sorted_idx) sorted_idx[p] = idx;
+            bb[q] = kp[q] ? boxes_src[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kp[q] && sorted_idx) sorted_idx[tid * PERC + q] = idx;
+        }
+#pragma unroll
+        for (int q = 0; q < PERC; ++q) {
             if (MODE == 0) {
-                f32x4 b = boxes_src[idx];
+                f32x4 b = bb[q];
                 b[0] = fmaxf(b[0], 0.f); b[1] = fmaxf(b[1], 0.f);
                 b[2] = fminf(b[2], image_h); b[3] = fminf(b[3], image_w);
-                const bool keep = ((b[2] - b[0]) >= min_side) && ((b[3] - b[1]) >= min_side);
-                local += keep;
-            } else {
-                local += 1;
+                bb[q] = b;
+                kp[q] = kp[q] && ((b[2] - b[0]) >= min_side) && ((b[3] - b[1]) >= min_side);
+            }
+            local += kp[q];
+        }
+        // block exclusive scan of `local`
+        int incl = local;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if ((tid & 63) >= o) incl += v;
+        }
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int wv = 0; wv < (tid >> 6); ++wv) wave_off += wave_tot[wv];
+        pos = wave_off + incl - local;
+#pragma unroll
+        for (int q = 0; q < PERC; ++q) {
+            if (kp[q]) {
+                cand_boxes[pos] = bb[q];
+                cand_scores[pos] = from_ordered_bits((unsigned)(kk[q] >> 32));
+                ++pos;
             }
         }
-    }
-    // block exclusive scan of `local`
-    int incl = local;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if ((tid & 63) >= o) incl += v;
-    }
-    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
-    __syncthreads();
-    int wave_off = 0;
-    for (int wv = 0; wv < (tid >> 6); ++wv) wave_off += wave_tot[wv];
-    int pos = wave_off + incl - local;
-    for (int q = 0; q < per; ++q) {
-        const int p = tid * per + q;
-        if (p < want && p < sort_n) {
-            const u64 k = buf[p];
-            const unsigned low = (unsigned)(k & 0xFFFFFFFFull);
-            const int idx = MODE == 0 ? (int)(low - 1u) : (int)(0xFFFFFFFFu - low);
-            f32x4 b = boxes_src[idx];
-            bool keep = true;
-            if (MODE == 0) {
-                b[0] = fmaxf(b[0], 0.f); b[1] = fmaxf(b[1], 0.f);
-                b[2] = fminf(b[2], image_h); b[3] = fminf(b[3], image_w);
-                keep = ((b[2] - b[0]) >= min_side) && ((b[3] - b[1]) >= min_side);
+    };
+    if (per == 8) {
+        emit(std::integral_constant<int, 8>());
+    } else if (per == 16) {
+        emit(std::integral_constant<int, 16>());
+    } else {
+        int local = 0;
+        for (int q = 0; q < per; ++q) {
+            const int p = tid * per + q;
+            if (p < want && p < sort_n) {
+                const u64 k = buf[p];
+                const unsigned low = (unsigned)(k & 0xFFFFFFFFull);
+                const int idx = MODE == 0 ? (int)(low - 1u) : (int)(0xFFFFFFFFu - low);
+                if (sorted_idx) sorted_idx[p] = idx;
+                if (MODE == 0) {
+                    f32x4 b = boxes_src[idx];
+                    b[0] = fmaxf(b[0], 0.f); b[1] = fmaxf(b[1], 0.f);
+                    b[2] = fminf(b[2], image_h); b[3] = fminf(b[3], image_w);
+                    const bool keep = ((b[2] - b[0]) >= min_side) && ((b[3] - b[1]) >= min_side);
+                    local += keep;
+                } else {
+                    local += 1;
+                }
             }
-            if (keep) {
-                cand_boxes[pos] = b;
-                cand_scores[pos] = from_ordered_bits((unsigned)(k >> 32));
-                ++pos;
+        }
+        int incl = local;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if ((tid & 63) >= o) incl += v;
+        }
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int wv = 0; wv < (tid >> 6); ++wv) wave_off += wave_tot[wv];
+        pos = wave_off + incl - local;
+        for (int q = 0; q < per; ++q) {
+            const int p = tid * per + q;
+            if (p < want && p < sort_n) {
+                const u64 k = buf[p];
+                const unsigned low = (unsigned)(k & 0xFFFFFFFFull);
+                const int idx = MODE == 0 ? (int)(low - 1u) : (int)(0xFFFFFFFFu - low);
+                f32x4 b = boxes_src[idx];
+                bool keep = true;
+                if (MODE == 0) {
+                    b[0] = fmaxf(b[0], 0.f); b[1] = fmaxf(b[1], 0.f);
+                    b[2] = fminf(b[2], image_h); b[3] = fminf(b[3], image_w);
+                    keep = ((b[2] - b[0]) >= min_side) && ((b[3] - b[1]) >= min_side);
+                }
+                if (keep) {
+                    cand_boxes[pos] = b;
+                    cand_scores[pos] = from_ordered_bits((unsigned)(k >> 32));
+                    ++pos;
+                }
             }
         }
     }
     if (tid == 1023) { counts[0] = want; counts[1] = pos; }
+#ifdef TOPK_CLOCKS
+    tk[5] = __builtin_readcyclecounter();
+    if (tid == 0 && n_keys > 20000) printf("topk cycles: load %llu  select %llu  gather %llu  sort %llu  emit %llu\n", tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4]);
+#endif
 }
 
 // IoU exactly as torchvision's nms kernels compute it (fp32, no +1, no epsilon):
@@ -515,12 +612,12 @@ static int launch_topk(const u64* keys, int n_keys, int K, const float* boxes_sr
 {
     const int sort_n = pow2_at_least(K);
     if (sort_n > 16384) return FRCNN_EUNSUPPORTED;
-    const size_t lds = (size_t)sort_n * 8 + 256 * 4 + 64 * 4;
+    const size_t lds = (size_t)sort_n * 8 + 4096 * 4 + 64 * 4;
     auto kern = topk_sort_kernel<MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + 2048));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + 4096 * 4 + 64 * 4));
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, s, keys, n_keys, K, sort_n,
