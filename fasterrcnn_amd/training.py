@@ -658,6 +658,15 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
     """
     global _GRAD_MATH
     _GRAD_MATH = nv.GRAD_MATHS[model.grad_math]
+    try:
+        return _train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_object_indices,
+                           gt_rpn_background_indices, gt_boxes, detail)
+    finally:
+        _GRAD_MATH = 0              # the module-level helpers (gemm_tn, conv3x3_wgrad, ...) default to float32 outside a step
+
+
+def _train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_object_indices,
+                gt_rpn_background_indices, gt_boxes, detail):
     model.train()
     assert image_data.shape[0] == 1, "Batch size must be 1"
     assert len(gt_rpn_map.shape) == 5 and gt_rpn_map.shape[0] == 1, "Batch size must be 1"
