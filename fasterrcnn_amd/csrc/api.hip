@@ -646,6 +646,9 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
     c->lin_ws_bytes = lin;
     c->conv_ws_bytes = cws;
     proposal_scratch_carve(c->ps, ps_base, c->a_cap, c->pre_cap, 2048);
+    // the padding rows of the activation record arrays (rows max_rois .. 319) are written by nobody afterwards
+    e = hipMemset(c->roi_rec, 0, (size_t)FRCNN_LINEAR_X6_ROWS * 49 * 512 * 6);
+    if (e != hipSuccess) { set_hip_error(e); hipFree(c->slab); delete c; return FRCNN_EHIP; }
     *out = c;
     return FRCNN_OK;
 }
@@ -861,16 +864,20 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
 
     // stage 3: detector (models/detector.py:65-80, models/vgg16.py:129-133)
     const int R_ = p->post_nms;
+    const bool fc_x6 = p->fc_math_mode == FRCNN_FC_F32X6;
+    if (fc_x6 && R_ > FRCNN_LINEAR_X6_ROWS) return FRCNN_EUNSUPPORTED;
     if (p->roi_op == FRCNN_ROI_ALIGN) {
         STEP(4, launch_roi_align(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, p->roi_sampling_ratio, 0, c->roi_out, s));
+        if (fc_x6) STEP(2, launch_split_rows_x6(c->roi_out, 49 * 512, c->roi_rec, R_, FRCNN_LINEAR_X6_ROWS, 49 * 512, s));
+    } else if (fc_x6) {
+        // RoIPool writes fc1's operand records itself (rows R_ .. 319 of the array were zeroed when the ctx was created)
+        STEP(4, launch_roi_pool_x6(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_rec, FRCNN_LINEAR_X6_ROWS, s));
     } else {
         STEP(4, launch_roi_pool(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
     }
-    if (p->fc_math_mode == FRCNN_FC_F32X6) {
-        // fc1 / fc2 on the bf16 pipe with exactly split operands: the RoI-pool output is split once, fc1's reduction emits the
-        // records fc2 consumes, fc2's the float32 rows the (exact-f32) heads consume
-        if (R_ > 320) return FRCNN_EUNSUPPORTED;
-        STEP(2, launch_split_rows_x6(c->roi_out, 49 * 512, c->roi_rec, R_, FRCNN_LINEAR_X6_ROWS, 49 * 512, s));
+    if (fc_x6) {
+        // fc1 / fc2 on the bf16 pipe with exactly split operands: fc1's reduction emits the records fc2 consumes, fc2's the float32
+        // rows the (exact-f32) heads consume
         STEP(2, launch_linear_x6(c->roi_rec, w->fc1_w, w->fc1_b, c->fc1_out, 4096, c->fc1_rec, R_, 4096, 49 * 512, R,
                                  c->lin_ws, c->lin_ws_bytes, s));
         STEP(2, launch_linear_x6(c->fc1_rec, w->fc2_w, w->fc2_b, c->fc2_out, 4096, nullptr, R_, 4096, 4096, R,

@@ -146,6 +146,8 @@ int launch_nms(const ProposalScratch& ps, const float* boxes, const float* score
 
 int launch_roi_pool(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
                     int max_rois, int pooled, float scale, float* out, hipStream_t s);
+int launch_roi_pool_x6(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
+                       int max_rois, int pooled, float scale, void* rec, int rec_rows, hipStream_t s);
 
 // roialign.hip
 int launch_roi_align(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois, int max_rois, int pooled,

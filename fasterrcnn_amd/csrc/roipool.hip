@@ -7,7 +7,7 @@
 //   roi_w = max(re_w - rs_w + 1, 1); bin = roi_w / pooled (float);
 //   bin window [floor(p*bin) + rs, ceil((p+1)*bin) + rs) clipped to the map; empty -> 0, else max.
 // The feature map is NHWC, so a bin-window pixel is one contiguous C-float run: the block
-// (roi, ph) sweeps it with float4 lanes (coalesced 2 KB rows for C = 512), output is
+// (roi, ph, pw) sweeps it with float4 lanes (coalesced 2 KB rows for C = 512), output is
 // [roi][ph][pw][C] which the repacked fc1 weight consumes directly (frcnn_pack_fc_chw_to_hwc).
 //
 // anchors_kernel replaces models/anchors.py:43-135 bit-exactly: float64 arithmetic on a
@@ -18,16 +18,53 @@
 
 namespace frcnn {
 
-__global__ __launch_bounds__(256)
+// One block per output bin (roi, ph, pw), one thread per 4 channels: 14,700 blocks of two waves for 300 RoIs.  The kernel is a
+// gather with a dependent max chain per thread (up to ~60 window pixels), i.e. latency bound: what pays is many waves in flight and
+// independent loads inside a thread (two partial maxima), not wide blocks -- one block per (roi, ph) that walked the 7 bins in
+// sequence with half of its 256 threads idle took 54 us for the 30 MB it writes.
+//
+// X6: instead of float32 rows the kernel emits the "x6 records" that csrc/linear_x6.hip multiplies (x = hi + mid + lo bf16, the
+// arithmetic of split_rows_x6_kernel, chunk-major [K/16][rec_rows][96 B] with K = pooled * pooled * C): the fused forward's fc1
+// then needs neither the 30 MB float32 round trip nor the split launch.
+__device__ __forceinline__ unsigned short rp_bf16_rne(float f)
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float rp_bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+template <bool X6>
+__global__ __launch_bounds__(128)
 void roi_pool_kernel(const float* __restrict__ fm, int fh, int fw, int C,
                      const float* __restrict__ rois, const int32_t* __restrict__ n_rois,
-                     int pooled, float scale, float* __restrict__ out)
+                     int pooled, float scale, float* __restrict__ out, int rec_rows)
 {
-    const int r = blockIdx.x, ph = blockIdx.y;
+    const int r = blockIdx.x, ph = blockIdx.y, pw = blockIdx.z;
     const int C4 = C >> 2;
-    f32x4* orow = reinterpret_cast<f32x4*>(out + ((size_t)(r * pooled + ph) * pooled) * C);
+    f32x4* obin = reinterpret_cast<f32x4*>(out + (((size_t)(r * pooled + ph) * pooled) + pw) * C);
+    auto emit = [&](int c4, const f32x4& m) {
+        if (!X6) { obin[c4] = m; return; }
+        unsigned short hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hi[j] = rp_bf16_rne(m[j]);
+            const float r1 = m[j] - rp_bf16_f32(hi[j]);
+            mid[j] = rp_bf16_rne(r1);
+            lo[j] = rp_bf16_rne(r1 - rp_bf16_f32(mid[j]));
+        }
+        const int k = ((ph * pooled) + pw) * C + 4 * c4;
+        unsigned char* p = reinterpret_cast<unsigned char*>(out) + ((size_t)(k >> 4) * rec_rows + r) * 96 + (k & 15) * 2;
+        uint2 ph_, pm_, pl_;
+        ph_.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16);   ph_.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
+        pm_.x = (unsigned)mid[0] | ((unsigned)mid[1] << 16); pm_.y = (unsigned)mid[2] | ((unsigned)mid[3] << 16);
+        pl_.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16);   pl_.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
+        *reinterpret_cast<uint2*>(p) = ph_;
+        *reinterpret_cast<uint2*>(p + 32) = pm_;
+        *reinterpret_cast<uint2*>(p + 64) = pl_;
+    };
     if (r >= *n_rois) {
-        for (int i = threadIdx.x; i < pooled * C4; i += 256) orow[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = threadIdx.x; i < C4; i += 128) emit(i, f32x4{0.f, 0.f, 0.f, 0.f});
         return;
     }
     const f32x4 roi = reinterpret_cast<const f32x4*>(rois)[r];     // y1, x1, y2, x2
@@ -38,23 +75,31 @@ void roi_pool_kernel(const float* __restrict__ fm, int fh, int fw, int C,
     int hs = (int)floorf((float)ph * bin_h) + rs_h;
     int he = (int)ceilf((float)(ph + 1) * bin_h) + rs_h;
     hs = min(max(hs, 0), fh); he = min(max(he, 0), fh);
-    for (int pw = 0; pw < pooled; ++pw) {
-        int ws = (int)floorf((float)pw * bin_w) + rs_w;
-        int we = (int)ceilf((float)(pw + 1) * bin_w) + rs_w;
-        ws = min(max(ws, 0), fw); we = min(max(we, 0), fw);
-        const bool empty = (he <= hs) || (we <= ws);
-        for (int c4 = threadIdx.x; c4 < C4; c4 += 256) {
-            f32x4 m = empty ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
-            for (int h = hs; h < he; ++h) {
-                const f32x4* p = reinterpret_cast<const f32x4*>(fm + ((size_t)h * fw + ws) * C) + c4;
-                for (int w = ws; w < we; ++w, p += C4) {
-                    const f32x4 v = *p;
+    int ws = (int)floorf((float)pw * bin_w) + rs_w;
+    int we = (int)ceilf((float)(pw + 1) * bin_w) + rs_w;
+    ws = min(max(ws, 0), fw); we = min(max(we, 0), fw);
+    const bool empty = (he <= hs) || (we <= ws);
+    for (int c4 = threadIdx.x; c4 < C4; c4 += 128) {
+        const f32x4 lowest = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+        f32x4 m0 = lowest, m1 = lowest;                // max is exact: the association does not matter
+        for (int h = hs; h < he; ++h) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(fm + ((size_t)h * fw + ws) * C) + c4;
+            int w = ws;
+            for (; w + 1 < we; w += 2, p += 2 * C4) {
+                const f32x4 v0 = p[0], v1 = p[C4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
-                }
+                for (int j = 0; j < 4; ++j) { m0[j] = v0[j] > m0[j] ? v0[j] : m0[j]; m1[j] = v1[j] > m1[j] ? v1[j] : m1[j]; }
             }
-            orow[pw * C4 + c4] = m;
+            if (w < we) {
+                const f32x4 v0 = p[0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m0[j] = v0[j] > m0[j] ? v0[j] : m0[j];
+            }
         }
+        f32x4 m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = empty ? 0.f : (m1[j] > m0[j] ? m1[j] : m0[j]);
+        emit(c4, m);
     }
 }
 
@@ -91,8 +136,19 @@ int launch_roi_pool(const float* fm, int fh, int fw, int c, const float* rois, c
                     int max_rois, int pooled, float scale, float* out, hipStream_t s)
 {
     if (fh < 1 || fw < 1 || c < 4 || c % 4 != 0 || max_rois < 1 || pooled < 1) return FRCNN_EINVAL;
-    hipLaunchKernelGGL(roi_pool_kernel, dim3(max_rois, pooled), dim3(256), 0, s, fm, fh, fw, c, rois,
-                       n_rois, pooled, scale, out);
+    hipLaunchKernelGGL(roi_pool_kernel<false>, dim3(max_rois, pooled, pooled), dim3(128), 0, s, fm, fh, fw, c, rois,
+                       n_rois, pooled, scale, out, 0);
+    return check_launch();
+}
+
+// the same pooling, output = the x6 record array of the [max_rois][pooled * pooled * c] matrix (rec_rows >= max_rois rows
+// allocated; the rows max_rois .. rec_rows-1 are the caller's to zero once); c % 16 == 0
+int launch_roi_pool_x6(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
+                       int max_rois, int pooled, float scale, void* rec, int rec_rows, hipStream_t s)
+{
+    if (fh < 1 || fw < 1 || c < 16 || c % 16 != 0 || max_rois < 1 || pooled < 1 || rec_rows < max_rois) return FRCNN_EINVAL;
+    hipLaunchKernelGGL(roi_pool_kernel<true>, dim3(max_rois, pooled, pooled), dim3(128), 0, s, fm, fh, fw, c, rois,
+                       n_rois, pooled, scale, static_cast<float*>(rec), rec_rows);
     return check_launch();
 }
 
