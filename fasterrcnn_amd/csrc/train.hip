@@ -305,56 +305,81 @@ __global__ __launch_bounds__(256)
 void roi_pool_argmax_kernel(const float* __restrict__ fm, int fh, int fw, int C, const float* __restrict__ rois,
                             int pooled, float scale, int32_t* __restrict__ argmax)
 {
-    const int r = blockIdx.x, ph = blockIdx.y;
+    const int r = blockIdx.x, ph = blockIdx.y, pw = blockIdx.z;      // one block per bin: the gather is latency bound (csrc/roipool.hip)
     const RoiGeom g = roi_geom(reinterpret_cast<const f32x4*>(rois)[r], scale, pooled);
-    int hs, he;
+    int hs, he, ws, we;
     bin_range(ph, g.bin_h, g.rs_h, fh, &hs, &he);
-    for (int pw = 0; pw < pooled; ++pw) {
-        int ws, we;
-        bin_range(pw, g.bin_w, g.rs_w, fw, &ws, &we);
-        for (int c = threadIdx.x; c < C; c += 256) {
-            float m = -FLT_MAX; int am = -1;
-            for (int h = hs; h < he; ++h)
-                for (int w = ws; w < we; ++w) {
-                    const float v = fm[((size_t)h * fw + w) * C + c];
-                    if (v > m) { m = v; am = h * fw + w; }
-                }
-            argmax[((size_t)(r * pooled + ph) * pooled + pw) * C + c] = am;
-        }
+    bin_range(pw, g.bin_w, g.rs_w, fw, &ws, &we);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float m = -FLT_MAX; int am = -1;
+        for (int h = hs; h < he; ++h)
+            for (int w = ws; w < we; ++w) {
+                const float v = fm[((size_t)h * fw + w) * C + c];
+                if (v > m) { m = v; am = h * fw + w; }
+            }
+        argmax[((size_t)(r * pooled + ph) * pooled + pw) * C + c] = am;
     }
 }
 
 // phase 2: one block per feature-map cell; RoIs ascending, bins in (ph, pw) order -> fixed summation order.
+// Which bins of which RoIs hold the cell is pure geometry, the same for every thread of the block: 64 RoIs at a time, one lane
+// per RoI works it out (a cell can sit in every bin of a RoI smaller than the 7 x 7 grid), an ordered compaction puts the
+// (roi, ph, pw) hits in LDS, and then all threads walk only the hits.  (Every thread evaluating all n_rois x 49 bin ranges
+// itself: 437 us for 128 RoIs on the 37 x 62 map.)
 __global__ __launch_bounds__(256)
 void roi_pool_scatter_kernel(const float* __restrict__ rois, int n_rois, int fh, int fw, int C, int pooled, float scale,
                              const int32_t* __restrict__ argmax, const float* __restrict__ dout,
                              float* __restrict__ dfm, int accumulate)
 {
+    __shared__ int hits[64 * 49];
+    __shared__ int n_hits;
     const int cell = blockIdx.x;
     const int h = cell / fw, w = cell - h * fw;
+    const int tid = threadIdx.x;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};          // channels tid, tid+256, ... (C <= 1024)
-    for (int r = 0; r < n_rois; ++r) {
-        const RoiGeom g = roi_geom(reinterpret_cast<const f32x4*>(rois)[r], scale, pooled);
-        for (int ph = 0; ph < pooled; ++ph) {
-            int hs, he;
-            bin_range(ph, g.bin_h, g.rs_h, fh, &hs, &he);
-            if (h < hs || h >= he) continue;
-            for (int pw = 0; pw < pooled; ++pw) {
-                int ws, we;
-                bin_range(pw, g.bin_w, g.rs_w, fw, &ws, &we);
-                if (w < ws || w >= we) continue;
-                const size_t base = ((size_t)(r * pooled + ph) * pooled + pw) * C;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int c = threadIdx.x + 256 * k;
-                    if (c < C && argmax[base + c] == cell) acc[k] += dout[base + c];
+    for (int r0 = 0; r0 < n_rois; r0 += 64) {
+        if (tid < 64) {
+            const int r = r0 + tid;
+            unsigned phm = 0u, pwm = 0u;           // bins (pooled <= 7) whose range holds the cell's row / column
+            if (r < n_rois) {
+                const RoiGeom g = roi_geom(reinterpret_cast<const f32x4*>(rois)[r], scale, pooled);
+                for (int p = 0; p < pooled; ++p) {
+                    int s0, e0;
+                    bin_range(p, g.bin_h, g.rs_h, fh, &s0, &e0);
+                    if (h >= s0 && h < e0) phm |= 1u << p;
+                    bin_range(p, g.bin_w, g.rs_w, fw, &s0, &e0);
+                    if (w >= s0 && w < e0) pwm |= 1u << p;
                 }
             }
+            const int mine = __popc(phm) * __popc(pwm);
+            int incl = mine;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (tid >= o) incl += v;
+            }
+            int at = incl - mine;
+            for (unsigned a = phm; a != 0u; a &= a - 1u) {
+                const int ph = __ffs((int)a) - 1;
+                for (unsigned b2 = pwm; b2 != 0u; b2 &= b2 - 1u) hits[at++] = (r * pooled + ph) * pooled + (__ffs((int)b2) - 1);
+            }
+            if (tid == 63) n_hits = incl;
         }
+        __syncthreads();
+        const int nh = n_hits;
+#pragma unroll 2
+        for (int i = 0; i < nh; ++i) {
+            const size_t base = (size_t)hits[i] * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = tid + 256 * k;
+                if (c < C && argmax[base + c] == cell) acc[k] += dout[base + c];
+            }
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int c = threadIdx.x + 256 * k;
+        const int c = tid + 256 * k;
         if (c < C) {
             float* o = dfm + (size_t)cell * C + c;
             *o = accumulate ? *o + acc[k] : acc[k];
@@ -542,11 +567,11 @@ int launch_roi_pool_backward(const float* fm, int fh, int fw, int C, const float
                              float scale, const float* dout, float* dfm, int accumulate, void* ws, size_t ws_bytes,
                              hipStream_t s)
 {
-    if (fh < 1 || fw < 1 || C < 1 || C > 1024 || n_rois < 0 || pooled < 1) return FRCNN_EINVAL;
+    if (fh < 1 || fw < 1 || C < 1 || C > 1024 || n_rois < 0 || pooled < 1 || pooled > 7) return FRCNN_EINVAL;   // hit list: 64 RoIs x 49 bins
     if (n_rois > 0 && (!ws || ws_bytes < roi_pool_backward_workspace_bytes(n_rois, pooled, C))) return FRCNN_EINVAL;
     int32_t* argmax = static_cast<int32_t*>(ws);
     if (n_rois > 0) {
-        hipLaunchKernelGGL(roi_pool_argmax_kernel, dim3(n_rois, pooled), dim3(256), 0, s, fm, fh, fw, C, rois, pooled,
+        hipLaunchKernelGGL(roi_pool_argmax_kernel, dim3(n_rois, pooled, pooled), dim3(256), 0, s, fm, fh, fw, C, rois, pooled,
                            scale, argmax);
         int rc = check_launch();
         if (rc) return rc;
