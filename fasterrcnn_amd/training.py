@@ -282,6 +282,7 @@ class VGG16TrainState(TrainState):
             raise NotImplementedError("dropout > 0 is not implemented in the train step (reference default: 0.0)")
         # clones: the inference-side packed caches are rebuilt from the parameters, these are the training masters
         self.conv = fe.packed_direct()
+        self._frozen_banks = {}                # one-launch Winograd banks of the frozen layers (their weights never change here)
         w1p, b1, w2, b2 = pv.packed_direct()      # float32 masters whatever arithmetic inference uses for fc1 / fc2
         self.fc1, self.fc1_b, self.fc2, self.fc2_b = w1p, b1.clone(), w2.clone(), b2.clone()
 
@@ -324,7 +325,13 @@ class VGG16TrainState(TrainState):
                 y_out[i] = y
                 cur = maxpool2x2(y) if pool else y
             else:
-                cur = vgg16.conv3x3(cur, wp, b, cin, cout, relu=True, pool=pool)      # frozen: pool fused
+                # frozen (vgg16.py:49-58): pool fused; in the f32_winograd mode the same one-launch Winograd layer as inference,
+                # its bank built once (conv1_2, conv2_1, conv2_2: 0.91 ms of direct convolutions -> 0.47 ms)
+                if self.winograd and nv.uses_winograd_fused(cin, cout):
+                    if i not in self._frozen_banks:
+                        self._frozen_banks[i] = winograd_bank(wp, cout, cin)
+                    wp = self._frozen_banks[i]
+                cur = vgg16.conv3x3(cur, wp, b, cin, cout, relu=True, pool=pool)
         return cur, (x_in, y_out)
 
     def features_backward(self, g, saved, grads):
