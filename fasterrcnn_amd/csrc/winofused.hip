@@ -490,8 +490,9 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
 // ---- host side ------------------------------------------------------------------------------------------------------------
 bool conv3x3_winograd_fused_ok(int H, int W, int cin, int cout)
 {
+    // the buffer descriptors' sizes and every byte offset inside them are 32-bit quantities computed in int
     return H >= 1 && W >= 1 && cin >= 16 && cin % 16 == 0 && cout >= WF_BN && cout % WF_BN == 0 &&
-           (size_t)H * W * cin * sizeof(float) < ((size_t)1 << 32);
+           (size_t)H * W * cin * sizeof(float) < ((size_t)1 << 31) && (size_t)16 * cin * cout * sizeof(float) < ((size_t)1 << 31);
 }
 
 int launch_pack_conv3x3_winograd_fused(const float* w, const float* scale, float* u, int cout, int cin, hipStream_t s)

@@ -166,7 +166,7 @@ int frcnn_conv3x3_nhwc_winograd(const float* d_x, const float* d_u, const float*
  * (v_mfma_f32_16x16x4_f32; the position rows are split over wave pairs); the input transform B^T d B is evaluated on the LDS-staged halo when the operand is formed
  * (same float32 operation order as the three-launch form), the output transform A^T M A + bias + ReLU + optional
  * 2x2 max-pool runs on the accumulators.  HBM traffic of a layer = its input, filter bank and output, so the form pays for
- * every 3x3 stride-1 layer with cin % 16 == 0 and cout % 64 == 0 (FRCNN_EUNSUPPORTED otherwise; H*W*cin*4 < 2^32).
+ * every 3x3 stride-1 layer with cin % 16 == 0 and cout % 64 == 0 (FRCNN_EUNSUPPORTED otherwise; H*W*cin*4 and 64*cin*cout < 2^31).
  *   d_u : float32 [cin/16][cout/64][16][64][16] (the 16 positions in the kernel's slab order) from frcnn_pack_conv3x3_winograd_fused (OIHW in; optional per-cout
  *         d_row_scale as above) or frcnn_pack_conv3x3_winograd_fused_taps (tap-major [9][cout][cin] in; data_gradient = 1
  *         packs the bank of the data-gradient convolution cout -> cin channels).  16*cout*cin floats, the values of
