@@ -47,7 +47,7 @@ _MFMA_CONVS = [(64, 64, 600, 1000), (64, 128, 300, 500), (128, 128, 300, 500), (
 
 
 def uses_winograd(cin, cout):       # fasterrcnn_amd/_native.py uses_winograd_fused: every single-map 3x3 layer from conv1_2 on
-    return cin >= 64 and cin % 16 == 0 and cout >= 64 and cout % 32 == 0
+    return cin >= 64 and cin % 16 == 0 and cout >= 64 and cout % 64 == 0
 
 
 def conv_mfma_flops_per_image():
@@ -65,7 +65,7 @@ def winograd_layers(math):
 
 def winograd_gemm_flops(ci, co, h, w):
     """FLOP the matrix pipe executes for one Winograd F(2x2,3x3) layer: 16 positions x tiles x cin x cout x 2 (tiles = the image's
-    ceil(h/2) x ceil(w/2); the padding of the kernel's 4 x 16-tile blocks is NOT counted -- it is waste, not work)."""
+    ceil(h/2) x ceil(w/2); the padding of the kernel's 2 x 16-tile blocks is NOT counted -- it is waste, not work)."""
     return 2.0 * 16 * ((h + 1) // 2) * ((w + 1) // 2) * ci * co
 
 

@@ -83,7 +83,7 @@ def main():
         oh, ow = (h // 2, w // 2) if pool else (h, w)
         y = torch.empty((oh, ow, cout), device=dev)
         wino = args.winograd and cout % 128 == 0
-        fused = args.fused and cout % 32 == 0 and cin % 16 == 0
+        fused = args.fused and cout % 64 == 0 and cin % 16 == 0
         if fused:
             w_oihw = torch.randn((cout, cin, 3, 3), device=dev) * 0.02
             wf = torch.empty((16 * cout * cin,), device=dev)
