@@ -9,7 +9,12 @@ A "step" is one `predict()` of one synthetic, already-preprocessed float32 3x600
 resident in HBM when the timed region starts: VGG-16 backbone, RPN (6000 pre- / 300 post-NMS),
 RoI pooling, FC head, on-device float64 decode + per-class NMS, one D2H copy of the detections.
 Every image is an independent batch-1 forward (BASELINE.json configs[1]); `--inflight` of them (default 3)
-are in flight on separate HIP streams (GPU_MAX_HW_QUEUES=16 unless the environment says otherwise).  fp32 end to end (the reference's dtype), exact-f32 MFMA.
+are in flight on separate HIP streams (GPU_MAX_HW_QUEUES=16 unless the environment says otherwise).  float32 tensors end to end (the
+reference's dtype).  WHICH matrix pipe every GEMM-shaped layer runs on is part of the JSON line (`layer_arithmetic`, `fc_math`,
+`f32_pipe_tflops`, `bf16_pipe_tflops`): the 3x3 convolutions on the exact-f32 MFMA pipe as one-launch Winograd F(2x2,3x3) layers
+(`math`), fc1 / fc2 by default in the "f32x6" arithmetic -- every f32 operand split exactly into three bf16 terms, six bf16 MFMAs
+per product, f32 accumulation, dropped terms <= 2^-24 relative (fp32-class accuracy, tests/test_linear_x6_gpu.py) -- and the 1x1 / head
+GEMMs on the exact-f32 pipe.  `fc_math_f32_images_per_sec` is the same workload with fc1 / fc2 on the exact-f32 pipe as well.
 
 Multi-GPU: image-parallel, rank r owns its own images, no data-path collective; weak scaling
 (K steps per rank).  The mAP@0.5 bookkeeping runs after the timed region on a small labelled
@@ -38,6 +43,7 @@ import torch.distributed as dist   # noqa: E402
 
 H, W = 600, 1000
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # same table, "Peak BF16/FP16 MFMA" dense (never the 2:1-sparsity figure)
 
 # (cin, cout, h, w) of the 3x3 convolutions that run on the MFMA kernel (conv1_1 is the VALU kernel)
 _MFMA_CONVS = [(64, 64, 600, 1000), (64, 128, 300, 500), (128, 128, 300, 500), (128, 256, 150, 250),
@@ -69,13 +75,50 @@ def winograd_gemm_flops(ci, co, h, w):
     return 2.0 * 16 * ((h + 1) // 2) * ((w + 1) // 2) * ci * co
 
 
-def executed_mfma_flops_per_image(math, n_rois=300):
-    """Matrix-pipe FLOP actually executed per image (Winograd layers count their GEMM FLOP, not the direct-form FLOP)."""
-    conv = sum(2.0 * 9 * ci * co * h * w for ci, co, h, w in direct_layers(math))
-    wino = sum(winograd_gemm_flops(*l) for l in winograd_layers(math))
-    rpn_heads = 2.0 * 512 * 45 * 37 * 62
-    det = n_rois * 2.0 * (25088 * 4096 + 4096 * 4096 + 4096 * 101)
-    return conv + wino + rpn_heads + det
+_CONV_NAMES = ["conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2",
+               "conv5_3", "rpn_trunk"]
+
+
+def layer_arithmetic(math, fc_math, n_rois=300, num_classes=21):
+    """One row per GEMM-shaped layer of one image: which kernel family and WHICH matrix pipe it runs on, the FLOP that pipe executes
+    for it and the algorithmic (direct-form) FLOP it stands for.  Winograd layers execute 16 x tiles x cin x cout x 2; an "x6" layer
+    executes six bf16 MFMAs per algorithmic product."""
+    rows = []
+    for name, (ci, co, h, w) in zip(_CONV_NAMES, _MFMA_CONVS):
+        alg = 2.0 * 9 * ci * co * h * w
+        if math == "f32_winograd" and uses_winograd(ci, co):
+            rows.append((name, "wino_fused_kernel", "f32", winograd_gemm_flops(ci, co, h, w), alg))
+        elif math == "f32x6":
+            rows.append((name, "conv3x3_x6_kernel", "bf16", 6.0 * alg, alg))
+        else:
+            rows.append((name, "conv3x3_mfma_kernel", "f32", alg, alg))
+    alg = 2.0 * 512 * 45 * 37 * 62
+    rows.append(("rpn_heads_1x1", "linear_mfma_kernel", "f32", alg, alg))
+    for name, k, n in (("fc1", 25088, 4096), ("fc2", 4096, 4096)):
+        alg = n_rois * 2.0 * k * n
+        if fc_math == "f32x6":
+            rows.append((name, "linear_x6_kernel", "bf16", 6.0 * alg, alg))
+        else:
+            rows.append((name, "linear_mfma_kernel", "f32", alg, alg))
+    alg = n_rois * 2.0 * 4096 * (5 * num_classes - 4)
+    rows.append(("detector_heads", "linear_mfma_kernel", "f32", alg, alg))
+    return rows
+
+
+def pipe_flops_per_image(math, fc_math, backbone_only=False):
+    """{"f32": FLOP the exact-f32 matrix pipe executes per image, "bf16": FLOP the bf16 matrix pipe executes per image}."""
+    out = {"f32": 0.0, "bf16": 0.0}
+    for name, _, pipe, ex, _ in layer_arithmetic(math, fc_math):
+        if backbone_only and not name.startswith("conv"):
+            continue
+        out[pipe] += ex
+    return out
+
+
+def executed_mfma_flops_per_image(math, fc_math="f32"):
+    """Matrix-pipe FLOP executed per image, both pipes added (kept for continuity with rounds 1-2; the per-pipe figures are the meaningful ones)."""
+    f = pipe_flops_per_image(math, fc_math)
+    return f["f32"] + f["bf16"]
 
 
 def total_flops_per_image(n_rois=300):
@@ -262,6 +305,30 @@ def planted_ground_truth(seed, det, num_classes=21):
     return boxes
 
 
+def launcher_command(gpus, argv, environ=None):
+    """(command, environment) that re-runs this file as `gpus` ranks of ONE node under torch.distributed.run -- exactly the form the
+    driver uses for N > 1 (docstring above): rendezvous on 127.0.0.1 (the container hostname may not resolve), a free port, the
+    caller's flags passed through.  The environment adds what a multi-process GPU job needs on this stack: dmabuf IPC for RCCL
+    (HSA_ENABLE_IPC_MODE_LEGACY=0) and the HIP hardware-queue count of the in-flight streams."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(gpus)),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ if environ is None else environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GPU_MAX_HW_QUEUES", "16")
+    return cmd, env
+
+
+def rank_environment(environ=None):
+    """(rank, local_rank, world) as torch.distributed.run exports them; a plain `python bench.py` is rank 0 of 1.  LOCAL_RANK is the
+    HIP device index of the rank (one process per GPU)."""
+    e = os.environ if environ is None else environ
+    return int(e.get("RANK", "0")), int(e.get("LOCAL_RANK", "0")), int(e.get("WORLD_SIZE", "1"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,19 +361,12 @@ def main():
                     help="vgg16 is the BASELINE.json metric; the ResNets are informational (configs[2])")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = rank_environment()
     if world == 1 and args.gpus > 1:
         # started without a launcher: re-run under torch.distributed.run, one rank per GPU (the form the docstring shows)
-        import socket
         import subprocess
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
+        cmd, env = launcher_command(args.gpus, sys.argv[1:])
+        sys.exit(subprocess.call(cmd, env=env))
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -389,6 +449,19 @@ def main():
     run(max(args.warmup, nslots))
     elapsed, bursts = timed_median(run, args.steps, args.min_timed_seconds)
     value = n_gpus * args.steps / elapsed
+    # per-rank view of the same timed region (each rank's own wall time of its median burst is not kept: the burst time is already the
+    # max over ranks; what differs per rank is its LOCAL burst, measured here without the barrier), gathered for the JSON line
+    torch.cuda.synchronize(dev)
+    t_loc = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize(dev)
+    local_ips = args.steps / (time.perf_counter() - t_loc)
+    per_rank = [round(local_ips, 3)]
+    if use_dist:
+        tt = torch.zeros(world, dtype=torch.float64, device=dev)
+        tt[rank] = local_ips
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        per_rank = [round(float(v), 3) for v in tt.tolist()]
 
     # clocks / power under the headline load (rocm-smi sampled in the middle of one more, untimed, second of the same load)
     smi = None
@@ -406,6 +479,16 @@ def main():
             dt, _ = timed_median(run, args.steps, min(args.min_timed_seconds, 0.5))
             secondary[mode] = round(n_gpus * args.steps / dt, 3)
         model.math_mode = args.math
+    fc_math = model.fc_math_mode
+    fc_f32_value = None
+    if not is_resnet and not args.no_secondary and fc_math != "f32":
+        # the same workload with fc1 / fc2 on the exact-f32 pipe too: every GEMM of the image on v_mfma_f32_*_f32
+        model.fc_math_mode = "f32"
+        run(max(args.warmup, nslots))
+        dt, _ = timed_median(run, args.steps, min(args.min_timed_seconds, 0.5))
+        fc_f32_value = round(n_gpus * args.steps / dt, 3)
+        model.fc_math_mode = fc_math
+        run(nslots)
 
     # ---- driver-timed secondary legs (rank 0 of a one-GPU run; none of them is the headline value) -------------------
     extra = {}
@@ -538,13 +621,34 @@ def main():
         if is_resnet:
             roofline = {"note": "roofline block is defined for the VGG-16 headline workload only",
                         "per_class_ms_per_image": roofline["per_class_ms_per_image"]}
+        pipes = {}
+        if not is_resnet:
+            ips = value / n_gpus
+            pf = pipe_flops_per_image(args.math, fc_math)
+            pb = pipe_flops_per_image(args.math, fc_math, backbone_only=True)
+            f32_tf, bf16_tf = ips * pf["f32"] / 1e12, ips * pf["bf16"] / 1e12
+            pipes = {
+                "layer_arithmetic": [{"layer": n_, "kernel": k_, "pipe": p_, "executed_gflop": round(e_ / 1e9, 3), "algorithmic_gflop": round(a_ / 1e9, 3)}
+                                     for n_, k_, p_, e_, a_ in layer_arithmetic(args.math, fc_math)],
+                "f32_pipe_tflops": round(f32_tf, 2), "f32_pipe_frac": round(f32_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                "bf16_pipe_tflops": round(bf16_tf, 2), "bf16_pipe_frac": round(bf16_tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                "pipe_note": "FLOP each matrix pipe EXECUTES per image x images/sec per GPU, over that pipe's dense peak (157.3 / 2500 TFLOP/s); "
+                             "the two pipes share the SIMDs' MFMA issue, so the fractions add up to the matrix-unit busy fraction the workload needs at peak rate",
+                # "fraction of conv roofline" = backbone(+RPN trunk) 3x3 conv FLOP x images/sec / MFMA peak, per pipe
+                "conv_roofline_frac": round(ips * pb["f32"] / 1e12 / PEAK_F32_MFMA_TFLOPS + ips * pb["bf16"] / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                "conv_roofline_note": "EXECUTED 3x3-conv FLOP (conv1_2 .. conv5_3 + RPN trunk; Winograd layers count 16 x tiles x cin x cout x 2) x images/sec "
+                                      "per GPU / the peak of the pipe each layer runs on, summed; direct-form FLOP (3.75e11 per image) would give %.4f of the f32 peak"
+                                      % (ips * conv_mfma_flops_per_image() / 1e12 / PEAK_F32_MFMA_TFLOPS),
+                "mfma_tflops_executed_per_gpu": round(f32_tf + bf16_tf, 2),
+                "mfma_tflops_executed_note": "sum over BOTH pipes (kept for continuity with rounds 1-2); read f32_pipe_tflops / bf16_pipe_tflops instead",
+            }
         out = {
             "metric": "images/sec (600x1000) Faster-RCNN %s inference" % ("VGG-16" if not is_resnet else args.backbone), "value": round(value, 3),
             "unit": "images/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ramp_seconds": args.ramp_seconds,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "timed_bursts": {"count": len(bursts), "reported": "median burst of `steps` steps", "min_ms": round(1e3 * min(bursts), 3),
                              "max_ms": round(1e3 * max(bursts), 3), "total_timed_s": round(sum(bursts), 3)},
-            "rocm_smi_under_load": smi, "process_group": ("nccl x%d" % world) if use_dist else None, "higher_is_better": True, "scaling": "weak",
+            "rocm_smi_under_load": smi, "process_group": ("nccl x%d" % world) if use_dist else None, "world_size": world, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("VGG-16" if not is_resnet else args.backbone) + " Faster R-CNN predict(), 3x600x1000 float32, batch=1 per forward, "
                                    "6000 pre-/300 post-NMS proposals, score_threshold 0.05",
@@ -552,11 +656,16 @@ def main():
                        "flops_per_image": flops_img},
             "tflops_per_gpu": round(value / n_gpus * flops_img / 1e12, 2),
             "tflops_per_gpu_note": "direct-convolution FLOP of the workload x images/sec (BASELINE.md's 4.4922e11 per image); "
-                                   "in the f32_winograd mode the matrix pipe executes fewer: see mfma_tflops_executed_per_gpu",
-            "mfma_tflops_executed_per_gpu": None if is_resnet else round(value / n_gpus * executed_mfma_flops_per_image(args.math) / 1e12, 2),
-            "math": args.math, "other_math_modes_images_per_sec": secondary,
+                                   "in the f32_winograd mode the matrix pipes execute fewer: see f32_pipe_tflops / bf16_pipe_tflops",
+            "math": args.math, "fc_math": None if is_resnet else fc_math, "roi": model._stage3_detector_network.pooling,
+            "other_math_modes_images_per_sec": secondary, "fc_math_f32_images_per_sec": fc_f32_value,
+            "per_rank_images_per_sec": per_rank, "slowest_rank_images_per_sec": min(per_rank),
+            **pipes,
             **extra,
             "map_at_0.5": mean_ap, "map_images": int(args.map_images * world),
+            "map_note": "plumbing check, not accuracy: random-init weights; the ground truth of each labelled image is seeded random boxes plus up "
+                        "to 3 of the model's OWN top detections jittered by a few pixels, so the value only shows that predict -> per-image "
+                        "records -> (all-gather) -> AP integration runs end to end and is reproducible; README.md:38's mAP needs trained weights",
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

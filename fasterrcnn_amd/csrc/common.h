@@ -28,6 +28,28 @@ inline int check_launch() {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE attribute: one flag per (kernel instantiation, device), so that a
+// process which moves a model to a second GPU (`model.cuda(1)`) raises the limit there too (a process-wide flag left the
+// > 64 KB launches of the second device at the default limit).  `once` is a function-local static of the launcher.
+struct DeviceOnce { unsigned char done[64]; };
+inline int set_max_dynamic_lds(DeviceOnce& once, const void* kern, size_t bytes)
+{
+    int dev = 0;
+    FRCNN_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return FRCNN_EINVAL;
+    if (!once.done[dev]) {
+        FRCNN_HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        once.done[dev] = 1;
+    }
+    return FRCNN_OK;
+}
+#define FRCNN_MAX_LDS_ONCE(kern, bytes)                                                                  \
+    do {                                                                                                 \
+        static ::frcnn::DeviceOnce _once = {};                                                           \
+        const int _rc = ::frcnn::set_max_dynamic_lds(_once, reinterpret_cast<const void*>(kern), (bytes)); \
+        if (_rc) return _rc;                                                                             \
+    } while (0)
+
 // 3x3 layers that run as Winograd F(2x2,3x3) in math mode FRCNN_MATH_F32_WINOGRAD (VGG-16: conv3_1 ... conv5_3 and the RPN trunk)
 static inline bool conv3x3_uses_winograd(int cin, int cout) { return cin >= 128 && cout >= 256 && cin % 16 == 0 && cout % 128 == 0; }
 // ResNet bottlenecks (3x3 width -> width): the stride-1 blocks of layer3 (width 256, one 38 x 63 map) and layer4 (width 512,

@@ -486,12 +486,7 @@ static int launch_cfg(const float* x, const float* wp, const float* b, float* y,
     const int nchunks = cin / 16;
     dim3 grid(cdiv(W, 32), cdiv(H, C::TR), cout_tiles * ksplit);
     auto kern = conv3x3_mfma_kernel<WM, WN, POOL>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
-    }
+    FRCNN_MAX_LDS_ONCE(kern, C::LDS_BYTES);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, x, wp, b, y, H, W, cin, cout, relu, cout_tiles,
                        cdiv(nchunks, ksplit), ksplit > 1 ? ws : (float*)nullptr);
     return check_launch();

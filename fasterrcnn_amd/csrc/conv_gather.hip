@@ -415,12 +415,7 @@ static int launch_gather_cfg(const GatherPlan& p, const float* x, const float* w
 {
     using C = GatherCfg<TM, TN, WM, WN>;
     auto kern = conv_gather_mfma_kernel<TM, TN, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
-    }
+    FRCNN_MAX_LDS_ONCE(kern, C::LDS_BYTES);
     dim3 grid(p.nblocks, p.mblocks, p.splits);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, x, wp, bias, residual, y, ws, g, p.stages_per_split, relu);
     return check_launch();

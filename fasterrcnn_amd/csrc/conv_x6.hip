@@ -555,12 +555,7 @@ static int launch_x6_cfg(const float* x, const void* wq, const float* b, float* 
 {
     using C = X6Cfg<WM, WN, MT>;
     auto kern = conv3x3_x6_kernel<WM, WN, MT, POOL>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
-    }
+    FRCNN_MAX_LDS_ONCE(kern, C::LDS_BYTES);
     const int cout_tiles = cout / C::BN;
     const int nchunks = cin / 16;
     dim3 grid(cdiv(W, 32), cdiv(H, C::TR), cout_tiles * ksplit);
@@ -576,11 +571,7 @@ static int launch_x6p(const float* x, const void* wq, const float* b, float* y, 
     using C = X6Cfg<2, 2, 2>;
     constexpr size_t lds = (size_t)2 * C::HALO_B + 2 * C::WT_B;
     auto kern = conv3x3_x6p_kernel<POOL>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    FRCNN_MAX_LDS_ONCE(kern, lds);
     const int cout_tiles = cout / C::BN;
     const int nchunks = cin / 16;
     dim3 grid(cdiv(W, 32), cdiv(H, C::TR), cout_tiles * ksplit);

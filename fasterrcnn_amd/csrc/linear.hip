@@ -360,12 +360,7 @@ static int launch_linear_cfg(const LinearPlan& p, const float* a, int lda, const
 {
     using C = GemmCfg<TM, TN, WM, WN>;
     auto kern = linear_mfma_kernel<TM, TN, WM, WN, false>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
-    }
+    FRCNN_MAX_LDS_ONCE(kern, C::LDS_BYTES);
     dim3 grid(p.nblocks, p.mblocks, p.splits);
     hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), C::LDS_BYTES, s, a, lda, w, bias, y, ldy, ws, M, N, K,
                        p.stages_per_split, relu, BatchGeom{0, 0, 0, 0, 0, 0});
@@ -378,12 +373,7 @@ static int launch_linear_batched_cfg(const float* a, int lda, const float* w, fl
 {
     using C = GemmCfg<TM, TN, WM, WN>;
     auto kern = linear_mfma_kernel<TM, TN, WM, WN, true, NSETS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
-    }
+    FRCNN_MAX_LDS_ONCE(kern, C::LDS_BYTES);
     const long long total = (long long)bg.nblocks * bg.mblocks * bg.batches;
     if (total < 1 || total > 0x7fffffffLL) return FRCNN_EINVAL;
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(C::THREADS), C::LDS_BYTES, s, a, lda, w,

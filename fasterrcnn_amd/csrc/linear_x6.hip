@@ -349,12 +349,7 @@ int launch_linear_x6(const void* a_rec, const void* w_rec, const float* bias, fl
         return FRCNN_EINVAL;
     const LxPlan p = plan_linear_x6(N, K);
     if (ws == nullptr || ws_bytes < (size_t)p.splits * M * N * sizeof(float)) return FRCNN_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_x6_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LX_LDS_BYTES));
-        attr_set = true;
-    }
+    FRCNN_MAX_LDS_ONCE(linear_x6_kernel, LX_LDS_BYTES);
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
     hipLaunchKernelGGL(linear_x6_kernel, dim3(p.nblocks, 1, p.splits), dim3(LX_THREADS), LX_LDS_BYTES, s,
                        static_cast<const unsigned char*>(a_rec), static_cast<const unsigned char*>(w_rec), bias, y, ldy,

@@ -614,12 +614,7 @@ static int launch_topk(const u64* keys, int n_keys, int K, const float* boxes_sr
     if (sort_n > 16384) return FRCNN_EUNSUPPORTED;
     const size_t lds = (size_t)sort_n * 8 + 4096 * 4 + 64 * 4;
     auto kern = topk_sort_kernel<MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + 4096 * 4 + 64 * 4));
-        attr_set = true;
-    }
+    FRCNN_MAX_LDS_ONCE(kern, 16384 * 8 + 4096 * 4 + 64 * 4);
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, s, keys, n_keys, K, sort_n,
                        reinterpret_cast<const f32x4*>(boxes_src), ih, iw, min_side, sorted_idx,
                        reinterpret_cast<f32x4*>(cand_boxes), cand_scores, counts);

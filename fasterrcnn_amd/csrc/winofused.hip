@@ -553,13 +553,11 @@ int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b
     const int xt = 8 >> gm.xcl, totx = gm.total >> gm.xcl;
     const unsigned grid = 8u * (unsigned)cdiv(totx, xt);
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WF_LDS_BYTES));
-        FRCNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WF_LDS_BYTES));
-        attr_set = true;
+    FRCNN_MAX_LDS_ONCE(wino_fused_kernel<true>, WF_LDS_BYTES);
+    FRCNN_MAX_LDS_ONCE(wino_fused_kernel<false>, WF_LDS_BYTES);
+    static bool occ_printed = false;
+    if (!occ_printed) {
+        occ_printed = true;
         if (getenv("FRCNN_DEBUG_OCCUPANCY")) {
             int nb = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(wino_fused_kernel<false>), 256, WF_LDS_BYTES);

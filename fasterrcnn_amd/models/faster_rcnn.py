@@ -201,7 +201,7 @@ class FasterRCNNModel(nn.Module):
             return self._weights_resnet()
         s1 = self._stage1_feature_extractor.packed()
         s2 = self._stage2_region_proposal_network.packed()
-        pv = self._stage3_detector_network._pool_to_feature_vector.packed()
+        pv = self._stage3_detector_network._pool_to_feature_vector.packed(self._effective_fc_math())
         hd = self._stage3_detector_network.packed()
         tensors = [x for pair in s1 for x in pair] + list(s2) + list(pv) + list(hd)
         key = tuple(x.data_ptr() for x in tensors)
@@ -245,10 +245,22 @@ class FasterRCNNModel(nn.Module):
             self._wstruct, self._wstruct_key, self._wkeep = w, key, (tensors, fe, l4)
         return self._wstruct
 
-    def _check_limits(self):
-        if not 1 <= int(self.max_proposals_post_nms) <= nv.MAX_POST_NMS_DETECT:
-            raise ValueError("max_proposals_post_nms must be in [1, %d] for predict() (the per-class NMS of csrc/detect.hip keeps "
-                             "its IoU bit matrix in LDS); got %r" % (nv.MAX_POST_NMS_DETECT, self.max_proposals_post_nms))
+    def _effective_fc_math(self):
+        """The arithmetic fc1 / fc2 actually run in: the x6 kernel multiplies at most LINEAR_X6_ROWS (320) rows per call, so a model
+        configured for more proposals runs the exact-f32 kernel on an f32 pack of the same weights (no refusal, no error)."""
+        if self._is_resnet:
+            return "f32"
+        if self._fc_math_mode == "f32x6" and int(self.max_proposals_post_nms) > nv.LINEAR_X6_ROWS:
+            return "f32"
+        return self._fc_math_mode
+
+    def _check_limits(self, with_detections=True):
+        if not 1 <= int(self.max_proposals_post_nms) <= nv.MAX_POST_NMS_CTX:
+            raise ValueError("max_proposals_post_nms must be in [1, %d] (capacity of a frcnn_ctx); got %r" % (
+                nv.MAX_POST_NMS_CTX, self.max_proposals_post_nms))
+        if with_detections and int(self.max_proposals_post_nms) > nv.MAX_POST_NMS_DETECT:
+            raise ValueError("max_proposals_post_nms must be <= %d for predict() (the per-class NMS of csrc/detect.hip keeps "
+                             "its IoU bit matrix in LDS); forward() has no such limit; got %r" % (nv.MAX_POST_NMS_DETECT, self.max_proposals_post_nms))
         if not 1 <= int(self.max_proposals_pre_nms) <= nv.MAX_PRE_NMS:
             raise ValueError("max_proposals_pre_nms must be in [1, %d] (one-block sort of csrc/proposals.hip); got %r" % (
                 nv.MAX_PRE_NMS, self.max_proposals_pre_nms))
@@ -258,8 +270,13 @@ class FasterRCNNModel(nn.Module):
         Drops every packed / folded / transformed weight cache so that the next forward rebuilds them from the
         nn.Parameters.  The caches are keyed on (data_ptr, _version) of the parameters, which `load_state_dict`, `copy_`
         and optimizers bump -- writes through `.data` (p.data.normal_(), p.data.copy_()) do NOT: call this after them.
+        While weights trained by `train_step` are still pending in the packed masters a `.data` write cannot be told apart from the
+        stale parameter values, and writing the masters back would silently overwrite the edit: this raises instead --
+        call `sync_parameters()` BEFORE editing parameters of a model that has been trained in place.
         """
-        self.sync_parameters()
+        if self._train_state is not None and self._train_state.dirty:
+            raise RuntimeError("invalidate_packed(): weights trained by train_step are still pending in the packed masters; call "
+                               "model.sync_parameters() before writing parameters through .data, then invalidate_packed()")
         for m in self.modules():
             if hasattr(m, "_packed_key"):
                 m._packed_key = None
@@ -286,7 +303,7 @@ class FasterRCNNModel(nn.Module):
 
     def _enqueue(self, image_data, anchor_map, anchor_valid_map, score_threshold, slot_index):
         assert image_data.shape[0] == 1, "Batch size must be 1"
-        self._check_limits()
+        self._check_limits(with_detections=score_threshold is not None)
         self.sync_parameters()
         device = self._device()
         image = rt.as_f32_cuda(image_data, "image_data")
@@ -309,7 +326,7 @@ class FasterRCNNModel(nn.Module):
                                   # slot 0 = one image at a time (latency); slots > 0 = many images in flight on their own
                                   # streams, where longer split-K work units give more throughput (csrc/conv.hip)
                                   0 if slot_index == 0 else self.inflight_conv_blocks_target,
-                                  0 if self._is_resnet else nv.FC_MATH_MODES[self._fc_math_mode],
+                                  nv.FC_MATH_MODES[self._effective_fc_math()],
                                   nv.ROI_OPS[self._stage3_detector_network.pooling], self._stage3_detector_network.sampling_ratio,
                                   0 if slot_index == 0 else self.inflight_winograd_tile_rows)
         lib = nv.lib()

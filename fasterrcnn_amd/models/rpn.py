@@ -28,19 +28,27 @@ def pack_stack_rows(m1, m2, n_pad=128):
     return wo, bo
 
 
-_scratch = {}
+import collections
+
+_scratch = collections.OrderedDict()
+_SCRATCH_MAX = 8            # proposals-only contexts kept alive (LRU): programs that create streams dynamically must not leak 50 MB each
 
 
 def scratch_context(device, h=1024, w=1024, rois=512):
     """Proposal scratch for the stage-level entry points (RegionProposalNetwork.forward, the train step): one proposals-only
     frcnn_ctx (~50 MB, frcnn_ctx_create_proposals) per (device, stream) -- a ctx is not re-entrant, and ctypes calls drop the GIL,
-    so two streams / threads must never share one.  The fused model owns its own per-slot contexts."""
+    so two streams / threads must never share one.  The fused model owns its own per-slot contexts.  At most _SCRATCH_MAX contexts
+    are cached; the least recently used one is dropped (its frcnn_ctx is destroyed once the work enqueued on its stream has drained:
+    hipFree synchronises)."""
     dev = t.device(device)
     key = (str(dev), int(t.cuda.current_stream(dev).cuda_stream))
     ctx = _scratch.get(key)
     if ctx is None or h > ctx.max_h or w > ctx.max_w:
         ctx = rt.Context(dev, max(h, 1024), max(w, 1024), 0, proposals_only=True)
         _scratch[key] = ctx
+    _scratch.move_to_end(key)
+    while len(_scratch) > _SCRATCH_MAX:
+        _scratch.popitem(last=False)
     return ctx
 
 

@@ -167,27 +167,33 @@ class PoolToFeatureVector(nn.Module):
                 rt.as_f32_cuda(self._fc2.weight.detach(), "fc2 weight"),
                 rt.as_f32_cuda(self._fc2.bias.detach(), "fc2 bias"))
 
-    def packed(self):
-        """(fc1 weight, fc1 bias, fc2 weight, fc2 bias) in the layout of `fc_math_mode`: float32 matrices ("f32") or their x6
-        records (uint8 tensors of 96 B per (row, 16-k chunk): frcnn_split_rows_x6)."""
+    def packed(self, mode=None):
+        """(fc1 weight, fc1 bias, fc2 weight, fc2 bias) in the layout of `mode` (default: `fc_math_mode`): float32 matrices ("f32") or
+        their x6 records (uint8 tensors of 96 B per (row, 16-k chunk): frcnn_split_rows_x6).  One pack per mode is cached: a model
+        whose row count exceeds the x6 kernel's 320-row tile runs the f32 pack of the same weights."""
+        mode = mode or self.fc_math_mode
         params = [self._fc1.weight, self._fc1.bias, self._fc2.weight, self._fc2.bias]
-        key = (self.fc_math_mode,) + rt.param_key(params)
-        if key != self._packed_key:
-            w1p, b1, w2, b2 = self.packed_direct()
-            if self.fc_math_mode == "f32x6":
-                w1p, w2 = split_rows_x6(w1p, rows_out=4096), split_rows_x6(w2, rows_out=4096)
-            self._packed = (w1p, b1, w2, b2)
+        key = rt.param_key(params)
+        if key != self._packed_key or self._packed is None:
+            self._packed = {}
             self._packed_key = key
-        return self._packed
+        if mode not in self._packed:
+            w1p, b1, w2, b2 = self.packed_direct()
+            if mode == "f32x6":
+                w1p, w2 = split_rows_x6(w1p, rows_out=4096), split_rows_x6(w2, rows_out=4096)
+            self._packed[mode] = (w1p, b1, w2, b2)
+        return self._packed[mode]
 
     def forward(self, rois):
-        """rois (N, 512, 7, 7) -> (N, 4096): fc1+ReLU, fc2+ReLU (dropout = identity at inference)."""
+        """rois (N, 512, 7, 7) -> (N, 4096): fc1+ReLU, fc2+ReLU (dropout = identity at inference).  More rows than the x6 kernel's
+        320-row tile run on the exact-f32 kernel (same weights, f32 pack)."""
         if self.training and (self._dropout1.p > 0 or self._dropout2.p > 0):
             raise NotImplementedError("training-mode dropout is outside the inference hot path")
         x = rt.as_f32_cuda(rois, "rois")
         n = int(x.shape[0])
         x = x.permute(0, 2, 3, 1).contiguous().reshape(n, 49 * 512)   # layout plumbing: (C,7,7) -> (7,7,C)
-        w1p, b1, w2, b2 = self.packed()
+        mode = self.fc_math_mode if n <= nv.LINEAR_X6_ROWS else "f32"
+        w1p, b1, w2, b2 = self.packed(mode)
         if w1p.dtype == t.uint8:
             h1_rec = linear_x6(split_rows_x6(x), w1p, b1, n, 4096, 49 * 512, relu=True, want="records")
             return linear_x6(h1_rec, w2, b2, n, 4096, 4096, relu=True, want="float32")

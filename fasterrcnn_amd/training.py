@@ -590,6 +590,10 @@ class GradientAverager:
             self._owner = owner
 
         def __setitem__(self, name, tensor):
+            # a gradient is handed to the exchange exactly once, final: a second assignment would send it twice (or race with the
+            # in-place reduce of the first)
+            if name in self:
+                raise RuntimeError("gradient %r was assigned twice in one step: the first tensor is already being all-reduced" % name)
             super().__setitem__(name, tensor)
             self._owner.ready(name, tensor)
 
@@ -633,6 +637,17 @@ class GradientAverager:
                     off += k
         self._inflight = []
 
+    def abort(self):
+        """After an exception between track() and finish(): waits for every exchange already started, so that no collective is left
+        in flight on tensors that are about to be freed, and drops the step's state.  (The peers of a rank that failed mid-step still
+        need their own error handling: the process group's timeout ends their wait.)"""
+        for work, _, _ in self._inflight:
+            try:
+                work.wait()
+            except Exception:
+                pass
+        self._pending, self._pending_bytes, self._inflight = [], 0, []
+
     def __call__(self, grads):
         tracked = self.track()
         for name in sorted(grads):
@@ -668,6 +683,11 @@ def train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rp
     try:
         return _train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_rpn_map, gt_rpn_object_indices,
                            gt_rpn_background_indices, gt_boxes, detail)
+    except BaseException:
+        sync = getattr(model, "_gradient_sync", None)
+        if sync is not None:
+            sync.abort()            # never leave async all-reduces in flight on tensors this frame is about to free
+        raise
     finally:
         _GRAD_MATH = 0              # the module-level helpers (gemm_tn, conv3x3_wgrad, ...) default to float32 outside a step
 

@@ -225,3 +225,23 @@ def test_predict_one_on_png_file(gpu_model, sd_cpu, tmp_path):
     arr, img_obj, sf, shape = I.load_image(path, gpu_model.backbone.image_preprocessing_params, min_dimension_pixels=600)
     assert isinstance(arr, np.ndarray) and arr.dtype == np.float32 and np.array_equal(arr, data)
     assert shape == (3, 375, 500) and sf == scale and img_obj.size == (800, 600)
+
+
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs two GPUs in ONE process")
+def test_model_moves_to_second_device_in_one_process():
+    """The > 64 KB dynamic-LDS limit of the MFMA kernels is a PER-DEVICE function attribute (csrc/common.h: FRCNN_MAX_LDS_ONCE):
+    the same process must be able to run the model on cuda:0 and then on cuda:1 (VERDICT r2 #7d).  Skipped on one-GPU boxes."""
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    from fasterrcnn_amd.models.vgg16 import VGG16Backbone
+    sd = synthetic.vgg16_state_dict(1234)
+    model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+    model.load_state_dict(sd, strict=True)
+    img = synthetic.image(3, 224, 320).unsqueeze(0)
+    out = []
+    for d in (0, 1):
+        dev = torch.device("cuda", d)
+        model = model.cuda(dev).eval()
+        with torch.cuda.device(dev):
+            out.append(model.predict(image_data=img.to(dev), score_threshold=0.05))
+    for c in out[0]:
+        assert np.array_equal(out[0][c], out[1][c])

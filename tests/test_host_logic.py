@@ -200,3 +200,60 @@ def test_optimizer_hyper_parameters_from_torch_sgd():
     bad = t.optim.SGD([{"params": [p], "weight_decay": 0.0}, {"params": [q], "weight_decay": 5e-4}], lr=1e-3, momentum=0.9)
     with pytest.raises(NotImplementedError):
         training.sgd_hyper_parameters(bad)
+
+
+# ---- bench.py's N > 1 launch path without hardware (VERDICT r2 #7b) ----------------------------------------------------------
+def test_bench_multi_gpu_relaunch_command_and_environment(monkeypatch):
+    """`python bench.py --gpus 8` without a launcher re-executes itself under torch.distributed.run: the command line must be the
+    driver's form (one node, 8 ranks, 127.0.0.1 rendezvous, flags passed through) and the children's environment must carry
+    dmabuf IPC + the HIP queue count.  The launcher itself is mocked."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = list(cmd), dict(env)
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "7", "--warmup", "2"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "HSA_ENABLE_IPC_MODE_LEGACY"):
+        monkeypatch.delenv(k, raising=False)
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    else:
+        raise AssertionError("bench.main() must hand over to the launcher")
+    cmd, env = seen["cmd"], seen["env"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    script = cmd.index(bench.os.path.abspath(bench.__file__))
+    assert cmd[script + 1:] == ["--gpus", "8", "--steps", "7", "--warmup", "2"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["GPU_MAX_HW_QUEUES"] == "16"
+    # a rank of that job reads its identity (and its device = LOCAL_RANK) from the launcher's variables
+    assert bench.rank_environment({"RANK": "5", "LOCAL_RANK": "5", "WORLD_SIZE": "8"}) == (5, 5, 8)
+    assert bench.rank_environment({}) == (0, 0, 1)
+    # an explicit user setting wins over the defaults
+    _, env2 = bench.launcher_command(2, [], {"GPU_MAX_HW_QUEUES": "4", "HSA_ENABLE_IPC_MODE_LEGACY": "1"})
+    assert env2["GPU_MAX_HW_QUEUES"] == "4" and env2["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+
+
+def test_bench_layer_arithmetic_discloses_pipes():
+    """Every GEMM-shaped layer of the image appears once with the pipe it runs on; the per-pipe sums equal the documented figures."""
+    import bench
+    rows = bench.layer_arithmetic("f32_winograd", "f32x6")
+    names = [r[0] for r in rows]
+    assert names == bench._CONV_NAMES + ["rpn_heads_1x1", "fc1", "fc2", "detector_heads"]
+    by = {r[0]: r for r in rows}
+    assert by["fc1"][2] == "bf16" and by["fc1"][3] == 6.0 * by["fc1"][4]
+    assert all(by[n][2] == "f32" and by[n][1] == "wino_fused_kernel" for n in bench._CONV_NAMES)
+    pf = bench.pipe_flops_per_image("f32_winograd", "f32x6")
+    assert abs(pf["f32"] - (1.683e11 + 2.0 * 512 * 45 * 37 * 62 + 300 * 2.0 * 4096 * 101)) / pf["f32"] < 1e-3
+    assert abs(pf["bf16"] - 6.0 * 300 * 2.0 * (25088 * 4096 + 4096 * 4096)) / pf["bf16"] < 1e-12
+    assert bench.pipe_flops_per_image("f32", "f32")["bf16"] == 0.0
+    # algorithmic total == BASELINE.md section 3 minus conv1_1 (the VALU layer): 4.4922e11 - 2*27*64*600*1000
+    alg = sum(r[4] for r in bench.layer_arithmetic("f32", "f32"))
+    assert abs(alg - (4.4922e11 - 2.0 * 27 * 64 * 600 * 1000)) / alg < 2e-4
