@@ -52,6 +52,10 @@ _MFMA_CONVS = [(64, 64, 600, 1000), (64, 128, 300, 500), (128, 128, 300, 500), (
                (512, 512, 37, 62)]   # last = RPN trunk (models/rpn.py:88)
 
 
+_CONV_NAMES = ["conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2",
+               "conv5_3", "rpn_trunk"]
+
+
 def uses_winograd(cin, cout):       # fasterrcnn_amd/_native.py uses_winograd_fused: every single-map 3x3 layer from conv1_2 on
     return cin >= 64 and cin % 16 == 0 and cout >= 64 and cout % 64 == 0
 
@@ -60,13 +64,24 @@ def conv_mfma_flops_per_image():
     return float(sum(2.0 * 9 * ci * co * h * w for ci, co, h, w in _MFMA_CONVS))
 
 
-def direct_layers(math):
+_POOLED = ("conv1_2", "conv2_2", "conv3_3", "conv4_3")       # layers with the fused 2x2 max-pool (models/vgg16.py:79,82,86,90)
+
+
+def direct_layers(math, x6=()):
     """The 3x3 layers that run on conv3x3_mfma_kernel in this math mode."""
-    return [l for l in _MFMA_CONVS if not (math == "f32_winograd" and uses_winograd(l[0], l[1]))]
+    return [l for n, l in zip(_CONV_NAMES, _MFMA_CONVS) if not (math == "f32_winograd" and (uses_winograd(l[0], l[1]) or n in x6))]
 
 
-def winograd_layers(math):
-    return [l for l in _MFMA_CONVS if math == "f32_winograd" and uses_winograd(l[0], l[1])]
+def winograd_layers(math, x6=(), named=False):
+    """The layers that run as one-launch float32 Winograd layers (wino_fused_kernel, exact-f32 pipe)."""
+    out = [(n, l) for n, l in zip(_CONV_NAMES, _MFMA_CONVS) if math == "f32_winograd" and uses_winograd(l[0], l[1]) and n not in x6]
+    return out if named else [l for _, l in out]
+
+
+def x6_winograd_layers(math, x6=(), named=False):
+    """The layers that run as x6 Winograd layers (csrc/wino_x6.hip: gemm_x6t_kernel on the bf16 pipe)."""
+    out = [(n, l) for n, l in zip(_CONV_NAMES, _MFMA_CONVS) if math == "f32_winograd" and n in x6]
+    return out if named else [l for _, l in out]
 
 
 def winograd_gemm_flops(ci, co, h, w):
@@ -75,18 +90,16 @@ def winograd_gemm_flops(ci, co, h, w):
     return 2.0 * 16 * ((h + 1) // 2) * ((w + 1) // 2) * ci * co
 
 
-_CONV_NAMES = ["conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2",
-               "conv5_3", "rpn_trunk"]
-
-
-def layer_arithmetic(math, fc_math, n_rois=300, num_classes=21):
+def layer_arithmetic(math, fc_math, x6=(), n_rois=300, num_classes=21):
     """One row per GEMM-shaped layer of one image: which kernel family and WHICH matrix pipe it runs on, the FLOP that pipe executes
     for it and the algorithmic (direct-form) FLOP it stands for.  Winograd layers execute 16 x tiles x cin x cout x 2; an "x6" layer
     executes six bf16 MFMAs per algorithmic product."""
     rows = []
     for name, (ci, co, h, w) in zip(_CONV_NAMES, _MFMA_CONVS):
         alg = 2.0 * 9 * ci * co * h * w
-        if math == "f32_winograd" and uses_winograd(ci, co):
+        if math == "f32_winograd" and name in x6:
+            rows.append((name, "gemm_x6t_kernel (x6 Winograd layer)", "bf16", 6.0 * winograd_gemm_flops(ci, co, h, w), alg))
+        elif math == "f32_winograd" and uses_winograd(ci, co):
             rows.append((name, "wino_fused_kernel", "f32", winograd_gemm_flops(ci, co, h, w), alg))
         elif math == "f32x6":
             rows.append((name, "conv3x3_x6_kernel", "bf16", 6.0 * alg, alg))
@@ -105,19 +118,19 @@ def layer_arithmetic(math, fc_math, n_rois=300, num_classes=21):
     return rows
 
 
-def pipe_flops_per_image(math, fc_math, backbone_only=False):
+def pipe_flops_per_image(math, fc_math, x6=(), backbone_only=False):
     """{"f32": FLOP the exact-f32 matrix pipe executes per image, "bf16": FLOP the bf16 matrix pipe executes per image}."""
     out = {"f32": 0.0, "bf16": 0.0}
-    for name, _, pipe, ex, _ in layer_arithmetic(math, fc_math):
-        if backbone_only and not name.startswith("conv"):
+    for name, _, pipe, ex, _ in layer_arithmetic(math, fc_math, x6):
+        if backbone_only and not (name.startswith("conv") or name == "rpn_trunk"):
             continue
         out[pipe] += ex
     return out
 
 
-def executed_mfma_flops_per_image(math, fc_math="f32"):
+def executed_mfma_flops_per_image(math, fc_math="f32", x6=()):
     """Matrix-pipe FLOP executed per image, both pipes added (kept for continuity with rounds 1-2; the per-pipe figures are the meaningful ones)."""
-    f = pipe_flops_per_image(math, fc_math)
+    f = pipe_flops_per_image(math, fc_math, x6)
     return f["f32"] + f["bf16"]
 
 
@@ -243,7 +256,7 @@ def train_step_leg(backbone, dev, steps=10, warmup=3, lr=1e-6, pool=2, grad_math
 
 
 def winograd_chip_full_leg(layers, dev, streams=8, reps=6):
-    """The dominant kernel with the chip FULL -- the regime of the headline number (several images in flight): every Winograd layer of one
+    """`layers`: [(name, (cin, cout, h, w))].  The float32 Winograd kernel with the chip FULL -- the regime of the headline number (several images in flight): every Winograd layer of one
     image launched back to back on each of `streams` HIP streams (own buffers per stream, random operands), wall time by events.
     achieved = streams x reps x sum of executed Winograd FLOP / wall.  A single stream (the `roofline` block) leaves the tail of every
     launch to an emptying chip: 640 work units on 512 resident-block slots (conv4_x) or 160 on 256 CUs (conv5_x)."""
@@ -253,8 +266,8 @@ def winograd_chip_full_leg(layers, dev, streams=8, reps=6):
     bufs = []
     for _ in range(streams):
         per = []
-        for i, (ci, co, h, w) in enumerate(layers):
-            pool = i in (0, 2, 5, 8)
+        for name, (ci, co, h, w) in layers:
+            pool = name in _POOLED
             x = torch.randn((h, w, ci), device=dev)
             wt = torch.randn((co, ci, 3, 3), device=dev) * 0.02
             u = torch.empty((16 * co * ci,), device=dev)
@@ -283,7 +296,7 @@ def winograd_chip_full_leg(layers, dev, streams=8, reps=6):
         torch.cuda.synchronize(dev)
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[1]
-    flops = streams * reps * sum(winograd_gemm_flops(*l) for l in layers)
+    flops = streams * reps * sum(winograd_gemm_flops(*l) for _, l in layers)
     ach = flops / dt / 1e12
     return {"regime": "%d streams x %d repetitions of the %d Winograd layers of one image in flight (chip full), wall clock, median of 3"
                       % (streams, reps, len(layers)),
@@ -480,6 +493,7 @@ def main():
             secondary[mode] = round(n_gpus * args.steps / dt, 3)
         model.math_mode = args.math
     fc_math = model.fc_math_mode
+    x6 = tuple(getattr(model, "winograd_x6_layers", ())) if args.math == "f32_winograd" else ()
     fc_f32_value = None
     if not is_resnet and not args.no_secondary and fc_math != "f32":
         # the same workload with fc1 / fc2 on the exact-f32 pipe too: every GEMM of the image on v_mfma_f32_*_f32
@@ -488,6 +502,16 @@ def main():
         dt, _ = timed_median(run, args.steps, min(args.min_timed_seconds, 0.5))
         fc_f32_value = round(n_gpus * args.steps / dt, 3)
         model.fc_math_mode = fc_math
+        run(nslots)
+
+    wino_f32_value = None
+    if not is_resnet and not args.no_secondary and x6:
+        # the same workload with EVERY 3x3 layer on the exact-f32 pipe (rounds 1-2's default table: no x6 Winograd layer)
+        model.winograd_x6_layers = ()
+        run(max(args.warmup, nslots))
+        dt, _ = timed_median(run, args.steps, min(args.min_timed_seconds, 0.5))
+        wino_f32_value = round(n_gpus * args.steps / dt, 3)
+        model.winograd_x6_layers = x6
         run(nslots)
 
     # ---- driver-timed secondary legs (rank 0 of a one-GPU run; none of them is the headline value) -------------------
@@ -574,30 +598,60 @@ def main():
 
         regime = ("HIP events around every launch, one image at a time on one stream, median image of %d (after the timed region: with "
                   "several images in flight concurrent kernels share the CUs and a launch's wall duration is not its own)" % n_img)
-        dl, wl = direct_layers(args.math), winograd_layers(args.math)
+        dl, wl_named = direct_layers(args.math, x6), winograd_layers(args.math, x6, named=True)
+        wl = [l for _, l in wl_named]
+        xl_named = x6_winograd_layers(args.math, x6, named=True)
+        xl = [l for _, l in xl_named]
         r_direct = mfma_roofline("conv3x3_mfma_kernel (direct 3x3 layers: %d per image)" % len(dl), "conv3x3_mfma",
                                  [2.0 * 9 * ci * co * h * w for ci, co, h, w in dl], "FLOP = direct-convolution FLOP of the layers")
         if r_direct is not None:
             r_direct["traffic"] = measured_traffic()
-        r_wino = mfma_roofline("wino_fused_kernel (one-launch Winograd F(2x2,3x3) layer, all 16 positions in MFMA accumulators: %d layers "
-                               "per image)" % len(wl), "winograd_gemm", [winograd_gemm_flops(*l) for l in wl],
-                               "FLOP = the FLOP the matrix pipe executes (16 x tiles x cin x cout x 2), NOT the 2.25x larger "
+        r_wino = mfma_roofline("wino_fused_kernel (one-launch float32 Winograd F(2x2,3x3) layer, all 16 positions in MFMA accumulators: %d layers "
+                               "per image: %s)" % (len(wl), ", ".join(n for n, _ in wl_named)), "winograd_gemm", [winograd_gemm_flops(*l) for l in wl],
+                               "FLOP = the FLOP the exact-f32 matrix pipe executes (16 x tiles x cin x cout x 2), NOT the 2.25x larger "
                                "direct-convolution FLOP the layers replace") if wl else None
         if r_wino is not None:
             r_wino["traffic"] = measured_traffic("wino_fused_kernel")
-            r_wino["algorithmic_bytes_per_launch"] = float(sum(4.0 * (h * w * ci + 16 * ci * co + (h // (2 if i in (0, 2, 5, 8) else 1)) * (w // (2 if i in (0, 2, 5, 8) else 1)) * co)
-                                                               for i, (ci, co, h, w) in enumerate(wl))) / len(wl)
+            r_wino["algorithmic_bytes_per_launch"] = float(sum(4.0 * (h * w * ci + 16 * ci * co + (h // (2 if n in _POOLED else 1)) * (w // (2 if n in _POOLED else 1)) * co)
+                                                               for n, (ci, co, h, w) in wl_named)) / len(wl)
         if r_wino is not None and not args.no_extra_legs:
             try:
-                r_wino["chip_full"] = winograd_chip_full_leg(wl, dev)
+                r_wino["chip_full"] = winograd_chip_full_leg(wl_named, dev)
             except Exception as e:
                 r_wino["chip_full"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # the x6 Winograd layers' batched GEMM on the bf16 pipe: executed FLOP = 6 x (16 x tiles x cin x cout x 2), priced against the
+        # DENSE bf16 peak (the split-K reduction of the small maps is a separate, tiny launch in the same class: it is counted in the
+        # class time but not in `launches`' FLOP, so the figure is slightly pessimistic)
+        r_x6 = None
+        if xl:
+            ms6, l6 = timing["winograd_x6_gemm"]
+            if l6:
+                per_launch = 6.0 * sum(winograd_gemm_flops(*l) for l in xl) / len(xl)
+                n_gemm = len(xl) * n_img                               # GEMM launches (the class also holds the split-K reductions)
+                avg_s = (ms6 / 1e3) / n_gemm
+                ach = per_launch / avg_s / 1e12
+                t8 = timing["winograd_x6_transforms"]
+                r_x6 = {"kernel": "gemm_x6t_kernel (the 16 position GEMMs of an x6 Winograd layer in one launch, f32x6 arithmetic: %d layers per image: %s)"
+                                  % (len(xl), ", ".join(n for n, _ in xl_named)),
+                        "regime": regime, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": measured_traffic("gemm_x6t_kernel"),
+                        "flops_per_launch": per_launch, "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(n_gemm),
+                        "ms_per_image": round(ms6 / max(args.roofline_images, 1), 4),
+                        "f32_equivalent_tflops": round(ach / 6.0, 2),
+                        "transforms_ms_per_image": round(t8[0] / max(args.roofline_images, 1), 4),
+                        "algorithmic_bytes_per_launch": float(sum(16.0 * ((h + 1) // 2) * ((w + 1) // 2) * (6 * ci + 4 * co) + 16.0 * 6 * ci * co
+                                                                  for ci, co, h, w in xl)) / len(xl),
+                        "note": "FLOP = 6 bf16 MFMA products per float32 product x the Winograd GEMM FLOP (16 x tiles x cin x cout x 2), against the dense "
+                                "bf16 peak; f32_equivalent_tflops = the same launches counted once per float32 product; bytes = V records (6 B per "
+                                "element) read + M (4 B) written + the filter record bank"}
         # `roofline` = the kernel with the most GPU time per image, the other one rides along
-        both = [r for r in (r_direct, r_wino) if r is not None]
+        both = [r for r in (r_direct, r_wino, r_x6) if r is not None]
         both.sort(key=lambda r: -r["ms_per_image"])
         roofline = dict(both[0]) if both else {"note": "timing disabled"}
         if len(both) > 1:
             roofline["second_kernel"] = both[1]
+        if len(both) > 2:
+            roofline["third_kernel"] = both[2]
         roofline["per_class_ms_per_image"] = {k: round(v[0] / max(args.roofline_images, 1), 4) for k, v in timing.items()}
 
         cpu = None
@@ -624,12 +678,12 @@ def main():
         pipes = {}
         if not is_resnet:
             ips = value / n_gpus
-            pf = pipe_flops_per_image(args.math, fc_math)
-            pb = pipe_flops_per_image(args.math, fc_math, backbone_only=True)
+            pf = pipe_flops_per_image(args.math, fc_math, x6)
+            pb = pipe_flops_per_image(args.math, fc_math, x6, backbone_only=True)
             f32_tf, bf16_tf = ips * pf["f32"] / 1e12, ips * pf["bf16"] / 1e12
             pipes = {
                 "layer_arithmetic": [{"layer": n_, "kernel": k_, "pipe": p_, "executed_gflop": round(e_ / 1e9, 3), "algorithmic_gflop": round(a_ / 1e9, 3)}
-                                     for n_, k_, p_, e_, a_ in layer_arithmetic(args.math, fc_math)],
+                                     for n_, k_, p_, e_, a_ in layer_arithmetic(args.math, fc_math, x6)],
                 "f32_pipe_tflops": round(f32_tf, 2), "f32_pipe_frac": round(f32_tf / PEAK_F32_MFMA_TFLOPS, 4),
                 "bf16_pipe_tflops": round(bf16_tf, 2), "bf16_pipe_frac": round(bf16_tf / PEAK_BF16_MFMA_TFLOPS, 4),
                 "pipe_note": "FLOP each matrix pipe EXECUTES per image x images/sec per GPU, over that pipe's dense peak (157.3 / 2500 TFLOP/s); "
@@ -657,8 +711,9 @@ def main():
             "tflops_per_gpu": round(value / n_gpus * flops_img / 1e12, 2),
             "tflops_per_gpu_note": "direct-convolution FLOP of the workload x images/sec (BASELINE.md's 4.4922e11 per image); "
                                    "in the f32_winograd mode the matrix pipes execute fewer: see f32_pipe_tflops / bf16_pipe_tflops",
-            "math": args.math, "fc_math": None if is_resnet else fc_math, "roi": model._stage3_detector_network.pooling,
+            "math": args.math, "winograd_x6_layers": list(x6), "fc_math": None if is_resnet else fc_math, "roi": model._stage3_detector_network.pooling,
             "other_math_modes_images_per_sec": secondary, "fc_math_f32_images_per_sec": fc_f32_value,
+            "winograd_all_f32_pipe_images_per_sec": wino_f32_value,
             "per_rank_images_per_sec": per_rank, "slowest_rank_images_per_sec": min(per_rank),
             **pipes,
             **extra,

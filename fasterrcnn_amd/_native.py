@@ -12,14 +12,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
-ABI_VERSION = 5     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
+ABI_VERSION = 6     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
 POOL2 = 2
-NUM_KCLASS = 8
+NUM_KCLASS = 10
 KCLASS_NAMES = ("conv3x3_mfma", "conv3x3_c3", "linear_mfma", "proposals", "roi_pool", "other", "winograd_transforms",
-                "winograd_gemm")
+                "winograd_gemm", "winograd_x6_transforms", "winograd_x6_gemm")
 
 # Every symbol include/frcnn_hip.h declares (tests check the .so exports all of them).
 SYMBOLS = (
@@ -40,6 +40,9 @@ SYMBOLS = (
     "frcnn_conv3x3_uses_winograd_fused", "frcnn_resnet_block_uses_winograd_fused", "frcnn_pack_conv3x3_winograd_fused", "frcnn_pack_conv3x3_winograd_fused_taps",
     "frcnn_conv3x3_nhwc_winograd_fused", "frcnn_split_rows_x6", "frcnn_linear_x6_workspace_bytes", "frcnn_linear_x6",
     "frcnn_roi_align", "frcnn_roi_align_backward",
+    "frcnn_x6t_record_bytes", "frcnn_split_rows_x6t", "frcnn_gemm_x6t_workspace_bytes", "frcnn_gemm_x6t",
+    "frcnn_conv3x3_uses_winograd_x6", "frcnn_conv3x3_winograd_x6_pack_bytes", "frcnn_pack_conv3x3_winograd_x6",
+    "frcnn_conv3x3_winograd_x6_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x6",
     # training path
     "frcnn_label_proposals", "frcnn_gather_rows", "frcnn_rpn_loss", "frcnn_detector_loss",
     "frcnn_gemm_tn_math", "frcnn_conv3x3_wgrad_math", "frcnn_conv_wgrad_math",
@@ -91,7 +94,7 @@ class ForwardParams(C.Structure):
     _fields_ = [("pre_nms", C.c_int32), ("post_nms", C.c_int32), ("rpn_nms_threshold", C.c_float),
                 ("min_side", C.c_float), ("allow_edge_proposals", C.c_int32), ("math_mode", C.c_int32),
                 ("conv_blocks_target", C.c_int32), ("fc_math_mode", C.c_int32), ("roi_op", C.c_int32), ("roi_sampling_ratio", C.c_int32),
-                ("winograd_tile_rows", C.c_int32)]
+                ("winograd_tile_rows", C.c_int32), ("winograd_x6_mask", C.c_int32), ("x6_gemm_tiles", C.c_int32)]
 
 
 # capacity limits of the kernels (validated by FasterRCNNModel with a message; the C entry points return FRCNN_EINVAL / EUNSUPPORTED)
@@ -104,6 +107,7 @@ MATH_F32 = 0      # exact f32 MFMA
 MATH_F32X6 = 1    # bf16x3 split operands, six bf16 MFMAs per product, f32 accumulate
 MATH_F32_WINOGRAD = 2   # exact f32 MFMA; 3x3 layers with uses_winograd(cin, cout) as Winograd F(2x2,3x3) in float32
 MATH_MODES = {"f32": MATH_F32, "f32x6": MATH_F32X6, "f32_winograd": MATH_F32_WINOGRAD}
+X6T_ROW_TILE, X6T_COL_TILE = 320, 256     # FRCNN_X6T_ROW_TILE / FRCNN_X6T_COL_TILE: row padding of x6t record arrays (csrc/gemm_x6t.hip)
 LINEAR_X6_ROWS = 320                      # FRCNN_LINEAR_X6_ROWS: row count of an activation record array (csrc/linear_x6.hip's row tile)
 GRAD_MATHS = {"f32": 0, "bf16": 1}         # FRCNN_GRAD_F32 / FRCNN_GRAD_BF16: arithmetic of the train step's gradient GEMMs
 ROI_OPS = {"pool": 0, "align": 1}          # FRCNN_ROI_POOL (the reference) / FRCNN_ROI_ALIGN (torchvision roi_align semantics)
@@ -113,6 +117,20 @@ FC_MATH_MODES = {"f32": 0, "f32x6": 1}   # FRCNN_FC_F32 / FRCNN_FC_F32X6: arithm
 def uses_winograd(cin, cout):
     """== frcnn_conv3x3_uses_winograd(cin, cout) (tests/test_abi.py): the 3x3 layers the f32_winograd mode transforms."""
     return cin >= 128 and cout >= 256 and cin % 16 == 0 and cout % 128 == 0
+
+
+X6_RPN_TRUNK_BIT = 13                     # FRCNN_X6_RPN_TRUNK_BIT of frcnn_forward_params.winograd_x6_mask
+# names of the 3x3 layers in the order of the mask bits (bit 0 = conv1_1, the VALU layer, is never an x6 layer)
+X6_LAYER_BITS = {"conv1_2": 1, "conv2_1": 2, "conv2_2": 3, "conv3_1": 4, "conv3_2": 5, "conv3_3": 6, "conv4_1": 7, "conv4_2": 8,
+                 "conv4_3": 9, "conv5_1": 10, "conv5_2": 11, "conv5_3": 12, "rpn_trunk": 13}
+
+
+DEFAULT_X6_LAYERS_VGG16 = ("conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3", "rpn_trunk")
+
+
+def uses_winograd_x6(cin, cout):
+    """== frcnn_conv3x3_uses_winograd_x6(cin, cout): the 3x3 layers that CAN run as x6 Winograd layers (csrc/wino_x6.hip)."""
+    return cin >= 256 and cin % 16 == 0 and cout >= 256 and cout % 256 == 0
 
 
 def uses_winograd_fused(cin, cout):
@@ -161,6 +179,15 @@ _SIGNATURES = {
     "frcnn_split_rows_x6": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "frcnn_linear_x6_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "frcnn_linear_x6": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_x6t_record_bytes": (C.c_size_t, [_i, _i]),
+    "frcnn_split_rows_x6t": (C.c_int, [_vp, _i, _sz, _vp, _i, _i, _i, _i, _vp]),
+    "frcnn_gemm_x6t_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "frcnn_gemm_x6t": (C.c_int, [_vp, _i, _sz, _vp, _i, _sz, _vp, _vp, _i, _sz, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_conv3x3_uses_winograd_x6": (C.c_int, [_i, _i]),
+    "frcnn_conv3x3_winograd_x6_pack_bytes": (C.c_size_t, [_i, _i]),
+    "frcnn_pack_conv3x3_winograd_x6": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
+    "frcnn_conv3x3_winograd_x6_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "frcnn_conv3x3_nhwc_winograd_x6": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_conv3x3_uses_winograd_fused": (C.c_int, [_i, _i]),
     "frcnn_resnet_block_uses_winograd_fused": (C.c_int, [_i, _i, _i]),
     "frcnn_pack_conv3x3_winograd_fused": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),

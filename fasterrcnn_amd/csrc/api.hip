@@ -41,6 +41,7 @@ struct frcnn_ctx {
     void* lin_ws = nullptr; size_t lin_ws_bytes = 0;
     void* conv_ws = nullptr; size_t conv_ws_bytes = 0;   // split-K partials of under-filled conv layers
     void* wino_ws = nullptr; size_t wino_ws_bytes = 0;   // V and M of the Winograd layers; allocated by the first forward that needs it
+    void* wx_ws = nullptr; size_t wx_ws_bytes = 0;       // V records, M and split-K partials of the x6 Winograd layers; allocated on first use
     float* res_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // ResNet bottleneck rotation
     size_t res_buf_floats = 0;
     int last_c = 512, last_vec = 4096;
@@ -262,6 +263,47 @@ int frcnn_linear_x6(const void* d_a_rec, const void* d_w_rec, const float* d_bia
 {
     if (!d_a_rec || !d_w_rec || !d_bias) return FRCNN_EINVAL;
     return launch_linear_x6(d_a_rec, d_w_rec, d_bias, d_y, ldy, d_y_rec, M, N, K, flags, d_ws, ws_bytes, as_stream(stream));
+}
+
+size_t frcnn_x6t_record_bytes(int rows_padded, int K)
+{
+    return (rows_padded > 0 && rows_padded % 32 == 0 && K >= 16 && K % 16 == 0) ? x6t_record_bytes(rows_padded, K) : 0;
+}
+
+int frcnn_split_rows_x6t(const float* d_a, int lda, size_t a_batch_floats, void* d_rec, int rows, int rows_padded, int K, int batches,
+                         void* stream)
+{
+    if (!d_a || !d_rec) return FRCNN_EINVAL;
+    return launch_split_rows_x6t(d_a, lda, a_batch_floats, d_rec, rows, rows_padded, K, batches, as_stream(stream));
+}
+
+size_t frcnn_gemm_x6t_workspace_bytes(int M, int N, int K, int batches) { return gemm_x6t_workspace_bytes(M, N, K, batches); }
+
+int frcnn_gemm_x6t(const void* d_a_rec, int a_rows, size_t a_batch_bytes, const void* d_b_rec, int b_rows, size_t b_batch_bytes,
+                   const float* d_bias, float* d_c, int ldc, size_t c_batch_floats, int M, int N, int K, int batches, unsigned flags,
+                   void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_a_rec || !d_b_rec || !d_c) return FRCNN_EINVAL;
+    return launch_gemm_x6t(d_a_rec, a_rows, a_batch_bytes, d_b_rec, b_rows, b_batch_bytes, d_bias, d_c, ldc, c_batch_floats, M, N, K,
+                           batches, flags, d_ws, ws_bytes, as_stream(stream));
+}
+
+int frcnn_conv3x3_uses_winograd_x6(int cin, int cout) { return conv3x3_uses_winograd_x6(cin, cout) ? 1 : 0; }
+size_t frcnn_conv3x3_winograd_x6_pack_bytes(int cout, int cin) { return conv3x3_winograd_x6_pack_bytes(cout, cin); }
+
+int frcnn_pack_conv3x3_winograd_x6(const float* d_w, const float* d_row_scale, void* d_u_rec, int cout, int cin, void* stream)
+{
+    if (!d_w || !d_u_rec) return FRCNN_EINVAL;
+    return launch_pack_conv3x3_winograd_x6(d_w, d_row_scale, d_u_rec, cout, cin, as_stream(stream));
+}
+
+size_t frcnn_conv3x3_winograd_x6_workspace_bytes(int H, int W, int cin, int cout) { return conv3x3_winograd_x6_workspace_bytes(H, W, cin, cout); }
+
+int frcnn_conv3x3_nhwc_winograd_x6(const float* d_x, const void* d_u_rec, const float* d_bias, float* d_y, int H, int W, int cin,
+                                   int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_x || !d_u_rec || !d_bias || !d_y) return FRCNN_EINVAL;
+    return launch_conv3x3_winograd_x6(d_x, d_u_rec, d_bias, d_y, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
 }
 
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream)
@@ -681,10 +723,11 @@ void frcnn_ctx_destroy(frcnn_ctx* ctx)
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->slab) (void)hipFree(ctx->slab);
     if (ctx->wino_ws) (void)hipFree(ctx->wino_ws);
+    if (ctx->wx_ws) (void)hipFree(ctx->wx_ws);
     delete ctx;
 }
 
-size_t frcnn_ctx_bytes(const frcnn_ctx* ctx) { return ctx ? ctx->slab_bytes + ctx->wino_ws_bytes : 0; }
+size_t frcnn_ctx_bytes(const frcnn_ctx* ctx) { return ctx ? ctx->slab_bytes + ctx->wino_ws_bytes + ctx->wx_ws_bytes : 0; }
 
 int frcnn_ctx_timing_enable(frcnn_ctx* ctx, int enable)
 {
@@ -770,6 +813,48 @@ int run_winograd_layer(frcnn_ctx* c, const float* x, const float* u, const float
     return launch_winograd_output(M, b, y, N, h, w, co, flags, s);
 }
 
+// Scratch of the x6 Winograd layers (V records + M + split-K partials of the largest eligible layer up to the ctx's largest image),
+// allocated once, on first use, zeroed (the padding row blocks of V are then zero for ever: nobody writes them).
+int ensure_wx_ws(frcnn_ctx* c)
+{
+    if (c->wx_ws) return FRCNN_OK;
+    size_t need = 0;
+    // VGG-16: conv4_x on the image / 8 map, conv5_x and the RPN trunk on image / 16; ResNet: the RPN trunk on the 1024-channel map
+    const int shapes[4][4] = {{c->max_h / 8, c->max_w / 8, 256, 512}, {c->max_h / 8, c->max_w / 8, 512, 512},
+                              {c->max_fh, c->max_fw, 512, 512}, {c->max_fh, c->max_fw, 1024, 1024}};
+    for (auto& sh : shapes) {
+        const size_t b = conv3x3_winograd_x6_workspace_bytes(sh[0], sh[1], sh[2], sh[3]);
+        if (b > need) need = b;
+    }
+    if (need == 0) return FRCNN_EINVAL;
+    hipError_t e = hipMalloc(&c->wx_ws, need);
+    if (e != hipSuccess) { set_hip_error(e); c->wx_ws = nullptr; return FRCNN_ENOMEM; }
+    e = hipMemset(c->wx_ws, 0, need);
+    if (e != hipSuccess) { set_hip_error(e); (void)hipFree(c->wx_ws); c->wx_ws = nullptr; return FRCNN_EHIP; }
+    c->wx_ws_bytes = need;
+    return FRCNN_OK;
+}
+
+// One x6 Winograd layer inside a fused forward: transforms timed as class 8, the batched bf16-pipe GEMM as class 9.
+int run_wino_x6_layer(frcnn_ctx* c, const float* x, const void* urec, const float* b, float* y, int h, int w, int ci, int co,
+                      unsigned flags, hipStream_t s)
+{
+    if (!conv3x3_uses_winograd_x6(ci, co)) return FRCNN_EINVAL;
+    int r = ensure_wx_ws(c);
+    if (r) return r;
+    void *V = nullptr, *G = nullptr;
+    float* M = nullptr;
+    size_t gb = 0;
+    r = winograd_x6_plan(h, w, ci, co, flags, c->wx_ws, c->wx_ws_bytes, &V, &M, &G, &gb);
+    if (r) return r;
+    { Scope _t(c, 8, s); r = launch_winograd_x6_input(x, V, h, w, ci, s); }
+    if (r) return r;
+    { Scope _g(c, 9, s); r = launch_winograd_x6_gemm(V, urec, M, h, w, ci, co, G, gb, s); }
+    if (r) return r;
+    Scope _o(c, 8, s);
+    return launch_winograd_output(M, b, y, 1, h, w, co, flags, s);
+}
+
 // One one-launch Winograd layer inside a fused forward (timed as class 7).
 // (A channel split of the small maps over more blocks -- partial outputs, arrival tickets, the last arriver sums in part order --
 //  was built and measured for one image on the chip: conv5_x 87 -> 84-87 us, conv4_2 227 -> 222 us with 2 parts, slower with 4.
@@ -782,8 +867,8 @@ int run_wino_fused_layer(frcnn_ctx* c, bool /*latency*/, const float* x, const f
 }
 
 struct BlocksTargetScope {
-    explicit BlocksTargetScope(int t, int wino_rows = 0) { conv3x3_set_blocks_target(t); linear_batched_set_tile(wino_rows); }
-    ~BlocksTargetScope() { conv3x3_set_blocks_target(0); linear_batched_set_tile(0); }
+    explicit BlocksTargetScope(int t, int wino_rows = 0, int x6_tiles = 0) { conv3x3_set_blocks_target(t); linear_batched_set_tile(wino_rows); gemm_x6t_set_tiles(x6_tiles); }
+    ~BlocksTargetScope() { conv3x3_set_blocks_target(0); linear_batched_set_tile(0); gemm_x6t_set_tiles(0); }
 };
 }  // namespace
 
@@ -810,11 +895,17 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     if (p->fc_math_mode != FRCNN_FC_F32 && p->fc_math_mode != FRCNN_FC_F32X6) return FRCNN_EINVAL;
     if ((p->roi_op != FRCNN_ROI_POOL && p->roi_op != FRCNN_ROI_ALIGN) || p->roi_sampling_ratio > 2) return FRCNN_EINVAL;
     if (p->winograd_tile_rows != 0 && p->winograd_tile_rows != 64 && p->winograd_tile_rows != 128) return FRCNN_EINVAL;
-    BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows);
+    if (p->x6_gemm_tiles < 0 || p->x6_gemm_tiles > 2) return FRCNN_EINVAL;
+    BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows, p->x6_gemm_tiles);
     const bool x6 = p->math_mode == FRCNN_MATH_F32X6;
     const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
+    if (p->winograd_x6_mask != 0 && (!wino || (p->winograd_x6_mask & ~0x3FFE) != 0)) return FRCNN_EINVAL;
+    int layer_index = 0;        // 1 .. 12 = conv_w[i], 13 = the RPN trunk (frcnn_forward_params.winograd_x6_mask)
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
+        ++layer_index;
+        if (wino && ((p->winograd_x6_mask >> layer_index) & 1))  // x6 Winograd layer: wgt = the record bank (csrc/wino_x6.hip)
+            return run_wino_x6_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
         if (wino && conv3x3_uses_winograd_fused(ci, co)) {     // one launch, no scratch (csrc/winofused.hip); timed as class 7
             return run_wino_fused_layer(c, p->conv_blocks_target == 0, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
         }
@@ -975,7 +1066,8 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     int rc;
     if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
     if (p->winograd_tile_rows != 0 && p->winograd_tile_rows != 64 && p->winograd_tile_rows != 128) return FRCNN_EINVAL;
-    BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows);
+    if (p->x6_gemm_tiles < 0 || p->x6_gemm_tiles > 2) return FRCNN_EINVAL;
+    BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows, p->x6_gemm_tiles);
     if (wino) { rc = ensure_wino_ws(c); if (rc) return rc; }
 #define STEP(cls, call) do { Scope _sc(c, cls, s); rc = (call); } while (0); if (rc) return rc
 
@@ -1000,7 +1092,11 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms; c->last_c = C;
 
     // stage 2: RPN (models/rpn.py:88-153)
-    if (wino && conv3x3_uses_winograd_fused(C, C)) {
+    if (p->winograd_x6_mask != 0 && (!wino || p->winograd_x6_mask != (1 << FRCNN_X6_RPN_TRUNK_BIT))) return FRCNN_EINVAL;
+    if (wino && p->winograd_x6_mask) {
+        rc = run_wino_x6_layer(c, c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU, s);
+        if (rc) return rc;
+    } else if (wino && conv3x3_uses_winograd_fused(C, C)) {
         rc = run_wino_fused_layer(c, p->conv_blocks_target == 0, c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU, s);
         if (rc) return rc;
     } else {

@@ -139,6 +139,27 @@ int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b
 bool linear_x6_shape_ok(int M, int N, int K);
 size_t linear_x6_workspace_bytes(int M, int N, int K);
 int launch_split_rows_x6(const float* a, int lda, void* rec, int R, int rows_out, int K, hipStream_t s);
+// gemm_x6t.hip: batched f32x6 GEMM on tile records, LDS-DMA staged
+int gemm_x6t_row_tile(int M);
+int gemm_x6t_col_tile(int N);
+size_t x6t_record_bytes(int rows_padded, int K);
+int launch_split_rows_x6t(const float* a, int lda, size_t a_batch_floats, void* rec, int R, int rows_padded, int K, int batches, hipStream_t s);
+bool gemm_x6t_shape_ok(int M, int N, int K, int batches);
+size_t gemm_x6t_workspace_bytes(int M, int N, int K, int batches);
+void gemm_x6t_set_tiles(int mode);          // tile choice of the calling thread's next launches: 0 cost model, 1 = 320 x 256, 2 = 160 x 128
+int launch_gemm_x6t(const void* a_rec, int a_rows, size_t a_batch_bytes, const void* b_rec, int b_rows, size_t b_batch_bytes,
+                    const float* bias, float* c, int ldc, size_t c_batch_floats, int M, int N, int K, int batches, unsigned flags,
+                    void* ws, size_t ws_bytes, hipStream_t s);
+// wino_x6.hip: Winograd F(2x2,3x3) layers whose position GEMMs run on gemm_x6t
+bool conv3x3_uses_winograd_x6(int cin, int cout);
+size_t conv3x3_winograd_x6_pack_bytes(int cout, int cin);
+size_t conv3x3_winograd_x6_workspace_bytes(int H, int W, int cin, int cout);
+int launch_pack_conv3x3_winograd_x6(const float* w, const float* scale, void* urec, int cout, int cin, hipStream_t s);
+int launch_winograd_x6_input(const float* x, void* vrec, int H, int W, int cin, hipStream_t s);
+int launch_winograd_x6_gemm(const void* vrec, const void* urec, float* M, int H, int W, int cin, int cout, void* gws, size_t gws_bytes, hipStream_t s);
+int winograd_x6_plan(int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, void** V, float** M, void** G, size_t* g_bytes);
+int launch_conv3x3_winograd_x6(const float* x, const void* urec, const float* b, float* y, int H, int W, int cin, int cout,
+                               unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_linear_x6(const void* a_rec, const void* w_rec, const float* bias, float* y, int ldy, void* y_rec, int M, int N, int K,
                      unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_softmax_rows(const float* x, int ldx, float* y, int M, int ncls, hipStream_t s);

@@ -110,6 +110,7 @@ class FasterRCNNModel(nn.Module):
         self.detector_nms_threshold = 0.3
         self.inflight_conv_blocks_target = 320      # frcnn_forward_params.conv_blocks_target used by predict_async slots
         self.inflight_winograd_tile_rows = 128      # frcnn_forward_params.winograd_tile_rows used by predict_async slots
+        self.inflight_x6_gemm_tiles = 2             # frcnn_forward_params.x6_gemm_tiles used by predict_async slots (160 x 128 tiles)
 
         # arithmetic of the 3x3 convolutions: "f32" = exact f32 MFMA, direct; "f32_winograd" = exact f32 MFMA with the
         # >= 256-channel layers as Winograd F(2x2,3x3) in float32 (2.25x fewer multiplies, fp32 rounding differences
@@ -119,6 +120,13 @@ class FasterRCNNModel(nn.Module):
         # stride-1 3x3 convolutions of layer3 / layer4 are the Winograd layers; there is no f32x6 ResNet path.
         self._math_mode = "f32"
         self.math_mode = "f32_winograd"
+        # per-layer arithmetic table of the f32_winograd mode (round 3): the layers named here run as x6 Winograd layers
+        # (csrc/wino_x6.hip: same float32 transforms, the 16 position GEMMs in the f32x6 arithmetic on the bf16 matrix pipe --
+        # exactly split bf16x3 operands, six bf16 MFMAs per product, f32 accumulation, fp32-class accuracy); every other layer of
+        # the mode stays a one-launch float32 Winograd layer on the exact-f32 pipe.  Default: the seven 512-channel layers of
+        # VGG-16 (frozen from tools/x6t_bench.py's per-layer timings); () = rounds 1-2's behaviour.
+        self._winograd_x6_layers = ()
+        self.winograd_x6_layers = () if self._is_resnet else nv.DEFAULT_X6_LAYERS_VGG16
         # arithmetic of the VGG-16 detector's fc1 / fc2 (models/vgg16.py:130-132): "f32" = exact f32 MFMA; "f32x6" = exactly split
         # bf16x3 operands, six bf16 MFMAs per product, f32 accumulation (csrc/linear_x6.hip) -- fp32-class accuracy (dropped terms
         # <= 2^-24 relative) at 2.67x the matrix-pipe rate; the default wherever it applies (ResNet heads have no fc1 / fc2)
@@ -162,6 +170,30 @@ class FasterRCNNModel(nn.Module):
         self._stage2_region_proposal_network.math_mode = mode
         if self._is_resnet:
             self._stage3_detector_network._pool_to_feature_vector.math_mode = mode
+
+    @property
+    def winograd_x6_layers(self):
+        return self._winograd_x6_layers
+
+    @winograd_x6_layers.setter
+    def winograd_x6_layers(self, names):
+        names = tuple(names)
+        allowed = ("rpn_trunk",) if self._is_resnet else tuple(n for n in nv.X6_LAYER_BITS if n.startswith(("conv4", "conv5", "conv3_2", "conv3_3", "rpn")))
+        for n in names:
+            if n not in allowed:
+                raise ValueError("winograd_x6_layers: %r cannot run as an x6 Winograd layer here (choices: %s)" % (n, ", ".join(allowed)))
+        self._winograd_x6_layers = names
+        if not self._is_resnet:
+            self._stage1_feature_extractor.x6_layers = tuple(n for n in names if n != "rpn_trunk")
+        self._stage2_region_proposal_network.x6_trunk = "rpn_trunk" in names
+
+    def _x6_mask(self):
+        if self._math_mode != "f32_winograd":
+            return 0
+        m = 0
+        for n in self._winograd_x6_layers:
+            m |= 1 << nv.X6_LAYER_BITS[n]
+        return m
 
     @property
     def grad_math(self):
@@ -328,7 +360,8 @@ class FasterRCNNModel(nn.Module):
                                   0 if slot_index == 0 else self.inflight_conv_blocks_target,
                                   nv.FC_MATH_MODES[self._effective_fc_math()],
                                   nv.ROI_OPS[self._stage3_detector_network.pooling], self._stage3_detector_network.sampling_ratio,
-                                  0 if slot_index == 0 else self.inflight_winograd_tile_rows)
+                                  0 if slot_index == 0 else self.inflight_winograd_tile_rows, self._x6_mask(),
+                                  0 if slot_index == 0 else self.inflight_x6_gemm_tiles)
         lib = nv.lib()
         with_det = score_threshold is not None
         fwd, fwd_name = ((lib.frcnn_resnet_forward, "frcnn_resnet_forward") if self._is_resnet

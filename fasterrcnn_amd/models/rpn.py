@@ -68,13 +68,15 @@ class RegionProposalNetwork(nn.Module):
         self._packed_key = None
         self._packed = None
         self.math_mode = "f32"
+        self.x6_trunk = False        # the 3x3 trunk as an x6 Winograd layer (csrc/wino_x6.hip) in the f32_winograd mode
 
     def packed(self):
         params = [p for m in (self._rpn_conv1, self._rpn_class, self._rpn_boxes) for p in (m.weight, m.bias)]
-        key = (self.math_mode,) + rt.param_key(params)
+        trunk_math = "f32_winograd_x6" if (self.math_mode == "f32_winograd" and self.x6_trunk) else self.math_mode
+        key = (trunk_math,) + rt.param_key(params)
         if key != self._packed_key:
             head_w, head_b = pack_stack_rows(self._rpn_class, self._rpn_boxes)
-            self._packed = (pack_conv3x3(self._rpn_conv1, self.math_mode), rt.as_f32_cuda(self._rpn_conv1.bias.detach(), "bias"),
+            self._packed = (pack_conv3x3(self._rpn_conv1, trunk_math), rt.as_f32_cuda(self._rpn_conv1.bias.detach(), "bias"),
                             head_w, head_b)
             self._packed_key = key
         return self._packed

@@ -26,12 +26,23 @@ def pack_conv3x3(conv, math_mode="f32"):
     OIHW weight of a 3x3 nn.Conv2d -> tap-major [9][cout][cin] (or [27][cout] when cin == 3); in the
     "f32x6" math mode -> the exactly split [9][cout][cin/16][hi,mid,lo][16] bf16 layout; in the
     "f32_winograd" mode, for cin >= 64 (% 16) and cout >= 64 (% 64) -> the transformed filters G g G^T in the one-launch
-    kernel's [cin/16][cout/64][16][64][16] order (flat); "f32_winograd_3launch" (tests / experiments) keeps round 1's
+    kernel's [cin/16][cout/64][16][64][16] order (flat); "f32_winograd_x6" (a per-layer choice of the f32_winograd mode, round 3)
+    -> the same bank as x6t records (uint8) for csrc/wino_x6.hip; "f32_winograd_3launch" (tests / experiments) keeps round 1's
     [16][cout][cin] bank of the three-launch form for cin >= 128 and cout >= 256.
     """
     w = conv.weight.detach()
     cout, cin = int(w.shape[0]), int(w.shape[1])
     w = rt.as_f32_cuda(w, "conv weight")
+    if math_mode == "f32_winograd_x6":
+        # x6 Winograd layer (csrc/wino_x6.hip): the transformed filter bank as x6t records, uint8 (dtype marks it)
+        if not nv.uses_winograd_x6(cin, cout):
+            raise ValueError("a %d -> %d 3x3 layer cannot run as an x6 Winograd layer (cin >= 256, cout %% 256 == 0)" % (cin, cout))
+        lib = nv.lib()
+        out = t.empty((int(lib.frcnn_conv3x3_winograd_x6_pack_bytes(cout, cin)),), dtype=t.uint8, device=w.device)
+        with t.cuda.device(w.device):
+            nv.check(lib.frcnn_pack_conv3x3_winograd_x6(nv.ptr(w), None, nv.ptr(out), cout, cin, nv.stream_ptr()),
+                     "frcnn_pack_conv3x3_winograd_x6")
+        return out
     if math_mode == "f32_winograd" and nv.uses_winograd_fused(cin, cout):
         # one-launch Winograd layer (csrc/winofused.hip): [cin/16][cout/64][16][64][16], kept flat (dim() == 1 marks it)
         out = t.empty((16 * cout * cin,), dtype=t.float32, device=w.device)
@@ -67,6 +78,14 @@ def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False):
     oh, ow = (h // 2, w // 2) if pool else (h, w)
     y = t.empty((oh, ow, cout), dtype=t.float32, device=x_hwc.device)
     lib = nv.lib()
+    if wp.dtype == t.uint8:                              # x6 Winograd layer: record bank + scratch (V records, M, split-K partials)
+        flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
+        ws_bytes = int(lib.frcnn_conv3x3_winograd_x6_workspace_bytes(h, w, cin, cout))
+        ws = t.empty((ws_bytes,), dtype=t.uint8, device=x_hwc.device)
+        with t.cuda.device(x_hwc.device):
+            nv.check(lib.frcnn_conv3x3_nhwc_winograd_x6(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
+                                                        nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc_winograd_x6")
+        return y
     if wp.dtype == t.float32 and wp.dim() == 1:          # one-launch Winograd bank
         flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
         with t.cuda.device(x_hwc.device):
@@ -103,6 +122,14 @@ class FeatureExtractor(nn.Module):
         self._packed_key = None
         self._packed = None
         self.math_mode = "f32"
+        self.x6_layers = ()          # names ("conv4_1", ...) of the layers that run as x6 Winograd layers in the f32_winograd mode
+
+    def layer_math(self, i):
+        """Pack / arithmetic kind of layer i in the current mode."""
+        name = "conv%s_%s" % (_LAYERS[i][0][6], _LAYERS[i][0][-1])
+        if self.math_mode == "f32_winograd" and name in self.x6_layers:
+            return "f32_winograd_x6"
+        return self.math_mode
 
     def convs(self):
         return [getattr(self, name) for name, _, _, _ in _LAYERS]
@@ -110,9 +137,10 @@ class FeatureExtractor(nn.Module):
     def packed(self):
         """[(packed_weight, bias)] x 13 on the parameters' device, rebuilt when parameters change."""
         params = [p for c in self.convs() for p in (c.weight, c.bias)]
-        key = (self.math_mode,) + rt.param_key(params)
+        key = (self.math_mode, tuple(sorted(self.x6_layers))) + rt.param_key(params)
         if key != self._packed_key:
-            self._packed = [(pack_conv3x3(c, self.math_mode), rt.as_f32_cuda(c.bias.detach(), "conv bias")) for c in self.convs()]
+            self._packed = [(pack_conv3x3(c, self.layer_math(i)), rt.as_f32_cuda(c.bias.detach(), "conv bias"))
+                            for i, c in enumerate(self.convs())]
             self._packed_key = key
         return self._packed
 

@@ -37,8 +37,9 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 5   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
-                                 5: bf16 gradient GEMMs (the *_math entry points) */
+#define FRCNN_ABI_VERSION 6   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
+                                 5: bf16 gradient GEMMs (the *_math entry points); 6: x6t GEMM, x6 Winograd layers, frcnn_forward_params.winograd_x6_mask,
+                                 timing classes 8 / 9 */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -198,6 +199,43 @@ int frcnn_split_rows_x6(const float* d_a, int lda, void* d_rec, int rows, int ro
 size_t frcnn_linear_x6_workspace_bytes(int M, int N, int K);
 int frcnn_linear_x6(const void* d_a_rec, const void* d_w_rec, const float* d_bias, float* d_y, int ldy, void* d_y_rec,
                     int M, int N, int K, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Round 3: the f32x6 arithmetic as a general batched GEMM on TILE records ("x6t", csrc/gemm_x6t.hip) and the Winograd layers built
+ * on it (csrc/wino_x6.hip).  Replaces the multiply-accumulate of the 512-channel 3x3 convolutions, models/vgg16.py:89-96 and
+ * models/rpn.py:88 (cuDNN fp32 in the reference), with fp32-class accuracy on the bf16 matrix pipe.
+ *
+ * x6t records of a row-major float32 matrix X[R][K], K % 16 == 0, rows padded to `rows_padded` (% 32 == 0):
+ *   [K/16][rows_padded/32][3 = hi, mid, lo][1024 B], 1024 B = [k-half 2][row 32][8 bf16]; x = hi + mid + lo exactly.
+ *   frcnn_x6t_record_bytes(rows_padded, K)  : bytes of one record array
+ *   frcnn_split_rows_x6t                    : [batches][rows][lda] float32 -> [batches] record arrays (rows beyond `rows` zero)
+ *   frcnn_gemm_x6t                          : C_b[m][n] = act(bias[n] + sum_k A_b[m][k] B_b[n][k]), b < batches; A records padded
+ *       to a_rows (% FRCNN_X6T_ROW_TILE == 0, >= M), B records padded to b_rows (% FRCNN_X6T_COL_TILE == 0, >= N); batch strides
+ *       of the record arrays in BYTES (0: shared by all batches), of C in floats; N % 4 == 0, ldc % 4 == 0; deterministic
+ *       (fixed-order split-K when the grid would not cover the chip: d_ws >= frcnn_gemm_x6t_workspace_bytes(M, N, K, batches)).
+ * Winograd F(2x2,3x3) layer in this arithmetic (three launches: input transform + exact split -> 16 batched GEMMs -> output
+ * transform + bias + ReLU + optional fused 2x2 max-pool), NHWC float32 in and out, cin % 16 == 0, cout % 4 == 0:
+ *   frcnn_pack_conv3x3_winograd_x6          : OIHW float32 (optional per-cout scale, as frcnn_pack_conv3x3_winograd) -> the
+ *       transformed filter bank as x6t records, frcnn_conv3x3_winograd_x6_pack_bytes(cout, cin) bytes
+ *   frcnn_conv3x3_nhwc_winograd_x6          : the layer; d_ws >= frcnn_conv3x3_winograd_x6_workspace_bytes(H, W, cin, cout)
+ *   frcnn_conv3x3_uses_winograd_x6(cin,cout): the layers the fused VGG-16 forward runs this way in math mode
+ *       FRCNN_MATH_F32_WINOGRAD when frcnn_forward_params.winograd_x6 != 0 (cin >= 256, cout % 256 == 0).
+ * ---------------------------------------------------------------------------------------- */
+#define FRCNN_X6T_ROW_TILE 320
+#define FRCNN_X6T_COL_TILE 256
+size_t frcnn_x6t_record_bytes(int rows_padded, int K);
+int frcnn_split_rows_x6t(const float* d_a, int lda, size_t a_batch_floats, void* d_rec, int rows, int rows_padded, int K, int batches,
+                         void* stream);
+size_t frcnn_gemm_x6t_workspace_bytes(int M, int N, int K, int batches);
+int frcnn_gemm_x6t(const void* d_a_rec, int a_rows, size_t a_batch_bytes, const void* d_b_rec, int b_rows, size_t b_batch_bytes,
+                   const float* d_bias, float* d_c, int ldc, size_t c_batch_floats, int M, int N, int K, int batches, unsigned flags,
+                   void* d_ws, size_t ws_bytes, void* stream);
+int frcnn_conv3x3_uses_winograd_x6(int cin, int cout);
+size_t frcnn_conv3x3_winograd_x6_pack_bytes(int cout, int cin);
+int frcnn_pack_conv3x3_winograd_x6(const float* d_w_oihw, const float* d_row_scale, void* d_u_rec, int cout, int cin, void* stream);
+size_t frcnn_conv3x3_winograd_x6_workspace_bytes(int H, int W, int cin, int cout);
+int frcnn_conv3x3_nhwc_winograd_x6(const float* d_x, const void* d_u_rec, const float* d_bias, float* d_y, int H, int W, int cin,
+                                   int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
 /* Stand-alone 2x2/stride-2 floor max-pool on NHWC (vgg16.py:78,82,87,92), c % 4 == 0. */
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream);
 
@@ -375,7 +413,17 @@ typedef struct frcnn_forward_params {
     int32_t winograd_tile_rows; /* three-launch Winograd form only (ResNet layer4): row count of the batched GEMM's block tile.  0 = 64 (64 x 128 tiles, five
                                    blocks per CU: best latency for one image on the chip); 128 with many images in flight (the chip
                                    is then at its power limit and the tile with fewer operand bytes per MFMA wins) */
+    int32_t winograd_x6_mask;   /* FRCNN_MATH_F32_WINOGRAD only: bit i set = 3x3 layer i runs as an x6 Winograd layer (csrc/wino_x6.hip: the position
+                                   GEMMs in the f32x6 arithmetic on the bf16 pipe) and its weight pointer is frcnn_pack_conv3x3_winograd_x6's record bank.
+                                   VGG-16: bit i = conv_w[i] (1 .. 12: conv1_2 .. conv5_3), bit 13 = the RPN trunk.  ResNet: bit 13 = the RPN trunk only.
+                                   A set bit on a layer with frcnn_conv3x3_uses_winograd_x6(cin, cout) == 0 is FRCNN_EINVAL.  0 = rounds 1-2's behaviour */
+    int32_t x6_gemm_tiles;      /* block tile of the x6 Winograd layers' batched GEMM (csrc/gemm_x6t.hip): 0 = chosen per shape by the cost model (best
+                                   latency for one image on the chip: 320 x 256 tiles, one 8-wave block per CU, where they cover the chip in one
+                                   round), 1 = 320 x 256 always, 2 = 160 x 128 always (4-wave blocks that leave registers and LDS for a second kernel on
+                                   the CU: with several images in flight the transforms, epilogues and proposal kernels of the other images then
+                                   overlap the GEMM -- measured +3..8 % images/sec at 3 images in flight) */
 } frcnn_forward_params;
+#define FRCNN_X6_RPN_TRUNK_BIT 13
 #define FRCNN_MATH_F32   0
 #define FRCNN_MATH_F32X6 1
 #define FRCNN_MATH_F32_WINOGRAD 2
@@ -556,10 +604,11 @@ int frcnn_ctx_tensor(frcnn_ctx* ctx, int which, void** d_ptr, size_t* bytes);
 /* Per-kernel-class HIP-event timing for bench.py's roofline block: when enabled, every launch
  * of class `k` inside frcnn_vgg16_forward is bracketed by events on the launch stream.
  * classes: 0 conv3x3 MFMA (backbone+RPN), 1 conv first layer, 2 linear MFMA, 3 proposals,
- * 4 roi_pool, 5 other, 6 Winograd input / output transforms, 7 Winograd batched MFMA GEMM (math mode
- * FRCNN_MATH_F32_WINOGRAD).  frcnn_ctx_timing_read synchronises the recorded events and returns
+ * 4 roi_pool, 5 other, 6 Winograd input / output transforms (three-launch float32 form), 7 float32 Winograd MFMA kernels
+ * (wino_fused_kernel; the three-launch form's batched GEMM), 8 x6 Winograd input / output transforms, 9 x6 Winograd batched GEMM
+ * (gemm_x6t_kernel, bf16 pipe).  frcnn_ctx_timing_read synchronises the recorded events and returns
  * accumulated milliseconds and launch counts since the last reset. */
-#define FRCNN_NUM_KCLASS 8
+#define FRCNN_NUM_KCLASS 10
 int frcnn_ctx_timing_enable(frcnn_ctx* ctx, int enable);
 int frcnn_ctx_timing_read(frcnn_ctx* ctx, double ms[FRCNN_NUM_KCLASS], int64_t launches[FRCNN_NUM_KCLASS],
                           int reset);

@@ -1,0 +1,272 @@
+"""
+GPU parity tests of round 3's f32x6 building blocks: the tile-record ("x6t") batched GEMM (csrc/gemm_x6t.hip) and the Winograd
+F(2x2,3x3) layer whose 16 position GEMMs run on it (csrc/wino_x6.hip) -- models/vgg16.py:89-96 (conv4_1 ... conv5_3) and
+models/rpn.py:88 (the RPN trunk) of the reference.
+
+Tolerances: the split is exact (hi + mid + lo == x bit for bit, checked through the record layout); a GEMM against float64 truth is
+no worse than 1.5x the exact-f32 MFMA kernel's own error + 2e-7 of max|y| (the three dropped partial products are <= 2^-24
+relative each) and within 4e-6 sqrt(K); a layer against a float64 convolution is no worse than 1.5x the one-launch float32 Winograd
+layer's error + 2e-7 (VERDICT r2's bar) -- the transforms are the same float32 operations in the same order.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fasterrcnn_amd import _native as nv
+from fasterrcnn_amd.models import vgg16 as V
+
+pytestmark = pytest.mark.gpu
+
+
+def pad_to(n, t):
+    return (n + t - 1) // t * t
+
+
+def split_x6t(a, rows_padded):
+    """(batches, R, K) or (R, K) float32 CUDA -> x6t records (uint8)."""
+    lib = nv.lib()
+    if a.dim() == 2:
+        a = a.unsqueeze(0)
+    a = a.contiguous()
+    nb, r, k = (int(v) for v in a.shape)
+    per = int(lib.frcnn_x6t_record_bytes(rows_padded, k))
+    rec = torch.full((nb * per,), 0xAB, dtype=torch.uint8, device=a.device)
+    nv.check(lib.frcnn_split_rows_x6t(nv.ptr(a), k, r * k, nv.ptr(rec), r, rows_padded, k, nb, nv.stream_ptr()), "split_rows_x6t")
+    return rec, per
+
+
+def records_to_planes(rec, rows_padded, k):
+    """one record array [k/16][rows/32][3][khalf 2][row 32][8] bf16 -> (hi, mid, lo) float32 (rows_padded, k)."""
+    r = rec.cpu().numpy().view(np.uint16).reshape(k // 16, rows_padded // 32, 3, 2, 32, 8)
+    f = (r.astype(np.uint32) << 16).view(np.float32)
+    # -> [term][rb][row][chunk][khalf][8]
+    f = f.transpose(2, 1, 4, 0, 3, 5).reshape(3, rows_padded, k)
+    return f[0], f[1], f[2]
+
+
+def gemm_x6t(a_rec, a_rows, a_stride, b_rec, b_rows, b_stride, bias, m, n, k, batches, relu):
+    lib = nv.lib()
+    c = torch.full((batches, m, n), float("nan"), device="cuda")
+    wsb = int(lib.frcnn_gemm_x6t_workspace_bytes(m, n, k, batches))
+    ws = torch.empty((max(wsb, 4) // 4,), device="cuda")
+    nv.check(lib.frcnn_gemm_x6t(nv.ptr(a_rec), a_rows, a_stride, nv.ptr(b_rec), b_rows, b_stride, nv.ptr(bias), nv.ptr(c), n, m * n,
+                                m, n, k, batches, nv.RELU if relu else 0, nv.ptr(ws), wsb, nv.stream_ptr()), "gemm_x6t")
+    torch.cuda.synchronize()
+    return c
+
+
+def test_x6t_split_is_exact_and_layout_is_the_fragment_image():
+    gen = torch.Generator().manual_seed(1)
+    a = torch.randn((2, 70, 48), generator=gen) * torch.exp(torch.randn((2, 70, 48), generator=gen) * 3)      # wide dynamic range
+    a[0, 0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e-30, 65504.0, 1e-3, 0.1])
+    rec, per = split_x6t(a.cuda(), 96)
+    assert per == 3 * 3 * 3072 and rec.numel() == 2 * per
+    for b in range(2):
+        hi, mid, lo = records_to_planes(rec[b * per:(b + 1) * per], 96, 48)
+        x = a[b].numpy()
+        assert np.array_equal((hi[:70].astype(np.float64) + mid[:70] + lo[:70]).astype(np.float32), x)
+        assert (hi[70:] == 0).all() and (mid[70:] == 0).all() and (lo[70:] == 0).all()
+        assert np.abs(mid[:70]).max() <= np.abs(hi[:70]).max() * 2.0 ** -7
+
+
+@pytest.mark.parametrize("M,N,K,batches,relu", [
+    (2394, 512, 512, 16, False),     # the position GEMMs of conv4_2 / conv4_3: 8 x 2 x 16 = 256 blocks
+    (589, 512, 512, 16, False),      # conv5_x / RPN trunk: split-K fills the chip
+    (300, 4096, 4096, 1, True),      # fc2's shape
+    (137, 260, 80, 3, False),        # ragged M and N, five 16-k stages, batches
+    (1, 4, 16, 1, True),             # one row, one stage
+    (321, 256, 32, 2, False),        # one row more than a tile
+])
+def test_gemm_x6t_against_float64_and_the_exact_f32_kernel(M, N, K, batches, relu):
+    gen = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((batches, M, K), generator=gen) * torch.exp(torch.randn((batches, 1, K), generator=gen))   # per-channel scales
+    w = torch.randn((batches, N, K), generator=gen) * (2.0 / K) ** 0.5
+    b = torch.randn((N,), generator=gen) * 0.1
+    ref = torch.einsum("bmk,bnk->bmn", a.double(), w.double()) + b.double()
+    if relu:
+        ref = ref.clamp(min=0)
+    ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+    a_rows, b_rows = pad_to(M, nv.X6T_ROW_TILE), pad_to(N, nv.X6T_COL_TILE)
+    a_rec, a_per = split_x6t(ad, a_rows)
+    w_rec, w_per = split_x6t(wd, b_rows)
+    c = gemm_x6t(a_rec, a_rows, a_per, w_rec, b_rows, w_per, bd, M, N, K, batches, relu)
+    assert not torch.isnan(c).any()
+    scale = float(ref.abs().max())
+    e6 = float((c.cpu().double() - ref).abs().max()) / scale
+    # the exact-f32 MFMA kernel on the same operands (batch 0)
+    npad = pad_to(N, 128)
+    wpad = torch.zeros((npad, K), device="cuda")
+    wpad[:N] = wd[0]
+    y32 = V.linear(ad[0].contiguous(), wpad, bd, N, relu)
+    e32 = float((y32.cpu().double() - ref[0]).abs().max()) / float(ref[0].abs().max())
+    print("gemm_x6t M=%d N=%d K=%d x%d: max err / max|y| = %.3g (exact-f32 MFMA kernel, batch 0: %.3g)" % (M, N, K, batches, e6, e32))
+    assert e6 <= 1.5 * e32 + 2e-7 and e6 <= 4e-6 * np.sqrt(K)
+    c2 = gemm_x6t(a_rec, a_rows, a_per, w_rec, b_rows, w_per, bd, M, N, K, batches, relu)
+    assert torch.equal(c, c2)                                   # deterministic (fixed-order split-K)
+    if batches > 1:
+        # a shared B operand (batch stride 0)
+        c3 = gemm_x6t(a_rec, a_rows, a_per, w_rec, b_rows, 0, bd, M, N, K, batches, relu)
+        ref3 = torch.einsum("bmk,nk->bmn", a.double(), w[0].double()) + b.double()
+        if relu:
+            ref3 = ref3.clamp(min=0)
+        assert float((c3.cpu().double() - ref3).abs().max()) / float(ref3.abs().max()) <= 1.5 * e32 + 4e-7
+
+
+def test_gemm_x6t_rejects_bad_arguments():
+    lib = nv.lib()
+    s = nv.stream_ptr()
+    x = torch.zeros((1 << 20,), device="cuda")
+    p = nv.ptr(x)
+    assert lib.frcnn_gemm_x6t(None, 320, 0, p, 256, 0, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1
+    assert lib.frcnn_gemm_x6t(p, 300, 0, p, 256, 0, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1      # a_rows % 320
+    assert lib.frcnn_gemm_x6t(p, 320, 0, p, 128, 0, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1      # b_rows % 256
+    assert lib.frcnn_gemm_x6t(p, 320, 0, p, 256, 0, None, p, 256, 0, 8, 256, 40, 1, 0, p, 1 << 22, s) == -4      # K % 16
+    assert lib.frcnn_gemm_x6t(p, 320, 0, p, 256, 0, None, p, 256, 0, 8, 250, 64, 1, 0, p, 1 << 22, s) == -4      # N % 4
+    assert lib.frcnn_x6t_record_bytes(320, 512) == 32 * 10 * 3072 and lib.frcnn_x6t_record_bytes(100, 512) == 0
+    assert lib.frcnn_split_rows_x6t(p, 40, 0, p, 4, 32, 40, 1, s) == -1                                           # K % 16
+
+
+def pack_x6(w_oihw, scale=None):
+    lib = nv.lib()
+    cout, cin = int(w_oihw.shape[0]), int(w_oihw.shape[1])
+    u = torch.full((int(lib.frcnn_conv3x3_winograd_x6_pack_bytes(cout, cin)),), 0xAB, dtype=torch.uint8, device=w_oihw.device)
+    nv.check(lib.frcnn_pack_conv3x3_winograd_x6(nv.ptr(w_oihw), nv.ptr(scale), nv.ptr(u), cout, cin, nv.stream_ptr()), "pack_winograd_x6")
+    return u
+
+
+def run_x6(x, u, b, cout, relu, pool):
+    lib = nv.lib()
+    h, wd, cin = (int(v) for v in x.shape)
+    oh, ow = (h // 2, wd // 2) if pool else (h, wd)
+    y = torch.full((oh, ow, cout), float("nan"), device=x.device)
+    wsb = int(lib.frcnn_conv3x3_winograd_x6_workspace_bytes(h, wd, cin, cout))
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
+    nv.check(lib.frcnn_conv3x3_nhwc_winograd_x6(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), h, wd, cin, cout, flags, nv.ptr(ws), wsb,
+                                                nv.stream_ptr()), "conv_winograd_x6")
+    torch.cuda.synchronize()
+    return y
+
+
+def run_fused_f32(x, w_oihw, b, relu, pool):
+    lib = nv.lib()
+    h, wd, cin = (int(v) for v in x.shape)
+    cout = int(w_oihw.shape[0])
+    oh, ow = (h // 2, wd // 2) if pool else (h, wd)
+    y = torch.full((oh, ow, cout), float("nan"), device=x.device)
+    u = torch.empty((16 * cout * cin,), device=x.device)
+    nv.check(lib.frcnn_pack_conv3x3_winograd_fused(nv.ptr(w_oihw), None, nv.ptr(u), cout, cin, nv.stream_ptr()), "pack_winograd_fused")
+    flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
+    nv.check(lib.frcnn_conv3x3_nhwc_winograd_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), h, wd, cin, cout, flags,
+                                                   nv.stream_ptr()), "conv_winograd_fused")
+    torch.cuda.synchronize()
+    return y
+
+
+def test_x6_filter_bank_is_the_exact_split_of_the_float32_bank():
+    lib = nv.lib()
+    gen = torch.Generator().manual_seed(5)
+    cout, cin = 200, 48
+    w = torch.randn((cout, cin, 3, 3), generator=gen).cuda()
+    scale = (torch.rand((cout,), generator=gen) + 0.5).cuda()
+    for sc in (None, scale):
+        u3 = torch.empty((16, cout, cin), device="cuda")
+        nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w), nv.ptr(sc), nv.ptr(u3), cout, cin, nv.stream_ptr()), "pack_winograd")
+        rec = pack_x6(w, sc)
+        rows = pad_to(cout, nv.X6T_COL_TILE)
+        per = int(lib.frcnn_x6t_record_bytes(rows, cin))
+        assert rec.numel() == 16 * per
+        want, _ = split_x6t(u3, rows)                       # the generic splitter over the float32 bank
+        assert torch.equal(rec, want)
+
+
+@pytest.mark.parametrize("h,w,cin,cout,relu,pool", [
+    (75, 125, 512, 512, True, False),     # conv4_2
+    (75, 125, 256, 512, True, False),     # conv4_1
+    (75, 125, 512, 512, True, True),      # conv4_3 with the fused pool (floor: 37 x 62)
+    (37, 62, 512, 512, True, False),      # block 5 / RPN trunk (split-K GEMM)
+    (9, 11, 256, 256, False, False),      # tiny, odd, no ReLU (negative values must survive)
+    (2, 2, 16, 256, True, True),          # a single tile, a single pooled pixel, one chunk
+    (1, 5, 32, 260, True, False),         # one row; cout not a multiple of the column tile
+    (38, 63, 1024, 1024, True, False),    # ResNet's RPN trunk
+])
+def test_layer_against_float64_and_the_float32_winograd_layer(h, w, cin, cout, relu, pool):
+    gen = torch.Generator().manual_seed(h * 1000 + w + cin)
+    x = torch.randn((h, w, cin), generator=gen) * torch.exp(torch.randn((1, 1, cin), generator=gen))     # per-channel scales
+    wt = torch.randn((cout, cin, 3, 3), generator=gen) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn((cout,), generator=gen) * 0.1
+    ref = F.conv2d(x.permute(2, 0, 1).unsqueeze(0).double(), wt.double(), b.double(), padding=1)
+    if relu:
+        ref = ref.clamp(min=0)
+    if pool:
+        ref = F.max_pool2d(ref, 2)
+    ref = ref[0].permute(1, 2, 0)
+    xd, wd, bd = x.cuda(), wt.cuda(), b.cuda()
+    y = run_x6(xd, pack_x6(wd), bd, cout, relu, pool)
+    assert not torch.isnan(y).any()                               # every output written
+    scale = float(ref.abs().max())
+    e6 = float((y.cpu().double() - ref).abs().max()) / scale
+    if cout % 64 == 0:
+        e32 = float((run_fused_f32(xd, wd, bd, relu, pool).cpu().double() - ref).abs().max()) / scale
+    else:
+        e32 = 1e-6
+    print("winograd x6 %dx%d %d->%d: max err / max|y| = %.3g (float32 one-launch Winograd layer %.3g)" % (h, w, cin, cout, e6, e32))
+    assert e6 <= 1.5 * e32 + 2e-7
+    y2 = run_x6(xd, pack_x6(wd), bd, cout, relu, pool)
+    assert torch.equal(y, y2)
+
+
+def test_layer_impulse_responses_at_corners_and_tile_block_seams():
+    """A single non-zero pixel at image corners and across the 32-tile record blocks / the 320-tile GEMM tiles: catches any
+    mis-addressed record piece, padding row or tile edge."""
+    h, w, cin, cout = 22, 70, 32, 256                              # 11 x 35 = 385 tiles: two GEMM row tiles, 13 record blocks
+    gen = torch.Generator().manual_seed(9)
+    wt = torch.randn((cout, cin, 3, 3), generator=gen) * 0.1
+    b = torch.zeros((cout,))
+    u = pack_x6(wt.cuda())
+    for (py, px) in ((0, 0), (0, w - 1), (h - 1, 0), (h - 1, w - 1), (1, 63), (2, 64), (19, 33), (18, 9), (10, 35)):
+        x = torch.zeros((h, w, cin))
+        x[py, px, (py * 7 + px) % cin] = 1.5
+        ref = F.conv2d(x.permute(2, 0, 1).unsqueeze(0).double(), wt.double(), None, padding=1)[0].permute(1, 2, 0)
+        y = run_x6(x.cuda(), u, b.cuda(), cout, False, False)
+        assert float((y.cpu().double() - ref).abs().max()) <= 1e-6, (py, px)
+
+
+def test_model_layer_table_x6_vs_float32_winograd(gpu_model):
+    """The per-layer arithmetic table of the f32_winograd mode: the default runs the seven 512-channel layers as x6 Winograd layers,
+    `winograd_x6_layers = ()` puts them back on the float32 one-launch kernel.  Same transforms, fp32-class accumulation in both:
+    the feature maps agree to 1e-5 of the largest activation and the proposals are the same rows."""
+    from fasterrcnn_amd import synthetic
+    assert gpu_model.math_mode == "f32_winograd" and gpu_model.winograd_x6_layers == nv.DEFAULT_X6_LAYERS_VGG16
+    img = synthetic.image(0).unsqueeze(0).cuda()
+    out = {}
+    try:
+        for name, layers in (("x6", nv.DEFAULT_X6_LAYERS_VGG16), ("f32", ()), ("mixed", ("conv4_2", "rpn_trunk"))):
+            gpu_model.winograd_x6_layers = layers
+            p, c, d = gpu_model(image_data=img)
+            ctx = gpu_model.context(0)
+            fm = ctx.tensor(0).clone()
+            ctx.timing_enable(True)
+            gpu_model(image_data=img)
+            torch.cuda.synchronize()
+            t = ctx.timing_read(reset=True)
+            ctx.timing_enable(False)
+            out[name] = (p, c, d, fm, t)
+            # the table is honoured: one bf16-pipe GEMM launch (+ at most one split-K reduction) and two transforms per x6 layer
+            n6 = len(layers)
+            assert n6 <= t["winograd_x6_gemm"][1] <= 2 * n6 and t["winograd_x6_transforms"][1] == 2 * n6
+            assert t["winograd_gemm"][1] == 13 - n6
+    finally:
+        gpu_model.winograd_x6_layers = nv.DEFAULT_X6_LAYERS_VGG16
+    for name in ("x6", "mixed"):
+        fm6, fm32 = out[name][3], out["f32"][3]
+        rel = float((fm6 - fm32).abs().max()) / float(fm32.abs().max())
+        p6, p32 = out[name][0].cpu().numpy(), out["f32"][0].cpu().numpy()
+        assert p6.shape == p32.shape
+        d = np.abs(p6[:, None, :] - p32[None, :, :]).max(axis=2).min(axis=0)
+        print("layer table %s vs all-float32 Winograd: feature map %.3g of max, %d/%d proposals within 1e-3 px" % (
+            name, rel, int((d <= 1e-3).sum()), len(d)))
+        assert rel <= 1e-5 and (d <= 1e-3).mean() >= 0.99
+    with pytest.raises(ValueError):
+        gpu_model.winograd_x6_layers = ("conv1_2",)
