@@ -304,6 +304,108 @@ def winograd_chip_full_leg(layers, dev, streams=8, reps=6):
             "ms_per_image_equivalent": round(1e3 * dt / (streams * reps), 4)}
 
 
+def resnet_conv_table(model, h=H, w=W, n_rois=300):
+    """Every convolution of one ResNet image in execution order: (stage, name, kernel family, pipe, executed FLOP, algorithmic FLOP),
+    mirroring the dispatch of csrc/api.hip's run_bottleneck for the model's current modes."""
+    from fasterrcnn_amd.models import resnet as R
+    fe = model._stage1_feature_extractor
+    l4 = model._stage3_detector_network._pool_to_feature_vector
+    wino = model.math_mode == "f32_winograd"
+    rows = []
+    hh, ww = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    rows.append(("backbone", "stem 7x7/s2", "conv7x7_s2_c3_kernel", "valu", 0.0, 2.0 * 147 * 64 * hh * ww))
+    hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+
+    def block(stage, tag, blk, n, hh, ww, x6, single):
+        cin, width, cout, st = blk.conv1.in_channels, blk.conv1.out_channels, blk.conv3.out_channels, blk.stride
+        ho, wo = (hh - 1) // st + 1, (ww - 1) // st + 1
+
+        def one(name, ci, co, px, ok):
+            alg = 2.0 * ci * co * px
+            if x6 and wino and ok:
+                rows.append((stage, tag + name, "gemm_x6t_kernel", "bf16", 6.0 * alg, alg))
+            else:
+                rows.append((stage, tag + name, "conv_gather_mfma_kernel", "f32", alg, alg))
+        one(".conv1", cin, width, n * hh * ww, R.x6_conv1x1_ok(cin, width))
+        alg = 2.0 * 9 * width * width * n * ho * wo
+        if wino and st == 1 and single and width % 64 == 0:
+            rows.append((stage, tag + ".conv2", "wino_fused_kernel", "f32", 2.0 * 16 * ((hh + 1) // 2) * ((ww + 1) // 2) * width * width, alg))
+        elif wino and st == 1 and width >= 256 and width % 128 == 0:
+            rows.append((stage, tag + ".conv2", "linear_mfma_kernel (three-launch Winograd)", "f32",
+                         2.0 * 16 * n * ((hh + 1) // 2) * ((ww + 1) // 2) * width * width, alg))
+        else:
+            rows.append((stage, tag + ".conv2", "conv_gather_mfma_kernel", "f32", alg, alg))
+        if blk.downsample is not None:
+            one(".downsample", cin, cout, n * ho * wo, R.x6_conv1x1_ok(cin, cout))
+        one(".conv3", width, cout, n * ho * wo, R.x6_conv1x1_ok(width, cout))
+        return ho, wo
+
+    seq = fe._feature_extractor
+    for li, layer in ((1, seq[4]), (2, seq[5]), (3, seq[6])):
+        for bi, blk in enumerate(layer):
+            hh, ww = block("backbone", "layer%d.%d" % (li, bi), blk, 1, hh, ww, fe.x6_conv1x1, True)
+    c = 1024
+    alg = 2.0 * 9 * c * c * hh * ww
+    if wino and "rpn_trunk" in model.winograd_x6_layers:
+        rows.append(("rpn", "rpn_trunk", "gemm_x6t_kernel (x6 Winograd layer)", "bf16", 6.0 * 2 * 16 * ((hh + 1) // 2) * ((ww + 1) // 2) * c * c, alg))
+    elif wino:
+        rows.append(("rpn", "rpn_trunk", "wino_fused_kernel", "f32", 2.0 * 16 * ((hh + 1) // 2) * ((ww + 1) // 2) * c * c, alg))
+    else:
+        rows.append(("rpn", "rpn_trunk", "conv3x3_mfma_kernel", "f32", alg, alg))
+    rows.append(("rpn", "rpn_heads_1x1", "linear_mfma_kernel", "f32", 2.0 * c * 45 * hh * ww, 2.0 * c * 45 * hh * ww))
+    h4, w4 = 7, 7
+    for bi, blk in enumerate(l4._layer4):
+        h4, w4 = block("head", "layer4.%d" % bi, blk, n_rois, h4, w4, l4.x6_conv1x1, False)
+    rows.append(("head", "detector_heads", "linear_mfma_kernel", "f32", n_rois * 2.0 * 2048 * 101, n_rois * 2.0 * 2048 * 101))
+    return rows
+
+
+def resnet_roofline_leg(model, image, dev, images=6):
+    """Per-kernel-class HIP-event times of ONE ResNet image at a time (slot 0) against the FLOP each class executes:
+    BASELINE configs[2]'s roofline evidence.  Classes (csrc/api.hip): conv3x3_mfma = the backbone's conv_gather_mfma_kernel launches
+    (exact-f32 pipe), winograd_gemm = wino_fused_kernel (backbone 3x3 + RPN trunk, exact-f32 pipe), linear_mfma = the head's float32
+    launches (layer4's gather / three-launch Winograd convolutions + the RPN / detector heads), x6_gemm = gemm_x6t_kernel (bf16 pipe)."""
+    for _ in range(2):
+        model.predict(image, score_threshold=0.05)
+    ctx = model.context(0)
+    ctx.timing_enable(True)
+    per = []
+    for _ in range(images):
+        model.predict(image, score_threshold=0.05)
+        torch.cuda.synchronize(dev)
+        per.append(ctx.timing_read(reset=True))
+    ctx.timing_enable(False)
+    med = {k: sorted(t[k][0] for t in per)[len(per) // 2] for k in per[0]}
+    launches = {k: per[0][k][1] for k in per[0]}
+    table = resnet_conv_table(model)
+    by = {"conv3x3_mfma": 0.0, "winograd_gemm": 0.0, "linear_mfma": 0.0, "winograd_x6_gemm": 0.0}
+    for stage, name, kern, pipe, ex, alg in table:
+        if kern.startswith("gemm_x6t"):
+            by["winograd_x6_gemm"] += ex
+        elif kern.startswith("wino_fused"):
+            by["winograd_gemm"] += ex
+        elif stage == "backbone" and kern.startswith("conv_gather"):
+            by["conv3x3_mfma"] += ex
+        elif pipe == "f32":
+            by["linear_mfma"] += ex
+    out = {"regime": "HIP events around every launch, one image at a time on one stream, median image of %d" % images,
+           "ms_per_image_by_class": {k: round(v, 4) for k, v in med.items()}, "launches_by_class": launches, "classes": {}}
+    for cls, peak, unit in (("conv3x3_mfma", PEAK_F32_MFMA_TFLOPS, "f32"), ("winograd_gemm", PEAK_F32_MFMA_TFLOPS, "f32"),
+                            ("linear_mfma", PEAK_F32_MFMA_TFLOPS, "f32"), ("winograd_x6_gemm", PEAK_BF16_MFMA_TFLOPS, "bf16")):
+        if med.get(cls, 0.0) > 0 and by[cls] > 0:
+            ach = by[cls] / (med[cls] / 1e3) / 1e12
+            out["classes"][cls] = {"pipe": unit, "executed_gflop_per_image": round(by[cls] / 1e9, 2), "ms_per_image": round(med[cls], 4),
+                                   "achieved_tflops": round(ach, 2), "peak": peak, "frac": round(ach / peak, 4)}
+    dom = max(out["classes"], key=lambda k: out["classes"][k]["ms_per_image"]) if out["classes"] else None
+    kernel_of = {"conv3x3_mfma": "conv_gather_mfma_kernel (backbone 1x1 / strided convolutions, exact-f32 pipe)",
+                 "winograd_gemm": "wino_fused_kernel (backbone 3x3 + RPN trunk)", "linear_mfma": "the head's float32 launches",
+                 "winograd_x6_gemm": "gemm_x6t_kernel (layer4's 1x1 convolutions, f32x6 on the bf16 pipe)"}
+    if dom:
+        out.update({"kernel": kernel_of[dom], "bound": "mfma", "achieved": out["classes"][dom]["achieved_tflops"], "peak": out["classes"][dom]["peak"],
+                    "unit": "TFLOP/s", "frac": out["classes"][dom]["frac"], "traffic": measured_traffic("conv_gather_mfma_kernel")})
+    return out
+
+
 def planted_ground_truth(seed, det, num_classes=21):
     """Synthetic GT for image `seed`: seeded random boxes plus up to 3 of the image's own top
     detections jittered by a few pixels (so mAP@0.5 is neither 0 nor 1)."""
@@ -542,7 +644,24 @@ def main():
         run50(16)
         dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
         extra["resnet50_images_per_sec"] = round(args.steps / dt, 3)
-        extra["resnet50_config"] = "ResNet-50 predict(), 3x600x1000, 8 batch-1 images in flight, math %s" % m50.math_mode
+        extra["resnet50_config"] = ("ResNet-50 predict(), 3x600x1000, 8 batch-1 images in flight, math %s, x6_conv1x1=%s (the 1x1 convolutions of "
+                                    "layer4 as f32x6 GEMMs on the bf16 pipe; every golden proposal / detection reproduced), winograd_x6_layers=%s"
+                                    % (m50.math_mode, m50.x6_conv1x1, list(m50.winograd_x6_layers)))
+        # the same with every eligible 1x1 convolution (layer2 / layer3 too) and the RPN trunk on the bf16 pipe: faster, and a few
+        # near-tied RPN candidates swap at the NMS cut (296 / 300 golden proposals: tests/test_resnet_gpu.py::test_resnet50_x6_modes)
+        m50.x6_conv1x1, m50.winograd_x6_layers = "all", ("rpn_trunk",)
+        run50(16)
+        dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
+        extra["resnet50_x6_all_images_per_sec"] = round(args.steps / dt, 3)
+        m50.x6_conv1x1, m50.winograd_x6_layers = "off", ()
+        run50(16)
+        dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
+        extra["resnet50_all_f32_pipe_images_per_sec"] = round(args.steps / dt, 3)
+        m50.x6_conv1x1, m50.winograd_x6_layers = "head", ()
+        try:
+            extra["resnet50_roofline"] = resnet_roofline_leg(m50, pool50[0], dev)
+        except Exception as e:
+            extra["resnet50_roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         del m50, pool50
         # (3) the train step (row f3): the reference's fp32 RoIPool step, and configs[4]'s single-GPU form (bf16 gradient GEMMs, RoIAlign)
         extra["train_step_ms"] = {}
@@ -586,7 +705,7 @@ def main():
             timing[k] = (med * n_img, sum(t[k][1] for t in per_image))     # (median image x images, launches)
         def mfma_roofline(kernel, cls, layer_flops, note):
             ms, launches = timing[cls]
-            if not launches:
+            if not launches or not layer_flops:
                 return None
             per_launch = float(sum(layer_flops)) / len(layer_flops)
             avg_s = (ms / 1e3) / launches

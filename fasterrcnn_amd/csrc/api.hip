@@ -42,6 +42,8 @@ struct frcnn_ctx {
     void* conv_ws = nullptr; size_t conv_ws_bytes = 0;   // split-K partials of under-filled conv layers
     void* wino_ws = nullptr; size_t wino_ws_bytes = 0;   // V and M of the Winograd layers; allocated by the first forward that needs it
     void* wx_ws = nullptr; size_t wx_ws_bytes = 0;       // V records, M and split-K partials of the x6 Winograd layers; allocated on first use
+    void* rx_rec = nullptr; size_t rx_rec_bytes = 0;     // activation records of the x6 1x1 convolutions (ResNet bottlenecks); on first use
+    void* rx_ws = nullptr; size_t rx_ws_bytes = 0;       // their split-K partials
     float* res_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // ResNet bottleneck rotation
     size_t res_buf_floats = 0;
     int last_c = 512, last_vec = 4096;
@@ -280,12 +282,18 @@ int frcnn_split_rows_x6t(const float* d_a, int lda, size_t a_batch_floats, void*
 size_t frcnn_gemm_x6t_workspace_bytes(int M, int N, int K, int batches) { return gemm_x6t_workspace_bytes(M, N, K, batches); }
 
 int frcnn_gemm_x6t(const void* d_a_rec, int a_rows, size_t a_batch_bytes, const void* d_b_rec, int b_rows, size_t b_batch_bytes,
-                   const float* d_bias, float* d_c, int ldc, size_t c_batch_floats, int M, int N, int K, int batches, unsigned flags,
-                   void* d_ws, size_t ws_bytes, void* stream)
+                   const float* d_bias, const float* d_residual, float* d_c, int ldc, size_t c_batch_floats, int M, int N, int K,
+                   int batches, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
 {
     if (!d_a_rec || !d_b_rec || !d_c) return FRCNN_EINVAL;
-    return launch_gemm_x6t(d_a_rec, a_rows, a_batch_bytes, d_b_rec, b_rows, b_batch_bytes, d_bias, d_c, ldc, c_batch_floats, M, N, K,
-                           batches, flags, d_ws, ws_bytes, as_stream(stream));
+    return launch_gemm_x6t(d_a_rec, a_rows, a_batch_bytes, d_b_rec, b_rows, b_batch_bytes, d_bias, d_residual, d_c, ldc, c_batch_floats,
+                           M, N, K, batches, flags, d_ws, ws_bytes, as_stream(stream));
+}
+
+int frcnn_split_pixels_x6t(const float* d_x, void* d_rec, int N, int H, int W, int C, int stride, int rows_padded, void* stream)
+{
+    if (!d_x || !d_rec) return FRCNN_EINVAL;
+    return launch_split_pixels_x6t(d_x, d_rec, N, H, W, C, stride, rows_padded, as_stream(stream));
 }
 
 int frcnn_conv3x3_uses_winograd_x6(int cin, int cout) { return conv3x3_uses_winograd_x6(cin, cout) ? 1 : 0; }
@@ -724,10 +732,12 @@ void frcnn_ctx_destroy(frcnn_ctx* ctx)
     if (ctx->slab) (void)hipFree(ctx->slab);
     if (ctx->wino_ws) (void)hipFree(ctx->wino_ws);
     if (ctx->wx_ws) (void)hipFree(ctx->wx_ws);
+    if (ctx->rx_rec) (void)hipFree(ctx->rx_rec);
+    if (ctx->rx_ws) (void)hipFree(ctx->rx_ws);
     delete ctx;
 }
 
-size_t frcnn_ctx_bytes(const frcnn_ctx* ctx) { return ctx ? ctx->slab_bytes + ctx->wino_ws_bytes + ctx->wx_ws_bytes : 0; }
+size_t frcnn_ctx_bytes(const frcnn_ctx* ctx) { return ctx ? ctx->slab_bytes + ctx->wino_ws_bytes + ctx->wx_ws_bytes + ctx->rx_rec_bytes + ctx->rx_ws_bytes : 0; }
 
 int frcnn_ctx_timing_enable(frcnn_ctx* ctx, int enable)
 {
@@ -990,6 +1000,37 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
 
 // ---- fused ResNet forward ----------------------------------------------------------------------
 namespace {
+// One 1x1 convolution (stride 1 or 2) of a bottleneck as an f32x6 GEMM: y[N Ho Wo][cout] = act(bias + residual + x_pixels . w^T).
+// The activation records live in the ctx's rx_rec scratch (grown on demand: hipMalloc synchronises, first image of a shape only).
+int run_conv1x1_x6(frcnn_ctx* c, const float* x, const void* wrec, const float* bias, const float* residual, float* y, int N, int h,
+                   int w, int cin, int cout, int stride, unsigned flags, int cls, hipStream_t s)
+{
+    if (cin % 16 != 0 || cout % 4 != 0) return FRCNN_EINVAL;
+    const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+    const long long rows = (long long)N * ho * wo;
+    if (rows > 0x7fffffffLL / 8) return FRCNN_EINVAL;
+    const int M = (int)rows;
+    const int Mp = cdiv(M, gemm_x6t_row_tile(M)) * gemm_x6t_row_tile(M), Np = cdiv(cout, gemm_x6t_col_tile(cout)) * gemm_x6t_col_tile(cout);
+    const size_t need = x6t_record_bytes(Mp, cin), gneed = gemm_x6t_workspace_bytes(M, cout, cin, 1);
+    if (need > c->rx_rec_bytes) {
+        if (c->rx_rec) { FRCNN_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(c->rx_rec); c->rx_rec = nullptr; c->rx_rec_bytes = 0; }
+        hipError_t e = hipMalloc(&c->rx_rec, need);
+        if (e != hipSuccess) { set_hip_error(e); c->rx_rec = nullptr; return FRCNN_ENOMEM; }
+        c->rx_rec_bytes = need;
+    }
+    if (gneed > c->rx_ws_bytes) {
+        if (c->rx_ws) { FRCNN_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(c->rx_ws); c->rx_ws = nullptr; c->rx_ws_bytes = 0; }
+        hipError_t e = hipMalloc(&c->rx_ws, gneed);
+        if (e != hipSuccess) { set_hip_error(e); c->rx_ws = nullptr; return FRCNN_ENOMEM; }
+        c->rx_ws_bytes = gneed;
+    }
+    int rc;
+    { Scope _t(c, 8, s); rc = launch_split_pixels_x6t(x, c->rx_rec, N, h, w, cin, stride, Mp, s); }
+    if (rc) return rc;
+    Scope _g(c, cls, s);
+    return launch_gemm_x6t(c->rx_rec, Mp, 0, wrec, Np, 0, bias, residual, y, cout, 0, M, cout, cin, 1, flags, c->rx_ws, c->rx_ws_bytes, s);
+}
+
 // One Bottleneck (torchvision v1.5): out = relu(conv3(relu(conv2(relu(conv1(x))))) + identity).
 // x: [N][h][w][cin] in `cur`; returns the buffer index holding the output, updates h, w.
 int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& h, int& w, int cur,
@@ -1009,7 +1050,13 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
     const size_t need1 = (size_t)N * h * w * b.width, need2 = (size_t)N * ho * wo * b.cout;
     if (need1 > c->res_buf_floats || need2 > c->res_buf_floats) return FRCNN_EINVAL;
 #define RSTEP(call) do { Scope _sc(c, cls_conv, s); rc = (call); } while (0); if (rc) return rc
-    RSTEP(launch_conv_gather(X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s));
+    if (b.x6_mask != 0 && !wino) return FRCNN_EINVAL;
+    if (b.x6_mask & FRCNN_X6_CONV1) {
+        rc = run_conv1x1_x6(c, X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, R, 9, s);
+        if (rc) return rc;
+    } else {
+        RSTEP(launch_conv_gather(X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s));
+    }
     if (wino && resnet_block_uses_winograd_fused(N, b.width, b.stride)) {
         rc = run_wino_fused_layer(c, latency, T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s);
         if (rc) return rc;
@@ -1024,14 +1071,24 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
     }
     const float* identity = X;
     if (b.wd) {
-        RSTEP(launch_conv_gather(X, b.wd, b.bd, nullptr, ID, N, h, w, b.cin, b.cout, 1, b.stride, 0, 0u,
-                                 c->conv_ws, c->conv_ws_bytes, s));
+        if (b.x6_mask & FRCNN_X6_DOWN) {
+            rc = run_conv1x1_x6(c, X, b.wd, b.bd, nullptr, ID, N, h, w, b.cin, b.cout, b.stride, 0u, 9, s);
+            if (rc) return rc;
+        } else {
+            RSTEP(launch_conv_gather(X, b.wd, b.bd, nullptr, ID, N, h, w, b.cin, b.cout, 1, b.stride, 0, 0u,
+                                     c->conv_ws, c->conv_ws_bytes, s));
+        }
         identity = ID;
     } else if (b.cin != b.cout || b.stride != 1) {
         return FRCNN_EINVAL;
     }
-    RSTEP(launch_conv_gather(T2, b.w3, b.b3, identity, OUT, N, ho, wo, b.width, b.cout, 1, 1, 0, R,
-                             c->conv_ws, c->conv_ws_bytes, s));
+    if (b.x6_mask & FRCNN_X6_CONV3) {
+        rc = run_conv1x1_x6(c, T2, b.w3, b.b3, identity, OUT, N, ho, wo, b.width, b.cout, 1, R, 9, s);
+        if (rc) return rc;
+    } else {
+        RSTEP(launch_conv_gather(T2, b.w3, b.b3, identity, OUT, N, ho, wo, b.width, b.cout, 1, 1, 0, R,
+                                 c->conv_ws, c->conv_ws_bytes, s));
+    }
 #undef RSTEP
     h = ho; w = wo;
     *out_idx = f[3];

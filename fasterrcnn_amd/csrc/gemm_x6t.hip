@@ -100,12 +100,42 @@ void split_rows_x6t_kernel(const float* __restrict__ a, int lda, size_t a_batch,
     *reinterpret_cast<uint4*>(dst + 2 * GX_PIECE) = pl;
 }
 
+// NHWC [N][H][W][C] -> x6t records of the [N Ho Wo][C] matrix of its pixels taken with `stride` in y and x (a 1x1 convolution's A
+// operand; stride 2 = the downsample / strided 1x1 convolutions of models/resnet.py's bottlenecks).  Waves as split_rows_x6t_kernel;
+// consecutive waves = consecutive chunks of one row block, so a pixel's channels are read in 64-byte runs.
+__global__ __launch_bounds__(256)
+void split_pixels_x6t_kernel(const float* __restrict__ x, unsigned char* __restrict__ rec, int H, int W, int Ho, int Wo, int C, int stride,
+                             int R, int rbt, int K16)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= (long long)K16 * rbt) return;
+    const int chunk = (int)(wave % K16), rb = (int)(wave / K16);
+    const int row = rb * 32 + (lane & 31), k = chunk * 16 + 8 * (lane >> 5);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (row < R) {
+        const int n = row / (Ho * Wo), rem = row - n * (Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const float* src = x + (((size_t)n * H + (size_t)oy * stride) * W + (size_t)ox * stride) * C + k;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+    }
+    uint4 ph, pm, pl;
+    gx_split8(v, ph, pm, pl);
+    unsigned char* dst = rec + ((size_t)chunk * rbt + rb) * GX_RB + lane * 16;
+    *reinterpret_cast<uint4*>(dst) = ph;
+    *reinterpret_cast<uint4*>(dst + GX_PIECE) = pm;
+    *reinterpret_cast<uint4*>(dst + 2 * GX_PIECE) = pl;
+}
+
 struct GxParams {
     const unsigned char* a;     // A records: [batch][chunk][a_rbt][3][1 KB]
     const unsigned char* b;     // B records: [batch][chunk][b_rbt][3][1 KB]
     float* c;                   // C [batch][M][ldc]            (splits == 1)
     float* ws;                  // partials [split][batch][M][N] (splits > 1)
     const float* bias;          // per n, may be NULL (splits == 1 only)
+    const float* residual;      // [batch][M][ldc] like C, added before the activation, may be NULL (splits == 1 only)
     size_t a_batch, b_batch, c_batch;       // bytes, bytes, floats
     int a_rbt, b_rbt;           // row blocks per chunk of the record arrays
     int M, N, ldc;              // valid rows / columns, C row stride in floats
@@ -298,6 +328,8 @@ void gemm_x6t_kernel(const GxParams p)
                 if (n >= p.N) continue;                     // N % 4 == 0: a group of four is inside or outside as a whole
                 f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (direct && p.bias != nullptr) v = v + *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (direct && p.residual != nullptr)
+                    v = v + *reinterpret_cast<const f32x4*>(p.residual + (size_t)batch * p.c_batch + (size_t)m * ldd + n);
                 if (direct && p.relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -319,10 +351,10 @@ void gemm_x6t_kernel(const GxParams p)
 #endif
 }
 
-// c[b][m][n] = act(bias[n] + sum_z ws[z][b][m][n]) in fixed z order (deterministic).  One thread = 4 consecutive n.
+// c[b][m][n] = act(bias[n] + residual[b][m][n] + sum_z ws[z][b][m][n]) in fixed z order (deterministic).  One thread = 4 consecutive n.
 __global__ __launch_bounds__(256)
-void gemm_x6t_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias, float* __restrict__ c, int ldc, size_t c_batch,
-                            int M, int N, int batches, int splits, int relu)
+void gemm_x6t_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias, const float* __restrict__ residual,
+                            float* __restrict__ c, int ldc, size_t c_batch, int M, int N, int batches, int splits, int relu)
 {
     const int q4 = N >> 2;
     const size_t per_batch = (size_t)M * q4, total = per_batch * batches, plane = (size_t)batches * M * N;
@@ -334,6 +366,7 @@ void gemm_x6t_reduce_kernel(const float* __restrict__ ws, const float* __restric
         f32x4 v = *reinterpret_cast<const f32x4*>(ws + off);
         for (int z = 1; z < splits; ++z) v = v + *reinterpret_cast<const f32x4*>(ws + (size_t)z * plane + off);
         if (bias != nullptr) v = v + *reinterpret_cast<const f32x4*>(bias + n);
+        if (residual != nullptr) v = v + *reinterpret_cast<const f32x4*>(residual + (size_t)b * c_batch + (size_t)m * ldc + n);
         if (relu) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -358,6 +391,18 @@ int launch_split_rows_x6t(const float* a, int lda, size_t a_batch_floats, void* 
     if (blocks > 0x7fffffffLL) return FRCNN_EINVAL;
     hipLaunchKernelGGL(split_rows_x6t_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, lda, a_batch_floats,
                        static_cast<unsigned char*>(rec), R, rows_padded / 32, K / 16, batches);
+    return check_launch();
+}
+
+int launch_split_pixels_x6t(const float* x, void* rec, int N, int H, int W, int C, int stride, int rows_padded, hipStream_t s)
+{
+    if (N < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || stride < 1 || stride > 2 || rows_padded % 32 != 0) return FRCNN_EINVAL;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long long R = (long long)N * Ho * Wo;
+    if (R > rows_padded || R > 0x7fffffffLL) return FRCNN_EINVAL;
+    const long long waves = (long long)(C / 16) * (rows_padded / 32);
+    hipLaunchKernelGGL(split_pixels_x6t_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, static_cast<unsigned char*>(rec), H, W,
+                       Ho, Wo, C, stride, (int)R, rows_padded / 32, C / 16);
     return check_launch();
 }
 
@@ -412,11 +457,11 @@ size_t gemm_x6t_workspace_bytes(int M, int N, int K, int batches)
     return need;
 }
 
-// a_rec: records of A [batches][M][K] with rows padded to a_rows (multiple of 320, >= M); b_rec: records of B [batches][N][K] with rows
+// C_b = act(bias + residual_b + A_b B_b^T).  a_rec: records of A [batches][M][K] with rows padded to a_rows (multiple of 320, >= M); b_rec: records of B [batches][N][K] with rows
 // padded to b_rows (multiple of 256, >= N); batch strides in BYTES (0 = the operand is shared by every batch).
 int launch_gemm_x6t(const void* a_rec, int a_rows, size_t a_batch_bytes, const void* b_rec, int b_rows, size_t b_batch_bytes,
-                    const float* bias, float* c, int ldc, size_t c_batch_floats, int M, int N, int K, int batches, unsigned flags,
-                    void* ws, size_t ws_bytes, hipStream_t s)
+                    const float* bias, const float* residual, float* c, int ldc, size_t c_batch_floats, int M, int N, int K, int batches,
+                    unsigned flags, void* ws, size_t ws_bytes, hipStream_t s)
 {
     if (!gemm_x6t_shape_ok(M, N, K, batches)) return FRCNN_EUNSUPPORTED;
     if (!a_rec || !b_rec || !c || a_rows % 320 != 0 || a_rows < M || b_rows % 256 != 0 || b_rows < N || ldc < N || ldc % 4 != 0)
@@ -429,6 +474,7 @@ int launch_gemm_x6t(const void* a_rec, int a_rows, size_t a_batch_bytes, const v
     p.c = c;
     p.ws = static_cast<float*>(ws);
     p.bias = bias;
+    p.residual = residual;
     p.a_batch = a_batch_bytes; p.b_batch = b_batch_bytes; p.c_batch = c_batch_floats;
     p.a_rbt = a_rows / 32; p.b_rbt = b_rows / 32;
     p.M = M; p.N = N; p.ldc = ldc;
@@ -454,8 +500,8 @@ int launch_gemm_x6t(const void* a_rec, int a_rows, size_t a_batch_bytes, const v
     const size_t n4 = (size_t)batches * M * (N / 4);
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gemm_x6t_reduce_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(ws), bias, c, ldc,
-                       c_batch_floats, M, N, batches, pl.splits, p.relu);
+    hipLaunchKernelGGL(gemm_x6t_reduce_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(ws), bias, residual, c,
+                       ldc, c_batch_floats, M, N, batches, pl.splits, p.relu);
     return check_launch();
 }
 

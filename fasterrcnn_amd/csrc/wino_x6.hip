@@ -237,7 +237,7 @@ int launch_winograd_x6_gemm(const void* vrec, const void* urec, float* M, int H,
                             hipStream_t s)
 {
     const int T = cdiv(H, 2) * cdiv(W, 2), Tp = wx_tiles_padded(T), Np = wx_cout_padded(cout);
-    return launch_gemm_x6t(vrec, Tp, x6t_record_bytes(Tp, cin), urec, Np, x6t_record_bytes(Np, cin), nullptr, M, cout,
+    return launch_gemm_x6t(vrec, Tp, x6t_record_bytes(Tp, cin), urec, Np, x6t_record_bytes(Np, cin), nullptr, nullptr, M, cout,
                            (size_t)T * cout, T, cout, cin, 16, 0u, gws, gws_bytes, s);
 }
 

@@ -124,7 +124,15 @@ class FasterRCNNModel(nn.Module):
         # (csrc/wino_x6.hip: same float32 transforms, the 16 position GEMMs in the f32x6 arithmetic on the bf16 matrix pipe --
         # exactly split bf16x3 operands, six bf16 MFMAs per product, f32 accumulation, fp32-class accuracy); every other layer of
         # the mode stays a one-launch float32 Winograd layer on the exact-f32 pipe.  Default: the seven 512-channel layers of
-        # VGG-16 (frozen from tools/x6t_bench.py's per-layer timings); () = rounds 1-2's behaviour.
+        # VGG-16 (frozen from tools/x6t_bench.py's per-layer timings), the 1024-channel RPN trunk of the ResNets;
+        # () = rounds 1-2's behaviour.
+        # ResNet: the 1x1 convolutions of the bottlenecks with resnet.x6_conv1x1_ok(cin, cout) (layer2's reductions, layer3, layer4)
+        # as f32x6 GEMMs on the bf16 pipe (csrc/gemm_x6t.hip) in the f32_winograd mode: "head" (default) = the per-RoI layer4 only,
+        # "all" = layer2 / layer3 as well (faster; the backbone's rounding then differs at the 1e-6 level from the float32 kernels and
+        # a few near-tied RPN candidates swap at the NMS cut: 296 instead of 300 of the reference's proposals on the 600 x 1000
+        # ResNet-50 fixture), "off" = rounds 1-2's exact-f32 gather kernel everywhere
+        self._x6_conv1x1 = "off"
+        self.x6_conv1x1 = "head" if self._is_resnet else "off"
         self._winograd_x6_layers = ()
         self.winograd_x6_layers = () if self._is_resnet else nv.DEFAULT_X6_LAYERS_VGG16
         # arithmetic of the VGG-16 detector's fc1 / fc2 (models/vgg16.py:130-132): "f32" = exact f32 MFMA; "f32x6" = exactly split
@@ -170,6 +178,25 @@ class FasterRCNNModel(nn.Module):
         self._stage2_region_proposal_network.math_mode = mode
         if self._is_resnet:
             self._stage3_detector_network._pool_to_feature_vector.math_mode = mode
+
+    @property
+    def x6_conv1x1(self):
+        return self._x6_conv1x1
+
+    @x6_conv1x1.setter
+    def x6_conv1x1(self, mode):
+        """ "off" | "head" | "all" (False / True are accepted as "off" / "all"): which bottleneck 1x1 convolutions run as f32x6 GEMMs.
+        "head" = layer4 only (the per-RoI detector head: class scores and box deltas, continuous outputs);  "all" adds layer2 / layer3
+        of the feature extractor, whose 1e-6-level rounding differences can swap near-tied RPN candidates at the NMS cut."""
+        mode = {False: "off", True: "all", None: "off"}.get(mode, mode)
+        if mode not in ("off", "head", "all"):
+            raise ValueError("x6_conv1x1 must be 'off', 'head' or 'all'")
+        if mode != "off" and not self._is_resnet:
+            raise NotImplementedError("x6_conv1x1 applies to the ResNet bottlenecks (VGG-16 has no 1x1 convolutions besides the RPN heads)")
+        self._x6_conv1x1 = mode
+        if self._is_resnet:
+            self._stage1_feature_extractor.x6_conv1x1 = mode == "all"
+            self._stage3_detector_network._pool_to_feature_vector.x6_conv1x1 = mode in ("head", "all")
 
     @property
     def winograd_x6_layers(self):
@@ -271,6 +298,7 @@ class FasterRCNNModel(nn.Module):
                 for k in ("w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd"):
                     setattr(bw, k, None if b[k] is None else b[k].data_ptr())
                 bw.cin, bw.width, bw.cout, bw.stride = b["cin"], b["width"], b["cout"], b["stride"]
+                bw.x6_mask = int(b.get("x6_mask", 0))
             w.rpn_conv_w, w.rpn_conv_b, w.rpn_head_w, w.rpn_head_b = (x.data_ptr() for x in s2)
             w.head_w, w.head_b = (x.data_ptr() for x in hd)
             w.num_classes = self._num_classes

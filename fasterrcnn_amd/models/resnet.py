@@ -119,9 +119,28 @@ def fold_conv_bn_winograd(conv, bn, fused=False):
     return u, shift, args + [scale]
 
 
-def pack_block(block, math_mode="f32", single_map=False):
+def x6_conv1x1_ok(cin, cout):
+    """The 1x1 convolutions worth running as f32x6 GEMMs (csrc/gemm_x6t.hip): enough reduction depth for the 16-k stages to
+    amortise a block's prologue / epilogue and enough output channels to fill a 128-column tile.  layer1's 64-channel
+    convolutions and layer2's 128 -> 512 expansions stay on the exact-f32 gather kernel."""
+    return cin % 16 == 0 and cout % 4 == 0 and cin >= 256 and cout >= 128
+
+
+def records_x6t(wp, cout, cin):
+    """folded float32 [1][cout][cin] pack of a 1x1 convolution -> the x6t records of the [cout][cin] matrix (uint8)."""
+    lib = nv.lib()
+    rows = (cout + nv.X6T_COL_TILE - 1) // nv.X6T_COL_TILE * nv.X6T_COL_TILE
+    rec = t.empty((int(lib.frcnn_x6t_record_bytes(rows, cin)),), dtype=t.uint8, device=wp.device)
+    with t.cuda.device(wp.device):
+        nv.check(lib.frcnn_split_rows_x6t(nv.ptr(wp), cin, 0, nv.ptr(rec), cout, rows, cin, 1, nv.stream_ptr()), "frcnn_split_rows_x6t")
+    return rec
+
+
+def pack_block(block, math_mode="f32", single_map=False, x6=False):
     """dict of packed tensors + shape info for one Bottleneck.  single_map: the block runs on ONE map (layer1..3 of the feature
-    extractor) -> its 3x3 is a one-launch Winograd layer in the f32_winograd mode; the per-RoI maps of layer4 use the batched form."""
+    extractor) -> its 3x3 is a one-launch Winograd layer in the f32_winograd mode; the per-RoI maps of layer4 use the batched form.
+    x6 (f32_winograd mode only): the 1x1 convolutions with x6_conv1x1_ok() carry x6t record arrays instead of float32 packs
+    (`x6_mask` bits FRCNN_X6_CONV1 / _CONV3 / _DOWN) and run as f32x6 GEMMs on the bf16 pipe."""
     w1, b1, k1 = fold_conv_bn(block.conv1, block.bn1)
     width = block.conv2.out_channels
     if math_mode == "f32_winograd" and nv.resnet_block_uses_winograd_fused(1 if single_map else 2, width, block.stride):
@@ -137,6 +156,12 @@ def pack_block(block, math_mode="f32", single_map=False):
     if block.downsample is not None:
         out["wd"], out["bd"], kd = fold_conv_bn(block.downsample[0], block.downsample[1])
         out["keep"].append(kd)
+    out["x6_mask"] = 0
+    if x6 and math_mode == "f32_winograd":
+        for bit, key, ci, co in ((1, "w1", out["cin"], out["width"]), (2, "w3", out["width"], out["cout"]), (4, "wd", out["cin"], out["cout"])):
+            if out[key] is not None and x6_conv1x1_ok(ci, co):
+                out[key] = records_x6t(out[key], co, ci)
+                out["x6_mask"] |= bit
     return out
 
 
@@ -161,9 +186,31 @@ def conv_nhwc(x, wp, bp, n, h, w, cin, cout, k, stride, pad, relu, residual=None
     return y, ho, wo
 
 
+def conv1x1_x6(x, wrec, bp, n, h, w, cin, cout, stride, relu, residual=None):
+    """1x1 convolution (stride 1 / 2) as an f32x6 GEMM: frcnn_split_pixels_x6t + frcnn_gemm_x6t; returns (y, ho, wo)."""
+    lib = nv.lib()
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    m = n * ho * wo
+    mp = (m + nv.X6T_ROW_TILE - 1) // nv.X6T_ROW_TILE * nv.X6T_ROW_TILE
+    np_ = (cout + nv.X6T_COL_TILE - 1) // nv.X6T_COL_TILE * nv.X6T_COL_TILE
+    rec = t.empty((int(lib.frcnn_x6t_record_bytes(mp, cin)),), dtype=t.uint8, device=x.device)
+    y = t.empty((n, ho, wo, cout), dtype=t.float32, device=x.device)
+    wsb = int(lib.frcnn_gemm_x6t_workspace_bytes(m, cout, cin, 1))
+    ws = t.empty((max(wsb, 4),), dtype=t.uint8, device=x.device)
+    with t.cuda.device(x.device):
+        nv.check(lib.frcnn_split_pixels_x6t(nv.ptr(x), nv.ptr(rec), n, h, w, cin, stride, mp, nv.stream_ptr()), "frcnn_split_pixels_x6t")
+        nv.check(lib.frcnn_gemm_x6t(nv.ptr(rec), mp, 0, nv.ptr(wrec), np_, 0, nv.ptr(bp), nv.ptr(residual), nv.ptr(y), cout, 0, m, cout, cin, 1,
+                                    nv.RELU if relu else 0, nv.ptr(ws), wsb, nv.stream_ptr()), "frcnn_gemm_x6t")
+    return y, ho, wo
+
+
 def run_block(x, n, h, w, pb):
     """One Bottleneck on NHWC data through the C ABI (stage-level path; the fused model uses frcnn_resnet_forward)."""
-    t1, _, _ = conv_nhwc(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, 1, 0, True)
+    xm = pb.get("x6_mask", 0)
+    if xm & 1:
+        t1, _, _ = conv1x1_x6(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, True)
+    else:
+        t1, _, _ = conv_nhwc(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, 1, 0, True)
     if pb["w2"].dim() == 1:                                             # one-launch Winograd bank (f32_winograd mode, one map)
         assert n == 1
         width = pb["width"]
@@ -186,8 +233,14 @@ def run_block(x, n, h, w, pb):
         t2, ho, wo = conv_nhwc(t1, pb["w2"], pb["b2"], n, h, w, pb["width"], pb["width"], 3, pb["stride"], 1, True)
     identity = x
     if pb["wd"] is not None:
-        identity, _, _ = conv_nhwc(x, pb["wd"], pb["bd"], n, h, w, pb["cin"], pb["cout"], 1, pb["stride"], 0, False)
-    out, _, _ = conv_nhwc(t2, pb["w3"], pb["b3"], n, ho, wo, pb["width"], pb["cout"], 1, 1, 0, True, residual=identity)
+        if xm & 4:
+            identity, _, _ = conv1x1_x6(x, pb["wd"], pb["bd"], n, h, w, pb["cin"], pb["cout"], pb["stride"], False)
+        else:
+            identity, _, _ = conv_nhwc(x, pb["wd"], pb["bd"], n, h, w, pb["cin"], pb["cout"], 1, pb["stride"], 0, False)
+    if xm & 2:
+        out, _, _ = conv1x1_x6(t2, pb["w3"], pb["b3"], n, ho, wo, pb["width"], pb["cout"], 1, True, residual=identity)
+    else:
+        out, _, _ = conv_nhwc(t2, pb["w3"], pb["b3"], n, ho, wo, pb["width"], pb["cout"], 1, 1, 0, True, residual=identity)
     return out, ho, wo
 
 
@@ -215,6 +268,7 @@ class FeatureExtractor(nn.Module):
         self._packed_key = None
         self._packed = None
         self.math_mode = "f32"
+        self.x6_conv1x1 = False      # the eligible 1x1 convolutions as f32x6 GEMMs (f32_winograd mode)
 
     def blocks(self):
         fe = self._feature_extractor
@@ -224,10 +278,11 @@ class FeatureExtractor(nn.Module):
         """{'stem': (w, b), 'blocks': [dict]} of BN-folded packed weights, rebuilt when parameters change."""
         fe = self._feature_extractor
         params = [fe[0].weight] + _bn_params(fe[1]) + [p for b in self.blocks() for p in block_params(b)]
-        key = (self.math_mode,) + rt.param_key(params)
+        key = (self.math_mode, self.x6_conv1x1) + rt.param_key(params)
         if key != self._packed_key:
             sw, sb, keep = fold_conv_bn(fe[0], fe[1])
-            self._packed = {"stem": (sw, sb), "keep": keep, "blocks": [pack_block(b, self.math_mode, single_map=True) for b in self.blocks()],
+            self._packed = {"stem": (sw, sb), "keep": keep,
+                            "blocks": [pack_block(b, self.math_mode, single_map=True, x6=self.x6_conv1x1) for b in self.blocks()],
                             "n_blocks": [len(fe[4]), len(fe[5]), len(fe[6])]}
             self._packed_key = key
         return self._packed
@@ -264,12 +319,13 @@ class PoolToFeatureVector(nn.Module):
         self._packed_key = None
         self._packed = None
         self.math_mode = "f32"
+        self.x6_conv1x1 = False      # the eligible 1x1 convolutions as f32x6 GEMMs (f32_winograd mode)
 
     def packed(self):
         params = [p for b in self._layer4 for p in block_params(b)]
-        key = (self.math_mode,) + rt.param_key(params)
+        key = (self.math_mode, self.x6_conv1x1) + rt.param_key(params)
         if key != self._packed_key:
-            self._packed = [pack_block(b, self.math_mode) for b in self._layer4]
+            self._packed = [pack_block(b, self.math_mode, x6=self.x6_conv1x1) for b in self._layer4]
             self._packed_key = key
         return self._packed
 

@@ -209,7 +209,8 @@ int frcnn_linear_x6(const void* d_a_rec, const void* d_w_rec, const float* d_bia
  *   [K/16][rows_padded/32][3 = hi, mid, lo][1024 B], 1024 B = [k-half 2][row 32][8 bf16]; x = hi + mid + lo exactly.
  *   frcnn_x6t_record_bytes(rows_padded, K)  : bytes of one record array
  *   frcnn_split_rows_x6t                    : [batches][rows][lda] float32 -> [batches] record arrays (rows beyond `rows` zero)
- *   frcnn_gemm_x6t                          : C_b[m][n] = act(bias[n] + sum_k A_b[m][k] B_b[n][k]), b < batches; A records padded
+ *   frcnn_gemm_x6t                          : C_b[m][n] = act(bias[n] + residual_b[m][n] + sum_k A_b[m][k] B_b[n][k]), b < batches
+ *       (bias / residual may be NULL; the residual has C's layout); A records padded
  *       to a_rows (% FRCNN_X6T_ROW_TILE == 0, >= M), B records padded to b_rows (% FRCNN_X6T_COL_TILE == 0, >= N); batch strides
  *       of the record arrays in BYTES (0: shared by all batches), of C in floats; N % 4 == 0, ldc % 4 == 0; deterministic
  *       (fixed-order split-K when the grid would not cover the chip: d_ws >= frcnn_gemm_x6t_workspace_bytes(M, N, K, batches)).
@@ -228,8 +229,11 @@ int frcnn_split_rows_x6t(const float* d_a, int lda, size_t a_batch_floats, void*
                          void* stream);
 size_t frcnn_gemm_x6t_workspace_bytes(int M, int N, int K, int batches);
 int frcnn_gemm_x6t(const void* d_a_rec, int a_rows, size_t a_batch_bytes, const void* d_b_rec, int b_rows, size_t b_batch_bytes,
-                   const float* d_bias, float* d_c, int ldc, size_t c_batch_floats, int M, int N, int K, int batches, unsigned flags,
-                   void* d_ws, size_t ws_bytes, void* stream);
+                   const float* d_bias, const float* d_residual, float* d_c, int ldc, size_t c_batch_floats, int M, int N, int K,
+                   int batches, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
+/* NHWC float32 [N][H][W][C] -> the x6t records of the [N Ho Wo][C] matrix of its pixels taken with `stride` in y and x
+ * (Ho = (H - 1) / stride + 1): the A operand of a 1x1 convolution (stride 1 or 2) as a GEMM.  C % 16 == 0. */
+int frcnn_split_pixels_x6t(const float* d_x, void* d_rec, int N, int H, int W, int C, int stride, int rows_padded, void* stream);
 int frcnn_conv3x3_uses_winograd_x6(int cin, int cout);
 size_t frcnn_conv3x3_winograd_x6_pack_bytes(int cout, int cin);
 int frcnn_pack_conv3x3_winograd_x6(const float* d_w_oihw, const float* d_row_scale, void* d_u_rec, int cout, int cin, void* stream);
@@ -455,7 +459,14 @@ typedef struct frcnn_bottleneck_weights {
     const float *w3, *b3;      /* 1x1 width->cout, [1][cout][width] */
     const float *wd, *bd;      /* downsample 1x1 cin->cout (stride), NULL when identity */
     int32_t cin, width, cout, stride;
+    int32_t x6_mask;           /* round 3: bit 0 / 1 / 2 set = w1 / w3 / wd is NOT a float32 pack but the x6t record array of the folded
+                                  [cout][cin] matrix (frcnn_split_rows_x6t, rows padded to FRCNN_X6T_COL_TILE): that 1x1 convolution runs as a
+                                  GEMM in the f32x6 arithmetic on the bf16 pipe (csrc/gemm_x6t.hip; the activations are split on the fly by
+                                  frcnn_split_pixels_x6t).  Needs cin % 16 == 0 and cout % 4 == 0; FRCNN_MATH_F32_WINOGRAD only */
 } frcnn_bottleneck_weights;
+#define FRCNN_X6_CONV1 1
+#define FRCNN_X6_CONV3 2
+#define FRCNN_X6_DOWN  4
 
 typedef struct frcnn_resnet_weights {
     const float* stem_w;       /* [147][64] */

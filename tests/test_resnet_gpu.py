@@ -179,7 +179,7 @@ def test_resnet50_stages_and_end_to_end(r50, golden_dir, name):
     j, err = match_rows(props.cpu().numpy(), g["proposals"])
     ok = err <= 1e-3
     print("%s forward: %.1f%% of the reference's proposals within 1e-3 px" % (name, 100 * ok.mean()))
-    assert ok.mean() == 1.0                                   # observed: every proposal of both ResNet-50 fixtures
+    assert ok.mean() == 1.0                                   # observed: every proposal of both ResNet-50 fixtures (default: x6 head only)
     assert np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max() <= 2e-4
     pooled = model.context(0).tensor(5).reshape(-1, 2048)
     assert pooled.shape[0] == 300
@@ -264,3 +264,78 @@ def test_resnet50_direct_mode_agrees_with_default_winograd_mode(r50):
     assert np.abs(a[1].cpu().numpy()[j[ok]] - b[1].cpu().numpy()[ok]).max() <= 2e-4
     with pytest.raises(NotImplementedError):
         model.math_mode = "f32x6"
+
+
+def test_resnet50_x6_modes(r50, golden_dir):
+    """Round 3: the bottleneck 1x1 convolutions as f32x6 GEMMs (csrc/gemm_x6t.hip).  The default "head" mode (layer4 only) must keep
+    EVERY golden proposal and detection (checked by test_resnet50_stages_and_end_to_end); "off" is rounds 1-2's path; "all" (+ the RPN
+    trunk as an x6 Winograd layer) changes the backbone's rounding at the 1e-6 level: the feature map stays within the same error
+    of the oracle, and the discrete RPN decisions are held to the observed 296 / 300 proposals and 230 / 232 detections."""
+    model, sd = r50
+    assert model.x6_conv1x1 == "head" and model.winograd_x6_layers == ()
+    g = np.load(os.path.join(golden_dir, "resnet50_600x1000_s0.npz"))
+    img = synthetic.image_rgb(int(g["seed"]), 600, 1000).unsqueeze(0).cuda()
+    res = {}
+    try:
+        for mode, layers in (("head", ()), ("off", ()), ("all", ("rpn_trunk",))):
+            model.x6_conv1x1 = mode
+            model.winograd_x6_layers = layers
+            p, c, d = model(image_data=img)
+            fm = model.context(0).tensor(0).clone()
+            det = model.predict(image_data=img, score_threshold=0.05)
+            res[mode] = (p.cpu().numpy(), c.cpu().numpy(), fm, det)
+    finally:
+        model.x6_conv1x1 = "head"
+        model.winograd_x6_layers = ()
+    ref = g["detections"]
+
+    def n_det(det):
+        n = 0
+        for c in range(1, 21):
+            r = ref[ref[:, 0] == c][:, 1:]
+            if len(r) and len(det[c]):
+                j, err = match_rows(det[c], r)
+                n += int(((err <= 1e-3) & (np.abs(det[c][j, 4] - r[:, 4]) <= 2e-4)).sum())
+        return n
+
+    for mode in ("head", "off", "all"):
+        j, err = match_rows(res[mode][0], g["proposals"])
+        print("x6_conv1x1=%s: %d/300 proposals, %d/%d detections" % (mode, int((err <= 1e-3).sum()), n_det(res[mode][3]), len(ref)))
+    # head vs off: identical backbone -> identical proposals; class probabilities within 2e-5
+    assert np.array_equal(res["head"][0], res["off"][0]) and torch.equal(res["head"][2], res["off"][2])
+    assert np.abs(res["head"][1] - res["off"][1]).max() <= 2e-5
+    assert n_det(res["head"][3]) == len(ref) and n_det(res["off"][3]) == len(ref)
+    # all: the feature map differs from the float32 kernels' by float32 rounding only; discrete decisions at the observed numbers
+    rel = float((res["all"][2] - res["off"][2]).abs().max()) / float(res["off"][2].abs().max())
+    j, err = match_rows(res["all"][0], g["proposals"])
+    print("x6 all vs off: feature map %.3g of max" % rel)
+    assert rel <= 5e-6 and int((err <= 1e-3).sum()) >= 294 and n_det(res["all"][3]) >= len(ref) - 4
+    with pytest.raises(ValueError):
+        model.x6_conv1x1 = "some"
+
+
+@pytest.mark.parametrize("n,h,w,cin,width,cout,stride", [(3, 7, 7, 1024, 512, 2048, 2), (2, 4, 4, 2048, 512, 2048, 1), (1, 19, 31, 512, 256, 1024, 2),
+                                                         (1, 10, 12, 1024, 256, 1024, 1)])
+def test_bottleneck_x6_1x1_against_the_float32_block(n, h, w, cin, width, cout, stride):
+    """One bottleneck through the stage-level path with its 1x1 convolutions as f32x6 GEMMs (incl. the stride-2 downsample and the
+    fused residual + ReLU epilogue) against the same block on the exact-f32 gather kernel: <= 3e-6 of the largest output."""
+    from fasterrcnn_amd.models import resnet as R
+    torch.manual_seed(n * 100 + h)
+    blk = R._Bottleneck(cin, width, stride).cuda().eval()
+    assert (blk.downsample is not None) == (stride != 1 or cin != cout)
+    for bn in [blk.bn1, blk.bn2, blk.bn3] + ([blk.downsample[1]] if blk.downsample is not None else []):
+        bn.running_mean.normal_(0, 0.1)
+        bn.running_var.uniform_(0.5, 1.5)
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_(0, 0.1)
+    x = torch.randn((n, h, w, cin), device="cuda")
+    pb32 = R.pack_block(blk, "f32_winograd", single_map=(n == 1), x6=False)
+    pb6 = R.pack_block(blk, "f32_winograd", single_map=(n == 1), x6=True)
+    assert pb6["x6_mask"] == (7 if blk.downsample is not None else 3) and pb32["x6_mask"] == 0
+    y32, ho, wo = R.run_block(x, n, h, w, pb32)
+    y6, ho6, wo6 = R.run_block(x, n, h, w, pb6)
+    torch.cuda.synchronize()
+    assert (ho, wo) == (ho6, wo6) and y32.shape == y6.shape
+    rel = float((y6 - y32).abs().max()) / float(y32.abs().max())
+    print("bottleneck %dx%dx%d %d->%d->%d s%d: x6 vs f32 %.3g of max" % (n, h, w, cin, width, cout, stride, rel))
+    assert rel <= 3e-6

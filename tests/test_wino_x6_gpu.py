@@ -50,7 +50,7 @@ def gemm_x6t(a_rec, a_rows, a_stride, b_rec, b_rows, b_stride, bias, m, n, k, ba
     c = torch.full((batches, m, n), float("nan"), device="cuda")
     wsb = int(lib.frcnn_gemm_x6t_workspace_bytes(m, n, k, batches))
     ws = torch.empty((max(wsb, 4) // 4,), device="cuda")
-    nv.check(lib.frcnn_gemm_x6t(nv.ptr(a_rec), a_rows, a_stride, nv.ptr(b_rec), b_rows, b_stride, nv.ptr(bias), nv.ptr(c), n, m * n,
+    nv.check(lib.frcnn_gemm_x6t(nv.ptr(a_rec), a_rows, a_stride, nv.ptr(b_rec), b_rows, b_stride, nv.ptr(bias), None, nv.ptr(c), n, m * n,
                                 m, n, k, batches, nv.RELU if relu else 0, nv.ptr(ws), wsb, nv.stream_ptr()), "gemm_x6t")
     torch.cuda.synchronize()
     return c
@@ -118,11 +118,11 @@ def test_gemm_x6t_rejects_bad_arguments():
     s = nv.stream_ptr()
     x = torch.zeros((1 << 20,), device="cuda")
     p = nv.ptr(x)
-    assert lib.frcnn_gemm_x6t(None, 320, 0, p, 256, 0, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1
-    assert lib.frcnn_gemm_x6t(p, 300, 0, p, 256, 0, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1      # a_rows % 320
-    assert lib.frcnn_gemm_x6t(p, 320, 0, p, 128, 0, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1      # b_rows % 256
-    assert lib.frcnn_gemm_x6t(p, 320, 0, p, 256, 0, None, p, 256, 0, 8, 256, 40, 1, 0, p, 1 << 22, s) == -4      # K % 16
-    assert lib.frcnn_gemm_x6t(p, 320, 0, p, 256, 0, None, p, 256, 0, 8, 250, 64, 1, 0, p, 1 << 22, s) == -4      # N % 4
+    assert lib.frcnn_gemm_x6t(None, 320, 0, p, 256, 0, None, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1
+    assert lib.frcnn_gemm_x6t(p, 300, 0, p, 256, 0, None, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1      # a_rows % 320
+    assert lib.frcnn_gemm_x6t(p, 320, 0, p, 128, 0, None, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1      # b_rows % 256
+    assert lib.frcnn_gemm_x6t(p, 320, 0, p, 256, 0, None, None, p, 256, 0, 8, 256, 40, 1, 0, p, 1 << 22, s) == -4      # K % 16
+    assert lib.frcnn_gemm_x6t(p, 320, 0, p, 256, 0, None, None, p, 256, 0, 8, 250, 64, 1, 0, p, 1 << 22, s) == -4      # N % 4
     assert lib.frcnn_x6t_record_bytes(320, 512) == 32 * 10 * 3072 and lib.frcnn_x6t_record_bytes(100, 512) == 0
     assert lib.frcnn_split_rows_x6t(p, 40, 0, p, 4, 32, 40, 1, s) == -1                                           # K % 16
 

@@ -29,7 +29,7 @@ def run(M, N, K, B, reps=300):
     for rep in range(reps):
         if rep == reps - 1:
             e0.record()
-        nv.check(lib.frcnn_gemm_x6t(nv.ptr(ar), Mp, a_per, nv.ptr(br), Np, b_per, None, nv.ptr(c), N, M * N, M, N, K, B, 0, nv.ptr(dbg),
+        nv.check(lib.frcnn_gemm_x6t(nv.ptr(ar), Mp, a_per, nv.ptr(br), Np, b_per, None, None, nv.ptr(c), N, M * N, M, N, K, B, 0, nv.ptr(dbg),
                                     dbg.numel() * 4, s), "gemm_x6t")
     e1.record()
     t.cuda.synchronize()

@@ -47,7 +47,7 @@ def main():
         c = torch.empty((B, M, N), device=dev)
         gwsb = int(lib.frcnn_gemm_x6t_workspace_bytes(M, N, K, B))
         gws = torch.empty((max(gwsb, 4),), dtype=torch.uint8, device=dev)
-        us = timeit(lambda: nv.check(lib.frcnn_gemm_x6t(nv.ptr(ar), Mp, a_per, nv.ptr(br), Np, b_per, None, nv.ptr(c), N, M * N, M, N, K, B, 0,
+        us = timeit(lambda: nv.check(lib.frcnn_gemm_x6t(nv.ptr(ar), Mp, a_per, nv.ptr(br), Np, b_per, None, None, nv.ptr(c), N, M * N, M, N, K, B, 0,
                                                         nv.ptr(gws), gwsb, s), "gemm_x6t"), args.reps)
         fl = 2.0 * M * N * K * B
         print("gemm_x6t M=%d N=%d K=%d x%d: %8.1f us = %6.1f TF f32-equivalent, %.3f of the bf16 peak (splitws %d B)" % (
@@ -84,7 +84,7 @@ def main():
         m = torch.empty((16, T, cout), device=dev)
         gwsb = int(lib.frcnn_gemm_x6t_workspace_bytes(T, cout, cin, 16))
         gws = torch.empty((max(gwsb, 4),), dtype=torch.uint8, device=dev)
-        usg = timeit(lambda: nv.check(lib.frcnn_gemm_x6t(nv.ptr(ws), Tp, a_per, nv.ptr(u), Np, b_per, None, nv.ptr(m), cout, T * cout, T,
+        usg = timeit(lambda: nv.check(lib.frcnn_gemm_x6t(nv.ptr(ws), Tp, a_per, nv.ptr(u), Np, b_per, None, None, nv.ptr(m), cout, T * cout, T,
                                                          cout, cin, 16, 0, nv.ptr(gws), gwsb, s), "gemm_x6t"), args.reps)
         print("%-8s %4d->%4d %4dx%-4d pool=%d  f32 one-launch %7.1f us (%.3f of 157.3) | x6 layer %7.1f us | x6 GEMM alone %7.1f us "
               "= %6.1f TF f32-equivalent, %.3f of the bf16 peak (splitws %d B)" % (
