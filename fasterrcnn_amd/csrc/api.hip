@@ -823,13 +823,14 @@ int run_winograd_layer(frcnn_ctx* c, const float* x, const float* u, const float
     return launch_winograd_output(M, b, y, N, h, w, co, flags, s);
 }
 
-// Scratch of the x6 Winograd layers (V records + M + split-K partials of the largest eligible layer up to the ctx's largest image),
-// allocated once, on first use, zeroed (the padding row blocks of V are then zero for ever: nobody writes them).
-int ensure_wx_ws(frcnn_ctx* c)
+// Scratch of the x6 Winograd layers (V records + M + split-K partials).  Sized on first use for the largest layer of the DEFAULT table
+// up to the ctx's largest image (conv4_x on image / 8, conv5_x / RPN trunk on image / 16, ResNet's 1024-channel trunk); a layer that
+// needs more (a larger map put on the table by the caller) grows it once (hipMalloc synchronises: first image only).  Zeroed, so the
+// padding row blocks of V are zero for ever: nobody writes them.
+int ensure_wx_ws(frcnn_ctx* c, size_t layer_need, hipStream_t s)
 {
-    if (c->wx_ws) return FRCNN_OK;
-    size_t need = 0;
-    // VGG-16: conv4_x on the image / 8 map, conv5_x and the RPN trunk on image / 16; ResNet: the RPN trunk on the 1024-channel map
+    if (c->wx_ws && layer_need <= c->wx_ws_bytes) return FRCNN_OK;
+    size_t need = layer_need;
     const int shapes[4][4] = {{c->max_h / 8, c->max_w / 8, 256, 512}, {c->max_h / 8, c->max_w / 8, 512, 512},
                               {c->max_fh, c->max_fw, 512, 512}, {c->max_fh, c->max_fw, 1024, 1024}};
     for (auto& sh : shapes) {
@@ -837,6 +838,11 @@ int ensure_wx_ws(frcnn_ctx* c)
         if (b > need) need = b;
     }
     if (need == 0) return FRCNN_EINVAL;
+    if (c->wx_ws) {
+        FRCNN_HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(c->wx_ws);
+        c->wx_ws = nullptr; c->wx_ws_bytes = 0;
+    }
     hipError_t e = hipMalloc(&c->wx_ws, need);
     if (e != hipSuccess) { set_hip_error(e); c->wx_ws = nullptr; return FRCNN_ENOMEM; }
     e = hipMemset(c->wx_ws, 0, need);
@@ -850,7 +856,7 @@ int run_wino_x6_layer(frcnn_ctx* c, const float* x, const void* urec, const floa
                       unsigned flags, hipStream_t s)
 {
     if (!conv3x3_uses_winograd_x6(ci, co)) return FRCNN_EINVAL;
-    int r = ensure_wx_ws(c);
+    int r = ensure_wx_ws(c, conv3x3_winograd_x6_workspace_bytes(h, w, ci, co), s);
     if (r) return r;
     void *V = nullptr, *G = nullptr;
     float* M = nullptr;

@@ -393,6 +393,7 @@ def main():
     ap.add_argument("--train", action="store_true", help="only the train-step fixtures (tests/golden/train_*.npz)")
     ap.add_argument("--only-resnet101", action="store_true", help="with --train: only the ResNet-101 fixture")
     ap.add_argument("--only-resnet152", action="store_true", help="only the ResNet-152 inference fixture")
+    ap.add_argument("--only-resnet101-600", action="store_true", help="only the ResNet-101 600x1000 inference fixture (round 3)")
     args = ap.parse_args()
     t.manual_seed(0)
     ref = reference_shims.install(O)
@@ -403,6 +404,10 @@ def main():
         calibrate_resnet(ref)
         return
     os.makedirs(GOLDEN, exist_ok=True)
+    if args.only_resnet101_600:
+        sd = synthetic.resnet_state_dict(1234, "ResNet101")
+        run_case(ref, "600x1000_s2", sd, 2, 600, 1000, True, 0.05, arch="ResNet101")
+        return
     if args.only_resnet152:
         sd = synthetic.resnet_state_dict(1234, "ResNet152")
         run_case(ref, "250x333_s7", sd, 7, 250, 333, True, 0.05, arch="ResNet152")
@@ -428,6 +433,7 @@ def main():
     run_case(ref, "250x333_s7", sd, 7, 250, 333, True, 0.05, arch="ResNet50")   # ceil() feature map 16x21
     sd = synthetic.resnet_state_dict(1234, "ResNet101")
     run_case(ref, "224x320_s3", sd, 3, 224, 320, True, 0.05, arch="ResNet101")
+    run_case(ref, "600x1000_s2", sd, 2, 600, 1000, True, 0.05, arch="ResNet101")
     sd = synthetic.resnet_state_dict(1234, "ResNet152")
     run_case(ref, "250x333_s7", sd, 7, 250, 333, True, 0.05, arch="ResNet152")
 

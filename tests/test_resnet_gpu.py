@@ -212,6 +212,45 @@ def test_resnet101_end_to_end(golden_dir):
     assert abs(sum(len(v) for v in out.values()) - len(g["detections"])) <= 4
 
 
+def test_resnet101_600x1000_end_to_end(golden_dir):
+    """Round 3: ResNet-101 at the headline size against a fixture generated from the imported reference
+    (oracle/make_golden.py --only-resnet101-600).  Gates = the observed numbers, printed by the test."""
+    model, sd = make_model("ResNet101")
+    g = np.load(os.path.join(golden_dir, "resnet101_600x1000_s2.npz"))
+    img = synthetic.image_rgb(2, 600, 1000).unsqueeze(0)
+    props, classes, deltas = model(image_data=img.cuda())
+    assert g["proposals"].shape[0] == 300 and props.shape[0] == 300
+    j, err = match_rows(props.cpu().numpy(), g["proposals"])
+    ok = err <= 1e-3
+    scores = model.context(0).tensor(2).cpu().numpy()
+    s_err = float(np.abs(scores[::7] - g["scores_sample"]).max())
+    fm = model.context(0).tensor(0).cpu().reshape(38, 63, 1024).permute(2, 0, 1)
+    fm_err = float((fm[::32] - torch.from_numpy(g["feature_map_sample"])).abs().max()) / float(np.abs(g["feature_map_sample"]).max())
+    c_err = float(np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max())
+    out = model.predict(image_data=img.cuda(), score_threshold=0.05)
+    ref = g["detections"]
+    n_ok = 0
+    for c in range(1, 21):
+        r = ref[ref[:, 0] == c][:, 1:]
+        if len(r) and len(out[c]):
+            jj, ee = match_rows(out[c], r)
+            n_ok += int(((ee <= 1e-3) & (np.abs(out[c][jj, 4] - r[:, 4]) <= 2e-4)).sum())
+    n_ours = sum(len(v) for v in out.values())
+    print("ResNet-101 600x1000: %d/300 proposals within 1e-3 px, feature map %.3g of max, objectness %.3g, class prob %.3g, "
+          "%d/%d detections (ours %d)" % (int(ok.sum()), fm_err, s_err, c_err, n_ok, len(ref), n_ours))
+    assert fm_err <= 5e-5 and s_err <= 1e-5 and c_err <= 2e-4
+    assert int(ok.sum()) >= R101_600_PROPOSALS and n_ok >= R101_600_DETECTIONS and abs(n_ours - len(ref)) <= len(ref) - R101_600_DETECTIONS
+
+
+# Observed on the MI355X (default modes; the kernels are deterministic, so these are exact expectations): 286 of the reference's 300
+# proposals and 149 of its 157 detections.  The rest are near-ties, not errors: this fixture's top-6000 RPN scores have a MEDIAN
+# gap of 2.4e-5 (13 exact ties; make_golden prints it) while two float32 implementations of a 101-layer network differ by ~3e-6 in
+# objectness (measured above: 3.1e-6), so roughly one adjacent pair in ten changes order and a handful of those sit at the NMS cut.
+# Feature map (1.2e-6 of max), objectness and class probabilities are gated at float32 accuracy above.
+R101_600_PROPOSALS = 286
+R101_600_DETECTIONS = 149
+
+
 def test_resnet152_end_to_end(golden_dir):
     """models/resnet.py:144-149 ResNet152 ([3, 8, 36, 3] bottlenecks, 155 convolutions): golden vectors of the reference."""
     model, sd = make_model("ResNet152")
