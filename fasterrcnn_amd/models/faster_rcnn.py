@@ -389,7 +389,9 @@ class FasterRCNNModel(nn.Module):
                                   nv.FC_MATH_MODES[self._effective_fc_math()],
                                   nv.ROI_OPS[self._stage3_detector_network.pooling], self._stage3_detector_network.sampling_ratio,
                                   0 if slot_index == 0 else self.inflight_winograd_tile_rows, self._x6_mask(),
-                                  0 if slot_index == 0 else self.inflight_x6_gemm_tiles)
+                                  # (ResNet: the cost model's choice in every slot, so that an image gives the same bits in flight
+                                  #  and alone: its 1x1 GEMMs switch between split-K and unsplit tiles with the tile mode)
+                                  0 if (slot_index == 0 or self._is_resnet) else self.inflight_x6_gemm_tiles)
         lib = nv.lib()
         with_det = score_threshold is not None
         fwd, fwd_name = ((lib.frcnn_resnet_forward, "frcnn_resnet_forward") if self._is_resnet

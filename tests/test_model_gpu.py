@@ -114,15 +114,18 @@ def test_stage2_rpn_on_oracle_feature_map(gpu_model, model_edge_off, golden_dir,
     print("RPN %s: %d/%d proposals, %.1f%% of reference rows matched within 1e-3 px (max %.3g)" % (
         tag, ours.shape[0], props_ref.shape[0], 100 * frac, float(err.max())))
     assert ours.shape[0] == props_ref.shape[0]
-    assert frac >= 0.97
+    assert frac == 1.0                                        # observed (round 3): every reference proposal, all three cases
     # anchor indices of the top-N: identical as a set up to near-tie swaps at the cut
     ours_idx = rpn.last_sorted_indices.cpu().numpy()
     ref_idx = detail["sorted_idx"]
     assert len(ours_idx) == len(ref_idx)
-    assert len(set(ours_idx.tolist()) ^ set(ref_idx.tolist())) <= 8
+    # observed and required: the top-N anchor SET is identical in all three cases; positions differ only where two scores are
+    # closer than float32 resolves (600x1000: 99.52 % of positions identical, 224x320: 99.92 %, 333x517: 100 %); on identical
+    # scores the order is exact (tests/test_kernels_gpu.py)
+    assert len(set(ours_idx.tolist()) ^ set(ref_idx.tolist())) == 0
     same = float((ours_idx == ref_idx).mean())
     print("   sorted anchor indices: %.2f%% positions identical" % (100 * same))
-    assert same >= 0.95
+    assert same >= {"600x1000_s0": 0.995, "224x320_s3": 0.999, "333x517_s5_noedge": 1.0}[tag]
 
 
 @pytest.mark.parametrize("tag,allow_edge", CASES)
@@ -291,7 +294,7 @@ def test_anchor_maps_argument_and_async_slots(gpu_model):
             assert np.array_equal(runs[0][i][c], runs[1][i][c]), (i, c)
             j, d = match_rows(runs[0][i][c], base[i][c])
             n_same += int((d <= 1e-3).sum())
-        assert n_same >= 0.97 * n_base, (i, n_same, n_base)
+        assert n_same == n_base, (i, n_same, n_base)            # observed: every detection of every image (168, 176, 201)
     with pytest.raises(RuntimeError):
         p = gpu_model.predict_async(imgs[0], 0.05, slot=1)
         gpu_model.predict_async(imgs[1], 0.05, slot=1)       # slot busy until collected
@@ -417,7 +420,7 @@ def test_larger_image_grows_the_context(gpu_model, sd_cpu):
     props, classes, deltas = gpu_model(image_data=img.cuda())
     assert props.shape[0] == o_props.shape[0]
     j, err = match_rows(props.cpu().numpy(), o_props.numpy())
-    assert (err <= 1e-3).mean() >= 0.95
+    assert int((err <= 1e-3).sum()) >= 297                   # observed: 297 of 300 (near-tied candidates at the NMS cut)
     fm = gpu_model.context(0).tensor(0).reshape(45, 80, 512).permute(2, 0, 1).cpu()
     ref = detail["feature_map"][0]
     assert float((fm - ref).abs().max()) / float(ref.abs().max()) <= 2e-5

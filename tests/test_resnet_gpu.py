@@ -201,15 +201,15 @@ def test_resnet101_end_to_end(golden_dir):
     g = np.load(os.path.join(golden_dir, "resnet101_224x320_s3.npz"))
     img = synthetic.image_rgb(3, 224, 320).unsqueeze(0)
     props, classes, deltas = model(image_data=img.cuda())
-    # fewer than 300 survive NMS here (149 in the reference); a borderline IoU / 16-px decision may
-    # flip under fp32 noise, so the count is held to +-2 and the rows to the usual matching criterion
-    assert g["proposals"].shape[0] == 149 and abs(props.shape[0] - 149) <= 2
+    # fewer than 300 survive NMS here (149 in the reference).  Gates = the observed numbers: the same count, 147 of the 149 rows
+    # (one borderline NMS decision swaps a pair), the same number of detections
+    assert g["proposals"].shape[0] == 149 and props.shape[0] == 149
     j, err = match_rows(props.cpu().numpy(), g["proposals"])
     ok = err <= 1e-3
-    assert ok.mean() >= 0.95
-    assert np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max() <= 2e-4
     out = model.predict(image_data=img.cuda(), score_threshold=0.05)
-    assert abs(sum(len(v) for v in out.values()) - len(g["detections"])) <= 4
+    assert int(ok.sum()) >= 147
+    assert np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max() <= 2e-4
+    assert sum(len(v) for v in out.values()) == len(g["detections"])
 
 
 def test_resnet101_600x1000_end_to_end(golden_dir):
@@ -298,8 +298,8 @@ def test_resnet50_direct_mode_agrees_with_default_winograd_mode(r50):
         assert torch.equal(u, v)                                         # deterministic, packs restored
     j, err = match_rows(a[0].cpu().numpy(), b[0].cpu().numpy())
     ok = err <= 1e-3
-    print("ResNet-50 f32 vs f32_winograd: %.1f%% of proposals within 1e-3 px" % (100 * ok.mean()))
-    assert ok.mean() >= 0.95
+    print("ResNet-50 f32 vs f32_winograd: %d/%d of proposals within 1e-3 px" % (int(ok.sum()), len(ok)))
+    assert ok.mean() == 1.0                                   # observed: 300 / 300
     assert np.abs(a[1].cpu().numpy()[j[ok]] - b[1].cpu().numpy()[ok]).max() <= 2e-4
     with pytest.raises(NotImplementedError):
         model.math_mode = "f32x6"
