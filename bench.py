@@ -109,8 +109,8 @@ def layer_arithmetic(math, fc_math, x6=(), n_rois=300, num_classes=21):
     rows.append(("rpn_heads_1x1", "linear_mfma_kernel", "f32", alg, alg))
     for name, k, n in (("fc1", 25088, 4096), ("fc2", 4096, 4096)):
         alg = n_rois * 2.0 * k * n
-        if fc_math == "f32x6":
-            rows.append((name, "linear_x6_kernel", "bf16", 6.0 * alg, alg))
+        if fc_math in ("f32x6", "f32x6_v1"):
+            rows.append((name, "gemm_x6t_kernel" if fc_math == "f32x6" else "linear_x6_kernel", "bf16", 6.0 * alg, alg))
         else:
             rows.append((name, "linear_mfma_kernel", "f32", alg, alg))
     alg = n_rois * 2.0 * 4096 * (5 * num_classes - 4)

@@ -111,7 +111,9 @@ X6T_ROW_TILE, X6T_COL_TILE = 320, 256     # FRCNN_X6T_ROW_TILE / FRCNN_X6T_COL_T
 LINEAR_X6_ROWS = 320                      # FRCNN_LINEAR_X6_ROWS: row count of an activation record array (csrc/linear_x6.hip's row tile)
 GRAD_MATHS = {"f32": 0, "bf16": 1}         # FRCNN_GRAD_F32 / FRCNN_GRAD_BF16: arithmetic of the train step's gradient GEMMs
 ROI_OPS = {"pool": 0, "align": 1}          # FRCNN_ROI_POOL (the reference) / FRCNN_ROI_ALIGN (torchvision roi_align semantics)
-FC_MATH_MODES = {"f32": 0, "f32x6": 1}   # FRCNN_FC_F32 / FRCNN_FC_F32X6: arithmetic of the VGG-16 detector's fc1 / fc2
+# arithmetic of the VGG-16 detector's fc1 / fc2: FRCNN_FC_F32 (exact-f32 pipe) / FRCNN_FC_F32X6T ("f32x6": exactly split bf16x3 operands on
+# csrc/gemm_x6t.hip, round 3) / FRCNN_FC_F32X6 ("f32x6_v1": the same arithmetic on round 2's csrc/linear_x6.hip, <= 320 RoIs; kept for A/B)
+FC_MATH_MODES = {"f32": 0, "f32x6": 2, "f32x6_v1": 1}
 
 
 def uses_winograd(cin, cout):

@@ -36,7 +36,8 @@ struct frcnn_ctx {
     float *anchor_map = nullptr, *valid_map = nullptr;
     float *roi_out = nullptr;                      // [max_rois][7][7][512]
     float *fc1_out = nullptr, *fc2_out = nullptr;  // [max_rois][4096]
-    void *roi_rec = nullptr, *fc1_rec = nullptr;   // x6 records of roi_out ([max_rois][25088]) and fc1_out (FRCNN_FC_F32X6)
+    void *roi_rec = nullptr, *fc1_rec = nullptr;   // x6 / x6t records of roi_out ([rec_rows][25088]) and fc1_out (FRCNN_FC_F32X6 / _F32X6T)
+    int rec_rows = 0;
     float *head_logits = nullptr;                  // [max_rois][128]
     void* lin_ws = nullptr; size_t lin_ws_bytes = 0;
     void* conv_ws = nullptr; size_t conv_ws_bytes = 0;   // split-K partials of under-filled conv layers
@@ -640,7 +641,13 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         const size_t x2 = linear_x6_workspace_bytes(max_rois > 320 ? 320 : max_rois, 4096, 4096);
         if (x1 > lin) lin = x1;
         if (x2 > lin) lin = x2;
+        const size_t t1 = gemm_x6t_workspace_bytes(max_rois, 4096, 512 * 49, 1), t2 = gemm_x6t_workspace_bytes(max_rois, 4096, 4096, 1);
+        if (t1 > lin) lin = t1;
+        if (t2 > lin) lin = t2;
     }
+    // row count of the activation record arrays: the x6t GEMM's 320-row tiles over max_rois (>= the 320 rows of the round-2 kernel)
+    const int rec_rows = cdiv(max_rois, gemm_x6t_row_tile(max_rois)) * gemm_x6t_row_tile(max_rois);
+    c->rec_rows = rec_rows;
     size_t cws = 0;
     {
         // the layers that may split: every VGG-16 shape at the largest image this ctx accepts
@@ -678,7 +685,7 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         {(void**)&c->anchor_map, (size_t)c->a_cap * 16}, {(void**)&c->valid_map, (size_t)c->a_cap * 4},
         {(void**)&c->roi_out, (size_t)max_rois * 49 * 1024 * 4},
         {(void**)&c->fc1_out, (size_t)max_rois * 4096 * 4}, {(void**)&c->fc2_out, (size_t)max_rois * 4096 * 4},
-        {(void**)&c->roi_rec, (size_t)FRCNN_LINEAR_X6_ROWS * 49 * 512 * 6}, {(void**)&c->fc1_rec, (size_t)FRCNN_LINEAR_X6_ROWS * 4096 * 6},
+        {(void**)&c->roi_rec, (size_t)rec_rows * 49 * 512 * 6}, {(void**)&c->fc1_rec, (size_t)rec_rows * 4096 * 6},
         {(void**)&c->head_logits, (size_t)max_rois * 128 * 4},
         {(void**)&c->lin_ws, lin}, {(void**)&c->conv_ws, cws},
         {(void**)&c->res_buf[0], c->res_buf_floats * 4}, {(void**)&c->res_buf[1], c->res_buf_floats * 4},
@@ -697,7 +704,7 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
     c->conv_ws_bytes = cws;
     proposal_scratch_carve(c->ps, ps_base, c->a_cap, c->pre_cap, 2048);
     // the padding rows of the activation record arrays (rows max_rois .. 319) are written by nobody afterwards
-    e = hipMemset(c->roi_rec, 0, (size_t)FRCNN_LINEAR_X6_ROWS * 49 * 512 * 6);
+    e = hipMemset(c->roi_rec, 0, (size_t)rec_rows * 49 * 512 * 6);
     if (e != hipSuccess) { set_hip_error(e); hipFree(c->slab); delete c; return FRCNN_EHIP; }
     *out = c;
     return FRCNN_OK;
@@ -908,7 +915,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32X6 && p->math_mode != FRCNN_MATH_F32_WINOGRAD)
         return FRCNN_EINVAL;
     if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
-    if (p->fc_math_mode != FRCNN_FC_F32 && p->fc_math_mode != FRCNN_FC_F32X6) return FRCNN_EINVAL;
+    if (p->fc_math_mode != FRCNN_FC_F32 && p->fc_math_mode != FRCNN_FC_F32X6 && p->fc_math_mode != FRCNN_FC_F32X6T) return FRCNN_EINVAL;
     if ((p->roi_op != FRCNN_ROI_POOL && p->roi_op != FRCNN_ROI_ALIGN) || p->roi_sampling_ratio > 2) return FRCNN_EINVAL;
     if (p->winograd_tile_rows != 0 && p->winograd_tile_rows != 64 && p->winograd_tile_rows != 128) return FRCNN_EINVAL;
     if (p->x6_gemm_tiles < 0 || p->x6_gemm_tiles > 2) return FRCNN_EINVAL;
@@ -972,7 +979,24 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     // stage 3: detector (models/detector.py:65-80, models/vgg16.py:129-133)
     const int R_ = p->post_nms;
     const bool fc_x6 = p->fc_math_mode == FRCNN_FC_F32X6;
+    const bool fc_x6t = p->fc_math_mode == FRCNN_FC_F32X6T;
     if (fc_x6 && R_ > FRCNN_LINEAR_X6_ROWS) return FRCNN_EUNSUPPORTED;
+    if (fc_x6t) {
+        // fc1 / fc2 as f32x6 GEMMs on tile records (csrc/gemm_x6t.hip): RoIPool writes fc1's operand records itself (the rows R_ ..
+        // rec_rows - 1 were zeroed when the ctx was created); fc1's float32 output is split again for fc2 (5 MB: a 3 us launch)
+        const int rr = c->rec_rows;
+        if (p->roi_op == FRCNN_ROI_ALIGN) {
+            STEP(4, launch_roi_align(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, p->roi_sampling_ratio, 0, c->roi_out, s));
+            STEP(2, launch_split_rows_x6t(c->roi_out, 49 * 512, 0, c->roi_rec, R_, rr, 49 * 512, 1, s));
+        } else {
+            STEP(4, launch_roi_pool_x6t(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_rec, rr, s));
+        }
+        STEP(2, launch_gemm_x6t(c->roi_rec, rr, 0, w->fc1_w, 4096, 0, w->fc1_b, nullptr, c->fc1_out, 4096, 0, R_, 4096, 49 * 512, 1, R,
+                                c->lin_ws, c->lin_ws_bytes, s, 0));
+        STEP(2, launch_split_rows_x6t(c->fc1_out, 4096, 0, c->fc1_rec, R_, rr, 4096, 1, s));
+        STEP(2, launch_gemm_x6t(c->fc1_rec, rr, 0, w->fc2_w, 4096, 0, w->fc2_b, nullptr, c->fc2_out, 4096, 0, R_, 4096, 4096, 1, R,
+                                c->lin_ws, c->lin_ws_bytes, s, 0));
+    } else
     if (p->roi_op == FRCNN_ROI_ALIGN) {
         STEP(4, launch_roi_align(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, p->roi_sampling_ratio, 0, c->roi_out, s));
         if (fc_x6) STEP(2, launch_split_rows_x6(c->roi_out, 49 * 512, c->roi_rec, R_, FRCNN_LINEAR_X6_ROWS, 49 * 512, s));
@@ -982,7 +1006,8 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     } else {
         STEP(4, launch_roi_pool(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
     }
-    if (fc_x6) {
+    if (fc_x6t) {
+    } else if (fc_x6) {
         // fc1 / fc2 on the bf16 pipe with exactly split operands: fc1's reduction emits the records fc2 consumes, fc2's the float32
         // rows the (exact-f32) heads consume
         STEP(2, launch_linear_x6(c->roi_rec, w->fc1_w, w->fc1_b, c->fc1_out, 4096, c->fc1_rec, R_, 4096, 49 * 512, R,

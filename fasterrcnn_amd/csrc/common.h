@@ -149,7 +149,7 @@ size_t gemm_x6t_workspace_bytes(int M, int N, int K, int batches);
 void gemm_x6t_set_tiles(int mode);          // tile choice of the calling thread's next launches: 0 cost model, 1 = 320 x 256, 2 = 160 x 128
 int launch_gemm_x6t(const void* a_rec, int a_rows, size_t a_batch_bytes, const void* b_rec, int b_rows, size_t b_batch_bytes,
                     const float* bias, const float* residual, float* c, int ldc, size_t c_batch_floats, int M, int N, int K, int batches,
-                    unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
+                    unsigned flags, void* ws, size_t ws_bytes, hipStream_t s, int tiles_mode = -1);
 int launch_split_pixels_x6t(const float* x, void* rec, int N, int H, int W, int C, int stride, int rows_padded, hipStream_t s);
 // wino_x6.hip: Winograd F(2x2,3x3) layers whose position GEMMs run on gemm_x6t
 bool conv3x3_uses_winograd_x6(int cin, int cout);
@@ -192,6 +192,8 @@ int launch_roi_pool(const float* fm, int fh, int fw, int c, const float* rois, c
                     int max_rois, int pooled, float scale, float* out, hipStream_t s);
 int launch_roi_pool_x6(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
                        int max_rois, int pooled, float scale, void* rec, int rec_rows, hipStream_t s);
+int launch_roi_pool_x6t(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
+                        int max_rois, int pooled, float scale, void* rec, int rec_rows, hipStream_t s);
 
 // roialign.hip
 int launch_roi_align(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois, int max_rois, int pooled,

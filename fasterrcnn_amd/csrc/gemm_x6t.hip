@@ -461,12 +461,12 @@ size_t gemm_x6t_workspace_bytes(int M, int N, int K, int batches)
 // padded to b_rows (multiple of 256, >= N); batch strides in BYTES (0 = the operand is shared by every batch).
 int launch_gemm_x6t(const void* a_rec, int a_rows, size_t a_batch_bytes, const void* b_rec, int b_rows, size_t b_batch_bytes,
                     const float* bias, const float* residual, float* c, int ldc, size_t c_batch_floats, int M, int N, int K, int batches,
-                    unsigned flags, void* ws, size_t ws_bytes, hipStream_t s)
+                    unsigned flags, void* ws, size_t ws_bytes, hipStream_t s, int tiles_mode)
 {
     if (!gemm_x6t_shape_ok(M, N, K, batches)) return FRCNN_EUNSUPPORTED;
     if (!a_rec || !b_rec || !c || a_rows % 320 != 0 || a_rows < M || b_rows % 256 != 0 || b_rows < N || ldc < N || ldc % 4 != 0)
         return FRCNN_EINVAL;
-    const GxPlan pl = plan_gemm_x6t(M, N, K, batches);
+    const GxPlan pl = plan_gemm_x6t(M, N, K, batches, tiles_mode);
     if (pl.splits > 1 && (ws == nullptr || ws_bytes < (size_t)pl.splits * batches * M * N * sizeof(float))) return FRCNN_EINVAL;
     GxParams p;
     p.a = static_cast<const unsigned char*>(a_rec);

@@ -34,7 +34,9 @@ __device__ __forceinline__ unsigned short rp_bf16_rne(float f)
 }
 __device__ __forceinline__ float rp_bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
-template <bool X6>
+// X6 = 0: float32 rows; 1: the chunk-major x6 records of csrc/linear_x6.hip; 2: the x6t TILE records of csrc/gemm_x6t.hip
+// ([K/16][rec_rows/32][3][khalf 2][row 32][8 bf16]) -- round 3: fc1 runs on gemm_x6t_kernel
+template <int X6>
 __global__ __launch_bounds__(128)
 void roi_pool_kernel(const float* __restrict__ fm, int fh, int fw, int C,
                      const float* __restrict__ rois, const int32_t* __restrict__ n_rois,
@@ -54,14 +56,23 @@ void roi_pool_kernel(const float* __restrict__ fm, int fh, int fw, int C,
             lo[j] = rp_bf16_rne(r1 - rp_bf16_f32(mid[j]));
         }
         const int k = ((ph * pooled) + pw) * C + 4 * c4;
-        unsigned char* p = reinterpret_cast<unsigned char*>(out) + ((size_t)(k >> 4) * rec_rows + r) * 96 + (k & 15) * 2;
+        unsigned char* p;
+        int tstride;
+        if (X6 == 2) {
+            p = reinterpret_cast<unsigned char*>(out) + ((size_t)(k >> 4) * (rec_rows >> 5) + (r >> 5)) * 3072 + ((k >> 3) & 1) * 512 +
+                (r & 31) * 16 + (k & 7) * 2;
+            tstride = 1024;
+        } else {
+            p = reinterpret_cast<unsigned char*>(out) + ((size_t)(k >> 4) * rec_rows + r) * 96 + (k & 15) * 2;
+            tstride = 32;
+        }
         uint2 ph_, pm_, pl_;
         ph_.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16);   ph_.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
         pm_.x = (unsigned)mid[0] | ((unsigned)mid[1] << 16); pm_.y = (unsigned)mid[2] | ((unsigned)mid[3] << 16);
         pl_.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16);   pl_.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
         *reinterpret_cast<uint2*>(p) = ph_;
-        *reinterpret_cast<uint2*>(p + 32) = pm_;
-        *reinterpret_cast<uint2*>(p + 64) = pl_;
+        *reinterpret_cast<uint2*>(p + tstride) = pm_;
+        *reinterpret_cast<uint2*>(p + 2 * tstride) = pl_;
     };
     if (r >= *n_rois) {
         for (int i = threadIdx.x; i < C4; i += 128) emit(i, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -136,7 +147,7 @@ int launch_roi_pool(const float* fm, int fh, int fw, int c, const float* rois, c
                     int max_rois, int pooled, float scale, float* out, hipStream_t s)
 {
     if (fh < 1 || fw < 1 || c < 4 || c % 4 != 0 || max_rois < 1 || pooled < 1) return FRCNN_EINVAL;
-    hipLaunchKernelGGL(roi_pool_kernel<false>, dim3(max_rois, pooled, pooled), dim3(128), 0, s, fm, fh, fw, c, rois,
+    hipLaunchKernelGGL(roi_pool_kernel<0>, dim3(max_rois, pooled, pooled), dim3(128), 0, s, fm, fh, fw, c, rois,
                        n_rois, pooled, scale, out, 0);
     return check_launch();
 }
@@ -147,7 +158,18 @@ int launch_roi_pool_x6(const float* fm, int fh, int fw, int c, const float* rois
                        int max_rois, int pooled, float scale, void* rec, int rec_rows, hipStream_t s)
 {
     if (fh < 1 || fw < 1 || c < 16 || c % 16 != 0 || max_rois < 1 || pooled < 1 || rec_rows < max_rois) return FRCNN_EINVAL;
-    hipLaunchKernelGGL(roi_pool_kernel<true>, dim3(max_rois, pooled, pooled), dim3(128), 0, s, fm, fh, fw, c, rois,
+    hipLaunchKernelGGL(roi_pool_kernel<1>, dim3(max_rois, pooled, pooled), dim3(128), 0, s, fm, fh, fw, c, rois,
+                       n_rois, pooled, scale, static_cast<float*>(rec), rec_rows);
+    return check_launch();
+}
+
+// the same pooling, output = the x6t record array (csrc/gemm_x6t.hip) of the [max_rois][pooled * pooled * c] matrix; rec_rows % 32 == 0
+// rows allocated, the rows max_rois .. rec_rows-1 are the caller's to zero once; c % 16 == 0
+int launch_roi_pool_x6t(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
+                        int max_rois, int pooled, float scale, void* rec, int rec_rows, hipStream_t s)
+{
+    if (fh < 1 || fw < 1 || c < 16 || c % 16 != 0 || max_rois < 1 || pooled < 1 || rec_rows < max_rois || rec_rows % 32 != 0) return FRCNN_EINVAL;
+    hipLaunchKernelGGL(roi_pool_kernel<2>, dim3(max_rois, pooled, pooled), dim3(128), 0, s, fm, fh, fw, c, rois,
                        n_rois, pooled, scale, static_cast<float*>(rec), rec_rows);
     return check_launch();
 }

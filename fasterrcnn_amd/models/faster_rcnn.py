@@ -240,7 +240,7 @@ class FasterRCNNModel(nn.Module):
     def fc_math_mode(self, mode):
         if mode not in nv.FC_MATH_MODES:
             raise ValueError("fc_math_mode must be one of %s" % sorted(nv.FC_MATH_MODES))
-        if mode == "f32x6" and self._is_resnet:
+        if mode != "f32" and self._is_resnet:
             raise NotImplementedError("the ResNet detector head (layer4 + mean) has no fc1 / fc2")
         self._fc_math_mode = mode
         if not self._is_resnet:
@@ -310,8 +310,8 @@ class FasterRCNNModel(nn.Module):
         configured for more proposals runs the exact-f32 kernel on an f32 pack of the same weights (no refusal, no error)."""
         if self._is_resnet:
             return "f32"
-        if self._fc_math_mode == "f32x6" and int(self.max_proposals_post_nms) > nv.LINEAR_X6_ROWS:
-            return "f32"
+        if self._fc_math_mode == "f32x6_v1" and int(self.max_proposals_post_nms) > nv.LINEAR_X6_ROWS:
+            return "f32"                    # round 2's kernel multiplies at most 320 rows; the round-3 kernel ("f32x6") has no such limit
         return self._fc_math_mode
 
     def _check_limits(self, with_detections=True):

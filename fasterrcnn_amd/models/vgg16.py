@@ -207,8 +207,10 @@ class PoolToFeatureVector(nn.Module):
             self._packed_key = key
         if mode not in self._packed:
             w1p, b1, w2, b2 = self.packed_direct()
-            if mode == "f32x6":
+            if mode == "f32x6_v1":
                 w1p, w2 = split_rows_x6(w1p, rows_out=4096), split_rows_x6(w2, rows_out=4096)
+            elif mode == "f32x6":
+                w1p, w2 = split_rows_x6t(w1p, 4096), split_rows_x6t(w2, 4096)
             self._packed[mode] = (w1p, b1, w2, b2)
         return self._packed[mode]
 
@@ -220,12 +222,47 @@ class PoolToFeatureVector(nn.Module):
         x = rt.as_f32_cuda(rois, "rois")
         n = int(x.shape[0])
         x = x.permute(0, 2, 3, 1).contiguous().reshape(n, 49 * 512)   # layout plumbing: (C,7,7) -> (7,7,C)
-        mode = self.fc_math_mode if n <= nv.LINEAR_X6_ROWS else "f32"
+        mode = self.fc_math_mode
+        if mode == "f32x6_v1" and n > nv.LINEAR_X6_ROWS:
+            mode = "f32"
         w1p, b1, w2, b2 = self.packed(mode)
-        if w1p.dtype == t.uint8:
+        if mode == "f32x6":
+            h1 = linear_x6t(x, w1p, b1, 4096, relu=True)
+            return linear_x6t(h1, w2, b2, 4096, relu=True)
+        if mode == "f32x6_v1":
             h1_rec = linear_x6(split_rows_x6(x), w1p, b1, n, 4096, 49 * 512, relu=True, want="records")
             return linear_x6(h1_rec, w2, b2, n, 4096, 4096, relu=True, want="float32")
         return linear(linear(x, w1p, b1, 4096, relu=True), w2, b2, 4096, relu=True)
+
+
+def split_rows_x6t(a, rows_padded):
+    """float32 (R, K) CUDA matrix -> its x6t TILE records (uint8, [K/16][rows_padded/32][3][1 KB]: csrc/gemm_x6t.hip); rows beyond R zero."""
+    r, k = int(a.shape[0]), int(a.shape[1])
+    a = a.contiguous()
+    lib = nv.lib()
+    rec = t.empty((int(lib.frcnn_x6t_record_bytes(rows_padded, k)),), dtype=t.uint8, device=a.device)
+    with t.cuda.device(a.device):
+        nv.check(lib.frcnn_split_rows_x6t(nv.ptr(a), k, 0, nv.ptr(rec), r, rows_padded, k, 1, nv.stream_ptr()), "frcnn_split_rows_x6t")
+    return rec
+
+
+def linear_x6t(x, w_rec, b, n_out, relu):
+    """y = act(x @ w.T + b) in the f32x6 arithmetic through frcnn_gemm_x6t; x (M, K) float32 CUDA, w_rec = x6t records of w [n_out][K]
+    (rows padded to a multiple of 256).  Any M: the activation records are padded to the GEMM's 320-row tiles."""
+    m, k = int(x.shape[0]), int(x.shape[1])
+    y = t.empty((m, n_out), dtype=t.float32, device=x.device)
+    if m == 0:
+        return y
+    lib = nv.lib()
+    mp = (m + nv.X6T_ROW_TILE - 1) // nv.X6T_ROW_TILE * nv.X6T_ROW_TILE
+    np_ = (n_out + nv.X6T_COL_TILE - 1) // nv.X6T_COL_TILE * nv.X6T_COL_TILE
+    a_rec = split_rows_x6t(x, mp)
+    wsb = int(lib.frcnn_gemm_x6t_workspace_bytes(m, n_out, k, 1))
+    ws = t.empty((max(wsb, 4),), dtype=t.uint8, device=x.device)
+    with t.cuda.device(x.device):
+        nv.check(lib.frcnn_gemm_x6t(nv.ptr(a_rec), mp, 0, nv.ptr(w_rec), np_, 0, nv.ptr(b), None, nv.ptr(y), n_out, 0, m, n_out, k, 1,
+                                    nv.RELU if relu else 0, nv.ptr(ws), wsb, nv.stream_ptr()), "frcnn_gemm_x6t")
+    return y
 
 
 def split_rows_x6(a, rows_out=None):

@@ -434,7 +434,9 @@ typedef struct frcnn_forward_params {
 #define FRCNN_ROI_POOL  0
 #define FRCNN_ROI_ALIGN 1
 #define FRCNN_FC_F32   0
-#define FRCNN_FC_F32X6 1
+#define FRCNN_FC_F32X6 1      /* rounds 2's kernel (csrc/linear_x6.hip, chunk-major records, <= FRCNN_LINEAR_X6_ROWS RoIs) */
+#define FRCNN_FC_F32X6T 2     /* round 3: the same arithmetic on csrc/gemm_x6t.hip (fc1_w / fc2_w = frcnn_split_rows_x6t records of the
+                                 same matrices, rows padded to FRCNN_X6T_COL_TILE; any number of RoIs the ctx holds) */
 
 /* d_image: float32 NCHW [3][H][W] (preprocessed as models/vgg16.py:146 prescribes).
  * d_anchor_map / d_valid_map: optional caller-provided maps (faster_rcnn.py:113-115); NULL =

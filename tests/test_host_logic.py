@@ -248,7 +248,7 @@ def test_bench_layer_arithmetic_discloses_pipes():
     names = [r[0] for r in rows]
     assert names == bench._CONV_NAMES + ["rpn_heads_1x1", "fc1", "fc2", "detector_heads"]
     by = {r[0]: r for r in rows}
-    assert by["fc1"][2] == "bf16" and by["fc1"][3] == 6.0 * by["fc1"][4]
+    assert by["fc1"][2] == "bf16" and by["fc1"][3] == 6.0 * by["fc1"][4] and by["fc1"][1] == "gemm_x6t_kernel"
     assert all(by[n][2] == "f32" and by[n][1] == "wino_fused_kernel" for n in bench._CONV_NAMES)
     pf = bench.pipe_flops_per_image("f32_winograd", "f32x6")
     assert abs(pf["f32"] - (1.683e11 + 2.0 * 512 * 45 * 37 * 62 + 300 * 2.0 * 4096 * 101)) / pf["f32"] < 1e-3
