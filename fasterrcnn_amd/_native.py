@@ -98,7 +98,8 @@ class ForwardParams(C.Structure):
 
 
 # capacity limits of the kernels (validated by FasterRCNNModel with a message; the C entry points return FRCNN_EINVAL / EUNSUPPORTED)
-MAX_NUM_CLASSES = 26        # classifier (n) + regressor (4n-4) rows stacked into one 128-row operand (csrc/api.hip)
+MAX_NUM_CLASSES = 103       # FRCNN_MAX_NUM_CLASSES: classifier (n) + regressor (4n-4) rows stacked into one operand of <= 512 rows (csrc/api.hip)
+MAX_NUM_CLASSES_TRAIN = 26  # the train step's loss / gradient kernels keep the 128-row stacked head (fasterrcnn_amd/training.py)
 MAX_POST_NMS_DETECT = 512   # DET_MAX of csrc/detect.hip (per-class NMS bit matrix in LDS)
 MAX_POST_NMS_CTX = 512      # frcnn_ctx_create's max_rois bound (forward() without detections is limited by the ctx only)
 MAX_PRE_NMS = 16384         # frcnn_ctx pre_cap (csrc/api.hip): one-block radix select + sort

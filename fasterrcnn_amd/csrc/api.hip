@@ -47,7 +47,7 @@ struct frcnn_ctx {
     void* rx_ws = nullptr; size_t rx_ws_bytes = 0;       // their split-K partials
     float* res_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // ResNet bottleneck rotation
     size_t res_buf_floats = 0;
-    int last_c = 512, last_vec = 4096;
+    int last_c = 512, last_vec = 4096, last_head_ld = 128;
     ProposalScratch ps{};
     // anchor cache key
     int anc_h = -1, anc_w = -1, anc_fh = -1, anc_fw = -1;
@@ -632,10 +632,10 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
     {
         const size_t w1 = linear_workspace_bytes(max_rois, 4096, 512 * 49);
         const size_t w2 = linear_workspace_bytes(max_rois, 4096, 4096);
-        const size_t w3 = linear_workspace_bytes(max_rois, 128, 4096);
+        const size_t w3 = linear_workspace_bytes(max_rois, FRCNN_HEAD_LD_MAX, 4096);
         const size_t w4 = linear_workspace_bytes(c->max_fh * c->max_fw, 45, 512);
         const size_t w5 = linear_workspace_bytes(c->max_fh * c->max_fw, 45, 1024);
-        const size_t w6 = linear_workspace_bytes(max_rois, 128, 2048);
+        const size_t w6 = linear_workspace_bytes(max_rois, FRCNN_HEAD_LD_MAX, 2048);
         lin = w1; if (w2 > lin) lin = w2; if (w3 > lin) lin = w3; if (w4 > lin) lin = w4; if (w5 > lin) lin = w5; if (w6 > lin) lin = w6;
         const size_t x1 = linear_x6_workspace_bytes(max_rois > 320 ? 320 : max_rois, 4096, 512 * 49);
         const size_t x2 = linear_x6_workspace_bytes(max_rois > 320 ? 320 : max_rois, 4096, 4096);
@@ -686,7 +686,7 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         {(void**)&c->roi_out, (size_t)max_rois * 49 * 1024 * 4},
         {(void**)&c->fc1_out, (size_t)max_rois * 4096 * 4}, {(void**)&c->fc2_out, (size_t)max_rois * 4096 * 4},
         {(void**)&c->roi_rec, (size_t)rec_rows * 49 * 512 * 6}, {(void**)&c->fc1_rec, (size_t)rec_rows * 4096 * 6},
-        {(void**)&c->head_logits, (size_t)max_rois * 128 * 4},
+        {(void**)&c->head_logits, (size_t)max_rois * FRCNN_HEAD_LD_MAX * 4},
         {(void**)&c->lin_ws, lin}, {(void**)&c->conv_ws, cws},
         {(void**)&c->res_buf[0], c->res_buf_floats * 4}, {(void**)&c->res_buf[1], c->res_buf_floats * 4},
         {(void**)&c->res_buf[2], c->res_buf_floats * 4}, {(void**)&c->res_buf[3], c->res_buf_floats * 4},
@@ -784,7 +784,7 @@ int frcnn_ctx_tensor(frcnn_ctx* c, int which, void** d_ptr, size_t* bytes)
         case 5: *d_ptr = c->fc2_out; *bytes = (size_t)c->last_post * c->last_vec * 4; break;
         case 6: *d_ptr = c->anchor_map; *bytes = fmsz * 9 * 16; break;
         case 7: *d_ptr = c->valid_map; *bytes = fmsz * 9 * 4; break;
-        case 8: *d_ptr = c->head_logits; *bytes = (size_t)c->last_post * 128 * 4; break;
+        case 8: *d_ptr = c->head_logits; *bytes = (size_t)c->last_post * c->last_head_ld * 4; break;
         default: return FRCNN_EINVAL;
     }
     return FRCNN_OK;
@@ -904,7 +904,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     if (!c || !w || !p || !d_image || !d_props || !d_classes || !d_deltas || !d_counts) return FRCNN_EINVAL;
     if (H < 16 || W < 16 || H > c->max_h || W > c->max_w) return FRCNN_EINVAL;
     if (p->post_nms < 1 || p->post_nms > c->max_rois || p->pre_nms < 1 || p->pre_nms > c->pre_cap) return FRCNN_EINVAL;
-    if (w->num_classes < 2 || w->num_classes > 26) return FRCNN_EUNSUPPORTED;   // ncls + 4(ncls-1) <= 128
+    if (w->num_classes < 2 || w->num_classes > FRCNN_MAX_NUM_CLASSES) return FRCNN_EUNSUPPORTED;   // ncls + 4 (ncls - 1) <= FRCNN_HEAD_LD_MAX
     for (int i = 0; i < 13; ++i) if (!w->conv_w[i] || !w->conv_b[i]) return FRCNN_EINVAL;
     if (!w->rpn_conv_w || !w->rpn_conv_b || !w->rpn_head_w || !w->rpn_head_b || !w->fc1_w || !w->fc1_b ||
         !w->fc2_w || !w->fc2_b || !w->head_w || !w->head_b)
@@ -1021,9 +1021,11 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
                               c->lin_ws, c->lin_ws_bytes, s));
     }
     const int ncls = w->num_classes, nd = (ncls - 1) * 4;
-    STEP(2, launch_linear(c->fc2_out, 4096, w->head_w, w->head_b, c->head_logits, 128, R_, ncls + nd, 4096, 0u,
+    const int hld = cdiv(ncls + nd, 128) * 128;                  // row count of the stacked classifier + regressor operand (zero padded)
+    c->last_head_ld = hld;
+    STEP(2, launch_linear(c->fc2_out, 4096, w->head_w, w->head_b, c->head_logits, hld, R_, ncls + nd, 4096, 0u,
                           c->lin_ws, c->lin_ws_bytes, s));
-    STEP(5, launch_head_finish(c->head_logits, 128, R_, ncls, nd, d_classes, d_deltas, s));
+    STEP(5, launch_head_finish(c->head_logits, hld, R_, ncls, nd, d_classes, d_deltas, s));
 #undef STEP
 #undef CONV
     return FRCNN_OK;
@@ -1135,7 +1137,7 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     if (!c || !w || !p || !d_image || !d_props || !d_classes || !d_deltas || !d_counts) return FRCNN_EINVAL;
     if (H < 32 || W < 32 || H > c->max_h || W > c->max_w) return FRCNN_EINVAL;
     if (p->post_nms < 1 || p->post_nms > c->max_rois || p->pre_nms < 1 || p->pre_nms > c->pre_cap) return FRCNN_EINVAL;
-    if (w->num_classes < 2 || w->num_classes > 26) return FRCNN_EUNSUPPORTED;
+    if (w->num_classes < 2 || w->num_classes > FRCNN_MAX_NUM_CLASSES) return FRCNN_EUNSUPPORTED;
     if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32_WINOGRAD) return FRCNN_EUNSUPPORTED;   // no f32x6 ResNet path
     const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
     if ((p->roi_op != FRCNN_ROI_POOL && p->roi_op != FRCNN_ROI_ALIGN) || p->roi_sampling_ratio > 2) return FRCNN_EINVAL;
@@ -1232,9 +1234,11 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     c->last_vec = V;
     STEP(5, launch_spatial_mean(head_in, c->fc2_out, R_, h, wd, V, s));
     const int ncls = w->num_classes, nd = (ncls - 1) * 4;
-    STEP(2, launch_linear(c->fc2_out, V, w->head_w, w->head_b, c->head_logits, 128, R_, ncls + nd, V, 0u,
+    const int hld = cdiv(ncls + nd, 128) * 128;
+    c->last_head_ld = hld;
+    STEP(2, launch_linear(c->fc2_out, V, w->head_w, w->head_b, c->head_logits, hld, R_, ncls + nd, V, 0u,
                           c->lin_ws, c->lin_ws_bytes, s));
-    STEP(5, launch_head_finish(c->head_logits, 128, R_, ncls, nd, d_classes, d_deltas, s));
+    STEP(5, launch_head_finish(c->head_logits, hld, R_, ncls, nd, d_classes, d_deltas, s));
 #undef STEP
     return FRCNN_OK;
 }

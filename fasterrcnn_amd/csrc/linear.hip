@@ -262,15 +262,17 @@ void softmax_rows_kernel(const float* __restrict__ x, int ldx, float* __restrict
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
-    const float v = lane < ncls ? x[(size_t)row * ldx + lane] : -INFINITY;
-    float mx = v;
+    const float* xr = x + (size_t)row * ldx;
+    const float v0 = lane < ncls ? xr[lane] : -INFINITY, v1 = lane + 64 < ncls ? xr[lane + 64] : -INFINITY;     // ncls <= 128
+    float mx = fmaxf(v0, v1);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    const float e = lane < ncls ? expf(v - mx) : 0.f;
-    float sum = e;
+    const float e0 = lane < ncls ? expf(v0 - mx) : 0.f, e1 = lane + 64 < ncls ? expf(v1 - mx) : 0.f;
+    float sum = e0 + e1;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (lane < ncls) y[(size_t)row * ncls + lane] = e / sum;
+    if (lane < ncls) y[(size_t)row * ncls + lane] = e0 / sum;
+    if (lane + 64 < ncls) y[(size_t)row * ncls + lane + 64] = e1 / sum;
 }
 
 // Detector head epilogue: logits [M][ldx] = [cls(ncls) | box deltas(ndelta) | pad] ->
@@ -283,15 +285,17 @@ void head_finish_kernel(const float* __restrict__ x, int ldx, int M, int ncls, i
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
     const float* xr = x + (size_t)row * ldx;
-    const float v = lane < ncls ? xr[lane] : -INFINITY;
-    float mx = v;
+    // lane l holds the classes l and l + 64 (ncls <= 128); max and sum in the order of a 64-wide butterfly over the pairwise combination
+    const float v0 = lane < ncls ? xr[lane] : -INFINITY, v1 = lane + 64 < ncls ? xr[lane + 64] : -INFINITY;
+    float mx = fmaxf(v0, v1);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    const float e = lane < ncls ? expf(v - mx) : 0.f;
-    float sum = e;
+    const float e0 = lane < ncls ? expf(v0 - mx) : 0.f, e1 = lane + 64 < ncls ? expf(v1 - mx) : 0.f;
+    float sum = e0 + e1;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (lane < ncls) classes[(size_t)row * ncls + lane] = e / sum;
+    if (lane < ncls) classes[(size_t)row * ncls + lane] = e0 / sum;
+    if (lane + 64 < ncls) classes[(size_t)row * ncls + lane + 64] = e1 / sum;
     for (int j = lane; j < ndelta; j += 64) deltas[(size_t)row * ndelta + j] = xr[ncls + j];
 }
 
@@ -429,7 +433,7 @@ int launch_linear(const float* a, int lda, const float* w, const float* bias, fl
 
 int launch_softmax_rows(const float* x, int ldx, float* y, int M, int ncls, hipStream_t s)
 {
-    if (M < 1 || ncls < 1 || ncls > 64 || ldx < ncls) return FRCNN_EINVAL;
+    if (M < 1 || ncls < 1 || ncls > 128 || ldx < ncls) return FRCNN_EINVAL;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, x, ldx, y, M, ncls);
     return check_launch();
 }
@@ -437,7 +441,7 @@ int launch_softmax_rows(const float* x, int ldx, float* y, int M, int ncls, hipS
 int launch_head_finish(const float* x, int ldx, int M, int ncls, int ndelta, float* classes,
                        float* deltas, hipStream_t s)
 {
-    if (M < 1 || ncls < 1 || ncls > 64 || ndelta < 0 || ldx < ncls + ndelta) return FRCNN_EINVAL;
+    if (M < 1 || ncls < 1 || ncls > 128 || ndelta < 0 || ldx < ncls + ndelta) return FRCNN_EINVAL;
     hipLaunchKernelGGL(head_finish_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, x, ldx, M, ncls, ndelta,
                        classes, deltas);
     return check_launch();

@@ -139,12 +139,15 @@ __device__ void bitonic_sort_regs(u64* buf, int tid)
 //                 < min_side, compacts in order into cand_boxes/cand_scores.
 //   MODE 1 (NMS): idx = 0xFFFFFFFF-low; gathers boxes in sorted order, no clip/filter.
 // counts[0] = number selected (<= K), counts[1] = number emitted to cand_*.
-template <int MODE>
+//   SPLIT (round 3, MODE 0 only): the kernel stops after the radix select: the survivors go, unsorted, to `sel_out` (sort_n keys, zero
+//   padded), counts[0] = their number; topk_rank_kernel (many blocks) and topk_emit_kernel finish the job.  The one-block register
+//   bitonic sort of 8192 keys was 63 of this kernel's 103 us with the rest of the chip idle.
+template <int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(1024)
 void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_n,
                       const f32x4* __restrict__ boxes_src, float image_h, float image_w, float min_side,
                       int32_t* __restrict__ sorted_idx, f32x4* __restrict__ cand_boxes,
-                      float* __restrict__ cand_scores, int32_t* __restrict__ counts)
+                      float* __restrict__ cand_scores, int32_t* __restrict__ counts, u64* __restrict__ sel_out = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64* buf = reinterpret_cast<u64*>(smem_raw);                 // [sort_n]
@@ -289,6 +292,11 @@ void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_
 #ifdef TOPK_CLOCKS
     tk[3] = __builtin_readcyclecounter();
 #endif
+    if (SPLIT) {
+        for (int i = tid; i < sort_n; i += 1024) sel_out[i] = buf[i];
+        if (tid == 0) counts[0] = want;
+        return;
+    }
     if (sort_n == 8192) {
         bitonic_sort_regs<8>(buf, tid);          // the 6000-of-20646 case: 81 of 91 sub-passes barrier-free
     } else if (sort_n == 16384) {
@@ -427,6 +435,109 @@ void topk_sort_kernel(const u64* __restrict__ keys, int n_keys, int K, int sort_
     tk[5] = __builtin_readcyclecounter();
     if (tid == 0 && n_keys > 20000) printf("topk cycles: load %llu  select %llu  gather %llu  sort %llu  emit %llu\n", tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4]);
 #endif
+}
+
+// Rank sort of the selected keys (all different: the low word is the anchor index): rank = number of keys greater.  Block = 32 keys x 32
+// segments of the list (1024 threads): wave w holds the keys 32 b .. 32 b + 31 twice (lane halves) against the segments 2 w and 2 w + 1, so
+// that every LDS read of the inner loop is a broadcast; the 32 partial counts of a key meet in LDS.  The thread that owns a key then
+// writes everything the old kernel's emit phase produced for its rank: sorted_idx, the clipped box, the score and the keep flag of the
+// 16-pixel filter (models/rpn.py:135-144).  ~190 blocks for 6000 keys: the whole chip for a few microseconds.
+__global__ __launch_bounds__(1024)
+void topk_rank_kernel(const u64* __restrict__ sel, const int32_t* __restrict__ counts, int sort_n, const f32x4* __restrict__ boxes_src,
+                      float image_h, float image_w, float min_side, int32_t* __restrict__ sorted_idx, f32x4* __restrict__ tmp_boxes,
+                      float* __restrict__ tmp_scores, int32_t* __restrict__ keep_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_rank[];
+    u64* lk = reinterpret_cast<u64*>(smem_rank);                    // [sort_n]
+    int* part = reinterpret_cast<int*>(lk + sort_n);               // [32 keys][32 segments]
+    const int n = counts[0];
+    const int k0 = blockIdx.x * 32;
+    if (k0 >= n) return;
+    const int tid = threadIdx.x;
+    const int npad = (n + 31) & ~31;
+    for (int i = tid; i < npad; i += 1024) lk[i] = i < n ? sel[i] : 0ull;
+    __syncthreads();
+    const int kb = tid & 31, seg = tid >> 5;                         // 32 segments
+    const int seg_len = npad >> 5;
+    const u64 mine = k0 + kb < n ? lk[k0 + kb] : ~0ull;
+    const u64* p = lk + seg * seg_len;
+    int cnt = 0;
+    int j = 0;
+    for (; j + 4 <= seg_len; j += 4) {
+        const u64 a = p[j], b = p[j + 1], c = p[j + 2], d = p[j + 3];
+        cnt += (a > mine) + (b > mine) + (c > mine) + (d > mine);
+    }
+    for (; j < seg_len; ++j) cnt += p[j] > mine;
+    part[kb * 32 + seg] = cnt;
+    __syncthreads();
+    if (tid < 32 && k0 + tid < n) {
+        int rank = 0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) rank += part[tid * 32 + ((q + tid) & 31)];        // rotated: conflict-free column walk
+        const u64 k = lk[k0 + tid];
+        const int idx = (int)((unsigned)(k & 0xFFFFFFFFull) - 1u);
+        f32x4 b = boxes_src[idx];
+        b[0] = fmaxf(b[0], 0.f); b[1] = fmaxf(b[1], 0.f);
+        b[2] = fminf(b[2], image_h); b[3] = fminf(b[3], image_w);
+        if (sorted_idx) sorted_idx[rank] = idx;
+        tmp_boxes[rank] = b;
+        tmp_scores[rank] = from_ordered_bits((unsigned)(k >> 32));
+        keep_flag[rank] = (((b[2] - b[0]) >= min_side) && ((b[3] - b[1]) >= min_side)) ? 1 : 0;
+    }
+}
+
+// Order-preserving compaction of the ranked candidates that passed the size filter: one block, thread t owns the ranks
+// [t per, (t + 1) per).  counts[1] = number emitted.
+__global__ __launch_bounds__(1024)
+void topk_emit_kernel(const f32x4* __restrict__ tmp_boxes, const float* __restrict__ tmp_scores, const int32_t* __restrict__ keep_flag,
+                      int sort_n, f32x4* __restrict__ cand_boxes, float* __restrict__ cand_scores, int32_t* __restrict__ counts)
+{
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x;
+    const int n = counts[0];
+    // flags, boxes and scores of the thread's ranks are all requested before anything is used: ONE global round trip
+    auto body = [&](auto perc) {
+        constexpr int PER = decltype(perc)::value;
+        int fl[PER];
+        f32x4 bx[PER];
+        float sc[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int r = tid * PER + q;
+            const bool in = r < n;
+            fl[q] = in ? keep_flag[r] : 0;
+            bx[q] = in ? tmp_boxes[r] : f32x4{0.f, 0.f, 0.f, 0.f};
+            sc[q] = in ? tmp_scores[r] : 0.f;
+        }
+        int local = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) local += fl[q] ? 1 : 0;
+        int incl = local;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if ((tid & 63) >= o) incl += v;
+        }
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int wv = 0; wv < (tid >> 6); ++wv) wave_off += wave_tot[wv];
+        int pos = wave_off + incl - local;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            if (fl[q]) {
+                cand_boxes[pos] = bx[q];
+                cand_scores[pos] = sc[q];
+                ++pos;
+            }
+        }
+        if (tid == 1023) counts[1] = pos;
+    };
+    const int per = sort_n >> 10 ? sort_n >> 10 : 1;
+    if (per == 8) body(std::integral_constant<int, 8>());
+    else if (per == 16) body(std::integral_constant<int, 16>());
+    else if (per == 4) body(std::integral_constant<int, 4>());
+    else if (per == 2) body(std::integral_constant<int, 2>());
+    else body(std::integral_constant<int, 1>());
 }
 
 // IoU exactly as torchvision's nms kernels compute it (fp32, no +1, no epsilon):
@@ -605,19 +716,43 @@ void proposal_scratch_carve(ProposalScratch& ps, void* base, int a_cap, int pre_
 
 static int pow2_at_least(int v) { int p = 1024; while (p < v) p <<= 1; return p; }
 
+// tmp != NULL (MODE 0): the three-launch form (select -> rank on the whole chip -> emit); tmp holds >= 32 sort_n bytes
 template <int MODE>
 static int launch_topk(const u64* keys, int n_keys, int K, const float* boxes_src, float ih, float iw,
                        float min_side, int32_t* sorted_idx, float* cand_boxes, float* cand_scores,
-                       int32_t* counts, hipStream_t s)
+                       int32_t* counts, hipStream_t s, void* tmp = nullptr)
 {
     const int sort_n = pow2_at_least(K);
     if (sort_n > 16384) return FRCNN_EUNSUPPORTED;
     const size_t lds = (size_t)sort_n * 8 + 4096 * 4 + 64 * 4;
+    static const bool no_split = getenv("FRCNN_TOPK_ONE_BLOCK") != nullptr;          // experiments / A-B tests
+    if (MODE == 0 && tmp != nullptr && !no_split) {
+        unsigned char* tb = static_cast<unsigned char*>(tmp);
+        u64* sel = reinterpret_cast<u64*>(tb);
+        f32x4* tboxes = reinterpret_cast<f32x4*>(tb + (size_t)sort_n * 8);
+        float* tscores = reinterpret_cast<float*>(tb + (size_t)sort_n * 24);
+        int32_t* flags = reinterpret_cast<int32_t*>(tb + (size_t)sort_n * 28);
+        auto k1 = topk_sort_kernel<0, true>;
+        FRCNN_MAX_LDS_ONCE(k1, 16384 * 8 + 4096 * 4 + 64 * 4);
+        hipLaunchKernelGGL(k1, dim3(1), dim3(1024), lds, s, keys, n_keys, K, sort_n, reinterpret_cast<const f32x4*>(boxes_src), ih, iw,
+                           min_side, sorted_idx, reinterpret_cast<f32x4*>(cand_boxes), cand_scores, counts, sel);
+        int rc = check_launch();
+        if (rc) return rc;
+        const size_t lds2 = (size_t)sort_n * 8 + 32 * 32 * 4;
+        FRCNN_MAX_LDS_ONCE(topk_rank_kernel, 16384 * 8 + 32 * 32 * 4);
+        hipLaunchKernelGGL(topk_rank_kernel, dim3(cdiv(K, 32)), dim3(1024), lds2, s, sel, counts, sort_n,
+                           reinterpret_cast<const f32x4*>(boxes_src), ih, iw, min_side, sorted_idx, tboxes, tscores, flags);
+        rc = check_launch();
+        if (rc) return rc;
+        hipLaunchKernelGGL(topk_emit_kernel, dim3(1), dim3(1024), 0, s, tboxes, tscores, flags, sort_n, reinterpret_cast<f32x4*>(cand_boxes),
+                           cand_scores, counts);
+        return check_launch();
+    }
     auto kern = topk_sort_kernel<MODE>;
     FRCNN_MAX_LDS_ONCE(kern, 16384 * 8 + 4096 * 4 + 64 * 4);
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, s, keys, n_keys, K, sort_n,
                        reinterpret_cast<const f32x4*>(boxes_src), ih, iw, min_side, sorted_idx,
-                       reinterpret_cast<f32x4*>(cand_boxes), cand_scores, counts);
+                       reinterpret_cast<f32x4*>(cand_boxes), cand_scores, counts, (u64*)nullptr);
     return check_launch();
 }
 
@@ -635,8 +770,9 @@ int launch_rpn_proposals(const ProposalScratch& ps, const float* head, int ld_he
                        valid_map, A, scores, reinterpret_cast<f32x4*>(ps.boxes_all), ps.keys);
     int rc = check_launch();
     if (rc) return rc;
+    // (the NMS bit matrix is written after the top-N: its storage doubles as the top-N's scratch)
     rc = launch_topk<0>(ps.keys, A, pre_nms, ps.boxes_all, (float)image_h, (float)image_w, min_side,
-                        sorted_idx, ps.cand_boxes, ps.cand_scores, counts, s);
+                        sorted_idx, ps.cand_boxes, ps.cand_scores, counts, s, ps.mask);
     if (rc) return rc;
     const int nw = cdiv(pre_nms, 64);
     const int nw_stride = ps.pre_cap / 64;

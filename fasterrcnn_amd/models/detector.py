@@ -44,7 +44,8 @@ class DetectorNetwork(nn.Module):
         params = [self._classifier.weight, self._classifier.bias, self._regressor.weight, self._regressor.bias]
         key = rt.param_key(params)
         if key != self._packed_key:
-            self._packed = pack_stack_rows(self._classifier, self._regressor)
+            n = 5 * self._num_classes - 4
+            self._packed = pack_stack_rows(self._classifier, self._regressor, n_pad=(n + 127) // 128 * 128)
             self._packed_key = key
         return self._packed
 

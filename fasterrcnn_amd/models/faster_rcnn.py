@@ -77,8 +77,8 @@ class FasterRCNNModel(nn.Module):
         # capacity limits of the kernels behind this class (csrc/api.hip, csrc/detect.hip); the reference has none, so
         # they are refused here with their reason instead of as a bare error code from the first forward
         if not 2 <= int(num_classes) <= nv.MAX_NUM_CLASSES:
-            raise ValueError("num_classes must be in [2, %d]: classifier + regressor rows are stacked into one 128-row GEMM "
-                             "operand (5 x num_classes - 4 <= 128); got %r" % (nv.MAX_NUM_CLASSES, num_classes))
+            raise ValueError("num_classes must be in [2, %d]: classifier + regressor rows are stacked into one GEMM operand of at "
+                             "most 512 rows (5 x num_classes - 4 <= 512); got %r" % (nv.MAX_NUM_CLASSES, num_classes))
 
         # Constants (faster_rcnn.py:60-64)
         self._num_classes = num_classes

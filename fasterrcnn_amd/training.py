@@ -663,6 +663,9 @@ def enable_data_parallel(model, group=None, bucket_bytes=64 << 20, direct_bytes=
 
 
 def make_train_state(model):
+    if model._num_classes > nv.MAX_NUM_CLASSES_TRAIN:
+        raise NotImplementedError("train_step supports num_classes <= %d (its loss / gradient kernels keep the 128-row stacked head); "
+                                  "inference supports up to %d" % (nv.MAX_NUM_CLASSES_TRAIN, nv.MAX_NUM_CLASSES))
     return ResNetTrainState(model) if model._is_resnet else VGG16TrainState(model)
 
 

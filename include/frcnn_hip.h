@@ -428,6 +428,10 @@ typedef struct frcnn_forward_params {
                                    overlap the GEMM -- measured +3..8 % images/sec at 3 images in flight) */
 } frcnn_forward_params;
 #define FRCNN_X6_RPN_TRUNK_BIT 13
+/* capacity of the detector heads: classifier (n) + regressor (4 n - 4) rows are stacked into one zero-padded GEMM operand of
+ * ceil((5 n - 4) / 128) * 128 rows (head_w / head_b of the weight structs), at most FRCNN_HEAD_LD_MAX */
+#define FRCNN_HEAD_LD_MAX 512
+#define FRCNN_MAX_NUM_CLASSES 103
 #define FRCNN_MATH_F32   0
 #define FRCNN_MATH_F32X6 1
 #define FRCNN_MATH_F32_WINOGRAD 2

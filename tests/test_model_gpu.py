@@ -438,3 +438,36 @@ def test_smallest_supported_image(gpu_model, sd_cpu):
     if o[0].shape[0]:
         j, err = match_rows(g[0].cpu().numpy(), o[0].numpy())
         assert (err <= 1e-3).mean() >= 0.9
+
+
+def test_model_with_81_classes_matches_the_oracle():
+    """the reference accepts any num_classes (models/detector.py:29-30); rounds 1-2 stopped at 26 (one 128-row stacked head
+    operand).  COCO-sized heads: 81 classes = 401 stacked rows, softmax over 81 columns, 80 per-class NMS blocks."""
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    from fasterrcnn_amd.models.vgg16 import VGG16Backbone
+    sd = synthetic.vgg16_state_dict(1234, num_classes=81)
+    model = FasterRCNNModel(num_classes=81, backbone=VGG16Backbone(dropout_probability=0.0))
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    img = synthetic.image(6, 320, 448).unsqueeze(0)
+    p, c, d = model(image_data=img.cuda())
+    rp, rc, rd = O.forward(sd, img)
+    assert tuple(c.shape) == (p.shape[0], 81) and tuple(d.shape) == (p.shape[0], 320) and p.shape[0] == rp.shape[0]
+    j, err = match_rows(p.cpu().numpy(), rp.numpy())
+    ok = err <= 1e-3
+    c_err = float(np.abs(c.cpu().numpy()[j[ok]] - rc.numpy()[ok]).max())
+    d_err = float(np.abs(d.cpu().numpy()[j[ok]] - rd.numpy()[ok]).max())
+    print("81 classes: %d/%d proposals, class err %.3g, delta err %.3g" % (int(ok.sum()), len(ok), c_err, d_err))
+    assert ok.mean() == 1.0 and c_err <= 1e-5 and d_err <= 5e-5        # observed: 300 / 300, 2.7e-6, 6.3e-6
+    assert float(np.abs(c.cpu().numpy().sum(axis=1) - 1.0).max()) <= 1e-5
+    det = model.predict(image_data=img.cuda(), score_threshold=0.02)
+    ref = O.predict(sd, img, 0.02)
+    assert sorted(det.keys()) == list(range(1, 81))
+    n_ref = sum(len(v) for v in ref.values())
+    n_ok = 0
+    for cls in ref:
+        if len(ref[cls]) and len(det[cls]):
+            jj, ee = match_rows(det[cls], ref[cls])
+            n_ok += int(((ee <= 1e-3) & (np.abs(det[cls][jj, 4] - ref[cls][:, 4]) <= 1e-4)).sum())
+    print("81 classes: %d/%d oracle detections reproduced (ours %d)" % (n_ok, n_ref, sum(len(v) for v in det.values())))
+    assert n_ref > 0 and n_ok == n_ref and sum(len(v) for v in det.values()) == n_ref      # observed: 441 / 441, no extra rows

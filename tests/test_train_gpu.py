@@ -844,7 +844,12 @@ def test_constructor_refuses_unsupported_capacities():
     from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
     from fasterrcnn_amd.models.vgg16 import VGG16Backbone
     with pytest.raises(ValueError, match="num_classes"):
-        FasterRCNNModel(num_classes=81, backbone=VGG16Backbone(dropout_probability=0.0))
+        FasterRCNNModel(num_classes=104, backbone=VGG16Backbone(dropout_probability=0.0))
+    from fasterrcnn_amd import training
+    m81 = FasterRCNNModel(num_classes=81, backbone=VGG16Backbone(dropout_probability=0.0)).cuda()      # inference: fine (round 3)
+    with pytest.raises(NotImplementedError, match="num_classes"):
+        training.make_train_state(m81)                                                                    # the train step keeps <= 26
+    del m81
     m = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0)).cuda().eval()
     m.max_proposals_post_nms = 1000
     with pytest.raises(ValueError, match="max_proposals_post_nms"):
