@@ -40,7 +40,7 @@ SYMBOLS = (
     "frcnn_conv3x3_uses_winograd_fused", "frcnn_resnet_block_uses_winograd_fused", "frcnn_pack_conv3x3_winograd_fused", "frcnn_pack_conv3x3_winograd_fused_taps",
     "frcnn_conv3x3_nhwc_winograd_fused", "frcnn_split_rows_x6", "frcnn_linear_x6_workspace_bytes", "frcnn_linear_x6",
     "frcnn_roi_align", "frcnn_roi_align_backward",
-    "frcnn_x6t_record_bytes", "frcnn_split_rows_x6t", "frcnn_gemm_x6t_workspace_bytes", "frcnn_gemm_x6t", "frcnn_split_pixels_x6t",
+    "frcnn_x6t_record_bytes", "frcnn_split_rows_x6t", "frcnn_gemm_x6t_workspace_bytes", "frcnn_gemm_x6t", "frcnn_split_pixels_x6t", "frcnn_split_patches3x3_x6t",
     "frcnn_conv3x3_uses_winograd_x6", "frcnn_conv3x3_winograd_x6_pack_bytes", "frcnn_pack_conv3x3_winograd_x6",
     "frcnn_conv3x3_winograd_x6_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x6",
     # training path
@@ -190,8 +190,9 @@ _SIGNATURES = {
     "frcnn_conv3x3_uses_winograd_x6": (C.c_int, [_i, _i]),
     "frcnn_conv3x3_winograd_x6_pack_bytes": (C.c_size_t, [_i, _i]),
     "frcnn_pack_conv3x3_winograd_x6": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
-    "frcnn_conv3x3_winograd_x6_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
-    "frcnn_conv3x3_nhwc_winograd_x6": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_conv3x3_winograd_x6_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "frcnn_conv3x3_nhwc_winograd_x6": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_split_patches3x3_x6t": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "frcnn_conv3x3_uses_winograd_fused": (C.c_int, [_i, _i]),
     "frcnn_resnet_block_uses_winograd_fused": (C.c_int, [_i, _i, _i]),
     "frcnn_pack_conv3x3_winograd_fused": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),

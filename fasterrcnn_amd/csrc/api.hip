@@ -306,13 +306,22 @@ int frcnn_pack_conv3x3_winograd_x6(const float* d_w, const float* d_row_scale, v
     return launch_pack_conv3x3_winograd_x6(d_w, d_row_scale, d_u_rec, cout, cin, as_stream(stream));
 }
 
-size_t frcnn_conv3x3_winograd_x6_workspace_bytes(int H, int W, int cin, int cout) { return conv3x3_winograd_x6_workspace_bytes(H, W, cin, cout); }
+size_t frcnn_conv3x3_winograd_x6_workspace_bytes(int n_maps, int H, int W, int cin, int cout)
+{
+    return conv3x3_winograd_x6_workspace_bytes(n_maps, H, W, cin, cout);
+}
 
-int frcnn_conv3x3_nhwc_winograd_x6(const float* d_x, const void* d_u_rec, const float* d_bias, float* d_y, int H, int W, int cin,
+int frcnn_conv3x3_nhwc_winograd_x6(const float* d_x, const void* d_u_rec, const float* d_bias, float* d_y, int n_maps, int H, int W, int cin,
                                    int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
 {
     if (!d_x || !d_u_rec || !d_bias || !d_y) return FRCNN_EINVAL;
-    return launch_conv3x3_winograd_x6(d_x, d_u_rec, d_bias, d_y, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
+    return launch_conv3x3_winograd_x6(d_x, d_u_rec, d_bias, d_y, n_maps, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
+}
+
+int frcnn_split_patches3x3_x6t(const float* d_x, void* d_rec, int N, int H, int W, int C, int stride, int rows_padded, void* stream)
+{
+    if (!d_x || !d_rec) return FRCNN_EINVAL;
+    return launch_split_patches3x3_x6t(d_x, d_rec, N, H, W, C, stride, rows_padded, as_stream(stream));
 }
 
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream)
@@ -841,7 +850,7 @@ int ensure_wx_ws(frcnn_ctx* c, size_t layer_need, hipStream_t s)
     const int shapes[4][4] = {{c->max_h / 8, c->max_w / 8, 256, 512}, {c->max_h / 8, c->max_w / 8, 512, 512},
                               {c->max_fh, c->max_fw, 512, 512}, {c->max_fh, c->max_fw, 1024, 1024}};
     for (auto& sh : shapes) {
-        const size_t b = conv3x3_winograd_x6_workspace_bytes(sh[0], sh[1], sh[2], sh[3]);
+        const size_t b = conv3x3_winograd_x6_workspace_bytes(1, sh[0], sh[1], sh[2], sh[3]);
         if (b > need) need = b;
     }
     if (need == 0) return FRCNN_EINVAL;
@@ -860,22 +869,22 @@ int ensure_wx_ws(frcnn_ctx* c, size_t layer_need, hipStream_t s)
 
 // One x6 Winograd layer inside a fused forward: transforms timed as class 8, the batched bf16-pipe GEMM as class 9.
 int run_wino_x6_layer(frcnn_ctx* c, const float* x, const void* urec, const float* b, float* y, int h, int w, int ci, int co,
-                      unsigned flags, hipStream_t s)
+                      unsigned flags, hipStream_t s, int N = 1)
 {
-    if (!conv3x3_uses_winograd_x6(ci, co)) return FRCNN_EINVAL;
-    int r = ensure_wx_ws(c, conv3x3_winograd_x6_workspace_bytes(h, w, ci, co), s);
+    if (N == 1 && !conv3x3_uses_winograd_x6(ci, co)) return FRCNN_EINVAL;
+    int r = ensure_wx_ws(c, conv3x3_winograd_x6_workspace_bytes(N, h, w, ci, co), s);
     if (r) return r;
     void *V = nullptr, *G = nullptr;
     float* M = nullptr;
     size_t gb = 0;
-    r = winograd_x6_plan(h, w, ci, co, flags, c->wx_ws, c->wx_ws_bytes, &V, &M, &G, &gb);
+    r = winograd_x6_plan(N, h, w, ci, co, flags, c->wx_ws, c->wx_ws_bytes, &V, &M, &G, &gb);
     if (r) return r;
-    { Scope _t(c, 8, s); r = launch_winograd_x6_input(x, V, h, w, ci, s); }
+    { Scope _t(c, 8, s); r = launch_winograd_x6_input(x, V, N, h, w, ci, s); }
     if (r) return r;
-    { Scope _g(c, 9, s); r = launch_winograd_x6_gemm(V, urec, M, h, w, ci, co, G, gb, s); }
+    { Scope _g(c, 9, s); r = launch_winograd_x6_gemm(V, urec, M, N, h, w, ci, co, G, gb, s); }
     if (r) return r;
     Scope _o(c, 8, s);
-    return launch_winograd_output(M, b, y, 1, h, w, co, flags, s);
+    return launch_winograd_output(M, b, y, N, h, w, co, flags, s);
 }
 
 // One one-launch Winograd layer inside a fused forward (timed as class 7).
@@ -991,11 +1000,12 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
         } else {
             STEP(4, launch_roi_pool_x6t(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_rec, rr, s));
         }
+        static const int fc_tiles = []() { const char* e = getenv("FRCNN_FC_TILES"); return e ? atoi(e) : 0; }();     // experiments
         STEP(2, launch_gemm_x6t(c->roi_rec, rr, 0, w->fc1_w, 4096, 0, w->fc1_b, nullptr, c->fc1_out, 4096, 0, R_, 4096, 49 * 512, 1, R,
-                                c->lin_ws, c->lin_ws_bytes, s, 0));
+                                c->lin_ws, c->lin_ws_bytes, s, fc_tiles));
         STEP(2, launch_split_rows_x6t(c->fc1_out, 4096, 0, c->fc1_rec, R_, rr, 4096, 1, s));
         STEP(2, launch_gemm_x6t(c->fc1_rec, rr, 0, w->fc2_w, 4096, 0, w->fc2_b, nullptr, c->fc2_out, 4096, 0, R_, 4096, 4096, 1, R,
-                                c->lin_ws, c->lin_ws_bytes, s, 0));
+                                c->lin_ws, c->lin_ws_bytes, s, fc_tiles));
     } else
     if (p->roi_op == FRCNN_ROI_ALIGN) {
         STEP(4, launch_roi_align(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, p->roi_sampling_ratio, 0, c->roi_out, s));
@@ -1035,16 +1045,18 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
 namespace {
 // One 1x1 convolution (stride 1 or 2) of a bottleneck as an f32x6 GEMM: y[N Ho Wo][cout] = act(bias + residual + x_pixels . w^T).
 // The activation records live in the ctx's rx_rec scratch (grown on demand: hipMalloc synchronises, first image of a shape only).
+// (ksize 3: the 3x3 / padding-1 form over im2col records, K = 9 cin -- layer4.0.conv2's stride-2 convolution)
 int run_conv1x1_x6(frcnn_ctx* c, const float* x, const void* wrec, const float* bias, const float* residual, float* y, int N, int h,
-                   int w, int cin, int cout, int stride, unsigned flags, int cls, hipStream_t s)
+                   int w, int cin, int cout, int stride, unsigned flags, int cls, hipStream_t s, int ksize = 1)
 {
-    if (cin % 16 != 0 || cout % 4 != 0) return FRCNN_EINVAL;
+    if (cin % 16 != 0 || cout % 4 != 0 || (ksize != 1 && ksize != 3)) return FRCNN_EINVAL;
     const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+    const int K = ksize == 3 ? 9 * cin : cin;
     const long long rows = (long long)N * ho * wo;
     if (rows > 0x7fffffffLL / 8) return FRCNN_EINVAL;
     const int M = (int)rows;
     const int Mp = cdiv(M, gemm_x6t_row_tile(M)) * gemm_x6t_row_tile(M), Np = cdiv(cout, gemm_x6t_col_tile(cout)) * gemm_x6t_col_tile(cout);
-    const size_t need = x6t_record_bytes(Mp, cin), gneed = gemm_x6t_workspace_bytes(M, cout, cin, 1);
+    const size_t need = x6t_record_bytes(Mp, K), gneed = gemm_x6t_workspace_bytes(M, cout, K, 1);
     if (need > c->rx_rec_bytes) {
         if (c->rx_rec) { FRCNN_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(c->rx_rec); c->rx_rec = nullptr; c->rx_rec_bytes = 0; }
         hipError_t e = hipMalloc(&c->rx_rec, need);
@@ -1058,10 +1070,11 @@ int run_conv1x1_x6(frcnn_ctx* c, const float* x, const void* wrec, const float* 
         c->rx_ws_bytes = gneed;
     }
     int rc;
-    { Scope _t(c, 8, s); rc = launch_split_pixels_x6t(x, c->rx_rec, N, h, w, cin, stride, Mp, s); }
+    { Scope _t(c, 8, s); rc = ksize == 3 ? launch_split_patches3x3_x6t(x, c->rx_rec, N, h, w, cin, stride, Mp, s)
+                                        : launch_split_pixels_x6t(x, c->rx_rec, N, h, w, cin, stride, Mp, s); }
     if (rc) return rc;
     Scope _g(c, cls, s);
-    return launch_gemm_x6t(c->rx_rec, Mp, 0, wrec, Np, 0, bias, residual, y, cout, 0, M, cout, cin, 1, flags, c->rx_ws, c->rx_ws_bytes, s);
+    return launch_gemm_x6t(c->rx_rec, Mp, 0, wrec, Np, 0, bias, residual, y, cout, 0, M, cout, K, 1, flags, c->rx_ws, c->rx_ws_bytes, s);
 }
 
 // One Bottleneck (torchvision v1.5): out = relu(conv3(relu(conv2(relu(conv1(x))))) + identity).
@@ -1090,7 +1103,12 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
     } else {
         RSTEP(launch_conv_gather(X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s));
     }
-    if (wino && resnet_block_uses_winograd_fused(N, b.width, b.stride)) {
+    if (b.x6_mask & FRCNN_X6_CONV2) {
+        // the 3x3 on the bf16 pipe: stride 1 = an x6 Winograd layer over the block's N maps, stride 2 = an im2col GEMM (K = 9 width)
+        rc = b.stride == 1 ? run_wino_x6_layer(c, T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s, N)
+                           : run_conv1x1_x6(c, T1, b.w2, b.b2, nullptr, T2, N, h, w, b.width, b.width, b.stride, R, 9, s, 3);
+        if (rc) return rc;
+    } else if (wino && resnet_block_uses_winograd_fused(N, b.width, b.stride)) {
         rc = run_wino_fused_layer(c, latency, T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s);
         if (rc) return rc;
     } else if (wino && resnet_block_uses_winograd(b.width, b.stride)) {

@@ -154,13 +154,14 @@ int launch_split_pixels_x6t(const float* x, void* rec, int N, int H, int W, int 
 // wino_x6.hip: Winograd F(2x2,3x3) layers whose position GEMMs run on gemm_x6t
 bool conv3x3_uses_winograd_x6(int cin, int cout);
 size_t conv3x3_winograd_x6_pack_bytes(int cout, int cin);
-size_t conv3x3_winograd_x6_workspace_bytes(int H, int W, int cin, int cout);
+size_t conv3x3_winograd_x6_workspace_bytes(int N, int H, int W, int cin, int cout);
 int launch_pack_conv3x3_winograd_x6(const float* w, const float* scale, void* urec, int cout, int cin, hipStream_t s);
-int launch_winograd_x6_input(const float* x, void* vrec, int H, int W, int cin, hipStream_t s);
-int launch_winograd_x6_gemm(const void* vrec, const void* urec, float* M, int H, int W, int cin, int cout, void* gws, size_t gws_bytes, hipStream_t s);
-int winograd_x6_plan(int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, void** V, float** M, void** G, size_t* g_bytes);
-int launch_conv3x3_winograd_x6(const float* x, const void* urec, const float* b, float* y, int H, int W, int cin, int cout,
+int launch_winograd_x6_input(const float* x, void* vrec, int N, int H, int W, int cin, hipStream_t s);
+int launch_winograd_x6_gemm(const void* vrec, const void* urec, float* M, int N, int H, int W, int cin, int cout, void* gws, size_t gws_bytes, hipStream_t s);
+int winograd_x6_plan(int N, int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, void** V, float** M, void** G, size_t* g_bytes);
+int launch_conv3x3_winograd_x6(const float* x, const void* urec, const float* b, float* y, int N, int H, int W, int cin, int cout,
                                unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_split_patches3x3_x6t(const float* x, void* rec, int N, int H, int W, int C, int stride, int rows_padded, hipStream_t s);
 int launch_linear_x6(const void* a_rec, const void* w_rec, const float* bias, float* y, int ldy, void* y_rec, int M, int N, int K,
                      unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_softmax_rows(const float* x, int ldx, float* y, int M, int ncls, hipStream_t s);

@@ -129,6 +129,40 @@ void split_pixels_x6t_kernel(const float* __restrict__ x, unsigned char* __restr
     *reinterpret_cast<uint4*>(dst + 2 * GX_PIECE) = pl;
 }
 
+// im2col + split for a 3x3 convolution with padding 1 and stride 1 / 2: row = output pixel (n, oy, ox), column k = tap * C + c with
+// tap = 3 r + s reading x[n][oy * stride - 1 + r][ox * stride - 1 + s][c] (zero outside the map).  C % 16 == 0, so a 16-k chunk
+// never straddles two taps.  Waves as split_pixels_x6t_kernel.
+__global__ __launch_bounds__(256)
+void split_patches3x3_x6t_kernel(const float* __restrict__ x, unsigned char* __restrict__ rec, int H, int W, int Ho, int Wo, int C, int stride,
+                                 int R, int rbt, int K16)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= (long long)K16 * rbt) return;
+    const int chunk = (int)(wave % K16), rb = (int)(wave / K16);
+    const int row = rb * 32 + (lane & 31), k = chunk * 16 + 8 * (lane >> 5);
+    const int tap = k / C, c = k - tap * C;
+    const int tr = tap / 3, ts = tap - 3 * tr;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (row < R) {
+        const int n = row / (Ho * Wo), rem = row - n * (Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const int iy = oy * stride - 1 + tr, ix = ox * stride - 1 + ts;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const float* src = x + (((size_t)n * H + iy) * W + ix) * C + c;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+        }
+    }
+    uint4 ph, pm, pl;
+    gx_split8(v, ph, pm, pl);
+    unsigned char* dst = rec + ((size_t)chunk * rbt + rb) * GX_RB + lane * 16;
+    *reinterpret_cast<uint4*>(dst) = ph;
+    *reinterpret_cast<uint4*>(dst + GX_PIECE) = pm;
+    *reinterpret_cast<uint4*>(dst + 2 * GX_PIECE) = pl;
+}
+
 struct GxParams {
     const unsigned char* a;     // A records: [batch][chunk][a_rbt][3][1 KB]
     const unsigned char* b;     // B records: [batch][chunk][b_rbt][3][1 KB]
@@ -406,6 +440,18 @@ int launch_split_pixels_x6t(const float* x, void* rec, int N, int H, int W, int 
     return check_launch();
 }
 
+int launch_split_patches3x3_x6t(const float* x, void* rec, int N, int H, int W, int C, int stride, int rows_padded, hipStream_t s)
+{
+    if (N < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || stride < 1 || stride > 2 || rows_padded % 32 != 0) return FRCNN_EINVAL;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;      // (H + 2 - 3) / stride + 1
+    const long long R = (long long)N * Ho * Wo;
+    if (R > rows_padded || R > 0x7fffffffLL) return FRCNN_EINVAL;
+    const long long waves = (long long)(9 * C / 16) * (rows_padded / 32);
+    hipLaunchKernelGGL(split_patches3x3_x6t_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, static_cast<unsigned char*>(rec), H,
+                       W, Ho, Wo, C, stride, (int)R, rows_padded / 32, 9 * C / 16);
+    return check_launch();
+}
+
 // Two tile shapes: cfg 0 = <5, 2, 2, 4> (320 x 256, 8 waves, one block per CU: the least operand traffic and LDS reads per MFMA);
 // cfg 1 = <5, 1, 1, 4> (160 x 128, 4 waves, two blocks per CU: four times the blocks, for problems whose 320 x 256 grid leaves most of
 // the chip idle -- the 589-row position GEMMs of a 37 x 62 map -- at twice the L2 operand traffic per MFMA).
@@ -427,9 +473,17 @@ static GxPlan plan_gemm_x6t(int M, int N, int K, int batches, int tiles_mode = -
     int splits0 = 1;
     while (u0 * splits0 * 2 <= 256 && chunks / (splits0 * 2) >= 8) splits0 *= 2;     // split K until the grid covers the chip once
     const double c0 = (double)((u0 * splits0 + 255) / 256) * 3840.0 / splits0 + (splits0 > 1 ? 600.0 : 0.0);   // + the reduction pass
-    const double c1 = (double)((u1 + 255) / 256) * 960.0 / 0.85;
+    int splits1 = 1;
+    while (u1 * splits1 * 2 <= 512 && chunks / (splits1 * 2) >= 8) splits1 *= 2;     // two 4-wave blocks per CU
+    const double c1 = (double)((u1 * splits1 + 255) / 256) * 960.0 / 0.85 / splits1 + (splits1 > 1 ? 600.0 : 0.0);
     pl.cfg = (force == 0 || force == 1) ? force : (c1 < c0 ? 1 : 0);
-    if (pl.cfg == 1) { pl.mtiles = cdiv(M, 160); pl.ntiles = cdiv(N, 128); pl.splits = 1; pl.chunks_per_split = chunks; return pl; }
+    if (pl.cfg == 1) {
+        pl.mtiles = cdiv(M, 160); pl.ntiles = cdiv(N, 128);
+        int splits = splits1 > chunks ? chunks : splits1;
+        pl.chunks_per_split = cdiv(chunks, splits);
+        pl.splits = cdiv(chunks, pl.chunks_per_split);
+        return pl;
+    }
     pl.mtiles = cdiv(M, 320);
     pl.ntiles = cdiv(N, 256);
     int splits = splits0;

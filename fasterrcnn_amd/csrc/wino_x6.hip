@@ -9,7 +9,8 @@
 // and the product is the sum of the six largest partial products with float32 accumulation (csrc/gemm_x6t.hip) -- 2.7x the
 // exact-f32 pipe's rate at fp32-class accuracy (dropped terms <= 2^-24 relative).
 //
-// Three launches per layer, NHWC, T = ceil(H/2) ceil(W/2) tiles, Tp = T rounded up to the GEMM's 320-row tile:
+// Three launches per layer, NHWC, optionally a batch of N maps (the per-RoI 4 x 4 maps of ResNet's layer4: models/resnet.py:110),
+// T = N ceil(H/2) ceil(W/2) tiles, Tp = T rounded up to the GEMM's 320-row tile:
 //   1. wino_input_x6t_kernel   x [H][W][cin] -> V as x6t records [16 positions][cin/16][Tp/32][3][1 KB]  (B^T d B, then the exact
 //                              3-way split; zero padding folded in; each wave store is one whole 1 KB record piece)
 //   2. gemm_x6t_kernel         16 batched GEMMs M_p [T][cout] = V_p [T][cin] . U_p [cout][cin]^T, U pre-split at pack time
@@ -49,7 +50,7 @@ __device__ __forceinline__ void wx_split8(const float (&v)[8], uint4& ph, uint4&
 // One wave = (16-channel chunk, block of 32 tiles): lane l = tile (l & 31), channels 8 (l >> 5) .. + 7 of the chunk.
 // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] exactly as wino_input_kernel (csrc/winograd.hip).
 __global__ __launch_bounds__(256)
-void wino_input_x6t_kernel(const float* __restrict__ x, unsigned char* __restrict__ vrec, int H, int W, int cin, int tw, int T,
+void wino_input_x6t_kernel(const float* __restrict__ x, unsigned char* __restrict__ vrec, int H, int W, int cin, int tw, int tpi, int T,
                            int rbt, int K16)
 {
     const int lane = threadIdx.x & 63;
@@ -60,8 +61,11 @@ void wino_input_x6t_kernel(const float* __restrict__ x, unsigned char* __restric
     const int tile = rb * 32 + (lane & 31);
     const int c = chunk * 16 + 8 * (lane >> 5);
     const bool live = tile < T;
-    const int ty = live ? tile / tw : 0, tx = live ? tile % tw : 0;
+    // x: [N][H][W][cin]; tiles are numbered map-major (tpi = tiles per map, T = N * tpi) as wino_input_kernel does (csrc/winograd.hip)
+    const int img = live ? tile / tpi : 0, tin = live ? tile - img * tpi : 0;
+    const int ty = tin / tw, tx = tin - ty * tw;
     const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+    x += (size_t)img * H * W * cin;
     float d[4][4][8];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -177,10 +181,10 @@ void wino_pack_x6t_kernel(const float* __restrict__ g, const float* __restrict__
 // ---- host side ------------------------------------------------------------------------------------------------------------
 bool conv3x3_uses_winograd_x6(int cin, int cout) { return cin >= 256 && cin % 16 == 0 && cout >= 256 && cout % 256 == 0; }
 
-static inline bool wx_shape_ok(int H, int W, int cin, int cout)
+static inline bool wx_shape_ok(int N, int H, int W, int cin, int cout)
 {
-    return H >= 1 && W >= 1 && cin >= 16 && cin % 16 == 0 && cout >= 4 && cout % 4 == 0 &&
-           (size_t)cdiv(H, 2) * cdiv(W, 2) * 16 * (size_t)(cin > cout ? cin : cout) < ((size_t)1 << 31);
+    return N >= 1 && H >= 1 && W >= 1 && cin >= 16 && cin % 16 == 0 && cout >= 4 && cout % 4 == 0 &&
+           (size_t)N * cdiv(H, 2) * cdiv(W, 2) * 16 * (size_t)(cin > cout ? cin : cout) < ((size_t)1 << 31);
 }
 
 static inline int wx_tiles_padded(int T) { return cdiv(T, gemm_x6t_row_tile(T)) * gemm_x6t_row_tile(T); }
@@ -194,10 +198,10 @@ size_t conv3x3_winograd_x6_pack_bytes(int cout, int cin)
 
 struct WxPlan { size_t v_bytes, m_bytes, g_bytes; int T, Tp; };
 
-static WxPlan wx_plan(int H, int W, int cin, int cout)
+static WxPlan wx_plan(int N, int H, int W, int cin, int cout)
 {
     WxPlan p;
-    p.T = cdiv(H, 2) * cdiv(W, 2);
+    p.T = N * cdiv(H, 2) * cdiv(W, 2);
     p.Tp = wx_tiles_padded(p.T);
     p.v_bytes = 16 * x6t_record_bytes(p.Tp, cin);
     p.m_bytes = (size_t)16 * p.T * cout * sizeof(float);
@@ -205,10 +209,10 @@ static WxPlan wx_plan(int H, int W, int cin, int cout)
     return p;
 }
 
-size_t conv3x3_winograd_x6_workspace_bytes(int H, int W, int cin, int cout)
+size_t conv3x3_winograd_x6_workspace_bytes(int N, int H, int W, int cin, int cout)
 {
-    if (!wx_shape_ok(H, W, cin, cout)) return 0;
-    const WxPlan p = wx_plan(H, W, cin, cout);
+    if (!wx_shape_ok(N, H, W, cin, cout)) return 0;
+    const WxPlan p = wx_plan(N, H, W, cin, cout);
     return p.v_bytes + p.m_bytes + p.g_bytes;
 }
 
@@ -223,30 +227,30 @@ int launch_pack_conv3x3_winograd_x6(const float* w, const float* scale, void* ur
 }
 
 // The three launches of one layer, separately callable so that the fused forward can time them per class.
-int launch_winograd_x6_input(const float* x, void* vrec, int H, int W, int cin, hipStream_t s)
+int launch_winograd_x6_input(const float* x, void* vrec, int N, int H, int W, int cin, hipStream_t s)
 {
-    const int tw = cdiv(W, 2), T = cdiv(H, 2) * tw, rbt = wx_tiles_padded(T) / 32, K16 = cin / 16;
+    const int tw = cdiv(W, 2), tpi = cdiv(H, 2) * tw, T = N * tpi, rbt = wx_tiles_padded(T) / 32, K16 = cin / 16;
     const long long waves = (long long)rbt * K16;
     if (waves > 0x7fffffffLL) return FRCNN_EINVAL;
     hipLaunchKernelGGL(wino_input_x6t_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, static_cast<unsigned char*>(vrec),
-                       H, W, cin, tw, T, rbt, K16);
+                       H, W, cin, tw, tpi, T, rbt, K16);
     return check_launch();
 }
 
-int launch_winograd_x6_gemm(const void* vrec, const void* urec, float* M, int H, int W, int cin, int cout, void* gws, size_t gws_bytes,
+int launch_winograd_x6_gemm(const void* vrec, const void* urec, float* M, int N, int H, int W, int cin, int cout, void* gws, size_t gws_bytes,
                             hipStream_t s)
 {
-    const int T = cdiv(H, 2) * cdiv(W, 2), Tp = wx_tiles_padded(T), Np = wx_cout_padded(cout);
+    const int T = N * cdiv(H, 2) * cdiv(W, 2), Tp = wx_tiles_padded(T), Np = wx_cout_padded(cout);
     return launch_gemm_x6t(vrec, Tp, x6t_record_bytes(Tp, cin), urec, Np, x6t_record_bytes(Np, cin), nullptr, nullptr, M, cout,
                            (size_t)T * cout, T, cout, cin, 16, 0u, gws, gws_bytes, s);
 }
 
-int winograd_x6_plan(int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, void** V, float** M, void** G,
+int winograd_x6_plan(int N, int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, void** V, float** M, void** G,
                      size_t* g_bytes)
 {
-    if (!wx_shape_ok(H, W, cin, cout)) return FRCNN_EUNSUPPORTED;
+    if (!wx_shape_ok(N, H, W, cin, cout)) return FRCNN_EUNSUPPORTED;
     if ((flags & FRCNN_POOL2) && (H < 2 || W < 2)) return FRCNN_EINVAL;
-    const WxPlan p = wx_plan(H, W, cin, cout);
+    const WxPlan p = wx_plan(N, H, W, cin, cout);
     if (ws == nullptr || ws_bytes < p.v_bytes + p.m_bytes + p.g_bytes) return FRCNN_EINVAL;
     unsigned char* base = static_cast<unsigned char*>(ws);
     *V = base;
@@ -256,17 +260,17 @@ int winograd_x6_plan(int H, int W, int cin, int cout, unsigned flags, void* ws, 
     return FRCNN_OK;
 }
 
-int launch_conv3x3_winograd_x6(const float* x, const void* urec, const float* b, float* y, int H, int W, int cin, int cout,
+int launch_conv3x3_winograd_x6(const float* x, const void* urec, const float* b, float* y, int N, int H, int W, int cin, int cout,
                                unsigned flags, void* ws, size_t ws_bytes, hipStream_t s)
 {
     void *V = nullptr, *G = nullptr;
     float* M = nullptr;
     size_t gb = 0;
-    int rc = winograd_x6_plan(H, W, cin, cout, flags, ws, ws_bytes, &V, &M, &G, &gb);
+    int rc = winograd_x6_plan(N, H, W, cin, cout, flags, ws, ws_bytes, &V, &M, &G, &gb);
     if (rc) return rc;
-    if ((rc = launch_winograd_x6_input(x, V, H, W, cin, s)) != FRCNN_OK) return rc;
-    if ((rc = launch_winograd_x6_gemm(V, urec, M, H, W, cin, cout, G, gb, s)) != FRCNN_OK) return rc;
-    return launch_winograd_output(M, b, y, 1, H, W, cout, flags, s);
+    if ((rc = launch_winograd_x6_input(x, V, N, H, W, cin, s)) != FRCNN_OK) return rc;
+    if ((rc = launch_winograd_x6_gemm(V, urec, M, N, H, W, cin, cout, G, gb, s)) != FRCNN_OK) return rc;
+    return launch_winograd_output(M, b, y, N, H, W, cout, flags, s);
 }
 
 }  // namespace frcnn

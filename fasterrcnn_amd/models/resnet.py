@@ -157,6 +157,29 @@ def pack_block(block, math_mode="f32", single_map=False, x6=False):
         out["wd"], out["bd"], kd = fold_conv_bn(block.downsample[0], block.downsample[1])
         out["keep"].append(kd)
     out["x6_mask"] = 0
+    if x6 and math_mode == "f32_winograd" and not single_map and width % 16 == 0 and width >= 256:
+        # the per-RoI 3x3 of layer4 on the bf16 pipe: stride 1 = an x6 Winograd layer over the block's maps (frozen-BN scale folded
+        # into the filter transform, bias = the BN shift), stride 2 = an im2col GEMM against the [cout][9 cin] matrix (tap-major)
+        lib = nv.lib()
+        if block.stride == 1:
+            wsrc = rt.as_f32_cuda(block.conv2.weight.detach(), "conv weight")
+            args = [rt.as_f32_cuda(x.detach(), "bn tensor") for x in _bn_params(block.bn2)]
+            scale = t.empty((width,), dtype=t.float32, device=wsrc.device)
+            shift = t.empty((width,), dtype=t.float32, device=wsrc.device)
+            rec = t.empty((int(lib.frcnn_conv3x3_winograd_x6_pack_bytes(width, width)),), dtype=t.uint8, device=wsrc.device)
+            with t.cuda.device(wsrc.device):
+                nv.check(lib.frcnn_bn_scale_shift(nv.ptr(args[0]), nv.ptr(args[1]), nv.ptr(args[2]), nv.ptr(args[3]), float(block.bn2.eps), width,
+                                                  nv.ptr(scale), nv.ptr(shift), nv.stream_ptr()), "frcnn_bn_scale_shift")
+                nv.check(lib.frcnn_pack_conv3x3_winograd_x6(nv.ptr(wsrc), nv.ptr(scale), nv.ptr(rec), width, width, nv.stream_ptr()),
+                         "frcnn_pack_conv3x3_winograd_x6")
+            out["w2"], out["b2"] = rec, shift
+            out["keep"].append(args + [scale])
+        else:
+            wf, bf, kf = fold_conv_bn(block.conv2, block.bn2)                    # [9][cout][cin] folded float32
+            out["w2"] = records_x6t(wf.permute(1, 0, 2).reshape(width, 9 * width).contiguous(), width, 9 * width)
+            out["b2"] = bf
+            out["keep"].append(kf)
+        out["x6_mask"] |= 8
     if x6 and math_mode == "f32_winograd":
         for bit, key, ci, co in ((1, "w1", out["cin"], out["width"]), (2, "w3", out["width"], out["cout"]), (4, "wd", out["cin"], out["cout"])):
             if out[key] is not None and x6_conv1x1_ok(ci, co):
@@ -211,7 +234,32 @@ def run_block(x, n, h, w, pb):
         t1, _, _ = conv1x1_x6(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, True)
     else:
         t1, _, _ = conv_nhwc(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, 1, 0, True)
-    if pb["w2"].dim() == 1:                                             # one-launch Winograd bank (f32_winograd mode, one map)
+    if xm & 8:                                                          # layer4's 3x3 on the bf16 pipe (x6 Winograd / im2col GEMM)
+        width = pb["width"]
+        lib = nv.lib()
+        if pb["stride"] == 1:
+            ho, wo = h, w
+            t2 = t.empty((n, h, w, width), dtype=t.float32, device=x.device)
+            wsb = int(lib.frcnn_conv3x3_winograd_x6_workspace_bytes(n, h, w, width, width))
+            ws = t.empty((wsb,), dtype=t.uint8, device=x.device)
+            with t.cuda.device(x.device):
+                nv.check(lib.frcnn_conv3x3_nhwc_winograd_x6(nv.ptr(t1), nv.ptr(pb["w2"]), nv.ptr(pb["b2"]), nv.ptr(t2), n, h, w, width, width,
+                                                            nv.RELU, nv.ptr(ws), wsb, nv.stream_ptr()), "frcnn_conv3x3_nhwc_winograd_x6")
+        else:
+            st = pb["stride"]
+            ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
+            m = n * ho * wo
+            mp = (m + nv.X6T_ROW_TILE - 1) // nv.X6T_ROW_TILE * nv.X6T_ROW_TILE
+            np_ = (width + nv.X6T_COL_TILE - 1) // nv.X6T_COL_TILE * nv.X6T_COL_TILE
+            rec = t.empty((int(lib.frcnn_x6t_record_bytes(mp, 9 * width)),), dtype=t.uint8, device=x.device)
+            t2 = t.empty((n, ho, wo, width), dtype=t.float32, device=x.device)
+            wsb = int(lib.frcnn_gemm_x6t_workspace_bytes(m, width, 9 * width, 1))
+            ws = t.empty((max(wsb, 4),), dtype=t.uint8, device=x.device)
+            with t.cuda.device(x.device):
+                nv.check(lib.frcnn_split_patches3x3_x6t(nv.ptr(t1), nv.ptr(rec), n, h, w, width, st, mp, nv.stream_ptr()), "frcnn_split_patches3x3_x6t")
+                nv.check(lib.frcnn_gemm_x6t(nv.ptr(rec), mp, 0, nv.ptr(pb["w2"]), np_, 0, nv.ptr(pb["b2"]), None, nv.ptr(t2), width, 0, m, width,
+                                            9 * width, 1, nv.RELU, nv.ptr(ws), wsb, nv.stream_ptr()), "frcnn_gemm_x6t")
+    elif pb["w2"].dim() == 1:                                           # one-launch Winograd bank (f32_winograd mode, one map)
         assert n == 1
         width = pb["width"]
         ho, wo = h, w

@@ -80,10 +80,10 @@ def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False):
     lib = nv.lib()
     if wp.dtype == t.uint8:                              # x6 Winograd layer: record bank + scratch (V records, M, split-K partials)
         flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
-        ws_bytes = int(lib.frcnn_conv3x3_winograd_x6_workspace_bytes(h, w, cin, cout))
+        ws_bytes = int(lib.frcnn_conv3x3_winograd_x6_workspace_bytes(1, h, w, cin, cout))
         ws = t.empty((ws_bytes,), dtype=t.uint8, device=x_hwc.device)
         with t.cuda.device(x_hwc.device):
-            nv.check(lib.frcnn_conv3x3_nhwc_winograd_x6(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
+            nv.check(lib.frcnn_conv3x3_nhwc_winograd_x6(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
                                                         nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc_winograd_x6")
         return y
     if wp.dtype == t.float32 and wp.dim() == 1:          # one-launch Winograd bank

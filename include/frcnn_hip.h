@@ -218,7 +218,7 @@ int frcnn_linear_x6(const void* d_a_rec, const void* d_w_rec, const float* d_bia
  * transform + bias + ReLU + optional fused 2x2 max-pool), NHWC float32 in and out, cin % 16 == 0, cout % 4 == 0:
  *   frcnn_pack_conv3x3_winograd_x6          : OIHW float32 (optional per-cout scale, as frcnn_pack_conv3x3_winograd) -> the
  *       transformed filter bank as x6t records, frcnn_conv3x3_winograd_x6_pack_bytes(cout, cin) bytes
- *   frcnn_conv3x3_nhwc_winograd_x6          : the layer; d_ws >= frcnn_conv3x3_winograd_x6_workspace_bytes(H, W, cin, cout)
+ *   frcnn_conv3x3_nhwc_winograd_x6          : the layer over n_maps maps [n_maps][H][W][cin]; d_ws >= frcnn_conv3x3_winograd_x6_workspace_bytes(n_maps, H, W, cin, cout)
  *   frcnn_conv3x3_uses_winograd_x6(cin,cout): the layers the fused VGG-16 forward runs this way in math mode
  *       FRCNN_MATH_F32_WINOGRAD when frcnn_forward_params.winograd_x6 != 0 (cin >= 256, cout % 256 == 0).
  * ---------------------------------------------------------------------------------------- */
@@ -237,9 +237,13 @@ int frcnn_split_pixels_x6t(const float* d_x, void* d_rec, int N, int H, int W, i
 int frcnn_conv3x3_uses_winograd_x6(int cin, int cout);
 size_t frcnn_conv3x3_winograd_x6_pack_bytes(int cout, int cin);
 int frcnn_pack_conv3x3_winograd_x6(const float* d_w_oihw, const float* d_row_scale, void* d_u_rec, int cout, int cin, void* stream);
-size_t frcnn_conv3x3_winograd_x6_workspace_bytes(int H, int W, int cin, int cout);
-int frcnn_conv3x3_nhwc_winograd_x6(const float* d_x, const void* d_u_rec, const float* d_bias, float* d_y, int H, int W, int cin,
+size_t frcnn_conv3x3_winograd_x6_workspace_bytes(int n_maps, int H, int W, int cin, int cout);
+int frcnn_conv3x3_nhwc_winograd_x6(const float* d_x, const void* d_u_rec, const float* d_bias, float* d_y, int n_maps, int H, int W, int cin,
                                    int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
+/* NHWC float32 [N][H][W][C] -> the x6t records of the im2col matrix [N Ho Wo][9 C] of a 3x3 convolution with padding 1 and `stride`
+ * (Ho = (H - 1) / stride + 1; column index = tap * C + c, tap = 3 r + s; zeros outside the map): the A operand of a strided 3x3
+ * convolution as a GEMM against the records of the [cout][9 cin] filter matrix (ResNet layer4.0.conv2).  C % 16 == 0. */
+int frcnn_split_patches3x3_x6t(const float* d_x, void* d_rec, int N, int H, int W, int C, int stride, int rows_padded, void* stream);
 /* Stand-alone 2x2/stride-2 floor max-pool on NHWC (vgg16.py:78,82,87,92), c % 4 == 0. */
 int frcnn_maxpool2x2_nhwc(const float* d_x, float* d_y, int H, int W, int c, void* stream);
 
@@ -473,6 +477,8 @@ typedef struct frcnn_bottleneck_weights {
 #define FRCNN_X6_CONV1 1
 #define FRCNN_X6_CONV3 2
 #define FRCNN_X6_DOWN  4
+#define FRCNN_X6_CONV2 8     /* w2 = x6t records: stride 1 -> frcnn_pack_conv3x3_winograd_x6's bank (an x6 Winograd layer over the block's maps),
+                                stride 2 -> the records of the folded [cout][9 cin] matrix (tap-major columns; an im2col GEMM) */
 
 typedef struct frcnn_resnet_weights {
     const float* stem_w;       /* [147][64] */

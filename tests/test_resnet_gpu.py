@@ -243,12 +243,13 @@ def test_resnet101_600x1000_end_to_end(golden_dir):
 
 
 # Observed on the MI355X (default modes; the kernels are deterministic, so these are exact expectations): 286 of the reference's 300
-# proposals and 149 of its 157 detections.  The rest are near-ties, not errors: this fixture's top-6000 RPN scores have a MEDIAN
+# proposals and 147 of its 157 detections (149 before layer4's 3x3 convolutions moved to the f32x6 arithmetic: the 14 proposals that
+# differ make a few of the final per-class NMS decisions borderline too).  The rest are near-ties, not errors: this fixture's top-6000 RPN scores have a MEDIAN
 # gap of 2.4e-5 (13 exact ties; make_golden prints it) while two float32 implementations of a 101-layer network differ by ~3e-6 in
 # objectness (measured above: 3.1e-6), so roughly one adjacent pair in ten changes order and a handful of those sit at the NMS cut.
 # Feature map (1.2e-6 of max), objectness and class probabilities are gated at float32 accuracy above.
 R101_600_PROPOSALS = 286
-R101_600_DETECTIONS = 149
+R101_600_DETECTIONS = 147
 
 
 def test_resnet152_end_to_end(golden_dir):
@@ -370,11 +371,12 @@ def test_bottleneck_x6_1x1_against_the_float32_block(n, h, w, cin, width, cout, 
     x = torch.randn((n, h, w, cin), device="cuda")
     pb32 = R.pack_block(blk, "f32_winograd", single_map=(n == 1), x6=False)
     pb6 = R.pack_block(blk, "f32_winograd", single_map=(n == 1), x6=True)
-    assert pb6["x6_mask"] == (7 if blk.downsample is not None else 3) and pb32["x6_mask"] == 0
+    want = (7 if blk.downsample is not None else 3) | (8 if (n > 1 and width >= 256) else 0)     # the 3x3 too on multi-map (layer4) blocks
+    assert pb6["x6_mask"] == want and pb32["x6_mask"] == 0
     y32, ho, wo = R.run_block(x, n, h, w, pb32)
     y6, ho6, wo6 = R.run_block(x, n, h, w, pb6)
     torch.cuda.synchronize()
     assert (ho, wo) == (ho6, wo6) and y32.shape == y6.shape
     rel = float((y6 - y32).abs().max()) / float(y32.abs().max())
     print("bottleneck %dx%dx%d %d->%d->%d s%d: x6 vs f32 %.3g of max" % (n, h, w, cin, width, cout, stride, rel))
-    assert rel <= 3e-6
+    assert rel <= 4e-6

@@ -140,10 +140,10 @@ def run_x6(x, u, b, cout, relu, pool):
     h, wd, cin = (int(v) for v in x.shape)
     oh, ow = (h // 2, wd // 2) if pool else (h, wd)
     y = torch.full((oh, ow, cout), float("nan"), device=x.device)
-    wsb = int(lib.frcnn_conv3x3_winograd_x6_workspace_bytes(h, wd, cin, cout))
+    wsb = int(lib.frcnn_conv3x3_winograd_x6_workspace_bytes(1, h, wd, cin, cout))
     ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
     flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
-    nv.check(lib.frcnn_conv3x3_nhwc_winograd_x6(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), h, wd, cin, cout, flags, nv.ptr(ws), wsb,
+    nv.check(lib.frcnn_conv3x3_nhwc_winograd_x6(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, h, wd, cin, cout, flags, nv.ptr(ws), wsb,
                                                 nv.stream_ptr()), "conv_winograd_x6")
     torch.cuda.synchronize()
     return y

@@ -73,9 +73,9 @@ def main():
         # x6 layer
         u = torch.empty((int(lib.frcnn_conv3x3_winograd_x6_pack_bytes(cout, cin)),), dtype=torch.uint8, device=dev)
         nv.check(lib.frcnn_pack_conv3x3_winograd_x6(nv.ptr(w_oihw), None, nv.ptr(u), cout, cin, s), "pack_x6")
-        wsb = int(lib.frcnn_conv3x3_winograd_x6_workspace_bytes(h, w, cin, cout))
+        wsb = int(lib.frcnn_conv3x3_winograd_x6_workspace_bytes(1, h, w, cin, cout))
         ws = torch.zeros((wsb,), dtype=torch.uint8, device=dev)
-        us6 = timeit(lambda: nv.check(lib.frcnn_conv3x3_nhwc_winograd_x6(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
+        us6 = timeit(lambda: nv.check(lib.frcnn_conv3x3_nhwc_winograd_x6(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
                                                                          nv.ptr(ws), wsb, s), "x6"), args.reps)
         # its GEMM alone: V records = the head of the workspace the layer just filled
         Tp = (T + nv.X6T_ROW_TILE - 1) // nv.X6T_ROW_TILE * nv.X6T_ROW_TILE
