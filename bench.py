@@ -328,7 +328,13 @@ def resnet_conv_table(model, h=H, w=W, n_rois=300):
                 rows.append((stage, tag + name, "conv_gather_mfma_kernel", "f32", alg, alg))
         one(".conv1", cin, width, n * hh * ww, R.x6_conv1x1_ok(cin, width))
         alg = 2.0 * 9 * width * width * n * ho * wo
-        if wino and st == 1 and single and width % 64 == 0:
+        if x6 and wino and not single and width >= 256:
+            if st == 1:
+                rows.append((stage, tag + ".conv2", "gemm_x6t_kernel (x6 Winograd layer)", "bf16",
+                             6.0 * 2 * 16 * n * ((hh + 1) // 2) * ((ww + 1) // 2) * width * width, alg))
+            else:
+                rows.append((stage, tag + ".conv2", "gemm_x6t_kernel (im2col)", "bf16", 6.0 * alg, alg))
+        elif wino and st == 1 and single and width % 64 == 0:
             rows.append((stage, tag + ".conv2", "wino_fused_kernel", "f32", 2.0 * 16 * ((hh + 1) // 2) * ((ww + 1) // 2) * width * width, alg))
         elif wino and st == 1 and width >= 256 and width % 128 == 0:
             rows.append((stage, tag + ".conv2", "linear_mfma_kernel (three-launch Winograd)", "f32",

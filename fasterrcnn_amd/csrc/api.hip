@@ -36,8 +36,8 @@ struct frcnn_ctx {
     float *anchor_map = nullptr, *valid_map = nullptr;
     float *roi_out = nullptr;                      // [max_rois][7][7][512]
     float *fc1_out = nullptr, *fc2_out = nullptr;  // [max_rois][4096]
-    void *roi_rec = nullptr, *fc1_rec = nullptr;   // x6 / x6t records of roi_out ([rec_rows][25088]) and fc1_out (FRCNN_FC_F32X6 / _F32X6T)
-    int rec_rows = 0;
+    void *roi_rec = nullptr, *fc1_rec = nullptr;   // x6 / x6t records of roi_out ([rec_rows][25088]) and fc1_out (FRCNN_FC_F32X6 / _F32X6T):
+    int rec_rows = 0;                              // one allocation, made by the first forward that runs fc1 / fc2 in an x6 mode
     float *head_logits = nullptr;                  // [max_rois][128]
     void* lin_ws = nullptr; size_t lin_ws_bytes = 0;
     void* conv_ws = nullptr; size_t conv_ws_bytes = 0;   // split-K partials of under-filled conv layers
@@ -694,7 +694,6 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         {(void**)&c->anchor_map, (size_t)c->a_cap * 16}, {(void**)&c->valid_map, (size_t)c->a_cap * 4},
         {(void**)&c->roi_out, (size_t)max_rois * 49 * 1024 * 4},
         {(void**)&c->fc1_out, (size_t)max_rois * 4096 * 4}, {(void**)&c->fc2_out, (size_t)max_rois * 4096 * 4},
-        {(void**)&c->roi_rec, (size_t)rec_rows * 49 * 512 * 6}, {(void**)&c->fc1_rec, (size_t)rec_rows * 4096 * 6},
         {(void**)&c->head_logits, (size_t)max_rois * FRCNN_HEAD_LD_MAX * 4},
         {(void**)&c->lin_ws, lin}, {(void**)&c->conv_ws, cws},
         {(void**)&c->res_buf[0], c->res_buf_floats * 4}, {(void**)&c->res_buf[1], c->res_buf_floats * 4},
@@ -712,9 +711,6 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
     c->lin_ws_bytes = lin;
     c->conv_ws_bytes = cws;
     proposal_scratch_carve(c->ps, ps_base, c->a_cap, c->pre_cap, 2048);
-    // the padding rows of the activation record arrays (rows max_rois .. 319) are written by nobody afterwards
-    e = hipMemset(c->roi_rec, 0, (size_t)rec_rows * 49 * 512 * 6);
-    if (e != hipSuccess) { set_hip_error(e); hipFree(c->slab); delete c; return FRCNN_EHIP; }
     *out = c;
     return FRCNN_OK;
 }
@@ -748,12 +744,13 @@ void frcnn_ctx_destroy(frcnn_ctx* ctx)
     if (ctx->slab) (void)hipFree(ctx->slab);
     if (ctx->wino_ws) (void)hipFree(ctx->wino_ws);
     if (ctx->wx_ws) (void)hipFree(ctx->wx_ws);
+    if (ctx->roi_rec) (void)hipFree(ctx->roi_rec);
     if (ctx->rx_rec) (void)hipFree(ctx->rx_rec);
     if (ctx->rx_ws) (void)hipFree(ctx->rx_ws);
     delete ctx;
 }
 
-size_t frcnn_ctx_bytes(const frcnn_ctx* ctx) { return ctx ? ctx->slab_bytes + ctx->wino_ws_bytes + ctx->wx_ws_bytes + ctx->rx_rec_bytes + ctx->rx_ws_bytes : 0; }
+size_t frcnn_ctx_bytes(const frcnn_ctx* ctx) { return ctx ? ctx->slab_bytes + ctx->wino_ws_bytes + ctx->wx_ws_bytes + ctx->rx_rec_bytes + ctx->rx_ws_bytes + (ctx->roi_rec ? (size_t)ctx->rec_rows * (49 * 512 + 4096) * 6 : 0) : 0; }
 
 int frcnn_ctx_timing_enable(frcnn_ctx* ctx, int enable)
 {
@@ -864,6 +861,22 @@ int ensure_wx_ws(frcnn_ctx* c, size_t layer_need, hipStream_t s)
     e = hipMemset(c->wx_ws, 0, need);
     if (e != hipSuccess) { set_hip_error(e); (void)hipFree(c->wx_ws); c->wx_ws = nullptr; return FRCNN_EHIP; }
     c->wx_ws_bytes = need;
+    return FRCNN_OK;
+}
+
+// The activation record arrays of fc1 / fc2 (x6 modes of the VGG-16 detector): 53 MB at 320 rows, allocated and zeroed by the first
+// forward that needs them (ResNet models and fc_math_mode f32 never do).  The padding rows max_rois .. rec_rows - 1 stay zero.
+int ensure_fc_records(frcnn_ctx* c)
+{
+    if (c->roi_rec) return FRCNN_OK;
+    const size_t b1 = (size_t)c->rec_rows * 49 * 512 * 6, b2 = (size_t)c->rec_rows * 4096 * 6;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, b1 + b2);
+    if (e != hipSuccess) { set_hip_error(e); return FRCNN_ENOMEM; }
+    e = hipMemset(p, 0, b1 + b2);
+    if (e != hipSuccess) { set_hip_error(e); (void)hipFree(p); return FRCNN_EHIP; }
+    c->roi_rec = p;
+    c->fc1_rec = static_cast<unsigned char*>(p) + b1;
     return FRCNN_OK;
 }
 
@@ -990,6 +1003,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     const bool fc_x6 = p->fc_math_mode == FRCNN_FC_F32X6;
     const bool fc_x6t = p->fc_math_mode == FRCNN_FC_F32X6T;
     if (fc_x6 && R_ > FRCNN_LINEAR_X6_ROWS) return FRCNN_EUNSUPPORTED;
+    if (fc_x6 || fc_x6t) { rc = ensure_fc_records(c); if (rc) return rc; }
     if (fc_x6t) {
         // fc1 / fc2 as f32x6 GEMMs on tile records (csrc/gemm_x6t.hip): RoIPool writes fc1's operand records itself (the rows R_ ..
         // rec_rows - 1 were zeroed when the ctx was created); fc1's float32 output is split again for fc2 (5 MB: a 3 us launch)

@@ -3,7 +3,7 @@
 # 1. the default bench line; 2. rocprofv3 kernel trace + stats of a bench run; 3. PMC passes
 # (counters in their own runs, kernel-trace only, as the pool requires).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -19,6 +19,16 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_IN
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $P > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?"
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $P > $OUT/pmc_write.log 2>&1; echo "pmc write exit $?"
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL --output-format csv -d $OUT/pmc_lds -o p -- $P > $OUT/pmc_lds.log 2>&1; echo "pmc lds exit $?"
+# ResNet-50 (BASELINE configs[2]): kernel stats one image at a time and 8 in flight; PMC (MFMA busy, FETCH / WRITE) of its kernels
+R="python bench.py --backbone resnet50 --no-cpu-baseline --no-secondary --no-extra-legs --map-images 0 --roofline-images 1"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_r50_single -o t -- $R --steps 30 --warmup 5 --inflight 1 > $OUT/trace_r50_single.log 2>&1; echo "r50 single trace exit $?"
+rm -f $OUT/trace_r50_single/t_kernel_trace.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_r50 -o t -- $R --steps 60 --warmup 10 --inflight 8 > $OUT/trace_r50.log 2>&1; echo "r50 in-flight trace exit $?"
+rm -f $OUT/trace_r50/t_kernel_trace.csv
+RP="$R --steps 8 --warmup 2 --ramp-seconds 0 --inflight 1 --min-timed-seconds 0"
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_r50_mfma -o p -- $RP > $OUT/pmc_r50_mfma.log 2>&1; echo "pmc r50 mfma exit $?"
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_r50_fetch -o p -- $RP > $OUT/pmc_r50_fetch.log 2>&1; echo "pmc r50 fetch exit $?"
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_r50_write -o p -- $RP > $OUT/pmc_r50_write.log 2>&1; echo "pmc r50 write exit $?"
 # train step: wall time per step + per-kernel stats
 timeout 600 python tools/train_bench.py --steps 20 --warmup 3 > $OUT/train_bench.json 2> $OUT/train_bench.err; echo "train bench exit $?"; cat $OUT/train_bench.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -o t -- python tools/train_bench.py --steps 8 --warmup 2 > $OUT/trace_train.log 2>&1; echo "train trace exit $?"

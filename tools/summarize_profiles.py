@@ -43,12 +43,24 @@ def main(d):
         for r in sstats[:20]:
             print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                      float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
-        for fam in ("wino_fused_kernel", "linear_x6_kernel", "linear_mfma_kernel", "conv3x3_mfma_kernel"):
+        for fam in ("wino_fused_kernel", "gemm_x6t_kernel", "wino_input_x6t_kernel", "wino_output_kernel", "linear_x6_kernel", "linear_mfma_kernel",
+                    "conv3x3_mfma_kernel"):
             f_ns = sum(float(r["TotalDurationNs"]) for r in sstats if fam in r["Name"])
             f_calls = sum(int(r["Calls"]) for r in sstats if fam in r["Name"])
             if f_calls:
                 print("\n%s, all instantiations: %d launches, mean %.1f us" % (fam, f_calls, f_ns / f_calls / 1e3))
         print()
+    for sub, title in (("trace_r50_single", "ResNet-50 (BASELINE configs[2]), one image at a time: kernel stats (bench.py --backbone resnet50 "
+                                             "--inflight 1; default modes: x6_conv1x1 = head)"),
+                       ("trace_r50", "ResNet-50, 8 batch-1 images in flight: kernel stats (bench.py --backbone resnet50 --inflight 8)")):
+        rs = load(os.path.join(d, sub, "*kernel_stats.csv"))
+        if rs:
+            print("## %s\n" % title)
+            print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+            for r in rs[:22]:
+                print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                         float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+            print()
     tb = os.path.join(d, "train_bench.json")
     if os.path.exists(tb):
         lines = [l for l in open(tb).read().splitlines() if l.startswith("{")]
@@ -67,7 +79,7 @@ def main(d):
     if kt:
         agg = collections.defaultdict(list)
         for r in kt:
-            if any(x in r["Kernel_Name"] for x in ("conv3x3_mfma", "linear_mfma", "wino_fused", "linear_x6")):
+            if any(x in r["Kernel_Name"] for x in ("conv3x3_mfma", "linear_mfma", "wino_fused", "linear_x6", "gemm_x6t")):
                 key = (short(r["Kernel_Name"]), r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
                 agg[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         print("## MFMA kernels by grid (threads x, blocks y, z), multi-stream run\n")
@@ -76,7 +88,8 @@ def main(d):
             print("| %s | %s x %s x %s | %d | %.1f |" % (k[0], k[1], k[2], k[3], len(v), sum(v) / len(v)))
         print()
     for tag, title in (("pmc_mfma", "MFMA / wave-state counters"), ("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"),
-                       ("pmc_lds", "LDS counters")):
+                       ("pmc_lds", "LDS counters"), ("pmc_r50_mfma", "ResNet-50: MFMA / wave-state counters"),
+                       ("pmc_r50_fetch", "ResNet-50: FETCH_SIZE"), ("pmc_r50_write", "ResNet-50: WRITE_SIZE")):
         rows = load(os.path.join(d, tag, "*counter_collection.csv"))
         if not rows:
             continue
@@ -84,7 +97,8 @@ def main(d):
         cnt = collections.defaultdict(set)
         for r in rows:
             k = short(r["Kernel_Name"])
-            if not any(x in k for x in ("conv3x3", "linear_", "wino_", "roi_", "topk", "nms_", "detections", "splitk", "conv_splitk", "split_rows")):
+            if not any(x in k for x in ("conv3x3", "linear_", "wino_", "roi_", "topk", "nms_", "detections", "splitk", "conv_splitk", "split_rows",
+                                        "gemm_x6t", "conv_gather", "split_pixels", "split_patches")):
                 continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k].add(r["Dispatch_Id"])
@@ -95,7 +109,7 @@ def main(d):
             n = max(len(cnt[k]), 1)
             print("| %s | %d | " % (k, n) + " | ".join("%.4g" % (v.get(c, 0.0) / n) for c in names) + " |")
         print()
-        if tag == "pmc_mfma":
+        if tag in ("pmc_mfma", "pmc_r50_mfma"):
             print("derived (per kernel, summed over its launches): MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCD * 1024 SIMD); "
                   "clock = GRBM_GUI_ACTIVE/8 / duration\n")
             print("| kernel | MFMA busy | waves/SIMD avg (SQ_WAVE_CYCLES*4 / (1024 * GUI/8)) | WAIT_INST_ANY | WAIT_ANY | ACTIVE |\n|---|---|---|---|---|---|")
@@ -119,6 +133,10 @@ def traffic(d):
     """
     import json
     families = (("wino_fused_kernel", lambda n: "wino_fused_kernel" in n),
+                ("gemm_x6t_kernel", lambda n: "gemm_x6t_kernel" in n),
+                ("wino_input_x6t_kernel", lambda n: "wino_input_x6t_kernel" in n),
+                ("wino_output_kernel", lambda n: "wino_output_kernel" in n),
+                ("conv_gather_mfma_kernel", lambda n: "conv_gather_mfma_kernel" in n),
                 ("linear_x6_kernel", lambda n: "linear_x6_kernel" in n),
                 ("conv3x3_mfma_kernel", lambda n: "conv3x3_mfma" in n),
                 ("conv3x3_c3_kernel", lambda n: "conv3x3_c3" in n),
@@ -126,6 +144,11 @@ def traffic(d):
     raw = {}
     for tag, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         raw[name] = [r for r in load(os.path.join(d, tag, "*counter_collection.csv")) if r["Counter_Name"] == name]
+        # the ResNet-50 passes contribute the kernels the VGG-16 run does not launch (conv_gather_mfma_kernel); Dispatch ids are made
+        # unique per pass
+        extra = [dict(r, Dispatch_Id="r50_" + r["Dispatch_Id"]) for r in load(os.path.join(d, tag.replace("pmc_", "pmc_r50_"), "*counter_collection.csv"))
+                 if r["Counter_Name"] == name and "conv_gather" in r["Kernel_Name"]]
+        raw[name] += extra
     if not raw["FETCH_SIZE"] or not raw["WRITE_SIZE"]:
         return
     by = {}
@@ -154,7 +177,7 @@ def traffic(d):
 def condense_pmc(d):
     """Per-dispatch counter dumps -> <dir>/pmc_counters_by_kernel.csv (pass, kernel, counter, dispatches, sum): what gets committed."""
     out = []
-    for tag in ("mfma", "fetch", "write", "lds"):
+    for tag in ("mfma", "fetch", "write", "lds", "r50_mfma", "r50_fetch", "r50_write"):
         rows = load(os.path.join(d, "pmc_" + tag, "*counter_collection.csv"))
         agg = collections.defaultdict(float)
         cnt = collections.defaultdict(set)
