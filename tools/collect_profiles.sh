@@ -36,3 +36,7 @@ rm -f $OUT/trace_train/t_kernel_trace.csv
 ls -la $OUT $OUT/trace | head -40
 # keep the merged output small: drop the raw per-dispatch traces beyond what the summary needs
 python tools/summarize_profiles.py $OUT > $OUT/summary.md 2> $OUT/summary.err; echo "summary exit $?"; head -60 $OUT/summary.md
+# gpurun merges at most 64 MiB back: the raw per-dispatch dumps are condensed above (summary.md, traffic.json, pmc_counters_by_kernel.csv,
+# *_kernel_stats.csv) and dropped here
+rm -f $OUT/pmc_*/*counter_collection.csv $OUT/pmc_*/*kernel_trace.csv $OUT/trace/*kernel_trace.csv $OUT/*/*.db $OUT/*/*/*.db
+du -sh $OUT
