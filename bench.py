@@ -664,6 +664,38 @@ def main():
         dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
         extra["resnet50_all_f32_pipe_images_per_sec"] = round(args.steps / dt, 3)
         m50.x6_conv1x1, m50.winograd_x6_layers = "head", ()
+        # configs[2] as a TRUE batch: 8 images through one pass of the feature extractor (frcnn_resnet_backbone: every bottleneck launch
+        # covers the 8 maps), RPN + head per image on 8 streams behind it; two batches in flight
+        try:
+            batch50 = torch.cat(pool50, dim=0)
+
+            def run50b(n_steps):
+                pend, lane = [], 0
+                for _ in range((n_steps + 7) // 8):
+                    if len(pend) == 2:
+                        for h_ in pend.pop(0):
+                            h_.result()
+                    pend.append(m50.predict_batch_async(batch50, 0.05, lane=lane))
+                    lane ^= 1
+                while pend:
+                    for h_ in pend.pop(0):
+                        h_.result()
+            steps_b = (args.steps + 7) // 8 * 8
+            run50b(32)
+            dt, _ = timed_median(run50b, steps_b, min(args.min_timed_seconds, 0.5))
+            extra["resnet50_batch8_images_per_sec"] = round(steps_b / dt, 3)
+            extra["resnet50_batch8_config"] = ("the same model and images as resnet50_images_per_sec as batches of 8 (model.predict_batch_async): one "
+                                               "feature-extractor pass per batch, two batches in flight; x6_conv1x1=head")
+            m50.x6_conv1x1, m50.winograd_x6_layers = "all", ("rpn_trunk",)
+            run50b(32)
+            dt, _ = timed_median(run50b, steps_b, min(args.min_timed_seconds, 0.5))
+            extra["resnet50_batch8_x6_all_images_per_sec"] = round(steps_b / dt, 3)
+            m50.x6_conv1x1, m50.winograd_x6_layers = "head", ()
+            m50._lanes.clear()
+            del batch50
+        except Exception as e:
+            extra["resnet50_batch8_images_per_sec"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            m50.x6_conv1x1, m50.winograd_x6_layers = "head", ()
         try:
             extra["resnet50_roofline"] = resnet_roofline_leg(m50, pool50[0], dev)
         except Exception as e:

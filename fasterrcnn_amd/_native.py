@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
-ABI_VERSION = 6     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
+ABI_VERSION = 7     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
@@ -43,6 +43,7 @@ SYMBOLS = (
     "frcnn_x6t_record_bytes", "frcnn_split_rows_x6t", "frcnn_gemm_x6t_workspace_bytes", "frcnn_gemm_x6t", "frcnn_split_pixels_x6t", "frcnn_split_patches3x3_x6t",
     "frcnn_conv3x3_uses_winograd_x6", "frcnn_conv3x3_winograd_x6_pack_bytes", "frcnn_pack_conv3x3_winograd_x6",
     "frcnn_conv3x3_winograd_x6_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x6",
+    "frcnn_conv3x3_nhwc_winograd_fused_maps", "frcnn_ctx_create_backbone", "frcnn_resnet_backbone", "frcnn_resnet_forward_features",
     # training path
     "frcnn_label_proposals", "frcnn_gather_rows", "frcnn_rpn_loss", "frcnn_detector_loss",
     "frcnn_gemm_tn_math", "frcnn_conv3x3_wgrad_math", "frcnn_conv_wgrad_math",
@@ -225,6 +226,11 @@ _SIGNATURES = {
     "frcnn_spatial_mean_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "frcnn_resnet_forward": (C.c_int, [_vp, C.POINTER(ResNetWeights), C.POINTER(ForwardParams), _vp, _i, _i,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "frcnn_resnet_forward_features": (C.c_int, [_vp, C.POINTER(ResNetWeights), C.POINTER(ForwardParams), _vp, _i, _i,
+                                                _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "frcnn_resnet_backbone": (C.c_int, [_vp, C.POINTER(ResNetWeights), C.POINTER(ForwardParams), _vp, _i, _i, _i, _vp, _vp]),
+    "frcnn_ctx_create_backbone": (C.c_int, [C.POINTER(C.c_void_p), _i, _i, _i]),
+    "frcnn_conv3x3_nhwc_winograd_fused_maps": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp]),
     "frcnn_label_proposals": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         _vp, _vp, _vp, _vp, _vp, _vp]),
     "frcnn_gather_rows": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp]),

@@ -22,7 +22,7 @@ struct EventRec { int cls; hipEvent_t start, stop; };
 using namespace frcnn;
 
 struct frcnn_ctx {
-    int max_h = 0, max_w = 0, max_rois = 0;
+    int max_h = 0, max_w = 0, max_rois = 0, max_images = 0;     // max_images > 0: a backbone-only ctx (frcnn_ctx_create_backbone)
     int max_fh = 0, max_fw = 0, a_cap = 0, pre_cap = 0;
     void* slab = nullptr;
     size_t slab_bytes = 0;
@@ -251,6 +251,13 @@ int frcnn_conv3x3_nhwc_winograd_fused(const float* d_x, const float* d_u, const 
 {
     if (!d_x || !d_u || !d_bias || !d_y || H < 1 || W < 1) return FRCNN_EINVAL;
     return launch_conv3x3_winograd_fused(d_x, d_u, d_bias, d_y, H, W, cin, cout, flags, as_stream(stream));
+}
+
+int frcnn_conv3x3_nhwc_winograd_fused_maps(const float* d_x, const float* d_u, const float* d_bias, float* d_y, int n_maps, int H, int W,
+                                           int cin, int cout, unsigned flags, void* stream)
+{
+    if (!d_x || !d_u || !d_bias || !d_y || H < 1 || W < 1 || n_maps < 1) return FRCNN_EINVAL;
+    return launch_conv3x3_winograd_fused(d_x, d_u, d_bias, d_y, H, W, cin, cout, flags, as_stream(stream), n_maps);
 }
 
 int frcnn_split_rows_x6(const float* d_a, int lda, void* d_rec, int rows, int rows_out, int K, void* stream)
@@ -905,10 +912,10 @@ int run_wino_x6_layer(frcnn_ctx* c, const float* x, const void* urec, const floa
 //  was built and measured for one image on the chip: conv5_x 87 -> 84-87 us, conv4_2 227 -> 222 us with 2 parts, slower with 4.
 //  The per-block prologue / epilogue and the partial traffic cost what the shorter serial chain wins, so it is not in the tree.)
 int run_wino_fused_layer(frcnn_ctx* c, bool /*latency*/, const float* x, const float* u, const float* b, float* y, int h, int w, int ci,
-                         int co, unsigned flags, hipStream_t s)
+                         int co, unsigned flags, hipStream_t s, int n_maps = 1)
 {
     Scope _w(c, 7, s);
-    return launch_conv3x3_winograd_fused(x, u, b, y, h, w, ci, co, flags, s);
+    return launch_conv3x3_winograd_fused(x, u, b, y, h, w, ci, co, flags, s, n_maps);
 }
 
 struct BlocksTargetScope {
@@ -1093,9 +1100,12 @@ int run_conv1x1_x6(frcnn_ctx* c, const float* x, const void* wrec, const float* 
 
 // One Bottleneck (torchvision v1.5): out = relu(conv3(relu(conv2(relu(conv1(x))))) + identity).
 // x: [N][h][w][cin] in `cur`; returns the buffer index holding the output, updates h, w.
+// `backbone`: the block belongs to the feature extractor (layer1..3): its 3x3 is packed for the one-launch Winograd kernel whatever the
+// number of images N in the launch (the per-RoI blocks of layer4 are packed for the three-launch form).
 int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& h, int& w, int cur,
-                   int* out_idx, hipStream_t s, int cls_conv, bool wino, bool latency)
+                   int* out_idx, hipStream_t s, int cls_conv, bool wino, bool latency, bool backbone)
 {
+    const int pack_maps = backbone ? 1 : N;
     // pick three scratch buffers different from `cur`
     int f[4], k = 0;
     for (int i = 0; i < 5 && k < 4; ++i) if (i != cur) f[k++] = i;
@@ -1122,14 +1132,18 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
         rc = b.stride == 1 ? run_wino_x6_layer(c, T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s, N)
                            : run_conv1x1_x6(c, T1, b.w2, b.b2, nullptr, T2, N, h, w, b.width, b.width, b.stride, R, 9, s, 3);
         if (rc) return rc;
-    } else if (wino && resnet_block_uses_winograd_fused(N, b.width, b.stride)) {
-        rc = run_wino_fused_layer(c, latency, T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s);
+    } else if (wino && resnet_block_uses_winograd_fused(pack_maps, b.width, b.stride)) {
+        rc = run_wino_fused_layer(c, latency, T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s, N);
         if (rc) return rc;
     } else if (wino && resnet_block_uses_winograd(b.width, b.stride)) {
         rc = run_winograd_layer(c, T1, b.w2, b.b2, T2, N, h, w, b.width, b.width, R, s);
         if (rc) return rc;
-    } else if (b.stride == 1 && N == 1 && b.width % 64 == 0) {
-        RSTEP(launch_conv3x3_nhwc(T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, c->conv_ws, c->conv_ws_bytes, s));
+    } else if (b.stride == 1 && pack_maps == 1 && b.width % 64 == 0) {
+        // direct exact-f32 3x3 (math mode "f32"): one launch per image of the batch
+        for (int i = 0; i < N; ++i) {
+            RSTEP(launch_conv3x3_nhwc(T1 + (size_t)i * h * w * b.width, b.w2, b.b2, T2 + (size_t)i * h * w * b.width, h, w, b.width, b.width, R,
+                                      c->conv_ws, c->conv_ws_bytes, s));
+        }
     } else {
         RSTEP(launch_conv_gather(T1, b.w2, b.b2, nullptr, T2, N, h, w, b.width, b.width, 3, b.stride, 1, R,
                                  c->conv_ws, c->conv_ws_bytes, s));
@@ -1161,59 +1175,73 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
 }
 }  // namespace
 
-int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p,
-                         const float* d_image, int H, int W, const float* d_anchor_map,
-                         const float* d_valid_map, float* d_props, float* d_classes, float* d_deltas,
-                         int32_t* d_counts, void* stream)
+namespace {
+int resnet_check_weights(const frcnn_resnet_weights* w, bool with_heads)
 {
-    if (!c || !w || !p || !d_image || !d_props || !d_classes || !d_deltas || !d_counts) return FRCNN_EINVAL;
-    if (H < 32 || W < 32 || H > c->max_h || W > c->max_w) return FRCNN_EINVAL;
-    if (p->post_nms < 1 || p->post_nms > c->max_rois || p->pre_nms < 1 || p->pre_nms > c->pre_cap) return FRCNN_EINVAL;
-    if (w->num_classes < 2 || w->num_classes > FRCNN_MAX_NUM_CLASSES) return FRCNN_EUNSUPPORTED;
-    if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32_WINOGRAD) return FRCNN_EUNSUPPORTED;   // no f32x6 ResNet path
-    const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
-    if ((p->roi_op != FRCNN_ROI_POOL && p->roi_op != FRCNN_ROI_ALIGN) || p->roi_sampling_ratio > 2) return FRCNN_EINVAL;
     int nb = 0;
     for (int i = 0; i < 4; ++i) { if (w->n_blocks[i] < 1) return FRCNN_EINVAL; nb += w->n_blocks[i]; }
     if (nb > FRCNN_RESNET_MAX_BLOCKS) return FRCNN_EINVAL;
-    if (!w->stem_w || !w->stem_b || !w->rpn_conv_w || !w->rpn_conv_b || !w->rpn_head_w || !w->rpn_head_b ||
-        !w->head_w || !w->head_b)
-        return FRCNN_EINVAL;
+    if (!w->stem_w || !w->stem_b) return FRCNN_EINVAL;
+    if (with_heads && (!w->rpn_conv_w || !w->rpn_conv_b || !w->rpn_head_w || !w->rpn_head_b || !w->head_w || !w->head_b)) return FRCNN_EINVAL;
     for (int i = 0; i < nb; ++i) {
         const frcnn_bottleneck_weights& b = w->blocks[i];
         if (!b.w1 || !b.b1 || !b.w2 || !b.b2 || !b.w3 || !b.b3 || (b.wd && !b.bd)) return FRCNN_EINVAL;
         if (b.cin % 16 || b.width % 16 || b.cout % 64 || (b.stride != 1 && b.stride != 2)) return FRCNN_EINVAL;
     }
-    hipStream_t s = as_stream(stream);
-    int rc;
+    return FRCNN_OK;
+}
+
+int resnet_check_params(const frcnn_forward_params* p)
+{
+    if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32_WINOGRAD) return FRCNN_EUNSUPPORTED;   // no f32x6 ResNet path
+    if ((p->roi_op != FRCNN_ROI_POOL && p->roi_op != FRCNN_ROI_ALIGN) || p->roi_sampling_ratio > 2) return FRCNN_EINVAL;
     if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
     if (p->winograd_tile_rows != 0 && p->winograd_tile_rows != 64 && p->winograd_tile_rows != 128) return FRCNN_EINVAL;
     if (p->x6_gemm_tiles < 0 || p->x6_gemm_tiles > 2) return FRCNN_EINVAL;
-    BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows, p->x6_gemm_tiles);
-    if (wino) { rc = ensure_wino_ws(c); if (rc) return rc; }
-#define STEP(cls, call) do { Scope _sc(c, cls, s); rc = (call); } while (0); if (rc) return rc
+    return FRCNN_OK;
+}
 
-    // stage 1: conv1/bn1/relu/maxpool/layer1..3 (models/resnet.py:38-46)
+// stage 1: conv1 / bn1 / relu / maxpool / layer1..3 (models/resnet.py:38-46) over n images [n][3][H][W] in ONE pass: every bottleneck
+// launch covers the n maps (the 1x1 convolutions are GEMMs over n * h * w pixels).  Leaves the [n][fh][fw][C] maps in res_buf[*cur].
+int resnet_stage1(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p, const float* d_images, int n, int H, int W,
+                  int* cur_out, int* fh_out, int* fw_out, int* c_out, hipStream_t s)
+{
+    const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
+    int rc;
     int h = (H + 6 - 7) / 2 + 1, wd = (W + 6 - 7) / 2 + 1;
-    if ((size_t)h * wd * 64 > c->res_buf_floats) return FRCNN_EINVAL;
-    STEP(1, launch_conv7x7_s2_c3(d_image, w->stem_w, w->stem_b, c->res_buf[0], H, W, 64, FRCNN_RELU, s));
-    STEP(5, launch_maxpool3x3_s2(c->res_buf[0], c->res_buf[1], h, wd, 64, s));
-    h = (h + 2 - 3) / 2 + 1; wd = (wd + 2 - 3) / 2 + 1;
+    if ((size_t)n * h * wd * 64 > c->res_buf_floats) return FRCNN_EINVAL;
+    const int hp = (h + 2 - 3) / 2 + 1, wp = (wd + 2 - 3) / 2 + 1;
+    for (int i = 0; i < n; ++i) {
+        { Scope _sc(c, 1, s); rc = launch_conv7x7_s2_c3(d_images + (size_t)i * 3 * H * W, w->stem_w, w->stem_b, c->res_buf[0] + (size_t)i * h * wd * 64,
+                                                       H, W, 64, FRCNN_RELU, s); }
+        if (rc) return rc;
+        { Scope _sc(c, 5, s); rc = launch_maxpool3x3_s2(c->res_buf[0] + (size_t)i * h * wd * 64, c->res_buf[1] + (size_t)i * hp * wp * 64, h, wd, 64, s); }
+        if (rc) return rc;
+    }
+    h = hp; wd = wp;
     int cur = 1, bi = 0;
     for (int layer = 0; layer < 3; ++layer)
         for (int k = 0; k < w->n_blocks[layer]; ++k, ++bi) {
             int out = -1;
-            rc = run_bottleneck(c, w->blocks[bi], 1, h, wd, cur, &out, s, 0, wino, p->conv_blocks_target == 0);
+            rc = run_bottleneck(c, w->blocks[bi], n, h, wd, cur, &out, s, 0, wino, p->conv_blocks_target == 0, true);
             if (rc) return rc;
             cur = out;
         }
-    const int fh = h, fw = wd;
-    const int C = w->blocks[bi - 1].cout;                       // 1024
-    if (fh > c->max_fh || fw > c->max_fw || C > 1024 || C % 64) return FRCNN_EINVAL;
-    FRCNN_HIP_TRY(hipMemcpyAsync(c->fm, c->res_buf[cur], (size_t)fh * fw * C * sizeof(float), hipMemcpyDeviceToDevice, s));
-    c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms; c->last_c = C;
+    *cur_out = cur; *fh_out = h; *fw_out = wd; *c_out = w->blocks[bi - 1].cout;     // 1024
+    return FRCNN_OK;
+}
 
-    // stage 2: RPN (models/rpn.py:88-153)
+// stages 2 and 3 on the feature map in c->fm: RPN (models/rpn.py:88-153), RoI pooling, layer4 per RoI, spatial mean, heads
+// (models/detector.py:65-80, resnet.py:109-118)
+int resnet_tail(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p, int H, int W, int fh, int fw, int C,
+                const float* d_anchor_map, const float* d_valid_map, float* d_props, float* d_classes, float* d_deltas, int32_t* d_counts,
+                hipStream_t s)
+{
+    const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
+    int rc;
+    int bi = w->n_blocks[0] + w->n_blocks[1] + w->n_blocks[2];
+#define STEP(cls, call) do { Scope _sc(c, cls, s); rc = (call); } while (0); if (rc) return rc
+    c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms; c->last_c = C;
     if (p->winograd_x6_mask != 0 && (!wino || p->winograd_x6_mask != (1 << FRCNN_X6_RPN_TRUNK_BIT))) return FRCNN_EINVAL;
     if (wino && p->winograd_x6_mask) {
         rc = run_wino_x6_layer(c, c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU, s);
@@ -1241,21 +1269,19 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
                                  H, W, p->pre_nms, p->post_nms, p->rpn_nms_threshold, p->min_side, c->scores,
                                  c->sorted_idx, d_props, d_counts, s));
 
-    // stage 3: RoIPool, layer4 per RoI, spatial mean, heads (models/detector.py:65-80, resnet.py:109-118)
     const int R_ = p->post_nms;
     if (p->roi_op == FRCNN_ROI_ALIGN) {
         STEP(4, launch_roi_align(c->fm, fh, fw, C, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, p->roi_sampling_ratio, 0, c->roi_out, s));
     } else {
         STEP(4, launch_roi_pool(c->fm, fh, fw, C, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
     }
-    if ((size_t)R_ * 49 * C > c->res_buf_floats * 2) { /* roi_out is its own buffer; nothing to check */ }
     // layer4 reads its input from roi_out: stage it as res_buf "cur" by pointer swap
     float* saved = c->res_buf[0];
     c->res_buf[0] = c->roi_out;
-    cur = 0; h = 7; wd = 7;
+    int cur = 0, h = 7, wd = 7;
     for (int k = 0; k < w->n_blocks[3]; ++k, ++bi) {
         int out = -1;
-        rc = run_bottleneck(c, w->blocks[bi], R_, h, wd, cur, &out, s, 2, wino, p->conv_blocks_target == 0);
+        rc = run_bottleneck(c, w->blocks[bi], R_, h, wd, cur, &out, s, 2, wino, p->conv_blocks_target == 0, false);
         if (rc) { c->res_buf[0] = saved; return rc; }
         cur = out;
     }
@@ -1273,6 +1299,101 @@ int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcn
     STEP(5, launch_head_finish(c->head_logits, hld, R_, ncls, nd, d_classes, d_deltas, s));
 #undef STEP
     return FRCNN_OK;
+}
+}  // namespace
+
+int frcnn_resnet_forward(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p,
+                         const float* d_image, int H, int W, const float* d_anchor_map,
+                         const float* d_valid_map, float* d_props, float* d_classes, float* d_deltas,
+                         int32_t* d_counts, void* stream)
+{
+    if (!c || !w || !p || !d_image || !d_props || !d_classes || !d_deltas || !d_counts) return FRCNN_EINVAL;
+    if (H < 32 || W < 32 || H > c->max_h || W > c->max_w) return FRCNN_EINVAL;
+    if (p->post_nms < 1 || p->post_nms > c->max_rois || p->pre_nms < 1 || p->pre_nms > c->pre_cap) return FRCNN_EINVAL;
+    if (w->num_classes < 2 || w->num_classes > FRCNN_MAX_NUM_CLASSES) return FRCNN_EUNSUPPORTED;
+    int rc = resnet_check_params(p);
+    if (rc) return rc;
+    rc = resnet_check_weights(w, true);
+    if (rc) return rc;
+    hipStream_t s = as_stream(stream);
+    BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows, p->x6_gemm_tiles);
+    if (p->math_mode == FRCNN_MATH_F32_WINOGRAD) { rc = ensure_wino_ws(c); if (rc) return rc; }
+    int cur = 0, fh = 0, fw = 0, C = 0;
+    rc = resnet_stage1(c, w, p, d_image, 1, H, W, &cur, &fh, &fw, &C, s);
+    if (rc) return rc;
+    if (fh > c->max_fh || fw > c->max_fw || C > 1024 || C % 64) return FRCNN_EINVAL;
+    FRCNN_HIP_TRY(hipMemcpyAsync(c->fm, c->res_buf[cur], (size_t)fh * fw * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return resnet_tail(c, w, p, H, W, fh, fw, C, d_anchor_map, d_valid_map, d_props, d_classes, d_deltas, d_counts, s);
+}
+
+// ---- the same forward in two calls: the feature extractor over a BATCH of images, then RPN + detector per image -----------------
+int frcnn_ctx_create_backbone(frcnn_ctx** out, int max_image_h, int max_image_w, int max_images)
+{
+    // scratch of frcnn_resnet_backbone only: the five rotating activation buffers sized for max_images maps and the split-K scratch of
+    // the gather kernel; Winograd / x6 scratch is allocated by the first call that needs it.  The fused forwards refuse such a ctx.
+    if (!out || max_image_h < 32 || max_image_w < 32 || max_images < 1 || max_images > 64) return FRCNN_EINVAL;
+    frcnn_ctx* c = new (std::nothrow) frcnn_ctx();
+    if (!c) return FRCNN_ENOMEM;
+    c->max_h = max_image_h; c->max_w = max_image_w; c->max_rois = 0; c->max_images = max_images;
+    c->max_fh = cdiv(max_image_h, 16); c->max_fw = cdiv(max_image_w, 16);
+    const size_t stem = (size_t)((max_image_h + 1) / 2) * ((max_image_w + 1) / 2) * 64;
+    c->res_buf_floats = stem * max_images;
+    const size_t cws = (size_t)160 << 20;
+    const size_t total = 5 * align_up(c->res_buf_floats * 4, 256) + align_up(cws, 256);
+    hipError_t e = hipMalloc(&c->slab, total);
+    if (e != hipSuccess) { set_hip_error(e); delete c; return FRCNN_ENOMEM; }
+    c->slab_bytes = total;
+    unsigned char* q = static_cast<unsigned char*>(c->slab);
+    for (int i = 0; i < 5; ++i) { c->res_buf[i] = reinterpret_cast<float*>(q); q += align_up(c->res_buf_floats * 4, 256); }
+    c->conv_ws = q; c->conv_ws_bytes = cws;
+    *out = c;
+    return FRCNN_OK;
+}
+
+int frcnn_resnet_backbone(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p, const float* d_images,
+                          int n_images, int H, int W, float* d_features, void* stream)
+{
+    if (!c || !w || !p || !d_images || !d_features || n_images < 1) return FRCNN_EINVAL;
+    if (H < 32 || W < 32 || H > c->max_h || W > c->max_w || n_images > (c->max_images > 0 ? c->max_images : 1)) return FRCNN_EINVAL;
+    int rc = resnet_check_params(p);
+    if (rc) return rc;
+    rc = resnet_check_weights(w, false);
+    if (rc) return rc;
+    hipStream_t s = as_stream(stream);
+    BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows, p->x6_gemm_tiles);
+    int cur = 0, fh = 0, fw = 0, C = 0;
+    rc = resnet_stage1(c, w, p, d_images, n_images, H, W, &cur, &fh, &fw, &C, s);
+    if (rc) return rc;
+    FRCNN_HIP_TRY(hipMemcpyAsync(d_features, c->res_buf[cur], (size_t)n_images * fh * fw * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return FRCNN_OK;
+}
+
+int frcnn_resnet_forward_features(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p,
+                                  const float* d_feature_map, int H, int W, const float* d_anchor_map,
+                                  const float* d_valid_map, float* d_props, float* d_classes, float* d_deltas,
+                                  int32_t* d_counts, void* stream)
+{
+    if (!c || !w || !p || !d_feature_map || !d_props || !d_classes || !d_deltas || !d_counts) return FRCNN_EINVAL;
+    if (H < 32 || W < 32 || H > c->max_h || W > c->max_w) return FRCNN_EINVAL;
+    if (p->post_nms < 1 || p->post_nms > c->max_rois || p->pre_nms < 1 || p->pre_nms > c->pre_cap) return FRCNN_EINVAL;
+    if (w->num_classes < 2 || w->num_classes > FRCNN_MAX_NUM_CLASSES) return FRCNN_EUNSUPPORTED;
+    int rc = resnet_check_params(p);
+    if (rc) return rc;
+    rc = resnet_check_weights(w, true);
+    if (rc) return rc;
+    hipStream_t s = as_stream(stream);
+    BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows, p->x6_gemm_tiles);
+    if (p->math_mode == FRCNN_MATH_F32_WINOGRAD) { rc = ensure_wino_ws(c); if (rc) return rc; }
+    // the map's shape follows from the image's (conv1 7x7/2 pad 3, maxpool 3x3/2 pad 1, layer2 and layer3 stride 2)
+    int fh = (H + 6 - 7) / 2 + 1, fw = (W + 6 - 7) / 2 + 1;
+    fh = (fh + 2 - 3) / 2 + 1; fw = (fw + 2 - 3) / 2 + 1;
+    for (int i = 0; i < 2; ++i) { fh = (fh + 2 - 3) / 2 + 1; fw = (fw + 2 - 3) / 2 + 1; }
+    const int nb3 = w->n_blocks[0] + w->n_blocks[1] + w->n_blocks[2];
+    const int C = w->blocks[nb3 - 1].cout;
+    if (fh > c->max_fh || fw > c->max_fw || C > 1024 || C % 64) return FRCNN_EINVAL;
+    if (d_feature_map != c->fm)
+        FRCNN_HIP_TRY(hipMemcpyAsync(c->fm, d_feature_map, (size_t)fh * fw * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return resnet_tail(c, w, p, H, W, fh, fw, C, d_anchor_map, d_valid_map, d_props, d_classes, d_deltas, d_counts, s);
 }
 
 }  // extern "C"

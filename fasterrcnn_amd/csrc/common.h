@@ -134,7 +134,7 @@ bool conv3x3_winograd_fused_ok(int H, int W, int cin, int cout);
 int launch_pack_conv3x3_winograd_fused(const float* w, const float* scale, float* u, int cout, int cin, hipStream_t s);
 int launch_pack_conv3x3_winograd_fused_taps(const float* wp, float* u, int cout, int cin, int data_gradient, hipStream_t s);
 int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
-                                  unsigned flags, hipStream_t s);
+                                  unsigned flags, hipStream_t s, int n_maps = 1);
 // linear_x6.hip: fc1 / fc2 on the bf16 pipe with exactly split operands
 bool linear_x6_shape_ok(int M, int N, int K);
 size_t linear_x6_workspace_bytes(int M, int N, int K);

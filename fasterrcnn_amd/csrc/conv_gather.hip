@@ -179,7 +179,7 @@ void conv_gather_mfma_kernel(const float* __restrict__ x, const float* __restric
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], b0[j][kk], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[j][kk], a0[i][kk], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < N_RD; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
 #pragma unroll
@@ -203,33 +203,56 @@ void conv_gather_mfma_kernel(const float* __restrict__ x, const float* __restric
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[j][kk], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[j][kk], a1[i][kk], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < N_RD; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
+    // The weights are the MFMA's ROW operand and the pixels its column operand: a lane then holds, for its pixel m (= lane & 31), the
+    // output channels 8 q + 4 (lane >> 5) + 0..3 in the registers 4 q .. 4 q + 3 -- four consecutive floats of one NHWC row, so the
+    // bias / residual / output accesses are 16-byte ones (a product does not depend on which operand carries which factor: the
+    // sums are those of the pixel-major form bit for bit).
     const bool direct = (gridDim.z == 1);
     float* const dst = direct ? y : ws + (size_t)blockIdx.z * M * g.Cout;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + 32 * (TN * wn + j) + li;
-        if (n >= g.Cout) continue;
-        const float bv = (direct && bias) ? bias[n] : 0.f;
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + 32 * (TM * wm + i) + li;
+        if (m >= M) continue;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j) {
+            f32x4 res[4];
+            if (direct && residual) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < M) {
-                    float v = acc[i][j][r] + bv;
-                    if (direct) {
-                        if (residual) v += residual[(size_t)m * g.Cout + n];
-                        if (relu) v = fmaxf(v, 0.f);
-                    }
-                    dst[(size_t)m * g.Cout + n] = v;
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + 32 * (TN * wn + j) + 8 * q + 4 * lh;
+                    res[q] = n < g.Cout ? *reinterpret_cast<const f32x4*>(residual + (size_t)m * g.Cout + n) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + 32 * (TN * wn + j) + 8 * q + 4 * lh;
+                if (n >= g.Cout) continue;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                if (direct) {
+                    if (bias) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                    }
+                    if (residual) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += res[q][e];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(dst + (size_t)m * g.Cout + n) = v;
             }
         }
     }
@@ -388,12 +411,16 @@ static GatherPlan plan_gather(int M, int Cout, int stages)
     p.mblocks = cdiv(M, bm);
     p.nblocks = cdiv(Cout, bn);
     const int blocks = p.mblocks * p.nblocks;
-    int want = 1280 / (blocks > 0 ? blocks : 1);     // ~5 blocks per CU (see conv.hip)
+    static const int target = []() { const char* e = getenv("FRCNN_GATHER_BLOCKS"); return e ? atoi(e) : 1280; }();   // experiments
+    int want = target / (blocks > 0 ? blocks : 1);     // ~5 blocks per CU (see conv.hip)
     int cap = stages / 8;
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     if ((size_t)M * Cout * sizeof(float) > ((size_t)40 << 20)) want = 1;
+    // a tall GEMM (a batch of images through a 1x1 convolution) with two blocks per CU already: the partial planes would cost more
+    // than the tail they fill (measured at 8 x 75x125 pixels, 512 -> 128: 124 us unsplit, 127 + 17 us split in two)
+    if (blocks >= 512 && M >= 32768) want = 1;
     p.stages_per_split = cdiv(stages, want);
     p.splits = cdiv(stages, p.stages_per_split);
     return p;

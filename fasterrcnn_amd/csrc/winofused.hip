@@ -140,7 +140,8 @@ void wino_pack_fused_taps_kernel(const float* __restrict__ wp, float* __restrict
     }
 }
 
-struct WfGeom { int tbx, tby, ncb, total, xcl; };        // xcl: log2 of the number of XCD groups the cout blocks are split over
+struct WfGeom { int tbx, tby, ncb, total, xcl, tbm; };   // xcl: log2 of the number of XCD groups the cout blocks are split over;
+                                                         // tbm = tbx * tby: tile blocks per map (the maps of a launch follow each other)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 wf_lo(const f32x4& a) { return __builtin_shufflevector(a, a, 0, 1); }
@@ -157,8 +158,8 @@ __device__ __forceinline__ f32x2 wf_pk(bool sub, f32x2 a, f32x2 b)
 
 template <bool POOL>
 __global__ __launch_bounds__(256, 2)
-void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ bias,
-                       float* __restrict__ y, int H, int W, int Cin, int Cout, int relu, WfGeom gm)
+void wino_fused_kernel(const float* __restrict__ x_maps, const float* __restrict__ u, const float* __restrict__ bias,
+                       float* __restrict__ y_maps, int H, int W, int Cin, int Cout, int relu, WfGeom gm)
 {
 #ifdef WF_CLOCKS
     const unsigned long long real_entry = __builtin_amdgcn_s_memrealtime();
@@ -191,6 +192,12 @@ void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ u,
         tb = L / ncbx;
         cb = xci * ncbx + (L - tb * ncbx);
     }
+    // several maps in one launch (a batch of images through a ResNet bottleneck): tile blocks are numbered map-major, the map index
+    // only shifts the two base pointers (scalar arithmetic: the block is uniform)
+    const int map = tb / gm.tbm;
+    tb -= map * gm.tbm;
+    const float* __restrict__ const x = x_maps + (size_t)map * H * W * Cin;
+    float* __restrict__ const y = y_maps + (size_t)map * (POOL ? (H >> 1) * (W >> 1) : H * W) * Cout;
     const int bx = tb % gm.tbx, by = tb / gm.tbx;
     const int n0 = cb * WF_BN;
     const int y0 = 2 * WF_TR * by - 1, x0 = 2 * WF_TC * bx - 1;
@@ -537,8 +544,9 @@ static int wf_choose_xcl(int cin, int cout, int ncb)
 }
 
 int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
-                                  unsigned flags, hipStream_t s)
+                                  unsigned flags, hipStream_t s, int n_maps)
 {
+    if (n_maps < 1) return FRCNN_EINVAL;
     if (!conv3x3_winograd_fused_ok(H, W, cin, cout)) return FRCNN_EUNSUPPORTED;
     if ((flags & FRCNN_POOL2) && (H < 2 || W < 2)) return FRCNN_EINVAL;
     const int th = cdiv(H, 2), tw = cdiv(W, 2);
@@ -546,7 +554,8 @@ int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b
     gm.tbx = cdiv(tw, WF_TC);
     gm.tby = cdiv(th, WF_TR);
     gm.ncb = cout / WF_BN;
-    const long long total = (long long)gm.tbx * gm.tby * gm.ncb;
+    gm.tbm = gm.tbx * gm.tby;
+    const long long total = (long long)gm.tbm * n_maps * gm.ncb;
     if (total > 0x7fffffffLL) return FRCNN_EINVAL;
     gm.total = (int)total;
     gm.xcl = wf_choose_xcl(cin, cout, gm.ncb);

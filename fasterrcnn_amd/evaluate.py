@@ -92,11 +92,13 @@ def merged_calculator(records, device=None, force_gather=False):
     return calc
 
 
-def evaluate_stream(model, samples, score_threshold=0.05, inflight=4, rank=0, world=1, on_result=None):
+def evaluate_stream(model, samples, score_threshold=0.05, inflight=4, rank=0, world=1, on_result=None, batch=1):
     """
     samples: sequence of (image_index, image (1,3,H,W) CUDA float32 tensor, gt_boxes list[Box]).
     Processes the samples whose position p satisfies p % world == rank, `inflight` at a time, and
     returns this rank's ImageRecords.  `on_result(image_index, dict)` is called per finished image.
+    batch > 1 (ResNet backbones): consecutive samples of one shape go through the feature extractor as ONE batch of up to `batch`
+    images (model.predict_batch_async), max(1, inflight // batch) batches in flight; results and their order are per image as before.
     """
     records = ImageRecords()
     pending = []   # (Pending, image_index, gt_boxes)
@@ -108,6 +110,37 @@ def evaluate_stream(model, samples, score_threshold=0.05, inflight=4, rank=0, wo
             on_result(image_index, det)
         if gt_boxes is not None:
             records.add(image_index, det, gt_boxes)
+
+    batch = max(1, int(batch))
+    if batch > 1:
+        nlanes = max(1, int(inflight) // batch)
+        group, lanes, state = [], [], {"lane": 0}             # lanes[i]: the lane of pending[i]
+
+        def flush():
+            if not group:
+                return
+            while state["lane"] in lanes:                    # the lane about to be reused must have been collected (in image order)
+                collect(pending.pop(0))
+                lanes.pop(0)
+            images = group[0][1] if len(group) == 1 else t.cat([g[1] for g in group], dim=0)
+            handles = model.predict_batch_async(images, score_threshold, lane=state["lane"])
+            pending.extend((hd, g[0], g[2]) for hd, g in zip(handles, group))
+            lanes.extend([state["lane"]] * len(group))
+            state["lane"] = (state["lane"] + 1) % nlanes
+            del group[:]
+
+        for p, (image_index, image, gt_boxes) in enumerate(samples):
+            if p % world != rank:
+                continue
+            if group and tuple(group[0][1].shape[1:]) != tuple(image.shape[1:]):
+                flush()
+            group.append((image_index, image, gt_boxes))
+            if len(group) == batch:
+                flush()
+        flush()
+        while pending:
+            collect(pending.pop(0))
+        return records
 
     nslots = max(1, int(inflight))
     k = 0

@@ -155,6 +155,7 @@ class FasterRCNNModel(nn.Module):
         self._train_state = None
         self._gradient_sync = None          # training.enable_data_parallel
         self._slots = {}
+        self._lanes = {}           # (device, lane) -> runtime.BackboneLane: batches going through the ResNet feature extractor together
         self._wstruct = None
         self._wstruct_key = None
         self._wkeep = None
@@ -349,6 +350,7 @@ class FasterRCNNModel(nn.Module):
         out = super()._apply(fn, *args, **kwargs)
         self._train_state = None
         self._slots = {}
+        self._lanes = {}
         self._wstruct_key = None
         return out
 
@@ -360,6 +362,97 @@ class FasterRCNNModel(nn.Module):
                            own_stream=(index > 0))
             self._slots[key] = slot
         return slot
+
+    def _forward_params(self, slot_index):
+        return nv.ForwardParams(int(self.max_proposals_pre_nms), int(self.max_proposals_post_nms),
+                                float(self.rpn_nms_threshold), float(self.rpn_min_side),
+                                1 if self._allow_edge_proposals else 0, nv.MATH_MODES[self._math_mode],
+                                # slot 0 = one image at a time (latency); slots > 0 = many images in flight on their own
+                                # streams, where longer split-K work units give more throughput (csrc/conv.hip)
+                                0 if slot_index == 0 else self.inflight_conv_blocks_target,
+                                nv.FC_MATH_MODES[self._effective_fc_math()],
+                                nv.ROI_OPS[self._stage3_detector_network.pooling], self._stage3_detector_network.sampling_ratio,
+                                0 if slot_index == 0 else self.inflight_winograd_tile_rows, self._x6_mask(),
+                                # (ResNet: the cost model's choice in every slot, so that an image gives the same bits in flight
+                                #  and alone: its 1x1 GEMMs switch between split-K and unsplit tiles with the tile mode)
+                                0 if (slot_index == 0 or self._is_resnet) else self.inflight_x6_gemm_tiles)
+
+    def _enqueue_outputs(self, slot, h, w, score_threshold, sp):
+        """decode + per-class NMS (faster_rcnn.py:179-224) and the D2H copies of one image, behind its forward on stream `sp`."""
+        lib = nv.lib()
+        if score_threshold is not None:
+            nv.check(lib.frcnn_detections(nv.ptr(slot.props), nv.ptr(slot.classes), nv.ptr(slot.deltas),
+                                          slot.counts.data_ptr() + 8, slot.max_rois, self._num_classes, h, w,
+                                          float(score_threshold), float(self.detector_nms_threshold),
+                                          nv.ptr(slot.det), nv.ptr(slot.det_cnt), sp), "frcnn_detections")
+            slot.h_det.copy_(slot.det, non_blocking=True)
+            slot.h_det_cnt.copy_(slot.det_cnt, non_blocking=True)
+        slot.h_counts.copy_(slot.counts, non_blocking=True)
+
+    def _enqueue_batch(self, image_data, score_threshold, lane_index):
+        """
+        A true batch (B, 3, H, W) through a ResNet model (the reference asserts B == 1, faster_rcnn.py:108; BASELINE configs[2] is
+        "batch=8"): ONE pass of the feature extractor over the B images on the lane's stream (frcnn_resnet_backbone: every bottleneck
+        launch covers the B maps), then RPN + detector head + decode / NMS per image on B slot streams behind it
+        (frcnn_resnet_forward_features).  Returns B Pending handles.  Lane l uses the slots 1 + l * B ... (l + 1) * B.
+        """
+        if not self._is_resnet:
+            raise NotImplementedError("batched forward: ResNet backbones only (VGG-16's layers fill the chip with one image)")
+        self._check_limits(with_detections=score_threshold is not None)
+        self.sync_parameters()
+        device = self._device()
+        images = rt.as_f32_cuda(image_data, "image_data")
+        if images.device != device:
+            raise RuntimeError("image_data is on %s but the model is on %s" % (images.device, device))
+        if images.dim() != 4 or images.shape[1] != 3 or images.shape[0] < 1:
+            raise ValueError("image_data must be shaped (B, 3, H, W)")
+        B, h, w = int(images.shape[0]), int(images.shape[2]), int(images.shape[3])
+        lane_index = int(lane_index)
+        channels = 1024
+        key = (str(device), lane_index)
+        lane = self._lanes.get(key)
+        if lane is None or not lane.fits(h, w, B):
+            if lane is not None:
+                for sl in lane.readers:
+                    sl.done.synchronize()
+            lane = rt.BackboneLane(device, max(h, 608), max(w, 1008), max(B, lane.max_images if lane is not None else 1), channels)
+            self._lanes[key] = lane
+        cap = lane.max_images
+        slots = [self._slot(1 + lane_index * cap + i, h, w, device) for i in range(B)]
+        for i, slot in enumerate(slots):
+            if slot.busy:
+                raise RuntimeError("slot %d still has an un-collected image in flight" % (1 + lane_index * cap + i))
+        weights = self._weights()
+        params = self._forward_params(1)
+        lib = nv.lib()
+        fh, fw = rt.feature_map_shape(h, w)
+        per_map = fh * fw * channels * 4
+        out = []
+        with t.cuda.device(device):
+            lane.stream.wait_stream(t.cuda.current_stream(device))
+            for sl in lane.readers:                       # the previous batch of this lane may still be reading the feature maps
+                lane.stream.wait_event(sl.done)
+            with t.cuda.stream(lane.stream):
+                nv.check(lib.frcnn_resnet_backbone(lane.handle, C.byref(weights), C.byref(params), nv.ptr(images), B, h, w,
+                                                   nv.ptr(lane.features), lane.stream.cuda_stream), "frcnn_resnet_backbone")
+                lane.ready.record(lane.stream)
+            for i, slot in enumerate(slots):
+                stream = slot.use_stream()
+                stream.wait_event(lane.ready)
+                with t.cuda.stream(stream):
+                    nv.check(lib.frcnn_resnet_forward_features(slot.ctx.handle, C.byref(weights), C.byref(params),
+                                                               lane.features.data_ptr() + i * per_map, h, w, None, None,
+                                                               nv.ptr(slot.props), nv.ptr(slot.classes), nv.ptr(slot.deltas),
+                                                               nv.ptr(slot.counts), stream.cuda_stream), "frcnn_resnet_forward_features")
+                    self._enqueue_outputs(slot, h, w, score_threshold, stream.cuda_stream)
+                    slot.done.record(stream)
+                slot.graph, slot.graph_input, slot.graph_key = None, None, None
+                slot.busy = True
+                slot.keepalive = (images,)
+                out.append(Pending(self, slot, score_threshold is not None))
+        lane.readers = slots
+        lane.keepalive = images
+        return out
 
     def _enqueue(self, image_data, anchor_map, anchor_valid_map, score_threshold, slot_index):
         assert image_data.shape[0] == 1, "Batch size must be 1"
@@ -380,18 +473,7 @@ class FasterRCNNModel(nn.Module):
         if amap is None or vmap is None:
             amap = vmap = None
         weights = self._weights()
-        params = nv.ForwardParams(int(self.max_proposals_pre_nms), int(self.max_proposals_post_nms),
-                                  float(self.rpn_nms_threshold), float(self.rpn_min_side),
-                                  1 if self._allow_edge_proposals else 0, nv.MATH_MODES[self._math_mode],
-                                  # slot 0 = one image at a time (latency); slots > 0 = many images in flight on their own
-                                  # streams, where longer split-K work units give more throughput (csrc/conv.hip)
-                                  0 if slot_index == 0 else self.inflight_conv_blocks_target,
-                                  nv.FC_MATH_MODES[self._effective_fc_math()],
-                                  nv.ROI_OPS[self._stage3_detector_network.pooling], self._stage3_detector_network.sampling_ratio,
-                                  0 if slot_index == 0 else self.inflight_winograd_tile_rows, self._x6_mask(),
-                                  # (ResNet: the cost model's choice in every slot, so that an image gives the same bits in flight
-                                  #  and alone: its 1x1 GEMMs switch between split-K and unsplit tiles with the tile mode)
-                                  0 if (slot_index == 0 or self._is_resnet) else self.inflight_x6_gemm_tiles)
+        params = self._forward_params(slot_index)
         lib = nv.lib()
         with_det = score_threshold is not None
         fwd, fwd_name = ((lib.frcnn_resnet_forward, "frcnn_resnet_forward") if self._is_resnet
@@ -402,14 +484,7 @@ class FasterRCNNModel(nn.Module):
             nv.check(fwd(slot.ctx.handle, C.byref(weights), C.byref(params), nv.ptr(img), h, w,
                          nv.ptr(amap), nv.ptr(vmap), nv.ptr(slot.props), nv.ptr(slot.classes),
                          nv.ptr(slot.deltas), nv.ptr(slot.counts), sp), fwd_name)
-            if with_det:
-                nv.check(lib.frcnn_detections(nv.ptr(slot.props), nv.ptr(slot.classes), nv.ptr(slot.deltas),
-                                              slot.counts.data_ptr() + 8, slot.max_rois, self._num_classes, h, w,
-                                              float(score_threshold), float(self.detector_nms_threshold),
-                                              nv.ptr(slot.det), nv.ptr(slot.det_cnt), sp), "frcnn_detections")
-                slot.h_det.copy_(slot.det, non_blocking=True)
-                slot.h_det_cnt.copy_(slot.det_cnt, non_blocking=True)
-            slot.h_counts.copy_(slot.counts, non_blocking=True)
+            self._enqueue_outputs(slot, h, w, score_threshold, sp)
 
         gkey = None
         if self.use_hip_graphs and amap is None and not slot.ctx.timing:
@@ -474,6 +549,22 @@ class FasterRCNNModel(nn.Module):
         collected before it is reused.
         """
         return self._enqueue(image_data, anchor_map, anchor_valid_map, score_threshold, int(slot))
+
+    def forward_batch(self, image_data, lane=0):
+        """`forward` over a batch (B, 3, H, W) of equally sized images (ResNet backbones): list of B (proposals, classes, box deltas)."""
+        with t.no_grad():
+            return [p.result() for p in self._enqueue_batch(image_data, None, lane)]
+
+    @utils.no_grad
+    def predict_batch(self, image_data, score_threshold, lane=0):
+        """`predict` over a batch (B, 3, H, W) of equally sized images (ResNet backbones): list of B dicts as `predict` returns them."""
+        self.eval()
+        return [p.result() for p in self._enqueue_batch(image_data, score_threshold, lane)]
+
+    @utils.no_grad
+    def predict_batch_async(self, image_data, score_threshold, lane=0):
+        """Enqueues `predict_batch` on lane `lane` and returns the B Pending handles (several lanes keep several batches in flight)."""
+        return self._enqueue_batch(image_data, score_threshold, lane)
 
     def context(self, slot=0):
         """The runtime.Context of an in-flight slot (parity tests read intermediate tensors from it)."""

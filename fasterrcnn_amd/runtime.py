@@ -108,6 +108,47 @@ class Slot:
         return self.stream if self.stream is not None else t.cuda.current_stream(self.device)
 
 
+class BackboneLane:
+    """
+    A batch of images going through the ResNet feature extractor together (frcnn_resnet_backbone): a backbone-only frcnn_ctx sized for
+    `max_images` maps, the lane's stream, the [max_images][fh][fw][C] feature maps the per-image slots read, and the event that says
+    the maps are complete.
+    """
+    def __init__(self, device, max_h, max_w, max_images, channels):
+        nv.require_gpu()
+        self.device = t.device(device)
+        self.max_h, self.max_w, self.max_images = int(max_h), int(max_w), int(max_images)
+        handle = C.c_void_p()
+        with t.cuda.device(self.device):
+            nv.check(nv.lib().frcnn_ctx_create_backbone(C.byref(handle), self.max_h, self.max_w, self.max_images), "frcnn_ctx_create_backbone")
+            self.stream = t.cuda.Stream(device=self.device)
+        self.handle = handle
+        fh, fw = feature_map_shape(self.max_h, self.max_w)
+        self.features = t.empty((self.max_images * fh * fw * int(channels),), dtype=t.float32, device=self.device)
+        self.ready = t.cuda.Event()
+        self.readers = []            # the slots whose enqueued work still reads self.features
+        self.keepalive = None
+
+    def fits(self, h, w, n):
+        return h <= self.max_h and w <= self.max_w and n <= self.max_images
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) is not None and self.handle.value:
+                nv.lib().frcnn_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def feature_map_shape(h, w):
+    """(fh, fw) of the ResNet feature map of an h x w image: conv1 7x7/2 pad 3, maxpool 3x3/2 pad 1, layer2 and layer3 stride 2
+    (models/resnet.py:38-46) -- each halves as (x - 1) // 2 + 1."""
+    for _ in range(4):
+        h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    return h, w
+
+
 def param_key(params):
     """Cache key that changes whenever any of the tensors is replaced, moved or written in place."""
     return tuple((p.data_ptr(), p._version, str(p.device), tuple(p.shape)) for p in params)

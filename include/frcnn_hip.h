@@ -37,9 +37,10 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 6   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
+#define FRCNN_ABI_VERSION 7   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
                                  5: bf16 gradient GEMMs (the *_math entry points); 6: x6t GEMM, x6 Winograd layers, frcnn_forward_params.winograd_x6_mask,
-                                 timing classes 8 / 9 */
+                                 timing classes 8 / 9; 7: batched feature extractor (frcnn_resnet_backbone, frcnn_resnet_forward_features,
+                                 frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps) */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -183,6 +184,10 @@ int frcnn_pack_conv3x3_winograd_fused(const float* d_w_oihw, const float* d_row_
 int frcnn_pack_conv3x3_winograd_fused_taps(const float* d_w_packed, float* d_u, int cout, int cin, int data_gradient, void* stream);
 int frcnn_conv3x3_nhwc_winograd_fused(const float* d_x, const float* d_u, const float* d_bias, float* d_y,
                                       int H, int W, int cin, int cout, unsigned flags, void* stream);
+/* The same launch over n_maps maps [n_maps][H][W][cin] -> [n_maps][Ho][Wo][cout] (a batch of images through one layer): the tile
+ * blocks of the maps follow each other in ONE grid, every map's result is bit-identical to its own single-map call. */
+int frcnn_conv3x3_nhwc_winograd_fused_maps(const float* d_x, const float* d_u, const float* d_bias, float* d_y, int n_maps,
+                                           int H, int W, int cin, int cout, unsigned flags, void* stream);
 /* Dense layer with ReLU (models/vgg16.py:130-132) in the "f32x6" arithmetic (csrc/linear_x6.hip): both operands as "x6 records"
  * -- for a row-major float32 matrix [R][K] the record of (row, 16-k chunk) is 96 contiguous bytes [hi 16 | mid 16 | lo 16] bf16 with
  * x = hi + mid + lo exactly -- six bf16 MFMAs per product, f32 accumulation (dropped terms <= 2^-24 relative: fp32-rounding class).
@@ -500,6 +505,29 @@ int frcnn_resnet_forward(frcnn_ctx* ctx, const frcnn_resnet_weights* w, const fr
                          const float* d_anchor_map, const float* d_valid_map,
                          float* d_props, float* d_classes, float* d_deltas, int32_t* d_counts,
                          void* stream);
+
+/* The same forward in two calls, for a true batch of images (BASELINE configs[2] "batch=8"; the reference asserts batch 1 at
+ * models/faster_rcnn.py:108, SURVEY 8b allows lifting it):
+ *   frcnn_resnet_backbone          conv1 / bn1 / relu / maxpool / layer1..3 (models/resnet.py:38-46) over n_images images
+ *                                  [n][3][H][W] -> d_features [n][fh][fw][1024] (NHWC float32) with EVERY bottleneck launch covering
+ *                                  the n maps: the 1x1 convolutions become GEMMs over n * h * w pixels (one map of 38 x 63 fills 38
+ *                                  tiles of a 256-CU chip).  ctx: frcnn_ctx_create_backbone(max_h, max_w, max_images) -- only the
+ *                                  activation rotation and the gather kernel's split-K scratch (the fused forwards refuse it) -- or any
+ *                                  full ctx with n_images == 1.
+ *   frcnn_resnet_forward_features  RPN + RoI pooling + layer4 + heads (models/faster_rcnn.py:116-132) of ONE image from its feature
+ *                                  map (copied into the ctx's own map unless it already is frcnn_ctx_tensor(ctx, 0)); H, W = the image's
+ *                                  size as in frcnn_resnet_forward.
+ * frcnn_resnet_forward(image) == frcnn_resnet_backbone(1 image) + frcnn_resnet_forward_features bit for bit; with n > 1 the split-K
+ * factors of the under-filled GEMMs differ (fewer splits are needed), so feature maps agree to float32 rounding (~1e-6 relative),
+ * deterministically. */
+int frcnn_ctx_create_backbone(frcnn_ctx** out, int max_image_h, int max_image_w, int max_images);
+int frcnn_resnet_backbone(frcnn_ctx* ctx, const frcnn_resnet_weights* w, const frcnn_forward_params* p,
+                          const float* d_images, int n_images, int H, int W, float* d_features, void* stream);
+int frcnn_resnet_forward_features(frcnn_ctx* ctx, const frcnn_resnet_weights* w, const frcnn_forward_params* p,
+                                  const float* d_feature_map, int H, int W,
+                                  const float* d_anchor_map, const float* d_valid_map,
+                                  float* d_props, float* d_classes, float* d_deltas, int32_t* d_counts,
+                                  void* stream);
 
 /* ==========================================================================================
  * Training path (SURVEY.md section 8 rows f2 + f3): FasterRCNNModel.train_step,
