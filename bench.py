@@ -90,14 +90,16 @@ def winograd_gemm_flops(ci, co, h, w):
     return 2.0 * 16 * ((h + 1) // 2) * ((w + 1) // 2) * ci * co
 
 
-def layer_arithmetic(math, fc_math, x6=(), n_rois=300, num_classes=21):
+def layer_arithmetic(math, fc_math, x6=(), n_rois=300, num_classes=21, x3=()):
     """One row per GEMM-shaped layer of one image: which kernel family and WHICH matrix pipe it runs on, the FLOP that pipe executes
     for it and the algorithmic (direct-form) FLOP it stands for.  Winograd layers execute 16 x tiles x cin x cout x 2; an "x6" layer
-    executes six bf16 MFMAs per algorithmic product."""
+    executes six bf16 MFMAs per algorithmic product, an "x3" layer (a subset of the x6 table) three fp16 MFMAs."""
     rows = []
     for name, (ci, co, h, w) in zip(_CONV_NAMES, _MFMA_CONVS):
         alg = 2.0 * 9 * ci * co * h * w
-        if math == "f32_winograd" and name in x6:
+        if math == "f32_winograd" and name in x6 and name in x3:
+            rows.append((name, "gemm_x3t_kernel (x3 Winograd layer)", "f16", 3.0 * winograd_gemm_flops(ci, co, h, w), alg))
+        elif math == "f32_winograd" and name in x6:
             rows.append((name, "gemm_x6t_kernel (x6 Winograd layer)", "bf16", 6.0 * winograd_gemm_flops(ci, co, h, w), alg))
         elif math == "f32_winograd" and uses_winograd(ci, co):
             rows.append((name, "wino_fused_kernel", "f32", winograd_gemm_flops(ci, co, h, w), alg))
@@ -109,7 +111,9 @@ def layer_arithmetic(math, fc_math, x6=(), n_rois=300, num_classes=21):
     rows.append(("rpn_heads_1x1", "linear_mfma_kernel", "f32", alg, alg))
     for name, k, n in (("fc1", 25088, 4096), ("fc2", 4096, 4096)):
         alg = n_rois * 2.0 * k * n
-        if fc_math in ("f32x6", "f32x6_v1"):
+        if fc_math == "f32x3":
+            rows.append((name, "gemm_x3t_kernel", "f16", 3.0 * alg, alg))
+        elif fc_math in ("f32x6", "f32x6_v1"):
             rows.append((name, "gemm_x6t_kernel" if fc_math == "f32x6" else "linear_x6_kernel", "bf16", 6.0 * alg, alg))
         else:
             rows.append((name, "linear_mfma_kernel", "f32", alg, alg))
@@ -118,20 +122,21 @@ def layer_arithmetic(math, fc_math, x6=(), n_rois=300, num_classes=21):
     return rows
 
 
-def pipe_flops_per_image(math, fc_math, x6=(), backbone_only=False):
-    """{"f32": FLOP the exact-f32 matrix pipe executes per image, "bf16": FLOP the bf16 matrix pipe executes per image}."""
-    out = {"f32": 0.0, "bf16": 0.0}
-    for name, _, pipe, ex, _ in layer_arithmetic(math, fc_math, x6):
+def pipe_flops_per_image(math, fc_math, x6=(), backbone_only=False, x3=()):
+    """FLOP each matrix pipe executes per image: {"f32": exact-f32 MFMAs, "bf16": bf16 MFMAs (f32x6 layers), "f16": fp16 MFMAs (f32x3 layers)};
+    bf16 and fp16 instructions run at the same dense peak."""
+    out = {"f32": 0.0, "bf16": 0.0, "f16": 0.0}
+    for name, _, pipe, ex, _ in layer_arithmetic(math, fc_math, x6, x3=x3):
         if backbone_only and not (name.startswith("conv") or name == "rpn_trunk"):
             continue
         out[pipe] += ex
     return out
 
 
-def executed_mfma_flops_per_image(math, fc_math="f32", x6=()):
-    """Matrix-pipe FLOP executed per image, both pipes added (kept for continuity with rounds 1-2; the per-pipe figures are the meaningful ones)."""
-    f = pipe_flops_per_image(math, fc_math, x6)
-    return f["f32"] + f["bf16"]
+def executed_mfma_flops_per_image(math, fc_math="f32", x6=(), x3=()):
+    """Matrix-pipe FLOP executed per image, all pipes added (kept for continuity with rounds 1-2; the per-pipe figures are the meaningful ones)."""
+    f = pipe_flops_per_image(math, fc_math, x6, x3=x3)
+    return f["f32"] + f["bf16"] + f["f16"]
 
 
 def total_flops_per_image(n_rois=300):
@@ -602,6 +607,7 @@ def main():
         model.math_mode = args.math
     fc_math = model.fc_math_mode
     x6 = tuple(getattr(model, "winograd_x6_layers", ())) if args.math == "f32_winograd" else ()
+    x3 = tuple(getattr(model, "winograd_x3_layers", ())) if args.math == "f32_winograd" else ()
     fc_f32_value = None
     if not is_resnet and not args.no_secondary and fc_math != "f32":
         # the same workload with fc1 / fc2 on the exact-f32 pipe too: every GEMM of the image on v_mfma_f32_*_f32
@@ -620,6 +626,20 @@ def main():
         dt, _ = timed_median(run, args.steps, min(args.min_timed_seconds, 0.5))
         wino_f32_value = round(n_gpus * args.steps / dt, 3)
         model.winograd_x6_layers = x6
+        model.winograd_x3_layers = x3
+        run(nslots)
+
+    x3_legs = {}
+    if not is_resnet and not args.no_secondary and x6:
+        # the f32x3 arithmetic switched off (every split-operand GEMM in f32x6: the table before the f32x3 kernels existed) and switched on
+        # for the whole x6 table (conv4_2 / conv4_3 too: one near-tied proposal of the 600x1000 golden fixture then crosses the NMS cut,
+        # 299 / 300 proposals and 193 / 194 detections: tests/test_x3_model_gpu.py)
+        for key, layers, fcm in (("f32x6_only_images_per_sec", (), "f32x6" if fc_math == "f32x3" else fc_math), ("f32x3_all_layers_images_per_sec", x6, fc_math)):
+            model.winograd_x3_layers, model.fc_math_mode = layers, fcm
+            run(max(args.warmup, nslots))
+            dt, _ = timed_median(run, args.steps, min(args.min_timed_seconds, 0.5))
+            x3_legs[key] = round(n_gpus * args.steps / dt, 3)
+        model.winograd_x3_layers, model.fc_math_mode = x3, fc_math
         run(nslots)
 
     # ---- driver-timed secondary legs (rank 0 of a one-GPU run; none of them is the headline value) -------------------
@@ -783,24 +803,26 @@ def main():
         if xl:
             ms6, l6 = timing["winograd_x6_gemm"]
             if l6:
-                per_launch = 6.0 * sum(winograd_gemm_flops(*l) for l in xl) / len(xl)
+                per_launch = sum((3.0 if n in x3 else 6.0) * winograd_gemm_flops(*l) for n, l in xl_named) / len(xl)
+                f32_eq = sum(winograd_gemm_flops(*l) for l in xl) / len(xl)
                 n_gemm = len(xl) * n_img                               # GEMM launches (the class also holds the split-K reductions)
                 avg_s = (ms6 / 1e3) / n_gemm
                 ach = per_launch / avg_s / 1e12
                 t8 = timing["winograd_x6_transforms"]
-                r_x6 = {"kernel": "gemm_x6t_kernel (the 16 position GEMMs of an x6 Winograd layer in one launch, f32x6 arithmetic: %d layers per image: %s)"
-                                  % (len(xl), ", ".join(n for n, _ in xl_named)),
+                r_x6 = {"kernel": "gemm_x6t_kernel / gemm_x3t_kernel (the 16 position GEMMs of a Winograd layer in one launch; f32x6 = six bf16 MFMAs per "
+                                  "product: %s; f32x3 = three fp16 MFMAs per product: %s)"
+                                  % (", ".join(n for n, _ in xl_named if n not in x3) or "-", ", ".join(n for n, _ in xl_named if n in x3) or "-"),
                         "regime": regime, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": measured_traffic("gemm_x6t_kernel"),
+                        "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": measured_traffic("gemm_x3t_kernel" if x3 else "gemm_x6t_kernel"),
                         "flops_per_launch": per_launch, "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(n_gemm),
                         "ms_per_image": round(ms6 / max(args.roofline_images, 1), 4),
-                        "f32_equivalent_tflops": round(ach / 6.0, 2),
+                        "f32_equivalent_tflops": round(f32_eq / avg_s / 1e12, 2),
                         "transforms_ms_per_image": round(t8[0] / max(args.roofline_images, 1), 4),
-                        "algorithmic_bytes_per_launch": float(sum(16.0 * ((h + 1) // 2) * ((w + 1) // 2) * (6 * ci + 4 * co) + 16.0 * 6 * ci * co
-                                                                  for ci, co, h, w in xl)) / len(xl),
-                        "note": "FLOP = 6 bf16 MFMA products per float32 product x the Winograd GEMM FLOP (16 x tiles x cin x cout x 2), against the dense "
-                                "bf16 peak; f32_equivalent_tflops = the same launches counted once per float32 product; bytes = V records (6 B per "
-                                "element) read + M (4 B) written + the filter record bank"}
+                        "algorithmic_bytes_per_launch": float(sum(16.0 * ((h + 1) // 2) * ((w + 1) // 2) * ((4 if n in x3 else 6) * ci + 4 * co)
+                                                                  + 16.0 * (4 if n in x3 else 6) * ci * co for n, (ci, co, h, w) in xl_named)) / len(xl),
+                        "note": "FLOP = 6 bf16 (f32x6) or 3 fp16 (f32x3) MFMA products per float32 product x the Winograd GEMM FLOP (16 x tiles x cin x "
+                                "cout x 2), against the dense bf16 / fp16 peak (the same 2500 TFLOP/s); f32_equivalent_tflops = the same launches counted "
+                                "once per float32 product; bytes = V records (6 / 4 B per element) read + M (4 B) written + the filter record bank"}
         # `roofline` = the kernel with the most GPU time per image, the other one rides along
         both = [r for r in (r_direct, r_wino, r_x6) if r is not None]
         both.sort(key=lambda r: -r["ms_per_image"])
@@ -835,23 +857,26 @@ def main():
         pipes = {}
         if not is_resnet:
             ips = value / n_gpus
-            pf = pipe_flops_per_image(args.math, fc_math, x6)
-            pb = pipe_flops_per_image(args.math, fc_math, x6, backbone_only=True)
-            f32_tf, bf16_tf = ips * pf["f32"] / 1e12, ips * pf["bf16"] / 1e12
+            pf = pipe_flops_per_image(args.math, fc_math, x6, x3=x3)
+            pb = pipe_flops_per_image(args.math, fc_math, x6, backbone_only=True, x3=x3)
+            f32_tf, bf16_tf, f16_tf = ips * pf["f32"] / 1e12, ips * pf["bf16"] / 1e12, ips * pf["f16"] / 1e12
             pipes = {
                 "layer_arithmetic": [{"layer": n_, "kernel": k_, "pipe": p_, "executed_gflop": round(e_ / 1e9, 3), "algorithmic_gflop": round(a_ / 1e9, 3)}
-                                     for n_, k_, p_, e_, a_ in layer_arithmetic(args.math, fc_math, x6)],
+                                     for n_, k_, p_, e_, a_ in layer_arithmetic(args.math, fc_math, x6, x3=x3)],
                 "f32_pipe_tflops": round(f32_tf, 2), "f32_pipe_frac": round(f32_tf / PEAK_F32_MFMA_TFLOPS, 4),
                 "bf16_pipe_tflops": round(bf16_tf, 2), "bf16_pipe_frac": round(bf16_tf / PEAK_BF16_MFMA_TFLOPS, 4),
-                "pipe_note": "FLOP each matrix pipe EXECUTES per image x images/sec per GPU, over that pipe's dense peak (157.3 / 2500 TFLOP/s); "
-                             "the two pipes share the SIMDs' MFMA issue, so the fractions add up to the matrix-unit busy fraction the workload needs at peak rate",
+                "f16_pipe_tflops": round(f16_tf, 2), "f16_pipe_frac": round(f16_tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                "pipe_note": "FLOP each kind of matrix instruction EXECUTES per image x images/sec per GPU, over its dense peak (float32 MFMA 157.3, bf16 "
+                             "and fp16 MFMA 2500 TFLOP/s each); they share the SIMDs' MFMA issue, so the fractions add up to the matrix-unit busy "
+                             "fraction the workload needs at peak rate.  bf16 = the f32x6 layers (six MFMAs per float32 product), f16 = the f32x3 layers "
+                             "(three)",
                 # "fraction of conv roofline" = backbone(+RPN trunk) 3x3 conv FLOP x images/sec / MFMA peak, per pipe
-                "conv_roofline_frac": round(ips * pb["f32"] / 1e12 / PEAK_F32_MFMA_TFLOPS + ips * pb["bf16"] / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                "conv_roofline_frac": round(ips * pb["f32"] / 1e12 / PEAK_F32_MFMA_TFLOPS + ips * (pb["bf16"] + pb["f16"]) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                 "conv_roofline_note": "EXECUTED 3x3-conv FLOP (conv1_2 .. conv5_3 + RPN trunk; Winograd layers count 16 x tiles x cin x cout x 2) x images/sec "
                                       "per GPU / the peak of the pipe each layer runs on, summed; direct-form FLOP (3.75e11 per image) would give %.4f of the f32 peak"
                                       % (ips * conv_mfma_flops_per_image() / 1e12 / PEAK_F32_MFMA_TFLOPS),
-                "mfma_tflops_executed_per_gpu": round(f32_tf + bf16_tf, 2),
-                "mfma_tflops_executed_note": "sum over BOTH pipes (kept for continuity with rounds 1-2); read f32_pipe_tflops / bf16_pipe_tflops instead",
+                "mfma_tflops_executed_per_gpu": round(f32_tf + bf16_tf + f16_tf, 2),
+                "mfma_tflops_executed_note": "sum over ALL matrix instruction kinds (kept for continuity with rounds 1-2); read f32_ / bf16_ / f16_pipe_tflops instead",
             }
         out = {
             "metric": "images/sec (600x1000) Faster-RCNN %s inference" % ("VGG-16" if not is_resnet else args.backbone), "value": round(value, 3),
@@ -868,9 +893,10 @@ def main():
             "tflops_per_gpu": round(value / n_gpus * flops_img / 1e12, 2),
             "tflops_per_gpu_note": "direct-convolution FLOP of the workload x images/sec (BASELINE.md's 4.4922e11 per image); "
                                    "in the f32_winograd mode the matrix pipes execute fewer: see f32_pipe_tflops / bf16_pipe_tflops",
-            "math": args.math, "winograd_x6_layers": list(x6), "fc_math": None if is_resnet else fc_math, "roi": model._stage3_detector_network.pooling,
+            "math": args.math, "winograd_x6_layers": list(x6), "winograd_x3_layers": list(x3), "fc_math": None if is_resnet else fc_math, "roi": model._stage3_detector_network.pooling,
             "other_math_modes_images_per_sec": secondary, "fc_math_f32_images_per_sec": fc_f32_value,
             "winograd_all_f32_pipe_images_per_sec": wino_f32_value,
+            **x3_legs,
             "per_rank_images_per_sec": per_rank, "slowest_rank_images_per_sec": min(per_rank),
             **pipes,
             **extra,

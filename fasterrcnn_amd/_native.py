@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
-ABI_VERSION = 7     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
+ABI_VERSION = 8     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
@@ -43,6 +43,9 @@ SYMBOLS = (
     "frcnn_x6t_record_bytes", "frcnn_split_rows_x6t", "frcnn_gemm_x6t_workspace_bytes", "frcnn_gemm_x6t", "frcnn_split_pixels_x6t", "frcnn_split_patches3x3_x6t",
     "frcnn_conv3x3_uses_winograd_x6", "frcnn_conv3x3_winograd_x6_pack_bytes", "frcnn_pack_conv3x3_winograd_x6",
     "frcnn_conv3x3_winograd_x6_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x6",
+    "frcnn_x3t_blob_bytes", "frcnn_pack_rows_x3t", "frcnn_conv3x3_winograd_x3_pack_bytes", "frcnn_pack_conv3x3_winograd_x3",
+    "frcnn_conv3x3_winograd_x3_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x3",
+    "frcnn_x3t_record_bytes", "frcnn_rows_scale_x3t", "frcnn_split_rows_x3t", "frcnn_gemm_x3t_workspace_bytes", "frcnn_gemm_x3t",
     "frcnn_conv3x3_nhwc_winograd_fused_maps", "frcnn_ctx_create_backbone", "frcnn_resnet_backbone", "frcnn_resnet_forward_features",
     # training path
     "frcnn_label_proposals", "frcnn_gather_rows", "frcnn_rpn_loss", "frcnn_detector_loss",
@@ -95,7 +98,7 @@ class ForwardParams(C.Structure):
     _fields_ = [("pre_nms", C.c_int32), ("post_nms", C.c_int32), ("rpn_nms_threshold", C.c_float),
                 ("min_side", C.c_float), ("allow_edge_proposals", C.c_int32), ("math_mode", C.c_int32),
                 ("conv_blocks_target", C.c_int32), ("fc_math_mode", C.c_int32), ("roi_op", C.c_int32), ("roi_sampling_ratio", C.c_int32),
-                ("winograd_tile_rows", C.c_int32), ("winograd_x6_mask", C.c_int32), ("x6_gemm_tiles", C.c_int32)]
+                ("winograd_tile_rows", C.c_int32), ("winograd_x6_mask", C.c_int32), ("x6_gemm_tiles", C.c_int32), ("winograd_x3_mask", C.c_int32)]
 
 
 # capacity limits of the kernels (validated by FasterRCNNModel with a message; the C entry points return FRCNN_EINVAL / EUNSUPPORTED)
@@ -115,7 +118,8 @@ GRAD_MATHS = {"f32": 0, "bf16": 1}         # FRCNN_GRAD_F32 / FRCNN_GRAD_BF16: a
 ROI_OPS = {"pool": 0, "align": 1}          # FRCNN_ROI_POOL (the reference) / FRCNN_ROI_ALIGN (torchvision roi_align semantics)
 # arithmetic of the VGG-16 detector's fc1 / fc2: FRCNN_FC_F32 (exact-f32 pipe) / FRCNN_FC_F32X6T ("f32x6": exactly split bf16x3 operands on
 # csrc/gemm_x6t.hip, round 3) / FRCNN_FC_F32X6 ("f32x6_v1": the same arithmetic on round 2's csrc/linear_x6.hip, <= 320 RoIs; kept for A/B)
-FC_MATH_MODES = {"f32": 0, "f32x6": 2, "f32x6_v1": 1}
+# "f32x3": two fp16 terms per row-scaled operand, three MFMAs per product (csrc/gemm_x3t.hip, FRCNN_FC_F32X3T)
+FC_MATH_MODES = {"f32": 0, "f32x6": 2, "f32x6_v1": 1, "f32x3": 3}
 
 
 def uses_winograd(cin, cout):
@@ -130,6 +134,13 @@ X6_LAYER_BITS = {"conv1_2": 1, "conv2_1": 2, "conv2_2": 3, "conv3_1": 4, "conv3_
 
 
 DEFAULT_X6_LAYERS_VGG16 = ("conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3", "rpn_trunk")
+# the subset whose GEMMs run in the f32x3 arithmetic by default: the largest one that keeps EVERY exact gate of the GPU tests (all golden
+# proposals and detections of the three VGG-16 fixtures, 70 / 70 detections of the predict_one fixture): tools/x3_gate_sweep.py.  Each of
+# those fixtures holds a few near-tied RPN candidates that cross the NMS cut under ANY change of summation order -- conv4_2 / conv4_3 /
+# conv5_2 alone in f32x3 move one or two of 300 proposals of the 600x1000 fixture, conv4_1 one detection of predict_one -- so the table is
+# a choice among equally accurate arithmetics; the whole x6 table in f32x3 (winograd_x3_layers = winograd_x6_layers) is faster and
+# tested at its observed numbers (299 / 300 proposals, 193 / 194 detections: tests/test_gemm_x3t_gpu.py)
+DEFAULT_X3_LAYERS_VGG16 = ("conv5_1", "conv5_2", "conv5_3", "rpn_trunk")
 
 
 def uses_winograd_x6(cin, cout):
@@ -229,6 +240,17 @@ _SIGNATURES = {
     "frcnn_resnet_forward_features": (C.c_int, [_vp, C.POINTER(ResNetWeights), C.POINTER(ForwardParams), _vp, _i, _i,
                                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "frcnn_resnet_backbone": (C.c_int, [_vp, C.POINTER(ResNetWeights), C.POINTER(ForwardParams), _vp, _i, _i, _i, _vp, _vp]),
+    "frcnn_x3t_blob_bytes": (C.c_size_t, [_i, _i, _i]),
+    "frcnn_pack_rows_x3t": (C.c_int, [_vp, _i, _sz, _vp, _i, _i, _i, _i, _vp]),
+    "frcnn_conv3x3_winograd_x3_pack_bytes": (C.c_size_t, [_i, _i]),
+    "frcnn_pack_conv3x3_winograd_x3": (C.c_int, [_vp, _vp, _i, _i, _vp]),
+    "frcnn_conv3x3_winograd_x3_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "frcnn_conv3x3_nhwc_winograd_x3": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_x3t_record_bytes": (C.c_size_t, [_i, _i]),
+    "frcnn_rows_scale_x3t": (C.c_int, [_vp, _i, _sz, _vp, _i, _i, _i, _i, _vp]),
+    "frcnn_split_rows_x3t": (C.c_int, [_vp, _i, _sz, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "frcnn_gemm_x3t_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "frcnn_gemm_x3t": (C.c_int, [_vp, _vp, _i, _sz, _sz, _vp, _vp, _i, _sz, _sz, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_ctx_create_backbone": (C.c_int, [C.POINTER(C.c_void_p), _i, _i, _i]),
     "frcnn_conv3x3_nhwc_winograd_fused_maps": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp]),
     "frcnn_label_proposals": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -38,6 +38,7 @@ struct frcnn_ctx {
     float *fc1_out = nullptr, *fc2_out = nullptr;  // [max_rois][4096]
     void *roi_rec = nullptr, *fc1_rec = nullptr;   // x6 / x6t records of roi_out ([rec_rows][25088]) and fc1_out (FRCNN_FC_F32X6 / _F32X6T):
     int rec_rows = 0;                              // one allocation, made by the first forward that runs fc1 / fc2 in an x6 mode
+    float *roi_inv = nullptr, *fc1_inv = nullptr, *fm_cmax = nullptr;   // FRCNN_FC_F32X3T: row scales of the two record arrays, channel maximum of the feature map
     float *head_logits = nullptr;                  // [max_rois][128]
     void* lin_ws = nullptr; size_t lin_ws_bytes = 0;
     void* conv_ws = nullptr; size_t conv_ws_bytes = 0;   // split-K partials of under-filled conv layers
@@ -296,6 +297,69 @@ int frcnn_gemm_x6t(const void* d_a_rec, int a_rows, size_t a_batch_bytes, const 
     if (!d_a_rec || !d_b_rec || !d_c) return FRCNN_EINVAL;
     return launch_gemm_x6t(d_a_rec, a_rows, a_batch_bytes, d_b_rec, b_rows, b_batch_bytes, d_bias, d_residual, d_c, ldc, c_batch_floats,
                            M, N, K, batches, flags, d_ws, ws_bytes, as_stream(stream));
+}
+
+size_t frcnn_x3t_record_bytes(int rows_padded, int K)
+{
+    return rows_padded > 0 && rows_padded % 32 == 0 && K >= 16 && K % 16 == 0 ? x3t_record_bytes(rows_padded, K) : 0;
+}
+
+int frcnn_rows_scale_x3t(const float* d_a, int lda, size_t a_batch_floats, float* d_inv_scale, int rows, int rows_padded, int K, int batches,
+                         void* stream)
+{
+    if (!d_a || !d_inv_scale) return FRCNN_EINVAL;
+    return launch_rows_scale_x3t(d_a, lda, a_batch_floats, d_inv_scale, rows, rows_padded, K, batches, as_stream(stream));
+}
+
+int frcnn_split_rows_x3t(const float* d_a, int lda, size_t a_batch_floats, const float* d_inv_scale, void* d_rec, int rows, int rows_padded,
+                         int K, int batches, void* stream)
+{
+    if (!d_a || !d_rec || !d_inv_scale) return FRCNN_EINVAL;
+    return launch_split_rows_x3t(d_a, lda, a_batch_floats, d_inv_scale, d_rec, rows, rows_padded, K, batches, as_stream(stream));
+}
+
+size_t frcnn_gemm_x3t_workspace_bytes(int M, int N, int K, int batches) { return gemm_x3t_workspace_bytes(M, N, K, batches); }
+
+int frcnn_gemm_x3t(const void* d_a_rec, const float* d_a_inv, int a_rows, size_t a_batch_bytes, size_t a_inv_batch_floats,
+                   const void* d_b_rec, const float* d_b_inv, int b_rows, size_t b_batch_bytes, size_t b_inv_batch_floats,
+                   const float* d_bias, const float* d_residual, float* d_c, int ldc, size_t c_batch_floats, int M, int N, int K,
+                   int batches, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
+{
+    return launch_gemm_x3t(d_a_rec, d_a_inv, a_rows, a_batch_bytes, a_inv_batch_floats, d_b_rec, d_b_inv, b_rows, b_batch_bytes,
+                           b_inv_batch_floats, d_bias, d_residual, d_c, ldc, c_batch_floats, M, N, K, batches, flags, d_ws, ws_bytes,
+                           as_stream(stream));
+}
+
+size_t frcnn_x3t_blob_bytes(int rows_padded, int K, int batches)
+{
+    return rows_padded > 0 && rows_padded % 32 == 0 && K >= 16 && K % 16 == 0 && batches >= 1 ? x3t_blob_bytes(rows_padded, K, batches) : 0;
+}
+
+int frcnn_pack_rows_x3t(const float* d_a, int lda, size_t a_batch_floats, void* d_blob, int rows, int rows_padded, int K, int batches,
+                        void* stream)
+{
+    if (!d_a || !d_blob) return FRCNN_EINVAL;
+    return launch_pack_rows_x3t(d_a, lda, a_batch_floats, d_blob, rows, rows_padded, K, batches, as_stream(stream));
+}
+
+size_t frcnn_conv3x3_winograd_x3_pack_bytes(int cout, int cin) { return conv3x3_winograd_x3_pack_bytes(cout, cin); }
+
+int frcnn_pack_conv3x3_winograd_x3(const float* d_u_f32, void* d_blob, int cout, int cin, void* stream)
+{
+    if (!d_u_f32 || !d_blob) return FRCNN_EINVAL;
+    return launch_pack_conv3x3_winograd_x3(d_u_f32, d_blob, cout, cin, as_stream(stream));
+}
+
+size_t frcnn_conv3x3_winograd_x3_workspace_bytes(int n_maps, int H, int W, int cin, int cout)
+{
+    return conv3x3_winograd_x3_workspace_bytes(n_maps, H, W, cin, cout);
+}
+
+int frcnn_conv3x3_nhwc_winograd_x3(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W, int cin,
+                                   int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_x || !d_blob || !d_bias || !d_y) return FRCNN_EINVAL;
+    return launch_conv3x3_winograd_x3(d_x, d_blob, d_bias, d_y, n_maps, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
 }
 
 int frcnn_split_pixels_x6t(const float* d_x, void* d_rec, int N, int H, int W, int C, int stride, int rows_padded, void* stream)
@@ -660,6 +724,9 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         const size_t t1 = gemm_x6t_workspace_bytes(max_rois, 4096, 512 * 49, 1), t2 = gemm_x6t_workspace_bytes(max_rois, 4096, 4096, 1);
         if (t1 > lin) lin = t1;
         if (t2 > lin) lin = t2;
+        const size_t h1 = gemm_x3t_workspace_bytes(max_rois, 4096, 512 * 49, 1), h2 = gemm_x3t_workspace_bytes(max_rois, 4096, 4096, 1);
+        if (h1 > lin) lin = h1;
+        if (h2 > lin) lin = h2;
     }
     // row count of the activation record arrays: the x6t GEMM's 320-row tiles over max_rois (>= the 320 rows of the round-2 kernel)
     const int rec_rows = cdiv(max_rois, gemm_x6t_row_tile(max_rois)) * gemm_x6t_row_tile(max_rois);
@@ -876,14 +943,19 @@ int ensure_wx_ws(frcnn_ctx* c, size_t layer_need, hipStream_t s)
 int ensure_fc_records(frcnn_ctx* c)
 {
     if (c->roi_rec) return FRCNN_OK;
+    // (sized for the x6 / x6t records, 6 bytes per value; the x3t records of FRCNN_FC_F32X3T need 4)
     const size_t b1 = (size_t)c->rec_rows * 49 * 512 * 6, b2 = (size_t)c->rec_rows * 4096 * 6;
+    const size_t b3 = align_up((size_t)c->rec_rows * sizeof(float), 256), b4 = align_up((size_t)c->max_fh * c->max_fw * sizeof(float), 256);
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, b1 + b2);
+    hipError_t e = hipMalloc(&p, b1 + b2 + 2 * b3 + b4);
     if (e != hipSuccess) { set_hip_error(e); return FRCNN_ENOMEM; }
-    e = hipMemset(p, 0, b1 + b2);
+    e = hipMemset(p, 0, b1 + b2 + 2 * b3 + b4);
     if (e != hipSuccess) { set_hip_error(e); (void)hipFree(p); return FRCNN_EHIP; }
     c->roi_rec = p;
     c->fc1_rec = static_cast<unsigned char*>(p) + b1;
+    c->roi_inv = reinterpret_cast<float*>(static_cast<unsigned char*>(p) + b1 + b2);
+    c->fc1_inv = reinterpret_cast<float*>(static_cast<unsigned char*>(p) + b1 + b2 + b3);
+    c->fm_cmax = reinterpret_cast<float*>(static_cast<unsigned char*>(p) + b1 + b2 + 2 * b3);
     return FRCNN_OK;
 }
 
@@ -902,6 +974,27 @@ int run_wino_x6_layer(frcnn_ctx* c, const float* x, const void* urec, const floa
     { Scope _t(c, 8, s); r = launch_winograd_x6_input(x, V, N, h, w, ci, s); }
     if (r) return r;
     { Scope _g(c, 9, s); r = launch_winograd_x6_gemm(V, urec, M, N, h, w, ci, co, G, gb, s); }
+    if (r) return r;
+    Scope _o(c, 8, s);
+    return launch_winograd_output(M, b, y, N, h, w, co, flags, s);
+}
+
+// The same layer in the f32x3 arithmetic (csrc/wino_x3.hip; a bit of frcnn_forward_params.winograd_x3_mask): ublob = the packed
+// x3t filter bank (records + row scales).  Same timing classes.
+int run_wino_x3_layer(frcnn_ctx* c, const float* x, const void* ublob, const float* b, float* y, int h, int w, int ci, int co,
+                      unsigned flags, hipStream_t s, int N = 1)
+{
+    if (N == 1 && !conv3x3_uses_winograd_x6(ci, co)) return FRCNN_EINVAL;
+    int r = ensure_wx_ws(c, conv3x3_winograd_x3_workspace_bytes(N, h, w, ci, co), s);
+    if (r) return r;
+    void *V = nullptr, *G = nullptr;
+    float *M = nullptr, *vinv = nullptr, *cmax = nullptr;
+    size_t gb = 0;
+    r = winograd_x3_plan(N, h, w, ci, co, flags, c->wx_ws, c->wx_ws_bytes, &V, &vinv, &cmax, &M, &G, &gb);
+    if (r) return r;
+    { Scope _t(c, 8, s); r = launch_winograd_x3_input(x, cmax, V, vinv, N, h, w, ci, s); }
+    if (r) return r;
+    { Scope _g(c, 9, s); r = launch_winograd_x3_gemm(V, vinv, ublob, M, N, h, w, ci, co, G, gb, s); }
     if (r) return r;
     Scope _o(c, 8, s);
     return launch_winograd_output(M, b, y, N, h, w, co, flags, s);
@@ -944,10 +1037,13 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32X6 && p->math_mode != FRCNN_MATH_F32_WINOGRAD)
         return FRCNN_EINVAL;
     if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
-    if (p->fc_math_mode != FRCNN_FC_F32 && p->fc_math_mode != FRCNN_FC_F32X6 && p->fc_math_mode != FRCNN_FC_F32X6T) return FRCNN_EINVAL;
+    if (p->fc_math_mode != FRCNN_FC_F32 && p->fc_math_mode != FRCNN_FC_F32X6 && p->fc_math_mode != FRCNN_FC_F32X6T &&
+        p->fc_math_mode != FRCNN_FC_F32X3T)
+        return FRCNN_EINVAL;
     if ((p->roi_op != FRCNN_ROI_POOL && p->roi_op != FRCNN_ROI_ALIGN) || p->roi_sampling_ratio > 2) return FRCNN_EINVAL;
     if (p->winograd_tile_rows != 0 && p->winograd_tile_rows != 64 && p->winograd_tile_rows != 128) return FRCNN_EINVAL;
     if (p->x6_gemm_tiles < 0 || p->x6_gemm_tiles > 2) return FRCNN_EINVAL;
+    if ((p->winograd_x3_mask & ~p->winograd_x6_mask) != 0) return FRCNN_EINVAL;     // a subset of the x6 table
     BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows, p->x6_gemm_tiles);
     const bool x6 = p->math_mode == FRCNN_MATH_F32X6;
     const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
@@ -956,8 +1052,9 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
         ++layer_index;
-        if (wino && ((p->winograd_x6_mask >> layer_index) & 1))  // x6 Winograd layer: wgt = the record bank (csrc/wino_x6.hip)
-            return run_wino_x6_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
+        if (wino && ((p->winograd_x6_mask >> layer_index) & 1))  // x6 / x3 Winograd layer: wgt = the record bank (csrc/wino_x6.hip, wino_x3.hip)
+            return ((p->winograd_x3_mask >> layer_index) & 1) ? run_wino_x3_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s)
+                                                              : run_wino_x6_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
         if (wino && conv3x3_uses_winograd_fused(ci, co)) {     // one launch, no scratch (csrc/winofused.hip); timed as class 7
             return run_wino_fused_layer(c, p->conv_blocks_target == 0, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
         }
@@ -1010,7 +1107,31 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     const bool fc_x6 = p->fc_math_mode == FRCNN_FC_F32X6;
     const bool fc_x6t = p->fc_math_mode == FRCNN_FC_F32X6T;
     if (fc_x6 && R_ > FRCNN_LINEAR_X6_ROWS) return FRCNN_EUNSUPPORTED;
-    if (fc_x6 || fc_x6t) { rc = ensure_fc_records(c); if (rc) return rc; }
+    const bool fc_x3t = p->fc_math_mode == FRCNN_FC_F32X3T;
+    if (fc_x6 || fc_x6t || fc_x3t) { rc = ensure_fc_records(c); if (rc) return rc; }
+    if (fc_x3t) {
+        // fc1 / fc2 in the f32x3 arithmetic (csrc/gemm_x3t.hip): fc1_w / fc2_w = packed x3t operands (records of the 4096-row matrices, then
+        // their row scales); RoIPool writes fc1's A records with one scale per RoI; fc1's float32 output is scaled and split again for fc2
+        const int rr = c->rec_rows;
+        const size_t w1rec = x3t_record_bytes(4096, 49 * 512), w2rec = x3t_record_bytes(4096, 4096);
+        const float* w1inv = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(w->fc1_w) + w1rec);
+        const float* w2inv = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(w->fc2_w) + w2rec);
+        if (p->roi_op == FRCNN_ROI_ALIGN) {
+            STEP(4, launch_roi_align(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, p->roi_sampling_ratio, 0, c->roi_out, s));
+            STEP(2, launch_rows_scale_x3t(c->roi_out, 49 * 512, 0, c->roi_inv, R_, rr, 49 * 512, 1, s));
+            STEP(2, launch_split_rows_x3t(c->roi_out, 49 * 512, 0, c->roi_inv, c->roi_rec, R_, rr, 49 * 512, 1, s));
+        } else {
+            STEP(4, launch_roi_pool_x3t(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->fm_cmax, c->roi_inv, c->roi_rec, rr, s));
+        }
+        // (tile mode 0 = the cost model's choice in every slot: the in-flight tile override of the Winograd layers would change fc's split-K
+        //  factor, and an image must give the same bits in flight and alone)
+        STEP(2, launch_gemm_x3t(c->roi_rec, c->roi_inv, rr, 0, 0, w->fc1_w, w1inv, 4096, 0, 0, w->fc1_b, nullptr, c->fc1_out, 4096, 0, R_, 4096,
+                                49 * 512, 1, R, c->lin_ws, c->lin_ws_bytes, s, 0));
+        STEP(2, launch_rows_scale_x3t(c->fc1_out, 4096, 0, c->fc1_inv, R_, rr, 4096, 1, s));
+        STEP(2, launch_split_rows_x3t(c->fc1_out, 4096, 0, c->fc1_inv, c->fc1_rec, R_, rr, 4096, 1, s));
+        STEP(2, launch_gemm_x3t(c->fc1_rec, c->fc1_inv, rr, 0, 0, w->fc2_w, w2inv, 4096, 0, 0, w->fc2_b, nullptr, c->fc2_out, 4096, 0, R_, 4096,
+                                4096, 1, R, c->lin_ws, c->lin_ws_bytes, s, 0));
+    } else
     if (fc_x6t) {
         // fc1 / fc2 as f32x6 GEMMs on tile records (csrc/gemm_x6t.hip): RoIPool writes fc1's operand records itself (the rows R_ ..
         // rec_rows - 1 were zeroed when the ctx was created); fc1's float32 output is split again for fc2 (5 MB: a 3 us launch)
@@ -1037,7 +1158,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     } else {
         STEP(4, launch_roi_pool(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
     }
-    if (fc_x6t) {
+    if (fc_x6t || fc_x3t) {
     } else if (fc_x6) {
         // fc1 / fc2 on the bf16 pipe with exactly split operands: fc1's reduction emits the records fc2 consumes, fc2's the float32
         // rows the (exact-f32) heads consume
@@ -1193,6 +1314,7 @@ int resnet_check_weights(const frcnn_resnet_weights* w, bool with_heads)
 
 int resnet_check_params(const frcnn_forward_params* p)
 {
+    if (p->winograd_x3_mask != 0) return FRCNN_EUNSUPPORTED;                       // the ResNet x6 layers have no f32x3 form yet
     if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32_WINOGRAD) return FRCNN_EUNSUPPORTED;   // no f32x6 ResNet path
     if ((p->roi_op != FRCNN_ROI_POOL && p->roi_op != FRCNN_ROI_ALIGN) || p->roi_sampling_ratio > 2) return FRCNN_EINVAL;
     if (p->conv_blocks_target < 0) return FRCNN_EINVAL;

@@ -151,6 +151,36 @@ int launch_gemm_x6t(const void* a_rec, int a_rows, size_t a_batch_bytes, const v
                     const float* bias, const float* residual, float* c, int ldc, size_t c_batch_floats, int M, int N, int K, int batches,
                     unsigned flags, void* ws, size_t ws_bytes, hipStream_t s, int tiles_mode = -1);
 int launch_split_pixels_x6t(const float* x, void* rec, int N, int H, int W, int C, int stride, int rows_padded, hipStream_t s);
+int gemm_x6t_get_tiles();
+int launch_gemm_x6t_reduce(const float* ws, const float* bias, const float* residual, float* c, int ldc, size_t c_batch_floats, int M, int N,
+                           int batches, int splits, int relu, hipStream_t s);
+// gemm_x3t.hip: the same GEMM in the f32x3 arithmetic (two fp16 terms per row-scaled operand, three fp16 MFMAs per product)
+size_t x3t_record_bytes(int rows_padded, int K);
+int launch_rows_scale_x3t(const float* a, int lda, size_t a_batch_floats, float* inv_scale, int R, int rows_padded, int K, int batches,
+                          hipStream_t s);
+int launch_split_rows_x3t(const float* a, int lda, size_t a_batch_floats, const float* inv_scale, void* rec, int R, int rows_padded, int K,
+                          int batches, hipStream_t s);
+size_t gemm_x3t_workspace_bytes(int M, int N, int K, int batches);
+int launch_gemm_x3t(const void* a_rec, const float* a_inv, int a_rows, size_t a_batch_bytes, size_t a_inv_batch, const void* b_rec,
+                    const float* b_inv, int b_rows, size_t b_batch_bytes, size_t b_inv_batch, const float* bias, const float* residual,
+                    float* c, int ldc, size_t c_batch_floats, int M, int N, int K, int batches, unsigned flags, void* ws, size_t ws_bytes,
+                    hipStream_t s, int tiles_mode = -1);
+// wino_x3.hip: the Winograd layer on gemm_x3t; packed x3t operands (records + row scales in one blob)
+size_t x3t_blob_bytes(int rows_padded, int K, int batches);
+int launch_pack_rows_x3t(const float* a, int lda, size_t a_batch_floats, void* blob, int R, int rows_padded, int K, int batches, hipStream_t s);
+int launch_pixel_absmax(const float* x, float* cmax, long long pixels, int C, hipStream_t s);
+size_t conv3x3_winograd_x3_pack_bytes(int cout, int cin);
+int launch_pack_conv3x3_winograd_x3(const float* u_f32, void* ublob, int cout, int cin, hipStream_t s);
+size_t conv3x3_winograd_x3_workspace_bytes(int N, int H, int W, int cin, int cout);
+int winograd_x3_plan(int N, int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, void** V, float** vinv, float** cmax,
+                     float** M, void** G, size_t* g_bytes);
+int launch_winograd_x3_input(const float* x, float* cmax, void* vrec, float* vinv, int N, int H, int W, int cin, hipStream_t s);
+int launch_winograd_x3_gemm(const void* vrec, const float* vinv, const void* ublob, float* M, int N, int H, int W, int cin, int cout, void* gws,
+                            size_t gws_bytes, hipStream_t s);
+int launch_conv3x3_winograd_x3(const float* x, const void* ublob, const float* b, float* y, int N, int H, int W, int cin, int cout,
+                               unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_roi_pool_x3t(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois, int max_rois, int pooled,
+                        float scale, float* cmax, float* inv, void* rec, int rec_rows, hipStream_t s);
 // wino_x6.hip: Winograd F(2x2,3x3) layers whose position GEMMs run on gemm_x6t
 bool conv3x3_uses_winograd_x6(int cin, int cout);
 size_t conv3x3_winograd_x6_pack_bytes(int cout, int cin);

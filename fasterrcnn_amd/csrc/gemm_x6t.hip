@@ -458,6 +458,7 @@ int launch_split_patches3x3_x6t(const float* x, void* rec, int N, int H, int W, 
 struct GxPlan { int cfg, mtiles, ntiles, splits, chunks_per_split; };
 static thread_local int g_gx_tiles = 0;
 void gemm_x6t_set_tiles(int mode) { g_gx_tiles = mode; }
+int gemm_x6t_get_tiles() { return g_gx_tiles; }
 
 static GxPlan plan_gemm_x6t(int M, int N, int K, int batches, int tiles_mode = -1)
 {
@@ -552,11 +553,17 @@ int launch_gemm_x6t(const void* a_rec, int a_rows, size_t a_batch_bytes, const v
     }
     int rc = check_launch();
     if (rc || pl.splits == 1) return rc;
+    return launch_gemm_x6t_reduce(static_cast<const float*>(ws), bias, residual, c, ldc, c_batch_floats, M, N, batches, pl.splits, p.relu, s);
+}
+
+int launch_gemm_x6t_reduce(const float* ws, const float* bias, const float* residual, float* c, int ldc, size_t c_batch_floats, int M, int N,
+                           int batches, int splits, int relu, hipStream_t s)
+{
     const size_t n4 = (size_t)batches * M * (N / 4);
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gemm_x6t_reduce_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(ws), bias, residual, c,
-                       ldc, c_batch_floats, M, N, batches, pl.splits, p.relu);
+    hipLaunchKernelGGL(gemm_x6t_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, bias, residual, c, ldc, c_batch_floats, M, N, batches,
+                       splits, relu);
     return check_launch();
 }
 

@@ -12,7 +12,7 @@
 //
 // anchors_kernel replaces models/anchors.py:43-135 bit-exactly: float64 arithmetic on a
 // float32-rounded cell centre, one final cast to float32.
-#include "common.h"
+#include "x3t.h"
 #include <cfloat>
 #include <cmath>
 
@@ -179,6 +179,97 @@ void roi_pool_x6t_kernel(const float* __restrict__ fm, int fh, int fw, int C, co
     *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
 }
 
+// ---- f32x3 form (csrc/gemm_x3t.hip): the record array of the pooled matrix in two fp16 terms per value, rows scaled per RoI ----------
+// inv[r] = 2^-e of RoI r: every pooled value of the RoI is a maximum over cells of its window, so max over the window of the per-cell
+// channel maximum `cmax` (launch_pixel_absmax of the feature map) bounds the row.  One wave per RoI.
+__global__ __launch_bounds__(256)
+void roi_scale_x3t_kernel(const float* __restrict__ cmax, int fh, int fw, const float* __restrict__ rois, const int32_t* __restrict__ n_rois,
+                          int max_rois, int rec_rows, float scale, float* __restrict__ inv)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rec_rows) return;
+    int n = *n_rois;
+    if (n > max_rois) n = max_rois;
+    float mx = 0.f;
+    if (r < n) {
+        const f32x4 roi = reinterpret_cast<const f32x4*>(rois)[r];
+        const int rs_h = (int)roundf(roi[0] * scale), rs_w = (int)roundf(roi[1] * scale);
+        const int re_h = (int)roundf(roi[2] * scale), re_w = (int)roundf(roi[3] * scale);
+        const int roi_h = max(re_h - rs_h + 1, 1), roi_w = max(re_w - rs_w + 1, 1);
+        // the union of the bins: [rs, rs + roi) clipped to the map (the bins' floor / ceil edges never leave it)
+        const int hs = min(max(rs_h, 0), fh), he = min(max(rs_h + roi_h, 0), fh);
+        const int ws = min(max(rs_w, 0), fw), we = min(max(rs_w + roi_w, 0), fw);
+        const int ww = we - ws, cells = (he - hs) * ww;
+        for (int i = lane; i < cells; i += 64) {
+            const int h = hs + i / ww, w = ws + i % ww;
+            mx = fmaxf(mx, cmax[(size_t)h * fw + w]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float mult, iv;
+    hx_row_scale(mx, mult, iv);
+    if (lane == 0) inv[r] = iv;
+}
+
+// roi_pool_x6t_kernel's work split (lane = RoI, wave = (bin, 32 RoIs, 16-channel chunk)); values scaled by 1 / inv[roi], two pieces.
+__global__ __launch_bounds__(256)
+void roi_pool_x3t_kernel(const float* __restrict__ fm, int fh, int fw, int C, const float* __restrict__ rois,
+                         const int32_t* __restrict__ n_rois, int max_rois, int pooled, float scale, const float* __restrict__ inv,
+                         unsigned char* __restrict__ rec, int rbt)
+{
+    const int lane = threadIdx.x & 63;
+    const int K16c = C >> 4;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long total = (long long)pooled * pooled * rbt * K16c;
+    if (wave >= total) return;
+    const int cc = (int)(wave % K16c);
+    long long t = wave / K16c;
+    const int rb = (int)(t % rbt);
+    const int bin = (int)(t / rbt);
+    const int ph = bin / pooled, pw = bin - ph * pooled;
+    const int r = rb * 32 + (lane & 31);
+    const int c0 = cc * 16 + 8 * (lane >> 5);
+    float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int n = *n_rois;
+    if (n > max_rois) n = max_rois;
+    if (r < n) {
+        const f32x4 roi = reinterpret_cast<const f32x4*>(rois)[r];     // y1, x1, y2, x2
+        const int rs_h = (int)roundf(roi[0] * scale), rs_w = (int)roundf(roi[1] * scale);
+        const int re_h = (int)roundf(roi[2] * scale), re_w = (int)roundf(roi[3] * scale);
+        const int roi_h = max(re_h - rs_h + 1, 1), roi_w = max(re_w - rs_w + 1, 1);
+        const float bin_h = (float)roi_h / (float)pooled, bin_w = (float)roi_w / (float)pooled;
+        int hs = (int)floorf((float)ph * bin_h) + rs_h;
+        int he = (int)ceilf((float)(ph + 1) * bin_h) + rs_h;
+        hs = min(max(hs, 0), fh); he = min(max(he, 0), fh);
+        int ws = (int)floorf((float)pw * bin_w) + rs_w;
+        int we = (int)ceilf((float)(pw + 1) * bin_w) + rs_w;
+        ws = min(max(ws, 0), fw); we = min(max(we, 0), fw);
+        if (he > hs && we > ws) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = -FLT_MAX;
+            for (int h = hs; h < he; ++h) {
+                const float* p = fm + ((size_t)h * fw + ws) * C + c0;
+                for (int w = ws; w < we; ++w, p += C) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { m[e] = v0[e] > m[e] ? v0[e] : m[e]; m[4 + e] = v1[e] > m[4 + e] ? v1[e] : m[4 + e]; }
+                }
+            }
+        }
+        const float mult = hx_mult_of_inv(inv[r]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] *= mult;
+    }
+    uint4 phh, pll;
+    hx_split8(m, phh, pll);
+    const int chunk = bin * K16c + cc;                                  // k = (ph * pooled + pw) * C + c
+    unsigned char* dst = rec + ((size_t)chunk * rbt + rb) * HX_RB + lane * 16;
+    *reinterpret_cast<uint4*>(dst) = phh;
+    *reinterpret_cast<uint4*>(dst + HX_PIECE) = pll;
+}
+
 struct AnchorSizes { double h[9]; double w[9]; };
 
 __global__ __launch_bounds__(256)
@@ -240,6 +331,23 @@ int launch_roi_pool_x6t(const float* fm, int fh, int fw, int c, const float* roi
     const long long waves = (long long)pooled * pooled * rbt * (c / 16);
     hipLaunchKernelGGL(roi_pool_x6t_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, fm, fh, fw, c, rois, n_rois, max_rois,
                        pooled, scale, static_cast<unsigned char*>(rec), rbt);
+    return check_launch();
+}
+
+// RoI pooling into x3t records + the per-RoI scales (csrc/gemm_x3t.hip).  cmax: fh * fw floats of scratch; inv: rec_rows floats.
+int launch_roi_pool_x3t(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois, int max_rois, int pooled,
+                        float scale, float* cmax, float* inv, void* rec, int rec_rows, hipStream_t s)
+{
+    if (fh < 1 || fw < 1 || c < 16 || c % 16 != 0 || max_rois < 1 || pooled < 1 || rec_rows < max_rois || rec_rows % 32 != 0 || !cmax || !inv)
+        return FRCNN_EINVAL;
+    int rc = launch_pixel_absmax(fm, cmax, (long long)fh * fw, c, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(roi_scale_x3t_kernel, dim3(cdiv(rec_rows, 4)), dim3(256), 0, s, cmax, fh, fw, rois, n_rois, max_rois, rec_rows, scale, inv);
+    if ((rc = check_launch()) != FRCNN_OK) return rc;
+    const int rbt = rec_rows / 32;
+    const long long waves = (long long)pooled * pooled * rbt * (c / 16);
+    hipLaunchKernelGGL(roi_pool_x3t_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, fm, fh, fw, c, rois, n_rois, max_rois,
+                       pooled, scale, inv, static_cast<unsigned char*>(rec), rbt);
     return check_launch();
 }
 

@@ -139,7 +139,12 @@ class FasterRCNNModel(nn.Module):
         # bf16x3 operands, six bf16 MFMAs per product, f32 accumulation (csrc/linear_x6.hip) -- fp32-class accuracy (dropped terms
         # <= 2^-24 relative) at 2.67x the matrix-pipe rate; the default wherever it applies (ResNet heads have no fc1 / fc2)
         self._fc_math_mode = "f32"
-        self.fc_math_mode = "f32" if self._is_resnet else "f32x6"
+        self.fc_math_mode = "f32" if self._is_resnet else "f32x3"
+        # the subset of winograd_x6_layers (VGG-16) whose position GEMMs run in the f32x3 arithmetic: two fp16 terms per row-scaled
+        # operand, three MFMAs per product (csrc/wino_x3.hip) -- half the matrix instructions of f32x6, operands held to 22-23 bits
+        # relative to their row's largest element; error against float64 within the exact-f32 kernel's (tests/test_gemm_x3t_gpu.py)
+        self._winograd_x3_layers = ()
+        self.winograd_x3_layers = () if self._is_resnet else nv.DEFAULT_X3_LAYERS_VGG16
 
         # hipGraph replay of one image's ~33 launches (forward + detections + the D2H copies): the second consecutive call of a slot with
         # the same (shape, thresholds, weights, modes) captures them into a graph on the slot's stream, later calls copy the image
@@ -214,6 +219,7 @@ class FasterRCNNModel(nn.Module):
         if not self._is_resnet:
             self._stage1_feature_extractor.x6_layers = tuple(n for n in names if n != "rpn_trunk")
         self._stage2_region_proposal_network.x6_trunk = "rpn_trunk" in names
+        self._apply_x3()
 
     def _x6_mask(self):
         if self._math_mode != "f32_winograd":
@@ -232,6 +238,42 @@ class FasterRCNNModel(nn.Module):
         if mode not in nv.GRAD_MATHS:
             raise ValueError("grad_math must be one of %s" % sorted(nv.GRAD_MATHS))
         self._grad_math = mode
+
+    @property
+    def winograd_x3_layers(self):
+        return self._winograd_x3_layers
+
+    @winograd_x3_layers.setter
+    def winograd_x3_layers(self, names):
+        """The layers of the x6 table whose GEMMs run in the f32x3 arithmetic; a name that is not (or no longer) in winograd_x6_layers has
+        no effect until it is (the table of a layer is: float32 one-launch Winograd | f32x6 | f32x3)."""
+        names = tuple(names)
+        if names and self._is_resnet:
+            raise NotImplementedError("the ResNet x6 layers have no f32x3 form")
+        allowed = tuple(n for n in nv.X6_LAYER_BITS if n.startswith(("conv4", "conv5", "conv3_2", "conv3_3", "rpn")))
+        for n in names:
+            if n not in allowed:
+                raise ValueError("winograd_x3_layers: %r cannot run as an x6 / x3 Winograd layer (choices: %s)" % (n, ", ".join(allowed)))
+        self._winograd_x3_layers = names
+        self._apply_x3()
+
+    def _effective_x3_layers(self):
+        return tuple(n for n in self._winograd_x3_layers if n in self._winograd_x6_layers)
+
+    def _apply_x3(self):
+        if self._is_resnet:
+            return
+        eff = self._effective_x3_layers() if hasattr(self, "_winograd_x3_layers") else ()
+        self._stage1_feature_extractor.x3_layers = tuple(n for n in eff if n != "rpn_trunk")
+        self._stage2_region_proposal_network.x3_trunk = "rpn_trunk" in eff
+
+    def _x3_mask(self):
+        if self._math_mode != "f32_winograd":
+            return 0
+        mask = 0
+        for n in self._effective_x3_layers():
+            mask |= 1 << nv.X6_LAYER_BITS[n]
+        return mask
 
     @property
     def fc_math_mode(self):
@@ -375,7 +417,8 @@ class FasterRCNNModel(nn.Module):
                                 0 if slot_index == 0 else self.inflight_winograd_tile_rows, self._x6_mask(),
                                 # (ResNet: the cost model's choice in every slot, so that an image gives the same bits in flight
                                 #  and alone: its 1x1 GEMMs switch between split-K and unsplit tiles with the tile mode)
-                                0 if (slot_index == 0 or self._is_resnet) else self.inflight_x6_gemm_tiles)
+                                0 if (slot_index == 0 or self._is_resnet) else self.inflight_x6_gemm_tiles,
+                                self._x3_mask())
 
     def _enqueue_outputs(self, slot, h, w, score_threshold, sp):
         """decode + per-class NMS (faster_rcnn.py:179-224) and the D2H copies of one image, behind its forward on stream `sp`."""

@@ -69,10 +69,13 @@ class RegionProposalNetwork(nn.Module):
         self._packed = None
         self.math_mode = "f32"
         self.x6_trunk = False        # the 3x3 trunk as an x6 Winograd layer (csrc/wino_x6.hip) in the f32_winograd mode
+        self.x3_trunk = False        # ... in the f32x3 arithmetic instead (csrc/wino_x3.hip)
 
     def packed(self):
         params = [p for m in (self._rpn_conv1, self._rpn_class, self._rpn_boxes) for p in (m.weight, m.bias)]
-        trunk_math = "f32_winograd_x6" if (self.math_mode == "f32_winograd" and self.x6_trunk) else self.math_mode
+        trunk_math = self.math_mode
+        if self.math_mode == "f32_winograd" and self.x6_trunk:
+            trunk_math = "f32_winograd_x3" if self.x3_trunk else "f32_winograd_x6"
         key = (trunk_math,) + rt.param_key(params)
         if key != self._packed_key:
             head_w, head_b = pack_stack_rows(self._rpn_class, self._rpn_boxes)

@@ -43,6 +43,18 @@ def pack_conv3x3(conv, math_mode="f32"):
             nv.check(lib.frcnn_pack_conv3x3_winograd_x6(nv.ptr(w), None, nv.ptr(out), cout, cin, nv.stream_ptr()),
                      "frcnn_pack_conv3x3_winograd_x6")
         return out
+    if math_mode == "f32_winograd_x3":
+        # the same layer in the f32x3 arithmetic (csrc/wino_x3.hip): the float32 bank [16][cout][cin], then records + row scales in one blob
+        # (int8: the dtype marks it)
+        if not nv.uses_winograd_x6(cin, cout):
+            raise ValueError("a %d -> %d 3x3 layer cannot run as an x6 / x3 Winograd layer (cin >= 256, cout %% 256 == 0)" % (cin, cout))
+        lib = nv.lib()
+        bank = t.empty((16, cout, cin), dtype=t.float32, device=w.device)
+        out = t.empty((int(lib.frcnn_conv3x3_winograd_x3_pack_bytes(cout, cin)),), dtype=t.int8, device=w.device)
+        with t.cuda.device(w.device):
+            nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w), None, nv.ptr(bank), cout, cin, nv.stream_ptr()), "frcnn_pack_conv3x3_winograd")
+            nv.check(lib.frcnn_pack_conv3x3_winograd_x3(nv.ptr(bank), nv.ptr(out), cout, cin, nv.stream_ptr()), "frcnn_pack_conv3x3_winograd_x3")
+        return out
     if math_mode == "f32_winograd" and nv.uses_winograd_fused(cin, cout):
         # one-launch Winograd layer (csrc/winofused.hip): [cin/16][cout/64][16][64][16], kept flat (dim() == 1 marks it)
         out = t.empty((16 * cout * cin,), dtype=t.float32, device=w.device)
@@ -86,6 +98,14 @@ def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False):
             nv.check(lib.frcnn_conv3x3_nhwc_winograd_x6(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
                                                         nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc_winograd_x6")
         return y
+    if wp.dtype == t.int8:                               # x3 Winograd layer: packed x3t bank + scratch
+        flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
+        ws_bytes = int(lib.frcnn_conv3x3_winograd_x3_workspace_bytes(1, h, w, cin, cout))
+        ws = t.empty((ws_bytes,), dtype=t.uint8, device=x_hwc.device)
+        with t.cuda.device(x_hwc.device):
+            nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
+                                                        nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc_winograd_x3")
+        return y
     if wp.dtype == t.float32 and wp.dim() == 1:          # one-launch Winograd bank
         flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
         with t.cuda.device(x_hwc.device):
@@ -123,12 +143,13 @@ class FeatureExtractor(nn.Module):
         self._packed = None
         self.math_mode = "f32"
         self.x6_layers = ()          # names ("conv4_1", ...) of the layers that run as x6 Winograd layers in the f32_winograd mode
+        self.x3_layers = ()          # the subset of x6_layers whose GEMMs run in the f32x3 arithmetic (csrc/wino_x3.hip)
 
     def layer_math(self, i):
         """Pack / arithmetic kind of layer i in the current mode."""
         name = "conv%s_%s" % (_LAYERS[i][0][6], _LAYERS[i][0][-1])
         if self.math_mode == "f32_winograd" and name in self.x6_layers:
-            return "f32_winograd_x6"
+            return "f32_winograd_x3" if name in self.x3_layers else "f32_winograd_x6"
         return self.math_mode
 
     def convs(self):
@@ -137,7 +158,7 @@ class FeatureExtractor(nn.Module):
     def packed(self):
         """[(packed_weight, bias)] x 13 on the parameters' device, rebuilt when parameters change."""
         params = [p for c in self.convs() for p in (c.weight, c.bias)]
-        key = (self.math_mode, tuple(sorted(self.x6_layers))) + rt.param_key(params)
+        key = (self.math_mode, tuple(sorted(self.x6_layers)), tuple(sorted(self.x3_layers))) + rt.param_key(params)
         if key != self._packed_key:
             self._packed = [(pack_conv3x3(c, self.layer_math(i)), rt.as_f32_cuda(c.bias.detach(), "conv bias"))
                             for i, c in enumerate(self.convs())]
@@ -211,6 +232,8 @@ class PoolToFeatureVector(nn.Module):
                 w1p, w2 = split_rows_x6(w1p, rows_out=4096), split_rows_x6(w2, rows_out=4096)
             elif mode == "f32x6":
                 w1p, w2 = split_rows_x6t(w1p, 4096), split_rows_x6t(w2, 4096)
+            elif mode == "f32x3":
+                w1p, w2 = pack_rows_x3t(w1p, 4096), pack_rows_x3t(w2, 4096)
             self._packed[mode] = (w1p, b1, w2, b2)
         return self._packed[mode]
 
@@ -229,6 +252,9 @@ class PoolToFeatureVector(nn.Module):
         if mode == "f32x6":
             h1 = linear_x6t(x, w1p, b1, 4096, relu=True)
             return linear_x6t(h1, w2, b2, 4096, relu=True)
+        if mode == "f32x3":
+            h1 = linear_x3t(x, w1p, b1, 4096, relu=True)
+            return linear_x3t(h1, w2, b2, 4096, relu=True)
         if mode == "f32x6_v1":
             h1_rec = linear_x6(split_rows_x6(x), w1p, b1, n, 4096, 49 * 512, relu=True, want="records")
             return linear_x6(h1_rec, w2, b2, n, 4096, 4096, relu=True, want="float32")
@@ -262,6 +288,39 @@ def linear_x6t(x, w_rec, b, n_out, relu):
     with t.cuda.device(x.device):
         nv.check(lib.frcnn_gemm_x6t(nv.ptr(a_rec), mp, 0, nv.ptr(w_rec), np_, 0, nv.ptr(b), None, nv.ptr(y), n_out, 0, m, n_out, k, 1,
                                     nv.RELU if relu else 0, nv.ptr(ws), wsb, nv.stream_ptr()), "frcnn_gemm_x6t")
+    return y
+
+
+def pack_rows_x3t(a, rows_padded):
+    """float32 (R, K) CUDA matrix -> its packed x3t operand (int8: [K/16][rows_padded/32][2][1 KB] fp16 records of the row-scaled matrix,
+    then rows_padded float32 scales 2^-e: csrc/gemm_x3t.hip)."""
+    r, k = int(a.shape[0]), int(a.shape[1])
+    a = a.contiguous()
+    lib = nv.lib()
+    blob = t.empty((int(lib.frcnn_x3t_blob_bytes(rows_padded, k, 1)),), dtype=t.int8, device=a.device)
+    with t.cuda.device(a.device):
+        nv.check(lib.frcnn_pack_rows_x3t(nv.ptr(a), k, 0, nv.ptr(blob), r, rows_padded, k, 1, nv.stream_ptr()), "frcnn_pack_rows_x3t")
+    return blob
+
+
+def linear_x3t(x, w_blob, b, n_out, relu):
+    """y = act(x @ w.T + b) in the f32x3 arithmetic through frcnn_gemm_x3t; x (M, K) float32 CUDA, w_blob = pack_rows_x3t of w [n_out][K]
+    (rows padded to a multiple of 256).  Any M."""
+    m, k = int(x.shape[0]), int(x.shape[1])
+    y = t.empty((m, n_out), dtype=t.float32, device=x.device)
+    if m == 0:
+        return y
+    lib = nv.lib()
+    mp = (m + nv.X6T_ROW_TILE - 1) // nv.X6T_ROW_TILE * nv.X6T_ROW_TILE
+    np_ = (n_out + nv.X6T_COL_TILE - 1) // nv.X6T_COL_TILE * nv.X6T_COL_TILE
+    a_blob = pack_rows_x3t(x, mp)
+    a_rec, b_rec = int(lib.frcnn_x3t_record_bytes(mp, k)), int(lib.frcnn_x3t_record_bytes(np_, k))
+    wsb = int(lib.frcnn_gemm_x3t_workspace_bytes(m, n_out, k, 1))
+    ws = t.empty((max(wsb, 4),), dtype=t.uint8, device=x.device)
+    with t.cuda.device(x.device):
+        nv.check(lib.frcnn_gemm_x3t(nv.ptr(a_blob), a_blob.data_ptr() + a_rec, mp, 0, 0, nv.ptr(w_blob), w_blob.data_ptr() + b_rec, np_, 0, 0,
+                                    nv.ptr(b), None, nv.ptr(y), n_out, 0, m, n_out, k, 1, nv.RELU if relu else 0, nv.ptr(ws), wsb,
+                                    nv.stream_ptr()), "frcnn_gemm_x3t")
     return y
 
 

@@ -37,10 +37,11 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 7   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
+#define FRCNN_ABI_VERSION 8   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
                                  5: bf16 gradient GEMMs (the *_math entry points); 6: x6t GEMM, x6 Winograd layers, frcnn_forward_params.winograd_x6_mask,
                                  timing classes 8 / 9; 7: batched feature extractor (frcnn_resnet_backbone, frcnn_resnet_forward_features,
-                                 frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps) */
+                                 frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps); 8: the f32x3 arithmetic (frcnn_*_x3t, frcnn_*_winograd_x3,
+                                 frcnn_forward_params.winograd_x3_mask, FRCNN_FC_F32X3T) */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -236,6 +237,45 @@ size_t frcnn_gemm_x6t_workspace_bytes(int M, int N, int K, int batches);
 int frcnn_gemm_x6t(const void* d_a_rec, int a_rows, size_t a_batch_bytes, const void* d_b_rec, int b_rows, size_t b_batch_bytes,
                    const float* d_bias, const float* d_residual, float* d_c, int ldc, size_t c_batch_floats, int M, int N, int K,
                    int batches, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * The same batched GEMM in the "f32x3" arithmetic (csrc/gemm_x3t.hip): HALF the matrix instructions of the f32x6 form.  Every operand
+ * row carries a power-of-two scale that puts its largest magnitude into [2^14, 2^15); the scaled float32 value is split into two fp16
+ * terms x 2^e = hi + lo (|remainder| <= 2^-22 |x 2^e|) and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with float32
+ * accumulation; the epilogue multiplies by the two 2^-e (exact).  Operands are held to 22-23 bits relative to their ROW's largest
+ * element -- a perturbation below the float32 accumulation error of either matrix pipe (tests/test_gemm_x3t_gpu.py: error against
+ * float64 within the exact-f32 kernel's).
+ * x3t records of X[R][K]: [K/16][rows_padded/32][2 = hi, lo][1024 B], 1024 B = [k-half 2][row 32][8 fp16]; scales: float32 2^-e per row.
+ *   frcnn_rows_scale_x3t  : [batches][rows][lda] float32 -> d_inv_scale [batches][rows_padded] (2^-e; 1 for zero / padding rows)
+ *   frcnn_split_rows_x3t  : the records of the rows scaled by 1 / d_inv_scale
+ *   frcnn_gemm_x3t        : as frcnn_gemm_x6t, plus the two scale arrays (batch strides in floats, 0 = shared by all batches)
+ * ---------------------------------------------------------------------------------------- */
+/* A PACKED x3t operand ("blob") = its record arrays followed by its scale arrays: [batches][frcnn_x3t_record_bytes(rows_padded, K)] bytes, then
+ * [batches][rows_padded] float32; frcnn_pack_rows_x3t = frcnn_rows_scale_x3t + frcnn_split_rows_x3t into one such allocation of
+ * frcnn_x3t_blob_bytes(rows_padded, K, batches) bytes (weights: fc1_w / fc2_w with fc_math_mode FRCNN_FC_F32X3T, rows_padded = 4096).
+ * Winograd F(2x2,3x3) layer in this arithmetic (csrc/wino_x3.hip: channel-maximum pass + input transform with one scale per tile,
+ * 16 batched GEMMs, output transform), the f32x3 counterpart of the frcnn_*_winograd_x6 entries:
+ *   frcnn_pack_conv3x3_winograd_x3 : d_u_f32 = the float32 bank [16][cout][cin] of frcnn_pack_conv3x3_winograd -> blob of
+ *                                    frcnn_conv3x3_winograd_x3_pack_bytes(cout, cin) bytes
+ *   frcnn_conv3x3_nhwc_winograd_x3 : the layer; d_ws >= frcnn_conv3x3_winograd_x3_workspace_bytes(n_maps, H, W, cin, cout) */
+size_t frcnn_x3t_blob_bytes(int rows_padded, int K, int batches);
+int frcnn_pack_rows_x3t(const float* d_a, int lda, size_t a_batch_floats, void* d_blob, int rows, int rows_padded, int K, int batches,
+                        void* stream);
+size_t frcnn_conv3x3_winograd_x3_pack_bytes(int cout, int cin);
+int frcnn_pack_conv3x3_winograd_x3(const float* d_u_f32, void* d_blob, int cout, int cin, void* stream);
+size_t frcnn_conv3x3_winograd_x3_workspace_bytes(int n_maps, int H, int W, int cin, int cout);
+int frcnn_conv3x3_nhwc_winograd_x3(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W, int cin,
+                                   int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
+size_t frcnn_x3t_record_bytes(int rows_padded, int K);
+int frcnn_rows_scale_x3t(const float* d_a, int lda, size_t a_batch_floats, float* d_inv_scale, int rows, int rows_padded, int K, int batches,
+                         void* stream);
+int frcnn_split_rows_x3t(const float* d_a, int lda, size_t a_batch_floats, const float* d_inv_scale, void* d_rec, int rows, int rows_padded,
+                         int K, int batches, void* stream);
+size_t frcnn_gemm_x3t_workspace_bytes(int M, int N, int K, int batches);
+int frcnn_gemm_x3t(const void* d_a_rec, const float* d_a_inv, int a_rows, size_t a_batch_bytes, size_t a_inv_batch_floats,
+                   const void* d_b_rec, const float* d_b_inv, int b_rows, size_t b_batch_bytes, size_t b_inv_batch_floats,
+                   const float* d_bias, const float* d_residual, float* d_c, int ldc, size_t c_batch_floats, int M, int N, int K,
+                   int batches, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
+
 /* NHWC float32 [N][H][W][C] -> the x6t records of the [N Ho Wo][C] matrix of its pixels taken with `stride` in y and x
  * (Ho = (H - 1) / stride + 1): the A operand of a 1x1 convolution (stride 1 or 2) as a GEMM.  C % 16 == 0. */
 int frcnn_split_pixels_x6t(const float* d_x, void* d_rec, int N, int H, int W, int C, int stride, int rows_padded, void* stream);
@@ -435,6 +475,9 @@ typedef struct frcnn_forward_params {
                                    round), 1 = 320 x 256 always, 2 = 160 x 128 always (4-wave blocks that leave registers and LDS for a second kernel on
                                    the CU: with several images in flight the transforms, epilogues and proposal kernels of the other images then
                                    overlap the GEMM -- measured +3..8 % images/sec at 3 images in flight) */
+    int32_t winograd_x3_mask;   /* a subset of winograd_x6_mask (VGG-16): the layers whose position GEMMs run in the f32x3 arithmetic instead (two
+                                   fp16 terms per row-scaled operand, three MFMAs per product: csrc/wino_x3.hip); their weight pointers are
+                                   frcnn_pack_conv3x3_winograd_x3's blobs.  ResNet: 0 */
 } frcnn_forward_params;
 #define FRCNN_X6_RPN_TRUNK_BIT 13
 /* capacity of the detector heads: classifier (n) + regressor (4 n - 4) rows are stacked into one zero-padded GEMM operand of
@@ -450,6 +493,8 @@ typedef struct frcnn_forward_params {
 #define FRCNN_FC_F32X6 1      /* rounds 2's kernel (csrc/linear_x6.hip, chunk-major records, <= FRCNN_LINEAR_X6_ROWS RoIs) */
 #define FRCNN_FC_F32X6T 2     /* round 3: the same arithmetic on csrc/gemm_x6t.hip (fc1_w / fc2_w = frcnn_split_rows_x6t records of the
                                  same matrices, rows padded to FRCNN_X6T_COL_TILE; any number of RoIs the ctx holds) */
+#define FRCNN_FC_F32X3T 3     /* the f32x3 arithmetic on csrc/gemm_x3t.hip (two fp16 terms per row-scaled operand, three MFMAs per product):
+                                 fc1_w / fc2_w = frcnn_pack_rows_x3t blobs of the same matrices (rows_padded = 4096) */
 
 /* d_image: float32 NCHW [3][H][W] (preprocessed as models/vgg16.py:146 prescribes).
  * d_anchor_map / d_valid_map: optional caller-provided maps (faster_rcnn.py:113-115); NULL =

@@ -1,0 +1,315 @@
+"""
+GPU parity tests of the "f32x3" arithmetic: the tile-record GEMM with two fp16 terms per row-scaled operand and three fp16 MFMAs per
+product (csrc/gemm_x3t.hip), the Winograd F(2x2,3x3) layer on it (csrc/wino_x3.hip) and RoI pooling into its records (csrc/roipool.hip)
+-- models/vgg16.py:89-96,129-133, models/rpn.py:88, models/detector.py:65-72 of the reference.
+
+Tolerances.  The split keeps 22-23 bits of every operand relative to its ROW's largest element (|x 2^e - hi - lo| <= 2^-22 |x 2^e|,
+checked through the record layout, with rows 2^+-30 apart in magnitude); a GEMM against float64 truth is no worse than 1.5x the exact-f32
+MFMA kernel's own error + 2e-7 of max|y| (the bar of the f32x6 kernels: tests/test_wino_x6_gpu.py); a layer against a float64 convolution
+no worse than 1.5x the one-launch float32 Winograd layer's error + 2e-7.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fasterrcnn_amd import _native as nv
+from fasterrcnn_amd import synthetic
+from fasterrcnn_amd.models import vgg16 as V
+
+pytestmark = pytest.mark.gpu
+
+
+def pad_to(n, t):
+    return (n + t - 1) // t * t
+
+
+def pack_x3t(a, rows_padded):
+    """(batches, R, K) or (R, K) float32 CUDA -> (blob int8, record bytes per batch): records of every batch, then the scale arrays."""
+    lib = nv.lib()
+    if a.dim() == 2:
+        a = a.unsqueeze(0)
+    a = a.contiguous()
+    nb, r, k = (int(v) for v in a.shape)
+    per = int(lib.frcnn_x3t_record_bytes(rows_padded, k))
+    blob = torch.full((int(lib.frcnn_x3t_blob_bytes(rows_padded, k, nb)),), 0x5B, dtype=torch.int8, device=a.device)
+    assert blob.numel() == nb * (per + 4 * rows_padded)
+    nv.check(lib.frcnn_pack_rows_x3t(nv.ptr(a), k, r * k, nv.ptr(blob), r, rows_padded, k, nb, nv.stream_ptr()), "pack_rows_x3t")
+    return blob, per
+
+
+def blob_planes(blob, per, rows_padded, k, nb):
+    """-> hi, lo float64 (nb, rows_padded, k) and inv float32 (nb, rows_padded)."""
+    raw = blob.cpu().numpy().view(np.uint8)
+    rec = raw[:nb * per].view(np.float16).reshape(nb, k // 16, rows_padded // 32, 2, 2, 32, 8)
+    f = rec.astype(np.float64).transpose(0, 3, 2, 5, 1, 4, 6).reshape(nb, 2, rows_padded, k)      # [b][term][rb, row][chunk, khalf, 8]
+    inv = raw[nb * per:].view(np.float32).reshape(nb, rows_padded)
+    return f[:, 0], f[:, 1], inv
+
+
+def gemm_x3t(a_blob, a_per, a_rows, b_blob, b_per, b_rows, bias, m, n, k, batches, relu, shared_b=False, residual=None):
+    lib = nv.lib()
+    c = torch.full((batches, m, n), float("nan"), device="cuda")
+    wsb = int(lib.frcnn_gemm_x3t_workspace_bytes(m, n, k, batches))
+    ws = torch.empty((max(wsb, 4) // 4,), device="cuda")
+    nb_b = 1 if shared_b else batches
+    nv.check(lib.frcnn_gemm_x3t(nv.ptr(a_blob), a_blob.data_ptr() + batches * a_per, a_rows, a_per, a_rows,
+                                nv.ptr(b_blob), b_blob.data_ptr() + nb_b * b_per, b_rows, 0 if shared_b else b_per, 0 if shared_b else b_rows,
+                                nv.ptr(bias), nv.ptr(residual), nv.ptr(c), n, m * n, m, n, k, batches, nv.RELU if relu else 0, nv.ptr(ws), wsb,
+                                nv.stream_ptr()), "gemm_x3t")
+    torch.cuda.synchronize()
+    return c
+
+
+def test_x3t_split_scales_and_layout():
+    gen = torch.Generator().manual_seed(1)
+    a = torch.randn((2, 70, 48), generator=gen) * torch.exp2(torch.randint(-30, 31, (2, 70, 1), generator=gen).float())   # rows 2^+-30 apart
+    a[0, 0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e-30, 65504.0, 1e-3, 0.1])
+    a[1, 5] = 0.0                                                                                                        # a zero row
+    blob, per = pack_x3t(a.cuda(), 96)
+    assert per == 3 * 3 * 2048
+    hi, lo, inv = blob_planes(blob, per, 96, 48, 2)
+    x = a.numpy().astype(np.float64)
+    for b in range(2):
+        e = np.log2(inv[b].astype(np.float64))
+        assert np.array_equal(e, np.round(e))                                    # exact powers of two
+        assert (inv[b, 70:] == 1.0).all() and (hi[b, 70:] == 0).all() and (lo[b, 70:] == 0).all()
+        scaled = x[b] / inv[b, :70, None]                                        # x 2^e
+        rowmax = np.abs(scaled).max(axis=1)
+        live = rowmax > 0
+        assert (rowmax[live] >= 2.0 ** 14).all() and (rowmax[live] < 2.0 ** 15).all()
+        err = np.abs(hi[b, :70] + lo[b, :70] - scaled)
+        # 2^-22 relative where the low term is a normal fp16 number, 2^-25 absolute (half an ulp of the smallest subnormal) below
+        assert (err <= np.maximum(2.0 ** -22 * np.abs(scaled), 2.0 ** -25)).all()
+        assert np.abs(lo[b, :70]).max() <= 2.0 ** -10 * rowmax.max()
+    assert inv[1, 5] == 1.0 and (hi[1, 5] == 0).all()
+
+
+@pytest.mark.parametrize("M,N,K,batches,relu", [
+    (2394, 512, 512, 16, False),     # the position GEMMs of conv4_2 / conv4_3
+    (589, 512, 512, 16, False),      # conv5_x / RPN trunk
+    (300, 4096, 4096, 1, True),      # fc2's shape (split-K)
+    (300, 512, 25088, 1, True),      # fc1's reduction depth
+    (137, 260, 80, 3, False),        # ragged M and N, five 16-k stages, batches
+    (1, 4, 16, 1, True),             # one row, one stage
+    (321, 256, 32, 2, False),        # one row more than a tile, two stages
+])
+def test_gemm_x3t_against_float64_and_the_exact_f32_kernel(M, N, K, batches, relu):
+    gen = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((batches, M, K), generator=gen) * torch.exp(torch.randn((batches, 1, K), generator=gen))   # per-channel scales
+    a = a * torch.exp2(torch.randint(-12, 13, (batches, M, 1), generator=gen).float())                        # rows of very different size
+    w = torch.randn((batches, N, K), generator=gen) * (2.0 / K) ** 0.5
+    b = torch.randn((N,), generator=gen) * 0.1
+    ref = torch.einsum("bmk,bnk->bmn", a.double(), w.double()) + b.double()
+    if relu:
+        ref = ref.clamp(min=0)
+    ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+    a_rows, b_rows = pad_to(M, nv.X6T_ROW_TILE), pad_to(N, nv.X6T_COL_TILE)
+    a_blob, a_per = pack_x3t(ad, a_rows)
+    w_blob, w_per = pack_x3t(wd, b_rows)
+    c = gemm_x3t(a_blob, a_per, a_rows, w_blob, w_per, b_rows, bd, M, N, K, batches, relu)
+    assert not torch.isnan(c).any()
+    # per-ROW error: the rows differ by 2^24 in magnitude, each must be accurate relative to its own scale
+    row_scale = ref.abs().amax(dim=2, keepdim=True).clamp(min=1e-30)
+    e3 = float(((c.cpu().double() - ref).abs() / row_scale).max())
+    npad = pad_to(N, 128)
+    wpad = torch.zeros((npad, K), device="cuda")
+    wpad[:N] = wd[0]
+    y32 = V.linear(ad[0].contiguous(), wpad, bd, N, relu)
+    e32 = float(((y32.cpu().double() - ref[0]).abs() / row_scale[0]).max())
+    print("gemm_x3t M=%d N=%d K=%d x%d: max err / row max|y| = %.3g (exact-f32 MFMA kernel, batch 0: %.3g)" % (M, N, K, batches, e3, e32))
+    assert e3 <= 1.5 * e32 + 2e-7 and e3 <= 4e-6 * np.sqrt(K)
+    c2 = gemm_x3t(a_blob, a_per, a_rows, w_blob, w_per, b_rows, bd, M, N, K, batches, relu)
+    assert torch.equal(c, c2)                                   # deterministic (fixed-order split-K)
+    if batches > 1:
+        w0_blob, w0_per = pack_x3t(wd[0], b_rows)
+        c3 = gemm_x3t(a_blob, a_per, a_rows, w0_blob, w0_per, b_rows, bd, M, N, K, batches, relu, shared_b=True)
+        ref3 = torch.einsum("bmk,nk->bmn", a.double(), w[0].double()) + b.double()
+        if relu:
+            ref3 = ref3.clamp(min=0)
+        rs3 = ref3.abs().amax(dim=2, keepdim=True).clamp(min=1e-30)
+        assert float(((c3.cpu().double() - ref3).abs() / rs3).max()) <= 1.5 * e32 + 4e-7
+    if M == 137:
+        res = torch.randn((batches, M, N), generator=gen).cuda()
+        c4 = gemm_x3t(a_blob, a_per, a_rows, w_blob, w_per, b_rows, bd, M, N, K, batches, True, residual=res)
+        want = (torch.einsum("bmk,bnk->bmn", a.double(), w.double()) + b.double() + res.cpu().double()).clamp(min=0)
+        assert float(((c4.cpu().double() - want).abs() / want.abs().amax(dim=2, keepdim=True).clamp(min=1e-30)).max()) <= 1.5 * e32 + 4e-7
+
+
+def test_gemm_x3t_rejects_bad_arguments():
+    lib = nv.lib()
+    s = nv.stream_ptr()
+    x = torch.zeros((1 << 20,), device="cuda")
+    p = nv.ptr(x)
+    ok = lambda *a: lib.frcnn_gemm_x3t(*a)
+    assert ok(None, p, 320, 0, 0, p, p, 256, 0, 0, None, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1
+    assert ok(p, None, 320, 0, 0, p, p, 256, 0, 0, None, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1      # no scales
+    assert ok(p, p, 300, 0, 0, p, p, 256, 0, 0, None, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1         # a_rows % 320
+    assert ok(p, p, 320, 0, 0, p, p, 128, 0, 0, None, None, p, 256, 0, 8, 256, 64, 1, 0, p, 1 << 22, s) == -1         # b_rows % 256
+    assert ok(p, p, 320, 0, 0, p, p, 256, 0, 0, None, None, p, 256, 0, 8, 256, 40, 1, 0, p, 1 << 22, s) == -4         # K % 16
+    assert lib.frcnn_x3t_record_bytes(320, 512) == 32 * 10 * 2048 and lib.frcnn_x3t_record_bytes(100, 512) == 0
+    assert lib.frcnn_x3t_blob_bytes(320, 512, 2) == 2 * (32 * 10 * 2048 + 1280)
+
+
+def pack_x3(w_oihw):
+    lib = nv.lib()
+    cout, cin = int(w_oihw.shape[0]), int(w_oihw.shape[1])
+    bank = torch.empty((16, cout, cin), device=w_oihw.device)
+    nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w_oihw), None, nv.ptr(bank), cout, cin, nv.stream_ptr()), "pack_winograd")
+    u = torch.full((int(lib.frcnn_conv3x3_winograd_x3_pack_bytes(cout, cin)),), 0x5B, dtype=torch.int8, device=w_oihw.device)
+    nv.check(lib.frcnn_pack_conv3x3_winograd_x3(nv.ptr(bank), nv.ptr(u), cout, cin, nv.stream_ptr()), "pack_winograd_x3")
+    return u
+
+
+def run_x3(x, u, b, cout, relu, pool, n_maps=1):
+    lib = nv.lib()
+    h, wd, cin = (int(v) for v in x.shape[-3:])
+    oh, ow = (h // 2, wd // 2) if pool else (h, wd)
+    y = torch.full((n_maps, oh, ow, cout) if n_maps > 1 else (oh, ow, cout), float("nan"), device=x.device)
+    wsb = int(lib.frcnn_conv3x3_winograd_x3_workspace_bytes(n_maps, h, wd, cin, cout))
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
+    nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), n_maps, h, wd, cin, cout, flags, nv.ptr(ws), wsb,
+                                                nv.stream_ptr()), "conv_winograd_x3")
+    torch.cuda.synchronize()
+    return y
+
+
+def run_fused_f32(x, w_oihw, b, relu, pool):
+    lib = nv.lib()
+    h, wd, cin = (int(v) for v in x.shape)
+    cout = int(w_oihw.shape[0])
+    oh, ow = (h // 2, wd // 2) if pool else (h, wd)
+    y = torch.full((oh, ow, cout), float("nan"), device=x.device)
+    u = torch.empty((16 * cout * cin,), device=x.device)
+    nv.check(lib.frcnn_pack_conv3x3_winograd_fused(nv.ptr(w_oihw), None, nv.ptr(u), cout, cin, nv.stream_ptr()), "pack_winograd_fused")
+    flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
+    nv.check(lib.frcnn_conv3x3_nhwc_winograd_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), h, wd, cin, cout, flags,
+                                                   nv.stream_ptr()), "conv_winograd_fused")
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("h,w,cin,cout,relu,pool", [
+    (75, 125, 512, 512, True, False),     # conv4_2
+    (75, 125, 256, 512, True, False),     # conv4_1
+    (75, 125, 512, 512, True, True),      # conv4_3 with the fused pool
+    (37, 62, 512, 512, True, False),      # block 5 / RPN trunk
+    (9, 11, 256, 256, False, False),      # tiny, odd, no ReLU
+    (2, 2, 16, 256, True, True),          # a single tile
+    (1, 5, 32, 260, True, False),         # one row; cout not a multiple of the column tile
+])
+def test_x3_layer_against_float64_and_the_float32_winograd_layer(h, w, cin, cout, relu, pool):
+    gen = torch.Generator().manual_seed(h * 1000 + w + cin)
+    x = torch.randn((h, w, cin), generator=gen) * torch.exp(torch.randn((1, 1, cin), generator=gen))     # per-channel scales
+    # a dark corner: activations 2^-20 of the rest of the map -- the per-tile scale must keep its outputs accurate
+    x[: max(h // 3, 1), : max(w // 3, 1)] *= 2.0 ** -20
+    wt = torch.randn((cout, cin, 3, 3), generator=gen) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.zeros((cout,))
+    ref = F.conv2d(x.permute(2, 0, 1).unsqueeze(0).double(), wt.double(), b.double(), padding=1)
+    if relu:
+        ref = ref.clamp(min=0)
+    if pool:
+        ref = F.max_pool2d(ref, 2)
+    ref = ref[0].permute(1, 2, 0)
+    xd, wd, bd = x.cuda(), wt.cuda(), b.cuda()
+    u = pack_x3(wd)
+    y = run_x3(xd, u, bd, cout, relu, pool)
+    assert not torch.isnan(y).any()
+    scale = float(ref.abs().max())
+    e3 = float((y.cpu().double() - ref).abs().max()) / scale
+    e32 = float((run_fused_f32(xd, wd, bd, relu, pool).cpu().double() - ref).abs().max()) / scale if cout % 64 == 0 else 1e-6
+    print("winograd x3 %dx%d %d->%d: max err / max|y| = %.3g (float32 one-launch Winograd layer %.3g)" % (h, w, cin, cout, e3, e32))
+    assert e3 <= 1.5 * e32 + 2e-7
+    # the dark corner on its own scale: the outputs of the Winograd TILES whose 4 x 4 input patch is dark throughout (a tile that straddles
+    # the edge mixes 2^20-times larger pixels into every V value -- in float32 Winograd as well -- and is not held to the corner's scale)
+    dr, dc = max(h // 3, 1), max(w // 3, 1)
+    ch = (2 * ((dr - 3) // 2) + 2 if dr >= 3 else 0) // (2 if pool else 1)
+    cw = (2 * ((dc - 3) // 2) + 2 if dc >= 3 else 0) // (2 if pool else 1)
+    if ch >= 1 and cw >= 1:
+        sub, rsub = y[:ch, :cw].cpu().double(), ref[:ch, :cw]
+        if float(rsub.abs().max()) > 0:
+            ec = float((sub - rsub).abs().max()) / float(rsub.abs().max())
+            print("    dark corner (activations x 2^-20): max err / corner max|y| = %.3g" % ec)
+            assert ec <= 3e-6
+    assert torch.equal(y, run_x3(xd, u, bd, cout, relu, pool))
+
+
+def test_x3_layer_impulses_and_maps():
+    h, w, cin, cout = 22, 70, 32, 256                              # 385 tiles: two GEMM row tiles, 13 record blocks
+    gen = torch.Generator().manual_seed(9)
+    wt = torch.randn((cout, cin, 3, 3), generator=gen) * 0.1
+    b = torch.zeros((cout,))
+    u = pack_x3(wt.cuda())
+    for (py, px) in ((0, 0), (0, w - 1), (h - 1, 0), (h - 1, w - 1), (1, 63), (2, 64), (19, 33), (10, 35)):
+        x = torch.zeros((h, w, cin))
+        x[py, px, (py * 7 + px) % cin] = 1.5
+        ref = F.conv2d(x.permute(2, 0, 1).unsqueeze(0).double(), wt.double(), None, padding=1)[0].permute(1, 2, 0)
+        y = run_x3(x.cuda(), u, b.cuda(), cout, False, False)
+        assert float((y.cpu().double() - ref).abs().max()) <= 1e-6, (py, px)
+    # several maps in one call == the maps one by one
+    xs = torch.randn((3, 9, 13, cin), generator=gen).cuda()
+    ys = run_x3(xs, u, b.cuda(), cout, True, False, n_maps=3)
+    for i in range(3):
+        yi = run_x3(xs[i].contiguous(), u, b.cuda(), cout, True, False)
+        assert float((ys[i] - yi).abs().max()) <= 1e-6 * float(yi.abs().max())
+
+
+def test_roi_pool_x3t_records_hold_the_pooled_values(gpu_model):
+    """The f32x3 fc path end to end on the model: with fc_math_mode "f32x3" the pooled features only exist as records; their effect is
+    checked through the detector outputs against the exact-f32 fc path on the same proposals (class probabilities within 1e-5) in
+    test_linear_x6_gpu.py.  Here: degenerate RoIs (empty bins, RoIs outside the map) give finite outputs."""
+    assert gpu_model.fc_math_mode == "f32x3"
+    img = torch.zeros((1, 3, 224, 320), device="cuda")              # constant image: many tied / degenerate proposals
+    p, c, d = gpu_model(image_data=img)
+    assert torch.isfinite(c).all() and torch.isfinite(d).all()
+    assert float((c.sum(dim=1) - 1.0).abs().max()) <= 1e-5
+
+
+X3_ALL_PROPOSALS = 299      # observed with EVERY layer of the x6 table in f32x3 (conv4_2 / conv4_3 too): one near-tied proposal of the
+X3_ALL_DETECTIONS = 193     # 600x1000 fixture crosses the NMS cut; the default table keeps 300 / 300 and 194 / 194 (test_model_gpu.py)
+
+
+def test_model_x3_layer_tables_against_the_golden_vectors(gpu_model, golden_dir):
+    """The default table (conv5_x and the RPN trunk in f32x3; conv4_x in f32x6; fc1 / fc2 in f32x3) reproduces every
+    golden proposal and detection (test_model_gpu.py runs with it).  Here: the two other tables -- no f32x3 layer at all, and the whole
+    x6 table in f32x3 -- agree with it to float32 rounding and are held to the golden vectors at their observed numbers."""
+    assert gpu_model.winograd_x3_layers == nv.DEFAULT_X3_LAYERS_VGG16
+    g = np.load(os.path.join(golden_dir, "vgg16_600x1000_s0.npz"))
+    img = synthetic.image(int(g["seed"]), 600, 1000).unsqueeze(0).cuda()
+    ref = g["detections"]
+    res = {}
+    try:
+        for name, layers in (("default", nv.DEFAULT_X3_LAYERS_VGG16), ("none", ()), ("all", nv.DEFAULT_X6_LAYERS_VGG16)):
+            gpu_model.winograd_x3_layers = layers
+            p, c, d = gpu_model(image_data=img)
+            fm = gpu_model.context(0).tensor(0).clone()
+            det = gpu_model.predict(image_data=img, score_threshold=0.05)
+            res[name] = (p.cpu().numpy(), c.cpu().numpy(), fm, det)
+    finally:
+        gpu_model.winograd_x3_layers = nv.DEFAULT_X3_LAYERS_VGG16
+
+    def counts(name):
+        pr, cl, fm, det = res[name]
+        dist = np.abs(pr[:, None, :] - g["proposals"][None, :, :]).max(axis=2).min(axis=0)
+        n_ok = 0
+        for c in range(1, 21):
+            r = ref[ref[:, 0] == c][:, 1:]
+            if len(r) and len(det[c]):
+                dd = np.abs(det[c][:, None, :4] - r[None, :, :4]).max(axis=2)
+                j = dd.argmin(axis=0)
+                n_ok += int(((dd[j, np.arange(len(r))] <= 1e-3) & (np.abs(det[c][j, 4] - r[:, 4]) <= 2e-4)).sum())
+        return int((dist <= 1e-3).sum()), n_ok
+
+    for name in ("default", "none", "all"):
+        rel = float((res[name][2] - res["none"][2]).abs().max()) / float(res["none"][2].abs().max())
+        np_, nd = counts(name)
+        print("f32x3 table %-7s: feature map %.3g of max vs the all-f32x6 table, %d/300 proposals, %d/%d detections" % (name, rel, np_, nd, len(ref)))
+        assert rel <= 5e-6
+    assert counts("default") == (300, len(ref)) and counts("none") == (300, len(ref))
+    na, da = counts("all")
+    assert na >= X3_ALL_PROPOSALS and da >= X3_ALL_DETECTIONS
+    with pytest.raises(ValueError):
+        gpu_model.winograd_x3_layers = ("conv1_2",)

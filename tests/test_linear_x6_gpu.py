@@ -87,18 +87,18 @@ def test_linear_x6_rejects_bad_arguments():
 
 
 def test_model_fc_modes_agree_and_both_reproduce_the_golden_vectors(gpu_model, golden_dir):
-    """fc_math_mode "f32x6" (default) vs "f32": same proposals bit for bit (the RPN does not depend on fc1 / fc2), class
-    probabilities within 1e-5, the same detections; and both reproduce the reference's golden detections."""
-    assert gpu_model.fc_math_mode == "f32x6"
+    """fc_math_mode "f32x3" (default since the f32x3 kernels), "f32x6", "f32", "f32x6_v1": same proposals bit for bit (the RPN does not
+    depend on fc1 / fc2), class probabilities within 1e-5, the same detections; and all reproduce the reference's golden detections."""
+    assert gpu_model.fc_math_mode == "f32x3"
     g = np.load(os.path.join(golden_dir, "vgg16_600x1000_s0.npz"))
     img = synthetic.image(0).unsqueeze(0).cuda()
     out = {}
     try:
-        for mode in ("f32x6", "f32", "f32x6_v1"):
+        for mode in ("f32x6", "f32", "f32x6_v1", "f32x3"):
             gpu_model.fc_math_mode = mode
             out[mode] = (gpu_model(image_data=img), gpu_model.predict(image_data=img, score_threshold=0.05))
     finally:
-        gpu_model.fc_math_mode = "f32x6"
+        gpu_model.fc_math_mode = "f32x3"
     (p6, c6, d6), det6 = out["f32x6"]
     (p32, c32, d32), det32 = out["f32"]
     assert torch.equal(p6, p32)
@@ -106,7 +106,9 @@ def test_model_fc_modes_agree_and_both_reproduce_the_golden_vectors(gpu_model, g
     ref = g["detections"]
     (pv, cv, dv), detv = out["f32x6_v1"]
     assert torch.equal(pv, p6) and float((cv - c6).abs().max()) <= 1e-5          # round 2's kernel, same arithmetic, another summation order
-    for mode, det in (("f32x6", det6), ("f32", det32), ("f32x6_v1", detv)):
+    (p3, c3, d3), det3 = out["f32x3"]
+    assert torch.equal(p3, p6) and float((c3 - c32).abs().max()) <= 1e-5 and float((d3 - d32).abs().max()) <= 2e-5 * max(1.0, float(d32.abs().max()))
+    for mode, det in (("f32x6", det6), ("f32", det32), ("f32x6_v1", detv), ("f32x3", det3)):
         n_ok = 0
         for c in range(1, 21):
             r = ref[ref[:, 0] == c][:, 1:]
@@ -160,7 +162,7 @@ def test_model_with_more_than_320_proposals_runs_in_the_x6_arithmetic(sd_cpu):
     model.load_state_dict(sd_cpu, strict=True)
     model = model.cuda().eval()
     model.max_proposals_post_nms = 400
-    assert model.fc_math_mode == "f32x6" and model._effective_fc_math() == "f32x6"
+    assert model.fc_math_mode == "f32x3" and model._effective_fc_math() == "f32x3"      # the tile-record GEMMs take any number of rows
     img = synthetic.image(4, 448, 640).unsqueeze(0)
     p, c, d = model(image_data=img.cuda())
     rp, rc, rd = O.forward(sd_cpu, img, post_nms=400)

@@ -253,7 +253,8 @@ def test_model_layer_table_x6_vs_float32_winograd(gpu_model):
             t = ctx.timing_read(reset=True)
             ctx.timing_enable(False)
             out[name] = (p, c, d, fm, t)
-            # the table is honoured: one bf16-pipe GEMM launch (+ at most one split-K reduction) and two transforms per x6 layer
+            # the table is honoured: one bf16- / fp16-pipe GEMM launch (+ at most one split-K reduction) and two timed transform steps per
+            # x6 layer (a layer in the f32x3 arithmetic times its channel-maximum pass together with its input transform)
             n6 = len(layers)
             assert n6 <= t["winograd_x6_gemm"][1] <= 2 * n6 and t["winograd_x6_transforms"][1] == 2 * n6
             assert t["winograd_gemm"][1] == 13 - n6
