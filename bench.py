@@ -10,11 +10,15 @@ resident in HBM when the timed region starts: VGG-16 backbone, RPN (6000 pre- / 
 RoI pooling, FC head, on-device float64 decode + per-class NMS, one D2H copy of the detections.
 Every image is an independent batch-1 forward (BASELINE.json configs[1]); `--inflight` of them (default 3)
 are in flight on separate HIP streams (GPU_MAX_HW_QUEUES=16 unless the environment says otherwise).  float32 tensors end to end (the
-reference's dtype).  WHICH matrix pipe every GEMM-shaped layer runs on is part of the JSON line (`layer_arithmetic`, `fc_math`,
-`f32_pipe_tflops`, `bf16_pipe_tflops`): the 3x3 convolutions on the exact-f32 MFMA pipe as one-launch Winograd F(2x2,3x3) layers
-(`math`), fc1 / fc2 by default in the "f32x6" arithmetic -- every f32 operand split exactly into three bf16 terms, six bf16 MFMAs
-per product, f32 accumulation, dropped terms <= 2^-24 relative (fp32-class accuracy, tests/test_linear_x6_gpu.py) -- and the 1x1 / head
-GEMMs on the exact-f32 pipe.  `fc_math_f32_images_per_sec` is the same workload with fc1 / fc2 on the exact-f32 pipe as well.
+reference's dtype).  WHICH matrix instructions every GEMM-shaped layer runs on is part of the JSON line (`layer_arithmetic`, `fc_math`,
+`winograd_x6_layers`, `winograd_x3_layers`, `f32_pipe_tflops` / `bf16_pipe_tflops` / `f16_pipe_tflops`): the 3x3 convolutions up to conv3_3
+on the exact-f32 MFMA pipe as one-launch Winograd F(2x2,3x3) layers (`math`); the 512-channel layers as Winograd layers whose GEMMs run
+in a split-operand arithmetic -- "f32x6" (conv4_x: every f32 operand split exactly into three bf16 terms, six bf16 MFMAs per product,
+dropped terms <= 2^-24 relative) or "f32x3" (conv5_x, the RPN trunk, fc1 / fc2: two fp16 terms per row-scaled operand, three fp16
+MFMAs per product, operands held to 22-23 bits of their row's largest element) -- both with f32 accumulation and an error against
+float64 within the exact-f32 kernel's (tests/test_wino_x6_gpu.py, tests/test_gemm_x3t_gpu.py); the 1x1 / head GEMMs on the exact-f32
+pipe.  Secondary legs of the same workload: `fc_math_f32_images_per_sec` (fc1 / fc2 on the exact-f32 pipe), `winograd_all_f32_pipe_
+images_per_sec` (every 3x3 layer too), `f32x6_only_images_per_sec` (no f32x3 layer), `f32x3_all_layers_images_per_sec` (conv4_x as well).
 
 Multi-GPU: image-parallel, rank r owns its own images, no data-path collective; weak scaling
 (K steps per rank).  The mAP@0.5 bookkeeping runs after the timed region on a small labelled

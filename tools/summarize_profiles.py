@@ -43,7 +43,7 @@ def main(d):
         for r in sstats[:20]:
             print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                      float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
-        for fam in ("wino_fused_kernel", "gemm_x6t_kernel", "wino_input_x6t_kernel", "wino_output_kernel", "linear_x6_kernel", "linear_mfma_kernel",
+        for fam in ("wino_fused_kernel", "gemm_x6t_kernel", "gemm_x3t_kernel", "wino_input_x6t_kernel", "wino_input_x3t_kernel", "wino_output_kernel", "linear_x6_kernel", "linear_mfma_kernel",
                     "conv3x3_mfma_kernel"):
             f_ns = sum(float(r["TotalDurationNs"]) for r in sstats if fam in r["Name"])
             f_calls = sum(int(r["Calls"]) for r in sstats if fam in r["Name"])
@@ -79,7 +79,7 @@ def main(d):
     if kt:
         agg = collections.defaultdict(list)
         for r in kt:
-            if any(x in r["Kernel_Name"] for x in ("conv3x3_mfma", "linear_mfma", "wino_fused", "linear_x6", "gemm_x6t")):
+            if any(x in r["Kernel_Name"] for x in ("conv3x3_mfma", "linear_mfma", "wino_fused", "linear_x6", "gemm_x6t", "gemm_x3t")):
                 key = (short(r["Kernel_Name"]), r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
                 agg[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         print("## MFMA kernels by grid (threads x, blocks y, z), multi-stream run\n")
@@ -98,7 +98,7 @@ def main(d):
         for r in rows:
             k = short(r["Kernel_Name"])
             if not any(x in k for x in ("conv3x3", "linear_", "wino_", "roi_", "topk", "nms_", "detections", "splitk", "conv_splitk", "split_rows",
-                                        "gemm_x6t", "conv_gather", "split_pixels", "split_patches")):
+                                        "gemm_x6t", "gemm_x3t", "conv_gather", "split_pixels", "split_patches")):
                 continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k].add(r["Dispatch_Id"])
@@ -134,6 +134,7 @@ def traffic(d):
     import json
     families = (("wino_fused_kernel", lambda n: "wino_fused_kernel" in n),
                 ("gemm_x6t_kernel", lambda n: "gemm_x6t_kernel" in n),
+                ("gemm_x3t_kernel", lambda n: "gemm_x3t_kernel" in n),
                 ("wino_input_x6t_kernel", lambda n: "wino_input_x6t_kernel" in n),
                 ("wino_output_kernel", lambda n: "wino_output_kernel" in n),
                 ("conv_gather_mfma_kernel", lambda n: "conv_gather_mfma_kernel" in n),
