@@ -273,7 +273,7 @@ X3_ALL_DETECTIONS = 193     # 600x1000 fixture crosses the NMS cut; the default 
 
 
 def test_model_x3_layer_tables_against_the_golden_vectors(gpu_model, golden_dir):
-    """The default table (conv5_x and the RPN trunk in f32x3; conv4_x in f32x6; fc1 / fc2 in f32x3) reproduces every
+    """The default table (every layer of the x6 table except conv5_1 in f32x3; fc1 / fc2 in f32x3) reproduces every
     golden proposal and detection (test_model_gpu.py runs with it).  Here: the two other tables -- no f32x3 layer at all, and the whole
     x6 table in f32x3 -- agree with it to float32 rounding and are held to the golden vectors at their observed numbers."""
     assert gpu_model.winograd_x3_layers == nv.DEFAULT_X3_LAYERS_VGG16

@@ -74,8 +74,20 @@ def gates(x3, fc):
     return out
 
 
-configs = [((), "f32x6"), ((), "f32x3")] + [((n,), "f32x3") for n in X6]
-configs += [(("conv5_1", "conv5_2", "conv5_3", "rpn_trunk"), "f32x3"), (("conv4_1", "conv5_1", "conv5_2", "conv5_3", "rpn_trunk"), "f32x3"),
-            (("conv4_1", "conv5_1", "conv5_3", "rpn_trunk"), "f32x3"), (("conv5_1", "conv5_3", "rpn_trunk"), "f32x3"), (X6, "f32x3"), (X6, "f32x6")]
+base = ("conv5_1", "conv5_2", "conv5_3", "rpn_trunk")
+configs = [(base, "f32x3")]
+if len(sys.argv) > 1 and sys.argv[1] == "wide":
+    rest = ("conv4_1", "conv4_2", "conv4_3")
+    for r in range(1, 4):
+        for extra in itertools.combinations(rest, r):
+            configs.append((tuple(extra) + base, "f32x3"))
+    # tables without some of the conv5 / trunk layers but with conv4_2 / conv4_3
+    for drop in base:
+        configs.append((("conv4_2", "conv4_3") + tuple(n for n in base if n != drop), "f32x3"))
+        configs.append((("conv4_1", "conv4_2", "conv4_3") + tuple(n for n in base if n != drop), "f32x3"))
+    configs.append((("conv4_2", "conv4_3"), "f32x3"))
+    configs.append((("conv4_1", "conv4_2", "conv4_3"), "f32x3"))
+else:
+    configs = [((), "f32x6"), ((), "f32x3")] + [((n,), "f32x3") for n in X6] + configs + [(("conv4_1",) + base, "f32x3"), (X6, "f32x3"), (X6, "f32x6")]
 for x3, fc in configs:
     print("x3 = %-60s fc %s | %s" % (",".join(x3) or "-", fc, " | ".join(gates(x3, fc))))
