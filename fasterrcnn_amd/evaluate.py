@@ -112,6 +112,8 @@ def evaluate_stream(model, samples, score_threshold=0.05, inflight=4, rank=0, wo
             records.add(image_index, det, gt_boxes)
 
     batch = max(1, int(batch))
+    if batch > 1 and not getattr(model, "_is_resnet", False):
+        batch = 1               # VGG-16's layers fill the chip with one image: its images go in flight one by one
     if batch > 1:
         nlanes = max(1, int(inflight) // batch)
         group, lanes, state = [], [], {"lane": 0}             # lanes[i]: the lane of pending[i]
