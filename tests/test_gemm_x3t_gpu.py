@@ -268,8 +268,9 @@ def test_roi_pool_x3t_records_hold_the_pooled_values(gpu_model):
     assert float((c.sum(dim=1) - 1.0).abs().max()) <= 1e-5
 
 
-X3_ALL_PROPOSALS = 299      # observed with EVERY layer of the x6 table in f32x3 (conv4_2 / conv4_3 too): one near-tied proposal of the
-X3_ALL_DETECTIONS = 193     # 600x1000 fixture crosses the NMS cut; the default table keeps 300 / 300 and 194 / 194 (test_model_gpu.py)
+X3_ALL_PROPOSALS = 299      # observed with EVERY layer of the x6 table in f32x3: the same 300 rows in the same order, but the 599 px box of
+X3_ALL_DETECTIONS = 193     # golden proposal 38 comes out 1.04e-3 px off (1.7e-6 of its side) and counts as missed at the 1e-3 px gate, with
+                            # it one detection; the default table's worst coordinate is 0.92e-3 px (300 / 300, 194 / 194: test_model_gpu.py)
 
 
 def test_model_x3_layer_tables_against_the_golden_vectors(gpu_model, golden_dir):
@@ -311,5 +312,10 @@ def test_model_x3_layer_tables_against_the_golden_vectors(gpu_model, golden_dir)
     assert counts("default") == (300, len(ref)) and counts("none") == (300, len(ref))
     na, da = counts("all")
     assert na >= X3_ALL_PROPOSALS and da >= X3_ALL_DETECTIONS
+    # every table: the SAME proposals in the SAME order as the golden vector, coordinates within 1.5e-3 px (float32 noise on 600 px boxes)
+    for name in ("default", "none", "all"):
+        err = np.abs(res[name][0] - g["proposals"]).max(axis=1)
+        print("f32x3 table %-7s: row-by-row coordinate error max %.3g px, median %.3g px" % (name, err.max(), np.median(err)))
+        assert res[name][0].shape == g["proposals"].shape and err.max() <= 1.5e-3
     with pytest.raises(ValueError):
         gpu_model.winograd_x3_layers = ("conv1_2",)
