@@ -325,24 +325,25 @@ def resnet_conv_table(model, h=H, w=W, n_rois=300):
     rows.append(("backbone", "stem 7x7/s2", "conv7x7_s2_c3_kernel", "valu", 0.0, 2.0 * 147 * 64 * hh * ww))
     hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
 
-    def block(stage, tag, blk, n, hh, ww, x6, single):
+    def block(stage, tag, blk, n, hh, ww, x6, single, x3=False):
         cin, width, cout, st = blk.conv1.in_channels, blk.conv1.out_channels, blk.conv3.out_channels, blk.stride
         ho, wo = (hh - 1) // st + 1, (ww - 1) // st + 1
+        gk, gp, gf = ("gemm_x3t_kernel", "f16", 3.0) if x3 else ("gemm_x6t_kernel", "bf16", 6.0)     # f32x3: three fp16 MFMAs per product
 
         def one(name, ci, co, px, ok):
             alg = 2.0 * ci * co * px
             if x6 and wino and ok:
-                rows.append((stage, tag + name, "gemm_x6t_kernel", "bf16", 6.0 * alg, alg))
+                rows.append((stage, tag + name, gk, gp, gf * alg, alg))
             else:
                 rows.append((stage, tag + name, "conv_gather_mfma_kernel", "f32", alg, alg))
         one(".conv1", cin, width, n * hh * ww, R.x6_conv1x1_ok(cin, width))
         alg = 2.0 * 9 * width * width * n * ho * wo
         if x6 and wino and not single and width >= 256:
             if st == 1:
-                rows.append((stage, tag + ".conv2", "gemm_x6t_kernel (x6 Winograd layer)", "bf16",
-                             6.0 * 2 * 16 * n * ((hh + 1) // 2) * ((ww + 1) // 2) * width * width, alg))
+                rows.append((stage, tag + ".conv2", gk + " (split-operand Winograd layer)", gp,
+                             gf * 2 * 16 * n * ((hh + 1) // 2) * ((ww + 1) // 2) * width * width, alg))
             else:
-                rows.append((stage, tag + ".conv2", "gemm_x6t_kernel (im2col)", "bf16", 6.0 * alg, alg))
+                rows.append((stage, tag + ".conv2", gk + " (im2col)", gp, gf * alg, alg))
         elif wino and st == 1 and single and width % 64 == 0:
             rows.append((stage, tag + ".conv2", "wino_fused_kernel", "f32", 2.0 * 16 * ((hh + 1) // 2) * ((ww + 1) // 2) * width * width, alg))
         elif wino and st == 1 and width >= 256 and width % 128 == 0:
@@ -358,11 +359,13 @@ def resnet_conv_table(model, h=H, w=W, n_rois=300):
     seq = fe._feature_extractor
     for li, layer in ((1, seq[4]), (2, seq[5]), (3, seq[6])):
         for bi, blk in enumerate(layer):
-            hh, ww = block("backbone", "layer%d.%d" % (li, bi), blk, 1, hh, ww, fe.x6_conv1x1, True)
+            hh, ww = block("backbone", "layer%d.%d" % (li, bi), blk, 1, hh, ww, fe.x6_conv1x1, True, getattr(fe, "x3", False))
     c = 1024
     alg = 2.0 * 9 * c * c * hh * ww
     if wino and "rpn_trunk" in model.winograd_x6_layers:
-        rows.append(("rpn", "rpn_trunk", "gemm_x6t_kernel (x6 Winograd layer)", "bf16", 6.0 * 2 * 16 * ((hh + 1) // 2) * ((ww + 1) // 2) * c * c, alg))
+        t3 = "rpn_trunk" in getattr(model, "winograd_x3_layers", ())
+        rows.append(("rpn", "rpn_trunk", ("gemm_x3t_kernel" if t3 else "gemm_x6t_kernel") + " (split-operand Winograd layer)", "f16" if t3 else "bf16",
+                     (3.0 if t3 else 6.0) * 2 * 16 * ((hh + 1) // 2) * ((ww + 1) // 2) * c * c, alg))
     elif wino:
         rows.append(("rpn", "rpn_trunk", "wino_fused_kernel", "f32", 2.0 * 16 * ((hh + 1) // 2) * ((ww + 1) // 2) * c * c, alg))
     else:
@@ -370,7 +373,7 @@ def resnet_conv_table(model, h=H, w=W, n_rois=300):
     rows.append(("rpn", "rpn_heads_1x1", "linear_mfma_kernel", "f32", 2.0 * c * 45 * hh * ww, 2.0 * c * 45 * hh * ww))
     h4, w4 = 7, 7
     for bi, blk in enumerate(l4._layer4):
-        h4, w4 = block("head", "layer4.%d" % bi, blk, n_rois, h4, w4, l4.x6_conv1x1, False)
+        h4, w4 = block("head", "layer4.%d" % bi, blk, n_rois, h4, w4, l4.x6_conv1x1, False, getattr(l4, "x3", False))
     rows.append(("head", "detector_heads", "linear_mfma_kernel", "f32", n_rois * 2.0 * 2048 * 101, n_rois * 2.0 * 2048 * 101))
     return rows
 
@@ -395,7 +398,7 @@ def resnet_roofline_leg(model, image, dev, images=6):
     table = resnet_conv_table(model)
     by = {"conv3x3_mfma": 0.0, "winograd_gemm": 0.0, "linear_mfma": 0.0, "winograd_x6_gemm": 0.0}
     for stage, name, kern, pipe, ex, alg in table:
-        if kern.startswith("gemm_x6t"):
+        if kern.startswith("gemm_x6t") or kern.startswith("gemm_x3t"):
             by["winograd_x6_gemm"] += ex
         elif kern.startswith("wino_fused"):
             by["winograd_gemm"] += ex
@@ -406,7 +409,7 @@ def resnet_roofline_leg(model, image, dev, images=6):
     out = {"regime": "HIP events around every launch, one image at a time on one stream, median image of %d" % images,
            "ms_per_image_by_class": {k: round(v, 4) for k, v in med.items()}, "launches_by_class": launches, "classes": {}}
     for cls, peak, unit in (("conv3x3_mfma", PEAK_F32_MFMA_TFLOPS, "f32"), ("winograd_gemm", PEAK_F32_MFMA_TFLOPS, "f32"),
-                            ("linear_mfma", PEAK_F32_MFMA_TFLOPS, "f32"), ("winograd_x6_gemm", PEAK_BF16_MFMA_TFLOPS, "bf16")):
+                            ("linear_mfma", PEAK_F32_MFMA_TFLOPS, "f32"), ("winograd_x6_gemm", PEAK_BF16_MFMA_TFLOPS, "bf16 / fp16")):
         if med.get(cls, 0.0) > 0 and by[cls] > 0:
             ach = by[cls] / (med[cls] / 1e3) / 1e12
             out["classes"][cls] = {"pipe": unit, "executed_gflop_per_image": round(by[cls] / 1e9, 2), "ms_per_image": round(med[cls], 4),
@@ -414,7 +417,7 @@ def resnet_roofline_leg(model, image, dev, images=6):
     dom = max(out["classes"], key=lambda k: out["classes"][k]["ms_per_image"]) if out["classes"] else None
     kernel_of = {"conv3x3_mfma": "conv_gather_mfma_kernel (backbone 1x1 / strided convolutions, exact-f32 pipe)",
                  "winograd_gemm": "wino_fused_kernel (backbone 3x3 + RPN trunk)", "linear_mfma": "the head's float32 launches",
-                 "winograd_x6_gemm": "gemm_x6t_kernel (layer4's 1x1 convolutions, f32x6 on the bf16 pipe)"}
+                 "winograd_x6_gemm": "gemm_x3t_kernel / gemm_x6t_kernel (layer4's convolutions and the RPN trunk as split-operand GEMMs)"}
     if dom:
         out.update({"kernel": kernel_of[dom], "bound": "mfma", "achieved": out["classes"][dom]["achieved_tflops"], "peak": out["classes"][dom]["peak"],
                     "unit": "TFLOP/s", "frac": out["classes"][dom]["frac"], "traffic": measured_traffic("conv_gather_mfma_kernel")})
@@ -674,20 +677,31 @@ def main():
         run50(16)
         dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
         extra["resnet50_images_per_sec"] = round(args.steps / dt, 3)
-        extra["resnet50_config"] = ("ResNet-50 predict(), 3x600x1000, 8 batch-1 images in flight, math %s, x6_conv1x1=%s (the 1x1 convolutions of "
-                                    "layer4 as f32x6 GEMMs on the bf16 pipe; every golden proposal / detection reproduced), winograd_x6_layers=%s"
-                                    % (m50.math_mode, m50.x6_conv1x1, list(m50.winograd_x6_layers)))
-        # the same with every eligible 1x1 convolution (layer2 / layer3 too) and the RPN trunk on the bf16 pipe: faster, and a few
-        # near-tied RPN candidates swap at the NMS cut (296 / 300 golden proposals: tests/test_resnet_gpu.py::test_resnet50_x6_modes)
-        m50.x6_conv1x1, m50.winograd_x6_layers = "all", ("rpn_trunk",)
+        extra["resnet50_config"] = ("ResNet-50 predict(), 3x600x1000, 8 batch-1 images in flight, math %s, x6_conv1x1=%s in the %s arithmetic (the "
+                                    "convolutions of the per-RoI layer4 as split-operand GEMMs on the fp16 / bf16 matrix instructions), winograd_x6_layers=%s, "
+                                    "winograd_x3_layers=%s; every golden proposal / detection reproduced"
+                                    % (m50.math_mode, m50.x6_conv1x1, m50.x6_conv1x1_arith, list(m50.winograd_x6_layers), list(m50.winograd_x3_layers)))
+        d50 = dict(x6_conv1x1=m50.x6_conv1x1, x6_conv1x1_arith=m50.x6_conv1x1_arith, winograd_x6_layers=m50.winograd_x6_layers,
+                   winograd_x3_layers=m50.winograd_x3_layers)
+
+        def set50(**kw):
+            for k_, v_ in kw.items():
+                setattr(m50, k_, v_)
+        # the same with every eligible 1x1 convolution of the backbone (layer2 / layer3) as a split-operand GEMM too
+        set50(x6_conv1x1="all")
         run50(16)
         dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
         extra["resnet50_x6_all_images_per_sec"] = round(args.steps / dt, 3)
-        m50.x6_conv1x1, m50.winograd_x6_layers = "off", ()
+        # the default of the first half of round 3: layer4 in f32x6, RPN trunk on the float32 one-launch Winograd kernel
+        set50(x6_conv1x1="head", x6_conv1x1_arith="f32x6", winograd_x6_layers=(), winograd_x3_layers=())
+        run50(16)
+        dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
+        extra["resnet50_f32x6_head_images_per_sec"] = round(args.steps / dt, 3)
+        set50(x6_conv1x1="off")
         run50(16)
         dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
         extra["resnet50_all_f32_pipe_images_per_sec"] = round(args.steps / dt, 3)
-        m50.x6_conv1x1, m50.winograd_x6_layers = "head", ()
+        set50(**d50)
         # configs[2] as a TRUE batch: 8 images through one pass of the feature extractor (frcnn_resnet_backbone: every bottleneck launch
         # covers the 8 maps), RPN + head per image on 8 streams behind it; two batches in flight
         try:
@@ -709,17 +723,17 @@ def main():
             dt, _ = timed_median(run50b, steps_b, min(args.min_timed_seconds, 0.5))
             extra["resnet50_batch8_images_per_sec"] = round(steps_b / dt, 3)
             extra["resnet50_batch8_config"] = ("the same model and images as resnet50_images_per_sec as batches of 8 (model.predict_batch_async): one "
-                                               "feature-extractor pass per batch, two batches in flight; x6_conv1x1=head")
-            m50.x6_conv1x1, m50.winograd_x6_layers = "all", ("rpn_trunk",)
+                                               "feature-extractor pass per batch, two batches in flight; default modes")
+            set50(x6_conv1x1="all")
             run50b(32)
             dt, _ = timed_median(run50b, steps_b, min(args.min_timed_seconds, 0.5))
             extra["resnet50_batch8_x6_all_images_per_sec"] = round(steps_b / dt, 3)
-            m50.x6_conv1x1, m50.winograd_x6_layers = "head", ()
+            set50(**d50)
             m50._lanes.clear()
             del batch50
         except Exception as e:
             extra["resnet50_batch8_images_per_sec"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            m50.x6_conv1x1, m50.winograd_x6_layers = "head", ()
+            set50(**d50)
         try:
             extra["resnet50_roofline"] = resnet_roofline_leg(m50, pool50[0], dev)
         except Exception as e:

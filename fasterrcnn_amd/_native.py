@@ -43,6 +43,7 @@ SYMBOLS = (
     "frcnn_x6t_record_bytes", "frcnn_split_rows_x6t", "frcnn_gemm_x6t_workspace_bytes", "frcnn_gemm_x6t", "frcnn_split_pixels_x6t", "frcnn_split_patches3x3_x6t",
     "frcnn_conv3x3_uses_winograd_x6", "frcnn_conv3x3_winograd_x6_pack_bytes", "frcnn_pack_conv3x3_winograd_x6",
     "frcnn_conv3x3_winograd_x6_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x6",
+    "frcnn_pixel_absmax", "frcnn_split_pixels_x3t", "frcnn_split_patches3x3_x3t",
     "frcnn_x3t_blob_bytes", "frcnn_pack_rows_x3t", "frcnn_conv3x3_winograd_x3_pack_bytes", "frcnn_pack_conv3x3_winograd_x3",
     "frcnn_conv3x3_winograd_x3_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x3",
     "frcnn_x3t_record_bytes", "frcnn_rows_scale_x3t", "frcnn_split_rows_x3t", "frcnn_gemm_x3t_workspace_bytes", "frcnn_gemm_x3t",
@@ -83,7 +84,7 @@ RESNET_MAX_BLOCKS = 64
 class BottleneckWeights(C.Structure):
     _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
                 ("w3", C.c_void_p), ("b3", C.c_void_p), ("wd", C.c_void_p), ("bd", C.c_void_p),
-                ("cin", C.c_int32), ("width", C.c_int32), ("cout", C.c_int32), ("stride", C.c_int32), ("x6_mask", C.c_int32)]
+                ("cin", C.c_int32), ("width", C.c_int32), ("cout", C.c_int32), ("stride", C.c_int32), ("x6_mask", C.c_int32), ("x3_mask", C.c_int32)]
 
 
 class ResNetWeights(C.Structure):
@@ -241,6 +242,9 @@ _SIGNATURES = {
     "frcnn_resnet_forward_features": (C.c_int, [_vp, C.POINTER(ResNetWeights), C.POINTER(ForwardParams), _vp, _i, _i,
                                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "frcnn_resnet_backbone": (C.c_int, [_vp, C.POINTER(ResNetWeights), C.POINTER(ForwardParams), _vp, _i, _i, _i, _vp, _vp]),
+    "frcnn_pixel_absmax": (C.c_int, [_vp, _vp, C.c_longlong, _i, _vp]),
+    "frcnn_split_pixels_x3t": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "frcnn_split_patches3x3_x3t": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "frcnn_x3t_blob_bytes": (C.c_size_t, [_i, _i, _i]),
     "frcnn_pack_rows_x3t": (C.c_int, [_vp, _i, _sz, _vp, _i, _i, _i, _i, _vp]),
     "frcnn_conv3x3_winograd_x3_pack_bytes": (C.c_size_t, [_i, _i]),

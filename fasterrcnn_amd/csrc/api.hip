@@ -46,6 +46,7 @@ struct frcnn_ctx {
     void* wx_ws = nullptr; size_t wx_ws_bytes = 0;       // V records, M and split-K partials of the x6 Winograd layers; allocated on first use
     void* rx_rec = nullptr; size_t rx_rec_bytes = 0;     // activation records of the x6 1x1 convolutions (ResNet bottlenecks); on first use
     void* rx_ws = nullptr; size_t rx_ws_bytes = 0;       // their split-K partials
+    float* rx_aux = nullptr; size_t rx_aux_floats = 0;   // f32x3 form: row scales of the record array + channel maxima of the layer input
     float* res_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // ResNet bottleneck rotation
     size_t res_buf_floats = 0;
     int last_c = 512, last_vec = 4096, last_head_ld = 128;
@@ -328,6 +329,26 @@ int frcnn_gemm_x3t(const void* d_a_rec, const float* d_a_inv, int a_rows, size_t
     return launch_gemm_x3t(d_a_rec, d_a_inv, a_rows, a_batch_bytes, a_inv_batch_floats, d_b_rec, d_b_inv, b_rows, b_batch_bytes,
                            b_inv_batch_floats, d_bias, d_residual, d_c, ldc, c_batch_floats, M, N, K, batches, flags, d_ws, ws_bytes,
                            as_stream(stream));
+}
+
+int frcnn_pixel_absmax(const float* d_x, float* d_cmax, long long pixels, int c, void* stream)
+{
+    if (!d_x || !d_cmax) return FRCNN_EINVAL;
+    return launch_pixel_absmax(d_x, d_cmax, pixels, c, as_stream(stream));
+}
+
+int frcnn_split_pixels_x3t(const float* d_x, const float* d_cmax, void* d_rec, float* d_inv_scale, int n_maps, int H, int W, int c, int stride,
+                           int rows_padded, void* stream)
+{
+    if (!d_x || !d_rec) return FRCNN_EINVAL;
+    return launch_split_pixels_x3t(d_x, d_cmax, d_rec, d_inv_scale, n_maps, H, W, c, stride, rows_padded, as_stream(stream));
+}
+
+int frcnn_split_patches3x3_x3t(const float* d_x, const float* d_cmax, void* d_rec, float* d_inv_scale, int n_maps, int H, int W, int c,
+                               int stride, int rows_padded, void* stream)
+{
+    if (!d_x || !d_rec) return FRCNN_EINVAL;
+    return launch_split_patches3x3_x3t(d_x, d_cmax, d_rec, d_inv_scale, n_maps, H, W, c, stride, rows_padded, as_stream(stream));
 }
 
 size_t frcnn_x3t_blob_bytes(int rows_padded, int K, int batches)
@@ -821,6 +842,7 @@ void frcnn_ctx_destroy(frcnn_ctx* ctx)
     if (ctx->roi_rec) (void)hipFree(ctx->roi_rec);
     if (ctx->rx_rec) (void)hipFree(ctx->rx_rec);
     if (ctx->rx_ws) (void)hipFree(ctx->rx_ws);
+    if (ctx->rx_aux) (void)hipFree(ctx->rx_aux);
     delete ctx;
 }
 
@@ -932,7 +954,9 @@ int ensure_wx_ws(frcnn_ctx* c, size_t layer_need, hipStream_t s)
     }
     hipError_t e = hipMalloc(&c->wx_ws, need);
     if (e != hipSuccess) { set_hip_error(e); c->wx_ws = nullptr; return FRCNN_ENOMEM; }
-    e = hipMemset(c->wx_ws, 0, need);
+    // zeroed ON THE CALLER'S STREAM: the slots of in-flight images run on non-blocking streams, which a null-stream hipMemset is not
+    // ordered with (it could still be clearing the buffer while the first layer writes its records)
+    e = hipMemsetAsync(c->wx_ws, 0, need, s);
     if (e != hipSuccess) { set_hip_error(e); (void)hipFree(c->wx_ws); c->wx_ws = nullptr; return FRCNN_EHIP; }
     c->wx_ws_bytes = need;
     return FRCNN_OK;
@@ -940,7 +964,7 @@ int ensure_wx_ws(frcnn_ctx* c, size_t layer_need, hipStream_t s)
 
 // The activation record arrays of fc1 / fc2 (x6 modes of the VGG-16 detector): 53 MB at 320 rows, allocated and zeroed by the first
 // forward that needs them (ResNet models and fc_math_mode f32 never do).  The padding rows max_rois .. rec_rows - 1 stay zero.
-int ensure_fc_records(frcnn_ctx* c)
+int ensure_fc_records(frcnn_ctx* c, hipStream_t s)
 {
     if (c->roi_rec) return FRCNN_OK;
     // (sized for the x6 / x6t records, 6 bytes per value; the x3t records of FRCNN_FC_F32X3T need 4)
@@ -949,7 +973,7 @@ int ensure_fc_records(frcnn_ctx* c)
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, b1 + b2 + 2 * b3 + b4);
     if (e != hipSuccess) { set_hip_error(e); return FRCNN_ENOMEM; }
-    e = hipMemset(p, 0, b1 + b2 + 2 * b3 + b4);
+    e = hipMemsetAsync(p, 0, b1 + b2 + 2 * b3 + b4, s);     // on the caller's stream (see ensure_wx_ws)
     if (e != hipSuccess) { set_hip_error(e); (void)hipFree(p); return FRCNN_EHIP; }
     c->roi_rec = p;
     c->fc1_rec = static_cast<unsigned char*>(p) + b1;
@@ -1108,7 +1132,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     const bool fc_x6t = p->fc_math_mode == FRCNN_FC_F32X6T;
     if (fc_x6 && R_ > FRCNN_LINEAR_X6_ROWS) return FRCNN_EUNSUPPORTED;
     const bool fc_x3t = p->fc_math_mode == FRCNN_FC_F32X3T;
-    if (fc_x6 || fc_x6t || fc_x3t) { rc = ensure_fc_records(c); if (rc) return rc; }
+    if (fc_x6 || fc_x6t || fc_x3t) { rc = ensure_fc_records(c, s); if (rc) return rc; }
     if (fc_x3t) {
         // fc1 / fc2 in the f32x3 arithmetic (csrc/gemm_x3t.hip): fc1_w / fc2_w = packed x3t operands (records of the 4096-row matrices, then
         // their row scales); RoIPool writes fc1's A records with one scale per RoI; fc1's float32 output is scaled and split again for fc2
@@ -1219,6 +1243,54 @@ int run_conv1x1_x6(frcnn_ctx* c, const float* x, const void* wrec, const float* 
     return launch_gemm_x6t(c->rx_rec, Mp, 0, wrec, Np, 0, bias, residual, y, cout, 0, M, cout, K, 1, flags, c->rx_ws, c->rx_ws_bytes, s);
 }
 
+// The same convolution in the f32x3 arithmetic (csrc/gemm_x3t.hip): wblob = frcnn_pack_rows_x3t of the [cout][K] matrix (records, then
+// the 2^-e of its rows); the activation rows are scaled per output pixel from a channel-maximum pass over the input.
+int run_conv1x1_x3(frcnn_ctx* c, const float* x, const void* wblob, const float* bias, const float* residual, float* y, int N, int h,
+                   int w, int cin, int cout, int stride, unsigned flags, int cls, hipStream_t s, int ksize = 1)
+{
+    if (cin % 16 != 0 || cout % 4 != 0 || (ksize != 1 && ksize != 3)) return FRCNN_EINVAL;
+    const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+    const int K = ksize == 3 ? 9 * cin : cin;
+    const long long rows = (long long)N * ho * wo;
+    if (rows > 0x7fffffffLL / 8) return FRCNN_EINVAL;
+    const int M = (int)rows;
+    const int Mp = cdiv(M, gemm_x6t_row_tile(M)) * gemm_x6t_row_tile(M), Np = cdiv(cout, gemm_x6t_col_tile(cout)) * gemm_x6t_col_tile(cout);
+    const size_t need = x3t_record_bytes(Mp, K), gneed = gemm_x3t_workspace_bytes(M, cout, K, 1);
+    const size_t aneed = (size_t)Mp + (size_t)N * h * w;
+    if (need > c->rx_rec_bytes) {
+        if (c->rx_rec) { FRCNN_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(c->rx_rec); c->rx_rec = nullptr; c->rx_rec_bytes = 0; }
+        hipError_t e = hipMalloc(&c->rx_rec, need);
+        if (e != hipSuccess) { set_hip_error(e); c->rx_rec = nullptr; return FRCNN_ENOMEM; }
+        c->rx_rec_bytes = need;
+    }
+    if (gneed > c->rx_ws_bytes) {
+        if (c->rx_ws) { FRCNN_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(c->rx_ws); c->rx_ws = nullptr; c->rx_ws_bytes = 0; }
+        hipError_t e = hipMalloc(&c->rx_ws, gneed);
+        if (e != hipSuccess) { set_hip_error(e); c->rx_ws = nullptr; return FRCNN_ENOMEM; }
+        c->rx_ws_bytes = gneed;
+    }
+    if (aneed > c->rx_aux_floats) {
+        if (c->rx_aux) { FRCNN_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(c->rx_aux); c->rx_aux = nullptr; c->rx_aux_floats = 0; }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->rx_aux), aneed * sizeof(float));
+        if (e != hipSuccess) { set_hip_error(e); c->rx_aux = nullptr; return FRCNN_ENOMEM; }
+        c->rx_aux_floats = aneed;
+    }
+    float* ainv = c->rx_aux;
+    float* cmax = c->rx_aux + Mp;
+    int rc;
+    {
+        Scope _t(c, 8, s);
+        rc = launch_pixel_absmax(x, cmax, (long long)N * h * w, cin, s);
+        if (!rc) rc = ksize == 3 ? launch_split_patches3x3_x3t(x, cmax, c->rx_rec, ainv, N, h, w, cin, stride, Mp, s)
+                                 : launch_split_pixels_x3t(x, cmax, c->rx_rec, ainv, N, h, w, cin, stride, Mp, s);
+    }
+    if (rc) return rc;
+    const float* winv = reinterpret_cast<const float*>(static_cast<const unsigned char*>(wblob) + x3t_record_bytes(Np, K));
+    Scope _g(c, cls, s);
+    return launch_gemm_x3t(c->rx_rec, ainv, Mp, 0, 0, wblob, winv, Np, 0, 0, bias, residual, y, cout, 0, M, cout, K, 1, flags, c->rx_ws,
+                           c->rx_ws_bytes, s);
+}
+
 // One Bottleneck (torchvision v1.5): out = relu(conv3(relu(conv2(relu(conv1(x))))) + identity).
 // x: [N][h][w][cin] in `cur`; returns the buffer index holding the output, updates h, w.
 // `backbone`: the block belongs to the feature extractor (layer1..3): its 3x3 is packed for the one-launch Winograd kernel whatever the
@@ -1242,16 +1314,22 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
     if (need1 > c->res_buf_floats || need2 > c->res_buf_floats) return FRCNN_EINVAL;
 #define RSTEP(call) do { Scope _sc(c, cls_conv, s); rc = (call); } while (0); if (rc) return rc
     if (b.x6_mask != 0 && !wino) return FRCNN_EINVAL;
+    if ((b.x3_mask & ~b.x6_mask) != 0) return FRCNN_EINVAL;          // x3_mask: the subset of the split-operand convolutions in f32x3
     if (b.x6_mask & FRCNN_X6_CONV1) {
-        rc = run_conv1x1_x6(c, X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, R, 9, s);
+        rc = (b.x3_mask & FRCNN_X6_CONV1) ? run_conv1x1_x3(c, X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, R, 9, s)
+                                          : run_conv1x1_x6(c, X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, R, 9, s);
         if (rc) return rc;
     } else {
         RSTEP(launch_conv_gather(X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s));
     }
     if (b.x6_mask & FRCNN_X6_CONV2) {
         // the 3x3 on the bf16 pipe: stride 1 = an x6 Winograd layer over the block's N maps, stride 2 = an im2col GEMM (K = 9 width)
-        rc = b.stride == 1 ? run_wino_x6_layer(c, T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s, N)
-                           : run_conv1x1_x6(c, T1, b.w2, b.b2, nullptr, T2, N, h, w, b.width, b.width, b.stride, R, 9, s, 3);
+        if (b.x3_mask & FRCNN_X6_CONV2)
+            rc = b.stride == 1 ? run_wino_x3_layer(c, T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s, N)
+                               : run_conv1x1_x3(c, T1, b.w2, b.b2, nullptr, T2, N, h, w, b.width, b.width, b.stride, R, 9, s, 3);
+        else
+            rc = b.stride == 1 ? run_wino_x6_layer(c, T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s, N)
+                               : run_conv1x1_x6(c, T1, b.w2, b.b2, nullptr, T2, N, h, w, b.width, b.width, b.stride, R, 9, s, 3);
         if (rc) return rc;
     } else if (wino && resnet_block_uses_winograd_fused(pack_maps, b.width, b.stride)) {
         rc = run_wino_fused_layer(c, latency, T1, b.w2, b.b2, T2, h, w, b.width, b.width, R, s, N);
@@ -1272,7 +1350,8 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
     const float* identity = X;
     if (b.wd) {
         if (b.x6_mask & FRCNN_X6_DOWN) {
-            rc = run_conv1x1_x6(c, X, b.wd, b.bd, nullptr, ID, N, h, w, b.cin, b.cout, b.stride, 0u, 9, s);
+            rc = (b.x3_mask & FRCNN_X6_DOWN) ? run_conv1x1_x3(c, X, b.wd, b.bd, nullptr, ID, N, h, w, b.cin, b.cout, b.stride, 0u, 9, s)
+                                             : run_conv1x1_x6(c, X, b.wd, b.bd, nullptr, ID, N, h, w, b.cin, b.cout, b.stride, 0u, 9, s);
             if (rc) return rc;
         } else {
             RSTEP(launch_conv_gather(X, b.wd, b.bd, nullptr, ID, N, h, w, b.cin, b.cout, 1, b.stride, 0, 0u,
@@ -1283,7 +1362,8 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
         return FRCNN_EINVAL;
     }
     if (b.x6_mask & FRCNN_X6_CONV3) {
-        rc = run_conv1x1_x6(c, T2, b.w3, b.b3, identity, OUT, N, ho, wo, b.width, b.cout, 1, R, 9, s);
+        rc = (b.x3_mask & FRCNN_X6_CONV3) ? run_conv1x1_x3(c, T2, b.w3, b.b3, identity, OUT, N, ho, wo, b.width, b.cout, 1, R, 9, s)
+                                          : run_conv1x1_x6(c, T2, b.w3, b.b3, identity, OUT, N, ho, wo, b.width, b.cout, 1, R, 9, s);
         if (rc) return rc;
     } else {
         RSTEP(launch_conv_gather(T2, b.w3, b.b3, identity, OUT, N, ho, wo, b.width, b.cout, 1, 1, 0, R,
@@ -1314,7 +1394,7 @@ int resnet_check_weights(const frcnn_resnet_weights* w, bool with_heads)
 
 int resnet_check_params(const frcnn_forward_params* p)
 {
-    if (p->winograd_x3_mask != 0) return FRCNN_EUNSUPPORTED;                       // the ResNet x6 layers have no f32x3 form yet
+    if ((p->winograd_x3_mask & ~p->winograd_x6_mask) != 0) return FRCNN_EINVAL;    // (only the RPN trunk bit exists for ResNet)
     if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32_WINOGRAD) return FRCNN_EUNSUPPORTED;   // no f32x6 ResNet path
     if ((p->roi_op != FRCNN_ROI_POOL && p->roi_op != FRCNN_ROI_ALIGN) || p->roi_sampling_ratio > 2) return FRCNN_EINVAL;
     if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
@@ -1366,7 +1446,8 @@ int resnet_tail(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward
     c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms; c->last_c = C;
     if (p->winograd_x6_mask != 0 && (!wino || p->winograd_x6_mask != (1 << FRCNN_X6_RPN_TRUNK_BIT))) return FRCNN_EINVAL;
     if (wino && p->winograd_x6_mask) {
-        rc = run_wino_x6_layer(c, c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU, s);
+        rc = p->winograd_x3_mask ? run_wino_x3_layer(c, c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU, s)
+                                 : run_wino_x6_layer(c, c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU, s);
         if (rc) return rc;
     } else if (wino && conv3x3_uses_winograd_fused(C, C)) {
         rc = run_wino_fused_layer(c, p->conv_blocks_target == 0, c->fm, w->rpn_conv_w, w->rpn_conv_b, c->rpn_trunk, fh, fw, C, C, FRCNN_RELU, s);

@@ -160,6 +160,10 @@ int launch_rows_scale_x3t(const float* a, int lda, size_t a_batch_floats, float*
                           hipStream_t s);
 int launch_split_rows_x3t(const float* a, int lda, size_t a_batch_floats, const float* inv_scale, void* rec, int R, int rows_padded, int K,
                           int batches, hipStream_t s);
+int launch_split_pixels_x3t(const float* x, const float* cmax, void* rec, float* inv, int N, int H, int W, int C, int stride, int rows_padded,
+                            hipStream_t s);
+int launch_split_patches3x3_x3t(const float* x, const float* cmax, void* rec, float* inv, int N, int H, int W, int C, int stride,
+                                int rows_padded, hipStream_t s);
 size_t gemm_x3t_workspace_bytes(int M, int N, int K, int batches);
 int launch_gemm_x3t(const void* a_rec, const float* a_inv, int a_rows, size_t a_batch_bytes, size_t a_inv_batch, const void* b_rec,
                     const float* b_inv, int b_rows, size_t b_batch_bytes, size_t b_inv_batch, const float* bias, const float* residual,

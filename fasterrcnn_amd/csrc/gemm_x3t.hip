@@ -83,6 +83,81 @@ void split_rows_x3t_kernel(const float* __restrict__ a, int lda, size_t a_batch,
     *reinterpret_cast<uint4*>(dst + HX_PIECE) = pl;
 }
 
+// NHWC [N][H][W][C] -> x3t records of the [N Ho Wo][C] matrix of its pixels taken with `stride` (a 1x1 convolution's A operand), each row
+// scaled by the power of two that `cmax` (max_c |x| per INPUT pixel: launch_pixel_absmax) gives; inv[row] = 2^-e.  Waves as
+// split_pixels_x6t_kernel (csrc/gemm_x6t.hip).
+__global__ __launch_bounds__(256)
+void split_pixels_x3t_kernel(const float* __restrict__ x, const float* __restrict__ cmax, unsigned char* __restrict__ rec,
+                             float* __restrict__ inv_out, int H, int W, int Ho, int Wo, int C, int stride, int R, int rbt, int K16)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= (long long)K16 * rbt) return;
+    const int chunk = (int)(wave % K16), rb = (int)(wave / K16);
+    const int row = rb * 32 + (lane & 31), k = chunk * 16 + 8 * (lane >> 5);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float mult = 1.f, inv = 1.f;
+    if (row < R) {
+        const int n = row / (Ho * Wo), rem = row - n * (Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const size_t pix = ((size_t)n * H + (size_t)oy * stride) * W + (size_t)ox * stride;
+        hx_row_scale(cmax[pix], mult, inv);
+        const float* src = x + pix * C + k;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = v0[j] * mult; v[4 + j] = v1[j] * mult; }
+    }
+    if (chunk == 0 && lane < 32) inv_out[row] = inv;
+    uint4 ph, pl;
+    hx_split8(v, ph, pl);
+    unsigned char* dst = rec + ((size_t)chunk * rbt + rb) * HX_RB + lane * 16;
+    *reinterpret_cast<uint4*>(dst) = ph;
+    *reinterpret_cast<uint4*>(dst + HX_PIECE) = pl;
+}
+
+// im2col + split for a 3x3 convolution with padding 1 and stride 1 / 2 (split_patches3x3_x6t_kernel's rows and columns); a row's scale
+// comes from the largest channel maximum among its (up to nine) patch pixels.
+__global__ __launch_bounds__(256)
+void split_patches3x3_x3t_kernel(const float* __restrict__ x, const float* __restrict__ cmax, unsigned char* __restrict__ rec,
+                                 float* __restrict__ inv_out, int H, int W, int Ho, int Wo, int C, int stride, int R, int rbt, int K16)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= (long long)K16 * rbt) return;
+    const int chunk = (int)(wave % K16), rb = (int)(wave / K16);
+    const int row = rb * 32 + (lane & 31), k = chunk * 16 + 8 * (lane >> 5);
+    const int tap = k / C, c = k - tap * C;
+    const int tr = tap / 3, ts = tap - 3 * tr;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float mult = 1.f, inv = 1.f;
+    if (row < R) {
+        const int n = row / (Ho * Wo), rem = row - n * (Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        float mx = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int yy = oy * stride - 1 + a, xx = ox * stride - 1 + b;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) mx = fmaxf(mx, cmax[((size_t)n * H + yy) * W + xx]);
+            }
+        hx_row_scale(mx, mult, inv);
+        const int iy = oy * stride - 1 + tr, ix = ox * stride - 1 + ts;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const float* src = x + (((size_t)n * H + iy) * W + ix) * C + c;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = v0[j] * mult; v[4 + j] = v1[j] * mult; }
+        }
+    }
+    if (chunk == 0 && lane < 32) inv_out[row] = inv;
+    uint4 ph, pl;
+    hx_split8(v, ph, pl);
+    unsigned char* dst = rec + ((size_t)chunk * rbt + rb) * HX_RB + lane * 16;
+    *reinterpret_cast<uint4*>(dst) = ph;
+    *reinterpret_cast<uint4*>(dst + HX_PIECE) = pl;
+}
+
 struct HxParams {
     const unsigned char* a;     // A records: [batch][chunk][a_rbt][2][1 KB]
     const unsigned char* b;     // B records: [batch][chunk][b_rbt][2][1 KB]
@@ -328,6 +403,33 @@ int launch_split_rows_x3t(const float* a, int lda, size_t a_batch_floats, const 
     if (blocks > 0x7fffffffLL) return FRCNN_EINVAL;
     hipLaunchKernelGGL(split_rows_x3t_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, lda, a_batch_floats, inv_scale,
                        static_cast<unsigned char*>(rec), R, rows_padded / 32, K / 16, batches);
+    return check_launch();
+}
+
+// cmax: N * H * W floats (launch_pixel_absmax of x); inv: rows_padded floats out
+int launch_split_pixels_x3t(const float* x, const float* cmax, void* rec, float* inv, int N, int H, int W, int C, int stride, int rows_padded,
+                            hipStream_t s)
+{
+    if (N < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || stride < 1 || stride > 2 || rows_padded % 32 != 0 || !cmax || !inv) return FRCNN_EINVAL;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long long R = (long long)N * Ho * Wo;
+    if (R > rows_padded || R > 0x7fffffffLL) return FRCNN_EINVAL;
+    const long long waves = (long long)(C / 16) * (rows_padded / 32);
+    hipLaunchKernelGGL(split_pixels_x3t_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, cmax, static_cast<unsigned char*>(rec),
+                       inv, H, W, Ho, Wo, C, stride, (int)R, rows_padded / 32, C / 16);
+    return check_launch();
+}
+
+int launch_split_patches3x3_x3t(const float* x, const float* cmax, void* rec, float* inv, int N, int H, int W, int C, int stride,
+                                int rows_padded, hipStream_t s)
+{
+    if (N < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || stride < 1 || stride > 2 || rows_padded % 32 != 0 || !cmax || !inv) return FRCNN_EINVAL;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long long R = (long long)N * Ho * Wo;
+    if (R > rows_padded || R > 0x7fffffffLL) return FRCNN_EINVAL;
+    const long long waves = (long long)(9 * C / 16) * (rows_padded / 32);
+    hipLaunchKernelGGL(split_patches3x3_x3t_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, cmax,
+                       static_cast<unsigned char*>(rec), inv, H, W, Ho, Wo, C, stride, (int)R, rows_padded / 32, 9 * C / 16);
     return check_launch();
 }
 

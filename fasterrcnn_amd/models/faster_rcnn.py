@@ -133,8 +133,10 @@ class FasterRCNNModel(nn.Module):
         # ResNet-50 fixture), "off" = rounds 1-2's exact-f32 gather kernel everywhere
         self._x6_conv1x1 = "off"
         self.x6_conv1x1 = "head" if self._is_resnet else "off"
+        self._x6_conv1x1_arith = "f32x6"
+        self.x6_conv1x1_arith = "f32x3" if self._is_resnet else "f32x6"
         self._winograd_x6_layers = ()
-        self.winograd_x6_layers = () if self._is_resnet else nv.DEFAULT_X6_LAYERS_VGG16
+        self.winograd_x6_layers = ("rpn_trunk",) if self._is_resnet else nv.DEFAULT_X6_LAYERS_VGG16
         # arithmetic of the VGG-16 detector's fc1 / fc2 (models/vgg16.py:130-132): "f32" = exact f32 MFMA; "f32x6" = exactly split
         # bf16x3 operands, six bf16 MFMAs per product, f32 accumulation (csrc/linear_x6.hip) -- fp32-class accuracy (dropped terms
         # <= 2^-24 relative) at 2.67x the matrix-pipe rate; the default wherever it applies (ResNet heads have no fc1 / fc2)
@@ -144,7 +146,7 @@ class FasterRCNNModel(nn.Module):
         # operand, three MFMAs per product (csrc/wino_x3.hip) -- half the matrix instructions of f32x6, operands held to 22-23 bits
         # relative to their row's largest element; error against float64 within the exact-f32 kernel's (tests/test_gemm_x3t_gpu.py)
         self._winograd_x3_layers = ()
-        self.winograd_x3_layers = () if self._is_resnet else nv.DEFAULT_X3_LAYERS_VGG16
+        self.winograd_x3_layers = ("rpn_trunk",) if self._is_resnet else nv.DEFAULT_X3_LAYERS_VGG16
 
         # hipGraph replay of one image's ~33 launches (forward + detections + the D2H copies): the second consecutive call of a slot with
         # the same (shape, thresholds, weights, modes) captures them into a graph on the slot's stream, later calls copy the image
@@ -205,6 +207,23 @@ class FasterRCNNModel(nn.Module):
             self._stage3_detector_network._pool_to_feature_vector.x6_conv1x1 = mode in ("head", "all")
 
     @property
+    def x6_conv1x1_arith(self):
+        return self._x6_conv1x1_arith
+
+    @x6_conv1x1_arith.setter
+    def x6_conv1x1_arith(self, arith):
+        """ResNet: the arithmetic of the convolutions `x6_conv1x1` names: "f32x6" (three bf16 terms per operand, six MFMAs per product) or
+        "f32x3" (two fp16 terms per row-scaled operand, three MFMAs per product: csrc/gemm_x3t.hip, csrc/wino_x3.hip)."""
+        if arith not in ("f32x6", "f32x3"):
+            raise ValueError("x6_conv1x1_arith must be 'f32x6' or 'f32x3'")
+        if arith != "f32x6" and not self._is_resnet:
+            raise NotImplementedError("x6_conv1x1_arith applies to the ResNet bottlenecks (VGG-16: winograd_x3_layers, fc_math_mode)")
+        self._x6_conv1x1_arith = arith
+        if self._is_resnet:
+            self._stage1_feature_extractor.x3 = arith == "f32x3"
+            self._stage3_detector_network._pool_to_feature_vector.x3 = arith == "f32x3"
+
+    @property
     def winograd_x6_layers(self):
         return self._winograd_x6_layers
 
@@ -248,9 +267,7 @@ class FasterRCNNModel(nn.Module):
         """The layers of the x6 table whose GEMMs run in the f32x3 arithmetic; a name that is not (or no longer) in winograd_x6_layers has
         no effect until it is (the table of a layer is: float32 one-launch Winograd | f32x6 | f32x3)."""
         names = tuple(names)
-        if names and self._is_resnet:
-            raise NotImplementedError("the ResNet x6 layers have no f32x3 form")
-        allowed = tuple(n for n in nv.X6_LAYER_BITS if n.startswith(("conv4", "conv5", "conv3_2", "conv3_3", "rpn")))
+        allowed = ("rpn_trunk",) if self._is_resnet else tuple(n for n in nv.X6_LAYER_BITS if n.startswith(("conv4", "conv5", "conv3_2", "conv3_3", "rpn")))
         for n in names:
             if n not in allowed:
                 raise ValueError("winograd_x3_layers: %r cannot run as an x6 / x3 Winograd layer (choices: %s)" % (n, ", ".join(allowed)))
@@ -261,10 +278,9 @@ class FasterRCNNModel(nn.Module):
         return tuple(n for n in self._winograd_x3_layers if n in self._winograd_x6_layers)
 
     def _apply_x3(self):
-        if self._is_resnet:
-            return
         eff = self._effective_x3_layers() if hasattr(self, "_winograd_x3_layers") else ()
-        self._stage1_feature_extractor.x3_layers = tuple(n for n in eff if n != "rpn_trunk")
+        if not self._is_resnet:
+            self._stage1_feature_extractor.x3_layers = tuple(n for n in eff if n != "rpn_trunk")
         self._stage2_region_proposal_network.x3_trunk = "rpn_trunk" in eff
 
     def _x3_mask(self):
@@ -342,6 +358,7 @@ class FasterRCNNModel(nn.Module):
                     setattr(bw, k, None if b[k] is None else b[k].data_ptr())
                 bw.cin, bw.width, bw.cout, bw.stride = b["cin"], b["width"], b["cout"], b["stride"]
                 bw.x6_mask = int(b.get("x6_mask", 0))
+                bw.x3_mask = int(b.get("x3_mask", 0))
             w.rpn_conv_w, w.rpn_conv_b, w.rpn_head_w, w.rpn_head_b = (x.data_ptr() for x in s2)
             w.head_w, w.head_b = (x.data_ptr() for x in hd)
             w.num_classes = self._num_classes

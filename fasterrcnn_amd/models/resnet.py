@@ -136,11 +136,19 @@ def records_x6t(wp, cout, cin):
     return rec
 
 
-def pack_block(block, math_mode="f32", single_map=False, x6=False):
+def blob_x3t(wp, cout, cin):
+    """folded float32 [1][cout][cin] pack -> the packed f32x3 operand (int8: records of the row-scaled [cout][cin] matrix, then its scales)."""
+    from .vgg16 import pack_rows_x3t
+    rows = (cout + nv.X6T_COL_TILE - 1) // nv.X6T_COL_TILE * nv.X6T_COL_TILE
+    return pack_rows_x3t(wp.reshape(cout, cin), rows)
+
+
+def pack_block(block, math_mode="f32", single_map=False, x6=False, x3=False):
     """dict of packed tensors + shape info for one Bottleneck.  single_map: the block runs on ONE map (layer1..3 of the feature
     extractor) -> its 3x3 is a one-launch Winograd layer in the f32_winograd mode; the per-RoI maps of layer4 use the batched form.
     x6 (f32_winograd mode only): the 1x1 convolutions with x6_conv1x1_ok() carry x6t record arrays instead of float32 packs
-    (`x6_mask` bits FRCNN_X6_CONV1 / _CONV3 / _DOWN) and run as f32x6 GEMMs on the bf16 pipe."""
+    (`x6_mask` bits FRCNN_X6_CONV1 / _CONV3 / _DOWN) and run as f32x6 GEMMs on the bf16 pipe; with x3 they carry f32x3 blobs instead
+    (`x3_mask` = `x6_mask`: two fp16 terms per row-scaled operand, three MFMAs per product, csrc/gemm_x3t.hip)."""
     w1, b1, k1 = fold_conv_bn(block.conv1, block.bn1)
     width = block.conv2.out_channels
     if math_mode == "f32_winograd" and nv.resnet_block_uses_winograd_fused(1 if single_map else 2, width, block.stride):
@@ -170,21 +178,31 @@ def pack_block(block, math_mode="f32", single_map=False, x6=False):
             with t.cuda.device(wsrc.device):
                 nv.check(lib.frcnn_bn_scale_shift(nv.ptr(args[0]), nv.ptr(args[1]), nv.ptr(args[2]), nv.ptr(args[3]), float(block.bn2.eps), width,
                                                   nv.ptr(scale), nv.ptr(shift), nv.stream_ptr()), "frcnn_bn_scale_shift")
-                nv.check(lib.frcnn_pack_conv3x3_winograd_x6(nv.ptr(wsrc), nv.ptr(scale), nv.ptr(rec), width, width, nv.stream_ptr()),
-                         "frcnn_pack_conv3x3_winograd_x6")
+                if x3:
+                    bank = t.empty((16, width, width), dtype=t.float32, device=wsrc.device)
+                    rec = t.empty((int(lib.frcnn_conv3x3_winograd_x3_pack_bytes(width, width)),), dtype=t.int8, device=wsrc.device)
+                    nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(wsrc), nv.ptr(scale), nv.ptr(bank), width, width, nv.stream_ptr()),
+                             "frcnn_pack_conv3x3_winograd")
+                    nv.check(lib.frcnn_pack_conv3x3_winograd_x3(nv.ptr(bank), nv.ptr(rec), width, width, nv.stream_ptr()),
+                             "frcnn_pack_conv3x3_winograd_x3")
+                else:
+                    nv.check(lib.frcnn_pack_conv3x3_winograd_x6(nv.ptr(wsrc), nv.ptr(scale), nv.ptr(rec), width, width, nv.stream_ptr()),
+                             "frcnn_pack_conv3x3_winograd_x6")
             out["w2"], out["b2"] = rec, shift
             out["keep"].append(args + [scale])
         else:
             wf, bf, kf = fold_conv_bn(block.conv2, block.bn2)                    # [9][cout][cin] folded float32
-            out["w2"] = records_x6t(wf.permute(1, 0, 2).reshape(width, 9 * width).contiguous(), width, 9 * width)
+            mat = wf.permute(1, 0, 2).reshape(width, 9 * width).contiguous()
+            out["w2"] = blob_x3t(mat, width, 9 * width) if x3 else records_x6t(mat, width, 9 * width)
             out["b2"] = bf
             out["keep"].append(kf)
         out["x6_mask"] |= 8
     if x6 and math_mode == "f32_winograd":
         for bit, key, ci, co in ((1, "w1", out["cin"], out["width"]), (2, "w3", out["width"], out["cout"]), (4, "wd", out["cin"], out["cout"])):
             if out[key] is not None and x6_conv1x1_ok(ci, co):
-                out[key] = records_x6t(out[key], co, ci)
+                out[key] = blob_x3t(out[key], co, ci) if x3 else records_x6t(out[key], co, ci)
                 out["x6_mask"] |= bit
+    out["x3_mask"] = out["x6_mask"] if x3 else 0
     return out
 
 
@@ -227,17 +245,55 @@ def conv1x1_x6(x, wrec, bp, n, h, w, cin, cout, stride, relu, residual=None):
     return y, ho, wo
 
 
+def conv_x3(x, wblob, bp, n, h, w, cin, cout, stride, relu, residual=None, ksize=1):
+    """1x1 (stride 1 / 2) or 3x3 / padding-1 convolution as an f32x3 GEMM: frcnn_pixel_absmax + frcnn_split_pixels_x3t /
+    frcnn_split_patches3x3_x3t + frcnn_gemm_x3t; returns (y, ho, wo)."""
+    lib = nv.lib()
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    k = cin * (9 if ksize == 3 else 1)
+    m = n * ho * wo
+    mp = (m + nv.X6T_ROW_TILE - 1) // nv.X6T_ROW_TILE * nv.X6T_ROW_TILE
+    np_ = (cout + nv.X6T_COL_TILE - 1) // nv.X6T_COL_TILE * nv.X6T_COL_TILE
+    rec = t.empty((int(lib.frcnn_x3t_record_bytes(mp, k)),), dtype=t.uint8, device=x.device)
+    inv = t.empty((mp,), dtype=t.float32, device=x.device)
+    cmax = t.empty((n * h * w,), dtype=t.float32, device=x.device)
+    y = t.empty((n, ho, wo, cout), dtype=t.float32, device=x.device)
+    wsb = int(lib.frcnn_gemm_x3t_workspace_bytes(m, cout, k, 1))
+    ws = t.empty((max(wsb, 4),), dtype=t.uint8, device=x.device)
+    wrec = int(lib.frcnn_x3t_record_bytes(np_, k))
+    with t.cuda.device(x.device):
+        nv.check(lib.frcnn_pixel_absmax(nv.ptr(x), nv.ptr(cmax), n * h * w, cin, nv.stream_ptr()), "frcnn_pixel_absmax")
+        split = lib.frcnn_split_patches3x3_x3t if ksize == 3 else lib.frcnn_split_pixels_x3t
+        nv.check(split(nv.ptr(x), nv.ptr(cmax), nv.ptr(rec), nv.ptr(inv), n, h, w, cin, stride, mp, nv.stream_ptr()), "frcnn_split_*_x3t")
+        nv.check(lib.frcnn_gemm_x3t(nv.ptr(rec), nv.ptr(inv), mp, 0, 0, nv.ptr(wblob), wblob.data_ptr() + wrec, np_, 0, 0, nv.ptr(bp),
+                                    nv.ptr(residual), nv.ptr(y), cout, 0, m, cout, k, 1, nv.RELU if relu else 0, nv.ptr(ws), wsb,
+                                    nv.stream_ptr()), "frcnn_gemm_x3t")
+    return y, ho, wo
+
+
 def run_block(x, n, h, w, pb):
     """One Bottleneck on NHWC data through the C ABI (stage-level path; the fused model uses frcnn_resnet_forward)."""
     xm = pb.get("x6_mask", 0)
+    x3 = pb.get("x3_mask", 0)
+    conv1x1 = (lambda *a, **k: conv_x3(*a, **k)) if x3 else conv1x1_x6
     if xm & 1:
-        t1, _, _ = conv1x1_x6(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, True)
+        t1, _, _ = conv1x1(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, True)
     else:
         t1, _, _ = conv_nhwc(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, 1, 0, True)
     if xm & 8:                                                          # layer4's 3x3 on the bf16 pipe (x6 Winograd / im2col GEMM)
         width = pb["width"]
         lib = nv.lib()
-        if pb["stride"] == 1:
+        if x3 and pb["stride"] == 1:
+            ho, wo = h, w
+            t2 = t.empty((n, h, w, width), dtype=t.float32, device=x.device)
+            wsb = int(lib.frcnn_conv3x3_winograd_x3_workspace_bytes(n, h, w, width, width))
+            ws = t.empty((wsb,), dtype=t.uint8, device=x.device)
+            with t.cuda.device(x.device):
+                nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3(nv.ptr(t1), nv.ptr(pb["w2"]), nv.ptr(pb["b2"]), nv.ptr(t2), n, h, w, width, width,
+                                                            nv.RELU, nv.ptr(ws), wsb, nv.stream_ptr()), "frcnn_conv3x3_nhwc_winograd_x3")
+        elif x3:
+            t2, ho, wo = conv_x3(t1, pb["w2"], pb["b2"], n, h, w, width, width, pb["stride"], True, ksize=3)
+        elif pb["stride"] == 1:
             ho, wo = h, w
             t2 = t.empty((n, h, w, width), dtype=t.float32, device=x.device)
             wsb = int(lib.frcnn_conv3x3_winograd_x6_workspace_bytes(n, h, w, width, width))
@@ -282,11 +338,11 @@ def run_block(x, n, h, w, pb):
     identity = x
     if pb["wd"] is not None:
         if xm & 4:
-            identity, _, _ = conv1x1_x6(x, pb["wd"], pb["bd"], n, h, w, pb["cin"], pb["cout"], pb["stride"], False)
+            identity, _, _ = conv1x1(x, pb["wd"], pb["bd"], n, h, w, pb["cin"], pb["cout"], pb["stride"], False)
         else:
             identity, _, _ = conv_nhwc(x, pb["wd"], pb["bd"], n, h, w, pb["cin"], pb["cout"], 1, pb["stride"], 0, False)
     if xm & 2:
-        out, _, _ = conv1x1_x6(t2, pb["w3"], pb["b3"], n, ho, wo, pb["width"], pb["cout"], 1, True, residual=identity)
+        out, _, _ = conv1x1(t2, pb["w3"], pb["b3"], n, ho, wo, pb["width"], pb["cout"], 1, True, residual=identity)
     else:
         out, _, _ = conv_nhwc(t2, pb["w3"], pb["b3"], n, ho, wo, pb["width"], pb["cout"], 1, 1, 0, True, residual=identity)
     return out, ho, wo
@@ -317,6 +373,7 @@ class FeatureExtractor(nn.Module):
         self._packed = None
         self.math_mode = "f32"
         self.x6_conv1x1 = False      # the eligible 1x1 convolutions as f32x6 GEMMs (f32_winograd mode)
+        self.x3 = False              # ... in the f32x3 arithmetic instead
 
     def blocks(self):
         fe = self._feature_extractor
@@ -326,11 +383,11 @@ class FeatureExtractor(nn.Module):
         """{'stem': (w, b), 'blocks': [dict]} of BN-folded packed weights, rebuilt when parameters change."""
         fe = self._feature_extractor
         params = [fe[0].weight] + _bn_params(fe[1]) + [p for b in self.blocks() for p in block_params(b)]
-        key = (self.math_mode, self.x6_conv1x1) + rt.param_key(params)
+        key = (self.math_mode, self.x6_conv1x1, self.x3) + rt.param_key(params)
         if key != self._packed_key:
             sw, sb, keep = fold_conv_bn(fe[0], fe[1])
             self._packed = {"stem": (sw, sb), "keep": keep,
-                            "blocks": [pack_block(b, self.math_mode, single_map=True, x6=self.x6_conv1x1) for b in self.blocks()],
+                            "blocks": [pack_block(b, self.math_mode, single_map=True, x6=self.x6_conv1x1, x3=self.x3) for b in self.blocks()],
                             "n_blocks": [len(fe[4]), len(fe[5]), len(fe[6])]}
             self._packed_key = key
         return self._packed
@@ -368,12 +425,13 @@ class PoolToFeatureVector(nn.Module):
         self._packed = None
         self.math_mode = "f32"
         self.x6_conv1x1 = False      # the eligible 1x1 convolutions as f32x6 GEMMs (f32_winograd mode)
+        self.x3 = False              # ... in the f32x3 arithmetic instead
 
     def packed(self):
         params = [p for b in self._layer4 for p in block_params(b)]
-        key = (self.math_mode, self.x6_conv1x1) + rt.param_key(params)
+        key = (self.math_mode, self.x6_conv1x1, self.x3) + rt.param_key(params)
         if key != self._packed_key:
-            self._packed = [pack_block(b, self.math_mode, x6=self.x6_conv1x1) for b in self._layer4]
+            self._packed = [pack_block(b, self.math_mode, x6=self.x6_conv1x1, x3=self.x3) for b in self._layer4]
             self._packed_key = key
         return self._packed
 

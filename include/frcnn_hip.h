@@ -41,7 +41,7 @@ extern "C" {
                                  5: bf16 gradient GEMMs (the *_math entry points); 6: x6t GEMM, x6 Winograd layers, frcnn_forward_params.winograd_x6_mask,
                                  timing classes 8 / 9; 7: batched feature extractor (frcnn_resnet_backbone, frcnn_resnet_forward_features,
                                  frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps); 8: the f32x3 arithmetic (frcnn_*_x3t, frcnn_*_winograd_x3,
-                                 frcnn_forward_params.winograd_x3_mask, FRCNN_FC_F32X3T) */
+                                 frcnn_forward_params.winograd_x3_mask, FRCNN_FC_F32X3T, frcnn_bottleneck_weights.x3_mask) */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -257,6 +257,16 @@ int frcnn_gemm_x6t(const void* d_a_rec, int a_rows, size_t a_batch_bytes, const 
  *   frcnn_pack_conv3x3_winograd_x3 : d_u_f32 = the float32 bank [16][cout][cin] of frcnn_pack_conv3x3_winograd -> blob of
  *                                    frcnn_conv3x3_winograd_x3_pack_bytes(cout, cin) bytes
  *   frcnn_conv3x3_nhwc_winograd_x3 : the layer; d_ws >= frcnn_conv3x3_winograd_x3_workspace_bytes(n_maps, H, W, cin, cout) */
+/* A-side producers for convolutions as f32x3 GEMMs (the f32x3 counterparts of frcnn_split_pixels_x6t / frcnn_split_patches3x3_x6t): the row
+ * of an output pixel is scaled by the power of two that the channel maxima of its input pixel(s) give.
+ *   frcnn_pixel_absmax           : x [pixels][c] -> d_cmax [pixels] = max_c |x|
+ *   frcnn_split_pixels_x3t       : 1x1 convolution, stride 1 / 2: records + d_inv_scale [rows_padded]
+ *   frcnn_split_patches3x3_x3t   : 3x3 / padding 1, stride 1 / 2 (im2col rows, K = 9 c) */
+int frcnn_pixel_absmax(const float* d_x, float* d_cmax, long long pixels, int c, void* stream);
+int frcnn_split_pixels_x3t(const float* d_x, const float* d_cmax, void* d_rec, float* d_inv_scale, int n_maps, int H, int W, int c, int stride,
+                           int rows_padded, void* stream);
+int frcnn_split_patches3x3_x3t(const float* d_x, const float* d_cmax, void* d_rec, float* d_inv_scale, int n_maps, int H, int W, int c,
+                               int stride, int rows_padded, void* stream);
 size_t frcnn_x3t_blob_bytes(int rows_padded, int K, int batches);
 int frcnn_pack_rows_x3t(const float* d_a, int lda, size_t a_batch_floats, void* d_blob, int rows, int rows_padded, int K, int batches,
                         void* stream);
@@ -523,6 +533,9 @@ typedef struct frcnn_bottleneck_weights {
                                   [cout][cin] matrix (frcnn_split_rows_x6t, rows padded to FRCNN_X6T_COL_TILE): that 1x1 convolution runs as a
                                   GEMM in the f32x6 arithmetic on the bf16 pipe (csrc/gemm_x6t.hip; the activations are split on the fly by
                                   frcnn_split_pixels_x6t).  Needs cin % 16 == 0 and cout % 4 == 0; FRCNN_MATH_F32_WINOGRAD only */
+    int32_t x3_mask;           /* a subset of x6_mask: those convolutions run in the f32x3 arithmetic instead (csrc/gemm_x3t.hip, csrc/wino_x3.hip) and
+                                  their weight pointers are f32x3 blobs: frcnn_pack_rows_x3t of the [cout][K] matrix (1x1 and stride-2 3x3
+                                  convolutions), frcnn_pack_conv3x3_winograd_x3's blob (stride-1 3x3) */
 } frcnn_bottleneck_weights;
 #define FRCNN_X6_CONV1 1
 #define FRCNN_X6_CONV3 2

@@ -23,10 +23,15 @@ def run(n, nslots=8):
         pend.append(m.predict_async(pool[i % 8], 0.05, slot=1 + (i % nslots)))
     while pend:
         pend.pop(0).result()
-for name, x6c, layers in (("all f32", "off", ()), ("x6 head (default)", "head", ()), ("x6 head + trunk", "head", ("rpn_trunk",)), ("x6 all 1x1", "all", ()),
-                          ("x6 all + trunk", "all", ("rpn_trunk",))):
+for name, x6c, layers, arith, x3l in (("x6 head (default)", "head", (), "f32x6", ()), ("x3 head", "head", (), "f32x3", ()),
+                                      ("x3 head + x3 trunk", "head", ("rpn_trunk",), "f32x3", ("rpn_trunk",)),
+                                      ("x6 all + x6 trunk", "all", ("rpn_trunk",), "f32x6", ()),
+                                      ("x3 all", "all", (), "f32x3", ()),
+                                      ("x3 all + x3 trunk", "all", ("rpn_trunk",), "f32x3", ("rpn_trunk",))):
+    m.x6_conv1x1_arith = arith
     m.x6_conv1x1 = x6c
     m.winograd_x6_layers = layers
+    m.winograd_x3_layers = x3l
     p, c, d = m(image_data=pool[0])
     err = match(p.cpu().numpy(), g["proposals"])
     det = m.predict(image_data=pool[0], score_threshold=0.05)
@@ -50,5 +55,7 @@ for name, x6c, layers in (("all f32", "off", ()), ("x6 head (default)", "head", 
         m.predict(pool[i % 8], score_threshold=0.05)
     torch.cuda.synchronize()
     t1 = time.perf_counter() - t0
+    pe = np.abs(p.cpu().numpy() - g["proposals"]).max(axis=1) if p.shape[0] == g["proposals"].shape[0] else np.array([np.inf])
+    print("%-22s max row-by-row proposal error %.3g px |" % (name, pe.max()), end=" ")
     print("%-18s proposals %d/%d  detections %d/%d (ours %d) | 8 in flight %.1f img/s | one at a time %.1f img/s" % (
         name, int((err <= 1e-3).sum()), len(err), n_ok, len(ref), sum(len(v) for v in det.values()), 100 / sorted(ts)[2], 40 / t1))
