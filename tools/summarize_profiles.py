@@ -51,7 +51,7 @@ def main(d):
                 print("\n%s, all instantiations: %d launches, mean %.1f us" % (fam, f_calls, f_ns / f_calls / 1e3))
         print()
     for sub, title in (("trace_r50_single", "ResNet-50 (BASELINE configs[2]), one image at a time: kernel stats (bench.py --backbone resnet50 "
-                                             "--inflight 1; default modes: x6_conv1x1 = head)"),
+                                             "--inflight 1; default modes: layer4 head + RPN trunk in f32x3)"),
                        ("trace_r50", "ResNet-50, 8 batch-1 images in flight: kernel stats (bench.py --backbone resnet50 --inflight 8)")):
         rs = load(os.path.join(d, sub, "*kernel_stats.csv"))
         if rs:
