@@ -240,14 +240,16 @@ def test_resnet101_600x1000_end_to_end(golden_dir):
           "%d/%d detections (ours %d)" % (int(ok.sum()), fm_err, s_err, c_err, n_ok, len(ref), n_ours))
     assert fm_err <= 5e-5 and s_err <= 1e-5 and c_err <= 2e-4
     assert int(ok.sum()) >= R101_600_PROPOSALS and n_ok >= R101_600_DETECTIONS and abs(n_ours - len(ref)) <= len(ref) - R101_600_DETECTIONS
+    rowerr = np.abs(props.cpu().numpy() - g["proposals"]).max(axis=1)
+    print("ResNet-101 600x1000: row-by-row proposal error max %.3g px (the same 300 rows in the same order)" % rowerr.max())
+    assert rowerr.max() <= 1e-2
 
 
-# Observed on the MI355X (default modes; the kernels are deterministic, so these are exact expectations): 286 of the reference's 300
-# proposals and 147 of its 157 detections (149 before layer4's 3x3 convolutions moved to the f32x6 arithmetic: the 14 proposals that
-# differ make a few of the final per-class NMS decisions borderline too).  The rest are near-ties, not errors: this fixture's top-6000 RPN scores have a MEDIAN
-# gap of 2.4e-5 (13 exact ties; make_golden prints it) while two float32 implementations of a 101-layer network differ by ~3e-6 in
-# objectness (measured above: 3.1e-6), so roughly one adjacent pair in ten changes order and a handful of those sit at the NMS cut.
-# Feature map (1.2e-6 of max), objectness and class probabilities are gated at float32 accuracy above.
+# Observed on the MI355X (the kernels are deterministic, so these are exact expectations; >= : 286 / 147 with the f32x6 head, 288 with the
+# f32x3 defaults).  ALL 300 proposals are the reference's rows at the reference's row indices (tools/r101_rows.py); the ones counted as
+# missed are 1.0e-3 ... 3.3e-3 px off -- the float32 noise of a 101-layer network on boxes up to 1000 px (1e-3 px = 1e-6 of the side), and
+# a few final per-class NMS decisions downstream of those coordinates.  Feature map (1.2e-6 of max), objectness and class probabilities
+# are gated at float32 accuracy above; the row identity is gated here at 1e-2 px.
 R101_600_PROPOSALS = 286
 R101_600_DETECTIONS = 147
 
