@@ -177,27 +177,31 @@ struct HxParams {
     int total;
 };
 
-template <int WTM, int WTN, int WVM, int WVN>
+// NSUB = 16-k chunks per stage (one barrier per stage).  NSUB = 1: three stage buffers, the DMA two stages ahead (a 16-k stage is ~1 us of
+// matrix work, about the L2 -> LDS latency of its 36 KB: one stage ahead left the pipe waiting).  NSUB = 2: 32-k stages, two buffers, the
+// DMA one (twice as long) stage ahead and half the barriers; needs an even number of chunks in every split.
+template <int WTM, int WTN, int WVM, int WVN, int NSUB>
 struct HxCfg {
     static constexpr int NW = WVM * WVN, THREADS = 64 * NW;
     static constexpr int ARB = WVM * WTM, BRB = WVN * WTN;
     static constexpr int BM = 32 * ARB, BN = 32 * BRB;
     static constexpr int A_BYTES = ARB * HX_RB, B_BYTES = BRB * HX_RB;
-    static constexpr int STAGE = A_BYTES + B_BYTES;
-    static constexpr int NBUF = 3;                                     // stage buffers: the DMA runs TWO stages ahead (a 16-k stage is ~1 us of
-                                                                       // matrix work, about the L2 -> LDS latency of its 36 KB: one stage ahead left the pipe waiting)
+    static constexpr int STAGE1 = A_BYTES + B_BYTES;                   // one chunk
+    static constexpr int STAGE = NSUB * STAGE1;
+    static constexpr int NBUF = NSUB == 1 ? 3 : 2;
+    static constexpr int DIST = NBUF - 1;                              // stages the DMA runs ahead
     static constexpr size_t LDS_BYTES = NBUF * (size_t)STAGE;
-    static constexpr int NPA = ARB * 2, NPB = BRB * 2, NP = NPA + NPB;
-    static constexpr int PPW = (NP + NW - 1) / NW;
+    static constexpr int NPA = ARB * 2, NPB = BRB * 2, NP = NPA + NPB;   // 1 KB pieces per chunk
+    static constexpr int PPW = (NSUB * NP + NW - 1) / NW;              // pieces per wave and stage
 };
 
 typedef __attribute__((address_space(3))) void* hx_lds_ptr;
 
-template <int WTM, int WTN, int WVM, int WVN>
+template <int WTM, int WTN, int WVM, int WVN, int NSUB>
 __global__ __launch_bounds__(64 * WVM * WVN, 2)
 void gemm_x3t_kernel(const HxParams p)
 {
-    using C = HxCfg<WTM, WTN, WVM, WVN>;
+    using C = HxCfg<WTM, WTN, WVM, WVN, NSUB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_hx[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -218,22 +222,23 @@ void gemm_x3t_kernel(const HxParams p)
     const int c_begin = split * p.chunks_per_split;
     int c_end = c_begin + p.chunks_per_split;
     if (c_end > p.nchunks) c_end = p.nchunks;
-    const int nst = c_end - c_begin;
+    const int nst = (c_end - c_begin) / NSUB;                 // stages (the launcher picks NSUB = 2 only for even chunk counts)
 
     const size_t a_chunk = (size_t)p.a_rbt * HX_RB, b_chunk = (size_t)p.b_rbt * HX_RB;
     const unsigned char* ag = p.a + (size_t)batch * p.a_batch + (size_t)mt * C::A_BYTES + (size_t)c_begin * a_chunk + lane * 16;
     const unsigned char* bg = p.b + (size_t)batch * p.b_batch + (size_t)nt * C::B_BYTES + (size_t)c_begin * b_chunk + lane * 16;
 
     auto issue_stage = [&](int s, int buf) {
-        const unsigned char* as = ag + (size_t)s * a_chunk;
-        const unsigned char* bs = bg + (size_t)s * b_chunk;
+        const unsigned char* as = ag + (size_t)s * NSUB * a_chunk;
+        const unsigned char* bs = bg + (size_t)s * NSUB * b_chunk;
         unsigned char* ldsb = smem_hx + buf * C::STAGE;
 #pragma unroll
         for (int i = 0; i < C::PPW; ++i) {
             int q = wave + C::NW * i;
-            q = q < C::NP ? q : C::NP - 1;
-            const unsigned char* src = q < C::NPA ? as + q * HX_PIECE : bs + (q - C::NPA) * HX_PIECE;
-            __builtin_amdgcn_global_load_lds(src, (hx_lds_ptr)(ldsb + q * HX_PIECE), 16, 0, 0);
+            q = q < NSUB * C::NP ? q : NSUB * C::NP - 1;             // a wave past the end repeats the last piece (same bytes, same place)
+            const int sub = q / C::NP, r = q - sub * C::NP;
+            const unsigned char* src = r < C::NPA ? as + sub * a_chunk + r * HX_PIECE : bs + sub * b_chunk + (r - C::NPA) * HX_PIECE;
+            __builtin_amdgcn_global_load_lds(src, (hx_lds_ptr)(ldsb + sub * C::STAGE1 + r * HX_PIECE), 16, 0, 0);
         }
     };
     f32x16 acc[WTM][WTN];
@@ -269,54 +274,62 @@ void gemm_x3t_kernel(const HxParams p)
 #endif
     if (nst > 0) {
         issue_stage(0, 0);
-        issue_stage(nst > 1 ? 1 : 0, 1);
-        // wait for stage 0 only: LDS-DMA completes in issue order, so "at most PPW loads outstanding" = everything but the newest stage
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW) : "memory");
+        if (C::DIST == 2) issue_stage(nst > 1 ? 1 : 0, 1);
+        // wait for stage 0 only: LDS-DMA completes in issue order, so "at most (DIST - 1) PPW loads outstanding" = everything but the newer stages
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::DIST - 1) * C::PPW) : "memory");
         __builtin_amdgcn_s_barrier();
-        int cur = 0;                          // buffer of stage s; stage s + 2 goes to the buffer stage s - 1 was read from
+        int cur = 0;                          // buffer of stage s; stage s + DIST goes to the buffer stage s - 1 was read from
         const int a_off = wm * WTM * HX_RB + lane * 16;
         const int b_off = C::A_BYTES + wn * WTN * HX_RB + lane * 16;
 #ifdef HX_CLOCKS
         clk0 = __builtin_readcyclecounter(); real0 = __builtin_amdgcn_s_memrealtime();
 #endif
         for (int s = 0; s < nst; ++s) {
-            const int nxt2 = cur == 0 ? 2 : cur - 1;               // (s + 2) % 3
-            const unsigned char* at = smem_hx + cur * C::STAGE + a_off;
-            const unsigned char* bt = smem_hx + cur * C::STAGE + b_off;
-            // first reads of the stage: hi of A, lo of B (registers the deferred product below does not touch)
-            if (!(HX_ABLATE & 16) || s == 0) {
+            const int nxt = C::NBUF == 3 ? (cur == 0 ? 2 : cur - 1) : (cur ^ 1);        // (s + DIST) % NBUF
 #pragma unroll
-            for (int i = 0; i < WTM; ++i) ah[i] = *reinterpret_cast<const hx_f16x8*>(at + i * HX_RB);
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const unsigned char* at = smem_hx + cur * C::STAGE + sub * C::STAGE1 + a_off;
+                const unsigned char* bt = smem_hx + cur * C::STAGE + sub * C::STAGE1 + b_off;
+                // first reads of the chunk: hi of A, lo of B (registers the deferred product below does not touch)
+                if (!(HX_ABLATE & 16) || s == 0) {
 #pragma unroll
-            for (int j = 0; j < WTN; ++j) bl[j] = *reinterpret_cast<const hx_f16x8*>(bt + j * HX_RB + HX_PIECE);
-            }
-            if (!(HX_ABLATE & 1)) issue_stage(s + 2 < nst ? s + 2 : nst - 1, nxt2);       // unconditional: the stage is one basic block (see gemm_x6t_kernel)
-            HX_TERM(al, bh)                                         // lo x hi of the PREVIOUS stage (zeros before the first)
-            HX_TERM(ah, bl)                                         // hi x lo
-            if (!(HX_ABLATE & 16) || s == 0) {
+                for (int i = 0; i < WTM; ++i) ah[i] = *reinterpret_cast<const hx_f16x8*>(at + i * HX_RB);
 #pragma unroll
-            for (int j = 0; j < WTN; ++j) bh[j] = *reinterpret_cast<const hx_f16x8*>(bt + j * HX_RB);
+                for (int j = 0; j < WTN; ++j) bl[j] = *reinterpret_cast<const hx_f16x8*>(bt + j * HX_RB + HX_PIECE);
+                }
+                // unconditional (the last stages re-load the last one into an idle buffer): the stage is one basic block (see gemm_x6t_kernel)
+                if (sub == 0 && !(HX_ABLATE & 1)) issue_stage(s + C::DIST < nst ? s + C::DIST : nst - 1, nxt);
+                HX_TERM(al, bh)                                         // lo x hi of the PREVIOUS chunk (zeros before the first)
+                HX_TERM(ah, bl)                                         // hi x lo
+                if (!(HX_ABLATE & 16) || s == 0) {
 #pragma unroll
-            for (int i = 0; i < WTM; ++i) al[i] = *reinterpret_cast<const hx_f16x8*>(at + i * HX_RB + HX_PIECE);
-            }
-            HX_TERM(ah, bh)                                         // hi x hi
+                for (int j = 0; j < WTN; ++j) bh[j] = *reinterpret_cast<const hx_f16x8*>(bt + j * HX_RB);
+#pragma unroll
+                for (int i = 0; i < WTM; ++i) al[i] = *reinterpret_cast<const hx_f16x8*>(at + i * HX_RB + HX_PIECE);
+                }
+                HX_TERM(ah, bh)                                         // hi x hi
 #if !HX_NO_SCHED && !HX_ABLATE
-            constexpr int NT = WTM * WTN, NF = WTM + WTN, PW = C::PPW;
-            HX_SGB(0x100, NF);                                                                          // ah, bl
-            _Pragma("unroll") for (int q = 0; q < (PW < NT ? PW : NT); ++q) { HX_SGB(0x008, 1); HX_SGB(0x010, 1); }   // lh(prev) || the DMA pieces
-            if (PW > NT) HX_SGB(0x010, PW - NT);
-            if (NT > PW) HX_SGB(0x008, NT - PW);
-            _Pragma("unroll") for (int q = 0; q < (NF < NT ? NF : NT); ++q) { HX_SGB(0x008, 1); HX_SGB(0x100, 1); }   // hl || bh, al
-            if (NF > NT) HX_SGB(0x100, NF - NT);
-            if (NT > NF) HX_SGB(0x008, NT - NF);
-            HX_SGB(0x008, NT);                                                                          // hh
+                constexpr int NT = WTM * WTN, NF = WTM + WTN, PW = C::PPW;
+                HX_SGB(0x100, NF);                                                                          // ah, bl
+                if (sub == 0) {
+                    _Pragma("unroll") for (int q = 0; q < (PW < NT ? PW : NT); ++q) { HX_SGB(0x008, 1); HX_SGB(0x010, 1); }   // lh(prev) || the DMA pieces
+                    if (PW > NT) HX_SGB(0x010, PW - NT);
+                    if (NT > PW) HX_SGB(0x008, NT - PW);
+                } else {
+                    HX_SGB(0x008, NT);                                                                      // lh(prev)
+                }
+                _Pragma("unroll") for (int q = 0; q < (NF < NT ? NF : NT); ++q) { HX_SGB(0x008, 1); HX_SGB(0x100, 1); }   // hl || bh, al
+                if (NF > NT) HX_SGB(0x100, NF - NT);
+                if (NT > NF) HX_SGB(0x008, NT - NF);
+                HX_SGB(0x008, NT);                                                                          // hh
 #endif
+            }
             __builtin_amdgcn_sched_barrier(0);
-            // stage s+1 has landed (the PPW pieces of stage s+2 may still be in flight), this wave's fragment reads of stage s are back
-            // (al is not consumed before the next stage), and after the barrier nobody reads stage s from LDS any more
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::PPW) : "memory");
+            // stage s+1 has landed (with DIST = 2 the pieces of stage s+2 may still be in flight), this wave's fragment reads of stage s are
+            // back (al is not consumed before the next chunk), and after the barrier nobody reads stage s from LDS any more
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((C::DIST - 1) * C::PPW) : "memory");
             __builtin_amdgcn_s_barrier();
-            cur = cur == 2 ? 0 : cur + 1;
+            cur = cur == C::NBUF - 1 ? 0 : cur + 1;
             __builtin_amdgcn_sched_barrier(0);
         }
 #ifdef HX_CLOCKS
@@ -504,17 +517,22 @@ int launch_gemm_x3t(const void* a_rec, const float* a_inv, int a_rows, size_t a_
     const long long total = (long long)pl.mtiles * pl.ntiles * batches * pl.splits;
     if (total > 0x7fffffffLL) return FRCNN_EINVAL;
     p.total = (int)total;
-    if (pl.cfg == 1) {
-        using C = HxCfg<5, 1, 1, 4>;
-        auto kern = gemm_x3t_kernel<5, 1, 1, 4>;
-        FRCNN_MAX_LDS_ONCE(kern, C::LDS_BYTES);
-        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(C::THREADS), C::LDS_BYTES, s, p);
-    } else {
-        using C = HxCfg<5, 2, 2, 4>;
-        auto kern = gemm_x3t_kernel<5, 2, 2, 4>;
-        FRCNN_MAX_LDS_ONCE(kern, C::LDS_BYTES);
-        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(C::THREADS), C::LDS_BYTES, s, p);
-    }
+    // 32-k stages for LONG reductions whose splits hold an even number of 16-k chunks (fc1: 98 chunks per split, 184 -> 176 us; the 16 / 32
+    // chunk reductions of the Winograd layers and fc2 measure the same either way and keep the three-buffer form), 16-k stages otherwise
+    static const int env_nsub = []() { const char* e = getenv("FRCNN_HX_NSUB"); return e ? atoi(e) : 0; }();     // experiments: 1 / 2
+    const int last = p.nchunks - (pl.splits - 1) * pl.chunks_per_split;
+    const bool even = pl.chunks_per_split % 2 == 0 && last % 2 == 0;
+    const int nsub = !even ? 1 : (env_nsub == 1 || env_nsub == 2) ? env_nsub : (pl.chunks_per_split >= 64 ? 2 : 1);
+#define HX_LAUNCH(TM, TN, VM, VN, NS)                                                                          \
+    do {                                                                                                      \
+        using C = HxCfg<TM, TN, VM, VN, NS>;                                                                    \
+        auto kern = gemm_x3t_kernel<TM, TN, VM, VN, NS>;                                                        \
+        FRCNN_MAX_LDS_ONCE(kern, C::LDS_BYTES);                                                                 \
+        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(C::THREADS), C::LDS_BYTES, s, p);                  \
+    } while (0)
+    if (pl.cfg == 1) { if (nsub == 2) HX_LAUNCH(5, 1, 1, 4, 2); else HX_LAUNCH(5, 1, 1, 4, 1); }
+    else             { if (nsub == 2) HX_LAUNCH(5, 2, 2, 4, 2); else HX_LAUNCH(5, 2, 2, 4, 1); }
+#undef HX_LAUNCH
     int rc = check_launch();
     if (rc || pl.splits == 1) return rc;
     return launch_gemm_x6t_reduce(static_cast<const float*>(ws), bias, residual, c, ldc, c_batch_floats, M, N, batches, pl.splits, p.relu, s);
