@@ -92,6 +92,7 @@ def test_x3t_split_scales_and_layout():
     (589, 512, 512, 16, False),      # conv5_x / RPN trunk
     (300, 4096, 4096, 1, True),      # fc2's shape (split-K)
     (300, 512, 25088, 1, True),      # fc1's reduction depth
+    (64, 4096, 25088, 1, True),      # fc1's split (16 x 98 chunks): the 32-k-stage instantiation of the kernel
     (137, 260, 80, 3, False),        # ragged M and N, five 16-k stages, batches
     (1, 4, 16, 1, True),             # one row, one stage
     (321, 256, 32, 2, False),        # one row more than a tile, two stages
