@@ -257,3 +257,124 @@ def test_bench_layer_arithmetic_discloses_pipes():
     # algorithmic total == BASELINE.md section 3 minus conv1_1 (the VALU layer): 4.4922e11 - 2*27*64*600*1000
     alg = sum(r[4] for r in bench.layer_arithmetic("f32", "f32"))
     assert abs(alg - (4.4922e11 - 2.0 * 27 * 64 * 600 * 1000)) / alg < 2e-4
+
+
+def test_bench_layer_arithmetic_f32x3_tables():
+    """The f32x3 layers count three fp16 MFMAs per float32 product, the f32x6 layers six bf16 MFMAs; a name in the x3 table only counts
+    when it is in the x6 table too; the default tables of the model are the ones bench.py accounts for."""
+    import bench
+    from fasterrcnn_amd import _native as nv
+    x6, x3 = nv.DEFAULT_X6_LAYERS_VGG16, nv.DEFAULT_X3_LAYERS_VGG16
+    assert set(x3) <= set(x6) and "conv5_1" in x6 and "conv5_1" not in x3
+    rows = {r[0]: r for r in bench.layer_arithmetic("f32_winograd", "f32x3", x6, x3=x3)}
+    for n in x6:
+        if n == "rpn_trunk":
+            continue
+        kern, pipe, ex = rows[n][1], rows[n][2], rows[n][3]
+        ci, co, h, w = dict(zip(bench._CONV_NAMES, bench._MFMA_CONVS))[n]
+        g = bench.winograd_gemm_flops(ci, co, h, w)
+        assert (pipe, ex) == (("f16", 3.0 * g) if n in x3 else ("bf16", 6.0 * g)), n
+        assert kern.startswith("gemm_x3t_kernel" if n in x3 else "gemm_x6t_kernel")
+    assert rows["fc1"][1] == "gemm_x3t_kernel" and rows["fc1"][2] == "f16" and rows["fc1"][3] == 3.0 * rows["fc1"][4]
+    # an x3 name outside the x6 table stays on the float32 kernel
+    r2 = {r[0]: r for r in bench.layer_arithmetic("f32_winograd", "f32", ("conv4_2",), x3=("conv4_2", "conv5_2"))}
+    assert r2["conv4_2"][2] == "f16" and r2["conv5_2"][2] == "f32" and r2["fc1"][2] == "f32"
+    pf = bench.pipe_flops_per_image("f32_winograd", "f32x3", x6, x3=x3)
+    assert pf["f16"] > 0 and pf["bf16"] > 0 and abs(pf["f32"] + pf["bf16"] + pf["f16"] - bench.executed_mfma_flops_per_image("f32_winograd", "f32x3", x6, x3)) < 1.0
+    m = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+    assert m.winograd_x6_layers == x6 and m.winograd_x3_layers == x3 and m.fc_math_mode == "f32x3"
+    assert m._x3_mask() & ~m._x6_mask() == 0
+    m.winograd_x6_layers = ("conv4_2",)                       # the x3 table is an overlay: names outside the x6 table have no effect ...
+    assert m._x3_mask() == 1 << nv.X6_LAYER_BITS["conv4_2"] and m._stage1_feature_extractor.x3_layers == ("conv4_2",)
+    m.winograd_x6_layers = x6                                 # ... and come back with it
+    assert m._x3_mask() == sum(1 << nv.X6_LAYER_BITS[n] for n in x3)
+    with pytest.raises(ValueError):
+        m.winograd_x3_layers = ("conv1_2",)
+
+
+def test_resnet_default_modes_and_conv_table():
+    """ResNet defaults: layer4 head + RPN trunk as f32x3 GEMMs; bench.py's convolution table follows the model's modes."""
+    import bench
+    from fasterrcnn_amd.models import resnet
+    m = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet50))
+    assert (m.x6_conv1x1, m.x6_conv1x1_arith, m.winograd_x6_layers, m.winograd_x3_layers) == ("head", "f32x3", ("rpn_trunk",), ("rpn_trunk",))
+    assert m._x6_mask() == m._x3_mask() == 1 << 13
+    table = bench.resnet_conv_table(m)
+    head = [r for r in table if r[0] == "head" and r[2].startswith("gemm_")]
+    assert head and all(r[2].startswith("gemm_x3t_kernel") and r[3] == "f16" and abs(r[4] / r[5] - 3.0) < 1e-9 or "Winograd" in r[2] for r in head)
+    trunk = [r for r in table if r[1] == "rpn_trunk"][0]
+    assert trunk[2].startswith("gemm_x3t_kernel") and trunk[3] == "f16"
+    assert all(r[3] in ("f32", "valu") for r in table if r[0] == "backbone")
+    m.x6_conv1x1_arith = "f32x6"
+    m.winograd_x3_layers = ()
+    table6 = bench.resnet_conv_table(m)
+    assert [r for r in table6 if r[1] == "rpn_trunk"][0][3] == "bf16"
+    assert all(r[3] == "bf16" for r in table6 if r[0] == "head" and r[2].startswith("gemm_"))
+    with pytest.raises(NotImplementedError):
+        FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0)).x6_conv1x1_arith = "f32x3"
+
+
+class _FakeHandle:
+    def __init__(self, log, tag):
+        self.log, self.tag = log, tag
+
+    def result(self):
+        self.log.append(("collect",) + self.tag)
+        return {1: np.zeros((0, 5))}
+
+
+class _FakeBatchModel:
+    """Stands in for a ResNet FasterRCNNModel: records which lane every batch went to and refuses a lane whose images are uncollected."""
+    _is_resnet = True
+
+    def __init__(self):
+        self.log, self.busy = [], {}
+
+    def predict_batch_async(self, images, score_threshold, lane=0):
+        assert not self.busy.get(lane), "lane %d reused while its images are in flight" % lane
+        n = int(images.shape[0])
+        self.log.append(("batch", lane, n, tuple(images.shape[1:])))
+        handles = [_FakeHandle(self.log, (lane, i)) for i in range(n)]
+        self.busy[lane] = n
+        model = self
+
+        def make(hd):
+            inner = hd.result
+
+            def result():
+                model.busy[lane] -= 1
+                return inner()
+            hd.result = result
+            return hd
+        return [make(h) for h in handles]
+
+
+def test_evaluate_stream_batches_group_by_shape_and_never_reuse_a_busy_lane():
+    from fasterrcnn_amd import evaluate as ev
+    model = _FakeBatchModel()
+    shapes = [(3, 8, 8)] * 5 + [(3, 8, 12)] * 3 + [(3, 8, 8)] * 4          # a shape change in the middle of a batch, twice
+    samples = [(i, torch.zeros((1,) + shp), None) for i, shp in enumerate(shapes)]
+    got = []
+    ev.evaluate_stream(model, samples, inflight=8, batch=4, on_result=lambda i, d: got.append(i))
+    assert got == list(range(12))                                          # results in image order
+    batches = [e for e in model.log if e[0] == "batch"]
+    assert [b[2] for b in batches] == [4, 1, 3, 4] and [b[1] for b in batches] == [0, 1, 0, 1]
+    assert all(v == 0 for v in model.busy.values())
+    # one lane only: every batch is collected before the next is enqueued; ranks take every world-th sample
+    model = _FakeBatchModel()
+    got = []
+    ev.evaluate_stream(model, samples, inflight=2, batch=4, rank=1, world=2, on_result=lambda i, d: got.append(i))
+    assert got == [i for i in range(12) if i % 2 == 1] and all(b[1] == 0 for b in model.log if b[0] == "batch")
+    # a VGG-16 model ignores `batch`
+    class _Vgg:
+        _is_resnet = False
+
+        def __init__(self):
+            self.calls = 0
+
+        def predict_async(self, image, thr, slot):
+            self.calls += 1
+            return _FakeHandle([], (slot, 0))
+    v = _Vgg()
+    ev.evaluate_stream(v, samples[:3], inflight=2, batch=4)
+    assert v.calls == 3
