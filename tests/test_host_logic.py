@@ -378,3 +378,15 @@ def test_evaluate_stream_batches_group_by_shape_and_never_reuse_a_busy_lane():
     v = _Vgg()
     ev.evaluate_stream(v, samples[:3], inflight=2, batch=4)
     assert v.calls == 3
+
+
+def test_runtime_feature_map_shape_matches_the_backbone_contract():
+    """runtime.feature_map_shape (used to address the per-image maps of a batch) == ResNetBackbone.compute_feature_map_shape
+    (models/resnet.py:161-185: ceil(H / 16), ceil(W / 16)) == the four stride-2 stages applied one by one."""
+    from fasterrcnn_amd import runtime as rt
+    from fasterrcnn_amd.models import resnet
+    bb = resnet.ResNetBackbone(resnet.Architecture.ResNet50)
+    for h in (32, 33, 47, 224, 333, 599, 600, 601, 1000, 1333):
+        for w in (32, 49, 320, 517, 1000, 1001):
+            c, fh, fw = bb.compute_feature_map_shape((3, h, w))
+            assert rt.feature_map_shape(h, w) == (fh, fw) and c == 1024
