@@ -331,6 +331,18 @@ int frcnn_gemm_x3t(const void* d_a_rec, const float* d_a_inv, int a_rows, size_t
                            as_stream(stream));
 }
 
+size_t frcnn_conv3x3_winograd_x3_fused_workspace_bytes(int n_maps, int H, int W)
+{
+    return n_maps > 0 && H > 0 && W > 0 ? conv3x3_winograd_x3_fused_workspace_bytes(n_maps, H, W) : 0;
+}
+
+int frcnn_conv3x3_nhwc_winograd_x3_fused(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W,
+                                         int cin, int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_x || !d_blob || !d_bias || !d_y) return FRCNN_EINVAL;
+    return launch_conv3x3_winograd_x3_fused(d_x, d_blob, d_bias, d_y, n_maps, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
+}
+
 int frcnn_pixel_absmax(const float* d_x, float* d_cmax, long long pixels, int c, void* stream)
 {
     if (!d_x || !d_cmax) return FRCNN_EINVAL;

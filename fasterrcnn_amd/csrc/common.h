@@ -183,6 +183,10 @@ int launch_winograd_x3_gemm(const void* vrec, const float* vinv, const void* ubl
                             size_t gws_bytes, hipStream_t s);
 int launch_conv3x3_winograd_x3(const float* x, const void* ublob, const float* b, float* y, int N, int H, int W, int cin, int cout,
                                unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
+// wino_x3f.hip: EXPERIMENTAL one-launch form of the x3 Winograd layer (not used by any forward yet)
+size_t conv3x3_winograd_x3_fused_workspace_bytes(int N, int H, int W);
+int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const float* b, float* y, int N, int H, int W, int cin, int cout,
+                                     unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_roi_pool_x3t(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois, int max_rois, int pooled,
                         float scale, float* cmax, float* inv, void* rec, int rec_rows, hipStream_t s);
 // wino_x6.hip: Winograd F(2x2,3x3) layers whose position GEMMs run on gemm_x6t

@@ -275,6 +275,13 @@ int frcnn_pack_conv3x3_winograd_x3(const float* d_u_f32, void* d_blob, int cout,
 size_t frcnn_conv3x3_winograd_x3_workspace_bytes(int n_maps, int H, int W, int cin, int cout);
 int frcnn_conv3x3_nhwc_winograd_x3(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W, int cin,
                                    int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
+/* EXPERIMENTAL (round 3: validated bit for bit against the three-launch layer, not tuned yet, no forward uses it): the same layer as ONE launch
+ * (csrc/wino_x3f.hip: V formed in registers from an LDS-staged halo, all 16 positions in MFMA accumulators, output transform in the
+ * epilogue; no V / M scratch), for the layers whose scratch does not fit the Infinity Cache.  By construction bit-identical to
+ * frcnn_conv3x3_nhwc_winograd_x3 on the same blob.  cout % 64 == 0; d_ws >= frcnn_conv3x3_winograd_x3_fused_workspace_bytes. */
+size_t frcnn_conv3x3_winograd_x3_fused_workspace_bytes(int n_maps, int H, int W);
+int frcnn_conv3x3_nhwc_winograd_x3_fused(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W,
+                                         int cin, int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
 size_t frcnn_x3t_record_bytes(int rows_padded, int K);
 int frcnn_rows_scale_x3t(const float* d_a, int lda, size_t a_batch_floats, float* d_inv_scale, int rows, int rows_padded, int K, int batches,
                          void* stream);

@@ -320,3 +320,41 @@ def test_model_x3_layer_tables_against_the_golden_vectors(gpu_model, golden_dir)
         assert res[name][0].shape == g["proposals"].shape and err.max() <= 1.5e-3
     with pytest.raises(ValueError):
         gpu_model.winograd_x3_layers = ("conv1_2",)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,relu,pool", [
+    (1, 9, 11, 32, 64, True, False),          # one block column, partial tiles
+    (1, 38, 66, 64, 64, True, False),
+    (1, 150, 250, 64, 128, True, False),      # conv2_1's shape at a quarter of the size
+    (1, 75, 125, 256, 256, True, True),       # conv3_3 at half size, fused pool
+    (2, 21, 35, 128, 192, False, False),      # two maps, three cout blocks, no ReLU
+])
+def test_x3_one_launch_layer_equals_the_three_launch_layer_bit_for_bit(n, h, w, cin, cout, relu, pool):
+    """csrc/wino_x3f.hip (experimental first version, not used by a forward yet): same scale, same split, same accumulation order, same
+    output transform -> the same bits as the three-launch layer."""
+    import time
+    lib = nv.lib()
+    gen = torch.Generator().manual_seed(h * 1000 + w + cin)
+    x = (torch.randn((n, h, w, cin), generator=gen) * torch.exp(torch.randn((1, 1, 1, cin), generator=gen))).cuda()
+    wt = (torch.randn((cout, cin, 3, 3), generator=gen) * (2.0 / (9 * cin)) ** 0.5).cuda()
+    b = (torch.randn((cout,), generator=gen) * 0.1).cuda()
+    u = pack_x3(wt)
+    want = run_x3(x if n > 1 else x[0].contiguous(), u, b, cout, relu, pool, n_maps=n)
+    oh, ow = (h // 2, w // 2) if pool else (h, w)
+    y = torch.full((n, oh, ow, cout), float("nan"), device="cuda")
+    wsb = int(lib.frcnn_conv3x3_winograd_x3_fused_workspace_bytes(n, h, w))
+    ws = torch.empty((wsb,), dtype=torch.uint8, device="cuda")
+    flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
+    call = lambda: nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), n, h, w, cin, cout, flags,
+                                                                      nv.ptr(ws), wsb, nv.stream_ptr()), "x3_fused")
+    call()
+    torch.cuda.synchronize()
+    assert not torch.isnan(y).any()
+    diff = float((y.reshape(want.shape) - want).abs().max())
+    t0 = time.perf_counter()
+    for _ in range(10):
+        call()
+    torch.cuda.synchronize()
+    print("x3 one-launch %dx%dx%d %d->%d: max |diff| vs the three-launch layer %.3g; %.1f us per call" % (
+        n, h, w, cin, cout, diff, (time.perf_counter() - t0) / 10 * 1e6))
+    assert torch.equal(y.reshape(want.shape), want)

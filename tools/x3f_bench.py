@@ -1,0 +1,48 @@
+"""tools/x3f_bench.py -- the experimental one-launch f32x3 Winograd layer (csrc/wino_x3f.hip) against the float32 one-launch layer
+(csrc/winofused.hip) on the six VGG-16 layers the latter still owns."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from fasterrcnn_amd import _native as nv  # noqa: E402
+from tools.layer_bench import timeit      # noqa: E402
+
+LAYERS = [("conv1_2", 64, 64, 600, 1000, True), ("conv2_1", 64, 128, 300, 500, False), ("conv2_2", 128, 128, 300, 500, True),
+          ("conv3_1", 128, 256, 150, 250, False), ("conv3_2", 256, 256, 150, 250, False), ("conv3_3", 256, 256, 150, 250, True)]
+
+
+def main():
+    nv.require_gpu()
+    lib = nv.lib()
+    dev = "cuda:0"
+    s = nv.stream_ptr()
+    for name, cin, cout, h, w, pool in LAYERS:
+        x = torch.randn((h, w, cin), device=dev).clamp(min=0)
+        wt = torch.randn((cout, cin, 3, 3), device=dev) * 0.02
+        b = torch.zeros((cout,), device=dev)
+        oh, ow = (h // 2, w // 2) if pool else (h, w)
+        y = torch.empty((oh, ow, cout), device=dev)
+        flags = nv.RELU | (nv.POOL2 if pool else 0)
+        wf = torch.empty((16 * cout * cin,), device=dev)
+        nv.check(lib.frcnn_pack_conv3x3_winograd_fused(nv.ptr(wt), None, nv.ptr(wf), cout, cin, s), "pack_fused")
+        us32 = timeit(lambda: nv.check(lib.frcnn_conv3x3_nhwc_winograd_fused(nv.ptr(x), nv.ptr(wf), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags, s),
+                                       "fused"), 10, ramp_s=0.3)
+        bank = torch.empty((16, cout, cin), device=dev)
+        u = torch.empty((int(lib.frcnn_conv3x3_winograd_x3_pack_bytes(cout, cin)),), dtype=torch.int8, device=dev)
+        nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(wt), None, nv.ptr(bank), cout, cin, s), "pack")
+        nv.check(lib.frcnn_pack_conv3x3_winograd_x3(nv.ptr(bank), nv.ptr(u), cout, cin, s), "pack_x3")
+        wsb = int(lib.frcnn_conv3x3_winograd_x3_fused_workspace_bytes(1, h, w))
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        us3 = timeit(lambda: nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
+                                                                              nv.ptr(ws), wsb, s), "x3_fused"), 10, ramp_s=0.3)
+        gfl = 2.0 * 16 * ((h + 1) // 2) * ((w + 1) // 2) * cin * cout
+        print("%-8s %4d->%4d %4dx%-4d pool=%d | float32 one-launch %7.1f us (%.2f of 157.3) | f32x3 one-launch (+ channel maxima) %7.1f us "
+              "(%.2f of the fp16 peak, %.2fx)" % (name, cin, cout, h, w, pool, us32, gfl / us32 / 1e6 / 157.3, us3, 3 * gfl / us3 / 1e6 / 2500.0, us32 / us3))
+
+
+if __name__ == "__main__":
+    main()
