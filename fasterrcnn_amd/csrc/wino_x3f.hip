@@ -32,11 +32,16 @@ static constexpr int XF_HR = 2 * XF_TR + 2, XF_HC = 2 * XF_TC + 2;   // halo row
 static constexpr int XF_PS = 20;                              // floats per halo pixel (16 + 4 padding)
 static constexpr int XF_HALO_BYTES = XF_HR * XF_HC * XF_PS * 4;      // 16,320
 static constexpr int XF_U_BYTES = 16 * 2 * 2 * HX_PIECE;     // one chunk of the bank for 64 output channels: 65,536
-static constexpr size_t XF_LDS_BYTES = (size_t)XF_HALO_BYTES + 2 * XF_U_BYTES;     // 147,392
+static constexpr size_t XF_LDS_BYTES = (size_t)XF_HALO_BYTES + 2 * XF_U_BYTES;     // 147,392 (version 1)
+static constexpr size_t XF_LDS_BYTES2 = 2 * (size_t)XF_HALO_BYTES + 2 * XF_U_BYTES;   // 163,712 (version 2: two halo buffers) <= 163,840
 
 struct XfGeom { int tbx, tby, ncb, tw, th; };
 
-template <bool POOL>
+// VER 1: the first, validated version.  VER 2 (written after the GPU budget of round 3 was spent: compiled, NOT yet run -- select it with
+// FRCNN_X3F_VER=2 and check it with the same bit-for-bit test): V of chunk c+1 is formed under the MFMAs of chunk c (two halo buffers),
+// the filter DMA runs two chunks ahead, ONE barrier per chunk, and the three products of a chunk are issued term-major so that
+// consecutive MFMAs hit different accumulators (the per-accumulator order, hence every bit, is unchanged).
+template <bool POOL, int VER>
 __global__ __launch_bounds__(256, 1)
 void wino_x3f_kernel(const float* __restrict__ x_maps, const float* __restrict__ cmax_maps, const unsigned char* __restrict__ ublob,
                      const float* __restrict__ bias, float* __restrict__ y_maps, int H, int W, int Cin, int Cout, int u_rbt, int relu,
@@ -44,7 +49,7 @@ void wino_x3f_kernel(const float* __restrict__ x_maps, const float* __restrict__
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_xf[];
     float* const halo = reinterpret_cast<float*>(smem_xf);
-    unsigned char* const ubuf = smem_xf + XF_HALO_BYTES;
+    unsigned char* const ubuf = smem_xf + (VER == 1 ? 1 : 2) * XF_HALO_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // position row i
@@ -98,10 +103,11 @@ void wino_x3f_kernel(const float* __restrict__ x_maps, const float* __restrict__
         for (int it = 0; it < 4; ++it)
             hreg[it] = h_src[it] >= 0 ? *reinterpret_cast<const f32x4*>(x + h_src[it] + 16 * chunk) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    auto store_halo = [&]() {
+    auto store_halo = [&](int hb = 0) {
+        float* hbuf = halo + hb * (XF_HALO_BYTES / 4);
 #pragma unroll
         for (int it = 0; it < 4; ++it)
-            if (h_dst[it] >= 0) *reinterpret_cast<f32x4*>(halo + h_dst[it]) = hreg[it];
+            if (h_dst[it] >= 0) *reinterpret_cast<f32x4*>(hbuf + h_dst[it]) = hreg[it];
     };
     // ---- filter records: piece (position p, row block r, term t) of chunk c = ublob + ((p K16 + c) u_rbt + 2 cb + r) 2 KB + t 1 KB ------
     auto issue_u = [&](int chunk, int buf) {
@@ -129,61 +135,110 @@ void wino_x3f_kernel(const float* __restrict__ x_maps, const float* __restrict__
     const bool rsub = wave != 1;                                            // i = 1: d1 + d2; i = 0, 2, 3: differences
     const int d_off = ((2 * tyl) * XF_HC + 2 * txl) * XF_PS + 8 * kh;       // + (a XF_HC + b) XF_PS
 
-    load_halo(0);
-    issue_u(0, 0);
-    store_halo();
-    __syncthreads();                                                         // (the compiler's fence waits for the DMA: vmcnt(0))
-
-    for (int c = 0; c < K16; ++c) {
-        // ---- V of this wave's four positions for its lane's tile and 8 channels, in registers --------------------------------------------
-        xf_f16x8 vh[4], vl[4];
-        {
-            float r[4][8];
+    // V of this wave's four positions for its lane's tile and 8 channels, from halo buffer `hb`, as two fp16 fragments per position
+    auto form_v = [&](int hb, xf_f16x8 (&vh)[4], xf_f16x8 (&vl)[4]) {
+        const float* hbuf = halo + hb * (XF_HALO_BYTES / 4);
+        float r[4][8];
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                const float* p1 = halo + d_off + (a1 * XF_HC + bb) * XF_PS;
-                const float* p2 = halo + d_off + (a2 * XF_HC + bb) * XF_PS;
-                const f32x4 u0 = *reinterpret_cast<const f32x4*>(p1), u1 = *reinterpret_cast<const f32x4*>(p1 + 4);
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(p2), w1 = *reinterpret_cast<const f32x4*>(p2 + 4);
+        for (int bb = 0; bb < 4; ++bb) {
+            const float* p1 = hbuf + d_off + (a1 * XF_HC + bb) * XF_PS;
+            const float* p2 = hbuf + d_off + (a2 * XF_HC + bb) * XF_PS;
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(p1), u1 = *reinterpret_cast<const f32x4*>(p1 + 4);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(p2), w1 = *reinterpret_cast<const f32x4*>(p2 + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    r[bb][e] = rsub ? u0[e] - w0[e] : u0[e] + w0[e];
-                    r[bb][4 + e] = rsub ? u1[e] - w1[e] : u1[e] + w1[e];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float t = j == 0 ? r[0][e] - r[2][e] : j == 1 ? r[1][e] + r[2][e] : j == 2 ? r[2][e] - r[1][e] : r[1][e] - r[3][e];
-                    v[e] = t * mult;
-                }
-                uint4 ph, pl;
-                hx_split8(v, ph, pl);
-                vh[j] = __builtin_bit_cast(xf_f16x8, ph);
-                vl[j] = __builtin_bit_cast(xf_f16x8, pl);
+            for (int e = 0; e < 4; ++e) {
+                r[bb][e] = rsub ? u0[e] - w0[e] : u0[e] + w0[e];
+                r[bb][4 + e] = rsub ? u1[e] - w1[e] : u1[e] + w1[e];
             }
         }
-        __syncthreads();                                                     // everybody has read halo(c)
-        const bool more = c + 1 < K16;
-        if (more) { load_halo(c + 1); issue_u(c + 1, (c + 1) & 1); }
-        // ---- 24 MFMAs: per (position, output tile) hi*lo, hi*hi, lo*hi -- the accumulation order of gemm_x3t_kernel ------------------------
-        const unsigned char* ub = ubuf + (c & 1) * XF_U_BYTES + lane * 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int p = 4 * wave + j;
+            float v[8];
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const xf_f16x8 uh = *reinterpret_cast<const xf_f16x8*>(ub + ((p * 2 + ct) * 2 + 0) * HX_PIECE);
-                const xf_f16x8 ul = *reinterpret_cast<const xf_f16x8*>(ub + ((p * 2 + ct) * 2 + 1) * HX_PIECE);
-                acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul, vh[j], acc[j][ct], 0, 0, 0);      // A.hi x B.lo
-                acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vh[j], acc[j][ct], 0, 0, 0);      // A.hi x B.hi
-                acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vl[j], acc[j][ct], 0, 0, 0);      // A.lo x B.hi
+            for (int e = 0; e < 8; ++e) {
+                const float t = j == 0 ? r[0][e] - r[2][e] : j == 1 ? r[1][e] + r[2][e] : j == 2 ? r[2][e] - r[1][e] : r[1][e] - r[3][e];
+                v[e] = t * mult;
+            }
+            uint4 ph, pl;
+            hx_split8(v, ph, pl);
+            vh[j] = __builtin_bit_cast(xf_f16x8, ph);
+            vl[j] = __builtin_bit_cast(xf_f16x8, pl);
+        }
+    };
+
+    if (VER == 1) {
+        load_halo(0);
+        issue_u(0, 0);
+        store_halo();
+        __syncthreads();                                                     // (the compiler's fence waits for the DMA: vmcnt(0))
+        for (int c = 0; c < K16; ++c) {
+            xf_f16x8 vh[4], vl[4];
+            form_v(0, vh, vl);
+            __syncthreads();                                                 // everybody has read halo(c)
+            const bool more = c + 1 < K16;
+            if (more) { load_halo(c + 1); issue_u(c + 1, (c + 1) & 1); }
+            // ---- 24 MFMAs: per (position, output tile) hi*lo, hi*hi, lo*hi -- the accumulation order of gemm_x3t_kernel --------------------
+            const unsigned char* ub = ubuf + (c & 1) * XF_U_BYTES + lane * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = 4 * wave + j;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const xf_f16x8 uh = *reinterpret_cast<const xf_f16x8*>(ub + ((p * 2 + ct) * 2 + 0) * HX_PIECE);
+                    const xf_f16x8 ul = *reinterpret_cast<const xf_f16x8*>(ub + ((p * 2 + ct) * 2 + 1) * HX_PIECE);
+                    acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul, vh[j], acc[j][ct], 0, 0, 0);      // filter lo x V hi
+                    acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vh[j], acc[j][ct], 0, 0, 0);      // filter hi x V hi
+                    acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vl[j], acc[j][ct], 0, 0, 0);      // filter hi x V lo
+                }
+            }
+            if (more) store_halo();
+            __syncthreads();                                                 // halo(c+1) and U(c+1) have landed; U(c) is no longer read
+        }
+    } else {
+        // ---- version 2: V(c+1) under the MFMAs of chunk c; halo(c) lives in halo buffer c & 1, U(c) in filter buffer c & 1 ------------------
+        xf_f16x8 vh[4], vl[4], nh[4], nl[4];
+        load_halo(0);
+        issue_u(0, 0);
+        store_halo(0);
+        __syncthreads();
+        form_v(0, vh, vl);
+        if (K16 > 1) { load_halo(1); issue_u(1, 1); store_halo(1); }
+        __syncthreads();                                                     // halo(1), U(0), U(1) have landed
+        for (int c = 0; c < K16; ++c) {
+            const bool more1 = c + 1 < K16, more2 = c + 2 < K16;
+            if (more2) load_halo(c + 2);                                     // registers; written to halo buffer c & 1 below (halo(c) is spent)
+            const unsigned char* ub = ubuf + (c & 1) * XF_U_BYTES + lane * 16;
+            xf_f16x8 uh[4][2], ul[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    uh[j][ct] = *reinterpret_cast<const xf_f16x8*>(ub + (((4 * wave + j) * 2 + ct) * 2 + 0) * HX_PIECE);
+                    ul[j][ct] = *reinterpret_cast<const xf_f16x8*>(ub + (((4 * wave + j) * 2 + ct) * 2 + 1) * HX_PIECE);
+                }
+            // term-major: eight independent accumulators per term; per accumulator still lo*hi, hi*hi, hi*lo in this order
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul[j][ct], vh[j], acc[j][ct], 0, 0, 0);
+            if (more1) form_v((c + 1) & 1, nh, nl);                          // vector work for the next chunk while the matrix pipe runs
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh[j][ct], vh[j], acc[j][ct], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh[j][ct], vl[j], acc[j][ct], 0, 0, 0);
+            if (more2) store_halo(c & 1);
+            __syncthreads();                                                 // U(c) and halo(c+1) are spent, halo(c+2) is visible, U(c+1) has landed
+            if (more2) issue_u(c + 2, c & 1);
+            if (more1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vh[j] = nh[j]; vl[j] = nl[j]; }
             }
         }
-        if (more) store_halo();
-        __syncthreads();                                                     // halo(c+1) and U(c+1) have landed; U(c) is no longer read
+        __syncthreads();
     }
 
     // ---- epilogue: scaled M to LDS [16 positions][32 tiles][64 channels], then wino_output_kernel's arithmetic ----------------------------
@@ -286,14 +341,18 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     if (total > 0x7fffffffLL) return FRCNN_EINVAL;
     const int u_rbt = cdiv(cout, gemm_x6t_col_tile(cout)) * gemm_x6t_col_tile(cout) / 32;
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
-    FRCNN_MAX_LDS_ONCE(wino_x3f_kernel<true>, XF_LDS_BYTES);
-    FRCNN_MAX_LDS_ONCE(wino_x3f_kernel<false>, XF_LDS_BYTES);
-    if (flags & FRCNN_POOL2)
-        hipLaunchKernelGGL(wino_x3f_kernel<true>, dim3((unsigned)total), dim3(256), XF_LDS_BYTES, s, x, cmax,
-                           static_cast<const unsigned char*>(ublob), b, y, H, W, cin, cout, u_rbt, relu, gm);
-    else
-        hipLaunchKernelGGL(wino_x3f_kernel<false>, dim3((unsigned)total), dim3(256), XF_LDS_BYTES, s, x, cmax,
-                           static_cast<const unsigned char*>(ublob), b, y, H, W, cin, cout, u_rbt, relu, gm);
+    static const int ver = []() { const char* e = getenv("FRCNN_X3F_VER"); return e ? atoi(e) : 1; }();       // 2: the not-yet-run version
+    const unsigned char* ub = static_cast<const unsigned char*>(ublob);
+#define XF_LAUNCH(P, V, LDS)                                                                                        \
+    do {                                                                                                           \
+        auto kern = wino_x3f_kernel<P, V>;                                                                          \
+        FRCNN_MAX_LDS_ONCE(kern, LDS);                                                                              \
+        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), LDS, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm);   \
+    } while (0)
+    const bool pool = (flags & FRCNN_POOL2) != 0;
+    if (ver == 2) { if (pool) XF_LAUNCH(true, 2, XF_LDS_BYTES2); else XF_LAUNCH(false, 2, XF_LDS_BYTES2); }
+    else          { if (pool) XF_LAUNCH(true, 1, XF_LDS_BYTES); else XF_LAUNCH(false, 1, XF_LDS_BYTES); }
+#undef XF_LAUNCH
     return check_launch();
 }
 
