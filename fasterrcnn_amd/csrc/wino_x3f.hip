@@ -1,8 +1,7 @@
 // wino_x3f.hip -- EXPERIMENTAL, first version (end of round 3): the Winograd F(2x2,3x3) layer in the f32x3 arithmetic as ONE launch, the
 // form the layers conv1_2 ... conv3_3 need (their V + M scratch is 600 MB per layer in the three-launch form of csrc/wino_x3.hip:
 // DESIGN.md 7.1).  Validated on the MI355X bit for bit against the three-launch layer (tests/test_gemm_x3t_gpu.py); NOT yet tuned and
-// not used by any forward: 0.5-0.8x the speed of the float32 one-launch kernel on the six VGG-16 layers (tools/x3f_bench.py: one 4-wave
-// block per CU, two barriers per chunk, V formation and MFMAs not overlapped, halo staged through registers).
+// not used by any forward: 0.5-0.8x the speed of the float32 one-launch kernel on the six VGG-16 layers (tools/x3f_bench.py).
 //
 // By construction the result equals launch_conv3x3_winograd_x3's BIT FOR BIT (same per-tile scale, same fp16 split, the same sequence of
 // float32 accumulations per (position, tile, output channel) -- hi*lo, hi*hi, lo*hi per 16-channel chunk, chunks in order -- and
@@ -37,10 +36,11 @@ static constexpr size_t XF_LDS_BYTES2 = 2 * (size_t)XF_HALO_BYTES + 2 * XF_U_BYT
 
 struct XfGeom { int tbx, tby, ncb, tw, th; };
 
-// VER 1: the first, validated version.  VER 2 (written after the GPU budget of round 3 was spent: compiled, NOT yet run -- select it with
-// FRCNN_X3F_VER=2 and check it with the same bit-for-bit test): V of chunk c+1 is formed under the MFMAs of chunk c (two halo buffers),
-// the filter DMA runs two chunks ahead, ONE barrier per chunk, and the three products of a chunk are issued term-major so that
-// consecutive MFMAs hit different accumulators (the per-accumulator order, hence every bit, is unchanged).
+// VER 1: the first version.  VER 2 (FRCNN_X3F_VER=2; passes the same bit-for-bit test): V of chunk c+1 is formed under the MFMAs of chunk c
+// (two halo buffers), the filter DMA runs two chunks ahead, ONE barrier per chunk, and the three products of a chunk are issued
+// term-major so that consecutive MFMAs hit different accumulators (the per-accumulator order, hence every bit, is unchanged).  Measured:
+// no faster than VER 1 (conv3_2 232 vs 213 us) -- the kernel is bound by the L2 -> LDS staging of the filter records (64 KB per chunk and
+// block for 96 MFMAs), not by barriers or vector work: DESIGN.md 7.1.  The next version needs 64 tiles per block.
 template <bool POOL, int VER>
 __global__ __launch_bounds__(256, 1)
 void wino_x3f_kernel(const float* __restrict__ x_maps, const float* __restrict__ cmax_maps, const unsigned char* __restrict__ ublob,
