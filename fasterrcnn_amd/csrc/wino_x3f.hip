@@ -319,6 +319,248 @@ void wino_x3f_kernel(const float* __restrict__ x_maps, const float* __restrict__
     }
 }
 
+// ---- VER 3: 64 tiles per block (4 tile rows x 16; FRCNN_X3F_VER=3) -----------------------------------------------------------------------
+// The same arithmetic with twice the tiles per staged filter chunk (75 instead of 43 FLOP per staged byte).  A lane owns the tiles
+// (tile row 2 h + ((l & 31) >> 4), column l & 15) for h = 0, 1: 16 accumulator tiles per wave = 256 accumulator registers.  The loop
+// has VER 1's structure; the epilogue goes through LDS one half (32 tiles) at a time.  Bit-identical too; measured 3 % faster than VER 1
+// (conv3_2 208 us): with VER 1's loop the filter DMA of a chunk is exposed.  Next: this tile with VER 2's DMA distance.
+static constexpr int X3_HR = 10;                                              // halo rows: 4 tile rows x 2 + 2
+static constexpr int X3_HALO_BYTES = X3_HR * XF_HC * XF_PS * 4;               // 27,200
+static constexpr int X3_NPC = (X3_HR * XF_HC * 4 + 255) / 256;                // halo pieces per thread: 6
+static constexpr size_t XF_LDS_BYTES3 = (size_t)X3_HALO_BYTES + 2 * XF_U_BYTES;   // 158,272
+
+template <bool POOL>
+__global__ __launch_bounds__(256, 1)
+void wino_x3f64_kernel(const float* __restrict__ x_maps, const float* __restrict__ cmax_maps, const unsigned char* __restrict__ ublob,
+                       const float* __restrict__ bias, float* __restrict__ y_maps, int H, int W, int Cin, int Cout, int u_rbt, int relu,
+                       XfGeom gm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_xf[];
+    float* const halo = reinterpret_cast<float*>(smem_xf);
+    unsigned char* const ubuf = smem_xf + X3_HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K16 = Cin >> 4;
+
+    int b = blockIdx.x;
+    const int cb = b % gm.ncb;
+    b /= gm.ncb;
+    const int bx = b % gm.tbx;
+    b /= gm.tbx;
+    const int by = b % gm.tby;                                               // gm.tby counts blocks of FOUR tile rows here
+    const int map = b / gm.tby;
+    const float* __restrict__ const x = x_maps + (size_t)map * H * W * Cin;
+    const float* __restrict__ const cmax = cmax_maps + (size_t)map * H * W;
+    float* __restrict__ const y = y_maps + (size_t)map * (POOL ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) * Cout;
+
+    const int tl = lane & 31, tyl = tl >> 4, txl = tl & 15, kh = lane >> 5;
+    const int tx = XF_TC * bx + txl;
+    float mult[2], vinv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ty = 4 * by + 2 * h + tyl;
+        float dmax = 0.f;
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int yy = y0 + a, xx = x0 + c;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) dmax = fmaxf(dmax, cmax[(size_t)yy * W + xx]);
+            }
+        hx_row_scale(4.0f * dmax, mult[h], vinv[h]);
+    }
+
+    const int hy0 = 8 * by - 1, hx0 = 2 * XF_TC * bx - 1;
+    int h_src[X3_NPC], h_dst[X3_NPC];
+#pragma unroll
+    for (int it = 0; it < X3_NPC; ++it) {
+        const int q = tid + 256 * it;
+        const int px = q >> 2, quad = q & 3;
+        const int hr = px / XF_HC, hc = px - hr * XF_HC;
+        const int gy = hy0 + hr, gx = hx0 + hc;
+        const bool live = q < X3_HR * XF_HC * 4;
+        const bool inb = live && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        h_src[it] = inb ? (gy * W + gx) * Cin + 4 * quad : -1;
+        h_dst[it] = live ? (hr * XF_HC + hc) * XF_PS + 4 * quad : -1;
+    }
+    f32x4 hreg[X3_NPC];
+    auto load_halo = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < X3_NPC; ++it)
+            hreg[it] = h_src[it] >= 0 ? *reinterpret_cast<const f32x4*>(x + h_src[it] + 16 * chunk) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int it = 0; it < X3_NPC; ++it)
+            if (h_dst[it] >= 0) *reinterpret_cast<f32x4*>(halo + h_dst[it]) = hreg[it];
+    };
+    auto issue_u = [&](int chunk, int buf) {
+        unsigned char* dst = ubuf + buf * XF_U_BYTES;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int q = wave + 4 * it;
+            const int p = q >> 2, r = (q >> 1) & 1, t = q & 1;
+            const unsigned char* src = ublob + (((size_t)p * K16 + chunk) * u_rbt + 2 * cb + r) * HX_RB + t * HX_PIECE + lane * 16;
+            __builtin_amdgcn_global_load_lds(src, (xf_lds_ptr)(dst + q * HX_PIECE), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[h][j][ct][r] = 0.f;
+
+    const int a1 = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int a2 = wave == 0 ? 2 : (wave == 2 ? 1 : (wave == 1 ? 2 : 3));
+    const bool rsub = wave != 1;
+
+    auto form_v = [&](int h, xf_f16x8 (&vh)[4], xf_f16x8 (&vl)[4]) {
+        const int d_off = ((2 * (2 * h + tyl)) * XF_HC + 2 * txl) * XF_PS + 8 * kh;
+        float r[4][8];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const float* p1 = halo + d_off + (a1 * XF_HC + bb) * XF_PS;
+            const float* p2 = halo + d_off + (a2 * XF_HC + bb) * XF_PS;
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(p1), u1 = *reinterpret_cast<const f32x4*>(p1 + 4);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(p2), w1 = *reinterpret_cast<const f32x4*>(p2 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r[bb][e] = rsub ? u0[e] - w0[e] : u0[e] + w0[e];
+                r[bb][4 + e] = rsub ? u1[e] - w1[e] : u1[e] + w1[e];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = j == 0 ? r[0][e] - r[2][e] : j == 1 ? r[1][e] + r[2][e] : j == 2 ? r[2][e] - r[1][e] : r[1][e] - r[3][e];
+                v[e] = t * mult[h];
+            }
+            uint4 ph, pl;
+            hx_split8(v, ph, pl);
+            vh[j] = __builtin_bit_cast(xf_f16x8, ph);
+            vl[j] = __builtin_bit_cast(xf_f16x8, pl);
+        }
+    };
+
+    load_halo(0);
+    issue_u(0, 0);
+    store_halo();
+    __syncthreads();
+    for (int c = 0; c < K16; ++c) {
+        xf_f16x8 vh[2][4], vl[2][4];
+        form_v(0, vh[0], vl[0]);
+        form_v(1, vh[1], vl[1]);
+        __syncthreads();                                                     // everybody has read halo(c)
+        const bool more = c + 1 < K16;
+        if (more) { load_halo(c + 1); issue_u(c + 1, (c + 1) & 1); }
+        const unsigned char* ub = ubuf + (c & 1) * XF_U_BYTES + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = 4 * wave + j;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const xf_f16x8 uh = *reinterpret_cast<const xf_f16x8*>(ub + ((p * 2 + ct) * 2 + 0) * HX_PIECE);
+                const xf_f16x8 ul = *reinterpret_cast<const xf_f16x8*>(ub + ((p * 2 + ct) * 2 + 1) * HX_PIECE);
+                // per accumulator: filter lo x V hi, filter hi x V hi, filter hi x V lo; the two halves alternate (independent accumulators)
+                acc[0][j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul, vh[0][j], acc[0][j][ct], 0, 0, 0);
+                acc[1][j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul, vh[1][j], acc[1][j][ct], 0, 0, 0);
+                acc[0][j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vh[0][j], acc[0][j][ct], 0, 0, 0);
+                acc[1][j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vh[1][j], acc[1][j][ct], 0, 0, 0);
+                acc[0][j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vl[0][j], acc[0][j][ct], 0, 0, 0);
+                acc[1][j][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vl[1][j], acc[1][j][ct], 0, 0, 0);
+            }
+        }
+        if (more) store_halo();
+        __syncthreads();
+    }
+
+    float* const mbuf = reinterpret_cast<float*>(ubuf);
+    const int Np = u_rbt * 32;
+    const float* uinv = reinterpret_cast<const float*>(ublob + (size_t)16 * K16 * u_rbt * HX_RB);
+    const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();                                              // the first half's transform has read mbuf
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = 4 * wave + j;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = 32 * ct + 8 * g + 4 * kh;
+                    const f32x4 sb = *reinterpret_cast<const f32x4*>(uinv + (size_t)p * Np + 64 * cb + co);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (acc[h][j][ct][4 * g + e] * vinv[h]) * sb[e];
+                    *reinterpret_cast<f32x4*>(mbuf + ((size_t)p * 32 + tl) * 64 + co) = v;
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = tid + 256 * it;
+            const int t = item >> 4, k = (item & 15) * 4;
+            const int oty = 4 * by + 2 * h + (t >> 4), otx = XF_TC * bx + (t & 15);
+            if (oty >= gm.th || otx >= gm.tw) continue;
+            if (POOL && (oty >= Ho || otx >= Wo)) continue;
+            const int kg = 64 * cb + k;
+            const float* mp = mbuf + (size_t)t * 64 + k;
+            f32x4 s[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 m0 = *reinterpret_cast<const f32x4*>(mp + (size_t)(0 + j) * 2048);
+                const f32x4 m1 = *reinterpret_cast<const f32x4*>(mp + (size_t)(4 + j) * 2048);
+                const f32x4 m2 = *reinterpret_cast<const f32x4*>(mp + (size_t)(8 + j) * 2048);
+                const f32x4 m3 = *reinterpret_cast<const f32x4*>(mp + (size_t)(12 + j) * 2048);
+                s[0][j] = (m0 + m1) + m2;
+                s[1][j] = (m1 - m2) - m3;
+            }
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + kg);
+            f32x4 o[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                o[a][0] = ((s[a][0] + s[a][1]) + s[a][2]) + bv;
+                o[a][1] = ((s[a][1] - s[a][2]) - s[a][3]) + bv;
+            }
+            if (relu) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[a][bb][e] = fmaxf(o[a][bb][e], 0.f);
+            }
+            if (POOL) {
+                f32x4 m;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
+                *reinterpret_cast<f32x4*>(y + ((size_t)oty * Wo + otx) * Cout + kg) = m;
+            } else {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int yy = 2 * oty + a;
+                    if (yy >= H) continue;
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int xx = 2 * otx + bb;
+                        if (xx < W) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * Cout + kg) = o[a][bb];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------
 // cmax scratch: n_maps * H * W floats (the channel maxima of the layer input, computed here)
 size_t conv3x3_winograd_x3_fused_workspace_bytes(int N, int H, int W) { return (size_t)N * H * W * sizeof(float); }
@@ -335,13 +577,13 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     if (rc) return rc;
     XfGeom gm;
     gm.tw = cdiv(W, 2); gm.th = cdiv(H, 2);
-    gm.tbx = cdiv(gm.tw, XF_TC); gm.tby = cdiv(gm.th, XF_TR);
+    static const int ver = []() { const char* e = getenv("FRCNN_X3F_VER"); return e ? atoi(e) : 1; }();       // 2, 3: the experimental variants
+    gm.tbx = cdiv(gm.tw, XF_TC); gm.tby = cdiv(gm.th, ver == 3 ? 4 : XF_TR);
     gm.ncb = cout / 64;
     const long long total = (long long)gm.tbx * gm.tby * gm.ncb * N;
     if (total > 0x7fffffffLL) return FRCNN_EINVAL;
     const int u_rbt = cdiv(cout, gemm_x6t_col_tile(cout)) * gemm_x6t_col_tile(cout) / 32;
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
-    static const int ver = []() { const char* e = getenv("FRCNN_X3F_VER"); return e ? atoi(e) : 1; }();       // 2: the not-yet-run version
     const unsigned char* ub = static_cast<const unsigned char*>(ublob);
 #define XF_LAUNCH(P, V, LDS)                                                                                        \
     do {                                                                                                           \
@@ -350,6 +592,17 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
         hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), LDS, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm);   \
     } while (0)
     const bool pool = (flags & FRCNN_POOL2) != 0;
+    if (ver == 3) {
+        if (pool) {
+            auto kern = wino_x3f64_kernel<true>;
+            FRCNN_MAX_LDS_ONCE(kern, XF_LDS_BYTES3);
+            hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), XF_LDS_BYTES3, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm);
+        } else {
+            auto kern = wino_x3f64_kernel<false>;
+            FRCNN_MAX_LDS_ONCE(kern, XF_LDS_BYTES3);
+            hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), XF_LDS_BYTES3, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm);
+        }
+    } else
     if (ver == 2) { if (pool) XF_LAUNCH(true, 2, XF_LDS_BYTES2); else XF_LAUNCH(false, 2, XF_LDS_BYTES2); }
     else          { if (pool) XF_LAUNCH(true, 1, XF_LDS_BYTES); else XF_LAUNCH(false, 1, XF_LDS_BYTES); }
 #undef XF_LAUNCH
