@@ -1,5 +1,8 @@
 // gemm_x3t.hip -- batched  C_b[m][n] = sum_k A_b[m][k] * B_b[n][k]  in the "f32x3" arithmetic on the fp16 matrix pipe: HALF the
-// matrix instructions of the f32x6 form (csrc/gemm_x6t.hip) at the accuracy of a float32 GEMM.
+// matrix instructions of the f32x6 form (csrc/gemm_x6t.hip) at the accuracy of a float32 GEMM.  Replaces the multiply-accumulate of
+// the reference's fc1 / fc2 (pytorch/FasterRCNN/models/vgg16.py:129-133, F.linear in float32), of the 512-channel 3x3 convolutions
+// (models/vgg16.py:89-96, models/rpn.py:88: the 16 Winograd position GEMMs, csrc/wino_x3.hip) and of ResNet's layer4 convolutions
+// (models/resnet.py:109-118 over torchvision's Bottleneck) -- cuDNN / cuBLAS float32 there.
 //
 // Arithmetic.  Every operand ROW r carries a power-of-two scale 2^e(r) that puts its largest magnitude into [2^14, 2^15); the scaled
 // float32 value is split into two fp16 terms

@@ -180,6 +180,7 @@ void roi_pool_x6t_kernel(const float* __restrict__ fm, int fh, int fw, int C, co
 }
 
 // ---- f32x3 form (csrc/gemm_x3t.hip): the record array of the pooled matrix in two fp16 terms per value, rows scaled per RoI ----------
+// (the same pooling as roi_pool_kernel = torchvision.ops.RoIPool at models/detector.py:65-72; only the output format differs)
 // inv[r] = 2^-e of RoI r: every pooled value of the RoI is a maximum over cells of its window, so max over the window of the per-cell
 // channel maximum `cmax` (launch_pixel_absmax of the feature map) bounds the row.  One wave per RoI.
 __global__ __launch_bounds__(256)

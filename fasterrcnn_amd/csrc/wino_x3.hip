@@ -1,4 +1,6 @@
-// wino_x3.hip -- the Winograd F(2x2,3x3) layer of csrc/wino_x6.hip with its 16 position GEMMs in the f32x3 arithmetic
+// wino_x3.hip -- 3x3 stride-1 "same" convolution + bias + ReLU (+ MaxPool2d(2)) of the reference's 512-channel layers
+// (pytorch/FasterRCNN/models/vgg16.py:89-96 conv4_1 ... conv5_3, models/rpn.py:88 the RPN trunk; ResNet: models/resnet.py:110 layer4's
+// 3x3 over the RoI maps) as the Winograd F(2x2,3x3) layer of csrc/wino_x6.hip with its 16 position GEMMs in the f32x3 arithmetic
 // (csrc/gemm_x3t.hip: two fp16 terms per row-scaled operand, three fp16 MFMAs per product -- half the matrix instructions of f32x6).
 // Same transforms in the same float32 operation order (V and U are bit-identical to csrc/winograd.hip's before the split).
 //

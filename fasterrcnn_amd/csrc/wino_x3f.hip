@@ -1,5 +1,5 @@
 // wino_x3f.hip -- EXPERIMENTAL, first version (end of round 3): the Winograd F(2x2,3x3) layer in the f32x3 arithmetic as ONE launch, the
-// form the layers conv1_2 ... conv3_3 need (their V + M scratch is 600 MB per layer in the three-launch form of csrc/wino_x3.hip:
+// form the layers conv1_2 ... conv3_3 (pytorch/FasterRCNN/models/vgg16.py:77-87: 3x3 convolution + ReLU, MaxPool2d after each block) need (their V + M scratch is 600 MB per layer in the three-launch form of csrc/wino_x3.hip:
 // DESIGN.md 7.1).  Validated on the MI355X bit for bit against the three-launch layer (tests/test_gemm_x3t_gpu.py); NOT yet tuned and
 // not used by any forward: 0.5-0.8x the speed of the float32 one-launch kernel on the six VGG-16 layers (tools/x3f_bench.py).
 //
