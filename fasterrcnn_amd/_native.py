@@ -28,7 +28,7 @@ SYMBOLS = (
     "frcnn_pack_stack_rows", "frcnn_conv3x3_c3", "frcnn_conv3x3_workspace_bytes", "frcnn_conv3x3_nhwc",
     "frcnn_maxpool2x2_nhwc",
     "frcnn_linear_workspace_bytes", "frcnn_linear", "frcnn_softmax_rows", "frcnn_rpn_proposals",
-    "frcnn_nms", "frcnn_roi_pool", "frcnn_detections", "frcnn_ctx_create", "frcnn_ctx_create_proposals", "frcnn_ctx_destroy",
+    "frcnn_nms", "frcnn_roi_pool", "frcnn_roi_pool_x3t", "frcnn_detections", "frcnn_ctx_create", "frcnn_ctx_create_proposals", "frcnn_ctx_destroy",
     "frcnn_ctx_bytes", "frcnn_vgg16_forward", "frcnn_ctx_tensor", "frcnn_ctx_timing_enable",
     "frcnn_ctx_timing_read",
     "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv7x7_s2_c3",
@@ -163,7 +163,7 @@ def resnet_block_uses_winograd_fused(n_maps, width, stride):
 
 def resnet_block_uses_winograd(width, stride):
     """== frcnn_resnet_block_uses_winograd(width, stride): the bottleneck 3x3 convolutions the f32_winograd mode transforms."""
-    return stride == 1 and width >= int(os.environ.get("FRCNN_RESNET_WINO_MIN_WIDTH", "256")) and width % 128 == 0
+    return stride == 1 and width >= 256 and width % 128 == 0
 
 
 _lib = None
@@ -220,6 +220,7 @@ _SIGNATURES = {
                                       _vp, _vp, _vp, _vp, _vp]),
     "frcnn_nms": (C.c_int, [_vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp]),
     "frcnn_roi_pool": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "frcnn_roi_pool_x3t": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "frcnn_detections": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "frcnn_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), _i, _i, _i]),
     "frcnn_ctx_create_proposals": (C.c_int, [C.POINTER(C.c_void_p), _i, _i]),

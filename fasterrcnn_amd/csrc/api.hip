@@ -517,6 +517,14 @@ int frcnn_roi_pool(const float* d_fm, int fh, int fw, int c, const float* d_rois
                            as_stream(stream));
 }
 
+int frcnn_roi_pool_x3t(const float* d_fm, int fh, int fw, int c, const float* d_rois, const int32_t* d_n_rois, int max_rois, int pooled,
+                       float spatial_scale, float* d_cmax, float* d_inv_scale, void* d_rec, int rec_rows, void* stream)
+{
+    if (!d_fm || !d_rois || !d_n_rois || !d_cmax || !d_inv_scale || !d_rec) return FRCNN_EINVAL;
+    return launch_roi_pool_x3t(d_fm, fh, fw, c, d_rois, d_n_rois, max_rois, pooled, spatial_scale, d_cmax, d_inv_scale, d_rec, rec_rows,
+                               as_stream(stream));
+}
+
 int frcnn_roi_align(const float* d_fm, int fh, int fw, int c, const float* d_rois, const int32_t* d_n_rois, int max_rois,
                     int pooled, float spatial_scale, int sampling_ratio, int aligned, float* d_out, void* stream)
 {
@@ -1178,7 +1186,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
         } else {
             STEP(4, launch_roi_pool_x6t(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_rec, rr, s));
         }
-        static const int fc_tiles = []() { const char* e = getenv("FRCNN_FC_TILES"); return e ? atoi(e) : 0; }();     // experiments
+        static const int fc_tiles = []() { const char* e = frcnn_knob("FRCNN_FC_TILES"); return e ? atoi(e) : 0; }();     // experiments
         STEP(2, launch_gemm_x6t(c->roi_rec, rr, 0, w->fc1_w, 4096, 0, w->fc1_b, nullptr, c->fc1_out, 4096, 0, R_, 4096, 49 * 512, 1, R,
                                 c->lin_ws, c->lin_ws_bytes, s, fc_tiles));
         STEP(2, launch_split_rows_x6t(c->fc1_out, 4096, 0, c->fc1_rec, R_, rr, 4096, 1, s));

@@ -9,6 +9,19 @@
 typedef float f32x4  __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Experiment knobs.  The tuning / A-B variables the tools/ scripts set (FRCNN_FC_TILES, FRCNN_HX_CFG, FRCNN_WF_XCL, ...) exist ONLY in a
+// library built with -DFRCNN_EXPERIMENT_KNOBS (`make KNOBS=1`, tools/build_ablate.sh).  The shipped library never reads the environment:
+// a stray variable must not change split-K factors -- i.e. output bits -- behind the hipGraph keys and the forward params.
+inline const char* frcnn_knob(const char* name)
+{
+#ifdef FRCNN_EXPERIMENT_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 namespace frcnn {
 
 // Record the last HIP error of this thread (read by frcnn_last_hip_error()).
@@ -58,7 +71,7 @@ static inline bool conv3x3_uses_winograd(int cin, int cout) { return cin >= 128 
 static inline int resnet_winograd_min_width()
 {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("FRCNN_RESNET_WINO_MIN_WIDTH"); v = e ? atoi(e) : 256; }
+    if (v < 0) { const char* e = frcnn_knob("FRCNN_RESNET_WINO_MIN_WIDTH"); v = e ? atoi(e) : 256; }
     return v;
 }
 static inline bool resnet_block_uses_winograd(int width, int stride) { return stride == 1 && width >= resnet_winograd_min_width() && width % 128 == 0; }

@@ -509,7 +509,7 @@ static int conv_blocks_target()
 {
     static int env_target = -1;
     if (env_target < 0) {
-        const char* e = getenv("FRCNN_CONV_BLOCKS_TARGET");
+        const char* e = frcnn_knob("FRCNN_CONV_BLOCKS_TARGET");
         env_target = e ? atoi(e) : 0;
         if (env_target < 0) env_target = 0;
     }

@@ -411,7 +411,7 @@ static GatherPlan plan_gather(int M, int Cout, int stages)
     p.mblocks = cdiv(M, bm);
     p.nblocks = cdiv(Cout, bn);
     const int blocks = p.mblocks * p.nblocks;
-    static const int target = []() { const char* e = getenv("FRCNN_GATHER_BLOCKS"); return e ? atoi(e) : 1280; }();   // experiments
+    static const int target = []() { const char* e = frcnn_knob("FRCNN_GATHER_BLOCKS"); return e ? atoi(e) : 1280; }();   // experiments
     int want = target / (blocks > 0 ? blocks : 1);     // ~5 blocks per CU (see conv.hip)
     int cap = stages / 8;
     if (cap < 1) cap = 1;

@@ -595,7 +595,7 @@ static int x6_ksplit(int H, int W, int cin, int cout)
     const int nchunks = cin / 16;
     static int env_target = -1;
     if (env_target < 0) {
-        const char* e = getenv("FRCNN_X6_BLOCKS_TARGET");       // tuning knob
+        const char* e = frcnn_knob("FRCNN_X6_BLOCKS_TARGET");       // tuning knob
         env_target = e ? atoi(e) : 0;
         if (env_target < 0) env_target = 0;
     }

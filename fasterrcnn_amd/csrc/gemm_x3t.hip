@@ -456,7 +456,7 @@ static HxPlan plan_gemm_x3t(int M, int N, int K, int batches, int tiles_mode = -
 {
     HxPlan pl;
     const int chunks = K / 16;
-    static const int env_force = []() { const char* e = getenv("FRCNN_HX_CFG"); return e ? atoi(e) : -1; }();   // experiments: 0 / 1
+    static const int env_force = []() { const char* e = frcnn_knob("FRCNN_HX_CFG"); return e ? atoi(e) : -1; }();   // experiments: 0 / 1
     const int mode = tiles_mode >= 0 ? tiles_mode : gemm_x6t_get_tiles();
     const int force = (env_force >= 0 && tiles_mode < 0) ? env_force : (mode == 1 ? 0 : mode == 2 ? 1 : -1);
     const long long u0 = (long long)cdiv(M, 320) * cdiv(N, 256) * batches;
@@ -522,7 +522,7 @@ int launch_gemm_x3t(const void* a_rec, const float* a_inv, int a_rows, size_t a_
     p.total = (int)total;
     // 32-k stages for LONG reductions whose splits hold an even number of 16-k chunks (fc1: 98 chunks per split, 184 -> 176 us; the 16 / 32
     // chunk reductions of the Winograd layers and fc2 measure the same either way and keep the three-buffer form), 16-k stages otherwise
-    static const int env_nsub = []() { const char* e = getenv("FRCNN_HX_NSUB"); return e ? atoi(e) : 0; }();     // experiments: 1 / 2
+    static const int env_nsub = []() { const char* e = frcnn_knob("FRCNN_HX_NSUB"); return e ? atoi(e) : 0; }();     // experiments: 1 / 2
     const int last = p.nchunks - (pl.splits - 1) * pl.chunks_per_split;
     const bool even = pl.chunks_per_split % 2 == 0 && last % 2 == 0;
     const int nsub = !even ? 1 : (env_nsub == 1 || env_nsub == 2) ? env_nsub : (pl.chunks_per_split >= 64 ? 2 : 1);

@@ -464,7 +464,7 @@ static GxPlan plan_gemm_x6t(int M, int N, int K, int batches, int tiles_mode = -
 {
     GxPlan pl;
     const int chunks = K / 16;
-    static const int env_force = []() { const char* e = getenv("FRCNN_GX_CFG"); return e ? atoi(e) : -1; }();   // experiments: 0 / 1
+    static const int env_force = []() { const char* e = frcnn_knob("FRCNN_GX_CFG"); return e ? atoi(e) : -1; }();   // experiments: 0 / 1
     const int mode = tiles_mode >= 0 ? tiles_mode : g_gx_tiles;
     const int force = (env_force >= 0 && tiles_mode < 0) ? env_force : (mode == 1 ? 0 : mode == 2 ? 1 : -1);
     // cost model in matrix-pipe cycles per 16-k stage of the busiest CU: cfg 0 runs one block per CU at 3840 cycles per stage; a cfg 1

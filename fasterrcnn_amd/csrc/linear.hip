@@ -339,7 +339,7 @@ static LinearPlan plan_linear(int M, int N, int K)
     p.nblocks = cdiv(N, 128);
     const int stages = K / 16;
     static int target = -1;
-    if (target < 0) { const char* e = getenv("FRCNN_LINEAR_BLOCKS_TARGET"); target = e ? atoi(e) : 256; if (target < 1) target = 1; }
+    if (target < 0) { const char* e = frcnn_knob("FRCNN_LINEAR_BLOCKS_TARGET"); target = e ? atoi(e) : 256; if (target < 1) target = 1; }
     int want = target / (p.mblocks * p.nblocks);    // fill 256 CUs
     int cap = stages / 8;                           // >= 8 stages (128 k) per split
     if (cap < 1) cap = 1;
@@ -400,7 +400,7 @@ int launch_linear_batched(const float* a, int lda, size_t a_stride, const float*
 {
     if (M < 1 || N < 1 || K < 16 || K % 16 != 0 || lda % 4 != 0 || lda < K || ldy < N || batches < 1) return FRCNN_EINVAL;
     static int env_tile = -1;
-    if (env_tile < 0) { const char* e = getenv("FRCNN_WINO_TILE"); env_tile = e ? atoi(e) : 0; }
+    if (env_tile < 0) { const char* e = frcnn_knob("FRCNN_WINO_TILE"); env_tile = e ? atoi(e) : 0; }
     const int tile = env_tile ? env_tile : (g_batched_tile ? g_batched_tile : 64);
     BatchGeom bg{(long long)a_stride, (long long)w_stride, (long long)y_stride, cdiv(N, 128), cdiv(M, 128), batches};
     if (tile == 128) return launch_linear_batched_cfg<2, 2, 2, 2, 1>(a, lda, w, y, ldy, M, N, K, bg, s);

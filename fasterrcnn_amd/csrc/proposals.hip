@@ -725,7 +725,7 @@ static int launch_topk(const u64* keys, int n_keys, int K, const float* boxes_sr
     const int sort_n = pow2_at_least(K);
     if (sort_n > 16384) return FRCNN_EUNSUPPORTED;
     const size_t lds = (size_t)sort_n * 8 + 4096 * 4 + 64 * 4;
-    static const bool no_split = getenv("FRCNN_TOPK_ONE_BLOCK") != nullptr;          // experiments / A-B tests
+    static const bool no_split = frcnn_knob("FRCNN_TOPK_ONE_BLOCK") != nullptr;          // experiments / A-B tests
     if (MODE == 0 && tmp != nullptr && !no_split) {
         unsigned char* tb = static_cast<unsigned char*>(tmp);
         u64* sel = reinterpret_cast<u64*>(tb);

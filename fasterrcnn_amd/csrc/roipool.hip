@@ -185,7 +185,7 @@ void roi_pool_x6t_kernel(const float* __restrict__ fm, int fh, int fw, int C, co
 // channel maximum `cmax` (launch_pixel_absmax of the feature map) bounds the row.  One wave per RoI.
 __global__ __launch_bounds__(256)
 void roi_scale_x3t_kernel(const float* __restrict__ cmax, int fh, int fw, const float* __restrict__ rois, const int32_t* __restrict__ n_rois,
-                          int max_rois, int rec_rows, float scale, float* __restrict__ inv)
+                          int max_rois, int rec_rows, int pooled, float scale, float* __restrict__ inv)
 {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -198,9 +198,13 @@ void roi_scale_x3t_kernel(const float* __restrict__ cmax, int fh, int fw, const 
         const int rs_h = (int)roundf(roi[0] * scale), rs_w = (int)roundf(roi[1] * scale);
         const int re_h = (int)roundf(roi[2] * scale), re_w = (int)roundf(roi[3] * scale);
         const int roi_h = max(re_h - rs_h + 1, 1), roi_w = max(re_w - rs_w + 1, 1);
-        // the union of the bins: [rs, rs + roi) clipped to the map (the bins' floor / ceil edges never leave it)
-        const int hs = min(max(rs_h, 0), fh), he = min(max(rs_h + roi_h, 0), fh);
-        const int ws = min(max(rs_w, 0), fw), we = min(max(rs_w + roi_w, 0), fw);
+        // the union of the bins, from roi_pool_x3t_kernel's OWN float32 edge expressions: the first bin starts at floor(0 * bin) + rs
+        // = rs and the last one ends at ceil(pooled * (roi / pooled)) + rs, which in float32 is roi + 1 for some sizes (roi = 57, 114,
+        // 121 with 7 bins: ADVICE r3) -- the bins CAN reach one cell past [rs, rs + roi), and a row scale taken from the shorter range
+        // would not bound that cell.
+        const float bin_h = (float)roi_h / (float)pooled, bin_w = (float)roi_w / (float)pooled;
+        const int hs = min(max(rs_h, 0), fh), he = min(max((int)ceilf((float)pooled * bin_h) + rs_h, 0), fh);
+        const int ws = min(max(rs_w, 0), fw), we = min(max((int)ceilf((float)pooled * bin_w) + rs_w, 0), fw);
         const int ww = we - ws, cells = (he - hs) * ww;
         for (int i = lane; i < cells; i += 64) {
             const int h = hs + i / ww, w = ws + i % ww;
@@ -343,7 +347,7 @@ int launch_roi_pool_x3t(const float* fm, int fh, int fw, int c, const float* roi
         return FRCNN_EINVAL;
     int rc = launch_pixel_absmax(fm, cmax, (long long)fh * fw, c, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(roi_scale_x3t_kernel, dim3(cdiv(rec_rows, 4)), dim3(256), 0, s, cmax, fh, fw, rois, n_rois, max_rois, rec_rows, scale, inv);
+    hipLaunchKernelGGL(roi_scale_x3t_kernel, dim3(cdiv(rec_rows, 4)), dim3(256), 0, s, cmax, fh, fw, rois, n_rois, max_rois, rec_rows, pooled, scale, inv);
     if ((rc = check_launch()) != FRCNN_OK) return rc;
     const int rbt = rec_rows / 32;
     const long long waves = (long long)pooled * pooled * rbt * (c / 16);

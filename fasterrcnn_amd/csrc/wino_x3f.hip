@@ -577,7 +577,7 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     if (rc) return rc;
     XfGeom gm;
     gm.tw = cdiv(W, 2); gm.th = cdiv(H, 2);
-    static const int ver = []() { const char* e = getenv("FRCNN_X3F_VER"); return e ? atoi(e) : 1; }();       // 2, 3: the experimental variants
+    static const int ver = []() { const char* e = frcnn_knob("FRCNN_X3F_VER"); return e ? atoi(e) : 1; }();       // 2, 3: the experimental variants
     gm.tbx = cdiv(gm.tw, XF_TC); gm.tby = cdiv(gm.th, ver == 3 ? 4 : XF_TR);
     gm.ncb = cout / 64;
     const long long total = (long long)gm.tbx * gm.tby * gm.ncb * N;

@@ -532,7 +532,7 @@ static int wf_choose_xcl(int cin, int cout, int ncb)
 {
     int maxl = 0;
     while (maxl < 3 && (ncb % (2 << maxl)) == 0) ++maxl;
-    static const char* env = getenv("FRCNN_WF_XCL");
+    static const char* env = frcnn_knob("FRCNN_WF_XCL");
     int want;
     if (env) {
         want = atoi(env);
@@ -567,7 +567,7 @@ int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b
     static bool occ_printed = false;
     if (!occ_printed) {
         occ_printed = true;
-        if (getenv("FRCNN_DEBUG_OCCUPANCY")) {
+        if (frcnn_knob("FRCNN_DEBUG_OCCUPANCY")) {
             int nb = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(wino_fused_kernel<false>), 256, WF_LDS_BYTES);
             fprintf(stderr, "wino_fused_kernel: %d blocks per CU at %zu B of LDS\n", nb, WF_LDS_BYTES);

@@ -18,8 +18,11 @@ __device__ __forceinline__ void hx_split8(const float (&v)[8], uint4& ph, uint4&
     _Float16 hi[8], lo[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        hi[j] = (_Float16)v[j];                       // round to nearest even
-        lo[j] = (_Float16)(v[j] - (float)hi[j]);
+        // every producer bounds its row (|v| < 2^15); the clamp keeps a value a producer failed to bound from becoming hi = inf,
+        // lo = -inf -> NaN in the GEMM: it saturates instead
+        const float vj = v[j] > 65504.f ? 65504.f : (v[j] < -65504.f ? -65504.f : v[j]);      // a NaN stays a NaN
+        hi[j] = (_Float16)vj;                         // round to nearest even
+        lo[j] = (_Float16)(vj - (float)hi[j]);
     }
     ph = make_uint4(hx_pack2(hi[0], hi[1]), hx_pack2(hi[2], hi[3]), hx_pack2(hi[4], hi[5]), hx_pack2(hi[6], hi[7]));
     pl = make_uint4(hx_pack2(lo[0], lo[1]), hx_pack2(lo[2], lo[3]), hx_pack2(lo[4], lo[5]), hx_pack2(lo[6], lo[7]));

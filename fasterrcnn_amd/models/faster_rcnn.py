@@ -418,7 +418,7 @@ class FasterRCNNModel(nn.Module):
         slot = self._slots.get(key)
         if slot is None or not slot.ctx.fits(h, w, self.max_proposals_post_nms) or slot.num_classes != self._num_classes:
             slot = rt.Slot(device, max(h, 608), max(w, 1008), self.max_proposals_post_nms, self._num_classes,
-                           own_stream=(index > 0))
+                           own_stream=(index != 0))
             self._slots[key] = slot
         return slot
 
@@ -454,7 +454,9 @@ class FasterRCNNModel(nn.Module):
         A true batch (B, 3, H, W) through a ResNet model (the reference asserts B == 1, faster_rcnn.py:108; BASELINE configs[2] is
         "batch=8"): ONE pass of the feature extractor over the B images on the lane's stream (frcnn_resnet_backbone: every bottleneck
         launch covers the B maps), then RPN + detector head + decode / NMS per image on B slot streams behind it
-        (frcnn_resnet_forward_features).  Returns B Pending handles.  Lane l uses the slots 1 + l * B ... (l + 1) * B.
+        (frcnn_resnet_forward_features).  Returns B Pending handles.  Lane l owns the slots ("lane", l, 0 ... B - 1): a key space of its own,
+        independent of the lane's capacity and of predict_async's integer slots (a stride derived from the lane's own max_images made
+        lanes of different capacity overlap: ADVICE r3).
         """
         if not self._is_resnet:
             raise NotImplementedError("batched forward: ResNet backbones only (VGG-16's layers fill the chip with one image)")
@@ -477,11 +479,10 @@ class FasterRCNNModel(nn.Module):
                     sl.done.synchronize()
             lane = rt.BackboneLane(device, max(h, 608), max(w, 1008), max(B, lane.max_images if lane is not None else 1), channels)
             self._lanes[key] = lane
-        cap = lane.max_images
-        slots = [self._slot(1 + lane_index * cap + i, h, w, device) for i in range(B)]
+        slots = [self._slot(("lane", lane_index, i), h, w, device) for i in range(B)]
         for i, slot in enumerate(slots):
             if slot.busy:
-                raise RuntimeError("slot %d still has an un-collected image in flight" % (1 + lane_index * cap + i))
+                raise RuntimeError("lane %d, image %d still has an un-collected image in flight" % (lane_index, i))
         weights = self._weights()
         params = self._forward_params(1)
         lib = nv.lib()

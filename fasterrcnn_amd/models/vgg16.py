@@ -218,8 +218,9 @@ class PoolToFeatureVector(nn.Module):
 
     def packed(self, mode=None):
         """(fc1 weight, fc1 bias, fc2 weight, fc2 bias) in the layout of `mode` (default: `fc_math_mode`): float32 matrices ("f32") or
-        their x6 records (uint8 tensors of 96 B per (row, 16-k chunk): frcnn_split_rows_x6).  One pack per mode is cached: a model
-        whose row count exceeds the x6 kernel's 320-row tile runs the f32 pack of the same weights."""
+        their x6 / x3 records.  Only the pack of the mode last asked for is kept (0.4 - 0.6 GB each: switching modes must not
+        accumulate device memory); a model whose row count exceeds the v1 x6 kernel's 320-row tile runs the f32 pack of the
+        same weights and re-packs when it alternates."""
         mode = mode or self.fc_math_mode
         params = [self._fc1.weight, self._fc1.bias, self._fc2.weight, self._fc2.bias]
         key = rt.param_key(params)
@@ -227,6 +228,7 @@ class PoolToFeatureVector(nn.Module):
             self._packed = {}
             self._packed_key = key
         if mode not in self._packed:
+            self._packed = {}                        # drop the other modes' packs BEFORE allocating this one
             w1p, b1, w2, b2 = self.packed_direct()
             if mode == "f32x6_v1":
                 w1p, w2 = split_rows_x6(w1p, rows_out=4096), split_rows_x6(w2, rows_out=4096)

@@ -398,6 +398,14 @@ int frcnn_nms(frcnn_ctx* ctx, const float* d_boxes, const float* d_scores, int n
 int frcnn_roi_pool(const float* d_fm, int fh, int fw, int c, const float* d_rois,
                    const int32_t* d_n_rois, int max_rois, int pooled, float spatial_scale,
                    float* d_out, void* stream);
+/* The same pooling writing fc1's operand in the f32x3 arithmetic directly (csrc/roipool.hip: roi_scale_x3t_kernel, roi_pool_x3t_kernel; what
+ * frcnn_vgg16_forward runs with fc_math_mode FRCNN_FC_F32X3T): x3t records of the matrix [rec_rows][pooled * pooled * c], k = (ph * pooled +
+ * pw) * c + channel, one power-of-two scale per RoI taken from the maximum of |fm| over the UNION OF THE RoI'S BINS (the bins' own float32
+ * floor / ceil edges, which can reach one cell past round(x2 / 16): tests/test_gemm_x3t_gpu.py).
+ *   d_cmax : scratch, float32 [fh * fw] (per-cell channel maximum of |fm|, written here);  d_inv_scale : float32 [rec_rows] (2^-e, written)
+ *   d_rec  : frcnn_x3t_record_bytes(rec_rows, pooled * pooled * c) bytes;  rec_rows % 32 == 0, >= max_rois;  c % 16 == 0 */
+int frcnn_roi_pool_x3t(const float* d_fm, int fh, int fw, int c, const float* d_rois, const int32_t* d_n_rois, int max_rois, int pooled,
+                       float spatial_scale, float* d_cmax, float* d_inv_scale, void* d_rec, int rec_rows, void* stream);
 /* RoIAlign with torchvision.ops.roi_align's semantics (csrc/roialign.hip) -- the pooling BASELINE.json's north_star names; the
  * reference pools with RoIPool (models/detector.py:16,27), so this is an option beyond it (DetectorNetwork(pooling="align")).
  * Same tensors as frcnn_roi_pool; sampling_ratio = samples per bin and axis (1 or 2; <= 0: adaptive ceil(roi_size / pooled)),

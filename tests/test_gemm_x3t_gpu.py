@@ -269,6 +269,43 @@ def test_roi_pool_x3t_records_hold_the_pooled_values(gpu_model):
     assert float((c.sum(dim=1) - 1.0).abs().max()) <= 1e-5
 
 
+def test_roi_scale_x3t_covers_the_bins_float32_edges():
+    """ceil(7 * (roi / 7.0f)) == roi + 1 in float32 for roi = 57, 114, 121, so the last bin of such a RoI reads one row /
+    column beyond [rs, rs + roi).  The per-RoI fp16 scale must bound that cell too: with an outlier there (1000x the rest) the f32x3
+    records used to overflow to hi = inf, lo = -inf (-> NaN in fc1).  The records must hold the float32 pooling's values to 2^-22."""
+    lib = nv.lib()
+    fh, fw, c, pooled = 60, 124, 32, 7
+    gen = torch.Generator().manual_seed(57)
+    fm = torch.rand((fh, fw, c), generator=gen)
+    fm[57, :, :] = 1000.0 + 1000.0 * torch.rand((fw, c), generator=gen)      # the row just past a 57-cell RoI that starts at row 0
+    fm[:, 114, :] = 1500.0                                                   # the column just past a 114-cell RoI from column 0
+    fm[:, 122, :] = 3000.0                                                   # ... past a 121-cell RoI from column 1
+    rois = torch.tensor([[0.0, 0.0, 56 * 16.0, 300.0],        # 57 rows: the last bin ends at row 58 (exclusive) in float32
+                         [16.0, 0.0, 400.0, 113 * 16.0],      # 114 columns
+                         [32.0, 16.0, 300.0, 121 * 16.0],     # 121 columns starting at column 1
+                         [100.0, 100.0, 300.0, 400.0]])       # an ordinary RoI
+    n, rec_rows, k = 4, 32, pooled * pooled * c
+    d_fm, d_rois = fm.cuda(), rois.cuda()
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    out = torch.empty((n, pooled, pooled, c), device="cuda")
+    nv.check(lib.frcnn_roi_pool(nv.ptr(d_fm), fh, fw, c, nv.ptr(d_rois), nv.ptr(d_n), n, pooled, 1.0 / 16.0, nv.ptr(out), nv.stream_ptr()), "roi_pool")
+    per = int(lib.frcnn_x3t_record_bytes(rec_rows, k))
+    blob = torch.zeros((per + 4 * rec_rows,), dtype=torch.int8, device="cuda")
+    cmax = torch.empty((fh * fw,), device="cuda")
+    nv.check(lib.frcnn_roi_pool_x3t(nv.ptr(d_fm), fh, fw, c, nv.ptr(d_rois), nv.ptr(d_n), n, pooled, 1.0 / 16.0, nv.ptr(cmax),
+                                    blob.data_ptr() + per, nv.ptr(blob), rec_rows, nv.stream_ptr()), "roi_pool_x3t")
+    torch.cuda.synchronize()
+    hi, lo, inv = blob_planes(blob, per, rec_rows, k, 1)
+    ref = out.cpu().numpy().astype(np.float64).reshape(n, k)
+    assert ref[0].max() >= 1000.0 and ref[1].max() == 1500.0 and ref[2].max() == 3000.0      # the outliers ARE inside the last bins
+    assert np.isfinite(hi).all() and np.isfinite(lo).all()
+    scaled = ref / inv[0, :n, None]
+    assert (np.abs(scaled).max(axis=1) < 2.0 ** 15).all()                                    # every row bounded by its scale
+    err = np.abs(hi[0, :n] + lo[0, :n] - scaled)
+    assert (err <= np.maximum(2.0 ** -22 * np.abs(scaled), 2.0 ** -25)).all()
+    assert (hi[0, n:] == 0).all() and (lo[0, n:] == 0).all()
+
+
 X3_ALL_PROPOSALS = 299      # observed with EVERY layer of the x6 table in f32x3: the same 300 rows in the same order, but the 599 px box of
 X3_ALL_DETECTIONS = 193     # golden proposal 38 comes out 1.04e-3 px off (1.7e-6 of its side) and counts as missed at the 1e-3 px gate, with
                             # it one detection; the default table's worst coordinate is 0.92e-3 px (300 / 300, 194 / 194: test_model_gpu.py)

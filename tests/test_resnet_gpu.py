@@ -508,3 +508,29 @@ def test_evaluate_stream_batched_matches_per_image(r50):
         na = sum(len(v) for v in got_a[i].values())
         nb = sum(len(v) for v in got_b[i].values())
         assert abs(na - nb) <= max(2, na // 20), (i, na, nb)
+
+
+def test_evaluate_stream_batched_partial_groups_on_mixed_shapes(r50):
+    """a lane's slots must not depend on the lane's own capacity.  Shapes A, A, B, A, A, A, B, B with batch = 2 and two lanes:
+    lane 1's FIRST group is a single image while lane 0's full group is still pending (the slot stride used to be the lane's
+    max_images, so lane 1 / image 0 landed on lane 0 / image 1: 'slot still has an un-collected image in flight'), and later a lane's
+    capacity grows from 1 to 2 while the other lane is busy."""
+    from fasterrcnn_amd import evaluate as ev
+    model, _ = r50
+    widths = [448, 448, 480, 448, 448, 448, 480, 480]
+    samples = [(i, synthetic.image_rgb(60 + i, 320, wd).unsqueeze(0).cuda(), None) for i, wd in enumerate(widths)]
+    got_a, got_b = {}, {}
+    ev.evaluate_stream(model, samples, score_threshold=0.05, inflight=4, on_result=lambda i, d: got_a.__setitem__(i, d))
+    ev.evaluate_stream(model, samples, score_threshold=0.05, inflight=4, batch=2, on_result=lambda i, d: got_b.__setitem__(i, d))
+    assert sorted(got_a) == sorted(got_b) == list(range(len(widths)))
+    for i in range(len(widths)):
+        na = sum(len(v) for v in got_a[i].values())
+        nb = sum(len(v) for v in got_b[i].values())
+        assert abs(na - nb) <= max(2, na // 20), (i, na, nb)
+    # and the batched lanes never touch predict_async's integer slots: an image in flight in slot 1 stays collectable
+    h1 = model.predict_async(samples[0][1], 0.05, slot=1)
+    hb = model.predict_batch_async(torch.cat([samples[0][1], samples[1][1]], dim=0), 0.05, lane=0)
+    n1 = sum(len(v) for v in h1.result().values())
+    nb0 = sum(len(v) for v in hb[0].result().values())
+    hb[1].result()
+    assert abs(n1 - nb0) <= max(2, n1 // 20)
