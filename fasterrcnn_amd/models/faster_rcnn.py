@@ -628,11 +628,12 @@ class FasterRCNNModel(nn.Module):
         return self._enqueue_batch(image_data, score_threshold, lane)
 
     def context(self, slot=0):
-        """The runtime.Context of an in-flight slot (parity tests read intermediate tensors from it)."""
+        """The runtime.Context of an in-flight slot (parity tests read intermediate tensors from it): an integer (forward / predict: 0,
+        predict_async: its `slot`) or ("lane", lane, image) for the images of predict_batch."""
         for (dev, idx), s in self._slots.items():
             if idx == slot:
                 return s.ctx
-        raise KeyError("slot %d has not been used yet" % slot)
+        raise KeyError("slot %r has not been used yet" % (slot,))
 
     # ------------------------------------------------------------------------------------------
     def _training_state(self):

@@ -147,6 +147,16 @@ def image(seed, height=600, width=1000):
     return (up - means).contiguous()
 
 
+def image_u8(seed, height=375, width=625):
+    """A DECODED image as imageio / PIL hand it to datasets/image.py: uint8 (height, width, 3) RGB, the same low-resolution noise field as
+    image() / image_rgb().  375 x 625 is a VOC-sized frame that load_image's 600-pixel minimum side scales to exactly 600 x 1000."""
+    g = t.Generator().manual_seed(1000003 * int(seed) + 17)
+    lh, lw = max(2, int(round(height / 19.75))), max(2, int(round(width / 19.53)))
+    low = t.rand((1, 3, lh, lw), generator=g, dtype=t.float32)
+    up = t.nn.functional.interpolate(low, size=(height, width), mode="bilinear", align_corners=False)[0] * 255.0
+    return up.round().clamp(0, 255).to(t.uint8).permute(1, 2, 0).contiguous()
+
+
 def ground_truth(seed, height=600, width=1000, num_classes=21):
     """
     1-5 ground-truth boxes for image `seed`: list of (class_index, (y1, x1, y2, x2) float32 array),

@@ -80,8 +80,12 @@ def measure(model, g):
     out["prop_rows"] = int(len(r_err))
     out["prop_rows_within_gate"] = int((r_err <= GATE).sum())
     out["prop_row_err_max"] = float(r_err.max()) if len(r_err) else 0.0
+    out["order_identical"] = bool(len(r_err) and np.isfinite(r_err).all() and r_err.max() <= 0.05)   # every row the reference's row
+    # the same as a SET (nearest row of ours for every reference row): one flipped NMS decision shifts every later row index by one
+    s_err, _ = T.proposal_errors(g["ref_proposals"], ours) if len(ours) else (np.full(len(g["ref_proposals"]), np.inf), None)
+    out["prop_rows_matched_within_gate"] = int((s_err <= GATE).sum())
     ref_det = g["ref_detections"]
-    d_ok = 0
+    d_ok = d_set = 0
     d_rows = len(ref_det)
     for c in np.unique(ref_det[:, 0]) if d_rows else []:
         r = ref_det[ref_det[:, 0] == c]
@@ -91,8 +95,13 @@ def measure(model, g):
         m = min(len(o), len(r))
         s[:m] = np.abs(o[:m, 5] - r[:m, 5])
         d_ok += int(((e <= GATE) & (s <= 1e-4)).sum())
+        if len(o):
+            dd = np.abs(o[None, :, 1:5] - r[:, None, 1:5]).max(axis=2)
+            jn = dd.argmin(axis=1)
+            d_set += int(((dd[np.arange(len(r)), jn] <= GATE) & (np.abs(o[jn, 5] - r[:, 5]) <= 1e-4)).sum())
     out["det_rows"] = int(d_rows)
     out["det_rows_within_gate"] = int(d_ok)
+    out["det_rows_matched_within_gate"] = int(d_set)
     out["det_extra_rows"] = int(max(0, det.shape[0] - d_rows))
     # --- against the truth
     p_err, p_near = T.proposal_errors(ours, g["truth_cand_boxes"])
@@ -114,10 +123,11 @@ def pooled(results, key):
 
 
 def format_line(r):
-    return ("%-9s s%-3d w%-4d | vs REF rows<=1e-3: prop %3d/%3d (max %.2e) det %3d/%3d (+%d) | vs TRUTH prop med %.2e p95 %.2e max %.2e far %d "
+    return ("%-9s s%-3d w%-4d | vs REF rows<=1e-3: prop %3d/%3d (as a set %3d; order %s; max %.2e) det %3d/%3d (set %3d, +%d) | vs TRUTH prop med %.2e p95 %.2e max %.2e far %d "
             "[ref %.2e %.2e %.2e] det med %.2e p95 %.2e [ref %.2e %.2e] | fm %.2e [ref %.2e] obj %.2e [ref %.2e]" % (
-                r["arch"], r["seed"], r["weights_seed"], r["prop_rows_within_gate"], r["prop_rows"], r["prop_row_err_max"],
-                r["det_rows_within_gate"], r["det_rows"], r["det_extra_rows"],
+                r["arch"], r["seed"], r["weights_seed"], r["prop_rows_within_gate"], r["prop_rows"], r["prop_rows_matched_within_gate"],
+                "same" if r["order_identical"] else "DIFFERS", r["prop_row_err_max"],
+                r["det_rows_within_gate"], r["det_rows"], r["det_rows_matched_within_gate"], r["det_extra_rows"],
                 r["prop_vs_truth"]["median"], r["prop_vs_truth"]["p95"], r["prop_vs_truth"]["max"], r["prop_vs_truth"]["n_far"],
                 r["ref_prop_vs_truth"]["median"], r["ref_prop_vs_truth"]["p95"], r["ref_prop_vs_truth"]["max"],
                 r["det_vs_truth"]["median"], r["det_vs_truth"]["p95"], r["ref_det_vs_truth"]["median"], r["ref_det_vs_truth"]["p95"],

@@ -245,3 +245,46 @@ def test_model_moves_to_second_device_in_one_process():
             out.append(model.predict(image_data=img.to(dev), score_threshold=0.05))
     for c in out[0]:
         assert np.array_equal(out[0][c], out[1][c])
+
+
+def test_host_feeder_equals_upload_then_predict(gpu_model, sd_cpu):
+    """The end-to-end leg of bench.py (`h2d_preprocess_images_per_sec`): pinned host frame -> async H2D -> frcnn_preprocess
+    -> predict_async on per-slot streams == the synchronous `preprocess_image(...)` + `predict` of the same frame, bit for bit, for
+    several frames in flight and re-used slots; the preprocessed tensor == the oracle's PIL-exact restatement (datasets/image.py:59-101);
+    `submit_preprocessed` (the reference's `t.from_numpy(image).cuda()`, __main__.py:80) == predict on the device-resident tensor."""
+    from fasterrcnn_amd.datasets import image as I
+    params = gpu_model.backbone.image_preprocessing_params
+    frames = [synthetic.image_u8(70 + i) for i in range(5)]
+    feeder = E.HostFeeder(gpu_model)
+    base = []
+    for f in frames:
+        img, scale, shape = I.preprocess_image(f.numpy(), params, 600, False)
+        assert tuple(img.shape) == (3, 600, 1000) and abs(scale - 1.6) < 1e-12 and shape == (3, 375, 625)
+        base.append(gpu_model.predict(image_data=img.unsqueeze(0), score_threshold=0.05))
+    ref = O.preprocess_image(frames[0].numpy(), params.channel_order.value == "BGR", params.scaling, params.means, params.stds, 600, False)
+    img0, _, _ = I.preprocess_image(frames[0].numpy(), params, 600, False)
+    assert np.array_equal(img0.cpu().numpy(), np.asarray(ref, dtype=np.float32))
+    saved = gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows, gpu_model.inflight_x6_gemm_tiles
+    gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows, gpu_model.inflight_x6_gemm_tiles = 0, 0, 0
+    try:
+        pinned = [f.pin_memory() for f in frames]
+        pend = []
+        got = {}
+        for i, f in enumerate(pinned):                      # 2 slots, 5 frames: slots are re-used
+            if len(pend) == 2:
+                j, h = pend.pop(0)
+                got[j] = h.result()
+            pend.append((i, feeder.submit(f, 0.05, slot=1 + i % 2)))
+        for j, h in pend:
+            got[j] = h.result()
+        for i in range(len(frames)):
+            for c in base[i]:
+                assert np.array_equal(base[i][c], got[i][c]), (i, c)
+        host_f32 = img0.cpu().pin_memory()
+        res = feeder.submit_preprocessed(host_f32, 0.05, slot=1).result()
+        for c in base[0]:
+            assert np.array_equal(base[0][c], res[c]), c
+    finally:
+        gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows, gpu_model.inflight_x6_gemm_tiles = saved
+    with pytest.raises(ValueError):
+        feeder.submit(torch.zeros((3, 10, 10), dtype=torch.uint8), 0.05, slot=1)

@@ -25,6 +25,16 @@ pytestmark = pytest.mark.gpu
 
 CASES = [("600x1000_s0", True), ("224x320_s3", True), ("333x517_s5_noedge", False)]
 
+# Gates against the reference's golden vectors (VGG-16).  GATE_PX is north_star's bar.  The other two come from the float64-truth
+# measurement of the held-out sweep (tests/test_holdout_gpu.py), not from these three images:
+#   ROW_BOUND_PX: a row of ours and the same row of the reference are two float32 evaluations of ONE anchor's box; over the held-out set
+#       the reference's worst row sits 0.67e-3 px from the float64 truth and ours 0.90e-3 px, so 2e-3 px bounds their difference.  A row that
+#       is NOT the reference's row (wrong anchor, wrong order) is off by pixels, not by 1e-3.
+#   ROW_FRACTION_FLOOR: the fraction of rows inside 1e-3 px that two such runs reach (held-out: 0.9994 pooled, 0.9967 for the worst image).
+GATE_PX = 1e-3
+ROW_BOUND_PX = 2e-3
+ROW_FRACTION_FLOOR = 0.99
+
 
 def load_case(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, "vgg16_%s.npz" % tag))
@@ -153,16 +163,20 @@ def test_forward_matches_reference_golden(gpu_model, model_edge_off, golden_dir,
     assert props.shape[1] == 4 and classes.shape[1] == 21 and deltas.shape[1] == 80
     assert props.shape[0] == classes.shape[0] == deltas.shape[0] == g["proposals"].shape[0]
     ours = props.cpu().numpy()
-    j, err = match_rows(ours, g["proposals"])
-    ok = err <= 1e-3
-    print("forward %s: %.1f%% of the reference's proposals reproduced within 1e-3 px" % (tag, 100 * ok.mean()))
-    # the gate is what is observed: every proposal of the two smaller cases, 299 of 300 at 600x1000 (one pair of
-    # RPN scores closer than two float32 implementations can resolve swaps at the NMS cut)
-    assert ok.mean() >= (0.996 if tag == "600x1000_s0" else 1.0)
-    # on the matched rows the detector outputs agree
+    # ROW BY ROW: the same proposals in the same ORDER as the reference (matching rows by best IoU never asserted the order)
+    err = np.abs(ours.astype(np.float64) - g["proposals"].astype(np.float64)).max(axis=1)
+    ok = err <= GATE_PX
+    print("forward %s: %d/%d of the reference's proposals reproduced AT THEIR ROW INDEX within 1e-3 px (worst row %.3g px, median %.3g)" % (
+        tag, int(ok.sum()), len(ok), err.max(), np.median(err)))
+    # every row is the reference's row (same anchor, same rank): its error is float32 noise, bounded by ROW_BOUND_PX; the fraction inside
+    # north_star's 1e-3 px is held to the floor the held-out sweep derives from the reference's own distance from the float64 truth
+    assert err.max() <= ROW_BOUND_PX
+    assert ok.mean() >= ROW_FRACTION_FLOOR
+    j = np.arange(len(ok))
+    # on those rows the detector outputs agree
     c_err = np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max()
     d_err = np.abs(deltas.cpu().numpy()[j[ok]] - g["box_deltas"][ok]).max()
-    print("   matched rows: max |d class prob| %.3g, max |d box delta| %.3g" % (c_err, d_err))
+    print("   same rows: max |d class prob| %.3g, max |d box delta| %.3g" % (c_err, d_err))
     assert c_err <= 1e-4 and d_err <= 1e-3
     # intermediate: objectness of every anchor vs the reference's (sampled) scores
     scores = model.context(0).tensor(2).cpu().numpy()
@@ -187,17 +201,22 @@ def test_predict_matches_reference_golden(gpu_model, model_edge_off, golden_dir,
         n_ref += len(r)
         if len(r) == 0:
             continue
-        j, err = match_rows(det[c], r) if len(det[c]) else (np.zeros(0, int), np.full(len(r), np.inf))
-        ok = err <= 1e-3
-        if ok.any():
-            ok &= np.abs(det[c][j, 4] - r[:, 4]) <= 1e-4
-            worst = max(worst, float(err[ok].max()) if ok.any() else 0.0)
+        # ROW BY ROW within the class: the reference's detections in the reference's (NMS) order
+        m = min(len(r), len(det[c]))
+        err = np.full(len(r), np.inf)
+        err[:m] = np.abs(det[c][:m, :4] - r[:m, :4]).max(axis=1)
+        serr = np.full(len(r), np.inf)
+        serr[:m] = np.abs(det[c][:m, 4] - r[:m, 4])
+        ok = (err <= GATE_PX) & (serr <= 1e-4)
+        worst = max(worst, float(err[:m].max()) if m else 0.0)
         n_ok += int(ok.sum())
     n_ours = sum(len(v) for v in det.values())
-    print("predict %s: %d/%d reference detections reproduced within 1e-3 px / 1e-4 score (ours: %d rows, worst %.3g px)" % (
+    print("predict %s: %d/%d reference detections reproduced at their row within 1e-3 px / 1e-4 score (ours: %d rows, worst row %.3g px)" % (
         tag, n_ok, n_ref, n_ours, worst))
-    # observed and therefore required in the default mode: EVERY reference detection (194 / 163 / 155), no extra rows
-    assert n_ok == n_ref and n_ours == n_ref
+    # the same rows in the same order (no extra, no missing row), every one within the float32-noise bound; the fraction inside 1e-3 px
+    # at the held-out sweep's floor
+    assert n_ours == n_ref and worst <= ROW_BOUND_PX
+    assert n_ok >= ROW_FRACTION_FLOOR * n_ref
 
 
 def test_predict_on_oracle_forward_outputs_is_exact(golden_dir, oracle_runs):

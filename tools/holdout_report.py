@@ -70,19 +70,22 @@ def main():
             print("%-12s %s" % (name, H.format_line(r)), flush=True)
         rows = sum(r["prop_rows"] for r in results)
         ok = sum(r["prop_rows_within_gate"] for r in results)
+        oks = sum(r["prop_rows_matched_within_gate"] for r in results)
+        doks = sum(r["det_rows_matched_within_gate"] for r in results)
         drows = sum(r["det_rows"] for r in results)
         dok = sum(r["det_rows_within_gate"] for r in results)
         p, rp = H.pooled(results, "prop_vs_truth"), H.pooled(results, "ref_prop_vs_truth")
         d, rd = H.pooled(results, "det_vs_truth"), H.pooled(results, "ref_det_vs_truth")
-        print("== %s / %s: %d cases | reference rows within 1e-3 px: proposals %d/%d = %.4f, detections %d/%d = %.4f | proposals vs truth: "
+        print("== %s / %s: %d cases | reference rows within 1e-3 px: proposals %d/%d = %.4f (set %.4f), detections %d/%d = %.4f (set %.4f) | proposals vs truth: "
               "median %.3g (ref %.3g, x%.2f) p95 %.3g (ref %.3g, x%.2f) max %.3g (ref %.3g) far %d | detections vs truth: median %.3g (ref %.3g, x%.2f) "
               "p95 %.3g (ref %.3g, x%.2f) | fm %.3g (ref %.3g)" % (
-                  args.arch, name, len(results), ok, rows, ok / max(rows, 1), dok, drows, dok / max(drows, 1),
+                  args.arch, name, len(results), ok, rows, ok / max(rows, 1), oks / max(rows, 1), dok, drows, dok / max(drows, 1), doks / max(drows, 1),
                   p["median"], rp["median"], p["median"] / rp["median"], p["p95"], rp["p95"], p["p95"] / rp["p95"], p["max"], rp["max"], p["n_far"],
                   d["median"], rd["median"], d["median"] / rd["median"], d["p95"], rd["p95"], d["p95"] / rd["p95"],
                   float(np.median([r["fm_err"] for r in results])), float(np.median([r["ref_fm_err"] for r in results]))), flush=True)
         report[name] = {"cases": results, "pooled": {"prop_vs_truth": p, "ref_prop_vs_truth": rp, "det_vs_truth": d, "ref_det_vs_truth": rd,
-                                                     "prop_rows": rows, "prop_rows_within_gate": ok, "det_rows": drows, "det_rows_within_gate": dok}}
+                                                     "prop_rows": rows, "prop_rows_within_gate": ok, "prop_rows_matched_within_gate": oks, "det_rows": drows,
+                                                     "det_rows_within_gate": dok, "det_rows_matched_within_gate": doks}}
     if args.out:
         os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
         with open(args.out, "w") as f:
