@@ -77,10 +77,15 @@ def direct_layers(math, x6=()):
     return [l for n, l in zip(_CONV_NAMES, _MFMA_CONVS) if not (math == "f32_winograd" and (uses_winograd(l[0], l[1]) or n in x6))]
 
 
-def winograd_layers(math, x6=(), named=False):
+def winograd_layers(math, x6=(), named=False, x3f=()):
     """The layers that run as one-launch float32 Winograd layers (wino_fused_kernel, exact-f32 pipe)."""
-    out = [(n, l) for n, l in zip(_CONV_NAMES, _MFMA_CONVS) if math == "f32_winograd" and uses_winograd(l[0], l[1]) and n not in x6]
+    out = [(n, l) for n, l in zip(_CONV_NAMES, _MFMA_CONVS) if math == "f32_winograd" and uses_winograd(l[0], l[1]) and n not in x6 and n not in x3f]
     return out if named else [l for _, l in out]
+
+
+def x3f_winograd_layers(math, x6=(), x3f=()):
+    """The layers that run as ONE-launch f32x3 Winograd layers (csrc/wino_x3f.hip: wino_x3d_kernel, fp16 pipe), named."""
+    return [(n, l) for n, l in zip(_CONV_NAMES, _MFMA_CONVS) if math == "f32_winograd" and n in x3f and n not in x6]
 
 
 def x6_winograd_layers(math, x6=(), named=False):
@@ -95,14 +100,16 @@ def winograd_gemm_flops(ci, co, h, w):
     return 2.0 * 16 * ((h + 1) // 2) * ((w + 1) // 2) * ci * co
 
 
-def layer_arithmetic(math, fc_math, x6=(), n_rois=300, num_classes=21, x3=()):
+def layer_arithmetic(math, fc_math, x6=(), n_rois=300, num_classes=21, x3=(), x3f=()):
     """One row per GEMM-shaped layer of one image: which kernel family and WHICH matrix pipe it runs on, the FLOP that pipe executes
     for it and the algorithmic (direct-form) FLOP it stands for.  Winograd layers execute 16 x tiles x cin x cout x 2; an "x6" layer
     executes six bf16 MFMAs per algorithmic product, an "x3" layer (a subset of the x6 table) three fp16 MFMAs."""
     rows = []
     for name, (ci, co, h, w) in zip(_CONV_NAMES, _MFMA_CONVS):
         alg = 2.0 * 9 * ci * co * h * w
-        if math == "f32_winograd" and name in x6 and name in x3:
+        if math == "f32_winograd" and name in x3f and name not in x6:
+            rows.append((name, "wino_x3d_kernel (one-launch x3 Winograd layer)", "f16", 3.0 * winograd_gemm_flops(ci, co, h, w), alg))
+        elif math == "f32_winograd" and name in x6 and name in x3:
             rows.append((name, "gemm_x3t_kernel (x3 Winograd layer)", "f16", 3.0 * winograd_gemm_flops(ci, co, h, w), alg))
         elif math == "f32_winograd" and name in x6:
             rows.append((name, "gemm_x6t_kernel (x6 Winograd layer)", "bf16", 6.0 * winograd_gemm_flops(ci, co, h, w), alg))
@@ -127,20 +134,20 @@ def layer_arithmetic(math, fc_math, x6=(), n_rois=300, num_classes=21, x3=()):
     return rows
 
 
-def pipe_flops_per_image(math, fc_math, x6=(), backbone_only=False, x3=()):
+def pipe_flops_per_image(math, fc_math, x6=(), backbone_only=False, x3=(), x3f=()):
     """FLOP each matrix pipe executes per image: {"f32": exact-f32 MFMAs, "bf16": bf16 MFMAs (f32x6 layers), "f16": fp16 MFMAs (f32x3 layers)};
     bf16 and fp16 instructions run at the same dense peak."""
     out = {"f32": 0.0, "bf16": 0.0, "f16": 0.0}
-    for name, _, pipe, ex, _ in layer_arithmetic(math, fc_math, x6, x3=x3):
+    for name, _, pipe, ex, _ in layer_arithmetic(math, fc_math, x6, x3=x3, x3f=x3f):
         if backbone_only and not (name.startswith("conv") or name == "rpn_trunk"):
             continue
         out[pipe] += ex
     return out
 
 
-def executed_mfma_flops_per_image(math, fc_math="f32", x6=(), x3=()):
+def executed_mfma_flops_per_image(math, fc_math="f32", x6=(), x3=(), x3f=()):
     """Matrix-pipe FLOP executed per image, all pipes added (kept for continuity with rounds 1-2; the per-pipe figures are the meaningful ones)."""
-    f = pipe_flops_per_image(math, fc_math, x6, x3=x3)
+    f = pipe_flops_per_image(math, fc_math, x6, x3=x3, x3f=x3f)
     return f["f32"] + f["bf16"] + f["f16"]
 
 
@@ -638,6 +645,7 @@ def main():
     fc_math = model.fc_math_mode
     x6 = tuple(getattr(model, "winograd_x6_layers", ())) if args.math == "f32_winograd" else ()
     x3 = tuple(getattr(model, "winograd_x3_layers", ())) if args.math == "f32_winograd" else ()
+    x3f = tuple(n_ for n_ in getattr(model, "winograd_x3f_layers", ()) if n_ not in x6) if (args.math == "f32_winograd" and not is_resnet) else ()
     fc_f32_value = None
     if not is_resnet and not args.no_secondary and fc_math != "f32":
         # the same workload with fc1 / fc2 on the exact-f32 pipe too: every GEMM of the image on v_mfma_f32_*_f32
@@ -649,26 +657,30 @@ def main():
         run(nslots)
 
     wino_f32_value = None
-    if not is_resnet and not args.no_secondary and x6:
+    if not is_resnet and not args.no_secondary and (x6 or x3f):
         # the same workload with EVERY 3x3 layer on the exact-f32 pipe (rounds 1-2's default table: no x6 Winograd layer)
         model.winograd_x6_layers = ()
+        model.winograd_x3f_layers = ()
         run(max(args.warmup, nslots))
         dt, _ = timed_median(run, args.steps, min(args.min_timed_seconds, 0.5))
         wino_f32_value = round(n_gpus * args.steps / dt, 3)
         model.winograd_x6_layers = x6
         model.winograd_x3_layers = x3
+        model.winograd_x3f_layers = x3f
         run(nslots)
 
     strict_f32_value = None
-    if not is_resnet and not args.no_secondary and (x6 or fc_math != "f32"):
+    if not is_resnet and not args.no_secondary and (x6 or x3f or fc_math != "f32"):
         # STRICT float32: every GEMM of the image on the exact-f32 matrix instructions (no split-operand layer anywhere)
         model.winograd_x6_layers = ()
+        model.winograd_x3f_layers = ()
         model.fc_math_mode = "f32"
         run(max(args.warmup, nslots))
         dt, _ = timed_median(run, args.steps, min(args.min_timed_seconds, 0.5))
         strict_f32_value = round(n_gpus * args.steps / dt, 3)
         model.winograd_x6_layers = x6
         model.winograd_x3_layers = x3
+        model.winograd_x3f_layers = x3f
         model.fc_math_mode = fc_math
         run(nslots)
 
@@ -707,6 +719,14 @@ def main():
         run(nslots)
 
     x3_legs = {}
+    if not is_resnet and not args.no_secondary and x3f:
+        # conv2_2 .. conv3_3 back on the float32 one-launch Winograd kernel (round 3's pipeline for those layers)
+        model.winograd_x3f_layers = ()
+        run(max(args.warmup, nslots))
+        dt, _ = timed_median(run, args.steps, min(args.min_timed_seconds, 0.5))
+        x3_legs["no_one_launch_x3_layers_images_per_sec"] = round(n_gpus * args.steps / dt, 3)
+        model.winograd_x3f_layers = x3f
+        run(nslots)
     if not is_resnet and not args.no_secondary and x6:
         # the f32x3 arithmetic switched off (every split-operand GEMM in f32x6: the table before the f32x3 kernels existed), and round 3's
         # default table (conv5_1 kept in f32x6 because one box of one golden fixture then landed at 0.92e-3 instead of 1.04e-3 px; round 4
@@ -863,7 +883,7 @@ def main():
 
         regime = ("HIP events around every launch, one image at a time on one stream, median image of %d (after the timed region: with "
                   "several images in flight concurrent kernels share the CUs and a launch's wall duration is not its own)" % n_img)
-        dl, wl_named = direct_layers(args.math, x6), winograd_layers(args.math, x6, named=True)
+        dl, wl_named = direct_layers(args.math, x6), winograd_layers(args.math, x6, named=True, x3f=x3f)
         wl = [l for _, l in wl_named]
         xl_named = x6_winograd_layers(args.math, x6, named=True)
         xl = [l for _, l in xl_named]
@@ -917,13 +937,34 @@ def main():
                                 "cout x 2), against the dense bf16 / fp16 peak (the same 2500 TFLOP/s); f32_equivalent_tflops = the same launches counted "
                                 "once per float32 product; bytes = V records (6 / 4 B per element) read + M (4 B) written + the filter record bank"}
         # `roofline` = the kernel with the most GPU time per image, the other one rides along
-        both = [r for r in (r_direct, r_wino, r_x6) if r is not None]
+        # the one-launch f32x3 Winograd layers (wino_x3d_kernel; the class time includes their channel-maximum pass): 3 fp16 MFMAs per float32 product
+        r_x3f = None
+        fl_named = x3f_winograd_layers(args.math, x6, x3f)
+        if fl_named and timing.get("winograd_x3f", (0, 0))[1]:
+            msf, lf = timing["winograd_x3f"]
+            per_launch = sum(3.0 * winograd_gemm_flops(*l) for _, l in fl_named) / len(fl_named)
+            avg_s = (msf / 1e3) / lf
+            ach = per_launch / avg_s / 1e12
+            r_x3f = {"kernel": "wino_x3d_kernel (ONE-launch Winograd F(2x2,3x3) layer in the f32x3 arithmetic: operand formed in registers from the LDS-staged halo, "
+                               "filter fragments straight from L2, all 16 positions in accumulators: %s; the time includes the channel-maximum pass)"
+                               % ", ".join(n for n, _ in fl_named),
+                     "regime": regime, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": measured_traffic("wino_x3d_kernel"), "flops_per_launch": per_launch,
+                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(lf), "ms_per_image": round(msf / max(args.roofline_images, 1), 4),
+                     "f32_equivalent_tflops": round(per_launch / 3.0 / avg_s / 1e12, 2),
+                     "algorithmic_bytes_per_launch": float(sum(4.0 * (h * w * ci + 16 * ci * co + (h // (2 if n in _POOLED else 1)) * (w // (2 if n in _POOLED else 1)) * co)
+                                                               for n, (ci, co, h, w) in fl_named)) / len(fl_named),
+                     "note": "FLOP = 3 fp16 MFMA products per float32 product x the Winograd GEMM FLOP (16 x tiles x cin x cout x 2) against the dense fp16 peak; "
+                             "f32_equivalent_tflops counts every float32 product once (the float32 one-launch kernel it replaces: ~100)"}
+        both = [r for r in (r_direct, r_wino, r_x6, r_x3f) if r is not None]
         both.sort(key=lambda r: -r["ms_per_image"])
         roofline = dict(both[0]) if both else {"note": "timing disabled"}
         if len(both) > 1:
             roofline["second_kernel"] = both[1]
         if len(both) > 2:
             roofline["third_kernel"] = both[2]
+        if len(both) > 3:
+            roofline["fourth_kernel"] = both[3]
         roofline["per_class_ms_per_image"] = {k: round(v[0] / max(args.roofline_images, 1), 4) for k, v in timing.items()}
 
         cpu = None
@@ -950,12 +991,12 @@ def main():
         pipes = {}
         if not is_resnet:
             ips = value / n_gpus
-            pf = pipe_flops_per_image(args.math, fc_math, x6, x3=x3)
-            pb = pipe_flops_per_image(args.math, fc_math, x6, backbone_only=True, x3=x3)
+            pf = pipe_flops_per_image(args.math, fc_math, x6, x3=x3, x3f=x3f)
+            pb = pipe_flops_per_image(args.math, fc_math, x6, backbone_only=True, x3=x3, x3f=x3f)
             f32_tf, bf16_tf, f16_tf = ips * pf["f32"] / 1e12, ips * pf["bf16"] / 1e12, ips * pf["f16"] / 1e12
             pipes = {
                 "layer_arithmetic": [{"layer": n_, "kernel": k_, "pipe": p_, "executed_gflop": round(e_ / 1e9, 3), "algorithmic_gflop": round(a_ / 1e9, 3)}
-                                     for n_, k_, p_, e_, a_ in layer_arithmetic(args.math, fc_math, x6, x3=x3)],
+                                     for n_, k_, p_, e_, a_ in layer_arithmetic(args.math, fc_math, x6, x3=x3, x3f=x3f)],
                 "f32_pipe_tflops": round(f32_tf, 2), "f32_pipe_frac": round(f32_tf / PEAK_F32_MFMA_TFLOPS, 4),
                 "bf16_pipe_tflops": round(bf16_tf, 2), "bf16_pipe_frac": round(bf16_tf / PEAK_BF16_MFMA_TFLOPS, 4),
                 "f16_pipe_tflops": round(f16_tf, 2), "f16_pipe_frac": round(f16_tf / PEAK_BF16_MFMA_TFLOPS, 4),
@@ -973,7 +1014,7 @@ def main():
             }
         # the arithmetic, said where `dtype` is read: tensors are float32 everywhere; the split-operand layers are NOT float32
         # operand arithmetic (f32x3 keeps 22-23 bits of an operand relative to its row's / tile's largest element)
-        n_x3 = len([n_ for n_ in x6 if n_ in x3]) + (2 if fc_math == "f32x3" else 0)
+        n_x3 = len([n_ for n_ in x6 if n_ in x3]) + len(x3f) + (2 if fc_math == "f32x3" else 0)
         n_x6 = len([n_ for n_ in x6 if n_ not in x3]) + (2 if fc_math in ("f32x6", "f32x6_v1") else 0)
         if is_resnet or (n_x3 == 0 and n_x6 == 0):
             dtype_str = "f32" if not is_resnet else "f32 (ResNet: layer4 / RPN trunk GEMMs in the model's default split-operand arithmetic, f32 accumulation)"
@@ -1000,7 +1041,7 @@ def main():
             "tflops_per_gpu": round(value / n_gpus * flops_img / 1e12, 2),
             "tflops_per_gpu_note": "direct-convolution FLOP of the workload x images/sec (BASELINE.md's 4.4922e11 per image); "
                                    "in the f32_winograd mode the matrix pipes execute fewer: see f32_pipe_tflops / bf16_pipe_tflops",
-            "math": args.math, "winograd_x6_layers": list(x6), "winograd_x3_layers": list(x3), "fc_math": None if is_resnet else fc_math, "roi": model._stage3_detector_network.pooling,
+            "math": args.math, "winograd_x6_layers": list(x6), "winograd_x3_layers": list(x3), "winograd_x3f_layers": list(x3f), "fc_math": None if is_resnet else fc_math, "roi": model._stage3_detector_network.pooling,
             "other_math_modes_images_per_sec": secondary, "fc_math_f32_images_per_sec": fc_f32_value,
             "winograd_all_f32_pipe_images_per_sec": wino_f32_value, "strict_f32_images_per_sec": strict_f32_value,
             **h2d,

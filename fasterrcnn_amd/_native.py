@@ -12,14 +12,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
-ABI_VERSION = 8     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
+ABI_VERSION = 9     # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
 POOL2 = 2
-NUM_KCLASS = 10
+NUM_KCLASS = 11
 KCLASS_NAMES = ("conv3x3_mfma", "conv3x3_c3", "linear_mfma", "proposals", "roi_pool", "other", "winograd_transforms",
-                "winograd_gemm", "winograd_x6_transforms", "winograd_x6_gemm")
+                "winograd_gemm", "winograd_x6_transforms", "winograd_x6_gemm", "winograd_x3f")
 
 # Every symbol include/frcnn_hip.h declares (tests check the .so exports all of them).
 SYMBOLS = (
@@ -100,7 +100,8 @@ class ForwardParams(C.Structure):
     _fields_ = [("pre_nms", C.c_int32), ("post_nms", C.c_int32), ("rpn_nms_threshold", C.c_float),
                 ("min_side", C.c_float), ("allow_edge_proposals", C.c_int32), ("math_mode", C.c_int32),
                 ("conv_blocks_target", C.c_int32), ("fc_math_mode", C.c_int32), ("roi_op", C.c_int32), ("roi_sampling_ratio", C.c_int32),
-                ("winograd_tile_rows", C.c_int32), ("winograd_x6_mask", C.c_int32), ("x6_gemm_tiles", C.c_int32), ("winograd_x3_mask", C.c_int32)]
+                ("winograd_tile_rows", C.c_int32), ("winograd_x6_mask", C.c_int32), ("x6_gemm_tiles", C.c_int32), ("winograd_x3_mask", C.c_int32),
+                ("winograd_x3f_mask", C.c_int32)]
 
 
 # capacity limits of the kernels (validated by FasterRCNNModel with a message; the C entry points return FRCNN_EINVAL / EUNSUPPORTED)
@@ -146,6 +147,17 @@ DEFAULT_X6_LAYERS_VGG16 = ("conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2"
 # x6 table in f32x6 1.63 / 1.52; every layer on the direct exact-f32 kernel (no Winograd) 1.84 / 1.78.  The f32x3 layers are the MOST
 # accurate arithmetic of the five: two wide fp16 MFMA accumulations per 16 products round less than sixteen float32 FMA steps.
 DEFAULT_X3_LAYERS_VGG16 = DEFAULT_X6_LAYERS_VGG16
+
+
+def uses_winograd_x3f(cin, cout):
+    """The 3x3 layers that CAN run as one-launch f32x3 Winograd layers (csrc/wino_x3f.hip; version 4 walks the 16-channel chunks in pairs)."""
+    return cin >= 32 and cin % 32 == 0 and cout >= 64 and cout % 64 == 0
+
+
+# One-launch f32x3 layers of the default table (round 4): the four layers whose three-launch form would move 600 MB of V + M through HBM.
+# Admitted by the held-out criterion (tests/test_holdout_gpu.py) like the rest of the table; conv1_2 / conv2_1 (4 chunks of 16 channels:
+# prologue bound) stay on the float32 one-launch kernel.
+DEFAULT_X3F_LAYERS_VGG16 = ("conv2_2", "conv3_1", "conv3_2", "conv3_3")
 
 
 def uses_winograd_x6(cin, cout):

@@ -3,6 +3,7 @@
 // fused VGG-16 forward that enqueues every kernel of FasterRCNNModel.forward
 // (reference: models/faster_rcnn.py:80-132) on one stream with no host round trip.
 #include "common.h"
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -44,6 +45,7 @@ struct frcnn_ctx {
     void* conv_ws = nullptr; size_t conv_ws_bytes = 0;   // split-K partials of under-filled conv layers
     void* wino_ws = nullptr; size_t wino_ws_bytes = 0;   // V and M of the Winograd layers; allocated by the first forward that needs it
     void* wx_ws = nullptr; size_t wx_ws_bytes = 0;       // V records, M and split-K partials of the x6 Winograd layers; allocated on first use
+    float* x3f_cmax = nullptr; size_t x3f_cmax_bytes = 0;   // channel maxima of a one-launch f32x3 Winograd layer's input (csrc/wino_x3f.hip); first use
     void* rx_rec = nullptr; size_t rx_rec_bytes = 0;     // activation records of the x6 1x1 convolutions (ResNet bottlenecks); on first use
     void* rx_ws = nullptr; size_t rx_ws_bytes = 0;       // their split-K partials
     float* rx_aux = nullptr; size_t rx_aux_floats = 0;   // f32x3 form: row scales of the record array + channel maxima of the layer input
@@ -859,6 +861,7 @@ void frcnn_ctx_destroy(frcnn_ctx* ctx)
     if (ctx->slab) (void)hipFree(ctx->slab);
     if (ctx->wino_ws) (void)hipFree(ctx->wino_ws);
     if (ctx->wx_ws) (void)hipFree(ctx->wx_ws);
+    if (ctx->x3f_cmax) (void)hipFree(ctx->x3f_cmax);
     if (ctx->roi_rec) (void)hipFree(ctx->roi_rec);
     if (ctx->rx_rec) (void)hipFree(ctx->rx_rec);
     if (ctx->rx_ws) (void)hipFree(ctx->rx_ws);
@@ -1044,6 +1047,23 @@ int run_wino_x3_layer(frcnn_ctx* c, const float* x, const void* ublob, const flo
     return launch_winograd_output(M, b, y, N, h, w, co, flags, s);
 }
 
+// A ONE-LAUNCH f32x3 Winograd layer inside a fused forward (csrc/wino_x3f.hip; a bit of frcnn_forward_params.winograd_x3f_mask; timing class 10,
+// which includes the channel-maximum pass over the layer input).  ublob = frcnn_pack_conv3x3_winograd_x3's blob.
+int run_wino_x3f_layer(frcnn_ctx* c, const float* x, const void* ublob, const float* b, float* y, int h, int w, int ci, int co,
+                       unsigned flags, hipStream_t s)
+{
+    const size_t need = conv3x3_winograd_x3_fused_workspace_bytes(1, h, w);
+    if (!c->x3f_cmax || c->x3f_cmax_bytes < need) {
+        if (c->x3f_cmax) { FRCNN_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(c->x3f_cmax); c->x3f_cmax = nullptr; c->x3f_cmax_bytes = 0; }
+        const size_t cap = std::max(need, (size_t)c->max_h * c->max_w * sizeof(float));
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->x3f_cmax), cap);
+        if (e != hipSuccess) { set_hip_error(e); c->x3f_cmax = nullptr; return FRCNN_ENOMEM; }
+        c->x3f_cmax_bytes = cap;
+    }
+    Scope _w(c, 10, s);
+    return launch_conv3x3_winograd_x3_fused(x, ublob, b, y, 1, h, w, ci, co, flags, c->x3f_cmax, c->x3f_cmax_bytes, s);
+}
+
 // One one-launch Winograd layer inside a fused forward (timed as class 7).
 // (A channel split of the small maps over more blocks -- partial outputs, arrival tickets, the last arriver sums in part order --
 //  was built and measured for one image on the chip: conv5_x 87 -> 84-87 us, conv4_2 227 -> 222 us with 2 parts, slower with 4.
@@ -1092,10 +1112,13 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     const bool x6 = p->math_mode == FRCNN_MATH_F32X6;
     const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
     if (p->winograd_x6_mask != 0 && (!wino || (p->winograd_x6_mask & ~0x3FFE) != 0)) return FRCNN_EINVAL;
+    if (p->winograd_x3f_mask != 0 && (!wino || (p->winograd_x3f_mask & ~0x1FFE) != 0 || (p->winograd_x3f_mask & p->winograd_x6_mask) != 0)) return FRCNN_EINVAL;
     int layer_index = 0;        // 1 .. 12 = conv_w[i], 13 = the RPN trunk (frcnn_forward_params.winograd_x6_mask)
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
         ++layer_index;
+        if (wino && ((p->winograd_x3f_mask >> layer_index) & 1))  // one-launch f32x3 Winograd layer: wgt = the x3 blob (csrc/wino_x3f.hip)
+            return run_wino_x3f_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
         if (wino && ((p->winograd_x6_mask >> layer_index) & 1))  // x6 / x3 Winograd layer: wgt = the record bank (csrc/wino_x6.hip, wino_x3.hip)
             return ((p->winograd_x3_mask >> layer_index) & 1) ? run_wino_x3_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s)
                                                               : run_wino_x6_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);

@@ -561,6 +561,411 @@ void wino_x3f64_kernel(const float* __restrict__ x_maps, const float* __restrict
     }
 }
 
+// ---- VER 4 (round 4): 64 tiles per block, the filter fragments straight from L2 into registers ----------------------------------------------
+// What bounded versions 1-3 was the L2 -> LDS staging of the filter records (64 KB per chunk and block by LDS-DMA: ~17 B per clock and CU).
+// Every filter piece is read by exactly ONE wave (a wave owns a position row), and a piece IS the register image of an MFMA operand
+// (lane l's fragment at byte 16 l), so the wave loads its 16 pieces of a chunk with plain 1 KB global loads into registers, one chunk
+// ahead (two register sets), and the LDS holds nothing but the input halo (two buffers: ONE barrier per chunk).  The vector work of the
+// operand formation (B^T d B, scale, fp16 split: packed float32 / packed conversion instructions) is spread over the MFMAs of the chunk
+// in eight steps of six MFMAs; step (h, j) forms the operand of step (h, j + 1).  Same arithmetic, same order per accumulator: bit-identical
+// to the three-launch layer (and to versions 1-3).
+typedef float xd_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 xd_f16x2 __attribute__((ext_vector_type(2)));
+
+static constexpr int XD_HP = XF_HC / 2;                                       // 17 pixel slots per (halo row, column parity)
+static constexpr int XD_HALO_FLOATS = X3_HR * XF_HC * XF_PS;                  // 6,800 floats = 27,200 B per buffer
+static constexpr int XD_MS = 68;                                              // floats between two tiles of the epilogue's M buffer (64 + 4: conflict-free)
+static constexpr int XD_M_BYTES = 16 * 32 * XD_MS * 4;                       // 139,264: the M buffer [16 positions][32 tiles][68] (>= the two halo buffers)
+static constexpr size_t XD_LDS_BYTES = XD_M_BYTES + 16 * 64 * 4 + 64 * 4;     // + the block's filter scales [16][64] and bias [64]: 143,616
+
+template <int N> struct XdInt { static constexpr int value = N; };
+
+__device__ __forceinline__ void xd_lds_barrier()
+{
+    // LDS writes of this wave done, then the block barrier; the outstanding GLOBAL loads (next chunk's filter fragments) stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(256, 1)
+void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__ cmax_maps, const unsigned char* __restrict__ ublob,
+                     const float* __restrict__ bias, float* __restrict__ y_maps, int H, int W, int Cin, int Cout, int u_rbt, int relu,
+                     XfGeom gm)
+{
+#ifdef XD_CLOCKS
+    const unsigned long long xd_t_in = __builtin_amdgcn_s_memrealtime();
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_xf[];
+    float* const hbuf0 = reinterpret_cast<float*>(smem_xf);
+    float* const hbuf1 = hbuf0 + XD_HALO_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K16 = Cin >> 4;
+
+    int b = blockIdx.x;
+    const int cb = b % gm.ncb;
+    b /= gm.ncb;
+    const int bx = b % gm.tbx;
+    b /= gm.tbx;
+    const int by = b % gm.tby;                                               // blocks of FOUR tile rows
+    const int map = b / gm.tby;
+    const float* __restrict__ const x = x_maps + (size_t)map * H * W * Cin;
+    const float* __restrict__ const cmax = cmax_maps + (size_t)map * H * W;
+    float* __restrict__ const y = y_maps + (size_t)map * (POOL ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) * Cout;
+
+    // Buffer loads: a piece outside the image carries an offset past the descriptor's size and the hardware returns zeros for it (the
+    // "same" padding and the channel maxima of absent pixels cost no branch)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, H * W * Cin * (int)sizeof(float), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cmax), 0, H * W * (int)sizeof(float), 0x00020000);
+
+    const int tl = lane & 31, tyl = tl >> 4, txl = tl & 15, kh = lane >> 5;
+    const int tx = XF_TC * bx + txl;
+    float mult[2], vinv[2];
+    {
+        float dm[2][16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ty = 4 * by + 2 * h + tyl;
+            const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int yy = y0 + a, xx = x0 + c;
+                    const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                    dm[h][4 * a + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, inb ? (yy * W + xx) * 4 : (int)0xFFFFFFF0u, 0, 0));
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float dmax = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dmax = fmaxf(dmax, dm[h][q]);
+            hx_row_scale(4.0f * dmax, mult[h], vinv[h]);
+        }
+    }
+
+    // ---- halo staging (global -> registers -> LDS): piece = (pixel, 4-channel quad); surplus threads duplicate the first pieces ----------
+    const int hy0 = 8 * by - 1, hx0 = 2 * XF_TC * bx - 1;
+    constexpr int NHP = X3_HR * XF_HC * 4;                                   // 1,360 pieces
+    int h_src[X3_NPC], h_dst[X3_NPC];
+#pragma unroll
+    for (int it = 0; it < X3_NPC; ++it) {
+        const int q = tid + 256 * it;
+        const int qq = q < NHP ? q : q - NHP;
+        const int px = qq >> 2, quad = qq & 3;
+        const int hr = px / XF_HC, hc = px - hr * XF_HC;
+        const int gy = hy0 + hr, gx = hx0 + hc;
+        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        h_src[it] = inb ? (int)((((unsigned)gy * W + gx) * Cin + 4 * quad) * sizeof(float)) : (int)0xFFFFFFF0u;
+        h_dst[it] = ((hr * 2 + (hc & 1)) * XD_HP + (hc >> 1)) * XF_PS + 4 * quad;      // columns de-interleaved by parity (below)
+    }
+    f32x4 hreg[X3_NPC];
+    auto load_halo = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < X3_NPC; ++it)
+            hreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, h_src[it], chunk * 64, 0));
+    };
+    auto store_halo = [&](float* hb) {
+#pragma unroll
+        for (int it = 0; it < X3_NPC; ++it) *reinterpret_cast<f32x4*>(hb + h_dst[it]) = hreg[it];
+    };
+
+    // ---- filter fragments: piece (position p, row block r, term t) of chunk c = ublob + ((p K16 + c) u_rbt + 2 cb + r) 2 KB + t 1 KB -------
+    // lane offset 16 l, everything else in the scalar offset
+    xf_f16x8 U[2][4][2][2];                                                  // [register set][position j][output tile][0 = hi, 1 = lo]
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(ublob), 0, 16 * K16 * u_rbt * HX_RB, 0x00020000);
+    const int chunk_stride = u_rbt * HX_RB;
+    int ubase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ubase[j] = ((4 * wave + j) * K16 * u_rbt + 2 * cb) * HX_RB;
+    const int lane16 = lane * 16;
+    auto load_u = [&](int chunk, auto SET, auto J) {
+        constexpr int set = decltype(SET)::value, j = decltype(J)::value;
+        const int so = ubase[j] + chunk * chunk_stride;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                U[set][j][ct][t] = __builtin_bit_cast(xf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16, so + ct * HX_RB + t * HX_PIECE, 0));
+    };
+
+    f32x16 acc[2][4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[h][j][ct][r] = 0.f;
+
+    // ---- operand formation -------------------------------------------------------------------------------------------------------------
+    // position row i = wave: r[b] = d[a1][b] +- d[a2][b] (B^T), V[i][j] = r[b1] +- r[b2] (B), csrc/winograd.hip's float32 operation order.
+    // Scalar float32 instructions on purpose: beside MFMAs a packed-f32 instruction costs more than the two scalar ones it replaces
+    // (MI355X_MICROARCH.md), and the file is compiled with -fno-slp-vectorize for the same reason.
+    const int a1 = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int a2 = wave == 0 ? 2 : (wave == 2 ? 1 : (wave == 1 ? 2 : 3));
+    const float rsgn = wave != 1 ? -1.0f : 1.0f;                             // i = 1: d1 + d2; i = 0, 2, 3: differences
+    // LDS halo layout [row][column parity][17 slots][20 floats]: the 16 lanes of a tile row read patch column b of their tiles at pixel
+    // columns 2 t + b, i.e. at CONSECUTIVE slots t + (b >> 1) of parity b & 1 -- 80 bytes apart, and 16 x 80 B covers every bank group once
+    // (with the plain [row][column] layout of versions 1-3 the lanes are 160 B apart: lanes t and t + 8 collide, every read takes twice)
+    const int d_lane = (4 * tyl * XD_HP + txl) * XF_PS + 8 * kh;             // + ((4 h + a) 2 + (b & 1)) XD_HP XF_PS + (b >> 1) XF_PS
+    float r[4][8];                                                           // [patch column b][channel]
+    f32x4 du0, du1, dw0, dw1;                                                // the two patch rows of one column on their way from LDS
+    auto read_d = [&](const float* hb, int h, int bb) {
+        const float* p1 = hb + d_lane + (((4 * h + a1) * 2 + (bb & 1)) * XD_HP + (bb >> 1)) * XF_PS;
+        const float* p2 = hb + d_lane + (((4 * h + a2) * 2 + (bb & 1)) * XD_HP + (bb >> 1)) * XF_PS;
+        du0 = *reinterpret_cast<const f32x4*>(p1); du1 = *reinterpret_cast<const f32x4*>(p1 + 4);
+        dw0 = *reinterpret_cast<const f32x4*>(p2); dw1 = *reinterpret_cast<const f32x4*>(p2 + 4);
+    };
+    // u + sgn w as ONE fused operation == u +- w rounded once (sgn w is exact)
+    auto make_r = [&](int bb, int half) {
+        if (half == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[bb][e] = __builtin_fmaf(dw0[e], rsgn, du0[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[bb][4 + e] = __builtin_fmaf(dw1[e], rsgn, du1[e]);
+        }
+    };
+    unsigned vhi[2][4], vlo[2][4];                                           // [slot][channel pair]: the operand in use and the one being formed
+    // Channel pairs (e2, e2 + 1) of V(h, j): t = r[b1] +- r[b2]; hi = fp16(t 2^e), lo = fp16(t 2^e - hi).  v_fma_mix{lo,hi}_f16 form both
+    // straight from t (the product with the power of two and the difference hi leaves are exact, so each is ONE rounding -- the bits of
+    // hx_split8).  Two pairs travel together so that no partial register write is read by the very next instruction (hipcc pads such
+    // pairs with s_nop, and an s_nop costs an issue slot beside the MFMAs like any other instruction).
+    float tt[4];
+    auto v_adds = [&](int j, int e2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = 2 * e2 + q;
+            tt[q] = j == 0 ? r[0][e] - r[2][e] : j == 1 ? r[1][e] + r[2][e] : j == 2 ? r[2][e] - r[1][e] : r[1][e] - r[3][e];
+        }
+    };
+    auto v_hi = [&](int h, int slot, int e2) {
+        unsigned ha, hb;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(ha) : "v"(tt[0]), "v"(mult[h]));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hb) : "v"(tt[2]), "v"(mult[h]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(ha) : "v"(tt[1]), "v"(mult[h]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hb) : "v"(tt[3]), "v"(mult[h]));
+        vhi[slot][e2] = ha;
+        vhi[slot][e2 + 1] = hb;
+    };
+    auto v_lo = [&](int h, int slot, int e2) {
+        unsigned la, lb;
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(la) : "v"(tt[0]), "v"(mult[h]), "v"(vhi[slot][e2]));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(tt[2]), "v"(mult[h]), "v"(vhi[slot][e2 + 1]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(la) : "v"(tt[1]), "v"(mult[h]), "v"(vhi[slot][e2]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(tt[3]), "v"(mult[h]), "v"(vhi[slot][e2 + 1]));
+        vlo[slot][e2] = la;
+        vlo[slot][e2 + 1] = lb;
+    };
+    auto frag = [&](const unsigned (&q)[4]) { return __builtin_bit_cast(xf_f16x8, uint4{q[0], q[1], q[2], q[3]}); };
+    // the six MFMAs of step (h, j): per accumulator filter lo x V hi, filter hi x V hi, filter hi x V lo (gemm_x3t_kernel's order)
+#define XD_MFMA(SET, H_, J_, CT, UT, VV) \
+    do { if (!(XD_ABLATE & 16)) acc[H_][J_][CT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(U[SET][J_][CT][UT], VV, acc[H_][J_][CT], 0, 0, 0); } while (0)
+#define XD_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef XD_ABLATE
+#define XD_ABLATE 0          // timing experiments (tools/build_ablate.sh): 1 no operand VALU, 2 no patch reads / r, 4 no filter loads, 8 no halo traffic, 16 no MFMAs
+#endif
+#define XD_IF(BIT, STMT) do { if (!(XD_ABLATE & (BIT))) { STMT; } } while (0)
+
+    // One chunk = eight steps (h, j) of six MFMAs.  Between the MFMAs of step s: the operand of step s + 1 (four channel pairs), one patch
+    // column of the r the step after next needs, two of the next chunk's sixteen filter pieces, and the halo traffic -- about seven
+    // instructions per MFMA, placed by hand (sched_barrier after every slice).  Order of the r columns: b = 0, 2, 1, 3, each into the slot
+    // whose old value died in the previous step (V(., 1) = r1 + r2, V(., 2) = r2 - r1, V(., 3) = r1 - r3, V(., 0) = r0 - r2).
+    auto step = [&](int ucb, int hso, float* hcur, float* hnxt, auto PAR, auto S) {
+        constexpr int par = decltype(PAR)::value, s = decltype(S)::value;
+        constexpr int h = s >> 2, j = s & 3, slot = s & 1, nslot = slot ^ 1;
+        constexpr int nh = s == 3 ? 1 : s == 7 ? 0 : h, nj = (j + 1) & 3;                 // the operand formed in this step: V(nh, nj)
+        constexpr int rb = j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 1 : 3;                        // the r column read and formed in this step ...
+        constexpr int rh = h ^ 1;                                                           // ... belongs to the other half (h 0: this chunk's, h 1: the next chunk's)
+        const float* rsrc = h == 0 ? hcur : hnxt;
+        const xf_f16x8 vh = frag(vhi[slot]), vl = frag(vlo[slot]);
+        XD_MFMA(par, h, j, 0, 1, vh);
+        XD_IF(2, read_d(rsrc, rh, rb));
+        XD_IF(1, v_adds(nj, 0));
+        XD_FENCE();
+        XD_MFMA(par, h, j, 1, 1, vh);
+        XD_IF(1, v_hi(nh, nslot, 0));
+        if (!(XD_ABLATE & 4)) {   // two of the next chunk's filter pieces per step: U[par ^ 1][s >> 1][s & 1][hi, lo]; the constants land in the instruction offset
+            const int so = ubase[s >> 1] + ucb;
+            U[par ^ 1][s >> 1][s & 1][0] = __builtin_bit_cast(xf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16 + (s & 1) * HX_RB, so, 0));
+            U[par ^ 1][s >> 1][s & 1][1] = __builtin_bit_cast(xf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16 + (s & 1) * HX_RB + HX_PIECE, so, 0));
+        }
+        XD_FENCE();
+        XD_MFMA(par, h, j, 0, 0, vh);
+        XD_IF(1, v_lo(nh, nslot, 0));
+        if (s == 2 && !(XD_ABLATE & 8)) {                                                        // halo(c + 1): registers -> LDS, first half
+#pragma unroll
+            for (int it = 0; it < 3; ++it) *reinterpret_cast<f32x4*>(hnxt + h_dst[it]) = hreg[it];
+        }
+        if (s == 4 && !(XD_ABLATE & 8)) {                                                        // halo(c + 2) leaves for registers, first half
+#pragma unroll
+            for (int it = 0; it < 3; ++it) hreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, h_src[it], hso, 0));
+        }
+        XD_FENCE();
+        XD_MFMA(par, h, j, 1, 0, vh);
+        XD_IF(1, v_adds(nj, 2));
+        XD_IF(1, v_hi(nh, nslot, 2));
+        XD_FENCE();
+        XD_MFMA(par, h, j, 0, 0, vl);
+        XD_IF(1, v_lo(nh, nslot, 2));
+        XD_IF(2, make_r(rb, 0));
+        XD_FENCE();
+        XD_MFMA(par, h, j, 1, 0, vl);
+        XD_IF(2, make_r(rb, 1));
+        if (s == 3) {
+            if (!(XD_ABLATE & 8)) {
+#pragma unroll
+                for (int it = 3; it < X3_NPC; ++it) *reinterpret_cast<f32x4*>(hnxt + h_dst[it]) = hreg[it];
+            }
+            xd_lds_barrier();                                                // halo(c + 1) visible to every wave, halo(c - 1)'s buffer spent
+        }
+        if (s == 5 && !(XD_ABLATE & 8)) {
+#pragma unroll
+            for (int it = 3; it < X3_NPC; ++it) hreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, h_src[it], hso, 0));
+        }
+        XD_FENCE();
+    };
+    auto chunk = [&](int c, auto PAR) {
+        constexpr int par = decltype(PAR)::value;
+        float* const hcur = par ? hbuf1 : hbuf0;
+        float* const hnxt = par ? hbuf0 : hbuf1;
+        // past the last chunk the loads re-read it instead of branching (nobody consumes them)
+        const int ucb = (c + 1 < K16 ? c + 1 : K16 - 1) * chunk_stride, hso = (c + 2 < K16 ? c + 2 : K16 - 1) * 64;
+        step(ucb, hso, hcur, hnxt, PAR, XdInt<0>{}); step(ucb, hso, hcur, hnxt, PAR, XdInt<1>{});
+        step(ucb, hso, hcur, hnxt, PAR, XdInt<2>{}); step(ucb, hso, hcur, hnxt, PAR, XdInt<3>{});
+        step(ucb, hso, hcur, hnxt, PAR, XdInt<4>{}); step(ucb, hso, hcur, hnxt, PAR, XdInt<5>{});
+        step(ucb, hso, hcur, hnxt, PAR, XdInt<6>{}); step(ucb, hso, hcur, hnxt, PAR, XdInt<7>{});
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------------------------------------------------
+    // the block's 16 x 64 filter scales and 64 biases go to LDS now (one load per thread): the epilogue has no register to prefetch them into
+    // and would otherwise wait for each of its 64 scale vectors in turn (measured: ~15 us per block in versions 3 and 4a)
+    float* const sc_lds = reinterpret_cast<float*>(smem_xf + XD_M_BYTES);
+    {
+        const int Np0 = u_rbt * 32;
+        const float* uinv0 = reinterpret_cast<const float*>(ublob + (size_t)16 * K16 * u_rbt * HX_RB);
+        const int p = tid >> 4, q = (tid & 15) * 4;
+        *reinterpret_cast<f32x4*>(sc_lds + p * 64 + q) = *reinterpret_cast<const f32x4*>(uinv0 + (size_t)p * Np0 + 64 * cb + q);
+        if (tid < 16) *reinterpret_cast<f32x4*>(sc_lds + 1024 + 4 * tid) = *reinterpret_cast<const f32x4*>(bias + 64 * cb + 4 * tid);
+    }
+    load_halo(0);
+    load_u(0, XdInt<0>{}, XdInt<0>{}); load_u(0, XdInt<0>{}, XdInt<1>{}); load_u(0, XdInt<0>{}, XdInt<2>{}); load_u(0, XdInt<0>{}, XdInt<3>{});
+    store_halo(hbuf0);
+    load_halo(K16 > 1 ? 1 : 0);                                              // halo(1) waits in registers for step 2 / 3 of chunk 0
+    xd_lds_barrier();
+    // state at the top of a chunk: r = the r of (chunk, half 0) with column 0 already replaced ... the loop's steady state is entered with
+    // V(0, 0) formed and r[1..3] of half 0 live; r[0] is free (the loop's first step writes half 1's column 0 there)
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) { read_d(hbuf0, 0, bb); make_r(bb, 0); make_r(bb, 1); }
+    v_adds(0, 0); v_hi(0, 0, 0); v_lo(0, 0, 0);
+    v_adds(0, 2); v_hi(0, 0, 2); v_lo(0, 0, 2);
+#ifdef XD_CLOCKS
+    const unsigned long long xd_t_loop = __builtin_amdgcn_s_memrealtime(), xd_c_loop = __builtin_readcyclecounter();
+#endif
+    for (int c = 0; c < K16; c += 2) {                                       // K16 is even (cin % 32 == 0: checked by the launcher)
+        chunk(c, XdInt<0>{});
+        chunk(c + 1, XdInt<1>{});
+    }
+#undef XD_MFMA
+#undef XD_FENCE
+#undef XD_IF
+#ifdef XD_CLOCKS
+    const unsigned long long xd_t_done = __builtin_amdgcn_s_memrealtime(), xd_c_done = __builtin_readcyclecounter();
+#endif
+    __syncthreads();                                                         // every wave is past its last halo read: the M buffer may overwrite it
+
+    // ---- epilogue: one half = 32 tiles at a time through LDS, wino_output_kernel's arithmetic.  A tile's 64 channels are 68 floats apart:
+    // with 64 (versions 1-3) the 32 lanes of a ds_write_b128 hit the same four banks (measured: 10-12 us per block for the epilogue) ----
+    float* const mbuf = reinterpret_cast<float*>(smem_xf);
+    const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = 4 * wave + j;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = 32 * ct + 8 * g + 4 * kh;
+                    const f32x4 sb = *reinterpret_cast<const f32x4*>(sc_lds + p * 64 + co);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (acc[h][j][ct][4 * g + e] * vinv[h]) * sb[e];
+                    *reinterpret_cast<f32x4*>(mbuf + (p * 32 + tl) * XD_MS + co) = v;
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = tid + 256 * it;
+            const int t = item >> 4, k = (item & 15) * 4;
+            const int oty = 4 * by + 2 * h + (t >> 4), otx = XF_TC * bx + (t & 15);
+            if (oty >= gm.th || otx >= gm.tw) continue;
+            if (POOL && (oty >= Ho || otx >= Wo)) continue;
+            const int kg = 64 * cb + k;
+            const float* mp = mbuf + t * XD_MS + k;
+            f32x4 s[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 m0 = *reinterpret_cast<const f32x4*>(mp + (0 + j) * (32 * XD_MS));
+                const f32x4 m1 = *reinterpret_cast<const f32x4*>(mp + (4 + j) * (32 * XD_MS));
+                const f32x4 m2 = *reinterpret_cast<const f32x4*>(mp + (8 + j) * (32 * XD_MS));
+                const f32x4 m3 = *reinterpret_cast<const f32x4*>(mp + (12 + j) * (32 * XD_MS));
+                s[0][j] = (m0 + m1) + m2;
+                s[1][j] = (m1 - m2) - m3;
+            }
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(sc_lds + 1024 + k);
+            f32x4 o[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                o[a][0] = ((s[a][0] + s[a][1]) + s[a][2]) + bv;
+                o[a][1] = ((s[a][1] - s[a][2]) - s[a][3]) + bv;
+            }
+            if (relu) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[a][bb][e] = fmaxf(o[a][bb][e], 0.f);
+            }
+            if (POOL) {
+                f32x4 m;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
+                *reinterpret_cast<f32x4*>(y + ((size_t)oty * Wo + otx) * Cout + kg) = m;
+            } else {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int yy = 2 * oty + a;
+                    if (yy >= H) continue;
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int xx = 2 * otx + bb;
+                        if (xx < W) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * Cout + kg) = o[a][bb];
+                    }
+                }
+            }
+        }
+    }
+#ifdef XD_CLOCKS
+    // timing build (tools/xd_clocks.py): wave 0 / lane 0 of every block leaves its stamps behind the (single-map) output
+    if (tid == 0) {
+        const unsigned long long t_out = __builtin_amdgcn_s_memrealtime();
+        float* rec = y_maps + (POOL ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) * Cout + (size_t)blockIdx.x * 8;
+        rec[0] = (float)(xd_t_loop - xd_t_in); rec[1] = (float)(xd_t_done - xd_t_loop); rec[2] = (float)(t_out - xd_t_done);
+        rec[3] = (float)(xd_c_done - xd_c_loop); rec[4] = (float)(xd_t_in & 0xFFFFFF); rec[5] = (float)(t_out & 0xFFFFFF);
+        rec[6] = (float)K16; rec[7] = 1.0f;
+    }
+#endif
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------
 // cmax scratch: n_maps * H * W floats (the channel maxima of the layer input, computed here)
 size_t conv3x3_winograd_x3_fused_workspace_bytes(int N, int H, int W) { return (size_t)N * H * W * sizeof(float); }
@@ -577,8 +982,9 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     if (rc) return rc;
     XfGeom gm;
     gm.tw = cdiv(W, 2); gm.th = cdiv(H, 2);
-    static const int ver = []() { const char* e = frcnn_knob("FRCNN_X3F_VER"); return e ? atoi(e) : 1; }();       // 2, 3: the experimental variants
-    gm.tbx = cdiv(gm.tw, XF_TC); gm.tby = cdiv(gm.th, ver == 3 ? 4 : XF_TR);
+    static const int ver_env = []() { const char* e = frcnn_knob("FRCNN_X3F_VER"); return e ? atoi(e) : 4; }();   // 1-3: round 3's variants
+    const int ver = (ver_env == 4 && cin % 32 != 0) ? 3 : ver_env;          // version 4 walks the chunks in pairs
+    gm.tbx = cdiv(gm.tw, XF_TC); gm.tby = cdiv(gm.th, ver >= 3 ? 4 : XF_TR);
     gm.ncb = cout / 64;
     const long long total = (long long)gm.tbx * gm.tby * gm.ncb * N;
     if (total > 0x7fffffffLL) return FRCNN_EINVAL;
@@ -592,6 +998,17 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
         hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), LDS, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm);   \
     } while (0)
     const bool pool = (flags & FRCNN_POOL2) != 0;
+    if (ver == 4) {
+        if (pool) {
+            auto kern = wino_x3d_kernel<true>;
+            FRCNN_MAX_LDS_ONCE(kern, XD_LDS_BYTES);
+            hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm);
+        } else {
+            auto kern = wino_x3d_kernel<false>;
+            FRCNN_MAX_LDS_ONCE(kern, XD_LDS_BYTES);
+            hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm);
+        }
+    } else
     if (ver == 3) {
         if (pool) {
             auto kern = wino_x3f64_kernel<true>;

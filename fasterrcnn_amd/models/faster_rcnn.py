@@ -147,6 +147,11 @@ class FasterRCNNModel(nn.Module):
         # relative to their row's largest element; error against float64 within the exact-f32 kernel's (tests/test_gemm_x3t_gpu.py)
         self._winograd_x3_layers = ()
         self.winograd_x3_layers = ("rpn_trunk",) if self._is_resnet else nv.DEFAULT_X3_LAYERS_VGG16
+        # VGG-16 layers that run as ONE-launch f32x3 Winograd layers (csrc/wino_x3f.hip; disjoint from winograd_x6_layers): the layers whose
+        # V + M scratch would not fit the Infinity Cache in the three-launch form
+        self._winograd_x3f_layers = ()
+        if not self._is_resnet:
+            self.winograd_x3f_layers = nv.DEFAULT_X3F_LAYERS_VGG16
 
         # hipGraph replay of one image's ~33 launches (forward + detections + the D2H copies): the second consecutive call of a slot with
         # the same (shape, thresholds, weights, modes) captures them into a graph on the slot's stream, later calls copy the image
@@ -274,6 +279,35 @@ class FasterRCNNModel(nn.Module):
         self._winograd_x3_layers = names
         self._apply_x3()
 
+    @property
+    def winograd_x3f_layers(self):
+        return self._winograd_x3f_layers
+
+    @winograd_x3f_layers.setter
+    def winograd_x3f_layers(self, names):
+        """VGG-16, f32_winograd mode: the 3x3 layers that run as ONE-launch Winograd layers in the f32x3 arithmetic (csrc/wino_x3f.hip): any
+        of conv2_1 .. conv5_3 (cin % 32 == 0) that is not in winograd_x6_layers (a name in both runs as the x6 / x3 three-launch layer)."""
+        names = tuple(names)
+        if names and self._is_resnet:
+            raise NotImplementedError("winograd_x3f_layers applies to the VGG-16 feature extractor")
+        allowed = tuple(n for n in nv.X6_LAYER_BITS if n not in ("conv1_2", "rpn_trunk"))
+        for n in names:
+            if n not in allowed:
+                raise ValueError("winograd_x3f_layers: %r cannot run as a one-launch f32x3 Winograd layer (choices: %s)" % (n, ", ".join(allowed)))
+        self._winograd_x3f_layers = names
+        self._apply_x3()
+
+    def _effective_x3f_layers(self):
+        return tuple(n for n in self._winograd_x3f_layers if n not in self._winograd_x6_layers)
+
+    def _x3f_mask(self):
+        if self._math_mode != "f32_winograd" or self._is_resnet:
+            return 0
+        mask = 0
+        for n in self._effective_x3f_layers():
+            mask |= 1 << nv.X6_LAYER_BITS[n]
+        return mask
+
     def _effective_x3_layers(self):
         return tuple(n for n in self._winograd_x3_layers if n in self._winograd_x6_layers)
 
@@ -281,6 +315,7 @@ class FasterRCNNModel(nn.Module):
         eff = self._effective_x3_layers() if hasattr(self, "_winograd_x3_layers") else ()
         if not self._is_resnet:
             self._stage1_feature_extractor.x3_layers = tuple(n for n in eff if n != "rpn_trunk")
+            self._stage1_feature_extractor.x3f_layers = self._effective_x3f_layers() if hasattr(self, "_winograd_x3f_layers") else ()
         self._stage2_region_proposal_network.x3_trunk = "rpn_trunk" in eff
 
     def _x3_mask(self):
@@ -435,7 +470,7 @@ class FasterRCNNModel(nn.Module):
                                 # (ResNet: the cost model's choice in every slot, so that an image gives the same bits in flight
                                 #  and alone: its 1x1 GEMMs switch between split-K and unsplit tiles with the tile mode)
                                 0 if (slot_index == 0 or self._is_resnet) else self.inflight_x6_gemm_tiles,
-                                self._x3_mask())
+                                self._x3_mask(), self._x3f_mask())
 
     def _enqueue_outputs(self, slot, h, w, score_threshold, sp):
         """decode + per-class NMS (faster_rcnn.py:179-224) and the D2H copies of one image, behind its forward on stream `sp`."""

@@ -21,7 +21,7 @@ _LAYERS = [  # (name, cin, cout, pool_after)
 ]
 
 
-def pack_conv3x3(conv, math_mode="f32"):
+def pack_conv3x3(conv, math_mode="f32", one_launch=False):
     """
     OIHW weight of a 3x3 nn.Conv2d -> tap-major [9][cout][cin] (or [27][cout] when cin == 3); in the
     "f32x6" math mode -> the exactly split [9][cout][cin/16][hi,mid,lo][16] bf16 layout; in the
@@ -46,8 +46,10 @@ def pack_conv3x3(conv, math_mode="f32"):
     if math_mode == "f32_winograd_x3":
         # the same layer in the f32x3 arithmetic (csrc/wino_x3.hip): the float32 bank [16][cout][cin], then records + row scales in one blob
         # (int8: the dtype marks it)
-        if not nv.uses_winograd_x6(cin, cout):
-            raise ValueError("a %d -> %d 3x3 layer cannot run as an x6 / x3 Winograd layer (cin >= 256, cout %% 256 == 0)" % (cin, cout))
+        # (`one_launch`: the blob feeds csrc/wino_x3f.hip, whose shape rule is wider: cin % 32 == 0, cout % 64 == 0)
+        if not (nv.uses_winograd_x3f(cin, cout) if one_launch else nv.uses_winograd_x6(cin, cout)):
+            raise ValueError("a %d -> %d 3x3 layer cannot run as an x6 / x3 Winograd layer (cin >= 256, cout %% 256 == 0; one-launch x3: cin %% 32 == 0, "
+                             "cout %% 64 == 0)" % (cin, cout))
         lib = nv.lib()
         bank = t.empty((16, cout, cin), dtype=t.float32, device=w.device)
         out = t.empty((int(lib.frcnn_conv3x3_winograd_x3_pack_bytes(cout, cin)),), dtype=t.int8, device=w.device)
@@ -82,7 +84,7 @@ def pack_conv3x3(conv, math_mode="f32"):
     return out
 
 
-def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False):
+def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False, one_launch=False):
     """One 3x3 'same' convolution (+ReLU, + fused 2x2 max-pool) on an NHWC CUDA tensor via frcnn_conv3x3_nhwc
     (frcnn_conv3x3_nhwc_x6 when `wp` is a split int16 weight buffer, frcnn_conv3x3_nhwc_winograd when it is a
     [16][cout][cin] transformed filter bank)."""
@@ -97,6 +99,14 @@ def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False):
         with t.cuda.device(x_hwc.device):
             nv.check(lib.frcnn_conv3x3_nhwc_winograd_x6(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
                                                         nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc_winograd_x6")
+        return y
+    if wp.dtype == t.int8 and one_launch:                # one-launch x3 Winograd layer (csrc/wino_x3f.hip): scratch = the input's channel maxima
+        flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
+        ws_bytes = int(lib.frcnn_conv3x3_winograd_x3_fused_workspace_bytes(1, h, w))
+        ws = t.empty((ws_bytes,), dtype=t.uint8, device=x_hwc.device)
+        with t.cuda.device(x_hwc.device):
+            nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
+                                                              nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc_winograd_x3_fused")
         return y
     if wp.dtype == t.int8:                               # x3 Winograd layer: packed x3t bank + scratch
         flags = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
@@ -144,10 +154,17 @@ class FeatureExtractor(nn.Module):
         self.math_mode = "f32"
         self.x6_layers = ()          # names ("conv4_1", ...) of the layers that run as x6 Winograd layers in the f32_winograd mode
         self.x3_layers = ()          # the subset of x6_layers whose GEMMs run in the f32x3 arithmetic (csrc/wino_x3.hip)
+        self.x3f_layers = ()         # layers (disjoint from x6_layers) that run as ONE-launch f32x3 Winograd layers (csrc/wino_x3f.hip)
+
+    @staticmethod
+    def layer_name(i):
+        return "conv%s_%s" % (_LAYERS[i][0][6], _LAYERS[i][0][-1])
 
     def layer_math(self, i):
         """Pack / arithmetic kind of layer i in the current mode."""
-        name = "conv%s_%s" % (_LAYERS[i][0][6], _LAYERS[i][0][-1])
+        name = self.layer_name(i)
+        if self.math_mode == "f32_winograd" and name in self.x3f_layers:
+            return "f32_winograd_x3"
         if self.math_mode == "f32_winograd" and name in self.x6_layers:
             return "f32_winograd_x3" if name in self.x3_layers else "f32_winograd_x6"
         return self.math_mode
@@ -158,9 +175,10 @@ class FeatureExtractor(nn.Module):
     def packed(self):
         """[(packed_weight, bias)] x 13 on the parameters' device, rebuilt when parameters change."""
         params = [p for c in self.convs() for p in (c.weight, c.bias)]
-        key = (self.math_mode, tuple(sorted(self.x6_layers)), tuple(sorted(self.x3_layers))) + rt.param_key(params)
+        key = (self.math_mode, tuple(sorted(self.x6_layers)), tuple(sorted(self.x3_layers)), tuple(sorted(self.x3f_layers))) + rt.param_key(params)
         if key != self._packed_key:
-            self._packed = [(pack_conv3x3(c, self.layer_math(i)), rt.as_f32_cuda(c.bias.detach(), "conv bias"))
+            x3f = self.x3f_layers if self.math_mode == "f32_winograd" else ()
+            self._packed = [(pack_conv3x3(c, self.layer_math(i), one_launch=self.layer_name(i) in x3f), rt.as_f32_cuda(c.bias.detach(), "conv bias"))
                             for i, c in enumerate(self.convs())]
             self._packed_key = key
         return self._packed
@@ -188,7 +206,8 @@ class FeatureExtractor(nn.Module):
                     nv.check(lib.frcnn_conv3x3_c3(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(cur), h, w, cout, nv.RELU,
                                                   nv.stream_ptr()), "frcnn_conv3x3_c3")
             else:
-                cur = conv3x3(cur, wp, b, cin, cout, relu=True, pool=pool)
+                cur = conv3x3(cur, wp, b, cin, cout, relu=True, pool=pool,
+                              one_launch=self.math_mode == "f32_winograd" and self.layer_name(i) in self.x3f_layers)
         return cur.permute(2, 0, 1).unsqueeze(0)
 
 

@@ -37,11 +37,12 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 8   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
+#define FRCNN_ABI_VERSION 9   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
                                  5: bf16 gradient GEMMs (the *_math entry points); 6: x6t GEMM, x6 Winograd layers, frcnn_forward_params.winograd_x6_mask,
                                  timing classes 8 / 9; 7: batched feature extractor (frcnn_resnet_backbone, frcnn_resnet_forward_features,
                                  frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps); 8: the f32x3 arithmetic (frcnn_*_x3t, frcnn_*_winograd_x3,
-                                 frcnn_forward_params.winograd_x3_mask, FRCNN_FC_F32X3T, frcnn_bottleneck_weights.x3_mask) */
+                                 frcnn_forward_params.winograd_x3_mask, FRCNN_FC_F32X3T, frcnn_bottleneck_weights.x3_mask); 9: one-launch f32x3 Winograd layers
+                                 in the forward (frcnn_forward_params.winograd_x3f_mask, timing class 10), frcnn_roi_pool_x3t */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -275,10 +276,11 @@ int frcnn_pack_conv3x3_winograd_x3(const float* d_u_f32, void* d_blob, int cout,
 size_t frcnn_conv3x3_winograd_x3_workspace_bytes(int n_maps, int H, int W, int cin, int cout);
 int frcnn_conv3x3_nhwc_winograd_x3(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W, int cin,
                                    int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
-/* EXPERIMENTAL (round 3: validated bit for bit against the three-launch layer, not tuned yet, no forward uses it): the same layer as ONE launch
- * (csrc/wino_x3f.hip: V formed in registers from an LDS-staged halo, all 16 positions in MFMA accumulators, output transform in the
- * epilogue; no V / M scratch), for the layers whose scratch does not fit the Infinity Cache.  By construction bit-identical to
- * frcnn_conv3x3_nhwc_winograd_x3 on the same blob.  cout % 64 == 0; d_ws >= frcnn_conv3x3_winograd_x3_fused_workspace_bytes. */
+/* The same layer as ONE launch (csrc/wino_x3f.hip, round 4: 64 tiles x 64 output channels x all 16 positions per block; the operand formed in
+ * registers from an LDS-staged halo, the filter fragments loaded straight from L2 into registers, output transform in the epilogue; no
+ * V / M scratch), for the layers whose scratch does not fit the Infinity Cache (frcnn_forward_params.winograd_x3f_mask: conv2_2 .. conv3_3
+ * of VGG-16).  By construction bit-identical to frcnn_conv3x3_nhwc_winograd_x3 on the same blob.  cin % 16 == 0, cout % 64 == 0;
+ * d_ws >= frcnn_conv3x3_winograd_x3_fused_workspace_bytes (the channel maxima of the input). */
 size_t frcnn_conv3x3_winograd_x3_fused_workspace_bytes(int n_maps, int H, int W);
 int frcnn_conv3x3_nhwc_winograd_x3_fused(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W,
                                          int cin, int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
@@ -503,6 +505,11 @@ typedef struct frcnn_forward_params {
     int32_t winograd_x3_mask;   /* a subset of winograd_x6_mask (VGG-16): the layers whose position GEMMs run in the f32x3 arithmetic instead (two
                                    fp16 terms per row-scaled operand, three MFMAs per product: csrc/wino_x3.hip); their weight pointers are
                                    frcnn_pack_conv3x3_winograd_x3's blobs.  ResNet: 0 */
+    int32_t winograd_x3f_mask;  /* round 4 (ABI 9), VGG-16, FRCNN_MATH_F32_WINOGRAD only: bit i set = 3x3 layer i (1 .. 12; disjoint from winograd_x6_mask)
+                                   runs as a ONE-LAUNCH Winograd layer in the f32x3 arithmetic (csrc/wino_x3f.hip: operand formed in registers from the
+                                   LDS-staged halo, filter fragments straight from L2, all 16 positions in accumulators, no V / M scratch; the same bits
+                                   as the three-launch f32x3 layer) and its weight pointer is frcnn_pack_conv3x3_winograd_x3's blob.  For the
+                                   layers whose V + M scratch does not fit the Infinity Cache (conv2_2 .. conv3_3).  cin % 32 == 0, cout % 64 == 0 */
 } frcnn_forward_params;
 #define FRCNN_X6_RPN_TRUNK_BIT 13
 /* capacity of the detector heads: classifier (n) + regressor (4 n - 4) rows are stacked into one zero-padded GEMM operand of
@@ -730,9 +737,10 @@ int frcnn_ctx_tensor(frcnn_ctx* ctx, int which, void** d_ptr, size_t* bytes);
  * classes: 0 conv3x3 MFMA (backbone+RPN), 1 conv first layer, 2 linear MFMA, 3 proposals,
  * 4 roi_pool, 5 other, 6 Winograd input / output transforms (three-launch float32 form), 7 float32 Winograd MFMA kernels
  * (wino_fused_kernel; the three-launch form's batched GEMM), 8 x6 Winograd input / output transforms, 9 x6 Winograd batched GEMM
- * (gemm_x6t_kernel, bf16 pipe).  frcnn_ctx_timing_read synchronises the recorded events and returns
+ * (gemm_x6t_kernel / gemm_x3t_kernel), 10 one-launch f32x3 Winograd layers (wino_x3d_kernel + their channel-maximum pass).
+ * frcnn_ctx_timing_read synchronises the recorded events and returns
  * accumulated milliseconds and launch counts since the last reset. */
-#define FRCNN_NUM_KCLASS 10
+#define FRCNN_NUM_KCLASS 11
 int frcnn_ctx_timing_enable(frcnn_ctx* ctx, int enable);
 int frcnn_ctx_timing_read(frcnn_ctx* ctx, double ms[FRCNN_NUM_KCLASS], int64_t launches[FRCNN_NUM_KCLASS],
                           int reset);

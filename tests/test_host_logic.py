@@ -265,8 +265,18 @@ def test_bench_layer_arithmetic_f32x3_tables():
     import bench
     from fasterrcnn_amd import _native as nv
     x6, x3 = nv.DEFAULT_X6_LAYERS_VGG16, nv.DEFAULT_X3_LAYERS_VGG16
-    assert set(x3) <= set(x6) and "conv5_1" in x6 and "conv5_1" not in x3
-    rows = {r[0]: r for r in bench.layer_arithmetic("f32_winograd", "f32x3", x6, x3=x3)}
+    x3f = nv.DEFAULT_X3F_LAYERS_VGG16
+    assert x3 == x6 and "conv5_1" in x3                     # round 4: the whole x6 table in f32x3 (chosen on the held-out set: DESIGN.md section 4)
+    assert x3f == ("conv2_2", "conv3_1", "conv3_2", "conv3_3") and not set(x3f) & set(x6)
+    rows = {r[0]: r for r in bench.layer_arithmetic("f32_winograd", "f32x3", x6, x3=x3, x3f=x3f)}
+    for n in x3f:                                            # the one-launch f32x3 layers: three fp16 MFMAs per product, no x6 entry needed
+        ci, co, h, w = dict(zip(bench._CONV_NAMES, bench._MFMA_CONVS))[n]
+        assert rows[n][1].startswith("wino_x3d_kernel") and rows[n][2] == "f16" and rows[n][3] == 3.0 * bench.winograd_gemm_flops(ci, co, h, w)
+    assert rows["conv1_2"][1] == "wino_fused_kernel" and rows["conv2_1"][2] == "f32"
+    assert [n for n, _ in bench.winograd_layers("f32_winograd", x6, named=True, x3f=x3f)] == ["conv1_2", "conv2_1"]
+    assert [n for n, _ in bench.x3f_winograd_layers("f32_winograd", x6, x3f)] == list(x3f)
+    rows = {r[0]: r for r in bench.layer_arithmetic("f32_winograd", "f32x3", x6, x3=tuple(n for n in x3 if n != "conv5_1"))}
+    x3 = tuple(n for n in x3 if n != "conv5_1")
     for n in x6:
         if n == "rpn_trunk":
             continue
@@ -281,9 +291,19 @@ def test_bench_layer_arithmetic_f32x3_tables():
     assert r2["conv4_2"][2] == "f16" and r2["conv5_2"][2] == "f32" and r2["fc1"][2] == "f32"
     pf = bench.pipe_flops_per_image("f32_winograd", "f32x3", x6, x3=x3)
     assert pf["f16"] > 0 and pf["bf16"] > 0 and abs(pf["f32"] + pf["bf16"] + pf["f16"] - bench.executed_mfma_flops_per_image("f32_winograd", "f32x3", x6, x3)) < 1.0
+    x3 = nv.DEFAULT_X3_LAYERS_VGG16
     m = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
-    assert m.winograd_x6_layers == x6 and m.winograd_x3_layers == x3 and m.fc_math_mode == "f32x3"
-    assert m._x3_mask() & ~m._x6_mask() == 0
+    assert m.winograd_x6_layers == x6 and m.winograd_x3_layers == x3 and m.fc_math_mode == "f32x3" and m.winograd_x3f_layers == x3f
+    assert m._x3_mask() & ~m._x6_mask() == 0 and m._x3f_mask() & m._x6_mask() == 0
+    assert m._x3f_mask() == sum(1 << nv.X6_LAYER_BITS[n] for n in x3f) and m._stage1_feature_extractor.x3f_layers == x3f
+    m.winograd_x6_layers = x6 + ("conv3_2",)                  # a layer in both tables runs as the three-launch x6 / x3 layer
+    assert m._x3f_mask() & (1 << nv.X6_LAYER_BITS["conv3_2"]) == 0 and "conv3_2" not in m._stage1_feature_extractor.x3f_layers
+    m.winograd_x6_layers = x6
+    m.math_mode = "f32"
+    assert m._x3f_mask() == 0
+    m.math_mode = "f32_winograd"
+    with pytest.raises(ValueError):
+        m.winograd_x3f_layers = ("conv1_2",)
     m.winograd_x6_layers = ("conv4_2",)                       # the x3 table is an overlay: names outside the x6 table have no effect ...
     assert m._x3_mask() == 1 << nv.X6_LAYER_BITS["conv4_2"] and m._stage1_feature_extractor.x3_layers == ("conv4_2",)
     m.winograd_x6_layers = x6                                 # ... and come back with it

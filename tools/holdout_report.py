@@ -20,14 +20,17 @@ from fasterrcnn_amd import _native as nv
 X6 = ("conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3", "rpn_trunk")
 
 # name -> attributes set on the model (VGG-16).  "default" leaves the model as constructed.
+X3F = ("conv2_2", "conv3_1", "conv3_2", "conv3_3")
 VGG_TABLES = {
     "default": {},
-    "f32": {"winograd_x6_layers": (), "winograd_x3_layers": (), "fc_math_mode": "f32"},                 # every GEMM on the exact-f32 pipe
+    "f32": {"winograd_x6_layers": (), "winograd_x3_layers": (), "winograd_x3f_layers": (), "fc_math_mode": "f32"},   # every GEMM on the exact-f32 pipe
     "f32_direct": {"math_mode": "f32", "fc_math_mode": "f32"},                                         # no Winograd at all
-    "x6": {"winograd_x6_layers": X6, "winograd_x3_layers": (), "fc_math_mode": "f32x6"},
-    "x3_all": {"winograd_x6_layers": X6, "winograd_x3_layers": X6, "fc_math_mode": "f32x3"},
-    "x3_conv_only": {"winograd_x6_layers": X6, "winograd_x3_layers": X6, "fc_math_mode": "f32"},
-    "x3_fc_only": {"winograd_x6_layers": (), "winograd_x3_layers": (), "fc_math_mode": "f32x3"},
+    "x6": {"winograd_x6_layers": X6, "winograd_x3_layers": (), "winograd_x3f_layers": (), "fc_math_mode": "f32x6"},
+    "x3_all": {"winograd_x6_layers": X6, "winograd_x3_layers": X6, "winograd_x3f_layers": (), "fc_math_mode": "f32x3"},   # round 4's table without the one-launch layers
+    "x3_conv_only": {"winograd_x6_layers": X6, "winograd_x3_layers": X6, "winograd_x3f_layers": (), "fc_math_mode": "f32"},
+    "x3_fc_only": {"winograd_x6_layers": (), "winograd_x3_layers": (), "winograd_x3f_layers": (), "fc_math_mode": "f32x3"},
+    "x3f_only": {"winograd_x6_layers": (), "winograd_x3_layers": (), "winograd_x3f_layers": X3F, "fc_math_mode": "f32"},
+    "x3_everything": {"winograd_x6_layers": X6, "winograd_x3_layers": X6, "winograd_x3f_layers": ("conv2_1",) + X3F, "fc_math_mode": "f32x3"},
 }
 RESNET_TABLES = {
     "default": {},

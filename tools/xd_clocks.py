@@ -1,0 +1,52 @@
+"""tools/xd_clocks.py -- where a block of the one-launch f32x3 Winograd kernel (csrc/wino_x3f.hip, version 4) spends its time.
+Needs a library built with -DXD_CLOCKS:  SRC=wino_x3f tools/build_ablate.sh xdclk -DXD_CLOCKS ; FRCNN_LIB_PATH=build/libfrcnn_xdclk.so"""
+import sys
+import numpy as np
+import torch as t
+sys.path.insert(0, ".")
+from fasterrcnn_amd import _native as nv
+
+
+def run(name, cin, cout, h, w, pool, reps=20):
+    dev = t.device("cuda:0")
+    lib = nv.lib()
+    s = nv.stream_ptr()
+    x = t.randn((h, w, cin), device=dev).clamp(min=0)
+    wt = t.randn((cout, cin, 3, 3), device=dev) * 0.02
+    b = t.zeros((cout,), device=dev)
+    bank = t.empty((16, cout, cin), device=dev)
+    u = t.empty((int(lib.frcnn_conv3x3_winograd_x3_pack_bytes(cout, cin)),), dtype=t.int8, device=dev)
+    nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(wt), None, nv.ptr(bank), cout, cin, s), "pack")
+    nv.check(lib.frcnn_pack_conv3x3_winograd_x3(nv.ptr(bank), nv.ptr(u), cout, cin, s), "pack_x3")
+    oh, ow = (h // 2, w // 2) if pool else (h, w)
+    th, tw = (h + 1) // 2, (w + 1) // 2
+    nblk = ((th + 3) // 4) * ((tw + 15) // 16) * (cout // 64)
+    y = t.zeros((oh * ow * cout + 8 * nblk,), device=dev)
+    wsb = int(lib.frcnn_conv3x3_winograd_x3_fused_workspace_bytes(1, h, w))
+    ws = t.empty((wsb,), dtype=t.uint8, device=dev)
+    flags = nv.RELU | (nv.POOL2 if pool else 0)
+    e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+    for rep in range(reps):
+        if rep == reps - 1:
+            e0.record()
+        nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags, nv.ptr(ws), wsb, s), "x3f")
+    e1.record()
+    t.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3
+    o = y[oh * ow * cout:].view(nblk, 8).cpu().numpy().astype(np.float64)
+    assert (o[:, 7] == 1.0).all()
+    pro, loop, epi, cyc, t_in, t_out, k16 = (o[:, i] for i in range(7))
+    k16 = k16[0]
+    span = ((t_out.max() - t_in.min()) % (1 << 24)) / 100.0
+    start = np.sort(((t_in - t_in.min()) % (1 << 24)) / 100.0)
+    print("%-8s %3d->%3d %4dx%-4d blocks %4d | launch (with the channel-maximum pass) %.1f us, first entry -> last exit %.1f us | per block: before the "
+          "loop %.2f us, loop %.2f us = %.3f us / chunk (%.0f cycles / chunk at %.0f MHz; 1536 = the MFMAs alone), after %.2f us | block starts: "
+          "p25 %.1f p50 %.1f p75 %.1f p100 %.1f us" % (name, cin, cout, h, w, nblk, us, span, pro.mean() / 100, loop.mean() / 100, loop.mean() / 100 / k16,
+                                                       cyc.mean() / k16, (cyc / loop).mean() * 100, epi.mean() / 100,
+                                                       np.percentile(start, 25), np.percentile(start, 50), np.percentile(start, 75), start.max()))
+
+
+if __name__ == "__main__":
+    for a in [("conv2_2", 128, 128, 300, 500, True), ("conv3_1", 128, 256, 150, 250, False), ("conv3_2", 256, 256, 150, 250, False),
+              ("conv3_3", 256, 256, 150, 250, True), ("conv4_2", 512, 512, 75, 125, False)]:
+        run(*a)
