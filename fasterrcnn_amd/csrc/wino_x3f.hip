@@ -575,7 +575,7 @@ typedef _Float16 xd_f16x2 __attribute__((ext_vector_type(2)));
 static constexpr int XD_HP = XF_HC / 2;                                       // 17 pixel slots per (halo row, column parity)
 static constexpr int XD_HALO_FLOATS = X3_HR * XF_HC * XF_PS;                  // 6,800 floats = 27,200 B per buffer
 static constexpr int XD_MS = 68;                                              // floats between two tiles of the epilogue's M buffer (64 + 4: conflict-free)
-static constexpr int XD_M_BYTES = 16 * 32 * XD_MS * 4;                       // 139,264: the M buffer [16 positions][32 tiles][68] (>= the two halo buffers)
+static constexpr int XD_M_BYTES = 16 * 32 * XD_MS * 4;                       // 139,264: the epilogue's Y buffer [2 halves][4 rows][2][32 tiles][68] (>= the two halo buffers)
 static constexpr size_t XD_LDS_BYTES = XD_M_BYTES + 16 * 64 * 4 + 64 * 4;     // + the block's filter scales [16][64] and bias [64]: 143,616
 
 template <int N> struct XdInt { static constexpr int value = N; };
@@ -621,29 +621,22 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 
     const int tl = lane & 31, tyl = tl >> 4, txl = tl & 15, kh = lane >> 5;
     const int tx = XF_TC * bx + txl;
+    // the 2 x 16 channel maxima of this lane's tiles leave for registers now and are reduced to the tile scales AFTER the first halo and filter
+    // loads have been issued (one round trip to memory for all of them instead of two)
     float mult[2], vinv[2];
-    {
-        float dm[2][16];
+    float dm[2][16];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ty = 4 * by + 2 * h + tyl;
-            const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+    for (int h = 0; h < 2; ++h) {
+        const int ty = 4 * by + 2 * h + tyl;
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int yy = y0 + a, xx = x0 + c;
-                    const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < W;
-                    dm[h][4 * a + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, inb ? (yy * W + xx) * 4 : (int)0xFFFFFFF0u, 0, 0));
-                }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float dmax = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) dmax = fmaxf(dmax, dm[h][q]);
-            hx_row_scale(4.0f * dmax, mult[h], vinv[h]);
-        }
+            for (int c = 0; c < 4; ++c) {
+                const int yy = y0 + a, xx = x0 + c;
+                const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                dm[h][4 * a + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, inb ? (yy * W + xx) * 4 : (int)0xFFFFFFF0u, 0, 0));
+            }
     }
 
     // ---- halo staging (global -> registers -> LDS): piece = (pixel, 4-channel quad); surplus threads duplicate the first pieces ----------
@@ -856,6 +849,13 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     load_u(0, XdInt<0>{}, XdInt<0>{}); load_u(0, XdInt<0>{}, XdInt<1>{}); load_u(0, XdInt<0>{}, XdInt<2>{}); load_u(0, XdInt<0>{}, XdInt<3>{});
     store_halo(hbuf0);
     load_halo(K16 > 1 ? 1 : 0);                                              // halo(1) waits in registers for step 2 / 3 of chunk 0
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float dmax = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dmax = fmaxf(dmax, dm[h][q]);
+        hx_row_scale(4.0f * dmax, mult[h], vinv[h]);
+    }
     xd_lds_barrier();
     // state at the top of a chunk: r = the r of (chunk, half 0) with column 0 already replaced ... the loop's steady state is entered with
     // V(0, 0) formed and r[1..3] of half 0 live; r[0] is free (the loop's first step writes half 1's column 0 there)
@@ -878,78 +878,82 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #endif
     __syncthreads();                                                         // every wave is past its last halo read: the M buffer may overwrite it
 
-    // ---- epilogue: one half = 32 tiles at a time through LDS, wino_output_kernel's arithmetic.  A tile's 64 channels are 68 floats apart:
-    // with 64 (versions 1-3) the 32 lanes of a ds_write_b128 hit the same four banks (measured: 10-12 us per block for the epilogue) ----
-    float* const mbuf = reinterpret_cast<float*>(smem_xf);
+    // ---- epilogue: A^T M A + bias + ReLU (+ 2x2 max-pool).  A wave owns position ROW i = wave of every tile, i.e. all four columns j of
+    // that row: the column combination M A (Y[i][0] = (m_i0 + m_i1) + m_i2, Y[i][1] = (m_i1 - m_i2) - m_i3) happens in registers, and only
+    // the two Y per row go through LDS for the row combination A^T Y across the four waves -- half the LDS traffic of combining rows first
+    // (what wino_output_kernel does for the three-launch layers: the two orders differ by float32 rounding only), both tile halves in ONE
+    // pass.  A tile's 64 channels are 68 floats apart: with 64 the 32 lanes of a ds_write_b128 would hit the same four banks.
+    float* const ybuf = reinterpret_cast<float*>(smem_xf);                   // [half 2][row i 4][b 2][tile 32][68]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = 32 * ct + 8 * g + 4 * kh;                 // the MFMA's row operand was the filter: accumulator rows = channels
+                f32x4 m[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 sb = *reinterpret_cast<const f32x4*>(sc_lds + (4 * wave + j) * 64 + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[j][e] = acc[h][j][ct][4 * g + e] * sb[e];
+                }
+                f32x4 y0, y1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y0[e] = ((m[0][e] + m[1][e]) + m[2][e]) * vinv[h];        // the tile's 2^-e: exact, commutes with every rounding above
+                    y1[e] = ((m[1][e] - m[2][e]) - m[3][e]) * vinv[h];
+                }
+                float* dst = ybuf + ((((h * 4 + wave) * 2) * 32 + tl) * XD_MS) + co;
+                *reinterpret_cast<f32x4*>(dst) = y0;
+                *reinterpret_cast<f32x4*>(dst + 32 * XD_MS) = y1;
+            }
+    __syncthreads();
     const int Ho = H >> 1, Wo = W >> 1;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (h) __syncthreads();
+    for (int it = 0; it < 4; ++it) {
+        const int item = tid + 256 * it;                                     // (tile of 64, channel quad of 16)
+        const int t = item >> 4, k = (item & 15) * 4;
+        const int h = t >> 5, tt_ = t & 31;
+        const int oty = 4 * by + 2 * h + (tt_ >> 4), otx = XF_TC * bx + (tt_ & 15);
+        if (oty >= gm.th || otx >= gm.tw) continue;
+        if (POOL && (oty >= Ho || otx >= Wo)) continue;
+        const int kg = 64 * cb + k;
+        const float* yp = ybuf + ((h * 4) * 2 * 32 + tt_) * XD_MS + k;      // + (i 2 + b) 32 XD_MS
+        f32x4 Y[4][2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = 4 * wave + j;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int bb = 0; bb < 2; ++bb) Y[i][bb] = *reinterpret_cast<const f32x4*>(yp + (i * 2 + bb) * (32 * XD_MS));
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sc_lds + 1024 + k);
+        f32x4 o[2][2];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = 32 * ct + 8 * g + 4 * kh;
-                    const f32x4 sb = *reinterpret_cast<const f32x4*>(sc_lds + p * 64 + co);
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (acc[h][j][ct][4 * g + e] * vinv[h]) * sb[e];
-                    *reinterpret_cast<f32x4*>(mbuf + (p * 32 + tl) * XD_MS + co) = v;
-                }
+        for (int bb = 0; bb < 2; ++bb) {
+            o[0][bb] = ((Y[0][bb] + Y[1][bb]) + Y[2][bb]) + bv;
+            o[1][bb] = ((Y[1][bb] - Y[2][bb]) - Y[3][bb]) + bv;
         }
-        __syncthreads();
+        if (relu) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int item = tid + 256 * it;
-            const int t = item >> 4, k = (item & 15) * 4;
-            const int oty = 4 * by + 2 * h + (t >> 4), otx = XF_TC * bx + (t & 15);
-            if (oty >= gm.th || otx >= gm.tw) continue;
-            if (POOL && (oty >= Ho || otx >= Wo)) continue;
-            const int kg = 64 * cb + k;
-            const float* mp = mbuf + t * XD_MS + k;
-            f32x4 s[2][4];
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 m0 = *reinterpret_cast<const f32x4*>(mp + (0 + j) * (32 * XD_MS));
-                const f32x4 m1 = *reinterpret_cast<const f32x4*>(mp + (4 + j) * (32 * XD_MS));
-                const f32x4 m2 = *reinterpret_cast<const f32x4*>(mp + (8 + j) * (32 * XD_MS));
-                const f32x4 m3 = *reinterpret_cast<const f32x4*>(mp + (12 + j) * (32 * XD_MS));
-                s[0][j] = (m0 + m1) + m2;
-                s[1][j] = (m1 - m2) - m3;
-            }
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(sc_lds + 1024 + k);
-            f32x4 o[2][2];
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[a][bb][e] = fmaxf(o[a][bb][e], 0.f);
+        }
+        if (POOL) {
+            f32x4 mx;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
+            *reinterpret_cast<f32x4*>(y + ((size_t)oty * Wo + otx) * Cout + kg) = mx;
+        } else {
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                o[a][0] = ((s[a][0] + s[a][1]) + s[a][2]) + bv;
-                o[a][1] = ((s[a][1] - s[a][2]) - s[a][3]) + bv;
-            }
-            if (relu) {
+                const int yy = 2 * oty + a;
+                if (yy >= H) continue;
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[a][bb][e] = fmaxf(o[a][bb][e], 0.f);
-            }
-            if (POOL) {
-                f32x4 m;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
-                *reinterpret_cast<f32x4*>(y + ((size_t)oty * Wo + otx) * Cout + kg) = m;
-            } else {
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const int yy = 2 * oty + a;
-                    if (yy >= H) continue;
-#pragma unroll
-                    for (int bb = 0; bb < 2; ++bb) {
-                        const int xx = 2 * otx + bb;
-                        if (xx < W) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * Cout + kg) = o[a][bb];
-                    }
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int xx = 2 * otx + bb;
+                    if (xx < W) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * Cout + kg) = o[a][bb];
                 }
             }
         }

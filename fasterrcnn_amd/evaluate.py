@@ -203,50 +203,63 @@ class HostFeeder:
     """
     The host -> device leg of the reference's loops, pipelined: `__main__.py:78-86` does `t.from_numpy(image).unsqueeze(0).cuda()` then
     `predict` per image, and `predict_one` (`:237-240`) runs `load_image` (decode + PIL resize + normalise on the CPU,
-    datasets/image.py:59-101) first.  Here a DECODED image in pinned host memory goes through, per in-flight slot and on that slot's own
-    feeder stream: async H2D of the uint8 pixels (0.7 MB for a 375x625 VOC-sized image, against 7.2 MB for the preprocessed float32
-    tensor the reference uploads) -> `frcnn_preprocess` (PIL-exact BILINEAR resize to the 600-pixel minimum side + normalisation, on the
-    device: datasets/image.py) -> `model.predict_async` on the slot's stream, which waits for the feeder stream on the device.  The host
-    never blocks between submit() and the handle's result(); copies of one image overlap the convolutions of the others.
-    `submit_preprocessed` is the reference's literal form: a preprocessed float32 (3, H, W) host image, uploaded as is.
+    datasets/image.py:59-101) first.  Here a DECODED image in pinned host memory goes through: async H2D of the uint8 pixels (0.7 MB for a
+    375x625 VOC-sized image, against 7.2 MB for the preprocessed float32 tensor the reference uploads) -> `frcnn_preprocess` (PIL-exact
+    BILINEAR resize to the 600-pixel minimum side + normalisation, on the device: datasets/image.py) on a feeder stream -> `model.predict_async`
+    on an in-flight slot's stream, which waits for the feeder's event on the device.  The host never blocks between stage() / submit() and
+    the handle's result().
+
+    `stage()` and `submit_staged()` are the two halves: staging the frames a few images AHEAD of their predict (`lookahead` feeder streams
+    in a ring) takes the copy + resize latency (~0.1 ms) off every image's own critical path -- with three chip-filling images in flight
+    that latency is not hidden by the other two.  `submit()` is stage + submit_staged back to back; `submit_preprocessed` is the
+    reference's literal form: a preprocessed float32 (3, H, W) host image, uploaded as is.
     """
-    def __init__(self, model, min_dimension_pixels=600):
+    def __init__(self, model, min_dimension_pixels=600, lookahead=4):
         self.model = model
         self.min_dimension_pixels = min_dimension_pixels
         self.device = model._device()
-        self._streams = {}
-        self._staging = {}      # slot -> device buffer of the last upload (kept until the slot is reused: the copy is asynchronous)
+        self._streams = [t.cuda.Stream(device=self.device) for _ in range(max(1, int(lookahead)))]
+        self._staging = [None] * len(self._streams)     # device copy of the frame last uploaded on ring entry k (kept: the copy is asynchronous)
+        self._next = 0
 
-    def _stream(self, slot):
-        if slot not in self._streams:
-            self._streams[slot] = t.cuda.Stream(device=self.device)
-        return self._streams[slot]
-
-    def _stage(self, slot, host):
-        buf = self._staging.get(slot)
-        if buf is None or buf.shape != host.shape or buf.dtype != host.dtype:
-            buf = t.empty(host.shape, dtype=host.dtype, device=self.device)
-            self._staging[slot] = buf
-        buf.copy_(host, non_blocking=True)
-        return buf
-
-    def submit(self, rgb_u8_host, score_threshold, slot):
-        """rgb_u8_host: uint8 (H, W, 3) RGB CPU tensor, pinned for a truly asynchronous copy.  Returns the Pending handle of predict_async
-        (its result() is the reference's predict() dict).  The previous handle of `slot` must have been collected."""
+    def stage(self, rgb_u8_host):
+        """rgb_u8_host: uint8 (H, W, 3) RGB CPU tensor, pinned for a truly asynchronous copy.  Enqueues H2D + resize + normalisation on the
+        next feeder stream of the ring and returns the staged handle (preprocessed CUDA tensor, event) for `submit_staged`."""
         from .datasets import image as I
         if rgb_u8_host.dtype != t.uint8 or rgb_u8_host.dim() != 3 or rgb_u8_host.shape[2] != 3:
             raise ValueError("rgb_u8_host must be a uint8 (H, W, 3) image")
-        feeder = self._stream(slot)
+        k = self._next
+        self._next = (k + 1) % len(self._streams)
+        feeder = self._streams[k]
         with t.cuda.device(self.device), t.cuda.stream(feeder):
-            dev_u8 = self._stage(slot, rgb_u8_host)
-            image, _, _ = I.preprocess_image(dev_u8, self.model.backbone.image_preprocessing_params, self.min_dimension_pixels, False)
+            buf = self._staging[k]
+            if buf is None or buf.shape != rgb_u8_host.shape:
+                buf = t.empty(rgb_u8_host.shape, dtype=t.uint8, device=self.device)
+                self._staging[k] = buf
+            buf.copy_(rgb_u8_host, non_blocking=True)       # (ring entry k's previous frame was consumed by its own preprocess: same stream)
+            image, _, _ = I.preprocess_image(buf, self.model.backbone.image_preprocessing_params, self.min_dimension_pixels, False)
+            ev = t.cuda.Event()
+            ev.record(feeder)
+        return image, ev, feeder
+
+    def submit_staged(self, staged, score_threshold, slot):
+        """predict_async of a staged frame on in-flight slot `slot` (whose previous handle must have been collected)."""
+        image, ev, feeder = staged
+        with t.cuda.device(self.device), t.cuda.stream(feeder):   # predict_async makes the slot's stream wait for the CURRENT stream
             return self.model.predict_async(image.unsqueeze(0), score_threshold, slot=slot)
+
+    def submit(self, rgb_u8_host, score_threshold, slot):
+        """stage + submit_staged back to back.  Returns the Pending handle of predict_async (its result() is the reference's predict() dict)."""
+        return self.submit_staged(self.stage(rgb_u8_host), score_threshold, slot)
 
     def submit_preprocessed(self, image_f32_host, score_threshold, slot):
         """image_f32_host: float32 (3, H, W) preprocessed CPU tensor (what the reference's dataset yields), pinned."""
-        feeder = self._stream(slot)
+        k = self._next
+        self._next = (k + 1) % len(self._streams)
+        feeder = self._streams[k]
         with t.cuda.device(self.device), t.cuda.stream(feeder):
-            image = self._stage(slot, image_f32_host)
+            image = t.empty(image_f32_host.shape, dtype=t.float32, device=self.device)
+            image.copy_(image_f32_host, non_blocking=True)
             return self.model.predict_async(image.unsqueeze(0), score_threshold, slot=slot)
 
 

@@ -358,9 +358,12 @@ def test_model_x3_layer_tables_against_the_golden_vectors(gpu_model, golden_dir)
     (1, 75, 125, 256, 256, True, True),       # conv3_3 at half size, fused pool
     (2, 21, 35, 128, 192, False, False),      # two maps, three cout blocks, no ReLU
 ])
-def test_x3_one_launch_layer_equals_the_three_launch_layer_bit_for_bit(n, h, w, cin, cout, relu, pool):
-    """csrc/wino_x3f.hip (experimental first version, not used by a forward yet): same scale, same split, same accumulation order, same
-    output transform -> the same bits as the three-launch layer."""
+def test_x3_one_launch_layer_against_the_three_launch_layer_and_float64(n, h, w, cin, cout, relu, pool):
+    """csrc/wino_x3f.hip (round 4: the one-launch f32x3 Winograd layer of conv2_2 .. conv3_3): the same per-tile scale, fp16 split and
+    accumulation order per (position, tile, channel) as the three-launch layer -- the GEMM part is the same bits -- and an output
+    transform that combines the position COLUMNS in registers before the rows (the three-launch layer's wino_output_kernel does rows
+    first): the two differ by float32 rounding of the 2 x 2 output sums only.  Held to the three-launch layer within 2e-6 of max|y| and to a
+    float64 convolution at the three-launch layer's own bar (<= 1.5 x its error + 2e-7 of max|y|); deterministic."""
     import time
     lib = nv.lib()
     gen = torch.Generator().manual_seed(h * 1000 + w + cin)
@@ -379,11 +382,22 @@ def test_x3_one_launch_layer_equals_the_three_launch_layer_bit_for_bit(n, h, w, 
     call()
     torch.cuda.synchronize()
     assert not torch.isnan(y).any()
-    diff = float((y.reshape(want.shape) - want).abs().max())
+    first = y.clone()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), b.double(), padding=1)
+    if relu:
+        ref = ref.clamp(min=0)
+    if pool:
+        ref = F.max_pool2d(ref, 2)
+    ref = ref.permute(0, 2, 3, 1).cpu()
+    scale = float(ref.abs().max())
+    e1 = float((y.cpu().double() - ref).abs().max()) / scale
+    e3 = float((want.reshape(y.shape).cpu().double() - ref).abs().max()) / scale
+    diff = float((y.reshape(want.shape) - want).abs().max()) / scale
     t0 = time.perf_counter()
     for _ in range(10):
         call()
     torch.cuda.synchronize()
-    print("x3 one-launch %dx%dx%d %d->%d: max |diff| vs the three-launch layer %.3g; %.1f us per call" % (
-        n, h, w, cin, cout, diff, (time.perf_counter() - t0) / 10 * 1e6))
-    assert torch.equal(y.reshape(want.shape), want)
+    print("x3 one-launch %dx%dx%d %d->%d: vs float64 %.3g of max|y| (three-launch layer %.3g), vs the three-launch layer %.3g; %.1f us per call" % (
+        n, h, w, cin, cout, e1, e3, diff, (time.perf_counter() - t0) / 10 * 1e6))
+    assert diff <= 2e-6 and e1 <= 1.5 * e3 + 2e-7
+    assert torch.equal(y, first)                                           # run-to-run identical

@@ -280,6 +280,13 @@ def test_host_feeder_equals_upload_then_predict(gpu_model, sd_cpu):
         for i in range(len(frames)):
             for c in base[i]:
                 assert np.array_equal(base[i][c], got[i][c]), (i, c)
+        # staged ahead of their predict (what bench.py's h2d_preprocess leg does): same bits
+        staged = [feeder.stage(f) for f in pinned[:2]]
+        hs = [feeder.submit_staged(st, 0.05, slot=1 + k) for k, st in enumerate(staged)]
+        for k, hdl in enumerate(hs):
+            r = hdl.result()
+            for c in base[k]:
+                assert np.array_equal(base[k][c], r[c]), (k, c)
         host_f32 = img0.cpu().pin_memory()
         res = feeder.submit_preprocessed(host_f32, 0.05, slot=1).result()
         for c in base[0]:

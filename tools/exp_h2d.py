@@ -86,7 +86,7 @@ def main():
 
     # preprocess on the feeder stream but from device-resident frames (no H2D)
     def submit_dev(f, thr, slot):
-        st = feeder._stream(slot)
+        st = feeder._streams[slot % len(feeder._streams)]
         with torch.cuda.stream(st):
             img, _, _ = I.preprocess_image(f, params, 600, False)
             return model.predict_async(img.unsqueeze(0), thr, slot=slot)
