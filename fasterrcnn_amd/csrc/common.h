@@ -196,7 +196,7 @@ int launch_winograd_x3_gemm(const void* vrec, const float* vinv, const void* ubl
                             size_t gws_bytes, hipStream_t s);
 int launch_conv3x3_winograd_x3(const float* x, const void* ublob, const float* b, float* y, int N, int H, int W, int cin, int cout,
                                unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
-// wino_x3f.hip: EXPERIMENTAL one-launch form of the x3 Winograd layer (not used by any forward yet)
+// wino_x3f.hip: the one-launch form of the x3 Winograd layer (frcnn_forward_params.winograd_x3f_mask: conv2_2 .. conv3_3 of VGG-16)
 size_t conv3x3_winograd_x3_fused_workspace_bytes(int N, int H, int W);
 int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const float* b, float* y, int N, int H, int W, int cin, int cout,
                                      unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);

@@ -1,4 +1,4 @@
-"""tools/x3f_bench.py -- the experimental one-launch f32x3 Winograd layer (csrc/wino_x3f.hip) against the float32 one-launch layer
+"""tools/x3f_bench.py -- the one-launch f32x3 Winograd layer (csrc/wino_x3f.hip) against the float32 one-launch layer
 (csrc/winofused.hip) on the six VGG-16 layers the latter still owns."""
 import os
 import sys
