@@ -720,16 +720,16 @@ def main():
                     staged.append(feeder.stage(host_u8[(i + nslots) % len(host_u8)]))
             while pending:
                 pending.pop(0).result()
-        for key, fn in (("h2d_preprocess_images_per_sec", run_staged),
-                        ("h2d_preprocess_unstaged_images_per_sec", run_host(feeder.submit, host_u8)),
+        for key, fn in (("h2d_preprocess_images_per_sec", run_host(feeder.submit, host_u8)),
+                        ("h2d_preprocess_staged_images_per_sec", run_staged),
                         ("h2d_float32_images_per_sec", run_host(feeder.submit_preprocessed, host_f32))):
             fn(max(args.warmup, nslots))
             dt, _ = timed_median(fn, args.steps, min(args.min_timed_seconds, 0.5))
             h2d[key] = round(n_gpus * args.steps / dt, 3)
         h2d["h2d_note"] = ("the headline loop fed from PINNED HOST memory inside the timed region: h2d_preprocess = uint8 375x625 RGB frame -> async "
-                           "H2D (0.7 MB) -> frcnn_preprocess (PIL-exact resize to 600x1000 + normalisation on the device) -> predict, the frames staged "
-                           "as many images ahead as there are in flight (HostFeeder.stage / submit_staged; _unstaged = copy + resize on each image's "
-                           "own critical path); h2d_float32 = the "
+                           "H2D (0.7 MB) -> frcnn_preprocess (PIL-exact resize to 600x1000 + normalisation on the device) -> predict (HostFeeder.submit); "
+                           "_staged = the same with the frames staged as many images ahead as there are in flight (HostFeeder.stage / submit_staged: "
+                           "measured no better -- the copy + resize of one image already overlap the other images' convolutions); h2d_float32 = the "
                            "reference's literal `t.from_numpy(image).cuda()` of the preprocessed 3x600x1000 float32 tensor (7.2 MB) -> predict")
         del feeder, host_u8, host_f32
         run(nslots)

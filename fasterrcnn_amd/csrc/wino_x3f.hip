@@ -23,7 +23,7 @@ static constexpr int XF_PS = 20;                             // floats per halo 
 static constexpr int X3_HR = 10;                             // halo rows: 4 tile rows x 2 + 2
 static constexpr int X3_NPC = (X3_HR * XF_HC * 4 + 255) / 256;   // halo pieces (pixel, 4-channel quad) per thread: 6
 
-struct XfGeom { int tbx, tby, ncb, tw, th; };
+struct XfGeom { int tbx, tby, ncb, tw, th, xg; };
 
 // ---- the kernel: 64 tiles per block, the filter fragments straight from L2 into registers ------------------------------------------------------
 // What bounded round 3's versions was the L2 -> LDS staging of the filter records (64 KB per chunk and block by LDS-DMA: ~17 B per clock and CU).
@@ -70,8 +70,19 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     const int K16 = Cin >> 4;
 
     int b = blockIdx.x;
-    const int cb = b % gm.ncb;
-    b /= gm.ncb;
+    // Block -> XCD mapping (hardware block b runs on XCD b % 8, every XCD has its own 4 MB L2).  gm.xg != 0 (the number of tile blocks is a
+    // multiple of 8): the ncb output-channel blocks of one tile block run on the SAME XCD, back to back -- they share the input halo through
+    // that XCD's L2 instead of fetching it ncb times through the fabric (measured: fabric traffic 203 MB per launch against 72 MB algorithmic
+    // with the plain order, and 1-2 % of the launch time).  Otherwise: output-channel block fastest, round-robin over the XCDs.
+    int cb;
+    if (gm.xg) {
+        const int xcd = b & 7, q = b >> 3;
+        cb = q % gm.ncb;
+        b = (q / gm.ncb) * 8 + xcd;
+    } else {
+        cb = b % gm.ncb;
+        b /= gm.ncb;
+    }
     const int bx = b % gm.tbx;
     b /= gm.tbx;
     const int by = b % gm.tby;                                               // blocks of FOUR tile rows
@@ -457,6 +468,7 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     gm.ncb = cout / 64;
     const long long total = (long long)gm.tbx * gm.tby * gm.ncb * N;
     if (total > 0x7fffffffLL) return FRCNN_EINVAL;
+    gm.xg = ((long long)gm.tbx * gm.tby * N) % 8 == 0 ? 1 : 0;
     const int u_rbt = cdiv(cout, gemm_x6t_col_tile(cout)) * gemm_x6t_col_tile(cout) / 32;
     if ((size_t)16 * (cin / 16) * u_rbt * HX_RB >= ((size_t)1 << 31)) return FRCNN_EUNSUPPORTED;   // the record bank behind one buffer descriptor
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;

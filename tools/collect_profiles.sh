@@ -3,13 +3,15 @@
 # 1. the default bench line; 2. rocprofv3 kernel trace + stats of a bench run; 3. PMC passes
 # (counters in their own runs, kernel-trace only, as the pool requires).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-secondary --no-extra-legs"
 timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench exit $?"
 tail -c 2500 $OUT/bench_default.json
+# the driver's form of the same command (BENCH_rNN.json): --steps 20 --warmup 5
+timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_form.json 2> $OUT/bench_driver_form.err; echo "driver-form bench exit $?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/trace.log 2>&1; echo "trace exit $?"
 P="python bench.py --steps 12 --warmup 4 --ramp-seconds 0 --no-cpu-baseline --no-secondary --no-extra-legs --inflight 1 --roofline-images 2 --map-images 0 --min-timed-seconds 0"
 # single-stream kernel durations (what bench.py's roofline block times with HIP events): kernel trace + stats, no counters
@@ -29,6 +31,9 @@ RP="$R --steps 8 --warmup 2 --ramp-seconds 0 --inflight 1 --min-timed-seconds 0"
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_r50_mfma -o p -- $RP > $OUT/pmc_r50_mfma.log 2>&1; echo "pmc r50 mfma exit $?"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_r50_fetch -o p -- $RP > $OUT/pmc_r50_fetch.log 2>&1; echo "pmc r50 fetch exit $?"
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_r50_write -o p -- $RP > $OUT/pmc_r50_write.log 2>&1; echo "pmc r50 write exit $?"
+# held-out parity sweep of the default tables (tests/test_holdout_gpu.py measures the same): per-case numbers for profiles/
+for A in VGG16 ResNet50 ResNet101; do timeout 600 python tools/holdout_report.py --arch $A --tables default --out $OUT/holdout_$A.json > $OUT/holdout_$A.log 2>&1; echo "holdout $A exit $?"; done
+grep "^==" $OUT/holdout_*.log
 # train step: wall time per step + per-kernel stats
 timeout 600 python tools/train_bench.py --steps 20 --warmup 3 > $OUT/train_bench.json 2> $OUT/train_bench.err; echo "train bench exit $?"; cat $OUT/train_bench.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -o t -- python tools/train_bench.py --steps 8 --warmup 2 > $OUT/trace_train.log 2>&1; echo "train trace exit $?"

@@ -43,7 +43,7 @@ def main(d):
         for r in sstats[:20]:
             print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                      float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
-        for fam in ("wino_fused_kernel", "gemm_x6t_kernel", "gemm_x3t_kernel", "wino_input_x6t_kernel", "wino_input_x3t_kernel", "wino_output_kernel", "linear_x6_kernel", "linear_mfma_kernel",
+        for fam in ("wino_x3d_kernel", "wino_fused_kernel", "gemm_x6t_kernel", "gemm_x3t_kernel", "wino_input_x6t_kernel", "wino_input_x3t_kernel", "wino_output_kernel", "linear_x6_kernel", "linear_mfma_kernel",
                     "conv3x3_mfma_kernel"):
             f_ns = sum(float(r["TotalDurationNs"]) for r in sstats if fam in r["Name"])
             f_calls = sum(int(r["Calls"]) for r in sstats if fam in r["Name"])
@@ -132,7 +132,8 @@ def traffic(d):
     `hbm_bytes_per_launch` = conv3x3_mfma_kernel (all instantiations), `by_kernel` = the same figure per kernel family.
     """
     import json
-    families = (("wino_fused_kernel", lambda n: "wino_fused_kernel" in n),
+    families = (("wino_x3d_kernel", lambda n: "wino_x3d_kernel" in n),
+                ("wino_fused_kernel", lambda n: "wino_fused_kernel" in n),
                 ("gemm_x6t_kernel", lambda n: "gemm_x6t_kernel" in n),
                 ("gemm_x3t_kernel", lambda n: "gemm_x3t_kernel" in n),
                 ("wino_input_x6t_kernel", lambda n: "wino_input_x6t_kernel" in n),
@@ -164,7 +165,7 @@ def traffic(d):
         f, w = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
         by[fam] = {"launches": vals["FETCH_SIZE"][1], "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
                    "hbm_bytes_per_launch": f * 1024 * 2.0 + w * 1024}
-    head = "wino_fused_kernel" if "wino_fused_kernel" in by else ("conv3x3_mfma_kernel" if "conv3x3_mfma_kernel" in by else None)
+    head = "wino_x3d_kernel" if "wino_x3d_kernel" in by else "wino_fused_kernel" if "wino_fused_kernel" in by else ("conv3x3_mfma_kernel" if "conv3x3_mfma_kernel" in by else None)
     if head is None:
         return
     c = by[head]
