@@ -9,7 +9,7 @@
 //
 // Block = 4 waves = 64 tiles (4 tile rows x 16) x 64 output channels x all 16 positions; wave w owns position row i = w (positions
 // 4 w .. 4 w + 3) of every tile: 16 accumulator tiles of 32 x 32 = 256 accumulator registers, one block per CU.  History (rounds 3-4,
-// DESIGN.md section 7.1): versions 1-3 staged the filter records through LDS by LDS-DMA and were bound by that staging (conv3_2: 208-232 us
+// DESIGN.md section 5): versions 1-3 staged the filter records through LDS by LDS-DMA and were bound by that staging (conv3_2: 208-232 us
 // against the float32 kernel's 174); version 4 below loads them straight into registers (conv3_2: 119 us).
 #include "x3t.h"
 
@@ -34,7 +34,7 @@ struct XfGeom { int tbx, tby, ncb, tw, th, xg; };
 // operand of step (h, j + 1).  Measured with the shader clock inside the kernel (tools/xd_clocks.py, ablation builds XD_ABLATE): 3100-3400
 // cycles per chunk against the 1536 of its 48 MFMAs -- the MFMA stream alone runs at 1620, the operand-forming vector instructions add
 // ~770 (they do not overlap: one wave per SIMD issues in order), the halo traffic ~400, the filter loads ~200; before the loop 3.8 us,
-// after it 5.5 us per block (DESIGN.md section 7.1).
+// after it 5.5 us per block (DESIGN.md section 5).
 typedef float xd_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 xd_f16x2 __attribute__((ext_vector_type(2)));
 
