@@ -46,7 +46,7 @@ SYMBOLS = (
     "frcnn_pixel_absmax", "frcnn_split_pixels_x3t", "frcnn_split_patches3x3_x3t",
     "frcnn_x3t_blob_bytes", "frcnn_pack_rows_x3t", "frcnn_conv3x3_winograd_x3_pack_bytes", "frcnn_pack_conv3x3_winograd_x3",
     "frcnn_conv3x3_winograd_x3_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x3",
-    "frcnn_conv3x3_winograd_x3_fused_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x3_fused",
+    "frcnn_conv3x3_winograd_x3_fused_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x3_fused", "frcnn_conv3x3_nhwc_winograd_x3_chain",
     "frcnn_x3t_record_bytes", "frcnn_rows_scale_x3t", "frcnn_split_rows_x3t", "frcnn_gemm_x3t_workspace_bytes", "frcnn_gemm_x3t",
     "frcnn_conv3x3_nhwc_winograd_fused_maps", "frcnn_ctx_create_backbone", "frcnn_resnet_backbone", "frcnn_resnet_forward_features",
     # training path
@@ -269,6 +269,7 @@ _SIGNATURES = {
     "frcnn_conv3x3_nhwc_winograd_x3": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_conv3x3_winograd_x3_fused_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "frcnn_conv3x3_nhwc_winograd_x3_fused": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_conv3x3_nhwc_winograd_x3_chain": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _i, _vp, _sz, _vp, _vp, _vp]),
     "frcnn_x3t_record_bytes": (C.c_size_t, [_i, _i]),
     "frcnn_rows_scale_x3t": (C.c_int, [_vp, _i, _sz, _vp, _i, _i, _i, _i, _vp]),
     "frcnn_split_rows_x3t": (C.c_int, [_vp, _i, _sz, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -397,6 +397,18 @@ int frcnn_conv3x3_nhwc_winograd_x3(const float* d_x, const void* d_blob, const f
     return launch_conv3x3_winograd_x3(d_x, d_blob, d_bias, d_y, n_maps, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
 }
 
+int frcnn_conv3x3_nhwc_winograd_x3_chain(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W, int cin,
+                                         int cout, unsigned flags, int one_launch, void* d_ws, size_t ws_bytes, const float* d_cmax_in,
+                                         float* d_cmax_out, void* stream)
+{
+    if (!d_x || !d_blob || !d_bias || !d_y) return FRCNN_EINVAL;
+    if (one_launch)
+        return launch_conv3x3_winograd_x3_fused(d_x, d_blob, d_bias, d_y, n_maps, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream),
+                                                d_cmax_in, d_cmax_out);
+    return launch_conv3x3_winograd_x3(d_x, d_blob, d_bias, d_y, n_maps, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream), d_cmax_in,
+                                      d_cmax_out);
+}
+
 int frcnn_split_pixels_x6t(const float* d_x, void* d_rec, int N, int H, int W, int C, int stride, int rows_padded, void* stream)
 {
     if (!d_x || !d_rec) return FRCNN_EINVAL;
@@ -1028,8 +1040,10 @@ int run_wino_x6_layer(frcnn_ctx* c, const float* x, const void* urec, const floa
 
 // The same layer in the f32x3 arithmetic (csrc/wino_x3.hip; a bit of frcnn_forward_params.winograd_x3_mask): ublob = the packed
 // x3t filter bank (records + row scales).  Same timing classes.
+// cmax_ready: the channel maxima of x, left behind by the producing layer's epilogue (skips the pass over x); cmax_out: where this layer's
+// output transform accumulates the channel maxima of y (zeroed by the caller; needs winograd_output_emits_cmax(co, flags)).
 int run_wino_x3_layer(frcnn_ctx* c, const float* x, const void* ublob, const float* b, float* y, int h, int w, int ci, int co,
-                      unsigned flags, hipStream_t s, int N = 1)
+                      unsigned flags, hipStream_t s, int N = 1, const float* cmax_ready = nullptr, float* cmax_out = nullptr)
 {
     if (N == 1 && !conv3x3_uses_winograd_x6(ci, co)) return FRCNN_EINVAL;
     int r = ensure_wx_ws(c, conv3x3_winograd_x3_workspace_bytes(N, h, w, ci, co), s);
@@ -1039,29 +1053,37 @@ int run_wino_x3_layer(frcnn_ctx* c, const float* x, const void* ublob, const flo
     size_t gb = 0;
     r = winograd_x3_plan(N, h, w, ci, co, flags, c->wx_ws, c->wx_ws_bytes, &V, &vinv, &cmax, &M, &G, &gb);
     if (r) return r;
-    { Scope _t(c, 8, s); r = launch_winograd_x3_input(x, cmax, V, vinv, N, h, w, ci, s); }
+    { Scope _t(c, 8, s); r = launch_winograd_x3_input(x, cmax, V, vinv, N, h, w, ci, s, cmax_ready); }
     if (r) return r;
     { Scope _g(c, 9, s); r = launch_winograd_x3_gemm(V, vinv, ublob, M, N, h, w, ci, co, G, gb, s); }
     if (r) return r;
     Scope _o(c, 8, s);
-    return launch_winograd_output(M, b, y, N, h, w, co, flags, s);
+    return launch_winograd_output(M, b, y, N, h, w, co, flags, s, cmax_out);
 }
+
+// The three channel-maximum buffers of a ctx (max_h x max_w floats each): [0] scratch of a layer that has to compute its input's maxima
+// itself, [1] / [2] the ping-pong pair the f32x3 layers hand the maxima of their OUTPUT to the next layer in.
+int ensure_x3f_cmax(frcnn_ctx* c, size_t need, hipStream_t s)
+{
+    if (c->x3f_cmax && c->x3f_cmax_bytes >= need) return FRCNN_OK;
+    if (c->x3f_cmax) { FRCNN_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(c->x3f_cmax); c->x3f_cmax = nullptr; c->x3f_cmax_bytes = 0; }
+    const size_t cap = std::max(need, (size_t)c->max_h * c->max_w * sizeof(float));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->x3f_cmax), 3 * cap);
+    if (e != hipSuccess) { set_hip_error(e); c->x3f_cmax = nullptr; return FRCNN_ENOMEM; }
+    c->x3f_cmax_bytes = cap;
+    return FRCNN_OK;
+}
+float* x3f_cmax_buffer(frcnn_ctx* c, int which) { return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(c->x3f_cmax) + (size_t)which * c->x3f_cmax_bytes); }
 
 // A ONE-LAUNCH f32x3 Winograd layer inside a fused forward (csrc/wino_x3f.hip; a bit of frcnn_forward_params.winograd_x3f_mask; timing class 10,
 // which includes the channel-maximum pass over the layer input).  ublob = frcnn_pack_conv3x3_winograd_x3's blob.
 int run_wino_x3f_layer(frcnn_ctx* c, const float* x, const void* ublob, const float* b, float* y, int h, int w, int ci, int co,
-                       unsigned flags, hipStream_t s)
+                       unsigned flags, hipStream_t s, const float* cmax_ready = nullptr, float* cmax_out = nullptr)
 {
-    const size_t need = conv3x3_winograd_x3_fused_workspace_bytes(1, h, w);
-    if (!c->x3f_cmax || c->x3f_cmax_bytes < need) {
-        if (c->x3f_cmax) { FRCNN_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(c->x3f_cmax); c->x3f_cmax = nullptr; c->x3f_cmax_bytes = 0; }
-        const size_t cap = std::max(need, (size_t)c->max_h * c->max_w * sizeof(float));
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->x3f_cmax), cap);
-        if (e != hipSuccess) { set_hip_error(e); c->x3f_cmax = nullptr; return FRCNN_ENOMEM; }
-        c->x3f_cmax_bytes = cap;
-    }
+    int r = ensure_x3f_cmax(c, conv3x3_winograd_x3_fused_workspace_bytes(1, h, w), s);
+    if (r) return r;
     Scope _w(c, 10, s);
-    return launch_conv3x3_winograd_x3_fused(x, ublob, b, y, 1, h, w, ci, co, flags, c->x3f_cmax, c->x3f_cmax_bytes, s);
+    return launch_conv3x3_winograd_x3_fused(x, ublob, b, y, 1, h, w, ci, co, flags, x3f_cmax_buffer(c, 0), c->x3f_cmax_bytes, s, cmax_ready, cmax_out);
 }
 
 // One one-launch Winograd layer inside a fused forward (timed as class 7).
@@ -1114,14 +1136,39 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     if (p->winograd_x6_mask != 0 && (!wino || (p->winograd_x6_mask & ~0x3FFE) != 0)) return FRCNN_EINVAL;
     if (p->winograd_x3f_mask != 0 && (!wino || (p->winograd_x3f_mask & ~0x1FFE) != 0 || (p->winograd_x3f_mask & p->winograd_x6_mask) != 0)) return FRCNN_EINVAL;
     int layer_index = 0;        // 1 .. 12 = conv_w[i], 13 = the RPN trunk (frcnn_forward_params.winograd_x6_mask)
+    const float* cmax_ready = nullptr;     // channel maxima of the activation tensor produced last, if its producer emitted them
+    int cmax_flip = 0;
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
         ++layer_index;
-        if (wino && ((p->winograd_x3f_mask >> layer_index) & 1))  // one-launch f32x3 Winograd layer: wgt = the x3 blob (csrc/wino_x3f.hip)
-            return run_wino_x3f_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
-        if (wino && ((p->winograd_x6_mask >> layer_index) & 1))  // x6 / x3 Winograd layer: wgt = the record bank (csrc/wino_x6.hip, wino_x3.hip)
-            return ((p->winograd_x3_mask >> layer_index) & 1) ? run_wino_x3_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s)
-                                                              : run_wino_x6_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
+        // The f32x3 layers take their scales from the per-pixel channel maximum of their INPUT.  A layer whose producer was an f32x3 layer finds
+        // those maxima ready (`cmax_ready`: the producer's epilogue accumulated them with atomic maxima) instead of reading the tensor once more
+        // (pixel_absmax_kernel: 11 of the 12 passes of an image); the same values, so the same bits.  The RPN trunk's output feeds no such layer.
+        const float* in_cmax = cmax_ready;
+        cmax_ready = nullptr;
+        const bool is_x3f = wino && ((p->winograd_x3f_mask >> layer_index) & 1);
+        const bool is_x3 = wino && !is_x3f && ((p->winograd_x6_mask >> layer_index) & 1) && ((p->winograd_x3_mask >> layer_index) & 1);
+        float* out_cmax = nullptr;
+        if ((is_x3f || is_x3) && layer_index != FRCNN_X6_RPN_TRUNK_BIT && (fl & FRCNN_RELU) && (is_x3f || winograd_output_emits_cmax(co, fl))) {
+            const int oh = (fl & FRCNN_POOL2) ? hh / 2 : hh, ow = (fl & FRCNN_POOL2) ? ww / 2 : ww;
+            int r0 = ensure_x3f_cmax(c, (size_t)hh * ww * sizeof(float), s);
+            if (r0) return r0;
+            out_cmax = x3f_cmax_buffer(c, 1 + (cmax_flip ^= 1));
+            FRCNN_HIP_TRY(hipMemsetAsync(out_cmax, 0, (size_t)oh * ow * sizeof(float), s));
+        }
+        int r1;
+        if (is_x3f)                                                  // one-launch f32x3 Winograd layer: wgt = the x3 blob (csrc/wino_x3f.hip)
+            r1 = run_wino_x3f_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s, in_cmax, out_cmax);
+        else if (is_x3)                                              // three-launch f32x3 layer: wgt = the x3 blob (csrc/wino_x3.hip)
+            r1 = run_wino_x3_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s, 1, in_cmax, out_cmax);
+        else if (wino && ((p->winograd_x6_mask >> layer_index) & 1)) // x6 Winograd layer: wgt = the record bank (csrc/wino_x6.hip)
+            r1 = run_wino_x6_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
+        else
+            r1 = -9999;
+        if (r1 != -9999) {
+            if (r1 == FRCNN_OK) cmax_ready = out_cmax;
+            return r1;
+        }
         if (wino && conv3x3_uses_winograd_fused(ci, co)) {     // one launch, no scratch (csrc/winofused.hip); timed as class 7
             return run_wino_fused_layer(c, p->conv_blocks_target == 0, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
         }
@@ -1148,6 +1195,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     CONV(conv3(B, w->conv_w[10], w->conv_b[10], A, h, wd, 512, 512, R));
     CONV(conv3(A, w->conv_w[11], w->conv_b[11], B, h, wd, 512, 512, R));
     CONV(conv3(B, w->conv_w[12], w->conv_b[12], c->fm, h, wd, 512, 512, R));
+    const float* fm_cmax_ready = cmax_ready;            // the feature map's channel maxima, if conv5_3 left them (the RoI pooling's scale source)
     const int fh = h, fw = wd;
     c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms; c->last_c = 512; c->last_vec = 4096;
 
@@ -1188,7 +1236,8 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
             STEP(2, launch_rows_scale_x3t(c->roi_out, 49 * 512, 0, c->roi_inv, R_, rr, 49 * 512, 1, s));
             STEP(2, launch_split_rows_x3t(c->roi_out, 49 * 512, 0, c->roi_inv, c->roi_rec, R_, rr, 49 * 512, 1, s));
         } else {
-            STEP(4, launch_roi_pool_x3t(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->fm_cmax, c->roi_inv, c->roi_rec, rr, s));
+            STEP(4, launch_roi_pool_x3t(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f,
+                                        fm_cmax_ready ? const_cast<float*>(fm_cmax_ready) : c->fm_cmax, c->roi_inv, c->roi_rec, rr, s, fm_cmax_ready != nullptr));
         }
         // (tile mode 0 = the cost model's choice in every slot: the in-flight tile override of the Winograd layers would change fc's split-K
         //  factor, and an image must give the same bits in flight and alone)

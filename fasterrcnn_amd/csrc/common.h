@@ -134,7 +134,11 @@ int launch_conv3x3_winograd(const float* x, const float* u, const float* b, floa
 int winograd_plan(int N, int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, float** V, float** M);
 int launch_winograd_input(const float* x, float* V, int N, int H, int W, int cin, hipStream_t s);
 int launch_winograd_gemm(const float* V, const float* u, float* M, int N, int H, int W, int cin, int cout, hipStream_t s);
-int launch_winograd_output(const float* M, const float* b, float* y, int N, int H, int W, int cout, unsigned flags, hipStream_t s);
+// cmax_out (optional, cout % 256 == 0 and ReLU): the per-pixel channel maximum of the OUTPUT, accumulated with atomic maxima into a buffer the
+// caller zeroed -- the next f32x3 layer's scale source, so that it need not read the tensor again (launch_pixel_absmax)
+int launch_winograd_output(const float* M, const float* b, float* y, int N, int H, int W, int cout, unsigned flags, hipStream_t s,
+                           float* cmax_out = nullptr);
+bool winograd_output_emits_cmax(int cout, unsigned flags);
 // winofused.hip: the same layer for one map as ONE launch (all 16 positions in accumulators, no V / M scratch)
 static inline bool conv3x3_uses_winograd_fused(int cin, int cout) { return cin >= 64 && cin % 16 == 0 && cout >= 64 && cout % 64 == 0; }
 // ResNet bottleneck 3x3 (width -> width) on ONE map (the feature extractor's layer1..3 at inference): every stride-1 block;
@@ -191,17 +195,20 @@ int launch_pack_conv3x3_winograd_x3(const float* u_f32, void* ublob, int cout, i
 size_t conv3x3_winograd_x3_workspace_bytes(int N, int H, int W, int cin, int cout);
 int winograd_x3_plan(int N, int H, int W, int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, void** V, float** vinv, float** cmax,
                      float** M, void** G, size_t* g_bytes);
-int launch_winograd_x3_input(const float* x, float* cmax, void* vrec, float* vinv, int N, int H, int W, int cin, hipStream_t s);
+int launch_winograd_x3_input(const float* x, float* cmax, void* vrec, float* vinv, int N, int H, int W, int cin, hipStream_t s,
+                             const float* cmax_ready = nullptr);   // cmax_ready: the channel maxima of x are already there (skips the pass)
 int launch_winograd_x3_gemm(const void* vrec, const float* vinv, const void* ublob, float* M, int N, int H, int W, int cin, int cout, void* gws,
                             size_t gws_bytes, hipStream_t s);
 int launch_conv3x3_winograd_x3(const float* x, const void* ublob, const float* b, float* y, int N, int H, int W, int cin, int cout,
-                               unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
+                               unsigned flags, void* ws, size_t ws_bytes, hipStream_t s,
+                               const float* cmax_ready = nullptr, float* cmax_out = nullptr);
 // wino_x3f.hip: the one-launch form of the x3 Winograd layer (frcnn_forward_params.winograd_x3f_mask: conv2_2 .. conv3_3 of VGG-16)
 size_t conv3x3_winograd_x3_fused_workspace_bytes(int N, int H, int W);
 int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const float* b, float* y, int N, int H, int W, int cin, int cout,
-                                     unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
+                                     unsigned flags, void* ws, size_t ws_bytes, hipStream_t s, const float* cmax_ready = nullptr,
+                                     float* cmax_out = nullptr);   // cmax_ready / cmax_out: as above (cmax_out needs ReLU; zeroed by the caller)
 int launch_roi_pool_x3t(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois, int max_rois, int pooled,
-                        float scale, float* cmax, float* inv, void* rec, int rec_rows, hipStream_t s);
+                        float scale, float* cmax, float* inv, void* rec, int rec_rows, hipStream_t s, bool cmax_ready = false);
 // wino_x6.hip: Winograd F(2x2,3x3) layers whose position GEMMs run on gemm_x6t
 bool conv3x3_uses_winograd_x6(int cin, int cout);
 size_t conv3x3_winograd_x6_pack_bytes(int cout, int cin);

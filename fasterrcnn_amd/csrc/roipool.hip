@@ -341,11 +341,11 @@ int launch_roi_pool_x6t(const float* fm, int fh, int fw, int c, const float* roi
 
 // RoI pooling into x3t records + the per-RoI scales (csrc/gemm_x3t.hip).  cmax: fh * fw floats of scratch; inv: rec_rows floats.
 int launch_roi_pool_x3t(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois, int max_rois, int pooled,
-                        float scale, float* cmax, float* inv, void* rec, int rec_rows, hipStream_t s)
+                        float scale, float* cmax, float* inv, void* rec, int rec_rows, hipStream_t s, bool cmax_ready)
 {
     if (fh < 1 || fw < 1 || c < 16 || c % 16 != 0 || max_rois < 1 || pooled < 1 || rec_rows < max_rois || rec_rows % 32 != 0 || !cmax || !inv)
         return FRCNN_EINVAL;
-    int rc = launch_pixel_absmax(fm, cmax, (long long)fh * fw, c, s);
+    int rc = cmax_ready ? FRCNN_OK : launch_pixel_absmax(fm, cmax, (long long)fh * fw, c, s);      // (ready: conv5_3's epilogue wrote them)
     if (rc) return rc;
     hipLaunchKernelGGL(roi_scale_x3t_kernel, dim3(cdiv(rec_rows, 4)), dim3(256), 0, s, cmax, fh, fw, rois, n_rois, max_rois, rec_rows, pooled, scale, inv);
     if ((rc = check_launch()) != FRCNN_OK) return rc;

@@ -198,10 +198,14 @@ int launch_pixel_absmax(const float* x, float* cmax, long long pixels, int C, hi
     return check_launch();
 }
 
-int launch_winograd_x3_input(const float* x, float* cmax, void* vrec, float* vinv, int N, int H, int W, int cin, hipStream_t s)
+int launch_winograd_x3_input(const float* x, float* cmax, void* vrec, float* vinv, int N, int H, int W, int cin, hipStream_t s, const float* cmax_ready)
 {
-    int rc = launch_pixel_absmax(x, cmax, (long long)N * H * W, cin, s);
-    if (rc) return rc;
+    if (cmax_ready) {
+        cmax = const_cast<float*>(cmax_ready);            // the producing layer's epilogue left the channel maxima behind
+    } else {
+        int rc = launch_pixel_absmax(x, cmax, (long long)N * H * W, cin, s);
+        if (rc) return rc;
+    }
     const int tw = cdiv(W, 2), tpi = cdiv(H, 2) * tw, T = N * tpi, rbt = wh_tiles_padded(T) / 32, K16 = cin / 16;
     const long long waves = (long long)rbt * K16;
     if (waves > 0x7fffffffLL) return FRCNN_EINVAL;
@@ -221,16 +225,16 @@ int launch_winograd_x3_gemm(const void* vrec, const float* vinv, const void* ubl
 }
 
 int launch_conv3x3_winograd_x3(const float* x, const void* ublob, const float* b, float* y, int N, int H, int W, int cin, int cout,
-                               unsigned flags, void* ws, size_t ws_bytes, hipStream_t s)
+                               unsigned flags, void* ws, size_t ws_bytes, hipStream_t s, const float* cmax_ready, float* cmax_out)
 {
     void *V = nullptr, *G = nullptr;
     float *M = nullptr, *vinv = nullptr, *cmax = nullptr;
     size_t gb = 0;
     int rc = winograd_x3_plan(N, H, W, cin, cout, flags, ws, ws_bytes, &V, &vinv, &cmax, &M, &G, &gb);
     if (rc) return rc;
-    if ((rc = launch_winograd_x3_input(x, cmax, V, vinv, N, H, W, cin, s)) != FRCNN_OK) return rc;
+    if ((rc = launch_winograd_x3_input(x, cmax, V, vinv, N, H, W, cin, s, cmax_ready)) != FRCNN_OK) return rc;
     if ((rc = launch_winograd_x3_gemm(V, vinv, ublob, M, N, H, W, cin, cout, G, gb, s)) != FRCNN_OK) return rc;
-    return launch_winograd_output(M, b, y, N, H, W, cout, flags, s);
+    return launch_winograd_output(M, b, y, N, H, W, cout, flags, s, cmax_out);
 }
 
 }  // namespace frcnn

@@ -56,7 +56,7 @@ template <bool POOL>
 __global__ __launch_bounds__(256, 1)
 void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__ cmax_maps, const unsigned char* __restrict__ ublob,
                      const float* __restrict__ bias, float* __restrict__ y_maps, int H, int W, int Cin, int Cout, int u_rbt, int relu,
-                     XfGeom gm)
+                     XfGeom gm, float* __restrict__ cmax_out_maps)
 {
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_in = __builtin_amdgcn_s_memrealtime();
@@ -90,6 +90,9 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     const float* __restrict__ const x = x_maps + (size_t)map * H * W * Cin;
     const float* __restrict__ const cmax = cmax_maps + (size_t)map * H * W;
     float* __restrict__ const y = y_maps + (size_t)map * (POOL ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) * Cout;
+    // optional: the per-pixel channel maximum of the OUTPUT (atomic maxima into a buffer the caller zeroed; outputs are post-ReLU, and
+    // non-negative floats order like their bit patterns) -- the next f32x3 layer's scale source
+    float* __restrict__ const cmax_out = cmax_out_maps ? cmax_out_maps + (size_t)map * (POOL ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) : nullptr;
 
     // Buffer loads: a piece outside the image carries an offset past the descriptor's size and the hardware returns zeros for it (the
     // "same" padding and the channel maxima of absent pixels cost no branch)
@@ -393,8 +396,8 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         const int t = item >> 4, k = (item & 15) * 4;
         const int h = t >> 5, tt_ = t & 31;
         const int oty = 4 * by + 2 * h + (tt_ >> 4), otx = XF_TC * bx + (tt_ & 15);
-        if (oty >= gm.th || otx >= gm.tw) continue;
-        if (POOL && (oty >= Ho || otx >= Wo)) continue;
+        const bool live = oty < gm.th && otx < gm.tw && !(POOL && (oty >= Ho || otx >= Wo));
+        if (!live && !cmax_out) continue;
         const int kg = 64 * cb + k;
         const float* yp = ybuf + ((h * 4) * 2 * 32 + tt_) * XD_MS + k;      // + (i 2 + b) 32 XD_MS
         f32x4 Y[4][2];
@@ -417,20 +420,33 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[a][bb][e] = fmaxf(o[a][bb][e], 0.f);
         }
+        // (the 16 lanes of a tile's 64 channels reduce their maxima with four shuffles; one atomic per pixel and block)
         if (POOL) {
             f32x4 mx;
 #pragma unroll
             for (int e = 0; e < 4; ++e) mx[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
-            *reinterpret_cast<f32x4*>(y + ((size_t)oty * Wo + otx) * Cout + kg) = mx;
+            if (live) *reinterpret_cast<f32x4*>(y + ((size_t)oty * Wo + otx) * Cout + kg) = mx;
+            if (cmax_out) {
+                float pm = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off));
+                if (live && (item & 15) == 0) atomicMax(reinterpret_cast<unsigned*>(cmax_out + (size_t)oty * Wo + otx), __float_as_uint(pm));
+            }
         } else {
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int yy = 2 * oty + a;
-                if (yy >= H) continue;
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb) {
                     const int xx = 2 * otx + bb;
-                    if (xx < W) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * Cout + kg) = o[a][bb];
+                    const bool ok = live && yy < H && xx < W;
+                    if (ok) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * Cout + kg) = o[a][bb];
+                    if (cmax_out) {
+                        float pm = fmaxf(fmaxf(o[a][bb][0], o[a][bb][1]), fmaxf(o[a][bb][2], o[a][bb][3]));
+#pragma unroll
+                        for (int off = 8; off >= 1; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off));
+                        if (ok && (item & 15) == 0) atomicMax(reinterpret_cast<unsigned*>(cmax_out + (size_t)yy * W + xx), __float_as_uint(pm));
+                    }
                 }
             }
         }
@@ -452,16 +468,20 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 size_t conv3x3_winograd_x3_fused_workspace_bytes(int N, int H, int W) { return (size_t)N * H * W * sizeof(float); }
 
 int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const float* b, float* y, int N, int H, int W, int cin, int cout,
-                                     unsigned flags, void* ws, size_t ws_bytes, hipStream_t s)
+                                     unsigned flags, void* ws, size_t ws_bytes, hipStream_t s, const float* cmax_ready, float* cmax_out)
 {
     // the kernel walks the 16-channel chunks in pairs: cin % 32 == 0 (other widths: the three-launch layer, csrc/wino_x3.hip)
     if (N < 1 || H < 1 || W < 1 || cin < 32 || cin % 32 != 0 || cout < 64 || cout % 64 != 0) return FRCNN_EUNSUPPORTED;
     if ((size_t)H * W * cin >= ((size_t)1 << 29)) return FRCNN_EUNSUPPORTED;          // 32-bit byte offsets inside one map
     if ((flags & FRCNN_POOL2) && (H < 2 || W < 2)) return FRCNN_EINVAL;
-    if (!ws || ws_bytes < conv3x3_winograd_x3_fused_workspace_bytes(N, H, W)) return FRCNN_EINVAL;
-    float* cmax = static_cast<float*>(ws);
-    int rc = launch_pixel_absmax(x, cmax, (long long)N * H * W, cin, s);
-    if (rc) return rc;
+    if (!cmax_ready && (!ws || ws_bytes < conv3x3_winograd_x3_fused_workspace_bytes(N, H, W))) return FRCNN_EINVAL;
+    if (cmax_out && !(flags & FRCNN_RELU)) return FRCNN_EINVAL;          // the emitted maxima are those of non-negative outputs
+    const float* cmax = cmax_ready;
+    if (!cmax) {                                                          // nobody left the input's channel maxima behind: one pass over x
+        int rc = launch_pixel_absmax(x, static_cast<float*>(ws), (long long)N * H * W, cin, s);
+        if (rc) return rc;
+        cmax = static_cast<const float*>(ws);
+    }
     XfGeom gm;
     gm.tw = cdiv(W, 2); gm.th = cdiv(H, 2);
     gm.tbx = cdiv(gm.tw, XF_TC); gm.tby = cdiv(gm.th, 4);
@@ -476,11 +496,11 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     if (flags & FRCNN_POOL2) {
         auto kern = wino_x3d_kernel<true>;
         FRCNN_MAX_LDS_ONCE(kern, XD_LDS_BYTES);
-        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm);
+        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm, cmax_out);
     } else {
         auto kern = wino_x3d_kernel<false>;
         FRCNN_MAX_LDS_ONCE(kern, XD_LDS_BYTES);
-        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm);
+        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm, cmax_out);
     }
     return check_launch();
 }

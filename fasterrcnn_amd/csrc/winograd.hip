@@ -140,61 +140,82 @@ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ v, int H
 }
 
 // One thread = one tile x 4 output channels.  A^T = [[1,1,1,0],[0,1,-1,-1]].
+// cmax_out (optional; the launcher guarantees cout % 256 == 0 and ReLU): a wave covers 256 consecutive channels of ONE tile, so the
+// per-pixel channel maximum of the output is a wave reduction + one atomic maximum per pixel and wave (non-negative floats order like
+// their bit patterns) -- what the next f32x3 layer would otherwise read the whole tensor again for (launch_pixel_absmax).
 template <bool POOL>
 __global__ __launch_bounds__(256)
 void wino_output_kernel(const float* __restrict__ m, const float* __restrict__ bias, float* __restrict__ y,
-                        int H, int W, int cout, int tw, int tpi, int T, int relu)
+                        int H, int W, int cout, int tw, int tpi, int T, int relu, float* __restrict__ cmax_out)
 {
     const int k4n = cout >> 2;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)T * k4n) return;
-    const int tile = (int)(idx / k4n), k = (int)(idx % k4n) * 4;
+    const bool in_range = idx < (size_t)T * k4n;
+    if (!in_range && cmax_out == nullptr) return;
+    const int tile = in_range ? (int)(idx / k4n) : 0, k = in_range ? (int)(idx % k4n) * 4 : 0;
     const int img = tile / tpi, tin = tile - img * tpi;
     const int ty = tin / tw, tx = tin % tw;
     const int Ho = H >> 1, Wo = W >> 1;
-    if (POOL && (ty >= Ho || tx >= Wo)) return;      // floor pooling drops the odd last row / column
-    y += (size_t)img * (POOL ? (size_t)Ho * Wo : (size_t)H * W) * cout;
-    const size_t plane = (size_t)T * cout;
-    const float* mp = m + (size_t)tile * cout + k;
-    f32x4 s[2][4];                           // A^T M
+    const bool live = in_range && !(POOL && (ty >= Ho || tx >= Wo));      // floor pooling drops the odd last row / column
+    if (!live && cmax_out == nullptr) return;
+    f32x4 o[2][2] = {};
+    if (live) {
+        const size_t plane = (size_t)T * cout;
+        const float* mp = m + (size_t)tile * cout + k;
+        f32x4 s[2][4];                           // A^T M
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x4 m0 = *reinterpret_cast<const f32x4*>(mp + (size_t)(0 + j) * plane);
-        const f32x4 m1 = *reinterpret_cast<const f32x4*>(mp + (size_t)(4 + j) * plane);
-        const f32x4 m2 = *reinterpret_cast<const f32x4*>(mp + (size_t)(8 + j) * plane);
-        const f32x4 m3 = *reinterpret_cast<const f32x4*>(mp + (size_t)(12 + j) * plane);
-        s[0][j] = (m0 + m1) + m2;
-        s[1][j] = (m1 - m2) - m3;
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(mp + (size_t)(0 + j) * plane);
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(mp + (size_t)(4 + j) * plane);
+            const f32x4 m2 = *reinterpret_cast<const f32x4*>(mp + (size_t)(8 + j) * plane);
+            const f32x4 m3 = *reinterpret_cast<const f32x4*>(mp + (size_t)(12 + j) * plane);
+            s[0][j] = (m0 + m1) + m2;
+            s[1][j] = (m1 - m2) - m3;
+        }
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + k);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {            // (A^T M) A
+            o[a][0] = ((s[a][0] + s[a][1]) + s[a][2]) + bv;
+            o[a][1] = ((s[a][1] - s[a][2]) - s[a][3]) + bv;
+        }
+        if (relu) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[a][b][e] = fmaxf(o[a][b][e], 0.f);
+        }
     }
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + k);
-    f32x4 o[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {            // (A^T M) A
-        o[a][0] = ((s[a][0] + s[a][1]) + s[a][2]) + bv;
-        o[a][1] = ((s[a][1] - s[a][2]) - s[a][3]) + bv;
-    }
-    if (relu) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[a][b][e] = fmaxf(o[a][b][e], 0.f);
-    }
+    float* yi = y + (size_t)img * (POOL ? (size_t)Ho * Wo : (size_t)H * W) * cout;
+    float* ci = cmax_out ? cmax_out + (size_t)img * (POOL ? (size_t)Ho * Wo : (size_t)H * W) : nullptr;
+    const int lane = threadIdx.x & 63;
     if (POOL) {
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
-        *reinterpret_cast<f32x4*>(y + ((size_t)ty * Wo + tx) * cout + k) = r;
+        if (live) *reinterpret_cast<f32x4*>(yi + ((size_t)ty * Wo + tx) * cout + k) = r;
+        if (cmax_out) {
+            float mx = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]));
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            if (lane == 0 && live) atomicMax(reinterpret_cast<unsigned*>(ci + (size_t)ty * Wo + tx), __float_as_uint(mx));
+        }
     } else {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int yy = 2 * ty + a;
-            if (yy >= H) continue;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const int xx = 2 * tx + b;
-                if (xx < W) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * cout + k) = o[a][b];
+                const bool ok = live && yy < H && xx < W;
+                if (ok) *reinterpret_cast<f32x4*>(yi + ((size_t)yy * W + xx) * cout + k) = o[a][b];
+                if (cmax_out) {
+                    float mx = fmaxf(fmaxf(o[a][b][0], o[a][b][1]), fmaxf(o[a][b][2], o[a][b][3]));
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+                    if (lane == 0 && ok) atomicMax(reinterpret_cast<unsigned*>(ci + (size_t)yy * W + xx), __float_as_uint(mx));
+                }
             }
         }
     }
@@ -249,15 +270,18 @@ int launch_winograd_gemm(const float* V, const float* u, float* M, int N, int H,
     return launch_linear_batched(V, cin, (size_t)T * cin, u, (size_t)cout * cin, M, cout, (size_t)T * cout, T, cout, cin, 16, s);
 }
 
-int launch_winograd_output(const float* M, const float* b, float* y, int N, int H, int W, int cout, unsigned flags, hipStream_t s)
+bool winograd_output_emits_cmax(int cout, unsigned flags) { return cout % 256 == 0 && (flags & FRCNN_RELU) != 0; }
+
+int launch_winograd_output(const float* M, const float* b, float* y, int N, int H, int W, int cout, unsigned flags, hipStream_t s, float* cmax_out)
 {
+    if (cmax_out && !winograd_output_emits_cmax(cout, flags)) return FRCNN_EINVAL;
     const int tw = cdiv(W, 2), tpi = cdiv(H, 2) * tw, T = N * tpi;
     const size_t n = (size_t)T * (cout / 4);
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
     if (flags & FRCNN_POOL2)
-        hipLaunchKernelGGL(wino_output_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, b, y, H, W, cout, tw, tpi, T, relu);
+        hipLaunchKernelGGL(wino_output_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, b, y, H, W, cout, tw, tpi, T, relu, cmax_out);
     else
-        hipLaunchKernelGGL(wino_output_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, b, y, H, W, cout, tw, tpi, T, relu);
+        hipLaunchKernelGGL(wino_output_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, b, y, H, W, cout, tw, tpi, T, relu, cmax_out);
     return check_launch();
 }
 

@@ -284,6 +284,15 @@ int frcnn_conv3x3_nhwc_winograd_x3(const float* d_x, const void* d_blob, const f
 size_t frcnn_conv3x3_winograd_x3_fused_workspace_bytes(int n_maps, int H, int W);
 int frcnn_conv3x3_nhwc_winograd_x3_fused(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W,
                                          int cin, int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
+/* The same two layers CHAINED (round 4): an f32x3 layer takes its scales from the per-pixel channel maximum of its INPUT.  d_cmax_in (optional):
+ * those maxima [n_maps][H][W] if a producer already left them -- the layer then does not read its input once more (frcnn_pixel_absmax).
+ * d_cmax_out (optional; FRCNN_RELU required, three-launch form: cout % 256 == 0): the channel maxima of the OUTPUT [n_maps][Ho][Wo],
+ * accumulated with atomic maxima into a buffer the CALLER ZEROED -- the next layer's d_cmax_in.  Outputs are bit-identical with or
+ * without either pointer.  one_launch != 0: csrc/wino_x3f.hip (d_ws as frcnn_conv3x3_nhwc_winograd_x3_fused), else the three-launch form.
+ * frcnn_vgg16_forward chains conv2_2 ... conv5_3, the RPN trunk and the RoI pooling this way (11 of 12 channel-maximum passes disappear). */
+int frcnn_conv3x3_nhwc_winograd_x3_chain(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W, int cin,
+                                         int cout, unsigned flags, int one_launch, void* d_ws, size_t ws_bytes, const float* d_cmax_in,
+                                         float* d_cmax_out, void* stream);
 size_t frcnn_x3t_record_bytes(int rows_padded, int K);
 int frcnn_rows_scale_x3t(const float* d_a, int lda, size_t a_batch_floats, float* d_inv_scale, int rows, int rows_padded, int K, int batches,
                          void* stream);

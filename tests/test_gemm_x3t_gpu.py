@@ -401,3 +401,45 @@ def test_x3_one_launch_layer_against_the_three_launch_layer_and_float64(n, h, w,
         n, h, w, cin, cout, e1, e3, diff, (time.perf_counter() - t0) / 10 * 1e6))
     assert diff <= 2e-6 and e1 <= 1.5 * e3 + 2e-7
     assert torch.equal(y, first)                                           # run-to-run identical
+
+
+@pytest.mark.parametrize("one_launch,h,w,cin,cout,pool", [
+    (1, 38, 66, 64, 128, False),       # one-launch layer, two cout blocks
+    (1, 75, 125, 128, 256, True),      # fused pool, XCD-grouped block order
+    (0, 38, 62, 256, 256, False),      # three-launch layer (wino_output_kernel's wave reduction)
+    (0, 75, 125, 256, 512, True),      # conv4_3's shape class: fused pool
+])
+def test_x3_layers_chain_their_channel_maxima(one_launch, h, w, cin, cout, pool):
+    """Round 4: an f32x3 layer can leave the per-pixel channel maximum of its OUTPUT behind for the next f32x3 layer (atomic maxima from its
+    epilogue into a zeroed buffer) and take its INPUT's maxima from its producer (frcnn_conv3x3_nhwc_winograd_x3_chain; what
+    frcnn_vgg16_forward does for conv2_2 ... conv5_3, the RPN trunk and the RoI pooling).  The emitted maxima equal frcnn_pixel_absmax of the
+    output bit for bit, and the output does not depend on which way the input's maxima arrived."""
+    lib = nv.lib()
+    gen = torch.Generator().manual_seed(h + w + cin + cout)
+    x = torch.randn((h, w, cin), generator=gen).clamp(min=0).cuda()
+    wt = (torch.randn((cout, cin, 3, 3), generator=gen) * (2.0 / (9 * cin)) ** 0.5).cuda()
+    b = (torch.randn((cout,), generator=gen) * 0.1).cuda()
+    u = pack_x3(wt)
+    flags = nv.RELU | (nv.POOL2 if pool else 0)
+    oh, ow = (h // 2, w // 2) if pool else (h, w)
+    wsb = int(lib.frcnn_conv3x3_winograd_x3_fused_workspace_bytes(1, h, w) if one_launch else lib.frcnn_conv3x3_winograd_x3_workspace_bytes(1, h, w, cin, cout))
+    ws = torch.empty((wsb,), dtype=torch.uint8, device="cuda")
+
+    def run(cmax_in, cmax_out):
+        y = torch.full((oh, ow, cout), float("nan"), device="cuda")
+        nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_chain(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags, one_launch, nv.ptr(ws), wsb,
+                                                          nv.ptr(cmax_in), nv.ptr(cmax_out), nv.stream_ptr()), "x3_chain")
+        torch.cuda.synchronize()
+        return y
+    y0 = run(None, None)
+    assert not torch.isnan(y0).any()
+    cin_max = torch.empty((h * w,), device="cuda")
+    nv.check(lib.frcnn_pixel_absmax(nv.ptr(x), nv.ptr(cin_max), h * w, cin, nv.stream_ptr()), "pixel_absmax")
+    cout_max = torch.zeros((oh * ow,), device="cuda")
+    y1 = run(cin_max, cout_max)
+    assert torch.equal(y0, y1)
+    want = torch.empty((oh * ow,), device="cuda")
+    nv.check(lib.frcnn_pixel_absmax(nv.ptr(y1), nv.ptr(want), oh * ow, cout, nv.stream_ptr()), "pixel_absmax")
+    torch.cuda.synchronize()
+    assert float(want.max()) > 0 and torch.equal(cout_max, want)
+    assert torch.equal(want.reshape(oh, ow), y1.max(dim=2).values)
