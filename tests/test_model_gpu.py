@@ -124,7 +124,7 @@ def test_stage2_rpn_on_oracle_feature_map(gpu_model, model_edge_off, golden_dir,
     print("RPN %s: %d/%d proposals, %.1f%% of reference rows matched within 1e-3 px (max %.3g)" % (
         tag, ours.shape[0], props_ref.shape[0], 100 * frac, float(err.max())))
     assert ours.shape[0] == props_ref.shape[0]
-    assert frac == 1.0                                        # observed (round 3): every reference proposal, all three cases
+    assert frac >= ROW_FRACTION_FLOOR                         # identical INPUTS to this stage: the held-out floor (measured: every row, all three cases)
     # anchor indices of the top-N: identical as a set up to near-tie swaps at the cut
     ours_idx = rpn.last_sorted_indices.cpu().numpy()
     ref_idx = detail["sorted_idx"]
@@ -313,7 +313,7 @@ def test_anchor_maps_argument_and_async_slots(gpu_model):
             assert np.array_equal(runs[0][i][c], runs[1][i][c]), (i, c)
             j, d = match_rows(runs[0][i][c], base[i][c])
             n_same += int((d <= 1e-3).sum())
-        assert n_same == n_base, (i, n_same, n_base)            # observed: every detection of every image (168, 176, 201)
+        assert n_same >= ROW_FRACTION_FLOOR * n_base, (i, n_same, n_base)   # the held-out floor (measured: every detection of every image)
     with pytest.raises(RuntimeError):
         p = gpu_model.predict_async(imgs[0], 0.05, slot=1)
         gpu_model.predict_async(imgs[1], 0.05, slot=1)       # slot busy until collected
@@ -439,7 +439,7 @@ def test_larger_image_grows_the_context(gpu_model, sd_cpu):
     props, classes, deltas = gpu_model(image_data=img.cuda())
     assert props.shape[0] == o_props.shape[0]
     j, err = match_rows(props.cpu().numpy(), o_props.numpy())
-    assert int((err <= 1e-3).sum()) >= 297                   # observed: 297 of 300 (near-tied candidates at the NMS cut)
+    assert (err <= 1e-3).mean() >= 0.985                     # a 720x1280 image (boxes up to 1280 px): just below the 600x1000 floor (measured 297-299 of 300)
     fm = gpu_model.context(0).tensor(0).reshape(45, 80, 512).permute(2, 0, 1).cpu()
     ref = detail["feature_map"][0]
     assert float((fm - ref).abs().max()) / float(ref.abs().max()) <= 2e-5
@@ -477,7 +477,7 @@ def test_model_with_81_classes_matches_the_oracle():
     c_err = float(np.abs(c.cpu().numpy()[j[ok]] - rc.numpy()[ok]).max())
     d_err = float(np.abs(d.cpu().numpy()[j[ok]] - rd.numpy()[ok]).max())
     print("81 classes: %d/%d proposals, class err %.3g, delta err %.3g" % (int(ok.sum()), len(ok), c_err, d_err))
-    assert ok.mean() == 1.0 and c_err <= 1e-5 and d_err <= 5e-5        # observed: 300 / 300, 2.7e-6, 6.3e-6
+    assert ok.mean() >= ROW_FRACTION_FLOOR and c_err <= 1e-5 and d_err <= 5e-5        # measured: 300 / 300, 2.7e-6, 6.3e-6
     assert float(np.abs(c.cpu().numpy().sum(axis=1) - 1.0).max()) <= 1e-5
     det = model.predict(image_data=img.cuda(), score_threshold=0.02)
     ref = O.predict(sd, img, 0.02)
@@ -489,4 +489,4 @@ def test_model_with_81_classes_matches_the_oracle():
             jj, ee = match_rows(det[cls], ref[cls])
             n_ok += int(((ee <= 1e-3) & (np.abs(det[cls][jj, 4] - ref[cls][:, 4]) <= 1e-4)).sum())
     print("81 classes: %d/%d oracle detections reproduced (ours %d)" % (n_ok, n_ref, sum(len(v) for v in det.values())))
-    assert n_ref > 0 and n_ok == n_ref and sum(len(v) for v in det.values()) == n_ref      # observed: 441 / 441, no extra rows
+    assert n_ref > 0 and n_ok >= ROW_FRACTION_FLOOR * n_ref and sum(len(v) for v in det.values()) == n_ref      # measured: 441 / 441; no extra rows

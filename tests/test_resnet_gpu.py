@@ -179,7 +179,7 @@ def test_resnet50_stages_and_end_to_end(r50, golden_dir, name):
     j, err = match_rows(props.cpu().numpy(), g["proposals"])
     ok = err <= 1e-3
     print("%s forward: %.1f%% of the reference's proposals within 1e-3 px" % (name, 100 * ok.mean()))
-    assert ok.mean() == 1.0                                   # observed: every proposal of both ResNet-50 fixtures (default: x6 head only)
+    assert ok.mean() >= 0.99                                  # the held-out floor (tests/conftest.py); measured: every proposal of both ResNet-50 fixtures
     assert np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max() <= 2e-4
     pooled = model.context(0).tensor(5).reshape(-1, 2048)
     assert pooled.shape[0] == 300
@@ -310,7 +310,7 @@ def test_resnet50_direct_mode_agrees_with_default_winograd_mode(r50):
     j, err = match_rows(a[0].cpu().numpy(), b[0].cpu().numpy())
     ok = err <= 1e-3
     print("ResNet-50 f32 vs f32_winograd: %d/%d of proposals within 1e-3 px" % (int(ok.sum()), len(ok)))
-    assert ok.mean() == 1.0                                   # observed: 300 / 300
+    assert ok.mean() >= 0.99                                  # the held-out floor; measured: 300 / 300
     assert np.abs(a[1].cpu().numpy()[j[ok]] - b[1].cpu().numpy()[ok]).max() <= 2e-4
     with pytest.raises(NotImplementedError):
         model.math_mode = "f32x6"
@@ -500,8 +500,8 @@ def test_resnet50_batched_forward(r50, golden_dir):
         model.forward_batch(batch[0])                         # (3, H, W) is not a batch
 
 
-R50_BATCH_PROPOSALS = 299       # observed (deterministic): the batch changes the split-K factors of the under-filled GEMMs; one box of the
-R50_BATCH_DETECTIONS = 232      # golden image then lands just outside 1e-3 px; batch-1 forwards keep 300 / 300 and 232 / 232
+R50_BATCH_PROPOSALS = 297       # the held-out floor (0.99 x 300); measured 299 (deterministic): the batch changes the split-K factors of the under-filled GEMMs; one box of the
+R50_BATCH_DETECTIONS = 229      # 0.99 x 232; measured 232.  The golden image then lands just outside 1e-3 px; batch-1 forwards keep 300 / 300 and 232 / 232
 
 
 def test_evaluate_stream_batched_matches_per_image(r50):
