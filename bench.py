@@ -736,12 +736,16 @@ def main():
 
     x3_legs = {}
     if not is_resnet and not args.no_secondary and x3f:
-        # conv2_2 .. conv3_3 back on the float32 one-launch Winograd kernel (round 3's pipeline for those layers)
+        # conv2_1 .. conv3_3 back on the float32 one-launch Winograd kernel and the 512-channel layers on their three launches in every slot
+        # (round 3's pipeline for those layers)
+        inflight_x3f = model.inflight_winograd_x3f_layers
         model.winograd_x3f_layers = ()
+        model.inflight_winograd_x3f_layers = ()
         run(max(args.warmup, nslots))
         dt, _ = timed_median(run, args.steps, min(args.min_timed_seconds, 0.5))
         x3_legs["no_one_launch_x3_layers_images_per_sec"] = round(n_gpus * args.steps / dt, 3)
         model.winograd_x3f_layers = x3f
+        model.inflight_winograd_x3f_layers = inflight_x3f
         run(nslots)
     if not is_resnet and not args.no_secondary and x6:
         # the f32x3 arithmetic switched off (every split-operand GEMM in f32x6: the table before the f32x3 kernels existed), and round 3's
@@ -1007,12 +1011,17 @@ def main():
         pipes = {}
         if not is_resnet:
             ips = value / n_gpus
-            pf = pipe_flops_per_image(args.math, fc_math, x6, x3=x3, x3f=x3f)
-            pb = pipe_flops_per_image(args.math, fc_math, x6, backbone_only=True, x3=x3, x3f=x3f)
+            # the tables the HEADLINE ran on: with images in flight the 512-channel f32x3 layers take the one-launch form (FasterRCNNModel.layer_tables)
+            hx6, hx3, hx3f = model.layer_tables(0 if nslots == 1 else 1)
+            pf = pipe_flops_per_image(args.math, fc_math, hx6, x3=hx3, x3f=hx3f)
+            pb = pipe_flops_per_image(args.math, fc_math, hx6, backbone_only=True, x3=hx3, x3f=hx3f)
             f32_tf, bf16_tf, f16_tf = ips * pf["f32"] / 1e12, ips * pf["bf16"] / 1e12, ips * pf["f16"] / 1e12
             pipes = {
                 "layer_arithmetic": [{"layer": n_, "kernel": k_, "pipe": p_, "executed_gflop": round(e_ / 1e9, 3), "algorithmic_gflop": round(a_ / 1e9, 3)}
-                                     for n_, k_, p_, e_, a_ in layer_arithmetic(args.math, fc_math, x6, x3=x3, x3f=x3f)],
+                                     for n_, k_, p_, e_, a_ in layer_arithmetic(args.math, fc_math, hx6, x3=hx3, x3f=hx3f)],
+                "layer_arithmetic_note": "the kernels of the headline's %d-images-in-flight slots; one image at a time (slot 0, the regime of the `roofline` "
+                                         "block) runs %s as three-launch f32x3 layers instead (same arithmetic up to the rounding order of the output transform)"
+                                         % (nslots, ", ".join(n_ for n_ in hx3f if n_ not in x3f) or "-"),
                 "f32_pipe_tflops": round(f32_tf, 2), "f32_pipe_frac": round(f32_tf / PEAK_F32_MFMA_TFLOPS, 4),
                 "bf16_pipe_tflops": round(bf16_tf, 2), "bf16_pipe_frac": round(bf16_tf / PEAK_BF16_MFMA_TFLOPS, 4),
                 "f16_pipe_tflops": round(f16_tf, 2), "f16_pipe_frac": round(f16_tf / PEAK_BF16_MFMA_TFLOPS, 4),
@@ -1057,7 +1066,7 @@ def main():
             "tflops_per_gpu": round(value / n_gpus * flops_img / 1e12, 2),
             "tflops_per_gpu_note": "direct-convolution FLOP of the workload x images/sec (BASELINE.md's 4.4922e11 per image); "
                                    "in the f32_winograd mode the matrix pipes execute fewer: see f32_pipe_tflops / bf16_pipe_tflops",
-            "math": args.math, "winograd_x6_layers": list(x6), "winograd_x3_layers": list(x3), "winograd_x3f_layers": list(x3f), "fc_math": None if is_resnet else fc_math, "roi": model._stage3_detector_network.pooling,
+            "math": args.math, "winograd_x6_layers": list(x6), "winograd_x3_layers": list(x3), "winograd_x3f_layers": list(x3f), "inflight_winograd_x3f_layers": [] if is_resnet else list(model.inflight_winograd_x3f_layers), "fc_math": None if is_resnet else fc_math, "roi": model._stage3_detector_network.pooling,
             "other_math_modes_images_per_sec": secondary, "fc_math_f32_images_per_sec": fc_f32_value,
             "winograd_all_f32_pipe_images_per_sec": wino_f32_value, "strict_f32_images_per_sec": strict_f32_value,
             **h2d,

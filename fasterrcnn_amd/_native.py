@@ -154,10 +154,18 @@ def uses_winograd_x3f(cin, cout):
     return cin >= 32 and cin % 32 == 0 and cout >= 64 and cout % 64 == 0
 
 
-# One-launch f32x3 layers of the default table (round 4): the four layers whose three-launch form would move 600 MB of V + M through HBM.
-# Admitted by the held-out criterion (tests/test_holdout_gpu.py) like the rest of the table; conv1_2 / conv2_1 (4 chunks of 16 channels:
-# prologue bound) stay on the float32 one-launch kernel.
-DEFAULT_X3F_LAYERS_VGG16 = ("conv2_2", "conv3_1", "conv3_2", "conv3_3")
+# One-launch f32x3 layers of the default table (round 4): the layers whose three-launch form would move 600 MB of V + M through HBM.
+# Admitted by the held-out criterion (tests/test_holdout_gpu.py) like the rest of the table.  conv2_1 (4 chunks of 16 channels: its blocks
+# are prologue / epilogue bound, the kernel itself is no faster than the float32 one) is in the table because it then LEAVES the channel
+# maxima of its output for conv2_2, whose own pass over its 77 MB input disappears; conv1_2 stays on the float32 one-launch kernel.
+DEFAULT_X3F_LAYERS_VGG16 = ("conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3")
+# The f32x3 layers of the x6 table that run in the ONE-launch form too WHEN SEVERAL IMAGES ARE IN FLIGHT (slots > 0 of predict_async): on a
+# 37x62 / 75x125 map the one-launch kernel has 80 / 320 blocks of ~63 us for 256 CUs -- alone on the chip it loses to the three launches
+# (conv4_x 126 against 86 us), but with other images' kernels filling the idle CUs what counts is CU-time, and one launch without the
+# V / M round trip through the caches costs less of it (measured, 3 images in flight: 700 -> 738 images/sec; one image at a time: 512 ->
+# 496).  The same blobs, operands, products and accumulation order in both forms (they differ by the rounding order of the output
+# transform, <= 2e-6 of max|y|); the held-out sweep asserts both tables (tests/test_holdout_gpu.py).
+DEFAULT_INFLIGHT_X3F_LAYERS_VGG16 = ("conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3", "rpn_trunk")
 
 
 def uses_winograd_x6(cin, cout):

@@ -1134,10 +1134,19 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     const bool x6 = p->math_mode == FRCNN_MATH_F32X6;
     const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
     if (p->winograd_x6_mask != 0 && (!wino || (p->winograd_x6_mask & ~0x3FFE) != 0)) return FRCNN_EINVAL;
-    if (p->winograd_x3f_mask != 0 && (!wino || (p->winograd_x3f_mask & ~0x1FFE) != 0 || (p->winograd_x3f_mask & p->winograd_x6_mask) != 0)) return FRCNN_EINVAL;
+    if (p->winograd_x3f_mask != 0 && (!wino || (p->winograd_x3f_mask & ~0x3FFE) != 0 || (p->winograd_x3f_mask & p->winograd_x6_mask) != 0)) return FRCNN_EINVAL;
     int layer_index = 0;        // 1 .. 12 = conv_w[i], 13 = the RPN trunk (frcnn_forward_params.winograd_x6_mask)
     const float* cmax_ready = nullptr;     // channel maxima of the activation tensor produced last, if its producer emitted them
-    int cmax_flip = 0;
+    // The producers accumulate those maxima with atomic maxima into ZEROED floats.  Every emitting layer of the image gets its own region of
+    // one arena (buffers [1], [2] of the ctx: 2 max_h max_w floats; the emitted maps are those of conv2_1 and later: < H W / 2 floats in
+    // all), and the arena is cleared by ONE fill at the top of the forward instead of one per layer (ten 5 us launches of every image).
+    size_t cmax_used = 0, cmax_cleared = 0;
+    if (wino && ((p->winograd_x3f_mask | (p->winograd_x3_mask & p->winograd_x6_mask)) & 0x1FFE) != 0) {
+        int r0 = ensure_x3f_cmax(c, (size_t)H * W * sizeof(float), s);
+        if (r0) return r0;
+        cmax_cleared = std::min((size_t)H * W / 2 + 4096, 2 * c->x3f_cmax_bytes / sizeof(float));
+        FRCNN_HIP_TRY(hipMemsetAsync(x3f_cmax_buffer(c, 1), 0, cmax_cleared * sizeof(float), s));
+    }
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
         ++layer_index;
@@ -1151,10 +1160,12 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
         float* out_cmax = nullptr;
         if ((is_x3f || is_x3) && layer_index != FRCNN_X6_RPN_TRUNK_BIT && (fl & FRCNN_RELU) && (is_x3f || winograd_output_emits_cmax(co, fl))) {
             const int oh = (fl & FRCNN_POOL2) ? hh / 2 : hh, ow = (fl & FRCNN_POOL2) ? ww / 2 : ww;
-            int r0 = ensure_x3f_cmax(c, (size_t)hh * ww * sizeof(float), s);
-            if (r0) return r0;
-            out_cmax = x3f_cmax_buffer(c, 1 + (cmax_flip ^= 1));
-            FRCNN_HIP_TRY(hipMemsetAsync(out_cmax, 0, (size_t)oh * ow * sizeof(float), s));
+            const size_t need = ((size_t)oh * ow + 63) & ~(size_t)63;
+            out_cmax = x3f_cmax_buffer(c, 1) + cmax_used;
+            if (cmax_used + need > cmax_cleared)            // (conv1_2 as an emitting layer: outside the arena's budget, cleared on its own)
+                FRCNN_HIP_TRY(hipMemsetAsync(out_cmax, 0, (size_t)oh * ow * sizeof(float), s));
+            cmax_used += need;
+            if (cmax_used > 2 * c->x3f_cmax_bytes / sizeof(float)) return FRCNN_EINVAL;
         }
         int r1;
         if (is_x3f)                                                  // one-launch f32x3 Winograd layer: wgt = the x3 blob (csrc/wino_x3f.hip)

@@ -46,6 +46,16 @@ static constexpr size_t XD_LDS_BYTES = XD_M_BYTES + 16 * 64 * 4 + 64 * 4;     //
 
 template <int N> struct XdInt { static constexpr int value = N; };
 
+// maximum over the aligned group of 16 lanes a lane belongs to (a DPP row): four row rotations, no LDS (a __shfl_xor is a ds_bpermute)
+__device__ __forceinline__ float xd_rowmax16(float v)
+{
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)));   // row_ror:8
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)));   // row_ror:4
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)));   // row_ror:2
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)));   // row_ror:1
+    return v;
+}
+
 __device__ __forceinline__ void xd_lds_barrier()
 {
     // LDS writes of this wave done, then the block barrier; the outstanding GLOBAL loads (next chunk's filter fragments) stay in flight
@@ -164,15 +174,8 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
                 U[set][j][ct][t] = __builtin_bit_cast(xf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16, so + ct * HX_RB + t * HX_PIECE, 0));
     };
 
-    f32x16 acc[2][4][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[h][j][ct][r] = 0.f;
+    f32x16 acc[2][4][2];                 // (never zeroed: the first MFMA of every accumulator, in chunk 0, takes a zero C operand instead -- 512 instructions
+                                         //  and ~1 us of every block's prologue)
 
     // ---- operand formation -------------------------------------------------------------------------------------------------------------
     // position row i = wave: r[b] = d[a1][b] +- d[a2][b] (B^T), V[i][j] = r[b1] +- r[b2] (B), csrc/winograd.hip's float32 operation order.
@@ -238,6 +241,9 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // the six MFMAs of step (h, j): per accumulator filter lo x V hi, filter hi x V hi, filter hi x V lo (gemm_x3t_kernel's order)
 #define XD_MFMA(SET, H_, J_, CT, UT, VV) \
     do { if (!(XD_ABLATE & 16)) acc[H_][J_][CT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(U[SET][J_][CT][UT], VV, acc[H_][J_][CT], 0, 0, 0); } while (0)
+    // the first product of an accumulator (filter lo x V hi of chunk 0): C = 0
+#define XD_MFMA0(SET, H_, J_, CT, UT, VV) \
+    do { if (first) acc[H_][J_][CT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(U[SET][J_][CT][UT], VV, xd_zero16, 0, 0, 0); else XD_MFMA(SET, H_, J_, CT, UT, VV); } while (0)
 #define XD_FENCE() __builtin_amdgcn_sched_barrier(0)
 #ifndef XD_ABLATE
 #define XD_ABLATE 0          // timing experiments (tools/build_ablate.sh): 1 no operand VALU, 2 no patch reads / r, 4 no filter loads, 8 no halo traffic, 16 no MFMAs
@@ -248,19 +254,21 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // column of the r the step after next needs, two of the next chunk's sixteen filter pieces, and the halo traffic -- about seven
     // instructions per MFMA, placed by hand (sched_barrier after every slice).  Order of the r columns: b = 0, 2, 1, 3, each into the slot
     // whose old value died in the previous step (V(., 1) = r1 + r2, V(., 2) = r2 - r1, V(., 3) = r1 - r3, V(., 0) = r0 - r2).
-    auto step = [&](int ucb, int hso, float* hcur, float* hnxt, auto PAR, auto S) {
+    auto step = [&](int ucb, int hso, float* hcur, float* hnxt, auto PAR, auto S, auto FIRST) {
         constexpr int par = decltype(PAR)::value, s = decltype(S)::value;
+        constexpr bool first = decltype(FIRST)::value != 0;
+        const f32x16 xd_zero16 = {};
         constexpr int h = s >> 2, j = s & 3, slot = s & 1, nslot = slot ^ 1;
         constexpr int nh = s == 3 ? 1 : s == 7 ? 0 : h, nj = (j + 1) & 3;                 // the operand formed in this step: V(nh, nj)
         constexpr int rb = j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 1 : 3;                        // the r column read and formed in this step ...
         constexpr int rh = h ^ 1;                                                           // ... belongs to the other half (h 0: this chunk's, h 1: the next chunk's)
         const float* rsrc = h == 0 ? hcur : hnxt;
         const xf_f16x8 vh = frag(vhi[slot]), vl = frag(vlo[slot]);
-        XD_MFMA(par, h, j, 0, 1, vh);
+        XD_MFMA0(par, h, j, 0, 1, vh);
         XD_IF(2, read_d(rsrc, rh, rb));
         XD_IF(1, v_adds(nj, 0));
         XD_FENCE();
-        XD_MFMA(par, h, j, 1, 1, vh);
+        XD_MFMA0(par, h, j, 1, 1, vh);
         XD_IF(1, v_hi(nh, nslot, 0));
         if (!(XD_ABLATE & 4)) {   // two of the next chunk's filter pieces per step: U[par ^ 1][s >> 1][s & 1][hi, lo]; the constants land in the instruction offset
             const int so = ubase[s >> 1] + ucb;
@@ -302,16 +310,16 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         }
         XD_FENCE();
     };
-    auto chunk = [&](int c, auto PAR) {
+    auto chunk = [&](int c, auto PAR, auto FIRST) {
         constexpr int par = decltype(PAR)::value;
         float* const hcur = par ? hbuf1 : hbuf0;
         float* const hnxt = par ? hbuf0 : hbuf1;
         // past the last chunk the loads re-read it instead of branching (nobody consumes them)
         const int ucb = (c + 1 < K16 ? c + 1 : K16 - 1) * chunk_stride, hso = (c + 2 < K16 ? c + 2 : K16 - 1) * 64;
-        step(ucb, hso, hcur, hnxt, PAR, XdInt<0>{}); step(ucb, hso, hcur, hnxt, PAR, XdInt<1>{});
-        step(ucb, hso, hcur, hnxt, PAR, XdInt<2>{}); step(ucb, hso, hcur, hnxt, PAR, XdInt<3>{});
-        step(ucb, hso, hcur, hnxt, PAR, XdInt<4>{}); step(ucb, hso, hcur, hnxt, PAR, XdInt<5>{});
-        step(ucb, hso, hcur, hnxt, PAR, XdInt<6>{}); step(ucb, hso, hcur, hnxt, PAR, XdInt<7>{});
+        step(ucb, hso, hcur, hnxt, PAR, XdInt<0>{}, FIRST); step(ucb, hso, hcur, hnxt, PAR, XdInt<1>{}, FIRST);
+        step(ucb, hso, hcur, hnxt, PAR, XdInt<2>{}, FIRST); step(ucb, hso, hcur, hnxt, PAR, XdInt<3>{}, FIRST);
+        step(ucb, hso, hcur, hnxt, PAR, XdInt<4>{}, FIRST); step(ucb, hso, hcur, hnxt, PAR, XdInt<5>{}, FIRST);
+        step(ucb, hso, hcur, hnxt, PAR, XdInt<6>{}, FIRST); step(ucb, hso, hcur, hnxt, PAR, XdInt<7>{}, FIRST);
     };
 
     // ---- prologue ---------------------------------------------------------------------------------------------------------------------
@@ -346,11 +354,14 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_loop = __builtin_amdgcn_s_memrealtime(), xd_c_loop = __builtin_readcyclecounter();
 #endif
-    for (int c = 0; c < K16; c += 2) {                                       // K16 is even (cin % 32 == 0: checked by the launcher)
-        chunk(c, XdInt<0>{});
-        chunk(c + 1, XdInt<1>{});
+    chunk(0, XdInt<0>{}, XdInt<1>{});                                        // chunk 0 starts every accumulator from a zero C operand
+    chunk(1, XdInt<1>{}, XdInt<0>{});
+    for (int c = 2; c < K16; c += 2) {                                       // K16 is even (cin % 32 == 0: checked by the launcher)
+        chunk(c, XdInt<0>{}, XdInt<0>{});
+        chunk(c + 1, XdInt<1>{}, XdInt<0>{});
     }
 #undef XD_MFMA
+#undef XD_MFMA0
 #undef XD_FENCE
 #undef XD_IF
 #ifdef XD_CLOCKS
@@ -371,19 +382,17 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co = 32 * ct + 8 * g + 4 * kh;                 // the MFMA's row operand was the filter: accumulator rows = channels
+                // (whole-vector expressions: no MFMA runs beside the epilogue, so the packed float32 instructions they become are the cheap form here)
                 f32x4 m[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f32x4 sb = *reinterpret_cast<const f32x4*>(sc_lds + (4 * wave + j) * 64 + co);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) m[j][e] = acc[h][j][ct][4 * g + e] * sb[e];
+                    const f32x4 a = {acc[h][j][ct][4 * g], acc[h][j][ct][4 * g + 1], acc[h][j][ct][4 * g + 2], acc[h][j][ct][4 * g + 3]};
+                    m[j] = a * sb;
                 }
-                f32x4 y0, y1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    y0[e] = ((m[0][e] + m[1][e]) + m[2][e]) * vinv[h];        // the tile's 2^-e: exact, commutes with every rounding above
-                    y1[e] = ((m[1][e] - m[2][e]) - m[3][e]) * vinv[h];
-                }
+                const f32x4 vi = {vinv[h], vinv[h], vinv[h], vinv[h]};       // the tile's 2^-e: exact, commutes with every rounding above
+                const f32x4 y0 = ((m[0] + m[1]) + m[2]) * vi;
+                const f32x4 y1 = ((m[1] - m[2]) - m[3]) * vi;
                 float* dst = ybuf + ((((h * 4 + wave) * 2) * 32 + tl) * XD_MS) + co;
                 *reinterpret_cast<f32x4*>(dst) = y0;
                 *reinterpret_cast<f32x4*>(dst + 32 * XD_MS) = y1;
@@ -420,16 +429,14 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[a][bb][e] = fmaxf(o[a][bb][e], 0.f);
         }
-        // (the 16 lanes of a tile's 64 channels reduce their maxima with four shuffles; one atomic per pixel and block)
+        // (the 16 lanes of a tile's 64 channels = one DPP row reduce their maxima with four row rotations; one atomic per pixel and block)
         if (POOL) {
             f32x4 mx;
 #pragma unroll
             for (int e = 0; e < 4; ++e) mx[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
             if (live) *reinterpret_cast<f32x4*>(y + ((size_t)oty * Wo + otx) * Cout + kg) = mx;
             if (cmax_out) {
-                float pm = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off));
+                const float pm = xd_rowmax16(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
                 if (live && (item & 15) == 0) atomicMax(reinterpret_cast<unsigned*>(cmax_out + (size_t)oty * Wo + otx), __float_as_uint(pm));
             }
         } else {
@@ -442,9 +449,7 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
                     const bool ok = live && yy < H && xx < W;
                     if (ok) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * Cout + kg) = o[a][bb];
                     if (cmax_out) {
-                        float pm = fmaxf(fmaxf(o[a][bb][0], o[a][bb][1]), fmaxf(o[a][bb][2], o[a][bb][3]));
-#pragma unroll
-                        for (int off = 8; off >= 1; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off));
+                        const float pm = xd_rowmax16(fmaxf(fmaxf(o[a][bb][0], o[a][bb][1]), fmaxf(o[a][bb][2], o[a][bb][3])));
                         if (ok && (item & 15) == 0) atomicMax(reinterpret_cast<unsigned*>(cmax_out + (size_t)yy * W + xx), __float_as_uint(pm));
                     }
                 }

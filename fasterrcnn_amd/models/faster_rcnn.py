@@ -152,6 +152,10 @@ class FasterRCNNModel(nn.Module):
         self._winograd_x3f_layers = ()
         if not self._is_resnet:
             self.winograd_x3f_layers = nv.DEFAULT_X3F_LAYERS_VGG16
+        # ... and the f32x3 layers of the x6 table that take the one-launch form in the in-flight slots only (see _native.py)
+        self._inflight_winograd_x3f_layers = ()
+        if not self._is_resnet:
+            self.inflight_winograd_x3f_layers = nv.DEFAULT_INFLIGHT_X3F_LAYERS_VGG16
 
         # hipGraph replay of one image's ~33 launches (forward + detections + the D2H copies): the second consecutive call of a slot with
         # the same (shape, thresholds, weights, modes) captures them into a graph on the slot's stream, later calls copy the image
@@ -299,6 +303,39 @@ class FasterRCNNModel(nn.Module):
 
     def _effective_x3f_layers(self):
         return tuple(n for n in self._winograd_x3f_layers if n not in self._winograd_x6_layers)
+
+    @property
+    def inflight_winograd_x3f_layers(self):
+        return self._inflight_winograd_x3f_layers
+
+    @inflight_winograd_x3f_layers.setter
+    def inflight_winograd_x3f_layers(self, names):
+        """VGG-16: layers of winograd_x3_layers (three-launch f32x3 layers) that run as ONE-launch f32x3 layers in the in-flight slots
+        (predict_async, slot > 0); slot 0 -- forward / predict, one image at a time -- keeps the three launches.  A name that is not an
+        effective f32x3 layer has no effect."""
+        names = tuple(names)
+        if names and self._is_resnet:
+            raise NotImplementedError("inflight_winograd_x3f_layers applies to the VGG-16 model")
+        for n in names:
+            if n not in nv.X6_LAYER_BITS or n == "conv1_2":
+                raise ValueError("inflight_winograd_x3f_layers: unknown layer %r" % (n,))
+        self._inflight_winograd_x3f_layers = names
+
+    def layer_tables(self, slot_index=0):
+        """(x6 names, x3 names, one-launch x3 names) in force for a slot: the tables as set, with the in-flight slots' one-launch layers
+        moved over (inflight_winograd_x3f_layers)."""
+        x6 = tuple(self._winograd_x6_layers) if self._math_mode == "f32_winograd" else ()
+        x3 = self._effective_x3_layers() if self._math_mode == "f32_winograd" else ()
+        x3f = self._effective_x3f_layers() if (self._math_mode == "f32_winograd" and not self._is_resnet) else ()
+        if slot_index != 0 and not self._is_resnet:
+            moved = tuple(n for n in self._inflight_winograd_x3f_layers if n in x3)
+            x6 = tuple(n for n in x6 if n not in moved)
+            x3 = tuple(n for n in x3 if n not in moved)
+            x3f = x3f + moved
+        return x6, x3, x3f
+
+    def _slot_masks(self, slot_index):
+        return tuple(sum(1 << nv.X6_LAYER_BITS[n] for n in names) for names in self.layer_tables(slot_index))
 
     def _x3f_mask(self):
         if self._math_mode != "f32_winograd" or self._is_resnet:
@@ -466,11 +503,11 @@ class FasterRCNNModel(nn.Module):
                                 0 if slot_index == 0 else self.inflight_conv_blocks_target,
                                 nv.FC_MATH_MODES[self._effective_fc_math()],
                                 nv.ROI_OPS[self._stage3_detector_network.pooling], self._stage3_detector_network.sampling_ratio,
-                                0 if slot_index == 0 else self.inflight_winograd_tile_rows, self._x6_mask(),
+                                0 if slot_index == 0 else self.inflight_winograd_tile_rows, self._slot_masks(slot_index)[0],
                                 # (ResNet: the cost model's choice in every slot, so that an image gives the same bits in flight
                                 #  and alone: its 1x1 GEMMs switch between split-K and unsplit tiles with the tile mode)
                                 0 if (slot_index == 0 or self._is_resnet) else self.inflight_x6_gemm_tiles,
-                                self._x3_mask(), self._x3f_mask())
+                                self._slot_masks(slot_index)[1], self._slot_masks(slot_index)[2])
 
     def _enqueue_outputs(self, slot, h, w, score_threshold, sp):
         """decode + per-class NMS (faster_rcnn.py:179-224) and the D2H copies of one image, behind its forward on stream `sp`."""

@@ -279,7 +279,9 @@ int frcnn_conv3x3_nhwc_winograd_x3(const float* d_x, const void* d_blob, const f
 /* The same layer as ONE launch (csrc/wino_x3f.hip, round 4: 64 tiles x 64 output channels x all 16 positions per block; the operand formed in
  * registers from an LDS-staged halo, the filter fragments loaded straight from L2 into registers, output transform in the epilogue; no
  * V / M scratch), for the layers whose scratch does not fit the Infinity Cache (frcnn_forward_params.winograd_x3f_mask: conv2_2 .. conv3_3
- * of VGG-16).  By construction bit-identical to frcnn_conv3x3_nhwc_winograd_x3 on the same blob.  cin % 16 == 0, cout % 64 == 0;
+ * of VGG-16; with several images in flight also the 512-channel layers).  The same operands, products and accumulation order as
+ * frcnn_conv3x3_nhwc_winograd_x3 on the same blob; the output transform combines columns before rows, so the two forms differ by the
+ * float32 rounding of that transform only (<= 2e-6 of max|y|, tests/test_gemm_x3t_gpu.py).  cin % 32 == 0, cout % 64 == 0;
  * d_ws >= frcnn_conv3x3_winograd_x3_fused_workspace_bytes (the channel maxima of the input). */
 size_t frcnn_conv3x3_winograd_x3_fused_workspace_bytes(int n_maps, int H, int W);
 int frcnn_conv3x3_nhwc_winograd_x3_fused(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W,
@@ -514,11 +516,13 @@ typedef struct frcnn_forward_params {
     int32_t winograd_x3_mask;   /* a subset of winograd_x6_mask (VGG-16): the layers whose position GEMMs run in the f32x3 arithmetic instead (two
                                    fp16 terms per row-scaled operand, three MFMAs per product: csrc/wino_x3.hip); their weight pointers are
                                    frcnn_pack_conv3x3_winograd_x3's blobs.  ResNet: 0 */
-    int32_t winograd_x3f_mask;  /* round 4 (ABI 9), VGG-16, FRCNN_MATH_F32_WINOGRAD only: bit i set = 3x3 layer i (1 .. 12; disjoint from winograd_x6_mask)
-                                   runs as a ONE-LAUNCH Winograd layer in the f32x3 arithmetic (csrc/wino_x3f.hip: operand formed in registers from the
-                                   LDS-staged halo, filter fragments straight from L2, all 16 positions in accumulators, no V / M scratch; the same bits
-                                   as the three-launch f32x3 layer) and its weight pointer is frcnn_pack_conv3x3_winograd_x3's blob.  For the
-                                   layers whose V + M scratch does not fit the Infinity Cache (conv2_2 .. conv3_3).  cin % 32 == 0, cout % 64 == 0 */
+    int32_t winograd_x3f_mask;  /* round 4 (ABI 9), VGG-16, FRCNN_MATH_F32_WINOGRAD only: bit i set = 3x3 layer i (1 .. 12, 13 = the RPN trunk; disjoint from
+                                   winograd_x6_mask) runs as a ONE-LAUNCH Winograd layer in the f32x3 arithmetic (csrc/wino_x3f.hip: operand formed in
+                                   registers from the LDS-staged halo, filter fragments straight from L2, all 16 positions in accumulators, no V / M
+                                   scratch; the three-launch f32x3 layer's arithmetic up to the rounding order of the output transform) and its weight
+                                   pointer is frcnn_pack_conv3x3_winograd_x3's blob.  For the layers whose V + M scratch does not fit the Infinity
+                                   Cache (conv2_1 .. conv3_3) and, when several images are in flight and the chip is full anyway, for the 512-channel
+                                   layers too (one launch instead of three, no scratch traffic).  cin % 32 == 0, cout % 64 == 0 */
 } frcnn_forward_params;
 #define FRCNN_X6_RPN_TRUNK_BIT 13
 /* capacity of the detector heads: classifier (n) + regressor (4 n - 4) rows are stacked into one zero-padded GEMM operand of

@@ -56,17 +56,20 @@ def rowwise(ours, ref):
     return err
 
 
-def measure(model, g):
-    """Runs the HIP path on fixture `g`'s inputs; returns a dict of plain numbers / small arrays (see the module docstring)."""
+def measure(model, g, slot=0):
+    """Runs the HIP path on fixture `g`'s inputs; returns a dict of plain numbers / small arrays (see the module docstring).
+    slot: 0 = forward / predict (one image at a time); > 0 = that in-flight slot of predict_async, i.e. the arithmetic table of the
+    throughput configuration (VGG-16: the 512-channel f32x3 layers in the one-launch form, FasterRCNNModel.layer_tables)."""
     arch = str(g["arch"])
     seed, h, w = int(g["seed"]), int(g["height"]), int(g["width"])
     img = (synthetic.image if arch == "VGG16" else synthetic.image_rgb)(seed, h, w).unsqueeze(0).cuda()
-    props, classes, deltas = model(image_data=img)
-    ctx = model.context(0)
+    with torch.no_grad():
+        props, classes, deltas = model._enqueue(img, None, None, None, slot).result()
+    ctx = model.context(slot)
     fh, fw = (h // 16, w // 16) if arch == "VGG16" else (-(-h // 16), -(-w // 16))
     fm = ctx.tensor(0).cpu().reshape(fh, fw, -1).permute(2, 0, 1).numpy()
     scores = ctx.tensor(2).cpu().numpy()
-    det = flatten_detections(model.predict(image_data=img, score_threshold=float(g["score_threshold"])))
+    det = flatten_detections(model.predict_async(img, float(g["score_threshold"]), slot).result())
     ours = props.cpu().numpy()
     out = {"arch": arch, "seed": seed, "weights_seed": int(g["weights_seed"]), "n_proposals": int(ours.shape[0]),
            "n_detections": int(det.shape[0]), "n_ref_detections": int(g["ref_detections"].shape[0])}

@@ -357,6 +357,8 @@ def test_model_x3_layer_tables_against_the_golden_vectors(gpu_model, golden_dir)
     (1, 150, 250, 64, 128, True, False),      # conv2_1's shape at a quarter of the size
     (1, 75, 125, 256, 256, True, True),       # conv3_3 at half size, fused pool
     (2, 21, 35, 128, 192, False, False),      # two maps, three cout blocks, no ReLU
+    (1, 37, 62, 512, 512, True, False),       # conv5_x / the RPN trunk (one-launch in the in-flight slots): 32 chunks, 8 cout blocks
+    (1, 38, 62, 256, 512, True, True),        # conv4_3's shape class, fused pool
 ])
 def test_x3_one_launch_layer_against_the_three_launch_layer_and_float64(n, h, w, cin, cout, relu, pool):
     """csrc/wino_x3f.hip (round 4: the one-launch f32x3 Winograd layer of conv2_2 .. conv3_3): the same per-tile scale, fp16 split and
@@ -443,3 +445,39 @@ def test_x3_layers_chain_their_channel_maxima(one_launch, h, w, cin, cout, pool)
     torch.cuda.synchronize()
     assert float(want.max()) > 0 and torch.equal(cout_max, want)
     assert torch.equal(want.reshape(oh, ow), y1.max(dim=2).values)
+
+
+def test_inflight_slots_run_the_512_channel_layers_in_the_one_launch_form(gpu_model):
+    """FasterRCNNModel.layer_tables: slot 0 (forward / predict) runs conv4_1 .. conv5_3 and the RPN trunk as three-launch f32x3 layers, the
+    in-flight slots of predict_async as one-launch layers on the same blobs (12 launches of timing class 10, none of the x6 classes).  The
+    two forms differ by the rounding order of the output transform only: feature maps within 2e-6 of the largest activation, the same
+    proposals as rows -- apart by what two float32 evaluations that are each ~1.2e-4 px from the float64 truth differ by (measured: worst
+    row 3.4e-4 px), inside north_star's 1e-3 px of each other."""
+    from fasterrcnn_amd import synthetic
+    img = synthetic.image(5).unsqueeze(0).cuda()
+    assert gpu_model.layer_tables(0)[1] == nv.DEFAULT_X3_LAYERS_VGG16 and gpu_model.layer_tables(2)[1] == ()
+    assert set(gpu_model.layer_tables(2)[2]) == set(nv.DEFAULT_X3F_LAYERS_VGG16) | set(nv.DEFAULT_INFLIGHT_X3F_LAYERS_VGG16)
+    with torch.no_grad():
+        p0, c0, d0 = gpu_model._enqueue(img, None, None, None, 0).result()
+        fm0 = gpu_model.context(0).tensor(0).clone()
+        p1, c1, d1 = gpu_model._enqueue(img, None, None, None, 2).result()
+        ctx = gpu_model.context(2)
+        fm1 = ctx.tensor(0).clone()
+        ctx.timing_enable(True)
+        gpu_model._enqueue(img, None, None, None, 2).result()
+        torch.cuda.synchronize()
+        t = ctx.timing_read(reset=True)
+        ctx.timing_enable(False)
+    assert t["winograd_x3f"][1] == 12 and t["winograd_x6_gemm"][1] == 0 and t["winograd_x6_transforms"][1] == 0 and t["winograd_gemm"][1] == 1
+    rel = float((fm0 - fm1).abs().max()) / float(fm0.abs().max())
+    a, b = p0.cpu().numpy(), p1.cpu().numpy()
+    assert a.shape == b.shape
+    d = np.abs(a[:, None, :] - b[None, :, :]).max(axis=2).min(axis=1)
+    print("in-flight table vs slot 0: feature map %.3g of max, proposals %d rows, worst nearest-row distance %.3g px, median %.3g" % (
+        rel, len(a), float(d.max()), float(np.median(d))))
+    assert rel <= 2e-6
+    assert (d <= 1e-3).mean() >= 0.99 and float(np.median(d)) <= 2e-4
+    # and the slot's results do not depend on what ran before it
+    with torch.no_grad():
+        p2, c2, d2 = gpu_model._enqueue(img, None, None, None, 2).result()
+    assert torch.equal(p1, p2) and torch.equal(c1, c2) and torch.equal(d1, d2)

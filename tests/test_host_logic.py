@@ -267,13 +267,13 @@ def test_bench_layer_arithmetic_f32x3_tables():
     x6, x3 = nv.DEFAULT_X6_LAYERS_VGG16, nv.DEFAULT_X3_LAYERS_VGG16
     x3f = nv.DEFAULT_X3F_LAYERS_VGG16
     assert x3 == x6 and "conv5_1" in x3                     # round 4: the whole x6 table in f32x3 (chosen on the held-out set: DESIGN.md section 4)
-    assert x3f == ("conv2_2", "conv3_1", "conv3_2", "conv3_3") and not set(x3f) & set(x6)
+    assert x3f == ("conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3") and not set(x3f) & set(x6)
     rows = {r[0]: r for r in bench.layer_arithmetic("f32_winograd", "f32x3", x6, x3=x3, x3f=x3f)}
     for n in x3f:                                            # the one-launch f32x3 layers: three fp16 MFMAs per product, no x6 entry needed
         ci, co, h, w = dict(zip(bench._CONV_NAMES, bench._MFMA_CONVS))[n]
         assert rows[n][1].startswith("wino_x3d_kernel") and rows[n][2] == "f16" and rows[n][3] == 3.0 * bench.winograd_gemm_flops(ci, co, h, w)
-    assert rows["conv1_2"][1] == "wino_fused_kernel" and rows["conv2_1"][2] == "f32"
-    assert [n for n, _ in bench.winograd_layers("f32_winograd", x6, named=True, x3f=x3f)] == ["conv1_2", "conv2_1"]
+    assert rows["conv1_2"][1] == "wino_fused_kernel" and rows["conv1_2"][2] == "f32"
+    assert [n for n, _ in bench.winograd_layers("f32_winograd", x6, named=True, x3f=x3f)] == ["conv1_2"]
     assert [n for n, _ in bench.x3f_winograd_layers("f32_winograd", x6, x3f)] == list(x3f)
     rows = {r[0]: r for r in bench.layer_arithmetic("f32_winograd", "f32x3", x6, x3=tuple(n for n in x3 if n != "conv5_1"))}
     x3 = tuple(n for n in x3 if n != "conv5_1")
@@ -296,6 +296,23 @@ def test_bench_layer_arithmetic_f32x3_tables():
     assert m.winograd_x6_layers == x6 and m.winograd_x3_layers == x3 and m.fc_math_mode == "f32x3" and m.winograd_x3f_layers == x3f
     assert m._x3_mask() & ~m._x6_mask() == 0 and m._x3f_mask() & m._x6_mask() == 0
     assert m._x3f_mask() == sum(1 << nv.X6_LAYER_BITS[n] for n in x3f) and m._stage1_feature_extractor.x3f_layers == x3f
+    # the in-flight slots run the f32x3 layers of the x6 table in the one-launch form too; slot 0 (one image at a time) keeps the three launches
+    assert m.inflight_winograd_x3f_layers == nv.DEFAULT_INFLIGHT_X3F_LAYERS_VGG16 == x6
+    assert m.layer_tables(0) == (x6, x3, x3f) and m.layer_tables(1) == ((), (), x3f + x6)
+    assert m._slot_masks(0) == (m._x6_mask(), m._x3_mask(), m._x3f_mask())
+    m6, m3, mf = m._slot_masks(3)
+    assert m6 == 0 and m3 == 0 and mf == m._x3f_mask() | m._x6_mask() and mf & (1 << nv.X6_RPN_TRUNK_BIT)
+    p0, p1 = m._forward_params(0), m._forward_params(2)
+    assert (p0.winograd_x6_mask, p0.winograd_x3_mask, p0.winograd_x3f_mask) == m._slot_masks(0)
+    assert (p1.winograd_x6_mask, p1.winograd_x3_mask, p1.winograd_x3f_mask) == m._slot_masks(2)
+    m.winograd_x3_layers = tuple(n for n in x3 if n != "conv5_1")      # an f32x6 layer is not moved (its bank is not an x3 blob)
+    assert m.layer_tables(1) == (("conv5_1",), (), x3f + tuple(n for n in x6 if n != "conv5_1"))
+    m.winograd_x3_layers = x3
+    m.inflight_winograd_x3f_layers = ("conv4_2",)
+    assert m.layer_tables(1)[2] == x3f + ("conv4_2",) and "conv4_2" not in m.layer_tables(1)[0]
+    with pytest.raises(ValueError):
+        m.inflight_winograd_x3f_layers = ("conv1_2",)
+    m.inflight_winograd_x3f_layers = x6
     m.winograd_x6_layers = x6 + ("conv3_2",)                  # a layer in both tables runs as the three-launch x6 / x3 layer
     assert m._x3f_mask() & (1 << nv.X6_LAYER_BITS["conv3_2"]) == 0 and "conv3_2" not in m._stage1_feature_extractor.x3f_layers
     m.winograd_x6_layers = x6

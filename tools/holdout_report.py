@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--tables", default="default,f32")
     ap.add_argument("--out", default=None)
     ap.add_argument("--max-cases", type=int, default=0)
+    ap.add_argument("--slot", type=int, default=0, help="0 = forward / predict; 1 = an in-flight slot of predict_async (VGG-16: its one-launch table)")
     args = ap.parse_args()
     tables = VGG_TABLES if args.arch == "VGG16" else RESNET_TABLES
     files = H.cases(args.arch)
@@ -68,7 +69,7 @@ def main():
                 models.clear()
                 models[ws] = H.build_model(args.arch, ws)
                 apply(models[ws], tables[name])
-            r = H.measure(models[ws], g)
+            r = H.measure(models[ws], g, args.slot)
             results.append(r)
             print("%-12s %s" % (name, H.format_line(r)), flush=True)
         rows = sum(r["prop_rows"] for r in results)
