@@ -21,30 +21,47 @@ static constexpr int XF_TC = 16;                             // tile columns of 
 static constexpr int XF_HC = 2 * XF_TC + 2;                  // halo columns: 34 pixels
 static constexpr int XF_PS = 20;                             // floats per halo pixel (16 + 4 padding)
 static constexpr int X3_HR = 10;                             // halo rows: 4 tile rows x 2 + 2
-static constexpr int X3_NPC = (X3_HR * XF_HC * 4 + 255) / 256;   // halo pieces (pixel, 4-channel quad) per thread: 6
 
-struct XfGeom { int tbx, tby, ncb, tw, th, xg; };
+
+// m_*: ceil(2^32 / d) of the three divisors of the block index (0 for d = 1): the quotient is ONE scalar multiply-high on the device instead of
+// a division sequence per divisor between the block's entry and its first load (exact while block index x d < 2^32: checked by the launcher)
+struct XfGeom { int tbx, tby, ncb, tw, th, xg; unsigned m_tbx, m_tby, m_ncb; };
+__device__ __forceinline__ int xd_div(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
 
 // ---- the kernel: 64 tiles per block, the filter fragments straight from L2 into registers ------------------------------------------------------
 // What bounded round 3's versions was the L2 -> LDS staging of the filter records (64 KB per chunk and block by LDS-DMA: ~17 B per clock and CU).
 // Every filter piece is read by exactly ONE wave (a wave owns a position row), and a piece IS the register image of an MFMA operand
 // (lane l's fragment at byte 16 l), so the wave loads its 16 pieces of a chunk with plain 1 KB buffer loads into registers, one chunk
-// ahead (two register sets), and the LDS holds nothing but the input halo (two buffers: ONE barrier per chunk).  The vector work of the
-// operand formation (B^T d B, scale, fp16 split) is spread over the MFMAs of the chunk in eight steps of six MFMAs; step (h, j) forms the
-// operand of step (h, j + 1).  Measured with the shader clock inside the kernel (tools/xd_clocks.py, ablation builds XD_ABLATE): 3100-3400
-// cycles per chunk against the 1536 of its 48 MFMAs -- the MFMA stream alone runs at 1620, the operand-forming vector instructions add
-// ~770 (they do not overlap: one wave per SIMD issues in order), the halo traffic ~400, the filter loads ~200; before the loop 3.8 us,
-// after it 5.5 us per block.
+// ahead (two register sets), and the LDS holds nothing but the input halo (a ring of three buffers filled by LDS-DMA two chunks ahead: ONE
+// barrier per chunk, no staging registers).  The vector work of the operand formation (B^T d B, scale, fp16 split) is spread over the MFMAs
+// of the chunk in eight steps of six MFMAs; step (h, j) forms the operand of step (h, j + 1).
+// Measured with the shader clock inside the kernel (tools/xd_clocks.py, ablation builds XD_ABLATE; the chip runs this kernel at 1.55-1.8 GHz,
+// the MFMA-free ablation at 2.3): 2800-2880 cycles per chunk against the 1536 of its 48 MFMAs.  The MFMA stream alone runs at 1581, the
+// vector instructions alone (no MFMA) at 1211, and together they ADD rather than overlap: ~370 non-MFMA instructions per chunk are 7.7 per
+// MFMA, and one wave per SIMD issues in order.  History of the loop: 3150-3260 cycles with the halo staged through registers (the
+// ds_write of a chunk's halo waited ~570 cycles for loads issued six steps earlier); before the loop 3.7-4.2 us (one memory round trip:
+// every load of the prologue leaves back to back after the address arithmetic -- the earlier order was four round trips, 4.4-4.9 us), after
+// it 4.3-5.2 us per block (2,200 instructions: 256 accumulator reads, the scales, the column pass through LDS, the row pass).
 typedef float xd_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 xd_f16x2 __attribute__((ext_vector_type(2)));
 
 static constexpr int XD_HP = XF_HC / 2;                                       // 17 pixel slots per (halo row, column parity)
-static constexpr int XD_HALO_FLOATS = X3_HR * XF_HC * XF_PS;                  // 6,800 floats = 27,200 B per buffer
+// halo: X3_HR x XF_HC pixels x XF_PS floats = 6,800 floats = 27,200 B per chunk
+// The halo reaches LDS by DMA (buffer_load_dwordx4 ... lds: lane l of a wave instruction writes 16 B at base + 16 l, no staging registers, no
+// ds_write) into a ring of THREE buffers, two chunks ahead.  A pixel's 80 bytes are five consecutive lanes: four channel quads and one
+// padding lane whose load is out of range (nothing fetched) -- the 80-byte pixel stride is what keeps the patch reads conflict-free.
+static constexpr int XD_NDMA = 7;                                              // DMA instructions per thread and chunk: 7 x 256 x 16 B = 28,672 B
+static constexpr int XD_HBUF_BYTES = XD_NDMA * 256 * 16;                      // >= 27,200: the surplus lanes' zeros land in the buffer's tail
+static constexpr int XD_HBUF_FLOATS = XD_HBUF_BYTES / 4;
+typedef __attribute__((address_space(3))) void* xd_lds_ptr;
 static constexpr int XD_MS = 68;                                              // floats between two tiles of the epilogue's M buffer (64 + 4: conflict-free)
-static constexpr int XD_M_BYTES = 16 * 32 * XD_MS * 4;                       // 139,264: the epilogue's Y buffer [2 halves][4 rows][2][32 tiles][68] (>= the two halo buffers)
+static constexpr int XD_M_BYTES = 16 * 32 * XD_MS * 4;                       // 139,264: the epilogue's Y buffer [2 halves][4 rows][2][32 tiles][68] (>= the three halo buffers' 86,016)
 static constexpr size_t XD_LDS_BYTES = XD_M_BYTES + 16 * 64 * 4 + 64 * 4;     // + the block's filter scales [16][64] and bias [64]: 143,616
 
 template <int N> struct XdInt { static constexpr int value = N; };
+#ifndef XD_ABLATE
+#define XD_ABLATE 0          // timing experiments (tools/build_ablate.sh): 1 no operand VALU, 2 no patch reads / r, 4 no filter loads, 8 no halo traffic, 16 no MFMAs
+#endif
 
 // maximum over the aligned group of 16 lanes a lane belongs to (a DPP row): four row rotations, no LDS (a __shfl_xor is a ds_bpermute)
 __device__ __forceinline__ float xd_rowmax16(float v)
@@ -73,7 +90,6 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_xf[];
     float* const hbuf0 = reinterpret_cast<float*>(smem_xf);
-    float* const hbuf1 = hbuf0 + XD_HALO_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,17 +102,18 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // with the plain order, and 1-2 % of the launch time).  Otherwise: output-channel block fastest, round-robin over the XCDs.
     int cb;
     if (gm.xg) {
-        const int xcd = b & 7, q = b >> 3;
-        cb = q % gm.ncb;
-        b = (q / gm.ncb) * 8 + xcd;
+        const int xcd = b & 7, q = b >> 3, qq = xd_div(q, gm.ncb, gm.m_ncb);
+        cb = q - qq * gm.ncb;
+        b = qq * 8 + xcd;
     } else {
-        cb = b % gm.ncb;
-        b /= gm.ncb;
+        const int qq = xd_div(b, gm.ncb, gm.m_ncb);
+        cb = b - qq * gm.ncb;
+        b = qq;
     }
-    const int bx = b % gm.tbx;
-    b /= gm.tbx;
-    const int by = b % gm.tby;                                               // blocks of FOUR tile rows
-    const int map = b / gm.tby;
+    const int b1 = xd_div(b, gm.tbx, gm.m_tbx);
+    const int bx = b - b1 * gm.tbx;
+    const int map = xd_div(b1, gm.tby, gm.m_tby);
+    const int by = b1 - map * gm.tby;                                        // blocks of FOUR tile rows
     const float* __restrict__ const x = x_maps + (size_t)map * H * W * Cin;
     const float* __restrict__ const cmax = cmax_maps + (size_t)map * H * W;
     float* __restrict__ const y = y_maps + (size_t)map * (POOL ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) * Cout;
@@ -111,48 +128,51 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 
     const int tl = lane & 31, tyl = tl >> 4, txl = tl & 15, kh = lane >> 5;
     const int tx = XF_TC * bx + txl;
-    // the 2 x 16 channel maxima of this lane's tiles leave for registers now and are reduced to the tile scales AFTER the first halo and filter
-    // loads have been issued (one round trip to memory for all of them instead of two)
+    // The 2 x 16 channel maxima of this lane's tiles: offsets now, loads below with everything else the prologue fetches (ONE round trip
+    // to memory for all of it; the address arithmetic of the whole prologue comes first so that nothing touches a register with a load in flight).
+    // An absent row / column gets an offset past the descriptor's size: row and column parts are added, 2^31 and 2^30 mark the absent ones.
     float mult[2], vinv[2];
     float dm[2][16];
+    int dm_row[2][4], dm_col[4];
+    {
+        const int x0 = 2 * tx - 1;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int ty = 4 * by + 2 * h + tyl;
-        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+        for (int c = 0; c < 4; ++c) dm_col[c] = (x0 + c >= 0 && x0 + c < W) ? (x0 + c) * 4 : 0x40000000;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int h = 0; h < 2; ++h) {
+            const int y0 = 2 * (4 * by + 2 * h + tyl) - 1;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int yy = y0 + a, xx = x0 + c;
-                const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < W;
-                dm[h][4 * a + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, inb ? (yy * W + xx) * 4 : (int)0xFFFFFFF0u, 0, 0));
-            }
+            for (int a = 0; a < 4; ++a) dm_row[h][a] = (y0 + a >= 0 && y0 + a < H) ? (y0 + a) * W * 4 : (int)0x80000000u;
+        }
     }
 
-    // ---- halo staging (global -> registers -> LDS): piece = (pixel, 4-channel quad); surplus threads duplicate the first pieces ----------
+    // ---- halo staging by LDS-DMA: lane piece P = (7 it + ... ) -> LDS byte 16 P of the buffer = pixel slot P / 5, part P % 5 (4 = padding) ------
+    // slot order [row][column parity][17]: the de-interleaved columns of the patch reads below
     const int hy0 = 8 * by - 1, hx0 = 2 * XF_TC * bx - 1;
-    constexpr int NHP = X3_HR * XF_HC * 4;                                   // 1,360 pieces
-    int h_src[X3_NPC], h_dst[X3_NPC];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);                 // (wave-uniform: the DMA's LDS base travels in M0)
+    // (24-bit multiplies and reciprocal constants instead of integer divisions: this arithmetic stands between the block's entry and its first
+    //  halo load; P < 1792 and slot < 359 keep the constants exact)
+    int h_src[XD_NDMA];
+    auto halo_sources = [&]() {
 #pragma unroll
-    for (int it = 0; it < X3_NPC; ++it) {
-        const int q = tid + 256 * it;
-        const int qq = q < NHP ? q : q - NHP;
-        const int px = qq >> 2, quad = qq & 3;
-        const int hr = px / XF_HC, hc = px - hr * XF_HC;
-        const int gy = hy0 + hr, gx = hx0 + hc;
-        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        h_src[it] = inb ? (int)((((unsigned)gy * W + gx) * Cin + 4 * quad) * sizeof(float)) : (int)0xFFFFFFF0u;
-        h_dst[it] = ((hr * 2 + (hc & 1)) * XD_HP + (hc >> 1)) * XF_PS + 4 * quad;      // columns de-interleaved by parity (below)
-    }
-    f32x4 hreg[X3_NPC];
-    auto load_halo = [&](int chunk) {
-#pragma unroll
-        for (int it = 0; it < X3_NPC; ++it)
-            hreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, h_src[it], chunk * 64, 0));
+        for (int it = 0; it < XD_NDMA; ++it) {
+            const unsigned P = (unsigned)((it * 4 + wave) * 64 + lane);
+            const unsigned slot = __umul24(P, 52429u) >> 18, part = P - 5u * slot;            // P / 5, P % 5
+            const unsigned hr = __umul24(slot, 1928u) >> 16, rem = slot - (unsigned)XF_HC * hr;   // slot / 34, slot % 34
+            const unsigned par = rem >= (unsigned)XD_HP ? 1u : 0u, hc = 2u * (rem - par * (unsigned)XD_HP) + par;
+            const int gy = hy0 + (int)hr, gx = hx0 + (int)hc;
+            const bool inb = part < 4u && hr < (unsigned)X3_HR && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const unsigned off = (__umul24((unsigned)gy, (unsigned)W) + (unsigned)gx) * (unsigned)(Cin * 4) + 16u * part;
+            h_src[it] = inb ? (int)off : (int)0xFFFFFFF0u;
+        }
     };
-    auto store_halo = [&](float* hb) {
+    // pieces [it0, it1) of chunk `chunk_off / 64` into the buffer at hb
+    auto dma_halo = [&](float* hb, int chunk_off, auto IT0, auto IT1) {
+        if (XD_ABLATE & 8) return;
 #pragma unroll
-        for (int it = 0; it < X3_NPC; ++it) *reinterpret_cast<f32x4*>(hb + h_dst[it]) = hreg[it];
+        for (int it = decltype(IT0)::value; it < decltype(IT1)::value; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (xd_lds_ptr)(reinterpret_cast<unsigned char*>(hb) + (it * 4 + wave_u) * 1024), 16, h_src[it],
+                                                     chunk_off, 0, 0);
     };
 
     // ---- filter fragments: piece (position p, row block r, term t) of chunk c = ublob + ((p K16 + c) u_rbt + 2 cb + r) 2 KB + t 1 KB -------
@@ -195,6 +215,21 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         const float* p2 = hb + d_lane + (((4 * h + a2) * 2 + (bb & 1)) * XD_HP + (bb >> 1)) * XF_PS;
         du0 = *reinterpret_cast<const f32x4*>(p1); du1 = *reinterpret_cast<const f32x4*>(p1 + 4);
         dw0 = *reinterpret_cast<const f32x4*>(p2); dw1 = *reinterpret_cast<const f32x4*>(p2 + 4);
+    };
+    // the same column in two halves (channels 0..3, channels 4..7): the loop issues them two MFMAs apart and consumes each five MFMAs after
+    // its issue -- with all four reads of a column in one burst the four waves' sixteen 1 KB reads queue up behind each other and the last
+    // one returns after the r it feeds is due (measured: ~85 stall cycles per step on s_waitcnt lgkmcnt)
+    auto read_d_lo = [&](const float* hb, int h, int bb) {
+        const float* p1 = hb + d_lane + (((4 * h + a1) * 2 + (bb & 1)) * XD_HP + (bb >> 1)) * XF_PS;
+        const float* p2 = hb + d_lane + (((4 * h + a2) * 2 + (bb & 1)) * XD_HP + (bb >> 1)) * XF_PS;
+        du0 = *reinterpret_cast<const f32x4*>(p1);
+        dw0 = *reinterpret_cast<const f32x4*>(p2);
+    };
+    auto read_d_hi = [&](const float* hb, int h, int bb) {
+        const float* p1 = hb + d_lane + (((4 * h + a1) * 2 + (bb & 1)) * XD_HP + (bb >> 1)) * XF_PS;
+        const float* p2 = hb + d_lane + (((4 * h + a2) * 2 + (bb & 1)) * XD_HP + (bb >> 1)) * XF_PS;
+        du1 = *reinterpret_cast<const f32x4*>(p1 + 4);
+        dw1 = *reinterpret_cast<const f32x4*>(p2 + 4);
     };
     // u + sgn w as ONE fused operation == u +- w rounded once (sgn w is exact)
     auto make_r = [&](int bb, int half) {
@@ -245,47 +280,38 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #define XD_MFMA0(SET, H_, J_, CT, UT, VV) \
     do { if (first) acc[H_][J_][CT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(U[SET][J_][CT][UT], VV, xd_zero16, 0, 0, 0); else XD_MFMA(SET, H_, J_, CT, UT, VV); } while (0)
 #define XD_FENCE() __builtin_amdgcn_sched_barrier(0)
-#ifndef XD_ABLATE
-#define XD_ABLATE 0          // timing experiments (tools/build_ablate.sh): 1 no operand VALU, 2 no patch reads / r, 4 no filter loads, 8 no halo traffic, 16 no MFMAs
-#endif
 #define XD_IF(BIT, STMT) do { if (!(XD_ABLATE & (BIT))) { STMT; } } while (0)
 
     // One chunk = eight steps (h, j) of six MFMAs.  Between the MFMAs of step s: the operand of step s + 1 (four channel pairs), one patch
     // column of the r the step after next needs, two of the next chunk's sixteen filter pieces, and the halo traffic -- about seven
     // instructions per MFMA, placed by hand (sched_barrier after every slice).  Order of the r columns: b = 0, 2, 1, 3, each into the slot
     // whose old value died in the previous step (V(., 1) = r1 + r2, V(., 2) = r2 - r1, V(., 3) = r1 - r3, V(., 0) = r0 - r2).
-    auto step = [&](int ucb, int hso, float* hcur, float* hnxt, auto PAR, auto S, auto FIRST) {
+    // A column read in step s is first used by the operand formed in step s + 2, so its two channel halves are read in gaps 1 and 3 of step
+    // s and turned into r in gap 6 of step s and gap 2 of step s + 1: five MFMAs (160 cycles) between every ds_read and its use.
+    auto step = [&](int ucb, int hso, float* hcur, float* hnxt, auto PAR, auto S, auto FIRST) {     // hso: byte offset of chunk c + 3 in a pixel
         constexpr int par = decltype(PAR)::value, s = decltype(S)::value;
         constexpr bool first = decltype(FIRST)::value != 0;
         const f32x16 xd_zero16 = {};
         constexpr int h = s >> 2, j = s & 3, slot = s & 1, nslot = slot ^ 1;
         constexpr int nh = s == 3 ? 1 : s == 7 ? 0 : h, nj = (j + 1) & 3;                 // the operand formed in this step: V(nh, nj)
         constexpr int rb = j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 1 : 3;                        // the r column read and formed in this step ...
+        constexpr int prb = j == 0 ? 3 : j == 1 ? 0 : j == 2 ? 2 : 1;                       // ... and the previous step's, whose upper channels are still due
         constexpr int rh = h ^ 1;                                                           // ... belongs to the other half (h 0: this chunk's, h 1: the next chunk's)
         const float* rsrc = h == 0 ? hcur : hnxt;
         const xf_f16x8 vh = frag(vhi[slot]), vl = frag(vlo[slot]);
         XD_MFMA0(par, h, j, 0, 1, vh);
-        XD_IF(2, read_d(rsrc, rh, rb));
+        XD_IF(2, read_d_lo(rsrc, rh, rb));
         XD_IF(1, v_adds(nj, 0));
         XD_FENCE();
         XD_MFMA0(par, h, j, 1, 1, vh);
         XD_IF(1, v_hi(nh, nslot, 0));
-        if (!(XD_ABLATE & 4)) {   // two of the next chunk's filter pieces per step: U[par ^ 1][s >> 1][s & 1][hi, lo]; the constants land in the instruction offset
-            const int so = ubase[s >> 1] + ucb;
-            U[par ^ 1][s >> 1][s & 1][0] = __builtin_bit_cast(xf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16 + (s & 1) * HX_RB, so, 0));
-            U[par ^ 1][s >> 1][s & 1][1] = __builtin_bit_cast(xf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16 + (s & 1) * HX_RB + HX_PIECE, so, 0));
-        }
+        XD_IF(2, make_r(prb, 1));
         XD_FENCE();
         XD_MFMA(par, h, j, 0, 0, vh);
         XD_IF(1, v_lo(nh, nslot, 0));
-        if (s == 2 && !(XD_ABLATE & 8)) {                                                        // halo(c + 1): registers -> LDS, first half
-#pragma unroll
-            for (int it = 0; it < 3; ++it) *reinterpret_cast<f32x4*>(hnxt + h_dst[it]) = hreg[it];
-        }
-        if (s == 4 && !(XD_ABLATE & 8)) {                                                        // halo(c + 2) leaves for registers, first half
-#pragma unroll
-            for (int it = 0; it < 3; ++it) hreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, h_src[it], hso, 0));
-        }
+        XD_IF(2, read_d_hi(rsrc, rh, rb));
+        // halo(c + 3) -> the buffer halo(c) was read from, free since the barrier of step 3 (its last patch read is that step's)
+        if (s == 4) dma_halo(hcur, hso, XdInt<0>{}, XdInt<4>{});
         XD_FENCE();
         XD_MFMA(par, h, j, 1, 0, vh);
         XD_IF(1, v_adds(nj, 2));
@@ -293,50 +319,66 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         XD_FENCE();
         XD_MFMA(par, h, j, 0, 0, vl);
         XD_IF(1, v_lo(nh, nslot, 2));
-        XD_IF(2, make_r(rb, 0));
+        if (!(XD_ABLATE & 4)) {   // two of the next chunk's filter pieces per step: U[par ^ 1][s >> 1][s & 1][hi, lo]; the constants land in the instruction offset
+            const int so = ubase[s >> 1] + ucb;
+            U[par ^ 1][s >> 1][s & 1][0] = __builtin_bit_cast(xf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16 + (s & 1) * HX_RB, so, 0));
+            U[par ^ 1][s >> 1][s & 1][1] = __builtin_bit_cast(xf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16 + (s & 1) * HX_RB + HX_PIECE, so, 0));
+        }
         XD_FENCE();
         XD_MFMA(par, h, j, 1, 0, vl);
-        XD_IF(2, make_r(rb, 1));
+        XD_IF(2, make_r(rb, 0));
         if (s == 3) {
-            if (!(XD_ABLATE & 8)) {
-#pragma unroll
-                for (int it = 3; it < X3_NPC; ++it) *reinterpret_cast<f32x4*>(hnxt + h_dst[it]) = hreg[it];
-            }
-            xd_lds_barrier();                                                // halo(c + 1) visible to every wave, halo(c - 1)'s buffer spent
+            // halo(c + 1) has landed: its DMA left in chunk c - 2 (the prologue for c < 2), and LDS-DMA completes in issue order like any
+            // vector memory load -- at most the 15 youngest may be outstanding: halo(c + 2)'s 7 pieces and the 8 filter pieces of steps
+            // 0-3 (chunk 0: exactly those; later chunks have 16 more filter pieces in between).  Then the block barrier: halo(c + 1)
+            // visible to every wave, halo(c)'s buffer spent.
+            asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            xd_lds_barrier();
         }
-        if (s == 5 && !(XD_ABLATE & 8)) {
-#pragma unroll
-            for (int it = 3; it < X3_NPC; ++it) hreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, h_src[it], hso, 0));
-        }
+        if (s == 5) dma_halo(hcur, hso, XdInt<4>{}, XdInt<XD_NDMA>{});
         XD_FENCE();
     };
+    // the ring: chunk c reads halo(c) from hcur (steps 0-3) and halo(c + 1) from hnxt (steps 4-7)
+    float *hcur = hbuf0, *hnxt = hbuf0 + XD_HBUF_FLOATS, *hthird = hbuf0 + 2 * XD_HBUF_FLOATS;
     auto chunk = [&](int c, auto PAR, auto FIRST) {
-        constexpr int par = decltype(PAR)::value;
-        float* const hcur = par ? hbuf1 : hbuf0;
-        float* const hnxt = par ? hbuf0 : hbuf1;
         // past the last chunk the loads re-read it instead of branching (nobody consumes them)
-        const int ucb = (c + 1 < K16 ? c + 1 : K16 - 1) * chunk_stride, hso = (c + 2 < K16 ? c + 2 : K16 - 1) * 64;
+        const int ucb = (c + 1 < K16 ? c + 1 : K16 - 1) * chunk_stride, hso = (c + 3 < K16 ? c + 3 : K16 - 1) * 64;
         step(ucb, hso, hcur, hnxt, PAR, XdInt<0>{}, FIRST); step(ucb, hso, hcur, hnxt, PAR, XdInt<1>{}, FIRST);
         step(ucb, hso, hcur, hnxt, PAR, XdInt<2>{}, FIRST); step(ucb, hso, hcur, hnxt, PAR, XdInt<3>{}, FIRST);
         step(ucb, hso, hcur, hnxt, PAR, XdInt<4>{}, FIRST); step(ucb, hso, hcur, hnxt, PAR, XdInt<5>{}, FIRST);
         step(ucb, hso, hcur, hnxt, PAR, XdInt<6>{}, FIRST); step(ucb, hso, hcur, hnxt, PAR, XdInt<7>{}, FIRST);
+        float* const t = hcur; hcur = hnxt; hnxt = hthird; hthird = t;
     };
 
     // ---- prologue ---------------------------------------------------------------------------------------------------------------------
-    // the block's 16 x 64 filter scales and 64 biases go to LDS now (one load per thread): the epilogue has no register to prefetch them into
-    // and would otherwise wait for each of its 64 scale vectors in turn (measured: ~15 us per block in versions 3 and 4a)
+    // Every load the block needs before its first MFMA leaves HERE, back to back: the channel maxima, the filter pieces of chunk 0, the
+    // block's 16 x 64 filter scales and 64 biases (on their way to LDS: the epilogue has no register to prefetch them into and would
+    // otherwise wait for each of its 64 scale vectors in turn), then -- their source offsets computed under those loads -- halo(0 .. 2).  Their consumers follow below -- the earlier order
+    // (maxima, reduce, scales -> LDS, bias -> LDS, then the halo) was four round trips to memory, 4 us of every block.
     float* const sc_lds = reinterpret_cast<float*>(smem_xf + XD_M_BYTES);
-    {
-        const int Np0 = u_rbt * 32;
-        const float* uinv0 = reinterpret_cast<const float*>(ublob + (size_t)16 * K16 * u_rbt * HX_RB);
-        const int p = tid >> 4, q = (tid & 15) * 4;
-        *reinterpret_cast<f32x4*>(sc_lds + p * 64 + q) = *reinterpret_cast<const f32x4*>(uinv0 + (size_t)p * Np0 + 64 * cb + q);
-        if (tid < 16) *reinterpret_cast<f32x4*>(sc_lds + 1024 + 4 * tid) = *reinterpret_cast<const f32x4*>(bias + 64 * cb + 4 * tid);
-    }
-    load_halo(0);
+    const int sc_p = tid >> 4, sc_q = (tid & 15) * 4;
+    const float* const uinv0 = reinterpret_cast<const float*>(ublob + (size_t)16 * K16 * u_rbt * HX_RB) + (size_t)sc_p * (u_rbt * 32) + 64 * cb + sc_q;
+    const float* const bias0 = bias + 64 * cb + 4 * (tid & 15);
+    XD_FENCE();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                dm[h][4 * a + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, dm_row[h][a] + dm_col[c], 0, 0));
     load_u(0, XdInt<0>{}, XdInt<0>{}); load_u(0, XdInt<0>{}, XdInt<1>{}); load_u(0, XdInt<0>{}, XdInt<2>{}); load_u(0, XdInt<0>{}, XdInt<3>{});
-    store_halo(hbuf0);
-    load_halo(K16 > 1 ? 1 : 0);                                              // halo(1) waits in registers for step 2 / 3 of chunk 0
+    const f32x4 sc_v = *reinterpret_cast<const f32x4*>(uinv0);
+    const f32x4 bias_v = *reinterpret_cast<const f32x4*>(bias0);             // (every thread: 16 threads' worth is kept)
+    XD_FENCE();
+    halo_sources();                                                          // (under the loads above)
+    XD_FENCE();
+    dma_halo(hcur, 0, XdInt<0>{}, XdInt<XD_NDMA>{});
+    dma_halo(hnxt, (K16 > 1 ? 1 : 0) * 64, XdInt<0>{}, XdInt<XD_NDMA>{});
+    dma_halo(hthird, (K16 > 2 ? 2 : K16 - 1) * 64, XdInt<0>{}, XdInt<XD_NDMA>{});
+    XD_FENCE();
+    *reinterpret_cast<f32x4*>(sc_lds + sc_p * 64 + sc_q) = sc_v;
+    *reinterpret_cast<f32x4*>(sc_lds + 1024 + 4 * (tid & 15)) = bias_v;       // (sixteen threads per slot store the same bytes: no branch for the load to sink into)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float dmax = 0.f;
@@ -344,11 +386,18 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         for (int q = 0; q < 16; ++q) dmax = fmaxf(dmax, dm[h][q]);
         hx_row_scale(4.0f * dmax, mult[h], vinv[h]);
     }
+#ifdef XD_CLOCKS
+    const unsigned long long xd_t_issued = __builtin_amdgcn_s_memrealtime();
+#endif
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XD_NDMA) : "memory");       // everything but halo(1) and halo(2): halo(0) and the first filter pieces are in
     xd_lds_barrier();
+#ifdef XD_CLOCKS
+    const unsigned long long xd_t_landed = __builtin_amdgcn_s_memrealtime();
+#endif
     // state at the top of a chunk: r = the r of (chunk, half 0) with column 0 already replaced ... the loop's steady state is entered with
     // V(0, 0) formed and r[1..3] of half 0 live; r[0] is free (the loop's first step writes half 1's column 0 there)
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) { read_d(hbuf0, 0, bb); make_r(bb, 0); make_r(bb, 1); }
+    for (int bb = 0; bb < 4; ++bb) { read_d(hcur, 0, bb); make_r(bb, 0); make_r(bb, 1); }
     v_adds(0, 0); v_hi(0, 0, 0); v_lo(0, 0, 0);
     v_adds(0, 2); v_hi(0, 0, 2); v_lo(0, 0, 2);
 #ifdef XD_CLOCKS
@@ -367,7 +416,11 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_done = __builtin_amdgcn_s_memrealtime(), xd_c_done = __builtin_readcyclecounter();
 #endif
-    __syncthreads();                                                         // every wave is past its last halo read: the M buffer may overwrite it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the clamped re-loads of the last chunks have landed too ...
+    __syncthreads();                                                         // ... and every wave is past its last halo read: the M buffer may overwrite the ring
+#ifdef XD_CLOCKS
+    const unsigned long long xd_t_e0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- epilogue: A^T M A + bias + ReLU (+ 2x2 max-pool).  A wave owns position ROW i = wave of every tile, i.e. all four columns j of
     // that row: the column combination M A (Y[i][0] = (m_i0 + m_i1) + m_i2, Y[i][1] = (m_i1 - m_i2) - m_i3) happens in registers, and only
@@ -398,6 +451,9 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
                 *reinterpret_cast<f32x4*>(dst + 32 * XD_MS) = y1;
             }
     __syncthreads();
+#ifdef XD_CLOCKS
+    const unsigned long long xd_t_e1 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int Ho = H >> 1, Wo = W >> 1;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -460,10 +516,12 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // timing build (tools/xd_clocks.py): wave 0 / lane 0 of every block leaves its stamps behind the (single-map) output
     if (tid == 0) {
         const unsigned long long t_out = __builtin_amdgcn_s_memrealtime();
-        float* rec = y_maps + (POOL ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) * Cout + (size_t)blockIdx.x * 8;
+        float* rec = y_maps + (POOL ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) * Cout + (size_t)blockIdx.x * 16;
         rec[0] = (float)(xd_t_loop - xd_t_in); rec[1] = (float)(xd_t_done - xd_t_loop); rec[2] = (float)(t_out - xd_t_done);
         rec[3] = (float)(xd_c_done - xd_c_loop); rec[4] = (float)(xd_t_in & 0xFFFFFF); rec[5] = (float)(t_out & 0xFFFFFF);
         rec[6] = (float)K16; rec[7] = 1.0f;
+        rec[8] = (float)(xd_t_issued - xd_t_in); rec[9] = (float)(xd_t_landed - xd_t_issued); rec[10] = (float)(xd_t_loop - xd_t_landed);
+        rec[11] = (float)(xd_t_e0 - xd_t_done); rec[12] = (float)(xd_t_e1 - xd_t_e0); rec[13] = (float)(t_out - xd_t_e1);
     }
 #endif
 }
@@ -494,6 +552,9 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     const long long total = (long long)gm.tbx * gm.tby * gm.ncb * N;
     if (total > 0x7fffffffLL) return FRCNN_EINVAL;
     gm.xg = ((long long)gm.tbx * gm.tby * N) % 8 == 0 ? 1 : 0;
+    auto magic = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+    gm.m_tbx = magic(gm.tbx); gm.m_tby = magic(gm.tby); gm.m_ncb = magic(gm.ncb);
+    if (total * std::max(gm.ncb, std::max(gm.tbx, gm.tby)) >= 0x100000000ll) return FRCNN_EUNSUPPORTED;
     const int u_rbt = cdiv(cout, gemm_x6t_col_tile(cout)) * gemm_x6t_col_tile(cout) / 32;
     if ((size_t)16 * (cin / 16) * u_rbt * HX_RB >= ((size_t)1 << 31)) return FRCNN_EUNSUPPORTED;   // the record bank behind one buffer descriptor
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;

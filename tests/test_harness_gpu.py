@@ -116,13 +116,14 @@ def test_evaluate_stream_map_equals_sequential_reference_loop(gpu_model):
         calc.add_image_results(scored_boxes_by_class_index=det, gt_boxes=gt)
         samples.append(Sample(im.numpy(), gt))                     # numpy (3,H,W), as the reference's dataset yields it
     want = 100.0 * calc.compute_mean_average_precision()
-    saved = gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows
+    saved = gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows, gpu_model.inflight_winograd_x3f_layers
     gpu_model.inflight_conv_blocks_target = gpu_model.inflight_winograd_tile_rows = 0
+    gpu_model.inflight_winograd_x3f_layers = ()        # the sequential loop's arithmetic in the in-flight slots: the two mAPs are then EQUAL
     try:
         got = E.evaluate(gpu_model, samples, inflight=4)
         got_limited = E.evaluate(gpu_model, samples, num_samples=3, inflight=2)
     finally:
-        gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows = saved
+        gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows, gpu_model.inflight_winograd_x3f_layers = saved
     print("mAP sequential %.6f%%, evaluate() %.6f%%" % (want, got))
     assert 0.0 < want < 100.0
     assert got == want
@@ -265,7 +266,9 @@ def test_host_feeder_equals_upload_then_predict(gpu_model, sd_cpu):
     img0, _, _ = I.preprocess_image(frames[0].numpy(), params, 600, False)
     assert np.array_equal(img0.cpu().numpy(), np.asarray(ref, dtype=np.float32))
     saved = gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows, gpu_model.inflight_x6_gemm_tiles
+    saved_x3f = gpu_model.inflight_winograd_x3f_layers
     gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows, gpu_model.inflight_x6_gemm_tiles = 0, 0, 0
+    gpu_model.inflight_winograd_x3f_layers = ()        # (the in-flight slots' one-launch layers differ from slot 0's by float32 rounding order)
     try:
         pinned = [f.pin_memory() for f in frames]
         pend = []
@@ -293,5 +296,6 @@ def test_host_feeder_equals_upload_then_predict(gpu_model, sd_cpu):
             assert np.array_equal(base[0][c], res[c]), c
     finally:
         gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows, gpu_model.inflight_x6_gemm_tiles = saved
+        gpu_model.inflight_winograd_x3f_layers = saved_x3f
     with pytest.raises(ValueError):
         feeder.submit(torch.zeros((3, 10, 10), dtype=torch.uint8), 0.05, slot=1)

@@ -291,17 +291,17 @@ def test_anchor_maps_argument_and_async_slots(gpu_model):
     for c in base[0]:
         assert np.array_equal(base[0][c], again[c])
     # three images in flight on three slots/streams give the same dicts as the sequential calls -- bit for bit when the
-    # in-flight slots use the same split-K granularity as the sequential path ...
-    saved = gpu_model.inflight_conv_blocks_target
-    gpu_model.inflight_conv_blocks_target = 0
+    # in-flight slots use the same split-K granularity and the same form of the 512-channel f32x3 layers as the sequential path ...
+    saved = gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_x3f_layers
+    gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_x3f_layers = 0, ()
     pend = [gpu_model.predict_async(im, 0.05, slot=i + 1) for i, im in enumerate(imgs)]
     for i, p in enumerate(pend):
         res = p.result()
         for c in base[i]:
             assert np.array_equal(base[i][c], res[c]), (i, c)
-    # ... and the same detections up to float32 summation order with the throughput setting (fewer, longer split-K units):
-    # identical partition per image whatever else is in flight, so repeated runs agree exactly with each other
-    gpu_model.inflight_conv_blocks_target = saved
+    # ... and the same detections up to float32 summation order with the throughput setting (fewer, longer split-K units, the 512-channel
+    # layers in the one-launch form): identical partition per image whatever else is in flight, so repeated runs agree exactly with each other
+    gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_x3f_layers = saved
     runs = []
     for _ in range(2):
         pend = [gpu_model.predict_async(im, 0.05, slot=i + 1) for i, im in enumerate(imgs)]

@@ -21,7 +21,7 @@ def run(name, cin, cout, h, w, pool, reps=20):
     oh, ow = (h // 2, w // 2) if pool else (h, w)
     th, tw = (h + 1) // 2, (w + 1) // 2
     nblk = ((th + 3) // 4) * ((tw + 15) // 16) * (cout // 64)
-    y = t.zeros((oh * ow * cout + 8 * nblk,), device=dev)
+    y = t.zeros((oh * ow * cout + 16 * nblk,), device=dev)
     wsb = int(lib.frcnn_conv3x3_winograd_x3_fused_workspace_bytes(1, h, w))
     ws = t.empty((wsb,), dtype=t.uint8, device=dev)
     flags = nv.RELU | (nv.POOL2 if pool else 0)
@@ -33,7 +33,7 @@ def run(name, cin, cout, h, w, pool, reps=20):
     e1.record()
     t.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3
-    o = y[oh * ow * cout:].view(nblk, 8).cpu().numpy().astype(np.float64)
+    o = y[oh * ow * cout:].view(nblk, 16).cpu().numpy().astype(np.float64)
     assert (o[:, 7] == 1.0).all()
     pro, loop, epi, cyc, t_in, t_out, k16 = (o[:, i] for i in range(7))
     k16 = k16[0]
@@ -44,6 +44,8 @@ def run(name, cin, cout, h, w, pool, reps=20):
           "p25 %.1f p50 %.1f p75 %.1f p100 %.1f us" % (name, cin, cout, h, w, nblk, us, span, pro.mean() / 100, loop.mean() / 100, loop.mean() / 100 / k16,
                                                        cyc.mean() / k16, (cyc / loop).mean() * 100, epi.mean() / 100,
                                                        np.percentile(start, 25), np.percentile(start, 50), np.percentile(start, 75), start.max()))
+    print("         before the loop: loads issued after %.2f us, landed + barrier %.2f us later, first operand %.2f us | after: wait for the "
+          "other waves %.2f us, column pass + LDS %.2f us, row pass + stores %.2f us" % tuple(o[:, i].mean() / 100 for i in range(8, 14)))
 
 
 if __name__ == "__main__":
