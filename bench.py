@@ -736,7 +736,7 @@ def main():
 
     x3_legs = {}
     if not is_resnet and not args.no_secondary and x3f:
-        # conv2_1 .. conv3_3 back on the float32 one-launch Winograd kernel and the 512-channel layers on their three launches in every slot
+        # conv1_2 .. conv3_3 back on the float32 one-launch Winograd kernel and the 512-channel layers on their three launches in every slot
         # (round 3's pipeline for those layers)
         inflight_x3f = model.inflight_winograd_x3f_layers
         model.winograd_x3f_layers = ()
@@ -957,7 +957,7 @@ def main():
                                 "cout x 2), against the dense bf16 / fp16 peak (the same 2500 TFLOP/s); f32_equivalent_tflops = the same launches counted "
                                 "once per float32 product; bytes = V records (6 / 4 B per element) read + M (4 B) written + the filter record bank"}
         # `roofline` = the kernel with the most GPU time per image, the other one rides along
-        # the one-launch f32x3 Winograd layers (wino_x3d_kernel; the class time includes their channel-maximum pass): 3 fp16 MFMAs per float32 product
+        # the one-launch f32x3 Winograd layers (wino_x3d_kernel): 3 fp16 MFMAs per float32 product
         r_x3f = None
         fl_named = x3f_winograd_layers(args.math, x6, x3f)
         if fl_named and timing.get("winograd_x3f", (0, 0))[1]:
@@ -966,7 +966,8 @@ def main():
             avg_s = (msf / 1e3) / lf
             ach = per_launch / avg_s / 1e12
             r_x3f = {"kernel": "wino_x3d_kernel (ONE-launch Winograd F(2x2,3x3) layer in the f32x3 arithmetic: operand formed in registers from the LDS-staged halo, "
-                               "filter fragments straight from L2, all 16 positions in accumulators: %s; the time includes the channel-maximum pass)"
+                               "filter fragments straight from L2, all 16 positions in accumulators: %s; every producer leaves its output's channel maxima, "
+                               "so no pass over a layer input remains in the class)"
                                % ", ".join(n for n, _ in fl_named),
                      "regime": regime, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": measured_traffic("wino_x3d_kernel"), "flops_per_launch": per_launch,

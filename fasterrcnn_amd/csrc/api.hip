@@ -186,6 +186,14 @@ int frcnn_conv3x3_c3(const float* d_x, const float* d_wp, const float* d_bias, f
     return launch_conv3x3_c3(d_x, d_wp, d_bias, d_y, H, W, cout, flags, as_stream(stream));
 }
 
+int frcnn_conv3x3_c3_cmax(const float* d_x, const float* d_wp, const float* d_bias, float* d_y, int H, int W,
+                          int cout, unsigned flags, float* d_cmax_out, void* stream)
+{
+    if (!d_x || !d_wp || !d_bias || !d_y || !d_cmax_out) return FRCNN_EINVAL;
+    if (flags & FRCNN_POOL2) return FRCNN_EUNSUPPORTED;
+    return launch_conv3x3_c3(d_x, d_wp, d_bias, d_y, H, W, cout, flags, as_stream(stream), d_cmax_out);
+}
+
 size_t frcnn_conv3x3_workspace_bytes(int H, int W, int cin, int cout) { return conv3x3_workspace_bytes(H, W, cin, cout); }
 
 int frcnn_conv3x3_nhwc(const float* d_x, const float* d_wp, const float* d_bias, float* d_y, int H, int W,
@@ -1144,7 +1152,9 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     if (wino && ((p->winograd_x3f_mask | (p->winograd_x3_mask & p->winograd_x6_mask)) & 0x1FFE) != 0) {
         int r0 = ensure_x3f_cmax(c, (size_t)H * W * sizeof(float), s);
         if (r0) return r0;
-        cmax_cleared = std::min((size_t)H * W / 2 + 4096, 2 * c->x3f_cmax_bytes / sizeof(float));
+        // (with conv1_2 in the one-launch table its pooled output's maxima join: H W / 4 more floats)
+        const size_t want = ((p->winograd_x3f_mask >> 1) & 1) ? (size_t)H * W + 8192 : (size_t)H * W / 2 + 4096;
+        cmax_cleared = std::min(want, 2 * c->x3f_cmax_bytes / sizeof(float));
         FRCNN_HIP_TRY(hipMemsetAsync(x3f_cmax_buffer(c, 1), 0, cmax_cleared * sizeof(float), s));
     }
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
@@ -1193,7 +1203,11 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     // stage 1: feature extractor (models/vgg16.py:76-96)
     float *A = c->act_a, *B = c->act_b;
     int h = H, wd = W;
-    STEP(1, launch_conv3x3_c3(d_image, w->conv_w[0], w->conv_b[0], A, h, wd, 64, R, s));
+    // conv1_1 leaves the channel maxima of its output for conv1_2 when that is a one-launch f32x3 layer (a plain store per pixel from the
+    // lanes that hold its 64 channels, into the ctx's scratch buffer [0]: no pass over the 153.6 MB tensor anywhere in the image)
+    float* c11_cmax = (wino && ((p->winograd_x3f_mask >> 1) & 1)) ? x3f_cmax_buffer(c, 0) : nullptr;
+    STEP(1, launch_conv3x3_c3(d_image, w->conv_w[0], w->conv_b[0], A, h, wd, 64, R, s, c11_cmax));
+    cmax_ready = c11_cmax;
     CONV(conv3(A, w->conv_w[1], w->conv_b[1], B, h, wd, 64, 64, RP));   h /= 2; wd /= 2;
     CONV(conv3(B, w->conv_w[2], w->conv_b[2], A, h, wd, 64, 128, R));
     CONV(conv3(A, w->conv_w[3], w->conv_b[3], B, h, wd, 128, 128, RP)); h /= 2; wd /= 2;

@@ -95,7 +95,7 @@ int launch_pack_stack_rows(const float* w1, const float* b1, int n1, const float
                            int n2, int k, int n_pad, float* wo, float* bo, hipStream_t s);
 
 int launch_conv3x3_c3(const float* x, const float* wp, const float* b, float* y, int H, int W,
-                      int cout, unsigned flags, hipStream_t s);
+                      int cout, unsigned flags, hipStream_t s, float* cmax_out = nullptr);
 size_t conv3x3_workspace_bytes(int H, int W, int cin, int cout);
 int conv3x3_blocks_target();
 void conv3x3_set_blocks_target(int target);     // split-K work-unit target of the calling thread's next launches (0 = default)

@@ -385,9 +385,12 @@ void conv3x3_c3_kernel(const float* __restrict__ x, const float* __restrict__ wp
 // at a 256-byte lane stride: 81 us for the 153.6 MB of a 600x1000 image = 2 TB/s).  The 3 x 3 x 66 input patch of the block
 // is staged in LDS (zero padding folded in), the quad's 27 x 4 weights live in registers; the fmaf order over k = ci*9 + r*3 + s
 // is the one of the kernel above (bit-identical results).
+// cmax_out (optional): the per-pixel maximum over the 64 output channels, [H][W] -- the scale source of an f32x3 layer that consumes this
+// tensor (csrc/wino_x3f.hip).  The 16 lanes of a pixel hold all of its channels, so it is four DPP row rotations and ONE plain store per
+// pixel: no atomics, no zeroed buffer, and the consumer does not read the 153.6 MB tensor once more (pixel_absmax_kernel).
 __global__ __launch_bounds__(256)
 void conv3x3_c3_q16_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-                           float* __restrict__ y, int H, int W, int relu)
+                           float* __restrict__ y, int H, int W, int relu, float* __restrict__ cmax_out)
 {
     constexpr int COUT = 64, SEG = 64, ROWS = 8;          // 8 rows x 64 pixels per block: the quad's weights are loaded once per 512 pixels
     __shared__ float in_s[3][ROWS + 2][SEG + 2];
@@ -432,6 +435,15 @@ void conv3x3_c3_q16_kernel(const float* __restrict__ x, const float* __restrict_
                 o[j] = relu ? fmaxf(t, 0.f) : t;
             }
             *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + x0 + p) * COUT + 4 * q) = o;
+            if (cmax_out) {
+                // (post-ReLU values are >= 0; without ReLU the consumer wants the maximum MAGNITUDE)
+                float m = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x128, 0xf, 0xf, false)));   // row_ror:8
+                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x124, 0xf, 0xf, false)));   // row_ror:4
+                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x122, 0xf, 0xf, false)));   // row_ror:2
+                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x121, 0xf, 0xf, false)));   // row_ror:1
+                if (q == 0) cmax_out[(size_t)yy * W + x0 + p] = m;
+            }
         }
     }
 }
@@ -579,11 +591,12 @@ int launch_conv3x3_nhwc(const float* x, const float* wp, const float* b, float* 
 }
 
 int launch_conv3x3_c3(const float* x, const float* wp, const float* b, float* y, int H, int W,
-                      int cout, unsigned flags, hipStream_t s)
+                      int cout, unsigned flags, hipStream_t s, float* cmax_out)
 {
     if (cout % 16 != 0 || H < 1 || W < 1) return FRCNN_EINVAL;
+    if (cmax_out && cout != 64) return FRCNN_EINVAL;                        // only the 64-channel kernel holds a pixel's channels in one DPP row
     if (cout == 64) {
-        hipLaunchKernelGGL(conv3x3_c3_q16_kernel, dim3(cdiv(W, 64), cdiv(H, 8)), dim3(256), 0, s, x, wp, b, y, H, W, (flags & FRCNN_RELU) ? 1 : 0);
+        hipLaunchKernelGGL(conv3x3_c3_q16_kernel, dim3(cdiv(W, 64), cdiv(H, 8)), dim3(256), 0, s, x, wp, b, y, H, W, (flags & FRCNN_RELU) ? 1 : 0, cmax_out);
         return check_launch();
     }
     dim3 grid(cdiv(H * W, 256), 1);

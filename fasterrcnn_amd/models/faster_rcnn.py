@@ -290,11 +290,12 @@ class FasterRCNNModel(nn.Module):
     @winograd_x3f_layers.setter
     def winograd_x3f_layers(self, names):
         """VGG-16, f32_winograd mode: the 3x3 layers that run as ONE-launch Winograd layers in the f32x3 arithmetic (csrc/wino_x3f.hip): any
-        of conv2_1 .. conv5_3 (cin % 32 == 0) that is not in winograd_x6_layers (a name in both runs as the x6 / x3 three-launch layer)."""
+        of conv1_2 .. conv5_3 (cin % 32 == 0) that is not in winograd_x6_layers (a name in both runs as the x6 / x3 three-launch layer).
+        With conv1_2 in the table conv1_1 leaves the channel maxima of its output behind (frcnn_conv3x3_c3_cmax)."""
         names = tuple(names)
         if names and self._is_resnet:
             raise NotImplementedError("winograd_x3f_layers applies to the VGG-16 feature extractor")
-        allowed = tuple(n for n in nv.X6_LAYER_BITS if n not in ("conv1_2", "rpn_trunk"))
+        allowed = tuple(n for n in nv.X6_LAYER_BITS if n != "rpn_trunk")          # (the RPN trunk: inflight_winograd_x3f_layers)
         for n in names:
             if n not in allowed:
                 raise ValueError("winograd_x3f_layers: %r cannot run as a one-launch f32x3 Winograd layer (choices: %s)" % (n, ", ".join(allowed)))
@@ -317,7 +318,7 @@ class FasterRCNNModel(nn.Module):
         if names and self._is_resnet:
             raise NotImplementedError("inflight_winograd_x3f_layers applies to the VGG-16 model")
         for n in names:
-            if n not in nv.X6_LAYER_BITS or n == "conv1_2":
+            if n not in nv.X6_LAYER_BITS:
                 raise ValueError("inflight_winograd_x3f_layers: unknown layer %r" % (n,))
         self._inflight_winograd_x3f_layers = names
 

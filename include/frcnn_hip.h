@@ -37,12 +37,13 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 9   /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
+#define FRCNN_ABI_VERSION 10  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
                                  5: bf16 gradient GEMMs (the *_math entry points); 6: x6t GEMM, x6 Winograd layers, frcnn_forward_params.winograd_x6_mask,
                                  timing classes 8 / 9; 7: batched feature extractor (frcnn_resnet_backbone, frcnn_resnet_forward_features,
                                  frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps); 8: the f32x3 arithmetic (frcnn_*_x3t, frcnn_*_winograd_x3,
                                  frcnn_forward_params.winograd_x3_mask, FRCNN_FC_F32X3T, frcnn_bottleneck_weights.x3_mask); 9: one-launch f32x3 Winograd layers
-                                 in the forward (frcnn_forward_params.winograd_x3f_mask, timing class 10), frcnn_roi_pool_x3t */
+                                 in the forward (frcnn_forward_params.winograd_x3f_mask, timing class 10), frcnn_roi_pool_x3t; 10: frcnn_conv3x3_c3_cmax, bits 1 (conv1_2)
+                                 and 13 (RPN trunk) of winograd_x3f_mask */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -118,6 +119,11 @@ int frcnn_pack_stack_rows(const float* d_w1, const float* d_b1, int n1,
  * d_w_packed from frcnn_pack_conv3x3_c3. */
 int frcnn_conv3x3_c3(const float* d_x_chw, const float* d_w_packed, const float* d_bias,
                      float* d_y, int H, int W, int cout, unsigned flags, void* stream);
+/* The same layer (cout = 64 only) that also leaves the per-pixel maximum |y| over the 64 output channels in d_cmax_out [H][W]: the scale
+ * source of an f32x3 layer that consumes y (d_cmax_in of frcnn_conv3x3_nhwc_winograd_x3_chain).  A plain store per pixel from the lanes
+ * that hold its channels (no atomics, nothing to zero); y is bit-identical to frcnn_conv3x3_c3's.  ABI 10. */
+int frcnn_conv3x3_c3_cmax(const float* d_x_chw, const float* d_w_packed, const float* d_bias,
+                          float* d_y, int H, int W, int cout, unsigned flags, float* d_cmax_out, void* stream);
 /* General layer on the f32 MFMA pipe: x NHWC [H][W][cin], y NHWC [H][W][cout] or, with
  * FRCNN_POOL2, [H/2][W/2][cout].  Requires cin % 16 == 0, cout % 64 == 0.
  * d_w_packed from frcnn_pack_conv3x3.  Layers whose output grid cannot fill the chip (the 37x62
@@ -516,7 +522,7 @@ typedef struct frcnn_forward_params {
     int32_t winograd_x3_mask;   /* a subset of winograd_x6_mask (VGG-16): the layers whose position GEMMs run in the f32x3 arithmetic instead (two
                                    fp16 terms per row-scaled operand, three MFMAs per product: csrc/wino_x3.hip); their weight pointers are
                                    frcnn_pack_conv3x3_winograd_x3's blobs.  ResNet: 0 */
-    int32_t winograd_x3f_mask;  /* round 4 (ABI 9), VGG-16, FRCNN_MATH_F32_WINOGRAD only: bit i set = 3x3 layer i (1 .. 12, 13 = the RPN trunk; disjoint from
+    int32_t winograd_x3f_mask;  /* round 4 (ABI 9), VGG-16, FRCNN_MATH_F32_WINOGRAD only: bit i set = 3x3 layer i (1 = conv1_2 .. 12, 13 = the RPN trunk; disjoint from
                                    winograd_x6_mask) runs as a ONE-LAUNCH Winograd layer in the f32x3 arithmetic (csrc/wino_x3f.hip: operand formed in
                                    registers from the LDS-staged halo, filter fragments straight from L2, all 16 positions in accumulators, no V / M
                                    scratch; the three-launch f32x3 layer's arithmetic up to the rounding order of the output transform) and its weight

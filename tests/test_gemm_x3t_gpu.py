@@ -449,7 +449,7 @@ def test_x3_layers_chain_their_channel_maxima(one_launch, h, w, cin, cout, pool)
 
 def test_inflight_slots_run_the_512_channel_layers_in_the_one_launch_form(gpu_model):
     """FasterRCNNModel.layer_tables: slot 0 (forward / predict) runs conv4_1 .. conv5_3 and the RPN trunk as three-launch f32x3 layers, the
-    in-flight slots of predict_async as one-launch layers on the same blobs (12 launches of timing class 10, none of the x6 classes).  The
+    in-flight slots of predict_async as one-launch layers on the same blobs (13 launches of timing class 10, none of the x6 classes).  The
     two forms differ by the rounding order of the output transform only: feature maps within 2e-6 of the largest activation, the same
     proposals as rows -- apart by what two float32 evaluations that are each ~1.2e-4 px from the float64 truth differ by (measured: worst
     row 3.4e-4 px), inside north_star's 1e-3 px of each other."""
@@ -468,7 +468,7 @@ def test_inflight_slots_run_the_512_channel_layers_in_the_one_launch_form(gpu_mo
         torch.cuda.synchronize()
         t = ctx.timing_read(reset=True)
         ctx.timing_enable(False)
-    assert t["winograd_x3f"][1] == 12 and t["winograd_x6_gemm"][1] == 0 and t["winograd_x6_transforms"][1] == 0 and t["winograd_gemm"][1] == 1
+    assert t["winograd_x3f"][1] == 13 and t["winograd_x6_gemm"][1] == 0 and t["winograd_x6_transforms"][1] == 0 and t["winograd_gemm"][1] == 0
     rel = float((fm0 - fm1).abs().max()) / float(fm0.abs().max())
     a, b = p0.cpu().numpy(), p1.cpu().numpy()
     assert a.shape == b.shape

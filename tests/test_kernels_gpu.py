@@ -91,6 +91,33 @@ def test_conv3x3_c3(H, W):
     check_conv(y, x, w, b, True, False, "conv_c3 %dx%d" % (H, W))
 
 
+@pytest.mark.parametrize("H,W,relu", [(600, 1000, True), (33, 70, True), (1, 1, True), (5, 257, False)])
+def test_conv3x3_c3_leaves_the_channel_maxima(H, W, relu):
+    """frcnn_conv3x3_c3_cmax (round 4): conv1_1 writes the per-pixel maximum |y| over its 64 output channels next to y -- the scale source of
+    conv1_2 as a one-launch f32x3 layer.  y is the bits of frcnn_conv3x3_c3, the maxima those of frcnn_pixel_absmax over y (what the
+    consumer would otherwise compute with one more pass over the tensor); cout != 64 is refused."""
+    g = torch.Generator().manual_seed(H * 1000 + W + 1)
+    x = gpu(torch.randn((3, H, W), generator=g) * 60)
+    w = gpu(torch.randn((64, 3, 3, 3), generator=g) * 0.2)
+    b = gpu(torch.randn((64,), generator=g))
+    lib = nv.lib()
+    wp = torch.empty((27, 64), device=DEV)
+    nv.check(lib.frcnn_pack_conv3x3_c3(nv.ptr(w), nv.ptr(wp), 64, S()), "pack")
+    fl = nv.RELU if relu else 0
+    y0 = torch.empty((H, W, 64), device=DEV)
+    nv.check(lib.frcnn_conv3x3_c3(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(y0), H, W, 64, fl, S()), "conv_c3")
+    y1 = torch.full((H, W, 64), float("nan"), device=DEV)
+    cm = torch.full((H * W,), float("nan"), device=DEV)
+    nv.check(lib.frcnn_conv3x3_c3_cmax(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(y1), H, W, 64, fl, nv.ptr(cm), S()), "conv_c3_cmax")
+    want = torch.empty((H * W,), device=DEV)
+    nv.check(lib.frcnn_pixel_absmax(nv.ptr(y0), nv.ptr(want), H * W, 64, S()), "pixel_absmax")
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.equal(cm, want) and torch.equal(cm, y0.abs().amax(dim=2).reshape(-1))
+    assert lib.frcnn_conv3x3_c3_cmax(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(y1), H, W, 32, fl, nv.ptr(cm), S()) == -1      # FRCNN_EINVAL
+    assert lib.frcnn_conv3x3_c3_cmax(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(y1), H, W, 64, fl, None, S()) == -1
+
+
 @pytest.mark.parametrize("H,W,cin,cout,pool,relu", [
     (37, 62, 512, 512, False, True),     # block5 / RPN trunk shape
     (75, 125, 256, 512, True, True),     # block4 with fused pool (odd H, W: floor)

@@ -256,9 +256,9 @@ def test_model_layer_table_x6_vs_float32_winograd(gpu_model):
             # the table is honoured: one bf16- / fp16-pipe GEMM launch (+ at most one split-K reduction) and two timed transform steps per
             # x6 layer (a layer in the f32x3 arithmetic times its channel-maximum pass together with its input transform)
             n6 = len(layers)
-            nf = len([n for n in gpu_model.winograd_x3f_layers if n not in layers])      # one-launch f32x3 layers (round 4: conv2_1 .. conv3_3)
+            nf = len([n for n in gpu_model.winograd_x3f_layers if n not in layers])      # one-launch f32x3 layers (round 4: conv1_2 .. conv3_3)
             assert n6 <= t["winograd_x6_gemm"][1] <= 2 * n6 and t["winograd_x6_transforms"][1] == 2 * n6
-            assert t["winograd_x3f"][1] == nf == len(nv.DEFAULT_X3F_LAYERS_VGG16) == 5
+            assert t["winograd_x3f"][1] == nf == len(nv.DEFAULT_X3F_LAYERS_VGG16) == 6
             assert t["winograd_gemm"][1] == 13 - n6 - nf
     finally:
         gpu_model.winograd_x6_layers = nv.DEFAULT_X6_LAYERS_VGG16

@@ -17,6 +17,7 @@ from fasterrcnn_amd.models.vgg16 import VGG16Backbone
 
 X6 = ("conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3", "rpn_trunk")
 X3F = ("conv2_2", "conv3_1", "conv3_2", "conv3_3")
+X3F_ALL = ("conv1_2", "conv2_1") + X3F
 C4 = ("conv4_1", "conv4_2", "conv4_3")
 C5 = ("conv5_1", "conv5_2", "conv5_3")
 
@@ -28,10 +29,11 @@ def without(names, drop):
 TABLES = {
     "default": {},
     "no_x3f": {"winograd_x3f_layers": ()},
-    "x3f_conv4": {"winograd_x6_layers": without(X6, C4), "winograd_x3_layers": without(X6, C4), "winograd_x3f_layers": X3F + C4},
-    "x3f_conv5": {"winograd_x6_layers": without(X6, C5), "winograd_x3_layers": without(X6, C5), "winograd_x3f_layers": X3F + C5},
-    "x3f_conv45": {"winograd_x6_layers": ("rpn_trunk",), "winograd_x3_layers": ("rpn_trunk",), "winograd_x3f_layers": X3F + C4 + C5},
-    "x3f_conv2_1": {"winograd_x3f_layers": ("conv2_1",) + X3F},
+    "no_inflight_x3f": {"inflight_winograd_x3f_layers": ()},
+    "inflight_conv4": {"inflight_winograd_x3f_layers": C4},
+    "inflight_conv5": {"inflight_winograd_x3f_layers": C5 + ("rpn_trunk",)},
+    "no_conv1_2": {"winograd_x3f_layers": ("conv2_1",) + X3F},
+    "no_conv2_1": {"winograd_x3f_layers": X3F},
 }
 
 
@@ -40,14 +42,14 @@ def main():
     ap.add_argument("--inflight", type=int, default=3)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--repeats", type=int, default=3)
-    ap.add_argument("--tables", default="default,x3f_conv4,x3f_conv5,x3f_conv45,x3f_conv2_1,default")
+    ap.add_argument("--tables", default="default,no_inflight_x3f,no_conv1_2,no_x3f,default")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
     model.load_state_dict(synthetic.vgg16_state_dict(0), strict=True)
     model = model.to(dev).eval()
     pool = [synthetic.image(100 + i, 600, 1000).unsqueeze(0).to(dev) for i in range(8)]
-    base = {k: getattr(model, k) for k in ("winograd_x6_layers", "winograd_x3_layers", "winograd_x3f_layers", "fc_math_mode")}
+    base = {k: getattr(model, k) for k in ("winograd_x6_layers", "winograd_x3_layers", "winograd_x3f_layers", "inflight_winograd_x3f_layers", "fc_math_mode")}
     n = max(1, args.inflight)
 
     def run(steps):

@@ -30,6 +30,7 @@ VGG_TABLES = {
     "x3_conv_only": {"winograd_x6_layers": X6, "winograd_x3_layers": X6, "winograd_x3f_layers": (), "fc_math_mode": "f32"},
     "x3_fc_only": {"winograd_x6_layers": (), "winograd_x3_layers": (), "winograd_x3f_layers": (), "fc_math_mode": "f32x3"},
     "x3f_only": {"winograd_x6_layers": (), "winograd_x3_layers": (), "winograd_x3f_layers": X3F, "fc_math_mode": "f32"},
+    "x3f_conv1_2": {"winograd_x3f_layers": ("conv1_2", "conv2_1") + X3F},
     "x3_everything": {"winograd_x6_layers": X6, "winograd_x3_layers": X6, "winograd_x3f_layers": ("conv2_1",) + X3F, "fc_math_mode": "f32x3"},
 }
 RESNET_TABLES = {
