@@ -39,9 +39,13 @@ __device__ __forceinline__ int xd_div(int n, int d, unsigned m) { return d == 1 
 // the MFMA-free ablation at 2.3): 2800-2880 cycles per chunk against the 1536 of its 48 MFMAs.  The MFMA stream alone runs at 1581, the
 // vector instructions alone (no MFMA) at 1211, and together they ADD rather than overlap: ~370 non-MFMA instructions per chunk are 7.7 per
 // MFMA, and one wave per SIMD issues in order.  History of the loop: 3150-3260 cycles with the halo staged through registers (the
-// ds_write of a chunk's halo waited ~570 cycles for loads issued six steps earlier); before the loop 3.7-4.2 us (one memory round trip:
-// every load of the prologue leaves back to back after the address arithmetic -- the earlier order was four round trips, 4.4-4.9 us), after
-// it 4.3-5.2 us per block (2,200 instructions: 256 accumulator reads, the scales, the column pass through LDS, the row pass).
+// ds_write of a chunk's halo waited ~570 cycles for loads issued six steps earlier).  Per block around the loop: 3.0 us before it (ONE memory
+// round trip: the halo pixels' channel maxima, the scales and the bias go to LDS by DMA, the first filter pieces to registers, halo(0..2)
+// to the ring, all issued back to back after the address arithmetic -- the first order was four round trips, 4.4-4.9 us) and 3.7-4.3 us
+// after it (2,070 instructions: 256 accumulator reads, the scales, the column pass through LDS, the row pass, the output's channel maxima).
+// A PERSISTENT form of the kernel (one block per CU walking its items, the next item's loads issued at the start of the epilogue, the Y
+// buffer next to the ring instead of over it) was built and measured: the loads hide completely (0.02 us of wait) -- and the item costs
+// the same, because prologue and epilogue are bound by instruction issue (~5 cycles each), not by the round trip; not in the tree.
 typedef float xd_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 xd_f16x2 __attribute__((ext_vector_type(2)));
 
@@ -56,7 +60,9 @@ static constexpr int XD_HBUF_FLOATS = XD_HBUF_BYTES / 4;
 typedef __attribute__((address_space(3))) void* xd_lds_ptr;
 static constexpr int XD_MS = 68;                                              // floats between two tiles of the epilogue's M buffer (64 + 4: conflict-free)
 static constexpr int XD_M_BYTES = 16 * 32 * XD_MS * 4;                       // 139,264: the epilogue's Y buffer [2 halves][4 rows][2][32 tiles][68] (>= the three halo buffers' 86,016)
-static constexpr size_t XD_LDS_BYTES = XD_M_BYTES + 16 * 64 * 4 + 64 * 4;     // + the block's filter scales [16][64] and bias [64]: 143,616
+static constexpr int XD_SC_OFFSET = XD_M_BYTES;                               // the block's filter scales [16][64] and bias [64] (4,352 B)
+static constexpr int XD_CM_OFFSET = XD_SC_OFFSET + 16 * 64 * 4 + 64 * 4;      // the channel maxima of the block's 10 x 34 halo pixels (DMA: 512 floats)
+static constexpr size_t XD_LDS_BYTES = XD_CM_OFFSET + 512 * 4;                // 145,664
 
 template <int N> struct XdInt { static constexpr int value = N; };
 #ifndef XD_ABLATE
@@ -71,6 +77,16 @@ __device__ __forceinline__ float xd_rowmax16(float v)
     v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)));   // row_ror:2
     v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)));   // row_ror:1
     return v;
+}
+
+// a - b on four floats as two v_pk_add_f32 with the negate modifier (the compiler scalarises a float32 vector subtraction into four v_sub_f32:
+// there is no v_pk_sub_f32 and it does not fold the negation into the packed add).  Epilogue only: beside MFMAs packed float32 is the slow form.
+__device__ __forceinline__ f32x4 xd_sub4(f32x4 a, f32x4 b)
+{
+    xd_f32x2 a0 = {a[0], a[1]}, a1 = {a[2], a[3]}, b0 = {b[0], b[1]}, b1 = {b[2], b[3]}, r0, r1;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r0) : "v"(a0), "v"(b0));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r1) : "v"(a1), "v"(b1));
+    return f32x4{r0[0], r0[1], r1[0], r1[1]};
 }
 
 __device__ __forceinline__ void xd_lds_barrier()
@@ -127,24 +143,11 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cmax), 0, H * W * (int)sizeof(float), 0x00020000);
 
     const int tl = lane & 31, tyl = tl >> 4, txl = tl & 15, kh = lane >> 5;
-    const int tx = XF_TC * bx + txl;
-    // The 2 x 16 channel maxima of this lane's tiles: offsets now, loads below with everything else the prologue fetches (ONE round trip
-    // to memory for all of it; the address arithmetic of the whole prologue comes first so that nothing touches a register with a load in flight).
-    // An absent row / column gets an offset past the descriptor's size: row and column parts are added, 2^31 and 2^30 mark the absent ones.
+    // The channel maxima of the block's 10 x 34 halo pixels reach LDS by DMA with everything else the prologue fetches (ONE round trip to
+    // memory for all of it; the address arithmetic of the whole prologue comes first so that nothing touches a register with a load in
+    // flight); every lane then reduces the 4 x 4 of each of its two tiles to the tile's scale.  Absent pixels read as 0 (offset past the
+    // descriptor's size).  (As 2 x 16 register loads per lane this was 32 loads and ~100 address instructions of every block's prologue.)
     float mult[2], vinv[2];
-    float dm[2][16];
-    int dm_row[2][4], dm_col[4];
-    {
-        const int x0 = 2 * tx - 1;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dm_col[c] = (x0 + c >= 0 && x0 + c < W) ? (x0 + c) * 4 : 0x40000000;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int y0 = 2 * (4 * by + 2 * h + tyl) - 1;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) dm_row[h][a] = (y0 + a >= 0 && y0 + a < H) ? (y0 + a) * W * 4 : (int)0x80000000u;
-        }
-    }
 
     // ---- halo staging by LDS-DMA: lane piece P = (7 it + ... ) -> LDS byte 16 P of the buffer = pixel slot P / 5, part P % 5 (4 = padding) ------
     // slot order [row][column parity][17]: the de-interleaved columns of the patch reads below
@@ -355,21 +358,26 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // block's 16 x 64 filter scales and 64 biases (on their way to LDS: the epilogue has no register to prefetch them into and would
     // otherwise wait for each of its 64 scale vectors in turn), then -- their source offsets computed under those loads -- halo(0 .. 2).  Their consumers follow below -- the earlier order
     // (maxima, reduce, scales -> LDS, bias -> LDS, then the halo) was four round trips to memory, 4 us of every block.
-    float* const sc_lds = reinterpret_cast<float*>(smem_xf + XD_M_BYTES);
-    const int sc_p = tid >> 4, sc_q = (tid & 15) * 4;
-    const float* const uinv0 = reinterpret_cast<const float*>(ublob + (size_t)16 * K16 * u_rbt * HX_RB) + (size_t)sc_p * (u_rbt * 32) + 64 * cb + sc_q;
-    const float* const bias0 = bias + 64 * cb + 4 * (tid & 15);
+    float* const sc_lds = reinterpret_cast<float*>(smem_xf + XD_SC_OFFSET);
+    // the block's 16 x 64 filter scales and 64 biases -> LDS by DMA (16 bytes per thread = the [16][64] layout; the bias: 16 lanes): the
+    // epilogue has no register to prefetch them into and would otherwise wait for each of its 64 scale vectors in turn
+    const float* const uinv0 = reinterpret_cast<const float*>(ublob + (size_t)16 * K16 * u_rbt * HX_RB) + (size_t)(tid >> 4) * (u_rbt * 32) + 64 * cb + (tid & 15) * 4;
+    int cm_src[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const unsigned P = (unsigned)(tid + 256 * q);
+        const unsigned hr = __umul24(P, 1928u) >> 16, hc = P - (unsigned)XF_HC * hr;              // P / 34, P % 34
+        const int gy = hy0 + (int)hr, gx = hx0 + (int)hc;
+        const bool inb = hr < (unsigned)X3_HR && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        cm_src[q] = inb ? (int)((__umul24((unsigned)gy, (unsigned)W) + (unsigned)gx) * 4u) : (int)0xFFFFFFF0u;
+    }
     XD_FENCE();
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                dm[h][4 * a + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, dm_row[h][a] + dm_col[c], 0, 0));
+    for (int q = 0; q < 2; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(mrs, (xd_lds_ptr)(smem_xf + XD_CM_OFFSET + (q * 4 + wave_u) * 256), 4, cm_src[q], 0, 0, 0);
     load_u(0, XdInt<0>{}, XdInt<0>{}); load_u(0, XdInt<0>{}, XdInt<1>{}); load_u(0, XdInt<0>{}, XdInt<2>{}); load_u(0, XdInt<0>{}, XdInt<3>{});
-    const f32x4 sc_v = *reinterpret_cast<const f32x4*>(uinv0);
-    const f32x4 bias_v = *reinterpret_cast<const f32x4*>(bias0);             // (every thread: 16 threads' worth is kept)
+    __builtin_amdgcn_global_load_lds(uinv0, (xd_lds_ptr)(smem_xf + XD_SC_OFFSET + wave_u * 1024), 16, 0, 0);
+    if (wave_u == 0 && lane < 16) __builtin_amdgcn_global_load_lds(bias + 64 * cb + 4 * lane, (xd_lds_ptr)(smem_xf + XD_SC_OFFSET + 4096), 16, 0, 0);
     XD_FENCE();
     halo_sources();                                                          // (under the loads above)
     XD_FENCE();
@@ -377,20 +385,25 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     dma_halo(hnxt, (K16 > 1 ? 1 : 0) * 64, XdInt<0>{}, XdInt<XD_NDMA>{});
     dma_halo(hthird, (K16 > 2 ? 2 : K16 - 1) * 64, XdInt<0>{}, XdInt<XD_NDMA>{});
     XD_FENCE();
-    *reinterpret_cast<f32x4*>(sc_lds + sc_p * 64 + sc_q) = sc_v;
-    *reinterpret_cast<f32x4*>(sc_lds + 1024 + 4 * (tid & 15)) = bias_v;       // (sixteen threads per slot store the same bytes: no branch for the load to sink into)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float dmax = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) dmax = fmaxf(dmax, dm[h][q]);
-        hx_row_scale(4.0f * dmax, mult[h], vinv[h]);
-    }
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_issued = __builtin_amdgcn_s_memrealtime();
 #endif
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XD_NDMA) : "memory");       // everything but halo(1) and halo(2): halo(0) and the first filter pieces are in
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XD_NDMA) : "memory");       // everything but halo(1) and halo(2): the maxima, the scales, halo(0) and the first filter pieces are in
     xd_lds_barrier();
+    {   // the lane's two tile scales from the halo pixels' channel maxima (rows 4 h + 2 tyl + a, columns 2 txl + c)
+        const float* cm = reinterpret_cast<const float*>(smem_xf + XD_CM_OFFSET) + (2 * tyl) * XF_HC + 2 * txl;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float dmax = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const xd_f32x2 u = *reinterpret_cast<const xd_f32x2*>(cm + (4 * h + a) * XF_HC);
+                const xd_f32x2 v = *reinterpret_cast<const xd_f32x2*>(cm + (4 * h + a) * XF_HC + 2);
+                dmax = fmaxf(fmaxf(dmax, fmaxf(u[0], u[1])), fmaxf(v[0], v[1]));
+            }
+            hx_row_scale(4.0f * dmax, mult[h], vinv[h]);
+        }
+    }
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_landed = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -429,27 +442,30 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // pass.  A tile's 64 channels are 68 floats apart: with 64 the 32 lanes of a ds_write_b128 would hit the same four banks.
     float* const ybuf = reinterpret_cast<float*>(smem_xf);                   // [half 2][row i 4][b 2][tile 32][68]
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int g = 0; g < 4; ++g) {
+            const int co = 32 * ct + 8 * g + 4 * kh;                     // the MFMA's row operand was the filter: accumulator rows = channels
+            f32x4 sb[4];                                                 // one read of the four scale vectors serves both tile halves
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = 32 * ct + 8 * g + 4 * kh;                 // the MFMA's row operand was the filter: accumulator rows = channels
+            for (int j = 0; j < 4; ++j) sb[j] = *reinterpret_cast<const f32x4*>(sc_lds + (4 * wave + j) * 64 + co);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
                 // (whole-vector expressions: no MFMA runs beside the epilogue, so the packed float32 instructions they become are the cheap form here)
                 f32x4 m[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4 sb = *reinterpret_cast<const f32x4*>(sc_lds + (4 * wave + j) * 64 + co);
                     const f32x4 a = {acc[h][j][ct][4 * g], acc[h][j][ct][4 * g + 1], acc[h][j][ct][4 * g + 2], acc[h][j][ct][4 * g + 3]};
-                    m[j] = a * sb;
+                    m[j] = a * sb[j];
                 }
                 const f32x4 vi = {vinv[h], vinv[h], vinv[h], vinv[h]};       // the tile's 2^-e: exact, commutes with every rounding above
                 const f32x4 y0 = ((m[0] + m[1]) + m[2]) * vi;
-                const f32x4 y1 = ((m[1] - m[2]) - m[3]) * vi;
+                const f32x4 y1 = xd_sub4(xd_sub4(m[1], m[2]), m[3]) * vi;
                 float* dst = ybuf + ((((h * 4 + wave) * 2) * 32 + tl) * XD_MS) + co;
                 *reinterpret_cast<f32x4*>(dst) = y0;
                 *reinterpret_cast<f32x4*>(dst + 32 * XD_MS) = y1;
             }
+        }
     __syncthreads();
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_e1 = __builtin_amdgcn_s_memrealtime();
@@ -475,7 +491,7 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
             o[0][bb] = ((Y[0][bb] + Y[1][bb]) + Y[2][bb]) + bv;
-            o[1][bb] = ((Y[1][bb] - Y[2][bb]) - Y[3][bb]) + bv;
+            o[1][bb] = xd_sub4(xd_sub4(Y[1][bb], Y[2][bb]), Y[3][bb]) + bv;
         }
         if (relu) {
 #pragma unroll
