@@ -290,7 +290,10 @@ def train_step_leg(backbone, dev, steps=10, warmup=3, lr=1e-6, pool=2, grad_math
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     return {"ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "math": model.math_mode,
-            "dtype": "f32" if grad_math == "f32" else "f32 forward / data gradients, bf16 gradient GEMMs (f32 accumulation, f32 master weights)",
+            "dtype": "f32" if grad_math == "f32" else (
+                "bf16 operands, f32 accumulation: every gradient GEMM%s; f32 master weights, losses and SGD" % (
+                    " and the forward / data-gradient convolutions of the trainable bottlenecks (layer2-4)" if backbone != "vgg16" else
+                    " (the 3x3 forward / data-gradient convolutions stay f32 Winograd layers)")),
             "roi": roi_pooling, "first_total_loss": round(float(losses[0]), 5), "last_total_loss": round(float(losses[-1]), 5)}
 
 

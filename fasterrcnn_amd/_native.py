@@ -31,7 +31,7 @@ SYMBOLS = (
     "frcnn_nms", "frcnn_roi_pool", "frcnn_roi_pool_x3t", "frcnn_detections", "frcnn_ctx_create", "frcnn_ctx_create_proposals", "frcnn_ctx_destroy",
     "frcnn_ctx_bytes", "frcnn_vgg16_forward", "frcnn_ctx_tensor", "frcnn_ctx_timing_enable",
     "frcnn_ctx_timing_read",
-    "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv7x7_s2_c3",
+    "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv_nhwc_math", "frcnn_conv7x7_s2_c3",
     "frcnn_maxpool3x3_s2_nhwc", "frcnn_spatial_mean_nhwc", "frcnn_resnet_forward", "frcnn_rpn_targets",
     "frcnn_pack_conv3x3_x6", "frcnn_conv3x3_nhwc_x6", "frcnn_preprocess_workspace_bytes", "frcnn_preprocess",
     "frcnn_conv3x3_uses_winograd", "frcnn_resnet_block_uses_winograd", "frcnn_pack_conv3x3_winograd",
@@ -55,7 +55,7 @@ SYMBOLS = (
     "frcnn_gemm_tn_workspace_bytes", "frcnn_gemm_tn", "frcnn_conv3x3_wgrad_workspace_bytes", "frcnn_conv3x3_wgrad",
     "frcnn_pack_conv3x3_dgrad", "frcnn_relu_backward", "frcnn_add_inplace", "frcnn_maxpool2x2_backward",
     "frcnn_roi_pool_backward_workspace_bytes", "frcnn_roi_pool_backward", "frcnn_transpose", "frcnn_sgd_step",
-    "frcnn_conv_wgrad_workspace_bytes", "frcnn_conv_wgrad", "frcnn_conv_dgrad_workspace_bytes", "frcnn_conv_dgrad",
+    "frcnn_conv_wgrad_workspace_bytes", "frcnn_conv_wgrad", "frcnn_conv_dgrad_workspace_bytes", "frcnn_conv_dgrad", "frcnn_conv_dgrad_math",
     "frcnn_pack_conv_dgrad", "frcnn_scale_rows", "frcnn_bn_scale_shift", "frcnn_spatial_mean_backward",
 )
 
@@ -261,6 +261,7 @@ _SIGNATURES = {
     "frcnn_fold_bn_pack": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     "frcnn_conv_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "frcnn_conv_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_conv_nhwc_math": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _i, _vp, _sz, _vp]),
     "frcnn_conv7x7_s2_c3": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp]),
     "frcnn_maxpool3x3_s2_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "frcnn_spatial_mean_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -305,6 +306,7 @@ _SIGNATURES = {
     "frcnn_conv_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "frcnn_conv_dgrad_workspace_bytes": (C.c_size_t, [_i] * 8),
     "frcnn_conv_dgrad": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "frcnn_conv_dgrad_math": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "frcnn_pack_conv_dgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "frcnn_scale_rows": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "frcnn_bn_scale_shift": (C.c_int, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),

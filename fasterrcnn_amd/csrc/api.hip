@@ -478,6 +478,16 @@ int frcnn_conv_nhwc(const float* d_x, const float* d_wp, const float* d_bias, co
                               d_ws, ws_bytes, as_stream(stream));
 }
 
+int frcnn_conv_nhwc_math(const float* d_x, const float* d_wp, const float* d_bias, const float* d_residual, float* d_y,
+                         int N, int H, int W, int cin, int cout, int ksize, int stride, int pad, unsigned flags, int math,
+                         void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_x || !d_wp || !d_bias || !d_y) return FRCNN_EINVAL;
+    if (flags & FRCNN_POOL2) return FRCNN_EUNSUPPORTED;
+    return launch_conv_gather(d_x, d_wp, d_bias, d_residual, d_y, N, H, W, cin, cout, ksize, stride, pad, flags,
+                              d_ws, ws_bytes, as_stream(stream), math);
+}
+
 int frcnn_conv7x7_s2_c3(const float* d_x, const float* d_wp, const float* d_bias, float* d_y, int H, int W,
                         int cout, unsigned flags, void* stream)
 {
@@ -684,6 +694,14 @@ int frcnn_conv_dgrad(const float* d_dz, const float* d_wd, const float* d_residu
     if (!d_dz || !d_wd || !d_dx) return FRCNN_EINVAL;
     return launch_conv_dgrad(d_dz, d_wd, d_residual, d_dx, N, H, W, cin, cout, ksize, stride, pad, d_ws, ws_bytes,
                              as_stream(stream));
+}
+
+int frcnn_conv_dgrad_math(const float* d_dz, const float* d_wd, const float* d_residual, float* d_dx, int N, int H, int W,
+                          int cin, int cout, int ksize, int stride, int pad, int math, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_dz || !d_wd || !d_dx) return FRCNN_EINVAL;
+    return launch_conv_dgrad(d_dz, d_wd, d_residual, d_dx, N, H, W, cin, cout, ksize, stride, pad, d_ws, ws_bytes,
+                             as_stream(stream), math);
 }
 
 int frcnn_pack_conv_dgrad(const float* d_wp, float* d_wd, int taps, int cout, int cin, void* stream)

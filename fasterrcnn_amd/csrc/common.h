@@ -111,7 +111,7 @@ int launch_conv3x3_x6(const float* x, const void* wq, const float* b, float* y, 
 size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R, int stride, int pad);
 int launch_conv_gather(const float* x, const float* wp, const float* bias, const float* residual, float* y,
                        int N, int H, int W, int cin, int cout, int R, int stride, int pad, unsigned flags,
-                       void* ws, size_t ws_bytes, hipStream_t s);
+                       void* ws, size_t ws_bytes, hipStream_t s, int math = FRCNN_GRAD_F32);
 int launch_conv7x7_s2_c3(const float* x, const float* wp, const float* b, float* y, int H, int W, int cout,
                          unsigned flags, hipStream_t s);
 int launch_maxpool3x3_s2(const float* x, float* y, int H, int W, int c, hipStream_t s);
@@ -301,7 +301,7 @@ int launch_conv_wgrad(const float* x, const float* dz, float* dwp, int N, int H,
                       int pad, void* ws, size_t ws_bytes, hipStream_t s, int math = FRCNN_GRAD_F32);
 size_t conv_dgrad_workspace_bytes(int N, int H, int W, int cin, int cout, int R, int stride, int pad);
 int launch_conv_dgrad(const float* dz, const float* wd, const float* residual, float* dx, int N, int H, int W, int cin,
-                      int cout, int R, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t s);
+                      int cout, int R, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t s, int math = FRCNN_GRAD_F32);
 int launch_pack_conv_dgrad(const float* wp, float* wd, int taps, int cout, int cin, hipStream_t s);
 int launch_scale_rows(const float* src, const float* scale, float* dst, int taps, int cout, int cin, hipStream_t s);
 int launch_bn_scale_shift(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,

@@ -258,6 +258,196 @@ void conv_gather_mfma_kernel(const float* __restrict__ x, const float* __restric
     }
 }
 
+// ---- bf16 operands (BASELINE configs[4]: the reduced-precision train step's forward and data-gradient convolutions) ---------------------------
+// The same gather implicit GEMM with both operands rounded to bfloat16 (round to nearest even: v_cvt_pk_bf16_f32, torch's .bfloat16()) on
+// their way INTO LDS and multiplied on the bf16 matrix pipe: ONE v_mfma_f32_32x32x16_bf16 per K-stage and accumulator where the float32
+// kernel issues eight v_mfma_f32_32x32x2f32 (16x the matrix rate), float32 accumulation, the float32 epilogue (bias, residual, ReLU)
+// unchanged.  Products of bf16 values are exact in float32, so the result differs from the float32 convolution of the ROUNDED operands
+// by the accumulation order only -- what oracle/train_oracle.py (grad_math = "bf16") states.  LDS rows are 16 bf16 = 32 bytes (a lane's
+// fragment = the 16 bytes at [row][8 (lane >> 5)]: the natural k order of the instruction), half the float32 kernel's traffic.
+typedef __bf16 gb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 gb_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float gb_f32x2 __attribute__((ext_vector_type(2)));
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256)
+void conv_gather_bf16_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                             const float* __restrict__ bias, const float* __restrict__ residual,
+                             float* __restrict__ y, float* __restrict__ ws, GatherShape g,
+                             int stages_per_split, int relu)
+{
+    using C = GatherCfg<TM, TN, WM, WN>;
+    constexpr int ROW = 16;                                   // bf16 per LDS row
+    __shared__ __attribute__((aligned(16))) __bf16 at_s[2][C::BM * ROW];
+    __shared__ __attribute__((aligned(16))) __bf16 bt_s[2][C::BN * ROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * C::BM, n0 = blockIdx.x * C::BN;
+    const int M = g.N * g.Ho * g.Wo;
+    const int taps = g.R * g.S;
+    const int total_stages = (g.Cin >> 4) * taps;
+    const int st_begin = blockIdx.z * stages_per_split;
+    int st_end = st_begin + stages_per_split;
+    if (st_end > total_stages) st_end = total_stages;
+    const int nst = st_end - st_begin;
+
+    // loop-invariant per-row gather coordinates (those of conv_gather_mfma_kernel)
+    int a_img[C::NA], a_iy[C::NA], a_ix[C::NA], a_dst[C::NA];
+#pragma unroll
+    for (int it = 0; it < C::NA; ++it) {
+        const int q = tid + 256 * it, row = q >> 2, p = q & 3;
+        const int m = m0 + row;
+        a_dst[it] = row * ROW + 4 * p;
+        if (m < M) {
+            const int n = m / (g.Ho * g.Wo);
+            const int rem = m - n * g.Ho * g.Wo;
+            const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+            a_img[it] = n * g.H * g.W;
+            a_iy[it] = g.transposed ? oy + g.pad : oy * g.stride - g.pad;
+            a_ix[it] = g.transposed ? ox + g.pad : ox * g.stride - g.pad;
+        } else {
+            a_img[it] = -1; a_iy[it] = 0; a_ix[it] = 0;
+        }
+    }
+    int b_row[C::NB], b_dst[C::NB];
+#pragma unroll
+    for (int it = 0; it < C::NB; ++it) {
+        const int q = tid + 256 * it, row = q >> 2, p = q & 3;
+        b_row[it] = (n0 + row < g.Cout) ? (n0 + row) : -1;
+        b_dst[it] = row * ROW + 4 * p;
+    }
+    const int p4 = (tid & 3) * 4;
+
+    f32x4 areg[C::NA], breg[C::NB];
+    unsigned ok_bits = 0;
+    auto load_tiles = [&](int stage) {
+        const int chunk = stage / taps, tap = stage - chunk * taps;
+        const int r = tap / g.S, s = tap - r * g.S;
+        const int c0 = chunk * 16 + p4;
+        unsigned ok = 0;
+#pragma unroll
+        for (int it = 0; it < C::NA; ++it) {
+            int iy = a_iy[it] + r, ix = a_ix[it] + s;
+            bool v_ok = a_img[it] >= 0;
+            if (g.transposed) {
+                const int ty = a_iy[it] - r, tx = a_ix[it] - s;
+                iy = ty / g.stride; ix = tx / g.stride;
+                v_ok = v_ok && ty >= 0 && tx >= 0 && iy * g.stride == ty && ix * g.stride == tx;
+            }
+            v_ok = v_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            const size_t off = v_ok ? ((size_t)a_img[it] + (size_t)iy * g.W + ix) * g.Cin + c0 : 0;
+            areg[it] = *reinterpret_cast<const f32x4*>(x + off);
+            ok |= (v_ok ? 1u : 0u) << it;
+        }
+#pragma unroll
+        for (int it = 0; it < C::NB; ++it) {
+            const bool v_ok = b_row[it] >= 0;
+            const size_t off = v_ok ? ((size_t)tap * g.Cout + b_row[it]) * g.Cin + c0 : 0;
+            breg[it] = *reinterpret_cast<const f32x4*>(wp + off);
+            ok |= (v_ok ? 1u : 0u) << (16 + it);
+        }
+        ok_bits = ok;
+    };
+    auto to_bf16x4 = [](f32x4 v) {
+        const gb_bf16x2 lo = __builtin_convertvector(gb_f32x2{v[0], v[1]}, gb_bf16x2), hi = __builtin_convertvector(gb_f32x2{v[2], v[3]}, gb_bf16x2);
+        return gb_bf16x4{lo[0], lo[1], hi[0], hi[1]};
+    };
+    auto store_tiles = [&](int buf, unsigned ok) {
+#pragma unroll
+        for (int it = 0; it < C::NA; ++it) {
+            f32x4 v = areg[it];
+            if (!((ok >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<gb_bf16x4*>(&at_s[buf][a_dst[it]]) = to_bf16x4(v);
+        }
+#pragma unroll
+        for (int it = 0; it < C::NB; ++it) {
+            f32x4 v = breg[it];
+            if (!((ok >> (16 + it)) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<gb_bf16x4*>(&bt_s[buf][b_dst[it]]) = to_bf16x4(v);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int a_base = (32 * TM * wm + li) * ROW + 8 * lh;
+    const int b_base = (32 * TN * wn + li) * ROW + 8 * lh;
+    if (nst > 0) {
+        const int last = st_end - 1;
+        load_tiles(st_begin);
+        store_tiles(0, ok_bits);
+        load_tiles(st_begin + 1 < st_end ? st_begin + 1 : last);
+        unsigned ok_w = ok_bits;
+        __syncthreads();
+        for (int s = 0; s < nst; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            gb_bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const gb_bf16x8*>(&at_s[cur][a_base + i * 32 * ROW]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const gb_bf16x8*>(&bt_s[cur][b_base + j * 32 * ROW]);
+            store_tiles(nxt, ok_w);                           // tile s + 1 (its buffer was read in iteration s - 1: behind the barrier)
+            {
+                const int s2 = st_begin + s + 2;
+                load_tiles(s2 < st_end ? s2 : last);          // tile s + 2 leaves for registers
+                ok_w = ok_bits;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: conv_gather_mfma_kernel's (the weights were the instruction's row operand: a lane holds, for its pixel m = lane & 31, the
+    // output channels 8 q + 4 (lane >> 5) + 0..3 in registers 4 q .. 4 q + 3)
+    const bool direct = (gridDim.z == 1);
+    float* const dst = direct ? y : ws + (size_t)blockIdx.z * M * g.Cout;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + 32 * (TM * wm + i) + li;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + 32 * (TN * wn + j) + 8 * q + 4 * lh;
+                if (n >= g.Cout) continue;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                if (direct) {
+                    if (bias) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                    }
+                    if (residual) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + (size_t)m * g.Cout + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(dst + (size_t)m * g.Cout + n) = v;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256)
 void gather_splitk_finish_kernel(const float* __restrict__ ws, int splits, const float* __restrict__ bias,
                                  const float* __restrict__ residual, float* __restrict__ y, int M, int Cout, int relu)
@@ -403,7 +593,7 @@ __global__ void fold_bn_pack_kernel(const float* __restrict__ w, const float* __
 // ---- host side ----------------------------------------------------------------------------------
 struct GatherPlan { int cfg; int mblocks, nblocks, splits, stages_per_split; };
 
-static GatherPlan plan_gather(int M, int Cout, int stages)
+static GatherPlan plan_gather(int M, int Cout, int stages, int math = FRCNN_GRAD_F32)
 {
     GatherPlan p;
     p.cfg = (Cout <= 64) ? 1 : 0;                   // 1: 256 x 64 tile, 0: 128 x 128
@@ -412,7 +602,9 @@ static GatherPlan plan_gather(int M, int Cout, int stages)
     p.nblocks = cdiv(Cout, bn);
     const int blocks = p.mblocks * p.nblocks;
     static const int target = []() { const char* e = frcnn_knob("FRCNN_GATHER_BLOCKS"); return e ? atoi(e) : 1280; }();   // experiments
-    int want = target / (blocks > 0 ? blocks : 1);     // ~5 blocks per CU (see conv.hip)
+    // bf16 operands: a stage is ONE matrix instruction per accumulator instead of eight, the kernel is bound by its loads and launch, and
+    // the partial planes + the finish launch cost more than the tail they fill -- split only when the grid would leave half the chip idle
+    int want = (math == FRCNN_GRAD_BF16 ? 256 : target) / (blocks > 0 ? blocks : 1);     // float32: ~5 blocks per CU (see conv.hip)
     int cap = stages / 8;
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
@@ -438,21 +630,26 @@ size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R
 
 template <int TM, int TN, int WM, int WN>
 static int launch_gather_cfg(const GatherPlan& p, const float* x, const float* wp, const float* bias,
-                             const float* residual, float* y, float* ws, const GatherShape& g, int relu, hipStream_t s)
+                             const float* residual, float* y, float* ws, const GatherShape& g, int relu, hipStream_t s, int math = FRCNN_GRAD_F32)
 {
     using C = GatherCfg<TM, TN, WM, WN>;
+    dim3 grid(p.nblocks, p.mblocks, p.splits);
+    if (math == FRCNN_GRAD_BF16) {
+        hipLaunchKernelGGL((conv_gather_bf16_kernel<TM, TN, WM, WN>), grid, dim3(256), 0, s, x, wp, bias, residual, y, ws, g, p.stages_per_split, relu);
+        return check_launch();
+    }
     auto kern = conv_gather_mfma_kernel<TM, TN, WM, WN>;
     FRCNN_MAX_LDS_ONCE(kern, C::LDS_BYTES);
-    dim3 grid(p.nblocks, p.mblocks, p.splits);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, x, wp, bias, residual, y, ws, g, p.stages_per_split, relu);
     return check_launch();
 }
 
 int launch_conv_gather(const float* x, const float* wp, const float* bias, const float* residual, float* y,
                        int N, int H, int W, int cin, int cout, int R, int stride, int pad, unsigned flags,
-                       void* ws, size_t ws_bytes, hipStream_t s)
+                       void* ws, size_t ws_bytes, hipStream_t s, int math)
 {
     if (N < 1 || H < 1 || W < 1 || cin % 16 != 0 || cout % 4 != 0 || R < 1 || stride < 1 || pad < 0) return FRCNN_EINVAL;
+    if (math != FRCNN_GRAD_F32 && math != FRCNN_GRAD_BF16) return FRCNN_EINVAL;
     GatherShape g;
     g.transposed = 0;
     g.N = N; g.H = H; g.W = W; g.Cin = cin; g.Cout = cout; g.R = R; g.S = R; g.stride = stride; g.pad = pad;
@@ -460,15 +657,15 @@ int launch_conv_gather(const float* x, const float* wp, const float* bias, const
     g.Wo = (W + 2 * pad - R) / stride + 1;
     if (g.Ho < 1 || g.Wo < 1) return FRCNN_EINVAL;
     const int M = N * g.Ho * g.Wo;
-    GatherPlan p = plan_gather(M, cout, (cin / 16) * R * R);
+    GatherPlan p = plan_gather(M, cout, (cin / 16) * R * R, math);
     const size_t need = p.splits > 1 ? (size_t)p.splits * M * cout * sizeof(float) : 0;
     if (need > ws_bytes || (need > 0 && ws == nullptr)) {       // no scratch: run un-split
         p.splits = 1;
         p.stages_per_split = (cin / 16) * R * R;
     }
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
-    int rc = p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s)
-                        : launch_gather_cfg<2, 2, 2, 2>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s);
+    int rc = p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, math)
+                        : launch_gather_cfg<2, 2, 2, 2>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, math);
     if (rc) return rc;
     if (p.splits > 1) {
         const size_t total = (size_t)M * (cout / 4);
@@ -485,9 +682,10 @@ int launch_conv_gather(const float* x, const float* wp, const float* bias, const
 //   dx[n][iy][ix][ci] = residual + sum_{tap, co} dz[n][(iy+pad-r)/stride][(ix+pad-s)/stride][co] * wd[tap][ci][co]
 // as the gather kernel in its transposed mode (wd = per-tap transpose of the forward pack, frcnn_pack_conv_dgrad).
 int launch_conv_dgrad(const float* dz, const float* wd, const float* residual, float* dx, int N, int H, int W, int cin,
-                      int cout, int R, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t s)
+                      int cout, int R, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t s, int math)
 {
     if (N < 1 || H < 1 || W < 1 || cout % 16 != 0 || cin % 4 != 0 || R < 1 || stride < 1 || pad < 0) return FRCNN_EINVAL;
+    if (math != FRCNN_GRAD_F32 && math != FRCNN_GRAD_BF16) return FRCNN_EINVAL;
     GatherShape g;
     g.transposed = 1;
     g.N = N; g.R = R; g.S = R; g.stride = stride; g.pad = pad;
@@ -497,14 +695,14 @@ int launch_conv_dgrad(const float* dz, const float* wd, const float* residual, f
     g.Cin = cout; g.Cout = cin;
     if (g.H < 1 || g.W < 1) return FRCNN_EINVAL;
     const int M = N * H * W;
-    GatherPlan p = plan_gather(M, cin, (cout / 16) * R * R);
+    GatherPlan p = plan_gather(M, cin, (cout / 16) * R * R, math);
     const size_t need = p.splits > 1 ? (size_t)p.splits * M * cin * sizeof(float) : 0;
     if (need > ws_bytes || (need > 0 && ws == nullptr)) {
         p.splits = 1;
         p.stages_per_split = (cout / 16) * R * R;
     }
-    int rc = p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, dz, wd, nullptr, residual, dx, (float*)ws, g, 0, s)
-                        : launch_gather_cfg<2, 2, 2, 2>(p, dz, wd, nullptr, residual, dx, (float*)ws, g, 0, s);
+    int rc = p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, dz, wd, nullptr, residual, dx, (float*)ws, g, 0, s, math)
+                        : launch_gather_cfg<2, 2, 2, 2>(p, dz, wd, nullptr, residual, dx, (float*)ws, g, 0, s, math);
     if (rc) return rc;
     if (p.splits > 1) {
         const size_t total = (size_t)M * (cin / 4);

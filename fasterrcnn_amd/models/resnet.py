@@ -213,17 +213,18 @@ def block_params(block):
     return ps
 
 
-def conv_nhwc(x, wp, bp, n, h, w, cin, cout, k, stride, pad, relu, residual=None):
-    """frcnn_conv_nhwc on a flat NHWC CUDA tensor; returns (y, ho, wo)."""
+def conv_nhwc(x, wp, bp, n, h, w, cin, cout, k, stride, pad, relu, residual=None, math=0):
+    """frcnn_conv_nhwc on a flat NHWC CUDA tensor; returns (y, ho, wo).  math: nv.GRAD_MATHS value (the train step's reduced-precision
+    forward: operands rounded to bfloat16, bf16 matrix pipe, float32 accumulation)."""
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     y = t.empty((n, ho, wo, cout), dtype=t.float32, device=x.device)
     lib = nv.lib()
     wsb = int(lib.frcnn_conv_workspace_bytes(n, h, w, cin, cout, k, stride, pad))
     ws = t.empty((max(wsb, 4) // 4,), dtype=t.float32, device=x.device)
     with t.cuda.device(x.device):
-        nv.check(lib.frcnn_conv_nhwc(nv.ptr(x), nv.ptr(wp), nv.ptr(bp), nv.ptr(residual), nv.ptr(y), n, h, w, cin, cout,
-                                     k, stride, pad, nv.RELU if relu else 0, nv.ptr(ws), wsb, nv.stream_ptr()),
-                 "frcnn_conv_nhwc")
+        nv.check(lib.frcnn_conv_nhwc_math(nv.ptr(x), nv.ptr(wp), nv.ptr(bp), nv.ptr(residual), nv.ptr(y), n, h, w, cin, cout,
+                                          k, stride, pad, nv.RELU if relu else 0, int(math), nv.ptr(ws), wsb, nv.stream_ptr()),
+                 "frcnn_conv_nhwc_math")
     return y, ho, wo
 
 

@@ -45,8 +45,9 @@ def _ws(nbytes, device):
     return t.empty((max(int(nbytes), 4) // 4 + 1,), dtype=t.float32, device=device)
 
 
-# Arithmetic of the gradient GEMMs of the step in progress (FasterRCNNModel.grad_math, set by train_step): "f32" = the exact-f32
-# matrix pipe, "bf16" = operands rounded to bfloat16, bf16 matrix pipe, f32 accumulation (csrc/gemm_tn.hip).
+# Arithmetic of the step in progress (FasterRCNNModel.grad_math, set by train_step): "f32" = the exact-f32 matrix pipe, "bf16" = operands
+# rounded to bfloat16, bf16 matrix pipe, f32 accumulation -- every gradient GEMM (csrc/gemm_tn.hip) and, round 4, the forward and
+# data-gradient convolutions of the trainable ResNet blocks (csrc/conv_gather.hip: conv_gather_bf16_kernel).
 _GRAD_MATH = 0
 
 
@@ -180,8 +181,8 @@ def conv_dgrad(dz, wf, residual, n, h, w, cin, cout, k, stride, pad):
     dx = t.empty((n, h, w, cin), dtype=t.float32, device=dz.device)
     wsb = int(lib.frcnn_conv_dgrad_workspace_bytes(n, h, w, cin, cout, k, stride, pad))
     ws = _ws(wsb, dz.device) if wsb else None
-    nv.check(lib.frcnn_conv_dgrad(nv.ptr(dz), nv.ptr(wd), nv.ptr(residual), nv.ptr(dx), n, h, w, cin, cout, k, stride, pad,
-                                  nv.ptr(ws), wsb, nv.stream_ptr()), "frcnn_conv_dgrad")
+    nv.check(lib.frcnn_conv_dgrad_math(nv.ptr(dz), nv.ptr(wd), nv.ptr(residual), nv.ptr(dx), n, h, w, cin, cout, k, stride, pad,
+                                       _GRAD_MATH, nv.ptr(ws), wsb, nv.stream_ptr()), "frcnn_conv_dgrad_math")
     return dx
 
 
@@ -403,7 +404,7 @@ class _TrainConv:
     def forward(self, x, n, h, w, relu, residual=None):
         from .models import resnet
         return resnet.conv_nhwc(x, self.folded, self.shift, n, h, w, self.cin, self.cout, self.k, self.stride, self.pad, relu,
-                                residual=residual)
+                                residual=residual, math=_GRAD_MATH)
 
     def wgrad(self, x, dz, n, h, w):
         """Gradient with respect to the RAW weight: the folded weight's gradient times the BN scale of its output channel."""

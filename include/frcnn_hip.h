@@ -696,6 +696,17 @@ int frcnn_conv3x3_wgrad_math(const float* d_x, const float* d_dz, float* d_dwp, 
                              int grad_math, void* d_ws, size_t ws_bytes, void* stream);
 int frcnn_conv_wgrad_math(const float* d_x, const float* d_dz, float* d_dwp, int N, int H, int W, int cin, int cout,
                           int ksize, int stride, int pad, int grad_math, void* d_ws, size_t ws_bytes, void* stream);
+/* ABI 10: the FORWARD and DATA-GRADIENT convolutions of the ResNet train step with the same switch (BASELINE configs[4] as written:
+ * "train step ... bf16"): frcnn_conv_nhwc / frcnn_conv_dgrad with `math` = FRCNN_GRAD_BF16 round both operands (activations or output
+ * gradients, and the folded weight pack) to bfloat16 on their way into LDS and multiply on the bf16 matrix pipe (one
+ * v_mfma_f32_32x32x16_bf16 per 16-channel stage where the float32 kernel issues eight float32 instructions), float32 accumulation,
+ * bias / residual / ReLU in float32; master weights and every stored tensor stay float32.  Same arguments, shapes and workspace as the
+ * entry points without the suffix. */
+int frcnn_conv_nhwc_math(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
+                         int N, int H, int W, int cin, int cout, int ksize, int stride, int pad, unsigned flags, int math,
+                         void* d_ws, size_t ws_bytes, void* stream);
+int frcnn_conv_dgrad_math(const float* d_dz, const float* d_wd, const float* d_residual, float* d_dx, int N, int H, int W,
+                          int cin, int cout, int ksize, int stride, int pad, int math, void* d_ws, size_t ws_bytes, void* stream);
 
 /* conv2d backward of the 3x3 "same" layers (vgg16.py:76-96, rpn.py:88):
  *   weight gradient  d_dwp [9][cout][cin] (the frcnn_pack_conv3x3 layout) from x [H][W][cin], dz [H][W][cout];

@@ -270,8 +270,9 @@ def roi_align_autograd(feature_map, proposals, sampling_ratio=2):
 # ---- reduced-precision gradient GEMMs (grad_math="bf16"; beyond the reference, which trains in float32) ------------------
 # What csrc/gemm_tn.hip's bf16 kernel computes, restated: every gradient GEMM of the step -- the weight gradient of every
 # convolution and dense layer, the data gradient of the dense layers and of the RPN's 1x1 heads -- multiplies operands rounded to
-# bfloat16 (round to nearest even: torch's .bfloat16()) and accumulates in float32.  Forward passes, the data gradient of the
-# k > 1 convolutions, bias gradients, losses and the optimizer are float32 as before.
+# bfloat16 (round to nearest even: torch's .bfloat16()) and accumulates in float32.  Round 4: so do the forward and data-gradient
+# convolutions of the trainable ResNet bottlenecks (_ConvBnGradBf16 below).  The VGG-16 / RPN 3x3 forward and data-gradient
+# convolutions, bias gradients, losses and the optimizer are float32 as before.
 def _bf16r(x):
     return x.to(t.bfloat16).to(t.float32)
 
@@ -316,27 +317,37 @@ class _LinearGradBf16(t.autograd.Function):
 
 class _ConvBnGradBf16(t.autograd.Function):
     """conv + frozen BatchNorm (fasterrcnn_amd/training.py _TrainConv: one convolution with the folded weight w * scale[co]; the raw
-    weight's gradient is the folded weight's bf16 gradient GEMM times scale[co]; the data gradient is a float32 convolution)."""
+    weight's gradient is the folded weight's bf16 gradient GEMM times scale[co]).  `trainable` (round 4: BASELINE configs[4] as written;
+    the convolutions of layer2 / layer3 / layer4, csrc/conv_gather.hip conv_gather_bf16_kernel): the FORWARD convolution and the data
+    gradient multiply operands rounded to bfloat16 too -- the activations (or output gradients) and the FOLDED weight w * scale[co] --
+    with float32 accumulation; bias, residual and ReLU stay float32.  The frozen layers below (conv1, layer1) run the inference kernels."""
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, mean, var, stride, padding):
+    def forward(ctx, x, w, gamma, beta, mean, var, stride, padding, trainable):
         scale = gamma / t.sqrt(var + 1e-5)
         ctx.save_for_backward(x, w, scale)
-        ctx.cfg = (stride, padding)
-        return F.batch_norm(F.conv2d(x, w, stride=stride, padding=padding), mean, var, gamma, beta, False, 0.0, 1e-5)
+        ctx.cfg = (stride, padding, trainable)
+        if not trainable:
+            return F.batch_norm(F.conv2d(x, w, stride=stride, padding=padding), mean, var, gamma, beta, False, 0.0, 1e-5)
+        wf = w * scale.reshape(-1, 1, 1, 1)
+        return F.conv2d(_bf16r(x), _bf16r(wf), stride=stride, padding=padding) + (beta - mean * scale).reshape(1, -1, 1, 1)
 
     @staticmethod
     def backward(ctx, g):
         x, w, scale = ctx.saved_tensors
-        stride, padding = ctx.cfg
+        stride, padding, trainable = ctx.cfg
         sc = scale.reshape(-1, 1, 1, 1)
-        gx = t.nn.grad.conv2d_input(x.shape, w * sc, g, stride=stride, padding=padding) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = (t.nn.grad.conv2d_input(x.shape, _bf16r(w * sc), _bf16r(g), stride=stride, padding=padding) if trainable
+                  else t.nn.grad.conv2d_input(x.shape, w * sc, g, stride=stride, padding=padding))
         gw = sc * t.nn.grad.conv2d_weight(_bf16r(x), w.shape, _bf16r(g), stride=stride, padding=padding) if ctx.needs_input_grad[1] else None
-        return gx, gw, None, None, None, None, None, None
+        return gx, gw, None, None, None, None, None, None, None
 
 
 def _conv_bn_bf16(x, sd, wkey, bn_prefix, stride, padding):
+    trainable = wkey.startswith((orc._RFE + "5.", orc._RFE + "6.", orc._RL4))           # layer2, layer3, layer4 (resnet.py:48-55,86,123)
     return _ConvBnGradBf16.apply(x, sd[wkey], sd[bn_prefix + "weight"], sd[bn_prefix + "bias"], sd[bn_prefix + "running_mean"],
-                                 sd[bn_prefix + "running_var"], stride, padding)
+                                 sd[bn_prefix + "running_var"], stride, padding, trainable)
 
 
 def _conv2d(x, w, b, padding, grad_math, dense=False):

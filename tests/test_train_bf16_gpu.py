@@ -111,6 +111,103 @@ def test_conv_wgrad_bf16(N, H, W, cin, cout, k, stride, pad):
         assert torch.equal(dwp, dwp2)
 
 
+@pytest.mark.parametrize("N,H,W,cin,cout,k,stride,pad,relu,res", [
+    (1, 38, 63, 256, 64, 1, 1, 0, True, False),        # layer2-class 1x1 reduce
+    (1, 38, 63, 64, 64, 3, 1, 1, True, False),         # 3x3
+    (1, 38, 63, 64, 256, 1, 1, 0, True, True),         # 1x1 expand + residual + ReLU
+    (1, 75, 125, 256, 128, 3, 2, 1, True, False),      # layer2.0 conv2: 3x3 stride 2
+    (1, 75, 125, 256, 512, 1, 2, 0, False, False),     # downsample branch: 1x1 stride 2, no ReLU
+    (1, 38, 63, 1024, 256, 1, 1, 0, True, False),      # layer3: K = 1024 (split-K)
+    (37, 7, 7, 512, 512, 3, 2, 1, True, False),        # per-RoI layer4 shapes: a batch of small maps
+    (3, 5, 9, 32, 20, 3, 1, 1, False, True),           # ragged: cout not a multiple of 32
+])
+def test_conv_forward_and_data_gradient_bf16(N, H, W, cin, cout, k, stride, pad, relu, res):
+    """Round 4 (BASELINE configs[4] as written): frcnn_conv_nhwc_math / frcnn_conv_dgrad_math with FRCNN_GRAD_BF16 -- the forward and
+    data-gradient convolutions of the trainable ResNet bottlenecks with both operands rounded to bfloat16 on their way into LDS, bf16
+    matrix pipe, float32 accumulation, float32 bias / residual / ReLU.  Against the float64 convolution of the ROUNDED operands: products
+    of bf16 values are exact in float32, so only the accumulation order differs -- held to the float32 torch convolution's own error
+    class -- while the float32 entry point on the unrounded operands is >= 20x further away (the rounding is in effect); deterministic;
+    math 0 is the float32 entry point bit for bit."""
+    g = torch.Generator().manual_seed(N * 131 + H * 17 + cin + cout + k)
+    x = torch.randn((N, cin, H, W), generator=g)
+    wt = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    r = torch.randn((N, cout, Ho, Wo), generator=g) if res else None
+    lib = nv.lib()
+
+    def fin(y):
+        y = y + b.double().reshape(1, -1, 1, 1)
+        if res:
+            y = y + r.double()
+        return y.clamp(min=0) if relu else y
+    truth = fin(F.conv2d(r16(x).double(), r16(wt).double(), stride=stride, padding=pad)).numpy()
+    yard = rel_err(fin(F.conv2d(r16(x), r16(wt), stride=stride, padding=pad).double()).numpy(), truth)
+    plain = rel_err(fin(F.conv2d(x.double(), wt.double(), stride=stride, padding=pad)).numpy(), truth)
+    x_n = gpu(x.permute(0, 2, 3, 1))
+    wp = gpu(wt.permute(2, 3, 0, 1).reshape(k * k, cout, cin))
+    bp = gpu(b)
+    r_n = gpu(r.permute(0, 2, 3, 1)) if res else None
+    wsb = int(lib.frcnn_conv_workspace_bytes(N, H, W, cin, cout, k, stride, pad))
+    ws = torch.empty((wsb // 4 + 1,), device=DEV)
+
+    def fwd(math):
+        y = torch.full((N, Ho, Wo, cout), float("nan"), device=DEV)
+        nv.check(lib.frcnn_conv_nhwc_math(nv.ptr(x_n), nv.ptr(wp), nv.ptr(bp), nv.ptr(r_n), nv.ptr(y), N, H, W, cin, cout, k, stride, pad,
+                                          nv.RELU if relu else 0, math, nv.ptr(ws), wsb, S()), "conv_nhwc_math")
+        return y
+    y1 = fwd(BF16)
+    e = rel_err(y1.permute(0, 3, 1, 2).cpu().numpy(), truth)
+    K = cin * k * k
+    tol = max(4 * yard, 1.2e-7 * K ** 0.5)
+    assert e <= tol, (e, yard)
+    if K >= 256:
+        assert plain > 20 * tol, (plain, tol)
+    assert torch.equal(y1, fwd(BF16)), "deterministic"
+    y0 = torch.full((N, Ho, Wo, cout), float("nan"), device=DEV)
+    nv.check(lib.frcnn_conv_nhwc(nv.ptr(x_n), nv.ptr(wp), nv.ptr(bp), nv.ptr(r_n), nv.ptr(y0), N, H, W, cin, cout, k, stride, pad,
+                                 nv.RELU if relu else 0, nv.ptr(ws), wsb, S()), "conv_nhwc")
+    assert torch.equal(y0, fwd(0))
+    assert lib.frcnn_conv_nhwc_math(nv.ptr(x_n), nv.ptr(wp), nv.ptr(bp), nv.ptr(r_n), nv.ptr(y0), N, H, W, cin, cout, k, stride, pad, 0, 7,
+                                    nv.ptr(ws), wsb, S()) == -1
+    # ---- data gradient: dx = residual + conv_transpose(dz, w), dz [N][Ho][Wo][cout]
+    if cout % 16 != 0:
+        return
+    dz = torch.randn((N, cout, Ho, Wo), generator=g)
+    rx = torch.randn((N, cin, H, W), generator=g) if res else None
+    t64 = torch.nn.grad.conv2d_input((N, cin, H, W), r16(wt).double(), r16(dz).double(), stride=stride, padding=pad)
+    t32 = torch.nn.grad.conv2d_input((N, cin, H, W), r16(wt), r16(dz), stride=stride, padding=pad).double()
+    tpl = torch.nn.grad.conv2d_input((N, cin, H, W), wt.double(), dz.double(), stride=stride, padding=pad)
+    if res:
+        t64, t32, tpl = t64 + rx.double(), t32 + rx.double(), tpl + rx.double()
+    yard = rel_err(t32.numpy(), t64.numpy())
+    plain = rel_err(tpl.numpy(), t64.numpy())
+    dz_n = gpu(dz.permute(0, 2, 3, 1))
+    rx_n = gpu(rx.permute(0, 2, 3, 1)) if res else None
+    wd = torch.empty((k * k, cin, cout), device=DEV)
+    nv.check(lib.frcnn_pack_conv_dgrad(nv.ptr(wp), nv.ptr(wd), k * k, cout, cin, S()), "pack_conv_dgrad")
+    wsb = int(lib.frcnn_conv_dgrad_workspace_bytes(N, H, W, cin, cout, k, stride, pad))
+    ws = torch.empty((wsb // 4 + 1,), device=DEV)
+
+    def dgrad(math):
+        dx = torch.full((N, H, W, cin), float("nan"), device=DEV)
+        nv.check(lib.frcnn_conv_dgrad_math(nv.ptr(dz_n), nv.ptr(wd), nv.ptr(rx_n), nv.ptr(dx), N, H, W, cin, cout, k, stride, pad, math,
+                                           nv.ptr(ws), wsb, S()), "conv_dgrad_math")
+        return dx
+    d1 = dgrad(BF16)
+    e = rel_err(d1.permute(0, 3, 1, 2).cpu().numpy(), t64.numpy())
+    Kd = cout * k * k
+    tol = max(4 * yard, 1.2e-7 * Kd ** 0.5)
+    assert e <= tol, (e, yard)
+    if Kd >= 256:
+        assert plain > 20 * tol, (plain, tol)
+    assert torch.equal(d1, dgrad(BF16))
+    d0 = torch.full((N, H, W, cin), float("nan"), device=DEV)
+    nv.check(lib.frcnn_conv_dgrad(nv.ptr(dz_n), nv.ptr(wd), nv.ptr(rx_n), nv.ptr(d0), N, H, W, cin, cout, k, stride, pad, nv.ptr(ws), wsb, S()),
+             "conv_dgrad")
+    assert torch.equal(d0, dgrad(0))
+
+
 def _vgg_case(sd_cpu, h, w, seed):
     img = synthetic.image(seed, h, w).unsqueeze(0)
     gts = synthetic.ground_truth(seed, h, w)
@@ -221,11 +318,100 @@ def test_bf16_train_step_full_size_is_deterministic_and_learns(sd_cpu):
           % (ms_bf16, ms_f32, l1[0], l1[-1], lf[-1]))
 
 
-def test_bf16_resnet50_train_step_matches_the_bf16_oracle():
-    """ResNet-50 (frozen BatchNorm folded into each convolution: training.py _TrainConv), one step at 352x480 against the oracle's
-    bf16 restatement run here on the same seeds: identical selections and losses; gradients under the float32 step's criteria
-    (tests/test_train_gpu.py: a tight median, looser L2 / norm bounds because two float32 forwards flip a few ReLU decisions) --
-    and closer to the bf16 oracle than to the float32 oracle, which is what shows the arithmetic is the restated one."""
+@pytest.mark.parametrize("layer,index,h,w,n", [("layer2", 0, 38, 63, 1), ("layer3", 1, 19, 32, 1), ("layer4", 0, 7, 7, 24)])
+def test_bf16_bottleneck_forward_and_backward_on_injected_activations(layer, index, h, w, n):
+    """One trainable Bottleneck (training.py _TrainBlock: three or four conv + folded frozen BatchNorm) in the bf16 arithmetic, forward and
+    backward, against the oracle's restatement (oracle/train_oracle.py _ConvBnGradBf16 behind frcnn_oracle._bottleneck) on the SAME input
+    and the SAME upstream gradient -- the injected-activation form of the check: no proposal sampling, no NMS, nothing that turns a
+    last-bit difference into a different computation.  Inside the block an activation whose two float32 values straddle a bfloat16
+    rounding boundary still flips by 2^-8 of its size, and a near-zero one flips its ReLU mask (two internal layers), so the bars are:
+    output within 2e-4 in relative L2 and 1e-3 of its largest element at the 99.9th percentile (measured 2-6e-5 / 5e-5-1e-4); input and
+    weight gradients within 1e-2 in relative L2 -- two forwards that agree to 4e-5 flip the ReLU mask of the few pre-activations that
+    close to zero, which a block with x >= 0 on its identity path hardly has (layer3.1: 6e-5 .. 2e-4) and the first block of a layer,
+    whose identity is a convolution, has more of (layer2.0 / layer4.0: 1.3e-3 .. 5.8e-3, spread over every element of a weight gradient
+    because each sums over all pixels) -- and each of them at least 5x closer to the bf16 oracle than the float32 block is (measured
+    13-470x: the rounding itself moves outputs by 2e-3 and gradients by 4-8e-2)."""
+    from fasterrcnn_amd.models import resnet
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    sd0 = synthetic.resnet_state_dict(1234, "ResNet50")
+    model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet50))
+    model.load_state_dict(sd0, strict=True)
+    model = model.cuda()
+    state = T.make_train_state(model)
+    blocks = {b.name: b for b in state.blocks + state.head_blocks}
+    blk = blocks["%s.%d" % (layer, index)]
+    prefix = {"layer2": O._RFE + "5.", "layer3": O._RFE + "6.", "layer4": O._RL4}[layer] + "%d." % index
+    stride = 2 if index == 0 else 1
+    cin = blk.c1.cin
+    g = torch.Generator().manual_seed(h * 100 + w + n)
+    x = torch.randn((n, cin, h, w), generator=g).clamp(min=0)                 # a post-ReLU block input
+    sd = {k: v.clone().requires_grad_(k.endswith(".weight") and ("conv" in k or "downsample.0" in k)) for k, v in sd0.items() if k.startswith(prefix)}
+
+    def oracle(bf16):
+        for v in sd.values():
+            v.grad = None
+        xo = x.clone().requires_grad_(True)
+        O.CONV_BN = TO._conv_bn_bf16 if bf16 else None
+        try:
+            out = O._bottleneck(xo, sd, prefix, stride)
+        finally:
+            O.CONV_BN = None
+        gen = torch.Generator().manual_seed(7)
+        up = torch.randn(out.shape, generator=gen)
+        out.backward(up)
+        gw = {k: v.grad.clone() for k, v in sd.items() if v.grad is not None}
+        return out.detach(), xo.grad.clone(), gw, up
+    o_out, o_dx, o_gw, up = oracle(True)
+    f_out, f_dx, f_gw, _ = oracle(False)
+
+    def hip(gm):
+        T._GRAD_MATH = nv.GRAD_MATHS[gm]
+        try:
+            xn = gpu(x.permute(0, 2, 3, 1))
+            out, ho, wo, saved = blk.forward(xn, n, h, w)
+            grads = {}
+            dx = blk.backward(gpu(up.permute(0, 2, 3, 1)).clone(), saved, grads, need_dx=True)
+            torch.cuda.synchronize()
+        finally:
+            T._GRAD_MATH = 0
+        gw = {}
+        for name, gg in grads.items():
+            conv = name.split(".")[-1]
+            key = prefix + ("downsample.0.weight" if conv == "downsample" else conv + ".weight")
+            k = int(round(gg.shape[0] ** 0.5))
+            gw[key] = gg.permute(1, 2, 0).reshape(gg.shape[1], gg.shape[2], k, k).cpu()
+        return out.reshape(n, ho, wo, -1).permute(0, 3, 1, 2).cpu(), dx.reshape(n, h, w, cin).permute(0, 3, 1, 2).cpu(), gw
+    out, dx, gw = hip("bf16")
+    out2, dx2, gw2 = hip("bf16")
+    assert torch.equal(out, out2) and torch.equal(dx, dx2) and all(torch.equal(gw[k], gw2[k]) for k in gw), "deterministic"
+
+    def l2(a, b):
+        return float((a.double() - b.double()).norm()) / max(float(b.double().norm()), 1e-30)
+
+    def p999(a, b):
+        d = (a.double() - b.double()).abs().reshape(-1)
+        return float(torch.quantile(d[:: max(1, d.numel() // 2000000)], 0.999)) / float(b.abs().max())
+    rows = [("output", out, o_out, f_out), ("input gradient", dx, o_dx, f_dx)]
+    for name, a, o, f in rows:
+        print("%s.%d %s: vs the bf16 oracle L2 %.2e, 99.9th percentile %.2e of max; the float32 oracle is %.2e away" % (layer, index, name, l2(a, o), p999(a, o), l2(f, o)))
+        assert (l2(a, o) <= 2e-4 and p999(a, o) <= 1e-3) if name == "output" else l2(a, o) <= 1e-2, name
+        assert l2(a, o) * 5 <= l2(f, o), name
+    assert sorted(gw) == sorted(o_gw)
+    for k in sorted(gw):
+        print("%s.%d %s: vs the bf16 oracle L2 %.2e; the float32 oracle is %.2e away" % (layer, index, k[len(prefix):], l2(gw[k], o_gw[k]), l2(f_gw[k], o_gw[k])))
+        assert l2(gw[k], o_gw[k]) <= 1e-2, k
+        assert l2(gw[k], o_gw[k]) * 5 <= l2(f_gw[k], o_gw[k]), k
+
+
+def test_bf16_resnet50_train_step_against_the_bf16_oracle():
+    """ResNet-50 (frozen BatchNorm folded into each convolution: training.py _TrainConv), one whole step at 352x480 next to the oracle's bf16
+    restatement on the same seeds.  Round 4: the FORWARD of the trainable bottlenecks rounds its operands to bfloat16 too, so kernel and
+    oracle are two different valid bf16 evaluations of twenty-odd layers (an activation whose two float32 values straddle a bfloat16
+    boundary flips by 2^-8 of its size): the RPN sees feature maps that agree to ~1e-3, its losses agree to 1e-4, but the post-NMS proposal
+    list -- and with it the RANDOM sample of 128 proposals the detector trains on -- is a different draw, so detector losses and gradients
+    are not comparable element by element any more (the per-block test above is the elementwise check).  Asserted here: the step runs in
+    the restated arithmetic end to end -- same RPN losses, detector losses of the same size, finite gradients for every trainable tensor,
+    and the RPN-side gradients (which do not depend on the sample) close to the bf16 oracle's."""
     from fasterrcnn_amd.models import resnet
     from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
     h, w, seed = 352, 480, 4
@@ -235,13 +421,10 @@ def test_bf16_resnet50_train_step_matches_the_bf16_oracle():
     boxes = [Box(class_index=c, class_name="x", corners=k) for c, k in gts]
     am, vm = O.generate_anchor_maps((3, h, w), (1024, -(-h // 16), -(-w // 16)), 16)
     rmap, obj, bg = O.generate_rpn_map(am, vm, np.stack([k for _, k in gts]))
-    ref = {}
-    for gm in ("bf16", "f32"):
-        random.seed(5); torch.manual_seed(5)
-        od = {}
-        ref[gm] = TO.train_step(sd0, img, am, vm, torch.from_numpy(rmap).unsqueeze(0), obj, bg, np.stack([k for _, k in gts]),
-                                np.array([c for c, _ in gts]), 21, 1e-6, 0.9, 5e-4, detail=od, grad_math=gm) + (od,)
-    o_losses, o_grads, _, _, od = ref["bf16"]
+    random.seed(5); torch.manual_seed(5)
+    od = {}
+    o_losses, o_grads, _, _ = TO.train_step(sd0, img, am, vm, torch.from_numpy(rmap).unsqueeze(0), obj, bg, np.stack([k for _, k in gts]),
+                                            np.array([c for c, _ in gts]), 21, 1e-6, 0.9, 5e-4, detail=od, grad_math="bf16")
     model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet50))
     model.load_state_dict(sd0, strict=True)
     model = model.cuda()
@@ -250,30 +433,20 @@ def test_bf16_resnet50_train_step_matches_the_bf16_oracle():
     random.seed(5); torch.manual_seed(5)
     detail = {}
     loss = T.train_step(model, opt, img.cuda(), am, vm, torch.from_numpy(rmap).unsqueeze(0), [obj], [bg], [boxes], detail=detail)
-    assert np.array_equal(detail["sample_idx"].numpy(), od["proposal_sample_indices"])
     got = np.array([loss.rpn_class, loss.rpn_regression, loss.detector_class, loss.detector_regression])
     want = np.array([o_losses[k] for k in ("rpn_class", "rpn_regression", "detector_class", "detector_regression")])
-    assert np.all(np.abs(got - want) <= 2e-5 * np.abs(want) + 1e-7), (got, want)
+    same = len(set(detail["sample_idx"].numpy().tolist()) & set(od["proposal_sample_indices"].tolist()))
+    print("bf16 ResNet-50 step vs the bf16 oracle: losses %s vs %s; %d of %d sampled proposal indices in common" % (got, want, same, len(od["proposal_sample_indices"])))
+    assert np.all(np.abs(got[:2] - want[:2]) <= 1e-3 * np.abs(want[:2]) + 1e-6), (got, want)
+    assert np.all(np.abs(got[2:] - want[2:]) <= 0.1 * np.abs(want[2:])), (got, want)
     grads = canonical_grads_resnet(detail["grads"])
     assert sorted(grads) == sorted(o_grads)
-    gscale = max(float(g.norm()) for g in o_grads.values())
-    worst = {"median": (0.0, ""), "L2": (0.0, ""), "norm": (0.0, "")}
-    closer = 0
-    for k, g_ref in o_grads.items():
-        g = grads[k].cpu().double().reshape(-1)
-        r = g_ref.double().reshape(-1)
-        r32 = ref["f32"][1][k].double().reshape(-1)
-        ref_max = max(float(r.abs().max()), 1e-7 * gscale)
-        med = float((g - r).abs().median()) / ref_max
-        l2 = float((g - r).norm()) / max(float(r.norm()), 1e-7 * gscale)
-        nrm = abs(float(g.norm()) - float(r.norm())) / max(float(r.norm()), 1e-7 * gscale)
-        for name, val in (("median", med), ("L2", l2), ("norm", nrm)):
-            worst[name] = max(worst[name], (val, k.split(".")[-3] + "." + k.split(".")[-2]))
-        assert med <= 1e-4 and l2 <= 1e-2 and nrm <= 5e-3, (k, med, l2, nrm)
-        closer += float((g - r).norm()) < float((g - r32).norm())
-    print("bf16 ResNet-50 step vs the bf16 oracle: worst gradient errors %s; closer to the bf16 than to the f32 oracle on %d of %d tensors"
-          % (", ".join("%s %.2e (%s)" % (n, v[0], v[1]) for n, v in worst.items()), closer, len(o_grads)))
-    assert closer >= 0.9 * len(o_grads)
+    assert all(bool(torch.isfinite(g).all()) for g in grads.values())
+    for k in ("_stage2_region_proposal_network._rpn_class.weight", "_stage2_region_proposal_network._rpn_boxes.weight"):
+        g, r = grads[k].cpu().double(), o_grads[k].double()
+        rel = float((g - r).norm()) / float(r.norm())
+        print("   %s: L2 distance to the bf16 oracle %.2e" % (k, rel))
+        assert rel <= 2e-2, (k, rel)
 
 
 def test_bf16_resnet101_roialign_train_step_full_size():
@@ -310,6 +483,7 @@ def test_bf16_resnet101_roialign_train_step_full_size():
     lf, _, ms_f32 = run("f32")
     assert l1 == l2 and all(torch.equal(s1[k], s2[k]) for k in s1), "deterministic"
     assert all(np.isfinite(l1)) and l1[-1] < l1[0]
-    assert l1[0] == pytest.approx(lf[0], rel=1e-6) and abs(l1[-1] - lf[-1]) <= 0.05 * abs(lf[-1]), (l1, lf)
+    # (round 4: the bf16 forward of layer2 / layer3 / layer4 moves the first loss by ~1e-4 of its value)
+    assert l1[0] == pytest.approx(lf[0], rel=2e-3) and abs(l1[-1] - lf[-1]) <= 0.05 * abs(lf[-1]), (l1, lf)
     print("ResNet-101 600x1000 RoIAlign train step: grad_math bf16 %.2f ms, f32 %.2f ms; total loss %s (f32: %s)"
           % (ms_bf16, ms_f32, ["%.4f" % x for x in l1], ["%.4f" % x for x in lf]))
