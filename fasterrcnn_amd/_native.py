@@ -54,7 +54,7 @@ SYMBOLS = (
     "frcnn_gemm_tn_math", "frcnn_conv3x3_wgrad_math", "frcnn_conv_wgrad_math",
     "frcnn_gemm_tn_workspace_bytes", "frcnn_gemm_tn", "frcnn_conv3x3_wgrad_workspace_bytes", "frcnn_conv3x3_wgrad",
     "frcnn_pack_conv3x3_dgrad", "frcnn_relu_backward", "frcnn_add_inplace", "frcnn_maxpool2x2_backward",
-    "frcnn_roi_pool_backward_workspace_bytes", "frcnn_roi_pool_backward", "frcnn_transpose", "frcnn_sgd_step",
+    "frcnn_roi_pool_backward_workspace_bytes", "frcnn_roi_pool_backward", "frcnn_transpose", "frcnn_sgd_step", "frcnn_sgd_step_fold",
     "frcnn_conv_wgrad_workspace_bytes", "frcnn_conv_wgrad", "frcnn_conv_dgrad_workspace_bytes", "frcnn_conv_dgrad", "frcnn_conv_dgrad_math",
     "frcnn_pack_conv_dgrad", "frcnn_scale_rows", "frcnn_bn_scale_shift", "frcnn_spatial_mean_backward",
 )
@@ -318,6 +318,7 @@ _SIGNATURES = {
     "frcnn_roi_pool_backward": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _vp, _i, _vp, _sz, _vp]),
     "frcnn_transpose": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "frcnn_sgd_step": (C.c_int, [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _vp]),
+    "frcnn_sgd_step_fold": (C.c_int, [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _vp, _vp, _i, _i, _vp]),
     "frcnn_ctx_timing_enable": (C.c_int, [_vp, _i]),
     "frcnn_ctx_timing_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), _i]),
 }

@@ -774,6 +774,14 @@ int frcnn_sgd_step(float* d_w, const float* d_grad, float* d_momentum_buf, size_
     return launch_sgd(d_w, d_grad, d_momentum_buf, n, lr, momentum, weight_decay, first_step, as_stream(stream));
 }
 
+int frcnn_sgd_step_fold(float* d_w, const float* d_grad, float* d_momentum_buf, size_t n, float lr, float momentum,
+                        float weight_decay, int first_step, const float* d_scale, float* d_folded, int cout, int cin, void* stream)
+{
+    if (n > 0 && (!d_w || !d_grad || !d_scale || !d_folded)) return FRCNN_EINVAL;
+    return launch_sgd_fold(d_w, d_grad, d_momentum_buf, n, lr, momentum, weight_decay, first_step, d_scale, d_folded, cout, cin,
+                           as_stream(stream));
+}
+
 // ---- context ---------------------------------------------------------------------------------
 int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_rois)
 {

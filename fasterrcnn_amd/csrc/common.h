@@ -309,5 +309,7 @@ int launch_bn_scale_shift(const float* gamma, const float* beta, const float* me
 int launch_spatial_mean_backward(const float* dy, float* dx, int N, int H, int W, int c, hipStream_t s);
 int launch_sgd(float* w, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay, int first,
                hipStream_t s);
+int launch_sgd_fold(float* w, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay, int first,
+                    const float* scale, float* folded, int cout, int cin, hipStream_t s);
 
 }  // namespace frcnn

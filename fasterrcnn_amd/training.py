@@ -225,8 +225,13 @@ class TrainState:
     def after_update(self):
         """Hook: derived packs (BN-folded weights) are rebuilt from the masters after SGD."""
 
+    def folded_convs(self):
+        """name -> _TrainConv for the masters whose folded pack is rebuilt by the update itself (frcnn_sgd_step_fold)."""
+        return {}
+
     def apply_sgd(self, grads, lr, momentum, weight_decay):
         lib = _lib()
+        folded = self.folded_convs()
         for name, w in self.trainable().items():
             g = grads[name]
             assert g.shape == w.shape and g.is_contiguous() and w.is_contiguous(), name
@@ -239,8 +244,13 @@ class TrainState:
                     buf = t.empty_like(w)
                     self.momentum[name] = buf
                     first = 1
-            nv.check(lib.frcnn_sgd_step(nv.ptr(w), nv.ptr(g), nv.ptr(buf), w.numel(), lr, momentum, weight_decay, first,
-                                        nv.stream_ptr()), "frcnn_sgd_step")
+            c = folded.get(name)
+            if c is not None:
+                nv.check(lib.frcnn_sgd_step_fold(nv.ptr(w), nv.ptr(g), nv.ptr(buf), w.numel(), lr, momentum, weight_decay, first,
+                                                 nv.ptr(c.scale), nv.ptr(c.folded), c.cout, c.cin, nv.stream_ptr()), "frcnn_sgd_step_fold")
+            else:
+                nv.check(lib.frcnn_sgd_step(nv.ptr(w), nv.ptr(g), nv.ptr(buf), w.numel(), lr, momentum, weight_decay, first,
+                                            nv.stream_ptr()), "frcnn_sgd_step")
         self.after_update()
         self.steps += 1
         self.dirty = True
@@ -494,10 +504,11 @@ class ResNetTrainState(TrainState):
         out.update(rpn_conv=self.rpn_conv, rpn_head=self.rpn_head, head=self.head)
         return out
 
+    def folded_convs(self):
+        return {blk.name + "." + cname: c for blk in self.blocks + self.head_blocks for cname, c in blk.convs().items()}
+
     def after_update(self):
-        for blk in self.blocks + self.head_blocks:
-            for c in blk.convs().values():
-                c.refold()
+        pass                                     # the folded packs were rebuilt by frcnn_sgd_step_fold (same product as _TrainConv.refold)
 
     def _sync_backbone(self):
         for blk in self.blocks + self.head_blocks:

@@ -753,6 +753,10 @@ int frcnn_transpose(const float* d_x, int ldi, float* d_y, int ldo, int rows, in
  * momentum*buf + g; w -= lr*buf (layout agnostic: applied to the packed weights). */
 int frcnn_sgd_step(float* d_w, const float* d_grad, float* d_momentum_buf, size_t n, float lr, float momentum,
                    float weight_decay, int first_step, void* stream);
+/* The same update of a convolution master [taps][cout][cin] whose frozen BatchNorm is folded into the convolution (ResNet bottlenecks),
+ * with the folded pack rebuilt in the same launch: d_folded = w_new * d_scale[co] (frcnn_scale_rows' product; n = taps*cout*cin).  ABI 10. */
+int frcnn_sgd_step_fold(float* d_w, const float* d_grad, float* d_momentum_buf, size_t n, float lr, float momentum,
+                        float weight_decay, int first_step, const float* d_scale, float* d_folded, int cout, int cin, void* stream);
 
 /* Introspection for parity tests: device pointers of intermediate tensors of the LAST forward
  * on this ctx.  which: 0 feature map NHWC [fh][fw][512], 1 RPN head [fh*fw][128],
