@@ -25,7 +25,7 @@ static constexpr int X3_HR = 10;                             // halo rows: 4 til
 
 // m_*: ceil(2^32 / d) of the three divisors of the block index (0 for d = 1): the quotient is ONE scalar multiply-high on the device instead of
 // a division sequence per divisor between the block's entry and its first load (exact while block index x d < 2^32: checked by the launcher)
-struct XfGeom { int tbx, tby, ncb, tw, th, xg; unsigned m_tbx, m_tby, m_ncb; };
+struct XfGeom { int tbx, tby, ncb, tw, th, xg; unsigned m_tbx, m_tby, m_ncb; int ntb; unsigned m_ntb; };   // ntb: tile blocks of all maps
 __device__ __forceinline__ int xd_div(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
 
 // ---- the kernel: 64 tiles per block, the filter fragments straight from L2 into registers ------------------------------------------------------
@@ -116,8 +116,25 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // multiple of 8): the ncb output-channel blocks of one tile block run on the SAME XCD, back to back -- they share the input halo through
     // that XCD's L2 instead of fetching it ncb times through the fabric (measured: fabric traffic 203 MB per launch against 72 MB algorithmic
     // with the plain order, and 1-2 % of the launch time).  Otherwise: output-channel block fastest, round-robin over the XCDs.
+    // gm.xg == 2, FILTER-RESIDENT (layers with >= 256 input channels: a cout block's filter records are 1-2 MB, and with the order above
+    // every XCD streams the records of ALL cout blocks at once -- 16 MB against a 4 MB L2 for a 512-channel layer: each block fetched its
+    // 2 MB through the fabric, 640 MB per launch): an XCD OWNS cout blocks -- XCD x works on cout blocks x, x + 8, ... one after the other
+    // over all tile blocks (ncb >= 8), or 8 / ncb XCDs share a cout block and split the tile blocks (ncb = 1, 2, 4) -- so the records of
+    // the cout block in progress stay in that XCD's L2 and leave the fabric once per XCD; the input halo is what crosses it per cout block.
     int cb;
-    if (gm.xg) {
+    if (gm.xg == 2) {
+        const int xcd = b & 7, s = b >> 3;
+        if (gm.ncb >= 8) {
+            const int k = xd_div(s, gm.ntb, gm.m_ntb);
+            cb = xcd + 8 * k;
+            b = s - k * gm.ntb;
+        } else {
+            const int g = 8 / gm.ncb, sub = xd_div(xcd, gm.ncb, gm.m_ncb);
+            cb = xcd - sub * gm.ncb;
+            b = s * g + sub;
+            if (b >= gm.ntb) return;                                         // (the grid is 8 x ceil(ntb / g) blocks)
+        }
+    } else if (gm.xg) {
         const int xcd = b & 7, q = b >> 3, qq = xd_div(q, gm.ncb, gm.m_ncb);
         cb = q - qq * gm.ncb;
         b = qq * 8 + xcd;
@@ -568,9 +585,17 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     const long long total = (long long)gm.tbx * gm.tby * gm.ncb * N;
     if (total > 0x7fffffffLL) return FRCNN_EINVAL;
     gm.xg = ((long long)gm.tbx * gm.tby * N) % 8 == 0 ? 1 : 0;
+    gm.ntb = gm.tbx * gm.tby * N;
+    long long grid_blocks = total;
+#ifndef XD_NO_FILTER_RESIDENT
+    if (cin >= 256 && (gm.ncb % 8 == 0 || 8 % gm.ncb == 0)) {
+        gm.xg = 2;
+        if (gm.ncb < 8) grid_blocks = 8LL * cdiv(gm.ntb, 8 / gm.ncb);
+    }
+#endif
     auto magic = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
-    gm.m_tbx = magic(gm.tbx); gm.m_tby = magic(gm.tby); gm.m_ncb = magic(gm.ncb);
-    if (total * std::max(gm.ncb, std::max(gm.tbx, gm.tby)) >= 0x100000000ll) return FRCNN_EUNSUPPORTED;
+    gm.m_tbx = magic(gm.tbx); gm.m_tby = magic(gm.tby); gm.m_ncb = magic(gm.ncb); gm.m_ntb = magic(gm.ntb);
+    if (total * std::max(std::max(gm.ncb, gm.ntb), std::max(gm.tbx, gm.tby)) >= 0x100000000ll) return FRCNN_EUNSUPPORTED;
     const int u_rbt = cdiv(cout, gemm_x6t_col_tile(cout)) * gemm_x6t_col_tile(cout) / 32;
     if ((size_t)16 * (cin / 16) * u_rbt * HX_RB >= ((size_t)1 << 31)) return FRCNN_EUNSUPPORTED;   // the record bank behind one buffer descriptor
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
@@ -578,11 +603,11 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     if (flags & FRCNN_POOL2) {
         auto kern = wino_x3d_kernel<true>;
         FRCNN_MAX_LDS_ONCE(kern, XD_LDS_BYTES);
-        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm, cmax_out);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid_blocks), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm, cmax_out);
     } else {
         auto kern = wino_x3d_kernel<false>;
         FRCNN_MAX_LDS_ONCE(kern, XD_LDS_BYTES);
-        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm, cmax_out);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid_blocks), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm, cmax_out);
     }
     return check_launch();
 }
