@@ -33,9 +33,16 @@ timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OU
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_r50_write -o p -- $RP > $OUT/pmc_r50_write.log 2>&1; echo "pmc r50 write exit $?"
 # held-out parity sweep of the default tables (tests/test_holdout_gpu.py measures the same): per-case numbers for profiles/
 for A in VGG16 ResNet50 ResNet101; do timeout 600 python tools/holdout_report.py --arch $A --tables default --out $OUT/holdout_$A.json > $OUT/holdout_$A.log 2>&1; echo "holdout $A exit $?"; done
+# ... and of the in-flight slots' table (VGG-16: the 512-channel f32x3 layers in the one-launch form: what the headline runs on)
+timeout 600 python tools/holdout_report.py --arch VGG16 --tables default --slot 1 --out $OUT/holdout_VGG16_inflight.json > $OUT/holdout_VGG16_inflight.log 2>&1; echo "holdout VGG16 in-flight exit $?"
 grep "^==" $OUT/holdout_*.log
 # train step: wall time per step + per-kernel stats
 timeout 600 python tools/train_bench.py --steps 20 --warmup 3 > $OUT/train_bench.json 2> $OUT/train_bench.err; echo "train bench exit $?"; cat $OUT/train_bench.json
+# BASELINE configs[4] on one GPU: ResNet-101, RoIAlign, grad_math bf16 (and its float32 counterpart)
+timeout 600 python tools/train_bench.py --backbone resnet101 --grad-math bf16 --roi align --steps 20 --warmup 3 > $OUT/train_bench_r101_bf16.json 2>> $OUT/train_bench.err; cat $OUT/train_bench_r101_bf16.json
+timeout 600 python tools/train_bench.py --backbone resnet101 --grad-math f32 --roi align --steps 20 --warmup 3 > $OUT/train_bench_r101_f32.json 2>> $OUT/train_bench.err; cat $OUT/train_bench_r101_f32.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train_r101 -o t -- python tools/train_bench.py --backbone resnet101 --grad-math bf16 --roi align --steps 8 --warmup 2 > $OUT/trace_train_r101.log 2>&1; echo "r101 train trace exit $?"
+rm -f $OUT/trace_train_r101/t_kernel_trace.csv
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -o t -- python tools/train_bench.py --steps 8 --warmup 2 > $OUT/trace_train.log 2>&1; echo "train trace exit $?"
 rm -f $OUT/trace_train/t_kernel_trace.csv
 ls -la $OUT $OUT/trace | head -40

@@ -74,6 +74,29 @@ def main(d):
             print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                      float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
         print()
+    for name, title in (("train_bench_r101_bf16.json", "tools/train_bench.py --backbone resnet101 --grad-math bf16 --roi align (BASELINE configs[4] on one GPU)"),
+                        ("train_bench_r101_f32.json", "the same step in float32 (--grad-math f32)")):
+        f = os.path.join(d, name)
+        if os.path.exists(f):
+            lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
+            if lines:
+                print("## %s\n\n```json\n%s\n```\n" % (title, lines[-1]))
+    rstats = load(os.path.join(d, "trace_train_r101", "*kernel_stats.csv"))
+    if rstats:
+        print("## ResNet-101 + RoIAlign train step, grad_math bf16: kernel stats (10 steps)\n")
+        print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+        for r in rstats[:20]:
+            print("| %s | %s | %.2f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                     float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+        print()
+    hold = sorted(glob.glob(os.path.join(d, "holdout_*.log")))
+    if hold:
+        print("## held-out parity sweep (tools/holdout_report.py; the asserted form: tests/test_holdout_gpu.py)\n\n```")
+        for f in hold:
+            for l in open(f):
+                if l.startswith("=="):
+                    print(l.rstrip())
+        print("```\n")
     # per-layer conv durations by grid
     kt = load(os.path.join(d, "trace", "*kernel_trace.csv"))
     if kt:
