@@ -359,6 +359,8 @@ def test_model_x3_layer_tables_against_the_golden_vectors(gpu_model, golden_dir)
     (2, 21, 35, 128, 192, False, False),      # two maps, three cout blocks, no ReLU
     (1, 37, 62, 512, 512, True, False),       # conv5_x / the RPN trunk (one-launch in the in-flight slots): 32 chunks, 8 cout blocks
     (1, 38, 62, 256, 512, True, True),        # conv4_3's shape class, fused pool
+    (1, 21, 35, 256, 128, True, False),       # filter-resident block order, 4 XCDs per cout block: 6 tile blocks on a grid of 16 (surplus blocks leave)
+    (1, 44, 70, 256, 64, True, True),         # ... one cout block shared by all 8 XCDs
 ])
 def test_x3_one_launch_layer_against_the_three_launch_layer_and_float64(n, h, w, cin, cout, relu, pool):
     """csrc/wino_x3f.hip (round 4: the one-launch f32x3 Winograd layer of conv2_2 .. conv3_3): the same per-tile scale, fp16 split and
