@@ -150,7 +150,7 @@ DEFAULT_X3_LAYERS_VGG16 = DEFAULT_X6_LAYERS_VGG16
 
 
 def uses_winograd_x3f(cin, cout):
-    """The 3x3 layers that CAN run as one-launch f32x3 Winograd layers (csrc/wino_x3f.hip; version 4 walks the 16-channel chunks in pairs)."""
+    """The 3x3 layers that CAN run as one-launch f32x3 Winograd layers (csrc/wino_x3f.hip walks the 16-channel chunks in pairs)."""
     return cin >= 32 and cin % 32 == 0 and cout >= 64 and cout % 64 == 0
 
 

@@ -1,6 +1,7 @@
-// wino_x3f.hip -- the Winograd F(2x2,3x3) layer in the f32x3 arithmetic as ONE launch: the form the layers conv2_2 ... conv3_3 of VGG-16
-// need (pytorch/FasterRCNN/models/vgg16.py:80-87: 3x3 convolution + ReLU, MaxPool2d after each block): their V + M scratch would be
-// 600 MB per layer in the three-launch form of csrc/wino_x3.hip.  In the default forward since round 4 (frcnn_forward_params.winograd_x3f_mask).
+// wino_x3f.hip -- the Winograd F(2x2,3x3) layer in the f32x3 arithmetic as ONE launch: the form of every 3x3 layer of VGG-16 from conv1_2
+// on (pytorch/FasterRCNN/models/vgg16.py:77-96: 3x3 convolution + ReLU, MaxPool2d after each block) and of the RPN trunk (models/rpn.py:88).
+// The V + M scratch of conv1_2 ... conv3_3 would be 600 MB per layer in the three-launch form of csrc/wino_x3.hip: those layers run here in
+// every slot; the 512-channel layers run here when several images are in flight (frcnn_forward_params.winograd_x3f_mask, round 4).
 //
 // Arithmetic: the per-tile scale, the fp16 split and the float32 accumulation order per (position, tile, output channel) -- hi*lo, hi*hi,
 // lo*hi per 16-channel chunk, chunks in order -- are the three-launch layer's (launch_conv3x3_winograd_x3): the accumulators hold the same
@@ -9,8 +10,9 @@
 //
 // Block = 4 waves = 64 tiles (4 tile rows x 16) x 64 output channels x all 16 positions; wave w owns position row i = w (positions
 // 4 w .. 4 w + 3) of every tile: 16 accumulator tiles of 32 x 32 = 256 accumulator registers, one block per CU.  History (rounds 3-4,
-// DESIGN.md section 5): versions 1-3 staged the filter records through LDS by LDS-DMA and were bound by that staging (conv3_2: 208-232 us
-// against the float32 kernel's 174); version 4 below loads them straight into registers (conv3_2: 119 us).
+// DESIGN.md section 5): round 3's three variants staged the filter records through LDS by LDS-DMA and were bound by that staging
+// (conv3_2: 208-232 us against the float32 kernel's 174); the kernel below loads them straight into registers (conv3_2: 119 us), then moved
+// the halo to an LDS-DMA ring and the prologue's small loads to DMA (105 us).
 #include "x3t.h"
 
 namespace frcnn {
@@ -226,7 +228,7 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     const float rsgn = wave != 1 ? -1.0f : 1.0f;                             // i = 1: d1 + d2; i = 0, 2, 3: differences
     // LDS halo layout [row][column parity][17 slots][20 floats]: the 16 lanes of a tile row read patch column b of their tiles at pixel
     // columns 2 t + b, i.e. at CONSECUTIVE slots t + (b >> 1) of parity b & 1 -- 80 bytes apart, and 16 x 80 B covers every bank group once
-    // (with the plain [row][column] layout of versions 1-3 the lanes are 160 B apart: lanes t and t + 8 collide, every read takes twice)
+    // (with a plain [row][column] layout the lanes are 160 B apart: lanes t and t + 8 collide, every read takes twice)
     const int d_lane = (4 * tyl * XD_HP + txl) * XF_PS + 8 * kh;             // + ((4 h + a) 2 + (b & 1)) XD_HP XF_PS + (b >> 1) XF_PS
     float r[4][8];                                                           // [patch column b][channel]
     f32x4 du0, du1, dw0, dw1;                                                // the two patch rows of one column on their way from LDS

@@ -1,4 +1,4 @@
-"""tools/xd_clocks.py -- where a block of the one-launch f32x3 Winograd kernel (csrc/wino_x3f.hip, version 4) spends its time.
+"""tools/xd_clocks.py -- where a block of the one-launch f32x3 Winograd kernel (csrc/wino_x3f.hip) spends its time.
 Needs a library built with -DXD_CLOCKS:  SRC=wino_x3f tools/build_ablate.sh xdclk -DXD_CLOCKS ; FRCNN_LIB_PATH=build/libfrcnn_xdclk.so"""
 import sys
 import numpy as np
