@@ -119,7 +119,7 @@ int frcnn_pack_stack_rows(const float* d_w1, const float* d_b1, int n1,
  * d_w_packed from frcnn_pack_conv3x3_c3. */
 int frcnn_conv3x3_c3(const float* d_x_chw, const float* d_w_packed, const float* d_bias,
                      float* d_y, int H, int W, int cout, unsigned flags, void* stream);
-/* The same layer (cout = 64 only) that also leaves the per-pixel maximum |y| over the 64 output channels in d_cmax_out [H][W]: the scale
+/* The same layer (models/vgg16.py:76 conv1_1 + ReLU; cout = 64 only) that also leaves the per-pixel maximum |y| over the 64 output channels in d_cmax_out [H][W]: the scale
  * source of an f32x3 layer that consumes y (d_cmax_in of frcnn_conv3x3_nhwc_winograd_x3_chain).  A plain store per pixel from the lanes
  * that hold its channels (no atomics, nothing to zero); y is bit-identical to frcnn_conv3x3_c3's.  ABI 10. */
 int frcnn_conv3x3_c3_cmax(const float* d_x_chw, const float* d_w_packed, const float* d_bias,
@@ -696,7 +696,8 @@ int frcnn_conv3x3_wgrad_math(const float* d_x, const float* d_dz, float* d_dwp, 
                              int grad_math, void* d_ws, size_t ws_bytes, void* stream);
 int frcnn_conv_wgrad_math(const float* d_x, const float* d_dz, float* d_dwp, int N, int H, int W, int cin, int cout,
                           int ksize, int stride, int pad, int grad_math, void* d_ws, size_t ws_bytes, void* stream);
-/* ABI 10: the FORWARD and DATA-GRADIENT convolutions of the ResNet train step with the same switch (BASELINE configs[4] as written:
+/* ABI 10: the FORWARD and DATA-GRADIENT convolutions of the ResNet train step (models/faster_rcnn.py:228-362 train_step over the Bottleneck
+ * convolutions of models/resnet.py:38-46,110 and their autograd backward) with the same switch (BASELINE configs[4] as written:
  * "train step ... bf16"): frcnn_conv_nhwc / frcnn_conv_dgrad with `math` = FRCNN_GRAD_BF16 round both operands (activations or output
  * gradients, and the folded weight pack) to bfloat16 on their way into LDS and multiply on the bf16 matrix pipe (one
  * v_mfma_f32_32x32x16_bf16 per 16-channel stage where the float32 kernel issues eight float32 instructions), float32 accumulation,
@@ -753,7 +754,7 @@ int frcnn_transpose(const float* d_x, int ldi, float* d_y, int ldo, int rows, in
  * momentum*buf + g; w -= lr*buf (layout agnostic: applied to the packed weights). */
 int frcnn_sgd_step(float* d_w, const float* d_grad, float* d_momentum_buf, size_t n, float lr, float momentum,
                    float weight_decay, int first_step, void* stream);
-/* The same update of a convolution master [taps][cout][cin] whose frozen BatchNorm is folded into the convolution (ResNet bottlenecks),
+/* The same update (__main__.py:98-105 SGD) of a convolution master [taps][cout][cin] whose frozen BatchNorm (models/resnet.py:58-77) is folded into the convolution (ResNet bottlenecks),
  * with the folded pack rebuilt in the same launch: d_folded = w_new * d_scale[co] (frcnn_scale_rows' product; n = taps*cout*cin).  ABI 10. */
 int frcnn_sgd_step_fold(float* d_w, const float* d_grad, float* d_momentum_buf, size_t n, float lr, float momentum,
                         float weight_decay, int first_step, const float* d_scale, float* d_folded, int cout, int cin, void* stream);
