@@ -320,6 +320,36 @@ def test_anchor_maps_argument_and_async_slots(gpu_model):
     p.result()
 
 
+def test_inflight_slots_are_deterministic_under_load(gpu_model):
+    """The same images through predict_async with 1, 2, 3, 5 and 8 images in flight, in shuffled order, over and over (tools/soak_inflight.py
+    is the long form): every result of an image is bit-identical to its first in-flight result whatever else runs beside it and whichever
+    slot it lands in.  The one-launch f32x3 kernel orders its LDS-DMA ring by s_waitcnt counts and one barrier per chunk; a race there would
+    surface as a differing bit under some interleaving."""
+    imgs = [synthetic.image(300 + i).unsqueeze(0).cuda() for i in range(4)]
+    imgs += [synthetic.image(400 + i, h, w).unsqueeze(0).cuda() for i, (h, w) in enumerate([(224, 320), (333, 517)])]
+    first, checked = {}, 0
+
+    def check(j, res, n):
+        if j not in first:
+            first[j] = res
+            return 0
+        for c in res:
+            assert np.array_equal(first[j][c], res[c]), "image %d differs with %d in flight (class %d)" % (j, n, c)
+        return 1
+    for n in (1, 2, 3, 5, 8, 3):
+        for rep in range(3):
+            order = np.random.RandomState(rep * 10 + n).permutation(len(imgs) * 3) % len(imgs)
+            pending = []
+            for k, ii in enumerate(order):
+                if len(pending) == n:
+                    j, p = pending.pop(0)
+                    checked += check(j, p.result(), n)
+                pending.append((int(ii), gpu_model.predict_async(imgs[int(ii)], 0.05, slot=1 + (k % n))))
+            for j, p in pending:
+                checked += check(j, p.result(), n)
+    assert checked >= 300
+
+
 def test_hip_graph_replay_equals_eager(gpu_model):
     """use_hip_graphs: the second call of a shape captures the image's launches, later calls replay them -- bit-identical to the
     eager launches, also after a different shape ran in between (the graph is dropped and re-captured) and on an in-flight slot."""
