@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
-ABI_VERSION = 10    # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
+ABI_VERSION = 11    # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
@@ -31,7 +31,7 @@ SYMBOLS = (
     "frcnn_nms", "frcnn_roi_pool", "frcnn_roi_pool_x3t", "frcnn_detections", "frcnn_ctx_create", "frcnn_ctx_create_proposals", "frcnn_ctx_destroy",
     "frcnn_ctx_bytes", "frcnn_vgg16_forward", "frcnn_ctx_tensor", "frcnn_ctx_timing_enable",
     "frcnn_ctx_timing_read",
-    "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv_nhwc_math", "frcnn_conv7x7_s2_c3",
+    "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv_nhwc_math", "frcnn_conv_nhwc_x3g", "frcnn_tensor_absmax", "frcnn_conv7x7_s2_c3",
     "frcnn_maxpool3x3_s2_nhwc", "frcnn_spatial_mean_nhwc", "frcnn_resnet_forward", "frcnn_rpn_targets",
     "frcnn_pack_conv3x3_x6", "frcnn_conv3x3_nhwc_x6", "frcnn_preprocess_workspace_bytes", "frcnn_preprocess",
     "frcnn_conv3x3_uses_winograd", "frcnn_resnet_block_uses_winograd", "frcnn_pack_conv3x3_winograd",
@@ -85,7 +85,8 @@ RESNET_MAX_BLOCKS = 64
 class BottleneckWeights(C.Structure):
     _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
                 ("w3", C.c_void_p), ("b3", C.c_void_p), ("wd", C.c_void_p), ("bd", C.c_void_p),
-                ("cin", C.c_int32), ("width", C.c_int32), ("cout", C.c_int32), ("stride", C.c_int32), ("x6_mask", C.c_int32), ("x3_mask", C.c_int32)]
+                ("cin", C.c_int32), ("width", C.c_int32), ("cout", C.c_int32), ("stride", C.c_int32), ("x6_mask", C.c_int32), ("x3_mask", C.c_int32),
+                ("wmax", C.c_void_p), ("g3", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class ResNetWeights(C.Structure):
@@ -262,6 +263,8 @@ _SIGNATURES = {
     "frcnn_conv_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "frcnn_conv_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_conv_nhwc_math": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _i, _vp, _sz, _vp]),
+    "frcnn_conv_nhwc_x3g": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_tensor_absmax": (C.c_int, [_vp, C.c_longlong, _vp, _vp]),
     "frcnn_conv7x7_s2_c3": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp]),
     "frcnn_maxpool3x3_s2_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "frcnn_spatial_mean_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),

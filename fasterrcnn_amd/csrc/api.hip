@@ -49,6 +49,10 @@ struct frcnn_ctx {
     void* rx_rec = nullptr; size_t rx_rec_bytes = 0;     // activation records of the x6 1x1 convolutions (ResNet bottlenecks); on first use
     void* rx_ws = nullptr; size_t rx_ws_bytes = 0;       // their split-K partials
     float* rx_aux = nullptr; size_t rx_aux_floats = 0;   // f32x3 form: row scales of the record array + channel maxima of the layer input
+    // g3 bottlenecks (frcnn_bottleneck_weights.g3): the tensor maxima handed from one convolution's epilogue to the next one's scale.  One
+    // zeroed float per convolution output of a forward (gx_next counts them; one memset per stage), gx_x = the slot bounding the CURRENT
+    // block input (null: unknown, the next g3 block measures it)
+    float* gx_max = nullptr; int gx_next = 0; const float* gx_x = nullptr;
     float* res_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // ResNet bottleneck rotation
     size_t res_buf_floats = 0;
     int last_c = 512, last_vec = 4096, last_head_ld = 128;
@@ -488,6 +492,23 @@ int frcnn_conv_nhwc_math(const float* d_x, const float* d_wp, const float* d_bia
                               d_ws, ws_bytes, as_stream(stream), math);
 }
 
+int frcnn_conv_nhwc_x3g(const float* d_x, const float* d_wp, const float* d_bias, const float* d_residual, float* d_y,
+                        int N, int H, int W, int cin, int cout, int ksize, int stride, int pad, unsigned flags,
+                        const float* d_xmax, const float* d_wmax, float* d_ymax, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!d_x || !d_wp || !d_bias || !d_y || !d_xmax || !d_wmax) return FRCNN_EINVAL;
+    if (flags & FRCNN_POOL2) return FRCNN_EUNSUPPORTED;
+    const GatherX3 x3{d_xmax, d_wmax, d_ymax};
+    return launch_conv_gather(d_x, d_wp, d_bias, d_residual, d_y, N, H, W, cin, cout, ksize, stride, pad, flags,
+                              d_ws, ws_bytes, as_stream(stream), FRCNN_CONV_F32X3G, &x3);
+}
+
+int frcnn_tensor_absmax(const float* d_x, long long n, float* d_out, void* stream)
+{
+    if (!d_x || !d_out) return FRCNN_EINVAL;
+    return launch_tensor_absmax(d_x, n, d_out, as_stream(stream));
+}
+
 int frcnn_conv7x7_s2_c3(const float* d_x, const float* d_wp, const float* d_bias, float* d_y, int H, int W,
                         int cout, unsigned flags, void* stream)
 {
@@ -912,6 +933,7 @@ void frcnn_ctx_destroy(frcnn_ctx* ctx)
     if (ctx->rx_rec) (void)hipFree(ctx->rx_rec);
     if (ctx->rx_ws) (void)hipFree(ctx->rx_ws);
     if (ctx->rx_aux) (void)hipFree(ctx->rx_aux);
+    if (ctx->gx_max) (void)hipFree(ctx->gx_max);
     delete ctx;
 }
 
@@ -1434,6 +1456,27 @@ int run_conv1x1_x3(frcnn_ctx* c, const float* x, const void* wblob, const float*
                            c->rx_ws_bytes, s);
 }
 
+// the next zeroed maximum slot of this context's current pass (GX_SLOTS floats, zeroed by gx_begin)
+static constexpr int GX_SLOTS = 512;
+int gx_begin(frcnn_ctx* c, hipStream_t s)
+{
+    if (!c->gx_max) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->gx_max), GX_SLOTS * sizeof(float));
+        if (e != hipSuccess) { set_hip_error(e); c->gx_max = nullptr; return FRCNN_ENOMEM; }
+    }
+    FRCNN_HIP_TRY(hipMemsetAsync(c->gx_max, 0, GX_SLOTS * sizeof(float), s));
+    c->gx_next = 0;
+    c->gx_x = nullptr;
+    return FRCNN_OK;
+}
+int gx_slot(frcnn_ctx* c, hipStream_t s, float** out)
+{
+    if (!c->gx_max || c->gx_next >= GX_SLOTS) return FRCNN_EINVAL;
+    (void)s;
+    *out = c->gx_max + c->gx_next++;
+    return FRCNN_OK;
+}
+
 // One Bottleneck (torchvision v1.5): out = relu(conv3(relu(conv2(relu(conv1(x))))) + identity).
 // x: [N][h][w][cin] in `cur`; returns the buffer index holding the output, updates h, w.
 // `backbone`: the block belongs to the feature extractor (layer1..3): its 3x3 is packed for the one-launch Winograd kernel whatever the
@@ -1456,6 +1499,34 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
     const size_t need1 = (size_t)N * h * w * b.width, need2 = (size_t)N * ho * wo * b.cout;
     if (need1 > c->res_buf_floats || need2 > c->res_buf_floats) return FRCNN_EINVAL;
 #define RSTEP(call) do { Scope _sc(c, cls_conv, s); rc = (call); } while (0); if (rc) return rc
+    if (b.g3 != 0) {
+        if (b.x6_mask != 0 || !b.wmax) return FRCNN_EINVAL;
+        float *m1, *m2, *m3;
+        if (!c->gx_x) {                                          // the block input came from a kernel that leaves no maximum behind
+            float* mx;
+            if ((rc = gx_slot(c, s, &mx))) return rc;
+            RSTEP(launch_tensor_absmax(X, (long long)N * h * w * b.cin, mx, s));
+            c->gx_x = mx;
+        }
+        if ((rc = gx_slot(c, s, &m1)) || (rc = gx_slot(c, s, &m2)) || (rc = gx_slot(c, s, &m3))) return rc;
+        const GatherX3 g1{c->gx_x, b.wmax + 0, m1}, g2{m1, b.wmax + 1, m2}, g3{m2, b.wmax + 2, m3}, gd{c->gx_x, b.wmax + 3, nullptr};
+        const int X3 = FRCNN_CONV_F32X3G;
+        RSTEP(launch_conv_gather(X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s, X3, &g1));
+        RSTEP(launch_conv_gather(T1, b.w2, b.b2, nullptr, T2, N, h, w, b.width, b.width, 3, b.stride, 1, R, c->conv_ws, c->conv_ws_bytes, s, X3, &g2));
+        const float* identity = X;
+        if (b.wd) {
+            RSTEP(launch_conv_gather(X, b.wd, b.bd, nullptr, ID, N, h, w, b.cin, b.cout, 1, b.stride, 0, 0u, c->conv_ws, c->conv_ws_bytes, s, X3, &gd));
+            identity = ID;
+        } else if (b.cin != b.cout || b.stride != 1) {
+            return FRCNN_EINVAL;
+        }
+        RSTEP(launch_conv_gather(T2, b.w3, b.b3, identity, OUT, N, ho, wo, b.width, b.cout, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s, X3, &g3));
+        c->gx_x = m3;
+        h = ho; w = wo;
+        *out_idx = f[3];
+        return FRCNN_OK;
+    }
+    c->gx_x = nullptr;
     if (b.x6_mask != 0 && !wino) return FRCNN_EINVAL;
     if ((b.x3_mask & ~b.x6_mask) != 0) return FRCNN_EINVAL;          // x3_mask: the subset of the split-operand convolutions in f32x3
     if (b.x6_mask & FRCNN_X6_CONV1) {
@@ -1565,6 +1636,11 @@ int resnet_stage1(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forwa
     }
     h = hp; wd = wp;
     int cur = 1, bi = 0;
+    {
+        bool any_g3 = false;
+        for (int i = 0; i < w->n_blocks[0] + w->n_blocks[1] + w->n_blocks[2]; ++i) any_g3 = any_g3 || w->blocks[i].g3 != 0;
+        if (any_g3 && (rc = gx_begin(c, s))) return rc;
+    }
     for (int layer = 0; layer < 3; ++layer)
         for (int k = 0; k < w->n_blocks[layer]; ++k, ++bi) {
             int out = -1;
@@ -1625,6 +1701,11 @@ int resnet_tail(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward
     float* saved = c->res_buf[0];
     c->res_buf[0] = c->roi_out;
     int cur = 0, h = 7, wd = 7;
+    {
+        bool any_g3 = false;
+        for (int k = 0; k < w->n_blocks[3]; ++k) any_g3 = any_g3 || w->blocks[bi + k].g3 != 0;
+        if (any_g3 && (rc = gx_begin(c, s))) { c->res_buf[0] = saved; return rc; }
+    }
     for (int k = 0; k < w->n_blocks[3]; ++k, ++bi) {
         int out = -1;
         rc = run_bottleneck(c, w->blocks[bi], R_, h, wd, cur, &out, s, 2, wino, p->conv_blocks_target == 0, false);

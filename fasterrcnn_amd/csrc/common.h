@@ -109,9 +109,15 @@ int launch_conv3x3_x6(const float* x, const void* wq, const float* b, float* y, 
 
 // conv_gather.hip (ResNet path)
 size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R, int stride, int pad);
+// math FRCNN_CONV_F32X3G: both operands as two fp16 terms under ONE power-of-two scale per tensor (conv_gather_x3_kernel); x3 names the
+// device floats holding an upper bound of max|x|, max|wp| and (or null) the float that receives max|y| by atomic maximum (zero it first)
+#define FRCNN_CONV_F32X3G 2
+struct GatherX3 { const float* xmax; const float* wmax; float* ymax; };
 int launch_conv_gather(const float* x, const float* wp, const float* bias, const float* residual, float* y,
                        int N, int H, int W, int cin, int cout, int R, int stride, int pad, unsigned flags,
-                       void* ws, size_t ws_bytes, hipStream_t s, int math = FRCNN_GRAD_F32);
+                       void* ws, size_t ws_bytes, hipStream_t s, int math = FRCNN_GRAD_F32, const GatherX3* x3 = nullptr);
+// out[0] = max(out[0], max |x[i]|) (out zeroed by the caller or holding an earlier maximum)
+int launch_tensor_absmax(const float* x, long long n, float* out, hipStream_t s);
 int launch_conv7x7_s2_c3(const float* x, const float* wp, const float* b, float* y, int H, int W, int cout,
                          unsigned flags, hipStream_t s);
 int launch_maxpool3x3_s2(const float* x, float* y, int H, int W, int c, hipStream_t s);

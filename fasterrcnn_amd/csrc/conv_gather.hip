@@ -10,6 +10,8 @@
 // deterministic split-K are those of linear.hip; the epilogue fuses the folded BatchNorm bias, the
 // residual add and ReLU (Bottleneck: out = relu(bn3(conv3) + identity)).
 #include "common.h"
+#include "x3t.h"
+#include <type_traits>
 
 namespace frcnn {
 
@@ -448,10 +450,333 @@ void conv_gather_bf16_kernel(const float* __restrict__ x, const float* __restric
     }
 }
 
+// ---- f32x3 operands under ONE power-of-two scale per tensor (round 4: the ResNet backbone at inference) -------------------------------------------
+// The gather implicit GEMM in the split-operand arithmetic of csrc/gemm_x3t.hip -- every operand value as two fp16 terms hi = fp16(v 2^e),
+// lo = fp16(v 2^e - hi), three v_mfma_f32_32x32x16_f16 per product (lo x hi, hi x hi, hi x lo), float32 accumulation -- with the split done
+// ON THE WAY INTO LDS (two v_fma_mix per value) instead of by a separate record-writing pass, which is what makes it a drop-in for the
+// float32 kernel: no activation records, no per-row scale arrays, the float32 weight pack as is.  The scale is per TENSOR: 2^e with
+// max|x| 2^e in [2^14, 2^15), max|x| read from a device float the PRODUCER of x left behind (this kernel's own epilogue, atomic maximum over
+// its outputs; the stem convolution's) -- any upper bound works, so nothing is read twice.  A value far below the tensor's maximum keeps
+// 22 bits of ITSELF down to 2^-14 of the maximum and an absolute error of 2^-38 of the maximum below that: measured through the oracle on
+// the held-out ResNet-50 images (tools/exp_r50_global_scale.py) the proposals stay at 0.92-0.94 of the reference's own distance from the
+// float64 truth.  Matrix time per stage: 3 x 32 cycles against the float32 kernel's 8 x 64.
+typedef _Float16 gx_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gx_u32x2 __attribute__((ext_vector_type(2)));
+// A stage is 32 input channels of one filter tap.  LDS row of a stage: [hi 16 | lo 16] of channels 0..15, [hi 16 | lo 16] of 16..31,
+// 8 fp16 of padding (144 B: the 16-byte fragment reads of 16 consecutive rows cover the 64 banks once)
+static constexpr int GX_ROW = 72;
+template <int TM, int TN, int WM, int WN, int D>
+struct GatherX3Cfg {
+    static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    static constexpr int NA = BM / 32, NB = BN / 32;                      // 16-byte pieces of a stage per thread (8 per 32-channel row)
+    static constexpr int OUT_LD = BN + 4;                                 // the epilogue's float32 tile in LDS: row stride (conflict-free 16-byte writes)
+    static constexpr size_t STAGE_BYTES = (size_t)D * (BM + BN) * GX_ROW * sizeof(_Float16);
+    static constexpr size_t OUT_BYTES = (size_t)BM * OUT_LD * sizeof(float);
+    static constexpr size_t LDS_BYTES = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
+};
+
+// four floats -> their hi and lo fp16 terms under the scale m (two registers each); the bits of hx_split8 (x3t.h)
+__device__ __forceinline__ void gx_split4(const f32x4 v, float m, unsigned (&hi)[2], unsigned (&lo)[2])
+{
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi[0]) : "v"(v[0]), "v"(m));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi[1]) : "v"(v[2]), "v"(m));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi[0]) : "v"(v[1]), "v"(m));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi[1]) : "v"(v[3]), "v"(m));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lo[0]) : "v"(v[0]), "v"(m), "v"(hi[0]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lo[1]) : "v"(v[2]), "v"(m), "v"(hi[1]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo[0]) : "v"(v[1]), "v"(m), "v"(hi[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo[1]) : "v"(v[3]), "v"(m), "v"(hi[1]));
+}
+
+// One block's maximum into *out (a float >= 0, bit order = float order): four wave maxima through LDS, then ONE atomic -- and only when the
+// block's value exceeds what is already there (a stale read costs an atomic, never a wrong result): atomics on one address serialise at
+// a few ns each, and thousands of waves hitting one float cost more than the convolution (measured: 134 us against 36)
+__device__ __forceinline__ void gx_block_max(float vmax, float* out)
+{
+    __shared__ float red[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > __builtin_nontemporal_load(out)) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+    }
+}
+
+// Pipeline, depth D: D register sets and D LDS buffers in a ring.  While the matrix instructions of stage s run from LDS buffer s % D, the
+// float32 pieces of stage s + 1 (register set (s + 1) % D, fetched D stages ago) are converted and written to buffer (s + 1) % D and
+// the fetch of stage s + D + 1 is issued into the set just freed: a load has D whole stages to land (D = 2 at the 128 x 128 tile, 48
+// MFMAs a stage; D = 3 at the 64 x 64 tile, whose stages are a quarter as long), where the float32 kernel's single stage of eight
+// 64-cycle instructions per accumulator hid it by itself.
+// Block b -> tile: XCD b % 8 owns the row blocks m = 8 k + b % 8 and walks their column blocks, so an activation tile is fetched into
+// one XCD's L2 once; the weights (<= 2.4 MB) sit in every L2.
+// Epilogue: the accumulators go through LDS once so that a wave's 16-byte stores (and residual loads) cover whole 256 / 512-byte rows
+// of y instead of 32 bytes of 32 different rows.
+template <int TM, int TN, int WM, int WN, int D>
+__global__ __launch_bounds__(256, 2)
+void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                           const float* __restrict__ bias, const float* __restrict__ residual,
+                           float* __restrict__ y, float* __restrict__ ws, GatherShape g,
+                           int stages_per_split, int relu, const float* __restrict__ xmax, const float* __restrict__ wmax,
+                           float* __restrict__ ymax, int mblocks, int nblocks)
+{
+    using C = GatherX3Cfg<TM, TN, WM, WN, D>;
+#ifdef GX_CLOCKS
+    const unsigned long long gx_t_in = __builtin_amdgcn_s_memrealtime();
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char gx_smem[];
+    _Float16* const at_s = reinterpret_cast<_Float16*>(gx_smem);            // [D][BM][GX_ROW]
+    _Float16* const bt_s = at_s + D * C::BM * GX_ROW;                       // [D][BN][GX_ROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int jb = blockIdx.x >> 3;
+    const int mb = (jb / nblocks) * 8 + (blockIdx.x & 7), nb = jb % nblocks;
+    if (mb >= mblocks) return;
+    const int m0 = mb * C::BM, n0 = nb * C::BN;
+    const int M = g.N * g.Ho * g.Wo;
+    const int taps = g.R * g.S;
+    const int total_stages = (g.Cin >> 5) * taps;
+    const int st_begin = blockIdx.z * stages_per_split;
+    int st_end = st_begin + stages_per_split;
+    if (st_end > total_stages) st_end = total_stages;
+    const int nst = st_end - st_begin;
+
+    float xmult, xinv, wmult, winv;
+    hx_row_scale(*xmax, xmult, xinv);
+    hx_row_scale(*wmax, wmult, winv);
+
+    // thread -> piece: row (tid >> 3) + 32 it of the tile, channels 4 (tid & 7) .. + 3 of the stage.  Every fetch is a buffer load:
+    // per-piece byte offset (constant over the stages) in the VGPR, the stage's (tap, channel chunk) offset in an SGPR, and bit 31 of the
+    // VGPR offset = "outside" (row past the tile's data, tap outside the image): >= num_records, the load returns zeros -- no address
+    // arithmetic, no validity select and no 64-bit multiply in the loop.  The activation base is moved back by the padding so that both
+    // offsets stay non-negative.
+    constexpr unsigned OUTSIDE = 0x80000000u;
+    const int prow = tid >> 3, pc = tid & 7;
+    const int p_dst = prow * GX_ROW + (pc >> 2) * 32 + (pc & 3) * 4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) - (g.pad * g.W + g.pad) * g.Cin, 0, (int)OUTSIDE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, (int)OUTSIDE, 0x00020000);
+    unsigned a_off[C::NA], a_bad[C::NA];          // a_bad: bit t = tap t of this output pixel reads outside the image
+#pragma unroll
+    for (int it = 0; it < C::NA; ++it) {
+        const int m = m0 + prow + 32 * it;
+        a_off[it] = 0u; a_bad[it] = 0xFFFFFFFFu;
+        if (m < M) {
+            const int n = m / (g.Ho * g.Wo);
+            const int rem = m - n * g.Ho * g.Wo;
+            const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+            a_off[it] = (unsigned)((((n * g.H + oy * g.stride) * g.W + ox * g.stride) * g.Cin + pc * 4) * 4);
+            unsigned bad = 0u;
+            for (int r = 0; r < g.R; ++r)
+                for (int q = 0; q < g.S; ++q) {
+                    const int iy = oy * g.stride - g.pad + r, ix = ox * g.stride - g.pad + q;
+                    if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) bad |= 1u << (r * g.S + q);
+                }
+            a_bad[it] = bad;
+        }
+    }
+    unsigned b_off[C::NB];
+#pragma unroll
+    for (int it = 0; it < C::NB; ++it) {
+        const int n = n0 + prow + 32 * it;
+        b_off[it] = n < g.Cout ? (unsigned)((n * g.Cin + pc * 4) * 4) : OUTSIDE;
+    }
+
+    // the next stage to fetch (never past the split's last one: the tail re-fetches it and nobody reads the copy)
+    int ld_stage = st_begin, ld_chunk = st_begin / taps, ld_tap = st_begin - (st_begin / taps) * taps;
+    f32x4 areg[D][C::NA], breg[D][C::NB];
+    auto load_tiles = [&](f32x4 (&ar)[C::NA], f32x4 (&br)[C::NB]) {
+        const int r = g.S == 1 ? 0 : (ld_tap * 11) >> 5;                 // tap / 3 for tap < 9 (R = S in {1, 3})
+        const int q = ld_tap - r * g.S;
+        const int so_a = ((r * g.W + q) * g.Cin + ld_chunk * 32) * 4;
+        const int so_b = (ld_tap * g.Cout * g.Cin + ld_chunk * 32) * 4;
+        const unsigned sh = 31u - (unsigned)ld_tap;
+#pragma unroll
+        for (int it = 0; it < C::NA; ++it)
+            ar[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(a_off[it] | ((a_bad[it] << sh) & OUTSIDE)), so_a, 0));
+#pragma unroll
+        for (int it = 0; it < C::NB; ++it)
+            br[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)b_off[it], so_b, 0));
+        if (ld_stage + 1 < st_end) {
+            ++ld_stage;
+            if (++ld_tap == taps) { ld_tap = 0; ++ld_chunk; }
+        }
+    };
+    auto store_tiles = [&](int buf, const f32x4 (&ar)[C::NA], const f32x4 (&br)[C::NB]) {
+        _Float16* const ad = at_s + buf * C::BM * GX_ROW + p_dst;
+        _Float16* const bd = bt_s + buf * C::BN * GX_ROW + p_dst;
+#pragma unroll
+        for (int it = 0; it < C::NA; ++it) {
+            unsigned hi[2], lo[2];
+            gx_split4(ar[it], xmult, hi, lo);
+            *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW) = gx_u32x2{hi[0], hi[1]};
+            *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW + 16) = gx_u32x2{lo[0], lo[1]};
+        }
+#pragma unroll
+        for (int it = 0; it < C::NB; ++it) {
+            unsigned hi[2], lo[2];
+            gx_split4(br[it], wmult, hi, lo);
+            *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW) = gx_u32x2{hi[0], hi[1]};
+            *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW + 16) = gx_u32x2{lo[0], lo[1]};
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int a_base = (32 * TM * wm + li) * GX_ROW + 8 * lh;
+    const int b_base = (32 * TN * wn + li) * GX_ROW + 8 * lh;
+    // stage s (P = s % D): fragments from LDS buffer P; register set Q = (s + 1) % D -> LDS buffer Q; stage s + D + 1 -> register set Q
+    auto stage = [&](auto par) {
+        constexpr int P = decltype(par)::value, Q = (P + 1) % D;
+        const _Float16* const as = at_s + P * C::BM * GX_ROW + a_base;
+        const _Float16* const bs = bt_s + P * C::BN * GX_ROW + b_base;
+        gx_f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[kk][i] = *reinterpret_cast<const gx_f16x8*>(as + i * 32 * GX_ROW + kk * 32);
+                al[kk][i] = *reinterpret_cast<const gx_f16x8*>(as + i * 32 * GX_ROW + kk * 32 + 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[kk][j] = *reinterpret_cast<const gx_f16x8*>(bs + j * 32 * GX_ROW + kk * 32);
+                bl[kk][j] = *reinterpret_cast<const gx_f16x8*>(bs + j * 32 * GX_ROW + kk * 32 + 16);
+            }
+        }
+        store_tiles(Q, areg[Q], breg[Q]);
+        load_tiles(areg[Q], breg[Q]);
+        // per accumulator and 16 channels: weight lo x activation hi, hi x hi, hi x lo (gemm_x3t_kernel's order; the weights are the row operand)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk][j], ah[kk][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk][j], ah[kk][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk][j], al[kk][i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    };
+#ifdef GX_CLOCKS
+    unsigned long long gx_t_setup = 0, gx_t_first = 0;
+#endif
+    if (nst > 0) {
+#ifdef GX_CLOCKS
+        gx_t_setup = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+        for (int d = 0; d < D; ++d) load_tiles(areg[d], breg[d]);          // stages 0 .. D - 1
+        store_tiles(0, areg[0], breg[0]);
+        load_tiles(areg[0], breg[0]);                                      // stage D
+        __syncthreads();
+#ifdef GX_CLOCKS
+        gx_t_first = __builtin_amdgcn_s_memrealtime();
+#endif
+        // groups of D stages WITHOUT a branch between them: a conditional stage inside the loop makes the compiler's wait-count
+        // bookkeeping at the loop head assume the worst path (wait for the newest loads), which undoes the pipeline; the remainder
+        // runs after the loop
+        int s = 0;
+        for (; s + D <= nst; s += D) {
+            stage(std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 1>{});
+            if constexpr (D == 3) stage(std::integral_constant<int, 2>{});
+        }
+        if (s < nst) stage(std::integral_constant<int, 0>{});
+        if constexpr (D == 3) { if (s + 1 < nst) stage(std::integral_constant<int, 1>{}); }
+    }
+
+    // epilogue: accumulators -> LDS [BM][OUT_LD] (the last stage's barrier has retired every fragment read), then rows of the tile by
+    // consecutive threads: scales taken out (exact powers of two), bias / residual / ReLU as conv_gather_mfma_kernel, the maximum kept
+#ifdef GX_CLOCKS
+    const unsigned long long gx_t_loop = __builtin_amdgcn_s_memrealtime();
+#endif
+    float* const out_s = reinterpret_cast<float*>(gx_smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                *reinterpret_cast<f32x4*>(out_s + (32 * (TM * wm + i) + li) * C::OUT_LD + 32 * (TN * wn + j) + 8 * q + 4 * lh) = v;
+            }
+    __syncthreads();
+    const bool direct = (gridDim.z == 1);
+    float* const dst = direct ? y : ws + (size_t)blockIdx.z * M * g.Cout;
+    const float unscale = xinv * winv;
+    float vmax = 0.f;
+    constexpr int QN = C::BN / 4, RSTEP = 256 / QN;          // 16-byte pieces per tile row; rows covered by the block per pass
+    const int ec = (tid % QN) * 4, er = tid / QN;
+    const int n = n0 + ec;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (direct && bias && n < g.Cout) bv = *reinterpret_cast<const f32x4*>(bias + n);
+    if (n < g.Cout) {
+#pragma unroll 4
+        for (int r = er; r < C::BM; r += RSTEP) {
+            const int m = m0 + r;
+            if (m >= M) break;
+            f32x4 v = *reinterpret_cast<const f32x4*>(out_s + r * C::OUT_LD + ec);
+            if (direct) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * unscale + bv[e];
+                if (residual) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + (size_t)m * g.Cout + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[e]));
+            }
+            *reinterpret_cast<f32x4*>(dst + (size_t)m * g.Cout + n) = v;
+        }
+    }
+    if (direct && ymax) gx_block_max(vmax, ymax);
+#ifdef GX_CLOCKS
+    // timing build (tools/gx_clocks.py): thread 0 of every block leaves its stamps (10 ns units) behind the output
+    if (tid == 0 && direct) {
+        const unsigned long long t_out = __builtin_amdgcn_s_memrealtime();
+        float* rec = y + (size_t)M * g.Cout + (size_t)blockIdx.x * 8;
+        rec[0] = (float)(gx_t_setup - gx_t_in); rec[1] = (float)(gx_t_first - gx_t_setup); rec[2] = (float)(gx_t_loop - gx_t_first);
+        rec[3] = (float)(t_out - gx_t_loop); rec[4] = (float)(gx_t_in & 0xFFFFFF); rec[5] = (float)(t_out & 0xFFFFFF); rec[6] = (float)nst; rec[7] = 1.0f;
+    }
+#endif
+}
+
+// xmax / wmax (f32x3 mode, else null): the partial planes hold accumulators still multiplied by the two tensor scales; ymax: see above
 __global__ __launch_bounds__(256)
 void gather_splitk_finish_kernel(const float* __restrict__ ws, int splits, const float* __restrict__ bias,
-                                 const float* __restrict__ residual, float* __restrict__ y, int M, int Cout, int relu)
+                                 const float* __restrict__ residual, float* __restrict__ y, int M, int Cout, int relu,
+                                 const float* __restrict__ xmax = nullptr, const float* __restrict__ wmax = nullptr, float* __restrict__ ymax = nullptr)
 {
+    float unscale = 1.0f;
+    if (xmax) {
+        float xm, xi, wm_, wi;
+        hx_row_scale(*xmax, xm, xi);
+        hx_row_scale(*wmax, wm_, wi);
+        unscale = xi * wi;
+    }
+    float vmax = 0.f;
     const int C4 = Cout >> 2;
     const size_t total = (size_t)M * C4;
     const size_t plane = (size_t)M * Cout;
@@ -469,11 +794,13 @@ void gather_splitk_finish_kernel(const float* __restrict__ ws, int splits, const
         if (residual) r = reinterpret_cast<const f32x4*>(residual)[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float t = v[j] + b[j] + r[j];
+            const float t = (xmax ? v[j] * unscale : v[j]) + b[j] + r[j];
             v[j] = relu ? fmaxf(t, 0.f) : t;
+            vmax = fmaxf(vmax, fabsf(v[j]));
         }
         reinterpret_cast<f32x4*>(y)[i] = v;
     }
+    if (ymax) gx_block_max(vmax, ymax);
 }
 
 // ---- small ResNet-only kernels -----------------------------------------------------------------
@@ -590,8 +917,59 @@ __global__ void fold_bn_pack_kernel(const float* __restrict__ w, const float* __
     }
 }
 
+__global__ __launch_bounds__(256)
+void tensor_absmax_kernel(const float* __restrict__ x, long long n4, long long n, float* __restrict__ out)
+{
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) m = fmaxf(m, fabsf(x[4 * n4 + threadIdx.x]));
+    gx_block_max(m, out);
+}
+
 // ---- host side ----------------------------------------------------------------------------------
+int launch_tensor_absmax(const float* x, long long n, float* out, hipStream_t s)
+{
+    if (n < 1 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return FRCNN_EINVAL;
+    const long long n4 = n / 4;
+    long long blocks = (n4 + 1023) / 1024;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(tensor_absmax_kernel, dim3((int)blocks), dim3(256), 0, s, x, n4, n, out);
+    return check_launch();
+}
+
 struct GatherPlan { int cfg; int mblocks, nblocks, splits, stages_per_split; };
+
+// f32x3 kernel: stages of 32 channels; tiles 128 x 128 (cfg 0), 128 x 64 (cfg 2), 64 x 64 (cfg 3) -- the largest one that still gives
+// every CU a block, else the smallest; the reduction is split only when even that leaves most of the chip idle AND each part keeps
+// enough stages to amortise the pipeline's three-stage ramp
+static GatherPlan plan_gather_x3(int M, int Cout, int stages)
+{
+    static const int tiles_min = []() { const char* e = frcnn_knob("FRCNN_GATHER_X3_TILES"); return e ? atoi(e) : 224; }();
+    static const int split_to = []() { const char* e = frcnn_knob("FRCNN_GATHER_X3_BLOCKS"); return e ? atoi(e) : 256; }();
+    GatherPlan p;
+    const int big_n = Cout <= 64 ? 64 : 128;
+    p.cfg = Cout <= 64 ? 2 : 0;
+    p.mblocks = cdiv(M, 128);
+    p.nblocks = cdiv(Cout, big_n);
+    if (p.mblocks * p.nblocks < tiles_min) {
+        p.cfg = 3;
+        p.mblocks = cdiv(M, 64);
+        p.nblocks = cdiv(Cout, 64);
+    }
+    const int blocks = p.mblocks * p.nblocks;
+    int want = cdiv(split_to, blocks);
+    if ((size_t)want * M * Cout * sizeof(float) > ((size_t)24 << 20)) want = 1;      // the partial planes would cost more than the tail they fill
+    int cap = stages / 8;
+    if (cap < 1) cap = 1;
+    if (want > cap) want = cap;
+    p.stages_per_split = cdiv(stages, want);
+    p.splits = cdiv(stages, p.stages_per_split);
+    return p;
+}
 
 static GatherPlan plan_gather(int M, int Cout, int stages, int math = FRCNN_GRAD_F32)
 {
@@ -625,7 +1003,21 @@ size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R
     if (Ho < 1 || Wo < 1) return 0;
     const int M = N * Ho * Wo;
     const GatherPlan p = plan_gather(M, cout, (cin / 16) * R * R);
-    return p.splits > 1 ? (size_t)p.splits * M * cout * sizeof(float) : 0;
+    const GatherPlan q = plan_gather_x3(M, cout, (cin / 32 > 0 ? cin / 32 : 1) * R * R);
+    const int splits = p.splits > q.splits ? p.splits : q.splits;
+    return splits > 1 ? (size_t)splits * M * cout * sizeof(float) : 0;
+}
+
+template <int TM, int TN, int WM, int WN, int D>
+static int launch_gather_x3_cfg(const GatherPlan& p, const float* x, const float* wp, const float* bias, const float* residual, float* y, float* ws,
+                                const GatherShape& g, int relu, hipStream_t s, const GatherX3* x3)
+{
+    using X = GatherX3Cfg<TM, TN, WM, WN, D>;
+    auto kx = conv_gather_x3_kernel<TM, TN, WM, WN, D>;
+    FRCNN_MAX_LDS_ONCE(kx, X::LDS_BYTES);
+    hipLaunchKernelGGL(kx, dim3(8 * p.nblocks * cdiv(p.mblocks, 8), 1, p.splits), dim3(256), X::LDS_BYTES, s, x, wp, bias, residual, y, ws, g,
+                       p.stages_per_split, relu, x3->xmax, x3->wmax, x3->ymax, p.mblocks, p.nblocks);
+    return check_launch();
 }
 
 template <int TM, int TN, int WM, int WN>
@@ -634,6 +1026,7 @@ static int launch_gather_cfg(const GatherPlan& p, const float* x, const float* w
 {
     using C = GatherCfg<TM, TN, WM, WN>;
     dim3 grid(p.nblocks, p.mblocks, p.splits);
+
     if (math == FRCNN_GRAD_BF16) {
         hipLaunchKernelGGL((conv_gather_bf16_kernel<TM, TN, WM, WN>), grid, dim3(256), 0, s, x, wp, bias, residual, y, ws, g, p.stages_per_split, relu);
         return check_launch();
@@ -646,10 +1039,11 @@ static int launch_gather_cfg(const GatherPlan& p, const float* x, const float* w
 
 int launch_conv_gather(const float* x, const float* wp, const float* bias, const float* residual, float* y,
                        int N, int H, int W, int cin, int cout, int R, int stride, int pad, unsigned flags,
-                       void* ws, size_t ws_bytes, hipStream_t s, int math)
+                       void* ws, size_t ws_bytes, hipStream_t s, int math, const GatherX3* x3)
 {
     if (N < 1 || H < 1 || W < 1 || cin % 16 != 0 || cout % 4 != 0 || R < 1 || stride < 1 || pad < 0) return FRCNN_EINVAL;
-    if (math != FRCNN_GRAD_F32 && math != FRCNN_GRAD_BF16) return FRCNN_EINVAL;
+    if (math != FRCNN_GRAD_F32 && math != FRCNN_GRAD_BF16 && math != FRCNN_CONV_F32X3G) return FRCNN_EINVAL;
+    if (math == FRCNN_CONV_F32X3G && (!x3 || !x3->xmax || !x3->wmax)) return FRCNN_EINVAL;
     GatherShape g;
     g.transposed = 0;
     g.N = N; g.H = H; g.W = W; g.Cin = cin; g.Cout = cout; g.R = R; g.S = R; g.stride = stride; g.pad = pad;
@@ -657,22 +1051,37 @@ int launch_conv_gather(const float* x, const float* wp, const float* bias, const
     g.Wo = (W + 2 * pad - R) / stride + 1;
     if (g.Ho < 1 || g.Wo < 1) return FRCNN_EINVAL;
     const int M = N * g.Ho * g.Wo;
-    GatherPlan p = plan_gather(M, cout, (cin / 16) * R * R, math);
+    const bool gx3 = math == FRCNN_CONV_F32X3G;
+    // the f32x3 kernel: 32-channel stages, 1x1 / 3x3 taps, 31-bit byte offsets into the activations (moved back by the padding) and weights
+    if (gx3 && ((R != 1 && R != 3) || cin % 32 != 0 || pad > R / 2 + 1 ||
+                ((size_t)N * H * W + (size_t)pad * W + pad) * cin * sizeof(float) >= ((size_t)1 << 31) ||
+                (size_t)R * R * cout * cin * sizeof(float) >= ((size_t)1 << 31)))
+        return FRCNN_EUNSUPPORTED;
+    const int all_stages = gx3 ? (cin / 32) * R * R : (cin / 16) * R * R;
+    GatherPlan p = gx3 ? plan_gather_x3(M, cout, all_stages) : plan_gather(M, cout, all_stages, math);
     const size_t need = p.splits > 1 ? (size_t)p.splits * M * cout * sizeof(float) : 0;
     if (need > ws_bytes || (need > 0 && ws == nullptr)) {       // no scratch: run un-split
         p.splits = 1;
-        p.stages_per_split = (cin / 16) * R * R;
+        p.stages_per_split = all_stages;
     }
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
-    int rc = p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, math)
+    int rc;
+    if (gx3)
+        rc = p.cfg == 2 ? launch_gather_x3_cfg<2, 1, 2, 2, 2>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3)
+           : p.cfg == 3 ? launch_gather_x3_cfg<1, 1, 2, 2, 3>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3)
+                        : launch_gather_x3_cfg<2, 2, 2, 2, 2>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3);
+    else
+        rc = p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, math)
                         : launch_gather_cfg<2, 2, 2, 2>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, math);
     if (rc) return rc;
     if (p.splits > 1) {
         const size_t total = (size_t)M * (cout / 4);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
+        const bool gx = math == FRCNN_CONV_F32X3G;
         hipLaunchKernelGGL(gather_splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, p.splits, bias,
-                           residual, y, M, cout, relu);
+                           residual, y, M, cout, relu, gx ? x3->xmax : (const float*)nullptr, gx ? x3->wmax : (const float*)nullptr,
+                           gx ? x3->ymax : (float*)nullptr);
         rc = check_launch();
     }
     return rc;
@@ -709,7 +1118,7 @@ int launch_conv_dgrad(const float* dz, const float* wd, const float* residual, f
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(gather_splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, p.splits,
-                           (const float*)nullptr, residual, dx, M, cin, 0);
+                           (const float*)nullptr, residual, dx, M, cin, 0, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
         rc = check_launch();
     }
     return rc;

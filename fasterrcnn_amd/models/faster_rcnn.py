@@ -135,6 +135,7 @@ class FasterRCNNModel(nn.Module):
         self.x6_conv1x1 = "head" if self._is_resnet else "off"
         self._x6_conv1x1_arith = "f32x6"
         self.x6_conv1x1_arith = "f32x3" if self._is_resnet else "f32x6"
+        self._bottleneck_g3 = "off"
         self._winograd_x6_layers = ()
         self.winograd_x6_layers = ("rpn_trunk",) if self._is_resnet else nv.DEFAULT_X6_LAYERS_VGG16
         # arithmetic of the VGG-16 detector's fc1 / fc2 (models/vgg16.py:130-132): "f32" = exact f32 MFMA; "f32x6" = exactly split
@@ -214,6 +215,25 @@ class FasterRCNNModel(nn.Module):
         if self._is_resnet:
             self._stage1_feature_extractor.x6_conv1x1 = mode == "all"
             self._stage3_detector_network._pool_to_feature_vector.x6_conv1x1 = mode in ("head", "all")
+
+    @property
+    def bottleneck_g3(self):
+        return self._bottleneck_g3
+
+    @bottleneck_g3.setter
+    def bottleneck_g3(self, mode):
+        """ "off" | "backbone" | "all": which ResNet bottlenecks run ALL their convolutions in the f32x3 arithmetic under one power-of-two
+        scale per tensor (frcnn_bottleneck_weights.g3, csrc/conv_gather.hip conv_gather_x3_kernel): layer1..3 of the feature extractor
+        ("backbone"), layer4 of the detector as well ("all").  Overrides x6_conv1x1 for the blocks it names."""
+        mode = {False: "off", True: "backbone", None: "off"}.get(mode, mode)
+        if mode not in ("off", "backbone", "all"):
+            raise ValueError("bottleneck_g3 must be 'off', 'backbone' or 'all'")
+        if mode != "off" and not self._is_resnet:
+            raise NotImplementedError("bottleneck_g3 applies to the ResNet bottlenecks")
+        self._bottleneck_g3 = mode
+        if self._is_resnet:
+            self._stage1_feature_extractor.g3 = mode in ("backbone", "all")
+            self._stage3_detector_network._pool_to_feature_vector.g3 = mode == "all"
 
     @property
     def x6_conv1x1_arith(self):
@@ -416,7 +436,7 @@ class FasterRCNNModel(nn.Module):
         blocks = list(fe["blocks"]) + list(l4)
         tensors = [fe["stem"][0], fe["stem"][1]] + list(s2) + list(hd)
         for b in blocks:
-            tensors += [b[k] for k in ("w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd") if b[k] is not None]
+            tensors += [b[k] for k in ("w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd", "wmax") if b.get(k) is not None]
         key = tuple(x.data_ptr() for x in tensors)
         if key != self._wstruct_key:
             if len(blocks) > nv.RESNET_MAX_BLOCKS:
@@ -432,6 +452,8 @@ class FasterRCNNModel(nn.Module):
                 bw.cin, bw.width, bw.cout, bw.stride = b["cin"], b["width"], b["cout"], b["stride"]
                 bw.x6_mask = int(b.get("x6_mask", 0))
                 bw.x3_mask = int(b.get("x3_mask", 0))
+                bw.g3 = int(b.get("g3", 0))
+                bw.wmax = b["wmax"].data_ptr() if b.get("wmax") is not None else None
             w.rpn_conv_w, w.rpn_conv_b, w.rpn_head_w, w.rpn_head_b = (x.data_ptr() for x in s2)
             w.head_w, w.head_b = (x.data_ptr() for x in hd)
             w.num_classes = self._num_classes

@@ -143,12 +143,54 @@ def blob_x3t(wp, cout, cin):
     return pack_rows_x3t(wp.reshape(cout, cin), rows)
 
 
-def pack_block(block, math_mode="f32", single_map=False, x6=False, x3=False):
+def conv_nhwc_x3g(x, wp, bp, n, h, w, cin, cout, k, stride, pad, relu, xmax, wmax, ymax=None, residual=None):
+    """frcnn_conv_nhwc_x3g: the same convolution in the f32x3 arithmetic under one scale per tensor; xmax / wmax: one-element CUDA float
+    tensors bounding |x| and |wp|, ymax: a zeroed one that receives max|y| (or None).  Returns (y, ho, wo)."""
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    y = t.empty((n, ho, wo, cout), dtype=t.float32, device=x.device)
+    lib = nv.lib()
+    wsb = int(lib.frcnn_conv_workspace_bytes(n, h, w, cin, cout, k, stride, pad))
+    ws = t.empty((max(wsb, 4) // 4,), dtype=t.float32, device=x.device)
+    with t.cuda.device(x.device):
+        nv.check(lib.frcnn_conv_nhwc_x3g(nv.ptr(x), nv.ptr(wp), nv.ptr(bp), nv.ptr(residual), nv.ptr(y), n, h, w, cin, cout,
+                                         k, stride, pad, nv.RELU if relu else 0, nv.ptr(xmax), nv.ptr(wmax), nv.ptr(ymax), nv.ptr(ws), wsb,
+                                         nv.stream_ptr()), "frcnn_conv_nhwc_x3g")
+    return y, ho, wo
+
+
+def tensor_absmax(x):
+    """one-element CUDA tensor max|x| through frcnn_tensor_absmax"""
+    out = t.zeros((1,), dtype=t.float32, device=x.device)
+    with t.cuda.device(x.device):
+        nv.check(nv.lib().frcnn_tensor_absmax(nv.ptr(x), x.numel(), nv.ptr(out), nv.stream_ptr()), "frcnn_tensor_absmax")
+    return out
+
+
+def pack_block_g3(block):
+    """The block for frcnn_bottleneck_weights.g3: the four plain BN-folded float32 packs + `wmax` (their absolute maxima)."""
+    w1, b1, k1 = fold_conv_bn(block.conv1, block.bn1)
+    w2, b2, k2 = fold_conv_bn(block.conv2, block.bn2)
+    w3, b3, k3 = fold_conv_bn(block.conv3, block.bn3)
+    out = {"w1": w1, "b1": b1, "w2": w2, "b2": b2, "w3": w3, "b3": b3, "wd": None, "bd": None,
+           "cin": block.conv1.in_channels, "width": block.conv1.out_channels, "cout": block.conv3.out_channels,
+           "stride": block.stride, "keep": [k1, k2, k3], "x6_mask": 0, "x3_mask": 0, "g3": 1}
+    packs = [w1, w2, w3]
+    if block.downsample is not None:
+        out["wd"], out["bd"], kd = fold_conv_bn(block.downsample[0], block.downsample[1])
+        out["keep"].append(kd)
+        packs.append(out["wd"])
+    out["wmax"] = t.cat([tensor_absmax(p) for p in packs] + ([] if len(packs) == 4 else [t.ones((1,), dtype=t.float32, device=w1.device)]))
+    return out
+
+
+def pack_block(block, math_mode="f32", single_map=False, x6=False, x3=False, g3=False):
     """dict of packed tensors + shape info for one Bottleneck.  single_map: the block runs on ONE map (layer1..3 of the feature
     extractor) -> its 3x3 is a one-launch Winograd layer in the f32_winograd mode; the per-RoI maps of layer4 use the batched form.
     x6 (f32_winograd mode only): the 1x1 convolutions with x6_conv1x1_ok() carry x6t record arrays instead of float32 packs
     (`x6_mask` bits FRCNN_X6_CONV1 / _CONV3 / _DOWN) and run as f32x6 GEMMs on the bf16 pipe; with x3 they carry f32x3 blobs instead
     (`x3_mask` = `x6_mask`: two fp16 terms per row-scaled operand, three MFMAs per product, csrc/gemm_x3t.hip)."""
+    if g3:
+        return pack_block_g3(block)
     w1, b1, k1 = fold_conv_bn(block.conv1, block.bn1)
     width = block.conv2.out_channels
     if math_mode == "f32_winograd" and nv.resnet_block_uses_winograd_fused(1 if single_map else 2, width, block.stride):
@@ -274,6 +316,17 @@ def conv_x3(x, wblob, bp, n, h, w, cin, cout, stride, relu, residual=None, ksize
 
 def run_block(x, n, h, w, pb):
     """One Bottleneck on NHWC data through the C ABI (stage-level path; the fused model uses frcnn_resnet_forward)."""
+    if pb.get("g3", 0):
+        wm = pb["wmax"]
+        xmax = tensor_absmax(x)
+        m = t.zeros((3,), dtype=t.float32, device=x.device)
+        t1, _, _ = conv_nhwc_x3g(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, 1, 0, True, xmax, wm[0:1], m[0:1])
+        t2, ho, wo = conv_nhwc_x3g(t1, pb["w2"], pb["b2"], n, h, w, pb["width"], pb["width"], 3, pb["stride"], 1, True, m[0:1], wm[1:2], m[1:2])
+        identity = x
+        if pb["wd"] is not None:
+            identity, _, _ = conv_nhwc_x3g(x, pb["wd"], pb["bd"], n, h, w, pb["cin"], pb["cout"], 1, pb["stride"], 0, False, xmax, wm[3:4])
+        out, _, _ = conv_nhwc_x3g(t2, pb["w3"], pb["b3"], n, ho, wo, pb["width"], pb["cout"], 1, 1, 0, True, m[1:2], wm[2:3], m[2:3], residual=identity)
+        return out, ho, wo
     xm = pb.get("x6_mask", 0)
     x3 = pb.get("x3_mask", 0)
     conv1x1 = (lambda *a, **k: conv_x3(*a, **k)) if x3 else conv1x1_x6
@@ -375,6 +428,7 @@ class FeatureExtractor(nn.Module):
         self.math_mode = "f32"
         self.x6_conv1x1 = False      # the eligible 1x1 convolutions as f32x6 GEMMs (f32_winograd mode)
         self.x3 = False              # ... in the f32x3 arithmetic instead
+        self.g3 = False              # every bottleneck convolution in the f32x3 arithmetic under one scale per tensor (pack_block_g3)
 
     def blocks(self):
         fe = self._feature_extractor
@@ -384,11 +438,11 @@ class FeatureExtractor(nn.Module):
         """{'stem': (w, b), 'blocks': [dict]} of BN-folded packed weights, rebuilt when parameters change."""
         fe = self._feature_extractor
         params = [fe[0].weight] + _bn_params(fe[1]) + [p for b in self.blocks() for p in block_params(b)]
-        key = (self.math_mode, self.x6_conv1x1, self.x3) + rt.param_key(params)
+        key = (self.math_mode, self.x6_conv1x1, self.x3, self.g3) + rt.param_key(params)
         if key != self._packed_key:
             sw, sb, keep = fold_conv_bn(fe[0], fe[1])
             self._packed = {"stem": (sw, sb), "keep": keep,
-                            "blocks": [pack_block(b, self.math_mode, single_map=True, x6=self.x6_conv1x1, x3=self.x3) for b in self.blocks()],
+                            "blocks": [pack_block(b, self.math_mode, single_map=True, x6=self.x6_conv1x1, x3=self.x3, g3=self.g3) for b in self.blocks()],
                             "n_blocks": [len(fe[4]), len(fe[5]), len(fe[6])]}
             self._packed_key = key
         return self._packed
@@ -427,12 +481,13 @@ class PoolToFeatureVector(nn.Module):
         self.math_mode = "f32"
         self.x6_conv1x1 = False      # the eligible 1x1 convolutions as f32x6 GEMMs (f32_winograd mode)
         self.x3 = False              # ... in the f32x3 arithmetic instead
+        self.g3 = False              # pack_block_g3
 
     def packed(self):
         params = [p for b in self._layer4 for p in block_params(b)]
-        key = (self.math_mode, self.x6_conv1x1, self.x3) + rt.param_key(params)
+        key = (self.math_mode, self.x6_conv1x1, self.x3, self.g3) + rt.param_key(params)
         if key != self._packed_key:
-            self._packed = [pack_block(b, self.math_mode, x6=self.x6_conv1x1, x3=self.x3) for b in self._layer4]
+            self._packed = [pack_block(b, self.math_mode, x6=self.x6_conv1x1, x3=self.x3, g3=self.g3) for b in self._layer4]
             self._packed_key = key
         return self._packed
 

@@ -37,13 +37,13 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 10  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
+#define FRCNN_ABI_VERSION 11  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
                                  5: bf16 gradient GEMMs (the *_math entry points); 6: x6t GEMM, x6 Winograd layers, frcnn_forward_params.winograd_x6_mask,
                                  timing classes 8 / 9; 7: batched feature extractor (frcnn_resnet_backbone, frcnn_resnet_forward_features,
                                  frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps); 8: the f32x3 arithmetic (frcnn_*_x3t, frcnn_*_winograd_x3,
                                  frcnn_forward_params.winograd_x3_mask, FRCNN_FC_F32X3T, frcnn_bottleneck_weights.x3_mask); 9: one-launch f32x3 Winograd layers
                                  in the forward (frcnn_forward_params.winograd_x3f_mask, timing class 10), frcnn_roi_pool_x3t; 10: frcnn_conv3x3_c3_cmax, bits 1 (conv1_2)
-                                 and 13 (RPN trunk) of winograd_x3f_mask */
+                                 and 13 (RPN trunk) of winograd_x3f_mask; 11: frcnn_conv_nhwc_x3g, frcnn_tensor_absmax, frcnn_bottleneck_weights.g3 / .wmax */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -577,6 +577,12 @@ typedef struct frcnn_bottleneck_weights {
     int32_t x3_mask;           /* a subset of x6_mask: those convolutions run in the f32x3 arithmetic instead (csrc/gemm_x3t.hip, csrc/wino_x3.hip) and
                                   their weight pointers are f32x3 blobs: frcnn_pack_rows_x3t of the [cout][K] matrix (1x1 and stride-2 3x3
                                   convolutions), frcnn_pack_conv3x3_winograd_x3's blob (stride-1 3x3) */
+    const float* wmax;         /* round 4 (ABI 11), with g3 != 0: device float[4] = max |w1|, |w2|, |w3|, |wd| of the packs (upper bounds; [3] unused without wd) */
+    int32_t g3;                /* != 0: the block's four convolutions run in the f32x3 arithmetic under ONE scale per tensor (frcnn_conv_nhwc_x3g's kernel,
+                                  csrc/conv_gather.hip): w1 / w2 / w3 / wd are the plain float32 packs ([1][width][cin], [9][width][width], ...) whatever the
+                                  math mode, x6_mask must be 0.  The activation maxima travel from one convolution's epilogue to the next one's scale inside
+                                  the context.  Reference: the same Bottleneck forward, models/resnet.py:38-46 / :66-90 */
+    int32_t reserved0;
 } frcnn_bottleneck_weights;
 #define FRCNN_X6_CONV1 1
 #define FRCNN_X6_CONV3 2
@@ -708,6 +714,21 @@ int frcnn_conv_nhwc_math(const float* d_x, const float* d_w_packed, const float*
                          void* d_ws, size_t ws_bytes, void* stream);
 int frcnn_conv_dgrad_math(const float* d_dz, const float* d_wd, const float* d_residual, float* d_dx, int N, int H, int W,
                           int cin, int cout, int ksize, int stride, int pad, int math, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ABI 11: the same convolution (frcnn_conv_nhwc: the frozen-BN Bottleneck convolutions of models/resnet.py:38-46, BN folded) in the f32x3
+ * arithmetic under ONE power-of-two scale per tensor: every activation and weight value as two fp16 terms hi = fp16(v 2^e),
+ * lo = fp16(v 2^e - hi) with max|tensor| 2^e in [2^14, 2^15), split on the way into LDS, three v_mfma_f32_32x32x16_f16 per product,
+ * float32 accumulation, bias / residual / ReLU in float32.  About 22 bits per value relative to the value itself down to 2^-14 of the
+ * tensor maximum, 2^-38 of the maximum absolute below.
+ *   d_xmax, d_wmax : device floats, UPPER BOUNDS of max|x| and max|w_packed| (a bound below the true maximum overflows fp16 -> inf)
+ *   d_ymax         : NULL, or a device float that receives max(*d_ymax, max|y|) by atomic maximum -- zero it (or leave an older maximum)
+ *                    before the call; it is the next convolution's d_xmax
+ * Other arguments, shapes and workspace (frcnn_conv_workspace_bytes) as frcnn_conv_nhwc. */
+int frcnn_conv_nhwc_x3g(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
+                        int N, int H, int W, int cin, int cout, int ksize, int stride, int pad, unsigned flags,
+                        const float* d_xmax, const float* d_wmax, float* d_ymax, void* d_ws, size_t ws_bytes, void* stream);
+/* d_out[0] = max(d_out[0], max_i |d_x[i]|), n floats, d_x 16-byte aligned (the scale source of a tensor no frcnn_conv_nhwc_x3g produced) */
+int frcnn_tensor_absmax(const float* d_x, long long n, float* d_out, void* stream);
 
 /* conv2d backward of the 3x3 "same" layers (vgg16.py:76-96, rpn.py:88):
  *   weight gradient  d_dwp [9][cout][cin] (the frcnn_pack_conv3x3 layout) from x [H][W][cin], dz [H][W][cout];

@@ -1,52 +1,46 @@
-"""Timing experiment for gemm_x6t_kernel (needs a library built with -DGX_CLOCKS: SRC=gemm_x6t tools/build_ablate.sh gxclk -DGX_CLOCKS,
-run with FRCNN_LIB_PATH=build/libfrcnn_gxclk.so).  Prints the shader clock the K loop ran at and the shader cycles one 16-k stage
-took (120 MFMAs per SIMD = 3840 matrix-pipe cycles for the 320 x 256 tile, two waves per SIMD)."""
+"""tools/gx_clocks.py -- where a block of conv_gather_x3_kernel (csrc/conv_gather.hip) spends its time, per ResNet-50 backbone shape.
+Needs a library built with -DGX_CLOCKS:  SRC=conv_gather tools/build_ablate.sh gxclk -DGX_CLOCKS ; FRCNN_LIB_PATH=build/libfrcnn_gxclk.so"""
 import sys
+
 import numpy as np
-import torch as t
+import torch
+
 sys.path.insert(0, ".")
+sys.path.insert(0, "tools")
 from fasterrcnn_amd import _native as nv
+from fasterrcnn_amd.models import resnet as R
+from exp_conv_x3g import SHAPES
 
 
-def run(M, N, K, B, reps=300):
+def main():
     lib = nv.lib()
-    dev = t.device("cuda:0")
-    s = nv.stream_ptr()
-    Mp = (M + 319) // 320 * 320
-    Np = (N + 255) // 256 * 256
-    a = t.randn((B, M, K), device=dev)
-    w = t.randn((B, N, K), device=dev) * 0.02
-    a_per, b_per = int(lib.frcnn_x6t_record_bytes(Mp, K)), int(lib.frcnn_x6t_record_bytes(Np, K))
-    ar = t.zeros((B * a_per,), dtype=t.uint8, device=dev)
-    br = t.zeros((B * b_per,), dtype=t.uint8, device=dev)
-    nv.check(lib.frcnn_split_rows_x6t(nv.ptr(a), K, M * K, nv.ptr(ar), M, Mp, K, B, s), "split a")
-    nv.check(lib.frcnn_split_rows_x6t(nv.ptr(w), K, N * K, nv.ptr(br), N, Np, K, B, s), "split b")
-    c = t.empty((B, M, N), device=dev)
-    assert int(lib.frcnn_gemm_x6t_workspace_bytes(M, N, K, B)) == 0, "needs an unsplit shape"
-    nblk = (Mp // 320) * (Np // 256) * B
-    dbg = t.zeros((nblk * 8 * 8,), dtype=t.float32, device=dev)
-    e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-    for rep in range(reps):
-        if rep == reps - 1:
-            e0.record()
-        nv.check(lib.frcnn_gemm_x6t(nv.ptr(ar), Mp, a_per, nv.ptr(br), Np, b_per, None, None, nv.ptr(c), N, M * N, M, N, K, B, 0, nv.ptr(dbg),
-                                    dbg.numel() * 4, s), "gemm_x6t")
-    e1.record()
-    t.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3
-    o = dbg.view(nblk, 8, 8).cpu().numpy().astype(np.float64)
-    assert (o[:, :, 7] == 1.0).all()
-    cyc, real, pro, epi, nst = o[..., 0], o[..., 1], o[..., 2], o[..., 3], o[0, 0, 4]
-    mhz = cyc / real * 100.0
-    span = ((o[..., 6].max() - o[..., 5].min()) % (1 << 24)) / 100.0
-    print("gemm_x6t M=%d N=%d K=%d x%d: %d blocks | launch %.1f us (events), first entry -> last exit %.1f us | sclk %.0f MHz | K loop %.0f "
-          "cycles/stage (p10 %.0f, p90 %.0f; 3840 = both waves of a SIMD back to back) = %.3f of the pipe in shader cycles | per block: before "
-          "the loop %.2f us, loop %.2f us, after %.2f us" % (
-              M, N, K, B, nblk, us, span, mhz.mean(), (cyc / nst).mean(), np.percentile(cyc / nst, 10), np.percentile(cyc / nst, 90),
-              3840.0 / (cyc / nst).mean(), pro.mean() / 100.0, real.mean() / 100.0, epi.mean() / 100.0))
+    for name, h, w, cin, cout, k, stride, res, count in SHAPES:
+        pad = 1 if k == 3 else 0
+        ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        x = torch.randn(1, h, w, cin, device="cuda").relu()
+        wp = torch.randn(k * k, cout, cin, device="cuda") / (cin * k * k) ** 0.5
+        b = torch.randn(cout, device="cuda")
+        r = torch.randn(1, ho, wo, cout, device="cuda") if res else None
+        nrec = 8 * 8 * 4096
+        y = torch.zeros(ho * wo * cout + nrec, device="cuda")
+        xm, wm, ym = R.tensor_absmax(x), R.tensor_absmax(wp), torch.zeros(1, device="cuda")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rep in range(10):
+            if rep == 9:
+                e0.record()
+            # no workspace: the un-split form, whose blocks write the stamps
+            nv.check(lib.frcnn_conv_nhwc_x3g(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(r), nv.ptr(y), 1, h, w, cin, cout, k, stride, pad, nv.RELU,
+                                             nv.ptr(xm), nv.ptr(wm), nv.ptr(ym), None, 0, nv.stream_ptr()), "x3g")
+        e1.record()
+        torch.cuda.synchronize()
+        o = y[ho * wo * cout:].view(-1, 8).cpu().numpy().astype(np.float64)
+        o = o[o[:, 7] == 1.0]
+        span = ((o[:, 5].max() - o[:, 4].min()) % (1 << 24)) / 100.0
+        print("%-24s %5.1f us launch-to-launch | %4d blocks, %3d stages | block medians: setup %5.2f  fetch+first %5.2f  loop %6.2f (%.3f / stage)  epilogue %5.2f us | "
+              "block total median %6.2f max %6.2f | first in -> last out %6.2f us" % (
+                  name, e0.elapsed_time(e1) * 1e3, len(o), int(o[0, 6]), np.median(o[:, 0]) / 100, np.median(o[:, 1]) / 100, np.median(o[:, 2]) / 100,
+                  np.median(o[:, 2]) / 100 / max(o[0, 6], 1), np.median(o[:, 3]) / 100, np.median(o[:, :4].sum(1)) / 100, o[:, :4].sum(1).max() / 100, span), flush=True)
 
 
 if __name__ == "__main__":
-    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    for shp in [(2394, 512, 512, 16), (2394, 512, 2048, 16), (589, 512, 512, 16), (320, 4096, 512, 1)]:
-        run(*shp, reps=reps)
+    main()
