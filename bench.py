@@ -358,9 +358,18 @@ def resnet_conv_table(model, h=H, w=W, n_rois=300):
     rows.append(("backbone", "stem 7x7/s2", "conv7x7_s2_c3_kernel", "valu", 0.0, 2.0 * 147 * 64 * hh * ww))
     hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
 
-    def block(stage, tag, blk, n, hh, ww, x6, single, x3=False):
+    def block(stage, tag, blk, n, hh, ww, x6, single, x3=False, g3=False):
         cin, width, cout, st = blk.conv1.in_channels, blk.conv1.out_channels, blk.conv3.out_channels, blk.stride
         ho, wo = (hh - 1) // st + 1, (ww - 1) // st + 1
+        if g3:      # every convolution of the block on conv_gather_x3_kernel: two fp16 terms per operand under one scale per tensor, three MFMAs per product
+            convs = [(".conv1", cin, width, 1, n * hh * ww), (".conv2", width, width, 9, n * ho * wo)]
+            if blk.downsample is not None:
+                convs.append((".downsample", cin, cout, 1, n * ho * wo))
+            convs.append((".conv3", width, cout, 1, n * ho * wo))
+            for name, ci, co, taps, px in convs:
+                alg = 2.0 * taps * ci * co * px
+                rows.append((stage, tag + name, "conv_gather_x3_kernel", "f16", 3.0 * alg, alg))
+            return ho, wo
         gk, gp, gf = ("gemm_x3t_kernel", "f16", 3.0) if x3 else ("gemm_x6t_kernel", "bf16", 6.0)     # f32x3: three fp16 MFMAs per product
 
         def one(name, ci, co, px, ok):
@@ -392,7 +401,7 @@ def resnet_conv_table(model, h=H, w=W, n_rois=300):
     seq = fe._feature_extractor
     for li, layer in ((1, seq[4]), (2, seq[5]), (3, seq[6])):
         for bi, blk in enumerate(layer):
-            hh, ww = block("backbone", "layer%d.%d" % (li, bi), blk, 1, hh, ww, fe.x6_conv1x1, True, getattr(fe, "x3", False))
+            hh, ww = block("backbone", "layer%d.%d" % (li, bi), blk, 1, hh, ww, fe.x6_conv1x1, True, getattr(fe, "x3", False), getattr(fe, "g3", False))
     c = 1024
     alg = 2.0 * 9 * c * c * hh * ww
     if wino and "rpn_trunk" in model.winograd_x6_layers:
@@ -406,7 +415,7 @@ def resnet_conv_table(model, h=H, w=W, n_rois=300):
     rows.append(("rpn", "rpn_heads_1x1", "linear_mfma_kernel", "f32", 2.0 * c * 45 * hh * ww, 2.0 * c * 45 * hh * ww))
     h4, w4 = 7, 7
     for bi, blk in enumerate(l4._layer4):
-        h4, w4 = block("head", "layer4.%d" % bi, blk, n_rois, h4, w4, l4.x6_conv1x1, False, getattr(l4, "x3", False))
+        h4, w4 = block("head", "layer4.%d" % bi, blk, n_rois, h4, w4, l4.x6_conv1x1, False, getattr(l4, "x3", False), getattr(l4, "g3", False))
     rows.append(("head", "detector_heads", "linear_mfma_kernel", "f32", n_rois * 2.0 * 2048 * 101, n_rois * 2.0 * 2048 * 101))
     return rows
 
@@ -430,30 +439,44 @@ def resnet_roofline_leg(model, image, dev, images=6):
     launches = {k: per[0][k][1] for k in per[0]}
     table = resnet_conv_table(model)
     by = {"conv3x3_mfma": 0.0, "winograd_gemm": 0.0, "linear_mfma": 0.0, "winograd_x6_gemm": 0.0}
+    alg_backbone = 0.0
+    g3_backbone = bool(getattr(model._stage1_feature_extractor, "g3", False))
     for stage, name, kern, pipe, ex, alg in table:
         if kern.startswith("gemm_x6t") or kern.startswith("gemm_x3t"):
             by["winograd_x6_gemm"] += ex
         elif kern.startswith("wino_fused"):
             by["winograd_gemm"] += ex
-        elif stage == "backbone" and kern.startswith("conv_gather"):
+        elif stage == "backbone" and kern.startswith("conv_gather"):       # timing class 0: every launch of run_bottleneck's backbone blocks
             by["conv3x3_mfma"] += ex
+            alg_backbone += alg
+        elif kern.startswith("conv_gather_x3"):                              # layer4 with bottleneck_g3 = "all": timed with the head's launches
+            by["linear_mfma"] += alg
         elif pipe == "f32":
             by["linear_mfma"] += ex
     out = {"regime": "HIP events around every launch, one image at a time on one stream, median image of %d" % images,
            "ms_per_image_by_class": {k: round(v, 4) for k, v in med.items()}, "launches_by_class": launches, "classes": {}}
-    for cls, peak, unit in (("conv3x3_mfma", PEAK_F32_MFMA_TFLOPS, "f32"), ("winograd_gemm", PEAK_F32_MFMA_TFLOPS, "f32"),
+    for cls, peak, unit in (("conv3x3_mfma", PEAK_BF16_MFMA_TFLOPS if g3_backbone else PEAK_F32_MFMA_TFLOPS, "fp16 (f32x3)" if g3_backbone else "f32"),
+                            ("winograd_gemm", PEAK_F32_MFMA_TFLOPS, "f32"),
                             ("linear_mfma", PEAK_F32_MFMA_TFLOPS, "f32"), ("winograd_x6_gemm", PEAK_BF16_MFMA_TFLOPS, "bf16 / fp16")):
         if med.get(cls, 0.0) > 0 and by[cls] > 0:
             ach = by[cls] / (med[cls] / 1e3) / 1e12
             out["classes"][cls] = {"pipe": unit, "executed_gflop_per_image": round(by[cls] / 1e9, 2), "ms_per_image": round(med[cls], 4),
                                    "achieved_tflops": round(ach, 2), "peak": peak, "frac": round(ach / peak, 4)}
     dom = max(out["classes"], key=lambda k: out["classes"][k]["ms_per_image"]) if out["classes"] else None
-    kernel_of = {"conv3x3_mfma": "conv_gather_mfma_kernel (backbone 1x1 / strided convolutions, exact-f32 pipe)",
+    if g3_backbone and "conv3x3_mfma" in out["classes"]:
+        # what an exact-f32 kernel would have to sustain to match: the layer's algorithmic FLOP against the float32 matrix peak
+        c0 = out["classes"]["conv3x3_mfma"]
+        c0["f32_equivalent_tflops"] = round(alg_backbone / (med["conv3x3_mfma"] / 1e3) / 1e12, 2)
+        c0["f32_equivalent_frac_of_f32_peak"] = round(c0["f32_equivalent_tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
+        c0["note"] = ("conv_gather_x3_kernel is bound by the L2 -> CU fetch of its operand tiles (tools/gx_clocks.py: a stage takes the time its "
+                      "16-32 KB take at ~40 GB/s per CU), not by the matrix pipe")
+    kernel_of = {"conv3x3_mfma": ("conv_gather_x3_kernel (every backbone bottleneck convolution, f32x3 under one scale per tensor)" if g3_backbone else
+                                  "conv_gather_mfma_kernel (backbone 1x1 / strided convolutions, exact-f32 pipe)"),
                  "winograd_gemm": "wino_fused_kernel (backbone 3x3 + RPN trunk)", "linear_mfma": "the head's float32 launches",
                  "winograd_x6_gemm": "gemm_x3t_kernel / gemm_x6t_kernel (layer4's convolutions and the RPN trunk as split-operand GEMMs)"}
     if dom:
         out.update({"kernel": kernel_of[dom], "bound": "mfma", "achieved": out["classes"][dom]["achieved_tflops"], "peak": out["classes"][dom]["peak"],
-                    "unit": "TFLOP/s", "frac": out["classes"][dom]["frac"], "traffic": measured_traffic("conv_gather_mfma_kernel")})
+                    "unit": "TFLOP/s", "frac": out["classes"][dom]["frac"], "traffic": measured_traffic("conv_gather_x3_kernel" if (g3_backbone and dom == "conv3x3_mfma") else "conv_gather_mfma_kernel")})
     return out
 
 
@@ -790,17 +813,24 @@ def main():
         run50(16)
         dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
         extra["resnet50_images_per_sec"] = round(args.steps / dt, 3)
-        extra["resnet50_config"] = ("ResNet-50 predict(), 3x600x1000, 8 batch-1 images in flight, math %s, x6_conv1x1=%s in the %s arithmetic (the "
+        extra["resnet50_config"] = ("ResNet-50 predict(), 3x600x1000, 8 batch-1 images in flight, math %s, bottleneck_g3=%s (layer1..3: every bottleneck "
+                                    "convolution in the f32x3 arithmetic under one scale per tensor, conv_gather_x3_kernel), x6_conv1x1=%s in the %s arithmetic (the "
                                     "convolutions of the per-RoI layer4 as split-operand GEMMs on the fp16 / bf16 matrix instructions), winograd_x6_layers=%s, "
                                     "winograd_x3_layers=%s; every golden proposal / detection reproduced"
-                                    % (m50.math_mode, m50.x6_conv1x1, m50.x6_conv1x1_arith, list(m50.winograd_x6_layers), list(m50.winograd_x3_layers)))
+                                    % (m50.math_mode, m50.bottleneck_g3, m50.x6_conv1x1, m50.x6_conv1x1_arith, list(m50.winograd_x6_layers),
+                                       list(m50.winograd_x3_layers)))
         d50 = dict(x6_conv1x1=m50.x6_conv1x1, x6_conv1x1_arith=m50.x6_conv1x1_arith, winograd_x6_layers=m50.winograd_x6_layers,
-                   winograd_x3_layers=m50.winograd_x3_layers)
+                   winograd_x3_layers=m50.winograd_x3_layers, bottleneck_g3=m50.bottleneck_g3)
 
         def set50(**kw):
             for k_, v_ in kw.items():
                 setattr(m50, k_, v_)
-        # the same with every eligible 1x1 convolution of the backbone (layer2 / layer3) as a split-operand GEMM too
+        # round 3's default: the backbone on the exact-f32 gather / float32 Winograd kernels
+        set50(bottleneck_g3="off")
+        run50(16)
+        dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
+        extra["resnet50_f32_backbone_images_per_sec"] = round(args.steps / dt, 3)
+        # ... with every eligible 1x1 convolution of that backbone (layer2 / layer3) as a row-scaled split-operand GEMM
         set50(x6_conv1x1="all")
         run50(16)
         dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
@@ -837,10 +867,10 @@ def main():
             extra["resnet50_batch8_images_per_sec"] = round(steps_b / dt, 3)
             extra["resnet50_batch8_config"] = ("the same model and images as resnet50_images_per_sec as batches of 8 (model.predict_batch_async): one "
                                                "feature-extractor pass per batch, two batches in flight; default modes")
-            set50(x6_conv1x1="all")
+            set50(bottleneck_g3="off")
             run50b(32)
             dt, _ = timed_median(run50b, steps_b, min(args.min_timed_seconds, 0.5))
-            extra["resnet50_batch8_x6_all_images_per_sec"] = round(steps_b / dt, 3)
+            extra["resnet50_batch8_f32_backbone_images_per_sec"] = round(steps_b / dt, 3)
             set50(**d50)
             m50._lanes.clear()
             del batch50

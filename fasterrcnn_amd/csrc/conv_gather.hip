@@ -475,17 +475,20 @@ struct GatherX3Cfg {
     static constexpr size_t LDS_BYTES = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
 };
 
-// four floats -> their hi and lo fp16 terms under the scale m (two registers each); the bits of hx_split8 (x3t.h)
-__device__ __forceinline__ void gx_split4(const f32x4 v, float m, unsigned (&hi)[2], unsigned (&lo)[2])
+// four floats -> their hi and lo fp16 terms under the scale m: hi = fp16(v m), lo = fp16(v m - hi) (v m and the difference are exact in
+// float32: m is a power of two, the difference has <= 13 significant bits).  Plain C so that the scheduler can place the conversions between
+// the matrix instructions (it selects v_fma_mix / v_pk_fma_f32 + v_cvt_pk: ~10 instructions per piece)
+__device__ __forceinline__ void gx_split4(const f32x4 v, float m, gx_u32x2& hi, gx_u32x2& lo)
 {
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi[0]) : "v"(v[0]), "v"(m));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi[1]) : "v"(v[2]), "v"(m));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi[0]) : "v"(v[1]), "v"(m));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi[1]) : "v"(v[3]), "v"(m));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lo[0]) : "v"(v[0]), "v"(m), "v"(hi[0]));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lo[1]) : "v"(v[2]), "v"(m), "v"(hi[1]));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo[0]) : "v"(v[1]), "v"(m), "v"(hi[0]));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo[1]) : "v"(v[3]), "v"(m), "v"(hi[1]));
+    typedef _Float16 gx_f16x4 __attribute__((ext_vector_type(4)));
+    gx_f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (_Float16)__builtin_fmaf(v[e], m, 0.0f);
+        l[e] = (_Float16)__builtin_fmaf(v[e], m, -(float)h[e]);
+    }
+    hi = __builtin_bit_cast(gx_u32x2, h);
+    lo = __builtin_bit_cast(gx_u32x2, l);
 }
 
 // One block's maximum into *out (a float >= 0, bit order = float order): four wave maxima through LDS, then ONE atomic -- and only when the
@@ -559,22 +562,31 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) - (g.pad * g.W + g.pad) * g.Cin, 0, (int)OUTSIDE, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, (int)OUTSIDE, 0x00020000);
     unsigned a_off[C::NA], a_bad[C::NA];          // a_bad: bit t = tap t of this output pixel reads outside the image
+    const int hw = g.Ho * g.Wo;
+    const float r_hw = __builtin_amdgcn_rcpf((float)hw), r_w = __builtin_amdgcn_rcpf((float)g.Wo);
 #pragma unroll
     for (int it = 0; it < C::NA; ++it) {
         const int m = m0 + prow + 32 * it;
         a_off[it] = 0u; a_bad[it] = 0xFFFFFFFFu;
         if (m < M) {
-            const int n = m / (g.Ho * g.Wo);
-            const int rem = m - n * g.Ho * g.Wo;
-            const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+            // m -> (image, row, column) by a float reciprocal and one correction step (exact for m < 2^24; an integer division is ~40
+            // instructions, and 2 x NA of them were a third of a short block's life)
+            int n = (int)((float)m * r_hw);
+            int rem = m - n * hw;
+            if (rem < 0) { --n; rem += hw; } else if (rem >= hw) { ++n; rem -= hw; }
+            int oy = (int)((float)rem * r_w);
+            int ox = rem - oy * g.Wo;
+            if (ox < 0) { --oy; ox += g.Wo; } else if (ox >= g.Wo) { ++oy; ox -= g.Wo; }
             a_off[it] = (unsigned)((((n * g.H + oy * g.stride) * g.W + ox * g.stride) * g.Cin + pc * 4) * 4);
-            unsigned bad = 0u;
-            for (int r = 0; r < g.R; ++r)
-                for (int q = 0; q < g.S; ++q) {
-                    const int iy = oy * g.stride - g.pad + r, ix = ox * g.stride - g.pad + q;
-                    if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) bad |= 1u << (r * g.S + q);
-                }
-            a_bad[it] = bad;
+            const int iy0 = oy * g.stride - g.pad, ix0 = ox * g.stride - g.pad;
+            unsigned br = 0u, bc = 0u;                              // rows / columns of the 3 x 3 taps outside the image
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                br |= (iy0 + r < 0 || iy0 + r >= g.H ? 1u : 0u) << r;
+                bc |= (ix0 + r < 0 || ix0 + r >= g.W ? 1u : 0u) << r;
+            }
+            a_bad[it] = taps == 1 ? ((br | bc) & 1u)
+                                  : ((br & 1u ? 7u : bc) | ((br & 2u ? 7u : bc) << 3) | ((br & 4u ? 7u : bc) << 6));
         }
     }
     unsigned b_off[C::NB];
@@ -599,27 +611,29 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
 #pragma unroll
         for (int it = 0; it < C::NB; ++it)
             br[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)b_off[it], so_b, 0));
-        if (ld_stage + 1 < st_end) {
-            ++ld_stage;
-            if (++ld_tap == taps) { ld_tap = 0; ++ld_chunk; }
-        }
+        // advance without a branch (a branch here would cut the stage into several scheduling regions)
+        const int adv = ld_stage + 1 < st_end ? 1 : 0;
+        ld_stage += adv;
+        const int wrap = (ld_tap + adv == taps) ? 1 : 0;
+        ld_tap = wrap ? 0 : ld_tap + adv;
+        ld_chunk += wrap;
     };
     auto store_tiles = [&](int buf, const f32x4 (&ar)[C::NA], const f32x4 (&br)[C::NB]) {
         _Float16* const ad = at_s + buf * C::BM * GX_ROW + p_dst;
         _Float16* const bd = bt_s + buf * C::BN * GX_ROW + p_dst;
 #pragma unroll
         for (int it = 0; it < C::NA; ++it) {
-            unsigned hi[2], lo[2];
+            gx_u32x2 hi, lo;
             gx_split4(ar[it], xmult, hi, lo);
-            *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW) = gx_u32x2{hi[0], hi[1]};
-            *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW + 16) = gx_u32x2{lo[0], lo[1]};
+            *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW) = hi;
+            *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW + 16) = lo;
         }
 #pragma unroll
         for (int it = 0; it < C::NB; ++it) {
-            unsigned hi[2], lo[2];
+            gx_u32x2 hi, lo;
             gx_split4(br[it], wmult, hi, lo);
-            *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW) = gx_u32x2{hi[0], hi[1]};
-            *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW + 16) = gx_u32x2{lo[0], lo[1]};
+            *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW) = hi;
+            *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW + 16) = lo;
         }
     };
 
@@ -670,6 +684,19 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk][j], al[kk][i], acc[i][j], 0, 0, 0);
         }
+        // order: the fragment reads, then per matrix instruction one piece's conversion, its LDS write and the refill of its registers --
+        // a wave issues in order, so vector work placed BETWEEN two matrix instructions runs under the first one's 32 cycles; clustered
+        // after them (the compiler's own choice) it adds to them (measured: 0.42 us a stage at the 64 x 64 tile for 6 MFMAs = 0.08 us)
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+#pragma unroll
+        for (int q = 0; q < 6 * TM * TN; ++q) {
+            if (q < C::NA + C::NB) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
         __syncthreads();
     };
 #ifdef GX_CLOCKS
@@ -706,6 +733,20 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
     const unsigned long long gx_t_loop = __builtin_amdgcn_s_memrealtime();
 #endif
     float* const out_s = reinterpret_cast<float*>(gx_smem);
+    const bool direct = (gridDim.z == 1);
+    constexpr int QN = C::BN / 4, RSTEP = 256 / QN, NPASS = C::BM / RSTEP;   // 16-byte pieces per tile row; rows per pass of the block; passes
+    const int ec = (tid % QN) * 4, er = tid / QN;
+    const int n = n0 + ec;
+    // the residual rows and the bias are fetched BEFORE the accumulators go through LDS (the stage registers are free now)
+    f32x4 rv[NPASS];
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (direct && bias && n < g.Cout) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+        const int m = m0 + er + k * RSTEP;
+        rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (direct && residual && n < g.Cout && m < M) rv[k] = *reinterpret_cast<const f32x4*>(residual + (size_t)m * g.Cout + n);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -718,37 +759,25 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
                 *reinterpret_cast<f32x4*>(out_s + (32 * (TM * wm + i) + li) * C::OUT_LD + 32 * (TN * wn + j) + 8 * q + 4 * lh) = v;
             }
     __syncthreads();
-    const bool direct = (gridDim.z == 1);
     float* const dst = direct ? y : ws + (size_t)blockIdx.z * M * g.Cout;
     const float unscale = xinv * winv;
     float vmax = 0.f;
-    constexpr int QN = C::BN / 4, RSTEP = 256 / QN;          // 16-byte pieces per tile row; rows covered by the block per pass
-    const int ec = (tid % QN) * 4, er = tid / QN;
-    const int n = n0 + ec;
-    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (direct && bias && n < g.Cout) bv = *reinterpret_cast<const f32x4*>(bias + n);
     if (n < g.Cout) {
-#pragma unroll 4
-        for (int r = er; r < C::BM; r += RSTEP) {
-            const int m = m0 + r;
-            if (m >= M) break;
-            f32x4 v = *reinterpret_cast<const f32x4*>(out_s + r * C::OUT_LD + ec);
-            if (direct) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] * unscale + bv[e];
-                if (residual) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + (size_t)m * g.Cout + n);
+        for (int k = 0; k < NPASS; ++k) {
+            const int r = er + k * RSTEP, m = m0 + r;
+            if (m < M) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(out_s + r * C::OUT_LD + ec);
+                if (direct) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (v[e] * unscale + bv[e]) + rv[k][e];
+                        if (relu) v[e] = fmaxf(v[e], 0.f);
+                        vmax = fmaxf(vmax, fabsf(v[e]));
+                    }
                 }
-                if (relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[e]));
+                *reinterpret_cast<f32x4*>(dst + (size_t)m * g.Cout + n) = v;
             }
-            *reinterpret_cast<f32x4*>(dst + (size_t)m * g.Cout + n) = v;
         }
     }
     if (direct && ymax) gx_block_max(vmax, ymax);
@@ -943,32 +972,40 @@ int launch_tensor_absmax(const float* x, long long n, float* out, hipStream_t s)
 
 struct GatherPlan { int cfg; int mblocks, nblocks, splits, stages_per_split; };
 
-// f32x3 kernel: stages of 32 channels; tiles 128 x 128 (cfg 0), 128 x 64 (cfg 2), 64 x 64 (cfg 3) -- the largest one that still gives
-// every CU a block, else the smallest; the reduction is split only when even that leaves most of the chip idle AND each part keeps
-// enough stages to amortise the pipeline's three-stage ramp
+// f32x3 kernel: stages of 32 channels; tiles 128 x 128 (cfg 0), 128 x 64 (cfg 2, cout <= 64), 64 x 64 (cfg 3).  What bounds the kernel is
+// the L2 -> CU fetch (tools/gx_clocks.py: a block's stage takes the time its 16 / 24 / 32 KB take at ~40 GB/s per CU whatever the
+// instruction schedule, and the chip moves ~6 TB/s this way), so the plan minimises an estimate built from exactly that: a block's chain
+// of stages against the chip's time for all fetched bytes, a fixed entry / exit cost, and for a split reduction the finish launch and
+// its planes.  Microseconds; the constants are measurements of the ResNet-50 backbone shapes at 600 x 1000.
 static GatherPlan plan_gather_x3(int M, int Cout, int stages)
 {
-    static const int tiles_min = []() { const char* e = frcnn_knob("FRCNN_GATHER_X3_TILES"); return e ? atoi(e) : 224; }();
-    static const int split_to = []() { const char* e = frcnn_knob("FRCNN_GATHER_X3_BLOCKS"); return e ? atoi(e) : 256; }();
-    GatherPlan p;
-    const int big_n = Cout <= 64 ? 64 : 128;
-    p.cfg = Cout <= 64 ? 2 : 0;
-    p.mblocks = cdiv(M, 128);
-    p.nblocks = cdiv(Cout, big_n);
-    if (p.mblocks * p.nblocks < tiles_min) {
-        p.cfg = 3;
-        p.mblocks = cdiv(M, 64);
-        p.nblocks = cdiv(Cout, 64);
+    static const double chip_bytes_per_us = []() { const char* e = frcnn_knob("FRCNN_GATHER_X3_CHIP"); return e ? atof(e) : 6.0e6; }();
+    static const double split_us = []() { const char* e = frcnn_knob("FRCNN_GATHER_X3_SPLIT_US"); return e ? atof(e) : 3.5; }();
+    struct Cand { int cfg, bm, bn; double stage_us; };
+    const Cand big = Cout <= 64 ? Cand{2, 128, 64, 0.70} : Cand{0, 128, 128, 1.05};
+    const Cand cands[2] = {big, Cand{3, 64, 64, 0.42}};
+    GatherPlan best{};
+    double best_t = 1e30;
+    for (const Cand& c : cands) {
+        const int mb = cdiv(M, c.bm), nb = cdiv(Cout, c.bn);
+        const double tiles = (double)mb * nb;
+        const double t_chip = tiles * stages * (c.bm + c.bn) * 128.0 / chip_bytes_per_us;      // a stage row: 32 channels x 4 bytes
+        const int max_splits = stages / 4 < 1 ? 1 : (stages / 4 > 16 ? 16 : stages / 4);
+        for (int want = 1; want <= max_splits; ++want) {
+            const int sps = cdiv(stages, want), splits = cdiv(stages, sps);
+            if (splits != want) continue;
+            const double rounds = (double)cdiv((int)(tiles * splits), 512);
+            double t = rounds * sps * c.stage_us;
+            if (t < t_chip) t = t_chip;
+            t += 3.5;
+            if (splits > 1) {
+                if ((size_t)splits * M * Cout * sizeof(float) > ((size_t)40 << 20)) continue;
+                t += split_us + (double)(splits + 1) * M * Cout * 4.0 / 4.0e6;
+            }
+            if (t < best_t) { best_t = t; best = GatherPlan{c.cfg, mb, nb, splits, sps}; }
+        }
     }
-    const int blocks = p.mblocks * p.nblocks;
-    int want = cdiv(split_to, blocks);
-    if ((size_t)want * M * Cout * sizeof(float) > ((size_t)24 << 20)) want = 1;      // the partial planes would cost more than the tail they fill
-    int cap = stages / 8;
-    if (cap < 1) cap = 1;
-    if (want > cap) want = cap;
-    p.stages_per_split = cdiv(stages, want);
-    p.splits = cdiv(stages, p.stages_per_split);
-    return p;
+    return best;
 }
 
 static GatherPlan plan_gather(int M, int Cout, int stages, int math = FRCNN_GRAD_F32)

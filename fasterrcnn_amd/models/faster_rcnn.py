@@ -135,7 +135,12 @@ class FasterRCNNModel(nn.Module):
         self.x6_conv1x1 = "head" if self._is_resnet else "off"
         self._x6_conv1x1_arith = "f32x6"
         self.x6_conv1x1_arith = "f32x3" if self._is_resnet else "f32x6"
+        # ResNet: the bottlenecks of the feature extractor (layer1..3) run ALL their convolutions in the f32x3 arithmetic under one
+        # power-of-two scale per tensor (round 4, csrc/conv_gather.hip conv_gather_x3_kernel; the per-RoI layer4 keeps x6_conv1x1's
+        # row-scaled records).  "off" = round 3's exact-f32 gather / float32 Winograd kernels.  Held-out ResNet-50 / -101: DESIGN.md section 4
         self._bottleneck_g3 = "off"
+        if self._is_resnet:
+            self.bottleneck_g3 = "backbone"
         self._winograd_x6_layers = ()
         self.winograd_x6_layers = ("rpn_trunk",) if self._is_resnet else nv.DEFAULT_X6_LAYERS_VGG16
         # arithmetic of the VGG-16 detector's fc1 / fc2 (models/vgg16.py:130-132): "f32" = exact f32 MFMA; "f32x6" = exactly split

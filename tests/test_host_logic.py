@@ -336,13 +336,18 @@ def test_resnet_default_modes_and_conv_table():
     from fasterrcnn_amd.models import resnet
     m = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet50))
     assert (m.x6_conv1x1, m.x6_conv1x1_arith, m.winograd_x6_layers, m.winograd_x3_layers) == ("head", "f32x3", ("rpn_trunk",), ("rpn_trunk",))
+    assert m.bottleneck_g3 == "backbone" and m._stage1_feature_extractor.g3 and not m._stage3_detector_network._pool_to_feature_vector.g3
     assert m._x6_mask() == m._x3_mask() == 1 << 13
     table = bench.resnet_conv_table(m)
     head = [r for r in table if r[0] == "head" and r[2].startswith("gemm_")]
     assert head and all(r[2].startswith("gemm_x3t_kernel") and r[3] == "f16" and abs(r[4] / r[5] - 3.0) < 1e-9 or "Winograd" in r[2] for r in head)
     trunk = [r for r in table if r[1] == "rpn_trunk"][0]
     assert trunk[2].startswith("gemm_x3t_kernel") and trunk[3] == "f16"
-    assert all(r[3] in ("f32", "valu") for r in table if r[0] == "backbone")
+    assert all(r[2] == "conv_gather_x3_kernel" and r[3] == "f16" and abs(r[4] / r[5] - 3.0) < 1e-9 for r in table if r[0] == "backbone" and "stem" not in r[1])
+    m.bottleneck_g3 = "off"
+    assert all(r[3] in ("f32", "valu") for r in bench.resnet_conv_table(m) if r[0] == "backbone")
+    with pytest.raises(ValueError):
+        m.bottleneck_g3 = "layer3"
     m.x6_conv1x1_arith = "f32x6"
     m.winograd_x3_layers = ()
     table6 = bench.resnet_conv_table(m)
