@@ -464,13 +464,16 @@ typedef _Float16 gx_f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned gx_u32x2 __attribute__((ext_vector_type(2)));
 // A stage is 32 input channels of one filter tap.  LDS row of a stage: [hi 16 | lo 16] of channels 0..15, [hi 16 | lo 16] of 16..31,
 // 8 fp16 of padding (144 B: the 16-byte fragment reads of 16 consecutive rows cover the 64 banks once)
-static constexpr int GX_ROW = 72;
-template <int TM, int TN, int WM, int WN, int D>
+// MODE 1 (the train step's bf16 forward / data-gradient convolutions, conv_gather_bf16_kernel's arithmetic in this kernel's pipeline): one
+// bf16 term per value, LDS row = 32 bf16 + 8 of padding (80 B), one v_mfma_f32_32x32x16_bf16 per accumulator and 16 channels.
+static constexpr int GX_F32X3 = 0, GX_BF16 = 1;
+template <int TM, int TN, int WM, int WN, int D, int MODE = GX_F32X3>
 struct GatherX3Cfg {
+    static constexpr int ROW = MODE == GX_F32X3 ? 72 : 40;                // 16-bit elements per LDS row
     static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static constexpr int NA = BM / 32, NB = BN / 32;                      // 16-byte pieces of a stage per thread (8 per 32-channel row)
     static constexpr int OUT_LD = BN + 4;                                 // the epilogue's float32 tile in LDS: row stride (conflict-free 16-byte writes)
-    static constexpr size_t STAGE_BYTES = (size_t)D * (BM + BN) * GX_ROW * sizeof(_Float16);
+    static constexpr size_t STAGE_BYTES = (size_t)D * (BM + BN) * ROW * sizeof(_Float16);
     static constexpr size_t OUT_BYTES = (size_t)BM * OUT_LD * sizeof(float);
     static constexpr size_t LDS_BYTES = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
 };
@@ -516,7 +519,7 @@ __device__ __forceinline__ void gx_block_max(float vmax, float* out)
 // one XCD's L2 once; the weights (<= 2.4 MB) sit in every L2.
 // Epilogue: the accumulators go through LDS once so that a wave's 16-byte stores (and residual loads) cover whole 256 / 512-byte rows
 // of y instead of 32 bytes of 32 different rows.
-template <int TM, int TN, int WM, int WN, int D>
+template <int TM, int TN, int WM, int WN, int D, int MODE>
 __global__ __launch_bounds__(256, 2)
 void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                            const float* __restrict__ bias, const float* __restrict__ residual,
@@ -524,13 +527,14 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
                            int stages_per_split, int relu, const float* __restrict__ xmax, const float* __restrict__ wmax,
                            float* __restrict__ ymax, int mblocks, int nblocks)
 {
-    using C = GatherX3Cfg<TM, TN, WM, WN, D>;
+    using C = GatherX3Cfg<TM, TN, WM, WN, D, MODE>;
+    constexpr int GX_ROW = C::ROW;
 #ifdef GX_CLOCKS
     const unsigned long long gx_t_in = __builtin_amdgcn_s_memrealtime();
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char gx_smem[];
-    _Float16* const at_s = reinterpret_cast<_Float16*>(gx_smem);            // [D][BM][GX_ROW]
-    _Float16* const bt_s = at_s + D * C::BM * GX_ROW;                       // [D][BN][GX_ROW]
+    _Float16* const at_s = reinterpret_cast<_Float16*>(gx_smem);            // [D][BM][ROW] (16-bit elements: fp16 hi | lo, or bf16)
+    _Float16* const bt_s = at_s + D * C::BM * GX_ROW;                       // [D][BN][ROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -547,9 +551,11 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
     if (st_end > total_stages) st_end = total_stages;
     const int nst = st_end - st_begin;
 
-    float xmult, xinv, wmult, winv;
-    hx_row_scale(*xmax, xmult, xinv);
-    hx_row_scale(*wmax, wmult, winv);
+    float xmult = 1.f, xinv = 1.f, wmult = 1.f, winv = 1.f;
+    if constexpr (MODE == GX_F32X3) {
+        hx_row_scale(*xmax, xmult, xinv);
+        hx_row_scale(*wmax, wmult, winv);
+    }
 
     // thread -> piece: row (tid >> 3) + 32 it of the tile, channels 4 (tid & 7) .. + 3 of the stage.  Every fetch is a buffer load:
     // per-piece byte offset (constant over the stages) in the VGPR, the stage's (tap, channel chunk) offset in an SGPR, and bit 31 of the
@@ -558,8 +564,11 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
     // offsets stay non-negative.
     constexpr unsigned OUTSIDE = 0x80000000u;
     const int prow = tid >> 3, pc = tid & 7;
-    const int p_dst = prow * GX_ROW + (pc >> 2) * 32 + (pc & 3) * 4;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) - (g.pad * g.W + g.pad) * g.Cin, 0, (int)OUTSIDE, 0x00020000);
+    const int p_dst = MODE == GX_F32X3 ? prow * GX_ROW + (pc >> 2) * 32 + (pc & 3) * 4 : prow * GX_ROW + pc * 4;
+    // the data-gradient form at stride 1 (g.transposed) is the forward form with the taps walked backwards and padding R - 1 - pad:
+    // source pixel (oy + pad - r, ox + pad - s) = (oy - pad' + r', ox - pad' + s') with r' = R - 1 - r; only the weight tap index differs
+    const int pad_e = g.transposed ? g.R - 1 - g.pad : g.pad;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) - (pad_e * g.W + pad_e) * g.Cin, 0, (int)OUTSIDE, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, (int)OUTSIDE, 0x00020000);
     unsigned a_off[C::NA], a_bad[C::NA];          // a_bad: bit t = tap t of this output pixel reads outside the image
     const int hw = g.Ho * g.Wo;
@@ -578,7 +587,7 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
             int ox = rem - oy * g.Wo;
             if (ox < 0) { --oy; ox += g.Wo; } else if (ox >= g.Wo) { ++oy; ox -= g.Wo; }
             a_off[it] = (unsigned)((((n * g.H + oy * g.stride) * g.W + ox * g.stride) * g.Cin + pc * 4) * 4);
-            const int iy0 = oy * g.stride - g.pad, ix0 = ox * g.stride - g.pad;
+            const int iy0 = oy * g.stride - pad_e, ix0 = ox * g.stride - pad_e;
             unsigned br = 0u, bc = 0u;                              // rows / columns of the 3 x 3 taps outside the image
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -603,7 +612,7 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
         const int r = g.S == 1 ? 0 : (ld_tap * 11) >> 5;                 // tap / 3 for tap < 9 (R = S in {1, 3})
         const int q = ld_tap - r * g.S;
         const int so_a = ((r * g.W + q) * g.Cin + ld_chunk * 32) * 4;
-        const int so_b = (ld_tap * g.Cout * g.Cin + ld_chunk * 32) * 4;
+        const int so_b = ((g.transposed ? taps - 1 - ld_tap : ld_tap) * g.Cout * g.Cin + ld_chunk * 32) * 4;
         const unsigned sh = 31u - (unsigned)ld_tap;
 #pragma unroll
         for (int it = 0; it < C::NA; ++it)
@@ -621,19 +630,30 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
     auto store_tiles = [&](int buf, const f32x4 (&ar)[C::NA], const f32x4 (&br)[C::NB]) {
         _Float16* const ad = at_s + buf * C::BM * GX_ROW + p_dst;
         _Float16* const bd = bt_s + buf * C::BN * GX_ROW + p_dst;
+        if constexpr (MODE == GX_F32X3) {
 #pragma unroll
-        for (int it = 0; it < C::NA; ++it) {
-            gx_u32x2 hi, lo;
-            gx_split4(ar[it], xmult, hi, lo);
-            *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW) = hi;
-            *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW + 16) = lo;
-        }
+            for (int it = 0; it < C::NA; ++it) {
+                gx_u32x2 hi, lo;
+                gx_split4(ar[it], xmult, hi, lo);
+                *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW) = hi;
+                *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW + 16) = lo;
+            }
 #pragma unroll
-        for (int it = 0; it < C::NB; ++it) {
-            gx_u32x2 hi, lo;
-            gx_split4(br[it], wmult, hi, lo);
-            *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW) = hi;
-            *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW + 16) = lo;
+            for (int it = 0; it < C::NB; ++it) {
+                gx_u32x2 hi, lo;
+                gx_split4(br[it], wmult, hi, lo);
+                *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW) = hi;
+                *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW + 16) = lo;
+            }
+        } else {
+            auto to_bf16x4 = [](f32x4 v) {                      // round to nearest even: conv_gather_bf16_kernel's conversion
+                const gb_bf16x2 lo = __builtin_convertvector(gb_f32x2{v[0], v[1]}, gb_bf16x2), hi = __builtin_convertvector(gb_f32x2{v[2], v[3]}, gb_bf16x2);
+                return gb_bf16x4{lo[0], lo[1], hi[0], hi[1]};
+            };
+#pragma unroll
+            for (int it = 0; it < C::NA; ++it) *reinterpret_cast<gb_bf16x4*>(ad + it * 32 * GX_ROW) = to_bf16x4(ar[it]);
+#pragma unroll
+            for (int it = 0; it < C::NB; ++it) *reinterpret_cast<gb_bf16x4*>(bd + it * 32 * GX_ROW) = to_bf16x4(br[it]);
         }
     };
 
@@ -652,50 +672,70 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
         constexpr int P = decltype(par)::value, Q = (P + 1) % D;
         const _Float16* const as = at_s + P * C::BM * GX_ROW + a_base;
         const _Float16* const bs = bt_s + P * C::BN * GX_ROW + b_base;
-        gx_f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+        if constexpr (MODE == GX_F32X3) {
+            gx_f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[kk][i] = *reinterpret_cast<const gx_f16x8*>(as + i * 32 * GX_ROW + kk * 32);
-                al[kk][i] = *reinterpret_cast<const gx_f16x8*>(as + i * 32 * GX_ROW + kk * 32 + 16);
+                for (int i = 0; i < TM; ++i) {
+                    ah[kk][i] = *reinterpret_cast<const gx_f16x8*>(as + i * 32 * GX_ROW + kk * 32);
+                    al[kk][i] = *reinterpret_cast<const gx_f16x8*>(as + i * 32 * GX_ROW + kk * 32 + 16);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[kk][j] = *reinterpret_cast<const gx_f16x8*>(bs + j * 32 * GX_ROW + kk * 32);
+                    bl[kk][j] = *reinterpret_cast<const gx_f16x8*>(bs + j * 32 * GX_ROW + kk * 32 + 16);
+                }
             }
+            store_tiles(Q, areg[Q], breg[Q]);
+            load_tiles(areg[Q], breg[Q]);
+            // per accumulator and 16 channels: weight lo x activation hi, hi x hi, hi x lo (gemm_x3t_kernel's order; the weights are the row operand)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[kk][j] = *reinterpret_cast<const gx_f16x8*>(bs + j * 32 * GX_ROW + kk * 32);
-                bl[kk][j] = *reinterpret_cast<const gx_f16x8*>(bs + j * 32 * GX_ROW + kk * 32 + 16);
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk][j], ah[kk][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk][j], ah[kk][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk][j], al[kk][i], acc[i][j], 0, 0, 0);
             }
-        }
-        store_tiles(Q, areg[Q], breg[Q]);
-        load_tiles(areg[Q], breg[Q]);
-        // per accumulator and 16 channels: weight lo x activation hi, hi x hi, hi x lo (gemm_x3t_kernel's order; the weights are the row operand)
+        } else {
+            gb_bf16x8 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) af[kk][i] = *reinterpret_cast<const gb_bf16x8*>(as + i * 32 * GX_ROW + kk * 16);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk][j], ah[kk][i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) bf[kk][j] = *reinterpret_cast<const gb_bf16x8*>(bs + j * 32 * GX_ROW + kk * 16);
+            }
+            store_tiles(Q, areg[Q], breg[Q]);
+            load_tiles(areg[Q], breg[Q]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk][j], ah[kk][i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk][j], al[kk][i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
         }
         // order: the fragment reads, then per matrix instruction one piece's conversion, its LDS write and the refill of its registers --
         // a wave issues in order, so vector work placed BETWEEN two matrix instructions runs under the first one's 32 cycles; clustered
         // after them (the compiler's own choice) it adds to them (measured: 0.42 us a stage at the 64 x 64 tile for 6 MFMAs = 0.08 us)
-        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+        constexpr int NFR = MODE == GX_F32X3 ? 4 * (TM + TN) : 2 * (TM + TN), NMF = MODE == GX_F32X3 ? 6 * TM * TN : 2 * TM * TN;
+        __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);
 #pragma unroll
-        for (int q = 0; q < 6 * TM * TN; ++q) {
+        for (int q = 0; q < (NMF > C::NA + C::NB ? NMF : C::NA + C::NB); ++q) {
             if (q < C::NA + C::NB) {
-                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, MODE == GX_F32X3 ? 10 : 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (q < NMF) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
         __syncthreads();
     };
@@ -780,7 +820,7 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
             }
         }
     }
-    if (direct && ymax) gx_block_max(vmax, ymax);
+    if constexpr (MODE == GX_F32X3) { if (direct && ymax) gx_block_max(vmax, ymax); }
 #ifdef GX_CLOCKS
     // timing build (tools/gx_clocks.py): thread 0 of every block leaves its stamps (10 ns units) behind the output
     if (tid == 0 && direct) {
@@ -1045,16 +1085,33 @@ size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R
     return splits > 1 ? (size_t)splits * M * cout * sizeof(float) : 0;
 }
 
-template <int TM, int TN, int WM, int WN, int D>
+template <int TM, int TN, int WM, int WN, int D, int MODE>
 static int launch_gather_x3_cfg(const GatherPlan& p, const float* x, const float* wp, const float* bias, const float* residual, float* y, float* ws,
                                 const GatherShape& g, int relu, hipStream_t s, const GatherX3* x3)
 {
-    using X = GatherX3Cfg<TM, TN, WM, WN, D>;
-    auto kx = conv_gather_x3_kernel<TM, TN, WM, WN, D>;
+    using X = GatherX3Cfg<TM, TN, WM, WN, D, MODE>;
+    auto kx = conv_gather_x3_kernel<TM, TN, WM, WN, D, MODE>;
     FRCNN_MAX_LDS_ONCE(kx, X::LDS_BYTES);
     hipLaunchKernelGGL(kx, dim3(8 * p.nblocks * cdiv(p.mblocks, 8), 1, p.splits), dim3(256), X::LDS_BYTES, s, x, wp, bias, residual, y, ws, g,
-                       p.stages_per_split, relu, x3->xmax, x3->wmax, x3->ymax, p.mblocks, p.nblocks);
+                       p.stages_per_split, relu, x3 ? x3->xmax : (const float*)nullptr, x3 ? x3->wmax : (const float*)nullptr,
+                       x3 ? x3->ymax : (float*)nullptr, p.mblocks, p.nblocks);
     return check_launch();
+}
+template <int MODE>
+static int launch_gather_x3_plan(const GatherPlan& p, const float* x, const float* wp, const float* bias, const float* residual, float* y, float* ws,
+                                 const GatherShape& g, int relu, hipStream_t s, const GatherX3* x3)
+{
+    return p.cfg == 2 ? launch_gather_x3_cfg<2, 1, 2, 2, 2, MODE>(p, x, wp, bias, residual, y, ws, g, relu, s, x3)
+         : p.cfg == 3 ? launch_gather_x3_cfg<1, 1, 2, 2, 3, MODE>(p, x, wp, bias, residual, y, ws, g, relu, s, x3)
+                      : launch_gather_x3_cfg<2, 2, 2, 2, 2, MODE>(p, x, wp, bias, residual, y, ws, g, relu, s, x3);
+}
+// the shapes the pipelined kernel takes: 32-channel stages, 1x1 / 3x3 taps, 31-bit byte offsets into the activations (moved back by the
+// padding) and the weights; the data-gradient form at stride 1 only
+static bool gather_x3_takes(int N, int H, int W, int cin, int cout, int R, int pad, int transposed, int stride)
+{
+    return (R == 1 || R == 3) && cin % 32 == 0 && pad <= R - 1 && !(transposed && stride != 1) &&
+           ((size_t)N * H * W + (size_t)R * W + R) * cin * sizeof(float) < ((size_t)1 << 31) &&
+           (size_t)R * R * cout * cin * sizeof(float) < ((size_t)1 << 31);
 }
 
 template <int TM, int TN, int WM, int WN>
@@ -1088,12 +1145,10 @@ int launch_conv_gather(const float* x, const float* wp, const float* bias, const
     g.Wo = (W + 2 * pad - R) / stride + 1;
     if (g.Ho < 1 || g.Wo < 1) return FRCNN_EINVAL;
     const int M = N * g.Ho * g.Wo;
-    const bool gx3 = math == FRCNN_CONV_F32X3G;
-    // the f32x3 kernel: 32-channel stages, 1x1 / 3x3 taps, 31-bit byte offsets into the activations (moved back by the padding) and weights
-    if (gx3 && ((R != 1 && R != 3) || cin % 32 != 0 || pad > R / 2 + 1 ||
-                ((size_t)N * H * W + (size_t)pad * W + pad) * cin * sizeof(float) >= ((size_t)1 << 31) ||
-                (size_t)R * R * cout * cin * sizeof(float) >= ((size_t)1 << 31)))
-        return FRCNN_EUNSUPPORTED;
+    const bool takes = gather_x3_takes(N, H, W, cin, cout, R, pad, 0, stride);
+    if (math == FRCNN_CONV_F32X3G && !takes) return FRCNN_EUNSUPPORTED;
+    // the pipelined kernel: the f32x3 arithmetic always, the bf16 arithmetic wherever its shape limits allow (else conv_gather_bf16_kernel)
+    const bool gx3 = math == FRCNN_CONV_F32X3G || (math == FRCNN_GRAD_BF16 && takes);
     const int all_stages = gx3 ? (cin / 32) * R * R : (cin / 16) * R * R;
     GatherPlan p = gx3 ? plan_gather_x3(M, cout, all_stages) : plan_gather(M, cout, all_stages, math);
     const size_t need = p.splits > 1 ? (size_t)p.splits * M * cout * sizeof(float) : 0;
@@ -1104,9 +1159,8 @@ int launch_conv_gather(const float* x, const float* wp, const float* bias, const
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
     int rc;
     if (gx3)
-        rc = p.cfg == 2 ? launch_gather_x3_cfg<2, 1, 2, 2, 2>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3)
-           : p.cfg == 3 ? launch_gather_x3_cfg<1, 1, 2, 2, 3>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3)
-                        : launch_gather_x3_cfg<2, 2, 2, 2, 2>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3);
+        rc = math == FRCNN_GRAD_BF16 ? launch_gather_x3_plan<GX_BF16>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, nullptr)
+                                     : launch_gather_x3_plan<GX_F32X3>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3);
     else
         rc = p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, math)
                         : launch_gather_cfg<2, 2, 2, 2>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, math);
@@ -1141,13 +1195,17 @@ int launch_conv_dgrad(const float* dz, const float* wd, const float* residual, f
     g.Cin = cout; g.Cout = cin;
     if (g.H < 1 || g.W < 1) return FRCNN_EINVAL;
     const int M = N * H * W;
-    GatherPlan p = plan_gather(M, cin, (cout / 16) * R * R, math);
+    // bf16 at stride 1: the pipelined kernel (the forward form with the taps walked backwards)
+    const bool gx3 = math == FRCNN_GRAD_BF16 && gather_x3_takes(N, g.H, g.W, cout, cin, R, pad, 1, stride);
+    const int all_stages = gx3 ? (cout / 32) * R * R : (cout / 16) * R * R;
+    GatherPlan p = gx3 ? plan_gather_x3(M, cin, all_stages) : plan_gather(M, cin, all_stages, math);
     const size_t need = p.splits > 1 ? (size_t)p.splits * M * cin * sizeof(float) : 0;
     if (need > ws_bytes || (need > 0 && ws == nullptr)) {
         p.splits = 1;
-        p.stages_per_split = (cout / 16) * R * R;
+        p.stages_per_split = all_stages;
     }
-    int rc = p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, dz, wd, nullptr, residual, dx, (float*)ws, g, 0, s, math)
+    int rc = gx3 ? launch_gather_x3_plan<GX_BF16>(p, dz, wd, nullptr, residual, dx, (float*)ws, g, 0, s, nullptr)
+           : p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, dz, wd, nullptr, residual, dx, (float*)ws, g, 0, s, math)
                         : launch_gather_cfg<2, 2, 2, 2>(p, dz, wd, nullptr, residual, dx, (float*)ws, g, 0, s, math);
     if (rc) return rc;
     if (p.splits > 1) {
@@ -1166,7 +1224,9 @@ size_t conv_dgrad_workspace_bytes(int N, int H, int W, int cin, int cout, int R,
     if (N < 1 || H < 1 || W < 1 || cout % 16 != 0 || R < 1 || stride < 1) return 0;
     const int M = N * H * W;
     const GatherPlan p = plan_gather(M, cin, (cout / 16) * R * R);
-    return p.splits > 1 ? (size_t)p.splits * M * cin * sizeof(float) : 0;
+    const GatherPlan q = plan_gather_x3(M, cin, (cout / 32 > 0 ? cout / 32 : 1) * R * R);
+    const int splits = p.splits > q.splits ? p.splits : q.splits;
+    return splits > 1 ? (size_t)splits * M * cin * sizeof(float) : 0;
 }
 
 int launch_conv7x7_s2_c3(const float* x, const float* wp, const float* b, float* y, int H, int W, int cout,
