@@ -337,6 +337,9 @@ def test_resnet_default_modes_and_conv_table():
     m = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet50))
     assert (m.x6_conv1x1, m.x6_conv1x1_arith, m.winograd_x6_layers, m.winograd_x3_layers) == ("head", "f32x3", ("rpn_trunk",), ("rpn_trunk",))
     assert m.bottleneck_g3 == "backbone" and m._stage1_feature_extractor.g3 and not m._stage3_detector_network._pool_to_feature_vector.g3
+    m101 = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet101))
+    assert m101.bottleneck_g3 == "off" and not m101._stage1_feature_extractor.g3        # admitted by the criterion, not the default
+    del m101
     assert m._x6_mask() == m._x3_mask() == 1 << 13
     table = bench.resnet_conv_table(m)
     head = [r for r in table if r[0] == "head" and r[2].startswith("gemm_")]

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--arch", default="ResNet50")
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--modes", default="off,backbone,all,off")
+    ap.add_argument("--inflight", default="8", help="comma-separated numbers of batch-1 images in flight to time")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     m = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(getattr(resnet.Architecture, args.arch)))
@@ -67,8 +68,9 @@ def main():
 
     for mode in args.modes.split(","):
         m.bottleneck_g3 = mode
-        print("%-9s in flight x8: %7.1f img/s   one at a time: %7.1f   batches of 8: %7.1f" % (
-            mode, rate(inflight, args.steps), rate(single, args.steps // 2), rate(batches, args.steps)), flush=True)
+        fl = "  ".join("x%d: %7.1f" % (n, rate(lambda k, n=n: inflight(k, n), args.steps)) for n in (int(v) for v in args.inflight.split(",")))
+        print("%-9s in flight %s img/s   one at a time: %7.1f   batches of 8: %7.1f" % (
+            mode, fl, rate(single, args.steps // 2), rate(batches, args.steps)), flush=True)
 
 
 if __name__ == "__main__":

@@ -35,10 +35,11 @@ VGG_TABLES = {
 }
 RESNET_TABLES = {
     "default": {},
-    "f32": {"x6_conv1x1": "off", "winograd_x6_layers": (), "winograd_x3_layers": ()},
-    "f32_direct": {"math_mode": "f32", "x6_conv1x1": "off"},
-    "x6_head": {"x6_conv1x1": "head", "x6_conv1x1_arith": "f32x6", "winograd_x6_layers": (), "winograd_x3_layers": ()},
-    "x3_all": {"x6_conv1x1": "all", "x6_conv1x1_arith": "f32x3", "winograd_x6_layers": ("rpn_trunk",), "winograd_x3_layers": ("rpn_trunk",)},
+    "r3_default": {"bottleneck_g3": "off"},            # round 3's default: float32 backbone, layer4 head + RPN trunk in f32x3
+    "f32": {"bottleneck_g3": "off", "x6_conv1x1": "off", "winograd_x6_layers": (), "winograd_x3_layers": ()},
+    "f32_direct": {"bottleneck_g3": "off", "math_mode": "f32", "x6_conv1x1": "off"},
+    "x6_head": {"bottleneck_g3": "off", "x6_conv1x1": "head", "x6_conv1x1_arith": "f32x6", "winograd_x6_layers": (), "winograd_x3_layers": ()},
+    "x3_all": {"bottleneck_g3": "off", "x6_conv1x1": "all", "x6_conv1x1_arith": "f32x3", "winograd_x6_layers": ("rpn_trunk",), "winograd_x3_layers": ("rpn_trunk",)},
     "g3_backbone": {"bottleneck_g3": "backbone"},     # layer1..3 in the f32x3 arithmetic under one scale per tensor (conv_gather_x3_kernel)
     "g3_all": {"bottleneck_g3": "all"},               # ... and the per-RoI layer4
 }
