@@ -49,6 +49,7 @@ import torch.distributed as dist   # noqa: E402
 H, W = 600, 1000
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # same table, "Peak BF16/FP16 MFMA" dense (never the 2:1-sparsity figure)
+PEAK_HBM_GBS = 8000.0            # same guide: HBM3E ~8 TB/s
 
 # (cin, cout, h, w) of the 3x3 convolutions that run on the MFMA kernel (conv1_1 is the VALU kernel)
 _MFMA_CONVS = [(64, 64, 600, 1000), (64, 128, 300, 500), (128, 128, 300, 500), (128, 256, 150, 250),
@@ -420,6 +421,28 @@ def resnet_conv_table(model, h=H, w=W, n_rois=300):
     return rows
 
 
+def resnet_backbone_algorithmic_bytes(model, h=H, w=W):
+    """Bytes the bottleneck convolutions of layer1..3 must move per image if every tensor crossed HBM exactly once per convolution:
+    4 B x (input pixels x cin + output pixels x cout (+ the residual read) + the weights) -- DESIGN.md section 2's per-unit figure for
+    conv_gather_x3_kernel -- and the number of those convolutions."""
+    seq = model._stage1_feature_extractor._feature_extractor
+    hh, ww = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+    total, n = 0.0, 0
+    for layer in (seq[4], seq[5], seq[6]):
+        for blk in layer:
+            cin, width, cout, st = blk.conv1.in_channels, blk.conv1.out_channels, blk.conv3.out_channels, blk.stride
+            ho, wo = (hh - 1) // st + 1, (ww - 1) // st + 1
+            convs = [(hh * ww, cin, hh * ww, width, 1, False), (hh * ww, width, ho * wo, width, 9, False), (ho * wo, width, ho * wo, cout, 1, True)]
+            if blk.downsample is not None:
+                convs.append((hh * ww, cin, ho * wo, cout, 1, False))
+            for pin, ci, pout, co, taps, res in convs:
+                total += 4.0 * (pin * ci + pout * co * (2 if res else 1) + taps * ci * co)
+                n += 1
+            hh, ww = ho, wo
+    return total, n
+
+
 def resnet_roofline_leg(model, image, dev, images=6):
     """Per-kernel-class HIP-event times of ONE ResNet image at a time (slot 0) against the FLOP each class executes:
     BASELINE configs[2]'s roofline evidence.  Classes (csrc/api.hip): conv3x3_mfma = the backbone's conv_gather_mfma_kernel launches
@@ -474,9 +497,20 @@ def resnet_roofline_leg(model, image, dev, images=6):
                                   "conv_gather_mfma_kernel (backbone 1x1 / strided convolutions, exact-f32 pipe)"),
                  "winograd_gemm": "wino_fused_kernel (backbone 3x3 + RPN trunk)", "linear_mfma": "the head's float32 launches",
                  "winograd_x6_gemm": "gemm_x3t_kernel / gemm_x6t_kernel (layer4's convolutions and the RPN trunk as split-operand GEMMs)"}
-    if dom:
+    if dom and g3_backbone and dom == "conv3x3_mfma":
+        # the f32x3 gather kernel: of the two rooflines the HBM one binds (its algorithmic bytes take longer at 8 TB/s than its matrix
+        # instructions at the fp16 peak); what actually limits it is the L2 -> CU fetch in between (the class note)
+        abytes, nconv = resnet_backbone_algorithmic_bytes(model)
+        gbs = abytes / (med[dom] / 1e3) / 1e9
+        out.update({"kernel": kernel_of[dom], "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": measured_traffic("conv_gather_x3_kernel"),
+                    "algorithmic_bytes_per_launch": abytes / nconv, "launches_per_image": nconv,
+                    "mfma_frac": out["classes"][dom]["frac"],
+                    "note": "achieved = algorithmic bytes of the %d bottleneck convolutions (each tensor once per convolution) / the class's HIP-event "
+                            "time; traffic = measured HBM bytes per launch (profiles/, FETCH_SIZE x 2 + WRITE_SIZE)" % nconv})
+    elif dom:
         out.update({"kernel": kernel_of[dom], "bound": "mfma", "achieved": out["classes"][dom]["achieved_tflops"], "peak": out["classes"][dom]["peak"],
-                    "unit": "TFLOP/s", "frac": out["classes"][dom]["frac"], "traffic": measured_traffic("conv_gather_x3_kernel" if (g3_backbone and dom == "conv3x3_mfma") else "conv_gather_mfma_kernel")})
+                    "unit": "TFLOP/s", "frac": out["classes"][dom]["frac"], "traffic": measured_traffic("conv_gather_mfma_kernel")})
     return out
 
 

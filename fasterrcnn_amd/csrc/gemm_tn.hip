@@ -353,14 +353,18 @@ void gemm_tn_reduce_kernel(const float* __restrict__ ws, int splits, int taps, i
 }
 
 namespace {
-// Reduction ranges so that the launch has ~1024+ blocks, each range >= 64 rows, partials fit in ws.
+// Reduction ranges so that the launch has ~512+ blocks, each range >= 128 rows, partials fit in ws.  (Round 4: 1024 blocks / 64 rows gave the
+// small weight matrices of the ResNets up to 512 ranges whose planes gemm_tn_reduce_kernel then streams: ResNet-101 bf16 step 12.14 ms; 512 /
+// 64: 11.85, 512 / 128: 11.75, 256 / 128: 11.88, 2048 / 64: 12.29)
 void choose_split(int M, int N, int R, int taps, size_t ws_bytes, bool have_ws, int* splits, int* rows_per_split, int rk)
 {
     const long tiles = (long)cdiv(M, GT_T) * cdiv(N, GT_T) * taps;
     int s = 1;
     if (have_ws && (N % 2 == 0) && tiles < 768) {
-        s = (int)((1024 + tiles - 1) / tiles);
-        const int max_by_rows = R / 64 > 0 ? R / 64 : 1;
+        static const int target = []() { const char* e = frcnn_knob("FRCNN_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();        // experiments
+        static const int min_rows = []() { const char* e = frcnn_knob("FRCNN_WGRAD_MIN_ROWS"); return e ? atoi(e) : 128; }();
+        s = (int)((target + tiles - 1) / tiles);
+        const int max_by_rows = R / min_rows > 0 ? R / min_rows : 1;
         if (s > max_by_rows) s = max_by_rows;
         const size_t per = (size_t)taps * M * N * sizeof(float);
         const size_t max_by_ws = per ? ws_bytes / per : 1;

@@ -161,6 +161,7 @@ def traffic(d):
                 ("gemm_x3t_kernel", lambda n: "gemm_x3t_kernel" in n),
                 ("wino_input_x6t_kernel", lambda n: "wino_input_x6t_kernel" in n),
                 ("wino_output_kernel", lambda n: "wino_output_kernel" in n),
+                ("conv_gather_x3_kernel", lambda n: "conv_gather_x3_kernel" in n),
                 ("conv_gather_mfma_kernel", lambda n: "conv_gather_mfma_kernel" in n),
                 ("linear_x6_kernel", lambda n: "linear_x6_kernel" in n),
                 ("conv3x3_mfma_kernel", lambda n: "conv3x3_mfma" in n),
@@ -190,7 +191,9 @@ def traffic(d):
                    "hbm_bytes_per_launch": f * 1024 * 2.0 + w * 1024}
     head = "wino_x3d_kernel" if "wino_x3d_kernel" in by else "wino_fused_kernel" if "wino_fused_kernel" in by else ("conv3x3_mfma_kernel" if "conv3x3_mfma_kernel" in by else None)
     if head is None:
-        return
+        if not by:
+            return
+        head = next(iter(by))              # a partial collection (ResNet passes only): tools/collect_profiles.sh PARTIAL=1
     c = by[head]
     rec = {"source": "%s (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, single stream)" % d,
            "kernel": "%s (all instantiations)" % head, "launches": c["launches"],
