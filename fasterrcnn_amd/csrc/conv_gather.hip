@@ -450,16 +450,18 @@ void conv_gather_bf16_kernel(const float* __restrict__ x, const float* __restric
     }
 }
 
-// ---- f32x3 operands under ONE power-of-two scale per tensor (round 4: the ResNet backbone at inference) -------------------------------------------
+// ---- f32x3 operands under ONE power-of-two scale per tensor (round 4: the ResNet-50 backbone at inference) ----------------------------------------
+// Reference: the Bottleneck convolutions of models/resnet.py:38-46 (conv + frozen BatchNorm folded, residual add, ReLU), torchvision v1.5 layout.
 // The gather implicit GEMM in the split-operand arithmetic of csrc/gemm_x3t.hip -- every operand value as two fp16 terms hi = fp16(v 2^e),
 // lo = fp16(v 2^e - hi), three v_mfma_f32_32x32x16_f16 per product (lo x hi, hi x hi, hi x lo), float32 accumulation -- with the split done
-// ON THE WAY INTO LDS (two v_fma_mix per value) instead of by a separate record-writing pass, which is what makes it a drop-in for the
+// ON THE WAY INTO LDS (~2.5 vector instructions per value) instead of by a separate record-writing pass, which is what makes it a drop-in for the
 // float32 kernel: no activation records, no per-row scale arrays, the float32 weight pack as is.  The scale is per TENSOR: 2^e with
 // max|x| 2^e in [2^14, 2^15), max|x| read from a device float the PRODUCER of x left behind (this kernel's own epilogue, atomic maximum over
-// its outputs; the stem convolution's) -- any upper bound works, so nothing is read twice.  A value far below the tensor's maximum keeps
-// 22 bits of ITSELF down to 2^-14 of the maximum and an absolute error of 2^-38 of the maximum below that: measured through the oracle on
-// the held-out ResNet-50 images (tools/exp_r50_global_scale.py) the proposals stay at 0.92-0.94 of the reference's own distance from the
-// float64 truth.  Matrix time per stage: 3 x 32 cycles against the float32 kernel's 8 x 64.
+// its outputs; tensor_absmax_kernel for the max-pooled stem output) -- any upper bound works, so no convolution input is read twice.  A value far below the tensor's maximum keeps
+// 22 bits of ITSELF down to 2^-14 of the maximum and an absolute error of 2^-38 of the maximum below that.  Held-out ResNet-50 (DESIGN.md
+// section 4): 1.14 / 1.18 of the reference's own distance from the float64 truth (a CPU emulation through the oracle had said 0.92-0.94
+// before the kernel existed: tools/exp_r50_global_scale.py), 2397 / 2400 of its rows.  Matrix time per 16 channels: 3 x 32 cycles against
+// the float32 kernel's 8 x 64 -- and what bounds the kernel is neither: the L2 -> CU fetch of the operand tiles (tools/gx_clocks.py).
 typedef _Float16 gx_f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned gx_u32x2 __attribute__((ext_vector_type(2)));
 // A stage is 32 input channels of one filter tap.  LDS row of a stage: [hi 16 | lo 16] of channels 0..15, [hi 16 | lo 16] of 16..31,
@@ -480,15 +482,18 @@ struct GatherX3Cfg {
 
 // four floats -> their hi and lo fp16 terms under the scale m: hi = fp16(v m), lo = fp16(v m - hi) (v m and the difference are exact in
 // float32: m is a power of two, the difference has <= 13 significant bits).  Plain C so that the scheduler can place the conversions between
-// the matrix instructions (it selects v_fma_mix / v_pk_fma_f32 + v_cvt_pk: ~10 instructions per piece)
-__device__ __forceinline__ void gx_split4(const f32x4 v, float m, gx_u32x2& hi, gx_u32x2& lo)
+// the matrix instructions
+// `bound` = 65504 / m: a value beyond it (the caller's maximum was not one) saturates instead of becoming hi = inf, lo = -inf -> NaN
+// downstream (hx_split8's rule); one v_med3 per value, the products stay on v_fma_mix.
+__device__ __forceinline__ void gx_split4(const f32x4 v, float m, float bound, gx_u32x2& hi, gx_u32x2& lo)
 {
     typedef _Float16 gx_f16x4 __attribute__((ext_vector_type(4)));
     gx_f16x4 h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        h[e] = (_Float16)__builtin_fmaf(v[e], m, 0.0f);
-        l[e] = (_Float16)__builtin_fmaf(v[e], m, -(float)h[e]);
+        const float c = __builtin_amdgcn_fmed3f(v[e], -bound, bound);
+        h[e] = (_Float16)__builtin_fmaf(c, m, 0.0f);
+        l[e] = (_Float16)__builtin_fmaf(c, m, -(float)h[e]);
     }
     hi = __builtin_bit_cast(gx_u32x2, h);
     lo = __builtin_bit_cast(gx_u32x2, l);
@@ -512,9 +517,10 @@ __device__ __forceinline__ void gx_block_max(float vmax, float* out)
 
 // Pipeline, depth D: D register sets and D LDS buffers in a ring.  While the matrix instructions of stage s run from LDS buffer s % D, the
 // float32 pieces of stage s + 1 (register set (s + 1) % D, fetched D stages ago) are converted and written to buffer (s + 1) % D and
-// the fetch of stage s + D + 1 is issued into the set just freed: a load has D whole stages to land (D = 2 at the 128 x 128 tile, 48
+// the fetch of stage s + D + 1 is issued into the set just freed: a load has D whole stages to land (D = 2 at the 128-row tiles, 24-48
 // MFMAs a stage; D = 3 at the 64 x 64 tile, whose stages are a quarter as long), where the float32 kernel's single stage of eight
-// 64-cycle instructions per accumulator hid it by itself.
+// 64-cycle instructions per accumulator hid it by itself.  Measured (tools/gx_clocks.py): a stage takes 0.42 / 0.70 / 1.05 us at the
+// 64 x 64 / 128 x 64 / 128 x 128 tile = its 16 / 24 / 32 KB of operands at ~40 GB/s per CU, whatever D and the instruction order.
 // Block b -> tile: XCD b % 8 owns the row blocks m = 8 k + b % 8 and walks their column blocks, so an activation tile is fetched into
 // one XCD's L2 once; the weights (<= 2.4 MB) sit in every L2.
 // Epilogue: the accumulators go through LDS once so that a wave's 16-byte stores (and residual loads) cover whole 256 / 512-byte rows
@@ -556,6 +562,7 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
         hx_row_scale(*xmax, xmult, xinv);
         hx_row_scale(*wmax, wmult, winv);
     }
+    const float xbound = 65504.f * xinv, wbound = 65504.f * winv;        // the largest operand values whose hi term is finite
 
     // thread -> piece: row (tid >> 3) + 32 it of the tile, channels 4 (tid & 7) .. + 3 of the stage.  Every fetch is a buffer load:
     // per-piece byte offset (constant over the stages) in the VGPR, the stage's (tap, channel chunk) offset in an SGPR, and bit 31 of the
@@ -634,14 +641,14 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
 #pragma unroll
             for (int it = 0; it < C::NA; ++it) {
                 gx_u32x2 hi, lo;
-                gx_split4(ar[it], xmult, hi, lo);
+                gx_split4(ar[it], xmult, xbound, hi, lo);
                 *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW) = hi;
                 *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW + 16) = lo;
             }
 #pragma unroll
             for (int it = 0; it < C::NB; ++it) {
                 gx_u32x2 hi, lo;
-                gx_split4(br[it], wmult, hi, lo);
+                gx_split4(br[it], wmult, wbound, hi, lo);
                 *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW) = hi;
                 *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW + 16) = lo;
             }
@@ -851,16 +858,28 @@ void gather_splitk_finish_kernel(const float* __restrict__ ws, int splits, const
     const size_t plane = (size_t)M * Cout;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c4 = (int)(i % C4);
-        f32x4 v = reinterpret_cast<const f32x4*>(ws)[i];
-        for (int k = 1; k < splits; ++k) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(ws + k * plane + i * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += t[j];
-        }
+        // every load of the item is issued before the first add (the planes, the bias, the residual: one round trip instead of one per
+        // plane); the sum keeps the ascending plane order
         f32x4 b = {0.f, 0.f, 0.f, 0.f};
         if (bias) b = reinterpret_cast<const f32x4*>(bias)[c4];
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
         if (residual) r = reinterpret_cast<const f32x4*>(residual)[i];
+        f32x4 v = reinterpret_cast<const f32x4*>(ws)[i];
+        int k = 1;
+        for (; k + 4 <= splits; k += 4) {
+            f32x4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(ws + (size_t)(k + u) * plane + i * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += t[u][j];
+        }
+        for (; k < splits; ++k) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(ws + (size_t)k * plane + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += t[j];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float t = (xmax ? v[j] * unscale : v[j]) + b[j] + r[j];

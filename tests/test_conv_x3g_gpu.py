@@ -81,6 +81,19 @@ def test_conv_x3g_upper_bounds_scale_the_same_result():
     assert torch.isfinite(y1).all()
 
 
+def test_conv_x3g_saturates_on_a_bound_that_is_not_one():
+    """a caller's "maximum" 64x too small must not become hi = inf, lo = -inf -> NaN in the output: the operand saturates at the largest
+    finite fp16 hi term (the result is then wrong in value, finite, and the true maximum the epilogue leaves behind shows it)"""
+    g = torch.Generator().manual_seed(9)
+    n, h, w, cin, cout = 1, 9, 11, 64, 64
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wp = pack((torch.randn(cout, cin, 1, 1, generator=g) / 8.0).cuda())
+    b = torch.zeros(cout).cuda()
+    ymax = torch.zeros(1, device="cuda")
+    y, _, _ = R.conv_nhwc_x3g(x, wp, b, n, h, w, cin, cout, 1, 1, 0, False, R.tensor_absmax(x) / 64.0, R.tensor_absmax(wp), ymax)
+    assert torch.isfinite(y).all() and torch.isfinite(ymax).all()
+
+
 def test_conv_x3g_rejects_missing_scales():
     x = torch.zeros(1, 4, 4, 16).cuda()
     wp = torch.zeros(1, 4, 16).cuda()
