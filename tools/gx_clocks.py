@@ -12,9 +12,16 @@ from fasterrcnn_amd.models import resnet as R
 from exp_conv_x3g import SHAPES
 
 
+# --contiguity: 3x3 convolutions whose operand rows are (cin = 32: a pixel's stage is its whole 128-byte row, neighbouring pixels and filter
+# rows adjoin) or are not (cin = 64, 256: 128 bytes out of every 256 / 1024) contiguous in memory -- does the fetch rate depend on it?
+CONTIGUITY = [("3x3 cin 32 > 64", 150, 250, 32, 64, 3, 1, False, 1), ("3x3 cin 64 > 64", 150, 250, 64, 64, 3, 1, False, 1),
+              ("3x3 cin 32 > 128", 75, 125, 32, 128, 3, 1, False, 1), ("3x3 cin 128 > 128", 75, 125, 128, 128, 3, 1, False, 1),
+              ("3x3 cin 32 > 256", 38, 63, 32, 256, 3, 1, False, 1), ("3x3 cin 256 > 256", 38, 63, 256, 256, 3, 1, False, 1)]
+
+
 def main():
     lib = nv.lib()
-    for name, h, w, cin, cout, k, stride, res, count in SHAPES:
+    for name, h, w, cin, cout, k, stride, res, count in (CONTIGUITY if "--contiguity" in sys.argv else SHAPES):
         pad = 1 if k == 3 else 0
         ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
         x = torch.randn(1, h, w, cin, device="cuda").relu()
