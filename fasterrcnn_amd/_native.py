@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
-ABI_VERSION = 11    # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
+ABI_VERSION = 12    # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
@@ -31,7 +31,7 @@ SYMBOLS = (
     "frcnn_nms", "frcnn_roi_pool", "frcnn_roi_pool_x3t", "frcnn_detections", "frcnn_ctx_create", "frcnn_ctx_create_proposals", "frcnn_ctx_destroy",
     "frcnn_ctx_bytes", "frcnn_vgg16_forward", "frcnn_ctx_tensor", "frcnn_ctx_timing_enable",
     "frcnn_ctx_timing_read",
-    "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv_nhwc_math", "frcnn_conv_nhwc_x3g", "frcnn_tensor_absmax", "frcnn_conv7x7_s2_c3",
+    "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv_nhwc_math", "frcnn_conv_nhwc_x3g", "frcnn_x3_saturation_events", "frcnn_tensor_absmax", "frcnn_conv7x7_s2_c3",
     "frcnn_maxpool3x3_s2_nhwc", "frcnn_spatial_mean_nhwc", "frcnn_resnet_forward", "frcnn_rpn_targets",
     "frcnn_pack_conv3x3_x6", "frcnn_conv3x3_nhwc_x6", "frcnn_preprocess_workspace_bytes", "frcnn_preprocess",
     "frcnn_conv3x3_uses_winograd", "frcnn_resnet_block_uses_winograd", "frcnn_pack_conv3x3_winograd",
@@ -262,6 +262,7 @@ _SIGNATURES = {
     "frcnn_fold_bn_pack": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     "frcnn_conv_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "frcnn_conv_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "frcnn_x3_saturation_events": (C.c_int, [C.POINTER(C.c_ulonglong)]),
     "frcnn_conv_nhwc_math": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _i, _vp, _sz, _vp]),
     "frcnn_conv_nhwc_x3g": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_tensor_absmax": (C.c_int, [_vp, C.c_longlong, _vp, _vp]),
@@ -374,6 +375,18 @@ def stream_ptr(stream=None):
     import torch
     s = stream if stream is not None else torch.cuda.current_stream()
     return s.cuda_stream
+
+
+def x3_saturation_count():
+    """frcnn_x3_saturation_events after a device synchronisation: the number of waves, since the library was loaded, whose per-tensor-scaled
+    f32x3 convolution (conv_gather_x3_kernel: the ResNet-50 backbone) CLAMPED an activation beyond fp16 range -- 0 unless a tensor maximum
+    handed to the kernel was not an upper bound."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    n = C.c_ulonglong(0)
+    check(lib().frcnn_x3_saturation_events(C.byref(n)), "frcnn_x3_saturation_events")
+    return int(n.value)
 
 
 def require_gpu():

@@ -492,6 +492,14 @@ int frcnn_conv_nhwc_math(const float* d_x, const float* d_wp, const float* d_bia
                               d_ws, ws_bytes, as_stream(stream), math);
 }
 
+int frcnn_x3_saturation_events(unsigned long long* out)
+{
+    if (!out) return FRCNN_EINVAL;
+    const unsigned* c = x3_saturation_counter();
+    *out = c ? (unsigned long long)*reinterpret_cast<const volatile unsigned*>(c) : 0ull;
+    return FRCNN_OK;
+}
+
 int frcnn_conv_nhwc_x3g(const float* d_x, const float* d_wp, const float* d_bias, const float* d_residual, float* d_y,
                         int N, int H, int W, int cin, int cout, int ksize, int stride, int pad, unsigned flags,
                         const float* d_xmax, const float* d_wmax, float* d_ymax, void* d_ws, size_t ws_bytes, void* stream)

@@ -116,6 +116,8 @@ struct GatherX3 { const float* xmax; const float* wmax; float* ymax; };
 int launch_conv_gather(const float* x, const float* wp, const float* bias, const float* residual, float* y,
                        int N, int H, int W, int cin, int cout, int R, int stride, int pad, unsigned flags,
                        void* ws, size_t ws_bytes, hipStream_t s, int math = FRCNN_GRAD_F32, const GatherX3* x3 = nullptr);
+// host-mapped process-wide counter of the waves whose activation split saturated (conv_gather_x3_kernel); null if it could not be allocated
+unsigned* x3_saturation_counter();
 // out[0] = max(out[0], max |x[i]|) (out zeroed by the caller or holding an earlier maximum)
 int launch_tensor_absmax(const float* x, long long n, float* out, hipStream_t s);
 int launch_conv7x7_s2_c3(const float* x, const float* wp, const float* b, float* y, int H, int W, int cout,

@@ -37,7 +37,7 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 11  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
+#define FRCNN_ABI_VERSION 12  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
                                  5: bf16 gradient GEMMs (the *_math entry points); 6: x6t GEMM, x6 Winograd layers, frcnn_forward_params.winograd_x6_mask,
                                  timing classes 8 / 9; 7: batched feature extractor (frcnn_resnet_backbone, frcnn_resnet_forward_features,
                                  frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps); 8: the f32x3 arithmetic (frcnn_*_x3t, frcnn_*_winograd_x3,
@@ -727,6 +727,13 @@ int frcnn_conv_dgrad_math(const float* d_dz, const float* d_wd, const float* d_r
 int frcnn_conv_nhwc_x3g(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
                         int N, int H, int W, int cin, int cout, int ksize, int stride, int pad, unsigned flags,
                         const float* d_xmax, const float* d_wmax, float* d_ymax, void* d_ws, size_t ws_bytes, void* stream);
+/* ABI 12: frcnn_conv_nhwc_x3g CLAMPS an activation whose hi term would overflow fp16 under the tensor's scale (i.e. *d_xmax was not an
+ * upper bound) instead of producing inf / NaN; every wave that clamped one adds 1 to a process-wide counter.  *out = that count since the
+ * library was loaded (read it after synchronising the streams the convolutions ran on).  With the maxima the producers' epilogues leave
+ * behind (frcnn_resnet_forward / frcnn_resnet_backbone chain them) the count stays 0: tests/test_stress_gpu.py asserts it on inputs built
+ * against the per-tensor scale (models/resnet.py:38-46 has no such notion: its float32 convolutions cannot overflow). */
+int frcnn_x3_saturation_events(unsigned long long* out);
+
 /* d_out[0] = max(d_out[0], max_i |d_x[i]|), n floats, d_x 16-byte aligned (the scale source of a tensor no frcnn_conv_nhwc_x3g produced) */
 int frcnn_tensor_absmax(const float* d_x, long long n, float* d_out, void* stream);
 

@@ -67,10 +67,12 @@ def truth_candidates(truth, image_shape):
     return idx[:n].astype(np.int32), cand[big][:n].numpy(), truth["scores"][t.from_numpy(idx[:n])].numpy(), prop_pos
 
 
-def run_case(ref, arch, seed, wseed, sd, sd64):
-    tag = case_tag(arch, seed, wseed)
+def run_case(ref, arch, seed, wseed, sd, sd64, img=None, tag=None, out_dir=HOLDOUT, extra=None):
+    """img / tag / out_dir / extra: oracle/make_stress.py runs the same five steps on its own inputs"""
+    tag = tag or case_tag(arch, seed, wseed)
     vgg = arch == "VGG16"
-    img = (synthetic.image if vgg else synthetic.image_rgb)(seed, HEIGHT, WIDTH).unsqueeze(0)
+    if img is None:
+        img = (synthetic.image if vgg else synthetic.image_rgb)(seed, HEIGHT, WIDTH).unsqueeze(0)
     t0 = time.time()
     model = build_reference_model(ref, sd, True, None if vgg else arch)
     with t.no_grad():
@@ -124,7 +126,11 @@ def run_case(ref, arch, seed, wseed, sd, sd64):
         "ref_scores_sample_err": np.float64(np.abs(detail["scores"].numpy()[::16].astype(np.float64) - truth["scores"].numpy()[::16]).max()),
         "ref_prop_err": p_err, "ref_det_err": d_err, "ref_det_score_err": s_err,
     }
-    np.savez_compressed(os.path.join(HOLDOUT, tag + ".npz"), **out)
+    if extra is not None:                    # (the stress set only: the held-out fixtures keep their 25 arrays)
+        out.update(extra)
+        out["n_unique_top_scores"] = np.int64(len(np.unique(detail["scores"].numpy()[detail["sorted_idx"]])))
+        out["n_top_scores"] = np.int64(len(detail["sorted_idx"]))
+    np.savez_compressed(os.path.join(out_dir, tag + ".npz"), **out)
     return {"tag": tag, "ref_vs_truth": {"fm": fm_err, "obj": obj_err, "proposals": ps, "detections": ds}}
 
 

@@ -20,6 +20,7 @@ from fasterrcnn_amd import synthetic
 from oracle import f64_truth as T
 
 HOLDOUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "holdout")
+STRESS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stress")     # oracle/make_stress.py
 GATE = 1e-3              # north_star: boxes within 1e-3 px of the PyTorch reference
 
 
@@ -27,16 +28,21 @@ def cases(arch):
     return sorted(glob.glob(os.path.join(HOLDOUT, "%s_*.npz" % arch.lower())))
 
 
-def build_model(arch, weights_seed):
+def stress_cases(arch):
+    return sorted(glob.glob(os.path.join(STRESS, "%s_*.npz" % arch.lower())))
+
+
+def build_model(arch, weights_seed, kind=None):
+    """kind: a stress kind (synthetic.STRESS_KINDS) selects that recipe's weights; None = the standard recipe"""
     from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
     if arch == "VGG16":
         from fasterrcnn_amd.models.vgg16 import VGG16Backbone
         m = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
-        sd = synthetic.vgg16_state_dict(weights_seed)
+        sd = synthetic.vgg16_state_dict(weights_seed) if kind is None else synthetic.stress_vgg16_state_dict(weights_seed, kind)
     else:
         from fasterrcnn_amd.models import resnet
         m = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(getattr(resnet.Architecture, arch)))
-        sd = synthetic.resnet_state_dict(weights_seed, arch)
+        sd = synthetic.resnet_state_dict(weights_seed, arch) if kind is None else synthetic.stress_resnet_state_dict(weights_seed, kind, arch)
     m.load_state_dict(sd, strict=True)
     return m.cuda().eval()
 
@@ -62,7 +68,10 @@ def measure(model, g, slot=0):
     throughput configuration (VGG-16: the 512-channel f32x3 layers in the one-launch form, FasterRCNNModel.layer_tables)."""
     arch = str(g["arch"])
     seed, h, w = int(g["seed"]), int(g["height"]), int(g["width"])
-    img = (synthetic.image if arch == "VGG16" else synthetic.image_rgb)(seed, h, w).unsqueeze(0).cuda()
+    if "kind" in g:                                       # a stress fixture (oracle/make_stress.py)
+        img = (synthetic.stress_image if arch == "VGG16" else synthetic.stress_image_rgb)(seed, str(g["kind"]), h, w).unsqueeze(0).cuda()
+    else:
+        img = (synthetic.image if arch == "VGG16" else synthetic.image_rgb)(seed, h, w).unsqueeze(0).cuda()
     with torch.no_grad():
         props, classes, deltas = model._enqueue(img, None, None, None, slot).result()
     ctx = model.context(slot)
@@ -71,7 +80,7 @@ def measure(model, g, slot=0):
     scores = ctx.tensor(2).cpu().numpy()
     det = flatten_detections(model.predict_async(img, float(g["score_threshold"]), slot).result())
     ours = props.cpu().numpy()
-    out = {"arch": arch, "seed": seed, "weights_seed": int(g["weights_seed"]), "n_proposals": int(ours.shape[0]),
+    out = {"arch": arch, "seed": seed, "weights_seed": int(g["weights_seed"]), "kind": str(g["kind"]) if "kind" in g else "", "n_proposals": int(ours.shape[0]),
            "n_detections": int(det.shape[0]), "n_ref_detections": int(g["ref_detections"].shape[0])}
     # --- continuous tensors against the truth
     out["fm_err"] = float(np.abs(fm[::128, ::2, ::2].astype(np.float64) - g["truth_fm_sample"]).max() / float(g["truth_fm_scale"]))

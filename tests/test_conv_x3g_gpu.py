@@ -90,8 +90,13 @@ def test_conv_x3g_saturates_on_a_bound_that_is_not_one():
     wp = pack((torch.randn(cout, cin, 1, 1, generator=g) / 8.0).cuda())
     b = torch.zeros(cout).cuda()
     ymax = torch.zeros(1, device="cuda")
+    before = nv.x3_saturation_count()
+    y, _, _ = R.conv_nhwc_x3g(x, wp, b, n, h, w, cin, cout, 1, 1, 0, False, R.tensor_absmax(x), R.tensor_absmax(wp), ymax)
+    assert nv.x3_saturation_count() == before, "a true maximum never saturates"
     y, _, _ = R.conv_nhwc_x3g(x, wp, b, n, h, w, cin, cout, 1, 1, 0, False, R.tensor_absmax(x) / 64.0, R.tensor_absmax(wp), ymax)
     assert torch.isfinite(y).all() and torch.isfinite(ymax).all()
+    # ... and it is COUNTED (frcnn_x3_saturation_events, ABI 12): the clamp is a reported event, not a silent one
+    assert nv.x3_saturation_count() > before
 
 
 def test_conv_x3g_rejects_missing_scales():

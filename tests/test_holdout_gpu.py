@@ -13,20 +13,24 @@ Two questions, two kinds of assert.
 
         pooled over the held-out set, ours-vs-truth  <=  K_TRUTH x reference-vs-truth     (median of medians and median of p95s)
 
-    K_TRUTH = 1.5 = the measured level of the table with NO split-operand layer (every GEMM on the exact-f32 MFMA pipe, Winograd layers
-    in float32: 1.50 / 1.46 on the VGG-16 set; the all-direct exact-f32 table sits at 1.84 / 1.78 -- a float32 FMA chain over K = 4608
-    rounds more than oneDNN's blocked accumulation does).  I.e. a split-operand arithmetic is admitted where it is AT LEAST as close to
-    the exact answer as plain float32 matrix instructions are; the fastest admitted table is the default.  The measured value of every
-    table is printed by tools/holdout_report.py and recorded in DESIGN.md section 4 (default: VGG-16 1.30 / 1.17, ResNet-50 1.02 / 0.96,
-    ResNet-101 0.88 / 0.96 -- closer to the truth than the reference's own run).
+    K_TRUTH is set PER TABLE at its measured level plus a stated margin (below).  For orientation: the table with NO split-operand layer
+    (every GEMM on the exact-f32 MFMA pipe, Winograd layers in float32) measures 1.50 / 1.46 on the VGG-16 set, the all-direct exact-f32
+    table 1.84 / 1.78 -- a float32 FMA chain over K = 4608 rounds more than oneDNN's blocked accumulation does; the default tables sit at
+    VGG-16 1.30 / 1.17, ResNet-50 1.14 / 1.18, ResNet-101 0.88 / 0.96 (closer to the truth than the reference's own run).  The measured
+    value of every table is printed by tools/holdout_report.py and recorded in DESIGN.md section 4.
 
 (2) north_star's bar, "boxes within 1e-3 px of the PyTorch reference": the fraction of the reference's rows the HIP path reproduces within
     1e-3 px, pooled over the held-out set -- a printed and asserted number, counted two ways: AT THE SAME ROW INDEX (same proposals in the
     same order; one near-tied NMS decision that falls the other way shifts every later row of that image by one index), and as a SET
     (nearest row).  What two float32 runs that are each e_ref from the truth can agree to is ~sqrt(2) e_ref per row, so the floors are
-    derived from the fixture's own reference-vs-truth numbers, not from a golden image: VGG-16 / ResNet-50 >= 0.99 of the rows (set) and
-    >= 0.98 at the same index; ResNet-101 >= 0.90 (set): its reference sits 1e-3 px from the truth by itself, and the saturated class
-    scores of its synthetic head (exactly 1.0f for ~150 rows of one class) make the per-class NMS order a matter of last-bit ties.
+    are the measured fractions minus a margin of ~0.002 (VGG-16, ResNet-50) -- ResNet-101: its reference sits 1e-3 px from the truth by
+    itself, and the saturated class scores of its synthetic head (exactly 1.0f for ~150 rows of one class) make the per-class NMS order a
+    matter of last-bit ties: floors 0.95 / 0.90 / 0.94 against a measured 0.973 / 0.938 / 0.967.
+
+(3) The kernels are deterministic, so the pooled COUNTS of a run are reproducible to the row: tests/golden/holdout/observed_counts.json is the
+    committed snapshot of the last measured run and a run may lose at most COUNT_SLACK rows against it (a regression that stays
+    inside the floors is still caught).  test_the_gates_catch_one_layer_in_bf16 shows the gates measure something: ONE convolution's filter
+    rounded to bf16 fails them on every architecture.
 """
 import json
 import os
@@ -38,10 +42,47 @@ import holdout_lib as H
 
 pytestmark = pytest.mark.gpu
 
-K_TRUTH = 1.5
-# pooled fraction of the reference's rows reproduced within 1e-3 px: (proposals as a set, proposals at the same row index, detections as a set)
-ROW_FRACTION_FLOOR = {"VGG16": (0.99, 0.98, 0.99), "ResNet50": (0.99, 0.98, 0.99), "ResNet101": (0.90, 0.60, 0.85)}
+# (1) K_TRUTH per table = measured (profiles/r0*/holdout_*.json: proposals median, p95, detections median, p95) + a margin of ~0.1.
+# Measured: VGG-16 1.30 / 1.17 / 1.30 / 1.18 (in flight 1.28 / 1.21 / 1.26 / 1.30); ResNet-50 1.14 / 1.18 / 1.18 / 1.28; ResNet-101 0.88 /
+# 0.96 / 0.85 / 1.02; ResNet-101 with the f32x3 backbone (not its default) 1.30 / 1.25 / 1.27 / 1.17.  Round 4's single K = 1.5 let a
+# regression up to the level of the all-exact-f32 table pass.
+K_TRUTH = {"VGG16": 1.40, "ResNet50": 1.38, "ResNet101": 1.10, "ResNet101_g3": 1.40}
+# (2) pooled fraction of the reference's rows reproduced within 1e-3 px: (proposals as a set, proposals at the same row index, detections
+# as a set).  Measured: VGG-16 0.9985 / 0.9981 / 0.9991 (in flight 0.9994 / 0.9990 / 0.9996); ResNet-50 0.9988 / 0.9988 / 1.0;
+# ResNet-101 0.9733 / 0.9383 / 0.9671; with the f32x3 backbone 0.9604 / 0.9250 / 0.9526.
+ROW_FRACTION_FLOOR = {"VGG16": (0.997, 0.996, 0.997), "ResNet50": (0.997, 0.997, 0.998), "ResNet101": (0.95, 0.90, 0.94),
+                      "ResNet101_g3": (0.94, 0.90, 0.93)}
 MIN_CASES = {"VGG16": 16, "ResNet50": 8, "ResNet101": 8}
+# (3) the committed counts of the last measured run (tools/holdout_report.py --snapshot)
+COUNT_SLACK = 2
+SNAPSHOT = os.path.join(H.HOLDOUT, "observed_counts.json")
+COUNT_KEYS = ("prop_rows_ok", "prop_rows_ok_set", "det_rows_ok", "det_rows_ok_set")
+
+
+def violations(key, s):
+    """the gates of table `key` that summary `s` (report()) misses: a list of strings, empty = admitted"""
+    k = K_TRUTH[key]
+    bad = []
+    for name, ours, ref in (("proposals", s["prop_vs_truth"], s["ref_prop_vs_truth"]), ("detections", s["det_vs_truth"], s["ref_det_vs_truth"])):
+        for q in ("median", "p95"):
+            if not ours[q] <= k * ref[q]:
+                bad.append("%s %s vs truth x%.3f > K %.2f" % (name, q, ours[q] / ref[q], k))
+    fp, fpi, fd = ROW_FRACTION_FLOOR[key]
+    for name, v, floor in (("prop_set_fraction", s["prop_set_fraction"], fp), ("prop_row_fraction", s["prop_row_fraction"], fpi),
+                           ("det_set_fraction", s["det_set_fraction"], fd)):
+        if not v >= floor:
+            bad.append("%s %.4f < %.4f" % (name, v, floor))
+    return bad
+
+
+def snapshot_violations(key, s):
+    if not os.path.exists(SNAPSHOT):
+        return ["%s missing" % SNAPSHOT]
+    with open(SNAPSHOT) as f:
+        snap = json.load(f).get(key)
+    if snap is None:
+        return ["no snapshot for %s" % key]
+    return ["%s %d < snapshot %d - %d" % (n, s[n], snap[n], COUNT_SLACK) for n in COUNT_KEYS if s[n] < snap[n] - COUNT_SLACK]
 
 
 def sweep(arch, slot=0, attrs=None):
@@ -74,7 +115,7 @@ def report(arch, results):
     d, rd = H.pooled(results, "det_vs_truth"), H.pooled(results, "ref_det_vs_truth")
     out = {"arch": arch, "cases": len(results), "prop_row_fraction": ok / max(rows, 1), "det_row_fraction": dok / max(drows, 1),
            "prop_set_fraction": oks / max(rows, 1), "det_set_fraction": doks / max(drows, 1), "images_with_identical_order": same_order,
-           "prop_rows": rows, "det_rows": drows, "prop_vs_truth": p, "ref_prop_vs_truth": rp, "det_vs_truth": d, "ref_det_vs_truth": rd,
+           "prop_rows": rows, "det_rows": drows, "prop_rows_ok": ok, "prop_rows_ok_set": oks, "det_rows_ok": dok, "det_rows_ok_set": doks, "prop_vs_truth": p, "ref_prop_vs_truth": rp, "det_vs_truth": d, "ref_det_vs_truth": rd,
            "fm_err_median": float(np.median([r["fm_err"] for r in results])),
            "ref_fm_err_median": float(np.median([r["ref_fm_err"] for r in results]))}
     print("HELD-OUT %s (%d cases): reference rows reproduced within 1e-3 px: proposals %d/%d = %.4f as a set, %d = %.4f at the same row index "
@@ -111,15 +152,10 @@ def test_holdout_sweep(arch, slot):
     for r in results:
         assert r["n_proposals"] == r["prop_rows"], r
         assert r["prop_vs_truth"]["n_far"] == 0, r
-    # (1) the arithmetic criterion: ours-vs-truth <= K_TRUTH x reference-vs-truth, pooled
-    p, rp, d, rd = s["prop_vs_truth"], s["ref_prop_vs_truth"], s["det_vs_truth"], s["ref_det_vs_truth"]
-    assert p["median"] <= K_TRUTH * rp["median"] and p["p95"] <= K_TRUTH * rp["p95"], (p, rp)
-    assert d["median"] <= K_TRUTH * rd["median"] and d["p95"] <= K_TRUTH * rd["p95"], (d, rd)
-    # (2) north_star's bar against the reference, as a pooled fraction
-    fp, fpi, fd = ROW_FRACTION_FLOOR[arch]      # (both VGG-16 tables answer to the same floors)
-    assert s["prop_set_fraction"] >= fp, s["prop_set_fraction"]
-    assert s["prop_row_fraction"] >= fpi, s["prop_row_fraction"]
-    assert s["det_set_fraction"] >= fd, s["det_set_fraction"]
+    # (1) the arithmetic criterion (ours-vs-truth <= K_TRUTH x reference-vs-truth, pooled), (2) north_star's bar against the reference as
+    # pooled fractions, (3) the committed counts of the last measured run
+    bad = violations(arch, s) + snapshot_violations(arch if slot == 0 else "%s_inflight" % arch, s)
+    assert not bad, bad
 
 
 def test_resnet101_with_the_f32x3_backbone_meets_the_truth_criterion():
@@ -128,8 +164,37 @@ def test_resnet101_with_the_f32x3_backbone_meets_the_truth_criterion():
     same floor as the default table's)."""
     results = sweep("ResNet101", 0, {"bottleneck_g3": "backbone"})
     s = report("ResNet101_g3", results)
-    p, rp, d, rd = s["prop_vs_truth"], s["ref_prop_vs_truth"], s["det_vs_truth"], s["ref_det_vs_truth"]
-    assert p["median"] <= K_TRUTH * rp["median"] and p["p95"] <= K_TRUTH * rp["p95"], (p, rp)
-    assert d["median"] <= K_TRUTH * rd["median"] and d["p95"] <= K_TRUTH * rd["p95"], (d, rd)
-    fp, fpi, fd = ROW_FRACTION_FLOOR["ResNet101"]
-    assert s["prop_set_fraction"] >= fp and s["prop_row_fraction"] >= fpi and s["det_set_fraction"] >= fd, s
+    bad = violations("ResNet101_g3", s) + snapshot_violations("ResNet101_g3", s)
+    assert not bad, bad
+
+
+# one layer's filter rounded to bf16 (8 significant bits instead of the 22 of the f32x3 split): the regression the gates exist for
+DOWNGRADED_LAYER = {"VGG16": "_stage1_feature_extractor._block3_conv2.weight",
+                    "ResNet50": "_stage1_feature_extractor._feature_extractor.5.1.conv2.weight",
+                    "ResNet101": "_stage1_feature_extractor._feature_extractor.6.11.conv2.weight"}
+
+
+@pytest.mark.parametrize("arch", ["VGG16", "ResNet50", "ResNet101"])
+def test_the_gates_catch_one_layer_in_bf16(arch):
+    """VERDICT r4 'do this' 3: a deliberate one-layer downgrade to bf16 operands must fail at least one gate per architecture -- otherwise
+    the gates above measure nothing.  The FIXTURES stay those of the float32 weights; the HIP path runs with ONE convolution's filter
+    rounded to bf16 (every other layer, and the arithmetic of that layer, untouched)."""
+    import torch
+    files = H.cases(arch)[:4]
+    results, models = [], {}
+    for f in files:
+        g = np.load(f)
+        ws = int(g["weights_seed"])
+        if ws not in models:
+            models.clear()
+            m = H.build_model(arch, ws)
+            sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+            key = DOWNGRADED_LAYER[arch]
+            sd[key] = sd[key].to(torch.bfloat16).to(torch.float32)
+            m.load_state_dict(sd, strict=True)
+            models[ws] = m.cuda().eval()
+        results.append(H.measure(models[ws], g, 0))
+    s = report("%s_one_layer_bf16" % arch, results)
+    bad = violations(arch, s)
+    print("gates missed with %s in bf16: %s" % (DOWNGRADED_LAYER[arch], bad))
+    assert bad, "no gate noticed a bf16 layer: %s" % s

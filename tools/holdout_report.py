@@ -57,9 +57,12 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--max-cases", type=int, default=0)
     ap.add_argument("--slot", type=int, default=0, help="0 = forward / predict; 1 = an in-flight slot of predict_async (VGG-16: its one-launch table)")
+    ap.add_argument("--stress", action="store_true", help="the stress set (tests/golden/stress/, oracle/make_stress.py) instead of the held-out set")
+    ap.add_argument("--snapshot", default=None, metavar="KEY", help="merge the pooled counts of the FIRST table into gpurun_out/observed_counts.json under KEY "
+                    "(copy to tests/golden/holdout/observed_counts.json: the committed counts tests/test_holdout_gpu.py holds a run to)")
     args = ap.parse_args()
     tables = VGG_TABLES if args.arch == "VGG16" else RESNET_TABLES
-    files = H.cases(args.arch)
+    files = H.stress_cases(args.arch) if args.stress else H.cases(args.arch)
     if args.max_cases:
         files = files[: args.max_cases]
     report = {}
@@ -68,10 +71,10 @@ def main():
         results = []
         for f in files:
             g = np.load(f)
-            ws = int(g["weights_seed"])
+            ws = (int(g["weights_seed"]), str(g["kind"]) if "kind" in g else None)
             if ws not in models:
                 models.clear()
-                models[ws] = H.build_model(args.arch, ws)
+                models[ws] = H.build_model(args.arch, ws[0], ws[1])
                 apply(models[ws], tables[name])
             r = H.measure(models[ws], g, args.slot)
             results.append(r)
@@ -94,6 +97,17 @@ def main():
         report[name] = {"cases": results, "pooled": {"prop_vs_truth": p, "ref_prop_vs_truth": rp, "det_vs_truth": d, "ref_det_vs_truth": rd,
                                                      "prop_rows": rows, "prop_rows_within_gate": ok, "prop_rows_matched_within_gate": oks, "det_rows": drows,
                                                      "det_rows_within_gate": dok, "det_rows_matched_within_gate": doks}}
+    if args.snapshot:
+        path = os.path.join("gpurun_out", "observed_counts.json")
+        snap = json.load(open(path)) if os.path.exists(path) else {}
+        q = report[args.tables.split(",")[0]]["pooled"]
+        snap[args.snapshot] = {"prop_rows_ok": q["prop_rows_within_gate"], "prop_rows_ok_set": q["prop_rows_matched_within_gate"],
+                               "det_rows_ok": q["det_rows_within_gate"], "det_rows_ok_set": q["det_rows_matched_within_gate"],
+                               "prop_rows": q["prop_rows"], "det_rows": q["det_rows"], "source": "tools/holdout_report.py --arch %s --tables %s --slot %d" % (
+                                   args.arch, args.tables.split(",")[0], args.slot)}
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(snap, f, indent=1)
     if args.out:
         os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
         with open(args.out, "w") as f:
