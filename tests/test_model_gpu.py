@@ -21,6 +21,8 @@ import torch
 from fasterrcnn_amd import synthetic
 from oracle import frcnn_oracle as O
 
+import observed
+
 pytestmark = pytest.mark.gpu
 
 CASES = [("600x1000_s0", True), ("224x320_s3", True), ("333x517_s5_noedge", False)]
@@ -28,12 +30,15 @@ CASES = [("600x1000_s0", True), ("224x320_s3", True), ("333x517_s5_noedge", Fals
 # Gates against the reference's golden vectors (VGG-16).  GATE_PX is north_star's bar.  The other two come from the float64-truth
 # measurement of the held-out sweep (tests/test_holdout_gpu.py), not from these three images:
 #   ROW_BOUND_PX: a row of ours and the same row of the reference are two float32 evaluations of ONE anchor's box; over the held-out set
-#       the reference's worst row sits 0.67e-3 px from the float64 truth and ours 0.90e-3 px, so 2e-3 px bounds their difference.  A row that
-#       is NOT the reference's row (wrong anchor, wrong order) is off by pixels, not by 1e-3.
-#   ROW_FRACTION_FLOOR: the fraction of rows inside 1e-3 px that two such runs reach (held-out: 0.9994 pooled, 0.9967 for the worst image).
+#       the reference's worst row sits 0.67e-3 px from the float64 truth and ours 0.90e-3 px, so 1.5e-3 px bounds their difference (the
+#       golden images measure 0.85e-3).  A row that is NOT the reference's row (wrong anchor, wrong order) is off by pixels, not by 1e-3.
+#   ROW_FRACTION_FLOOR: the fraction of rows inside 1e-3 px that two such runs reach (held-out: 0.998 pooled over 4800 rows; round 4 gated at
+#       0.99, i.e. accepted 297 / 300): 0.997 -- on these fixtures that is every row of 300 / 194.
+#   ... and, because the kernels are deterministic, the COUNTS of the last measured run are committed (tests/observed.py): a run may not
+#       fall below them at all.
 GATE_PX = 1e-3
-ROW_BOUND_PX = 2e-3
-ROW_FRACTION_FLOOR = 0.99
+ROW_BOUND_PX = 1.5e-3
+ROW_FRACTION_FLOOR = 0.997
 
 
 def load_case(golden_dir, tag):
@@ -172,6 +177,7 @@ def test_forward_matches_reference_golden(gpu_model, model_edge_off, golden_dir,
     # north_star's 1e-3 px is held to the floor the held-out sweep derives from the reference's own distance from the float64 truth
     assert err.max() <= ROW_BOUND_PX
     assert ok.mean() >= ROW_FRACTION_FLOOR
+    observed.check("vgg16_%s/forward" % tag, {"rows_within_1e-3": int(ok.sum())})
     j = np.arange(len(ok))
     # on those rows the detector outputs agree
     c_err = np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max()
@@ -217,6 +223,7 @@ def test_predict_matches_reference_golden(gpu_model, model_edge_off, golden_dir,
     # at the held-out sweep's floor
     assert n_ours == n_ref and worst <= ROW_BOUND_PX
     assert n_ok >= ROW_FRACTION_FLOOR * n_ref
+    observed.check("vgg16_%s/predict" % tag, {"rows_within_1e-3": n_ok})
 
 
 def test_predict_on_oracle_forward_outputs_is_exact(golden_dir, oracle_runs):

@@ -14,6 +14,8 @@ from fasterrcnn_amd import _native as nv
 from fasterrcnn_amd import synthetic
 from oracle import frcnn_oracle as O
 
+import observed
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -201,13 +203,15 @@ def test_resnet101_end_to_end(golden_dir):
     g = np.load(os.path.join(golden_dir, "resnet101_224x320_s3.npz"))
     img = synthetic.image_rgb(3, 224, 320).unsqueeze(0)
     props, classes, deltas = model(image_data=img.cuda())
-    # fewer than 300 survive NMS here (149 in the reference).  Gates = the observed numbers: the same count, 147 of the 149 rows
-    # (one borderline NMS decision swaps a pair), the same number of detections
+    # fewer than 300 survive NMS here (149 in the reference): the same count; the fraction of its rows within 1e-3 px at the ResNet-101
+    # floor of the held-out sweep (R101_ROW_FRACTION_FLOOR below: 0.94 x 149 = 141), and not below the committed count of the last
+    # measured run (tests/observed.py; round 4: 147 -- one borderline NMS decision swaps a pair); the same number of detections
     assert g["proposals"].shape[0] == 149 and props.shape[0] == 149
     j, err = match_rows(props.cpu().numpy(), g["proposals"])
     ok = err <= 1e-3
     out = model.predict(image_data=img.cuda(), score_threshold=0.05)
-    assert int(ok.sum()) >= 147
+    assert int(ok.sum()) >= R101_ROW_FRACTION_FLOOR * 149
+    observed.check("resnet101_224x320_s3/forward", {"rows_within_1e-3": int(ok.sum())})
     assert np.abs(classes.cpu().numpy()[j[ok]] - g["classes"][ok]).max() <= 2e-4
     assert sum(len(v) for v in out.values()) == len(g["detections"])
 
@@ -247,6 +251,8 @@ def test_resnet101_600x1000_end_to_end(golden_dir):
     assert rowerr.max() <= R101_ROW_BOUND_PX
     assert (rowerr <= 1e-3).mean() >= R101_ROW_FRACTION_FLOOR and int(ok.sum()) >= R101_ROW_FRACTION_FLOOR * 300
     assert n_ok >= R101_DET_FRACTION_FLOOR * len(ref) and abs(n_ours - len(ref)) <= (1.0 - R101_DET_FRACTION_FLOOR) * len(ref)
+    observed.check("resnet101_600x1000_s2", {"rows_within_1e-3_at_index": int((rowerr <= 1e-3).sum()), "rows_within_1e-3": int(ok.sum()),
+                                             "detections_within_1e-3": n_ok})
 
 
 # ResNet-101 at 600x1000 and north_star's 1e-3 px (VERDICT r3 / ADVICE r3: "fix or classify the miss").  CLASSIFIED by measurement against the
@@ -255,11 +261,12 @@ def test_resnet101_600x1000_end_to_end(golden_dir):
 # (a 101-layer network on boxes up to 1000 px: 1e-3 px is 1e-6 of the side).  The HIP path measures 0.88x / 0.96x of those numbers (closer to
 # the truth than the reference).  Two float32 runs that are each ~6e-4 px (p95) from the truth agree within 1e-3 px on ~94 % of the rows:
 # held-out pooled fraction 0.938 (proposals), 0.93 (detections).  Hence: every row within R101_ROW_BOUND_PX = 3.5e-3 px of the reference's
-# row (reference's worst 1.43e-3 + ours 1.52e-3, rounded up), >= 90 % of the rows inside 1e-3 px; reaching 300 / 300 would mean matching the
-# reference's own rounding errors, not the network.
-R101_ROW_BOUND_PX = 3.5e-3
-R101_ROW_FRACTION_FLOOR = 0.90
-R101_DET_FRACTION_FLOOR = 0.85
+# row (reference's worst 1.43e-3 + ours 1.52e-3 = 2.95e-3, rounded up to 3e-3), >= 94 % of the rows inside 1e-3 px (measured on this fixture:
+# 288 / 300 = 0.96; held-out 0.938 at the row index, 0.973 as a set; round 4 gated at 0.90 / 0.85) -- reaching 300 / 300 would mean
+# matching the reference's own rounding errors, not the network -- and the committed counts of the last measured run (tests/observed.py).
+R101_ROW_BOUND_PX = 3.0e-3
+R101_ROW_FRACTION_FLOOR = 0.94
+R101_DET_FRACTION_FLOOR = 0.90
 
 
 def test_resnet152_end_to_end(golden_dir):
@@ -498,6 +505,7 @@ def test_resnet50_batched_forward(r50, golden_dir):
             n_ok += int(((err <= 1e-3) & (np.abs(dets[1][c][j, 4] - r[:, 4]) <= 2e-4)).sum())
     print("batched forward, golden image: %d/300 proposals, %d/%d detections" % (n_props, n_ok, len(ref)))
     assert n_props >= R50_BATCH_PROPOSALS and n_ok >= R50_BATCH_DETECTIONS
+    observed.check("resnet50_batch8", {"proposals_within_1e-3": n_props, "detections_within_1e-3": n_ok})
     again = model.forward_batch(batch)
     for a, b in zip(outs, again):
         for u, v in zip(a, b):
@@ -508,8 +516,8 @@ def test_resnet50_batched_forward(r50, golden_dir):
         model.forward_batch(batch[0])                         # (3, H, W) is not a batch
 
 
-R50_BATCH_PROPOSALS = 297       # the held-out floor (0.99 x 300); measured 299 (deterministic): the batch changes the split-K factors of the under-filled GEMMs; one box of the
-R50_BATCH_DETECTIONS = 229      # 0.99 x 232; measured 232.  The golden image then lands just outside 1e-3 px; batch-1 forwards keep 300 / 300 and 232 / 232
+R50_BATCH_PROPOSALS = 299       # the held-out floor (0.997 x 300); measured 299 (deterministic): the batch changes the split-K factors of the under-filled GEMMs; one box of the
+R50_BATCH_DETECTIONS = 231      # 0.997 x 232; measured 232.  The golden image then lands just outside 1e-3 px; batch-1 forwards keep 300 / 300 and 232 / 232
 
 
 def test_evaluate_stream_batched_matches_per_image(r50):
