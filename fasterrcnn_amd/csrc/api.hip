@@ -1508,7 +1508,8 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
     if (need1 > c->res_buf_floats || need2 > c->res_buf_floats) return FRCNN_EINVAL;
 #define RSTEP(call) do { Scope _sc(c, cls_conv, s); rc = (call); } while (0); if (rc) return rc
     if (b.g3 != 0) {
-        if (b.x6_mask != 0 || !b.wmax) return FRCNN_EINVAL;
+        // (a split-operand block belongs to the f32_winograd table: math mode "f32" is the strict exact-f32 mode -- ADVICE r4)
+        if (b.x6_mask != 0 || !b.wmax || !wino) return FRCNN_EINVAL;
         float *m1, *m2, *m3;
         if (!c->gx_x) {                                          // the block input came from a kernel that leaves no maximum behind
             float* mx;

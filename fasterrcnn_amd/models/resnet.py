@@ -430,6 +430,11 @@ class FeatureExtractor(nn.Module):
         self.x3 = False              # ... in the f32x3 arithmetic instead
         self.g3 = False              # every bottleneck convolution in the f32x3 arithmetic under one scale per tensor (pack_block_g3)
 
+    def _g3_active(self):
+        """the f32x3-under-a-tensor-scale arithmetic belongs to the `f32_winograd` table like every split-operand layer (x6_conv1x1 / x3):
+        `math_mode = "f32"` is the STRICT mode -- every convolution on the exact-f32 pipe"""
+        return bool(self.g3) and self.math_mode == "f32_winograd"
+
     def blocks(self):
         fe = self._feature_extractor
         return [b for layer in (fe[4], fe[5], fe[6]) for b in layer]
@@ -442,7 +447,7 @@ class FeatureExtractor(nn.Module):
         if key != self._packed_key:
             sw, sb, keep = fold_conv_bn(fe[0], fe[1])
             self._packed = {"stem": (sw, sb), "keep": keep,
-                            "blocks": [pack_block(b, self.math_mode, single_map=True, x6=self.x6_conv1x1, x3=self.x3, g3=self.g3) for b in self.blocks()],
+                            "blocks": [pack_block(b, self.math_mode, single_map=True, x6=self.x6_conv1x1, x3=self.x3, g3=self._g3_active()) for b in self.blocks()],
                             "n_blocks": [len(fe[4]), len(fe[5]), len(fe[6])]}
             self._packed_key = key
         return self._packed
@@ -483,11 +488,16 @@ class PoolToFeatureVector(nn.Module):
         self.x3 = False              # ... in the f32x3 arithmetic instead
         self.g3 = False              # pack_block_g3
 
+    def _g3_active(self):
+        """the f32x3-under-a-tensor-scale arithmetic belongs to the `f32_winograd` table like every split-operand layer (x6_conv1x1 / x3):
+        `math_mode = "f32"` is the STRICT mode -- every convolution on the exact-f32 pipe"""
+        return bool(self.g3) and self.math_mode == "f32_winograd"
+
     def packed(self):
         params = [p for b in self._layer4 for p in block_params(b)]
         key = (self.math_mode, self.x6_conv1x1, self.x3, self.g3) + rt.param_key(params)
         if key != self._packed_key:
-            self._packed = [pack_block(b, self.math_mode, x6=self.x6_conv1x1, x3=self.x3, g3=self.g3) for b in self._layer4]
+            self._packed = [pack_block(b, self.math_mode, x6=self.x6_conv1x1, x3=self.x3, g3=self._g3_active()) for b in self._layer4]
             self._packed_key = key
         return self._packed
 
