@@ -17,6 +17,7 @@ ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
 POOL2 = 2
+X3F_WAVES4, X3F_WAVES8 = 0x100, 0x200     # FRCNN_X3F_WAVES4 / _WAVES8: force a form of the one-launch f32x3 layer (tests, tools)
 NUM_KCLASS = 11
 KCLASS_NAMES = ("conv3x3_mfma", "conv3x3_c3", "linear_mfma", "proposals", "roi_pool", "other", "winograd_transforms",
                 "winograd_gemm", "winograd_x6_transforms", "winograd_x6_gemm", "winograd_x3f")

@@ -13,22 +13,9 @@
 // DESIGN.md section 5): round 3's three variants staged the filter records through LDS by LDS-DMA and were bound by that staging
 // (conv3_2: 208-232 us against the float32 kernel's 174); the kernel below loads them straight into registers (conv3_2: 119 us), then moved
 // the halo to an LDS-DMA ring and the prologue's small loads to DMA (105 us).
-#include "x3t.h"
+#include "wino_x3_shared.h"
 
 namespace frcnn {
-
-typedef _Float16 xf_f16x8 __attribute__((ext_vector_type(8)));
-
-static constexpr int XF_TC = 16;                             // tile columns of a block
-static constexpr int XF_HC = 2 * XF_TC + 2;                  // halo columns: 34 pixels
-static constexpr int XF_PS = 20;                             // floats per halo pixel (16 + 4 padding)
-static constexpr int X3_HR = 10;                             // halo rows: 4 tile rows x 2 + 2
-
-
-// m_*: ceil(2^32 / d) of the three divisors of the block index (0 for d = 1): the quotient is ONE scalar multiply-high on the device instead of
-// a division sequence per divisor between the block's entry and its first load (exact while block index x d < 2^32: checked by the launcher)
-struct XfGeom { int tbx, tby, ncb, tw, th, xg; unsigned m_tbx, m_tby, m_ncb; int ntb; unsigned m_ntb; };   // ntb: tile blocks of all maps
-__device__ __forceinline__ int xd_div(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
 
 // ---- the kernel: 64 tiles per block, the filter fragments straight from L2 into registers ------------------------------------------------------
 // What bounded round 3's versions was the L2 -> LDS staging of the filter records (64 KB per chunk and block by LDS-DMA: ~17 B per clock and CU).
@@ -48,55 +35,6 @@ __device__ __forceinline__ int xd_div(int n, int d, unsigned m) { return d == 1 
 // A PERSISTENT form of the kernel (one block per CU walking its items, the next item's loads issued at the start of the epilogue, the Y
 // buffer next to the ring instead of over it) was built and measured: the loads hide completely (0.02 us of wait) -- and the item costs
 // the same, because prologue and epilogue are bound by instruction issue (~5 cycles each), not by the round trip; not in the tree.
-typedef float xd_f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 xd_f16x2 __attribute__((ext_vector_type(2)));
-
-static constexpr int XD_HP = XF_HC / 2;                                       // 17 pixel slots per (halo row, column parity)
-// halo: X3_HR x XF_HC pixels x XF_PS floats = 6,800 floats = 27,200 B per chunk
-// The halo reaches LDS by DMA (buffer_load_dwordx4 ... lds: lane l of a wave instruction writes 16 B at base + 16 l, no staging registers, no
-// ds_write) into a ring of THREE buffers, two chunks ahead.  A pixel's 80 bytes are five consecutive lanes: four channel quads and one
-// padding lane whose load is out of range (nothing fetched) -- the 80-byte pixel stride is what keeps the patch reads conflict-free.
-static constexpr int XD_NDMA = 7;                                              // DMA instructions per thread and chunk: 7 x 256 x 16 B = 28,672 B
-static constexpr int XD_HBUF_BYTES = XD_NDMA * 256 * 16;                      // >= 27,200: the surplus lanes' zeros land in the buffer's tail
-static constexpr int XD_HBUF_FLOATS = XD_HBUF_BYTES / 4;
-typedef __attribute__((address_space(3))) void* xd_lds_ptr;
-static constexpr int XD_MS = 68;                                              // floats between two tiles of the epilogue's M buffer (64 + 4: conflict-free)
-static constexpr int XD_M_BYTES = 16 * 32 * XD_MS * 4;                       // 139,264: the epilogue's Y buffer [2 halves][4 rows][2][32 tiles][68] (>= the three halo buffers' 86,016)
-static constexpr int XD_SC_OFFSET = XD_M_BYTES;                               // the block's filter scales [16][64] and bias [64] (4,352 B)
-static constexpr int XD_CM_OFFSET = XD_SC_OFFSET + 16 * 64 * 4 + 64 * 4;      // the channel maxima of the block's 10 x 34 halo pixels (DMA: 512 floats)
-static constexpr size_t XD_LDS_BYTES = XD_CM_OFFSET + 512 * 4;                // 145,664
-
-template <int N> struct XdInt { static constexpr int value = N; };
-#ifndef XD_ABLATE
-#define XD_ABLATE 0          // timing experiments (tools/build_ablate.sh): 1 no operand VALU, 2 no patch reads / r, 4 no filter loads, 8 no halo traffic, 16 no MFMAs
-#endif
-
-// maximum over the aligned group of 16 lanes a lane belongs to (a DPP row): four row rotations, no LDS (a __shfl_xor is a ds_bpermute)
-__device__ __forceinline__ float xd_rowmax16(float v)
-{
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)));   // row_ror:8
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)));   // row_ror:4
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)));   // row_ror:2
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)));   // row_ror:1
-    return v;
-}
-
-// a - b on four floats as two v_pk_add_f32 with the negate modifier (the compiler scalarises a float32 vector subtraction into four v_sub_f32:
-// there is no v_pk_sub_f32 and it does not fold the negation into the packed add).  Epilogue only: beside MFMAs packed float32 is the slow form.
-__device__ __forceinline__ f32x4 xd_sub4(f32x4 a, f32x4 b)
-{
-    xd_f32x2 a0 = {a[0], a[1]}, a1 = {a[2], a[3]}, b0 = {b[0], b[1]}, b1 = {b[2], b[3]}, r0, r1;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r0) : "v"(a0), "v"(b0));
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r1) : "v"(a1), "v"(b1));
-    return f32x4{r0[0], r0[1], r1[0], r1[1]};
-}
-
-__device__ __forceinline__ void xd_lds_barrier()
-{
-    // LDS writes of this wave done, then the block barrier; the outstanding GLOBAL loads (next chunk's filter fragments) stay in flight
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 template <bool POOL>
 __global__ __launch_bounds__(256, 1)
 void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__ cmax_maps, const unsigned char* __restrict__ ublob,
@@ -113,42 +51,8 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K16 = Cin >> 4;
 
-    int b = blockIdx.x;
-    // Block -> XCD mapping (hardware block b runs on XCD b % 8, every XCD has its own 4 MB L2).  gm.xg != 0 (the number of tile blocks is a
-    // multiple of 8): the ncb output-channel blocks of one tile block run on the SAME XCD, back to back -- they share the input halo through
-    // that XCD's L2 instead of fetching it ncb times through the fabric (measured: fabric traffic 203 MB per launch against 72 MB algorithmic
-    // with the plain order, and 1-2 % of the launch time).  Otherwise: output-channel block fastest, round-robin over the XCDs.
-    // gm.xg == 2, FILTER-RESIDENT (layers with >= 256 input channels: a cout block's filter records are 1-2 MB, and with the order above
-    // every XCD streams the records of ALL cout blocks at once -- 16 MB against a 4 MB L2 for a 512-channel layer: each block fetched its
-    // 2 MB through the fabric, 640 MB per launch): an XCD OWNS cout blocks -- XCD x works on cout blocks x, x + 8, ... one after the other
-    // over all tile blocks (ncb >= 8), or 8 / ncb XCDs share a cout block and split the tile blocks (ncb = 1, 2, 4) -- so the records of
-    // the cout block in progress stay in that XCD's L2 and leave the fabric once per XCD; the input halo is what crosses it per cout block.
-    int cb;
-    if (gm.xg == 2) {
-        const int xcd = b & 7, s = b >> 3;
-        if (gm.ncb >= 8) {
-            const int k = xd_div(s, gm.ntb, gm.m_ntb);
-            cb = xcd + 8 * k;
-            b = s - k * gm.ntb;
-        } else {
-            const int g = 8 / gm.ncb, sub = xd_div(xcd, gm.ncb, gm.m_ncb);
-            cb = xcd - sub * gm.ncb;
-            b = s * g + sub;
-            if (b >= gm.ntb) return;                                         // (the grid is 8 x ceil(ntb / g) blocks)
-        }
-    } else if (gm.xg) {
-        const int xcd = b & 7, q = b >> 3, qq = xd_div(q, gm.ncb, gm.m_ncb);
-        cb = q - qq * gm.ncb;
-        b = qq * 8 + xcd;
-    } else {
-        const int qq = xd_div(b, gm.ncb, gm.m_ncb);
-        cb = b - qq * gm.ncb;
-        b = qq;
-    }
-    const int b1 = xd_div(b, gm.tbx, gm.m_tbx);
-    const int bx = b - b1 * gm.tbx;
-    const int map = xd_div(b1, gm.tby, gm.m_tby);
-    const int by = b1 - map * gm.tby;                                        // blocks of FOUR tile rows
+    int cb, bx, by, map;
+    if (!xd_block_to_tile(gm, blockIdx.x, cb, bx, by, map)) return;          // (block -> XCD mapping: wino_x3_shared.h)
     const float* __restrict__ const x = x_maps + (size_t)map * H * W * Cin;
     const float* __restrict__ const cmax = cmax_maps + (size_t)map * H * W;
     float* __restrict__ const y = y_maps + (size_t)map * (POOL ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) * Cout;
@@ -562,6 +466,9 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
+// Measured (tools/x3f_bench.py, tools/xd_clocks.py, profiles/r05): the two forms cost the same -- 2790-2870 against 2820-2900 cycles per chunk --
+// so the default stays the four-wave form; FRCNN_X3F_WAVES8 selects the other.
+static constexpr int X3F_EIGHT_WAVES_MIN_CIN = 1 << 30;
 // cmax scratch: n_maps * H * W floats (the channel maxima of the layer input, computed here)
 size_t conv3x3_winograd_x3_fused_workspace_bytes(int N, int H, int W) { return (size_t)N * H * W * sizeof(float); }
 
@@ -602,6 +509,12 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     if ((size_t)16 * (cin / 16) * u_rbt * HX_RB >= ((size_t)1 << 31)) return FRCNN_EUNSUPPORTED;   // the record bank behind one buffer descriptor
     const int relu = (flags & FRCNN_RELU) ? 1 : 0;
     const unsigned char* ub = static_cast<const unsigned char*>(ublob);
+    // Two forms, same results bit for bit: eight waves (two per SIMD: the waves overlap each other's MFMAs and vector work) where the
+    // loop dominates the block -- >= 8 chunks of 16 input channels -- and four waves (one LDS round trip less in the epilogue) for the
+    // 64-channel layers, whose blocks are half prologue and epilogue.  FRCNN_X3F_WAVES4 / _WAVES8 force one (tests, tools).
+    const bool eight = (flags & FRCNN_X3F_WAVES8) ? true : (flags & FRCNN_X3F_WAVES4) ? false : cin >= X3F_EIGHT_WAVES_MIN_CIN;
+    if (eight)
+        return launch_wino_x3e((flags & FRCNN_POOL2) != 0, (unsigned)grid_blocks, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm, cmax_out, s);
     if (flags & FRCNN_POOL2) {
         auto kern = wino_x3d_kernel<true>;
         FRCNN_MAX_LDS_ONCE(kern, XD_LDS_BYTES);

@@ -48,6 +48,11 @@ extern "C" {
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
 #define FRCNN_POOL2  2u   /* fuse MaxPool2d(2, stride 2, floor) into the conv epilogue */
+/* ABI 12, frcnn_conv3x3_nhwc_winograd_x3_fused / _chain only: force one of the two forms of the one-launch f32x3 layer (both bits clear: the
+ * launcher chooses by cin).  The forms give the same results bit for bit (tests/test_gemm_x3t_gpu.py); the bits exist for that test and for
+ * tools/x3f_bench.py / tools/xd_clocks.py. */
+#define FRCNN_X3F_WAVES4 0x100u   /* wino_x3d_kernel: four waves, one per SIMD, 256 accumulator registers (csrc/wino_x3f.hip) */
+#define FRCNN_X3F_WAVES8 0x200u   /* wino_x3e_kernel: eight waves, two per SIMD, 128 accumulator registers (csrc/wino_x3e.hip) */
 
 int         frcnn_abi_version(void);
 const char* frcnn_error_string(int code);

@@ -407,6 +407,68 @@ def test_x3_one_launch_layer_against_the_three_launch_layer_and_float64(n, h, w,
     assert torch.equal(y, first)                                           # run-to-run identical
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,relu,pool", [
+    (1, 9, 11, 32, 64, True, False),          # 2 chunks: chunk 0 and one steady-state chunk, partial tiles
+    (1, 38, 66, 64, 64, True, False),
+    (1, 150, 250, 64, 128, True, False),
+    (1, 75, 125, 256, 256, True, True),       # conv3_3 at half size, fused pool
+    (2, 21, 35, 128, 192, False, False),      # two maps, three cout blocks, no ReLU
+    (1, 37, 62, 512, 512, True, False),       # 32 chunks, 8 cout blocks, filter-resident order
+    (1, 38, 62, 256, 512, True, True),
+    (1, 21, 35, 256, 128, True, False),       # surplus blocks leave
+    (1, 44, 70, 256, 64, True, True),
+    (1, 16, 32, 32, 64, True, False),         # exactly one full tile block
+])
+def test_x3_one_launch_eight_wave_form_is_the_four_wave_form_bit_for_bit(n, h, w, cin, cout, relu, pool):
+    """csrc/wino_x3e.hip (round 5): the one-launch f32x3 layer as EIGHT waves, two per SIMD -- wave (i, jp) owns position row i and the position
+    columns 2 jp, 2 jp + 1 -- against csrc/wino_x3f.hip's four waves: the same operand formation (per value the same float32 operations), the
+    same MFMA order per accumulator and the same summation order in the output transform (the column pass crosses the wave pair through
+    LDS): EQUAL outputs and equal emitted channel maxima, forced through FRCNN_X3F_WAVES4 / _WAVES8 on every shape class."""
+    lib = nv.lib()
+    gen = torch.Generator().manual_seed(7 * h + w + cin + cout)
+    x = (torch.randn((n, h, w, cin), generator=gen) * torch.exp(torch.randn((1, 1, 1, cin), generator=gen))).clamp(min=-0.5).cuda()
+    wt = (torch.randn((cout, cin, 3, 3), generator=gen) * (2.0 / (9 * cin)) ** 0.5).cuda()
+    b = (torch.randn((cout,), generator=gen) * 0.1).cuda()
+    u = pack_x3(wt)
+    oh, ow = (h // 2, w // 2) if pool else (h, w)
+    wsb = int(lib.frcnn_conv3x3_winograd_x3_fused_workspace_bytes(n, h, w))
+    ws = torch.empty((wsb,), dtype=torch.uint8, device="cuda")
+    base = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
+    out = {}
+    for name, force in (("four", nv.X3F_WAVES4), ("eight", nv.X3F_WAVES8)):
+        y = torch.full((n, oh, ow, cout), float("nan"), device="cuda")
+        nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), n, h, w, cin, cout, base | force,
+                                                          nv.ptr(ws), wsb, nv.stream_ptr()), "x3_fused " + name)
+        torch.cuda.synchronize()
+        assert not torch.isnan(y).any(), name
+        out[name] = y
+    assert torch.equal(out["four"], out["eight"]), float((out["four"] - out["eight"]).abs().max())
+    if relu:    # the channel maxima the epilogue leaves for the next layer (frcnn_conv3x3_nhwc_winograd_x3_chain), given the input's own
+        cm_in = torch.empty((n, h, w), device="cuda")
+        nv.check(lib.frcnn_pixel_absmax(nv.ptr(x), nv.ptr(cm_in), n * h * w, cin, nv.stream_ptr()), "absmax")
+        cms = {}
+        for name, force in (("four", nv.X3F_WAVES4), ("eight", nv.X3F_WAVES8)):
+            y = torch.empty((n, oh, ow, cout), device="cuda")
+            cm = torch.zeros((n, oh, ow), device="cuda")
+            nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_chain(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), n, h, w, cin, cout, base | force, 1,
+                                                              nv.ptr(ws), wsb, nv.ptr(cm_in), nv.ptr(cm), nv.stream_ptr()), "x3_chain " + name)
+            torch.cuda.synchronize()
+            assert torch.equal(y, out[name])
+            assert torch.equal(cm, y.amax(dim=3)), name
+            cms[name] = cm
+        assert torch.equal(cms["four"], cms["eight"])
+    # the default choice is one of the two
+    y = torch.empty((n, oh, ow, cout), device="cuda")
+    nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), n, h, w, cin, cout, base, nv.ptr(ws), wsb,
+                                                      nv.stream_ptr()), "x3_fused")
+    assert torch.equal(y, out["four"])
+    # ... and twice the same
+    y2 = torch.empty_like(y)
+    nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y2), n, h, w, cin, cout, base | nv.X3F_WAVES8,
+                                                      nv.ptr(ws), wsb, nv.stream_ptr()), "x3_fused eight")
+    assert torch.equal(y2, out["eight"])
+
+
 @pytest.mark.parametrize("one_launch,h,w,cin,cout,pool", [
     (1, 38, 66, 64, 128, False),       # one-launch layer, two cout blocks
     (1, 75, 125, 128, 256, True),      # fused pool, XCD-grouped block order

@@ -12,7 +12,9 @@ from fasterrcnn_amd import _native as nv  # noqa: E402
 from tools.layer_bench import timeit      # noqa: E402
 
 LAYERS = [("conv1_2", 64, 64, 600, 1000, True), ("conv2_1", 64, 128, 300, 500, False), ("conv2_2", 128, 128, 300, 500, True),
-          ("conv3_1", 128, 256, 150, 250, False), ("conv3_2", 256, 256, 150, 250, False), ("conv3_3", 256, 256, 150, 250, True)]
+          ("conv3_1", 128, 256, 150, 250, False), ("conv3_2", 256, 256, 150, 250, False), ("conv3_3", 256, 256, 150, 250, True),
+          ("conv4_1", 256, 512, 75, 125, False), ("conv4_2", 512, 512, 75, 125, False), ("conv4_3", 512, 512, 75, 125, True),
+          ("conv5_x", 512, 512, 37, 62, False)]
 
 
 def main():
@@ -37,11 +39,18 @@ def main():
         nv.check(lib.frcnn_pack_conv3x3_winograd_x3(nv.ptr(bank), nv.ptr(u), cout, cin, s), "pack_x3")
         wsb = int(lib.frcnn_conv3x3_winograd_x3_fused_workspace_bytes(1, h, w))
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
-        us3 = timeit(lambda: nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
-                                                                              nv.ptr(ws), wsb, s), "x3_fused"), 10, ramp_s=0.3)
+        # the channel maxima computed once outside the timed calls (the forward chains them through the layers: no pass over the input)
+        cm = torch.empty((h, w), device=dev)
+        nv.check(lib.frcnn_pixel_absmax(nv.ptr(x), nv.ptr(cm), h * w, cin, s), "absmax")
+        us = {}
+        for form, force in (("four", nv.X3F_WAVES4), ("eight", nv.X3F_WAVES8)):
+            us[form] = timeit(lambda: nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_chain(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout,
+                                                                                     flags | force, 1, nv.ptr(ws), wsb, nv.ptr(cm), None, s), "x3_chain"), 10, ramp_s=0.3)
         gfl = 2.0 * 16 * ((h + 1) // 2) * ((w + 1) // 2) * cin * cout
-        print("%-8s %4d->%4d %4dx%-4d pool=%d | float32 one-launch %7.1f us (%.2f of 157.3) | f32x3 one-launch (+ channel maxima) %7.1f us "
-              "(%.2f of the fp16 peak, %.2fx)" % (name, cin, cout, h, w, pool, us32, gfl / us32 / 1e6 / 157.3, us3, 3 * gfl / us3 / 1e6 / 2500.0, us32 / us3))
+        print("%-8s %4d->%4d %4dx%-4d pool=%d | float32 one-launch %7.1f us (%.2f of 157.3) | f32x3 one-launch, channel maxima given: four waves %7.1f us "
+              "(%.2f of the fp16 peak), eight waves %7.1f us (%.2f; %.2fx)" % (name, cin, cout, h, w, pool, us32, gfl / us32 / 1e6 / 157.3, us["four"],
+                                                                         3 * gfl / us["four"] / 1e6 / 2500.0, us["eight"], 3 * gfl / us["eight"] / 1e6 / 2500.0,
+                                                                         us["four"] / us["eight"]))
 
 
 if __name__ == "__main__":

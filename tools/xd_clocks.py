@@ -7,7 +7,7 @@ sys.path.insert(0, ".")
 from fasterrcnn_amd import _native as nv
 
 
-def run(name, cin, cout, h, w, pool, reps=20):
+def run(name, cin, cout, h, w, pool, reps=20, force=0):
     dev = t.device("cuda:0")
     lib = nv.lib()
     s = nv.stream_ptr()
@@ -29,7 +29,7 @@ def run(name, cin, cout, h, w, pool, reps=20):
     for rep in range(reps):
         if rep == reps - 1:
             e0.record()
-        nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags, nv.ptr(ws), wsb, s), "x3f")
+        nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags | force, nv.ptr(ws), wsb, s), "x3f")
     e1.record()
     t.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3
@@ -39,16 +39,20 @@ def run(name, cin, cout, h, w, pool, reps=20):
     k16 = k16[0]
     span = ((t_out.max() - t_in.min()) % (1 << 24)) / 100.0
     start = np.sort(((t_in - t_in.min()) % (1 << 24)) / 100.0)
-    print("%-8s %3d->%3d %4dx%-4d blocks %4d | launch (with the channel-maximum pass) %.1f us, first entry -> last exit %.1f us | per block: before the "
+    print("%-8s %s %3d->%3d %4dx%-4d blocks %4d | launch (with the channel-maximum pass) %.1f us, first entry -> last exit %.1f us | per block: before the "
           "loop %.2f us, loop %.2f us = %.3f us / chunk (%.0f cycles / chunk at %.0f MHz; 1536 = the MFMAs alone), after %.2f us | block starts: "
-          "p25 %.1f p50 %.1f p75 %.1f p100 %.1f us" % (name, cin, cout, h, w, nblk, us, span, pro.mean() / 100, loop.mean() / 100, loop.mean() / 100 / k16,
+          "p25 %.1f p50 %.1f p75 %.1f p100 %.1f us" % (name, {0: "auto ", nv.X3F_WAVES4: "four ", nv.X3F_WAVES8: "eight"}[force], cin, cout, h, w, nblk, us, span, pro.mean() / 100, loop.mean() / 100, loop.mean() / 100 / k16,
                                                        cyc.mean() / k16, (cyc / loop).mean() * 100, epi.mean() / 100,
                                                        np.percentile(start, 25), np.percentile(start, 50), np.percentile(start, 75), start.max()))
     print("         before the loop: loads issued after %.2f us, landed + barrier %.2f us later, first operand %.2f us | after: wait for the "
           "other waves %.2f us, column pass + LDS %.2f us, row pass + stores %.2f us" % tuple(o[:, i].mean() / 100 for i in range(8, 14)))
+    return cyc.mean() / k16
 
 
 if __name__ == "__main__":
-    for a in [("conv2_2", 128, 128, 300, 500, True), ("conv3_1", 128, 256, 150, 250, False), ("conv3_2", 256, 256, 150, 250, False),
-              ("conv3_3", 256, 256, 150, 250, True), ("conv4_2", 512, 512, 75, 125, False)]:
-        run(*a)
+    for a in [("conv1_2", 64, 64, 600, 1000, True), ("conv2_2", 128, 128, 300, 500, True), ("conv3_1", 128, 256, 150, 250, False),
+              ("conv3_2", 256, 256, 150, 250, False), ("conv3_3", 256, 256, 150, 250, True), ("conv4_2", 512, 512, 75, 125, False),
+              ("conv5_x", 512, 512, 37, 62, False)]:
+        c4 = run(*a, force=nv.X3F_WAVES4)
+        c8 = run(*a, force=nv.X3F_WAVES8)
+        print("   => cycles per chunk: four waves %.0f, eight waves %.0f per wave pair (1536 = the MFMAs alone)" % (c4, c8))
