@@ -181,20 +181,19 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         }
     };
     auto v_hi = [&](int h, int slot, int e2) {
+        // ONE asm statement per pair of registers: hipcc pads a v_fma_mixhi that follows inline-asm partial writes with an s_nop it cannot
+        // prove unnecessary (an issue slot like any other); the other register's instruction between a register's two halves is the wait state
         unsigned ha, hb;
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(ha) : "v"(tt[0]), "v"(mult[h]));
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hb) : "v"(tt[2]), "v"(mult[h]));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(ha) : "v"(tt[1]), "v"(mult[h]));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hb) : "v"(tt[3]), "v"(mult[h]));
+        asm("v_fma_mixlo_f16 %0, %2, %6, 0\n\tv_fma_mixlo_f16 %1, %4, %6, 0\n\tv_fma_mixhi_f16 %0, %3, %6, 0\n\tv_fma_mixhi_f16 %1, %5, %6, 0"
+            : "=&v"(ha), "=&v"(hb) : "v"(tt[0]), "v"(tt[1]), "v"(tt[2]), "v"(tt[3]), "v"(mult[h]));
         vhi[slot][e2] = ha;
         vhi[slot][e2 + 1] = hb;
     };
     auto v_lo = [&](int h, int slot, int e2) {
         unsigned la, lb;
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(la) : "v"(tt[0]), "v"(mult[h]), "v"(vhi[slot][e2]));
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(tt[2]), "v"(mult[h]), "v"(vhi[slot][e2 + 1]));
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(la) : "v"(tt[1]), "v"(mult[h]), "v"(vhi[slot][e2]));
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(tt[3]), "v"(mult[h]), "v"(vhi[slot][e2 + 1]));
+        asm("v_fma_mixlo_f16 %0, %2, %6, -%7 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixlo_f16 %1, %4, %6, -%8 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %0, %3, %6, -%7 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %1, %5, %6, -%8 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(la), "=&v"(lb) : "v"(tt[0]), "v"(tt[1]), "v"(tt[2]), "v"(tt[3]), "v"(mult[h]), "v"(vhi[slot][e2]), "v"(vhi[slot][e2 + 1]));
         vlo[slot][e2] = la;
         vlo[slot][e2 + 1] = lb;
     };
