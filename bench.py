@@ -968,11 +968,14 @@ def main():
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(launches), "ms_per_image": round(ms / max(args.roofline_images, 1), 4),
                     "note": note}
 
+        # the tables SLOT 0 runs (this pass is one image at a time on slot 0): round 5 moves conv5_x / the RPN trunk to the one-launch form
+        # there too (FasterRCNNModel.alone_winograd_x3f_layers)
+        rx6, rx3, rx3f = (model.layer_tables(0) if not is_resnet else (x6, x3, x3f))
         regime = ("HIP events around every launch, one image at a time on one stream, median image of %d (after the timed region: with "
                   "several images in flight concurrent kernels share the CUs and a launch's wall duration is not its own)" % n_img)
-        dl, wl_named = direct_layers(args.math, x6), winograd_layers(args.math, x6, named=True, x3f=x3f)
+        dl, wl_named = direct_layers(args.math, rx6), winograd_layers(args.math, rx6, named=True, x3f=rx3f)
         wl = [l for _, l in wl_named]
-        xl_named = x6_winograd_layers(args.math, x6, named=True)
+        xl_named = x6_winograd_layers(args.math, rx6, named=True)
         xl = [l for _, l in xl_named]
         r_direct = mfma_roofline("conv3x3_mfma_kernel (direct 3x3 layers: %d per image)" % len(dl), "conv3x3_mfma",
                                  [2.0 * 9 * ci * co * h * w for ci, co, h, w in dl], "FLOP = direct-convolution FLOP of the layers")
@@ -996,14 +999,14 @@ def main():
                 r_wino["chip_full"] = winograd_chip_full_leg(wl_named, dev)
             except Exception as e:
                 r_wino["chip_full"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        # the x6 Winograd layers' batched GEMM on the bf16 pipe: executed FLOP = 6 x (16 x tiles x cin x cout x 2), priced against the
+        # the rx6 Winograd layers' batched GEMM on the bf16 pipe: executed FLOP = 6 x (16 x tiles x cin x cout x 2), priced against the
         # DENSE bf16 peak (the split-K reduction of the small maps is a separate, tiny launch in the same class: it is counted in the
         # class time but not in `launches`' FLOP, so the figure is slightly pessimistic)
         r_x6 = None
         if xl:
             ms6, l6 = timing["winograd_x6_gemm"]
             if l6:
-                per_launch = sum((3.0 if n in x3 else 6.0) * winograd_gemm_flops(*l) for n, l in xl_named) / len(xl)
+                per_launch = sum((3.0 if n in rx3 else 6.0) * winograd_gemm_flops(*l) for n, l in xl_named) / len(xl)
                 f32_eq = sum(winograd_gemm_flops(*l) for l in xl) / len(xl)
                 n_gemm = len(xl) * n_img                               # GEMM launches (the class also holds the split-K reductions)
                 avg_s = (ms6 / 1e3) / n_gemm
@@ -1011,22 +1014,22 @@ def main():
                 t8 = timing["winograd_x6_transforms"]
                 r_x6 = {"kernel": "gemm_x6t_kernel / gemm_x3t_kernel (the 16 position GEMMs of a Winograd layer in one launch; f32x6 = six bf16 MFMAs per "
                                   "product: %s; f32x3 = three fp16 MFMAs per product: %s)"
-                                  % (", ".join(n for n, _ in xl_named if n not in x3) or "-", ", ".join(n for n, _ in xl_named if n in x3) or "-"),
+                                  % (", ".join(n for n, _ in xl_named if n not in rx3) or "-", ", ".join(n for n, _ in xl_named if n in rx3) or "-"),
                         "regime": regime, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": measured_traffic("gemm_x3t_kernel" if x3 else "gemm_x6t_kernel"),
+                        "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": measured_traffic("gemm_x3t_kernel" if rx3 else "gemm_x6t_kernel"),
                         "flops_per_launch": per_launch, "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(n_gemm),
                         "ms_per_image": round(ms6 / max(args.roofline_images, 1), 4),
                         "f32_equivalent_tflops": round(f32_eq / avg_s / 1e12, 2),
                         "transforms_ms_per_image": round(t8[0] / max(args.roofline_images, 1), 4),
-                        "algorithmic_bytes_per_launch": float(sum(16.0 * ((h + 1) // 2) * ((w + 1) // 2) * ((4 if n in x3 else 6) * ci + 4 * co)
-                                                                  + 16.0 * (4 if n in x3 else 6) * ci * co for n, (ci, co, h, w) in xl_named)) / len(xl),
+                        "algorithmic_bytes_per_launch": float(sum(16.0 * ((h + 1) // 2) * ((w + 1) // 2) * ((4 if n in rx3 else 6) * ci + 4 * co)
+                                                                  + 16.0 * (4 if n in rx3 else 6) * ci * co for n, (ci, co, h, w) in xl_named)) / len(xl),
                         "note": "FLOP = 6 bf16 (f32x6) or 3 fp16 (f32x3) MFMA products per float32 product x the Winograd GEMM FLOP (16 x tiles x cin x "
                                 "cout x 2), against the dense bf16 / fp16 peak (the same 2500 TFLOP/s); f32_equivalent_tflops = the same launches counted "
                                 "once per float32 product; bytes = V records (6 / 4 B per element) read + M (4 B) written + the filter record bank"}
         # `roofline` = the kernel with the most GPU time per image, the other one rides along
         # the one-launch f32x3 Winograd layers (wino_x3d_kernel): 3 fp16 MFMAs per float32 product
         r_x3f = None
-        fl_named = x3f_winograd_layers(args.math, x6, x3f)
+        fl_named = x3f_winograd_layers(args.math, rx6, rx3f)
         if fl_named and timing.get("winograd_x3f", (0, 0))[1]:
             msf, lf = timing["winograd_x3f"]
             per_launch = sum(3.0 * winograd_gemm_flops(*l) for _, l in fl_named) / len(fl_named)
@@ -1054,6 +1057,40 @@ def main():
         if len(both) > 3:
             roofline["fourth_kernel"] = both[3]
         roofline["per_class_ms_per_image"] = {k: round(v[0] / max(args.roofline_images, 1), 4) for k, v in timing.items()}
+        # The same measurement for the table the HEADLINE runs (VERDICT r4 "do this" 5): the in-flight slots' arithmetic -- all 13 Winograd
+        # layers in the one-launch f32x3 form -- one image at a time on slot 1's stream, so that a launch's duration is its own.
+        if not is_resnet and nslots > 1 and args.math == "f32_winograd":
+            try:
+                for i in range(2):
+                    model.predict_async(pool[i % len(pool)], 0.05, 1).result()
+                ctx1 = model.context(1)
+                ctx1.timing_enable(True)
+                per1 = []
+                for i in range(max(args.roofline_images, 1)):
+                    model.predict_async(pool[i % len(pool)], 0.05, 1).result()
+                    torch.cuda.synchronize(dev)
+                    per1.append(ctx1.timing_read(reset=True))
+                ctx1.timing_enable(False)
+                n1 = len(per1)
+                med1 = {}
+                for k in per1[0]:
+                    ms = sorted(t_[k][0] for t_ in per1)
+                    med1[k] = (ms[n1 // 2] if n1 % 2 else 0.5 * (ms[n1 // 2 - 1] + ms[n1 // 2]), per1[0][k][1])
+                hx6, hx3, hx3f = model.layer_tables(1)
+                fl1 = x3f_winograd_layers(args.math, hx6, hx3f)
+                msf1, lf1 = med1.get("winograd_x3f", (0.0, 0))
+                if fl1 and lf1:
+                    fl_sum = sum(3.0 * winograd_gemm_flops(*l) for _, l in fl1)
+                    ach1 = fl_sum / (msf1 / 1e3) / 1e12
+                    roofline["headline_table"] = {
+                        "regime": "the arithmetic table of the in-flight slots (what `value` is measured on), one image at a time on slot 1's stream, "
+                                  "HIP events around every launch, median image of %d" % n1,
+                        "kernel": "wino_x3d_kernel: %s" % ", ".join(n_ for n_, _ in fl1), "launches_per_image": int(lf1),
+                        "ms_per_image": round(msf1, 4), "avg_launch_us": round(msf1 * 1e3 / lf1, 2), "executed_gflop_per_image": round(fl_sum / 1e9, 2),
+                        "achieved": round(ach1, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach1 / PEAK_BF16_MFMA_TFLOPS, 4),
+                        "per_class_ms_per_image": {k: round(v[0], 4) for k, v in med1.items()}}
+            except Exception as e:     # a secondary leg must never take the headline line down with it
+                roofline["headline_table"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
         cpu = None
         if not args.no_cpu_baseline and n_gpus == 1 and not is_resnet:

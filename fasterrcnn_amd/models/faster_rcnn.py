@@ -164,8 +164,10 @@ class FasterRCNNModel(nn.Module):
             self.winograd_x3f_layers = nv.DEFAULT_X3F_LAYERS_VGG16
         # ... and the f32x3 layers of the x6 table that take the one-launch form in the in-flight slots only (see _native.py)
         self._inflight_winograd_x3f_layers = ()
+        self._alone_winograd_x3f_layers = ()
         if not self._is_resnet:
             self.inflight_winograd_x3f_layers = nv.DEFAULT_INFLIGHT_X3F_LAYERS_VGG16
+            self.alone_winograd_x3f_layers = nv.DEFAULT_ALONE_X3F_LAYERS_VGG16
 
         # hipGraph replay of one image's ~33 launches (forward + detections + the D2H copies): the second consecutive call of a slot with
         # the same (shape, thresholds, weights, modes) captures them into a graph on the slot's stream, later calls copy the image
@@ -351,14 +353,32 @@ class FasterRCNNModel(nn.Module):
                 raise ValueError("inflight_winograd_x3f_layers: unknown layer %r" % (n,))
         self._inflight_winograd_x3f_layers = names
 
+    @property
+    def alone_winograd_x3f_layers(self):
+        return self._alone_winograd_x3f_layers
+
+    @alone_winograd_x3f_layers.setter
+    def alone_winograd_x3f_layers(self, names):
+        """VGG-16: layers of winograd_x3_layers that run as ONE-launch f32x3 layers in slot 0 too (forward / predict, one image at a time):
+        the layers whose one-launch form wins ALONE on the chip (round 5: conv5_1 .. conv5_3 and the RPN trunk, 47-48 us against ~57 for the
+        three launches; conv4_x stays three-launch there: 107-110 against 86).  Same blobs, operands and accumulation order either way."""
+        names = tuple(names)
+        if names and self._is_resnet:
+            raise NotImplementedError("alone_winograd_x3f_layers applies to the VGG-16 model")
+        for n in names:
+            if n not in nv.X6_LAYER_BITS:
+                raise ValueError("alone_winograd_x3f_layers: unknown layer %r" % (n,))
+        self._alone_winograd_x3f_layers = names
+        self._apply_x3()
+
     def layer_tables(self, slot_index=0):
         """(x6 names, x3 names, one-launch x3 names) in force for a slot: the tables as set, with the in-flight slots' one-launch layers
         moved over (inflight_winograd_x3f_layers)."""
         x6 = tuple(self._winograd_x6_layers) if self._math_mode == "f32_winograd" else ()
         x3 = self._effective_x3_layers() if self._math_mode == "f32_winograd" else ()
         x3f = self._effective_x3f_layers() if (self._math_mode == "f32_winograd" and not self._is_resnet) else ()
-        if slot_index != 0 and not self._is_resnet:
-            moved = tuple(n for n in self._inflight_winograd_x3f_layers if n in x3)
+        if not self._is_resnet:
+            moved = tuple(n for n in (self._inflight_winograd_x3f_layers if slot_index != 0 else self._alone_winograd_x3f_layers) if n in x3)
             x6 = tuple(n for n in x6 if n not in moved)
             x3 = tuple(n for n in x3 if n not in moved)
             x3f = x3f + moved
@@ -379,11 +399,23 @@ class FasterRCNNModel(nn.Module):
         return tuple(n for n in self._winograd_x3_layers if n in self._winograd_x6_layers)
 
     def _apply_x3(self):
-        eff = self._effective_x3_layers() if hasattr(self, "_winograd_x3_layers") else ()
+        """Pushes slot 0's tables (layer_tables(0), whatever the math mode: the stage modules gate on their own) into the stage modules, so
+        that the layer-wise path (model._stage1_feature_extractor(...), ..._region_proposal_network(...)) runs the arithmetic forward() runs."""
+        if not hasattr(self, "_winograd_x3_layers"):
+            return
+        x6n = tuple(self._winograd_x6_layers)
+        eff = self._effective_x3_layers()
+        x3f = self._effective_x3f_layers() if hasattr(self, "_winograd_x3f_layers") else ()
+        moved = tuple(n for n in getattr(self, "_alone_winograd_x3f_layers", ()) if n in eff)      # one-launch in slot 0 too
         if not self._is_resnet:
-            self._stage1_feature_extractor.x3_layers = tuple(n for n in eff if n != "rpn_trunk")
-            self._stage1_feature_extractor.x3f_layers = self._effective_x3f_layers() if hasattr(self, "_winograd_x3f_layers") else ()
-        self._stage2_region_proposal_network.x3_trunk = "rpn_trunk" in eff
+            fe = self._stage1_feature_extractor
+            fe.x6_layers = tuple(n for n in x6n if n != "rpn_trunk" and n not in moved)
+            fe.x3_layers = tuple(n for n in eff if n != "rpn_trunk" and n not in moved)
+            fe.x3f_layers = tuple(n for n in x3f + moved if n != "rpn_trunk")
+        rpn = self._stage2_region_proposal_network
+        rpn.x6_trunk = "rpn_trunk" in x6n and "rpn_trunk" not in moved
+        rpn.x3_trunk = "rpn_trunk" in eff and "rpn_trunk" not in moved
+        rpn.x3f_trunk = "rpn_trunk" in moved
 
     def _x3_mask(self):
         if self._math_mode != "f32_winograd":

@@ -70,16 +70,20 @@ class RegionProposalNetwork(nn.Module):
         self.math_mode = "f32"
         self.x6_trunk = False        # the 3x3 trunk as an x6 Winograd layer (csrc/wino_x6.hip) in the f32_winograd mode
         self.x3_trunk = False        # ... in the f32x3 arithmetic instead (csrc/wino_x3.hip)
+        self.x3f_trunk = False       # ... as the ONE-launch f32x3 layer (csrc/wino_x3f.hip; FasterRCNNModel.alone_winograd_x3f_layers)
 
     def packed(self):
         params = [p for m in (self._rpn_conv1, self._rpn_class, self._rpn_boxes) for p in (m.weight, m.bias)]
         trunk_math = self.math_mode
-        if self.math_mode == "f32_winograd" and self.x6_trunk:
+        one_launch = self.math_mode == "f32_winograd" and self.x3f_trunk
+        if one_launch:
+            trunk_math = "f32_winograd_x3"
+        elif self.math_mode == "f32_winograd" and self.x6_trunk:
             trunk_math = "f32_winograd_x3" if self.x3_trunk else "f32_winograd_x6"
-        key = (trunk_math,) + rt.param_key(params)
+        key = (trunk_math, one_launch) + rt.param_key(params)
         if key != self._packed_key:
             head_w, head_b = pack_stack_rows(self._rpn_class, self._rpn_boxes)
-            self._packed = (pack_conv3x3(self._rpn_conv1, trunk_math), rt.as_f32_cuda(self._rpn_conv1.bias.detach(), "bias"),
+            self._packed = (pack_conv3x3(self._rpn_conv1, trunk_math, one_launch=one_launch), rt.as_f32_cuda(self._rpn_conv1.bias.detach(), "bias"),
                             head_w, head_b)
             self._packed_key = key
         return self._packed
@@ -109,7 +113,7 @@ class RegionProposalNetwork(nn.Module):
         a = fh * fw * 9
         with t.cuda.device(dev):
             s = nv.stream_ptr()
-            trunk = conv3x3(x, wc, bc, c, c, relu=True, pool=False)
+            trunk = conv3x3(x, wc, bc, c, c, relu=True, pool=False, one_launch=self.math_mode == "f32_winograd" and self.x3f_trunk)
             head = t.zeros((fh * fw, 128), dtype=t.float32, device=dev)
             ws_bytes = int(lib.frcnn_linear_workspace_bytes(fh * fw, 45, c))
             ws = t.empty((max(ws_bytes, 4) // 4,), dtype=t.float32, device=dev)

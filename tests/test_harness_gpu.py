@@ -118,7 +118,7 @@ def test_evaluate_stream_map_equals_sequential_reference_loop(gpu_model):
     want = 100.0 * calc.compute_mean_average_precision()
     saved = gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows, gpu_model.inflight_winograd_x3f_layers
     gpu_model.inflight_conv_blocks_target = gpu_model.inflight_winograd_tile_rows = 0
-    gpu_model.inflight_winograd_x3f_layers = ()        # the sequential loop's arithmetic in the in-flight slots: the two mAPs are then EQUAL
+    gpu_model.inflight_winograd_x3f_layers = gpu_model.alone_winograd_x3f_layers        # the sequential loop's (slot 0's) arithmetic in the in-flight slots: the two mAPs are then EQUAL
     try:
         got = E.evaluate(gpu_model, samples, inflight=4)
         got_limited = E.evaluate(gpu_model, samples, num_samples=3, inflight=2)
@@ -268,7 +268,7 @@ def test_host_feeder_equals_upload_then_predict(gpu_model, sd_cpu):
     saved = gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows, gpu_model.inflight_x6_gemm_tiles
     saved_x3f = gpu_model.inflight_winograd_x3f_layers
     gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_tile_rows, gpu_model.inflight_x6_gemm_tiles = 0, 0, 0
-    gpu_model.inflight_winograd_x3f_layers = ()        # (the in-flight slots' one-launch layers differ from slot 0's by float32 rounding order)
+    gpu_model.inflight_winograd_x3f_layers = gpu_model.alone_winograd_x3f_layers        # (slot 0's table: the other one-launch layers of the in-flight slots differ from slot 0's by float32 rounding order)
     try:
         pinned = [f.pin_memory() for f in frames]
         pend = []

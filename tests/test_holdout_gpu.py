@@ -146,7 +146,8 @@ def test_holdout_sweep(arch, slot):
         from fasterrcnn_amd import _native as nv
         m = H.build_model(arch, 1234)
         arch_tables = m.layer_tables(slot)
-        assert set(nv.DEFAULT_INFLIGHT_X3F_LAYERS_VGG16) <= set(arch_tables[2] if slot else arch_tables[1]), arch_tables
+        assert set(nv.DEFAULT_INFLIGHT_X3F_LAYERS_VGG16) <= (set(arch_tables[2]) if slot else set(arch_tables[1]) | set(arch_tables[2])), arch_tables
+        assert set(nv.DEFAULT_ALONE_X3F_LAYERS_VGG16) <= set(arch_tables[2])
         del m
     # every case: the same number of proposals as the reference, every row the decode of a candidate anchor (no gross misses)
     for r in results:

@@ -296,11 +296,22 @@ def test_bench_layer_arithmetic_f32x3_tables():
     m = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
     assert m.winograd_x6_layers == x6 and m.winograd_x3_layers == x3 and m.fc_math_mode == "f32x3" and m.winograd_x3f_layers == x3f
     assert m._x3_mask() & ~m._x6_mask() == 0 and m._x3f_mask() & m._x6_mask() == 0
-    assert m._x3f_mask() == sum(1 << nv.X6_LAYER_BITS[n] for n in x3f) and m._stage1_feature_extractor.x3f_layers == x3f
+    alone = nv.DEFAULT_ALONE_X3F_LAYERS_VGG16
+    fe_alone = tuple(n for n in alone if n != "rpn_trunk")
+    assert m._x3f_mask() == sum(1 << nv.X6_LAYER_BITS[n] for n in x3f) and m._stage1_feature_extractor.x3f_layers == x3f + fe_alone
     # the in-flight slots run the f32x3 layers of the x6 table in the one-launch form too; slot 0 (one image at a time) keeps the three launches
-    assert m.inflight_winograd_x3f_layers == nv.DEFAULT_INFLIGHT_X3F_LAYERS_VGG16 == x6
-    assert m.layer_tables(0) == (x6, x3, x3f) and m.layer_tables(1) == ((), (), x3f + x6)
+    # for conv4_x and (round 5) runs conv5_x and the RPN trunk one-launch as well (alone_winograd_x3f_layers)
+    assert m.inflight_winograd_x3f_layers == nv.DEFAULT_INFLIGHT_X3F_LAYERS_VGG16 == x6 and m.alone_winograd_x3f_layers == alone
+    x6_0 = tuple(n for n in x6 if n not in alone)
+    assert m.layer_tables(0) == (x6_0, x6_0, x3f + alone) and m.layer_tables(1) == ((), (), x3f + x6)
+    bits = lambda names: sum(1 << nv.X6_LAYER_BITS[n] for n in names)
+    assert m._slot_masks(0) == (bits(x6_0), bits(x6_0), bits(x3f + alone))
+    rpn = m._stage2_region_proposal_network
+    assert rpn.x3f_trunk and not rpn.x3_trunk and not rpn.x6_trunk and m._stage1_feature_extractor.x3_layers == x6_0
+    m.alone_winograd_x3f_layers = ()
+    assert m.layer_tables(0) == (x6, x3, x3f) and rpn.x3_trunk and not rpn.x3f_trunk and m._stage1_feature_extractor.x3f_layers == x3f
     assert m._slot_masks(0) == (m._x6_mask(), m._x3_mask(), m._x3f_mask())
+    m.alone_winograd_x3f_layers = alone
     m6, m3, mf = m._slot_masks(3)
     assert m6 == 0 and m3 == 0 and mf == m._x3f_mask() | m._x6_mask() and mf & (1 << nv.X6_RPN_TRUNK_BIT)
     p0, p1 = m._forward_params(0), m._forward_params(2)

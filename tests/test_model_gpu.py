@@ -300,7 +300,7 @@ def test_anchor_maps_argument_and_async_slots(gpu_model):
     # three images in flight on three slots/streams give the same dicts as the sequential calls -- bit for bit when the
     # in-flight slots use the same split-K granularity and the same form of the 512-channel f32x3 layers as the sequential path ...
     saved = gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_x3f_layers
-    gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_x3f_layers = 0, ()
+    gpu_model.inflight_conv_blocks_target, gpu_model.inflight_winograd_x3f_layers = 0, gpu_model.alone_winograd_x3f_layers   # (slot 0's own one-launch layers)
     pend = [gpu_model.predict_async(im, 0.05, slot=i + 1) for i, im in enumerate(imgs)]
     for i, p in enumerate(pend):
         res = p.result()

@@ -255,10 +255,14 @@ def test_model_layer_table_x6_vs_float32_winograd(gpu_model):
             out[name] = (p, c, d, fm, t)
             # the table is honoured: one bf16- / fp16-pipe GEMM launch (+ at most one split-K reduction) and two timed transform steps per
             # x6 layer (a layer in the f32x3 arithmetic times its channel-maximum pass together with its input transform)
-            n6 = len(layers)
-            nf = len([n for n in gpu_model.winograd_x3f_layers if n not in layers])      # one-launch f32x3 layers (round 4: conv1_2 .. conv3_3)
+            # (round 5: the layers of the table that run one-launch in slot 0 too -- alone_winograd_x3f_layers: conv5_x, the RPN trunk -- count
+            #  as one-launch f32x3 layers)
+            x6t, x3t, x3ft = gpu_model.layer_tables(0)
+            n6, nf = len(x6t), len(x3ft)
+            assert n6 == len([n for n in layers if n not in nv.DEFAULT_ALONE_X3F_LAYERS_VGG16])
+            assert nf == len(nv.DEFAULT_X3F_LAYERS_VGG16) + len([n for n in layers if n in nv.DEFAULT_ALONE_X3F_LAYERS_VGG16])
             assert n6 <= t["winograd_x6_gemm"][1] <= 2 * n6 and t["winograd_x6_transforms"][1] == 2 * n6
-            assert t["winograd_x3f"][1] == nf == len(nv.DEFAULT_X3F_LAYERS_VGG16) == 6
+            assert t["winograd_x3f"][1] == nf
             assert t["winograd_gemm"][1] == 13 - n6 - nf
     finally:
         gpu_model.winograd_x6_layers = nv.DEFAULT_X6_LAYERS_VGG16
