@@ -1208,10 +1208,23 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     if (wino && ((p->winograd_x3f_mask | (p->winograd_x3_mask & p->winograd_x6_mask)) & 0x1FFE) != 0) {
         int r0 = ensure_x3f_cmax(c, (size_t)H * W * sizeof(float), s);
         if (r0) return r0;
-        // (with conv1_2 in the one-launch table its pooled output's maxima join: H W / 4 more floats)
-        const size_t want = ((p->winograd_x3f_mask >> 1) & 1) ? (size_t)H * W + 8192 : (size_t)H * W / 2 + 4096;
-        cmax_cleared = std::min(want, 2 * c->x3f_cmax_bytes / sizeof(float));
-        FRCNN_HIP_TRY(hipMemsetAsync(x3f_cmax_buffer(c, 1), 0, cmax_cleared * sizeof(float), s));
+        // The arena's size follows from the masks and (H, W) -- every emitting layer's output map, rounded up to 64 floats -- and is
+        // validated HERE, before anything is launched (the budget used to be two constants fitted to the default tables, with a
+        // per-layer fill and an EINVAL inside the layer loop for everything else).  Layers 1 .. 12 = conv1_2 .. conv5_3 (models/vgg16.py:27-47).
+        static const int co_of[13] = {0, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+        static const bool pool_of[13] = {false, true, false, true, false, false, true, false, false, true, false, false, false};
+        size_t want = 0;
+        int eh = H, ew = W;
+        for (int li = 1; li <= 12; ++li) {
+            const bool f3 = ((p->winograd_x3f_mask >> li) & 1) != 0;
+            const bool t3 = !f3 && ((p->winograd_x6_mask >> li) & 1) && ((p->winograd_x3_mask >> li) & 1);
+            const unsigned efl = FRCNN_RELU | (pool_of[li] ? FRCNN_POOL2 : 0u);
+            if (pool_of[li]) { eh /= 2; ew /= 2; }
+            if ((f3 || t3) && (f3 || winograd_output_emits_cmax(co_of[li], efl))) want += ((size_t)eh * ew + 63) & ~(size_t)63;
+        }
+        if (want > 2 * c->x3f_cmax_bytes / sizeof(float)) return FRCNN_EINVAL;      // (< 0.75 H W floats for any table: cannot happen)
+        cmax_cleared = want;
+        if (want) FRCNN_HIP_TRY(hipMemsetAsync(x3f_cmax_buffer(c, 1), 0, cmax_cleared * sizeof(float), s));
     }
     auto conv3 = [&](const float* xin, const float* wgt, const float* bs, float* yout, int hh, int ww, int ci, int co,
                      unsigned fl) -> int {
@@ -1228,10 +1241,8 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
             const int oh = (fl & FRCNN_POOL2) ? hh / 2 : hh, ow = (fl & FRCNN_POOL2) ? ww / 2 : ww;
             const size_t need = ((size_t)oh * ow + 63) & ~(size_t)63;
             out_cmax = x3f_cmax_buffer(c, 1) + cmax_used;
-            if (cmax_used + need > cmax_cleared)            // (conv1_2 as an emitting layer: outside the arena's budget, cleared on its own)
-                FRCNN_HIP_TRY(hipMemsetAsync(out_cmax, 0, (size_t)oh * ow * sizeof(float), s));
             cmax_used += need;
-            if (cmax_used > 2 * c->x3f_cmax_bytes / sizeof(float)) return FRCNN_EINVAL;
+            if (cmax_used > cmax_cleared) return FRCNN_EINVAL;      // (the plan above and this walk disagree: a bug, not an input)
         }
         int r1;
         if (is_x3f)                                                  // one-launch f32x3 Winograd layer: wgt = the x3 blob (csrc/wino_x3f.hip)

@@ -67,14 +67,10 @@ inline int set_max_dynamic_lds(DeviceOnce& once, const void* kern, size_t bytes)
 static inline bool conv3x3_uses_winograd(int cin, int cout) { return cin >= 128 && cout >= 256 && cin % 16 == 0 && cout % 128 == 0; }
 // ResNet bottlenecks (3x3 width -> width): the stride-1 blocks of layer3 (width 256, one 38 x 63 map) and layer4 (width 512,
 // 300 RoIs x 4 x 4 maps).  Measured: layer4 alone ResNet-50 311 -> 360 / ResNet-101 228 -> 258 img/s, with layer3 364 / 267;
-// the 128-wide blocks of layer2 are below the width where the transforms pay (FRCNN_RESNET_WINO_MIN_WIDTH overrides, experiments)
-static inline int resnet_winograd_min_width()
-{
-    static int v = -1;
-    if (v < 0) { const char* e = frcnn_knob("FRCNN_RESNET_WINO_MIN_WIDTH"); v = e ? atoi(e) : 256; }
-    return v;
-}
-static inline bool resnet_block_uses_winograd(int width, int stride) { return stride == 1 && width >= resnet_winograd_min_width() && width % 128 == 0; }
+// the 128-wide blocks of layer2 are below the width where the transforms pay.  (The experiment knob that moved this bound is gone: the
+// Python packer decides with the same constant -- fasterrcnn_amd/_native.py resnet_block_uses_winograd -- and a library that read the
+// environment would consume packs of the other layout: ADVICE r4.)
+static inline bool resnet_block_uses_winograd(int width, int stride) { return stride == 1 && width >= 256 && width % 128 == 0; }
 
 // Per-kernel-class event timer (see frcnn_ctx_timing_* in the header).
 struct KernelTimer;

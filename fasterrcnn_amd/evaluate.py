@@ -220,6 +220,7 @@ class HostFeeder:
         self.device = model._device()
         self._streams = [t.cuda.Stream(device=self.device) for _ in range(max(1, int(lookahead)))]
         self._staging = [None] * len(self._streams)     # device copy of the frame last uploaded on ring entry k (kept: the copy is asynchronous)
+        self._host = [None] * len(self._streams)        # (pinned source tensor, copy-done event) of ring entry k: the source stays referenced until its copy ran
         self._next = 0
 
     def stage(self, rgb_u8_host):
@@ -237,6 +238,9 @@ class HostFeeder:
                 buf = t.empty(rgb_u8_host.shape, dtype=t.uint8, device=self.device)
                 self._staging[k] = buf
             buf.copy_(rgb_u8_host, non_blocking=True)       # (ring entry k's previous frame was consumed by its own preprocess: same stream)
+            copied = t.cuda.Event()
+            copied.record(feeder)
+            self._host[k] = (rgb_u8_host, copied)           # the asynchronous copy reads the caller's pinned tensor: keep it alive
             image, _, _ = I.preprocess_image(buf, self.model.backbone.image_preprocessing_params, self.min_dimension_pixels, False)
             ev = t.cuda.Event()
             ev.record(feeder)
@@ -245,8 +249,9 @@ class HostFeeder:
     def submit_staged(self, staged, score_threshold, slot):
         """predict_async of a staged frame on in-flight slot `slot` (whose previous handle must have been collected)."""
         image, ev, feeder = staged
-        with t.cuda.device(self.device), t.cuda.stream(feeder):   # predict_async makes the slot's stream wait for the CURRENT stream
-            return self.model.predict_async(image.unsqueeze(0), score_threshold, slot=slot)
+        # the slot's stream waits for THIS frame's event, not for the feeder stream's tail (frames staged later on the same ring entry)
+        with t.cuda.device(self.device):
+            return self.model.predict_async(image.unsqueeze(0), score_threshold, slot=slot, wait_event=ev)
 
     def submit(self, rgb_u8_host, score_threshold, slot):
         """stage + submit_staged back to back.  Returns the Pending handle of predict_async (its result() is the reference's predict() dict)."""

@@ -651,7 +651,7 @@ class FasterRCNNModel(nn.Module):
         lane.keepalive = images
         return out
 
-    def _enqueue(self, image_data, anchor_map, anchor_valid_map, score_threshold, slot_index):
+    def _enqueue(self, image_data, anchor_map, anchor_valid_map, score_threshold, slot_index, wait_event=None):
         assert image_data.shape[0] == 1, "Batch size must be 1"
         self._check_limits(with_detections=score_threshold is not None)
         self.sync_parameters()
@@ -692,6 +692,10 @@ class FasterRCNNModel(nn.Module):
             if slot.stream is not None:
                 # the image (and packed weights) were produced on the caller's stream
                 stream.wait_stream(t.cuda.current_stream(device))
+            if wait_event is not None:
+                # ... or on another stream whose work up to `wait_event` is what this image needs (HostFeeder: the frame's own copy +
+                # preprocess, not whatever was staged on that feeder stream after it)
+                stream.wait_event(wait_event)
             with t.cuda.stream(stream):
                 if gkey is not None and slot.graph_key == gkey and slot.graph is not None:
                     slot.graph_input.copy_(image)
@@ -739,13 +743,14 @@ class FasterRCNNModel(nn.Module):
         return self._enqueue(image_data, anchor_map, anchor_valid_map, score_threshold, 0).result()
 
     @utils.no_grad
-    def predict_async(self, image_data, score_threshold, slot, anchor_map=None, anchor_valid_map=None):
+    def predict_async(self, image_data, score_threshold, slot, anchor_map=None, anchor_valid_map=None, wait_event=None):
         """
         Enqueues `predict` for one image on in-flight slot `slot` (0 = current stream, >0 = the slot's
         own stream) and returns a `Pending`; call `.result()` to obtain the dict.  A slot must be
-        collected before it is reused.
+        collected before it is reused.  `wait_event`: a torch.cuda.Event the slot's stream waits for first (the producer of
+        `image_data` on another stream); the slot keeps a reference to `image_data` until the handle is collected.
         """
-        return self._enqueue(image_data, anchor_map, anchor_valid_map, score_threshold, int(slot))
+        return self._enqueue(image_data, anchor_map, anchor_valid_map, score_threshold, int(slot), wait_event)
 
     def forward_batch(self, image_data, lane=0):
         """`forward` over a batch (B, 3, H, W) of equally sized images (ResNet backbones): list of B (proposals, classes, box deltas)."""

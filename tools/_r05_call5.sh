@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r05e
-timeout 900 python -m pytest -q -m gpu --tb=short "tests/test_harness_gpu.py::test_host_feeder_equals_upload_then_predict" "tests/test_model_gpu.py::test_anchor_maps_argument_and_async_slots" "tests/test_model_gpu.py::test_inflight_slots_are_deterministic_under_load" "tests/test_model_gpu.py::test_hip_graph_replay_equals_eager" "tests/test_winograd_gpu.py::test_winograd_mode_is_deterministic_and_layerwise_equals_fused" "tests/test_holdout_gpu.py::test_holdout_sweep[VGG16-0]" "tests/test_stress_gpu.py::test_stress_sweep[VGG16-0]" 2>&1 | grep -v "^tests/golden\|^VGG16 \|^heavy\|^edges\|^outlier" > gpurun_out/r05e/fail.log; grep -n "Error\|error\|assert\|^E " gpurun_out/r05e/fail.log | cut -c1-330 | head -60
+timeout 900 python -m pytest -q -m gpu --tb=short tests/test_harness_gpu.py tests/test_model_gpu.py tests/test_winograd_gpu.py tests/test_wino_x6_gpu.py "tests/test_holdout_gpu.py::test_holdout_sweep" tests/test_stress_gpu.py tests/test_gemm_x3t_gpu.py 2>&1 | grep -v "^tests/golden\|^VGG16 \|^heavy\|^edges\|^outlier\|^ResNet" > gpurun_out/r05e/fail.log; grep -n "^E \|passed\|failed\|^FAILED" gpurun_out/r05e/fail.log | cut -c1-300 | head -40
