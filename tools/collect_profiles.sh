@@ -3,7 +3,7 @@
 # 1. the default bench line; 2. rocprofv3 kernel trace + stats of a bench run; 3. PMC passes
 # (counters in their own runs, kernel-trace only, as the pool requires).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
