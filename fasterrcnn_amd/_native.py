@@ -170,10 +170,12 @@ DEFAULT_X3F_LAYERS_VGG16 = ("conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2
 # 496).  The same blobs, operands, products and accumulation order in both forms (they differ by the rounding order of the output
 # transform, <= 2e-6 of max|y|); the held-out sweep asserts both tables (tests/test_holdout_gpu.py).
 DEFAULT_INFLIGHT_X3F_LAYERS_VGG16 = ("conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3", "rpn_trunk")
-# ... and the ones that run one-launch in slot 0 too (one image at a time): since round 5 the one-launch form of the 37x62 layers wins alone
-# on the chip (tools/x3f_bench.py: 47-48 us against ~57 for the three launches); the 75x125 layers do not (107-110 against 86: 320 blocks
-# are 1.25 rounds of 256 CUs).  What is left different between slot 0 and the in-flight slots: conv4_1 .. conv4_3.
-DEFAULT_ALONE_X3F_LAYERS_VGG16 = ("conv5_1", "conv5_2", "conv5_3", "rpn_trunk")
+# ... and in slot 0 (forward / predict, one image at a time): since round 5 ALL of them, i.e. ONE table for every slot (VERDICT r4 "do this" 5).
+# Measured on one box, predict() one image at a time (tools/exp_alone_tables.py): none of the seven one-launch in slot 0 526.3 images/sec,
+# the four 37x62 layers 519.7, all seven 522.2 -- within 1.3 % of each other (the layer bench's "86 us for the three launches of conv4_2" is
+# a hot-cache figure: in the pipeline the GEMM + two transforms take 107 us, what the one-launch kernel takes) -- so forward / predict and the
+# throughput configuration run the SAME arithmetic and the three-launch f32x3 convolution leaves the default tables.
+DEFAULT_ALONE_X3F_LAYERS_VGG16 = DEFAULT_INFLIGHT_X3F_LAYERS_VGG16
 
 
 def uses_winograd_x6(cin, cout):

@@ -359,9 +359,10 @@ class FasterRCNNModel(nn.Module):
 
     @alone_winograd_x3f_layers.setter
     def alone_winograd_x3f_layers(self, names):
-        """VGG-16: layers of winograd_x3_layers that run as ONE-launch f32x3 layers in slot 0 too (forward / predict, one image at a time):
-        the layers whose one-launch form wins ALONE on the chip (round 5: conv5_1 .. conv5_3 and the RPN trunk, 47-48 us against ~57 for the
-        three launches; conv4_x stays three-launch there: 107-110 against 86).  Same blobs, operands and accumulation order either way."""
+        """VGG-16: layers of winograd_x3_layers that run as ONE-launch f32x3 layers in slot 0 too (forward / predict, one image at a time).
+        Default since round 5: all seven 512-channel layers -- the same table as the in-flight slots (one arithmetic for every slot; measured
+        within 1.3 % of the three-launch form one image at a time: _native.DEFAULT_ALONE_X3F_LAYERS_VGG16).  Same blobs, operands and
+        accumulation order either way; () restores round 4's slot 0."""
         names = tuple(names)
         if names and self._is_resnet:
             raise NotImplementedError("alone_winograd_x3f_layers applies to the VGG-16 model")

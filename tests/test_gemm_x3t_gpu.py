@@ -512,15 +512,34 @@ def test_x3_layers_chain_their_channel_maxima(one_launch, h, w, cin, cout, pool)
 
 
 def test_inflight_slots_run_the_512_channel_layers_in_the_one_launch_form(gpu_model):
-    """FasterRCNNModel.layer_tables: slot 0 (forward / predict) runs conv4_1 .. conv4_3 as three-launch f32x3 layers (round 5: conv5_x and the
-    RPN trunk one-launch there too -- alone_winograd_x3f_layers), the in-flight slots of predict_async all seven as one-launch layers on the same blobs (13 launches of timing class 10, none of the x6 classes).  The
+    """FasterRCNNModel.layer_tables: the in-flight slots of predict_async run conv4_1 .. conv5_3 and the RPN trunk as one-launch f32x3 layers;
+    slot 0 (forward / predict) does too since round 5 (alone_winograd_x3f_layers: ONE table for every slot) -- this test puts slot 0 back on
+    round 4's three launches to compare the two forms on the same blobs (13 launches of timing class 10, none of the x6 classes).  The
     two forms differ by the rounding order of the output transform only: feature maps within 2e-6 of the largest activation, the same
     proposals as rows -- apart by what two float32 evaluations that are each ~1.2e-4 px from the float64 truth differ by (measured: worst
     row 3.4e-4 px), inside north_star's 1e-3 px of each other."""
     from fasterrcnn_amd import synthetic
     img = synthetic.image(5).unsqueeze(0).cuda()
-    assert set(gpu_model.layer_tables(0)[1]) == set(nv.DEFAULT_X3_LAYERS_VGG16) - set(nv.DEFAULT_ALONE_X3F_LAYERS_VGG16) and gpu_model.layer_tables(2)[1] == ()
+    assert gpu_model.layer_tables(0) == gpu_model.layer_tables(2) and gpu_model.layer_tables(2)[1] == ()          # one table for every slot
     assert set(gpu_model.layer_tables(2)[2]) == set(nv.DEFAULT_X3F_LAYERS_VGG16) | set(nv.DEFAULT_INFLIGHT_X3F_LAYERS_VGG16)
+    saved_alone = gpu_model.alone_winograd_x3f_layers
+    gpu_model.alone_winograd_x3f_layers = ()
+    assert gpu_model.layer_tables(0)[1] == nv.DEFAULT_X3_LAYERS_VGG16
+    try:
+        _compare_three_launch_slot0_with_one_launch_slot2(gpu_model, img)
+    finally:
+        gpu_model.alone_winograd_x3f_layers = saved_alone
+    # with the default tables the feature extractor of every slot computes the same bits (the slots still differ in the split granularity of
+    # the fc GEMMs: inflight_conv_blocks_target)
+    with torch.no_grad():
+        gpu_model._enqueue(img, None, None, None, 0).result()
+        f0 = gpu_model.context(0).tensor(0).clone()
+        gpu_model._enqueue(img, None, None, None, 2).result()
+        f2 = gpu_model.context(2).tensor(0).clone()
+    assert torch.equal(f0, f2)
+
+
+def _compare_three_launch_slot0_with_one_launch_slot2(gpu_model, img):
     with torch.no_grad():
         p0, c0, d0 = gpu_model._enqueue(img, None, None, None, 0).result()
         fm0 = gpu_model.context(0).tensor(0).clone()

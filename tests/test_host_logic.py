@@ -299,19 +299,19 @@ def test_bench_layer_arithmetic_f32x3_tables():
     alone = nv.DEFAULT_ALONE_X3F_LAYERS_VGG16
     fe_alone = tuple(n for n in alone if n != "rpn_trunk")
     assert m._x3f_mask() == sum(1 << nv.X6_LAYER_BITS[n] for n in x3f) and m._stage1_feature_extractor.x3f_layers == x3f + fe_alone
-    # the in-flight slots run the f32x3 layers of the x6 table in the one-launch form too; slot 0 (one image at a time) keeps the three launches
-    # for conv4_x and (round 5) runs conv5_x and the RPN trunk one-launch as well (alone_winograd_x3f_layers)
-    assert m.inflight_winograd_x3f_layers == nv.DEFAULT_INFLIGHT_X3F_LAYERS_VGG16 == x6 and m.alone_winograd_x3f_layers == alone
-    x6_0 = tuple(n for n in x6 if n not in alone)
-    assert m.layer_tables(0) == (x6_0, x6_0, x3f + alone) and m.layer_tables(1) == ((), (), x3f + x6)
+    # ONE table for every slot since round 5: the f32x3 layers of the x6 table run in the one-launch form in the in-flight slots
+    # (inflight_winograd_x3f_layers) AND in slot 0 (alone_winograd_x3f_layers); () for the latter restores round 4's three launches there
+    assert m.inflight_winograd_x3f_layers == nv.DEFAULT_INFLIGHT_X3F_LAYERS_VGG16 == x6 and m.alone_winograd_x3f_layers == alone == x6
+    assert m.layer_tables(0) == ((), (), x3f + x6) == m.layer_tables(1)
     bits = lambda names: sum(1 << nv.X6_LAYER_BITS[n] for n in names)
-    assert m._slot_masks(0) == (bits(x6_0), bits(x6_0), bits(x3f + alone))
+    assert m._slot_masks(0) == (0, 0, bits(x3f + x6)) == m._slot_masks(2)
     rpn = m._stage2_region_proposal_network
-    assert rpn.x3f_trunk and not rpn.x3_trunk and not rpn.x6_trunk and m._stage1_feature_extractor.x3_layers == x6_0
+    assert rpn.x3f_trunk and not rpn.x3_trunk and not rpn.x6_trunk and m._stage1_feature_extractor.x3_layers == ()
+    m.alone_winograd_x3f_layers = ("conv5_1", "rpn_trunk")
+    assert m.layer_tables(0) == (tuple(n for n in x6 if n not in ("conv5_1", "rpn_trunk")),) * 2 + (x3f + ("conv5_1", "rpn_trunk"),)
     m.alone_winograd_x3f_layers = ()
     assert m.layer_tables(0) == (x6, x3, x3f) and rpn.x3_trunk and not rpn.x3f_trunk and m._stage1_feature_extractor.x3f_layers == x3f
     assert m._slot_masks(0) == (m._x6_mask(), m._x3_mask(), m._x3f_mask())
-    m.alone_winograd_x3f_layers = alone
     m6, m3, mf = m._slot_masks(3)
     assert m6 == 0 and m3 == 0 and mf == m._x3f_mask() | m._x6_mask() and mf & (1 << nv.X6_RPN_TRUNK_BIT)
     p0, p1 = m._forward_params(0), m._forward_params(2)
