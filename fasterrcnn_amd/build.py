@@ -6,8 +6,10 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 
 
-def build(verbose=True, jobs=8):
-    cmd = ["make", "-C", CSRC, "-j%d" % jobs]
+def build(verbose=True, jobs=8, clean=False):
+    """clean=True: every object is recompiled from the tracked sources (`make -B`), so the library cannot be a stale one that merely looks
+    current to make; the default is make's incremental build."""
+    cmd = ["make", "-C", CSRC, "-j%d" % jobs] + (["-B"] if clean else [])
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         sys.stdout.write(res.stdout)
