@@ -11,8 +11,8 @@
 //   :216-220  torchvision nms on float64 boxes: stable score-descending order, suppress iff
 //             inter/(area_i+area_j-inter) > 0.3 evaluated in float64
 //   :221-224  rows (y1,x1,y2,x2,score) float64, NMS order
-// Sorting is an LDS bitonic sort of (score bits, ~index) keys; the 512x512 IoU bit matrix lives
-// in LDS; the greedy pass is one wave holding the 8 "removed" words in lanes 0-7.
+// Sorting is a rank sort of the unique (score bits, ~index) keys; the 512x512 IoU bit matrix lives in LDS (a lane per row, a wave per
+// (64 rows, 64 columns) unit); the greedy pass is one wave holding the 8 "removed" words in lanes 0-7.
 #include "common.h"
 
 namespace frcnn {
@@ -33,7 +33,7 @@ void detections_kernel(const float* __restrict__ props, const float* __restrict_
                        int max_rois, int ncls, double clip_h, double clip_w, float score_thr,
                        double nms_thr, double* __restrict__ out, int32_t* __restrict__ out_cnt)
 {
-    __shared__ u64 keys[DET_MAX];
+    __shared__ u64 keys[DET_MAX];            // (score bits, ~proposal index) of the candidates (0 = below the threshold); after the sort: ranks 0 .. m - 1
     __shared__ double sbox[DET_MAX][4];      // boxes in sorted order
     __shared__ f32x4 fbox[DET_MAX];          // the same boxes rounded to float32: the IoU pre-filter of the bit matrix
     __shared__ unsigned char zero_area[DET_MAX];   // the float64 box has exactly zero height or width (clipped onto an image edge)
@@ -66,18 +66,35 @@ void detections_kernel(const float* __restrict__ props, const float* __restrict_
 #ifdef DET_CLOCKS
     tk[1] = __builtin_readcyclecounter();
 #endif
-    // bitonic sort, descending, 512 keys / 512 threads (256 compare-exchanges per pass)
-    for (int k = 2; k <= DET_MAX; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (t < DET_MAX / 2) {
-                const int i = 2 * t - (t & (j - 1));
-                const int l = i + j;
-                const bool desc = (i & k) == 0;
-                const u64 a = keys[i], b = keys[l];
-                if ((a < b) == desc) { keys[i] = b; keys[l] = a; }
+    // Rank sort, descending (round 5; the LDS bitonic sort it replaces was 45 passes with a 1024-thread barrier each): the keys are unique
+    // (the proposal index rides in the low word), so the rank of a key is the number of larger keys.  Threads t and t + 512 count over one
+    // half of the keys each (every lane of a wave reads the same key: an LDS broadcast), the halves meet in an LDS counter.
+    {
+        const int nk = n < DET_MAX ? n : DET_MAX;
+        const int half = (nk + 1) >> 1;
+        const int kt = t & (DET_MAX - 1);
+        const u64 mine = keys[kt];
+        int* const rank_of = keep_list;                                     // (the greedy pass's list: not in use yet)
+        if (t < DET_MAX) rank_of[t] = 0;
+        __syncthreads();
+        if (mine != 0ull) {
+            // eight keys per trip (four 16-byte broadcast reads issued together: an un-unrolled loop paid the LDS latency per key);
+            // slots past nk hold 0 and count nothing, so the ranges are rounded to whole trips
+            const int h8 = (half + 7) & ~7, n8 = (nk + 7) & ~7;
+            const int j0 = t < DET_MAX ? 0 : h8, j1 = t < DET_MAX ? h8 : n8;
+            int cnt = 0;
+            for (int j = j0; j < j1; j += 8) {
+                u64 k[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) k[q] = keys[j + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cnt += k[q] > mine ? 1 : 0;
             }
-            __syncthreads();
+            atomicAdd(&rank_of[kt], cnt);
         }
+        __syncthreads();                                                    // every read of keys[] is done: the sorted keys go in place
+        if (t < DET_MAX && mine != 0ull) keys[rank_of[t]] = mine;
+        __syncthreads();
     }
 
 #ifdef DET_CLOCKS
@@ -112,72 +129,59 @@ void detections_kernel(const float* __restrict__ props, const float* __restrict_
 #ifdef DET_CLOCKS
     tk[3] = __builtin_readcyclecounter();
 #endif
-    // IoU bit matrix (row i, columns > i).  One work item = (row, 64-column word) on or above the diagonal, dealt round-robin to the 8
-    // WAVES; lane l of the wave decides column 64 wq + l and a ballot assembles the word (round 2: one thread per ROW walked all its
-    // columns in float64 at ~450 cycles per pair -- 131k cycles for a 289-candidate class, the kernel's longest phase by far).
+    // IoU bit matrix (row i, columns > i).  One work unit = (group g of 64 rows, 64-column word wq >= g), dealt round-robin to the 16 waves;
+    // LANE l OWNS ROW 64 g + l and walks the word's 64 columns (every lane reads the same column box: an LDS broadcast), collecting its
+    // row's bits in a register -- no ballot, no per-item index arithmetic (round 3's form dealt (row, word) items to the waves with lane =
+    // column and a ballot per item: ~930 items of ~500 instructions per four for a 289-candidate class, 50 of the kernel's 76 us; round 2's
+    // lane-per-row form walked the columns in float64 at ~450 cycles per pair).
     // Each pair is first decided in float32 with a margin that covers the rounding of the boxes and of the float32 arithmetic
     // (coordinates <= a few thousand pixels: 1e-3 px per box side is > 8 ulp); only lanes inside that band -- a handful of pairs per
-    // image -- evaluate the reference's float64 expression inter / (area_i + area_j - inter) > thr.  Same bits as before.
-    // Four items per trip with every LDS operand of the four loaded up front and no short-circuit evaluation: the first version of
-    // this loop spent ~700 cycles per item in four DEPENDENT LDS round trips (flag -> branch -> boxes -> flag).
+    // image -- evaluate the reference's float64 expression inter / (area_i + area_j - inter) > thr.  Same decisions, same bits.
     {
         const int nw = (m + 63) >> 6;
         const float thr_f = (float)nms_thr;
         const int nwaves = blockDim.x >> 6;
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-        // rows 64 g .. 64 g + 63 need the words g .. nw - 1: items are numbered row-major over those (row, word) pairs only; the words left
-        // of a row's diagonal word are zero by construction of the greedy pass (it never reads them: a kept row only removes LATER boxes)
-        auto decode_item = [&](int item, int& i, int& wq) {
-            // closed form: rows of group g start at item S(g) = 64 * (g * nw - g * (g - 1) / 2)
-            int g = 0, start = 0;
-            while (g + 1 < nw && item >= start + 64 * (nw - g)) { start += 64 * (nw - g); ++g; }
-            const int per = nw - g, r = (item - start) / per;
-            i = 64 * g + r; wq = g + (item - start) - r * per;
-        };
-        int total = 0;
-        for (int g = 0; g < nw; ++g) { const int rows = (m - 64 * g) < 64 ? (m - 64 * g) : 64; total += rows * (nw - g); }
-        for (int base = wave; base < total; base += 4 * nwaves) {
-            f32x4 a[4], b[4];
-            unsigned z[4];
-            int ii[4], wqs[4], jc[4];
-            bool valid[4], live[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int item = base + nwaves * q;
-                live[q] = item < total;
-                decode_item(live[q] ? item : 0, ii[q], wqs[q]);
-                const int jj = wqs[q] * 64 + lane;
-                valid[q] = live[q] && jj > ii[q] && jj < m;
-                jc[q] = jj < m ? jj : m - 1;
-                a[q] = fbox[ii[q]]; b[q] = fbox[jc[q]];
-                z[q] = (unsigned)zero_area[ii[q]] | (unsigned)zero_area[jc[q]];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float oy = fminf(a[q][2], b[q][2]) - fmaxf(a[q][0], b[q][0]), ox = fminf(a[q][3], b[q][3]) - fmaxf(a[q][1], b[q][1]);
+        const int units = nw * (nw + 1) / 2;
+        for (int u = wave; u < units; u += nwaves) {
+            int g = 0, start = 0;                                            // unit -> (g, wq): row group g has the words g .. nw - 1
+            while (u >= start + (nw - g)) { start += nw - g; ++g; }
+            const int wq = g + (u - start);
+            const int i = 64 * g + lane;
+            const bool row_ok = i < m;
+            const f32x4 a = fbox[row_ok ? i : 0];
+            const unsigned za = zero_area[row_ok ? i : 0];
+            const float ha = a[2] - a[0], wa = a[3] - a[1];
+            const int jn = (m - 64 * wq) < 64 ? (m - 64 * wq) : 64;
+            u64 bits = 0ull;
+            for (int jj = 0; jj < jn; ++jj) {
+                const int j = 64 * wq + jj;
+                const f32x4 b = fbox[j];
+                const unsigned z = za | (unsigned)zero_area[j];
+                const float oy = fminf(a[2], b[2]) - fmaxf(a[0], b[0]), ox = fminf(a[3], b[3]) - fmaxf(a[1], b[1]);
                 const float inter = fmaxf(oy, 0.f) * fmaxf(ox, 0.f);
-                const float ha = a[q][2] - a[q][0], wa = a[q][3] - a[q][1], hb = b[q][2] - b[q][0], wb = b[q][3] - b[q][1];
+                const float hb = b[2] - b[0], wb = b[3] - b[1];
                 const float lhs = inter - thr_f * (ha * wa + hb * wb - inter);
                 const float margin = 1e-3f * (ha + wa + hb + wb + 1.0f);
                 // exact shortcuts that keep the float64 path rare: a box of exactly zero area intersects nothing (inter == 0 -> IoU 0 or NaN:
                 // never > thr), and boxes the float32 coordinates separate by more than 1e-3 px are separate in float64 too
-                const bool never = (z[q] != 0u) | (oy < -1e-3f) | (ox < -1e-3f);
+                const bool never = (z != 0u) | (oy < -1e-3f) | (ox < -1e-3f);
+                const bool valid = row_ok && j > i;
                 bool sup = (lhs > margin) & !never;
-                if (valid[q] & !never & (lhs <= margin) & (lhs >= -margin)) {
-                    const int i = ii[q], j = jc[q];
+                if (valid & !never & (lhs <= margin) & (lhs >= -margin)) {
                     const double a0 = sbox[i][0], a1 = sbox[i][1], a2 = sbox[i][2], a3 = sbox[i][3];
                     const double b0 = sbox[j][0], b1 = sbox[j][1], b2 = sbox[j][2], b3 = sbox[j][3];
                     const double e0 = fmax(fmin(a2, b2) - fmax(a0, b0), 0.0);
                     const double e1 = fmax(fmin(a3, b3) - fmax(a1, b1), 0.0);
                     const double it = e0 * e1;
-                    const double u = (a2 - a0) * (a3 - a1) + (b2 - b0) * (b3 - b1) - it, rhs = nms_thr * u;
+                    const double un = (a2 - a0) * (a3 - a1) + (b2 - b0) * (b3 - b1) - it, rhs = nms_thr * un;
                     if (it > rhs * (1.0 + 1e-12)) sup = true;                   // the divide only inside a 1e-12 band around the threshold
                     else if (it < rhs * (1.0 - 1e-12)) sup = false;
-                    else sup = it / u > nms_thr;
+                    else sup = it / un > nms_thr;
                 }
-                const u64 bits = __ballot(valid[q] & sup);
-                if (live[q] && lane == 0) mask[ii[q]][wqs[q]] = bits;
+                if (valid & sup) bits |= 1ull << jj;
             }
+            if (row_ok) mask[i][wq] = bits;
         }
     }
     __syncthreads();
@@ -185,21 +189,49 @@ void detections_kernel(const float* __restrict__ props, const float* __restrict_
 #ifdef DET_CLOCKS
     tk[4] = __builtin_readcyclecounter();
 #endif
-    // greedy pass: wave 0, lane w (< 8) owns removed word w
+    // greedy pass: wave 0, lane w (< 8) owns removed word w.  Per 64-row chunk (round 5; the row-by-row loop it replaces spent ~120 cycles on
+    // every one of the m rows in a readlane -> scalar test -> branch chain): the chunk's removed word is read ONCE, lane l fetches the diagonal
+    // word of row 64 c + l, the chunk is resolved on a wave-uniform 64-bit "alive" word (s_ff1 + v_readlane per KEPT row), then the kept
+    // rows are OR-ed into the later words four rows at a time.
     if (t < 64) {
         u64 rem = 0ull;
         int kept = 0;
         const int nw = (m + 63) >> 6;
-        for (int p = 0; p < m; ++p) {
-            const int src = __builtin_amdgcn_readfirstlane(p >> 6);
-            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rem & 0xFFFFFFFFull), src);
-            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rem >> 32), src);
-            const u64 word = ((u64)hi << 32) | lo;
-            if (!((word >> (p & 63)) & 1ull)) {
-                if (t == 0) keep_list[kept] = p;
+        for (int c = 0; c < nw; ++c) {
+            const int row = 64 * c + t;
+            const u64 diag = row < m ? mask[row][c] : 0ull;
+            const int src = __builtin_amdgcn_readfirstlane(c);
+            const unsigned clo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rem & 0xFFFFFFFFull), src);
+            const unsigned chi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rem >> 32), src);
+            const int left = m - 64 * c;
+            const u64 validm = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            u64 alive = ~(((u64)chi << 32) | clo) & validm;
+            u64 keepbits = 0ull;
+            while (alive != 0ull) {
+                const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)alive) - 1);
+                keepbits |= 1ull << b;
+                if (t == 0) keep_list[kept] = 64 * c + b;
                 ++kept;
-                // words left of the diagonal word of row p are never written (not needed: they could only remove EARLIER boxes)
-                if (t < nw && t >= (p >> 6)) rem |= mask[p][t];
+                const unsigned dlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(diag & 0xFFFFFFFFull), b);
+                const unsigned dhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(diag >> 32), b);
+                alive &= ~(((u64)dhi << 32) | dlo);
+                alive &= ~(1ull << b);
+            }
+            // words left of the diagonal word of a row are never written (not needed: they could only remove EARLIER boxes)
+            const bool mine_w = t < nw && t > c;
+            u64 kb = keepbits;
+            while (kb != 0ull) {
+                u64 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = 0ull;
+                    if (kb != 0ull) {
+                        const int b = __ffsll((long long)kb) - 1;
+                        kb &= kb - 1ull;
+                        if (mine_w) v[q] = mask[64 * c + b][t];
+                    }
+                }
+                rem |= (v[0] | v[1]) | (v[2] | v[3]);
             }
         }
         if (t == 0) counters[1] = kept;
