@@ -13,6 +13,8 @@ timeout 600 python tools/holdout_report.py --arch VGG16 --stress --tables defaul
 grep "^==" $OUT/stress_*.log | cut -c1-400
 timeout 300 python tools/x3f_bench.py > $OUT/x3f_bench.txt 2>&1
 FRCNN_LIB_PATH=build/libfrcnn_xdclk.so timeout 300 python tools/xd_clocks.py > $OUT/xd_clocks.txt 2>&1
+timeout 300 python tools/exp_alone_tables.py > $OUT/alone_tables.txt 2>&1; tail -3 $OUT/alone_tables.txt
+FRCNN_LIB_PATH=build/libfrcnn_detclk.so timeout 200 python tools/exp_det_clocks.py 2>&1 | grep "det cls" | sort -t' ' -k5 -n | tail -3 > $OUT/det_clocks.txt; cat $OUT/det_clocks.txt
 R="python bench.py --backbone resnet50 --no-cpu-baseline --no-secondary --no-extra-legs --map-images 0 --roofline-images 1 --steps 8 --warmup 2 --ramp-seconds 0 --inflight 1 --min-timed-seconds 0"
 timeout 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $OUT/pmc_r50_tcc -o p -- $R > $OUT/pmc_r50_tcc.log 2>&1; echo "pmc tcc exit $?"
 timeout 400 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d $OUT/pmc_r50_tcp -o p -- $R > $OUT/pmc_r50_tcp.log 2>&1; echo "pmc tcp exit $?"
