@@ -17,8 +17,9 @@ Asserted:
 
 (1) per architecture, pooled over its cases: ours-vs-truth <= K_STRESS x reference-vs-truth (proposals and detections, median and p95).
     K_STRESS = 1.5 is the ADMISSION criterion itself: the level of a table with every GEMM on the exact-f32 matrix
-    pipe.  (The held-out sweep's per-table K_TRUTH are regression gates: measured + margin on ITS inputs.)  Measured here (round 5,
-    profiles/r05): VGG-16 1.18 / 1.04 / 1.48 / 1.28 (in flight 1.20 / 1.03 / 1.33 / 1.28), ResNet-50 1.16 / 1.26 / 1.16 / 1.35.
+    pipe on the held-out set.  (The held-out sweep's per-table K_TRUTH are regression gates: measured + margin on ITS inputs.)  Measured
+    here (round 5, profiles/r05/stress_*.json): VGG-16 1.20 / 1.03 / 1.33 / 1.28 (every slot runs one table), ResNet-50 1.16 / 1.26 / 1.16 /
+    1.35; the all-exact-f32 table on the same cases: VGG-16 1.52 / 1.37 / 1.57 / 1.35, ResNet-50 1.12 / 1.27 / 1.21 / 0.91.
 (2) per case, north_star's bar against the reference -- where the reference itself allows it: on these inputs the REFERENCE's float32 run
     sits up to 1.1e-3 px (p95; worst row 2.0e-3) from the float64 truth, so two equally good float32 runs cannot agree to 1e-3 px on every
     row.  A row on which the reference is within HALF the gate of the exact answer is a row an equally good run reproduces within the gate:
