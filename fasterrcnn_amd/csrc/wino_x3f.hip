@@ -213,8 +213,20 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // whose old value died in the previous step (V(., 1) = r1 + r2, V(., 2) = r2 - r1, V(., 3) = r1 - r3, V(., 0) = r0 - r2).
     // A column read in step s is first used by the operand formed in step s + 2, so its two channel halves are read in gaps 1 and 3 of step
     // s and turned into r in gap 6 of step s and gap 2 of step s + 1: five MFMAs (160 cycles) between every ds_read and its use.
+#ifdef XD_STEPS
+    // timing experiment on top of XD_CLOCKS (tools/xd_steps.py): shader cycles per STEP of the chunk, summed over the chunks (the s_memtime
+    // at a step's entry waits for the wave's outstanding LDS reads: ~10 % more cycles than the un-instrumented loop)
+    unsigned long long xd_step_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xd_step_last = 0;
+#endif
     auto step = [&](int ucb, int hso, float* hcur, float* hnxt, auto PAR, auto S, auto FIRST) {     // hso: byte offset of chunk c + 3 in a pixel
         constexpr int par = decltype(PAR)::value, s = decltype(S)::value;
+#ifdef XD_STEPS
+        {
+            const unsigned long long now = __builtin_readcyclecounter();
+            if (xd_step_last != 0) xd_step_acc[(s + 7) & 7] += now - xd_step_last;
+            xd_step_last = now;
+        }
+#endif
         constexpr bool first = decltype(FIRST)::value != 0;
         const f32x16 xd_zero16 = {};
         constexpr int h = s >> 2, j = s & 3, slot = s & 1, nslot = slot ^ 1;
@@ -460,6 +472,9 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         rec[6] = (float)K16; rec[7] = 1.0f;
         rec[8] = (float)(xd_t_issued - xd_t_in); rec[9] = (float)(xd_t_landed - xd_t_issued); rec[10] = (float)(xd_t_loop - xd_t_landed);
         rec[11] = (float)(xd_t_e0 - xd_t_done); rec[12] = (float)(xd_t_e1 - xd_t_e0); rec[13] = (float)(t_out - xd_t_e1);
+#ifdef XD_STEPS
+        for (int q = 0; q < 8; ++q) rec[8 + q] = (float)xd_step_acc[q];
+#endif
     }
 #endif
 }
