@@ -1,7 +1,7 @@
 """tools/soak_inflight.py -- determinism of the in-flight slots under load: the same images through predict_async with 1 .. 8 images in
 flight, many times over; every result of an image must be bit-identical to its first result in an in-flight slot (the one-launch kernel's
 LDS-DMA ring is ordered by s_waitcnt counts and barriers: a race would show up here as a differing bit under some interleaving), and slot 0
-(the three-launch form of the 512-channel layers) must agree with itself.  Development aid."""
+(since round 5 the same table as the in-flight slots) must agree with itself.  Development aid."""
 import sys
 import time
 
