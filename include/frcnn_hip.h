@@ -43,7 +43,8 @@ extern "C" {
                                  frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps); 8: the f32x3 arithmetic (frcnn_*_x3t, frcnn_*_winograd_x3,
                                  frcnn_forward_params.winograd_x3_mask, FRCNN_FC_F32X3T, frcnn_bottleneck_weights.x3_mask); 9: one-launch f32x3 Winograd layers
                                  in the forward (frcnn_forward_params.winograd_x3f_mask, timing class 10), frcnn_roi_pool_x3t; 10: frcnn_conv3x3_c3_cmax, bits 1 (conv1_2)
-                                 and 13 (RPN trunk) of winograd_x3f_mask; 11: frcnn_conv_nhwc_x3g, frcnn_tensor_absmax, frcnn_bottleneck_weights.g3 / .wmax */
+                                 and 13 (RPN trunk) of winograd_x3f_mask; 11: frcnn_conv_nhwc_x3g, frcnn_tensor_absmax, frcnn_bottleneck_weights.g3 / .wmax;
+                                 12: frcnn_x3_saturation_events, FRCNN_X3F_WAVES4 / FRCNN_X3F_WAVES8 */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
