@@ -116,8 +116,6 @@ def layer_arithmetic(math, fc_math, x6=(), n_rois=300, num_classes=21, x3=(), x3
             rows.append((name, "gemm_x6t_kernel (x6 Winograd layer)", "bf16", 6.0 * winograd_gemm_flops(ci, co, h, w), alg))
         elif math == "f32_winograd" and uses_winograd(ci, co):
             rows.append((name, "wino_fused_kernel", "f32", winograd_gemm_flops(ci, co, h, w), alg))
-        elif math == "f32x6":
-            rows.append((name, "conv3x3_x6_kernel", "bf16", 6.0 * alg, alg))
         else:
             rows.append((name, "conv3x3_mfma_kernel", "f32", alg, alg))
     alg = 2.0 * 512 * 45 * 37 * 62
@@ -126,8 +124,8 @@ def layer_arithmetic(math, fc_math, x6=(), n_rois=300, num_classes=21, x3=(), x3
         alg = n_rois * 2.0 * k * n
         if fc_math == "f32x3":
             rows.append((name, "gemm_x3t_kernel", "f16", 3.0 * alg, alg))
-        elif fc_math in ("f32x6", "f32x6_v1"):
-            rows.append((name, "gemm_x6t_kernel" if fc_math == "f32x6" else "linear_x6_kernel", "bf16", 6.0 * alg, alg))
+        elif fc_math == "f32x6":
+            rows.append((name, "gemm_x6t_kernel", "bf16", 6.0 * alg, alg))
         else:
             rows.append((name, "linear_mfma_kernel", "f32", alg, alg))
     alg = n_rois * 2.0 * 4096 * (5 * num_classes - 4)
@@ -566,10 +564,9 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=12, help="images timed on the host CPU (rank 0, N=1 only): ~12 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-images", type=int, default=10)
-    ap.add_argument("--math", type=str, default=None, choices=["f32", "f32_winograd", "f32x6"],
+    ap.add_argument("--math", type=str, default=None, choices=["f32", "f32_winograd"],
                     help="3x3 conv arithmetic: f32_winograd (default: exact f32 MFMA, every 3x3 layer from conv1_2 on as a one-launch Winograd "
-                         "F(2x2,3x3) layer in float32), f32 (every layer on the direct exact-f32 kernel; the only mode of the ResNets), "
-                         "or f32x6 (exactly split bf16x3 operands, six bf16 MFMAs per product)")
+                         "F(2x2,3x3) layer in float32) or f32 (every layer on the direct exact-f32 kernel)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the informational legs in the other math modes")
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
                     help="untimed pre-roll before the warm-up steps: the GPU takes ~1-2 s of load to leave its idle power state "
@@ -694,7 +691,7 @@ def main():
     # ---- informational: the same workload in the other math modes (not the headline value) -----------
     secondary = {}
     if not is_resnet and not args.no_secondary:
-        for mode in ("f32", "f32_winograd", "f32x6"):
+        for mode in ("f32", "f32_winograd"):
             if mode == args.math:
                 continue
             model.math_mode = mode
@@ -1145,7 +1142,7 @@ def main():
         # the arithmetic, said where `dtype` is read: tensors are float32 everywhere; the split-operand layers are NOT float32
         # operand arithmetic (f32x3 keeps 22-23 bits of an operand relative to its row's / tile's largest element)
         n_x3 = len([n_ for n_ in x6 if n_ in x3]) + len(x3f) + (2 if fc_math == "f32x3" else 0)
-        n_x6 = len([n_ for n_ in x6 if n_ not in x3]) + (2 if fc_math in ("f32x6", "f32x6_v1") else 0)
+        n_x6 = len([n_ for n_ in x6 if n_ not in x3]) + (2 if fc_math == "f32x6" else 0)
         if is_resnet or (n_x3 == 0 and n_x6 == 0):
             dtype_str = "f32" if not is_resnet else "f32 (ResNet: layer4 / RPN trunk GEMMs in the model's default split-operand arithmetic, f32 accumulation)"
         else:

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
-ABI_VERSION = 12    # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
+ABI_VERSION = 13    # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
@@ -34,12 +34,12 @@ SYMBOLS = (
     "frcnn_ctx_timing_read",
     "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv_nhwc_math", "frcnn_conv_nhwc_x3g", "frcnn_x3_saturation_events", "frcnn_tensor_absmax", "frcnn_conv7x7_s2_c3",
     "frcnn_maxpool3x3_s2_nhwc", "frcnn_spatial_mean_nhwc", "frcnn_resnet_forward", "frcnn_rpn_targets",
-    "frcnn_pack_conv3x3_x6", "frcnn_conv3x3_nhwc_x6", "frcnn_preprocess_workspace_bytes", "frcnn_preprocess",
+    "frcnn_preprocess_workspace_bytes", "frcnn_preprocess",
     "frcnn_conv3x3_uses_winograd", "frcnn_resnet_block_uses_winograd", "frcnn_pack_conv3x3_winograd",
     "frcnn_pack_conv3x3_winograd_taps", "frcnn_conv3x3_winograd_workspace_bytes",
     "frcnn_conv3x3_nhwc_winograd",
     "frcnn_conv3x3_uses_winograd_fused", "frcnn_resnet_block_uses_winograd_fused", "frcnn_pack_conv3x3_winograd_fused", "frcnn_pack_conv3x3_winograd_fused_taps",
-    "frcnn_conv3x3_nhwc_winograd_fused", "frcnn_split_rows_x6", "frcnn_linear_x6_workspace_bytes", "frcnn_linear_x6",
+    "frcnn_conv3x3_nhwc_winograd_fused",
     "frcnn_roi_align", "frcnn_roi_align_backward",
     "frcnn_x6t_record_bytes", "frcnn_split_rows_x6t", "frcnn_gemm_x6t_workspace_bytes", "frcnn_gemm_x6t", "frcnn_split_pixels_x6t", "frcnn_split_patches3x3_x6t",
     "frcnn_conv3x3_uses_winograd_x6", "frcnn_conv3x3_winograd_x6_pack_bytes", "frcnn_pack_conv3x3_winograd_x6",
@@ -114,17 +114,15 @@ MAX_POST_NMS_CTX = 512      # frcnn_ctx_create's max_rois bound (forward() witho
 MAX_PRE_NMS = 16384         # frcnn_ctx pre_cap (csrc/api.hip): one-block radix select + sort
 
 MATH_F32 = 0      # exact f32 MFMA
-MATH_F32X6 = 1    # bf16x3 split operands, six bf16 MFMAs per product, f32 accumulate
 MATH_F32_WINOGRAD = 2   # exact f32 MFMA; 3x3 layers with uses_winograd(cin, cout) as Winograd F(2x2,3x3) in float32
-MATH_MODES = {"f32": MATH_F32, "f32x6": MATH_F32X6, "f32_winograd": MATH_F32_WINOGRAD}
+MATH_MODES = {"f32": MATH_F32, "f32_winograd": MATH_F32_WINOGRAD}     # (1 was the direct f32x6 convolution of round 2: removed, ABI 13)
 X6T_ROW_TILE, X6T_COL_TILE = 320, 256     # FRCNN_X6T_ROW_TILE / FRCNN_X6T_COL_TILE: row padding of x6t record arrays (csrc/gemm_x6t.hip)
-LINEAR_X6_ROWS = 320                      # FRCNN_LINEAR_X6_ROWS: row count of an activation record array (csrc/linear_x6.hip's row tile)
 GRAD_MATHS = {"f32": 0, "bf16": 1}         # FRCNN_GRAD_F32 / FRCNN_GRAD_BF16: arithmetic of the train step's gradient GEMMs
 ROI_OPS = {"pool": 0, "align": 1}          # FRCNN_ROI_POOL (the reference) / FRCNN_ROI_ALIGN (torchvision roi_align semantics)
 # arithmetic of the VGG-16 detector's fc1 / fc2: FRCNN_FC_F32 (exact-f32 pipe) / FRCNN_FC_F32X6T ("f32x6": exactly split bf16x3 operands on
-# csrc/gemm_x6t.hip, round 3) / FRCNN_FC_F32X6 ("f32x6_v1": the same arithmetic on round 2's csrc/linear_x6.hip, <= 320 RoIs; kept for A/B)
+# csrc/gemm_x6t.hip; 1 was round 2's kernel for the same arithmetic, removed in ABI 13)
 # "f32x3": two fp16 terms per row-scaled operand, three MFMAs per product (csrc/gemm_x3t.hip, FRCNN_FC_F32X3T)
-FC_MATH_MODES = {"f32": 0, "f32x6": 2, "f32x6_v1": 1, "f32x3": 3}
+FC_MATH_MODES = {"f32": 0, "f32x6": 2, "f32x3": 3}
 
 
 def uses_winograd(cin, cout):
@@ -217,8 +215,6 @@ _SIGNATURES = {
     "frcnn_conv3x3_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "frcnn_conv3x3_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_maxpool2x2_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
-    "frcnn_pack_conv3x3_x6": (C.c_int, [_vp, _vp, _i, _i, _vp]),
-    "frcnn_conv3x3_nhwc_x6": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_conv3x3_uses_winograd": (C.c_int, [_i, _i]),
     "frcnn_resnet_block_uses_winograd": (C.c_int, [_i, _i]),
     "frcnn_pack_conv3x3_winograd": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -227,9 +223,6 @@ _SIGNATURES = {
     "frcnn_conv3x3_nhwc_winograd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_roi_align": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i, _i, C.c_float, _i, _i, _vp, _vp]),
     "frcnn_roi_align_backward": (C.c_int, [_vp, _i, _i, _i, _i, _i, C.c_float, _i, _i, _vp, _vp, _i, _vp]),
-    "frcnn_split_rows_x6": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp]),
-    "frcnn_linear_x6_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
-    "frcnn_linear_x6": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_x6t_record_bytes": (C.c_size_t, [_i, _i]),
     "frcnn_split_rows_x6t": (C.c_int, [_vp, _i, _sz, _vp, _i, _i, _i, _i, _vp]),
     "frcnn_gemm_x6t_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),

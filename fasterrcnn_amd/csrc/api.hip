@@ -37,8 +37,8 @@ struct frcnn_ctx {
     float *anchor_map = nullptr, *valid_map = nullptr;
     float *roi_out = nullptr;                      // [max_rois][7][7][512]
     float *fc1_out = nullptr, *fc2_out = nullptr;  // [max_rois][4096]
-    void *roi_rec = nullptr, *fc1_rec = nullptr;   // x6 / x6t records of roi_out ([rec_rows][25088]) and fc1_out (FRCNN_FC_F32X6 / _F32X6T):
-    int rec_rows = 0;                              // one allocation, made by the first forward that runs fc1 / fc2 in an x6 mode
+    void *roi_rec = nullptr, *fc1_rec = nullptr;   // x6t / x3t records of roi_out ([rec_rows][25088]) and fc1_out (FRCNN_FC_F32X6T / _F32X3T):
+    int rec_rows = 0;                              // one allocation, made by the first forward that runs fc1 / fc2 in a record mode
     float *roi_inv = nullptr, *fc1_inv = nullptr, *fm_cmax = nullptr;   // FRCNN_FC_F32X3T: row scales of the two record arrays, channel maximum of the feature map
     float *head_logits = nullptr;                  // [max_rois][128]
     void* lin_ws = nullptr; size_t lin_ws_bytes = 0;
@@ -207,19 +207,6 @@ int frcnn_conv3x3_nhwc(const float* d_x, const float* d_wp, const float* d_bias,
     return launch_conv3x3_nhwc(d_x, d_wp, d_bias, d_y, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
 }
 
-int frcnn_pack_conv3x3_x6(const float* d_w, void* d_wq, int cout, int cin, void* stream)
-{
-    if (!d_w || !d_wq) return FRCNN_EINVAL;
-    return launch_pack_conv3x3_x6(d_w, d_wq, cout, cin, as_stream(stream));
-}
-
-int frcnn_conv3x3_nhwc_x6(const float* d_x, const void* d_wq, const float* d_bias, float* d_y, int H, int W,
-                          int cin, int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
-{
-    if (!d_x || !d_wq || !d_bias || !d_y) return FRCNN_EINVAL;
-    return launch_conv3x3_x6(d_x, d_wq, d_bias, d_y, H, W, cin, cout, flags, d_ws, ws_bytes, as_stream(stream));
-}
-
 int frcnn_conv3x3_uses_winograd(int cin, int cout) { return conv3x3_uses_winograd(cin, cout) ? 1 : 0; }
 int frcnn_resnet_block_uses_winograd(int width, int stride) { return resnet_block_uses_winograd(width, stride) ? 1 : 0; }
 
@@ -274,21 +261,6 @@ int frcnn_conv3x3_nhwc_winograd_fused_maps(const float* d_x, const float* d_u, c
 {
     if (!d_x || !d_u || !d_bias || !d_y || H < 1 || W < 1 || n_maps < 1) return FRCNN_EINVAL;
     return launch_conv3x3_winograd_fused(d_x, d_u, d_bias, d_y, H, W, cin, cout, flags, as_stream(stream), n_maps);
-}
-
-int frcnn_split_rows_x6(const float* d_a, int lda, void* d_rec, int rows, int rows_out, int K, void* stream)
-{
-    if (!d_a || !d_rec) return FRCNN_EINVAL;
-    return launch_split_rows_x6(d_a, lda, d_rec, rows, rows_out, K, as_stream(stream));
-}
-
-size_t frcnn_linear_x6_workspace_bytes(int M, int N, int K) { return linear_x6_workspace_bytes(M, N, K); }
-
-int frcnn_linear_x6(const void* d_a_rec, const void* d_w_rec, const float* d_bias, float* d_y, int ldy, void* d_y_rec,
-                    int M, int N, int K, unsigned flags, void* d_ws, size_t ws_bytes, void* stream)
-{
-    if (!d_a_rec || !d_w_rec || !d_bias) return FRCNN_EINVAL;
-    return launch_linear_x6(d_a_rec, d_w_rec, d_bias, d_y, ldy, d_y_rec, M, N, K, flags, d_ws, ws_bytes, as_stream(stream));
 }
 
 size_t frcnn_x6t_record_bytes(int rows_padded, int K)
@@ -835,10 +807,6 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         const size_t w5 = linear_workspace_bytes(c->max_fh * c->max_fw, 45, 1024);
         const size_t w6 = linear_workspace_bytes(max_rois, FRCNN_HEAD_LD_MAX, 2048);
         lin = w1; if (w2 > lin) lin = w2; if (w3 > lin) lin = w3; if (w4 > lin) lin = w4; if (w5 > lin) lin = w5; if (w6 > lin) lin = w6;
-        const size_t x1 = linear_x6_workspace_bytes(max_rois > 320 ? 320 : max_rois, 4096, 512 * 49);
-        const size_t x2 = linear_x6_workspace_bytes(max_rois > 320 ? 320 : max_rois, 4096, 4096);
-        if (x1 > lin) lin = x1;
-        if (x2 > lin) lin = x2;
         const size_t t1 = gemm_x6t_workspace_bytes(max_rois, 4096, 512 * 49, 1), t2 = gemm_x6t_workspace_bytes(max_rois, 4096, 4096, 1);
         if (t1 > lin) lin = t1;
         if (t2 > lin) lin = t2;
@@ -846,7 +814,7 @@ int frcnn_ctx_create(frcnn_ctx** out, int max_image_h, int max_image_w, int max_
         if (h1 > lin) lin = h1;
         if (h2 > lin) lin = h2;
     }
-    // row count of the activation record arrays: the x6t GEMM's 320-row tiles over max_rois (>= the 320 rows of the round-2 kernel)
+    // row count of the activation record arrays: the x6t GEMM's 320-row tiles over max_rois
     const int rec_rows = cdiv(max_rois, gemm_x6t_row_tile(max_rois)) * gemm_x6t_row_tile(max_rois);
     c->rec_rows = rec_rows;
     size_t cws = 0;
@@ -1061,12 +1029,12 @@ int ensure_wx_ws(frcnn_ctx* c, size_t layer_need, hipStream_t s)
     return FRCNN_OK;
 }
 
-// The activation record arrays of fc1 / fc2 (x6 modes of the VGG-16 detector): 53 MB at 320 rows, allocated and zeroed by the first
+// The activation record arrays of fc1 / fc2 (x6t / x3t modes of the VGG-16 detector): 53 MB at 320 rows, allocated and zeroed by the first
 // forward that needs them (ResNet models and fc_math_mode f32 never do).  The padding rows max_rois .. rec_rows - 1 stay zero.
 int ensure_fc_records(frcnn_ctx* c, hipStream_t s)
 {
     if (c->roi_rec) return FRCNN_OK;
-    // (sized for the x6 / x6t records, 6 bytes per value; the x3t records of FRCNN_FC_F32X3T need 4)
+    // (sized for the x6t records, 6 bytes per value; the x3t records of FRCNN_FC_F32X3T need 4)
     const size_t b1 = (size_t)c->rec_rows * 49 * 512 * 6, b2 = (size_t)c->rec_rows * 4096 * 6;
     const size_t b3 = align_up((size_t)c->rec_rows * sizeof(float), 256), b4 = align_up((size_t)c->max_fh * c->max_fw * sizeof(float), 256);
     void* p = nullptr;
@@ -1184,18 +1152,14 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     hipStream_t s = as_stream(stream);
     const unsigned R = FRCNN_RELU, RP = FRCNN_RELU | FRCNN_POOL2;
     int rc;
-    if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32X6 && p->math_mode != FRCNN_MATH_F32_WINOGRAD)
-        return FRCNN_EINVAL;
+    if (p->math_mode != FRCNN_MATH_F32 && p->math_mode != FRCNN_MATH_F32_WINOGRAD) return FRCNN_EINVAL;
     if (p->conv_blocks_target < 0) return FRCNN_EINVAL;
-    if (p->fc_math_mode != FRCNN_FC_F32 && p->fc_math_mode != FRCNN_FC_F32X6 && p->fc_math_mode != FRCNN_FC_F32X6T &&
-        p->fc_math_mode != FRCNN_FC_F32X3T)
-        return FRCNN_EINVAL;
+    if (p->fc_math_mode != FRCNN_FC_F32 && p->fc_math_mode != FRCNN_FC_F32X6T && p->fc_math_mode != FRCNN_FC_F32X3T) return FRCNN_EINVAL;
     if ((p->roi_op != FRCNN_ROI_POOL && p->roi_op != FRCNN_ROI_ALIGN) || p->roi_sampling_ratio > 2) return FRCNN_EINVAL;
     if (p->winograd_tile_rows != 0 && p->winograd_tile_rows != 64 && p->winograd_tile_rows != 128) return FRCNN_EINVAL;
     if (p->x6_gemm_tiles < 0 || p->x6_gemm_tiles > 2) return FRCNN_EINVAL;
     if ((p->winograd_x3_mask & ~p->winograd_x6_mask) != 0) return FRCNN_EINVAL;     // a subset of the x6 table
     BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows, p->x6_gemm_tiles);
-    const bool x6 = p->math_mode == FRCNN_MATH_F32X6;
     const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
     if (p->winograd_x6_mask != 0 && (!wino || (p->winograd_x6_mask & ~0x3FFE) != 0)) return FRCNN_EINVAL;
     if (p->winograd_x3f_mask != 0 && (!wino || (p->winograd_x3f_mask & ~0x3FFE) != 0 || (p->winograd_x3f_mask & p->winograd_x6_mask) != 0)) return FRCNN_EINVAL;
@@ -1261,8 +1225,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
             return run_wino_fused_layer(c, p->conv_blocks_target == 0, xin, wgt, bs, yout, hh, ww, ci, co, fl, s);
         }
         Scope _d(c, 0, s);
-        return x6 ? launch_conv3x3_x6(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s)
-                  : launch_conv3x3_nhwc(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s);
+        return launch_conv3x3_nhwc(xin, wgt, bs, yout, hh, ww, ci, co, fl, c->conv_ws, c->conv_ws_bytes, s);
     };
 #define STEP(cls, call) do { Scope _sc(c, cls, s); rc = (call); } while (0); if (rc) return rc
 #define CONV(call) do { rc = (call); } while (0); if (rc) return rc
@@ -1311,11 +1274,9 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
 
     // stage 3: detector (models/detector.py:65-80, models/vgg16.py:129-133)
     const int R_ = p->post_nms;
-    const bool fc_x6 = p->fc_math_mode == FRCNN_FC_F32X6;
     const bool fc_x6t = p->fc_math_mode == FRCNN_FC_F32X6T;
-    if (fc_x6 && R_ > FRCNN_LINEAR_X6_ROWS) return FRCNN_EUNSUPPORTED;
     const bool fc_x3t = p->fc_math_mode == FRCNN_FC_F32X3T;
-    if (fc_x6 || fc_x6t || fc_x3t) { rc = ensure_fc_records(c, s); if (rc) return rc; }
+    if (fc_x6t || fc_x3t) { rc = ensure_fc_records(c, s); if (rc) return rc; }
     if (fc_x3t) {
         // fc1 / fc2 in the f32x3 arithmetic (csrc/gemm_x3t.hip): fc1_w / fc2_w = packed x3t operands (records of the 4096-row matrices, then
         // their row scales); RoIPool writes fc1's A records with one scale per RoI; fc1's float32 output is scaled and split again for fc2
@@ -1357,24 +1318,12 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
         STEP(2, launch_gemm_x6t(c->fc1_rec, rr, 0, w->fc2_w, 4096, 0, w->fc2_b, nullptr, c->fc2_out, 4096, 0, R_, 4096, 4096, 1, R,
                                 c->lin_ws, c->lin_ws_bytes, s, fc_tiles));
     } else
-    if (p->roi_op == FRCNN_ROI_ALIGN) {
-        STEP(4, launch_roi_align(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, p->roi_sampling_ratio, 0, c->roi_out, s));
-        if (fc_x6) STEP(2, launch_split_rows_x6(c->roi_out, 49 * 512, c->roi_rec, R_, FRCNN_LINEAR_X6_ROWS, 49 * 512, s));
-    } else if (fc_x6) {
-        // RoIPool writes fc1's operand records itself (rows R_ .. 319 of the array were zeroed when the ctx was created)
-        STEP(4, launch_roi_pool_x6(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_rec, FRCNN_LINEAR_X6_ROWS, s));
-    } else {
-        STEP(4, launch_roi_pool(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
-    }
-    if (fc_x6t || fc_x3t) {
-    } else if (fc_x6) {
-        // fc1 / fc2 on the bf16 pipe with exactly split operands: fc1's reduction emits the records fc2 consumes, fc2's the float32
-        // rows the (exact-f32) heads consume
-        STEP(2, launch_linear_x6(c->roi_rec, w->fc1_w, w->fc1_b, c->fc1_out, 4096, c->fc1_rec, R_, 4096, 49 * 512, R,
-                                 c->lin_ws, c->lin_ws_bytes, s));
-        STEP(2, launch_linear_x6(c->fc1_rec, w->fc2_w, w->fc2_b, c->fc2_out, 4096, nullptr, R_, 4096, 4096, R,
-                                 c->lin_ws, c->lin_ws_bytes, s));
-    } else {
+    {
+        if (p->roi_op == FRCNN_ROI_ALIGN) {
+            STEP(4, launch_roi_align(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, p->roi_sampling_ratio, 0, c->roi_out, s));
+        } else {
+            STEP(4, launch_roi_pool(c->fm, fh, fw, 512, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
+        }
         STEP(2, launch_linear(c->roi_out, 49 * 512, w->fc1_w, w->fc1_b, c->fc1_out, 4096, R_, 4096, 49 * 512, R,
                               c->lin_ws, c->lin_ws_bytes, s));
         STEP(2, launch_linear(c->fc1_out, 4096, w->fc2_w, w->fc2_b, c->fc2_out, 4096, R_, 4096, 4096, R,

@@ -98,10 +98,6 @@ void conv3x3_set_blocks_target(int target);     // split-K work-unit target of t
 int launch_conv3x3_nhwc(const float* x, const float* wp, const float* b, float* y, int H, int W,
                         int cin, int cout, unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_maxpool2x2(const float* x, float* y, int H, int W, int c, hipStream_t s);
-// conv_x6.hip: same layer on the bf16 pipe with exactly split operands ("f32x6" math mode)
-int launch_pack_conv3x3_x6(const float* w, void* wq, int cout, int cin, hipStream_t s);
-int launch_conv3x3_x6(const float* x, const void* wq, const float* b, float* y, int H, int W, int cin, int cout,
-                      unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 
 // conv_gather.hip (ResNet path)
 size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R, int stride, int pad);
@@ -156,10 +152,6 @@ int launch_pack_conv3x3_winograd_fused(const float* w, const float* scale, float
 int launch_pack_conv3x3_winograd_fused_taps(const float* wp, float* u, int cout, int cin, int data_gradient, hipStream_t s);
 int launch_conv3x3_winograd_fused(const float* x, const float* u, const float* b, float* y, int H, int W, int cin, int cout,
                                   unsigned flags, hipStream_t s, int n_maps = 1);
-// linear_x6.hip: fc1 / fc2 on the bf16 pipe with exactly split operands
-bool linear_x6_shape_ok(int M, int N, int K);
-size_t linear_x6_workspace_bytes(int M, int N, int K);
-int launch_split_rows_x6(const float* a, int lda, void* rec, int R, int rows_out, int K, hipStream_t s);
 // gemm_x6t.hip: batched f32x6 GEMM on tile records, LDS-DMA staged
 int gemm_x6t_row_tile(int M);
 int gemm_x6t_col_tile(int N);
@@ -224,8 +216,6 @@ int winograd_x6_plan(int N, int H, int W, int cin, int cout, unsigned flags, voi
 int launch_conv3x3_winograd_x6(const float* x, const void* urec, const float* b, float* y, int N, int H, int W, int cin, int cout,
                                unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_split_patches3x3_x6t(const float* x, void* rec, int N, int H, int W, int C, int stride, int rows_padded, hipStream_t s);
-int launch_linear_x6(const void* a_rec, const void* w_rec, const float* bias, float* y, int ldy, void* y_rec, int M, int N, int K,
-                     unsigned flags, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_softmax_rows(const float* x, int ldx, float* y, int M, int ncls, hipStream_t s);
 int launch_head_finish(const float* x, int ldx, int M, int ncls, int ndelta, float* classes,
                        float* deltas, hipStream_t s);
@@ -253,8 +243,6 @@ int launch_nms(const ProposalScratch& ps, const float* boxes, const float* score
 
 int launch_roi_pool(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
                     int max_rois, int pooled, float scale, float* out, hipStream_t s);
-int launch_roi_pool_x6(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
-                       int max_rois, int pooled, float scale, void* rec, int rec_rows, hipStream_t s);
 int launch_roi_pool_x6t(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
                         int max_rois, int pooled, float scale, void* rec, int rec_rows, hipStream_t s);
 

@@ -2,7 +2,7 @@
 // TILE records ("x6t"), staged by LDS-DMA.  Round 3: the GEMM of the x6 Winograd layers (csrc/wino_x6.hip: the 512-channel
 // convolutions of models/vgg16.py:89-96 and the RPN trunk models/rpn.py:88) and of fc1 / fc2 (models/vgg16.py:129-133).
 //
-// Arithmetic (as csrc/linear_x6.hip, csrc/conv_x6.hip): every float32 operand is split EXACTLY into three bfloat16 terms
+// Arithmetic: every float32 operand is split EXACTLY into three bfloat16 terms
 // x = hi + mid + lo (residuals formed in float32); a product is the sum of the six largest bf16 x bf16 partial products
 // (hh, hl, lh, hm, mh, mm) on v_mfma_f32_32x32x16_bf16 with float32 accumulation; the three dropped terms are <= 2^-24 |a b| each.
 //
@@ -19,8 +19,8 @@
 // <5, 2, 2, 4>: block tile 320 x 256, 8 waves (two per SIMD), 10 accumulator tiles = 160 AGPRs + 21 fragments (84 VGPRs) per wave.
 // (A 4-wave block with 5 x 4 tiles per wave needs 320 accumulator registers: more than the 256 AGPRs an instruction can address, and
 // hipcc spills rather than mixing AGPR- and VGPR-resident accumulators.)  Per 16-k stage a wave issues 60 MFMAs (6 products x 10
-// tiles) against 21 ds_read_b128 and 7 LDS-DMA pieces: 0.35 LDS reads per MFMA (the 320 x 128 tile of linear_x6.hip: 0.6), and the
-// block reads 54 KB from L2 per 3840 matrix-pipe cycles = 14 B/clk/CU (linear_x6.hip: 22).
+// tiles) against 21 ds_read_b128 and 7 LDS-DMA pieces: 0.35 LDS reads per MFMA (round 2's 320 x 128 tile: 0.6), and the
+// block reads 54 KB from L2 per 3840 matrix-pipe cycles = 14 B/clk/CU (round 2's kernel: 22).
 // 320 rows = the 300 RoIs of fc1 / fc2 in one tile; 8 x 320 rows = the 2394 Winograd tiles of a 75 x 125 map, so that
 // 8 m-tiles x 2 n-tiles x 16 positions = 256 blocks = ONE block per CU.
 // Two LDS stage buffers (2 x 54 KB); the DMA of stage s+1 is issued at the top of stage s and waited for (vmcnt(0)) at the
@@ -47,7 +47,7 @@ __device__ __forceinline__ gx_u16 gx_bf16_rne(float f)
 }
 __device__ __forceinline__ float gx_bf16_f32(gx_u16 h) { return __uint_as_float((unsigned)h << 16); }
 
-// x = hi + mid + lo exactly (barring overflow / subnormal tails); identical to lx_split3 of csrc/linear_x6.hip
+// x = hi + mid + lo exactly (barring overflow / subnormal tails)
 __device__ __forceinline__ void gx_split3(float x, gx_u16& hi, gx_u16& mid, gx_u16& lo)
 {
     hi = gx_bf16_rne(x);

@@ -22,60 +22,16 @@ namespace frcnn {
 // gather with a dependent max chain per thread (up to ~60 window pixels), i.e. latency bound: what pays is many waves in flight and
 // independent loads inside a thread (two partial maxima), not wide blocks -- one block per (roi, ph) that walked the 7 bins in
 // sequence with half of its 256 threads idle took 54 us for the 30 MB it writes.
-//
-// X6: instead of float32 rows the kernel emits the "x6 records" that csrc/linear_x6.hip multiplies (x = hi + mid + lo bf16, the
-// arithmetic of split_rows_x6_kernel, chunk-major [K/16][rec_rows][96 B] with K = pooled * pooled * C): the fused forward's fc1
-// then needs neither the 30 MB float32 round trip nor the split launch.
-__device__ __forceinline__ unsigned short rp_bf16_rne(float f)
-{
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float rp_bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-
-// X6 = 0: float32 rows; 1: the chunk-major x6 records of csrc/linear_x6.hip; 2: the x6t TILE records of csrc/gemm_x6t.hip
-// ([K/16][rec_rows/32][3][khalf 2][row 32][8 bf16]) -- round 3: fc1 runs on gemm_x6t_kernel
-template <int X6>
 __global__ __launch_bounds__(128)
 void roi_pool_kernel(const float* __restrict__ fm, int fh, int fw, int C,
                      const float* __restrict__ rois, const int32_t* __restrict__ n_rois,
-                     int pooled, float scale, float* __restrict__ out, int rec_rows)
+                     int pooled, float scale, float* __restrict__ out)
 {
     const int r = blockIdx.x, ph = blockIdx.y, pw = blockIdx.z;
     const int C4 = C >> 2;
     f32x4* obin = reinterpret_cast<f32x4*>(out + (((size_t)(r * pooled + ph) * pooled) + pw) * C);
-    auto emit = [&](int c4, const f32x4& m) {
-        if (!X6) { obin[c4] = m; return; }
-        unsigned short hi[4], mid[4], lo[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            hi[j] = rp_bf16_rne(m[j]);
-            const float r1 = m[j] - rp_bf16_f32(hi[j]);
-            mid[j] = rp_bf16_rne(r1);
-            lo[j] = rp_bf16_rne(r1 - rp_bf16_f32(mid[j]));
-        }
-        const int k = ((ph * pooled) + pw) * C + 4 * c4;
-        unsigned char* p;
-        int tstride;
-        if (X6 == 2) {
-            p = reinterpret_cast<unsigned char*>(out) + ((size_t)(k >> 4) * (rec_rows >> 5) + (r >> 5)) * 3072 + ((k >> 3) & 1) * 512 +
-                (r & 31) * 16 + (k & 7) * 2;
-            tstride = 1024;
-        } else {
-            p = reinterpret_cast<unsigned char*>(out) + ((size_t)(k >> 4) * rec_rows + r) * 96 + (k & 15) * 2;
-            tstride = 32;
-        }
-        uint2 ph_, pm_, pl_;
-        ph_.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16);   ph_.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
-        pm_.x = (unsigned)mid[0] | ((unsigned)mid[1] << 16); pm_.y = (unsigned)mid[2] | ((unsigned)mid[3] << 16);
-        pl_.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16);   pl_.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
-        *reinterpret_cast<uint2*>(p) = ph_;
-        *reinterpret_cast<uint2*>(p + tstride) = pm_;
-        *reinterpret_cast<uint2*>(p + 2 * tstride) = pl_;
-    };
     if (r >= *n_rois) {
-        for (int i = threadIdx.x; i < C4; i += 128) emit(i, f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int i = threadIdx.x; i < C4; i += 128) obin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
     }
     const f32x4 roi = reinterpret_cast<const f32x4*>(rois)[r];     // y1, x1, y2, x2
@@ -110,13 +66,21 @@ void roi_pool_kernel(const float* __restrict__ fm, int fh, int fw, int C,
         f32x4 m;
 #pragma unroll
         for (int j = 0; j < 4; ++j) m[j] = empty ? 0.f : (m1[j] > m0[j] ? m1[j] : m0[j]);
-        emit(c4, m);
+        obin[c4] = m;
     }
 }
 
+__device__ __forceinline__ unsigned short rp_bf16_rne(float f)
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float rp_bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
 // RoIPool straight into x6t tile records (csrc/gemm_x6t.hip: fc1's A operand), written as WHOLE 1 KB pieces: one wave = (bin, block
 // of 32 RoIs, 16-channel chunk), lane l = RoI 32 rb + (l & 31), channels 8 (l >> 5) .. + 7 of the chunk -- exactly the record image, so
-// the wave's three stores are three contiguous kilobytes.  (roi_pool_kernel<2> keeps lanes on channels: its 8-byte record stores land
+// the wave's three stores are three contiguous kilobytes.  (A kernel that kept roi_pool_kernel's lanes on channels had 8-byte record stores that land
 // in 5.6 million different cache lines and the kernel took 56 us instead of the float32 version's 32.)  Each lane walks its own RoI's
 // window (32-byte reads of an L2-resident 4.7 MB map); max is exact, so the association does not matter and the values are
 // bit-identical to roi_pool_kernel's.
@@ -308,19 +272,8 @@ int launch_roi_pool(const float* fm, int fh, int fw, int c, const float* rois, c
                     int max_rois, int pooled, float scale, float* out, hipStream_t s)
 {
     if (fh < 1 || fw < 1 || c < 4 || c % 4 != 0 || max_rois < 1 || pooled < 1) return FRCNN_EINVAL;
-    hipLaunchKernelGGL(roi_pool_kernel<0>, dim3(max_rois, pooled, pooled), dim3(128), 0, s, fm, fh, fw, c, rois,
-                       n_rois, pooled, scale, out, 0);
-    return check_launch();
-}
-
-// the same pooling, output = the x6 record array of the [max_rois][pooled * pooled * c] matrix (rec_rows >= max_rois rows
-// allocated; the rows max_rois .. rec_rows-1 are the caller's to zero once); c % 16 == 0
-int launch_roi_pool_x6(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois,
-                       int max_rois, int pooled, float scale, void* rec, int rec_rows, hipStream_t s)
-{
-    if (fh < 1 || fw < 1 || c < 16 || c % 16 != 0 || max_rois < 1 || pooled < 1 || rec_rows < max_rois) return FRCNN_EINVAL;
-    hipLaunchKernelGGL(roi_pool_kernel<1>, dim3(max_rois, pooled, pooled), dim3(128), 0, s, fm, fh, fw, c, rois,
-                       n_rois, pooled, scale, static_cast<float*>(rec), rec_rows);
+    hipLaunchKernelGGL(roi_pool_kernel, dim3(max_rois, pooled, pooled), dim3(128), 0, s, fm, fh, fw, c, rois,
+                       n_rois, pooled, scale, out);
     return check_launch();
 }
 

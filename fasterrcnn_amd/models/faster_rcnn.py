@@ -114,10 +114,10 @@ class FasterRCNNModel(nn.Module):
 
         # arithmetic of the 3x3 convolutions: "f32" = exact f32 MFMA, direct; "f32_winograd" = exact f32 MFMA with the
         # >= 256-channel layers as Winograd F(2x2,3x3) in float32 (2.25x fewer multiplies, fp32 rounding differences
-        # only); "f32x6" = exactly split bf16x3 operands, six bf16 MFMAs per product with f32 accumulation
+        # only).
         # Default: the fastest mode that reproduces the reference's golden vectors at the exact-f32 rate
         # (tests/test_winograd_gpu.py, tests/test_model_gpu.py, tests/test_resnet_gpu.py).  ResNet: the RPN trunk and the
-        # stride-1 3x3 convolutions of layer3 / layer4 are the Winograd layers; there is no f32x6 ResNet path.
+        # stride-1 3x3 convolutions of layer3 / layer4 are the Winograd layers.
         self._math_mode = "f32"
         self.math_mode = "f32_winograd"
         # per-layer arithmetic table of the f32_winograd mode (round 3): the layers named here run as x6 Winograd layers
@@ -148,7 +148,7 @@ class FasterRCNNModel(nn.Module):
         self._winograd_x6_layers = ()
         self.winograd_x6_layers = ("rpn_trunk",) if self._is_resnet else nv.DEFAULT_X6_LAYERS_VGG16
         # arithmetic of the VGG-16 detector's fc1 / fc2 (models/vgg16.py:130-132): "f32" = exact f32 MFMA; "f32x6" = exactly split
-        # bf16x3 operands, six bf16 MFMAs per product, f32 accumulation (csrc/linear_x6.hip) -- fp32-class accuracy (dropped terms
+        # bf16x3 operands, six bf16 MFMAs per product, f32 accumulation (csrc/gemm_x6t.hip) -- fp32-class accuracy (dropped terms
         # <= 2^-24 relative) at 2.67x the matrix-pipe rate; the default wherever it applies (ResNet heads have no fc1 / fc2)
         self._fc_math_mode = "f32"
         self.fc_math_mode = "f32" if self._is_resnet else "f32x3"
@@ -196,12 +196,8 @@ class FasterRCNNModel(nn.Module):
     def math_mode(self, mode):
         if mode not in nv.MATH_MODES:
             raise ValueError("math_mode must be one of %s" % sorted(nv.MATH_MODES))
-        if mode == "f32x6" and self._is_resnet:
-            raise NotImplementedError("the ResNet path has no f32x6 kernels (math modes: f32, f32_winograd)")
         self._math_mode = mode
         if getattr(self, "_train_state", None) is not None:
-            if mode == "f32x6":
-                raise NotImplementedError("a model with a live train state runs in the f32 or f32_winograd math mode")
             self._train_state.winograd = mode == "f32_winograd"
         self._stage1_feature_extractor.math_mode = mode
         self._stage2_region_proposal_network.math_mode = mode
@@ -503,13 +499,8 @@ class FasterRCNNModel(nn.Module):
         return self._wstruct
 
     def _effective_fc_math(self):
-        """The arithmetic fc1 / fc2 actually run in: the x6 kernel multiplies at most LINEAR_X6_ROWS (320) rows per call, so a model
-        configured for more proposals runs the exact-f32 kernel on an f32 pack of the same weights (no refusal, no error)."""
-        if self._is_resnet:
-            return "f32"
-        if self._fc_math_mode == "f32x6_v1" and int(self.max_proposals_post_nms) > nv.LINEAR_X6_ROWS:
-            return "f32"                    # round 2's kernel multiplies at most 320 rows; the round-3 kernel ("f32x6") has no such limit
-        return self._fc_math_mode
+        """The arithmetic fc1 / fc2 actually run in (the ResNet heads have no fc1 / fc2)."""
+        return "f32" if self._is_resnet else self._fc_math_mode
 
     def _check_limits(self, with_detections=True):
         if not 1 <= int(self.max_proposals_post_nms) <= nv.MAX_POST_NMS_CTX:

@@ -24,7 +24,6 @@ _LAYERS = [  # (name, cin, cout, pool_after)
 def pack_conv3x3(conv, math_mode="f32", one_launch=False):
     """
     OIHW weight of a 3x3 nn.Conv2d -> tap-major [9][cout][cin] (or [27][cout] when cin == 3); in the
-    "f32x6" math mode -> the exactly split [9][cout][cin/16][hi,mid,lo][16] bf16 layout; in the
     "f32_winograd" mode, for cin >= 64 (% 16) and cout >= 64 (% 64) -> the transformed filters G g G^T in the one-launch
     kernel's [cin/16][cout/64][16][64][16] order (flat); "f32_winograd_x6" (a per-layer choice of the f32_winograd mode, round 3)
     -> the same bank as x6t records (uint8) for csrc/wino_x6.hip; "f32_winograd_3launch" (tests / experiments) keeps round 1's
@@ -70,11 +69,6 @@ def pack_conv3x3(conv, math_mode="f32", one_launch=False):
             nv.check(nv.lib().frcnn_pack_conv3x3_winograd(nv.ptr(w), None, nv.ptr(out), cout, cin, nv.stream_ptr()),
                      "frcnn_pack_conv3x3_winograd")
         return out
-    if math_mode == "f32x6" and cin != 3:
-        out = t.empty((9 * cout * cin * 3,), dtype=t.int16, device=w.device)
-        with t.cuda.device(w.device):
-            nv.check(nv.lib().frcnn_pack_conv3x3_x6(nv.ptr(w), nv.ptr(out), cout, cin, nv.stream_ptr()), "frcnn_pack_conv3x3_x6")
-        return out
     out = t.empty((27, cout) if cin == 3 else (9, cout, cin), dtype=t.float32, device=w.device)
     with t.cuda.device(w.device):
         if cin == 3:
@@ -86,8 +80,8 @@ def pack_conv3x3(conv, math_mode="f32", one_launch=False):
 
 def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False, one_launch=False):
     """One 3x3 'same' convolution (+ReLU, + fused 2x2 max-pool) on an NHWC CUDA tensor via frcnn_conv3x3_nhwc
-    (frcnn_conv3x3_nhwc_x6 when `wp` is a split int16 weight buffer, frcnn_conv3x3_nhwc_winograd when it is a
-    [16][cout][cin] transformed filter bank)."""
+    (frcnn_conv3x3_nhwc_winograd when `wp` is a [16][cout][cin] transformed filter bank, the x6 / x3 Winograd entry points when it is a
+    uint8 record bank / blob)."""
     h, w = int(x_hwc.shape[0]), int(x_hwc.shape[1])
     oh, ow = (h // 2, w // 2) if pool else (h, w)
     y = t.empty((oh, ow, cout), dtype=t.float32, device=x_hwc.device)
@@ -134,9 +128,8 @@ def conv3x3(x_hwc, wp, b, cin, cout, relu=True, pool=False, one_launch=False):
             nv.check(lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
                                                      nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc_winograd")
             return y
-        fn = lib.frcnn_conv3x3_nhwc_x6 if wp.dtype == t.int16 else lib.frcnn_conv3x3_nhwc
-        nv.check(fn(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
-                    nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc")
+        nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(x_hwc), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
+                                        nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_conv3x3_nhwc")
     return y
 
 
@@ -238,8 +231,7 @@ class PoolToFeatureVector(nn.Module):
     def packed(self, mode=None):
         """(fc1 weight, fc1 bias, fc2 weight, fc2 bias) in the layout of `mode` (default: `fc_math_mode`): float32 matrices ("f32") or
         their x6 / x3 records.  Only the pack of the mode last asked for is kept (0.4 - 0.6 GB each: switching modes must not
-        accumulate device memory); a model whose row count exceeds the v1 x6 kernel's 320-row tile runs the f32 pack of the
-        same weights and re-packs when it alternates."""
+        accumulate device memory)."""
         mode = mode or self.fc_math_mode
         params = [self._fc1.weight, self._fc1.bias, self._fc2.weight, self._fc2.bias]
         key = rt.param_key(params)
@@ -249,9 +241,7 @@ class PoolToFeatureVector(nn.Module):
         if mode not in self._packed:
             self._packed = {}                        # drop the other modes' packs BEFORE allocating this one
             w1p, b1, w2, b2 = self.packed_direct()
-            if mode == "f32x6_v1":
-                w1p, w2 = split_rows_x6(w1p, rows_out=4096), split_rows_x6(w2, rows_out=4096)
-            elif mode == "f32x6":
+            if mode == "f32x6":
                 w1p, w2 = split_rows_x6t(w1p, 4096), split_rows_x6t(w2, 4096)
             elif mode == "f32x3":
                 w1p, w2 = pack_rows_x3t(w1p, 4096), pack_rows_x3t(w2, 4096)
@@ -259,16 +249,13 @@ class PoolToFeatureVector(nn.Module):
         return self._packed[mode]
 
     def forward(self, rois):
-        """rois (N, 512, 7, 7) -> (N, 4096): fc1+ReLU, fc2+ReLU (dropout = identity at inference).  More rows than the x6 kernel's
-        320-row tile run on the exact-f32 kernel (same weights, f32 pack)."""
+        """rois (N, 512, 7, 7) -> (N, 4096): fc1+ReLU, fc2+ReLU (dropout = identity at inference)."""
         if self.training and (self._dropout1.p > 0 or self._dropout2.p > 0):
             raise NotImplementedError("training-mode dropout is outside the inference hot path")
         x = rt.as_f32_cuda(rois, "rois")
         n = int(x.shape[0])
         x = x.permute(0, 2, 3, 1).contiguous().reshape(n, 49 * 512)   # layout plumbing: (C,7,7) -> (7,7,C)
         mode = self.fc_math_mode
-        if mode == "f32x6_v1" and n > nv.LINEAR_X6_ROWS:
-            mode = "f32"
         w1p, b1, w2, b2 = self.packed(mode)
         if mode == "f32x6":
             h1 = linear_x6t(x, w1p, b1, 4096, relu=True)
@@ -276,9 +263,6 @@ class PoolToFeatureVector(nn.Module):
         if mode == "f32x3":
             h1 = linear_x3t(x, w1p, b1, 4096, relu=True)
             return linear_x3t(h1, w2, b2, 4096, relu=True)
-        if mode == "f32x6_v1":
-            h1_rec = linear_x6(split_rows_x6(x), w1p, b1, n, 4096, 49 * 512, relu=True, want="records")
-            return linear_x6(h1_rec, w2, b2, n, 4096, 4096, relu=True, want="float32")
         return linear(linear(x, w1p, b1, 4096, relu=True), w2, b2, 4096, relu=True)
 
 
@@ -343,40 +327,6 @@ def linear_x3t(x, w_blob, b, n_out, relu):
                                     nv.ptr(b), None, nv.ptr(y), n_out, 0, m, n_out, k, 1, nv.RELU if relu else 0, nv.ptr(ws), wsb,
                                     nv.stream_ptr()), "frcnn_gemm_x3t")
     return y
-
-
-def split_rows_x6(a, rows_out=None):
-    """float32 (R, K) CUDA matrix -> its x6 record array (uint8, chunk-major [K/16][rows_out][96 B]; rows R .. rows_out-1 zero).
-    rows_out: None = an activation matrix (the 320-row tile of frcnn_linear_x6); a weight matrix passes its row count, which is
-    rounded up to the 128-column tile."""
-    r, k = int(a.shape[0]), int(a.shape[1])
-    if rows_out is None:
-        if r > nv.LINEAR_X6_ROWS:
-            raise ValueError("frcnn_linear_x6 multiplies at most %d rows" % nv.LINEAR_X6_ROWS)
-        rows_out = nv.LINEAR_X6_ROWS
-    else:
-        rows_out = (max(int(rows_out), r) + 127) // 128 * 128
-    rec = t.empty((rows_out * (k // 16) * 96,), dtype=t.uint8, device=a.device)
-    a = a.contiguous()
-    with t.cuda.device(a.device):
-        nv.check(nv.lib().frcnn_split_rows_x6(nv.ptr(a), k, nv.ptr(rec), r, rows_out, k, nv.stream_ptr()), "frcnn_split_rows_x6")
-    return rec
-
-
-def linear_x6(a_rec, w_rec, b, m, n_out, k, relu, want="float32"):
-    """y = act(a @ w.T + b) through frcnn_linear_x6 on x6 records; returns the float32 (m, n_out) tensor or y's records."""
-    dev = a_rec.device
-    if m == 0:
-        return t.empty((0, n_out), dtype=t.float32, device=dev) if want == "float32" else t.empty((0,), dtype=t.uint8, device=dev)
-    lib = nv.lib()
-    y = t.empty((m, n_out), dtype=t.float32, device=dev) if want == "float32" else None
-    y_rec = t.empty((nv.LINEAR_X6_ROWS * (n_out // 16) * 96,), dtype=t.uint8, device=dev) if want == "records" else None
-    ws_bytes = int(lib.frcnn_linear_x6_workspace_bytes(m, n_out, k))
-    ws = t.empty((max(ws_bytes, 4) // 4,), dtype=t.float32, device=dev)
-    with t.cuda.device(dev):
-        nv.check(lib.frcnn_linear_x6(nv.ptr(a_rec), nv.ptr(w_rec), nv.ptr(b), nv.ptr(y), n_out, nv.ptr(y_rec), m, n_out, k,
-                                     nv.RELU if relu else 0, nv.ptr(ws), ws_bytes, nv.stream_ptr()), "frcnn_linear_x6")
-    return y if want == "float32" else y_rec
 
 
 def linear(x, w, b, n_out, relu):

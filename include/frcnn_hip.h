@@ -37,14 +37,16 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 12  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
+#define FRCNN_ABI_VERSION 13  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
                                  5: bf16 gradient GEMMs (the *_math entry points); 6: x6t GEMM, x6 Winograd layers, frcnn_forward_params.winograd_x6_mask,
                                  timing classes 8 / 9; 7: batched feature extractor (frcnn_resnet_backbone, frcnn_resnet_forward_features,
                                  frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps); 8: the f32x3 arithmetic (frcnn_*_x3t, frcnn_*_winograd_x3,
                                  frcnn_forward_params.winograd_x3_mask, FRCNN_FC_F32X3T, frcnn_bottleneck_weights.x3_mask); 9: one-launch f32x3 Winograd layers
                                  in the forward (frcnn_forward_params.winograd_x3f_mask, timing class 10), frcnn_roi_pool_x3t; 10: frcnn_conv3x3_c3_cmax, bits 1 (conv1_2)
                                  and 13 (RPN trunk) of winograd_x3f_mask; 11: frcnn_conv_nhwc_x3g, frcnn_tensor_absmax, frcnn_bottleneck_weights.g3 / .wmax;
-                                 12: frcnn_x3_saturation_events, FRCNN_X3F_WAVES4 / FRCNN_X3F_WAVES8 */
+                                 12: frcnn_x3_saturation_events, FRCNN_X3F_WAVES4 / FRCNN_X3F_WAVES8; 13: REMOVED the round-2 f32x6 kernels that no table has used since round 3
+                                 (frcnn_pack_conv3x3_x6, frcnn_conv3x3_nhwc_x6, frcnn_split_rows_x6, frcnn_linear_x6(_workspace_bytes), math mode 1 =
+                                 FRCNN_MATH_F32X6 and fc mode 1 = FRCNN_FC_F32X6 are FRCNN_EINVAL); the f32x6 arithmetic stays as gemm_x6t / wino_x6 */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -140,16 +142,6 @@ size_t frcnn_conv3x3_workspace_bytes(int H, int W, int cin, int cout);
 int frcnn_conv3x3_nhwc(const float* d_x, const float* d_w_packed, const float* d_bias,
                        float* d_y, int H, int W, int cin, int cout, unsigned flags,
                        void* d_ws, size_t ws_bytes, void* stream);
-/* The same layer in the "f32x6" math mode: every fp32 operand is split exactly into three bf16
- * terms and the product is formed from the six largest bf16 x bf16 partial products on
- * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms <= 2^-24 relative: fp32-rounding
- * class), 2.67x the matrix-pipe rate of the exact-f32 kernel.  d_w_split from
- * frcnn_pack_conv3x3_x6 (54*cout*cin bytes: [tap][cout][cin/16][hi,mid,lo][16] bf16); inputs,
- * outputs, bias and scratch are the same fp32 tensors as for frcnn_conv3x3_nhwc. */
-int frcnn_pack_conv3x3_x6(const float* d_w_oihw, void* d_w_split, int cout, int cin, void* stream);
-int frcnn_conv3x3_nhwc_x6(const float* d_x, const void* d_w_split, const float* d_bias,
-                          float* d_y, int H, int W, int cin, int cout, unsigned flags,
-                          void* d_ws, size_t ws_bytes, void* stream);
 /* The same layer (models/vgg16.py:36-47, models/rpn.py:39; with n_maps > 1 also the stride-1 3x3 of a ResNet
  * bottleneck on the per-RoI maps, models/resnet.py:110) as Winograd F(2x2,3x3) in float32: three launches
  * (input transform, 16 batched exact-f32 MFMA GEMMs over the channels, output transform + bias + ReLU +
@@ -202,22 +194,6 @@ int frcnn_conv3x3_nhwc_winograd_fused(const float* d_x, const float* d_u, const 
  * blocks of the maps follow each other in ONE grid, every map's result is bit-identical to its own single-map call. */
 int frcnn_conv3x3_nhwc_winograd_fused_maps(const float* d_x, const float* d_u, const float* d_bias, float* d_y, int n_maps,
                                            int H, int W, int cin, int cout, unsigned flags, void* stream);
-/* Dense layer with ReLU (models/vgg16.py:130-132) in the "f32x6" arithmetic (csrc/linear_x6.hip): both operands as "x6 records"
- * -- for a row-major float32 matrix [R][K] the record of (row, 16-k chunk) is 96 contiguous bytes [hi 16 | mid 16 | lo 16] bf16 with
- * x = hi + mid + lo exactly -- six bf16 MFMAs per product, f32 accumulation (dropped terms <= 2^-24 relative: fp32-rounding class).
- * A record array is CHUNK-MAJOR: [K/16][rows_out][96 B] (the tile a block stages per 16-k step is one contiguous run).
- *   frcnn_split_rows_x6 : float32 [rows][lda] (K used columns, K % 16 == 0) -> a record array of `rows_out` >= rows rows; rows beyond
- *                         `rows` are zero.  96 * rows_out * K / 16 bytes.  Weight matrices: rows_out = N rounded up to 128;
- *                         activations: rows_out = FRCNN_LINEAR_X6_ROWS.
- *   frcnn_linear_x6     : y[m][n] = act(bias[n] + sum_k a[m][k] w[n][k]),  M <= FRCNN_LINEAR_X6_ROWS, N % 4 == 0, K % 16 == 0,
- *                         K >= 32.  d_a_rec: a FRCNN_LINEAR_X6_ROWS-row record array; d_y float32 [M][ldy] and / or d_y_rec = the
- *                         records of y for the next layer (N % 16 == 0, a FRCNN_LINEAR_X6_ROWS-row array, rows beyond M zeroed);
- *                         either may be NULL.  Deterministic split-K; d_ws >= frcnn_linear_x6_workspace_bytes(M, N, K). */
-#define FRCNN_LINEAR_X6_ROWS 320
-int frcnn_split_rows_x6(const float* d_a, int lda, void* d_rec, int rows, int rows_out, int K, void* stream);
-size_t frcnn_linear_x6_workspace_bytes(int M, int N, int K);
-int frcnn_linear_x6(const void* d_a_rec, const void* d_w_rec, const float* d_bias, float* d_y, int ldy, void* d_y_rec,
-                    int M, int N, int K, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Round 3: the f32x6 arithmetic as a general batched GEMM on TILE records ("x6t", csrc/gemm_x6t.hip) and the Winograd layers built
@@ -482,9 +458,9 @@ typedef struct frcnn_vgg16_weights {
     const float* rpn_conv_b;
     const float* rpn_head_w;   /* frcnn_pack_stack_rows(_rpn_class, _rpn_boxes) -> [128][512] */
     const float* rpn_head_b;   /* [128]                                                       */
-    const float* fc1_w;        /* frcnn_pack_fc_chw_to_hwc(_fc1) [4096][25088]; with fc_math_mode FRCNN_FC_F32X6 its x6 records */
+    const float* fc1_w;        /* frcnn_pack_fc_chw_to_hwc(_fc1) [4096][25088]; FRCNN_FC_F32X6T / _F32X3T: its records */
     const float* fc1_b;
-    const float* fc2_w;        /* [4096][4096] as stored; with FRCNN_FC_F32X6 its x6 records  */
+    const float* fc2_w;        /* [4096][4096] as stored; FRCNN_FC_F32X6T / _F32X3T: its records */
     const float* fc2_b;
     const float* head_w;       /* frcnn_pack_stack_rows(_classifier, _regressor) -> [128][4096] */
     const float* head_b;       /* [128]                                                       */
@@ -497,9 +473,9 @@ typedef struct frcnn_forward_params {
     float   rpn_nms_threshold;  /* 0.7   (models/rpn.py:150)         */
     float   min_side;           /* 16    (models/rpn.py:142)         */
     int32_t allow_edge_proposals; /* 1   (models/faster_rcnn.py:36)  */
-    int32_t math_mode;          /* FRCNN_MATH_F32 (exact f32 MFMA, direct), FRCNN_MATH_F32X6 or FRCNN_MATH_F32_WINOGRAD;
+    int32_t math_mode;          /* FRCNN_MATH_F32 (exact f32 MFMA, direct) or FRCNN_MATH_F32_WINOGRAD;
                                    selects how the 3x3 conv weight pointers of the weights struct are interpreted:
-                                   frcnn_pack_conv3x3 / frcnn_pack_conv3x3_x6 / FRCNN_MATH_F32_WINOGRAD: layers with
+                                   FRCNN_MATH_F32: frcnn_pack_conv3x3; FRCNN_MATH_F32_WINOGRAD: layers with
                                    frcnn_conv3x3_uses_winograd_fused(cin, cout) (every 3x3 layer from conv1_2 on, the RPN trunk;
                                    ResNet: frcnn_resnet_block_uses_winograd_fused blocks) frcnn_pack_conv3x3_winograd_fused,
                                    ResNet layer4 blocks with frcnn_resnet_block_uses_winograd: frcnn_pack_conv3x3_winograd,
@@ -507,9 +483,8 @@ typedef struct frcnn_forward_params {
     int32_t conv_blocks_target; /* split-K granularity of the 3x3 layers: blocks per launch to aim for.  0 = 1280 (best
                                    latency for one image on the chip); ~320 when many images are in flight on separate
                                    streams (other images' kernels fill the tail, longer work units win) */
-    int32_t fc_math_mode;       /* VGG-16 detector fc1 / fc2: FRCNN_FC_F32 (exact f32 MFMA, fc1_w / fc2_w = float32 matrices) or FRCNN_FC_F32X6
-                                   (exactly split bf16x3 operands, six bf16 MFMAs per product, f32 accumulate: fc1_w / fc2_w = the x6
-                                   records of frcnn_split_rows_x6 over the same matrices, rows padded to a multiple of 128) */
+    int32_t fc_math_mode;       /* VGG-16 detector fc1 / fc2: FRCNN_FC_F32 (exact f32 MFMA, fc1_w / fc2_w = float32 matrices), FRCNN_FC_F32X6T or
+                                   FRCNN_FC_F32X3T (record operands, see the defines below) */
     int32_t roi_op;             /* FRCNN_ROI_POOL (the reference: torchvision RoIPool, models/detector.py:27) or FRCNN_ROI_ALIGN
                                    (torchvision roi_align semantics, aligned = 0) */
     int32_t roi_sampling_ratio; /* FRCNN_ROI_ALIGN: samples per bin and axis (1 or 2; <= 0 adaptive); ignored for FRCNN_ROI_POOL */
@@ -542,13 +517,13 @@ typedef struct frcnn_forward_params {
 #define FRCNN_HEAD_LD_MAX 512
 #define FRCNN_MAX_NUM_CLASSES 103
 #define FRCNN_MATH_F32   0
-#define FRCNN_MATH_F32X6 1
+/* (1 was FRCNN_MATH_F32X6, the direct f32x6 convolution of round 2: removed in ABI 13) */
 #define FRCNN_MATH_F32_WINOGRAD 2
 #define FRCNN_ROI_POOL  0
 #define FRCNN_ROI_ALIGN 1
 #define FRCNN_FC_F32   0
-#define FRCNN_FC_F32X6 1      /* rounds 2's kernel (csrc/linear_x6.hip, chunk-major records, <= FRCNN_LINEAR_X6_ROWS RoIs) */
-#define FRCNN_FC_F32X6T 2     /* round 3: the same arithmetic on csrc/gemm_x6t.hip (fc1_w / fc2_w = frcnn_split_rows_x6t records of the
+/* (1 was FRCNN_FC_F32X6, round 2's chunk-major-record kernel: removed in ABI 13) */
+#define FRCNN_FC_F32X6T 2     /* the f32x6 arithmetic (three bf16 terms per operand, six MFMAs per product) on csrc/gemm_x6t.hip (fc1_w / fc2_w = frcnn_split_rows_x6t records of the
                                  same matrices, rows padded to FRCNN_X6T_COL_TILE; any number of RoIs the ctx holds) */
 #define FRCNN_FC_F32X3T 3     /* the f32x3 arithmetic on csrc/gemm_x3t.hip (two fp16 terms per row-scaled operand, three MFMAs per product):
                                  fc1_w / fc2_w = frcnn_pack_rows_x3t blobs of the same matrices (rows_padded = 4096) */

@@ -261,7 +261,7 @@ def test_x3_layer_impulses_and_maps():
 def test_roi_pool_x3t_records_hold_the_pooled_values(gpu_model):
     """The f32x3 fc path end to end on the model: with fc_math_mode "f32x3" the pooled features only exist as records; their effect is
     checked through the detector outputs against the exact-f32 fc path on the same proposals (class probabilities within 1e-5) in
-    test_linear_x6_gpu.py.  Here: degenerate RoIs (empty bins, RoIs outside the map) give finite outputs."""
+    test_linear_x6t_gpu.py.  Here: degenerate RoIs (empty bins, RoIs outside the map) give finite outputs."""
     assert gpu_model.fc_math_mode == "f32x3"
     img = torch.zeros((1, 3, 224, 320), device="cuda")              # constant image: many tied / degenerate proposals
     p, c, d = gpu_model(image_data=img)

@@ -158,40 +158,6 @@ def test_conv3x3_nhwc(H, W, cin, cout, pool, relu):
         assert torch.equal(y, y1)
 
 
-@pytest.mark.parametrize("H,W,cin,cout,pool", [
-    (37, 62, 512, 512, False), (75, 125, 256, 512, True), (24, 40, 64, 64, True), (9, 33, 16, 128, False),
-    (150, 250, 128, 256, False), (7, 31, 32, 192, True), (1, 1, 16, 64, False),
-])
-def test_conv3x3_f32x6_math_mode(H, W, cin, cout, pool):
-    """bf16x3-split operands / six bf16 MFMAs per product: must meet the SAME fp64-truth tolerance as the
-    exact-f32 kernel (4e-6 * sqrt(K)); both errors are printed side by side."""
-    g = torch.Generator().manual_seed(H * 7 + W * 13 + cin + cout)
-    x = torch.randn((cin, H, W), generator=g) * torch.exp(torch.randn((cin, 1, 1), generator=g))   # wide dynamic range
-    w = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
-    b = torch.randn((cout,), generator=g) * 0.1
-    lib = nv.lib()
-    dw, db, xh = gpu(w), gpu(b), gpu(x.permute(1, 2, 0))
-    wq = torch.empty((9 * cout * cin * 3,), dtype=torch.int16, device=DEV)
-    wp = torch.empty((9, cout, cin), device=DEV)
-    nv.check(lib.frcnn_pack_conv3x3_x6(nv.ptr(dw), nv.ptr(wq), cout, cin, S()), "pack_x6")
-    nv.check(lib.frcnn_pack_conv3x3(nv.ptr(dw), nv.ptr(wp), cout, cin, S()), "pack")
-    oh, ow = (H // 2, W // 2) if pool else (H, W)
-    flags = nv.RELU | (nv.POOL2 if pool else 0)
-    ws_bytes = int(lib.frcnn_conv3x3_workspace_bytes(H, W, cin, cout))
-    ws = torch.empty((max(ws_bytes, 4) // 4,), device=DEV)
-    y6 = torch.full((oh, ow, cout), float("nan"), device=DEV)
-    y32 = torch.full((oh, ow, cout), float("nan"), device=DEV)
-    nv.check(lib.frcnn_conv3x3_nhwc_x6(nv.ptr(xh), nv.ptr(wq), nv.ptr(db), nv.ptr(y6), H, W, cin, cout, flags, nv.ptr(ws), ws_bytes, S()), "conv_x6")
-    nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(xh), nv.ptr(wp), nv.ptr(db), nv.ptr(y32), H, W, cin, cout, flags, nv.ptr(ws), ws_bytes, S()), "conv")
-    truth = conv_ref(x, w, b, True, pool, torch.float64)
-    scale = float(truth.abs().max()) + 1e-30
-    e6 = float((y6.cpu().permute(2, 0, 1).double() - truth).abs().max()) / scale
-    e32 = float((y32.cpu().permute(2, 0, 1).double() - truth).abs().max()) / scale
-    print("conv %dx%d %d->%d: rel err f32x6 %.3g, exact-f32 MFMA %.3g" % (H, W, cin, cout, e6, e32))
-    assert not torch.isnan(y6).any()
-    assert e6 <= 4e-6 * np.sqrt(cin * 9)
-
-
 def test_conv_rejects_unsupported_shapes():
     d = torch.zeros(16, device=DEV)
     lib = nv.lib()

@@ -1,6 +1,9 @@
 """
-GPU parity tests of the "f32x6" dense layers (csrc/linear_x6.hip): fc1 / fc2 of models/vgg16.py:129-133 with exactly split
+GPU parity tests of the "f32x6" dense layers (csrc/gemm_x6t.hip): fc1 / fc2 of models/vgg16.py:129-133 with exactly split
 bf16x3 operands, six bf16 MFMAs per product and f32 accumulation.
+
+(Round 2's first kernel for this arithmetic, linear_x6_kernel with chunk-major records and a 320-row limit, was removed in ABI 13; its
+tests went with it.  The exactness of the three-term split is tested on the tile records in tests/test_wino_x6_gpu.py.)
 
 Tolerances: the split is exact (hi + mid + lo == x bit for bit); a layer against float64 truth must be no worse than 1.5x the
 exact-f32 MFMA kernel's own error + 2e-7 of max|y| (dropped terms <= 2^-24 relative per product), and within 4e-6 * sqrt(K) of
@@ -19,82 +22,15 @@ from fasterrcnn_amd.models import vgg16 as V
 pytestmark = pytest.mark.gpu
 
 
-def records_to_planes(rec, rows, k):
-    """uint8 record array (chunk-major: [k/16][rows][hi, mid, lo][16] bf16) -> three float32 (rows, k) matrices (hi, mid, lo)."""
-    r = rec.cpu().numpy().view(np.uint16).reshape(k // 16, rows, 3, 16).transpose(1, 0, 2, 3)
-    f = (r.astype(np.uint32) << 16).view(np.float32)
-    return [f[:, :, p, :].reshape(rows, k) for p in range(3)]
-
-
-def test_split_is_exact_and_padded_rows_are_zero():
-    gen = torch.Generator().manual_seed(1)
-    a = torch.randn((37, 160), generator=gen) * torch.exp(torch.randn((37, 160), generator=gen) * 3)     # wide dynamic range
-    a[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e-30, 65504.0, 1e-3, 0.1])
-    rec = V.split_rows_x6(a.cuda(), rows_out=128)
-    assert rec.numel() == 128 * 10 * 96
-    hi, mid, lo = records_to_planes(rec, 128, 160)
-    x = a.numpy()
-    assert np.array_equal((hi[:37].astype(np.float64) + mid[:37] + lo[:37]).astype(np.float32), x)        # hi + mid + lo == x
-    assert np.abs(mid[:37]).max() <= np.abs(hi[:37]).max() * 2.0 ** -7 and (hi[37:] == 0).all() and (lo[37:] == 0).all()
-    with np.errstate(divide="ignore", invalid="ignore"):
-        rel = np.abs(lo[:37]) / np.abs(x)
-    assert np.nanmax(rel[np.abs(x) > 1e-20]) <= 2.0 ** -15
-
-
-@pytest.mark.parametrize("M,N,K,relu", [(300, 4096, 25088, True), (300, 4096, 4096, True), (137, 256, 512, False), (1, 128, 32, True),
-                                        (320, 132, 80, False), (7, 4, 48, True)])
-def test_linear_x6_against_float64_and_the_exact_f32_kernel(M, N, K, relu):
-    gen = torch.Generator().manual_seed(M + N + K)
-    a = torch.randn((M, K), generator=gen).clamp(min=0)          # post-ReLU features
-    w = torch.randn((N, K), generator=gen) * (2.0 / K) ** 0.5
-    b = torch.randn((N,), generator=gen) * 0.1
-    ref = a.double() @ w.double().t() + b.double()
-    if relu:
-        ref = ref.clamp(min=0)
-    ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
-    npad = (N + 127) // 128 * 128
-    a_rec, w_rec = V.split_rows_x6(ad), V.split_rows_x6(wd, rows_out=npad)
-    y = V.linear_x6(a_rec, w_rec, bd, M, N, K, relu, want="float32")
-    torch.cuda.synchronize()
-    scale = float(ref.abs().max())
-    e6 = float((y.cpu().double() - ref).abs().max()) / scale
-    wpad = torch.zeros((npad, K), device="cuda")
-    wpad[:N] = wd
-    e32 = float((V.linear(ad, wpad, bd, N, relu).cpu().double() - ref).abs().max()) / scale
-    print("linear_x6 M=%d N=%d K=%d: max err / max|y| = %.3g (exact-f32 MFMA kernel %.3g)" % (M, N, K, e6, e32))
-    assert e6 <= 1.5 * e32 + 2e-7 and e6 <= 4e-6 * np.sqrt(K)
-    # run-to-run identical (deterministic split-K)
-    y2 = V.linear_x6(a_rec, w_rec, bd, M, N, K, relu, want="float32")
-    assert torch.equal(y, y2)
-    if N % 16 == 0:
-        # the records the reduction emits for the next layer == the split of its float32 output
-        y_rec = V.linear_x6(a_rec, w_rec, bd, M, N, K, relu, want="records")
-        assert torch.equal(y_rec, V.split_rows_x6(y))
-
-
-def test_linear_x6_rejects_bad_arguments():
-    lib = nv.lib()
-    s = nv.stream_ptr()
-    x = torch.zeros((1 << 20,), device="cuda")
-    p = nv.ptr(x)
-    assert lib.frcnn_linear_x6(None, p, p, p, 128, None, 8, 128, 64, 0, p, 1 << 22, s) == -1
-    assert lib.frcnn_linear_x6(p, p, p, p, 128, None, 321, 128, 64, 0, p, 1 << 22, s) == -4        # M > 320
-    assert lib.frcnn_linear_x6(p, p, p, p, 128, None, 8, 128, 40, 0, p, 1 << 22, s) == -4         # K % 16
-    assert lib.frcnn_linear_x6(p, p, p, None, 128, None, 8, 128, 64, 0, p, 1 << 22, s) == -1      # no output
-    assert lib.frcnn_linear_x6(p, p, p, p, 128, None, 8, 128, 64, 0, p, 16, s) == -1              # scratch too small
-    assert lib.frcnn_linear_x6_workspace_bytes(300, 4096, 25088) == 8 * 300 * 4096 * 4
-    assert lib.frcnn_split_rows_x6(p, 40, p, 4, 4, 40, s) == -1                                    # K % 16
-
-
 def test_model_fc_modes_agree_and_both_reproduce_the_golden_vectors(gpu_model, golden_dir):
-    """fc_math_mode "f32x3" (default since the f32x3 kernels), "f32x6", "f32", "f32x6_v1": same proposals bit for bit (the RPN does not
+    """fc_math_mode "f32x3" (default since the f32x3 kernels), "f32x6", "f32": same proposals bit for bit (the RPN does not
     depend on fc1 / fc2), class probabilities within 1e-5, the same detections; and all reproduce the reference's golden detections."""
     assert gpu_model.fc_math_mode == "f32x3"
     g = np.load(os.path.join(golden_dir, "vgg16_600x1000_s0.npz"))
     img = synthetic.image(0).unsqueeze(0).cuda()
     out = {}
     try:
-        for mode in ("f32x6", "f32", "f32x6_v1", "f32x3"):
+        for mode in ("f32x6", "f32", "f32x3"):
             gpu_model.fc_math_mode = mode
             out[mode] = (gpu_model(image_data=img), gpu_model.predict(image_data=img, score_threshold=0.05))
     finally:
@@ -104,11 +40,9 @@ def test_model_fc_modes_agree_and_both_reproduce_the_golden_vectors(gpu_model, g
     assert torch.equal(p6, p32)
     assert float((c6 - c32).abs().max()) <= 1e-5 and float((d6 - d32).abs().max()) <= 2e-5 * max(1.0, float(d32.abs().max()))
     ref = g["detections"]
-    (pv, cv, dv), detv = out["f32x6_v1"]
-    assert torch.equal(pv, p6) and float((cv - c6).abs().max()) <= 1e-5          # round 2's kernel, same arithmetic, another summation order
     (p3, c3, d3), det3 = out["f32x3"]
     assert torch.equal(p3, p6) and float((c3 - c32).abs().max()) <= 1e-5 and float((d3 - d32).abs().max()) <= 2e-5 * max(1.0, float(d32.abs().max()))
-    for mode, det in (("f32x6", det6), ("f32", det32), ("f32x6_v1", detv), ("f32x3", det3)):
+    for mode, det in (("f32x6", det6), ("f32", det32), ("f32x3", det3)):
         n_ok = 0
         for c in range(1, 21):
             r = ref[ref[:, 0] == c][:, 1:]
@@ -120,14 +54,15 @@ def test_model_fc_modes_agree_and_both_reproduce_the_golden_vectors(gpu_model, g
         # the floor of the held-out sweep (tests/test_holdout_gpu.py, tests/test_model_gpu.py: ROW_FRACTION_FLOOR), not the count one
         # table happens to reach on this image: with the round-4 default conv table one 599 px box sits at 1.04e-3 px (193 / 194)
         assert n_ok >= 0.99 * len(ref)
-    with pytest.raises(ValueError):
-        gpu_model.fc_math_mode = "bf16"
+    for bad in ("bf16", "f32x6_v1"):             # ("f32x6_v1" named round 2's kernel: removed)
+        with pytest.raises(ValueError):
+            gpu_model.fc_math_mode = bad
 
 
 @pytest.mark.parametrize("M,N,K,relu", [(300, 4096, 25088, True), (300, 4096, 4096, True), (400, 256, 512, False), (700, 128, 160, True), (1, 4, 16, False)])
 def test_linear_x6t_against_float64_and_the_exact_f32_kernel(M, N, K, relu):
-    """Round 3: fc1 / fc2 on csrc/gemm_x6t.hip (tile records, LDS-DMA staging) -- the same f32x6 arithmetic as linear_x6_kernel with no
-    320-row limit (ADVICE r2 / VERDICT r2 #8): held to the same error bar against float64."""
+    """Round 3: fc1 / fc2 on csrc/gemm_x6t.hip (tile records, LDS-DMA staging) -- the f32x6 arithmetic at any row count (ADVICE r2 /
+    VERDICT r2 #8): held to the fp32-class error bar against float64."""
     gen = torch.Generator().manual_seed(M + N + K)
     a = torch.randn((M, K), generator=gen).clamp(min=0)
     w = torch.randn((N, K), generator=gen) * (2.0 / K) ** 0.5
@@ -146,7 +81,7 @@ def test_linear_x6t_against_float64_and_the_exact_f32_kernel(M, N, K, relu):
     wpad[:N] = wd
     e32 = float((V.linear(ad, wpad, bd, N, relu).cpu().double() - ref).abs().max()) / scale
     print("linear_x6t M=%d N=%d K=%d: max err / max|y| = %.3g (exact-f32 MFMA kernel %.3g)" % (M, N, K, e6, e32))
-    # Bar: 2x the exact-f32 kernel's error + 3e-7 of max|y|.  Measured (tools/exp_x6_error.py): the error of the f32x6 arithmetic grows
+    # Bar: 2x the exact-f32 kernel's error + 3e-7 of max|y|.  Measured in round 3: the error of the f32x6 arithmetic grows
     # with the square root of the number of MFMA accumulations in one chain (6 per 16-k stage) and one bf16-MFMA accumulation is worth
     # ~3.6 float32 roundings; a 32-stage unsplit chain (K = 512: rms 7.3e-8, max 6.5e-7) is the worst case, deeper reductions are
     # split into shorter chains (K = 2048: 2.3e-7 = the exact-f32 kernel's).  fp32 class throughout: 4e-6 sqrt(K) is the common bar.
@@ -177,7 +112,7 @@ def test_model_with_more_than_320_proposals_runs_in_the_x6_arithmetic(sd_cpu):
     assert ok.mean() >= 0.98 and float(np.abs(c.cpu().numpy()[j[ok]] - rc.numpy()[ok]).max()) <= 1e-4
     det = model.predict(image_data=img.cuda(), score_threshold=0.05)
     assert sorted(det.keys()) == list(range(1, 21))
-    model.fc_math_mode = "f32x6_v1"
-    assert model._effective_fc_math() == "f32"               # round 2's kernel: silently the exact-f32 kernel above 320 rows
+    model.fc_math_mode = "f32x6"
+    assert model._effective_fc_math() == "f32x6"
     p2, c2, d2 = model(image_data=img.cuda())
     assert torch.equal(p2, p) and float((c2 - c).abs().max()) <= 1e-5

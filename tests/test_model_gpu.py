@@ -405,11 +405,11 @@ def test_state_dict_roundtrip_repacks(gpu_model, sd_cpu):
 
 
 # ---------------------------------------------------------------------------------------------
-# The other math modes -- "f32" (every 3x3 layer on the direct exact-f32 kernel; the default is
-# "f32_winograd", which the tests above exercise) and "f32x6" (bf16x3-split operands, six bf16 MFMAs
-# per product): the SAME end-to-end thresholds as the default mode
+# The other math mode -- "f32" (every 3x3 layer on the direct exact-f32 kernel; the default is
+# "f32_winograd", which the tests above exercise): the SAME end-to-end thresholds as the default mode.
+# (Round 2's "f32x6" mode, a direct convolution on split bf16 operands, was removed with its kernel in ABI 13.)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["f32", "f32x6"])
+@pytest.mark.parametrize("mode", ["f32"])
 @pytest.mark.parametrize("tag,allow_edge", CASES[:2])
 def test_other_math_modes_end_to_end(gpu_model, golden_dir, oracle_runs, tag, allow_edge, mode):
     g, img = load_case(golden_dir, tag)
@@ -436,13 +436,14 @@ def test_other_math_modes_end_to_end(gpu_model, golden_dir, oracle_runs, tag, al
                 jj, ee = match_rows(det[c], r)
                 n_ok += int(((ee <= 1e-3) & (np.abs(det[c][jj, 4] - r[:, 4]) <= 1e-4)).sum())
         print("%s predict %s: %d/%d reference detections reproduced" % (mode, tag, n_ok, len(refd)))
-        # f32x6 reproduces every detection; the all-direct f32 mode is allowed the 3 of 194 that round 1 documented as its
+        # the all-direct f32 mode is allowed the 3 of 194 that round 1 documented as its
         # inherent RPN-rank flips at 600x1000 (194/194 with the round-2 kernels, 191/194 with round 1's)
         assert n_ok >= len(refd) - (3 if mode == "f32" else 0)
     finally:
         gpu_model.math_mode = "f32_winograd"
-    with pytest.raises(ValueError):
-        gpu_model.math_mode = "bf16"
+    for bad in ("bf16", "f32x6"):
+        with pytest.raises(ValueError):
+            gpu_model.math_mode = bad
 
 
 # ---------------------------------------------------------------------------------------------

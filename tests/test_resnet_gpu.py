@@ -320,7 +320,7 @@ def test_resnet50_direct_mode_agrees_with_default_winograd_mode(r50):
     print("ResNet-50 f32 vs f32_winograd: %d/%d of proposals within 1e-3 px" % (int(ok.sum()), len(ok)))
     assert ok.mean() >= 0.99                                  # the held-out floor; measured: 300 / 300
     assert np.abs(a[1].cpu().numpy()[j[ok]] - b[1].cpu().numpy()[ok]).max() <= 2e-4
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         model.math_mode = "f32x6"
 
 

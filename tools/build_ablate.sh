@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds timing-experiment variants of libfrcnn_hip.so into build/ (git-ignored, shipped by gpurun):
 #   tools/build_ablate.sh NAME "-DWF_ABLATE=3 ..."   ->  build/libfrcnn_NAME.so   (use with FRCNN_LIB_PATH=build/libfrcnn_NAME.so)
-#   SRC=linear_x6 tools/build_ablate.sh NAME -DLX_ABLATE=3
+#   SRC=gemm_x3t tools/build_ablate.sh NAME -DHX_ABLATE=3
 #   SRC="wino_x3f wino_x3e" tools/build_ablate.sh xdclk -DXD_CLOCKS
 # Only csrc/$SRC.hip (default winofused; several names allowed) are recompiled with the extra flags; the other objects come from the regular build.
 set -e

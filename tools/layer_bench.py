@@ -52,7 +52,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
-    ap.add_argument("--x6", action="store_true", help="time the f32x6 (bf16x3 split) conv kernels")
     ap.add_argument("--winograd", action="store_true", help="time the Winograd F(2x2,3x3) path for layers with cout %% 128 == 0 "
                     "(TF column = direct-convolution FLOP / time)")
     ap.add_argument("--fused", action="store_true", help="time the ONE-launch Winograd layer (csrc/winofused.hip); TF column = "
@@ -75,10 +74,6 @@ def main():
             continue
         x = torch.randn((h, w, cin), device=dev)
         wp = torch.randn((9, cout, cin), device=dev) * 0.02
-        if args.x6:
-            w_oihw = torch.randn((cout, cin, 3, 3), device=dev) * 0.02
-            wq = torch.empty((9 * cout * cin * 3,), dtype=torch.int16, device=dev)
-            nv.check(lib.frcnn_pack_conv3x3_x6(nv.ptr(w_oihw), nv.ptr(wq), cout, cin, s), "pack_x6")
         b = torch.zeros((cout,), device=dev)
         oh, ow = (h // 2, w // 2) if pool else (h, w)
         y = torch.empty((oh, ow, cout), device=dev)
@@ -95,7 +90,7 @@ def main():
             nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(w_oihw), None, nv.ptr(wu), cout, cin, s), "pack_winograd")
             wsb = int(lib.frcnn_conv3x3_winograd_workspace_bytes(1, h, w, cin, cout))
         else:
-            wsb = (160 << 20) if args.x6 else int(lib.frcnn_conv3x3_workspace_bytes(h, w, cin, cout))
+            wsb = int(lib.frcnn_conv3x3_workspace_bytes(h, w, cin, cout))
         ws = torch.empty((max(wsb, 4) // 4,), device=dev)
         flags = nv.RELU | (nv.POOL2 if pool else 0)
 
@@ -106,9 +101,6 @@ def main():
             elif wino:
                 nv.check(lib.frcnn_conv3x3_nhwc_winograd(nv.ptr(x), nv.ptr(wu), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags,
                                                          nv.ptr(ws), wsb, s), "conv_winograd")
-            elif args.x6:
-                nv.check(lib.frcnn_conv3x3_nhwc_x6(nv.ptr(x), nv.ptr(wq), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
-                                                   nv.ptr(ws), wsb, s), "conv_x6")
             else:
                 nv.check(lib.frcnn_conv3x3_nhwc(nv.ptr(x), nv.ptr(wp), nv.ptr(b), nv.ptr(y), h, w, cin, cout, flags,
                                                 nv.ptr(ws), wsb, s), "conv")
@@ -149,22 +141,6 @@ def main():
             nv.check(lib.frcnn_linear(nv.ptr(a), k, nv.ptr(wt), nv.ptr(b), nv.ptr(y), n, m, n, k, nv.RELU, nv.ptr(ws), wsb, s), "linear")
         us = timeit(run, args.reps)
         print("%-8s M=%d N=%d K=%d  %8.1f us  %6.1f TF" % (name, m, n, k, us, 2.0 * m * n * k / us / 1e6))
-        if m <= 320 and n % 16 == 0 and name.startswith("fc"):
-            from fasterrcnn_amd.models import vgg16 as V
-            a_rec, w_rec = V.split_rows_x6(a), V.split_rows_x6(wt, rows_out=n)
-            y_rec = torch.empty((nv.LINEAR_X6_ROWS * (n // 16) * 96,), dtype=torch.uint8, device=dev)
-            wsb6 = int(lib.frcnn_linear_x6_workspace_bytes(m, n, k))
-            ws6 = torch.empty((wsb6 // 4,), device=dev)
-
-            def run6():
-                nv.check(lib.frcnn_linear_x6(nv.ptr(a_rec), nv.ptr(w_rec), nv.ptr(b), nv.ptr(y), n, nv.ptr(y_rec), m, n, k, nv.RELU,
-                                             nv.ptr(ws6), wsb6, s), "linear_x6")
-            us = timeit(run6, args.reps)
-            print("%-8s x6 (bf16x3 split, six MFMAs per product)  %8.1f us  %6.1f TF fp32-equivalent" % (name, us, 2.0 * m * n * k / us / 1e6))
-
-            def run_split():
-                nv.check(lib.frcnn_split_rows_x6(nv.ptr(a), k, nv.ptr(a_rec), m, nv.LINEAR_X6_ROWS, k, s), "split")
-            print("%-8s split of the activations  %8.1f us" % (name, timeit(run_split, args.reps)))
 
 
 if __name__ == "__main__":
