@@ -40,7 +40,7 @@ static constexpr size_t XD_LDS_BYTES = XD_CM_OFFSET + 512 * 4;                //
 
 template <int N> struct XdInt { static constexpr int value = N; };
 #ifndef XD_ABLATE
-#define XD_ABLATE 0          // timing experiments (tools/build_ablate.sh): 1 no operand VALU, 2 no patch reads / r, 4 no filter loads, 8 no halo traffic, 16 no MFMAs
+#define XD_ABLATE 0          // timing experiments (tools/build_ablate.sh): 1 no operand VALU, 2 no patch reads / r, 4 no filter loads, 8 no halo traffic, 16 no MFMAs, 32 / 64 the prologue's loads (wino_x3f.hip)
 #endif
 
 // maximum over the aligned group of 16 lanes a lane belongs to (a DPP row): four row rotations, no LDS (a __shfl_xor is a ds_bpermute)

@@ -35,6 +35,11 @@ namespace frcnn {
 // A PERSISTENT form of the kernel (one block per CU walking its items, the next item's loads issued at the start of the epilogue, the Y
 // buffer next to the ring instead of over it) was built and measured: the loads hide completely (0.02 us of wait) -- and the item costs
 // the same, because prologue and epilogue are bound by instruction issue (~5 cycles each), not by the round trip; not in the tree.
+// Round 5 (profiles/r05/xd_clocks_prologue_ablation.txt, XD_ABLATE 32 / 64): WITHOUT the prologue's filter and halo loads a block spends
+// 1.9-2.0 us before its loop instead of 3.1-4.4 -- the 164 one-kilobyte loads of a block are 16 address cycles each on the CU's one
+// texture-address unit, wherever they are issued (that is what the persistent form moved into its epilogue).  A form that carried the
+// next item's pieces in the loop's own, today clamped and wasted, load slots could win that 1.1-2.5 us (3-7 % of a launch); the address
+// arithmetic (1.0 us), the first operand (0.35 us) and the 3.8-4.5 us after the loop would remain.  Not built.
 template <bool POOL>
 __global__ __launch_bounds__(256, 1)
 void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__ cmax_maps, const unsigned char* __restrict__ ublob,
@@ -309,20 +314,21 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #pragma unroll
     for (int q = 0; q < 2; ++q)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(mrs, (xd_lds_ptr)(smem_xf + XD_CM_OFFSET + (q * 4 + wave_u) * 256), 4, cm_src[q], 0, 0, 0);
-    load_u(0, XdInt<0>{}, XdInt<0>{}); load_u(0, XdInt<0>{}, XdInt<1>{}); load_u(0, XdInt<0>{}, XdInt<2>{}); load_u(0, XdInt<0>{}, XdInt<3>{});
+    if (!(XD_ABLATE & 32)) { load_u(0, XdInt<0>{}, XdInt<0>{}); load_u(0, XdInt<0>{}, XdInt<1>{}); load_u(0, XdInt<0>{}, XdInt<2>{}); load_u(0, XdInt<0>{}, XdInt<3>{}); }
     __builtin_amdgcn_global_load_lds(uinv0, (xd_lds_ptr)(smem_xf + XD_SC_OFFSET + wave_u * 1024), 16, 0, 0);
     if (wave_u == 0 && lane < 16) __builtin_amdgcn_global_load_lds(bias + 64 * cb + 4 * lane, (xd_lds_ptr)(smem_xf + XD_SC_OFFSET + 4096), 16, 0, 0);
     XD_FENCE();
     halo_sources();                                                          // (under the loads above)
     XD_FENCE();
-    dma_halo(hcur, 0, XdInt<0>{}, XdInt<XD_NDMA>{});
-    dma_halo(hnxt, (K16 > 1 ? 1 : 0) * 64, XdInt<0>{}, XdInt<XD_NDMA>{});
-    dma_halo(hthird, (K16 > 2 ? 2 : K16 - 1) * 64, XdInt<0>{}, XdInt<XD_NDMA>{});
+    // (XD_ABLATE 32 / 64, timing experiments: what the block pays for the prologue's loads -- 32: no filter pieces, no halo; 64: halo(0) only)
+    if (!(XD_ABLATE & 32)) dma_halo(hcur, 0, XdInt<0>{}, XdInt<XD_NDMA>{});
+    if (!(XD_ABLATE & (32 | 64))) dma_halo(hnxt, (K16 > 1 ? 1 : 0) * 64, XdInt<0>{}, XdInt<XD_NDMA>{});
+    if (!(XD_ABLATE & (32 | 64))) dma_halo(hthird, (K16 > 2 ? 2 : K16 - 1) * 64, XdInt<0>{}, XdInt<XD_NDMA>{});
     XD_FENCE();
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_issued = __builtin_amdgcn_s_memrealtime();
 #endif
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XD_NDMA) : "memory");       // everything but halo(1) and halo(2): the maxima, the scales, halo(0) and the first filter pieces are in
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD_ABLATE & (32 | 64)) ? 0 : 2 * XD_NDMA) : "memory");       // everything but halo(1) and halo(2): the maxima, the scales, halo(0) and the first filter pieces are in
     xd_lds_barrier();
     {   // the lane's two tile scales from the halo pixels' channel maxima (rows 4 h + 2 tyl + a, columns 2 txl + c)
         const float* cm = reinterpret_cast<const float*>(smem_xf + XD_CM_OFFSET) + (2 * tyl) * XF_HC + 2 * txl;

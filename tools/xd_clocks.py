@@ -54,5 +54,7 @@ if __name__ == "__main__":
               ("conv3_2", 256, 256, 150, 250, False), ("conv3_3", 256, 256, 150, 250, True), ("conv4_2", 512, 512, 75, 125, False),
               ("conv5_x", 512, 512, 37, 62, False)]:
         c4 = run(*a, force=nv.X3F_WAVES4)
+        if "four" in sys.argv[1:]:          # (the four-wave kernel only: ablation builds of csrc/wino_x3f.hip)
+            continue
         c8 = run(*a, force=nv.X3F_WAVES8)
         print("   => cycles per chunk: four waves %.0f, eight waves %.0f per wave pair (1536 = the MFMAs alone)" % (c4, c8))
