@@ -324,10 +324,16 @@ def make_boxes(n, seed, clusters=40):
     return b
 
 
-@pytest.mark.parametrize("n,thr,quant", [(0, 0.7, False), (1, 0.7, False), (63, 0.7, False), (64, 0.5, False),
-                                         (65, 0.3, False), (1000, 0.7, True), (6000, 0.7, False), (8000, 0.3, True)])
-def test_nms_vs_oracle(ctx, n, thr, quant):
-    b = make_boxes(n, n + 1)
+@pytest.mark.parametrize("n,thr,quant,clusters,max_keep", [
+    (0, 0.7, False, 40, 2048), (1, 0.7, False, 40, 2048), (63, 0.7, False, 40, 2048), (64, 0.5, False, 40, 2048),
+    (65, 0.3, False, 40, 2048), (1000, 0.7, True, 40, 2048), (6000, 0.7, False, 40, 2048), (8000, 0.3, True, 40, 2048),
+    # round 5 (nms_reduce_kernel's look-ahead ring): few clusters = long runs of chunks that keep nothing; thousands of clusters = chunks
+    # that keep more rows than the ring defers; > 8192 candidates = the second half of removed[]; small max_keep = the early exit
+    (6000, 0.7, False, 3, 2048), (6000, 0.5, False, 3000, 2048), (6000, 0.7, False, 40, 10), (6000, 0.7, False, 3000, 300),
+    (12000, 0.5, False, 40, 2048), (16384, 0.7, True, 400, 2048), (16384, 0.6, False, 8000, 2048), (8193, 0.7, False, 40, 2048),
+    (257, 0.7, False, 40, 2048), (320, 0.7, False, 1, 2048)])
+def test_nms_vs_oracle(ctx, n, thr, quant, clusters, max_keep):
+    b = make_boxes(n, n + 1, clusters)
     rng = np.random.RandomState(n)
     s = rng.rand(n).astype(np.float32)
     if quant:
@@ -336,8 +342,8 @@ def test_nms_vs_oracle(ctx, n, thr, quant):
     nk = torch.full((1,), -1, dtype=torch.int32, device=DEV)
     bb = gpu(b) if n else torch.zeros((1, 4), device=DEV)
     ss = gpu(s) if n else torch.zeros((1,), device=DEV)
-    nv.check(nv.lib().frcnn_nms(ctx.handle, nv.ptr(bb), nv.ptr(ss), n, thr, 2048, nv.ptr(keep), nv.ptr(nk), S()), "nms")
-    ref = O.nms(b, s, thr)[:2048]
+    nv.check(nv.lib().frcnn_nms(ctx.handle, nv.ptr(bb), nv.ptr(ss), n, thr, max_keep, nv.ptr(keep), nv.ptr(nk), S()), "nms")
+    ref = O.nms(b, s, thr)[:max_keep]
     got = keep.cpu().numpy()[: int(nk.item())]
     assert int(nk.item()) == len(ref)
     assert np.array_equal(got, ref.astype(np.int32))
