@@ -379,72 +379,143 @@ void conv3x3_c3_kernel(const float* __restrict__ x, const float* __restrict__ wp
     }
 }
 
-// The same layer for Cout = 64 with coalesced output stores (round 2): block = 8 rows x 64 consecutive pixels, thread =
-// (pixel p = t >> 4 (+16 per round), cout quad q = t & 15): the 16 lanes of a pixel write its 256 output bytes together and
-// a wave's store instruction covers four adjacent pixels = 1 KB contiguous (the pixel-per-thread kernel above stores 16 bytes
-// at a 256-byte lane stride: 81 us for the 153.6 MB of a 600x1000 image = 2 TB/s).  The 3 x 3 x 66 input patch of the block
-// is staged in LDS (zero padding folded in), the quad's 27 x 4 weights live in registers; the fmaf order over k = ci*9 + r*3 + s
-// is the one of the kernel above (bit-identical results).
+// The same layer for Cout = 64 (conv1_1).  Thread = (four adjacent pixels of a row, cout quad q = t & 15): the 16 lanes of a pixel write its
+// 256 output bytes together (the pixel-per-thread kernel above stores 16 bytes at a 256-byte lane stride: 81 us for the 153.6 MB of a
+// 600x1000 image); the input patch of a tile is staged in LDS (zero padding folded in), the quad's 27 x 4 weights live in registers.
 // cmax_out (optional): the per-pixel maximum over the 64 output channels, [H][W] -- the scale source of an f32x3 layer that consumes this
 // tensor (csrc/wino_x3f.hip).  The 16 lanes of a pixel hold all of its channels, so it is four DPP row rotations and ONE plain store per
 // pixel: no atomics, no zeroed buffer, and the consumer does not read the 153.6 MB tensor once more (pixel_absmax_kernel).
-__global__ __launch_bounds__(256)
-void conv3x3_c3_q16_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-                           float* __restrict__ y, int H, int W, int relu, float* __restrict__ cmax_out)
+// Round 5: a PERSISTENT kernel (two blocks per CU walk the 2-row x 64-pixel tiles of the image).  What round 2's kernel (block = 8 rows x
+// 64 pixels, one block per tile) paid on a 600x1000 image (51-53 us = 2.9 TB/s of output; issue-bound estimate of its instruction stream: 28 us):
+// 1200 blocks on 768 block slots = two rounds with the second half empty, a prologue per block (27 weight quads, the input patch with two
+// integer divisions per element) that nothing overlapped, and 15 LDS reads per 54 packed FMAs.  Here the weights are loaded once per block, the next tile's
+// input patch is fetched into registers before the current tile is computed (its element -> (channel, row, column) split is tile
+// independent: done once), 4800 tiles over 512 blocks leave a 7 % tail, and a thread owns FOUR ADJACENT pixels of a row so that the 3 x 6
+// input values of a (channel, row) are one ds_read_b128 + one ds_read_b64 for 24 packed FMAs.  The fmaf order over k = ci*9 + r*3 + s per
+// output is the one of conv3x3_c3_kernel: bit-identical results (tests/test_kernels_gpu.py compares the two).  Measured: 36.6 us alone
+// (4.2 TB/s), two blocks per CU (three: 38.0); one image at a time +0.5 %; with three images in flight the headline does not move
+// (846 / 846 images/sec, A/B on one box) -- conv1_1 runs in the gaps of the Winograd launches there.
+typedef float c3_f32x2 __attribute__((ext_vector_type(2)));
+template <bool RELU, bool CMAX, int BPC>
+__global__ __launch_bounds__(256, BPC)
+void conv3x3_c3_p_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                         float* __restrict__ y, int H, int W, float* __restrict__ cmax_out, int tiles_x, int ntiles)
 {
-    constexpr int COUT = 64, SEG = 64, ROWS = 8;          // 8 rows x 64 pixels per block: the quad's weights are loaded once per 512 pixels
-    __shared__ float in_s[3][ROWS + 2][SEG + 2];
-    const int y0 = blockIdx.y * ROWS, x0 = blockIdx.x * SEG;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 3 * (ROWS + 2) * (SEG + 2); i += 256) {
-        const int ci = i / ((ROWS + 2) * (SEG + 2)), rem = i - ci * (ROWS + 2) * (SEG + 2);
+    constexpr int COUT = 64, SEG = 64, ROWS = 2, LW = 68;      // LW: floats per staged row (66 used; 272 B keeps the 16-byte reads aligned)
+    constexpr int NEL = 3 * (ROWS + 2) * (SEG + 2);             // 792 input values per tile
+    __shared__ __attribute__((aligned(16))) float in_s[2][3][ROWS + 2][LW];
+    const int tid = threadIdx.x, q = tid & 15, g = tid >> 4;
+    // this thread's (up to four) elements of a tile's input patch, once: the offset from the tile's origin in x, and (row, column, LDS
+    // offset) packed into one register (bits 0-6 column, 8-10 row, 12-.. LDS offset; -1: no element)
+    int e_off[4], e_rc[4];
+    const int HW = H * W;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = tid + 256 * k;
+        const int ci = e / ((ROWS + 2) * (SEG + 2)), rem = e - ci * (ROWS + 2) * (SEG + 2);
         const int r = rem / (SEG + 2), c = rem - r * (SEG + 2);
-        const int gy = y0 + r - 1, gx = x0 + c - 1;
-        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        in_s[ci][r][c] = inb ? x[((size_t)ci * H + gy) * W + gx] : 0.f;
+        e_off[k] = ci * HW + (r - 1) * W + c - 1;
+        e_rc[k] = e < NEL ? (c | (r << 8) | (((ci * (ROWS + 2) + r) * LW + c) << 12)) : -1;
     }
-    const int q = tid & 15, p0 = tid >> 4;
+    auto fetch = [&](int tile, float (&v)[4]) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y0 = ty * ROWS, x0 = tx * SEG;
+        const int base = y0 * W + x0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gy = y0 + ((e_rc[k] >> 8) & 7) - 1, gx = x0 + (e_rc[k] & 127) - 1;
+            const bool inb = e_rc[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            v[k] = inb ? x[base + e_off[k]] : 0.f;
+        }
+    };
+    auto stage = [&](int buf, const float (&v)[4]) {
+        float* dst = &in_s[buf][0][0][0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e_rc[k] >= 0) dst[e_rc[k] >> 12] = v[k];
+    };
     f32x4 wq[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) wq[k] = *reinterpret_cast<const f32x4*>(wp + k * COUT + 4 * q);
     const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    {
+        float v[4];
+        fetch(tile, v);
+        stage(0, v);
+    }
     __syncthreads();
-    for (int row = 0; row < ROWS; ++row) {
-        const int yy = y0 + row;
-        if (yy >= H) break;
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        float nv_[4];
+        if (next < ntiles) fetch(next, nv_);                    // (in flight under the tile's arithmetic)
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y0 = ty * ROWS, x0 = tx * SEG;
 #pragma unroll
-        for (int round = 0; round < SEG / 16; ++round) {
-            const int p = p0 + 16 * round;
-            if (x0 + p >= W) break;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int row = 0; row < ROWS; ++row) {
+            const int yy = y0 + row;
+            if (yy >= H) break;
+            // One v_pk_fma_f32 per (pixel, channel pair, tap), the input value broadcast from its half of a register pair by op_sel.  Inline
+            // assembly: left to the compiler the nest was packed across pixels and spilled (SLP), or -- written with two-float vectors --
+            // got a v_mov per odd-positioned input value to build (v, v) pairs.
+            c3_f32x2 acc[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = c3_f32x2{0.f, 0.f};
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
+                for (int r = 0; r < 3; ++r) {
+                    const float* src = &in_s[buf][ci][row + r][4 * g];
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+                    c3_f32x2 pr[3];
+                    pr[0] = c3_f32x2{a[0], a[1]}; pr[1] = c3_f32x2{a[2], a[3]};
+                    pr[2] = *reinterpret_cast<const c3_f32x2*>(src + 4);
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) {
-                        const float v = in_s[ci][row + r][p + s];
-                        const f32x4 w4 = wq[ci * 9 + r * 3 + s];
+                    for (int s_ = 0; s_ < 3; ++s_) {
+                        const f32x4 w4 = wq[ci * 9 + r * 3 + s_];
+                        const c3_f32x2 wlo = {w4[0], w4[1]}, whi = {w4[2], w4[3]};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j] = fmaf(v, w4[j], acc[j]);
+                        for (int i = 0; i < 4; ++i) {
+                            const int k = i + s_;
+                            if ((k & 1) == 0) {
+                                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[i][0]) : "v"(pr[k >> 1]), "v"(wlo));
+                                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[i][1]) : "v"(pr[k >> 1]), "v"(whi));
+                            } else {
+                                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc[i][0]) : "v"(pr[k >> 1]), "v"(wlo));
+                                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc[i][1]) : "v"(pr[k >> 1]), "v"(whi));
+                            }
+                        }
                     }
-            f32x4 o;
+                }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float t = acc[j] + bq[j];
-                o[j] = relu ? fmaxf(t, 0.f) : t;
-            }
-            *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + x0 + p) * COUT + 4 * q) = o;
-            if (cmax_out) {
-                // (post-ReLU values are >= 0; without ReLU the consumer wants the maximum MAGNITUDE)
-                float m = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
-                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x128, 0xf, 0xf, false)));   // row_ror:8
-                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x124, 0xf, 0xf, false)));   // row_ror:4
-                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x122, 0xf, 0xf, false)));   // row_ror:2
-                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x121, 0xf, 0xf, false)));   // row_ror:1
-                if (q == 0) cmax_out[(size_t)yy * W + x0 + p] = m;
+            for (int i = 0; i < 4; ++i) {
+                const int xx = x0 + 4 * g + i;
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = acc[i][j >> 1][j & 1] + bq[j];
+                    o[j] = RELU ? fmaxf(t, 0.f) : t;
+                }
+                if (xx < W) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * COUT + 4 * q) = o;
+                if (CMAX) {
+                    // (post-ReLU values are >= 0; without ReLU the consumer wants the maximum MAGNITUDE)
+                    const float mf = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                    // (magnitudes: non-negative floats order like their bit patterns -- the row reduction as unsigned maxima, one
+                    //  instruction per rotation instead of the four a float maximum with its NaN canonicalisation takes)
+                    unsigned m = __builtin_bit_cast(unsigned, mf);
+                    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));   // row_ror:8
+                    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));   // row_ror:4
+                    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x122, 0xf, 0xf, false));   // row_ror:2
+                    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x121, 0xf, 0xf, false));   // row_ror:1
+                    if (q == 0 && xx < W) cmax_out[(size_t)yy * W + xx] = __builtin_bit_cast(float, m);
+                }
             }
         }
+        if (next < ntiles) stage(buf ^ 1, nv_);
+        __syncthreads();
+        buf ^= 1;
     }
 }
 
@@ -596,7 +667,18 @@ int launch_conv3x3_c3(const float* x, const float* wp, const float* b, float* y,
     if (cout % 16 != 0 || H < 1 || W < 1) return FRCNN_EINVAL;
     if (cmax_out && cout != 64) return FRCNN_EINVAL;                        // only the 64-channel kernel holds a pixel's channels in one DPP row
     if (cout == 64) {
-        hipLaunchKernelGGL(conv3x3_c3_q16_kernel, dim3(cdiv(W, 64), cdiv(H, 8)), dim3(256), 0, s, x, wp, b, y, H, W, (flags & FRCNN_RELU) ? 1 : 0, cmax_out);
+        const int tiles_x = cdiv(W, 64), tiles_y = cdiv(H, 2);
+        if ((long long)tiles_x * tiles_y > 0x7fffffffLL) return FRCNN_EINVAL;
+        const int ntiles = tiles_x * tiles_y;
+        static const int cus = []() { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
+        static const int bpc = []() { const char* e = frcnn_knob("FRCNN_C3_BPC"); return e && atoi(e) == 3 ? 3 : 2; }();      // blocks per CU (A/B runs)
+        const int grid = ntiles < bpc * cus ? ntiles : bpc * cus;             // (launch bounds: the 27 weight quads stay in registers), each block walking its tiles
+        const bool relu = (flags & FRCNN_RELU) != 0;
+#define C3P_LAUNCH(R_, C_) do { if (bpc == 3) hipLaunchKernelGGL((conv3x3_c3_p_kernel<R_, C_, 3>), dim3(grid), dim3(256), 0, s, x, wp, b, y, H, W, cmax_out, tiles_x, ntiles); \
+                                else hipLaunchKernelGGL((conv3x3_c3_p_kernel<R_, C_, 2>), dim3(grid), dim3(256), 0, s, x, wp, b, y, H, W, cmax_out, tiles_x, ntiles); } while (0)
+        if (relu) { if (cmax_out) C3P_LAUNCH(true, true); else C3P_LAUNCH(true, false); }
+        else { if (cmax_out) C3P_LAUNCH(false, true); else C3P_LAUNCH(false, false); }
+#undef C3P_LAUNCH
         return check_launch();
     }
     dim3 grid(cdiv(H * W, 256), 1);

@@ -91,6 +91,30 @@ def test_conv3x3_c3(H, W):
     check_conv(y, x, w, b, True, False, "conv_c3 %dx%d" % (H, W))
 
 
+@pytest.mark.parametrize("H,W,relu", [(600, 1000, True), (33, 70, True), (1, 1, True), (2, 64, False), (5, 257, False), (601, 999, True)])
+def test_conv3x3_c3_matches_the_generic_kernel(H, W, relu):
+    """The 64-channel kernel of conv1_1 (round 5: persistent, four adjacent pixels per thread, packed FMAs) against the pixel-per-thread
+    kernel every other width runs on: the same fmaf chain per output, so the same bits.  (The generic kernel is reached with the filter
+    bank twice in a row: 128 output channels, the first 64 and the last 64 both = the layer.)"""
+    g = torch.Generator().manual_seed(H * 31 + W)
+    x = gpu(torch.randn((3, H, W), generator=g) * 60)
+    w = torch.randn((64, 3, 3, 3), generator=g) * 0.2
+    b = torch.randn((64,), generator=g)
+    lib = nv.lib()
+    w64, b64 = gpu(w), gpu(b)
+    w128, b128 = gpu(torch.cat([w, w])), gpu(torch.cat([b, b]))
+    wp64, wp128 = torch.empty((27, 64), device=DEV), torch.empty((27, 128), device=DEV)
+    nv.check(lib.frcnn_pack_conv3x3_c3(nv.ptr(w64), nv.ptr(wp64), 64, S()), "pack")
+    nv.check(lib.frcnn_pack_conv3x3_c3(nv.ptr(w128), nv.ptr(wp128), 128, S()), "pack")
+    fl = nv.RELU if relu else 0
+    y64 = torch.full((H, W, 64), float("nan"), device=DEV)
+    y128 = torch.full((H, W, 128), float("nan"), device=DEV)
+    nv.check(lib.frcnn_conv3x3_c3(nv.ptr(x), nv.ptr(wp64), nv.ptr(b64), nv.ptr(y64), H, W, 64, fl, S()), "conv_c3")
+    nv.check(lib.frcnn_conv3x3_c3(nv.ptr(x), nv.ptr(wp128), nv.ptr(b128), nv.ptr(y128), H, W, 128, fl, S()), "conv_c3")
+    assert not torch.isnan(y64).any()
+    assert torch.equal(y64, y128[:, :, :64]) and torch.equal(y64, y128[:, :, 64:])
+
+
 @pytest.mark.parametrize("H,W,relu", [(600, 1000, True), (33, 70, True), (1, 1, True), (5, 257, False)])
 def test_conv3x3_c3_leaves_the_channel_maxima(H, W, relu):
     """frcnn_conv3x3_c3_cmax (round 4): conv1_1 writes the per-pixel maximum |y| over its 64 output channels next to y -- the scale source of
