@@ -469,6 +469,9 @@ typedef unsigned gx_u32x2 __attribute__((ext_vector_type(2)));
 // MODE 1 (the train step's bf16 forward / data-gradient convolutions, conv_gather_bf16_kernel's arithmetic in this kernel's pipeline): one
 // bf16 term per value, LDS row = 32 bf16 + 8 of padding (80 B), one v_mfma_f32_32x32x16_bf16 per accumulator and 16 channels.
 static constexpr int GX_F32X3 = 0, GX_BF16 = 1;
+#ifndef GX_ABLATE
+#define GX_ABLATE 0      // timing experiments (tools/build_ablate.sh, results wrong): 1 = the weight side of a stage is neither split nor written to LDS, 2 = nor fetched
+#endif
 template <int TM, int TN, int WM, int WN, int D, int MODE = GX_F32X3>
 struct GatherX3Cfg {
     static constexpr int ROW = MODE == GX_F32X3 ? 72 : 40;                // 16-bit elements per LDS row
@@ -625,9 +628,11 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
 #pragma unroll
         for (int it = 0; it < C::NA; ++it)
             ar[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(a_off[it] | ((a_bad[it] << sh) & OUTSIDE)), so_a, 0));
+        if (!(GX_ABLATE & 2)) {
 #pragma unroll
         for (int it = 0; it < C::NB; ++it)
             br[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)b_off[it], so_b, 0));
+        }
         // advance without a branch (a branch here would cut the stage into several scheduling regions)
         const int adv = ld_stage + 1 < st_end ? 1 : 0;
         ld_stage += adv;
@@ -649,12 +654,14 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
                 *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW) = hi;
                 *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW + 16) = lo;
             }
+            if (!(GX_ABLATE & 1)) {
 #pragma unroll
             for (int it = 0; it < C::NB; ++it) {
                 gx_u32x2 hi, lo;
                 gx_split4(br[it], wmult, wbound, hi, lo);
                 *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW) = hi;
                 *reinterpret_cast<gx_u32x2*>(bd + it * 32 * GX_ROW + 16) = lo;
+            }
             }
         } else {
             auto to_bf16x4 = [](f32x4 v) {                      // round to nearest even: conv_gather_bf16_kernel's conversion
