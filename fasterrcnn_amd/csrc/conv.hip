@@ -489,6 +489,7 @@ void conv3x3_c3_p_kernel(const float* __restrict__ x, const float* __restrict__ 
                         }
                     }
                 }
+            unsigned pm[4];                                        // the four pixels' channel maxima (after the row reduction: in every lane of the 16)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int xx = x0 + 4 * g + i;
@@ -509,8 +510,13 @@ void conv3x3_c3_p_kernel(const float* __restrict__ x, const float* __restrict__ 
                     m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));   // row_ror:4
                     m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x122, 0xf, 0xf, false));   // row_ror:2
                     m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x121, 0xf, 0xf, false));   // row_ror:1
-                    if (q == 0 && xx < W) cmax_out[(size_t)yy * W + xx] = __builtin_bit_cast(float, m);
+                    pm[i] = m;
                 }
+            }
+            if (CMAX) {                                            // lanes q = 0 .. 3 of the 16 store pixels 0 .. 3: ONE 16-byte run per thread group and row
+                const unsigned mine = q == 0 ? pm[0] : q == 1 ? pm[1] : q == 2 ? pm[2] : pm[3];
+                const int xq = x0 + 4 * g + q;
+                if (q < 4 && xq < W) cmax_out[(size_t)yy * W + xq] = __builtin_bit_cast(float, mine);
             }
         }
         if (next < ntiles) stage(buf ^ 1, nv_);
