@@ -505,15 +505,20 @@ void conv3x3_c3_p_kernel(const float* __restrict__ x, const float* __restrict__ 
                     const float mf = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
                     // (magnitudes: non-negative floats order like their bit patterns -- the row reduction as unsigned maxima, one
                     //  instruction per rotation instead of the four a float maximum with its NaN canonicalisation takes)
-                    unsigned m = __builtin_bit_cast(unsigned, mf);
-                    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));   // row_ror:8
-                    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));   // row_ror:4
-                    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x122, 0xf, 0xf, false));   // row_ror:2
-                    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x121, 0xf, 0xf, false));   // row_ror:1
-                    pm[i] = m;
+                    pm[i] = __builtin_bit_cast(unsigned, mf);
                 }
             }
-            if (CMAX) {                                            // lanes q = 0 .. 3 of the 16 store pixels 0 .. 3: ONE 16-byte run per thread group and row
+            if (CMAX) {
+                // the four pixels' rotations side by side: a DPP instruction may not read its predecessor's result without wait states
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pm[i] = max(pm[i], (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm[i], 0x128, 0xf, 0xf, false));   // row_ror:8
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pm[i] = max(pm[i], (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm[i], 0x124, 0xf, 0xf, false));   // row_ror:4
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pm[i] = max(pm[i], (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm[i], 0x122, 0xf, 0xf, false));   // row_ror:2
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pm[i] = max(pm[i], (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm[i], 0x121, 0xf, 0xf, false));   // row_ror:1
+                // lanes q = 0 .. 3 of the 16 store pixels 0 .. 3: ONE 16-byte run per thread group and row
                 const unsigned mine = q == 0 ? pm[0] : q == 1 ? pm[1] : q == 2 ? pm[2] : pm[3];
                 const int xq = x0 + 4 * g + q;
                 if (q < 4 && xq < W) cmax_out[(size_t)yy * W + xq] = __builtin_bit_cast(float, mine);
