@@ -674,7 +674,9 @@ void nms_reduce_kernel(const u64* __restrict__ mask, int nw_stride, const int32_
             unsigned char* slot = ring + p * NMS_SLOT_BYTES;
             issue_band(p, slot);
 #pragma unroll
-            for (int u = 0; u < NMS_PIECES; ++u) dma_piece(0, false, slot + 1024 + u * 1024);
+            // (with `wide` the odd places are row 0's UPPER half, as the main loop's filler: chunks 0 and 1 OR the odd pieces into words
+            //  128 .. 255 -- the lower half there made box 0 remove candidate 8192 + j with every box j it removes: ADVICE r5)
+            for (int u = 0; u < NMS_PIECES; ++u) dma_piece(0, wide && (u & 1), slot + 1024 + u * 1024);
         }
         for (int c = 0; c < nw; ++c) {
             NMS_T(0);

@@ -162,43 +162,50 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         du1 = *reinterpret_cast<const f32x4*>(p1 + 4);
         dw1 = *reinterpret_cast<const f32x4*>(p2 + 4);
     };
-    // u + sgn w as ONE fused operation == u +- w rounded once (sgn w is exact)
-    auto make_r = [&](int bb, int half) {
-        if (half == 0) {
+    // u + sgn w as ONE fused operation == u +- w rounded once (sgn w is exact).  Round 6: columns 1 and 2 are kept SCALED by their half's
+    // tile scale 2^e (exact: a power of two), because every V below is then the scaled t in ONE rounding without a multiply of its own --
+    // V0 2^e = fma(r0, 2^e, -r2s), V1 2^e = r1s + r2s, V2 2^e = r2s - r1s, V3 2^e = fma(r3, -2^e, r1s) -- and the fp16 hi term of a channel
+    // PAIR is one v_cvt_pk_f16_f32 of the scaled t instead of two v_fma_mix (tools/micro/split_fill.hip, profiles/r06/micro_split_fill.txt:
+    // every f32 <-> f16 converting instruction is half rate, ~8 cycles against 4.5 for a plain one, beside MFMAs or not; a step of six
+    // MFMAs with this split measures 267 cycles against 310).  Same bits: the scaling commutes with every rounding.
+    // (the multiply as volatile asm: the compiler otherwise sinks it from the gap it was placed in to the column's first use, four steps later)
+    auto make_r = [&](int bb, int half, int hs) {
+        const bool scaled = bb == 1 || bb == 2;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[bb][e] = __builtin_fmaf(dw0[e], rsgn, du0[e]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[bb][4 + e] = __builtin_fmaf(dw1[e], rsgn, du1[e]);
+        for (int e = 0; e < 4; ++e) {
+            float v = half == 0 ? __builtin_fmaf(dw0[e], rsgn, du0[e]) : __builtin_fmaf(dw1[e], rsgn, du1[e]);
+            if (scaled) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(mult[hs]));
+            r[bb][4 * half + e] = v;
         }
     };
     unsigned vhi[2][4], vlo[2][4];                                           // [slot][channel pair]: the operand in use and the one being formed
-    // Channel pairs (e2, e2 + 1) of V(h, j): t = r[b1] +- r[b2]; hi = fp16(t 2^e), lo = fp16(t 2^e - hi).  v_fma_mix{lo,hi}_f16 form both
-    // straight from t (the product with the power of two and the difference hi leaves are exact, so each is ONE rounding -- the bits of
-    // hx_split8).  Two pairs travel together so that no partial register write is read by the very next instruction (hipcc pads such
-    // pairs with s_nop, and an s_nop costs an issue slot beside the MFMAs like any other instruction).
+    // Channel pairs (e2, e2 + 1) of V(h, j): ts = (r[b1] +- r[b2]) 2^e in one rounding (above); hi = fp16(ts) by v_cvt_pk_f16_f32 (two channels
+    // per instruction), lo = fp16(ts - hi) by v_fma_mix{lo,hi}_f16 (the difference is exact, so ONE rounding -- the bits of hx_split8).
+    // Two pairs travel together so that no partial register write is read by the very next instruction (hipcc pads such pairs with
+    // s_nop, and an s_nop costs an issue slot beside the MFMAs like any other instruction).
     float tt[4];
-    auto v_adds = [&](int j, int e2) {
+    auto v_adds = [&](int h, int j, int e2) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = 2 * e2 + q;
-            tt[q] = j == 0 ? r[0][e] - r[2][e] : j == 1 ? r[1][e] + r[2][e] : j == 2 ? r[2][e] - r[1][e] : r[1][e] - r[3][e];
+            tt[q] = j == 0 ? __builtin_fmaf(r[0][e], mult[h], -r[2][e]) : j == 1 ? r[1][e] + r[2][e] : j == 2 ? r[2][e] - r[1][e]
+                                                                                                   : __builtin_fmaf(r[3][e], -mult[h], r[1][e]);
         }
     };
-    auto v_hi = [&](int h, int slot, int e2) {
-        // ONE asm statement per pair of registers: hipcc pads a v_fma_mixhi that follows inline-asm partial writes with an s_nop it cannot
-        // prove unnecessary (an issue slot like any other); the other register's instruction between a register's two halves is the wait state
+    auto v_hi = [&](int slot, int e2) {
         unsigned ha, hb;
-        asm("v_fma_mixlo_f16 %0, %2, %6, 0\n\tv_fma_mixlo_f16 %1, %4, %6, 0\n\tv_fma_mixhi_f16 %0, %3, %6, 0\n\tv_fma_mixhi_f16 %1, %5, %6, 0"
-            : "=&v"(ha), "=&v"(hb) : "v"(tt[0]), "v"(tt[1]), "v"(tt[2]), "v"(tt[3]), "v"(mult[h]));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ha) : "v"(tt[0]), "v"(tt[1]));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hb) : "v"(tt[2]), "v"(tt[3]));
         vhi[slot][e2] = ha;
         vhi[slot][e2 + 1] = hb;
     };
-    auto v_lo = [&](int h, int slot, int e2) {
+    auto v_lo = [&](int slot, int e2) {
+        // ONE asm statement per pair of registers: hipcc pads a v_fma_mixhi that follows inline-asm partial writes with an s_nop it cannot
+        // prove unnecessary (an issue slot like any other); the other register's instruction between a register's two halves is the wait state
         unsigned la, lb;
-        asm("v_fma_mixlo_f16 %0, %2, %6, -%7 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixlo_f16 %1, %4, %6, -%8 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %0, %3, %6, -%7 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %1, %5, %6, -%8 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-            : "=&v"(la), "=&v"(lb) : "v"(tt[0]), "v"(tt[1]), "v"(tt[2]), "v"(tt[3]), "v"(mult[h]), "v"(vhi[slot][e2]), "v"(vhi[slot][e2 + 1]));
+        asm("v_fma_mixlo_f16 %0, %2, 1.0, -%6 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixlo_f16 %1, %4, 1.0, -%7 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %0, %3, 1.0, -%6 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %1, %5, 1.0, -%7 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(la), "=&v"(lb) : "v"(tt[0]), "v"(tt[1]), "v"(tt[2]), "v"(tt[3]), "v"(vhi[slot][e2]), "v"(vhi[slot][e2 + 1]));
         vlo[slot][e2] = la;
         vlo[slot][e2 + 1] = lb;
     };
@@ -239,28 +246,29 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         constexpr int rb = j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 1 : 3;                        // the r column read and formed in this step ...
         constexpr int prb = j == 0 ? 3 : j == 1 ? 0 : j == 2 ? 2 : 1;                       // ... and the previous step's, whose upper channels are still due
         constexpr int rh = h ^ 1;                                                           // ... belongs to the other half (h 0: this chunk's, h 1: the next chunk's)
+        constexpr int prh = j == 0 ? h : rh;                                                // the half of the previous step's column (step (h, 0) finishes column 3 of half h)
         const float* rsrc = h == 0 ? hcur : hnxt;
         const xf_f16x8 vh = frag(vhi[slot]), vl = frag(vlo[slot]);
         XD_MFMA0(par, h, j, 0, 1, vh);
         XD_IF(2, read_d_lo(rsrc, rh, rb));
-        XD_IF(1, v_adds(nj, 0));
+        XD_IF(1, v_adds(nh, nj, 0));
         XD_FENCE();
         XD_MFMA0(par, h, j, 1, 1, vh);
-        XD_IF(1, v_hi(nh, nslot, 0));
-        XD_IF(2, make_r(prb, 1));
+        XD_IF(1, v_hi(nslot, 0));
+        XD_IF(2, make_r(prb, 1, prh));
         XD_FENCE();
         XD_MFMA(par, h, j, 0, 0, vh);
-        XD_IF(1, v_lo(nh, nslot, 0));
+        XD_IF(1, v_lo(nslot, 0));
         XD_IF(2, read_d_hi(rsrc, rh, rb));
         // halo(c + 3) -> the buffer halo(c) was read from, free since the barrier of step 3 (its last patch read is that step's)
         if (s == 4) dma_halo(hcur, hso, XdInt<0>{}, XdInt<4>{});
         XD_FENCE();
         XD_MFMA(par, h, j, 1, 0, vh);
-        XD_IF(1, v_adds(nj, 2));
-        XD_IF(1, v_hi(nh, nslot, 2));
+        XD_IF(1, v_adds(nh, nj, 2));
+        XD_IF(1, v_hi(nslot, 2));
         XD_FENCE();
         XD_MFMA(par, h, j, 0, 0, vl);
-        XD_IF(1, v_lo(nh, nslot, 2));
+        XD_IF(1, v_lo(nslot, 2));
         if (!(XD_ABLATE & 4)) {   // two of the next chunk's filter pieces per step: U[par ^ 1][s >> 1][s & 1][hi, lo]; the constants land in the instruction offset
             const int so = ubase[s >> 1] + ucb;
             U[par ^ 1][s >> 1][s & 1][0] = __builtin_bit_cast(xf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16 + (s & 1) * HX_RB, so, 0));
@@ -268,7 +276,7 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         }
         XD_FENCE();
         XD_MFMA(par, h, j, 1, 0, vl);
-        XD_IF(2, make_r(rb, 0));
+        XD_IF(2, make_r(rb, 0, rh));
         if (s == 3) {
             // halo(c + 1) has landed: its DMA left in chunk c - 2 (the prologue for c < 2), and LDS-DMA completes in issue order like any
             // vector memory load -- at most the 15 youngest may be outstanding: halo(c + 2)'s 7 pieces and the 8 filter pieces of steps
@@ -350,9 +358,9 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // state at the top of a chunk: r = the r of (chunk, half 0) with column 0 already replaced ... the loop's steady state is entered with
     // V(0, 0) formed and r[1..3] of half 0 live; r[0] is free (the loop's first step writes half 1's column 0 there)
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) { read_d(hcur, 0, bb); make_r(bb, 0); make_r(bb, 1); }
-    v_adds(0, 0); v_hi(0, 0, 0); v_lo(0, 0, 0);
-    v_adds(0, 2); v_hi(0, 0, 2); v_lo(0, 0, 2);
+    for (int bb = 0; bb < 4; ++bb) { read_d(hcur, 0, bb); make_r(bb, 0, 0); make_r(bb, 1, 0); }
+    v_adds(0, 0, 0); v_hi(0, 0); v_lo(0, 0);
+    v_adds(0, 0, 2); v_hi(0, 2); v_lo(0, 2);
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_loop = __builtin_amdgcn_s_memrealtime(), xd_c_loop = __builtin_readcyclecounter();
 #endif
@@ -534,7 +542,11 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     // 64-channel layers, whose blocks are half prologue and epilogue.  FRCNN_X3F_WAVES4 / _WAVES8 force one (tests, tools).
     const bool eight = (flags & FRCNN_X3F_WAVES8) ? true : (flags & FRCNN_X3F_WAVES4) ? false : cin >= X3F_EIGHT_WAVES_MIN_CIN;
     if (eight)
+#ifndef FRCNN_EXPERIMENTS
+        return FRCNN_EUNSUPPORTED;     // csrc/wino_x3e.hip ships in `make EXPERIMENTS=1` builds only (measured round 5: no gain over the four-wave form)
+#else
         return launch_wino_x3e((flags & FRCNN_POOL2) != 0, (unsigned)grid_blocks, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm, cmax_out, s);
+#endif
     if (flags & FRCNN_POOL2) {
         auto kern = wino_x3d_kernel<true>;
         FRCNN_MAX_LDS_ONCE(kern, XD_LDS_BYTES);

@@ -373,6 +373,37 @@ def test_nms_vs_oracle(ctx, n, thr, quant, clusters, max_keep):
     assert np.array_equal(got, ref.astype(np.int32))
 
 
+@pytest.mark.parametrize("n,j_list", [(9000, (5, 100, 777)), (12000, (1, 64, 3807)), (16384, (8191,))])
+def test_nms_wide_box0_does_not_reach_into_the_upper_half(ctx, n, j_list):
+    """ADVICE r5 (nms_reduce_kernel, > 8192 candidates): the prologue filled the ring's odd row places with the LOWER half of row 0, which
+    chunks 0 and 1 OR into words 128 .. 255 of removed[] -- every box j < 8192 that box 0 suppresses also suppressed candidate 8192 + j.
+    Directed case (the training path's shape, pre_nms = 12000: models/faster_rcnn.py:302 of the reference): scores descend with the index,
+    the first 8192 boxes sit on 40 sites (few kept: max_keep is not reached before index 8192), box 0 covers boxes j, and boxes
+    8192 + j are ISOLATED: they must be kept."""
+    rng = np.random.RandomState(n)
+    sites = np.stack(np.meshgrid(np.arange(8) * 120.0, np.arange(5) * 110.0), axis=-1).reshape(-1, 2)          # 40 sites, 100 x 90 boxes
+    which = rng.randint(1, 40, size=n)
+    which[0] = 0
+    for j in j_list:
+        which[j] = 0                                       # box j sits on box 0's site: suppressed by box 0
+    tl = sites[which] + rng.rand(n, 2) * 2.0
+    b = np.concatenate([tl, tl + np.array([100.0, 90.0])], axis=1).astype(np.float32)
+    for k, j in enumerate(j_list):                         # isolated boxes far from every site
+        b[8192 + j] = [2000.0 + 150.0 * k, 2000.0, 2100.0 + 150.0 * k, 2090.0]
+    s = np.linspace(1.0, 0.01, n).astype(np.float32)
+    keep = torch.full((2048,), -1, dtype=torch.int32, device=DEV)
+    nk = torch.full((1,), -1, dtype=torch.int32, device=DEV)
+    bb, ss = gpu(b), gpu(s)                                # (named: the launch is asynchronous, a temporary's memory could be handed out again)
+    nv.check(nv.lib().frcnn_nms(ctx.handle, nv.ptr(bb), nv.ptr(ss), n, 0.5, 2048, nv.ptr(keep), nv.ptr(nk), S()), "nms")
+    got = keep.cpu().numpy()[: int(nk.item())]
+    ref = O.nms(b, s, 0.5)[:2048]
+    for j in j_list:
+        assert j not in set(got.tolist())
+        assert 8192 + j in set(ref.tolist())               # (the case is what it claims to be)
+        assert 8192 + j in set(got.tolist()), "box 0 removed candidate %d through the upper half of removed[]" % (8192 + j)
+    assert np.array_equal(got, ref.astype(np.int32))
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("c,fh,fw,n", [(512, 37, 62, 300), (64, 20, 32, 57), (1024, 38, 63, 16)])
 def test_roi_pool_bit_exact(c, fh, fw, n):
