@@ -12,12 +12,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
-ABI_VERSION = 13    # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
+ABI_VERSION = 14    # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
 POOL2 = 2
-X3F_WAVES4, X3F_WAVES8 = 0x100, 0x200     # FRCNN_X3F_WAVES4 / _WAVES8: force a form of the one-launch f32x3 layer (tests, tools)
+X3F_WAVES4, X3F_WAVES8, X3F_PAIR = 0x100, 0x200, 0x400     # FRCNN_X3F_WAVES4 / _WAVES8: force a form of the one-launch f32x3 layer (tests, tools)
 NUM_KCLASS = 11
 KCLASS_NAMES = ("conv3x3_mfma", "conv3x3_c3", "linear_mfma", "proposals", "roi_pool", "other", "winograd_transforms",
                 "winograd_gemm", "winograd_x6_transforms", "winograd_x6_gemm", "winograd_x3f")
@@ -47,7 +47,7 @@ SYMBOLS = (
     "frcnn_pixel_absmax", "frcnn_split_pixels_x3t", "frcnn_split_patches3x3_x3t",
     "frcnn_x3t_blob_bytes", "frcnn_pack_rows_x3t", "frcnn_conv3x3_winograd_x3_pack_bytes", "frcnn_pack_conv3x3_winograd_x3",
     "frcnn_conv3x3_winograd_x3_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x3",
-    "frcnn_conv3x3_winograd_x3_fused_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x3_fused", "frcnn_conv3x3_nhwc_winograd_x3_chain",
+    "frcnn_conv3x3_winograd_x3_fused_workspace_bytes", "frcnn_conv3x3_winograd_x3_pair_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x3_fused", "frcnn_conv3x3_nhwc_winograd_x3_chain",
     "frcnn_x3t_record_bytes", "frcnn_rows_scale_x3t", "frcnn_split_rows_x3t", "frcnn_gemm_x3t_workspace_bytes", "frcnn_gemm_x3t",
     "frcnn_conv3x3_nhwc_winograd_fused_maps", "frcnn_ctx_create_backbone", "frcnn_resnet_backbone", "frcnn_resnet_forward_features",
     # training path
@@ -103,7 +103,7 @@ class ForwardParams(C.Structure):
                 ("min_side", C.c_float), ("allow_edge_proposals", C.c_int32), ("math_mode", C.c_int32),
                 ("conv_blocks_target", C.c_int32), ("fc_math_mode", C.c_int32), ("roi_op", C.c_int32), ("roi_sampling_ratio", C.c_int32),
                 ("winograd_tile_rows", C.c_int32), ("winograd_x6_mask", C.c_int32), ("x6_gemm_tiles", C.c_int32), ("winograd_x3_mask", C.c_int32),
-                ("winograd_x3f_mask", C.c_int32)]
+                ("winograd_x3f_mask", C.c_int32), ("winograd_x3p_mask", C.c_int32)]
 
 
 # capacity limits of the kernels (validated by FasterRCNNModel with a message; the C entry points return FRCNN_EINVAL / EUNSUPPORTED)
@@ -147,6 +147,12 @@ DEFAULT_X6_LAYERS_VGG16 = ("conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2"
 # x6 table in f32x6 1.63 / 1.52; every layer on the direct exact-f32 kernel (no Winograd) 1.84 / 1.78.  The f32x3 layers are the MOST
 # accurate arithmetic of the five: two wide fp16 MFMA accumulations per 16 products round less than sixteen float32 FMA steps.
 DEFAULT_X3_LAYERS_VGG16 = DEFAULT_X6_LAYERS_VGG16
+
+
+# One-launch f32x3 layers that run in the two-pass form with 128 output channels per block (csrc/wino_x3p.hip, round 6), per slot kind;
+# bit-identical results, chosen by measurement (profiles/r06)
+DEFAULT_INFLIGHT_PAIR_LAYERS_VGG16 = ()
+DEFAULT_ALONE_PAIR_LAYERS_VGG16 = ()
 
 
 def uses_winograd_x3f(cin, cout):
@@ -284,6 +290,7 @@ _SIGNATURES = {
     "frcnn_conv3x3_winograd_x3_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "frcnn_conv3x3_nhwc_winograd_x3": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_conv3x3_winograd_x3_fused_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "frcnn_conv3x3_winograd_x3_pair_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "frcnn_conv3x3_nhwc_winograd_x3_fused": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_conv3x3_nhwc_winograd_x3_chain": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _i, _vp, _sz, _vp, _vp, _vp]),
     "frcnn_x3t_record_bytes": (C.c_size_t, [_i, _i]),

@@ -45,6 +45,7 @@ struct frcnn_ctx {
     void* conv_ws = nullptr; size_t conv_ws_bytes = 0;   // split-K partials of under-filled conv layers
     void* wino_ws = nullptr; size_t wino_ws_bytes = 0;   // V and M of the Winograd layers; allocated by the first forward that needs it
     void* wx_ws = nullptr; size_t wx_ws_bytes = 0;       // V records, M and split-K partials of the x6 Winograd layers; allocated on first use
+    float* x3p_spill = nullptr; size_t x3p_spill_bytes = 0;  // scratch of the two-pass one-launch f32x3 layers (csrc/wino_x3p.hip); first use
     float* x3f_cmax = nullptr; size_t x3f_cmax_bytes = 0;   // channel maxima of a one-launch f32x3 Winograd layer's input (csrc/wino_x3f.hip); first use
     void* rx_rec = nullptr; size_t rx_rec_bytes = 0;     // activation records of the x6 1x1 convolutions (ResNet bottlenecks); on first use
     void* rx_ws = nullptr; size_t rx_ws_bytes = 0;       // their split-K partials
@@ -320,6 +321,11 @@ int frcnn_gemm_x3t(const void* d_a_rec, const float* d_a_inv, int a_rows, size_t
 size_t frcnn_conv3x3_winograd_x3_fused_workspace_bytes(int n_maps, int H, int W)
 {
     return n_maps > 0 && H > 0 && W > 0 ? conv3x3_winograd_x3_fused_workspace_bytes(n_maps, H, W) : 0;
+}
+
+size_t frcnn_conv3x3_winograd_x3_pair_workspace_bytes(int n_maps, int H, int W, int cout)
+{
+    return n_maps > 0 && H > 0 && W > 0 && cout > 0 ? conv3x3_winograd_x3_pair_workspace_bytes(n_maps, H, W, cout) : 0;
 }
 
 int frcnn_conv3x3_nhwc_winograd_x3_fused(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W,
@@ -905,6 +911,7 @@ void frcnn_ctx_destroy(frcnn_ctx* ctx)
     if (ctx->wino_ws) (void)hipFree(ctx->wino_ws);
     if (ctx->wx_ws) (void)hipFree(ctx->wx_ws);
     if (ctx->x3f_cmax) (void)hipFree(ctx->x3f_cmax);
+    if (ctx->x3p_spill) (void)hipFree(ctx->x3p_spill);
     if (ctx->roi_rec) (void)hipFree(ctx->roi_rec);
     if (ctx->rx_rec) (void)hipFree(ctx->rx_rec);
     if (ctx->rx_ws) (void)hipFree(ctx->rx_ws);
@@ -1110,12 +1117,24 @@ float* x3f_cmax_buffer(frcnn_ctx* c, int which) { return reinterpret_cast<float*
 // A ONE-LAUNCH f32x3 Winograd layer inside a fused forward (csrc/wino_x3f.hip; a bit of frcnn_forward_params.winograd_x3f_mask; timing class 10,
 // which includes the channel-maximum pass over the layer input).  ublob = frcnn_pack_conv3x3_winograd_x3's blob.
 int run_wino_x3f_layer(frcnn_ctx* c, const float* x, const void* ublob, const float* b, float* y, int h, int w, int ci, int co,
-                       unsigned flags, hipStream_t s, const float* cmax_ready = nullptr, float* cmax_out = nullptr)
+                       unsigned flags, hipStream_t s, const float* cmax_ready = nullptr, float* cmax_out = nullptr, bool pair = false)
 {
     int r = ensure_x3f_cmax(c, conv3x3_winograd_x3_fused_workspace_bytes(1, h, w), s);
     if (r) return r;
+    if (pair) {                                                   // the two-pass form (csrc/wino_x3p.hip): the ctx owns the spill scratch
+        const size_t need = conv3x3_winograd_x3_pair_spill_bytes(1, h, w, co);
+        if (!need) return FRCNN_EUNSUPPORTED;
+        if (!c->x3p_spill || c->x3p_spill_bytes < need) {
+            if (c->x3p_spill) { FRCNN_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(c->x3p_spill); c->x3p_spill = nullptr; c->x3p_spill_bytes = 0; }
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->x3p_spill), need);
+            if (e != hipSuccess) { set_hip_error(e); c->x3p_spill = nullptr; return FRCNN_ENOMEM; }
+            c->x3p_spill_bytes = need;
+        }
+        flags |= FRCNN_X3F_PAIR;
+    }
     Scope _w(c, 10, s);
-    return launch_conv3x3_winograd_x3_fused(x, ublob, b, y, 1, h, w, ci, co, flags, x3f_cmax_buffer(c, 0), c->x3f_cmax_bytes, s, cmax_ready, cmax_out);
+    return launch_conv3x3_winograd_x3_fused(x, ublob, b, y, 1, h, w, ci, co, flags, x3f_cmax_buffer(c, 0), c->x3f_cmax_bytes, s, cmax_ready, cmax_out,
+                                            pair ? c->x3p_spill : nullptr, pair ? c->x3p_spill_bytes : 0);
 }
 
 // One one-launch Winograd layer inside a fused forward (timed as class 7).
@@ -1163,6 +1182,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
     const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
     if (p->winograd_x6_mask != 0 && (!wino || (p->winograd_x6_mask & ~0x3FFE) != 0)) return FRCNN_EINVAL;
     if (p->winograd_x3f_mask != 0 && (!wino || (p->winograd_x3f_mask & ~0x3FFE) != 0 || (p->winograd_x3f_mask & p->winograd_x6_mask) != 0)) return FRCNN_EINVAL;
+    if ((p->winograd_x3p_mask & ~p->winograd_x3f_mask) != 0 || (p->winograd_x3p_mask & 0x2) != 0) return FRCNN_EINVAL;    // a subset of the one-launch table; conv1_2 has 64 output channels
     int layer_index = 0;        // 1 .. 12 = conv_w[i], 13 = the RPN trunk (frcnn_forward_params.winograd_x6_mask)
     const float* cmax_ready = nullptr;     // channel maxima of the activation tensor produced last, if its producer emitted them
     // The producers accumulate those maxima with atomic maxima into ZEROED floats.  Every emitting layer of the image gets its own region of
@@ -1210,7 +1230,7 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
         }
         int r1;
         if (is_x3f)                                                  // one-launch f32x3 Winograd layer: wgt = the x3 blob (csrc/wino_x3f.hip)
-            r1 = run_wino_x3f_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s, in_cmax, out_cmax);
+            r1 = run_wino_x3f_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s, in_cmax, out_cmax, ((p->winograd_x3p_mask >> layer_index) & 1) != 0);
         else if (is_x3)                                              // three-launch f32x3 layer: wgt = the x3 blob (csrc/wino_x3.hip)
             r1 = run_wino_x3_layer(c, xin, wgt, bs, yout, hh, ww, ci, co, fl, s, 1, in_cmax, out_cmax);
         else if (wino && ((p->winograd_x6_mask >> layer_index) & 1)) // x6 Winograd layer: wgt = the record bank (csrc/wino_x6.hip)

@@ -202,7 +202,10 @@ int launch_conv3x3_winograd_x3(const float* x, const void* ublob, const float* b
 size_t conv3x3_winograd_x3_fused_workspace_bytes(int N, int H, int W);
 int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const float* b, float* y, int N, int H, int W, int cin, int cout,
                                      unsigned flags, void* ws, size_t ws_bytes, hipStream_t s, const float* cmax_ready = nullptr,
-                                     float* cmax_out = nullptr);   // cmax_ready / cmax_out: as above (cmax_out needs ReLU; zeroed by the caller)
+                                     float* cmax_out = nullptr,    // cmax_ready / cmax_out: as above (cmax_out needs ReLU; zeroed by the caller)
+                                     float* pair_spill = nullptr, size_t pair_spill_bytes = 0);   // FRCNN_X3F_PAIR: the spill scratch if it is not behind the maxima in ws
+size_t conv3x3_winograd_x3_pair_spill_bytes(int N, int H, int W, int cout);       // wino_x3p.hip: the spill scratch alone (0: shape not supported)
+size_t conv3x3_winograd_x3_pair_workspace_bytes(int N, int H, int W, int cout);   // FRCNN_X3F_PAIR: channel maxima + spill scratch (0: shape not supported)
 int launch_roi_pool_x3t(const float* fm, int fh, int fw, int c, const float* rois, const int32_t* n_rois, int max_rois, int pooled,
                         float scale, float* cmax, float* inv, void* rec, int rec_rows, hipStream_t s, bool cmax_ready = false);
 // wino_x6.hip: Winograd F(2x2,3x3) layers whose position GEMMs run on gemm_x6t

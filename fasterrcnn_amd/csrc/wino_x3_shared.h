@@ -114,4 +114,10 @@ __device__ __forceinline__ bool xd_block_to_tile(const XfGeom& gm, int b, int& c
 int launch_wino_x3e(bool pool, unsigned grid_blocks, const float* x, const float* cmax, const unsigned char* ublob, const float* bias, float* y,
                     int H, int W, int cin, int cout, int u_rbt, int relu, const XfGeom& gm, float* cmax_out, hipStream_t s);
 
+// the two-pass form with 128 output channels per block (csrc/wino_x3p.hip, FRCNN_X3F_PAIR); same results bit for bit.  spill: block-private
+// scratch for the first pass's accumulators, >= conv3x3_winograd_x3_pair_spill_bytes (256 KB per block of the grid)
+size_t conv3x3_winograd_x3_pair_spill_bytes(int N, int H, int W, int cout);
+int launch_wino_x3p(bool pool, const float* x, const float* cmax, const unsigned char* ublob, const float* bias, float* y, int N, int H, int W,
+                    int cin, int cout, int relu, float* cmax_out, float* spill, size_t spill_bytes, hipStream_t s);
+
 }  // namespace frcnn

@@ -500,9 +500,46 @@ static constexpr int X3F_EIGHT_WAVES_MIN_CIN = 1 << 30;
 // cmax scratch: n_maps * H * W floats (the channel maxima of the layer input, computed here)
 size_t conv3x3_winograd_x3_fused_workspace_bytes(int N, int H, int W) { return (size_t)N * H * W * sizeof(float); }
 
-int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const float* b, float* y, int N, int H, int W, int cin, int cout,
-                                     unsigned flags, void* ws, size_t ws_bytes, hipStream_t s, const float* cmax_ready, float* cmax_out)
+static inline size_t x3f_align256(size_t v) { return (v + 255) / 256 * 256; }
+#ifndef FRCNN_EXPERIMENTS
+// csrc/wino_x3p.hip ships in `make EXPERIMENTS=1` builds only (measured round 6: its loop is 12 % shorter, the forward is not -- DESIGN.md section 5)
+size_t conv3x3_winograd_x3_pair_spill_bytes(int, int, int, int) { return 0; }
+#endif
+size_t conv3x3_winograd_x3_pair_workspace_bytes(int N, int H, int W, int cout)
 {
+    const size_t sp = conv3x3_winograd_x3_pair_spill_bytes(N, H, W, cout);
+    return sp ? x3f_align256(conv3x3_winograd_x3_fused_workspace_bytes(N, H, W)) + sp : 0;
+}
+
+int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const float* b, float* y, int N, int H, int W, int cin, int cout,
+                                     unsigned flags, void* ws, size_t ws_bytes, hipStream_t s, const float* cmax_ready, float* cmax_out,
+                                     float* pair_spill, size_t pair_spill_bytes)
+{
+    if (flags & FRCNN_X3F_PAIR) {
+#ifndef FRCNN_EXPERIMENTS
+        return FRCNN_EUNSUPPORTED;
+#else
+        // the two-pass form, 128 output channels per block (csrc/wino_x3p.hip): ws = [channel maxima | spill scratch] unless the caller brings the scratch
+        if (N < 1 || H < 1 || W < 1) return FRCNN_EUNSUPPORTED;
+        if ((flags & FRCNN_POOL2) && (H < 2 || W < 2)) return FRCNN_EINVAL;
+        if (cmax_out && !(flags & FRCNN_RELU)) return FRCNN_EINVAL;
+        const size_t cm_bytes = x3f_align256(conv3x3_winograd_x3_fused_workspace_bytes(N, H, W));
+        if (!cmax_ready && (!ws || ws_bytes < cm_bytes)) return FRCNN_EINVAL;
+        if (!pair_spill) {
+            if (!ws || ws_bytes < cm_bytes) return FRCNN_EINVAL;
+            pair_spill = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + cm_bytes);
+            pair_spill_bytes = ws_bytes - cm_bytes;
+        }
+        const float* cm = cmax_ready;
+        if (!cm) {
+            int rc = launch_pixel_absmax(x, static_cast<float*>(ws), (long long)N * H * W, cin, s);
+            if (rc) return rc;
+            cm = static_cast<const float*>(ws);
+        }
+        return launch_wino_x3p((flags & FRCNN_POOL2) != 0, x, cm, static_cast<const unsigned char*>(ublob), b, y, N, H, W, cin, cout,
+                               (flags & FRCNN_RELU) ? 1 : 0, cmax_out, pair_spill, pair_spill_bytes, s);
+#endif
+    }
     // the kernel walks the 16-channel chunks in pairs: cin % 32 == 0 (other widths: the three-launch layer, csrc/wino_x3.hip)
     if (N < 1 || H < 1 || W < 1 || cin < 32 || cin % 32 != 0 || cout < 64 || cout % 64 != 0) return FRCNN_EUNSUPPORTED;
     if ((size_t)H * W * cin >= ((size_t)1 << 29)) return FRCNN_EUNSUPPORTED;          // 32-bit byte offsets inside one map

@@ -168,6 +168,10 @@ class FasterRCNNModel(nn.Module):
         if not self._is_resnet:
             self.inflight_winograd_x3f_layers = nv.DEFAULT_INFLIGHT_X3F_LAYERS_VGG16
             self.alone_winograd_x3f_layers = nv.DEFAULT_ALONE_X3F_LAYERS_VGG16
+        # ... and the one-launch layers that take the TWO-PASS form with 128 output channels per block (csrc/wino_x3p.hip, round 6; same
+        # results bit for bit, so no table of the held-out / stress admissions changes): per slot kind, chosen by measurement (_native.py)
+        self.inflight_pair_layers = nv.DEFAULT_INFLIGHT_PAIR_LAYERS_VGG16 if not self._is_resnet else ()
+        self.alone_pair_layers = nv.DEFAULT_ALONE_PAIR_LAYERS_VGG16 if not self._is_resnet else ()
 
         # hipGraph replay of one image's ~33 launches (forward + detections + the D2H copies): the second consecutive call of a slot with
         # the same (shape, thresholds, weights, modes) captures them into a graph on the slot's stream, later calls copy the image
@@ -384,6 +388,16 @@ class FasterRCNNModel(nn.Module):
     def _slot_masks(self, slot_index):
         return tuple(sum(1 << nv.X6_LAYER_BITS[n] for n in names) for names in self.layer_tables(slot_index))
 
+    def _pair_mask(self, slot_index):
+        """frcnn_forward_params.winograd_x3p_mask of a slot: the slot's one-launch f32x3 layers named in alone_pair_layers (slot 0) /
+        inflight_pair_layers (slots > 0)."""
+        names = self.alone_pair_layers if slot_index == 0 else self.inflight_pair_layers
+        x3f = self.layer_tables(slot_index)[2]
+        for n in names:
+            if n not in nv.X6_LAYER_BITS or n == "conv1_2":
+                raise ValueError("pair layers: %r cannot run in the two-pass form (64 output channels, or no 3x3 layer of VGG-16)" % (n,))
+        return sum(1 << nv.X6_LAYER_BITS[n] for n in names if n in x3f)
+
     def _x3f_mask(self):
         if self._math_mode != "f32_winograd" or self._is_resnet:
             return 0
@@ -563,7 +577,7 @@ class FasterRCNNModel(nn.Module):
                                 # (ResNet: the cost model's choice in every slot, so that an image gives the same bits in flight
                                 #  and alone: its 1x1 GEMMs switch between split-K and unsplit tiles with the tile mode)
                                 0 if (slot_index == 0 or self._is_resnet) else self.inflight_x6_gemm_tiles,
-                                self._slot_masks(slot_index)[1], self._slot_masks(slot_index)[2])
+                                self._slot_masks(slot_index)[1], self._slot_masks(slot_index)[2], self._pair_mask(slot_index))
 
     def _enqueue_outputs(self, slot, h, w, score_threshold, sp):
         """decode + per-class NMS (faster_rcnn.py:179-224) and the D2H copies of one image, behind its forward on stream `sp`."""

@@ -37,7 +37,7 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 13  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
+#define FRCNN_ABI_VERSION 14  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
                                  5: bf16 gradient GEMMs (the *_math entry points); 6: x6t GEMM, x6 Winograd layers, frcnn_forward_params.winograd_x6_mask,
                                  timing classes 8 / 9; 7: batched feature extractor (frcnn_resnet_backbone, frcnn_resnet_forward_features,
                                  frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps); 8: the f32x3 arithmetic (frcnn_*_x3t, frcnn_*_winograd_x3,
@@ -46,7 +46,7 @@ extern "C" {
                                  and 13 (RPN trunk) of winograd_x3f_mask; 11: frcnn_conv_nhwc_x3g, frcnn_tensor_absmax, frcnn_bottleneck_weights.g3 / .wmax;
                                  12: frcnn_x3_saturation_events, FRCNN_X3F_WAVES4 / FRCNN_X3F_WAVES8; 13: REMOVED the round-2 f32x6 kernels that no table has used since round 3
                                  (frcnn_pack_conv3x3_x6, frcnn_conv3x3_nhwc_x6, frcnn_split_rows_x6, frcnn_linear_x6(_workspace_bytes), math mode 1 =
-                                 FRCNN_MATH_F32X6 and fc mode 1 = FRCNN_FC_F32X6 are FRCNN_EINVAL); the f32x6 arithmetic stays as gemm_x6t / wino_x6 */
+                                 FRCNN_MATH_F32X6 and fc mode 1 = FRCNN_FC_F32X6 are FRCNN_EINVAL); the f32x6 arithmetic stays as gemm_x6t / wino_x6; 14: FRCNN_X3F_PAIR, frcnn_conv3x3_winograd_x3_pair_workspace_bytes */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -56,6 +56,10 @@ extern "C" {
  * tools/x3f_bench.py / tools/xd_clocks.py. */
 #define FRCNN_X3F_WAVES4 0x100u   /* wino_x3d_kernel: four waves, one per SIMD, 256 accumulator registers (csrc/wino_x3f.hip) */
 #define FRCNN_X3F_WAVES8 0x200u   /* wino_x3e_kernel: eight waves, two per SIMD, 128 accumulator registers (csrc/wino_x3e.hip) */
+/* ABI 14: the TWO-PASS form of the one-launch f32x3 layer, 128 output channels per block (wino_x3p_kernel, csrc/wino_x3p.hip): cin % 32 == 0,
+ * cin >= 64, cout % 128 == 0; same results bit for bit; d_ws >= frcnn_conv3x3_winograd_x3_pair_workspace_bytes (channel maxima + the
+ * block-private scratch the first pass's accumulators rest in). */
+#define FRCNN_X3F_PAIR   0x400u
 
 int         frcnn_abi_version(void);
 const char* frcnn_error_string(int code);
@@ -272,6 +276,7 @@ int frcnn_conv3x3_nhwc_winograd_x3(const float* d_x, const void* d_blob, const f
  * float32 rounding of that transform only (<= 2e-6 of max|y|, tests/test_gemm_x3t_gpu.py).  cin % 32 == 0, cout % 64 == 0;
  * d_ws >= frcnn_conv3x3_winograd_x3_fused_workspace_bytes (the channel maxima of the input). */
 size_t frcnn_conv3x3_winograd_x3_fused_workspace_bytes(int n_maps, int H, int W);
+size_t frcnn_conv3x3_winograd_x3_pair_workspace_bytes(int n_maps, int H, int W, int cout);   /* with FRCNN_X3F_PAIR (0: shape not supported) */
 int frcnn_conv3x3_nhwc_winograd_x3_fused(const float* d_x, const void* d_blob, const float* d_bias, float* d_y, int n_maps, int H, int W,
                                          int cin, int cout, unsigned flags, void* d_ws, size_t ws_bytes, void* stream);
 /* The same two layers CHAINED (round 4): an f32x3 layer takes its scales from the per-pixel channel maximum of its INPUT.  d_cmax_in (optional):
@@ -510,6 +515,9 @@ typedef struct frcnn_forward_params {
                                    pointer is frcnn_pack_conv3x3_winograd_x3's blob.  For the layers whose V + M scratch does not fit the Infinity
                                    Cache (conv2_1 .. conv3_3) and, when several images are in flight and the chip is full anyway, for the 512-channel
                                    layers too (one launch instead of three, no scratch traffic).  cin % 32 == 0, cout % 64 == 0 */
+    int32_t winograd_x3p_mask;  /* round 6 (ABI 14): a subset of winograd_x3f_mask -- the one-launch f32x3 layers that run in the TWO-PASS form with 128 output
+                                   channels per block (FRCNN_X3F_PAIR, csrc/wino_x3p.hip; cin >= 64, cout % 128 == 0).  Same results bit for bit;
+                                   the ctx keeps the scratch the first pass's accumulators rest in (256 KB per block of the layer's grid) */
 } frcnn_forward_params;
 #define FRCNN_X6_RPN_TRUNK_BIT 13
 /* capacity of the detector heads: classifier (n) + regressor (4 n - 4) rows are stacked into one zero-padded GEMM operand of

@@ -476,6 +476,63 @@ def test_x3_one_launch_eight_wave_form_is_the_four_wave_form_bit_for_bit(n, h, w
     assert torch.equal(y2, out["eight"])
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,relu,pool", [
+    (1, 9, 11, 64, 128, True, False),         # 4 chunks per pass: first, second, one loop pair (which is also the last), partial tiles
+    (1, 38, 66, 64, 128, True, True),
+    (1, 150, 250, 128, 128, True, True),      # conv2_2 at half size: 8 chunks, pool, XCD-grouped block order
+    (1, 75, 125, 128, 256, True, False),      # conv3_1's class: two cout blocks
+    (1, 75, 125, 256, 256, True, True),       # conv3_3 at half size: filter-resident order, fused pool
+    (2, 21, 35, 128, 384, False, False),      # two maps, three cout blocks, no ReLU
+    (1, 37, 62, 512, 512, True, False),       # conv5_x: 32 chunks per pass, four cout blocks
+    (1, 21, 35, 256, 128, True, False),       # surplus blocks leave
+    (1, 16, 32, 96, 128, True, False),        # exactly one full tile block, 6 chunks
+])
+def test_x3_one_launch_pair_form_is_the_four_wave_form_bit_for_bit(n, h, w, cin, cout, relu, pool):
+    """csrc/wino_x3p.hip (round 6): the one-launch f32x3 layer with 128 output channels per block in two passes over the input channels -- a
+    wave owns HALF a position row per pass, the first pass's accumulators rest in a block-private scratch -- against csrc/wino_x3f.hip: the
+    same value per operand (r 2^e is exact: fma(r1, 2^e, r2 2^e) == r1 2^e + r2 2^e rounded once), the same MFMA order per accumulator,
+    the same output transform: EQUAL outputs and equal emitted channel maxima (FRCNN_X3F_PAIR against FRCNN_X3F_WAVES4)."""
+    lib = nv.lib()
+    gen = torch.Generator().manual_seed(11 * h + w + cin + cout)
+    x = (torch.randn((n, h, w, cin), generator=gen) * torch.exp(torch.randn((1, 1, 1, cin), generator=gen))).clamp(min=-0.5).cuda()
+    wt = (torch.randn((cout, cin, 3, 3), generator=gen) * (2.0 / (9 * cin)) ** 0.5).cuda()
+    b = (torch.randn((cout,), generator=gen) * 0.1).cuda()
+    u = pack_x3(wt)
+    oh, ow = (h // 2, w // 2) if pool else (h, w)
+    wsb = int(lib.frcnn_conv3x3_winograd_x3_pair_workspace_bytes(n, h, w, cout))
+    if wsb == 0:
+        pytest.skip("wino_x3p_kernel is not in this build (make EXPERIMENTS=1; FRCNN_LIB_PATH=build/libfrcnn_exp.so)")
+    assert wsb >= int(lib.frcnn_conv3x3_winograd_x3_fused_workspace_bytes(n, h, w)) + 256 * 1024
+    ws = torch.empty((wsb,), dtype=torch.uint8, device="cuda")
+    base = (nv.RELU if relu else 0) | (nv.POOL2 if pool else 0)
+    out = {}
+    for name, force in (("four", nv.X3F_WAVES4), ("pair", nv.X3F_PAIR)):
+        y = torch.full((n, oh, ow, cout), float("nan"), device="cuda")
+        nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), n, h, w, cin, cout, base | force,
+                                                          nv.ptr(ws), wsb, nv.stream_ptr()), "x3_fused " + name)
+        torch.cuda.synchronize()
+        assert not torch.isnan(y).any(), name
+        out[name] = y
+    assert torch.equal(out["four"], out["pair"]), float((out["four"] - out["pair"]).abs().max())
+    if relu:
+        cm_in = torch.empty((n, h, w), device="cuda")
+        nv.check(lib.frcnn_pixel_absmax(nv.ptr(x), nv.ptr(cm_in), n * h * w, cin, nv.stream_ptr()), "absmax")
+        y = torch.empty((n, oh, ow, cout), device="cuda")
+        cm = torch.zeros((n, oh, ow), device="cuda")
+        nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_chain(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), n, h, w, cin, cout, base | nv.X3F_PAIR, 1,
+                                                          nv.ptr(ws), wsb, nv.ptr(cm_in), nv.ptr(cm), nv.stream_ptr()), "x3_chain pair")
+        torch.cuda.synchronize()
+        assert torch.equal(y, out["four"])
+        assert torch.equal(cm, y.amax(dim=3))
+    # twice the same, and a workspace one byte short is refused
+    y2 = torch.empty_like(out["pair"])
+    nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y2), n, h, w, cin, cout, base | nv.X3F_PAIR,
+                                                      nv.ptr(ws), wsb, nv.stream_ptr()), "x3_fused pair")
+    assert torch.equal(y2, out["pair"])
+    assert lib.frcnn_conv3x3_nhwc_winograd_x3_fused(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y2), n, h, w, cin, cout, base | nv.X3F_PAIR,
+                                                    nv.ptr(ws), wsb - 256 * 1024, nv.stream_ptr()) != 0
+
+
 @pytest.mark.parametrize("one_launch,h,w,cin,cout,pool", [
     (1, 38, 66, 64, 128, False),       # one-launch layer, two cout blocks
     (1, 75, 125, 128, 256, True),      # fused pool, XCD-grouped block order

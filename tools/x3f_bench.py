@@ -37,20 +37,25 @@ def main():
         u = torch.empty((int(lib.frcnn_conv3x3_winograd_x3_pack_bytes(cout, cin)),), dtype=torch.int8, device=dev)
         nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(wt), None, nv.ptr(bank), cout, cin, s), "pack")
         nv.check(lib.frcnn_pack_conv3x3_winograd_x3(nv.ptr(bank), nv.ptr(u), cout, cin, s), "pack_x3")
-        wsb = int(lib.frcnn_conv3x3_winograd_x3_fused_workspace_bytes(1, h, w))
+        pair_ok = cin >= 64 and cout % 128 == 0
+        wsb = int(lib.frcnn_conv3x3_winograd_x3_pair_workspace_bytes(1, h, w, cout)) if pair_ok else int(lib.frcnn_conv3x3_winograd_x3_fused_workspace_bytes(1, h, w))
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
         # the channel maxima computed once outside the timed calls (the forward chains them through the layers: no pass over the input)
         cm = torch.empty((h, w), device=dev)
         nv.check(lib.frcnn_pixel_absmax(nv.ptr(x), nv.ptr(cm), h * w, cin, s), "absmax")
         us = {}
-        for form, force in (("four", nv.X3F_WAVES4), ("eight", nv.X3F_WAVES8)):
+        forms = [("four", nv.X3F_WAVES4)]
+        if lib.frcnn_conv3x3_nhwc_winograd_x3_chain(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout, flags | nv.X3F_WAVES8, 1, nv.ptr(ws), wsb, nv.ptr(cm), None, s) == 0:
+            forms.append(("eight", nv.X3F_WAVES8))        # (make EXPERIMENTS=1 builds only)
+        if pair_ok:
+            forms.append(("pair", nv.X3F_PAIR))           # csrc/wino_x3p.hip: two passes, 128 output channels per block
+        for form, force in forms:
             us[form] = timeit(lambda: nv.check(lib.frcnn_conv3x3_nhwc_winograd_x3_chain(nv.ptr(x), nv.ptr(u), nv.ptr(b), nv.ptr(y), 1, h, w, cin, cout,
                                                                                      flags | force, 1, nv.ptr(ws), wsb, nv.ptr(cm), None, s), "x3_chain"), 10, ramp_s=0.3)
         gfl = 2.0 * 16 * ((h + 1) // 2) * ((w + 1) // 2) * cin * cout
-        print("%-8s %4d->%4d %4dx%-4d pool=%d | float32 one-launch %7.1f us (%.2f of 157.3) | f32x3 one-launch, channel maxima given: four waves %7.1f us "
-              "(%.2f of the fp16 peak), eight waves %7.1f us (%.2f; %.2fx)" % (name, cin, cout, h, w, pool, us32, gfl / us32 / 1e6 / 157.3, us["four"],
-                                                                         3 * gfl / us["four"] / 1e6 / 2500.0, us["eight"], 3 * gfl / us["eight"] / 1e6 / 2500.0,
-                                                                         us["four"] / us["eight"]))
+        print("%-8s %4d->%4d %4dx%-4d pool=%d | float32 one-launch %7.1f us (%.2f of 157.3) | f32x3 one-launch, channel maxima given: " % (
+              name, cin, cout, h, w, pool, us32, gfl / us32 / 1e6 / 157.3) + ", ".join(
+              "%s %7.1f us (%.2f of the fp16 peak%s)" % (f, us[f], 3 * gfl / us[f] / 1e6 / 2500.0, "" if f == "four" else "; %.2fx" % (us["four"] / us[f])) for f, _ in forms))
 
 
 if __name__ == "__main__":
