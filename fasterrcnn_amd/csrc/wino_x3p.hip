@@ -63,7 +63,9 @@ void wino_x3p_kernel(const float* __restrict__ x_maps, const float* __restrict__
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, H * W * Cin * (int)sizeof(float), 0x00020000);
     const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cmax), 0, H * W * (int)sizeof(float), 0x00020000);
 
-    const int tl = lane & 31, tyl = tl >> 4, txl = tl & 15, kh = lane >> 5;
+    const int tl = lane & 31, kh = lane >> 5;
+    int tyl, txl;
+    xd_slot_tile(tl, tyl, txl);                                              // (a ds_read_b128 lane group = one tile row: conflict-free patch reads)
     float mult[2], vinv[2];
 
     // ---- halo staging by LDS-DMA (wino_x3d_kernel's: ring of three buffers, two chunks ahead) ------------------------------------------------
@@ -438,7 +440,9 @@ void wino_x3p_kernel(const float* __restrict__ x_maps, const float* __restrict__
             const int item = tid + 256 * it;                                 // (tile of 64, channel quad of 16)
             const int t = item >> 4, k = (item & 15) * 4;
             const int h = t >> 5, tt_ = t & 31;
-            const int oty = 4 * by + 2 * h + (tt_ >> 4), otx = XF_TC * bx + (tt_ & 15);
+            int sty, stx;
+            xd_slot_tile(tt_, sty, stx);
+            const int oty = 4 * by + 2 * h + sty, otx = XF_TC * bx + stx;
             const bool live = oty < gm.th && otx < gm.tw && !(POOL && (oty >= Ho || otx >= Wo));
             if (!live && !cmax_out) continue;
             const int kg = XP_CB * cb + 64 * rd + k;

@@ -38,7 +38,10 @@ import test_holdout_gpu as HG
 pytestmark = pytest.mark.gpu
 
 MIN_CASES = {"VGG16": 8, "ResNet50": 4}
-K_STRESS = 1.5
+# the admission criterion's level on this set: MEASURED (profiles/r05/stress_*.json, unchanged by round 6's bit-identical kernel changes) + 0.1, per
+# architecture -- VGG-16: proposals 1.20 / 1.03, detections 1.33 / 1.28 (median / p95 of our distance from the float64 truth over the reference's
+# own); ResNet-50: 1.16 / 1.26 and 1.16 / 1.35.  (Round 5 gated at the admission level 1.5 itself: a regression from 1.20 to 1.49 passed.)
+K_STRESS = {"VGG16": 1.43, "ResNet50": 1.46}
 
 
 def sweep(arch, slot):
@@ -79,6 +82,6 @@ def test_stress_sweep(arch, slot):
     # (1) the admission criterion
     for name, ours, ref in (("proposals", s["prop_vs_truth"], s["ref_prop_vs_truth"]), ("detections", s["det_vs_truth"], s["ref_det_vs_truth"])):
         for q in ("median", "p95"):
-            if not ours[q] <= K_STRESS * ref[q]:
-                bad.append("%s %s vs truth x%.3f > K %.2f" % (name, q, ours[q] / ref[q], K_STRESS))
+            if not ours[q] <= K_STRESS[arch] * ref[q]:
+                bad.append("%s %s vs truth x%.3f > K %.2f" % (name, q, ours[q] / ref[q], K_STRESS[arch]))
     assert not bad, bad

@@ -60,6 +60,12 @@ __device__ __forceinline__ void mix_lo(St& x, int p0, float mul)
                  : "=&v"(x.lo[p0]), "=&v"(x.lo[p0 + 1])
                  : "v"(x.t[2 * p0]), "v"(x.t[2 * p0 + 1]), "v"(x.t[2 * p0 + 2]), "v"(x.t[2 * p0 + 3]), "v"(mul), "v"(x.hi[p0]), "v"(x.hi[p0 + 1]));
 }
+// lo through float32: d = t - float(hi) exactly (v_fma_mix_f32 reads the fp16 half in place, full rate), then ONE v_cvt_pk_f16_f32 per pair
+__device__ __forceinline__ void lo_f32(St& x, int p)
+{
+    A1("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]", "=v"(x.l[2 * p]) : "v"(x.t[2 * p]), "v"(x.hi[p]));
+    A1("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]", "=v"(x.l[2 * p + 1]) : "v"(x.t[2 * p + 1]), "v"(x.hi[p]));
+}
 __device__ __forceinline__ void pk(unsigned& dst, float a, float b) { A1("v_cvt_pk_f16_f32 %0, %1, %2", "=v"(dst) : "v"(a), "v"(b)); }
 __device__ __forceinline__ void unpack(St& x, int p)
 {
@@ -94,6 +100,15 @@ template <int KIND> __device__ __forceinline__ void gap(St& x, int g)
         case 3: pk(x.hi[2], x.t[4], x.t[5]); pk(x.hi[3], x.t[6], x.t[7]); unpack(x, 2); unpack(x, 3); muls(x, 0, 0, 2); break;
         case 4: subs(x, 4); pk(x.lo[2], x.l[4], x.l[5]); pk(x.lo[3], x.l[6], x.l[7]); muls(x, 0, 2, 2); break;
         default: make_r(x, 2, 1); make_r(x, 0, 0); break;
+        }
+    } else if (KIND == 'F') {           // D with lo = v_cvt_pk(t - hi in float32): 4 more plain instructions, 8 fewer v_fma_mix, 4 more v_cvt_pk
+        switch (g) {
+        case 0: rd(x, 0); adds_scaled(x, 0); pk(x.hi[0], x.t[0], x.t[1]); pk(x.hi[1], x.t[2], x.t[3]); break;
+        case 1: lo_f32(x, 0); lo_f32(x, 1); muls(x, 0, 0, 2); break;
+        case 2: rd(x, 1); pk(x.lo[0], x.l[0], x.l[1]); pk(x.lo[1], x.l[2], x.l[3]); adds_scaled(x, 4); break;
+        case 3: pk(x.hi[2], x.t[4], x.t[5]); pk(x.hi[3], x.t[6], x.t[7]); lo_f32(x, 2); break;
+        case 4: lo_f32(x, 3); make_r(x, 2, 1); muls(x, 0, 2, 2); break;
+        default: pk(x.lo[2], x.l[4], x.l[5]); pk(x.lo[3], x.l[6], x.l[7]); make_r(x, 0, 0); break;
         }
     } else if (KIND == 'D') {
         switch (g) {
@@ -285,6 +300,8 @@ int main()
            run<'B', 0, 0, true>(blocks, out, cyc), run<'B', 0, 0, false>(blocks, out, cyc));
     printf("step D (hi by v_cvt_pk, lo by v_fma_mix, 36):    %.1f cycles per step with MFMAs, %.1f without\n",
            run<'D', 0, 0, true>(blocks, out, cyc), run<'D', 0, 0, false>(blocks, out, cyc));
+    printf("step F (hi by v_cvt_pk, lo by v_fma_mix_f32 + v_cvt_pk, 40): %.1f cycles per step with MFMAs, %.1f without\n",
+           run<'F', 0, 0, true>(blocks, out, cyc), run<'F', 0, 0, false>(blocks, out, cyc));
     unsigned char* blob;
     hipMalloc(&blob, 2 << 20); hipMemset(blob, 0x3c, 2 << 20);
     run_stream<0>(blocks, blob, out, cyc);

@@ -37,7 +37,7 @@ def main():
         u = torch.empty((int(lib.frcnn_conv3x3_winograd_x3_pack_bytes(cout, cin)),), dtype=torch.int8, device=dev)
         nv.check(lib.frcnn_pack_conv3x3_winograd(nv.ptr(wt), None, nv.ptr(bank), cout, cin, s), "pack")
         nv.check(lib.frcnn_pack_conv3x3_winograd_x3(nv.ptr(bank), nv.ptr(u), cout, cin, s), "pack_x3")
-        pair_ok = cin >= 64 and cout % 128 == 0
+        pair_ok = cin >= 64 and cout % 128 == 0 and int(lib.frcnn_conv3x3_winograd_x3_pair_workspace_bytes(1, h, w, cout)) > 0   # (make EXPERIMENTS=1 builds only)
         wsb = int(lib.frcnn_conv3x3_winograd_x3_pair_workspace_bytes(1, h, w, cout)) if pair_ok else int(lib.frcnn_conv3x3_winograd_x3_fused_workspace_bytes(1, h, w))
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
         # the channel maxima computed once outside the timed calls (the forward chains them through the layers: no pass over the input)
