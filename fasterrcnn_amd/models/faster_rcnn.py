@@ -385,6 +385,41 @@ class FasterRCNNModel(nn.Module):
             x3f = x3f + moved
         return x6, x3, x3f
 
+    # ---- ONE per-layer table (round 6): {layer: form}.  The five attributes above (winograd_x6_layers, winograd_x3_layers, winograd_x3f_layers,
+    # inflight_winograd_x3f_layers, alone_winograd_x3f_layers) remain as the storage and as DEPRECATED aliases; they grew one per round and
+    # since round 5 express one fact for VGG-16: "all 13 Winograd layers one-launch f32x3 in every slot".
+    LAYER_FORMS = ("f32", "f32x6", "f32x3", "f32x3_one_launch")
+
+    def layer_forms(self, slot_index=0):
+        """{layer: form} in force for a slot (f32_winograd mode; every layer "f32" otherwise): "f32" = the float32 one-launch Winograd / direct
+        kernel, "f32x6" / "f32x3" = the three-launch layer with split-operand position GEMMs, "f32x3_one_launch" = csrc/wino_x3f.hip."""
+        x6, x3, x3f = self.layer_tables(slot_index)
+        names = ("rpn_trunk",) if self._is_resnet else tuple(nv.X6_LAYER_BITS)
+        return {n: ("f32x3_one_launch" if n in x3f else "f32x3" if n in x3 else "f32x6" if n in x6 else "f32") for n in names}
+
+    def set_layer_forms(self, forms):
+        """Sets the table of EVERY slot from {layer: form} (layers not named keep "f32"); the deprecated per-kind attributes follow."""
+        forms = dict(forms)
+        for n, f in forms.items():
+            if n not in nv.X6_LAYER_BITS or f not in self.LAYER_FORMS:
+                raise ValueError("set_layer_forms: %r: %r (layers: %s; forms: %s)" % (n, f, ", ".join(nv.X6_LAYER_BITS), ", ".join(self.LAYER_FORMS)))
+        three = tuple(n for n in nv.X6_LAYER_BITS if forms.get(n) in ("f32x6", "f32x3"))
+        one = tuple(n for n in nv.X6_LAYER_BITS if forms.get(n) == "f32x3_one_launch")
+        if self._is_resnet:
+            if one or any(n != "rpn_trunk" for n in three):
+                raise NotImplementedError("ResNet: only the RPN trunk has a table entry (three-launch f32x6 / f32x3)")
+            self.winograd_x6_layers = three
+            self.winograd_x3_layers = tuple(n for n in three if forms[n] == "f32x3")
+            return
+        # one-launch layers that the three-launch kernels could also take live in the x6 / x3 tables and are MOVED per slot kind; the others
+        # (conv1_2 .. conv3_1, whose three-launch form has no packing) in winograd_x3f_layers
+        movable = tuple(n for n in one if n.startswith(("conv4", "conv5", "conv3_2", "conv3_3", "rpn")))
+        self.winograd_x6_layers = three + movable
+        self.winograd_x3_layers = tuple(n for n in three if forms[n] == "f32x3") + movable
+        self.winograd_x3f_layers = tuple(n for n in one if n not in movable)
+        self.inflight_winograd_x3f_layers = movable
+        self.alone_winograd_x3f_layers = movable
+
     def _slot_masks(self, slot_index):
         return tuple(sum(1 << nv.X6_LAYER_BITS[n] for n in names) for names in self.layer_tables(slot_index))
 

@@ -447,3 +447,25 @@ def test_runtime_feature_map_shape_matches_the_backbone_contract():
         for w in (32, 49, 320, 517, 1000, 1001):
             c, fh, fw = bb.compute_feature_map_shape((3, h, w))
             assert rt.feature_map_shape(h, w) == (fh, fw) and c == 1024
+
+
+def test_one_layer_table_round_trips_through_the_deprecated_attributes():
+    """set_layer_forms / layer_forms (round 6): one {layer: form} table for every slot; the five per-kind attributes are its storage."""
+    from fasterrcnn_amd import _native as nv
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    from fasterrcnn_amd.models.vgg16 import VGG16Backbone
+    m = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+    default = m.layer_forms(0)
+    assert default == m.layer_forms(1) == {n: "f32x3_one_launch" for n in nv.X6_LAYER_BITS}      # round 5: one table, all 13 layers one-launch f32x3
+    masks = (m._slot_masks(0), m._slot_masks(1))
+    m.set_layer_forms(default)
+    assert (m._slot_masks(0), m._slot_masks(1)) == masks and m.layer_forms(1) == default
+    mixed = {"conv1_2": "f32x3_one_launch", "conv3_2": "f32x6", "conv4_1": "f32x3", "conv5_3": "f32x3_one_launch", "rpn_trunk": "f32x3"}
+    m.set_layer_forms(mixed)
+    want = {n: mixed.get(n, "f32") for n in nv.X6_LAYER_BITS}
+    assert m.layer_forms(0) == want and m.layer_forms(2) == want
+    import pytest
+    with pytest.raises(ValueError):
+        m.set_layer_forms({"conv1_1": "f32x3"})
+    with pytest.raises(ValueError):
+        m.set_layer_forms({"conv4_1": "bf16"})
