@@ -49,7 +49,7 @@ SYMBOLS = (
     "frcnn_conv3x3_winograd_x3_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x3",
     "frcnn_conv3x3_winograd_x3_fused_workspace_bytes", "frcnn_conv3x3_winograd_x3_pair_workspace_bytes", "frcnn_conv3x3_nhwc_winograd_x3_fused", "frcnn_conv3x3_nhwc_winograd_x3_chain",
     "frcnn_x3t_record_bytes", "frcnn_rows_scale_x3t", "frcnn_split_rows_x3t", "frcnn_gemm_x3t_workspace_bytes", "frcnn_gemm_x3t",
-    "frcnn_conv3x3_nhwc_winograd_fused_maps", "frcnn_ctx_create_backbone", "frcnn_resnet_backbone", "frcnn_resnet_forward_features",
+    "frcnn_conv3x3_nhwc_winograd_fused_maps", "frcnn_ctx_create_backbone", "frcnn_resnet_backbone", "frcnn_resnet_forward_features", "frcnn_resnet_rpn_roipool", "frcnn_ctx_create_head", "frcnn_resnet_head",
     # training path
     "frcnn_label_proposals", "frcnn_gather_rows", "frcnn_rpn_loss", "frcnn_detector_loss",
     "frcnn_gemm_tn_math", "frcnn_conv3x3_wgrad_math", "frcnn_conv_wgrad_math",
@@ -299,6 +299,9 @@ _SIGNATURES = {
     "frcnn_gemm_x3t_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "frcnn_gemm_x3t": (C.c_int, [_vp, _vp, _i, _sz, _sz, _vp, _vp, _i, _sz, _sz, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "frcnn_ctx_create_backbone": (C.c_int, [C.POINTER(C.c_void_p), _i, _i, _i]),
+    "frcnn_ctx_create_head": (C.c_int, [C.POINTER(C.c_void_p), _i]),
+    "frcnn_resnet_rpn_roipool": (C.c_int, [_vp, C.POINTER(ResNetWeights), C.POINTER(ForwardParams), _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "frcnn_resnet_head": (C.c_int, [_vp, C.POINTER(ResNetWeights), C.POINTER(ForwardParams), _vp, _i, _vp, _vp, _vp]),
     "frcnn_conv3x3_nhwc_winograd_fused_maps": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u, _vp]),
     "frcnn_label_proposals": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         _vp, _vp, _vp, _vp, _vp, _vp]),

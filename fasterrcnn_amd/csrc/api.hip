@@ -45,6 +45,7 @@ struct frcnn_ctx {
     void* conv_ws = nullptr; size_t conv_ws_bytes = 0;   // split-K partials of under-filled conv layers
     void* wino_ws = nullptr; size_t wino_ws_bytes = 0;   // V and M of the Winograd layers; allocated by the first forward that needs it
     void* wx_ws = nullptr; size_t wx_ws_bytes = 0;       // V records, M and split-K partials of the x6 Winograd layers; allocated on first use
+    int max_head_rois = 0;      // frcnn_ctx_create_head: pooled RoIs a call of frcnn_resnet_head may bring
     float* x3p_spill = nullptr; size_t x3p_spill_bytes = 0;  // scratch of the two-pass one-launch f32x3 layers (csrc/wino_x3p.hip); first use
     float* x3f_cmax = nullptr; size_t x3f_cmax_bytes = 0;   // channel maxima of a one-launch f32x3 Winograd layer's input (csrc/wino_x3f.hip); first use
     void* rx_rec = nullptr; size_t rx_rec_bytes = 0;     // activation records of the x6 1x1 convolutions (ResNet bottlenecks); on first use
@@ -976,12 +977,13 @@ int ensure_wino_ws(frcnn_ctx* c)
     // VGG-16 layer shapes (image / 4, / 8, / 16)
     const int shapes[5][3] = {{4, 128, 256}, {4, 256, 256}, {8, 256, 512}, {8, 512, 512}, {16, 512, 512}};
     for (auto& sh : shapes) {
-        const size_t b = conv3x3_winograd_workspace_bytes(1, c->max_h / sh[0], c->max_w / sh[0], sh[1], sh[2]);
+        const size_t b = c->max_h > 0 ? conv3x3_winograd_workspace_bytes(1, c->max_h / sh[0], c->max_w / sh[0], sh[1], sh[2]) : 0;
         if (b > need) need = b;
     }
-    // ResNet: the RPN trunk on the 1024-channel map, layer4's 512-wide 3x3 on max_rois 4x4 maps
-    const size_t b1 = conv3x3_winograd_workspace_bytes(1, c->max_fh, c->max_fw, 1024, 1024);
-    const size_t b2 = conv3x3_winograd_workspace_bytes(c->max_rois, 4, 4, 512, 512);
+    // ResNet: the RPN trunk on the 1024-channel map, layer4's 512-wide 3x3 on max_rois 4x4 maps (a head ctx: max_head_rois)
+    const int rois = c->max_rois > c->max_head_rois ? c->max_rois : c->max_head_rois;
+    const size_t b1 = c->max_fh > 0 ? conv3x3_winograd_workspace_bytes(1, c->max_fh, c->max_fw, 1024, 1024) : 0;
+    const size_t b2 = rois > 0 ? conv3x3_winograd_workspace_bytes(rois, 4, 4, 512, 512) : 0;
     if (b1 > need) need = b1;
     if (b2 > need) need = b2;
     if (need == 0) return FRCNN_EINVAL;
@@ -1643,13 +1645,13 @@ int resnet_stage1(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forwa
 
 // stages 2 and 3 on the feature map in c->fm: RPN (models/rpn.py:88-153), RoI pooling, layer4 per RoI, spatial mean, heads
 // (models/detector.py:65-80, resnet.py:109-118)
-int resnet_tail(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p, int H, int W, int fh, int fw, int C,
-                const float* d_anchor_map, const float* d_valid_map, float* d_props, float* d_classes, float* d_deltas, int32_t* d_counts,
-                hipStream_t s)
+// ... in two halves (round 6): RPN + proposals + RoI pooling of ONE image into `roi_dst` ([post_nms][7][7][C]), and layer4 + spatial mean + heads over
+// `n_rois` pooled RoIs -- one image's (resnet_tail) or a whole batch's (frcnn_resnet_head: the per-RoI GEMMs of 8 images as ONE launch each)
+int resnet_rpn_roi(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p, int H, int W, int fh, int fw, int C,
+                   const float* d_anchor_map, const float* d_valid_map, float* d_props, int32_t* d_counts, float* roi_dst, hipStream_t s)
 {
     const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
     int rc;
-    int bi = w->n_blocks[0] + w->n_blocks[1] + w->n_blocks[2];
 #define STEP(cls, call) do { Scope _sc(c, cls, s); rc = (call); } while (0); if (rc) return rc
     c->last_fh = fh; c->last_fw = fw; c->last_pre = p->pre_nms; c->last_post = p->post_nms; c->last_c = C;
     if (p->winograd_x6_mask != 0 && (!wino || p->winograd_x6_mask != (1 << FRCNN_X6_RPN_TRUNK_BIT))) return FRCNN_EINVAL;
@@ -1682,13 +1684,25 @@ int resnet_tail(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward
 
     const int R_ = p->post_nms;
     if (p->roi_op == FRCNN_ROI_ALIGN) {
-        STEP(4, launch_roi_align(c->fm, fh, fw, C, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, p->roi_sampling_ratio, 0, c->roi_out, s));
+        STEP(4, launch_roi_align(c->fm, fh, fw, C, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, p->roi_sampling_ratio, 0, roi_dst, s));
     } else {
-        STEP(4, launch_roi_pool(c->fm, fh, fw, C, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, c->roi_out, s));
+        STEP(4, launch_roi_pool(c->fm, fh, fw, C, d_props, d_counts + 2, R_, 7, 1.0f / 16.0f, roi_dst, s));
     }
-    // layer4 reads its input from roi_out: stage it as res_buf "cur" by pointer swap
+#undef STEP
+    return FRCNN_OK;
+}
+
+int resnet_head(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p, float* roi_in, int n_rois, float* d_classes,
+                float* d_deltas, hipStream_t s)
+{
+    const bool wino = p->math_mode == FRCNN_MATH_F32_WINOGRAD;
+    int rc;
+    int bi = w->n_blocks[0] + w->n_blocks[1] + w->n_blocks[2];
+    const int R_ = n_rois;
+#define STEP(cls, call) do { Scope _sc(c, cls, s); rc = (call); } while (0); if (rc) return rc
+    // layer4 reads its input from the pooled RoIs: staged as res_buf "cur" by pointer swap
     float* saved = c->res_buf[0];
-    c->res_buf[0] = c->roi_out;
+    c->res_buf[0] = roi_in;
     int cur = 0, h = 7, wd = 7;
     {
         bool any_g3 = false;
@@ -1715,6 +1729,15 @@ int resnet_tail(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward
     STEP(5, launch_head_finish(c->head_logits, hld, R_, ncls, nd, d_classes, d_deltas, s));
 #undef STEP
     return FRCNN_OK;
+}
+
+int resnet_tail(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p, int H, int W, int fh, int fw, int C,
+                const float* d_anchor_map, const float* d_valid_map, float* d_props, float* d_classes, float* d_deltas, int32_t* d_counts,
+                hipStream_t s)
+{
+    int rc = resnet_rpn_roi(c, w, p, H, W, fh, fw, C, d_anchor_map, d_valid_map, d_props, d_counts, c->roi_out, s);
+    if (rc) return rc;
+    return resnet_head(c, w, p, c->roi_out, p->post_nms, d_classes, d_deltas, s);
 }
 }  // namespace
 
@@ -1810,6 +1833,84 @@ int frcnn_resnet_forward_features(frcnn_ctx* c, const frcnn_resnet_weights* w, c
     if (d_feature_map != c->fm)
         FRCNN_HIP_TRY(hipMemcpyAsync(c->fm, d_feature_map, (size_t)fh * fw * C * sizeof(float), hipMemcpyDeviceToDevice, s));
     return resnet_tail(c, w, p, H, W, fh, fw, C, d_anchor_map, d_valid_map, d_props, d_classes, d_deltas, d_counts, s);
+}
+
+// ---- ... and in THREE calls (round 6): the per-RoI head of a whole batch as one set of launches --------------------------------------------------
+// frcnn_resnet_rpn_roipool: stages 2 and the RoI pooling of ONE image (its own ctx and stream) into d_roi_out = its slice
+// [post_nms][7][7][C] of a batch buffer; frcnn_resnet_head (a ctx from frcnn_ctx_create_head): layer4 + spatial mean + heads
+// (models/resnet.py:109-118, detector.py:75-78) over the n_rois pooled RoIs of ALL images -- 14,700 / 4,800-row GEMMs per image become
+// 117,600 / 38,400-row GEMMs per batch of 8: whole tiles, no split-K, an eighth of the launches.
+int frcnn_resnet_rpn_roipool(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p, const float* d_feature_map, int H,
+                             int W, const float* d_anchor_map, const float* d_valid_map, float* d_props, int32_t* d_counts, float* d_roi_out,
+                             void* stream)
+{
+    if (!c || !w || !p || !d_feature_map || !d_props || !d_counts || !d_roi_out) return FRCNN_EINVAL;
+    if (H < 32 || W < 32 || H > c->max_h || W > c->max_w) return FRCNN_EINVAL;
+    if (p->post_nms < 1 || p->post_nms > c->max_rois || p->pre_nms < 1 || p->pre_nms > c->pre_cap) return FRCNN_EINVAL;
+    int rc = resnet_check_params(p);
+    if (rc) return rc;
+    rc = resnet_check_weights(w, true);
+    if (rc) return rc;
+    hipStream_t s = as_stream(stream);
+    BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows, p->x6_gemm_tiles);
+    if (p->math_mode == FRCNN_MATH_F32_WINOGRAD) { rc = ensure_wino_ws(c); if (rc) return rc; }
+    int fh = (H + 6 - 7) / 2 + 1, fw = (W + 6 - 7) / 2 + 1;
+    fh = (fh + 2 - 3) / 2 + 1; fw = (fw + 2 - 3) / 2 + 1;
+    for (int i = 0; i < 2; ++i) { fh = (fh + 2 - 3) / 2 + 1; fw = (fw + 2 - 3) / 2 + 1; }
+    const int nb3 = w->n_blocks[0] + w->n_blocks[1] + w->n_blocks[2];
+    const int C = w->blocks[nb3 - 1].cout;
+    if (fh > c->max_fh || fw > c->max_fw || C > 1024 || C % 64) return FRCNN_EINVAL;
+    if (d_feature_map != c->fm)
+        FRCNN_HIP_TRY(hipMemcpyAsync(c->fm, d_feature_map, (size_t)fh * fw * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return resnet_rpn_roi(c, w, p, H, W, fh, fw, C, d_anchor_map, d_valid_map, d_props, d_counts, d_roi_out, s);
+}
+
+int frcnn_ctx_create_head(frcnn_ctx** out, int max_rois_total)
+{
+    // scratch of frcnn_resnet_head only: the rotating layer4 buffers for max_rois_total pooled RoIs, the mean / logits rows, the split-K
+    // scratch of the gather kernel; record / Winograd scratch of the split-operand head modes is allocated by the first call that needs
+    // it.  Every other entry point refuses such a ctx (max_h = max_w = 0).
+    if (!out || max_rois_total < 1 || max_rois_total > 512 * 64) return FRCNN_EINVAL;
+    frcnn_ctx* c = new (std::nothrow) frcnn_ctx();
+    if (!c) return FRCNN_ENOMEM;
+    c->max_h = 0; c->max_w = 0; c->max_rois = 0; c->max_images = 0; c->max_head_rois = max_rois_total;
+    const size_t n = (size_t)max_rois_total;
+    c->res_buf_floats = n * 49 * 512 > n * 16 * 2048 ? n * 49 * 512 : n * 16 * 2048;
+    const size_t lin = linear_workspace_bytes(max_rois_total, FRCNN_HEAD_LD_MAX, 2048);
+    const size_t cws = (size_t)160 << 20;
+    struct Item { void** p; size_t bytes; };
+    Item items[] = {
+        {(void**)&c->fc2_out, n * 4096 * 4}, {(void**)&c->head_logits, n * FRCNN_HEAD_LD_MAX * 4}, {(void**)&c->lin_ws, lin}, {(void**)&c->conv_ws, cws},
+        {(void**)&c->res_buf[0], c->res_buf_floats * 4}, {(void**)&c->res_buf[1], c->res_buf_floats * 4}, {(void**)&c->res_buf[2], c->res_buf_floats * 4},
+        {(void**)&c->res_buf[3], c->res_buf_floats * 4}, {(void**)&c->res_buf[4], c->res_buf_floats * 4},
+    };
+    size_t total = 0;
+    for (auto& it : items) total += align_up(it.bytes, 256);
+    hipError_t e = hipMalloc(&c->slab, total);
+    if (e != hipSuccess) { set_hip_error(e); delete c; return FRCNN_ENOMEM; }
+    c->slab_bytes = total;
+    unsigned char* q = static_cast<unsigned char*>(c->slab);
+    for (auto& it : items) { *it.p = q; q += align_up(it.bytes, 256); }
+    c->lin_ws_bytes = lin;
+    c->conv_ws_bytes = cws;
+    *out = c;
+    return FRCNN_OK;
+}
+
+int frcnn_resnet_head(frcnn_ctx* c, const frcnn_resnet_weights* w, const frcnn_forward_params* p, float* d_rois, int n_rois, float* d_classes,
+                      float* d_deltas, void* stream)
+{
+    if (!c || !w || !p || !d_rois || !d_classes || !d_deltas) return FRCNN_EINVAL;
+    if (n_rois < 1 || n_rois > c->max_head_rois) return FRCNN_EINVAL;
+    if (w->num_classes < 2 || w->num_classes > FRCNN_MAX_NUM_CLASSES) return FRCNN_EUNSUPPORTED;
+    int rc = resnet_check_params(p);
+    if (rc) return rc;
+    rc = resnet_check_weights(w, true);
+    if (rc) return rc;
+    hipStream_t s = as_stream(stream);
+    BlocksTargetScope target_scope(p->conv_blocks_target, p->winograd_tile_rows, p->x6_gemm_tiles);
+    if (p->math_mode == FRCNN_MATH_F32_WINOGRAD) { rc = ensure_wino_ws(c); if (rc) return rc; }
+    return resnet_head(c, w, p, d_rois, n_rois, d_classes, d_deltas, s);
 }
 
 }  // extern "C"

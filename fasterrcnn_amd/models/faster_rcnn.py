@@ -138,7 +138,10 @@ class FasterRCNNModel(nn.Module):
         # ResNet: the bottlenecks of the feature extractor (layer1..3) run ALL their convolutions in the f32x3 arithmetic under one
         # power-of-two scale per tensor (round 4, csrc/conv_gather.hip conv_gather_x3_kernel; the per-RoI layer4 keeps x6_conv1x1's
         # row-scaled records).  "off" = round 3's exact-f32 gather / float32 Winograd kernels.  Default: "backbone" for ResNet-50
-        # (BASELINE configs[2]; held-out 1.14 / 1.18 of the reference's distance from the truth, 2397 / 2400 of its rows), "off" for
+        # (BASELINE configs[2]; held-out 1.14 / 1.18 of the reference's distance from the truth, 2397 / 2400 of its rows).  "all" (the per-RoI
+        # layer4 on the same kernel: no channel-maximum / record passes, no split-K reduce launches in the head) measured round 6: 641-654 ->
+        # 669-670 images/sec as batches of 8 with the held-out sweep unchanged to the row (1886 / 1886 detections, 1.18 / 1.27) -- and 230
+        # instead of 231 of the batch-8 golden image's 232 detections within 1e-3 px, so it stays an option (profiles/r06/r50_g3_all.txt); "off" for
         # ResNet-101 / -152: the criterion admits it there too (1.30 / 1.25) and it is 32 % faster, but the 23 blocks of layer3 cost 1.3 %
         # of the reference's rows within 1e-3 px (0.973 -> 0.960 as a set) on a configuration no BASELINE metric is quoted on
         # 
@@ -180,6 +183,10 @@ class FasterRCNNModel(nn.Module):
         # Off by default: measured on the MI355X box it changes nothing (one image at a time: 333.3 img/s with graphs, 334.2
         # eager) -- the kernels are 20-230 us long and the eager launch path already keeps their boundaries at ~2 us.
         self.use_hip_graphs = False
+        # predict_batch: the per-RoI head (layer4 + mean + classifier / regressor) of the whole batch as ONE set of launches on the lane's stream
+        # (frcnn_resnet_head, round 6) instead of one set per image on B streams
+        self.batch_head = False       # measured round 6: the head's kernel time falls by a third (1558 -> 1042 us per image) and images/sec do not
+                                      # follow (615 vs 650: the batch's 8 RPN / NMS chains must all end before ONE stream runs the head)
         # arithmetic of the train step's gradient GEMMs (every weight gradient, the data gradients of the dense layers):
         # "f32" (the reference's precision) or "bf16" (operands rounded to bfloat16, bf16 matrix pipe, f32 accumulation;
         # master weights, optimizer, losses and the convolutions' forward / data gradients stay float32) -- BASELINE.json configs[4]
@@ -674,6 +681,43 @@ class FasterRCNNModel(nn.Module):
                 nv.check(lib.frcnn_resnet_backbone(lane.handle, C.byref(weights), C.byref(params), nv.ptr(images), B, h, w,
                                                    nv.ptr(lane.features), lane.stream.cuda_stream), "frcnn_resnet_backbone")
                 lane.ready.record(lane.stream)
+            if self.batch_head and B > 1:
+                # the per-RoI head of the WHOLE batch as one set of launches (round 6): RPN + proposals + RoI pooling per image on its own
+                # stream into its slice of the lane's RoI buffer, layer4 + mean + heads over all B x post_nms RoIs on the lane's stream
+                # (frcnn_resnet_head), then decode / NMS / D2H per image again
+                R = int(self.max_proposals_post_nms)
+                lane.ensure_head(slots[0].max_rois, self._num_classes, channels)
+                per_roi = R * 49 * channels * 4                      # a slice = the image's post_nms pooled RoIs (every row written by the pooling)
+                for i, slot in enumerate(slots):
+                    stream = slot.use_stream()
+                    stream.wait_event(lane.ready)
+                    with t.cuda.stream(stream):
+                        nv.check(lib.frcnn_resnet_rpn_roipool(slot.ctx.handle, C.byref(weights), C.byref(params),
+                                                              lane.features.data_ptr() + i * per_map, h, w, None, None, nv.ptr(slot.props),
+                                                              nv.ptr(slot.counts), lane.roi_all.data_ptr() + i * per_roi, stream.cuda_stream),
+                                 "frcnn_resnet_rpn_roipool")
+                        slot.roi_ready.record(stream)
+                for slot in slots:
+                    lane.stream.wait_event(slot.roi_ready)
+                with t.cuda.stream(lane.stream):
+                    nv.check(lib.frcnn_resnet_head(lane.head_handle, C.byref(weights), C.byref(params), nv.ptr(lane.roi_all), B * R,
+                                                   nv.ptr(lane.classes_all), nv.ptr(lane.deltas_all), lane.stream.cuda_stream), "frcnn_resnet_head")
+                    lane.head_done.record(lane.stream)
+                for i, slot in enumerate(slots):
+                    stream = slot.use_stream()
+                    stream.wait_event(lane.head_done)
+                    with t.cuda.stream(stream):
+                        slot.classes[:R].copy_(lane.classes_all[i * R:(i + 1) * R], non_blocking=True)
+                        slot.deltas[:R].copy_(lane.deltas_all[i * R:(i + 1) * R], non_blocking=True)
+                        self._enqueue_outputs(slot, h, w, score_threshold, stream.cuda_stream)
+                        slot.done.record(stream)
+                    slot.graph, slot.graph_input, slot.graph_key = None, None, None
+                    slot.busy = True
+                    slot.keepalive = (images,)
+                    out.append(Pending(self, slot, score_threshold is not None))
+                lane.readers = slots
+                lane.keepalive = images
+                return out
             for i, slot in enumerate(slots):
                 stream = slot.use_stream()
                 stream.wait_event(lane.ready)

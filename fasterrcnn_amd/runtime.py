@@ -62,6 +62,9 @@ class Context:
             if getattr(self, "handle", None) is not None and self.handle.value:
                 nv.lib().frcnn_ctx_destroy(self.handle)
                 self.handle = None
+            if getattr(self, "head_handle", None) is not None and self.head_handle.value:
+                nv.lib().frcnn_ctx_destroy(self.head_handle)
+                self.head_handle = None
         except Exception:
             pass
 
@@ -100,6 +103,7 @@ class Slot:
         self.h_det_cnt = t.zeros((nfg,), dtype=t.int32).pin_memory()
         self.h_counts = t.zeros((4,), dtype=t.int32).pin_memory()
         self.done = t.cuda.Event()
+        self.roi_ready = t.cuda.Event()          # predict_batch: this image's pooled RoIs are in the lane's batch buffer
         self.graph, self.graph_key, self.graph_input, self.capture_stream = None, None, None, None    # hipGraph of the last call shape
         self.busy = False
         self.keepalive = None     # references that must outlive the enqueued work
@@ -128,6 +132,28 @@ class BackboneLane:
         self.ready = t.cuda.Event()
         self.readers = []            # the slots whose enqueued work still reads self.features
         self.keepalive = None
+        # the batch's per-RoI head as ONE set of launches (frcnn_resnet_head, round 6): made by ensure_head
+        self.head_handle = None
+        self.head_rois = 0
+        self.roi_all = self.classes_all = self.deltas_all = None
+        self.head_done = t.cuda.Event()
+
+    def ensure_head(self, max_rois, num_classes, channels=1024):
+        """The head ctx and the batch buffers: pooled RoIs [max_images][max_rois][7][7][channels], class scores and box deltas per RoI."""
+        total = self.max_images * int(max_rois)
+        if self.head_handle is not None and self.head_rois >= total and self.classes_all.shape[1] == num_classes:
+            return
+        if self.head_handle is not None:
+            t.cuda.synchronize(self.device)
+            nv.lib().frcnn_ctx_destroy(self.head_handle)
+            self.head_handle = None
+        handle = C.c_void_p()
+        with t.cuda.device(self.device):
+            nv.check(nv.lib().frcnn_ctx_create_head(C.byref(handle), total), "frcnn_ctx_create_head")
+        self.head_handle, self.head_rois = handle, total
+        self.roi_all = t.empty((total * 49 * int(channels),), dtype=t.float32, device=self.device)
+        self.classes_all = t.zeros((total, int(num_classes)), dtype=t.float32, device=self.device)
+        self.deltas_all = t.zeros((total, 4 * (int(num_classes) - 1)), dtype=t.float32, device=self.device)
 
     def fits(self, h, w, n):
         return h <= self.max_h and w <= self.max_w and n <= self.max_images
@@ -137,6 +163,9 @@ class BackboneLane:
             if getattr(self, "handle", None) is not None and self.handle.value:
                 nv.lib().frcnn_ctx_destroy(self.handle)
                 self.handle = None
+            if getattr(self, "head_handle", None) is not None and self.head_handle.value:
+                nv.lib().frcnn_ctx_destroy(self.head_handle)
+                self.head_handle = None
         except Exception:
             pass
 

@@ -46,7 +46,8 @@ extern "C" {
                                  and 13 (RPN trunk) of winograd_x3f_mask; 11: frcnn_conv_nhwc_x3g, frcnn_tensor_absmax, frcnn_bottleneck_weights.g3 / .wmax;
                                  12: frcnn_x3_saturation_events, FRCNN_X3F_WAVES4 / FRCNN_X3F_WAVES8; 13: REMOVED the round-2 f32x6 kernels that no table has used since round 3
                                  (frcnn_pack_conv3x3_x6, frcnn_conv3x3_nhwc_x6, frcnn_split_rows_x6, frcnn_linear_x6(_workspace_bytes), math mode 1 =
-                                 FRCNN_MATH_F32X6 and fc mode 1 = FRCNN_FC_F32X6 are FRCNN_EINVAL); the f32x6 arithmetic stays as gemm_x6t / wino_x6; 14: FRCNN_X3F_PAIR, frcnn_conv3x3_winograd_x3_pair_workspace_bytes */
+                                 FRCNN_MATH_F32X6 and fc mode 1 = FRCNN_FC_F32X6 are FRCNN_EINVAL); the f32x6 arithmetic stays as gemm_x6t / wino_x6; 14: FRCNN_X3F_PAIR, frcnn_conv3x3_winograd_x3_pair_workspace_bytes, frcnn_forward_params.winograd_x3p_mask,
+                                 frcnn_resnet_rpn_roipool / frcnn_ctx_create_head / frcnn_resnet_head */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -622,6 +623,18 @@ int frcnn_resnet_forward_features(frcnn_ctx* ctx, const frcnn_resnet_weights* w,
                                   const float* d_anchor_map, const float* d_valid_map,
                                   float* d_props, float* d_classes, float* d_deltas, int32_t* d_counts,
                                   void* stream);
+/* The same tail in THREE calls (round 6, ABI 14): frcnn_resnet_rpn_roipool = RPN + proposals + RoI pooling (models/rpn.py:88-153, detector.py:65-72) of ONE
+ * image from its feature map, into d_roi_out = that image's slice [post_nms][7][7][C] of a batch buffer (its own ctx and stream, as
+ * frcnn_resnet_forward_features); frcnn_resnet_head = layer4 + spatial mean + classifier / regressor (models/resnet.py:109-118, detector.py:75-78) over the
+ * n_rois pooled RoIs of ALL images in one set of launches (ctx: frcnn_ctx_create_head(max_rois_total)): d_classes [n_rois][num_classes],
+ * d_deltas [n_rois][4 (num_classes - 1)].  Rows are independent of each other; with the per-tensor-scaled f32x3 blocks (frcnn_bottleneck_weights.g3)
+ * the scales are those of the batch, so a batch's rows differ from the per-image call's at the rounding level (as frcnn_resnet_backbone's). */
+int frcnn_resnet_rpn_roipool(frcnn_ctx* ctx, const frcnn_resnet_weights* w, const frcnn_forward_params* p, const float* d_feature_map, int H,
+                             int W, const float* d_anchor_map, const float* d_valid_map, float* d_props, int32_t* d_counts, float* d_roi_out,
+                             void* stream);
+int frcnn_ctx_create_head(frcnn_ctx** out, int max_rois_total);
+int frcnn_resnet_head(frcnn_ctx* ctx, const frcnn_resnet_weights* w, const frcnn_forward_params* p, float* d_rois, int n_rois, float* d_classes,
+                      float* d_deltas, void* stream);
 
 /* ==========================================================================================
  * Training path (SURVEY.md section 8 rows f2 + f3): FasterRCNNModel.train_step,

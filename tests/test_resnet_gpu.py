@@ -517,6 +517,27 @@ def test_resnet50_batched_forward(r50, golden_dir):
         model.forward_batch(batch[0])                         # (3, H, W) is not a batch
 
 
+def test_resnet50_batch_head_option(r50):
+    """model.batch_head (round 6, off by default): frcnn_resnet_rpn_roipool per image + ONE frcnn_resnet_head over the batch's pooled RoIs.  The RPN half
+    is the per-image code on the same inputs (equal proposals); a RoI's head row is independent of the other rows, the batch only changes tile
+    and split-K choices of the GEMMs (float32 rounding)."""
+    model, _ = r50
+    batch = torch.stack([synthetic.image_rgb(s, 320, 448) for s in (31, 32, 33)]).cuda()
+    assert model.batch_head is False
+    per_image = model.forward_batch(batch)
+    model.batch_head = True
+    try:
+        batched = model.forward_batch(batch)
+        again = model.forward_batch(batch)
+    finally:
+        model.batch_head = False
+    for (p0, c0, d0), (p1, c1, d1), (p2, c2, d2) in zip(per_image, batched, again):
+        assert torch.equal(p0, p1)
+        assert float((c0 - c1).abs().max()) <= 1e-5
+        assert float((d0 - d1).abs().max()) <= 1e-4 * max(1.0, float(d0.abs().max()))
+        assert torch.equal(c1, c2) and torch.equal(d1, d2)            # deterministic
+
+
 R50_BATCH_PROPOSALS = 299       # the held-out floor (0.997 x 300); measured 299 (deterministic): the batch changes the split-K factors of the under-filled GEMMs; one box of the
 R50_BATCH_DETECTIONS = 231      # 0.997 x 232; measured 232.  The golden image then lands just outside 1e-3 px; batch-1 forwards keep 300 / 300 and 232 / 232
 
