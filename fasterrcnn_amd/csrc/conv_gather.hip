@@ -1123,12 +1123,14 @@ size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R
 }
 
 // the process-wide saturation counter of the per-tensor-scaled f32x3 convolutions: host-mapped (the kernels add to it with a system-scope
-// atomic, the host reads it after synchronising the stream -- no copy, no device allocation); null if the allocation fails (nothing is counted)
+// atomic, the host reads it after synchronising the stream -- no copy, no device allocation); null if the allocation fails (nothing is counted).
+// PORTABLE: one counter for the process, mapped for every device (allocated on first use with whichever device is current, it
+// was only guaranteed to be mapped there) -- the count is process-wide across devices
 unsigned* x3_saturation_counter()
 {
     static unsigned* counter = [] {
         unsigned* q = nullptr;
-        if (hipHostMalloc(reinterpret_cast<void**>(&q), 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return (unsigned*)nullptr; }
+        if (hipHostMalloc(reinterpret_cast<void**>(&q), 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return (unsigned*)nullptr; }
         *q = 0u;
         return q;
     }();
