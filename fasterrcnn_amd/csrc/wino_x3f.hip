@@ -40,7 +40,13 @@ namespace frcnn {
 // texture-address unit, wherever they are issued (that is what the persistent form moved into its epilogue).  A form that carried the
 // next item's pieces in the loop's own, today clamped and wasted, load slots could win that 1.1-2.5 us (3-7 % of a launch); the address
 // arithmetic (1.0 us), the first operand (0.35 us) and the 3.8-4.5 us after the loop would remain.  Not built.
-template <bool POOL>
+#ifndef XD_EARLY_HALO
+#define XD_EARLY_HALO 1      // 1: halo(1) / halo(2) leave in chunks 0 / 1; 0: at the end of the prologue (A/B: tools/run_ab_x3f.sh)
+#endif
+static constexpr int XD_FIRST = 1, XD_EARLY = XD_EARLY_HALO ? 2 : 0, XD_LAST = 4;             // chunk flags (the step lambda below)
+
+// TWO: the layer has exactly two 16-channel chunks (32 input channels)
+template <bool POOL, bool TWO>
 __global__ __launch_bounds__(256, 1)
 void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__ cmax_maps, const unsigned char* __restrict__ ublob,
                      const float* __restrict__ bias, float* __restrict__ y_maps, int H, int W, int Cin, int Cout, int u_rbt, int relu,
@@ -86,18 +92,16 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // (24-bit multiplies and reciprocal constants instead of integer divisions: this arithmetic stands between the block's entry and its first
     //  halo load; P < 1792 and slot < 359 keep the constants exact)
     int h_src[XD_NDMA];
-    auto halo_sources = [&]() {
-#pragma unroll
-        for (int it = 0; it < XD_NDMA; ++it) {
-            const unsigned P = (unsigned)((it * 4 + wave) * 64 + lane);
-            const unsigned slot = __umul24(P, 52429u) >> 18, part = P - 5u * slot;            // P / 5, P % 5
-            const unsigned hr = __umul24(slot, 1928u) >> 16, rem = slot - (unsigned)XF_HC * hr;   // slot / 34, slot % 34
-            const unsigned par = rem >= (unsigned)XD_HP ? 1u : 0u, hc = 2u * (rem - par * (unsigned)XD_HP) + par;
-            const int gy = hy0 + (int)hr, gx = hx0 + (int)hc;
-            const bool inb = part < 4u && hr < (unsigned)X3_HR && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const unsigned off = (__umul24((unsigned)gy, (unsigned)W) + (unsigned)gx) * (unsigned)(Cin * 4) + 16u * part;
-            h_src[it] = inb ? (int)off : (int)0xFFFFFFF0u;
-        }
+    auto halo_source = [&](auto IT) {
+        constexpr int it = decltype(IT)::value;
+        const unsigned P = (unsigned)((it * 4 + wave) * 64 + lane);
+        const unsigned slot = __umul24(P, 52429u) >> 18, part = P - 5u * slot;            // P / 5, P % 5
+        const unsigned hr = __umul24(slot, 1928u) >> 16, rem = slot - (unsigned)XF_HC * hr;   // slot / 34, slot % 34
+        const unsigned par = rem >= (unsigned)XD_HP ? 1u : 0u, hc = 2u * (rem - par * (unsigned)XD_HP) + par;
+        const int gy = hy0 + (int)hr, gx = hx0 + (int)hc;
+        const bool inb = part < 4u && hr < (unsigned)X3_HR && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const unsigned off = (__umul24((unsigned)gy, (unsigned)W) + (unsigned)gx) * (unsigned)(Cin * 4) + 16u * part;
+        h_src[it] = inb ? (int)off : (int)0xFFFFFFF0u;
     };
     // pieces [it0, it1) of chunk `chunk_off / 64` into the buffer at hb
     auto dma_halo = [&](float* hb, int chunk_off, auto IT0, auto IT1) {
@@ -232,7 +236,17 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // at a step's entry waits for the wave's outstanding LDS reads: ~10 % more cycles than the un-instrumented loop)
     unsigned long long xd_step_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xd_step_last = 0;
 #endif
-    auto step = [&](int ucb, int hso, float* hcur, float* hnxt, auto PAR, auto S, auto FIRST) {     // hso: byte offset of chunk c + 3 in a pixel
+    // FLAGS of a chunk (round 6: no load is issued twice, and none that nobody consumes):
+    //   XD_FIRST  chunk 0: every accumulator starts from a zero C operand
+    //   XD_EARLY  chunks 0 and 1: halo(c + 1) has NOT been issued yet (the prologue fetches halo(0) alone) -- its seven pieces leave in steps 0
+    //             and 1, beside the MFMAs, instead of standing between the block's entry and its first MFMA (each 1 KB load is 16 cycles of the
+    //             CU's one address unit, 64 with four waves: the prologue's 41 loads per wave were 2,600 cycles before the loop could start)
+    //   XD_LAST   the last chunk: no filter pieces for a next chunk, no patch reads / r / operand for it (they were clamped re-reads and
+    //             discarded work: ~23 loads and ~80 vector instructions of every block)
+    // Chunks K16 - 3 and K16 - 2 still re-read the last halo (14 pieces nobody consumes): as run-time branches around the two DMA groups
+    // of the generic chunk the skip cost the whole loop 250 cycles per chunk (measured; the branch ends the basic block the steps are
+    // placed in), and as more instantiations it costs code size.
+    auto step = [&](int ucb, int hso, int hso_next, float* hcur, float* hnxt, auto PAR, auto S, auto FLAGS) {     // hso: byte offset of chunk c + 3 in a pixel
         constexpr int par = decltype(PAR)::value, s = decltype(S)::value;
 #ifdef XD_STEPS
         {
@@ -241,7 +255,8 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
             xd_step_last = now;
         }
 #endif
-        constexpr bool first = decltype(FIRST)::value != 0;
+        constexpr bool first = (decltype(FLAGS)::value & XD_FIRST) != 0, early = (decltype(FLAGS)::value & XD_EARLY) != 0,
+                       last = (decltype(FLAGS)::value & XD_LAST) != 0;
         const f32x16 xd_zero16 = {};
         constexpr int h = s >> 2, j = s & 3, slot = s & 1, nslot = slot ^ 1;
         constexpr int nh = s == 3 ? 1 : s == 7 ? 0 : h, nj = (j + 1) & 3;                 // the operand formed in this step: V(nh, nj)
@@ -249,64 +264,75 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         constexpr int prb = j == 0 ? 3 : j == 1 ? 0 : j == 2 ? 2 : 1;                       // ... and the previous step's, whose upper channels are still due
         constexpr int rh = h ^ 1;                                                           // ... belongs to the other half (h 0: this chunk's, h 1: the next chunk's)
         constexpr int prh = j == 0 ? h : rh;                                                // the half of the previous step's column (step (h, 0) finishes column 3 of half h)
+        // the last chunk has no successor: its steps 4-7 read and form nothing for one (step 4 still finishes column 3 of ITS half 1)
+        constexpr bool col = !(last && h == 1), pcol = !(last && s >= 5), form = !(last && s == 7);
         const float* rsrc = h == 0 ? hcur : hnxt;
         const xf_f16x8 vh = frag(vhi[slot]), vl = frag(vlo[slot]);
         XD_MFMA0(par, h, j, 0, 1, vh);
-        XD_IF(2, read_d_lo(rsrc, rh, rb));
-        XD_IF(1, v_adds(nh, nj, 0));
+        if (col) XD_IF(2, read_d_lo(rsrc, rh, rb));
+        if (form) XD_IF(1, v_adds(nh, nj, 0));
         XD_FENCE();
         XD_MFMA0(par, h, j, 1, 1, vh);
-        XD_IF(1, v_hi(nslot, 0));
-        XD_IF(2, make_r(prb, 1, prh));
+        if (form) XD_IF(1, v_hi(nslot, 0));
+        if (pcol) XD_IF(2, make_r(prb, 1, prh));
         XD_FENCE();
         XD_MFMA(par, h, j, 0, 0, vh);
-        XD_IF(1, v_lo(nslot, 0));
-        XD_IF(2, read_d_hi(rsrc, rh, rb));
+        if (form) XD_IF(1, v_lo(nslot, 0));
+        if (col) XD_IF(2, read_d_hi(rsrc, rh, rb));
         // halo(c + 3) -> the buffer halo(c) was read from, free since the barrier of step 3 (its last patch read is that step's)
-        if (s == 4) dma_halo(hcur, hso, XdInt<0>{}, XdInt<4>{});
+        if (s == 4 && !last) dma_halo(hcur, hso, XdInt<0>{}, XdInt<4>{});
+        // chunks 0 and 1: halo(c + 1) -> the buffer steps 4-7 will read it from (landed by the barrier of step 3: the wait below)
+        if (early && !last && s == 0) dma_halo(hnxt, hso_next, XdInt<0>{}, XdInt<4>{});
+        if (early && !last && s == 1) dma_halo(hnxt, hso_next, XdInt<4>{}, XdInt<XD_NDMA>{});
         XD_FENCE();
         XD_MFMA(par, h, j, 1, 0, vh);
-        XD_IF(1, v_adds(nh, nj, 2));
-        XD_IF(1, v_hi(nslot, 2));
+        if (form) XD_IF(1, v_adds(nh, nj, 2));
+        if (form) XD_IF(1, v_hi(nslot, 2));
         XD_FENCE();
         XD_MFMA(par, h, j, 0, 0, vl);
-        XD_IF(1, v_lo(nslot, 2));
-        if (!(XD_ABLATE & 4)) {   // two of the next chunk's filter pieces per step: U[par ^ 1][s >> 1][s & 1][hi, lo]; the constants land in the instruction offset
+        if (form) XD_IF(1, v_lo(nslot, 2));
+        if (!last && !(XD_ABLATE & 4)) {   // two of the next chunk's filter pieces per step: U[par ^ 1][s >> 1][s & 1][hi, lo]; the constants land in the instruction offset
             const int so = ubase[s >> 1] + ucb;
             U[par ^ 1][s >> 1][s & 1][0] = __builtin_bit_cast(xf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16 + (s & 1) * HX_RB, so, 0));
             U[par ^ 1][s >> 1][s & 1][1] = __builtin_bit_cast(xf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16 + (s & 1) * HX_RB + HX_PIECE, so, 0));
         }
         XD_FENCE();
         XD_MFMA(par, h, j, 1, 0, vl);
-        XD_IF(2, make_r(rb, 0, rh));
+        if (col) XD_IF(2, make_r(rb, 0, rh));
         if (s == 3) {
-            // halo(c + 1) has landed: its DMA left in chunk c - 2 (the prologue for c < 2), and LDS-DMA completes in issue order like any
-            // vector memory load -- at most the 15 youngest may be outstanding: halo(c + 2)'s 7 pieces and the 8 filter pieces of steps
-            // 0-3 (chunk 0: exactly those; later chunks have 16 more filter pieces in between).  Then the block barrier: halo(c + 1)
-            // visible to every wave, halo(c)'s buffer spent.
-            asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            // halo(c + 1) has landed.  Steady state: its DMA left in chunk c - 2, and LDS-DMA completes in issue order like any vector
+            // memory load -- at most the 15 youngest may be outstanding: the last 3 pieces of halo(c + 2) (chunk c - 1, step 5), the 4
+            // filter pieces of that chunk's steps 6 and 7 and the 8 of this chunk's steps 0-3 (the tail chunks, which issue fewer
+            // loads, only make the count stricter).  Chunks 0 and 1 issued halo(c + 1) themselves, in steps 0 and 1: younger than its
+            // last piece are the 6 filter pieces of steps 1-3.  Then the block barrier: halo(c + 1) visible to every wave, halo(c)'s
+            // buffer spent.
+            if (early) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(last ? 0 : 6) : "memory");
+            else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
             xd_lds_barrier();
         }
-        if (s == 5) dma_halo(hcur, hso, XdInt<4>{}, XdInt<XD_NDMA>{});
+        if (s == 5 && !last) dma_halo(hcur, hso, XdInt<4>{}, XdInt<XD_NDMA>{});
         XD_FENCE();
     };
     // the ring: chunk c reads halo(c) from hcur (steps 0-3) and halo(c + 1) from hnxt (steps 4-7)
     float *hcur = hbuf0, *hnxt = hbuf0 + XD_HBUF_FLOATS, *hthird = hbuf0 + 2 * XD_HBUF_FLOATS;
-    auto chunk = [&](int c, auto PAR, auto FIRST) {
-        // past the last chunk the loads re-read it instead of branching (nobody consumes them)
-        const int ucb = (c + 1 < K16 ? c + 1 : K16 - 1) * chunk_stride, hso = (c + 3 < K16 ? c + 3 : K16 - 1) * 64;
-        step(ucb, hso, hcur, hnxt, PAR, XdInt<0>{}, FIRST); step(ucb, hso, hcur, hnxt, PAR, XdInt<1>{}, FIRST);
-        step(ucb, hso, hcur, hnxt, PAR, XdInt<2>{}, FIRST); step(ucb, hso, hcur, hnxt, PAR, XdInt<3>{}, FIRST);
-        step(ucb, hso, hcur, hnxt, PAR, XdInt<4>{}, FIRST); step(ucb, hso, hcur, hnxt, PAR, XdInt<5>{}, FIRST);
-        step(ucb, hso, hcur, hnxt, PAR, XdInt<6>{}, FIRST); step(ucb, hso, hcur, hnxt, PAR, XdInt<7>{}, FIRST);
+    auto chunk = [&](int c, auto PAR, auto FLAGS) {
+        // (past the last chunk the halo DMA re-reads it instead of branching; the filter offset of a chunk past the end is never used: XD_LAST)
+        const int ucb = (c + 1) * chunk_stride, hso = (c + 3 < K16 ? c + 3 : K16 - 1) * 64, hson = (c + 1) * 64;
+        step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<0>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<1>{}, FLAGS);
+        step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<2>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<3>{}, FLAGS);
+        step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<4>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<5>{}, FLAGS);
+        step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<6>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<7>{}, FLAGS);
         float* const t = hcur; hcur = hnxt; hnxt = hthird; hthird = t;
     };
 
     // ---- prologue ---------------------------------------------------------------------------------------------------------------------
-    // Every load the block needs before its first MFMA leaves HERE, back to back: the channel maxima, the filter pieces of chunk 0, the
-    // block's 16 x 64 filter scales and 64 biases (on their way to LDS: the epilogue has no register to prefetch them into and would
-    // otherwise wait for each of its 64 scale vectors in turn), then -- their source offsets computed under those loads -- halo(0 .. 2).  Their consumers follow below -- the earlier order
-    // (maxima, reduce, scales -> LDS, bias -> LDS, then the halo) was four round trips to memory, 4 us of every block.
+    // What the first MFMA needs leaves HERE, in order of need -- the halo pixels' channel maxima, the filter pieces of position column 0,
+    // halo(0) -- with the address arithmetic of the halo pieces BETWEEN those loads (a wave that has just issued a 1 KB load waits ~64
+    // cycles for the address unit's next slot whatever it does: the arithmetic used to stand in front of them); then, behind halo(0), the
+    // block's 16 x 64 filter scales and 64 biases (on their way to LDS: the epilogue has no register to prefetch them into) and the
+    // filter pieces of position columns 1-3, which land while the block forms its tile scales and its first operand.  halo(1) and
+    // halo(2) leave in chunks 0 and 1 (XD_EARLY).  Rounds 4-5 issued all 41 loads of a wave here, back to back: 2.2-3.5 us before the
+    // first could be consumed; the earliest order (maxima, reduce, scales -> LDS, bias -> LDS, then the halo) was four round trips.
     float* const sc_lds = reinterpret_cast<float*>(smem_xf + XD_SC_OFFSET);
     // the block's 16 x 64 filter scales and 64 biases -> LDS by DMA (16 bytes per thread = the [16][64] layout; the bias: 16 lanes): the
     // epilogue has no register to prefetch them into and would otherwise wait for each of its 64 scale vectors in turn
@@ -321,24 +347,38 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         cm_src[q] = inb ? (int)((__umul24((unsigned)gy, (unsigned)W) + (unsigned)gx) * 4u) : (int)0xFFFFFFF0u;
     }
     XD_FENCE();
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(mrs, (xd_lds_ptr)(smem_xf + XD_CM_OFFSET + (q * 4 + wave_u) * 256), 4, cm_src[q], 0, 0, 0);
-    if (!(XD_ABLATE & 32)) { load_u(0, XdInt<0>{}, XdInt<0>{}); load_u(0, XdInt<0>{}, XdInt<1>{}); load_u(0, XdInt<0>{}, XdInt<2>{}); load_u(0, XdInt<0>{}, XdInt<3>{}); }
+    auto load_u1 = [&](auto J, auto CT, auto T) {                            // one filter piece of chunk 0
+        constexpr int j = decltype(J)::value, ct = decltype(CT)::value, tt_ = decltype(T)::value;
+        U[0][j][ct][tt_] = __builtin_bit_cast(xf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16, ubase[j] + ct * HX_RB + tt_ * HX_PIECE, 0));
+    };
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(mrs, (xd_lds_ptr)(smem_xf + XD_CM_OFFSET + (0 * 4 + wave_u) * 256), 4, cm_src[0], 0, 0, 0);
+    halo_source(XdInt<0>{}); XD_FENCE();
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(mrs, (xd_lds_ptr)(smem_xf + XD_CM_OFFSET + (1 * 4 + wave_u) * 256), 4, cm_src[1], 0, 0, 0);
+    halo_source(XdInt<1>{}); XD_FENCE();
+    if (!(XD_ABLATE & 32)) load_u1(XdInt<0>{}, XdInt<0>{}, XdInt<0>{});
+    halo_source(XdInt<2>{}); XD_FENCE();
+    if (!(XD_ABLATE & 32)) load_u1(XdInt<0>{}, XdInt<0>{}, XdInt<1>{});
+    halo_source(XdInt<3>{}); XD_FENCE();
+    if (!(XD_ABLATE & 32)) load_u1(XdInt<0>{}, XdInt<1>{}, XdInt<0>{});
+    halo_source(XdInt<4>{}); XD_FENCE();
+    if (!(XD_ABLATE & 32)) load_u1(XdInt<0>{}, XdInt<1>{}, XdInt<1>{});
+    halo_source(XdInt<5>{}); halo_source(XdInt<6>{}); XD_FENCE();
+    // (XD_ABLATE 32, timing experiment: what the block pays for the prologue's loads -- no filter pieces, no halo)
+    if (!(XD_ABLATE & 32)) dma_halo(hcur, 0, XdInt<0>{}, XdInt<XD_NDMA>{});
     __builtin_amdgcn_global_load_lds(uinv0, (xd_lds_ptr)(smem_xf + XD_SC_OFFSET + wave_u * 1024), 16, 0, 0);
     if (wave_u == 0 && lane < 16) __builtin_amdgcn_global_load_lds(bias + 64 * cb + 4 * lane, (xd_lds_ptr)(smem_xf + XD_SC_OFFSET + 4096), 16, 0, 0);
     XD_FENCE();
-    halo_sources();                                                          // (under the loads above)
+    if (!(XD_ABLATE & 32)) { load_u(0, XdInt<0>{}, XdInt<1>{}); load_u(0, XdInt<0>{}, XdInt<2>{}); load_u(0, XdInt<0>{}, XdInt<3>{}); }
     XD_FENCE();
-    // (XD_ABLATE 32 / 64, timing experiments: what the block pays for the prologue's loads -- 32: no filter pieces, no halo; 64: halo(0) only)
-    if (!(XD_ABLATE & 32)) dma_halo(hcur, 0, XdInt<0>{}, XdInt<XD_NDMA>{});
-    if (!(XD_ABLATE & (32 | 64))) dma_halo(hnxt, (K16 > 1 ? 1 : 0) * 64, XdInt<0>{}, XdInt<XD_NDMA>{});
-    if (!(XD_ABLATE & (32 | 64))) dma_halo(hthird, (K16 > 2 ? 2 : K16 - 1) * 64, XdInt<0>{}, XdInt<XD_NDMA>{});
+    if (!XD_EARLY_HALO && !(XD_ABLATE & 32)) {
+        dma_halo(hnxt, 64, XdInt<0>{}, XdInt<XD_NDMA>{});
+        if (!TWO) dma_halo(hthird, 128, XdInt<0>{}, XdInt<XD_NDMA>{});
+    }
     XD_FENCE();
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_issued = __builtin_amdgcn_s_memrealtime();
 #endif
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD_ABLATE & (32 | 64)) ? 0 : 2 * XD_NDMA) : "memory");       // everything but halo(1) and halo(2): the maxima, the scales, halo(0) and the first filter pieces are in
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD_ABLATE & 32) ? 0 : 12 + (XD_EARLY_HALO ? 0 : (TWO ? 1 : 2) * XD_NDMA)) : "memory");       // everything but the 12 filter pieces of position columns 1-3: the maxima, column 0's pieces, halo(0), the scales and the bias are in
     xd_lds_barrier();
     {   // the lane's two tile scales from the halo pixels' channel maxima (rows 4 h + 2 tyl + a, columns 2 txl + c)
         const float* cm = reinterpret_cast<const float*>(smem_xf + XD_CM_OFFSET) + (2 * tyl) * XF_HC + 2 * txl;
@@ -366,11 +406,19 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_loop = __builtin_amdgcn_s_memrealtime(), xd_c_loop = __builtin_readcyclecounter();
 #endif
-    chunk(0, XdInt<0>{}, XdInt<1>{});                                        // chunk 0 starts every accumulator from a zero C operand
-    chunk(1, XdInt<1>{}, XdInt<0>{});
-    for (int c = 2; c < K16; c += 2) {                                       // K16 is even (cin % 32 == 0: checked by the launcher)
-        chunk(c, XdInt<0>{}, XdInt<0>{});
-        chunk(c + 1, XdInt<1>{}, XdInt<0>{});
+    // K16 is even (cin % 32 == 0: checked by the launcher).  Chunk 0 starts every accumulator from a zero C operand; chunks 0 and 1 fetch
+    // halo(1) and halo(2); the last chunk fetches and forms nothing for a successor
+    chunk(0, XdInt<0>{}, XdInt<XD_FIRST | XD_EARLY>{});
+    if constexpr (TWO) {                                                     // (its own instantiation: as a run-time branch the two paths cost the register allocation 318 spills)
+        chunk(1, XdInt<1>{}, XdInt<XD_EARLY | XD_LAST>{});
+    } else {
+        chunk(1, XdInt<1>{}, XdInt<XD_EARLY>{});
+        for (int c = 2; c < K16 - 2; c += 2) {
+            chunk(c, XdInt<0>{}, XdInt<0>{});
+            chunk(c + 1, XdInt<1>{}, XdInt<0>{});
+        }
+        chunk(K16 - 2, XdInt<0>{}, XdInt<0>{});
+        chunk(K16 - 1, XdInt<1>{}, XdInt<XD_LAST>{});
     }
 #undef XD_MFMA
 #undef XD_MFMA0
@@ -379,7 +427,7 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_done = __builtin_amdgcn_s_memrealtime(), xd_c_done = __builtin_readcyclecounter();
 #endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the clamped re-loads of the last chunks have landed too ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // (nothing is outstanding: the last chunks issue no load nobody consumes) ...
     __syncthreads();                                                         // ... and every wave is past its last halo read: the M buffer may overwrite the ring
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_e0 = __builtin_amdgcn_s_memrealtime();
@@ -402,15 +450,15 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 // (whole-vector expressions: no MFMA runs beside the epilogue, so the packed float32 instructions they become are the cheap form here)
-                f32x4 m[4];
+                // m_j = a_j x (filter scale 2^-e(j, channel)) is EXACT (a power of two), so every sum below is ONE fused multiply-add with the
+                // bits of the separately rounded form it replaces (round 6: 16 packed instructions per eight outputs instead of 20):
+                //   Y0 = ((m0 + m1) + m2) 2^-e(tile),   Y1 = ((m1 - m2) - m3) 2^-e(tile)
+                f32x4 a[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 a = {acc[h][j][ct][4 * g], acc[h][j][ct][4 * g + 1], acc[h][j][ct][4 * g + 2], acc[h][j][ct][4 * g + 3]};
-                    m[j] = a * sb[j];
-                }
+                for (int j = 0; j < 4; ++j) a[j] = f32x4{acc[h][j][ct][4 * g], acc[h][j][ct][4 * g + 1], acc[h][j][ct][4 * g + 2], acc[h][j][ct][4 * g + 3]};
                 const f32x4 vi = {vinv[h], vinv[h], vinv[h], vinv[h]};       // the tile's 2^-e: exact, commutes with every rounding above
-                const f32x4 y0 = ((m[0] + m[1]) + m[2]) * vi;
-                const f32x4 y1 = xd_sub4(xd_sub4(m[1], m[2]), m[3]) * vi;
+                const f32x4 y0 = __builtin_elementwise_fma(a[2], sb[2], __builtin_elementwise_fma(a[1], sb[1], a[0] * sb[0])) * vi;
+                const f32x4 y1 = __builtin_elementwise_fma(a[3], -sb[3], __builtin_elementwise_fma(a[2], -sb[2], a[1] * sb[1])) * vi;
                 float* dst = ybuf + ((((h * 4 + wave) * 2) * 32 + tl) * XD_MS) + co;
                 *reinterpret_cast<f32x4*>(dst) = y0;
                 *reinterpret_cast<f32x4*>(dst + 32 * XD_MS) = y1;
@@ -445,19 +493,15 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
             o[0][bb] = ((Y[0][bb] + Y[1][bb]) + Y[2][bb]) + bv;
             o[1][bb] = xd_sub4(xd_sub4(Y[1][bb], Y[2][bb]), Y[3][bb]) + bv;
         }
-        if (relu) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[a][bb][e] = fmaxf(o[a][bb][e], 0.f);
-        }
         // (the 16 lanes of a tile's 64 channels = one DPP row reduce their maxima with four row rotations; one atomic per pixel and block)
         if (POOL) {
+            // max-pool of the ReLUs = ReLU of the maximum: two v_max3_f32 per channel instead of four ReLUs and three maxima
             f32x4 mx;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mx[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
+            for (int e = 0; e < 4; ++e) {
+                mx[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
+                if (relu) mx[e] = fmaxf(mx[e], 0.f);
+            }
             if (live) *reinterpret_cast<f32x4*>(y + ((size_t)oty * Wo + otx) * Cout + kg) = mx;
             if (cmax_out) {
                 const float pm = xd_rowmax16(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
@@ -471,6 +515,10 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
                 for (int bb = 0; bb < 2; ++bb) {
                     const int xx = 2 * otx + bb;
                     const bool ok = live && yy < H && xx < W;
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[a][bb][e] = fmaxf(o[a][bb][e], 0.f);
+                    }
                     if (ok) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * Cout + kg) = o[a][bb];
                     if (cmax_out) {
                         const float pm = xd_rowmax16(fmaxf(fmaxf(o[a][bb][0], o[a][bb][1]), fmaxf(o[a][bb][2], o[a][bb][3])));
@@ -588,15 +636,15 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
 #else
         return launch_wino_x3e((flags & FRCNN_POOL2) != 0, (unsigned)grid_blocks, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm, cmax_out, s);
 #endif
-    if (flags & FRCNN_POOL2) {
-        auto kern = wino_x3d_kernel<true>;
-        FRCNN_MAX_LDS_ONCE(kern, XD_LDS_BYTES);
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid_blocks), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm, cmax_out);
-    } else {
-        auto kern = wino_x3d_kernel<false>;
-        FRCNN_MAX_LDS_ONCE(kern, XD_LDS_BYTES);
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid_blocks), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm, cmax_out);
-    }
+#define XD_LAUNCH(P_, T_)                                                                                                                    \
+    do {                                                                                                                                    \
+        auto kern = wino_x3d_kernel<P_, T_>;                                                                                                \
+        FRCNN_MAX_LDS_ONCE(kern, XD_LDS_BYTES);                                                                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid_blocks), dim3(256), XD_LDS_BYTES, s, x, cmax, ub, b, y, H, W, cin, cout, u_rbt, relu, gm, cmax_out); \
+    } while (0)
+    if (flags & FRCNN_POOL2) { if (cin == 32) XD_LAUNCH(true, true); else XD_LAUNCH(true, false); }
+    else                     { if (cin == 32) XD_LAUNCH(false, true); else XD_LAUNCH(false, false); }
+#undef XD_LAUNCH
     return check_launch();
 }
 
