@@ -17,7 +17,7 @@ static constexpr int X3_HR = 10;                             // halo rows: 4 til
 
 // m_*: ceil(2^32 / d) of the three divisors of the block index (0 for d = 1): the quotient is ONE scalar multiply-high on the device instead of
 // a division sequence per divisor between the block's entry and its first load (exact while block index x d < 2^32: checked by the launcher)
-struct XfGeom { int tbx, tby, ncb, tw, th, xg; unsigned m_tbx, m_tby, m_ncb; int ntb; unsigned m_ntb; };   // ntb: tile blocks of all maps
+struct XfGeom { int tbx, tby, ncb, tw, th, xg; unsigned m_tbx, m_tby, m_ncb; int ntb; unsigned m_ntb; int g8; };   // ntb: tile blocks of all maps; g8 = 8 / ncb (xg == 2, ncb < 8: a division sequence on the device otherwise)
 __device__ __forceinline__ int xd_div(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
 
 typedef float xd_f32x2 __attribute__((ext_vector_type(2)));
@@ -72,7 +72,7 @@ __device__ __forceinline__ f32x4 xd_sub4(f32x4 a, f32x4 b)
 __device__ __forceinline__ void xd_slot_tile(int s, int& ty, int& tx)
 {
     ty = (int)((0xF00F0FF0u >> s) & 1u);          // s: 0-3 -> 0, 4-11 -> 1, 12-15 -> 0, 16-19 -> 1, 20-27 -> 0, 28-31 -> 1
-    tx = s < 4 ? s : s < 12 ? s - 4 : s < 20 ? s - 8 : s < 28 ? s - 12 : s - 16;
+    tx = s - 4 * ((s + 4) >> 3);                  // s: 0-3 -> s, 4-11 -> s - 4, 12-19 -> s - 8, 20-27 -> s - 12, 28-31 -> s - 16 (as a chain of ?: the compiler made it divergent branches)
 }
 
 __device__ __forceinline__ void xd_lds_barrier()
@@ -101,7 +101,7 @@ __device__ __forceinline__ bool xd_block_to_tile(const XfGeom& gm, int b, int& c
             cb = xcd + 8 * k;
             b = s - k * gm.ntb;
         } else {
-            const int g = 8 / gm.ncb, sub = xd_div(xcd, gm.ncb, gm.m_ncb);
+            const int g = gm.g8, sub = xd_div(xcd, gm.ncb, gm.m_ncb);
             cb = xcd - sub * gm.ncb;
             b = s * g + sub;
             if (b >= gm.ntb) return false;

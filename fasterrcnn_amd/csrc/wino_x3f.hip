@@ -17,6 +17,8 @@
 
 namespace frcnn {
 
+typedef unsigned xp_u32x4_t __attribute__((ext_vector_type(4)));
+
 // ---- the kernel: 64 tiles per block, the filter fragments straight from L2 into registers ------------------------------------------------------
 // What bounded round 3's versions was the L2 -> LDS staging of the filter records (64 KB per chunk and block by LDS-DMA: ~17 B per clock and CU).
 // Every filter piece is read by exactly ONE wave (a wave owns a position row), and a piece IS the register image of an MFMA operand
@@ -40,6 +42,69 @@ namespace frcnn {
 // texture-address unit, wherever they are issued (that is what the persistent form moved into its epilogue).  A form that carried the
 // next item's pieces in the loop's own, today clamped and wasted, load slots could win that 1.1-2.5 us (3-7 % of a launch); the address
 // arithmetic (1.0 us), the first operand (0.35 us) and the 3.8-4.5 us after the loop would remain.  Not built.
+
+// ---- the epilogue's channel maxima: sixteen (four) row reductions as ONE butterfly -----------------------------------------------------------
+// A thread of the row pass holds, per output pixel, the maximum of its four channels; the 16 lanes of a DPP row hold the 64 channels of that
+// pixel.  Rounds 4-5 reduced every pixel on its own (four row rotations each: v_mov_b32_dpp + v_max_f32, every lane ending with the same
+// value) and lane 0 of the row issued one atomic per pixel: 16 reductions and 16 atomic instructions per thread for a layer without pooling --
+// and a vector-memory instruction is 16 cycles of the CU's address unit whatever its active lanes: the 16 stores + 16 atomics of a wave were
+// the row pass's time (2.2-2.5 us against 1.3 of the pooled layers).  Here the reductions share a reduce-scatter: v_max_f32 with a DPP operand
+// and a bank mask keeps, per step, the half of the values whose index bit equals the lane's bit (partner lane ^ 8, then lane ^ 4: banks of
+// four lanes), two quad permutations finish it, and lane i of the row ends with the maximum of value i: 32 instructions instead of 128, and
+// ONE atomic instruction per thread.  (VALU write -> DPP read of the same register needs two wait states: the order below keeps three
+// instructions between them; the s_nop covers the compiler's code in front.)
+// v[16] -> the row's maximum of v[lane & 15]
+__device__ __forceinline__ float xd_rowmax16_scatter16(const float (&v)[16])
+{
+    float n0, n1, n2, n3, n4, n5, n6, n7;
+    asm volatile("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\tv_max_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_max_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\tv_max_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_max_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\tv_max_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_max_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0x3\n\tv_max_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_max_f32_dpp %0, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\tv_max_f32_dpp %1, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_max_f32_dpp %2, %18, %18 row_ror:8 row_mask:0xf bank_mask:0xc\n\tv_max_f32_dpp %3, %19, %19 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_max_f32_dpp %4, %20, %20 row_ror:8 row_mask:0xf bank_mask:0xc\n\tv_max_f32_dpp %5, %21, %21 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_max_f32_dpp %6, %22, %22 row_ror:8 row_mask:0xf bank_mask:0xc\n\tv_max_f32_dpp %7, %23, %23 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "=&v"(n4), "=&v"(n5), "=&v"(n6), "=&v"(n7)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+          "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    float m0, m1, m2, m3;
+    // banks 0, 2 (lane bit 2 clear) keep n0..n3 and read lane + 4 (row_ror:12: lane i reads lane i - 12 = i + 4 of its row); banks 1, 3 keep n4..n7 and read lane - 4
+    asm volatile(
+        "v_max_f32_dpp %0, %4, %4 row_ror:12 row_mask:0xf bank_mask:0x5\n\tv_max_f32_dpp %1, %5, %5 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_max_f32_dpp %2, %6, %6 row_ror:12 row_mask:0xf bank_mask:0x5\n\tv_max_f32_dpp %3, %7, %7 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_max_f32_dpp %0, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xa\n\tv_max_f32_dpp %1, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_max_f32_dpp %2, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n\tv_max_f32_dpp %3, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+        : "v"(n0), "v"(n1), "v"(n2), "v"(n3), "v"(n4), "v"(n5), "v"(n6), "v"(n7));
+    const int q = (int)(threadIdx.x & 3);
+    return q == 0 ? m0 : q == 1 ? m1 : q == 2 ? m2 : m3;
+}
+// v[4] -> the row's maximum of v[(lane & 15) >> 2] (every lane of a bank of four ends with its bank's value)
+__device__ __forceinline__ float xd_rowmax16_scatter4(const float (&v)[4])
+{
+    float n0, n1, m;
+    asm volatile("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\tv_max_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_max_f32_dpp %0, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\tv_max_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %2, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\tv_max_f32_dpp %2, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "=&v"(n0), "=&v"(n1), "=&v"(m)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    return m;
+}
+
 #ifndef XD_EARLY_HALO
 #define XD_EARLY_HALO 1      // 1: halo(1) / halo(2) leave in chunks 0 / 1; 0: at the end of the prologue (A/B: tools/run_ab_x3f.sh)
 #endif
@@ -99,7 +164,10 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         const unsigned hr = __umul24(slot, 1928u) >> 16, rem = slot - (unsigned)XF_HC * hr;   // slot / 34, slot % 34
         const unsigned par = rem >= (unsigned)XD_HP ? 1u : 0u, hc = 2u * (rem - par * (unsigned)XD_HP) + par;
         const int gy = hy0 + (int)hr, gx = hx0 + (int)hc;
-        const bool inb = part < 4u && hr < (unsigned)X3_HR && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        // (one unsigned comparison per coordinate, no short circuit: as && the compiler made every piece a nest of execution-mask branches;
+        //  only the last piece reaches halo rows >= X3_HR)
+        bool inb = (part < 4u) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+        if (it == XD_NDMA - 1) inb &= hr < (unsigned)X3_HR;
         const unsigned off = (__umul24((unsigned)gy, (unsigned)W) + (unsigned)gx) * (unsigned)(Cin * 4) + 16u * part;
         h_src[it] = inb ? (int)off : (int)0xFFFFFFF0u;
     };
@@ -343,7 +411,7 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         const unsigned P = (unsigned)(tid + 256 * q);
         const unsigned hr = __umul24(P, 1928u) >> 16, hc = P - (unsigned)XF_HC * hr;              // P / 34, P % 34
         const int gy = hy0 + (int)hr, gx = hx0 + (int)hc;
-        const bool inb = hr < (unsigned)X3_HR && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bool inb = (hr < (unsigned)X3_HR) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
         cm_src[q] = inb ? (int)((__umul24((unsigned)gy, (unsigned)W) + (unsigned)gx) * 4u) : (int)0xFFFFFFF0u;
     }
     XD_FENCE();
@@ -409,16 +477,36 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // K16 is even (cin % 32 == 0: checked by the launcher).  Chunk 0 starts every accumulator from a zero C operand; chunks 0 and 1 fetch
     // halo(1) and halo(2); the last chunk fetches and forms nothing for a successor
     chunk(0, XdInt<0>{}, XdInt<XD_FIRST | XD_EARLY>{});
+#ifdef XD_CHUNK_CLOCKS
+    const unsigned long long xd_c_k0 = __builtin_readcyclecounter();
+    unsigned long long xd_c_k1 = xd_c_k0, xd_c_kl = xd_c_k0, xd_c_kl2 = xd_c_k0;
+#endif
     if constexpr (TWO) {                                                     // (its own instantiation: as a run-time branch the two paths cost the register allocation 318 spills)
-        chunk(1, XdInt<1>{}, XdInt<XD_EARLY | XD_LAST>{});
+        int one = 1;
+        asm volatile("" : "+s"(one));
+        for (int rep = 0; rep < one; ++rep) chunk(1, XdInt<1>{}, XdInt<XD_EARLY | XD_LAST>{});     // (one trip: see below)
     } else {
         chunk(1, XdInt<1>{}, XdInt<XD_EARLY>{});
+#ifdef XD_CHUNK_CLOCKS
+        xd_c_k1 = __builtin_readcyclecounter();
+#endif
         for (int c = 2; c < K16 - 2; c += 2) {
             chunk(c, XdInt<0>{}, XdInt<0>{});
             chunk(c + 1, XdInt<1>{}, XdInt<0>{});
         }
+#ifdef XD_CHUNK_CLOCKS
+        xd_c_kl2 = __builtin_readcyclecounter();
+#endif
         chunk(K16 - 2, XdInt<0>{}, XdInt<0>{});
-        chunk(K16 - 1, XdInt<1>{}, XdInt<XD_LAST>{});
+#ifdef XD_CHUNK_CLOCKS
+        xd_c_kl = __builtin_readcyclecounter();
+#endif
+        // (a loop of ONE trip the compiler cannot count: as straight-line code in front of the epilogue the register allocator moved the
+        //  epilogue's 176 accumulator reads up behind the last MFMA of each accumulator -- v_accvgpr_read_b32 behind s_nop 11, a full
+        //  MFMA latency of stall per accumulator: the last chunk measured 3,600 cycles against the 2,480 of a steady-state chunk)
+        int one = 1;
+        asm volatile("" : "+s"(one));
+        for (int rep = 0; rep < one; ++rep) chunk(K16 - 1, XdInt<1>{}, XdInt<XD_LAST>{});
     }
 #undef XD_MFMA
 #undef XD_MFMA0
@@ -469,6 +557,16 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     const unsigned long long xd_t_e1 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int Ho = H >> 1, Wo = W >> 1;
+    // ReLU as ONE v_max_f32 against a uniform lower bound (0 or -inf): fmaxf(x, 0) is two instructions (the compiler quiets a possible
+    // signalling NaN first) and `if (relu)` duplicated the row pass behind a branch
+    const float lowb = relu ? 0.f : -__builtin_inff();
+    auto xmax = [](float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    // Stores through a buffer descriptor: a pixel outside the image carries an offset past the descriptor's size and the hardware drops the
+    // store -- no execution-mask branch per pixel, 32-bit offsets (the launcher bounds a map's bytes by 2^31).  Every thread computes all
+    // four of its items (a tile outside the image is garbage nobody stores: its halo was zeros), so the row's lanes stay together for
+    // the reduce-scatter below.
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, (POOL ? Ho * Wo : H * W) * Cout * (int)sizeof(float), 0x00020000);
+    float pmv[POOL ? 4 : 16];                                                // per output pixel of the thread's four items: the maximum of its four channels
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int item = tid + 256 * it;                                     // (tile of 64, channel quad of 16)
@@ -477,8 +575,6 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         int sty, stx;
         xd_slot_tile(tt_, sty, stx);
         const int oty = 4 * by + 2 * h + sty, otx = XF_TC * bx + stx;
-        const bool live = oty < gm.th && otx < gm.tw && !(POOL && (oty >= Ho || otx >= Wo));
-        if (!live && !cmax_out) continue;
         const int kg = 64 * cb + k;
         const float* yp = ybuf + ((h * 4) * 2 * 32 + tt_) * XD_MS + k;      // + (i 2 + b) 32 XD_MS
         f32x4 Y[4][2];
@@ -493,39 +589,53 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
             o[0][bb] = ((Y[0][bb] + Y[1][bb]) + Y[2][bb]) + bv;
             o[1][bb] = xd_sub4(xd_sub4(Y[1][bb], Y[2][bb]), Y[3][bb]) + bv;
         }
-        // (the 16 lanes of a tile's 64 channels = one DPP row reduce their maxima with four row rotations; one atomic per pixel and block)
-        if (POOL) {
+        if constexpr (POOL) {
             // max-pool of the ReLUs = ReLU of the maximum: two v_max3_f32 per channel instead of four ReLUs and three maxima
             f32x4 mx;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                mx[e] = fmaxf(fmaxf(o[0][0][e], o[0][1][e]), fmaxf(o[1][0][e], o[1][1][e]));
-                if (relu) mx[e] = fmaxf(mx[e], 0.f);
+                float m3;
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(o[0][0][e]), "v"(o[0][1][e]), "v"(o[1][0][e]));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx[e]) : "v"(m3), "v"(o[1][1][e]), "v"(lowb));
             }
-            if (live) *reinterpret_cast<f32x4*>(y + ((size_t)oty * Wo + otx) * Cout + kg) = mx;
-            if (cmax_out) {
-                const float pm = xd_rowmax16(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
-                if (live && (item & 15) == 0) atomicMax(reinterpret_cast<unsigned*>(cmax_out + (size_t)oty * Wo + otx), __float_as_uint(pm));
-            }
+            const bool live = (oty < Ho) & (otx < Wo);                     // (Ho <= th, Wo <= tw)
+            const int off = live ? ((oty * Wo + otx) * Cout + kg) * 4 : (int)0xFFFFFFF0u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xp_u32x4_t, mx), yrs, off, 0, 0);
+            { float m3; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(mx[0]), "v"(mx[1]), "v"(mx[2])); pmv[it] = xmax(m3, mx[3]); }
         } else {
+            const int base = ((2 * oty * W + 2 * otx) * Cout + kg) * 4;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                const int yy = 2 * oty + a;
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb) {
-                    const int xx = 2 * otx + bb;
-                    const bool ok = live && yy < H && xx < W;
-                    if (relu) {
+                    const bool ok = (2 * oty + a < H) & (2 * otx + bb < W);  // (th = ceil(H / 2): a tile row past it has 2 oty >= H)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[a][bb][e] = fmaxf(o[a][bb][e], 0.f);
-                    }
-                    if (ok) *reinterpret_cast<f32x4*>(y + ((size_t)yy * W + xx) * Cout + kg) = o[a][bb];
-                    if (cmax_out) {
-                        const float pm = xd_rowmax16(fmaxf(fmaxf(o[a][bb][0], o[a][bb][1]), fmaxf(o[a][bb][2], o[a][bb][3])));
-                        if (ok && (item & 15) == 0) atomicMax(reinterpret_cast<unsigned*>(cmax_out + (size_t)yy * W + xx), __float_as_uint(pm));
-                    }
+                    for (int e = 0; e < 4; ++e) o[a][bb][e] = xmax(o[a][bb][e], lowb);
+                    const int off = ok ? base + (a * W + bb) * Cout * 4 : (int)0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xp_u32x4_t, o[a][bb]), yrs, off, 0, 0);
+                    { float m3; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(o[a][bb][0]), "v"(o[a][bb][1]), "v"(o[a][bb][2])); pmv[it * 4 + a * 2 + bb] = xmax(m3, o[a][bb][3]); }
                 }
             }
+        }
+    }
+    if (cmax_out) {
+        // the per-pixel channel maxima of the block's 64 channels: one reduce-scatter over the row, ONE atomic per thread (the buffer was
+        // zeroed by the caller; outputs are post-ReLU, and non-negative floats order like their bit patterns).  Lane l of a row ends
+        // with pixel (item l >> 2, position l & 3) of the row's items (pooled: item l >> 2, lanes l & 3 == 0 write).
+        const int li = tid & 15, itl = li >> 2;
+        const int t = (tid >> 4) + 16 * itl, h = t >> 5, tt_ = t & 31;
+        int sty, stx;
+        xd_slot_tile(tt_, sty, stx);
+        const int oty = 4 * by + 2 * h + sty, otx = XF_TC * bx + stx;
+        if constexpr (POOL) {
+            const float pm = xd_rowmax16_scatter4(reinterpret_cast<const float (&)[4]>(pmv));
+            const bool live = oty < gm.th && otx < gm.tw && oty < Ho && otx < Wo;
+            if (live && (li & 3) == 0) atomicMax(reinterpret_cast<unsigned*>(cmax_out + (size_t)oty * Wo + otx), __float_as_uint(pm));
+        } else {
+            const float pm = xd_rowmax16_scatter16(reinterpret_cast<const float (&)[16]>(pmv));
+            const int yy = 2 * oty + ((li >> 1) & 1), xx = 2 * otx + (li & 1);
+            const bool ok = oty < gm.th && otx < gm.tw && yy < H && xx < W;
+            if (ok) atomicMax(reinterpret_cast<unsigned*>(cmax_out + (size_t)yy * W + xx), __float_as_uint(pm));
         }
     }
 #ifdef XD_CLOCKS
@@ -538,6 +648,11 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         rec[6] = (float)K16; rec[7] = 1.0f;
         rec[8] = (float)(xd_t_issued - xd_t_in); rec[9] = (float)(xd_t_landed - xd_t_issued); rec[10] = (float)(xd_t_loop - xd_t_landed);
         rec[11] = (float)(xd_t_e0 - xd_t_done); rec[12] = (float)(xd_t_e1 - xd_t_e0); rec[13] = (float)(t_out - xd_t_e1);
+#ifdef XD_CHUNK_CLOCKS
+        // (tools/xd_clocks.py chunks: shader cycles of chunk 0, chunk 1, the steady-state chunks, chunk K16 - 2, the last chunk)
+        rec[8] = (float)(xd_c_k0 - xd_c_loop); rec[9] = (float)(xd_c_k1 - xd_c_k0); rec[10] = (float)(xd_c_kl2 - xd_c_k1);
+        rec[11] = (float)(xd_c_kl - xd_c_kl2); rec[12] = (float)(xd_c_done - xd_c_kl);
+#endif
 #ifdef XD_STEPS
         for (int q = 0; q < 8; ++q) rec[8 + q] = (float)xd_step_acc[q];
 #endif
@@ -594,7 +709,7 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     }
     // the kernel walks the 16-channel chunks in pairs: cin % 32 == 0 (other widths: the three-launch layer, csrc/wino_x3.hip)
     if (N < 1 || H < 1 || W < 1 || cin < 32 || cin % 32 != 0 || cout < 64 || cout % 64 != 0) return FRCNN_EUNSUPPORTED;
-    if ((size_t)H * W * cin >= ((size_t)1 << 29)) return FRCNN_EUNSUPPORTED;          // 32-bit byte offsets inside one map
+    if ((size_t)H * W * cin >= ((size_t)1 << 29) || (size_t)H * W * cout >= ((size_t)1 << 29)) return FRCNN_EUNSUPPORTED;          // 32-bit byte offsets inside one map (input and output)
     if ((flags & FRCNN_POOL2) && (H < 2 || W < 2)) return FRCNN_EINVAL;
     if (!cmax_ready && (!ws || ws_bytes < conv3x3_winograd_x3_fused_workspace_bytes(N, H, W))) return FRCNN_EINVAL;
     if (cmax_out && !(flags & FRCNN_RELU)) return FRCNN_EINVAL;          // the emitted maxima are those of non-negative outputs
@@ -621,6 +736,7 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
 #endif
     auto magic = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
     gm.m_tbx = magic(gm.tbx); gm.m_tby = magic(gm.tby); gm.m_ncb = magic(gm.ncb); gm.m_ntb = magic(gm.ntb);
+    gm.g8 = gm.ncb < 8 ? 8 / gm.ncb : 1;
     if (total * std::max(std::max(gm.ncb, gm.ntb), std::max(gm.tbx, gm.tby)) >= 0x100000000ll) return FRCNN_EUNSUPPORTED;
     const int u_rbt = cdiv(cout, gemm_x6t_col_tile(cout)) * gemm_x6t_col_tile(cout) / 32;
     if ((size_t)16 * (cin / 16) * u_rbt * HX_RB >= ((size_t)1 << 31)) return FRCNN_EUNSUPPORTED;   // the record bank behind one buffer descriptor

@@ -542,6 +542,7 @@ int launch_wino_x3p(bool pool, const float* x, const float* cmax, const unsigned
     }
     auto magic = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
     gm.m_tbx = magic(gm.tbx); gm.m_tby = magic(gm.tby); gm.m_ncb = magic(gm.ncb); gm.m_ntb = magic(gm.ntb);
+    gm.g8 = gm.ncb < 8 ? 8 / gm.ncb : 1;
     if (total * std::max(std::max(gm.ncb, gm.ntb), std::max(gm.tbx, gm.tby)) >= 0x100000000ll) return FRCNN_EUNSUPPORTED;
     if ((size_t)grid_blocks * XP_SPILL_FLOATS * sizeof(float) > spill_bytes) return FRCNN_EINVAL;
     const int u_rbt = cdiv(cout, gemm_x6t_col_tile(cout)) * gemm_x6t_col_tile(cout) / 32;

@@ -46,9 +46,13 @@ def run(name, cin, cout, h, w, pool, reps=20, force=0):
           "p25 %.1f p50 %.1f p75 %.1f p100 %.1f us" % (name, {0: "auto ", nv.X3F_WAVES4: "four ", nv.X3F_WAVES8: "eight", nv.X3F_PAIR: "pair "}[force], cin, cout, h, w, nblk, us, span, pro.mean() / 100, loop.mean() / 100, loop.mean() / 100 / k16,
                                                        cyc.mean() / k16, (cyc / loop).mean() * 100, epi.mean() / 100,
                                                        np.percentile(start, 25), np.percentile(start, 50), np.percentile(start, 75), start.max()))
-    print("         before the loop: loads issued after %.2f us, landed + barrier %.2f us later, first operand %.2f us | after: wait for the "
+    if "chunks" not in sys.argv[1:]:
+      print("         before the loop: loads issued after %.2f us, landed + barrier %.2f us later, first operand %.2f us | after: wait for the "
           "other waves %.2f us, column pass + LDS %.2f us, row pass + stores %.2f us" % tuple(o[:, i].mean() / 100 for i in range(8, 14))
           + (" | pair form: a 'chunk' is one pass over 16 input channels (48 MFMAs per wave, 64 tiles x 128 channels); the spill between the passes %.2f us (inside the loop time)" % (o[:, 14].mean() / 100) if pair else ""))
+    if "chunks" in sys.argv[1:]:
+        print("         cycles: chunk 0 %.0f, chunk 1 %.0f, steady-state chunks %.0f each (%d of them), chunk K16-2 %.0f, last chunk %.0f" % (
+            o[:, 8].mean(), o[:, 9].mean(), o[:, 10].mean() / max(1, k16 - 4), k16 - 4, o[:, 11].mean(), o[:, 12].mean()))
     return cyc.mean() / k16
 
 
