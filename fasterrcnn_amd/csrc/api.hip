@@ -55,6 +55,7 @@ struct frcnn_ctx {
     // zeroed float per convolution output of a forward (gx_next counts them; one memset per stage), gx_x = the slot bounding the CURRENT
     // block input (null: unknown, the next g3 block measures it)
     float* gx_max = nullptr; int gx_next = 0; const float* gx_x = nullptr;
+    unsigned* gx_cnt = nullptr;                  // GX_TILE_COUNTERS tile tickets of the in-kernel split reductions (conv_gather_x3_kernel), zero between launches
     float* res_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // ResNet bottleneck rotation
     size_t res_buf_floats = 0;
     int last_c = 512, last_vec = 4096, last_head_ld = 128;
@@ -918,6 +919,7 @@ void frcnn_ctx_destroy(frcnn_ctx* ctx)
     if (ctx->rx_ws) (void)hipFree(ctx->rx_ws);
     if (ctx->rx_aux) (void)hipFree(ctx->rx_aux);
     if (ctx->gx_max) (void)hipFree(ctx->gx_max);
+    if (ctx->gx_cnt) (void)hipFree(ctx->gx_cnt);
     delete ctx;
 }
 
@@ -1320,8 +1322,12 @@ int frcnn_vgg16_forward(frcnn_ctx* c, const frcnn_vgg16_weights* w, const frcnn_
                                 49 * 512, 1, R, c->lin_ws, c->lin_ws_bytes, s, 0));
         STEP(2, launch_rows_scale_x3t(c->fc1_out, 4096, 0, c->fc1_inv, R_, rr, 4096, 1, s));
         STEP(2, launch_split_rows_x3t(c->fc1_out, 4096, 0, c->fc1_inv, c->fc1_rec, R_, rr, 4096, 1, s));
+        // fc2 (K = 4096) on the 160 x 128 tiles: 64 tiles x 4 reduction ranges of 64 chunks instead of 16 tiles x 16 ranges of 16 -- a
+        // quarter of the partial planes (19.7 MB instead of 78.6 MB written and read again) and blocks that are not mostly prologue and
+        // epilogue: 42.7 us against 53.0 with its reduction (tools/exp_fc_cfg.sh; the cost model scores the two within 3 %).  The same
+        // in every slot (an image gives the same bits in flight and alone).
         STEP(2, launch_gemm_x3t(c->fc1_rec, c->fc1_inv, rr, 0, 0, w->fc2_w, w2inv, 4096, 0, 0, w->fc2_b, nullptr, c->fc2_out, 4096, 0, R_, 4096,
-                                4096, 1, R, c->lin_ws, c->lin_ws_bytes, s, 0));
+                                4096, 1, R, c->lin_ws, c->lin_ws_bytes, s, 2));
     } else
     if (fc_x6t) {
         // fc1 / fc2 as f32x6 GEMMs on tile records (csrc/gemm_x6t.hip): RoIPool writes fc1's operand records itself (the rows R_ ..
@@ -1454,6 +1460,11 @@ int gx_begin(frcnn_ctx* c, hipStream_t s)
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->gx_max), GX_SLOTS * sizeof(float));
         if (e != hipSuccess) { set_hip_error(e); c->gx_max = nullptr; return FRCNN_ENOMEM; }
     }
+    if (!c->gx_cnt) {                                              // zeroed ONCE: the last block of a tile leaves its counter at zero again
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->gx_cnt), GX_TILE_COUNTERS * sizeof(unsigned));
+        if (e != hipSuccess) { set_hip_error(e); c->gx_cnt = nullptr; return FRCNN_ENOMEM; }
+        FRCNN_HIP_TRY(hipMemsetAsync(c->gx_cnt, 0, GX_TILE_COUNTERS * sizeof(unsigned), s));
+    }
     FRCNN_HIP_TRY(hipMemsetAsync(c->gx_max, 0, GX_SLOTS * sizeof(float), s));
     c->gx_next = 0;
     c->gx_x = nullptr;
@@ -1500,7 +1511,7 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
             c->gx_x = mx;
         }
         if ((rc = gx_slot(c, s, &m1)) || (rc = gx_slot(c, s, &m2)) || (rc = gx_slot(c, s, &m3))) return rc;
-        const GatherX3 g1{c->gx_x, b.wmax + 0, m1}, g2{m1, b.wmax + 1, m2}, g3{m2, b.wmax + 2, m3}, gd{c->gx_x, b.wmax + 3, nullptr};
+        const GatherX3 g1{c->gx_x, b.wmax + 0, m1, c->gx_cnt}, g2{m1, b.wmax + 1, m2, c->gx_cnt}, g3{m2, b.wmax + 2, m3, c->gx_cnt}, gd{c->gx_x, b.wmax + 3, nullptr, c->gx_cnt};
         const int X3 = FRCNN_CONV_F32X3G;
         RSTEP(launch_conv_gather(X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s, X3, &g1));
         RSTEP(launch_conv_gather(T1, b.w2, b.b2, nullptr, T2, N, h, w, b.width, b.width, 3, b.stride, 1, R, c->conv_ws, c->conv_ws_bytes, s, X3, &g2));

@@ -104,7 +104,11 @@ size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R
 // math FRCNN_CONV_F32X3G: both operands as two fp16 terms under ONE power-of-two scale per tensor (conv_gather_x3_kernel); x3 names the
 // device floats holding an upper bound of max|x|, max|wp| and (or null) the float that receives max|y| by atomic maximum (zero it first)
 #define FRCNN_CONV_F32X3G 2
-struct GatherX3 { const float* xmax; const float* wmax; float* ymax; };
+// tile_counters (optional, f32x3 mode): >= GX_TILE_COUNTERS zeroed unsigned ints owned by the caller's stream -- a split reduction is then
+// finished by the LAST block of every output tile to arrive (conv_gather_x3_kernel) instead of by gather_splitk_finish_kernel; the last
+// block leaves its counter at zero again
+static constexpr int GX_TILE_COUNTERS = 16384;
+struct GatherX3 { const float* xmax; const float* wmax; float* ymax; unsigned* tile_counters = nullptr; };
 int launch_conv_gather(const float* x, const float* wp, const float* bias, const float* residual, float* y,
                        int N, int H, int W, int cin, int cout, int R, int stride, int pad, unsigned flags,
                        void* ws, size_t ws_bytes, hipStream_t s, int math = FRCNN_GRAD_F32, const GatherX3* x3 = nullptr);

@@ -502,6 +502,24 @@ __device__ __forceinline__ void gx_split4(const f32x4 v, float m, float bound, g
     lo = __builtin_bit_cast(gx_u32x2, l);
 }
 
+// 16 bytes written through to memory / read past the caches (system scope: sc0 sc1) -- the partial planes of an in-kernel split reduction
+__device__ __forceinline__ void gx_store_through(float* p, f32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+// eight such loads in flight, then one wait (ONE asm statement: the compiler must not touch a destination before the wait)
+__device__ __forceinline__ void gx_load8_past_caches(const float* const (&p)[8], f32x4 (&v)[8])
+{
+    asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+                 : "memory");
+}
+
 // One block's maximum into *out (a float >= 0, bit order = float order): four wave maxima through LDS, then ONE atomic -- and only when the
 // block's value exceeds what is already there (a stale read costs an atomic, never a wrong result): atomics on one address serialise at
 // a few ns each, and thousands of waves hitting one float cost more than the convolution (measured: 134 us against 36)
@@ -534,7 +552,8 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
                            const float* __restrict__ bias, const float* __restrict__ residual,
                            float* __restrict__ y, float* __restrict__ ws, GatherShape g,
                            int stages_per_split, int relu, const float* __restrict__ xmax, const float* __restrict__ wmax,
-                           float* __restrict__ ymax, int mblocks, int nblocks, unsigned* __restrict__ sat_events)
+                           float* __restrict__ ymax, int mblocks, int nblocks, unsigned* __restrict__ sat_events,
+                           unsigned* __restrict__ tile_counters)
 {
     using C = GatherX3Cfg<TM, TN, WM, WN, D, MODE>;
     constexpr int GX_ROW = C::ROW;
@@ -834,11 +853,84 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
                         vmax = fmaxf(vmax, fabsf(v[e]));
                     }
                 }
-                *reinterpret_cast<f32x4*>(dst + (size_t)m * g.Cout + n) = v;
+                if (!direct && tile_counters) gx_store_through(dst + (size_t)m * g.Cout + n, v);
+                else *reinterpret_cast<f32x4*>(dst + (size_t)m * g.Cout + n) = v;
             }
         }
     }
-    if constexpr (MODE == GX_F32X3) { if (direct && ymax) gx_block_max(vmax, ymax); }
+    bool finished = direct;
+    if (!direct && tile_counters) {
+        // Split reduction finished by the LAST block of this output tile to arrive (round 6; gather_splitk_finish_kernel was 10 launches
+        // and 5 % of a ResNet-50 image's kernel time): every block publishes its partial plane (release), takes a ticket, and the block
+        // that draws the last one reads the planes of its tile back -- each thread the elements it wrote itself -- and sums them in
+        // ASCENDING plane order, its own included: the bits of the separate pass.  No block waits for another one.
+        // The planes travel WRITE-THROUGH and are read back PAST the caches (sc0 sc1 on both sides), and the ticket is an agent-scope atomic:
+        // no cache-wide operation.  (With release / acquire fences at agent scope -- buffer_wbl2 / buffer_inv: every block writes back and
+        // invalidates its XCD's whole L2 -- ResNet-50 fell from 628 to 515 images/sec with eight images in flight.)
+        __shared__ int gx_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this thread's plane stores are acknowledged
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(tile_counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gx_last = old + 1u == gridDim.z ? 1 : 0;
+            if (gx_last) __hip_atomic_store(tile_counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (every ticket of this launch is drawn: ready for the next one)
+        }
+        __syncthreads();
+        if (gx_last) {
+            finished = true;
+            const size_t plane = (size_t)M * g.Cout;
+            const int splits = (int)gridDim.z;
+            f32x4 bq = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias && n < g.Cout) bq = *reinterpret_cast<const f32x4*>(bias + n);
+            // eight 16-byte pieces per round trip: two row passes x four planes (a piece that does not exist re-reads element 0 of plane 0)
+            static_assert(NPASS % 2 == 0, "row passes in pairs");
+            if (n < g.Cout) {
+#pragma unroll 1
+                for (int k = 0; k < NPASS; k += 2) {
+                    const int mA = m0 + er + k * RSTEP, mB = mA + RSTEP;
+                    const bool okA = mA < M, okB = mB < M;
+                    if (!okA) break;                                         // (rows ascend with k)
+                    const size_t iA = (size_t)mA * g.Cout + n, iB = okB ? (size_t)mB * g.Cout + n : iA;
+                    f32x4 vA = f32x4{0.f, 0.f, 0.f, 0.f}, vB = vA;
+                    for (int q0 = 0; q0 < splits; q0 += 4) {
+                        const float* ptr[8];
+                        f32x4 t[8];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const size_t po = (size_t)(q0 + u < splits ? q0 + u : 0) * plane;
+                            ptr[u] = ws + po + iA;
+                            ptr[4 + u] = ws + po + iB;
+                        }
+                        gx_load8_past_caches(ptr, t);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (q0 + u < splits) {
+                                if (q0 + u == 0) { vA = t[0]; vB = t[4]; }
+                                else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { vA[e] += t[u][e]; vB[e] += t[4 + u][e]; }
+                                }
+                            }
+                        }
+                    }
+                    f32x4 rA = f32x4{0.f, 0.f, 0.f, 0.f}, rB = rA;
+                    if (residual) { rA = *reinterpret_cast<const f32x4*>(residual + iA); rB = *reinterpret_cast<const f32x4*>(residual + iB); }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float tA = ((MODE == GX_F32X3 ? vA[e] * unscale : vA[e]) + bq[e]) + rA[e];
+                        const float tB = ((MODE == GX_F32X3 ? vB[e] * unscale : vB[e]) + bq[e]) + rB[e];
+                        vA[e] = relu ? fmaxf(tA, 0.f) : tA;
+                        vB[e] = relu ? fmaxf(tB, 0.f) : tB;
+                        vmax = fmaxf(vmax, fabsf(vA[e]));
+                        if (okB) vmax = fmaxf(vmax, fabsf(vB[e]));
+                    }
+                    *reinterpret_cast<f32x4*>(y + iA) = vA;
+                    if (okB) *reinterpret_cast<f32x4*>(y + iB) = vB;
+                }
+            }
+        }
+    }
+    if constexpr (MODE == GX_F32X3) { if (finished && ymax) gx_block_max(vmax, ymax); }
     if constexpr (MODE == GX_F32X3) {
         // An activation beyond the fp16 range under the tensor's scale -- the maximum the caller passed was not one -- was CLAMPED by the split
         // (gx_split4) instead of becoming inf / NaN: not silent any more: one event per wave that saw one, in a host-mapped
@@ -1137,6 +1229,11 @@ unsigned* x3_saturation_counter()
     return counter;
 }
 
+// the split reduction of a launch is finished inside the kernel (last block of a tile to arrive) when the caller brought tile counters
+static bool gather_x3_in_kernel_finish(const GatherPlan& p, const GatherX3* x3)
+{
+    return p.splits > 1 && x3 && x3->tile_counters && 8LL * p.nblocks * cdiv(p.mblocks, 8) <= GX_TILE_COUNTERS;
+}
 template <int TM, int TN, int WM, int WN, int D, int MODE>
 static int launch_gather_x3_cfg(const GatherPlan& p, const float* x, const float* wp, const float* bias, const float* residual, float* y, float* ws,
                                 const GatherShape& g, int relu, hipStream_t s, const GatherX3* x3)
@@ -1146,7 +1243,8 @@ static int launch_gather_x3_cfg(const GatherPlan& p, const float* x, const float
     FRCNN_MAX_LDS_ONCE(kx, X::LDS_BYTES);
     hipLaunchKernelGGL(kx, dim3(8 * p.nblocks * cdiv(p.mblocks, 8), 1, p.splits), dim3(256), X::LDS_BYTES, s, x, wp, bias, residual, y, ws, g,
                        p.stages_per_split, relu, x3 ? x3->xmax : (const float*)nullptr, x3 ? x3->wmax : (const float*)nullptr,
-                       x3 ? x3->ymax : (float*)nullptr, p.mblocks, p.nblocks, MODE == GX_F32X3 ? x3_saturation_counter() : (unsigned*)nullptr);
+                       x3 ? x3->ymax : (float*)nullptr, p.mblocks, p.nblocks, MODE == GX_F32X3 ? x3_saturation_counter() : (unsigned*)nullptr,
+                       gather_x3_in_kernel_finish(p, x3) ? x3->tile_counters : (unsigned*)nullptr);
     return check_launch();
 }
 template <int MODE>
@@ -1217,7 +1315,7 @@ int launch_conv_gather(const float* x, const float* wp, const float* bias, const
         rc = p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, math)
                         : launch_gather_cfg<2, 2, 2, 2>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, math);
     if (rc) return rc;
-    if (p.splits > 1) {
+    if (p.splits > 1 && !(gx3 && math == FRCNN_CONV_F32X3G && gather_x3_in_kernel_finish(p, x3))) {
         const size_t total = (size_t)M * (cout / 4);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
