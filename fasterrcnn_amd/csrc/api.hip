@@ -491,6 +491,19 @@ int frcnn_conv_nhwc_x3g(const float* d_x, const float* d_wp, const float* d_bias
                               d_ws, ws_bytes, as_stream(stream), FRCNN_CONV_F32X3G, &x3);
 }
 
+int frcnn_conv_nhwc_x3g_tickets(const float* d_x, const float* d_wp, const float* d_bias, const float* d_residual, float* d_y,
+                                int N, int H, int W, int cin, int cout, int ksize, int stride, int pad, unsigned flags,
+                                const float* d_xmax, const float* d_wmax, float* d_ymax, void* d_ws, size_t ws_bytes,
+                                unsigned* d_tile_counters, void* stream)
+{
+    static_assert(FRCNN_X3G_TILE_COUNTERS == GX_TILE_COUNTERS, "one bound on both sides of the ABI");
+    if (!d_x || !d_wp || !d_bias || !d_y || !d_xmax || !d_wmax || !d_tile_counters) return FRCNN_EINVAL;
+    if (flags & FRCNN_POOL2) return FRCNN_EUNSUPPORTED;
+    const GatherX3 x3{d_xmax, d_wmax, d_ymax, d_tile_counters};
+    return launch_conv_gather(d_x, d_wp, d_bias, d_residual, d_y, N, H, W, cin, cout, ksize, stride, pad, flags,
+                              d_ws, ws_bytes, as_stream(stream), FRCNN_CONV_F32X3G, &x3);
+}
+
 int frcnn_tensor_absmax(const float* d_x, long long n, float* d_out, void* stream)
 {
     if (!d_x || !d_out) return FRCNN_EINVAL;

@@ -143,18 +143,26 @@ def blob_x3t(wp, cout, cin):
     return pack_rows_x3t(wp.reshape(cout, cin), rows)
 
 
-def conv_nhwc_x3g(x, wp, bp, n, h, w, cin, cout, k, stride, pad, relu, xmax, wmax, ymax=None, residual=None):
+def conv_nhwc_x3g(x, wp, bp, n, h, w, cin, cout, k, stride, pad, relu, xmax, wmax, ymax=None, residual=None, tickets=None):
     """frcnn_conv_nhwc_x3g: the same convolution in the f32x3 arithmetic under one scale per tensor; xmax / wmax: one-element CUDA float
-    tensors bounding |x| and |wp|, ymax: a zeroed one that receives max|y| (or None).  Returns (y, ho, wo)."""
+    tensors bounding |x| and |wp|, ymax: a zeroed one that receives max|y| (or None).  tickets: a ZEROED int32 CUDA tensor of
+    nv.X3G_TILE_COUNTERS elements = frcnn_conv_nhwc_x3g_tickets (a split reduction is finished inside the kernel; the tensor is zero
+    again afterwards).  Returns (y, ho, wo)."""
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     y = t.empty((n, ho, wo, cout), dtype=t.float32, device=x.device)
     lib = nv.lib()
     wsb = int(lib.frcnn_conv_workspace_bytes(n, h, w, cin, cout, k, stride, pad))
     ws = t.empty((max(wsb, 4) // 4,), dtype=t.float32, device=x.device)
     with t.cuda.device(x.device):
-        nv.check(lib.frcnn_conv_nhwc_x3g(nv.ptr(x), nv.ptr(wp), nv.ptr(bp), nv.ptr(residual), nv.ptr(y), n, h, w, cin, cout,
-                                         k, stride, pad, nv.RELU if relu else 0, nv.ptr(xmax), nv.ptr(wmax), nv.ptr(ymax), nv.ptr(ws), wsb,
-                                         nv.stream_ptr()), "frcnn_conv_nhwc_x3g")
+        if tickets is not None:
+            assert tickets.numel() >= nv.X3G_TILE_COUNTERS and tickets.dtype == t.int32
+            nv.check(lib.frcnn_conv_nhwc_x3g_tickets(nv.ptr(x), nv.ptr(wp), nv.ptr(bp), nv.ptr(residual), nv.ptr(y), n, h, w, cin, cout,
+                                                     k, stride, pad, nv.RELU if relu else 0, nv.ptr(xmax), nv.ptr(wmax), nv.ptr(ymax), nv.ptr(ws),
+                                                     wsb, nv.ptr(tickets), nv.stream_ptr()), "frcnn_conv_nhwc_x3g_tickets")
+        else:
+            nv.check(lib.frcnn_conv_nhwc_x3g(nv.ptr(x), nv.ptr(wp), nv.ptr(bp), nv.ptr(residual), nv.ptr(y), n, h, w, cin, cout,
+                                             k, stride, pad, nv.RELU if relu else 0, nv.ptr(xmax), nv.ptr(wmax), nv.ptr(ymax), nv.ptr(ws), wsb,
+                                             nv.stream_ptr()), "frcnn_conv_nhwc_x3g")
     return y, ho, wo
 
 

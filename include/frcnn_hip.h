@@ -37,7 +37,7 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 14  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
+#define FRCNN_ABI_VERSION 15  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
                                  5: bf16 gradient GEMMs (the *_math entry points); 6: x6t GEMM, x6 Winograd layers, frcnn_forward_params.winograd_x6_mask,
                                  timing classes 8 / 9; 7: batched feature extractor (frcnn_resnet_backbone, frcnn_resnet_forward_features,
                                  frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps); 8: the f32x3 arithmetic (frcnn_*_x3t, frcnn_*_winograd_x3,
@@ -47,7 +47,7 @@ extern "C" {
                                  12: frcnn_x3_saturation_events, FRCNN_X3F_WAVES4 / FRCNN_X3F_WAVES8; 13: REMOVED the round-2 f32x6 kernels that no table has used since round 3
                                  (frcnn_pack_conv3x3_x6, frcnn_conv3x3_nhwc_x6, frcnn_split_rows_x6, frcnn_linear_x6(_workspace_bytes), math mode 1 =
                                  FRCNN_MATH_F32X6 and fc mode 1 = FRCNN_FC_F32X6 are FRCNN_EINVAL); the f32x6 arithmetic stays as gemm_x6t / wino_x6; 14: FRCNN_X3F_PAIR, frcnn_conv3x3_winograd_x3_pair_workspace_bytes, frcnn_forward_params.winograd_x3p_mask,
-                                 frcnn_resnet_rpn_roipool / frcnn_ctx_create_head / frcnn_resnet_head */
+                                 frcnn_resnet_rpn_roipool / frcnn_ctx_create_head / frcnn_resnet_head; 15: frcnn_conv_nhwc_x3g_tickets (split reductions finished inside the kernel) */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -729,6 +729,17 @@ int frcnn_conv_dgrad_math(const float* d_dz, const float* d_wd, const float* d_r
 int frcnn_conv_nhwc_x3g(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
                         int N, int H, int W, int cin, int cout, int ksize, int stride, int pad, unsigned flags,
                         const float* d_xmax, const float* d_wmax, float* d_ymax, void* d_ws, size_t ws_bytes, void* stream);
+/* ABI 15: the same call with the split reduction of a small convolution finished INSIDE the kernel, by the last block of every output tile
+ * to arrive (round 6: what frcnn_resnet_forward / frcnn_resnet_backbone run; frcnn_conv_nhwc_x3g keeps the separate finishing pass).
+ *   d_tile_counters : FRCNN_X3G_TILE_COUNTERS unsigned ints, ZERO before the first call; every call leaves them zero again.  They
+ *                     belong to one stream at a time (two convolutions in flight on different streams need two arrays).
+ * The partial planes are summed in ascending order like the separate pass: the results are the same bits (tests/test_conv_x3g_gpu.py).
+ * Launches whose tile count exceeds the array, and launches that do not split, behave as frcnn_conv_nhwc_x3g. */
+#define FRCNN_X3G_TILE_COUNTERS 16384
+int frcnn_conv_nhwc_x3g_tickets(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
+                                int N, int H, int W, int cin, int cout, int ksize, int stride, int pad, unsigned flags,
+                                const float* d_xmax, const float* d_wmax, float* d_ymax, void* d_ws, size_t ws_bytes,
+                                unsigned* d_tile_counters, void* stream);
 /* ABI 12: frcnn_conv_nhwc_x3g CLAMPS an activation whose hi term would overflow fp16 under the tensor's scale (i.e. *d_xmax was not an
  * upper bound) instead of producing inf / NaN; every wave that clamped one adds 1 to a process-wide counter.  *out = that count since the
  * library was loaded (read it after synchronising the streams the convolutions ran on).  With the maxima the producers' epilogues leave

@@ -106,3 +106,29 @@ def test_conv_x3g_rejects_missing_scales():
     y = torch.zeros(1, 4, 4, 4).cuda()
     rc = nv.lib().frcnn_conv_nhwc_x3g(nv.ptr(x), nv.ptr(wp), nv.ptr(b), None, nv.ptr(y), 1, 4, 4, 16, 4, 1, 1, 0, 0, None, None, None, None, 0, nv.stream_ptr())
     assert rc == -1          # FRCNN_EINVAL
+
+
+@pytest.mark.parametrize("shape", [(1, 38, 63, 256, 1024, 1, 1, 0), (1, 38, 63, 1024, 256, 1, 1, 0), (1, 38, 63, 256, 256, 3, 1, 1),
+                                   (1, 75, 125, 512, 256, 3, 2, 1), (2, 19, 31, 512, 128, 1, 1, 0), (1, 9, 11, 2048, 64, 1, 1, 0)])
+def test_conv_x3g_split_reduction_finished_in_the_kernel_is_the_same_bits(shape):
+    """frcnn_conv_nhwc_x3g_tickets (ABI 15, round 6): the last block of a tile to arrive sums the partial planes in ascending order --
+    the bits of frcnn_conv_nhwc_x3g's separate finishing pass, output and emitted maximum alike; the ticket array is zero again
+    afterwards, call after call (models/resnet.py:38-46: the small-map Bottleneck convolutions are the ones that split)."""
+    n, h, w, cin, cout, k, stride, pad = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wp = pack((torch.randn(cout, cin, k, k, generator=g) / (3.0 * (cin * k * k) ** 0.5)).cuda())
+    b = torch.randn(cout, generator=g).cuda()
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(n, ho, wo, cout, generator=g).cuda()
+    xm, wm = R.tensor_absmax(x), R.tensor_absmax(wp)
+    tickets = torch.zeros(nv.X3G_TILE_COUNTERS, dtype=torch.int32, device="cuda")
+    for relu, residual in ((True, res), (False, None)):
+        ym0, ym1 = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+        y0, _, _ = R.conv_nhwc_x3g(x, wp, b, n, h, w, cin, cout, k, stride, pad, relu, xm, wm, ym0, residual)
+        for _ in range(3):
+            ym1.zero_()
+            y1, _, _ = R.conv_nhwc_x3g(x, wp, b, n, h, w, cin, cout, k, stride, pad, relu, xm, wm, ym1, residual, tickets=tickets)
+            assert torch.equal(y0, y1)
+            assert float(ym0) == float(ym1)
+            assert int(tickets.abs().max()) == 0
