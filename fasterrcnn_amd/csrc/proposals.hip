@@ -551,7 +551,14 @@ __device__ __forceinline__ bool iou_gt(const f32x4 a, const f32x4 b, float thr)
     const float inter = d0 * d1;
     const float sa = (a[2] - a[0]) * (a[3] - a[1]);
     const float sb = (b[2] - b[0]) * (b[3] - b[1]);
-    return (inter / (sa + sb - inter)) > thr;
+    // The decision is torchvision's `inter / union > thr` to the last bit -- but the quotient (a ~10-instruction sequence, a third of this
+    // function) is computed only for the pairs that need it: with t = fl(thr * union), inter > t (1 + 1e-6) implies
+    // fl(inter / union) > thr and inter < t (1 - 1e-6) implies fl(inter / union) < thr (the two roundings involved are 6e-8 relative each);
+    // only a pair inside that band of 2e-6 -- or a degenerate one, union = 0: 0 / 0 is NaN, not greater -- takes the division.
+    const float uni = sa + sb - inter, t = thr * uni;
+    if (inter > t * 1.000001f) return true;
+    if (inter < t * 0.999999f) return false;
+    return (inter / uni) > thr;
 }
 
 // grid (nw, nw), one wave per 64x64 tile; only tiles on or above the diagonal are written.

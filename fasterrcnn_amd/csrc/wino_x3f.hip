@@ -172,11 +172,12 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         h_src[it] = inb ? (int)off : (int)0xFFFFFFF0u;
     };
     // pieces [it0, it1) of chunk `chunk_off / 64` into the buffer at hb
-    auto dma_halo = [&](float* hb, int chunk_off, auto IT0, auto IT1) {
+    __amdgpu_buffer_rsrc_t xrs_ring = xrs;                                   // the descriptor of the ring's steady-state DMA (zero records past the last chunk)
+    auto dma_halo = [&](float* hb, int chunk_off, auto IT0, auto IT1, const __amdgpu_buffer_rsrc_t& rs) {
         if (XD_ABLATE & 8) return;
 #pragma unroll
         for (int it = decltype(IT0)::value; it < decltype(IT1)::value; ++it)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (xd_lds_ptr)(reinterpret_cast<unsigned char*>(hb) + (it * 4 + wave_u) * 1024), 16, h_src[it],
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (xd_lds_ptr)(reinterpret_cast<unsigned char*>(hb) + (it * 4 + wave_u) * 1024), 16, h_src[it],
                                                      chunk_off, 0, 0);
     };
 
@@ -348,10 +349,10 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         if (form) XD_IF(1, v_lo(nslot, 0));
         if (col) XD_IF(2, read_d_hi(rsrc, rh, rb));
         // halo(c + 3) -> the buffer halo(c) was read from, free since the barrier of step 3 (its last patch read is that step's)
-        if (s == 4 && !last) dma_halo(hcur, hso, XdInt<0>{}, XdInt<4>{});
+        if (s == 4 && !last) dma_halo(hcur, hso, XdInt<0>{}, XdInt<4>{}, xrs_ring);
         // chunks 0 and 1: halo(c + 1) -> the buffer steps 4-7 will read it from (landed by the barrier of step 3: the wait below)
-        if (early && !last && s == 0) dma_halo(hnxt, hso_next, XdInt<0>{}, XdInt<4>{});
-        if (early && !last && s == 1) dma_halo(hnxt, hso_next, XdInt<4>{}, XdInt<XD_NDMA>{});
+        if (early && !last && s == 0) dma_halo(hnxt, hso_next, XdInt<0>{}, XdInt<4>{}, xrs);
+        if (early && !last && s == 1) dma_halo(hnxt, hso_next, XdInt<4>{}, XdInt<XD_NDMA>{}, xrs);
         XD_FENCE();
         XD_MFMA(par, h, j, 1, 0, vh);
         if (form) XD_IF(1, v_adds(nh, nj, 2));
@@ -378,14 +379,16 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
             else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
             xd_lds_barrier();
         }
-        if (s == 5 && !last) dma_halo(hcur, hso, XdInt<4>{}, XdInt<XD_NDMA>{});
+        if (s == 5 && !last) dma_halo(hcur, hso, XdInt<4>{}, XdInt<XD_NDMA>{}, xrs_ring);
         XD_FENCE();
     };
     // the ring: chunk c reads halo(c) from hcur (steps 0-3) and halo(c + 1) from hnxt (steps 4-7)
     float *hcur = hbuf0, *hnxt = hbuf0 + XD_HBUF_FLOATS, *hthird = hbuf0 + 2 * XD_HBUF_FLOATS;
     auto chunk = [&](int c, auto PAR, auto FLAGS) {
-        // (past the last chunk the halo DMA re-reads it instead of branching; the filter offset of a chunk past the end is never used: XD_LAST)
+        // (past the last chunk the halo DMA of the two generic tail chunks goes through a descriptor of ZERO records -- the hardware fetches
+        //  nothing and writes zeros nobody reads -- instead of branching; the filter offset of a chunk past the end is never used: XD_LAST)
         const int ucb = (c + 1) * chunk_stride, hso = (c + 3 < K16 ? c + 3 : K16 - 1) * 64, hson = (c + 1) * 64;
+        xrs_ring = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, c + 3 < K16 ? H * W * Cin * (int)sizeof(float) : 0, 0x00020000);
         step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<0>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<1>{}, FLAGS);
         step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<2>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<3>{}, FLAGS);
         step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<4>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<5>{}, FLAGS);
@@ -432,15 +435,15 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     if (!(XD_ABLATE & 32)) load_u1(XdInt<0>{}, XdInt<1>{}, XdInt<1>{});
     halo_source(XdInt<5>{}); halo_source(XdInt<6>{}); XD_FENCE();
     // (XD_ABLATE 32, timing experiment: what the block pays for the prologue's loads -- no filter pieces, no halo)
-    if (!(XD_ABLATE & 32)) dma_halo(hcur, 0, XdInt<0>{}, XdInt<XD_NDMA>{});
+    if (!(XD_ABLATE & 32)) dma_halo(hcur, 0, XdInt<0>{}, XdInt<XD_NDMA>{}, xrs);
     __builtin_amdgcn_global_load_lds(uinv0, (xd_lds_ptr)(smem_xf + XD_SC_OFFSET + wave_u * 1024), 16, 0, 0);
     if (wave_u == 0 && lane < 16) __builtin_amdgcn_global_load_lds(bias + 64 * cb + 4 * lane, (xd_lds_ptr)(smem_xf + XD_SC_OFFSET + 4096), 16, 0, 0);
     XD_FENCE();
     if (!(XD_ABLATE & 32)) { load_u(0, XdInt<0>{}, XdInt<1>{}); load_u(0, XdInt<0>{}, XdInt<2>{}); load_u(0, XdInt<0>{}, XdInt<3>{}); }
     XD_FENCE();
     if (!XD_EARLY_HALO && !(XD_ABLATE & 32)) {
-        dma_halo(hnxt, 64, XdInt<0>{}, XdInt<XD_NDMA>{});
-        if (!TWO) dma_halo(hthird, 128, XdInt<0>{}, XdInt<XD_NDMA>{});
+        dma_halo(hnxt, 64, XdInt<0>{}, XdInt<XD_NDMA>{}, xrs);
+        if (!TWO) dma_halo(hthird, 128, XdInt<0>{}, XdInt<XD_NDMA>{}, xrs);
     }
     XD_FENCE();
 #ifdef XD_CLOCKS
