@@ -32,7 +32,7 @@ SYMBOLS = (
     "frcnn_nms", "frcnn_roi_pool", "frcnn_roi_pool_x3t", "frcnn_detections", "frcnn_ctx_create", "frcnn_ctx_create_proposals", "frcnn_ctx_destroy",
     "frcnn_ctx_bytes", "frcnn_vgg16_forward", "frcnn_ctx_tensor", "frcnn_ctx_timing_enable",
     "frcnn_ctx_timing_read",
-    "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv_nhwc_math", "frcnn_conv_nhwc_x3g", "frcnn_conv_nhwc_x3g_tickets", "frcnn_x3_saturation_events", "frcnn_tensor_absmax", "frcnn_conv7x7_s2_c3",
+    "frcnn_fold_bn_pack", "frcnn_conv_workspace_bytes", "frcnn_conv_nhwc", "frcnn_conv_nhwc_math", "frcnn_conv_nhwc_x3g", "frcnn_conv_nhwc_x3g_tickets", "frcnn_pack_conv_x3g_weights", "frcnn_x3_saturation_events", "frcnn_tensor_absmax", "frcnn_conv7x7_s2_c3",
     "frcnn_maxpool3x3_s2_nhwc", "frcnn_spatial_mean_nhwc", "frcnn_resnet_forward", "frcnn_rpn_targets",
     "frcnn_preprocess_workspace_bytes", "frcnn_preprocess",
     "frcnn_conv3x3_uses_winograd", "frcnn_resnet_block_uses_winograd", "frcnn_pack_conv3x3_winograd",
@@ -116,6 +116,7 @@ MAX_PRE_NMS = 16384         # frcnn_ctx pre_cap (csrc/api.hip): one-block radix 
 MATH_F32 = 0      # exact f32 MFMA
 MATH_F32_WINOGRAD = 2   # exact f32 MFMA; 3x3 layers with uses_winograd(cin, cout) as Winograd F(2x2,3x3) in float32
 MATH_MODES = {"f32": MATH_F32, "f32_winograd": MATH_F32_WINOGRAD}     # (1 was the direct f32x6 convolution of round 2: removed, ABI 13)
+X3G_WSPLIT = 0x800                         # FRCNN_X3G_WSPLIT: frcnn_conv_nhwc_x3g's weights are a frcnn_pack_conv_x3g_weights image
 X3G_TILE_COUNTERS = 16384                  # FRCNN_X3G_TILE_COUNTERS: the ticket array of frcnn_conv_nhwc_x3g_tickets (csrc/conv_gather.hip)
 X6T_ROW_TILE, X6T_COL_TILE = 320, 256     # FRCNN_X6T_ROW_TILE / FRCNN_X6T_COL_TILE: row padding of x6t record arrays (csrc/gemm_x6t.hip)
 GRAD_MATHS = {"f32": 0, "bf16": 1}         # FRCNN_GRAD_F32 / FRCNN_GRAD_BF16: arithmetic of the train step's gradient GEMMs
@@ -273,6 +274,7 @@ _SIGNATURES = {
     "frcnn_conv_nhwc_math": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _i, _vp, _sz, _vp]),
     "frcnn_conv_nhwc_x3g": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_conv_nhwc_x3g_tickets": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "frcnn_pack_conv_x3g_weights": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "frcnn_tensor_absmax": (C.c_int, [_vp, C.c_longlong, _vp, _vp]),
     "frcnn_conv7x7_s2_c3": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp]),
     "frcnn_maxpool3x3_s2_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),

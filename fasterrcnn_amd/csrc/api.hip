@@ -486,9 +486,15 @@ int frcnn_conv_nhwc_x3g(const float* d_x, const float* d_wp, const float* d_bias
 {
     if (!d_x || !d_wp || !d_bias || !d_y || !d_xmax || !d_wmax) return FRCNN_EINVAL;
     if (flags & FRCNN_POOL2) return FRCNN_EUNSUPPORTED;
-    const GatherX3 x3{d_xmax, d_wmax, d_ymax};
+    const GatherX3 x3{d_xmax, d_wmax, d_ymax, nullptr, (flags & FRCNN_X3G_WSPLIT) != 0};
     return launch_conv_gather(d_x, d_wp, d_bias, d_residual, d_y, N, H, W, cin, cout, ksize, stride, pad, flags,
                               d_ws, ws_bytes, as_stream(stream), FRCNN_CONV_F32X3G, &x3);
+}
+
+int frcnn_pack_conv_x3g_weights(const float* d_wp, const float* d_wmax, void* d_out, int taps, int cout, int cin, void* stream)
+{
+    if (taps < 1 || cout < 1) return FRCNN_EINVAL;
+    return launch_pack_x3g_weights(d_wp, d_wmax, d_out, (long long)taps * cout, cin, as_stream(stream));
 }
 
 int frcnn_conv_nhwc_x3g_tickets(const float* d_x, const float* d_wp, const float* d_bias, const float* d_residual, float* d_y,
@@ -499,7 +505,7 @@ int frcnn_conv_nhwc_x3g_tickets(const float* d_x, const float* d_wp, const float
     static_assert(FRCNN_X3G_TILE_COUNTERS == GX_TILE_COUNTERS, "one bound on both sides of the ABI");
     if (!d_x || !d_wp || !d_bias || !d_y || !d_xmax || !d_wmax || !d_tile_counters) return FRCNN_EINVAL;
     if (flags & FRCNN_POOL2) return FRCNN_EUNSUPPORTED;
-    const GatherX3 x3{d_xmax, d_wmax, d_ymax, d_tile_counters};
+    const GatherX3 x3{d_xmax, d_wmax, d_ymax, d_tile_counters, (flags & FRCNN_X3G_WSPLIT) != 0};
     return launch_conv_gather(d_x, d_wp, d_bias, d_residual, d_y, N, H, W, cin, cout, ksize, stride, pad, flags,
                               d_ws, ws_bytes, as_stream(stream), FRCNN_CONV_F32X3G, &x3);
 }
@@ -1524,7 +1530,8 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
             c->gx_x = mx;
         }
         if ((rc = gx_slot(c, s, &m1)) || (rc = gx_slot(c, s, &m2)) || (rc = gx_slot(c, s, &m3))) return rc;
-        const GatherX3 g1{c->gx_x, b.wmax + 0, m1, c->gx_cnt}, g2{m1, b.wmax + 1, m2, c->gx_cnt}, g3{m2, b.wmax + 2, m3, c->gx_cnt}, gd{c->gx_x, b.wmax + 3, nullptr, c->gx_cnt};
+        const bool ws_ = b.g3 == 2;                              // the packs are pre-split images (frcnn_pack_conv_x3g_weights)
+        const GatherX3 g1{c->gx_x, b.wmax + 0, m1, c->gx_cnt, ws_}, g2{m1, b.wmax + 1, m2, c->gx_cnt, ws_}, g3{m2, b.wmax + 2, m3, c->gx_cnt, ws_}, gd{c->gx_x, b.wmax + 3, nullptr, c->gx_cnt, ws_};
         const int X3 = FRCNN_CONV_F32X3G;
         RSTEP(launch_conv_gather(X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s, X3, &g1));
         RSTEP(launch_conv_gather(T1, b.w2, b.b2, nullptr, T2, N, h, w, b.width, b.width, 3, b.stride, 1, R, c->conv_ws, c->conv_ws_bytes, s, X3, &g2));

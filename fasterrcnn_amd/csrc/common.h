@@ -108,7 +108,9 @@ size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R
 // finished by the LAST block of every output tile to arrive (conv_gather_x3_kernel) instead of by gather_splitk_finish_kernel; the last
 // block leaves its counter at zero again
 static constexpr int GX_TILE_COUNTERS = 16384;
-struct GatherX3 { const float* xmax; const float* wmax; float* ymax; unsigned* tile_counters = nullptr; };
+// wsplit: wp is NOT the float32 pack but its pre-split image (launch_pack_x3g_weights: same size, the kernel's LDS row format)
+struct GatherX3 { const float* xmax; const float* wmax; float* ymax; unsigned* tile_counters = nullptr; bool wsplit = false; };
+int launch_pack_x3g_weights(const float* wp, const float* wmax, void* out, long long rows, int cin, hipStream_t s);
 int launch_conv_gather(const float* x, const float* wp, const float* bias, const float* residual, float* y,
                        int N, int H, int W, int cin, int cout, int R, int stride, int pad, unsigned flags,
                        void* ws, size_t ws_bytes, hipStream_t s, int math = FRCNN_GRAD_F32, const GatherX3* x3 = nullptr);

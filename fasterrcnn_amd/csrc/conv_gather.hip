@@ -468,13 +468,16 @@ typedef unsigned gx_u32x2 __attribute__((ext_vector_type(2)));
 // 8 fp16 of padding (144 B: the 16-byte fragment reads of 16 consecutive rows cover the 64 banks once)
 // MODE 1 (the train step's bf16 forward / data-gradient convolutions, conv_gather_bf16_kernel's arithmetic in this kernel's pipeline): one
 // bf16 term per value, LDS row = 32 bf16 + 8 of padding (80 B), one v_mfma_f32_32x32x16_bf16 per accumulator and 16 channels.
-static constexpr int GX_F32X3 = 0, GX_BF16 = 1;
+// MODE 2 (round 6): MODE 0 with the WEIGHT pack already split (launch_pack_x3g_weights: the rows of the pack in this kernel's LDS row format,
+// byte for byte the size of the float32 pack) -- a weight piece is then a 16-byte copy into LDS instead of ten vector instructions in
+// every block of every launch (half of the loop's operand-forming work; the weights are constants).  Same bits: the pack kernel splits with gx_split4.
+static constexpr int GX_F32X3 = 0, GX_BF16 = 1, GX_F32X3W = 2;
 #ifndef GX_ABLATE
 #define GX_ABLATE 0      // timing experiments (tools/build_ablate.sh, results wrong): 1 = the weight side of a stage is neither split nor written to LDS, 2 = nor fetched
 #endif
 template <int TM, int TN, int WM, int WN, int D, int MODE = GX_F32X3>
 struct GatherX3Cfg {
-    static constexpr int ROW = MODE == GX_F32X3 ? 72 : 40;                // 16-bit elements per LDS row
+    static constexpr int ROW = MODE != GX_BF16 ? 72 : 40;                 // 16-bit elements per LDS row
     static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static constexpr int NA = BM / 32, NB = BN / 32;                      // 16-byte pieces of a stage per thread (8 per 32-channel row)
     static constexpr int OUT_LD = BN + 4;                                 // the epilogue's float32 tile in LDS: row stride (conflict-free 16-byte writes)
@@ -490,16 +493,22 @@ struct GatherX3Cfg {
 // downstream (hx_split8's rule); one v_med3 per value, the products stay on v_fma_mix.
 __device__ __forceinline__ void gx_split4(const f32x4 v, float m, float bound, gx_u32x2& hi, gx_u32x2& lo)
 {
-    typedef _Float16 gx_f16x4 __attribute__((ext_vector_type(4)));
-    gx_f16x4 h, l;
+    // Round 6 (csrc/wino_x3f.hip's recipe, tools/micro/split_fill.hip): t = clamp(v) m is ONE multiply (exact), the hi terms of a channel
+    // PAIR are one v_cvt_pk_f16_f32 and lo = fp16(t - hi) is one v_fma_mix{lo,hi}_f16 with hi as its fp16 operand -- five issue slots per
+    // value where `(_Float16)fma(c, m, -(float)h)` cost seven (an f16 <-> f32 converting instruction is half rate, and the compiler
+    // converted hi BACK to float32 for the difference): the same bits (t and the difference are exact in float32).  One asm statement per
+    // register pair: hipcc pads a v_fma_mixhi that follows inline-asm partial writes with an s_nop.
+    float t[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float c = __builtin_amdgcn_fmed3f(v[e], -bound, bound);
-        h[e] = (_Float16)__builtin_fmaf(c, m, 0.0f);
-        l[e] = (_Float16)__builtin_fmaf(c, m, -(float)h[e]);
-    }
-    hi = __builtin_bit_cast(gx_u32x2, h);
-    lo = __builtin_bit_cast(gx_u32x2, l);
+    for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_fmed3f(v[e], -bound, bound) * m;
+    unsigned ha, hb, la, lb;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ha) : "v"(t[0]), "v"(t[1]));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hb) : "v"(t[2]), "v"(t[3]));
+    asm("v_fma_mixlo_f16 %0, %2, 1.0, -%6 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixlo_f16 %1, %4, 1.0, -%7 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %3, 1.0, -%6 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %1, %5, 1.0, -%7 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(la), "=&v"(lb) : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(ha), "v"(hb));
+    hi = gx_u32x2{ha, hb};
+    lo = gx_u32x2{la, lb};
 }
 
 // 16 bytes written through to memory / read past the caches (system scope: sc0 sc1) -- the partial planes of an in-kernel split reduction
@@ -580,7 +589,7 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
     const int nst = st_end - st_begin;
 
     float xmult = 1.f, xinv = 1.f, wmult = 1.f, winv = 1.f;
-    if constexpr (MODE == GX_F32X3) {
+    if constexpr (MODE != GX_BF16) {
         hx_row_scale(*xmax, xmult, xinv);
         hx_row_scale(*wmax, wmult, winv);
     }
@@ -594,7 +603,8 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
     // offsets stay non-negative.
     constexpr unsigned OUTSIDE = 0x80000000u;
     const int prow = tid >> 3, pc = tid & 7;
-    const int p_dst = MODE == GX_F32X3 ? prow * GX_ROW + (pc >> 2) * 32 + (pc & 3) * 4 : prow * GX_ROW + pc * 4;
+    const int p_dst = MODE != GX_BF16 ? prow * GX_ROW + (pc >> 2) * 32 + (pc & 3) * 4 : prow * GX_ROW + pc * 4;
+    const int p_dst_w = prow * GX_ROW + pc * 8;                               // (MODE 2: piece pc of a pre-split weight row = 16 bytes of the LDS row)
     // the data-gradient form at stride 1 (g.transposed) is the forward form with the taps walked backwards and padding R - 1 - pad:
     // source pixel (oy + pad - r, ox + pad - s) = (oy - pad' + r', ox - pad' + s') with r' = R - 1 - r; only the weight tap index differs
     const int pad_e = g.transposed ? g.R - 1 - g.pad : g.pad;
@@ -662,7 +672,7 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
     auto store_tiles = [&](int buf, const f32x4 (&ar)[C::NA], const f32x4 (&br)[C::NB]) {
         _Float16* const ad = at_s + buf * C::BM * GX_ROW + p_dst;
         _Float16* const bd = bt_s + buf * C::BN * GX_ROW + p_dst;
-        if constexpr (MODE == GX_F32X3) {
+        if constexpr (MODE != GX_BF16) {
 #pragma unroll
             for (int it = 0; it < C::NA; ++it) {
                 gx_u32x2 hi, lo;
@@ -673,7 +683,11 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
                 *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW) = hi;
                 *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW + 16) = lo;
             }
-            if (!(GX_ABLATE & 1)) {
+            if constexpr (MODE == GX_F32X3W) {
+                _Float16* const bw = bt_s + buf * C::BN * GX_ROW + p_dst_w;
+#pragma unroll
+                for (int it = 0; it < C::NB; ++it) *reinterpret_cast<f32x4*>(bw + it * 32 * GX_ROW) = br[it];       // (already hi | lo halves: a copy)
+            } else if (!(GX_ABLATE & 1)) {
 #pragma unroll
             for (int it = 0; it < C::NB; ++it) {
                 gx_u32x2 hi, lo;
@@ -709,7 +723,7 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
         constexpr int P = decltype(par)::value, Q = (P + 1) % D;
         const _Float16* const as = at_s + P * C::BM * GX_ROW + a_base;
         const _Float16* const bs = bt_s + P * C::BN * GX_ROW + b_base;
-        if constexpr (MODE == GX_F32X3) {
+        if constexpr (MODE != GX_BF16) {
             gx_f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -763,12 +777,12 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
         // order: the fragment reads, then per matrix instruction one piece's conversion, its LDS write and the refill of its registers --
         // a wave issues in order, so vector work placed BETWEEN two matrix instructions runs under the first one's 32 cycles; clustered
         // after them (the compiler's own choice) it adds to them (measured: 0.42 us a stage at the 64 x 64 tile for 6 MFMAs = 0.08 us)
-        constexpr int NFR = MODE == GX_F32X3 ? 4 * (TM + TN) : 2 * (TM + TN), NMF = MODE == GX_F32X3 ? 6 * TM * TN : 2 * TM * TN;
+        constexpr int NFR = MODE != GX_BF16 ? 4 * (TM + TN) : 2 * (TM + TN), NMF = MODE != GX_BF16 ? 6 * TM * TN : 2 * TM * TN;
         __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);
 #pragma unroll
         for (int q = 0; q < (NMF > C::NA + C::NB ? NMF : C::NA + C::NB); ++q) {
             if (q < C::NA + C::NB) {
-                __builtin_amdgcn_sched_group_barrier(0x002, MODE == GX_F32X3 ? 10 : 4, 0);
+                if (!(MODE == GX_F32X3W && q >= C::NA)) __builtin_amdgcn_sched_group_barrier(0x002, MODE != GX_BF16 ? 10 : 4, 0);      // (a pre-split weight piece has no vector work)
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
@@ -917,8 +931,8 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
                     if (residual) { rA = *reinterpret_cast<const f32x4*>(residual + iA); rB = *reinterpret_cast<const f32x4*>(residual + iB); }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float tA = ((MODE == GX_F32X3 ? vA[e] * unscale : vA[e]) + bq[e]) + rA[e];
-                        const float tB = ((MODE == GX_F32X3 ? vB[e] * unscale : vB[e]) + bq[e]) + rB[e];
+                        const float tA = ((MODE != GX_BF16 ? vA[e] * unscale : vA[e]) + bq[e]) + rA[e];
+                        const float tB = ((MODE != GX_BF16 ? vB[e] * unscale : vB[e]) + bq[e]) + rB[e];
                         vA[e] = relu ? fmaxf(tA, 0.f) : tA;
                         vB[e] = relu ? fmaxf(tB, 0.f) : tB;
                         vmax = fmaxf(vmax, fabsf(vA[e]));
@@ -930,8 +944,8 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
             }
         }
     }
-    if constexpr (MODE == GX_F32X3) { if (finished && ymax) gx_block_max(vmax, ymax); }
-    if constexpr (MODE == GX_F32X3) {
+    if constexpr (MODE != GX_BF16) { if (finished && ymax) gx_block_max(vmax, ymax); }
+    if constexpr (MODE != GX_BF16) {
         // An activation beyond the fp16 range under the tensor's scale -- the maximum the caller passed was not one -- was CLAMPED by the split
         // (gx_split4) instead of becoming inf / NaN: not silent any more: one event per wave that saw one, in a host-mapped
         // counter (frcnn_x3_saturation_events).  With the maxima the producers' epilogues leave behind this never fires (tests/test_stress_gpu.py).
@@ -1243,7 +1257,7 @@ static int launch_gather_x3_cfg(const GatherPlan& p, const float* x, const float
     FRCNN_MAX_LDS_ONCE(kx, X::LDS_BYTES);
     hipLaunchKernelGGL(kx, dim3(8 * p.nblocks * cdiv(p.mblocks, 8), 1, p.splits), dim3(256), X::LDS_BYTES, s, x, wp, bias, residual, y, ws, g,
                        p.stages_per_split, relu, x3 ? x3->xmax : (const float*)nullptr, x3 ? x3->wmax : (const float*)nullptr,
-                       x3 ? x3->ymax : (float*)nullptr, p.mblocks, p.nblocks, MODE == GX_F32X3 ? x3_saturation_counter() : (unsigned*)nullptr,
+                       x3 ? x3->ymax : (float*)nullptr, p.mblocks, p.nblocks, MODE != GX_BF16 ? x3_saturation_counter() : (unsigned*)nullptr,
                        gather_x3_in_kernel_finish(p, x3) ? x3->tile_counters : (unsigned*)nullptr);
     return check_launch();
 }
@@ -1281,6 +1295,40 @@ static int launch_gather_cfg(const GatherPlan& p, const float* x, const float* w
     return check_launch();
 }
 
+// The float32 weight pack [rows = taps x cout][cin] -> the rows in conv_gather_x3_kernel's LDS row format under the tensor's scale: per 32-channel
+// stage 128 bytes = [hi 16 | lo 16] of channels 0..15, [hi 16 | lo 16] of 16..31 (MODE 2 above).  Thread = one (row, 16-channel half stage).
+__global__ __launch_bounds__(256)
+void pack_x3g_weights_kernel(const float* __restrict__ wp, const float* __restrict__ wmax, unsigned char* __restrict__ out, long long rows, int cin)
+{
+    const int halves = cin >> 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * halves) return;
+    float wmult, winv;
+    hx_row_scale(*wmax, wmult, winv);
+    const float wbound = 65504.f * winv;
+    const long long row = i / halves;
+    const int hf = (int)(i - row * halves);
+    const float* src = wp + row * cin + hf * 16;
+    gx_u32x2 hi[4], lo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gx_split4(*reinterpret_cast<const f32x4*>(src + 4 * q), wmult, wbound, hi[q], lo[q]);
+    unsigned char* dst = out + (row * cin + hf * 16) * 4;                   // 64 bytes: 16 hi halves, then 16 lo halves
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<gx_u32x2*>(dst + 8 * q) = hi[q];
+        *reinterpret_cast<gx_u32x2*>(dst + 32 + 8 * q) = lo[q];
+    }
+}
+
+int launch_pack_x3g_weights(const float* wp, const float* wmax, void* out, long long rows, int cin, hipStream_t s)
+{
+    if (!wp || !wmax || !out || rows < 1 || cin < 32 || cin % 32 != 0) return FRCNN_EINVAL;
+    const long long n = rows * (cin / 16);
+    if ((n + 255) / 256 > 0x7fffffffLL) return FRCNN_EINVAL;
+    hipLaunchKernelGGL(pack_x3g_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, wp, wmax, static_cast<unsigned char*>(out), rows, cin);
+    return check_launch();
+}
+
 int launch_conv_gather(const float* x, const float* wp, const float* bias, const float* residual, float* y,
                        int N, int H, int W, int cin, int cout, int R, int stride, int pad, unsigned flags,
                        void* ws, size_t ws_bytes, hipStream_t s, int math, const GatherX3* x3)
@@ -1310,7 +1358,8 @@ int launch_conv_gather(const float* x, const float* wp, const float* bias, const
     int rc;
     if (gx3)
         rc = math == FRCNN_GRAD_BF16 ? launch_gather_x3_plan<GX_BF16>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, nullptr)
-                                     : launch_gather_x3_plan<GX_F32X3>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3);
+           : x3->wsplit            ? launch_gather_x3_plan<GX_F32X3W>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3)
+                                   : launch_gather_x3_plan<GX_F32X3>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3);
     else
         rc = p.cfg == 1 ? launch_gather_cfg<2, 2, 4, 1>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, math)
                         : launch_gather_cfg<2, 2, 2, 2>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, math);

@@ -143,25 +143,26 @@ def blob_x3t(wp, cout, cin):
     return pack_rows_x3t(wp.reshape(cout, cin), rows)
 
 
-def conv_nhwc_x3g(x, wp, bp, n, h, w, cin, cout, k, stride, pad, relu, xmax, wmax, ymax=None, residual=None, tickets=None):
+def conv_nhwc_x3g(x, wp, bp, n, h, w, cin, cout, k, stride, pad, relu, xmax, wmax, ymax=None, residual=None, tickets=None, wsplit=False):
     """frcnn_conv_nhwc_x3g: the same convolution in the f32x3 arithmetic under one scale per tensor; xmax / wmax: one-element CUDA float
     tensors bounding |x| and |wp|, ymax: a zeroed one that receives max|y| (or None).  tickets: a ZEROED int32 CUDA tensor of
     nv.X3G_TILE_COUNTERS elements = frcnn_conv_nhwc_x3g_tickets (a split reduction is finished inside the kernel; the tensor is zero
-    again afterwards).  Returns (y, ho, wo)."""
+    again afterwards).  wsplit: wp is a pack_x3g_weights image (FRCNN_X3G_WSPLIT).  Returns (y, ho, wo)."""
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     y = t.empty((n, ho, wo, cout), dtype=t.float32, device=x.device)
     lib = nv.lib()
     wsb = int(lib.frcnn_conv_workspace_bytes(n, h, w, cin, cout, k, stride, pad))
     ws = t.empty((max(wsb, 4) // 4,), dtype=t.float32, device=x.device)
+    fl = (nv.RELU if relu else 0) | (nv.X3G_WSPLIT if wsplit else 0)
     with t.cuda.device(x.device):
         if tickets is not None:
             assert tickets.numel() >= nv.X3G_TILE_COUNTERS and tickets.dtype == t.int32
             nv.check(lib.frcnn_conv_nhwc_x3g_tickets(nv.ptr(x), nv.ptr(wp), nv.ptr(bp), nv.ptr(residual), nv.ptr(y), n, h, w, cin, cout,
-                                                     k, stride, pad, nv.RELU if relu else 0, nv.ptr(xmax), nv.ptr(wmax), nv.ptr(ymax), nv.ptr(ws),
+                                                     k, stride, pad, fl, nv.ptr(xmax), nv.ptr(wmax), nv.ptr(ymax), nv.ptr(ws),
                                                      wsb, nv.ptr(tickets), nv.stream_ptr()), "frcnn_conv_nhwc_x3g_tickets")
         else:
             nv.check(lib.frcnn_conv_nhwc_x3g(nv.ptr(x), nv.ptr(wp), nv.ptr(bp), nv.ptr(residual), nv.ptr(y), n, h, w, cin, cout,
-                                             k, stride, pad, nv.RELU if relu else 0, nv.ptr(xmax), nv.ptr(wmax), nv.ptr(ymax), nv.ptr(ws), wsb,
+                                             k, stride, pad, fl, nv.ptr(xmax), nv.ptr(wmax), nv.ptr(ymax), nv.ptr(ws), wsb,
                                              nv.stream_ptr()), "frcnn_conv_nhwc_x3g")
     return y, ho, wo
 
@@ -188,6 +189,25 @@ def pack_block_g3(block):
         out["keep"].append(kd)
         packs.append(out["wd"])
     out["wmax"] = t.cat([tensor_absmax(p) for p in packs] + ([] if len(packs) == 4 else [t.ones((1,), dtype=t.float32, device=w1.device)]))
+    if G3_PRESPLIT:
+        # round 6 (ABI 15): the packs split ONCE, here, into the kernel's operand format (frcnn_pack_conv_x3g_weights: same size, same
+        # results bit for bit) -- the kernel then copies a weight piece into LDS instead of splitting it in every block of every launch
+        for i, key in enumerate(["w1", "w2", "w3", "wd"][:len(packs)]):
+            out[key] = pack_x3g_weights(out[key], out["wmax"][i:i + 1])
+        out["g3"] = 2
+    return out
+
+
+G3_PRESPLIT = True          # (tools flip it for A/B runs; frcnn_bottleneck_weights.g3 = 2 / 1)
+
+
+def pack_x3g_weights(wp, wmax):
+    """frcnn_pack_conv_x3g_weights: the float32 pack [taps][cout][cin] -> its pre-split image (a float32-typed tensor of the same shape
+    holding fp16 hi / lo pairs: only its bytes mean anything)."""
+    taps, cout, cin = int(wp.shape[0]), int(wp.shape[1]), int(wp.shape[2])
+    out = t.empty_like(wp)
+    with t.cuda.device(wp.device):
+        nv.check(nv.lib().frcnn_pack_conv_x3g_weights(nv.ptr(wp), nv.ptr(wmax), nv.ptr(out), taps, cout, cin, nv.stream_ptr()), "frcnn_pack_conv_x3g_weights")
     return out
 
 
@@ -328,12 +348,13 @@ def run_block(x, n, h, w, pb):
         wm = pb["wmax"]
         xmax = tensor_absmax(x)
         m = t.zeros((3,), dtype=t.float32, device=x.device)
-        t1, _, _ = conv_nhwc_x3g(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, 1, 0, True, xmax, wm[0:1], m[0:1])
-        t2, ho, wo = conv_nhwc_x3g(t1, pb["w2"], pb["b2"], n, h, w, pb["width"], pb["width"], 3, pb["stride"], 1, True, m[0:1], wm[1:2], m[1:2])
+        sp = pb["g3"] == 2                                                  # pre-split packs (pack_x3g_weights)
+        t1, _, _ = conv_nhwc_x3g(x, pb["w1"], pb["b1"], n, h, w, pb["cin"], pb["width"], 1, 1, 0, True, xmax, wm[0:1], m[0:1], wsplit=sp)
+        t2, ho, wo = conv_nhwc_x3g(t1, pb["w2"], pb["b2"], n, h, w, pb["width"], pb["width"], 3, pb["stride"], 1, True, m[0:1], wm[1:2], m[1:2], wsplit=sp)
         identity = x
         if pb["wd"] is not None:
-            identity, _, _ = conv_nhwc_x3g(x, pb["wd"], pb["bd"], n, h, w, pb["cin"], pb["cout"], 1, pb["stride"], 0, False, xmax, wm[3:4])
-        out, _, _ = conv_nhwc_x3g(t2, pb["w3"], pb["b3"], n, ho, wo, pb["width"], pb["cout"], 1, 1, 0, True, m[1:2], wm[2:3], m[2:3], residual=identity)
+            identity, _, _ = conv_nhwc_x3g(x, pb["wd"], pb["bd"], n, h, w, pb["cin"], pb["cout"], 1, pb["stride"], 0, False, xmax, wm[3:4], wsplit=sp)
+        out, _, _ = conv_nhwc_x3g(t2, pb["w3"], pb["b3"], n, ho, wo, pb["width"], pb["cout"], 1, 1, 0, True, m[1:2], wm[2:3], m[2:3], residual=identity, wsplit=sp)
         return out, ho, wo
     xm = pb.get("x6_mask", 0)
     x3 = pb.get("x3_mask", 0)

@@ -47,7 +47,7 @@ extern "C" {
                                  12: frcnn_x3_saturation_events, FRCNN_X3F_WAVES4 / FRCNN_X3F_WAVES8; 13: REMOVED the round-2 f32x6 kernels that no table has used since round 3
                                  (frcnn_pack_conv3x3_x6, frcnn_conv3x3_nhwc_x6, frcnn_split_rows_x6, frcnn_linear_x6(_workspace_bytes), math mode 1 =
                                  FRCNN_MATH_F32X6 and fc mode 1 = FRCNN_FC_F32X6 are FRCNN_EINVAL); the f32x6 arithmetic stays as gemm_x6t / wino_x6; 14: FRCNN_X3F_PAIR, frcnn_conv3x3_winograd_x3_pair_workspace_bytes, frcnn_forward_params.winograd_x3p_mask,
-                                 frcnn_resnet_rpn_roipool / frcnn_ctx_create_head / frcnn_resnet_head; 15: frcnn_conv_nhwc_x3g_tickets (split reductions finished inside the kernel) */
+                                 frcnn_resnet_rpn_roipool / frcnn_ctx_create_head / frcnn_resnet_head; 15: frcnn_conv_nhwc_x3g_tickets (split reductions finished inside the kernel), frcnn_pack_conv_x3g_weights + FRCNN_X3G_WSPLIT + frcnn_bottleneck_weights.g3 == 2 (pre-split weight packs) */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -60,6 +60,7 @@ extern "C" {
 /* ABI 14: the TWO-PASS form of the one-launch f32x3 layer, 128 output channels per block (wino_x3p_kernel, csrc/wino_x3p.hip): cin % 32 == 0,
  * cin >= 64, cout % 128 == 0; same results bit for bit; d_ws >= frcnn_conv3x3_winograd_x3_pair_workspace_bytes (channel maxima + the
  * block-private scratch the first pass's accumulators rest in). */
+#define FRCNN_X3G_WSPLIT 0x800u   /* frcnn_conv_nhwc_x3g(_tickets): d_w_packed is the PRE-SPLIT image of the float32 pack (frcnn_pack_conv_x3g_weights, round 6) */
 #define FRCNN_X3F_PAIR   0x400u
 
 int         frcnn_abi_version(void);
@@ -568,7 +569,7 @@ typedef struct frcnn_bottleneck_weights {
                                   their weight pointers are f32x3 blobs: frcnn_pack_rows_x3t of the [cout][K] matrix (1x1 and stride-2 3x3
                                   convolutions), frcnn_pack_conv3x3_winograd_x3's blob (stride-1 3x3) */
     const float* wmax;         /* round 4 (ABI 11), with g3 != 0: device float[4] = max |w1|, |w2|, |w3|, |wd| of the packs (upper bounds; [3] unused without wd) */
-    int32_t g3;                /* != 0: the block's four convolutions run in the f32x3 arithmetic under ONE scale per tensor (frcnn_conv_nhwc_x3g's kernel,
+    int32_t g3;                /* != 0 (2, ABI 15: w1 / w2 / w3 / wd are frcnn_pack_conv_x3g_weights images of the float32 packs, same results): the block's four convolutions run in the f32x3 arithmetic under ONE scale per tensor (frcnn_conv_nhwc_x3g's kernel,
                                   csrc/conv_gather.hip): w1 / w2 / w3 / wd are the plain float32 packs ([1][width][cin], [9][width][width], ...) whatever the
                                   math mode, x6_mask must be 0.  The activation maxima travel from one convolution's epilogue to the next one's scale inside
                                   the context.  Reference: the same Bottleneck forward, models/resnet.py:38-46 / :66-90 */
@@ -740,6 +741,12 @@ int frcnn_conv_nhwc_x3g_tickets(const float* d_x, const float* d_w_packed, const
                                 int N, int H, int W, int cin, int cout, int ksize, int stride, int pad, unsigned flags,
                                 const float* d_xmax, const float* d_wmax, float* d_ymax, void* d_ws, size_t ws_bytes,
                                 unsigned* d_tile_counters, void* stream);
+/* ABI 15: the weight side of frcnn_conv_nhwc_x3g split ONCE, at pack time.  d_out (taps * cout * cin * 4 bytes, the size of the float32 pack
+ * [taps][cout][cin]) receives every row in the kernel's own operand format -- per 32 input channels 128 bytes: [hi x 16 | lo x 16] fp16 of channels
+ * 0..15, then of 16..31, hi = fp16(w 2^e), lo = fp16(w 2^e - hi) under the scale that *d_wmax gives -- so that a weight piece is a 16-byte copy
+ * into LDS in every block of every launch instead of a split.  Pass it as d_w_packed with FRCNN_X3G_WSPLIT in `flags` (and the SAME d_wmax):
+ * the results are the same bits as with the float32 pack.  cin % 32 == 0.  frcnn_bottleneck_weights.g3 == 2: the block's four packs are such images. */
+int frcnn_pack_conv_x3g_weights(const float* d_w_packed, const float* d_wmax, void* d_out, int taps, int cout, int cin, void* stream);
 /* ABI 12: frcnn_conv_nhwc_x3g CLAMPS an activation whose hi term would overflow fp16 under the tensor's scale (i.e. *d_xmax was not an
  * upper bound) instead of producing inf / NaN; every wave that clamped one adds 1 to a process-wide counter.  *out = that count since the
  * library was loaded (read it after synchronising the streams the convolutions ran on).  With the maxima the producers' epilogues leave

@@ -40,6 +40,7 @@ def test_argument_validation_without_gpu():
     assert lib.frcnn_detections(None, None, None, None, 300, 21, 600, 1000, 0.05, 0.3, None, None, None) == -1
     assert lib.frcnn_conv_nhwc_x3g(None, None, None, None, None, 1, 8, 8, 32, 64, 1, 1, 0, 0, None, None, None, None, 0, None) == -1
     assert lib.frcnn_conv_nhwc_x3g_tickets(None, None, None, None, None, 1, 8, 8, 32, 64, 1, 1, 0, 0, None, None, None, None, 0, None, None) == -1
+    assert lib.frcnn_pack_conv_x3g_weights(None, None, None, 1, 64, 64, None) == -1
     assert lib.frcnn_tensor_absmax(None, 16, None, None) == -1
     handle = C.c_void_p()
     assert lib.frcnn_ctx_create(C.byref(handle), 4, 4, 300) == -1          # image too small

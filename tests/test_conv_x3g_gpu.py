@@ -132,3 +132,25 @@ def test_conv_x3g_split_reduction_finished_in_the_kernel_is_the_same_bits(shape)
             assert torch.equal(y0, y1)
             assert float(ym0) == float(ym1)
             assert int(tickets.abs().max()) == 0
+
+
+@pytest.mark.parametrize("shape", [(1, 38, 63, 256, 1024, 1, 1, 0), (1, 75, 125, 128, 128, 3, 2, 1), (2, 19, 31, 512, 128, 1, 1, 0), (1, 150, 250, 64, 256, 1, 1, 0)])
+def test_conv_x3g_pre_split_weights_are_the_same_bits(shape):
+    """frcnn_pack_conv_x3g_weights + FRCNN_X3G_WSPLIT (ABI 15, round 6): the weight pack split once, at pack time, into the kernel's operand
+    format -- the convolution then copies a weight piece into LDS instead of splitting it in every block; output and emitted maximum are
+    the float32 pack's, bit for bit (models/resnet.py:38-46, frozen BN folded: the weights are constants)."""
+    n, h, w, cin, cout, k, stride, pad = shape
+    g = torch.Generator().manual_seed(7 + sum(shape))
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wp = pack((torch.randn(cout, cin, k, k, generator=g) / (3.0 * (cin * k * k) ** 0.5)).cuda())
+    b = torch.randn(cout, generator=g).cuda()
+    xm, wm = R.tensor_absmax(x), R.tensor_absmax(wp)
+    ws = R.pack_x3g_weights(wp, wm)
+    assert ws.shape == wp.shape and not torch.equal(ws, wp)
+    tickets = torch.zeros(nv.X3G_TILE_COUNTERS, dtype=torch.int32, device="cuda")
+    for relu in (True, False):
+        ym0, ym1 = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+        y0, _, _ = R.conv_nhwc_x3g(x, wp, b, n, h, w, cin, cout, k, stride, pad, relu, xm, wm, ym0)
+        y1, _, _ = R.conv_nhwc_x3g(x, ws, b, n, h, w, cin, cout, k, stride, pad, relu, xm, wm, ym1, tickets=tickets, wsplit=True)
+        assert torch.equal(y0, y1)
+        assert float(ym0) == float(ym1)

@@ -1,6 +1,6 @@
 """tools/cu_time_model.py -- a CU-time budget of one image from a SINGLE-STREAM rocprofv3 kernel trace (one image at a time: a dispatch's
 duration is its own).  For every dispatch: blocks resident per CU from its registers / LDS / block size, the fraction of the chip's block slots
-its grid fills, and  cu_time = duration x min(1, blocks / (256 x blocks per CU)).  The sum over an image's dispatches is what the chip must
+its grid fills over its rounds of resident blocks, and  cu_time = duration x (rounds / ceil(rounds)), rounds = blocks / (256 x blocks per CU).  The sum over an image's dispatches is what the chip must
 spend on the image however many images are in flight (kernels that leave CUs empty can overlap others'; kernels that fill it cannot).
     (1) rocprofv3 --kernel-trace -d DIR -- python tools/cu_time_model.py run vgg16|resnet50 [images]
     (2) python tools/cu_time_model.py report DIR"""
@@ -69,7 +69,8 @@ def report(d):
         for key, val in KNOWN_BLOCKS_PER_CU.items():               # (the trace's LDS column does not include dynamic LDS)
             if key in r["Kernel_Name"]:
                 bpc = val
-        frac = min(1.0, blocks / (256.0 * bpc))
+        rounds = blocks / (256.0 * bpc)
+        frac = rounds / max(1.0, float(-(-blocks // (256 * bpc))))          # mean fill over the launch's rounds of resident blocks (the last round is partial)
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("frcnn::", "")[:48]
         a = agg[name]
         a[0] += 1; a[1] += dur; a[2] += dur * frac; a[3] += frac; a[4] = bpc
