@@ -960,7 +960,7 @@ def main():
         dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
         extra["resnet50_images_per_sec"] = round(args.steps / dt, 3)
         extra["resnet50_config"] = ("ResNet-50 predict(), 3x600x1000, 8 batch-1 images in flight, math %s, bottleneck_g3=%s (layer1..3: every bottleneck "
-                                    "convolution in the f32x3 arithmetic under one scale per tensor, conv_gather_x3_kernel), x6_conv1x1=%s in the %s arithmetic (the "
+                                    "convolution in the f32x3 arithmetic under one scale per tensor, conv_gather_x3_kernel, weight packs split at pack time), x6_conv1x1=%s in the %s arithmetic (the "
                                     "convolutions of the per-RoI layer4 as split-operand GEMMs on the fp16 / bf16 matrix instructions), winograd_x6_layers=%s, "
                                     "winograd_x3_layers=%s; every golden proposal / detection reproduced"
                                     % (m50.math_mode, m50.bottleneck_g3, m50.x6_conv1x1, m50.x6_conv1x1_arith, list(m50.winograd_x6_layers),
@@ -971,6 +971,14 @@ def main():
         def set50(**kw):
             for k_, v_ in kw.items():
                 setattr(m50, k_, v_)
+        # the OPTION bottleneck_g3 = "all" (round 6: with the weight packs split at pack time it is the fastest table): layer4's per-RoI
+        # convolutions under one scale per tensor too -- admitted by the held-out sweep (same counts and K as the default), not the default:
+        # one golden detection of the batch-8 fixture moves past 1e-3 px (tests/test_resnet_gpu.py holds it to the observed counts)
+        set50(bottleneck_g3="all")
+        run50(16)
+        dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
+        extra["resnet50_g3_all_images_per_sec"] = round(args.steps / dt, 3)
+        set50(**d50)
         # round 3's default: the backbone on the exact-f32 gather / float32 Winograd kernels
         set50(bottleneck_g3="off")
         run50(16)

@@ -1531,7 +1531,7 @@ int run_bottleneck(frcnn_ctx* c, const frcnn_bottleneck_weights& b, int N, int& 
         }
         if ((rc = gx_slot(c, s, &m1)) || (rc = gx_slot(c, s, &m2)) || (rc = gx_slot(c, s, &m3))) return rc;
         const bool ws_ = b.g3 == 2;                              // the packs are pre-split images (frcnn_pack_conv_x3g_weights)
-        const GatherX3 g1{c->gx_x, b.wmax + 0, m1, c->gx_cnt, ws_}, g2{m1, b.wmax + 1, m2, c->gx_cnt, ws_}, g3{m2, b.wmax + 2, m3, c->gx_cnt, ws_}, gd{c->gx_x, b.wmax + 3, nullptr, c->gx_cnt, ws_};
+        const GatherX3 g1{c->gx_x, b.wmax + 0, m1, c->gx_cnt, ws_, ws_}, g2{m1, b.wmax + 1, m2, c->gx_cnt, ws_, ws_}, g3{m2, b.wmax + 2, m3, c->gx_cnt, ws_, ws_}, gd{c->gx_x, b.wmax + 3, nullptr, c->gx_cnt, ws_, ws_};      // (trusted: every maximum of this chain is a producer's or tensor_absmax_kernel's)
         const int X3 = FRCNN_CONV_F32X3G;
         RSTEP(launch_conv_gather(X, b.w1, b.b1, nullptr, T1, N, h, w, b.cin, b.width, 1, 1, 0, R, c->conv_ws, c->conv_ws_bytes, s, X3, &g1));
         RSTEP(launch_conv_gather(T1, b.w2, b.b2, nullptr, T2, N, h, w, b.width, b.width, 3, b.stride, 1, R, c->conv_ws, c->conv_ws_bytes, s, X3, &g2));

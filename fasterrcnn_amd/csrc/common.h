@@ -109,7 +109,8 @@ size_t conv_gather_workspace_bytes(int N, int H, int W, int cin, int cout, int R
 // block leaves its counter at zero again
 static constexpr int GX_TILE_COUNTERS = 16384;
 // wsplit: wp is NOT the float32 pack but its pre-split image (launch_pack_x3g_weights: same size, the kernel's LDS row format)
-struct GatherX3 { const float* xmax; const float* wmax; float* ymax; unsigned* tile_counters = nullptr; bool wsplit = false; };
+// trusted (with wsplit): *xmax is the tensor's TRUE maximum (a producer's epilogue / tensor_absmax_kernel left it): no clamp, no saturation count
+struct GatherX3 { const float* xmax; const float* wmax; float* ymax; unsigned* tile_counters = nullptr; bool wsplit = false; bool trusted = false; };
 int launch_pack_x3g_weights(const float* wp, const float* wmax, void* out, long long rows, int cin, hipStream_t s);
 int launch_conv_gather(const float* x, const float* wp, const float* bias, const float* residual, float* y,
                        int N, int H, int W, int cin, int cout, int R, int stride, int pad, unsigned flags,

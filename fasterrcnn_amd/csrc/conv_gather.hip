@@ -471,7 +471,10 @@ typedef unsigned gx_u32x2 __attribute__((ext_vector_type(2)));
 // MODE 2 (round 6): MODE 0 with the WEIGHT pack already split (launch_pack_x3g_weights: the rows of the pack in this kernel's LDS row format,
 // byte for byte the size of the float32 pack) -- a weight piece is then a 16-byte copy into LDS instead of ten vector instructions in
 // every block of every launch (half of the loop's operand-forming work; the weights are constants).  Same bits: the pack kernel splits with gx_split4.
-static constexpr int GX_F32X3 = 0, GX_BF16 = 1, GX_F32X3W = 2;
+// MODE 3: MODE 2 for a caller whose *xmax IS the tensor's maximum (the forwards' chains: every maximum comes from the producer's epilogue or from
+// tensor_absmax_kernel): no clamp per activation value and no saturation bookkeeping (a fifth of the activation side's vector instructions);
+// the clamp of MODE 0 / 2 never changes a value under a true maximum, so the bits are the same.
+static constexpr int GX_F32X3 = 0, GX_BF16 = 1, GX_F32X3W = 2, GX_F32X3WT = 3;
 #ifndef GX_ABLATE
 #define GX_ABLATE 0      // timing experiments (tools/build_ablate.sh, results wrong): 1 = the weight side of a stage is neither split nor written to LDS, 2 = nor fetched
 #endif
@@ -491,6 +494,7 @@ struct GatherX3Cfg {
 // the matrix instructions
 // `bound` = 65504 / m: a value beyond it (the caller's maximum was not one) saturates instead of becoming hi = inf, lo = -inf -> NaN
 // downstream (hx_split8's rule); one v_med3 per value, the products stay on v_fma_mix.
+template <bool CLAMP = true>
 __device__ __forceinline__ void gx_split4(const f32x4 v, float m, float bound, gx_u32x2& hi, gx_u32x2& lo)
 {
     // Round 6 (csrc/wino_x3f.hip's recipe, tools/micro/split_fill.hip): t = clamp(v) m is ONE multiply (exact), the hi terms of a channel
@@ -500,7 +504,7 @@ __device__ __forceinline__ void gx_split4(const f32x4 v, float m, float bound, g
     // register pair: hipcc pads a v_fma_mixhi that follows inline-asm partial writes with an s_nop.
     float t[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_fmed3f(v[e], -bound, bound) * m;
+    for (int e = 0; e < 4; ++e) t[e] = (CLAMP ? __builtin_amdgcn_fmed3f(v[e], -bound, bound) : v[e]) * m;
     unsigned ha, hb, la, lb;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ha) : "v"(t[0]), "v"(t[1]));
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hb) : "v"(t[2]), "v"(t[3]));
@@ -677,13 +681,15 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
             for (int it = 0; it < C::NA; ++it) {
                 gx_u32x2 hi, lo;
                 // the largest |activation| this thread splits (two v_max3 per four values): beyond xbound the split SATURATES -- counted below
-                x_amax = fmaxf(fmaxf(x_amax, fabsf(ar[it][0])), fabsf(ar[it][1]));
-                x_amax = fmaxf(fmaxf(x_amax, fabsf(ar[it][2])), fabsf(ar[it][3]));
-                gx_split4(ar[it], xmult, xbound, hi, lo);
+                if constexpr (MODE != GX_F32X3WT) {
+                    x_amax = fmaxf(fmaxf(x_amax, fabsf(ar[it][0])), fabsf(ar[it][1]));
+                    x_amax = fmaxf(fmaxf(x_amax, fabsf(ar[it][2])), fabsf(ar[it][3]));
+                }
+                gx_split4<MODE != GX_F32X3WT>(ar[it], xmult, xbound, hi, lo);
                 *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW) = hi;
                 *reinterpret_cast<gx_u32x2*>(ad + it * 32 * GX_ROW + 16) = lo;
             }
-            if constexpr (MODE == GX_F32X3W) {
+            if constexpr (MODE == GX_F32X3W || MODE == GX_F32X3WT) {
                 _Float16* const bw = bt_s + buf * C::BN * GX_ROW + p_dst_w;
 #pragma unroll
                 for (int it = 0; it < C::NB; ++it) *reinterpret_cast<f32x4*>(bw + it * 32 * GX_ROW) = br[it];       // (already hi | lo halves: a copy)
@@ -782,7 +788,7 @@ void conv_gather_x3_kernel(const float* __restrict__ x, const float* __restrict_
 #pragma unroll
         for (int q = 0; q < (NMF > C::NA + C::NB ? NMF : C::NA + C::NB); ++q) {
             if (q < C::NA + C::NB) {
-                if (!(MODE == GX_F32X3W && q >= C::NA)) __builtin_amdgcn_sched_group_barrier(0x002, MODE != GX_BF16 ? 10 : 4, 0);      // (a pre-split weight piece has no vector work)
+                if (!((MODE == GX_F32X3W || MODE == GX_F32X3WT) && q >= C::NA)) __builtin_amdgcn_sched_group_barrier(0x002, MODE == GX_F32X3WT ? 8 : MODE != GX_BF16 ? 10 : 4, 0);      // (a pre-split weight piece has no vector work)
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
@@ -1358,6 +1364,7 @@ int launch_conv_gather(const float* x, const float* wp, const float* bias, const
     int rc;
     if (gx3)
         rc = math == FRCNN_GRAD_BF16 ? launch_gather_x3_plan<GX_BF16>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, nullptr)
+           : x3->wsplit && x3->trusted ? launch_gather_x3_plan<GX_F32X3WT>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3)
            : x3->wsplit            ? launch_gather_x3_plan<GX_F32X3W>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3)
                                    : launch_gather_x3_plan<GX_F32X3>(p, x, wp, bias, residual, y, (float*)ws, g, relu, s, x3);
     else
