@@ -22,6 +22,7 @@ FRCNN_LIB_PATH=build/libfrcnn_chk.so timeout 300 python tools/xd_clocks.py four 
 # the CU-time budget of one image (tools/cu_time_model.py: single-stream kernel trace -> duration x chip fill per dispatch)
 for a in vgg16 resnet50; do rm -rf /tmp/tr_$a; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$a -o t -- python tools/cu_time_model.py run $a 40 > /dev/null 2>&1; python tools/cu_time_model.py report /tmp/tr_$a > $OUT/cu_time_$a.txt 2>&1; head -3 $OUT/cu_time_$a.txt | cut -c1-200; done
 timeout 300 python tools/exp_r50_graphs.py resnet50 8 > $OUT/exp_r50_graphs.txt 2>&1; timeout 300 python tools/exp_r50_threads.py > $OUT/exp_r50_threads.txt 2>&1
+timeout 600 python tools/exp_r50_presplit.py rev > $OUT/exp_r50_presplit.txt 2>&1; timeout 600 python tools/exp_r50_presplit.py all rev > $OUT/exp_r50_presplit_g3all.txt 2>&1
 FRCNN_LIB_PATH=build/libfrcnn_exp.so timeout 600 python -m pytest tests/test_gemm_x3t_gpu.py -m gpu -q > $OUT/pytest_x3_exp.log 2>&1; tail -1 $OUT/pytest_x3_exp.log
 rm -rf $OUT/tr_r50b8; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr_r50b8 -o t -- python tools/r50_batch8_trace.py 4 > $OUT/tr_r50b8.log 2>&1
 f=$(find $OUT/tr_r50b8 -name "*kernel_stats.csv" | head -1); cp $f $OUT/resnet50_batch8_kernel_stats.csv; rm -rf $OUT/tr_r50b8; grep images $OUT/tr_r50b8.log
