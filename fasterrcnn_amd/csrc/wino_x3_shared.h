@@ -17,7 +17,7 @@ static constexpr int X3_HR = 10;                             // halo rows: 4 til
 
 // m_*: ceil(2^32 / d) of the three divisors of the block index (0 for d = 1): the quotient is ONE scalar multiply-high on the device instead of
 // a division sequence per divisor between the block's entry and its first load (exact while block index x d < 2^32: checked by the launcher)
-struct XfGeom { int tbx, tby, ncb, tw, th, xg; unsigned m_tbx, m_tby, m_ncb; int ntb; unsigned m_ntb; int g8; };   // ntb: tile blocks of all maps; g8 = 8 / ncb (xg == 2, ncb < 8: a division sequence on the device otherwise)
+struct XfGeom { int tbx, tby, ncb, tw, th, xg; unsigned m_tbx, m_tby, m_ncb; int ntb; unsigned m_ntb; int g8; int n_items; };   // ntb: tile blocks of all maps; g8 = 8 / ncb (xg == 2, ncb < 8: a division sequence on the device otherwise); n_items = work items of the launch (= the grid of the one-item-per-block form)
 __device__ __forceinline__ int xd_div(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
 
 typedef float xd_f32x2 __attribute__((ext_vector_type(2)));

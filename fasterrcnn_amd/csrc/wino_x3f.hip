@@ -127,8 +127,26 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K16 = Cin >> 4;
 
+#ifdef XD_PERSIST
+    // experiment (tools/build_ablate.sh persist -DXD_PERSIST): one block per CU walks the items item, item + gridDim.x, ... (gridDim.x a multiple of 8:
+    // the XCD an item runs on is unchanged) -- no dispatch gap between the blocks of a CU (~0.45 us of every block).  MEASURED, round 6
+    // (same-box A/B): layers 105 / 58 / 81 / 50 / 88 / 84 / 55 / 97 / 96 / 42 us -> 147 / 82 / 106 / 68 / 107 / 102 / 67 / 113 / 109 / 50, 927 -> 796
+    // images/sec: with the item loop around it the compiler hoists ~50 lane constants of the prologue out of the loop into SCRATCH (53-60
+    // spilled registers, reloaded per item) and the row pass spills -- even a launch whose blocks walk ONE item each is 19 % slower.  Not built
+    // further (the prefetch of the next item's filter pieces between the epilogue's instructions, DESIGN.md section 7, needs this form).
+    for (int item = blockIdx.x; item < gm.n_items; item += gridDim.x) {
+#else
+    {
+    const int item = blockIdx.x;
+#endif
     int cb, bx, by, map;
-    if (!xd_block_to_tile(gm, blockIdx.x, cb, bx, by, map)) return;          // (block -> XCD mapping: wino_x3_shared.h)
+    if (!xd_block_to_tile(gm, item, cb, bx, by, map)) {                      // (block -> XCD mapping: wino_x3_shared.h)
+#ifdef XD_PERSIST
+        continue;
+#else
+        return;
+#endif
+    }
     const float* __restrict__ const x = x_maps + (size_t)map * H * W * Cin;
     const float* __restrict__ const cmax = cmax_maps + (size_t)map * H * W;
     float* __restrict__ const y = y_maps + (size_t)map * (POOL ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) * Cout;
@@ -641,6 +659,9 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
             if (ok) atomicMax(reinterpret_cast<unsigned*>(cmax_out + (size_t)yy * W + xx), __float_as_uint(pm));
         }
     }
+#ifdef XD_PERSIST
+    __syncthreads();                                                         // the Y buffer is read: the next item's DMA may write the ring it lies over
+#endif
 #ifdef XD_CLOCKS
     // timing build (tools/xd_clocks.py): wave 0 / lane 0 of every block leaves its stamps behind the (single-map) output
     if (tid == 0) {
@@ -661,6 +682,7 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
 #endif
     }
 #endif
+    }   // (the item: one per block, or the persistent walk)
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
@@ -740,6 +762,10 @@ int launch_conv3x3_winograd_x3_fused(const float* x, const void* ublob, const fl
     auto magic = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
     gm.m_tbx = magic(gm.tbx); gm.m_tby = magic(gm.tby); gm.m_ncb = magic(gm.ncb); gm.m_ntb = magic(gm.ntb);
     gm.g8 = gm.ncb < 8 ? 8 / gm.ncb : 1;
+    gm.n_items = (int)grid_blocks;
+#ifdef XD_PERSIST
+    if (grid_blocks > 256) grid_blocks = 256;                              // one block per CU walks the items
+#endif
     if (total * std::max(std::max(gm.ncb, gm.ntb), std::max(gm.tbx, gm.tby)) >= 0x100000000ll) return FRCNN_EUNSUPPORTED;
     const int u_rbt = cdiv(cout, gemm_x6t_col_tile(cout)) * gemm_x6t_col_tile(cout) / 32;
     if ((size_t)16 * (cin / 16) * u_rbt * HX_RB >= ((size_t)1 << 31)) return FRCNN_EUNSUPPORTED;   // the record bank behind one buffer descriptor
