@@ -106,7 +106,9 @@ __device__ __forceinline__ float xd_rowmax16_scatter4(const float (&v)[4])
 }
 
 #ifndef XD_EARLY_HALO
-#define XD_EARLY_HALO 1      // 1: halo(1) / halo(2) leave in chunks 0 / 1; 0: at the end of the prologue (A/B: tools/run_ab_x3f.sh)
+#define XD_EARLY_HALO 1      // 1 (shipped): halo(1) / halo(2) in chunks 0 / 1; 2: halo(1) at the end of the prologue, halo(2) in chunk 0; 0: both at the end of the prologue.
+                             // Same-box A/B (tools/run_ab_x3f.sh): the three forms are within 1 % of each other on every layer and on the headline (920 vs 920 for 1 vs 2) --
+                             // the 14 DMA pieces that fill the ring cost the address unit the same wherever they are issued
 #endif
 static constexpr int XD_FIRST = 1, XD_EARLY = XD_EARLY_HALO ? 2 : 0, XD_LAST = 4;             // chunk flags (the step lambda below)
 
@@ -333,7 +335,7 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // Chunks K16 - 3 and K16 - 2 still re-read the last halo (14 pieces nobody consumes): as run-time branches around the two DMA groups
     // of the generic chunk the skip cost the whole loop 250 cycles per chunk (measured; the branch ends the basic block the steps are
     // placed in), and as more instantiations it costs code size.
-    auto step = [&](int ucb, int hso, int hso_next, float* hcur, float* hnxt, auto PAR, auto S, auto FLAGS) {     // hso: byte offset of chunk c + 3 in a pixel
+    auto step = [&](int ucb, int hso, int hso_next, float* hcur, float* hnxt, float* hthird_, auto PAR, auto S, auto FLAGS) {     // hso: byte offset of chunk c + 3 in a pixel
         constexpr int par = decltype(PAR)::value, s = decltype(S)::value;
 #ifdef XD_STEPS
         {
@@ -369,8 +371,11 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         // halo(c + 3) -> the buffer halo(c) was read from, free since the barrier of step 3 (its last patch read is that step's)
         if (s == 4 && !last) dma_halo(hcur, hso, XdInt<0>{}, XdInt<4>{}, xrs_ring);
         // chunks 0 and 1: halo(c + 1) -> the buffer steps 4-7 will read it from (landed by the barrier of step 3: the wait below)
-        if (early && !last && s == 0) dma_halo(hnxt, hso_next, XdInt<0>{}, XdInt<4>{}, xrs);
-        if (early && !last && s == 1) dma_halo(hnxt, hso_next, XdInt<4>{}, XdInt<XD_NDMA>{}, xrs);
+        // (XD_EARLY_HALO 2: the piece that leaves early is halo(c + 2), into the third buffer, and only chunk 0 carries the flag: a DMA issued
+        //  in steps 0-1 for the barrier of step 3 of the SAME chunk made that barrier wait for its round trip -- chunk 0 2,600-3,170 cycles,
+        //  chunk 1 2,880-3,600 against 2,500; issued a chunk earlier it has landed when it is due)
+        if (early && !last && !(XD_EARLY_HALO == 2 && TWO) && s == 0) dma_halo(XD_EARLY_HALO == 2 ? hthird_ : hnxt, hso_next + (XD_EARLY_HALO == 2 ? 64 : 0), XdInt<0>{}, XdInt<4>{}, xrs);
+        if (early && !last && !(XD_EARLY_HALO == 2 && TWO) && s == 1) dma_halo(XD_EARLY_HALO == 2 ? hthird_ : hnxt, hso_next + (XD_EARLY_HALO == 2 ? 64 : 0), XdInt<4>{}, XdInt<XD_NDMA>{}, xrs);
         XD_FENCE();
         XD_MFMA(par, h, j, 1, 0, vh);
         if (form) XD_IF(1, v_adds(nh, nj, 2));
@@ -393,7 +398,9 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
             // loads, only make the count stricter).  Chunks 0 and 1 issued halo(c + 1) themselves, in steps 0 and 1: younger than its
             // last piece are the 6 filter pieces of steps 1-3.  Then the block barrier: halo(c + 1) visible to every wave, halo(c)'s
             // buffer spent.
-            if (early) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(last ? 0 : 6) : "memory");
+            // (XD_EARLY_HALO 2, chunk 0: halo(1) left last in the prologue; younger are halo(2)'s 7 pieces and the 8 filter pieces of steps 0-3: 15 again
+            //  -- 8 in the two-chunk kernel, which has no halo(2))
+            if (early) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XD_EARLY_HALO == 2 ? (last ? 0 : TWO ? 8 : 15) : (last ? 0 : 6)) : "memory");
             else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
             xd_lds_barrier();
         }
@@ -407,10 +414,10 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
         //  nothing and writes zeros nobody reads -- instead of branching; the filter offset of a chunk past the end is never used: XD_LAST)
         const int ucb = (c + 1) * chunk_stride, hso = (c + 3 < K16 ? c + 3 : K16 - 1) * 64, hson = (c + 1) * 64;
         xrs_ring = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, c + 3 < K16 ? H * W * Cin * (int)sizeof(float) : 0, 0x00020000);
-        step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<0>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<1>{}, FLAGS);
-        step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<2>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<3>{}, FLAGS);
-        step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<4>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<5>{}, FLAGS);
-        step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<6>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, PAR, XdInt<7>{}, FLAGS);
+        step(ucb, hso, hson, hcur, hnxt, hthird, PAR, XdInt<0>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, hthird, PAR, XdInt<1>{}, FLAGS);
+        step(ucb, hso, hson, hcur, hnxt, hthird, PAR, XdInt<2>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, hthird, PAR, XdInt<3>{}, FLAGS);
+        step(ucb, hso, hson, hcur, hnxt, hthird, PAR, XdInt<4>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, hthird, PAR, XdInt<5>{}, FLAGS);
+        step(ucb, hso, hson, hcur, hnxt, hthird, PAR, XdInt<6>{}, FLAGS); step(ucb, hso, hson, hcur, hnxt, hthird, PAR, XdInt<7>{}, FLAGS);
         float* const t = hcur; hcur = hnxt; hnxt = hthird; hthird = t;
     };
 
@@ -459,15 +466,15 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     XD_FENCE();
     if (!(XD_ABLATE & 32)) { load_u(0, XdInt<0>{}, XdInt<1>{}); load_u(0, XdInt<0>{}, XdInt<2>{}); load_u(0, XdInt<0>{}, XdInt<3>{}); }
     XD_FENCE();
-    if (!XD_EARLY_HALO && !(XD_ABLATE & 32)) {
+    if (XD_EARLY_HALO != 1 && !(XD_ABLATE & 32)) {
         dma_halo(hnxt, 64, XdInt<0>{}, XdInt<XD_NDMA>{}, xrs);
-        if (!TWO) dma_halo(hthird, 128, XdInt<0>{}, XdInt<XD_NDMA>{}, xrs);
+        if (XD_EARLY_HALO == 0 && !TWO) dma_halo(hthird, 128, XdInt<0>{}, XdInt<XD_NDMA>{}, xrs);
     }
     XD_FENCE();
 #ifdef XD_CLOCKS
     const unsigned long long xd_t_issued = __builtin_amdgcn_s_memrealtime();
 #endif
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD_ABLATE & 32) ? 0 : 12 + (XD_EARLY_HALO ? 0 : (TWO ? 1 : 2) * XD_NDMA)) : "memory");       // everything but the 12 filter pieces of position columns 1-3: the maxima, column 0's pieces, halo(0), the scales and the bias are in
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD_ABLATE & 32) ? 0 : 12 + (XD_EARLY_HALO == 1 ? 0 : XD_EARLY_HALO == 2 ? XD_NDMA : (TWO ? 1 : 2) * XD_NDMA)) : "memory");       // everything but the 12 filter pieces of position columns 1-3: the maxima, column 0's pieces, halo(0), the scales and the bias are in
     xd_lds_barrier();
     {   // the lane's two tile scales from the halo pixels' channel maxima (rows 4 h + 2 tyl + a, columns 2 txl + c)
         const float* cm = reinterpret_cast<const float*>(smem_xf + XD_CM_OFFSET) + (2 * tyl) * XF_HC + 2 * txl;
@@ -505,9 +512,9 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     if constexpr (TWO) {                                                     // (its own instantiation: as a run-time branch the two paths cost the register allocation 318 spills)
         int one = 1;
         asm volatile("" : "+s"(one));
-        for (int rep = 0; rep < one; ++rep) chunk(1, XdInt<1>{}, XdInt<XD_EARLY | XD_LAST>{});     // (one trip: see below)
+        for (int rep = 0; rep < one; ++rep) chunk(1, XdInt<1>{}, XdInt<(XD_EARLY_HALO == 1 ? XD_EARLY : 0) | XD_LAST>{});     // (one trip: see below)
     } else {
-        chunk(1, XdInt<1>{}, XdInt<XD_EARLY>{});
+        chunk(1, XdInt<1>{}, XdInt<(XD_EARLY_HALO == 1 ? XD_EARLY : 0)>{});
 #ifdef XD_CHUNK_CLOCKS
         xd_c_k1 = __builtin_readcyclecounter();
 #endif
