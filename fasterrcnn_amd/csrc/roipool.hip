@@ -245,7 +245,11 @@ void roi_pool_x3t_kernel(const float* __restrict__ fm, int fh, int fw, int C, co
 // (RoI, bin) with its 64 lanes on 8 consecutive channels each (one 2 KB cell = one fully coalesced load), eight RoIs per wave, the pooled
 // and scaled values of the block's 32 RoIs go through LDS ([32][C + 4] floats), and the four waves then write whole 1 KB pieces.  Same maxima,
 // same scale, same split: the same bits.  C <= 512 per pass (64 lanes x 8 channels); wider maps loop.
-__global__ __launch_bounds__(256)
+#ifndef FRCNN_ROI_ROWS_WAVES
+#define FRCNN_ROI_ROWS_WAVES 8      // measured (one image at a time): 4 waves 34.9 us, 8 waves 28.6 us, 16 waves 28.5 us; the lane-per-RoI kernel 47
+#endif
+template <int NW>
+__global__ __launch_bounds__(64 * NW)
 void roi_pool_x3t_rows_kernel(const float* __restrict__ fm, int fh, int fw, int C, const float* __restrict__ rois,
                               const int32_t* __restrict__ n_rois, int max_rois, int pooled, float scale, const float* __restrict__ inv,
                               unsigned char* __restrict__ rec, int rbt)
@@ -257,8 +261,8 @@ void roi_pool_x3t_rows_kernel(const float* __restrict__ fm, int fh, int fw, int 
     const int LD = C + 4;
     int n = *n_rois;
     if (n > max_rois) n = max_rois;
-    for (int q = 0; q < 8; ++q) {
-        const int rl = wave * 8 + q, r = rb * 32 + rl;                       // (wave-uniform)
+    for (int q = 0; q < 32 / NW; ++q) {                                      // (NW waves, 32 / NW RoIs each: the more waves, the more loads in flight per CU)
+        const int rl = wave * (32 / NW) + q, r = rb * 32 + rl;                       // (wave-uniform)
         int hs = 0, he = 0, ws = 0, we = 0;
         float mult = 0.f;
         if (r < n) {
@@ -281,13 +285,29 @@ void roi_pool_x3t_rows_kernel(const float* __restrict__ fm, int fh, int fw, int 
             if (any) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) m[e] = -FLT_MAX;
-                for (int h = hs; h < he; ++h) {
-                    const float* p = fm + ((size_t)h * fw + ws) * C + c0;
-                    for (int w = ws; w < we; ++w, p += C) {
-                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+                // the window as ONE run of cells, four loads in flight (the pooling was bound by the ONE load a wave kept in flight: 5.8 TB/s
+                // of the L2s' ~34); past the end the last cell is read again (a maximum does not mind)
+                const int ww = we - ws, ncell = (he - hs) * ww;
+                const float rww = __builtin_amdgcn_rcpf((float)ww);
+                constexpr int UN = 4;
+                for (int i0 = 0; i0 < ncell; i0 += UN) {
+                    f32x4 v[UN][2];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { m[e] = v0[e] > m[e] ? v0[e] : m[e]; m[4 + e] = v1[e] > m[4 + e] ? v1[e] : m[4 + e]; }
+                    for (int u = 0; u < UN; ++u) {
+                        const int i = min(i0 + u, ncell - 1);
+                        int dh = (int)((float)i * rww);                        // i / ww (ww <= fw: exact after one correction)
+                        int dw = i - dh * ww;
+                        if (dw < 0) { --dh; dw += ww; } else if (dw >= ww) { ++dh; dw -= ww; }
+                        const float* p = fm + ((size_t)(hs + dh) * fw + ws + dw) * C + c0;
+                        v[u][0] = *reinterpret_cast<const f32x4*>(p); v[u][1] = *reinterpret_cast<const f32x4*>(p + 4);
                     }
+#pragma unroll
+                    for (int u = 0; u < UN; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {                       // (one v_max_f32 per value: `v > m ? v : m` is a compare and a select; finite inputs: the same value)
+                            asm("v_max_f32 %0, %1, %2" : "=v"(m[e]) : "v"(v[u][0][e]), "v"(m[e]));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(m[4 + e]) : "v"(v[u][1][e]), "v"(m[4 + e]));
+                        }
                 }
             }
             if (r < n) {
@@ -300,9 +320,9 @@ void roi_pool_x3t_rows_kernel(const float* __restrict__ fm, int fh, int fw, int 
         }
     }
     __syncthreads();
-    // pieces: wave w writes the chunks w, w + 4, ...; lane = (row lane & 31, k-half lane >> 5) as in the record layout
+    // pieces: wave w writes the chunks w, w + 8, ...; lane = (row lane & 31, k-half lane >> 5) as in the record layout
     const int K16c = C >> 4;
-    for (int cc = wave; cc < K16c; cc += 4) {
+    for (int cc = wave; cc < K16c; cc += NW) {
         const float* sp = rp_pool + (lane & 31) * LD + cc * 16 + 8 * (lane >> 5);
         const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
         const float m[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -312,6 +332,102 @@ void roi_pool_x3t_rows_kernel(const float* __restrict__ fm, int fh, int fw, int 
         unsigned char* dst = rec + ((size_t)chunk * rbt + rb) * HX_RB + lane * 16;
         *reinterpret_cast<uint4*>(dst) = phh;
         *reinterpret_cast<uint4*>(dst + HX_PIECE) = pll;
+    }
+}
+
+// Round 6, second form: a WAVE per (RoI, bin ROW ph) pools the seven bins of that row in one sweep over the row's cells -- every cell of the
+// band is loaded ONCE (64 lanes x 8 channels = one coalesced 2 KB load) and folded into the one or two bins whose column range holds it
+// (adjacent bins overlap by the floor / ceil of their edges: a sweep per bin, the kernels above, reads the workload's proposals' cells 1.45x
+// as often: 257 MB per image against 177 MB, tools/exp_roi_cells.py; the pooling runs at the L2s' bandwidth).  The column ranges are
+// wave-uniform (scalar compares, uniform branches).  No LDS: a lane writes its 8 channels of a bin as one 16-byte hi and one 16-byte lo
+// store into the record pieces.  Same maxima, scale and split: the same bits.  pooled <= 8, C % 8 == 0; C > 512 loops.
+template <int P>
+__global__ __launch_bounds__(256)
+void roi_pool_x3t_bands_kernel(const float* __restrict__ fm, int fh, int fw, int C, const float* __restrict__ rois,
+                               const int32_t* __restrict__ n_rois, int max_rois, float scale, const float* __restrict__ inv,
+                               unsigned char* __restrict__ rec, int rbt)
+{
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+    if (wid >= rbt * 32 * P) return;
+    const int ph = wid % P, r = wid / P;
+    int n = *n_rois;
+    if (n > max_rois) n = max_rois;
+    int hs = 0, he = 0, ws[P], we[P], wlo = 0, whi = 0;
+    float mult = 0.f;
+#pragma unroll
+    for (int q = 0; q < P; ++q) { ws[q] = 0; we[q] = 0; }
+    if (r < n) {
+        const f32x4 roi = reinterpret_cast<const f32x4*>(rois)[r];     // y1, x1, y2, x2 (uniform address: every lane reads the same box)
+        const int rs_h = (int)roundf(roi[0] * scale), rs_w = (int)roundf(roi[1] * scale);
+        const int re_h = (int)roundf(roi[2] * scale), re_w = (int)roundf(roi[3] * scale);
+        const int roi_h = max(re_h - rs_h + 1, 1), roi_w = max(re_w - rs_w + 1, 1);
+        const float bin_h = (float)roi_h / (float)P, bin_w = (float)roi_w / (float)P;
+        hs = (int)floorf((float)ph * bin_h) + rs_h;
+        he = (int)ceilf((float)(ph + 1) * bin_h) + rs_h;
+        hs = min(max(hs, 0), fh); he = min(max(he, 0), fh);
+        wlo = fw; whi = 0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            int a = (int)floorf((float)q * bin_w) + rs_w;
+            int b = (int)ceilf((float)(q + 1) * bin_w) + rs_w;
+            a = min(max(a, 0), fw); b = min(max(b, 0), fw);
+            ws[q] = __builtin_amdgcn_readfirstlane(a); we[q] = __builtin_amdgcn_readfirstlane(b);
+            wlo = min(wlo, ws[q]); whi = max(whi, we[q]);
+        }
+        hs = __builtin_amdgcn_readfirstlane(hs); he = __builtin_amdgcn_readfirstlane(he);
+        wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
+        mult = hx_mult_of_inv(inv[r]);
+    }
+    const int K16c = C >> 4, rb = r >> 5, row = r & 31;
+    for (int c0 = 8 * lane; c0 < C; c0 += 512) {
+        float acc[P][8];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const float init = (r < n && he > hs && we[q] > ws[q]) ? -FLT_MAX : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[q][e] = init;
+        }
+        for (int h = hs; h < he; ++h) {
+            const float* prow = fm + ((size_t)h * fw) * C + c0;
+            for (int w0 = wlo; w0 < whi; w0 += 4) {
+                // four cells in flight (the tail re-reads the band's last cell: it is folded twice, a maximum does not mind)
+                f32x4 v[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int w = min(w0 + u, whi - 1);
+                    const float* p = prow + (size_t)w * C;
+                    v[u][0] = *reinterpret_cast<const f32x4*>(p); v[u][1] = *reinterpret_cast<const f32x4*>(p + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int w = min(w0 + u, whi - 1);
+#pragma unroll
+                    for (int q = 0; q < P; ++q) {
+                        if (w >= ws[q] && w < we[q]) {                      // (wave-uniform)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                acc[q][e] = v[u][0][e] > acc[q][e] ? v[u][0][e] : acc[q][e];
+                                acc[q][4 + e] = v[u][1][e] > acc[q][4 + e] ? v[u][1][e] : acc[q][4 + e];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const int cc = c0 >> 4, kh = (c0 >> 3) & 1;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            float m[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = r < n ? acc[q][e] * mult : 0.f;
+            uint4 phh, pll;
+            hx_split8(m, phh, pll);
+            const int chunk = (ph * P + q) * K16c + cc;                     // k = (ph * pooled + pw) * C + c
+            unsigned char* dst = rec + ((size_t)chunk * rbt + rb) * HX_RB + kh * 512 + row * 16;
+            *reinterpret_cast<uint4*>(dst) = phh;
+            *reinterpret_cast<uint4*>(dst + HX_PIECE) = pll;
+        }
     }
 }
 
@@ -379,12 +495,24 @@ int launch_roi_pool_x3t(const float* fm, int fh, int fw, int c, const float* roi
     hipLaunchKernelGGL(roi_scale_x3t_kernel, dim3(cdiv(rec_rows, 4)), dim3(256), 0, s, cmax, fh, fw, rois, n_rois, max_rois, rec_rows, pooled, scale, inv);
     if ((rc = check_launch()) != FRCNN_OK) return rc;
     const int rbt = rec_rows / 32;
+#ifdef FRCNN_ROI_BANDS
+    if (pooled == 7 && c % 8 == 0) {
+        // a wave per (RoI, bin row): every cell of the band read once (round 6, second form; the same bits as the kernels below).  MEASURED
+        // 68.7 us against the rows kernel's 44-46: the pooling is not bound by the bytes it reads (5.8 TB/s of the L2s' ~34) but by the loads
+        // it keeps in flight and by its compare-and-select work; not the shipped path
+        const long long waves = (long long)rec_rows * pooled;
+        hipLaunchKernelGGL(roi_pool_x3t_bands_kernel<7>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, fm, fh, fw, c, rois, n_rois, max_rois, scale,
+                           inv, static_cast<unsigned char*>(rec), rbt);
+        return check_launch();
+    }
+#endif
     const size_t lds = (size_t)32 * (c + 4) * sizeof(float);
     if (c % 8 == 0 && lds <= 160 * 1024) {
         // a block per (bin, 32 RoIs): coalesced cell reads, whole-piece writes (round 6; the same bits as the kernel below)
-        auto kern = roi_pool_x3t_rows_kernel;
+        constexpr int NW = FRCNN_ROI_ROWS_WAVES;
+        auto kern = roi_pool_x3t_rows_kernel<NW>;
         FRCNN_MAX_LDS_ONCE(kern, 160 * 1024);                           // (once per device: the largest size any c may ask for)
-        hipLaunchKernelGGL(kern, dim3((unsigned)(pooled * pooled * rbt)), dim3(256), lds, s, fm, fh, fw, c, rois, n_rois, max_rois, pooled, scale,
+        hipLaunchKernelGGL(kern, dim3((unsigned)(pooled * pooled * rbt)), dim3(64 * NW), lds, s, fm, fh, fw, c, rois, n_rois, max_rois, pooled, scale,
                            inv, static_cast<unsigned char*>(rec), rbt);
         return check_launch();
     }
