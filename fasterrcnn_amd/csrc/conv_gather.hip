@@ -1025,42 +1025,63 @@ void gather_splitk_finish_kernel(const float* __restrict__ ws, int splits, const
 // Stem: 7x7 stride-2 pad-3 convolution of the NCHW image (Cin = 3) with the folded bn1 and ReLU
 // (models/resnet.py:39-41 = torchvision resnet.conv1/bn1/relu).  K = 147: VALU kernel, thread =
 // output pixel x 16 channels, weights [147][cout] via scalar loads.
+// Round 6: a thread computes PX horizontally adjacent output pixels (their 7-wide windows at stride 2 share input columns, and a
+// tap's 16 weights -- one scalar load -- serve 16 PX fused multiply-adds instead of 16).  The fmaf order over k = (ci, r, s) per output is unchanged: same bits.
+#ifndef FRCNN_STEM_PX
+#define FRCNN_STEM_PX 2
+#endif
+template <int PX>
 __global__ __launch_bounds__(256)
 void conv7x7_s2_c3_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                           float* __restrict__ y, int H, int W, int Ho, int Wo, int Cout, int relu)
 {
-    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int WoP = (Wo + PX - 1) / PX;
+    const int pp = blockIdx.x * 256 + threadIdx.x;
     const int og = blockIdx.y;
-    if (pix >= Ho * Wo) return;
-    const int oy = pix / Wo, ox = pix - oy * Wo;
-    float acc[16];
+    if (pp >= Ho * WoP) return;
+    const int oy = pp / WoP, ox = (pp - oy * WoP) * PX;
+    float acc[PX][16];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    for (int px = 0; px < PX; ++px)
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[px][o] = 0.f;
     const float* wg = wp + og * 16;
     for (int ci = 0; ci < 3; ++ci) {
         for (int r = 0; r < 7; ++r) {
             const int iy = oy * 2 - 3 + r;
             const bool yin = iy >= 0 && iy < H;
+            float v[2 * PX + 5];                                            // input columns 2 ox - 3 .. 2 ox + 2 PX + 1
+#pragma unroll
+            for (int q = 0; q < 2 * PX + 5; ++q) {
+                const int ix = ox * 2 - 3 + q;
+                v[q] = (yin && ix >= 0 && ix < W) ? x[((size_t)ci * H + iy) * W + ix] : 0.f;
+            }
 #pragma unroll
             for (int s = 0; s < 7; ++s) {
-                const int ix = ox * 2 - 3 + s;
-                const float v = (yin && ix >= 0 && ix < W) ? x[((size_t)ci * H + iy) * W + ix] : 0.f;
                 const float* wk = wg + (size_t)((ci * 7 + r) * 7 + s) * Cout;
 #pragma unroll
-                for (int o = 0; o < 16; ++o) acc[o] = fmaf(v, wk[o], acc[o]);
+                for (int o = 0; o < 16; ++o) {
+                    const float wv = wk[o];
+#pragma unroll
+                    for (int px = 0; px < PX; ++px) acc[px][o] = fmaf(v[s + 2 * px], wv, acc[px][o]);
+                }
             }
         }
     }
-    float* out = y + (size_t)pix * Cout + og * 16;
 #pragma unroll
-    for (int o4 = 0; o4 < 4; ++o4) {
-        f32x4 v;
+    for (int px = 0; px < PX; ++px) {
+        if (ox + px >= Wo) break;
+        float* out = y + (size_t)(oy * Wo + ox + px) * Cout + og * 16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float t = acc[o4 * 4 + j] + bias[og * 16 + o4 * 4 + j];
-            v[j] = relu ? fmaxf(t, 0.f) : t;
+        for (int o4 = 0; o4 < 4; ++o4) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = acc[px][o4 * 4 + j] + bias[og * 16 + o4 * 4 + j];
+                v[j] = relu ? fmaxf(t, 0.f) : t;
+            }
+            *reinterpret_cast<f32x4*>(out + 4 * o4) = v;
         }
-        *reinterpret_cast<f32x4*>(out + 4 * o4) = v;
     }
 }
 
@@ -1440,8 +1461,8 @@ int launch_conv7x7_s2_c3(const float* x, const float* wp, const float* b, float*
 {
     if (cout % 16 != 0 || H < 1 || W < 1) return FRCNN_EINVAL;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-    dim3 grid(cdiv(Ho * Wo, 256), cout / 16);
-    hipLaunchKernelGGL(conv7x7_s2_c3_kernel, grid, dim3(256), 0, s, x, wp, b, y, H, W, Ho, Wo, cout,
+    dim3 grid(cdiv(Ho * cdiv(Wo, FRCNN_STEM_PX), 256), cout / 16);          // (FRCNN_STEM_PX output pixels of a row per thread)
+    hipLaunchKernelGGL(conv7x7_s2_c3_kernel<FRCNN_STEM_PX>, grid, dim3(256), 0, s, x, wp, b, y, H, W, Ho, Wo, cout,
                        (flags & FRCNN_RELU) ? 1 : 0);
     return check_launch();
 }
