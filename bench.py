@@ -8,7 +8,7 @@ bench.py -- images/sec of Faster R-CNN VGG-16 inference (600x1000, 300 proposals
 A "step" is one `predict()` of one synthetic, already-preprocessed float32 3x600x1000 image that is
 resident in HBM when the timed region starts: VGG-16 backbone, RPN (6000 pre- / 300 post-NMS),
 RoI pooling, FC head, on-device float64 decode + per-class NMS, one D2H copy of the detections.
-Every image is an independent batch-1 forward (BASELINE.json configs[1]); `--inflight` of them (default 3)
+Every image is an independent batch-1 forward (BASELINE.json configs[1]); `--inflight` of them (default 4)
 are in flight on separate HIP streams (GPU_MAX_HW_QUEUES=16 unless the environment says otherwise).  float32 tensors end to end (the
 reference's dtype).  WHICH matrix instructions every GEMM-shaped layer runs on is part of the JSON line (`dtype`, `layer_arithmetic`,
 `fc_math`, `winograd_x6_layers`, `winograd_x3_layers`, `f32_pipe_tflops` / `bf16_pipe_tflops` / `f16_pipe_tflops`): the 3x3 convolutions
@@ -670,10 +670,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--inflight", type=int, default=3,
-                    help="images in flight per GPU (separate HIP streams).  Round 2: the one-launch Winograd layers fill the chip with two "
-                         "long-running blocks per CU, so three images (one in its serial proposal / detection tail, two convolving) "
-                         "are enough -- measured 473-476 img/s at 3, 463-467 at 6-12, 455-460 at 24 (round 1's default)")
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="images in flight per GPU (separate HIP streams).  Every VGG-16 layer fills the chip from one image, so the images in "
+                         "flight only have to cover each other's serial proposal / detection tails; round 6, same box: 3 / 4 / 5 in flight = "
+                         "922-925 / 933-936 / 827-839 images/sec in bursts of 20 (7 + 7 + 6 against 5 + 5 + 5 + 5 images per slot) and "
+                         "959 / 972 / 856 in steady state (profiles/r06/exp_inflight_driver.txt)")
+    ap.add_argument("--hip-graphs", action="store_true",
+                    help="replay one captured hipGraph per in-flight slot instead of ~39 eager launches per image (FasterRCNNModel.use_hip_graphs)")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic images resident per GPU")
     ap.add_argument("--map-images", type=int, default=8, help="labelled images per rank for the mAP@0.5 leg")
     ap.add_argument("--cpu-images", type=int, default=12, help="images timed on the host CPU (rank 0, N=1 only): ~12 s of CPU work")
@@ -732,6 +735,8 @@ def main():
     if args.math is None:
         args.math = model.math_mode                 # the model's default: f32_winograd (VGG-16) / f32 (ResNet)
     model.math_mode = args.math
+    if args.hip_graphs:
+        model.use_hip_graphs = True
     make_image = synthetic.image_rgb if is_resnet else synthetic.image
 
     # synthetic image pool, resident in HBM before timing; per-image seed = global index

@@ -159,19 +159,30 @@ def evaluate_stream(model, samples, score_threshold=0.05, inflight=4, rank=0, wo
     return records
 
 
+def default_inflight(model):
+    """
+    Images in flight per GPU that measured best (profiles/r06/exp_inflight_driver.txt, inflight_sweep.txt): VGG-16's layers fill the chip
+    from one image, so 4 images -- one per default HIP hardware queue, 20-image bursts split 5 + 5 + 5 + 5 -- are enough to cover the serial
+    proposal / detection tails (3: -1 %, 5-6: -6 ... -12 %); ResNet-50's launches are short and many: 8.
+    """
+    return 8 if getattr(model, "_is_resnet", False) else 4
+
+
 def evaluate(model, eval_data, num_samples=None, print_average_precisions=False, class_index_to_name=None,
-             inflight=8, score_threshold=0.05, force_gather=False):
+             inflight=None, score_threshold=0.05, force_gather=False):
     """
     The reference's evaluate() (pytorch/FasterRCNN/__main__.py:62-96): `model.predict(score_threshold=0.05)` per
     sample of `eval_data`, `PrecisionRecallCurveCalculator.add_image_results`, returns 100 x mAP.
     `eval_data` iterates samples that carry `.image_data` (numpy or tensor (3, H, W), preprocessed) and `.gt_boxes`
     (the reference's TrainingSample); the dataset itself (voc.Dataset) stays the caller's.  Images are uploaded and
-    predicted `inflight` at a time; under an initialised process group each rank takes every world-th sample and the
+    predicted `inflight` at a time (None = default_inflight(model)); under an initialised process group each rank takes every world-th sample and the
     records are merged with one all-gather (merged_calculator), so every rank returns the same value.
     """
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     device = model._device()
+    if inflight is None:
+        inflight = default_inflight(model)
 
     def stream():
         for i, sample in enumerate(eval_data):
