@@ -1460,9 +1460,11 @@ int run_conv1x1_x3(frcnn_ctx* c, const float* x, const void* wblob, const float*
     int rc;
     {
         Scope _t(c, 8, s);
-        rc = launch_pixel_absmax(x, cmax, (long long)N * h * w, cin, s);
+        // (1x1: one launch that reduces the row maxima itself; the 3x3 patches take their scale from nine pixels' maxima: two launches)
+        static const bool two_pass = frcnn_knob("FRCNN_SPLIT_TWO_PASS") != nullptr;      // experiments / the bit-identity test
+        rc = (ksize == 3 || two_pass) ? launch_pixel_absmax(x, cmax, (long long)N * h * w, cin, s) : FRCNN_OK;
         if (!rc) rc = ksize == 3 ? launch_split_patches3x3_x3t(x, cmax, c->rx_rec, ainv, N, h, w, cin, stride, Mp, s)
-                                 : launch_split_pixels_x3t(x, cmax, c->rx_rec, ainv, N, h, w, cin, stride, Mp, s);
+                                 : launch_split_pixels_x3t(x, two_pass ? cmax : nullptr, c->rx_rec, ainv, N, h, w, cin, stride, Mp, s);
     }
     if (rc) return rc;
     const float* winv = reinterpret_cast<const float*>(static_cast<const unsigned char*>(wblob) + x3t_record_bytes(Np, K));

@@ -118,6 +118,72 @@ void split_pixels_x3t_kernel(const float* __restrict__ x, const float* __restric
     *reinterpret_cast<uint4*>(dst + HX_PIECE) = pl;
 }
 
+// The same records WITHOUT the channel-maximum pass in front of it (round 6: the per-RoI head of the ResNets ran pixel_absmax_kernel +
+// split_pixels_x3t_kernel per 1x1 convolution: 7 + 7 launches of an image, the tensor read twice from two launches).  One block = one
+// row block of 32 output pixels: its four waves first reduce max_c |x| of eight rows each (coalesced 1 KB reads per row, the eight rows'
+// loads independent), then write the block's K16 chunks as split_pixels_x3t_kernel does, the rows now coming from the caches.  max is
+// exact, so the scales -- and with them every record byte and inv[] -- are the two-launch form's.
+__global__ __launch_bounds__(256)
+void split_pixels_x3t_max_kernel(const float* __restrict__ x, unsigned char* __restrict__ rec, float* __restrict__ inv_out, int H, int W, int Ho,
+                                 int Wo, int C, int stride, int R, int rbt, int K16)
+{
+    __shared__ float smax[32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rb = blockIdx.x;
+    auto pixel_of = [&](int row) -> size_t {
+        const int n = row / (Ho * Wo), rem = row - n * (Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        return ((size_t)n * H + (size_t)oy * stride) * W + (size_t)ox * stride;
+    };
+    {
+        const float* src[8];
+        float mx[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = rb * 32 + wave * 8 + r;
+            src[r] = row < R ? x + pixel_of(row) * C : nullptr;
+            mx[r] = 0.f;
+        }
+        for (int c = 4 * lane; c < C; c += 256) {
+            f32x4 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = src[r] ? *reinterpret_cast<const f32x4*>(src[r] + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                mx[r] = fmaxf(fmaxf(mx[r], fmaxf(fabsf(v[r][0]), fabsf(v[r][1]))), fmaxf(fabsf(v[r][2]), fabsf(v[r][3])));
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float m = mx[r];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+            if (lane == 0) smax[wave * 8 + r] = m;
+        }
+    }
+    __syncthreads();
+    const int row = rb * 32 + (lane & 31);
+    float mult = 1.f, inv = 1.f;
+    const float* src = nullptr;
+    if (row < R) {
+        hx_row_scale(smax[lane & 31], mult, inv);
+        src = x + pixel_of(row) * C + 8 * (lane >> 5);
+    }
+    if (wave == 0 && lane < 32) inv_out[row] = inv;
+    for (int chunk = wave; chunk < K16; chunk += 4) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (src) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + chunk * 16), v1 = *reinterpret_cast<const f32x4*>(src + chunk * 16 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = v0[j] * mult; v[4 + j] = v1[j] * mult; }
+        }
+        uint4 ph, pl;
+        hx_split8(v, ph, pl);
+        unsigned char* dst = rec + ((size_t)chunk * rbt + rb) * HX_RB + lane * 16;
+        *reinterpret_cast<uint4*>(dst) = ph;
+        *reinterpret_cast<uint4*>(dst + HX_PIECE) = pl;
+    }
+}
+
 // im2col + split for a 3x3 convolution with padding 1 and stride 1 / 2 (split_patches3x3_x6t_kernel's rows and columns); a row's scale
 // comes from the largest channel maximum among its (up to nine) patch pixels.
 __global__ __launch_bounds__(256)
@@ -422,14 +488,19 @@ int launch_split_rows_x3t(const float* a, int lda, size_t a_batch_floats, const 
     return check_launch();
 }
 
-// cmax: N * H * W floats (launch_pixel_absmax of x); inv: rows_padded floats out
+// cmax: N * H * W floats (launch_pixel_absmax of x) or NULL (the kernel reduces the maxima of the rows it needs itself); inv: rows_padded floats out
 int launch_split_pixels_x3t(const float* x, const float* cmax, void* rec, float* inv, int N, int H, int W, int C, int stride, int rows_padded,
                             hipStream_t s)
 {
-    if (N < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || stride < 1 || stride > 2 || rows_padded % 32 != 0 || !cmax || !inv) return FRCNN_EINVAL;
+    if (N < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || stride < 1 || stride > 2 || rows_padded % 32 != 0 || !inv) return FRCNN_EINVAL;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const long long R = (long long)N * Ho * Wo;
     if (R > rows_padded || R > 0x7fffffffLL) return FRCNN_EINVAL;
+    if (!cmax) {                                                   // no maxima given: the one-launch form finds them itself (same bits)
+        hipLaunchKernelGGL(split_pixels_x3t_max_kernel, dim3((unsigned)(rows_padded / 32)), dim3(256), 0, s, x, static_cast<unsigned char*>(rec), inv, H, W,
+                           Ho, Wo, C, stride, (int)R, rows_padded / 32, C / 16);
+        return check_launch();
+    }
     const long long waves = (long long)(C / 16) * (rows_padded / 32);
     hipLaunchKernelGGL(split_pixels_x3t_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, cmax, static_cast<unsigned char*>(rec),
                        inv, H, W, Ho, Wo, C, stride, (int)R, rows_padded / 32, C / 16);

@@ -255,7 +255,8 @@ int frcnn_gemm_x6t(const void* d_a_rec, int a_rows, size_t a_batch_bytes, const 
 /* A-side producers for convolutions as f32x3 GEMMs (the f32x3 counterparts of frcnn_split_pixels_x6t / frcnn_split_patches3x3_x6t): the row
  * of an output pixel is scaled by the power of two that the channel maxima of its input pixel(s) give.
  *   frcnn_pixel_absmax           : x [pixels][c] -> d_cmax [pixels] = max_c |x|
- *   frcnn_split_pixels_x3t       : 1x1 convolution, stride 1 / 2: records + d_inv_scale [rows_padded]
+ *   frcnn_split_pixels_x3t       : 1x1 convolution, stride 1 / 2: records + d_inv_scale [rows_padded]; d_cmax = NULL: the launch reduces the
+ *                                  channel maxima of the rows it needs itself (one launch instead of two, the same bytes)
  *   frcnn_split_patches3x3_x3t   : 3x3 / padding 1, stride 1 / 2 (im2col rows, K = 9 c) */
 int frcnn_pixel_absmax(const float* d_x, float* d_cmax, long long pixels, int c, void* stream);
 int frcnn_split_pixels_x3t(const float* d_x, const float* d_cmax, void* d_rec, float* d_inv_scale, int n_maps, int H, int W, int c, int stride,

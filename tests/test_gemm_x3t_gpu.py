@@ -87,6 +87,40 @@ def test_x3t_split_scales_and_layout():
     assert inv[1, 5] == 1.0 and (hi[1, 5] == 0).all()
 
 
+@pytest.mark.parametrize("n,h,w,c,stride", [
+    (3, 7, 7, 1024, 1),       # block0.conv1 of the per-RoI layer4 (147 rows: a ragged last row block)
+    (5, 7, 7, 1024, 2),       # its downsample: rows = every other pixel
+    (2, 4, 4, 2048, 1),       # a 2048-channel input (eight 1 KB reads per row)
+    (1, 9, 13, 16, 1), (1, 5, 6, 272, 2),      # one chunk; a channel count that is no multiple of 256
+])
+def test_split_pixels_x3t_one_launch_form_is_the_two_launch_form_bit_for_bit(n, h, w, c, stride):
+    """frcnn_split_pixels_x3t with d_cmax = NULL (split_pixels_x3t_max_kernel: the row maxima reduced in the same launch -- the per-RoI
+    head's 1x1 convolutions, models/resnet.py:94-118) writes the records and scales of frcnn_pixel_absmax + frcnn_split_pixels_x3t."""
+    lib = nv.lib()
+    g = torch.Generator().manual_seed(n * 1000 + c + stride)
+    x = torch.randn((n, h, w, c), generator=g) * torch.exp2(torch.randint(-20, 20, (n, h, w, 1), generator=g).float())
+    x[0, 0, 0] = 0.0                                                           # a zero row: scale 1
+    x = x.cuda().contiguous()
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    rows = n * ho * wo
+    rp = pad_to(rows, 32)
+    per = int(lib.frcnn_x3t_record_bytes(rp, c))
+    out = []
+    for fused in (False, True):
+        rec = torch.full((per,), 0x5B, dtype=torch.int8, device="cuda")
+        inv = torch.full((rp,), float("nan"), device="cuda")
+        cmax = torch.empty((n * h * w,), device="cuda")
+        if not fused:
+            nv.check(lib.frcnn_pixel_absmax(nv.ptr(x), nv.ptr(cmax), n * h * w, c, nv.stream_ptr()), "pixel_absmax")
+        nv.check(lib.frcnn_split_pixels_x3t(nv.ptr(x), None if fused else nv.ptr(cmax), nv.ptr(rec), nv.ptr(inv), n, h, w, c, stride, rp,
+                                            nv.stream_ptr()), "split_pixels_x3t")
+        torch.cuda.synchronize()
+        out.append((rec.cpu().numpy(), inv.cpu().numpy()))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.isfinite(out[1][1]).all()
+
+
 @pytest.mark.parametrize("M,N,K,batches,relu", [
     (2394, 512, 512, 16, False),     # the position GEMMs of conv4_2 / conv4_3
     (589, 512, 512, 16, False),      # conv5_x / RPN trunk
