@@ -125,8 +125,10 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_xf[];
     float* const hbuf0 = reinterpret_cast<float*>(smem_xf);
 
+#ifndef XD_PERSIST
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
     const int K16 = Cin >> 4;
 
 #ifdef XD_PERSIST
@@ -137,6 +139,19 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // spilled registers, reloaded per item) and the row pass spills -- even a launch whose blocks walk ONE item each is 19 % slower.  Not built
     // further (the prefetch of the next item's filter pieces between the epilogue's instructions, DESIGN.md section 7, needs this form).
     for (int item = blockIdx.x; item < gm.n_items; item += gridDim.x) {
+    // (XD_PERSIST=2, second half of round 6: the thread index laundered per item, so that no lane constant derived from it is loop-invariant to
+    //  the compiler: 53-60 spilled registers -> 4-12, all of them outside the chunk loop; bit-identical (40 x3 tests).  MEASURED, same box
+    //  (profiles/r06/ab_persist2.txt): layers 117 / 64 / 89 / 54 / 92 / 89 / 55 / 96.5 / 95.5 / 42 us -> 119 / 66 / 91 / 56.5 / 96 / 92.5 / 58 / 100.5 / 99 / 45,
+    //  947-951 -> 919-924 images/sec in the driver's form: the 0.45 us dispatch gap a persistent block saves per item is what the item loop costs
+    //  it (scalar registers of the kernel arguments spilled to lanes, the barrier behind the row pass, a static item order that no longer
+    //  follows the CUs' finishing order) -- conv5_x, ONE item per block, is 7 % slower.  Only the prefetch of the next item's filter pieces
+    //  under the epilogue (~1 us of a block) could pay for that, and by this measurement it would about break even: not built.)
+    int tid_l = threadIdx.x;
+#if XD_PERSIST >= 2
+    asm volatile("" : "+v"(tid_l));
+#endif
+    const int tid = tid_l, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 #else
     {
     const int item = blockIdx.x;
@@ -462,7 +477,8 @@ void wino_x3d_kernel(const float* __restrict__ x_maps, const float* __restrict__
     // (XD_ABLATE 32, timing experiment: what the block pays for the prologue's loads -- no filter pieces, no halo)
     if (!(XD_ABLATE & 32)) dma_halo(hcur, 0, XdInt<0>{}, XdInt<XD_NDMA>{}, xrs);
     __builtin_amdgcn_global_load_lds(uinv0, (xd_lds_ptr)(smem_xf + XD_SC_OFFSET + wave_u * 1024), 16, 0, 0);
-    if (wave_u == 0 && lane < 16) __builtin_amdgcn_global_load_lds(bias + 64 * cb + 4 * lane, (xd_lds_ptr)(smem_xf + XD_SC_OFFSET + 4096), 16, 0, 0);
+    const xd_lds_ptr bias_lds = (xd_lds_ptr)(smem_xf + XD_SC_OFFSET + 4096);   // (the cast outside the divergent branch)
+    if (wave_u == 0 && lane < 16) __builtin_amdgcn_global_load_lds(bias + 64 * cb + 4 * lane, bias_lds, 16, 0, 0);
     XD_FENCE();
     if (!(XD_ABLATE & 32)) { load_u(0, XdInt<0>{}, XdInt<1>{}); load_u(0, XdInt<0>{}, XdInt<2>{}); load_u(0, XdInt<0>{}, XdInt<3>{}); }
     XD_FENCE();
