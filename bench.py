@@ -946,29 +946,33 @@ def main():
         run_single(5)
         dt, _ = timed_median(run_single, args.steps, min(args.min_timed_seconds, 0.5))
         extra["single_stream_images_per_sec"] = round(args.steps / dt, 3)
-        # (2) configs[2]: ResNet-50 backbone, 8 independent batch-1 images in flight (the reference asserts batch 1)
+        # (2) configs[2]: ResNet-50 backbone, independent batch-1 images in flight (the reference asserts batch 1)
         from fasterrcnn_amd.models import resnet as _resnet
         m50 = FasterRCNNModel(num_classes=21, backbone=_resnet.ResNetBackbone(_resnet.Architecture.ResNet50))
         m50.load_state_dict(synthetic.resnet_state_dict(1234, "ResNet50"), strict=True)
         m50 = m50.cuda(dev).eval()
         pool50 = [synthetic.image_rgb(s_).unsqueeze(0).to(dev) for s_ in seeds[:8]]
+        # images in flight: one per hardware pipe, on the process's slot streams (runtime.slot_stream: the streams VGG-16's slots used above);
+        # round 6: 4 in flight 702 / 679 images/sec steady / bursts of 20, 8 in flight 693 / 670 (profiles/r06/exp_r50_inflight.txt)
+        from fasterrcnn_amd.evaluate import default_inflight
+        n50 = default_inflight(m50)
 
         def run50(n_steps):
             pend = []
             for i in range(n_steps):
-                if len(pend) == 8:
+                if len(pend) == n50:
                     pend.pop(0).result()
-                pend.append(m50.predict_async(pool50[i % len(pool50)], 0.05, slot=1 + (i % 8)))
+                pend.append(m50.predict_async(pool50[i % len(pool50)], 0.05, slot=1 + (i % n50)))
             while pend:
                 pend.pop(0).result()
         run50(16)
         dt, _ = timed_median(run50, args.steps, min(args.min_timed_seconds, 0.5))
         extra["resnet50_images_per_sec"] = round(args.steps / dt, 3)
-        extra["resnet50_config"] = ("ResNet-50 predict(), 3x600x1000, 8 batch-1 images in flight, math %s, bottleneck_g3=%s (layer1..3: every bottleneck "
+        extra["resnet50_config"] = ("ResNet-50 predict(), 3x600x1000, %d batch-1 images in flight, math %s, bottleneck_g3=%s (layer1..3: every bottleneck "
                                     "convolution in the f32x3 arithmetic under one scale per tensor, conv_gather_x3_kernel, weight packs split at pack time), x6_conv1x1=%s in the %s arithmetic (the "
                                     "convolutions of the per-RoI layer4 as split-operand GEMMs on the fp16 / bf16 matrix instructions), winograd_x6_layers=%s, "
                                     "winograd_x3_layers=%s; every golden proposal / detection reproduced"
-                                    % (m50.math_mode, m50.bottleneck_g3, m50.x6_conv1x1, m50.x6_conv1x1_arith, list(m50.winograd_x6_layers),
+                                    % (n50, m50.math_mode, m50.bottleneck_g3, m50.x6_conv1x1, m50.x6_conv1x1_arith, list(m50.winograd_x6_layers),
                                        list(m50.winograd_x3_layers)))
         d50 = dict(x6_conv1x1=m50.x6_conv1x1, x6_conv1x1_arith=m50.x6_conv1x1_arith, winograd_x6_layers=m50.winograd_x6_layers,
                    winograd_x3_layers=m50.winograd_x3_layers, bottleneck_g3=m50.bottleneck_g3)

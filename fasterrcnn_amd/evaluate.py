@@ -98,7 +98,7 @@ def evaluate_stream(model, samples, score_threshold=0.05, inflight=4, rank=0, wo
     Processes the samples whose position p satisfies p % world == rank, `inflight` at a time, and
     returns this rank's ImageRecords.  `on_result(image_index, dict)` is called per finished image.
     batch > 1 (ResNet backbones): consecutive samples of one shape go through the feature extractor as ONE batch of up to `batch`
-    images (model.predict_batch_async), max(1, inflight // batch) batches in flight; results and their order are per image as before.
+    images (model.predict_batch_async), max(2, inflight // batch) batches in flight; results and their order are per image as before.
     """
     records = ImageRecords()
     pending = []   # (Pending, image_index, gt_boxes)
@@ -115,7 +115,7 @@ def evaluate_stream(model, samples, score_threshold=0.05, inflight=4, rank=0, wo
     if batch > 1 and not getattr(model, "_is_resnet", False):
         batch = 1               # VGG-16's layers fill the chip with one image: its images go in flight one by one
     if batch > 1:
-        nlanes = max(1, int(inflight) // batch)
+        nlanes = max(2, int(inflight) // batch)               # (two batches in flight: the second's feature extractor under the first's per-image tails)
         group, lanes, state = [], [], {"lane": 0}             # lanes[i]: the lane of pending[i]
 
         def flush():
@@ -163,9 +163,10 @@ def default_inflight(model):
     """
     Images in flight per GPU that measured best (profiles/r06/exp_inflight_driver.txt, inflight_sweep.txt): VGG-16's layers fill the chip
     from one image, so 4 images -- one per default HIP hardware queue, 20-image bursts split 5 + 5 + 5 + 5 -- are enough to cover the serial
-    proposal / detection tails (3: -1 %, 5-6: -6 ... -12 %); ResNet-50's launches are short and many: 8.
+    proposal / detection tails (3: -1 %, 5-6: -6 ... -12 %, 8 = two per pipe: -1.5 %).  ResNet-50 measures the same pattern (4: 702, 5-6: 624-651,
+    8: 693 images/sec, exp_r50_inflight.txt): one answer for every backbone.
     """
-    return 8 if getattr(model, "_is_resnet", False) else 4
+    return 4
 
 
 def evaluate(model, eval_data, num_samples=None, print_average_precisions=False, class_index_to_name=None,

@@ -602,7 +602,7 @@ class FasterRCNNModel(nn.Module):
         slot = self._slots.get(key)
         if slot is None or not slot.ctx.fits(h, w, self.max_proposals_post_nms) or slot.num_classes != self._num_classes:
             slot = rt.Slot(device, max(h, 608), max(w, 1008), self.max_proposals_post_nms, self._num_classes,
-                           own_stream=(index != 0))
+                           own_stream=(index != 0), index=index)
             self._slots[key] = slot
         return slot
 

@@ -81,16 +81,46 @@ def _hip_memcpy_dtod(dst, src, nbytes):
     return _hip.hipMemcpy(dst, src, nbytes, 3)   # hipMemcpyDeviceToDevice
 
 
+_slot_streams = {}
+
+
+def _lane_stream_index(lane, image):
+    """The stream of image `image` of batch lane `lane` (predict_batch_async: RPN + per-RoI head + decode per image behind the lane's feature
+    extractor): the in-flight slots' streams 1 .. 4, image i on stream 1 + i % 4, whatever the lane.  Round 6 (tools/exp_r50_lane_streams.py,
+    ResNet-50 as batches of 8, two batches in flight, bursts of 24 / 200 images): a stream per (lane, image) = 16 streams 624-641 / 658-666
+    images/sec, 8 shared streams 612-618 / 644-653, **these four 658-669 / 701-702** (four streams of their own: 677-680 / 703-715, but four more
+    hardware queues of the process): the chip runs four queues side by side, more streams only spread the tails unevenly over them."""
+    return 1 + (int(image) % 4)
+
+
+def slot_stream(device, index):
+    """
+    The HIP stream of in-flight slot `index` on `device`, ONE per process: every model's slot k enqueues on the same stream.  The chip runs
+    four hardware queues side by side and a process has GPU_MAX_HW_QUEUES of them (round 6, profiles/r06/exp_vgg_queues.txt): a second
+    model that made its own streams (bench.py's ResNet-50 legs behind VGG-16's slots and feeder streams) found the queues taken and two of
+    its slots serialised on one (599 against 680 images/sec standalone).  Models that run in turn lose nothing by sharing; two models in
+    flight AT ONCE on the same slot index run one behind the other -- give them different slot indices.
+    """
+    if isinstance(index, tuple) and len(index) == 3 and index[0] == "lane":
+        index = _lane_stream_index(index[1], index[2])
+    key = (str(t.device(device)), index)
+    st = _slot_streams.get(key)
+    if st is None:
+        st = t.cuda.Stream(device=t.device(device))
+        _slot_streams[key] = st
+    return st
+
+
 class Slot:
     """
     Everything one in-flight image needs: a Context, a stream, device output buffers for
     forward()/predict() and pinned host buffers for the (single) D2H copy of the detections.
     """
-    def __init__(self, device, max_h, max_w, max_rois, num_classes, own_stream):
+    def __init__(self, device, max_h, max_w, max_rois, num_classes, own_stream, index=None):
         self.device = t.device(device)
         self.ctx = Context(device, max_h, max_w, max_rois)
         self.max_rois, self.num_classes = int(max_rois), int(num_classes)
-        self.stream = t.cuda.Stream(device=self.device) if own_stream else None
+        self.stream = (slot_stream(self.device, index) if index is not None else t.cuda.Stream(device=self.device)) if own_stream else None
         nfg = num_classes - 1
         d = self.device
         self.props = t.zeros((max_rois, 4), dtype=t.float32, device=d)

@@ -327,6 +327,13 @@ def test_anchor_maps_argument_and_async_slots(gpu_model):
         p = gpu_model.predict_async(imgs[0], 0.05, slot=1)
         gpu_model.predict_async(imgs[1], 0.05, slot=1)       # slot busy until collected
     p.result()
+    # in-flight slot k enqueues on the process's stream k (runtime.slot_stream): a second model of the process takes no new hardware queue
+    from fasterrcnn_amd import runtime as rt
+    dev = imgs[0].device
+    for k in (1, 2, 3):
+        assert gpu_model._slot(k, 600, 1000, dev).stream is rt.slot_stream(dev, k)
+    assert rt.slot_stream(dev, 1) is not rt.slot_stream(dev, 2)
+    assert gpu_model._slot(0, 600, 1000, dev).stream is None   # slot 0 = the caller's current stream
 
 
 def test_inflight_slots_are_deterministic_under_load(gpu_model):
