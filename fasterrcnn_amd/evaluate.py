@@ -98,7 +98,7 @@ def evaluate_stream(model, samples, score_threshold=0.05, inflight=4, rank=0, wo
     Processes the samples whose position p satisfies p % world == rank, `inflight` at a time, and
     returns this rank's ImageRecords.  `on_result(image_index, dict)` is called per finished image.
     batch > 1 (ResNet backbones): consecutive samples of one shape go through the feature extractor as ONE batch of up to `batch`
-    images (model.predict_batch_async), max(2, inflight // batch) batches in flight; results and their order are per image as before.
+    images (model.predict_batch_async), max(1, inflight // batch) batches in flight (two measure best: inflight = 2 x batch); results and their order are per image as before.
     """
     records = ImageRecords()
     pending = []   # (Pending, image_index, gt_boxes)
@@ -115,7 +115,7 @@ def evaluate_stream(model, samples, score_threshold=0.05, inflight=4, rank=0, wo
     if batch > 1 and not getattr(model, "_is_resnet", False):
         batch = 1               # VGG-16's layers fill the chip with one image: its images go in flight one by one
     if batch > 1:
-        nlanes = max(2, int(inflight) // batch)               # (two batches in flight: the second's feature extractor under the first's per-image tails)
+        nlanes = max(1, int(inflight) // batch)               # (inflight = 2 x batch: the second batch's feature extractor under the first's per-image tails)
         group, lanes, state = [], [], {"lane": 0}             # lanes[i]: the lane of pending[i]
 
         def flush():
