@@ -24,6 +24,7 @@ kernel with a flipped/transposed weight pack.  Design points:
     proposals (the reference's `len()` / `t.where` calls) and the final read of the loss values.
 """
 import random
+import time
 
 import numpy as np
 import torch as t
@@ -49,6 +50,11 @@ def _ws(nbytes, device):
 # rounded to bfloat16, bf16 matrix pipe, f32 accumulation -- every gradient GEMM (csrc/gemm_tn.hip) and, round 4, the forward and
 # data-gradient convolutions of the trainable ResNet blocks (csrc/conv_gather.hip: conv_gather_bf16_kernel).
 _GRAD_MATH = 0
+
+# Host clocks of the steps (tools/train_bench.py --host-clocks): a list, or None.  Per step one tuple of time.perf_counter() readings: entry,
+# before / after host sync 1 (the labelled-proposal count), before / after host sync 2 (the losses) -- the two stretches between them are
+# what the host needs to ENQUEUE the step's launches (the queues are deep: enqueueing does not wait for the chip).
+HOST_CLOCKS = None
 
 
 def gemm_tn(a, lda, b, ldb, m, n, r, out=None, ldc=None):
@@ -389,6 +395,65 @@ class VGG16TrainState(TrainState):
             grads[name] = t.zeros_like(self.trainable()[name])
 
 
+_wgrad_streams = {}
+
+
+def _wgrad_stream(device):
+    """The process's second stream of a device for the weight-gradient GEMMs of the train step (one, shared by every model)."""
+    key = str(t.device(device))
+    st = _wgrad_streams.get(key)
+    if st is None:
+        st = t.cuda.Stream(device=t.device(device))
+        _wgrad_streams[key] = st
+    return st
+
+
+class _SideGrads:
+    """
+    Weight gradients of the trainable bottlenecks on a SECOND stream (round 6).  The backward of a block is a chain -- ReLU mask, data
+    gradient, ReLU mask, data gradient ... -- whose kernels fill 35-50 % of the chip (`tools/cu_time_model.py report DIR N` over a ResNet-101
+    step: 10.9 ms of kernel time, 4.4 ms of CU time), and the weight gradient of each convolution hangs OFF that chain: nothing of the
+    backward reads it.  `wgrad()` enqueues it (GEMM, split reduction, BatchNorm row scale) on the second stream behind an event of the main
+    stream, so it runs under the chain's next kernels; `flush(keep)` hands the gradients to `grads` in their production order -- the
+    main stream waits for each one's event first, so whoever reads `grads[name]` next (the data-parallel exchange, SGD) is ordered behind it.
+    `keep` = how many of the most recent ones stay pending: a block flushes all but the previous block's, whose kernels have had a block's
+    time to finish.  The values are the one-stream step's bit for bit (same kernels, same operands).  FRCNN_TRAIN_WGRAD_STREAM=0 / 1: off / on whatever the arithmetic.
+    Operands allocated on the main stream and read here are marked for the allocator (record_stream), the gradients likewise for the main stream.
+    """
+    def __init__(self, grads, device):
+        import os
+        self.grads, self.device, self.pending = grads, t.device(device), []
+        # Measured (tools/exp_train_wgrad_stream.sh, one MI355X): ResNet-101 float32 step 19.0-19.1 -> 17.7-17.9 ms, ResNet-50 11.9 -> 11.2-11.5;
+        # the bf16 step (11.6 ms) does NOT gain: its ~950 launches of ~11 us are issued by the host at the rate the chip retires them, and
+        # the two events per gradient are four more host calls each -- so the second stream is the float32 step's default only.
+        env = os.environ.get("FRCNN_TRAIN_WGRAD_STREAM", "")
+        self.enabled = env == "1" or (env != "0" and _GRAD_MATH == 0)
+
+    def wgrad(self, name, conv, x, dz, n, h, w):
+        if not self.enabled:
+            self.grads[name] = conv.wgrad(x, dz, n, h, w)
+            return
+        main, side = t.cuda.current_stream(self.device), _wgrad_stream(self.device)
+        ready = t.cuda.Event()
+        ready.record(main)
+        side.wait_event(ready)
+        with t.cuda.stream(side):
+            g = conv.wgrad(x, dz, n, h, w)
+            done = t.cuda.Event()
+            done.record(side)
+        x.record_stream(side)
+        dz.record_stream(side)
+        g.record_stream(main)
+        self.pending.append((name, g, done))
+
+    def flush(self, keep=0):
+        main = t.cuda.current_stream(self.device)
+        while len(self.pending) > keep:
+            name, g, done = self.pending.pop(0)
+            main.wait_event(done)
+            self.grads[name] = g
+
+
 class _TrainConv:
     """One conv + frozen BatchNorm of a trainable Bottleneck: raw master pack, BN scale/shift, folded pack."""
     def __init__(self, conv, bn):
@@ -454,23 +519,31 @@ class _TrainBlock:
         out, _, _ = self.c3.forward(t2, n, ho, wo, True, residual=identity)
         return out, ho, wo, (x, t1, t2, out, n, h, w, ho, wo)
 
-    def backward(self, g, saved, grads, need_dx):
-        """`g` = gradient with respect to the block output (consumed); returns the gradient with respect to x or None."""
+    def backward(self, g, saved, side, need_dx):
+        """`g` = gradient with respect to the block output (consumed); returns the gradient with respect to x or None.
+        `side`: the step's _SideGrads -- the four weight gradients leave on the second stream, in the order conv3, conv2, conv1, downsample."""
         x, t1, t2, out, n, h, w, ho, wo = saved
+        own = not isinstance(side, _SideGrads)                       # a plain gradient dict (a block's backward on its own: tests)
+        if own:
+            side = _SideGrads(side, g.device)
+        side.flush(keep=4)                                           # (the blocks before the previous one: their kernels are long done)
         relu_backward(g, out)
-        grads[self.name + ".conv3"] = self.c3.wgrad(t2, g, n, ho, wo)
+        side.wgrad(self.name + ".conv3", self.c3, t2, g, n, ho, wo)
         d_t2 = self.c3.dgrad(g, None, n, ho, wo)
         relu_backward(d_t2, t2)
-        grads[self.name + ".conv2"] = self.c2.wgrad(t1, d_t2, n, h, w)
+        side.wgrad(self.name + ".conv2", self.c2, t1, d_t2, n, h, w)
         d_t1 = self.c2.dgrad(d_t2, None, n, h, w)
         relu_backward(d_t1, t1)
-        grads[self.name + ".conv1"] = self.c1.wgrad(x, d_t1, n, h, w)
+        side.wgrad(self.name + ".conv1", self.c1, x, d_t1, n, h, w)
         if self.cd is not None:
-            grads[self.name + ".downsample"] = self.cd.wgrad(x, g, n, h, w)
-        if not need_dx:
-            return None
-        dx_id = self.cd.dgrad(g, None, n, h, w) if self.cd is not None else g
-        return self.c1.dgrad(d_t1, dx_id, n, h, w)
+            side.wgrad(self.name + ".downsample", self.cd, x, g, n, h, w)
+        dx = None
+        if need_dx:
+            dx_id = self.cd.dgrad(g, None, n, h, w) if self.cd is not None else g
+            dx = self.c1.dgrad(d_t1, dx_id, n, h, w)
+        if own:
+            side.flush()
+        return dx
 
 
 class ResNetTrainState(TrainState):
@@ -538,8 +611,10 @@ class ResNetTrainState(TrainState):
 
     def features_backward(self, g, saved, grads):
         g = g.reshape(1, g.shape[0], g.shape[1], g.shape[2])
+        side = _SideGrads(grads, self.device)
         for i in range(len(self.blocks) - 1, -1, -1):
-            g = self.blocks[i].backward(g, saved[i], grads, need_dx=(i > 0))      # layer1 below is frozen: no dx for block 0
+            g = self.blocks[i].backward(g, saved[i], side, need_dx=(i > 0))       # layer1 below is frozen: no dx for block 0
+        side.flush()                                                             # every gradient handed over, in production order, before SGD
 
     # ---- RoI features -> feature vector (resnet.py:109-118) -----------------------------------------------
     def head_forward(self, roi_out):
@@ -559,8 +634,10 @@ class ResNetTrainState(TrainState):
         g = t.empty((S, h, w, 2048), dtype=t.float32, device=self.device)
         nv.check(_lib().frcnn_spatial_mean_backward(nv.ptr(dvec), nv.ptr(g), S, h, w, 2048, nv.stream_ptr()),
                  "frcnn_spatial_mean_backward")
+        side = _SideGrads(grads, self.device)
         for i in range(len(self.head_blocks) - 1, -1, -1):
-            g = self.head_blocks[i].backward(g, blocks_saved[i], grads, need_dx=True)
+            g = self.head_blocks[i].backward(g, blocks_saved[i], side, need_dx=True)
+        side.flush()       # (before "rpn_head": the order in which `grads` fills is the one-stream step's, also on a rank without a proposal batch)
         return g.reshape(S, 49 * 1024)
 
     def zero_head_grads(self, grads):
@@ -724,6 +801,7 @@ def _train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_r
     ncls = model._num_classes
     nd = 4 * (ncls - 1)
     C, V = st.C, st.V
+    hc0 = time.perf_counter() if HOST_CLOCKS is not None else 0.0
     with t.no_grad(), t.cuda.device(dev):
         s = nv.stream_ptr()
         # ---- stage 1 forward, keeping what the backward needs ------------------------------------------
@@ -784,7 +862,9 @@ def _train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_r
         nv.check(lib.frcnn_label_proposals(nv.ptr(props), counts.data_ptr() + 8, post_nms, nv.ptr(gt_corners), nv.ptr(gt_cls), M,
                                            ncls, 0.0, 0.5, means, stds, nv.ptr(lab_props), nv.ptr(lab_cls), nv.ptr(lab_onehot),
                                            nv.ptr(lab_deltas), nv.ptr(lab_count), s), "frcnn_label_proposals")
+        hc1 = time.perf_counter() if HOST_CLOCKS is not None else 0.0
         K = int(lab_count.item())                                     # host sync 1 (the reference's len()/where)
+        hc2 = time.perf_counter() if HOST_CLOCKS is not None else 0.0
         class_indices = lab_cls[:K].cpu().to(t.int64)
         sample_idx = _sample_proposal_indices(class_indices, model._proposal_batch_size, 0.25)
         S = int(sample_idx.shape[0])
@@ -862,7 +942,10 @@ def _train_step(model, optimizer, image_data, anchor_map, anchor_valid_map, gt_r
         if detail is not None:
             detail["grads"] = {k: v.clone() for k, v in grads.items()}
         st.apply_sgd(grads, lr, momentum, weight_decay)
+        hc3 = time.perf_counter() if HOST_CLOCKS is not None else 0.0
         lv = losses.cpu().numpy()                                     # host sync 2
+        if HOST_CLOCKS is not None:
+            HOST_CLOCKS.append((hc0, hc1, hc2, hc3, time.perf_counter()))
     # total in float32 left to right, as the reference adds the four float32 scalars (faster_rcnn.py:344)
     total = np.float32(np.float32(np.float32(lv[0] + lv[1]) + lv[2]) + lv[3])
     return model.Loss(rpn_class=float(lv[0]), rpn_regression=float(lv[1]), detector_class=float(lv[2]),

@@ -3,7 +3,8 @@ duration is its own).  For every dispatch: blocks resident per CU from its regis
 its grid fills over its rounds of resident blocks, and  cu_time = duration x (rounds / ceil(rounds)), rounds = blocks / (256 x blocks per CU).  The sum over an image's dispatches is what the chip must
 spend on the image however many images are in flight (kernels that leave CUs empty can overlap others'; kernels that fill it cannot).
     (1) rocprofv3 --kernel-trace -d DIR -- python tools/cu_time_model.py run vgg16|resnet50 [images]
-    (2) python tools/cu_time_model.py report DIR"""
+    (2) python tools/cu_time_model.py report DIR
+    (3) python tools/cu_time_model.py report DIR N      (every dispatch of the trace over N units of work: e.g. train steps)"""
 import csv, glob, sys
 from collections import defaultdict
 
@@ -36,16 +37,20 @@ def run(arch, n):
     torch.cuda.synchronize()
 
 
-def report(d):
+def report(d, units=0):
     rows = []
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         rows += list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    # images = detections_kernel dispatches; keep the last 60 %
-    det = [i for i, r in enumerate(rows) if "detections_kernel" in r["Kernel_Name"]]
-    first = det[len(det) * 4 // 10]
-    rows = rows[first + 1:det[-1] + 1]
-    nimg = len(det) - 1 - len(det) * 4 // 10
+    if units > 0:
+        # (3) report DIR N: every dispatch of the trace over N units of work (e.g. the train steps of `rocprofv3 ... python tools/train_bench.py --steps a --warmup b`, N = a + b)
+        nimg = units
+    else:
+        # images = detections_kernel dispatches; keep the last 60 %
+        det = [i for i, r in enumerate(rows) if "detections_kernel" in r["Kernel_Name"]]
+        first = det[len(det) * 4 // 10]
+        rows = rows[first + 1:det[-1] + 1]
+        nimg = len(det) - 1 - len(det) * 4 // 10
     agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0, 0])
     for r in rows:
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
@@ -86,4 +91,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 40)
     else:
-        report(sys.argv[2])
+        report(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0)

@@ -13,8 +13,10 @@ dev = torch.device("cuda", 0)
 m = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet50))
 m.load_state_dict(synthetic.resnet_state_dict(1234, "ResNet50"), strict=True)
 m = m.cuda(dev).eval()
-if len(sys.argv) > 1 and sys.argv[1] == "all":
+if "all" in sys.argv[1:]:
     m.bottleneck_g3 = "all"
+if "batch_head" in sys.argv[1:]:
+    m.batch_head = True
 batch = torch.cat([synthetic.image_rgb(s).unsqueeze(0).to(dev) for s in range(8)], dim=0)
 
 
@@ -43,4 +45,4 @@ def measure(n, reps):
 t_end = time.perf_counter() + 2.0
 while time.perf_counter() < t_end:
     run(16)
-print("FRCNN_LANE_STREAMS=%s g3=%s: bursts of 24 %.1f images/sec, bursts of 200 %.1f" % (os.environ.get("FRCNN_LANE_STREAMS", "own"), m.bottleneck_g3, measure(24, 15), measure(200, 5)))
+print("FRCNN_LANE_STREAMS=%s g3=%s batch_head=%s: bursts of 24 %.1f images/sec, bursts of 200 %.1f" % (os.environ.get("FRCNN_LANE_STREAMS", "own"), m.bottleneck_g3, m.batch_head, measure(24, 15), measure(200, 5)))

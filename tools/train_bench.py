@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--grad-math", type=str, default="f32", choices=["f32", "bf16"],
                     help="arithmetic of the gradient GEMMs (FasterRCNNModel.grad_math); bf16 = BASELINE configs[4]'s reduced-precision step")
     ap.add_argument("--roi", type=str, default="pool", choices=["pool", "align"])
+    ap.add_argument("--host-clocks", action="store_true", help="also report what the host needs to ENQUEUE a step (training.HOST_CLOCKS)")
     args = ap.parse_args()
     h, w = args.height, args.width
     if args.backbone == "vgg16":
@@ -70,12 +71,21 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    if args.host_clocks:
+        training.HOST_CLOCKS = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         losses.append(step(i).total)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"metric": "train_step (%s Faster R-CNN, %dx%d, batch 1)" % (args.backbone, h, w), "ms_per_step": 1e3 * dt / args.steps,
+    host = {}
+    if args.host_clocks:
+        hc = np.array(training.HOST_CLOCKS)
+        host = {"host_ms_per_step": {"enqueue_until_sync_1": round(1e3 * float(np.median(hc[:, 1] - hc[:, 0])), 3),
+                                     "wait_sync_1": round(1e3 * float(np.median(hc[:, 2] - hc[:, 1])), 3),
+                                     "enqueue_until_sync_2": round(1e3 * float(np.median(hc[:, 3] - hc[:, 2])), 3),
+                                     "wait_sync_2": round(1e3 * float(np.median(hc[:, 4] - hc[:, 3])), 3)}}
+    print(json.dumps({**host, "metric": "train_step (%s Faster R-CNN, %dx%d, batch 1)" % (args.backbone, h, w), "ms_per_step": 1e3 * dt / args.steps,
                       "steps_per_sec": args.steps / dt, "steps": args.steps, "warmup": args.warmup, "dtype": "f32", "grad_math": model.grad_math, "roi": args.roi, "math": model.math_mode,
                       "first_total_loss": losses[0], "last_total_loss": losses[-1], "data": "synthetic"}))
 
