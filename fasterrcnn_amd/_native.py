@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libfrcnn_hip.so")   # override: kernel experiments
 
 OK = 0
-ABI_VERSION = 15    # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
+ABI_VERSION = 16    # must equal FRCNN_ABI_VERSION of include/frcnn_hip.h
 ERRORS = {0: "FRCNN_OK", -1: "FRCNN_EINVAL", -2: "FRCNN_EHIP", -3: "FRCNN_ENOMEM",
           -4: "FRCNN_EUNSUPPORTED", -5: "FRCNN_ENODEVICE"}
 RELU = 1
@@ -52,7 +52,7 @@ SYMBOLS = (
     "frcnn_conv3x3_nhwc_winograd_fused_maps", "frcnn_ctx_create_backbone", "frcnn_resnet_backbone", "frcnn_resnet_forward_features", "frcnn_resnet_rpn_roipool", "frcnn_ctx_create_head", "frcnn_resnet_head",
     # training path
     "frcnn_label_proposals", "frcnn_gather_rows", "frcnn_rpn_loss", "frcnn_detector_loss",
-    "frcnn_gemm_tn_math", "frcnn_conv3x3_wgrad_math", "frcnn_conv_wgrad_math",
+    "frcnn_gemm_tn_math", "frcnn_conv3x3_wgrad_math", "frcnn_conv_wgrad_math", "frcnn_bottleneck_backward_workspace_bytes", "frcnn_bottleneck_backward",
     "frcnn_gemm_tn_workspace_bytes", "frcnn_gemm_tn", "frcnn_conv3x3_wgrad_workspace_bytes", "frcnn_conv3x3_wgrad",
     "frcnn_pack_conv3x3_dgrad", "frcnn_relu_backward", "frcnn_add_inplace", "frcnn_maxpool2x2_backward",
     "frcnn_roi_pool_backward_workspace_bytes", "frcnn_roi_pool_backward", "frcnn_transpose", "frcnn_sgd_step", "frcnn_sgd_step_fold",
@@ -88,6 +88,12 @@ class BottleneckWeights(C.Structure):
                 ("w3", C.c_void_p), ("b3", C.c_void_p), ("wd", C.c_void_p), ("bd", C.c_void_p),
                 ("cin", C.c_int32), ("width", C.c_int32), ("cout", C.c_int32), ("stride", C.c_int32), ("x6_mask", C.c_int32), ("x3_mask", C.c_int32),
                 ("wmax", C.c_void_p), ("g3", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class TrainConv(C.Structure):
+    """frcnn_train_conv (ABI 16): one conv + frozen BatchNorm of a trainable bottleneck for frcnn_bottleneck_backward."""
+    _fields_ = [("folded", C.c_void_p), ("scale", C.c_void_p), ("grad", C.c_void_p), ("wd", C.c_void_p),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class ResNetWeights(C.Structure):
@@ -317,6 +323,9 @@ _SIGNATURES = {
     "frcnn_gemm_tn_math": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "frcnn_conv3x3_wgrad_math": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "frcnn_conv_wgrad_math": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "frcnn_bottleneck_backward_workspace_bytes": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "frcnn_bottleneck_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _sz,
+                                            _vp, _vp]),
     "frcnn_conv3x3_wgrad_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "frcnn_conv3x3_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "frcnn_pack_conv3x3_dgrad": (C.c_int, [_vp, _vp, _i, _i, _vp]),

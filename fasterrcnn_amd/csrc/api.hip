@@ -732,6 +732,119 @@ int frcnn_conv_dgrad_math(const float* d_dz, const float* d_wd, const float* d_r
                              as_stream(stream), math);
 }
 
+// ---- ABI 16: the backward of ONE trainable bottleneck as one call (fasterrcnn_amd/training.py: _TrainBlock.backward) ---------------------
+namespace {
+int tc_ok(const frcnn_train_conv* c)
+{
+    return c && c->folded && c->scale && c->grad && c->wd && c->cin > 0 && c->cout > 0 && c->ksize > 0 && c->stride > 0 && c->pad >= 0;
+}
+// The gradient of the RAW weight of a conv + frozen BatchNorm: the folded weight's gradient times the BN scale of its output channel.
+int tc_wgrad(const frcnn_train_conv* c, const float* x, const float* dz, int N, int H, int W, int math, void* ws, size_t ws_bytes, hipStream_t s)
+{
+    int rc = launch_conv_wgrad(x, dz, c->grad, N, H, W, c->cin, c->cout, c->ksize, c->stride, c->pad, ws, ws_bytes, s, math);
+    if (rc) return rc;
+    return launch_scale_rows(c->grad, c->scale, c->grad, c->ksize * c->ksize, c->cout, c->cin, s);
+}
+int tc_dgrad(const frcnn_train_conv* c, const float* dz, const float* residual, float* dx, int N, int H, int W, int math, void* ws, size_t ws_bytes,
+             hipStream_t s)
+{
+    int rc = launch_pack_conv_dgrad(c->folded, c->wd, c->ksize * c->ksize, c->cout, c->cin, s);
+    if (rc) return rc;
+    return launch_conv_dgrad(dz, c->wd, residual, dx, N, H, W, c->cin, c->cout, c->ksize, c->stride, c->pad, ws, ws_bytes, s, math);
+}
+size_t tc_wgrad_ws(const frcnn_train_conv* c, int N, int H, int W)
+{
+    return frcnn_conv_wgrad_workspace_bytes(N, H, W, c->cin, c->cout, c->ksize, c->stride, c->pad);
+}
+size_t tc_dgrad_ws(const frcnn_train_conv* c, int N, int H, int W)
+{
+    return conv_dgrad_workspace_bytes(N, H, W, c->cin, c->cout, c->ksize, c->stride, c->pad);
+}
+// the second stream runs behind everything the main stream holds at this point
+// (events from a ring per device, made once: hipStreamWaitEvent takes the event's state at the call, so an entry may be recorded again
+//  as soon as its wait has been enqueued; creating and destroying one per use measured ~25 us of host time per block)
+int side_behind_main(hipStream_t main, hipStream_t side)
+{
+    if (side == main) return FRCNN_OK;
+    static constexpr int RING = 16, MAXDEV = 16;
+    static thread_local hipEvent_t ring[MAXDEV][RING];
+    static thread_local bool made[MAXDEV];
+    static thread_local unsigned next[MAXDEV];
+    int dev = 0;
+    FRCNN_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAXDEV) return FRCNN_EUNSUPPORTED;
+    if (!made[dev]) {
+        for (int i = 0; i < RING; ++i) FRCNN_HIP_TRY(hipEventCreateWithFlags(&ring[dev][i], hipEventDisableTiming));
+        made[dev] = true;
+    }
+    hipEvent_t ev = ring[dev][next[dev]++ % RING];
+    FRCNN_HIP_TRY(hipEventRecord(ev, main));
+    FRCNN_HIP_TRY(hipStreamWaitEvent(side, ev, 0));
+    return FRCNN_OK;
+}
+}  // namespace
+
+int frcnn_bottleneck_backward_workspace_bytes(const frcnn_train_conv* c1, const frcnn_train_conv* c2, const frcnn_train_conv* c3,
+                                              const frcnn_train_conv* cd, int N, int H, int W, int Ho, int Wo, size_t* main_bytes,
+                                              size_t* side_bytes)
+{
+    if (!tc_ok(c1) || !tc_ok(c2) || !tc_ok(c3) || (cd && !tc_ok(cd)) || !main_bytes || !side_bytes || N < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1)
+        return FRCNN_EINVAL;
+    size_t m = std::max(std::max(tc_dgrad_ws(c3, N, Ho, Wo), tc_dgrad_ws(c2, N, H, W)), tc_dgrad_ws(c1, N, H, W));
+    size_t w = std::max(std::max(tc_wgrad_ws(c3, N, Ho, Wo), tc_wgrad_ws(c2, N, H, W)), tc_wgrad_ws(c1, N, H, W));
+    if (cd) { m = std::max(m, tc_dgrad_ws(cd, N, H, W)); w = std::max(w, tc_wgrad_ws(cd, N, H, W)); }
+    *main_bytes = m; *side_bytes = w;
+    return FRCNN_OK;
+}
+
+int frcnn_bottleneck_backward(const frcnn_train_conv* c1, const frcnn_train_conv* c2, const frcnn_train_conv* c3, const frcnn_train_conv* cd,
+                              const float* d_x, const float* d_t1, const float* d_t2, const float* d_out, float* d_g, float* d_dt2,
+                              float* d_dt1, float* d_dxid, float* d_dx, int N, int H, int W, int Ho, int Wo, int math, void* d_ws_main,
+                              size_t ws_main_bytes, void* d_ws_side, size_t ws_side_bytes, void* stream, void* side_stream)
+{
+    if (!tc_ok(c1) || !tc_ok(c2) || !tc_ok(c3) || (cd && !tc_ok(cd)) || !d_x || !d_t1 || !d_t2 || !d_out || !d_g || !d_dt2 || !d_dt1 ||
+        (cd && d_dx && !d_dxid) || N < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1)
+        return FRCNN_EINVAL;
+    size_t need_m = 0, need_s = 0;
+    int rc = frcnn_bottleneck_backward_workspace_bytes(c1, c2, c3, cd, N, H, W, Ho, Wo, &need_m, &need_s);
+    if (rc) return rc;
+    if ((need_m && (!d_ws_main || ws_main_bytes < need_m)) || (need_s && (!d_ws_side || ws_side_bytes < need_s))) return FRCNN_EINVAL;
+    hipStream_t s = as_stream(stream);
+    hipStream_t w = side_stream ? as_stream(side_stream) : s;
+    const size_t n_out = (size_t)N * Ho * Wo * c3->cout, n_t2 = (size_t)N * Ho * Wo * c3->cin, n_t1 = (size_t)N * H * W * c2->cin;
+#define BSTEP(call) do { rc = (call); if (rc) return rc; } while (0)
+    // The chain first -- out = relu(conv3(t2) + identity): the mask of the output's ReLU, conv3's data gradient, t2's mask, conv2's, t1's
+    // mask, (downsample's,) conv1's -- then ONE event, and the block's four weight gradients behind it on the second stream: they run under
+    // the NEXT block's chain (an event per gradient, each right behind the mask it needs, measured 80 us of host time per block and made the
+    // bf16 step host-bound again).  Without a second stream the order is the separate entry points': each gradient before its data gradient.
+    const bool two = w != s;
+    BSTEP(launch_relu_backward(d_g, d_out, n_out, s));
+    if (!two) BSTEP(tc_wgrad(c3, d_t2, d_g, N, Ho, Wo, math, d_ws_side, ws_side_bytes, s));
+    BSTEP(tc_dgrad(c3, d_g, nullptr, d_dt2, N, Ho, Wo, math, d_ws_main, ws_main_bytes, s));
+    BSTEP(launch_relu_backward(d_dt2, d_t2, n_t2, s));
+    if (!two) BSTEP(tc_wgrad(c2, d_t1, d_dt2, N, H, W, math, d_ws_side, ws_side_bytes, s));
+    BSTEP(tc_dgrad(c2, d_dt2, nullptr, d_dt1, N, H, W, math, d_ws_main, ws_main_bytes, s));
+    BSTEP(launch_relu_backward(d_dt1, d_t1, n_t1, s));
+    if (!two) {
+        BSTEP(tc_wgrad(c1, d_x, d_dt1, N, H, W, math, d_ws_side, ws_side_bytes, s));
+        if (cd) BSTEP(tc_wgrad(cd, d_x, d_g, N, H, W, math, d_ws_side, ws_side_bytes, s));
+    }
+    if (d_dx) {
+        const float* identity_grad = d_g;
+        if (cd) { BSTEP(tc_dgrad(cd, d_g, nullptr, d_dxid, N, H, W, math, d_ws_main, ws_main_bytes, s)); identity_grad = d_dxid; }
+        BSTEP(tc_dgrad(c1, d_dt1, identity_grad, d_dx, N, H, W, math, d_ws_main, ws_main_bytes, s));
+    }
+    if (two) {
+        BSTEP(side_behind_main(s, w));
+        BSTEP(tc_wgrad(c3, d_t2, d_g, N, Ho, Wo, math, d_ws_side, ws_side_bytes, w));
+        BSTEP(tc_wgrad(c2, d_t1, d_dt2, N, H, W, math, d_ws_side, ws_side_bytes, w));
+        BSTEP(tc_wgrad(c1, d_x, d_dt1, N, H, W, math, d_ws_side, ws_side_bytes, w));
+        if (cd) BSTEP(tc_wgrad(cd, d_x, d_g, N, H, W, math, d_ws_side, ws_side_bytes, w));
+    }
+#undef BSTEP
+    return FRCNN_OK;
+}
+
 int frcnn_pack_conv_dgrad(const float* d_wp, float* d_wd, int taps, int cout, int cin, void* stream)
 {
     if (!d_wp || !d_wd) return FRCNN_EINVAL;

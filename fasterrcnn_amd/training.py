@@ -413,45 +413,41 @@ class _SideGrads:
     Weight gradients of the trainable bottlenecks on a SECOND stream (round 6).  The backward of a block is a chain -- ReLU mask, data
     gradient, ReLU mask, data gradient ... -- whose kernels fill 35-50 % of the chip (`tools/cu_time_model.py report DIR N` over a ResNet-101
     step: 10.9 ms of kernel time, 4.4 ms of CU time), and the weight gradient of each convolution hangs OFF that chain: nothing of the
-    backward reads it.  `wgrad()` enqueues it (GEMM, split reduction, BatchNorm row scale) on the second stream behind an event of the main
-    stream, so it runs under the chain's next kernels; `flush(keep)` hands the gradients to `grads` in their production order -- the
-    main stream waits for each one's event first, so whoever reads `grads[name]` next (the data-parallel exchange, SGD) is ordered behind it.
-    `keep` = how many of the most recent ones stay pending: a block flushes all but the previous block's, whose kernels have had a block's
-    time to finish.  The values are the one-stream step's bit for bit (same kernels, same operands).  FRCNN_TRAIN_WGRAD_STREAM=0 / 1: off / on whatever the arithmetic.
-    Operands allocated on the main stream and read here are marked for the allocator (record_stream), the gradients likewise for the main stream.
+    backward reads it.  `frcnn_bottleneck_backward` (ABI 16: one C call per block instead of ~25 -- the step was bound by the host's enqueue
+    rate, 8.6 of its 11.4 ms) enqueues them on the second stream behind an event of the main stream each, so they run under the chain's
+    next kernels; `add()` takes a block's gradients with the event that follows them on the second stream, `flush(keep)` hands them to
+    `grads` in their production order -- the main stream waits for the block's event first, so whoever reads `grads[name]` next (the
+    data-parallel exchange, SGD) is ordered behind them.  `keep` = how many of the most recent blocks stay pending: a block flushes all but
+    the previous one, whose kernels have had a block's time to finish.  The values are the one-stream step's bit for bit (same kernels, same
+    operands).  FRCNN_TRAIN_WGRAD_STREAM=0: one stream.
     """
     def __init__(self, grads, device):
         import os
         self.grads, self.device, self.pending = grads, t.device(device), []
-        # Measured (tools/exp_train_wgrad_stream.sh, one MI355X): ResNet-101 float32 step 19.0-19.1 -> 17.7-17.9 ms, ResNet-50 11.9 -> 11.2-11.5;
-        # the bf16 step (11.6 ms) does NOT gain: its ~950 launches of ~11 us are issued by the host at the rate the chip retires them, and
-        # the two events per gradient are four more host calls each -- so the second stream is the float32 step's default only.
-        env = os.environ.get("FRCNN_TRAIN_WGRAD_STREAM", "")
-        self.enabled = env == "1" or (env != "0" and _GRAD_MATH == 0)
+        self.enabled = os.environ.get("FRCNN_TRAIN_WGRAD_STREAM", "1") != "0"
 
-    def wgrad(self, name, conv, x, dz, n, h, w):
-        if not self.enabled:
-            self.grads[name] = conv.wgrad(x, dz, n, h, w)
-            return
-        main, side = t.cuda.current_stream(self.device), _wgrad_stream(self.device)
-        ready = t.cuda.Event()
-        ready.record(main)
-        side.wait_event(ready)
-        with t.cuda.stream(side):
-            g = conv.wgrad(x, dz, n, h, w)
+    def stream(self):
+        return _wgrad_stream(self.device) if self.enabled else None
+
+    def add(self, named_grads, scratch):
+        """named_grads: [(name, tensor)] in production order, just enqueued (on the second stream when enabled); scratch: main-stream
+        tensors the second stream still reads -- kept referenced until the main stream has waited for the block's event, so the allocator
+        cannot hand their memory to a kernel that runs before the second stream is done with it (tensor.record_stream would say the same
+        to the allocator at ~4x the host time: measured, 6.2 against 4.6 ms to enqueue a ResNet-101 backward)."""
+        done = None
+        if self.enabled:
             done = t.cuda.Event()
-            done.record(side)
-        x.record_stream(side)
-        dz.record_stream(side)
-        g.record_stream(main)
-        self.pending.append((name, g, done))
+            done.record(_wgrad_stream(self.device))
+        self.pending.append((named_grads, done, scratch if self.enabled else None))
 
     def flush(self, keep=0):
         main = t.cuda.current_stream(self.device)
         while len(self.pending) > keep:
-            name, g, done = self.pending.pop(0)
-            main.wait_event(done)
-            self.grads[name] = g
+            named_grads, done, _scratch = self.pending.pop(0)
+            if done is not None:
+                main.wait_event(done)
+            for name, g in named_grads:
+                self.grads[name] = g
 
 
 class _TrainConv:
@@ -471,6 +467,8 @@ class _TrainConv:
                                           self.cout, nv.ptr(self.scale), nv.ptr(self.shift), nv.stream_ptr()), "frcnn_bn_scale_shift")
         self.folded = t.empty_like(self.raw)
         self.refold()
+        # frcnn_train_conv of frcnn_bottleneck_backward (folded / scale are written in place by every update: the pointers stay)
+        self.cstruct = nv.TrainConv(self.folded.data_ptr(), self.scale.data_ptr(), None, None, self.cin, self.cout, self.k, self.stride, self.pad, 0)
 
     def refold(self):
         nv.check(_lib().frcnn_scale_rows(nv.ptr(self.raw), nv.ptr(self.scale), nv.ptr(self.folded), self.k * self.k, self.cout,
@@ -521,26 +519,49 @@ class _TrainBlock:
 
     def backward(self, g, saved, side, need_dx):
         """`g` = gradient with respect to the block output (consumed); returns the gradient with respect to x or None.
-        `side`: the step's _SideGrads -- the four weight gradients leave on the second stream, in the order conv3, conv2, conv1, downsample."""
+        `side`: the step's _SideGrads (or a plain gradient dict: a block's backward on its own).  ONE call, frcnn_bottleneck_backward: the
+        ReLU masks and data gradients on the current stream, the four weight gradients -- in the order conv3, conv2, conv1, downsample --
+        on the second one."""
         x, t1, t2, out, n, h, w, ho, wo = saved
-        own = not isinstance(side, _SideGrads)                       # a plain gradient dict (a block's backward on its own: tests)
+        own = not isinstance(side, _SideGrads)
         if own:
             side = _SideGrads(side, g.device)
-        side.flush(keep=4)                                           # (the blocks before the previous one: their kernels are long done)
-        relu_backward(g, out)
-        side.wgrad(self.name + ".conv3", self.c3, t2, g, n, ho, wo)
-        d_t2 = self.c3.dgrad(g, None, n, ho, wo)
-        relu_backward(d_t2, t2)
-        side.wgrad(self.name + ".conv2", self.c2, t1, d_t2, n, h, w)
-        d_t1 = self.c2.dgrad(d_t2, None, n, h, w)
-        relu_backward(d_t1, t1)
-        side.wgrad(self.name + ".conv1", self.c1, x, d_t1, n, h, w)
-        if self.cd is not None:
-            side.wgrad(self.name + ".downsample", self.cd, x, g, n, h, w)
-        dx = None
-        if need_dx:
-            dx_id = self.cd.dgrad(g, None, n, h, w) if self.cd is not None else g
-            dx = self.c1.dgrad(d_t1, dx_id, n, h, w)
+        side.flush(keep=1)                                           # (the blocks before the previous one: their kernels are long done)
+        dev, lib = g.device, _lib()
+        convs = [("conv3", self.c3), ("conv2", self.c2), ("conv1", self.c1)] + ([("downsample", self.cd)] if self.cd is not None else [])
+        named, keepalive = [], []
+        for cname, c in convs:
+            gw = t.empty((c.k * c.k, c.cout, c.cin), dtype=t.float32, device=dev)
+            wd = t.empty((c.k * c.k, c.cin, c.cout), dtype=t.float32, device=dev)
+            c.cstruct.grad, c.cstruct.wd = gw.data_ptr(), wd.data_ptr()
+            named.append((self.name + "." + cname, gw))
+            keepalive.append(wd)
+        width, cin = self.c1.cout, self.c1.cin
+        d_t2 = t.empty((n, ho, wo, width), dtype=t.float32, device=dev)
+        d_t1 = t.empty((n, h, w, width), dtype=t.float32, device=dev)
+        dx = t.empty((n, h, w, cin), dtype=t.float32, device=dev) if need_dx else None
+        dx_id = t.empty((n, h, w, cin), dtype=t.float32, device=dev) if (need_dx and self.cd is not None) else None
+        C_ = nv.C
+        pcd = C_.byref(self.cd.cstruct) if self.cd is not None else None
+        key = (n, h, w, ho, wo)
+        sizes = getattr(self, "_bw_ws", {}).get(key)
+        if sizes is None:
+            mb, sb = C_.c_size_t(0), C_.c_size_t(0)
+            nv.check(lib.frcnn_bottleneck_backward_workspace_bytes(C_.byref(self.c1.cstruct), C_.byref(self.c2.cstruct), C_.byref(self.c3.cstruct), pcd,
+                                                                   n, h, w, ho, wo, C_.byref(mb), C_.byref(sb)), "frcnn_bottleneck_backward_workspace_bytes")
+            sizes = (int(mb.value), int(sb.value))
+            self._bw_ws = {key: sizes}
+        ws_main = _ws(sizes[0], dev) if sizes[0] else None
+        ws_side = _ws(sizes[1], dev) if sizes[1] else None
+        side_stream = side.stream()
+        nv.check(lib.frcnn_bottleneck_backward(C_.byref(self.c1.cstruct), C_.byref(self.c2.cstruct), C_.byref(self.c3.cstruct), pcd,
+                                               nv.ptr(x), nv.ptr(t1), nv.ptr(t2), nv.ptr(out), nv.ptr(g), nv.ptr(d_t2), nv.ptr(d_t1), nv.ptr(dx_id),
+                                               nv.ptr(dx), n, h, w, ho, wo, _GRAD_MATH, nv.ptr(ws_main), sizes[0], nv.ptr(ws_side), sizes[1],
+                                               nv.stream_ptr(), side_stream.cuda_stream if side_stream is not None else None),
+                 "frcnn_bottleneck_backward")
+        # what the second stream still reads or writes when this returns: the block's gradient, the two intermediate gradients, its workspace
+        # (x, t1, t2 stay referenced by the step until after the last flush)
+        side.add(named, [g, d_t2, d_t1] + ([ws_side] if ws_side is not None else []))
         if own:
             side.flush()
         return dx

@@ -37,7 +37,7 @@ extern "C" {
 #define FRCNN_EUNSUPPORTED -4   /* valid request outside what this build implements */
 #define FRCNN_ENODEVICE    -5   /* no gfx950 device visible */
 
-#define FRCNN_ABI_VERSION 15  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
+#define FRCNN_ABI_VERSION 16  /* 2: training entry points, frcnn_forward_params.conv_blocks_target; 3: Winograd F(2x2,3x3) layers; 4: one-launch Winograd layers;
                                  5: bf16 gradient GEMMs (the *_math entry points); 6: x6t GEMM, x6 Winograd layers, frcnn_forward_params.winograd_x6_mask,
                                  timing classes 8 / 9; 7: batched feature extractor (frcnn_resnet_backbone, frcnn_resnet_forward_features,
                                  frcnn_ctx_create_backbone, frcnn_conv3x3_nhwc_winograd_fused_maps); 8: the f32x3 arithmetic (frcnn_*_x3t, frcnn_*_winograd_x3,
@@ -47,7 +47,8 @@ extern "C" {
                                  12: frcnn_x3_saturation_events, FRCNN_X3F_WAVES4 / FRCNN_X3F_WAVES8; 13: REMOVED the round-2 f32x6 kernels that no table has used since round 3
                                  (frcnn_pack_conv3x3_x6, frcnn_conv3x3_nhwc_x6, frcnn_split_rows_x6, frcnn_linear_x6(_workspace_bytes), math mode 1 =
                                  FRCNN_MATH_F32X6 and fc mode 1 = FRCNN_FC_F32X6 are FRCNN_EINVAL); the f32x6 arithmetic stays as gemm_x6t / wino_x6; 14: FRCNN_X3F_PAIR, frcnn_conv3x3_winograd_x3_pair_workspace_bytes, frcnn_forward_params.winograd_x3p_mask,
-                                 frcnn_resnet_rpn_roipool / frcnn_ctx_create_head / frcnn_resnet_head; 15: frcnn_conv_nhwc_x3g_tickets (split reductions finished inside the kernel), frcnn_pack_conv_x3g_weights + FRCNN_X3G_WSPLIT + frcnn_bottleneck_weights.g3 == 2 (pre-split weight packs) */
+                                 frcnn_resnet_rpn_roipool / frcnn_ctx_create_head / frcnn_resnet_head; 15: frcnn_conv_nhwc_x3g_tickets (split reductions finished inside the kernel), frcnn_pack_conv_x3g_weights + FRCNN_X3G_WSPLIT + frcnn_bottleneck_weights.g3 == 2 (pre-split weight packs);
+                                 16: frcnn_train_conv, frcnn_bottleneck_backward(_workspace_bytes): the backward of one trainable bottleneck as ONE call, weight gradients on a second stream */
 
 /* flags for frcnn_conv3x3_nhwc / frcnn_linear */
 #define FRCNN_RELU   1u
@@ -718,6 +719,33 @@ int frcnn_conv_nhwc_math(const float* d_x, const float* d_w_packed, const float*
                          void* d_ws, size_t ws_bytes, void* stream);
 int frcnn_conv_dgrad_math(const float* d_dz, const float* d_wd, const float* d_residual, float* d_dx, int N, int H, int W,
                           int cin, int cout, int ksize, int stride, int pad, int math, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ABI 16: the backward of ONE trainable Bottleneck (models/resnet.py:38-46 with frozen BatchNorm folded into the convolutions; the reference
+ * gets it from autograd: pytorch/FasterRCNN/__main__.py:147-152 `loss.total.backward()`) as one call instead of ~25:
+ *   out = relu(conv3(t2) + identity), t2 = relu(conv2(t1)), t1 = relu(conv1(x)), identity = x or downsample(x)
+ * d_g = dL/d out on entry (overwritten: the ReLU mask of `out` is applied in place).  Writes, per convolution, the gradient of its RAW
+ * weight (the folded weight's gradient x the BatchNorm scale of the output channel) into frcnn_train_conv.grad, and, if d_dx is not NULL,
+ * dL/dx.  d_dt2 [N][Ho][Wo][width], d_dt1 [N][H][W][width], d_dxid [N][H][W][cin] (downsample blocks) are scratch the caller owns;
+ * frcnn_train_conv.wd is the convolution's data-gradient pack scratch ([k k][cin][cout] floats).  The chain ReLU mask -> data gradient ->
+ * ReLU mask ... runs on `stream`; the four weight gradients (GEMM + split reduction + row scale) run on `side_stream` behind ONE event
+ * recorded on `stream` after the chain (NULL: on `stream` too, each before its data gradient) -- they execute under the next block's
+ * chain, and the caller orders whatever reads the gradients, or frees the scratch, behind `side_stream`.  The values are those
+ * of the separate entry points (frcnn_relu_backward, frcnn_conv_wgrad_math + frcnn_scale_rows, frcnn_pack_conv_dgrad + frcnn_conv_dgrad_math)
+ * bit for bit.  (H, W): the block input's size; (Ho, Wo): its output's (stride of conv2 / downsample).  math: FRCNN_GRAD_F32 / _BF16. */
+typedef struct frcnn_train_conv {
+    const float* folded;   /* [k k][cout][cin]: W x BN scale (what the forward convolves with) */
+    const float* scale;    /* [cout] BatchNorm scale gamma / sqrt(var + eps) */
+    float* grad;           /* out: [k k][cout][cin] gradient of the raw weight */
+    float* wd;             /* scratch: [k k][cin][cout] */
+    int32_t cin, cout, ksize, stride, pad, reserved0;
+} frcnn_train_conv;
+int frcnn_bottleneck_backward_workspace_bytes(const frcnn_train_conv* c1, const frcnn_train_conv* c2, const frcnn_train_conv* c3,
+                                              const frcnn_train_conv* cd, int N, int H, int W, int Ho, int Wo, size_t* main_bytes,
+                                              size_t* side_bytes);
+int frcnn_bottleneck_backward(const frcnn_train_conv* c1, const frcnn_train_conv* c2, const frcnn_train_conv* c3, const frcnn_train_conv* cd,
+                              const float* d_x, const float* d_t1, const float* d_t2, const float* d_out, float* d_g, float* d_dt2,
+                              float* d_dt1, float* d_dxid, float* d_dx, int N, int H, int W, int Ho, int Wo, int math, void* d_ws_main,
+                              size_t ws_main_bytes, void* d_ws_side, size_t ws_side_bytes, void* stream, void* side_stream);
 
 /* ABI 11: the same convolution (frcnn_conv_nhwc: the frozen-BN Bottleneck convolutions of models/resnet.py:38-46, BN folded) in the f32x3
  * arithmetic under ONE power-of-two scale per tensor: every activation and weight value as two fp16 terms hi = fp16(v 2^e),

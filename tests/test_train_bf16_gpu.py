@@ -403,6 +403,59 @@ def test_bf16_bottleneck_forward_and_backward_on_injected_activations(layer, ind
         assert l2(gw[k], o_gw[k]) * 5 <= l2(f_gw[k], o_gw[k]), k
 
 
+@pytest.mark.parametrize("layer,index,n,h,w,gm", [("layer2", 0, 1, 24, 36, "f32"), ("layer3", 1, 1, 13, 19, "bf16"), ("layer4", 0, 6, 7, 7, "bf16"),
+                                                   ("layer4", 2, 5, 4, 4, "f32")])
+def test_bottleneck_backward_one_call_is_the_separate_entry_points_bit_for_bit(layer, index, n, h, w, gm, monkeypatch):
+    """frcnn_bottleneck_backward (ABI 16: _TrainBlock.backward as ONE call, the weight gradients on a second stream behind one event;
+    the reference gets all of it from autograd, __main__.py:147-152) against the separate entry points it replaces -- frcnn_relu_backward,
+    frcnn_conv_wgrad_math + frcnn_scale_rows, frcnn_pack_conv_dgrad + frcnn_conv_dgrad_math in _TrainBlock.backward's order -- on one
+    stream and on two: every weight gradient and the input gradient bit for bit, with and without a downsample convolution."""
+    from fasterrcnn_amd.models import resnet
+    from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
+    model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet50))
+    model.load_state_dict(synthetic.resnet_state_dict(1234, "ResNet50"), strict=True)
+    model = model.cuda()
+    state = T.make_train_state(model)
+    blk = {b.name: b for b in state.blocks + state.head_blocks}["%s.%d" % (layer, index)]
+    g0 = torch.Generator().manual_seed(h * 100 + w + n)
+    x = gpu(torch.randn((n, h, w, blk.c1.cin), generator=g0).clamp(min=0))
+    T._GRAD_MATH = nv.GRAD_MATHS[gm]
+    try:
+        out, ho, wo, saved = blk.forward(x, n, h, w)
+        up = gpu(torch.randn(tuple(out.shape), generator=g0))
+
+        def separate():
+            xs, t1, t2, o, n_, h_, w_, ho_, wo_ = saved
+            g = up.clone()
+            gr = {}
+            T.relu_backward(g, o)
+            gr["conv3"] = blk.c3.wgrad(t2, g, n_, ho_, wo_)
+            d_t2 = blk.c3.dgrad(g, None, n_, ho_, wo_)
+            T.relu_backward(d_t2, t2)
+            gr["conv2"] = blk.c2.wgrad(t1, d_t2, n_, h_, w_)
+            d_t1 = blk.c2.dgrad(d_t2, None, n_, h_, w_)
+            T.relu_backward(d_t1, t1)
+            gr["conv1"] = blk.c1.wgrad(xs, d_t1, n_, h_, w_)
+            if blk.cd is not None:
+                gr["downsample"] = blk.cd.wgrad(xs, g, n_, h_, w_)
+            dx_id = blk.cd.dgrad(g, None, n_, h_, w_) if blk.cd is not None else g
+            return blk.c1.dgrad(d_t1, dx_id, n_, h_, w_), gr
+        ref_dx, ref_g = separate()
+        torch.cuda.synchronize()
+        for streams in ("0", "1"):
+            monkeypatch.setenv("FRCNN_TRAIN_WGRAD_STREAM", streams)
+            grads = {}
+            dx = blk.backward(up.clone(), saved, grads, need_dx=True)
+            torch.cuda.synchronize()
+            assert list(grads) == [blk.name + "." + c for c in ("conv3", "conv2", "conv1") + (("downsample",) if blk.cd is not None else ())]
+            assert torch.equal(dx, ref_dx), streams
+            for cname, gw in ref_g.items():
+                assert torch.equal(grads[blk.name + "." + cname], gw), (streams, cname)
+            assert blk.backward(up.clone(), saved, {}, need_dx=False) is None
+    finally:
+        T._GRAD_MATH = 0
+
+
 def test_bf16_resnet50_train_step_against_the_bf16_oracle():
     """ResNet-50 (frozen BatchNorm folded into each convolution: training.py _TrainConv), one whole step at 352x480 next to the oracle's bf16
     restatement on the same seeds.  Round 4: the FORWARD of the trainable bottlenecks rounds its operands to bfloat16 too, so kernel and
