@@ -728,28 +728,36 @@ def test_scale_rows_bn_affine_and_mean_backward():
     assert torch.equal(dx.permute(0, 3, 1, 2).cpu(), x.grad)
 
 
-def test_data_parallel_gradient_exchange_single_rank(sd_cpu):
+@pytest.mark.parametrize("arch", ["vgg16", "resnet50"])
+def test_data_parallel_gradient_exchange_single_rank(sd_cpu, arch):
     """The RCCL exchange of training.GradientAverager (asynchronous all-reduces started during the backward pass, completed before
     the SGD update) on a one-rank group must leave the step bit-identical (average of one); the world-2 arithmetic is covered on
-    CPU by tests/test_distributed_gloo.py."""
+    CPU by tests/test_distributed_gloo.py.  resnet50: the bottlenecks' weight gradients come off the SECOND stream (training._SideGrads,
+    frcnn_bottleneck_backward) and reach the exchange behind their events, in the one-stream order."""
     import socket
     import torch.distributed as dist
     from fasterrcnn_amd.models.faster_rcnn import FasterRCNNModel
     from fasterrcnn_amd.models.vgg16 import VGG16Backbone
     h, w, seed = 352, 480, 4
-    img = synthetic.image(seed, h, w).unsqueeze(0).cuda()
+    vgg = arch == "vgg16"
+    img = (synthetic.image if vgg else synthetic.image_rgb)(seed, h, w).unsqueeze(0).cuda()
     gts = synthetic.ground_truth(seed, h, w)
     boxes = [Box(class_index=c, class_name="x", corners=k) for c, k in gts]
-    am, vm = O.generate_anchor_maps((3, h, w), (512, h // 16, w // 16), 16)
+    am, vm = O.generate_anchor_maps((3, h, w), (512, h // 16, w // 16) if vgg else (1024, -(-h // 16), -(-w // 16)), 16)
     rmap, obj, bg = O.generate_rpn_map(am, vm, np.stack([k for _, k in gts]))
     rmap_t = torch.from_numpy(rmap).unsqueeze(0)
+    sd = sd_cpu if vgg else synthetic.resnet_state_dict(1234, "ResNet50")
 
     def run(parallel):
-        model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
-        model.load_state_dict(sd_cpu, strict=True)
+        if vgg:
+            model = FasterRCNNModel(num_classes=21, backbone=VGG16Backbone(dropout_probability=0.0))
+        else:
+            from fasterrcnn_amd.models import resnet
+            model = FasterRCNNModel(num_classes=21, backbone=resnet.ResNetBackbone(resnet.Architecture.ResNet50))
+        model.load_state_dict(sd, strict=True)
         model = model.cuda()
         if parallel:
-            T.enable_data_parallel(model, bucket_bytes=64 << 20)
+            T.enable_data_parallel(model, bucket_bytes=64 << 20 if vgg else 4 << 20)
         opt = T.create_optimizer(model, learning_rate=1e-6)
         random.seed(9); torch.manual_seed(9)
         loss = model.train_step(opt, img, am, vm, rmap_t, [obj], [bg], [boxes])
