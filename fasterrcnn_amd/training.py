@@ -354,13 +354,16 @@ class VGG16TrainState(TrainState):
     def features_backward(self, g, saved, grads):
         """autograd of vgg16.py:84-96; `g` = gradient with respect to the (post-ReLU) feature map."""
         x_in, y_out = saved
+        side = _SideGrads(grads, self.device)          # the weight gradients on the second stream, under the data-gradient chain
         for i in range(12, 3, -1):
             _, cin, cout, _ = vgg16._LAYERS[i]
+            side.flush(keep=1)
             relu_backward(g, y_out[i])
-            grads["conv%d" % i] = conv3x3_wgrad(x_in[i], g, cin, cout)
+            side.run("conv%d" % i, lambda x=x_in[i], dz=g, ci=cin, co=cout: conv3x3_wgrad(x, dz, ci, co), (x_in[i], g))
             if i > 4:
                 gx = conv3x3_dgrad(g, self.conv[i][0], cin, cout, self.zero_bias, self.winograd)
                 g = maxpool2x2_backward(y_out[i - 1], gx) if (i - 1) in _POOL_AFTER else gx
+        side.flush()
 
     # ---- RoI features -> feature vector (vgg16.py:129-133) ------------------------------------------------
     def head_forward(self, roi_out, inject=None):
@@ -378,17 +381,20 @@ class VGG16TrainState(TrainState):
         S = int(h2.shape[0])
         if detail is not None:
             detail["dh2"] = dh2.clone()
+        side = _SideGrads(grads, self.device)          # fc2's and fc1's weight gradients on the second stream, under the chain dh2 -> dh1 -> d roi
         relu_backward(dh2, h2)
-        grads["fc2"] = gemm_tn(dh2, 4096, h1, 4096, 4096, 4096, S)
+        side.run("fc2", lambda: gemm_tn(dh2, 4096, h1, 4096, 4096, 4096, S), (dh2, h1))
         dh2_t, sp = transpose(dh2, S, 4096, 4096)
         dh1 = gemm_tn(dh2_t, sp, self.fc2, 4096, S, 4096, 4096)
         if detail is not None:
             detail["dh1"] = dh1.clone()
             detail.update(h1=h1, h2=h2)
         relu_backward(dh1, h1)
-        grads["fc1"] = gemm_tn(dh1, 4096, roi_out, 49 * 512, 4096, 49 * 512, S)
+        side.run("fc1", lambda: gemm_tn(dh1, 4096, roi_out, 49 * 512, 4096, 49 * 512, S), (dh1, roi_out))
         dh1_t, sp = transpose(dh1, S, 4096, 4096)
-        return gemm_tn(dh1_t, sp, self.fc1, 49 * 512, S, 49 * 512, 4096)
+        droi = gemm_tn(dh1_t, sp, self.fc1, 49 * 512, S, 49 * 512, 4096)
+        side.flush()       # (before "rpn_head": `grads` fills in the one-stream order, also on a rank without a proposal batch)
+        return droi
 
     def zero_head_grads(self, grads):
         for name in ("fc2", "fc1"):
@@ -439,6 +445,21 @@ class _SideGrads:
             done = t.cuda.Event()
             done.record(_wgrad_stream(self.device))
         self.pending.append((named_grads, done, scratch if self.enabled else None))
+
+    def run(self, name, fn, reads):
+        """One gradient from Python: grads[name] = fn(), with fn's launches on the second stream behind an event of the main stream
+        (VGG-16's nine convolution and two fc weight gradients: a dozen per step, so the ~35 us of host time this form costs each do not
+        matter there).  `reads`: the main-stream tensors fn reads."""
+        if not self.enabled:
+            self.grads[name] = fn()
+            return
+        main, side = t.cuda.current_stream(self.device), _wgrad_stream(self.device)
+        ready = t.cuda.Event()
+        ready.record(main)
+        side.wait_event(ready)
+        with t.cuda.stream(side):
+            g = fn()
+        self.add([(name, g)], list(reads))
 
     def flush(self, keep=0):
         main = t.cuda.current_stream(self.device)
