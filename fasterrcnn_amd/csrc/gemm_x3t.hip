@@ -539,6 +539,11 @@ static HxPlan plan_gemm_x3t(int M, int N, int K, int batches, int tiles_mode = -
     while (u1 * splits1 * 2 <= 256 && chunks / (splits1 * 2) >= 8) splits1 *= 2;
     const double c1 = (double)((u1 * splits1 + 255) / 256) * 480.0 / 0.85 / splits1 + (splits1 > 1 ? 600.0 : 0.0);
     pl.cfg = (force == 0 || force == 1) ? force : (c1 < c0 ? 1 : 0);
+    // experiment (make KNOBS=1, FRCNN_HX_BIG_UNSPLIT): where the model picks the 160 x 128 tiles WITHOUT a split reduction, the 320 x 256 tiles without one
+    // -- fewer, longer blocks (less chip fill, which images in flight do not need) and the same bits (an output's chunks are summed in order either way).
+    // MEASURED, round 6 (tools/exp_r50_big_unsplit.sh, ResNet-50, 4 images in flight, same box): 678-680 -> 682-685 images/sec steady, bursts of 20 unchanged: not taken
+    static const bool big_unsplit = frcnn_knob("FRCNN_HX_BIG_UNSPLIT") != nullptr;
+    if (big_unsplit && force < 0 && pl.cfg == 1 && splits1 == 1) { pl.cfg = 0; splits0 = 1; }
     int splits = pl.cfg == 1 ? splits1 : splits0;
     if (splits > chunks) splits = chunks;
     pl.mtiles = pl.cfg == 1 ? cdiv(M, 160) : cdiv(M, 320);
