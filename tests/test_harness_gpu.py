@@ -133,6 +133,42 @@ def test_evaluate_stream_map_equals_sequential_reference_loop(gpu_model):
     assert got_limited == 100.0 * calc3.compute_mean_average_precision()
 
 
+def test_background_uploader_keeps_order_values_and_errors():
+    """evaluate()'s upload leg (E.BackgroundUploader: the reference's `t.from_numpy(image).unsqueeze(0).cuda()`, __main__.py:78-86, from a
+    worker thread a few images ahead): the images arrive in order, bit for bit, entries without an image pass through, an exception of
+    the sample iterator reaches the consumer, and a consumer that stops early leaves no blocked worker behind."""
+    import threading
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(3)
+    arrays = [rng.rand(3, 40 + i, 64).astype(np.float32) for i in range(9)]
+
+    def items(fail_at=None):
+        for i, a in enumerate(arrays):
+            if i == fail_at:
+                raise ValueError("sample %d" % i)
+            yield i, (None if i % 4 == 3 else (torch.from_numpy(a) if i % 2 else a)), ("gt", i)
+    got = list(E.BackgroundUploader(dev, depth=2).iterate(items()))
+    assert [g[0] for g in got] == list(range(9)) and [g[2] for g in got] == [("gt", i) for i in range(9)]
+    for i, image, _ in got:
+        if i % 4 == 3:
+            assert image is None
+        else:
+            assert image.is_cuda and tuple(image.shape) == (1,) + arrays[i].shape
+            torch.cuda.current_stream().synchronize()
+            assert np.array_equal(image[0].cpu().numpy(), arrays[i])
+    with pytest.raises(ValueError, match="sample 5"):
+        list(E.BackgroundUploader(dev, depth=2).iterate(items(fail_at=5)))
+    gen = E.BackgroundUploader(dev, depth=1).iterate(items())
+    next(gen)
+    gen.close()                                                    # the consumer walks away: the worker must not stay blocked on its queue
+    for _ in range(50):
+        if not any(th.name == "frcnn-upload" and th.is_alive() for th in threading.enumerate()):
+            break
+        import time
+        time.sleep(0.1)
+    assert not any(th.name == "frcnn-upload" and th.is_alive() for th in threading.enumerate())
+
+
 def test_map_gather_over_rccl_one_rank_group(gpu_model):
     """merged_calculator's exchange (sizes + padded payload all-gather per array) on backend "nccl" = RCCL, in a child process
     so that the process group does not outlive the test: merged == local, bit for bit."""
