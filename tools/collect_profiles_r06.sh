@@ -17,7 +17,7 @@ grep "^==" $OUT/stress_*.log | cut -c1-400
 timeout 300 python tools/x3f_bench.py > $OUT/x3f_bench.txt 2>&1
 FRCNN_LIB_PATH=build/libfrcnn_exp.so timeout 300 python tools/x3f_bench.py > $OUT/x3f_bench_exp.txt 2>&1
 FRCNN_LIB_PATH=build/libfrcnn_xdclk.so timeout 300 python tools/xd_clocks.py four > $OUT/xd_clocks.txt 2>&1
-FRCNN_LIB_PATH=build/libfrcnn_xpclk.so timeout 300 python tools/xd_clocks.py pair > $OUT/xp_clocks.txt 2>&1
+[ -f build/libfrcnn_xpclk.so ] && FRCNN_LIB_PATH=build/libfrcnn_xpclk.so timeout 300 python tools/xd_clocks.py pair > $OUT/xp_clocks.txt 2>&1   # (the two-pass form's clock build: tools/build_experiments.sh -DXD_CLOCKS, renamed)
 FRCNN_LIB_PATH=build/libfrcnn_chk.so timeout 300 python tools/xd_clocks.py four chunks > $OUT/xd_chunk_clocks.txt 2>&1
 # the CU-time budget of one image (tools/cu_time_model.py: single-stream kernel trace -> duration x chip fill per dispatch)
 for a in vgg16 resnet50; do rm -rf /tmp/tr_$a; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$a -o t -- python tools/cu_time_model.py run $a 40 > /dev/null 2>&1; python tools/cu_time_model.py report /tmp/tr_$a > $OUT/cu_time_$a.txt 2>&1; head -3 $OUT/cu_time_$a.txt | cut -c1-200; done
